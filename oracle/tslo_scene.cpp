@@ -1,0 +1,571 @@
+// ORACLE (test infrastructure only -- see oracle/README.md).
+// CPU restatement of the scene driver /root/reference/code/engine/BaseScene.py:
+//   init_property (:361-383), push/pull copies (:317-330, :852-862), compute_energy (:427-451),
+//   compute_residual_and_Hessian (:976-1040), compute_Hessian (:1042-1052), newton_step (:1159-1230),
+//   timestep_init/finish (:1291-1325), time_step (:1327-1370; Scene_folding.py:279-322 differs only
+//   in the iteration cap and the plastic update), update_vel (:868-872),
+// the grippers gripper_single.py:50-162 / gripper_tactile.py:103-249 and the adjoint
+// analytic_grad_single.py:27-257.
+// Linear solve: the reference calls cupyx.scipy.sparse.linalg.spsolve (sparse_solver.py:85-105), an
+// un-vendored dependency; H p = F has a unique solution, restated here as block-Jacobi PCG on the
+// symmetric part + iterative refinement against the assembled H (tests check it against
+// scipy.sparse.linalg.spsolve).
+#include <cstdio>
+
+#include "tslo_engine.h"
+
+namespace tslo {
+
+void Scene::finalize() {
+  // BaseScene.py:72-100
+  tot_NF = 0;
+  for (auto& c : cloths) { c.offset_faces = tot_NF; tot_NF += c.NF; }
+  for (auto& e : elastics) { e.offset_faces = tot_NF; tot_NF += e.n_surfaces; }
+  pos.assign(tot_NV, V3()); vel.assign(tot_NV, V3()); ext_force.assign(tot_NV, V3()); vn.assign(tot_NV, V3());
+  prev_pos.assign(tot_NV, V3()); x1.assign(tot_NV, V3()); x_hat.assign(tot_NV, V3()); F_b.assign(tot_NV, V3());
+  mass.assign(tot_NV, 0.0); F.assign((size_t)tot_NV * 3, 0.0);
+  frozen.assign((size_t)tot_NV * 3, 0); border_flag.assign(tot_NV, 0);
+  faces.assign(tot_NF, I3{{0, 0, 0}});
+  body_list.clear();
+  int bidx = 0;
+  for (auto& c : cloths) { body_list.push_back(Body{c.offset, c.offset + c.NV, c.offset_faces, c.offset_faces + c.NF}); c.body_idx = bidx++; }
+  for (auto& e : elastics) { body_list.push_back(Body{e.offset, e.offset + e.n_verts, e.offset_faces, e.offset_faces + e.n_surfaces}); e.body_idx = bidx++; }
+  size_t nb = body_list.size();
+  proj_flag.assign(nb * tot_NV, 0); proj_dir.assign(nb * tot_NV, 0);
+  proj_idx.assign(nb * tot_NV, I3{{0, 0, 0}}); proj_w.assign(nb * tot_NV, V3()); contact_force.assign(nb * tot_NV, 0.0);
+  size_t mc = max_n_constraints;
+  const_idx.assign(mc, I4{{0, 0, 0, 0}}); const_w.assign(mc, V3()); const_n.assign(mc, V3()); const_dx0.assign(mc, V3());
+  const_k.assign(mc, 0.0); const_mu.assign(mc, 0.0); const_T.assign(mc * 6, 0.0);
+  det_H.assign(mc * 81, 0.0); det_G.assign(mc * 9, 0.0); cross_H.assign(mc * 81, 0.0); cross_G.assign(mc * 9, 0.0);
+  d_H.assign(mc * 81, 0.0); d_G.assign(mc * 9, 0.0); projT.assign(mc * 81, 0.0); projQ.assign(mc * 81, 0.0);
+  force_T.assign(mc, V3()); force_f.assign(mc, V3());
+  tmp_z_not_frozen.assign((size_t)tot_NV * 3, 0.0); tmp_z_frozen.assign((size_t)tot_NV * 3, 0.0);
+  // geometry.py:8-10
+  grid_n = (int)std::floor(0.2 / grid_h) * 2;
+  grid_bound = grid_h * (grid_n - 1) / 2;
+  // static sparsity: every vertex set one element couples
+  static_cliques.clear();
+  for (auto& c : cloths) {
+    for (int i = 0; i < c.NF; i++) {
+      static_cliques.push_back({c.f2v[i][0] + c.offset, c.f2v[i][1] + c.offset, c.f2v[i][2] + c.offset});
+      for (int l = 0; l < 3; l++)
+        if (c.counter_face[i][l] > i)
+          static_cliques.push_back({c.f2v[i][0] + c.offset, c.f2v[i][1] + c.offset, c.f2v[i][2] + c.offset,
+                                    c.f2v[c.counter_face[i][l]][c.counter_point[i][l]] + c.offset});
+    }
+  }
+  for (auto& e : elastics)
+    for (int t = 0; t < e.n_cells; t++)
+      static_cliques.push_back({e.F_vertices[t][0] + e.offset, e.F_vertices[t][1] + e.offset, e.F_vertices[t][2] + e.offset, e.F_vertices[t][3] + e.offset});
+  nc = 0;
+  rebuild_pattern();
+}
+
+void Scene::rebuild_pattern() {
+  std::vector<std::vector<int>> cl = static_cliques;
+  for (int i = 0; i < nc; i++) cl.push_back({const_idx[i][0], const_idx[i][1], const_idx[i][2], const_idx[i][3]});
+  H.build(tot_NV, cl);
+}
+
+// BaseScene.py:361-383 (+ init_mass :332-346, init_faces :348-359)
+void Scene::init_property() {
+  for (auto& c : cloths) c.gravity = gravity;
+  for (size_t i = 0; i < elastics.size(); i++) {
+    if (i == 0) elastics[i].gravity = gravity;
+    else if ((int)i < effector_cnt) elastics[i].gravity = V3(0, 0, 0);
+    else elastics[i].gravity = gravity;
+  }
+  pushup_all();
+  for (auto& c : cloths) for (int i = 0; i < c.NV; i++) mass[c.offset + i] = c.mass;
+  for (auto& e : elastics) for (int i = 0; i < e.n_verts; i++) mass[e.offset + i] = e.F_m[i];
+  for (auto& c : cloths) for (int i = 0; i < c.NF; i++) for (int k = 0; k < 3; k++) faces[c.offset_faces + i][k] = c.f2v[i][k] + c.offset;
+  for (auto& e : elastics) for (int i = 0; i < e.n_surfaces; i++) for (int k = 0; k < 3; k++) faces[e.offset_faces + i][k] = e.f2v[i][k] + e.offset;
+}
+
+void Scene::pushup_all() {
+  for (auto& c : cloths) for (int i = 0; i < c.NV; i++) { pos[c.offset + i] = c.pos[i]; vel[c.offset + i] = c.vel[i]; }
+  for (auto& e : elastics) for (int i = 0; i < e.n_verts; i++) { pos[e.offset + i] = e.F_x[i]; vel[e.offset + i] = e.F_v[i]; }
+}
+void Scene::push_down_pos() {
+  for (auto& c : cloths) for (int i = 0; i < c.NV; i++) c.pos[i] = pos[c.offset + i];
+  for (auto& e : elastics) for (int i = 0; i < e.n_verts; i++) e.F_x[i] = pos[e.offset + i];
+}
+void Scene::push_down_vel() {
+  for (auto& c : cloths) for (int i = 0; i < c.NV; i++) c.vel[i] = vel[c.offset + i];
+  for (auto& e : elastics) for (int i = 0; i < e.n_verts; i++) e.F_v[i] = vel[e.offset + i];
+}
+void Scene::push_down_prev() {
+  for (auto& c : cloths) for (int i = 0; i < c.NV; i++) c.prev_pos[i] = prev_pos[c.offset + i];
+  for (auto& e : elastics) for (int i = 0; i < e.n_verts; i++) e.F_x_prev[i] = prev_pos[e.offset + i];
+}
+
+// BaseScene.py:427-451
+void Scene::compute_energy() {
+  E = 0.0;
+  contact_energy(0, 0);
+  for (auto& c : cloths) { c.compute_normal_dir(); c.compute_energy(); E += c.U; }
+  for (auto& e : elastics) { e.compute_energy(); E += e.U; }
+}
+
+// BaseScene.py:976-1040 (check_PD=False path)
+void Scene::compute_residual_and_Hessian(int spd) {
+  for (auto& c : cloths) {
+    c.compute_normal_dir();
+    c.prepare_bending();
+    c.compute_residual();
+    for (int i = 0; i < c.NV; i++) F_b[c.offset + i] += c.F_b[i];
+  }
+  for (auto& e : elastics) {
+    e.get_force();
+    e.compute_residual();
+    for (int i = 0; i < e.n_verts; i++) F_b[e.offset + i] += e.F_b[i];
+  }
+  for (int i = 0; i < tot_NV; i++) for (int j = 0; j < 3; j++) F[3 * i + j] = F_b[i][j];
+  for (size_t i = 0; i < F.size(); i++) if (frozen[i]) F[i] = 0;
+  contact_energy(1, spd);
+  for (auto& e : elastics) e.compute_Hessian(*this, spd);
+  for (auto& c : cloths) c.compute_Hessian_me(*this, spd);
+  for (auto& c : cloths) c.compute_Hessian_ma(*this);
+  for (auto& c : cloths) c.compute_Hessian_bending(*this);
+}
+
+// BaseScene.py:1042-1052
+void Scene::compute_Hessian(int spd) {
+  for (auto& e : elastics) e.compute_Hessian(*this, spd);
+  for (auto& c : cloths) {
+    c.compute_normal_dir();
+    c.prepare_bending();
+    c.compute_Hessian_me(*this, spd);
+    c.compute_Hessian_ma(*this);
+    c.compute_Hessian_bending(*this);
+  }
+  contact_energy(1, spd);
+}
+
+// BaseScene.py:1077-1082
+void Scene::newton_step_init() {
+  H.clear_all();
+  E = 0;
+  std::fill(F.begin(), F.end(), 0.0);
+  for (auto& v : F_b) v = V3();
+}
+
+// Solve H x = b.  Returns 0 ok, 1 fell back to BiCGStab, 2 fell back to dense LU, 3 not converged.
+// Stage 1: block-Jacobi PCG run directly on the assembled H (its non-symmetric part -- the area
+// block's factor-2 quirk -- is O(strain) small), restarted from the true residual until
+// |b - Hx| <= cg_tol |b|.  Stage 2 (CG breakdown p^T H p <= 0 or stagnation: the un-projected
+// adjoint Hessian may be indefinite): block-Jacobi BiCGStab.  Stage 3 (n <= 3000): dense LU.
+int Scene::solve(const double* b, double* x) {
+  int n = tot_NV * 3;
+  stat_solves++;
+  std::vector<double> Dinv((size_t)tot_NV * 9);
+  for (int bi = 0; bi < tot_NV; bi++) {
+    int k = H.find_block(bi, bi);
+    M3 D;
+    for (int a = 0; a < 3; a++) for (int c = 0; c < 3; c++) D[a][c] = H.vals[(size_t)k * 9 + a * 3 + c];
+    M3 Di = inverse(D);
+    for (int a = 0; a < 3; a++) for (int c = 0; c < 3; c++) Dinv[(size_t)bi * 9 + a * 3 + c] = Di[a][c];
+  }
+  auto precond = [&](const double* r, double* z) {
+#pragma omp parallel for schedule(static)
+    for (int bi = 0; bi < tot_NV; bi++) {
+      const double* d = &Dinv[(size_t)bi * 9];
+      const double* rr = &r[bi * 3];
+      z[bi * 3 + 0] = d[0] * rr[0] + d[1] * rr[1] + d[2] * rr[2];
+      z[bi * 3 + 1] = d[3] * rr[0] + d[4] * rr[1] + d[5] * rr[2];
+      z[bi * 3 + 2] = d[6] * rr[0] + d[7] * rr[1] + d[8] * rr[2];
+    }
+  };
+  auto ddot = [&](const double* a, const double* c) {
+    double s = 0;
+#pragma omp parallel for reduction(+ : s) schedule(static)
+    for (int i = 0; i < n; i++) s += a[i] * c[i];
+    return s;
+  };
+  std::vector<double> r(n), z(n), p(n), Ap(n);
+  for (int i = 0; i < n; i++) x[i] = 0;
+  double bnorm = std::sqrt(ddot(b, b));
+  last_solve_flag = 0;
+  if (bnorm == 0) return 0;
+  bool need_fallback = false;
+  int total_it = 0;
+  for (int outer = 0; outer < 20; outer++) {
+    H.matvec(x, Ap.data());
+    for (int i = 0; i < n; i++) r[i] = b[i] - Ap[i];
+    double rn = std::sqrt(ddot(r.data(), r.data()));
+    if (rn <= cg_tol * bnorm) { need_fallback = false; break; }
+    if (outer > 0) stat_refine++;
+    need_fallback = true;  // cleared when the true residual passes the test above
+    precond(r.data(), z.data());
+    p = z;
+    double rz = ddot(r.data(), z.data());
+    bool broke = false;
+    for (; total_it < cg_maxit; total_it++) {
+      H.matvec(p.data(), Ap.data());
+      double pAp = ddot(p.data(), Ap.data());
+      if (!(pAp > 0) || !(rz > 0)) { broke = true; break; }
+      double alpha = rz / pAp;
+#pragma omp parallel for schedule(static)
+      for (int i = 0; i < n; i++) { x[i] += alpha * p[i]; r[i] -= alpha * Ap[i]; }
+      stat_cg++;
+      double rnorm = std::sqrt(ddot(r.data(), r.data()));
+      if (rnorm <= 0.5 * cg_tol * bnorm) { total_it++; break; }
+      precond(r.data(), z.data());
+      double rz_new = ddot(r.data(), z.data());
+      double beta = rz_new / rz;
+      rz = rz_new;
+#pragma omp parallel for schedule(static)
+      for (int i = 0; i < n; i++) p[i] = z[i] + beta * p[i];
+    }
+    if (broke || total_it >= cg_maxit) break;
+  }
+  if (!need_fallback) return 0;
+  // ---- stage 2: preconditioned BiCGStab on H, restarted from x = 0
+  {
+    std::vector<double> r0(n), v(n), s(n), t(n), ph(n), sh(n);
+    for (int i = 0; i < n; i++) { x[i] = 0; r[i] = b[i]; r0[i] = b[i]; p[i] = 0; v[i] = 0; }
+    double rho = 1, alpha = 1, omega = 1;
+    bool ok = false;
+    for (int it = 0; it < cg_maxit; it++) {
+      double rho_new = ddot(r0.data(), r.data());
+      if (rho_new == 0 || omega == 0) break;
+      double beta = (rho_new / rho) * (alpha / omega);
+      rho = rho_new;
+      for (int i = 0; i < n; i++) p[i] = r[i] + beta * (p[i] - omega * v[i]);
+      precond(p.data(), ph.data());
+      H.matvec(ph.data(), v.data());
+      double r0v = ddot(r0.data(), v.data());
+      if (r0v == 0) break;
+      alpha = rho / r0v;
+      for (int i = 0; i < n; i++) s[i] = r[i] - alpha * v[i];
+      precond(s.data(), sh.data());
+      H.matvec(sh.data(), t.data());
+      double tt = ddot(t.data(), t.data());
+      omega = tt > 0 ? ddot(t.data(), s.data()) / tt : 0;
+      for (int i = 0; i < n; i++) { x[i] += alpha * ph[i] + omega * sh[i]; r[i] = s[i] - omega * t[i]; }
+      stat_cg += 2;
+      if (std::sqrt(ddot(r.data(), r.data())) <= 0.5 * cg_tol * bnorm) {
+        H.matvec(x, Ap.data());
+        double tr = 0;
+        for (int i = 0; i < n; i++) tr += (b[i] - Ap[i]) * (b[i] - Ap[i]);
+        if (std::sqrt(tr) <= 10 * cg_tol * bnorm) { ok = true; break; }
+        for (int i = 0; i < n; i++) r[i] = b[i] - Ap[i];
+      }
+    }
+    if (ok) { last_solve_flag = 1; return 1; }
+  }
+  // ---- stage 3: dense LU with partial pivoting (small systems only)
+  if (n <= 3000) {
+    std::vector<double> A((size_t)n * n, 0.0), y(b, b + n);
+    for (int bi = 0; bi < tot_NV; bi++)
+      for (int k = H.row_ptr[bi]; k < H.row_ptr[bi + 1]; k++)
+        for (int a = 0; a < 3; a++) for (int c = 0; c < 3; c++) A[(size_t)(bi * 3 + a) * n + H.col[k] * 3 + c] = H.vals[(size_t)k * 9 + a * 3 + c];
+    for (int c = 0; c < n; c++) {
+      int piv = c; double best = std::fabs(A[(size_t)c * n + c]);
+      for (int rr = c + 1; rr < n; rr++) if (std::fabs(A[(size_t)rr * n + c]) > best) { best = std::fabs(A[(size_t)rr * n + c]); piv = rr; }
+      if (piv != c) { for (int k = 0; k < n; k++) std::swap(A[(size_t)piv * n + k], A[(size_t)c * n + k]); std::swap(y[piv], y[c]); }
+      double d = A[(size_t)c * n + c];
+#pragma omp parallel for schedule(static)
+      for (int rr = c + 1; rr < n; rr++) {
+        double f = A[(size_t)rr * n + c] / d;
+        if (f == 0) continue;
+        for (int k = c; k < n; k++) A[(size_t)rr * n + k] -= f * A[(size_t)c * n + k];
+        y[rr] -= f * y[c];
+      }
+    }
+    for (int c = n - 1; c >= 0; c--) {
+      double sacc = y[c];
+      for (int k = c + 1; k < n; k++) sacc -= A[(size_t)c * n + k] * x[k];
+      x[c] = sacc / A[(size_t)c * n + c];
+    }
+    last_solve_flag = 2;
+    return 2;
+  }
+  last_solve_flag = 3;
+  return 3;
+}
+
+// BaseScene.py:1159-1230
+double Scene::newton_step(double* alpha_out) {
+  int n = tot_NV * 3;
+  std::vector<double> p(n);
+  solve(F.data(), p.data());
+  double p_norm = 0.0;
+  for (int i = 0; i < n; i++) p_norm = std::max(p_norm, std::fabs(p[i]));
+  x1 = pos;
+  double E0 = E;
+  double alpha = 1.0;
+  while (alpha > 1e-8) {
+    for (int i = 0; i < tot_NV; i++)
+      for (int j = 0; j < 3; j++) pos[i][j] = x1[i][j] - p[i * 3 + j] * alpha;
+    push_down_pos();
+    compute_energy();
+    stat_ls++;
+    if (E < E0) break;
+    alpha /= 2;
+  }
+  if (alpha_out) *alpha_out = alpha;
+  return p_norm / h;
+}
+
+// BaseScene.py:1291-1314 (x_hat is computed but never consumed; omitted)
+void Scene::timestep_init() {
+  prev_pos = pos;
+  push_down_prev();
+}
+
+// BaseScene.py:868-872
+void Scene::update_vel() {
+  for (int i = 0; i < tot_NV; i++)
+    for (int j = 0; j < 3; j++) vel[i][j] = (pos[i][j] - prev_pos[i][j]) * damping / dt;
+}
+
+// BaseScene.py:1321-1325 ; Scene_folding.py:227-231
+void Scene::timestep_finish() {
+  update_vel();
+  push_down_vel();
+  if (plastic) for (auto& c : cloths) c.update_ref_angle();
+}
+
+// BaseScene.py:1327-1370
+void Scene::time_step() {
+  timestep_init();
+  calc_vn();
+  projection_query();
+  contact_analysis();
+  int iter = 0;
+  double delta = 1e5;
+  while (iter < newton_cap) {
+    iter++;
+    newton_step_init();
+    compute_energy();
+    compute_residual_and_Hessian(1);
+    double alpha;
+    delta = newton_step(&alpha);
+    stat_newton++;
+    if (delta < 1e-7) break;
+  }
+  timestep_finish();
+}
+
+// Scene_folding.py:215-225 / Scene_balancing action: gripper.step_simple -> update_bound -> pushup pads
+void Scene::action(const double* delta_pos, const double* delta_rot) {
+  gripper.step_simple(delta_pos, delta_rot);
+  gripper.update_bound(*this);
+  for (size_t j = 1; j < elastics.size(); j++) {
+    auto& e = elastics[j];
+    if (e.kind != 0) continue;
+    for (int i = 0; i < e.n_verts; i++) pos[e.offset + i] = e.F_x[i];
+  }
+}
+
+// ---------------------------------------------------------------- grippers
+void Gripper::construct(int paired_, int n_verts_, int n_bound_, int n_surf_, int cnt) {
+  paired = paired_; n_verts = n_verts_; n_bound = n_bound_; n_surf = n_surf_; n_part = cnt;
+  F_x.assign((size_t)cnt * n_verts, V3()); F_x_world.assign((size_t)cnt * n_verts, V3());
+  if (paired) { F_x_lower.assign((size_t)cnt * n_verts, V3()); F_x_lower_world.assign((size_t)cnt * n_verts, V3()); }
+  bound_idx.assign(n_bound, 0); surface_idx.assign(n_surf, 0);
+  pos.assign(cnt, V3()); d_pos.assign(cnt, V3()); d_angle.assign(cnt, V3());
+  rot.assign((size_t)cnt * 4, 0.0); rotmat.assign((size_t)cnt * 9, 0.f);
+}
+
+// gripper_single.py:50-74 / gripper_tactile.py:103-133
+void Gripper::init(Scene& sys, const double* pos_array) {
+  for (int j = 0; j < n_part; j++) {
+    pos[j] = V3(pos_array[j * 3], pos_array[j * 3 + 1], pos_array[j * 3 + 2]);
+    rot[j * 4] = 1.0; rot[j * 4 + 1] = rot[j * 4 + 2] = rot[j * 4 + 3] = 0.0;
+  }
+  for (int i = 0; i < n_verts; i++)
+    for (int j = 0; j < n_part; j++) {
+      if (!paired) F_x[(size_t)j * n_verts + i] = sys.elastics[j + 1].F_x[i] - pos[j];
+      else {
+        F_x[(size_t)j * n_verts + i] = sys.elastics[j * 2 + 1].F_x[i] - pos[j];
+        F_x_lower[(size_t)j * n_verts + i] = sys.elastics[j * 2 + 2].F_x[i] - pos[j];
+      }
+    }
+  int cnt0 = 0, cnt1 = 0;
+  const Elastic& e1 = sys.elastics[1];
+  for (int i = 0; i < e1.n_verts; i++) {
+    if (e1.is_bottom(i) || e1.is_inner_circle(i)) { if (cnt0 < n_bound) bound_idx[cnt0] = i; cnt0++; }
+    else if (e1.is_surf(i)) { if (cnt1 < n_surf) surface_idx[cnt1] = i; cnt1++; }
+  }
+  get_rotmat();
+}
+
+// gripper_single.py:87-95 (rotmat field is f32)
+void Gripper::get_rotmat() {
+  for (int j = 0; j < n_part; j++) {
+    double s = rot[j * 4], x = rot[j * 4 + 1], y = rot[j * 4 + 2], z = rot[j * 4 + 3];
+    double R[9] = {s * s + x * x - y * y - z * z, 2 * (x * y - s * z), 2 * (x * z + s * y),
+                   2 * (x * y + s * z), s * s - x * x + y * y - z * z, 2 * (y * z - s * x),
+                   2 * (x * z - s * y), 2 * (y * z + s * x), s * s - x * x - y * y + z * z};
+    for (int k = 0; k < 9; k++) rotmat[j * 9 + k] = (float)R[k];
+  }
+}
+
+static inline V3 rot_apply(const float* R, const V3& v) {
+  return V3((double)R[0] * v[0] + (double)R[1] * v[1] + (double)R[2] * v[2], (double)R[3] * v[0] + (double)R[4] * v[1] + (double)R[5] * v[2],
+            (double)R[6] * v[0] + (double)R[7] * v[1] + (double)R[8] * v[2]);
+}
+
+// gripper_single.py:81-85 / gripper_tactile.py:141-148
+void Gripper::get_vert_pos() {
+  for (int i = 0; i < n_verts; i++)
+    for (int j = 0; j < n_part; j++) {
+      F_x_world[(size_t)j * n_verts + i] = pos[j] + rot_apply(&rotmat[j * 9], F_x[(size_t)j * n_verts + i]);
+      if (paired) F_x_lower_world[(size_t)j * n_verts + i] = pos[j] + rot_apply(&rotmat[j * 9], F_x_lower[(size_t)j * n_verts + i]);
+    }
+}
+
+// gripper_single.py:115-131 / gripper_tactile.py:178-194
+void Gripper::step_simple(const double* delta_pos, const double* delta_rot) {
+  for (int j = 0; j < n_part; j++) {
+    V3 dp(delta_pos[j * 3], delta_pos[j * 3 + 1], delta_pos[j * 3 + 2]);
+    V3 dr(delta_rot[j * 3], delta_rot[j * 3 + 1], delta_rot[j * 3 + 2]);
+    pos[j] += dp;
+    V3 v2(rot[j * 4 + 1], rot[j * 4 + 2], rot[j * 4 + 3]);
+    double real = -dot(dr, v2);
+    V3 res = rot[j * 4] * dr + cross(dr, v2);
+    rot[j * 4] += real; rot[j * 4 + 1] += res[0]; rot[j * 4 + 2] += res[1]; rot[j * 4 + 3] += res[2];
+    double nn = std::sqrt(rot[j * 4] * rot[j * 4] + rot[j * 4 + 1] * rot[j * 4 + 1] + rot[j * 4 + 2] * rot[j * 4 + 2] + rot[j * 4 + 3] * rot[j * 4 + 3]);
+    for (int k = 0; k < 4; k++) rot[j * 4 + k] /= nn;
+  }
+  get_rotmat();
+  get_vert_pos();
+}
+
+// gripper_single.py:152-156 / gripper_tactile.py:244-249
+void Gripper::update_bound(Scene& sys) {
+  for (int i = 0; i < n_bound; i++)
+    for (int j = 0; j < n_part; j++) {
+      if (!paired) sys.elastics[j + 1].F_x[bound_idx[i]] = F_x_world[(size_t)j * n_verts + bound_idx[i]];
+      else {
+        sys.elastics[j * 2 + 1].F_x[bound_idx[i]] = F_x_world[(size_t)j * n_verts + bound_idx[i]];
+        sys.elastics[j * 2 + 2].F_x[bound_idx[i]] = F_x_lower_world[(size_t)j * n_verts + bound_idx[i]];
+      }
+    }
+}
+
+// gripper_single.py:133-150 / gripper_tactile.py:220-242
+void Gripper::gather_grad(const double* grad, Scene& sys) {
+  for (int j = 0; j < n_part; j++) { d_pos[j] = V3(); d_angle[j] = V3(); }
+  for (int i = 0; i < n_bound; i++)
+    for (int j = 0; j < n_part; j++) {
+      if (!paired) {
+        int xx = sys.elastics[j + 1].offset + bound_idx[i];
+        V3 g(grad[xx * 3], grad[xx * 3 + 1], grad[xx * 3 + 2]);
+        d_pos[j] += g;
+        d_angle[j] += cross(rot_apply(&rotmat[j * 9], F_x[(size_t)j * n_verts + bound_idx[i]]), g);
+      } else {
+        int xx = sys.elastics[j * 2 + 1].offset + bound_idx[i];
+        V3 g(grad[xx * 3], grad[xx * 3 + 1], grad[xx * 3 + 2]);
+        d_pos[j] += g;
+        d_angle[j] += cross(rot_apply(&rotmat[j * 9], F_x[(size_t)j * n_verts + bound_idx[i]]), g);
+        xx = sys.elastics[j * 2 + 2].offset + bound_idx[i];
+        g = V3(grad[xx * 3], grad[xx * 3 + 1], grad[xx * 3 + 2]);
+        d_pos[j] += g;
+        d_angle[j] += cross(rot_apply(&rotmat[j * 9], F_x_lower[(size_t)j * n_verts + bound_idx[i]]), g);
+      }
+    }
+  for (int j = 0; j < n_part; j++) {
+    double div = (paired ? 2.0 : 1.0) * n_bound;
+    d_pos[j] = d_pos[j] / div;
+    d_angle[j] = d_angle[j] / div;
+    double amax = paired ? 10.0 : 100.0;
+    for (int k = 0; k < 3; k++) {
+      d_pos[j][k] = std::min(std::max(d_pos[j][k], -10.0), 10.0);
+      d_angle[j][k] = std::min(std::max(d_angle[j][k], -amax), amax);
+    }
+  }
+}
+
+// ---------------------------------------------------------------- adjoint
+void Grad::construct(Scene& sys, int T, int n_parts) {
+  n_part = n_parts; tot_NV = sys.tot_NV; tot_timestep = T; cloth_cnt = (int)sys.cloths.size();
+  NF = sys.cloths.empty() ? 0 : sys.cloths[0].NF;
+  dt = sys.dt;
+  pos_buffer.assign((size_t)T * tot_NV * 3, 0.0); pos_grad.assign((size_t)T * tot_NV * 3, 0.0);
+  gripper_pos_buffer.assign((size_t)T * n_part * 3, 0.0); gripper_rot_buffer.assign((size_t)T * n_part * 4, 0.0);
+  ref_angle_buffer.assign((size_t)T * cloth_cnt * NF * 3, 0.0); angleref_grad.assign((size_t)T * cloth_cnt * NF * 3, 0.0);
+  x_hat_grad.assign((size_t)tot_NV * 3, 0.0); gripper_grad.assign((size_t)T * n_part * 6, 0.0);
+  mass = sys.mass; F.assign((size_t)tot_NV * 3, 0.0);
+}
+
+// analytic_grad_single.py:27-30
+void Grad::reset() {
+  std::fill(pos_buffer.begin(), pos_buffer.end(), 0.0);
+  std::fill(pos_grad.begin(), pos_grad.end(), 0.0);
+  std::fill(angleref_grad.begin(), angleref_grad.end(), 0.0);
+}
+
+// analytic_grad_single.py:37-51
+void Grad::copy_pos(Scene& sys, int step) {
+  for (int i = 0; i < tot_NV; i++) for (int j = 0; j < 3; j++) PB(step, i, j) = sys.pos[i][j];
+  for (int c = 0; c < cloth_cnt; c++)
+    for (int i = 0; i < NF; i++) for (int l = 0; l < 3; l++) RB(step, c, i, l) = sys.cloths[c].ref_angle[i][l];
+  if (sys.has_gripper)
+    for (int j = 0; j < n_part; j++) {
+      for (int k = 0; k < 3; k++) gripper_pos_buffer[((size_t)step * n_part + j) * 3 + k] = sys.gripper.pos[j][k];
+      for (int k = 0; k < 4; k++) gripper_rot_buffer[((size_t)step * n_part + j) * 4 + k] = sys.gripper.rot[j * 4 + k];
+    }
+}
+
+// analytic_grad_single.py:217-257
+void Grad::transfer_grad(int step, Scene& sys) {
+  // clamp_grad :176-185
+  for (int i = 0; i < tot_NV; i++) for (int j = 0; j < 3; j++) PG(step, i, j) = std::min(std::max(PG(step, i, j), -1000.0), 1000.0);
+  for (int i = 0; i < NF; i++) for (int c = 0; c < cloth_cnt; c++) for (int l = 0; l < 3; l++) AG(step, c, i, l) = std::min(std::max(AG(step, c, i, l), -1000.0), 1000.0);
+  // sys.copy_pos_only(pos_buffer, step-1)  BaseScene.py:308-315 : pos = prev_pos = x_{s-1}
+  for (int i = 0; i < tot_NV; i++) for (int j = 0; j < 3; j++) { sys.pos[i][j] = PB(step - 1, i, j); sys.prev_pos[i][j] = PB(step - 1, i, j); }
+  sys.push_down_pos();
+  sys.push_down_prev();
+  sys.calc_vn();
+  sys.projection_query();
+  sys.contact_analysis();
+  // sys.copy_pos_and_refangle(self, step)  BaseScene.py:284-292
+  for (int i = 0; i < tot_NV; i++) for (int j = 0; j < 3; j++) { sys.pos[i][j] = PB(step, i, j); sys.prev_pos[i][j] = PB(step - 1, i, j); }
+  sys.push_down_pos();
+  sys.push_down_prev();
+  for (int c = 0; c < cloth_cnt; c++)
+    for (int i = 0; i < NF; i++) for (int l = 0; l < 3; l++) sys.cloths[c].ref_angle[i][l] = RB(step - 1, c, i, l);
+  // sys.gripper.set(...)  gripper_single.py:76-79
+  if (sys.has_gripper)
+    for (int j = 0; j < n_part; j++) {
+      for (int k = 0; k < 3; k++) sys.gripper.pos[j][k] = gripper_pos_buffer[((size_t)step * n_part + j) * 3 + k];
+      for (int k = 0; k < 4; k++) sys.gripper.rot[j * 4 + k] = gripper_rot_buffer[((size_t)step * n_part + j) * 4 + k];
+    }
+  // sys.init_folding()  BaseScene.py:1527-1530
+  for (auto& c : sys.cloths) { c.compute_normal_dir(); c.prepare_bending(); }
+  for (int c = 0; c < cloth_cnt; c++) sys.cloths[c].ref_angle_backprop_a2ax(*this, step, c);
+  sys.H.clear_all();
+  sys.compute_Hessian(0);
+  for (int i = 0; i < tot_NV * 3; i++) F[i] = pos_grad[(size_t)step * tot_NV * 3 + i];  // get_F :55-60
+  std::vector<double> p((size_t)tot_NV * 3);
+  sys.solve(F.data(), p.data());
+  sys.tmp_z_not_frozen = p;  // copy_z :211-214
+  std::fill(sys.tmp_z_frozen.begin(), sys.tmp_z_frozen.end(), 0.0);
+  sys.counting_z_frozen = 1;
+  sys.compute_Hessian(0);
+  sys.counting_z_frozen = 0;
+  for (int i = 0; i < tot_NV; i++) for (int j = 0; j < 3; j++) x_hat_grad[i * 3 + j] = p[i * 3 + j] * mass[i] / (dt * dt);  // get_grad :81-92
+  sys.contact_energy_backprop(*this, step - 1, p.data());
+  for (int c = 0; c < cloth_cnt; c++) sys.cloths[c].ref_angle_backprop_x2a(*this, step, p.data(), c);
+  if (step > 0) {
+    for (int i = 0; i < tot_NV; i++) for (int j = 0; j < 3; j++)
+      if (!sys.frozen[i * 3 + j]) PG(step - 1, i, j) += x_hat_grad[i * 3 + j] * (1 + damping);  // get_prev_grad :94-99
+    if (sys.has_gripper) {
+      // get_gripper_grad :118-139
+      sys.gripper.get_rotmat();
+      sys.gripper.gather_grad(sys.tmp_z_frozen.data(), sys);
+      for (int j = 0; j < n_part; j++) {
+        double* gg = &gripper_grad[((size_t)step * n_part + j) * 6];
+        for (int k = 0; k < 3; k++) { gg[k] = sys.gripper.d_pos[j][k]; gg[3 + k] = sys.gripper.d_angle[j][k]; }
+      }
+    }
+  }
+  if (step > 1)
+    for (int i = 0; i < tot_NV; i++) for (int j = 0; j < 3; j++)
+      if (!sys.frozen[i * 3 + j]) PG(step - 2, i, j) -= x_hat_grad[i * 3 + j] * damping;  // get_prev_prev_grad :101-106
+}
+
+}  // namespace tslo
