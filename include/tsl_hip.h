@@ -1,0 +1,153 @@
+/*
+ * tsl_hip.h -- C ABI of libtsl_hip.so, the MI355X (gfx950) thin-shell engine.
+ *
+ * Drop-in boundary.  The reference (Genesis-Embodied-AI/ThinShellLab) has no FFI layer: its engine
+ * is a set of Python objects (code/engine/BaseScene.py, model_fold_offset.py, ...) whose methods the
+ * task scenes / Grad / trajopt scripts call.  This header declares what a Python `engine` package binds
+ * with ctypes so that those callers keep working; every entry point names the reference method it
+ * replaces (file:line under /root/reference/code).  See INTEGRATION.md for the binding stub.
+ *
+ * Conventions: extern "C"; plain pointers and sizes; all reals fp64 and all indices int32 like the
+ * reference (ti.init(default_fp=ti.f64, default_ip=ti.i32)); return 0 on success, <0 on error
+ * (message via tsl_last_error()).  Pointers named *_dev are device (HBM) pointers owned by the caller
+ * (torch tensors); pointers named *_host are host memory.  No ownership is transferred.  The library
+ * owns only the opaque tsl_ctx (topology, system matrix, scratch).  Work is enqueued on the stream set
+ * with tsl_set_stream(); calls that return a host scalar synchronise that stream.
+ * One context per GPU / per scene; contexts are independent (one process per GPU, no collectives).
+ */
+#ifndef TSL_HIP_H
+#define TSL_HIP_H
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef struct tsl_ctx tsl_ctx;
+
+/* One cloth (engine/model_fold_offset.py:10-107).  Index tables are the ones Cloth.init_mesh builds
+ * (model_fold_offset.py:928-1018), LOCAL vertex / face numbering; v_offset = Cloth.offset. */
+typedef struct {
+  int32_t N, M, NV, NF, v_offset;
+  double dx, mass, Kl, Ka, Kb, k_angle;
+  const int32_t* f2v_host;           /* NF x 3 */
+  const int32_t* counter_face_host;  /* NF x 3 */
+  const int32_t* counter_point_host; /* NF x 3 */
+  const double* rest_area_host;      /* NF      Cloth.V   (model_fold_offset.py:835) */
+  const double* rest_len_host;       /* NF x 3  Cloth.l_i (model_fold_offset.py:836-838) */
+} tsl_cloth_desc;
+
+/* One tetrahedral body.  kind 0: engine/model_elastic_tactile.py (stable Neo-Hookean, alpha);
+ * kind 1: engine/model_elastic_offset.py (Neo-Hookean with log J).  B = F_B (Ds^-1), W = F_W. */
+typedef struct {
+  int32_t kind, n_verts, n_cells, v_offset;
+  double mu, lam, alpha;
+  const int32_t* tets_host; /* n_cells x 4, LOCAL vertex ids */
+  const double* B_host;     /* n_cells x 9 row-major */
+  const double* W_host;     /* n_cells */
+} tsl_elastic_desc;
+
+/* One BaseScene.contact_pair_analysis call of the scene's contact_analysis()
+ * (BaseScene.py:818-835, Scene_folding.py:99-108): query vertices [v_start, v_end) against body b_idx. */
+typedef struct {
+  int32_t b_idx, v_start, v_end;
+  int32_t mu_is_param; /* 1: use the live mu_cloth_elastic parameter, 0: use mu */
+  double mu;
+} tsl_contact_pair;
+
+/* Body ranges of BaseScene.body_list (BaseScene.py:91-99). */
+typedef struct { int32_t v_start, v_end, f_start, f_end; } tsl_body;
+
+typedef struct {
+  int32_t tot_NV, tot_NF;
+  double dt, k_contact, eps_contact, eps_v, damping; /* BaseScene.py:44-48, scene init_scene_parameters */
+  int32_t max_n_constraints;
+  int32_t n_cloth;   const tsl_cloth_desc* cloths;
+  int32_t n_elastic; const tsl_elastic_desc* elastics;
+  int32_t n_body;    const tsl_body* bodies;
+  int32_t n_pair;    const tsl_contact_pair* pairs;
+  const double* mass_host;      /* tot_NV      BaseScene.mass (BaseScene.py:332-346) */
+  const double* gravity_host;   /* tot_NV x 3  per-vertex gravity acceleration of its body (BaseScene.py:361-379) */
+  const int32_t* faces_host;    /* tot_NF x 3  BaseScene.faces, GLOBAL vertex ids (BaseScene.py:348-359) */
+  const int32_t* frozen_host;   /* 3*tot_NV    BaseScene.frozen (BaseScene.py:80, set_frozen) */
+  double grid_h;                /* geometry.py:8 (0.003) */
+} tsl_scene_desc;
+
+typedef struct {
+  int32_t newton_iters, ls_evals, cg_iters, solves, restarts, fallback, nc;
+  double last_delta, last_alpha, energy;
+} tsl_step_stats;
+
+typedef struct {
+  int32_t iters, restarts, flag; /* flag 0 converged PCG, 1 BiCGStab fallback, 3 not converged */
+  double rel_residual;
+} tsl_solve_stats;
+
+const char* tsl_version(void);
+const char* tsl_last_error(void);
+
+/* BaseScene.__init__ + init_objects + init_property + set_frozen: upload topology, build the BSR(3x3)
+ * pattern (replaces SparseMatrix's dense n x n storage, sparse_solver.py:13-17). */
+int tsl_ctx_create(const tsl_scene_desc* desc, tsl_ctx** out);
+void tsl_ctx_destroy(tsl_ctx* ctx);
+int tsl_set_stream(tsl_ctx* ctx, void* hip_stream);
+
+/* 0-d field writes: "cloth<i>.Kb|Kl|Ka|k_angle", "mu_cloth_elastic", "k_contact", "eps_contact", "damping",
+ * "cg_tol", "cg_maxit", "newton_cap", "plastic", "cg_check" (trajopt_folding.py:50,66; Scene_folding.py:30-31). */
+int tsl_set_param(tsl_ctx* ctx, const char* key, double value);
+int tsl_set_frozen(tsl_ctx* ctx, const int32_t* frozen_host);          /* BaseScene.set_frozen */
+int tsl_set_ext_force(tsl_ctx* ctx, const double* ext_force_host);      /* BaseScene.ext_force / manipulate_force */
+int tsl_set_gravity(tsl_ctx* ctx, const double* gravity_host);          /* per-vertex, tot_NV x 3 */
+
+/* BaseScene.compute_energy (BaseScene.py:427-451) at the given state, constraints as last detected. */
+int tsl_energy(tsl_ctx* ctx, const double* pos_dev, const double* prev_pos_dev, const double* vel_dev,
+               const double* ref_angle_dev, double* energy_host);
+
+/* newton_step_init + compute_residual_and_Hessian(spd) (BaseScene.py:976-1040) or, with grad_dev == NULL,
+ * compute_Hessian(spd) (BaseScene.py:1042-1052).  grad_dev (3*tot_NV) receives BaseScene.F. */
+int tsl_assemble(tsl_ctx* ctx, const double* pos_dev, const double* prev_pos_dev, const double* vel_dev,
+                 const double* ref_angle_dev, int spd, double* grad_dev);
+
+/* SparseMatrix.solve (sparse_solver.py:85-105): x = H^-1 rhs for the matrix of the last tsl_assemble. */
+int tsl_solve(tsl_ctx* ctx, const double* rhs_dev, double* x_dev, tsl_solve_stats* stats_host);
+
+/* BaseScene.time_step (BaseScene.py:1327-1370; Scene_folding.py:279-322): contact detection, Newton loop with
+ * halving line search, velocity update, optional plastic ref-angle update.  State arrays are updated in place. */
+int tsl_step(tsl_ctx* ctx, double* pos_dev, double* prev_pos_dev, double* vel_dev, double* ref_angle_dev,
+             tsl_step_stats* stats_host);
+
+/* calc_vn + projection_query + contact_analysis (BaseScene.py:837-850, geometry.py:223-229, BaseScene.py:818-835).
+ * proj_flag / proj_dir persist inside the context between calls (geometry.py:210-219). */
+int tsl_contact_detect(tsl_ctx* ctx, const double* pos_dev, const double* prev_pos_dev, int32_t* nc_host);
+int tsl_contact_reset(tsl_ctx* ctx); /* BaseScene.reset: proj_flag.fill(0) (BaseScene.py:268) */
+
+/* Cloth.update_ref_angle (model_fold_offset.py:176-185) for every cloth. */
+int tsl_update_ref_angle(tsl_ctx* ctx, const double* pos_dev, double* ref_angle_dev);
+
+/* Grad.transfer_grad (analytic_grad_single.py:217-257) for one step s.  Buffers are the Grad fields:
+ * pos_buffer/pos_grad (T x tot_NV x 3), ref_angle_buffer/angleref_grad (T x cloth_faces x 3).
+ * On return tmp_z_frozen_dev (3*tot_NV) holds BaseScene.tmp_z_frozen for gripper.gather_grad. */
+int tsl_adjoint_step(tsl_ctx* ctx, int step, int tot_timestep, const double* pos_buffer_dev, double* pos_grad_dev,
+                     const double* ref_angle_buffer_dev, double* angleref_grad_dev, double* tmp_z_frozen_dev,
+                     double adjoint_damping, tsl_solve_stats* stats_host);
+
+/* Introspection used by the parity tests (tests/ only): assembled matrix as BSR on the host. */
+int tsl_matrix_nnzb(tsl_ctx* ctx, int32_t* nb_host, int32_t* nnzb_host);
+int tsl_matrix_export(tsl_ctx* ctx, int32_t* row_ptr_host, int32_t* col_host, double* vals_host);
+int tsl_constraints_export(tsl_ctx* ctx, int32_t* idx_host, double* w_host, double* k_host, double* dx0_host,
+                           double* T_host, double* n_host, double* mu_host, int32_t max_n);
+int tsl_proj_export(tsl_ctx* ctx, int32_t* proj_flag_host, int32_t* proj_dir_host, int32_t* proj_idx_host, double* proj_w_host);
+int tsl_proj_import(tsl_ctx* ctx, const int32_t* proj_flag_host, const int32_t* proj_dir_host);
+
+/* Batched SPD projections (linalg.py:5-12 and :15-148) on device arrays of D x D blocks, D in {2,3,9}. */
+int tsl_spd_project(tsl_ctx* ctx, double* blocks_dev, int32_t n_blocks, int32_t D);
+
+/* Timing of the dominant kernel for bench.py's roofline object: HIP-event time (ms) accumulated over the
+ * PCG iteration kernels since the last reset, launch count and the bytes one iteration moves algorithmically. */
+int tsl_profile_reset(tsl_ctx* ctx, int enable);
+int tsl_profile_read(tsl_ctx* ctx, double* spmv_ms_host, int64_t* spmv_launches_host, int64_t* spmv_bytes_per_launch_host);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* TSL_HIP_H */

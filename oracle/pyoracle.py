@@ -269,6 +269,11 @@ def set_threads(n):
     lib().tslo_set_threads(int(n))
 
 
+def set_spd_mode(m):
+    """0: literal reference QR projector (default); 1: converged Jacobi eigen-clamp"""
+    lib().tslo_set_spd_mode(int(m))
+
+
 def spd_project(A, K):
     A = np.array(A, dtype=np.float64, order="C")
     n = A.shape[0]

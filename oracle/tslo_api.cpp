@@ -143,6 +143,8 @@ void tslo_stats(void* h, long* out, int reset) {
   if (reset) s.stat_newton = s.stat_cg = s.stat_ls = s.stat_solves = s.stat_refine = 0;
 }
 
+void tslo_set_spd_mode(int m) { spd_mode() = m; }
+
 // SPD projections for unit tests
 int tslo_spd_project(double* A, int n, int K) {
   double T[81], Q[81];

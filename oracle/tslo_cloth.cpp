@@ -7,6 +7,14 @@
 
 namespace tslo {
 
+// Sign test of Cloth.compute_angle / judge_angle / compute_bending_energy (model_fold_offset.py:116,:135,:144):
+//   norm_dir[i2].dot(pos[f2v[i1][(l+1)%2]] - pos[f2v[i1][l]]) < 0
+// For the table slots init_mesh fills wrongly (odd-cell slot 2 -> face k-2) the edge vector lies exactly in the
+// plane of face i2, so the dot product is 0 in exact arithmetic and its floating-point sign is rounding noise
+// (it decides judge_angle -> sign of mat_M and c_i of those slots).  The restatement evaluates the test as in
+// exact arithmetic: values within 1e-10 |e| of zero count as zero (not negative).  Documented in DESIGN.md.
+static inline bool sign_test_negative(const V3& n2, const V3& e) { return dot(n2, e) < -1e-10 * norm(e); }
+
 // model_fold_offset.py:11-33
 void Cloth::construct(int N_, double dt_, double Len, double rho_, int offset_, bool is_square, int M_) {
   N = N_;
@@ -120,7 +128,7 @@ double Cloth::compute_angle(int i1, int i2, int l) const {
     double cos_theta = dot(norm_dir[i1], norm_dir[i2]);
     if (cos_theta < 0.999999) theta = std::acos(cos_theta);
     else theta = 2 * std::sqrt(std::fabs(1.0 - cos_theta)) / std::sqrt(1 + cos_theta);
-    if (dot(norm_dir[i2], pos[f2v[i1][(l + 1) % 2]] - pos[f2v[i1][l]]) < 0) theta = -theta;
+    if (sign_test_negative(norm_dir[i2], pos[f2v[i1][(l + 1) % 2]] - pos[f2v[i1][l]])) theta = -theta;
   }
   return theta;
 }
@@ -129,7 +137,7 @@ double Cloth::compute_angle(int i1, int i2, int l) const {
 bool Cloth::judge_angle(int i1, int i2, int l) const {
   bool ret = true;
   if (i2 != -1)
-    if (dot(norm_dir[i2], pos[f2v[i1][(l + 1) % 2]] - pos[f2v[i1][l]]) < 0) ret = false;
+    if (sign_test_negative(norm_dir[i2], pos[f2v[i1][(l + 1) % 2]] - pos[f2v[i1][l]])) ret = false;
   return ret;
 }
 
@@ -209,7 +217,7 @@ void Cloth::compute_energy() {
         double theta;
         if (cos_theta < 0.999999) theta = std::acos(cos_theta);
         else theta = 2 * std::sqrt(std::fabs(1.0 - cos_theta)) / std::sqrt(1 + cos_theta);
-        if (dot(norm_dir[i2], pos[f2v[i][(l + 1) % 2]] - pos[f2v[i][l]]) < 0) theta = -theta;
+        if (sign_test_negative(norm_dir[i2], pos[f2v[i][(l + 1) % 2]] - pos[f2v[i][l]])) theta = -theta;
         double dth = theta - ref_angle[i][l];
         Usum += Kb * dth * dth * dx * dx * 1.0 / 3.0;
       }

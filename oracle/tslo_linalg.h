@@ -118,8 +118,13 @@ inline int spd_qr(double* A, double* T, double* Q, int ld, int n, int K) {
   return sweeps;
 }
 
+inline void spd_project_jacobi(double* A, int ld, int n);
+// 0: literal Householder + K QR sweeps (reference); 1: converged Jacobi eigen-clamp (cross-check mode for tests)
+inline int& spd_mode() { static int m = 0; return m; }
+
 // linalg.py:132-148.  A, T, Q: n x n with leading dimension ld.
 inline int spd_project(double* A, double* T, double* Q, int ld, int n, int K) {
+  if (spd_mode() == 1) { spd_project_jacobi(A, ld, n); return 0; }
   spd_clear(T, Q, ld, n);
   spd_householder(A, T, Q, ld, n);
   int sweeps = spd_qr(A, T, Q, ld, n, K);

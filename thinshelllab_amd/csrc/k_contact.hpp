@@ -1,0 +1,567 @@
+// Vertex-triangle contact: broad phase (uniform grid, sorted cell keys), narrow phase (closest triangle),
+// constraint build, penalty + lagged friction energy / gradient / 12x12 blocks, matrix-free product.
+// Reference: /root/reference/code/engine/geometry.py:23-229, contact_diff.py:4-130,
+//            BaseScene.py:453-598 (energy/gradient/Hessian), :778-850 (constraints, vertex normals).
+// Native organisation: a body's triangles are bucketed by a radix sort of their cell ids (hipCUB) instead of
+// the reference's three prefix passes over a dense 132^3 grid; a query lane binary-searches the <=27 cells it
+// needs.  Contact couplings change every step, so they are NOT merged into the static SELL matrix: each
+// constraint keeps its dense 12x12 block in HBM and the PCG operator adds  sum_c P_c^T H_c P_c x  by atomics.
+#pragma once
+#include <hipcub/hipcub.hpp>
+
+#include "k_solver.hpp"
+#include "tsl_ctx.hpp"
+#include "tsl_device.hpp"
+
+struct ContactArgs {
+  const int* idx;
+  const double *w, *n, *dx0, *k, *mu, *T;
+  double k_contact, eps_contact, eps_vh;
+};
+
+// BaseScene.f0/f1/f2 (:453-478), eh = eps_v * h
+TSL_DEV double fr_f0(double x, double eh) { return (x > eh) ? x : (-x * x * x / (3.0 * eh * eh) + x * x / eh + eh / 3.0); }
+TSL_DEV double fr_f1(double x, double eh) { return (x > eh) ? 1.0 / x : (-x / (eh * eh) + 2.0 / eh); }
+TSL_DEV double fr_f2(double x, double eh) { return (x > eh) ? -1.0 / (x * x) : -1.0 / (eh * eh); }
+
+// ------------------------------------------------------------------------------------------------ vertex normals
+__global__ void k_vn_accum(int NF, const int* __restrict__ faces, const double* __restrict__ pos, double* __restrict__ vn) {
+  const int f = blockIdx.x * blockDim.x + threadIdx.x;
+  if (f >= NF) return;
+  const int a = faces[3 * f], b = faces[3 * f + 1], c = faces[3 * f + 2];
+  const d3 v1 = ld3(pos, a), v2 = ld3(pos, b), v3 = ld3(pos, c);
+  const d3 n = cross(v2 - v1, v3 - v1);
+  atomic_add3(vn, a, n); atomic_add3(vn, b, n); atomic_add3(vn, c, n);
+}
+__global__ void k_vn_normalize(int NV, double* __restrict__ vn) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= NV) return;
+  st3(vn, i, normalized(ld3(vn, i)));
+}
+
+// ------------------------------------------------------------------------------------------------ grid
+struct GridArgs { double h, bound; int n; };
+TSL_DEV void grid_idx3(const GridArgs& G, const d3& x, int o[3]) {
+  o[0] = (int)floor(fmin(fmax(x.x, -G.bound), G.bound) / G.h) + G.n / 2;
+  o[1] = (int)floor(fmin(fmax(x.y, -G.bound), G.bound) / G.h) + G.n / 2;
+  o[2] = (int)floor(fmin(fmax(x.z, -G.bound), G.bound) / G.h) + G.n / 2;
+}
+// geometry.p2g first pass (:108-113): cell of every triangle centroid + active box
+__global__ void k_grid_keys(GridArgs G, int f_start, int nf, const int* __restrict__ faces, const double* __restrict__ pos, int* __restrict__ key,
+                            int* __restrict__ val, int* __restrict__ range) {
+  const int t = blockIdx.x * blockDim.x + threadIdx.x;
+  if (t >= nf) return;
+  const int f = f_start + t;
+  const d3 mid = (ld3(pos, faces[3 * f]) + ld3(pos, faces[3 * f + 1]) + ld3(pos, faces[3 * f + 2])) / 3.0;
+  int id[3];
+  grid_idx3(G, mid, id);
+  key[t] = (id[0] * G.n + id[1]) * G.n + id[2];
+  val[t] = f;
+  for (int a = 0; a < 3; a++) { atomicMin(&range[a], id[a]); atomicMax(&range[3 + a], id[a]); }
+}
+__global__ void k_grid_range_init(int* range, int n) {
+  if (threadIdx.x < 3) range[threadIdx.x] = n; else if (threadIdx.x < 6) range[threadIdx.x] = 0;
+}
+
+// geometry.pt2tri (:23-87)
+TSL_DEV void pt2tri(const d3& x, const d3& p1, const d3& p2, const d3& p3, int& c, double& d, d3& w) {
+  const d3 e1 = normalized(p2 - p1), e2 = normalized(p3 - p2), e3 = normalized(p1 - p3);
+  const d3 n = -normalized(cross(e1, e3));
+  const d3 x1 = x - dot(x - p1, n) * n;
+  c = 0; d = 0; w = d3();
+  if (dot(cross(x1 - p1, e1), n) > 0) {
+    if (dot(x1 - p1, e1) < 0) { c = 1; d = norm(x - p1); w = d3(1, 0, 0); }
+    else if (dot(x1 - p2, e1) > 0) { c = 2; d = norm(x - p2); w = d3(0, 1, 0); }
+    else { c = -3; const double al = dot(x1 - p1, e1) / dot(p2 - p1, e1); d = norm(x - (p1 + al * (p2 - p1))); w = d3(1 - al, al, 0); }
+  } else if (dot(cross(x1 - p2, e2), n) > 0) {
+    if (dot(x1 - p2, e2) < 0) { c = 2; d = norm(x - p2); w = d3(0, 1, 0); }
+    else if (dot(x1 - p3, e2) > 0) { c = 3; d = norm(x - p3); w = d3(0, 0, 1); }
+    else { c = -1; const double al = dot(x1 - p2, e2) / dot(p3 - p2, e2); d = norm(x - (p2 + al * (p3 - p2))); w = d3(0, 1 - al, al); }
+  } else if (dot(cross(x1 - p3, e3), n) > 0) {
+    if (dot(x1 - p3, e3) < 0) { c = 3; d = norm(x - p3); w = d3(0, 0, 1); }
+    else if (dot(x1 - p1, e3) > 0) { c = 1; d = norm(x - p1); w = d3(1, 0, 0); }
+    else { c = -2; const double al = dot(x1 - p3, e3) / dot(p1 - p3, e3); d = norm(x - (p3 + al * (p1 - p3))); w = d3(al, 0, 1 - al); }
+  } else {
+    d = norm(x - x1);
+    const double S = norm(cross(p3 - p1, p2 - p1));
+    w = d3(dot(cross(p3 - p2, x1 - p2), n) / S, dot(cross(p1 - p3, x1 - p3), n) / S, dot(cross(p2 - p1, x1 - p1), n) / S);
+  }
+}
+
+TSL_DEV int lower_bound_dev(const int* __restrict__ a, int n, int key) {
+  int lo = 0, hi = n;
+  while (lo < hi) { const int mid = (lo + hi) >> 1; if (a[mid] < key) lo = mid + 1; else hi = mid; }
+  return lo;
+}
+
+// geometry.project_pair (:165-221): one lane per query vertex
+__global__ void k_project_pair(GridArgs G, int v_start, int v_end, int body_idx, int NV, int nf, const int* __restrict__ skey, const int* __restrict__ sval,
+                               const int* __restrict__ range, const int* __restrict__ faces, const double* __restrict__ pos, const double* __restrict__ vn,
+                               const int* __restrict__ border, int* __restrict__ proj_flag, int* __restrict__ proj_dir, int* __restrict__ proj_idx,
+                               double* __restrict__ proj_w) {
+  const int i = v_start + blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= v_end) return;
+  const d3 xq = ld3(pos, i);
+  int q[3];
+  grid_idx3(G, xq, q);
+  int r0[3], r1[3];
+  for (int a = 0; a < 3; a++) { r0[a] = max(q[a] - 1, range[a]); r1[a] = min(q[a] + 1, range[3 + a]) + 1; }
+  double d_min = 1e6, cos_max = -1e6;
+  int pflag = 0, pi0 = 0, pi1 = 0, pi2 = 0;
+  d3 pw = d3();
+  for (int gi = r0[0]; gi < r1[0]; gi++)
+    for (int gj = r0[1]; gj < r1[1]; gj++)
+      for (int gk = r0[2]; gk < r1[2]; gk++) {
+        const int cell = (gi * G.n + gj) * G.n + gk;
+        for (int s = lower_bound_dev(skey, nf, cell); s < nf && skey[s] == cell; s++) {
+          const int f = sval[s];
+          const int a = faces[3 * f], b = faces[3 * f + 1], c3 = faces[3 * f + 2];
+          const d3 v1 = ld3(pos, a), v2 = ld3(pos, b), v3 = ld3(pos, c3);
+          int c; double d; d3 w;
+          pt2tri(xq, v1, v2, v3, c, d, w);
+          const d3 vt = v1 * w.x + v2 * w.y + v3 * w.z;
+          const d3 nt = normalized(cross(v2 - v1, v3 - v1));
+          const double cs = dot(xq - vt, nt);
+          if (d < d_min - 1e-5 || (d < d_min + 1e-5 && cs > cos_max)) {
+            d_min = d; cos_max = cs; pi0 = a; pi1 = b; pi2 = c3; pw = w;
+            if (c == 0) pflag = 1;
+            else if (c > 0) { const int pv = (c == 1) ? a : ((c == 2) ? b : c3); pflag = !border[pv]; }
+            else {
+              const int p1 = (c != -3) ? c3 : a;
+              const int p2 = (c == -3) ? b : ((c == -1) ? b : a);  // particle_idx[pid, 2 + c]
+              pflag = !(border[p1] && border[p2]);
+            }
+          }
+        }
+      }
+  const d3 v = pw.x * ld3(pos, pi0) + pw.y * ld3(pos, pi1) + pw.z * ld3(pos, pi2);
+  const d3 n = pw.x * ld3(vn, pi0) + pw.y * ld3(vn, pi1) + pw.z * ld3(vn, pi2);
+  const size_t bi = (size_t)body_idx * NV + i;
+  if (proj_flag[bi] == 0 && pflag == 1) proj_dir[bi] = dot(xq - v, n) > 0 ? 1 : 0;
+  proj_flag[bi] = pflag;
+  proj_idx[3 * bi] = pi0; proj_idx[3 * bi + 1] = pi1; proj_idx[3 * bi + 2] = pi2;
+  proj_w[3 * bi] = pw.x; proj_w[3 * bi + 1] = pw.y; proj_w[3 * bi + 2] = pw.z;
+}
+
+// BaseScene.contact_pair_analysis (:778-816)
+__global__ void k_contact_pair(int b_idx, int v_start, int v_end, double mu, int NV, int max_nc, double k_contact, double eps_contact,
+                               const double* __restrict__ pos, const double* __restrict__ prev, const int* __restrict__ proj_flag, const int* __restrict__ proj_dir,
+                               const int* __restrict__ proj_idx, const double* __restrict__ proj_w, int* nc, int* __restrict__ c_idx, double* __restrict__ c_w,
+                               double* __restrict__ c_k, double* __restrict__ c_mu, double* __restrict__ c_dx0, double* __restrict__ c_T, double* __restrict__ c_n) {
+  const int i = v_start + blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= v_end) return;
+  const size_t bi = (size_t)b_idx * NV + i;
+  if (!proj_flag[bi]) return;
+  int i0 = proj_idx[3 * bi], i1 = proj_idx[3 * bi + 1], i2 = proj_idx[3 * bi + 2];
+  double w0 = proj_w[3 * bi], w1 = proj_w[3 * bi + 1], w2 = proj_w[3 * bi + 2];
+  const d3 x_c = ld3(pos, i0) * w0 + ld3(pos, i1) * w1 + ld3(pos, i2) * w2;
+  const d3 x0_c = ld3(prev, i0) * w0 + ld3(prev, i1) * w1 + ld3(prev, i2) * w2;
+  d3 n_c = normalized(cross(ld3(pos, i1) - ld3(pos, i0), ld3(pos, i2) - ld3(pos, i0)));
+  if (proj_dir[bi] == 0) {
+    n_c = -n_c;
+    const int ti = i1; i1 = i2; i2 = ti;
+    const double tw = w1; w1 = w2; w2 = tw;
+  }
+  const double gap = dot(ld3(pos, i) - x_c, n_c);
+  if (gap < eps_contact) {
+    const int c = atomicAdd(nc, 1);
+    if (c >= max_nc) return;
+    const double cforce = k_contact * (gap - eps_contact);
+    c_idx[4 * c] = i0; c_idx[4 * c + 1] = i1; c_idx[4 * c + 2] = i2; c_idx[4 * c + 3] = i;
+    c_w[3 * c] = w0; c_w[3 * c + 1] = w1; c_w[3 * c + 2] = w2;
+    c_k[c] = -mu * cforce;
+    c_mu[c] = mu;
+    st3(c_dx0, c, ld3(prev, i) - x0_c);
+    d3 t1 = (fabs(n_c.x) < 0.5) ? d3(n_c.x, n_c.z, -n_c.y) : d3(n_c.y, -n_c.x, n_c.z);
+    const d3 t2 = cross(n_c, t1);
+    t1 = cross(n_c, t2);
+    c_T[6 * c] = t1.x; c_T[6 * c + 1] = t1.y; c_T[6 * c + 2] = t1.z; c_T[6 * c + 3] = t2.x; c_T[6 * c + 4] = t2.y; c_T[6 * c + 5] = t2.z;
+    st3(c_n, c, n_c);
+  }
+}
+
+// ------------------------------------------------------------------------------------------------ energy
+// BaseScene.contact_energy(diff=False) (:490-543 normal, :548-595 friction)
+__global__ void k_contact_energy(int nc, ContactArgs A, const double* __restrict__ pos, double* e_out) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  double e = 0;
+  if (i < nc) {
+    const int i0 = A.idx[4 * i], i1 = A.idx[4 * i + 1], i2 = A.idx[4 * i + 2], i3 = A.idx[4 * i + 3];
+    const d3 x0 = ld3(pos, i0), xa = ld3(pos, i1), xb = ld3(pos, i2), xp = ld3(pos, i3);
+    const d3 p1 = xa - x0, p2 = xb - x0, p = xp - x0;
+    const d3 cr = cross(p1, p2);
+    const double D = dot(cr, p), C = norm(cr);
+    const double d = D / C;
+    if (d < A.eps_contact) e += 0.5 * A.k_contact * (d - A.eps_contact) * (d - A.eps_contact);
+    const d3 x_c = x0 * A.w[3 * i] + xa * A.w[3 * i + 1] + xb * A.w[3 * i + 2];
+    const d3 dx = xp - x_c - ld3(A.dx0, i);
+    const double* T = A.T + 6 * (size_t)i;
+    const double u0 = T[0] * dx.x + T[1] * dx.y + T[2] * dx.z, u1 = T[3] * dx.x + T[4] * dx.y + T[5] * dx.z;
+    e += A.k[i] * fr_f0(sqrt(u0 * u0 + u1 * u1), A.eps_vh);
+  }
+  e = wave_sum(e);
+  if ((threadIdx.x & 63) == 0 && e != 0.0) atomicAdd(e_out, e);
+}
+
+// ------------------------------------------------------------------------------------------------ gradient + blocks
+// One lane per constraint.  Normal part: d = D/C with D = p.(p1 x p2), C = |p1 x p2| in the relative coordinates
+// q = (p1,p2,p); quotient rule as BaseScene.py:502-521; derivatives of D and C written in vector form
+// (contact_diff.py carries the same quantities as expanded SymPy output).  Friction part BaseScene.py:548-593.
+// Output: gradient (12) into grad (atomics), dense 12x12 into Hfull[c] (vertex order idx0..idx3).
+__global__ void __launch_bounds__(64)
+k_contact_assemble(int nc, ContactArgs A, const double* __restrict__ pos, int spd, double* __restrict__ grad, double* __restrict__ Hfull) {
+  const int ci = blockIdx.x * blockDim.x + threadIdx.x;
+  if (ci >= nc) return;
+  int id[4];
+  for (int k = 0; k < 4; k++) id[k] = A.idx[4 * ci + k];
+  const d3 x0 = ld3(pos, id[0]), xa = ld3(pos, id[1]), xb = ld3(pos, id[2]), xp = ld3(pos, id[3]);
+  double Hc[144];
+  for (int k = 0; k < 144; k++) Hc[k] = 0;
+  double gv[12];
+  for (int k = 0; k < 12; k++) gv[k] = 0;
+  {
+    const d3 a = xa - x0, b = xb - x0, p = xp - x0;
+    const d3 cr = cross(a, b);
+    const double D = dot(cr, p), C = norm(cr);
+    if (D / C < A.eps_contact) {
+      const d3 nh = cr / C;
+      double gD[9], gC[9], HC[81], HD[81];
+      const d3 gDa = cross(b, p), gDb = cross(p, a), gDc = cr;
+      const d3 gCa = cross(b, nh), gCb = cross(nh, a);
+      gD[0] = gDa.x; gD[1] = gDa.y; gD[2] = gDa.z; gD[3] = gDb.x; gD[4] = gDb.y; gD[5] = gDb.z; gD[6] = gDc.x; gD[7] = gDc.y; gD[8] = gDc.z;
+      gC[0] = gCa.x; gC[1] = gCa.y; gC[2] = gCa.z; gC[3] = gCb.x; gC[4] = gCb.y; gC[5] = gCb.z; gC[6] = gC[7] = gC[8] = 0;
+      for (int k = 0; k < 81; k++) { HC[k] = 0; HD[k] = 0; }
+      const d3 ex[3] = {d3(1, 0, 0), d3(0, 1, 0), d3(0, 0, 1)};
+      for (int j = 0; j < 3; j++)
+        for (int k = 0; k < 3; k++) {
+          const d3 ejb = cross(ex[j], b), ekb = cross(ex[k], b), aej = cross(a, ex[j]), aek = cross(a, ex[k]);
+          const d3 ejk = cross(ex[j], ex[k]);
+          HC[(0 + j) * 9 + 0 + k] = (dot(ejb, ekb) - dot(nh, ejb) * dot(nh, ekb)) / C;
+          HC[(3 + j) * 9 + 3 + k] = (dot(aej, aek) - dot(nh, aej) * dot(nh, aek)) / C;
+          const double hab = (dot(ejb, aek) - dot(nh, ejb) * dot(nh, aek)) / C + dot(nh, ejk);
+          HC[(0 + j) * 9 + 3 + k] = hab;
+          HC[(3 + k) * 9 + 0 + j] = hab;
+          // D = a . (b x p): d2D/da_j db_k = e_j.(e_k x p) ... = (e_j x e_k).p etc.
+          const double dab = dot(ejk, p), dbc = dot(ejk, a), dca = dot(ejk, b);
+          HD[(0 + j) * 9 + 3 + k] = dab; HD[(3 + k) * 9 + 0 + j] = dab;
+          HD[(3 + j) * 9 + 6 + k] = dbc; HD[(6 + k) * 9 + 3 + j] = dbc;
+          HD[(6 + j) * 9 + 0 + k] = dca; HD[(0 + k) * 9 + 6 + j] = dca;
+        }
+      const double d = D / C;
+      double G9[9], H9[81];
+      for (int j = 0; j < 9; j++) G9[j] = gD[j] / C - D * gC[j] / (C * C);
+      for (int j = 0; j < 9; j++)
+        for (int k = 0; k < 9; k++)
+          H9[j * 9 + k] = HD[j * 9 + k] / C - gD[j] * gC[k] / (C * C) - gD[k] * gC[j] / (C * C) - D * HC[j * 9 + k] / (C * C) + 2 * D * gC[j] * gC[k] / (C * C * C);
+      const double pe_pd = A.k_contact * (d - A.eps_contact);
+      for (int j = 0; j < 9; j++)
+        for (int k = 0; k < 9; k++) H9[j * 9 + k] = A.k_contact * G9[j] * G9[k] + pe_pd * H9[j * 9 + k];
+      for (int j = 0; j < 9; j++) G9[j] *= pe_pd;
+      if (spd) spd_clamp<9>(H9);
+      // relative coordinate (k, j) <-> vertex k+1, axis j ; vertex 0 gets minus the sums
+      for (int k = 0; k < 3; k++)
+        for (int j = 0; j < 3; j++) {
+          const double g = G9[k * 3 + j];
+          gv[(k + 1) * 3 + j] += g;
+          gv[j] -= g;
+          for (int k2 = 0; k2 < 3; k2++)
+            for (int j2 = 0; j2 < 3; j2++) {
+              const double hh = H9[(k * 3 + j) * 9 + k2 * 3 + j2];
+              Hc[((k + 1) * 3 + j) * 12 + (k2 + 1) * 3 + j2] += hh;
+              Hc[((k + 1) * 3 + j) * 12 + j2] -= hh;
+              Hc[j * 12 + (k2 + 1) * 3 + j2] -= hh;
+              Hc[j * 12 + j2] += hh;
+            }
+        }
+    }
+  }
+  {
+    const double w[3] = {A.w[3 * ci], A.w[3 * ci + 1], A.w[3 * ci + 2]};
+    const double kf = A.k[ci];
+    const double* T = A.T + 6 * (size_t)ci;
+    const d3 x_c = x0 * w[0] + xa * w[1] + xb * w[2];
+    const d3 dx = xp - x_c - ld3(A.dx0, ci);
+    const double u[2] = {T[0] * dx.x + T[1] * dx.y + T[2] * dx.z, T[3] * dx.x + T[4] * dx.y + T[5] * dx.z};
+    const double r = sqrt(u[0] * u[0] + u[1] * u[1]);
+    const double f1 = fr_f1(r, A.eps_vh), f2 = fr_f2(r, A.eps_vh);
+    double g1[3];
+    for (int j = 0; j < 3; j++) g1[j] = kf * f1 * (u[0] * T[j] + u[1] * T[3 + j]);
+    double ha = f1, hb = 0, hd = f1;
+    if (r > 1e-9) { ha += f2 * u[0] * u[0] / r; hb += f2 * u[0] * u[1] / r; hd += f2 * u[1] * u[1] / r; }
+    if (spd) spd_clamp2(ha, hb, hd);
+    double h1[9];
+    for (int a = 0; a < 3; a++)
+      for (int b = 0; b < 3; b++)
+        h1[a * 3 + b] = kf * (T[a] * (ha * T[b] + hb * T[3 + b]) + T[3 + a] * (hb * T[b] + hd * T[3 + b]));
+    const double w1[4] = {-w[0], -w[1], -w[2], 1.0};
+    for (int i1 = 0; i1 < 4; i1++)
+      for (int j1 = 0; j1 < 3; j1++) {
+        gv[i1 * 3 + j1] += w1[i1] * g1[j1];
+        for (int i2 = 0; i2 < 4; i2++)
+          for (int j2 = 0; j2 < 3; j2++) Hc[(i1 * 3 + j1) * 12 + i2 * 3 + j2] += w1[i1] * w1[i2] * h1[j1 * 3 + j2];
+      }
+  }
+  if (grad)
+    for (int k = 0; k < 4; k++) atomic_add3(grad, id[k], d3(gv[3 * k], gv[3 * k + 1], gv[3 * k + 2]));
+  double* out = Hfull + 144 * (size_t)ci;
+  for (int k = 0; k < 144; k++) out[k] = Hc[k];
+}
+
+// masked copy of the per-constraint blocks (add_H frozen rule, BaseScene.py:399-405) + their diagonal 3x3 blocks
+// accumulated for the block-Jacobi preconditioner
+__global__ void k_contact_mask(int nc, const int* __restrict__ idx, const int* __restrict__ frozen, const int* __restrict__ rowpos, const double* __restrict__ Hfull,
+                               double* __restrict__ Hm, double* __restrict__ cdiag) {
+  const int ci = blockIdx.x * blockDim.x + threadIdx.x;
+  if (ci >= nc) return;
+  int fr[12], id[4];
+  for (int k = 0; k < 4; k++) { id[k] = idx[4 * ci + k]; for (int j = 0; j < 3; j++) fr[3 * k + j] = frozen[3 * id[k] + j]; }
+  const double* in = Hfull + 144 * (size_t)ci;
+  double* out = Hm + 144 * (size_t)ci;
+  for (int r = 0; r < 12; r++)
+    for (int c = 0; c < 12; c++) {
+      const double v = (fr[r] || fr[c]) ? 0.0 : in[r * 12 + c];
+      out[r * 12 + c] = v;
+      if (r / 3 == c / 3 && v != 0.0) atomicAdd(&cdiag[9 * (size_t)rowpos[id[r / 3]] + 3 * (r % 3) + (c % 3)], v);
+    }
+}
+
+// y += sum_c P_c^T H_c P_c x  (permuted vectors); dot(x, that) added to pAp[slot]
+__global__ void k_contact_matvec(int nc, const int* __restrict__ idx, const int* __restrict__ rowpos, const double* __restrict__ Hm, const double* __restrict__ x,
+                                 double* __restrict__ y, CgScal* sc, int slot, int check_flag) {
+  if (check_flag && sc->flag) return;
+  const int ci = blockIdx.x * blockDim.x + threadIdx.x;
+  double acc = 0;
+  if (ci < nc) {
+    int pr[4];
+    double xv[12];
+    for (int k = 0; k < 4; k++) {
+      pr[k] = rowpos[idx[4 * ci + k]];
+      const d3 v = ld3(x, pr[k]);
+      xv[3 * k] = v.x; xv[3 * k + 1] = v.y; xv[3 * k + 2] = v.z;
+    }
+    const double* H = Hm + 144 * (size_t)ci;
+    for (int r = 0; r < 12; r++) {
+      double s = 0;
+      for (int c = 0; c < 12; c++) s += H[r * 12 + c] * xv[c];
+      if (s != 0.0) atomicAdd(&y[3 * (size_t)pr[r / 3] + (r % 3)], s);
+      acc += s * xv[r];
+    }
+  }
+  if (slot >= 0) {
+    acc = wave_sum(acc);
+    if ((threadIdx.x & 63) == 0 && acc != 0.0) atomicAdd(&sc->pAp[slot], acc);
+  }
+}
+
+// tmp_z_frozen[j] -= H_ij z_i for i free, j frozen (second compute_Hessian pass of transfer_grad,
+// BaseScene.py:403-405 / analytic_grad_single.py:239-243), contact part; z, out in ORIGINAL order
+__global__ void k_contact_zfrozen(int nc, const int* __restrict__ idx, const int* __restrict__ frozen, const double* __restrict__ Hfull, const double* __restrict__ z,
+                                  double* __restrict__ out) {
+  const int ci = blockIdx.x * blockDim.x + threadIdx.x;
+  if (ci >= nc) return;
+  int id[4], fr[12];
+  double zv[12];
+  for (int k = 0; k < 4; k++) {
+    id[k] = idx[4 * ci + k];
+    for (int j = 0; j < 3; j++) { fr[3 * k + j] = frozen[3 * id[k] + j]; zv[3 * k + j] = z[3 * (size_t)id[k] + j]; }
+  }
+  const double* H = Hfull + 144 * (size_t)ci;
+  for (int c = 0; c < 12; c++) {
+    if (!fr[c]) continue;
+    double s = 0;
+    for (int r = 0; r < 12; r++) if (!fr[r]) s += H[r * 12 + c] * zv[r];
+    if (s != 0.0) atomicAdd(&out[3 * (size_t)id[c / 3] + (c % 3)], -s);
+  }
+}
+
+// BaseScene.contact_energy_backprop (:682-730): friction-lag adjoint into pos_grad[step-1] (pg points at that slice)
+__global__ void k_contact_backprop(int nc, ContactArgs A, const double* __restrict__ pos, const double* __restrict__ z, double* __restrict__ pg) {
+  const int ci = blockIdx.x * blockDim.x + threadIdx.x;
+  if (ci >= nc) return;
+  int id[4];
+  for (int k = 0; k < 4; k++) id[k] = A.idx[4 * ci + k];
+  const d3 x0 = ld3(pos, id[0]), xa = ld3(pos, id[1]), xb = ld3(pos, id[2]), xp = ld3(pos, id[3]);
+  const double w[3] = {A.w[3 * ci], A.w[3 * ci + 1], A.w[3 * ci + 2]};
+  const double kf = A.k[ci];
+  const double* T = A.T + 6 * (size_t)ci;
+  const d3 x_c = x0 * w[0] + xa * w[1] + xb * w[2];
+  const d3 dx = xp - x_c - ld3(A.dx0, ci);
+  const double u[2] = {T[0] * dx.x + T[1] * dx.y + T[2] * dx.z, T[3] * dx.x + T[4] * dx.y + T[5] * dx.z};
+  const double r = sqrt(u[0] * u[0] + u[1] * u[1]);
+  const double f1 = fr_f1(r, A.eps_vh), f2 = fr_f2(r, A.eps_vh);
+  const double pressure = kf / A.mu[ci];
+  double g1[3];
+  for (int j = 0; j < 3; j++) g1[j] = kf * f1 * (u[0] * T[j] + u[1] * T[3 + j]);
+  const d3 n_c = ld3(A.n, ci);
+  double acc[12];
+  for (int k = 0; k < 12; k++) acc[k] = 0;
+  double zv[12];
+  for (int k = 0; k < 4; k++) for (int j = 0; j < 3; j++) zv[3 * k + j] = z[3 * (size_t)id[k] + j];
+  {
+    const double wp[4] = {w[0], w[1], w[2], -1.0};
+    double s = 0;
+    for (int i1 = 0; i1 < 4; i1++)
+      for (int j1 = 0; j1 < 3; j1++) s += zv[3 * i1 + j1] * (wp[i1] * g1[j1] / pressure);
+    const double nn[3] = {n_c.x, n_c.y, n_c.z};
+    for (int i2 = 0; i2 < 4; i2++)
+      for (int j2 = 0; j2 < 3; j2++) acc[3 * i2 + j2] += s * wp[i2] * nn[j2] * A.k_contact;
+  }
+  {
+    double ha = f1, hb = 0, hd = f1;
+    if (r > 1e-9) { ha += f2 * u[0] * u[0] / r; hb += f2 * u[0] * u[1] / r; hd += f2 * u[1] * u[1] / r; }
+    double h1[9];
+    for (int a = 0; a < 3; a++)
+      for (int b = 0; b < 3; b++) h1[a * 3 + b] = kf * (T[a] * (ha * T[b] + hb * T[3 + b]) + T[3 + a] * (hb * T[b] + hd * T[3 + b]));
+    const double w1[4] = {-w[0], -w[1], -w[2], 1.0};
+    for (int i1 = 0; i1 < 4; i1++)
+      for (int i2 = 0; i2 < 4; i2++)
+        for (int j1 = 0; j1 < 3; j1++)
+          for (int j2 = 0; j2 < 3; j2++) acc[3 * i2 + j2] += zv[3 * i1 + j1] * w1[i1] * w1[i2] * h1[j1 * 3 + j2];
+  }
+  for (int k = 0; k < 4; k++) atomic_add3(pg, id[k], d3(acc[3 * k], acc[3 * k + 1], acc[3 * k + 2]));
+}
+
+// batched projections for unit tests
+__global__ void k_spd_batch(double* blocks, int n, int D) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  if (D == 3) {
+    double A[9];
+    for (int k = 0; k < 9; k++) A[k] = blocks[9 * (size_t)i + k];
+    spd_clamp<3>(A);
+    for (int k = 0; k < 9; k++) blocks[9 * (size_t)i + k] = A[k];
+  } else if (D == 9) {
+    double A[81];
+    for (int k = 0; k < 81; k++) A[k] = blocks[81 * (size_t)i + k];
+    spd_clamp<9>(A);
+    for (int k = 0; k < 81; k++) blocks[81 * (size_t)i + k] = A[k];
+  } else {
+    double a = blocks[4 * (size_t)i], b = 0.5 * (blocks[4 * (size_t)i + 1] + blocks[4 * (size_t)i + 2]), d = blocks[4 * (size_t)i + 3];
+    spd_clamp2(a, b, d);
+    blocks[4 * (size_t)i] = a; blocks[4 * (size_t)i + 1] = b; blocks[4 * (size_t)i + 2] = b; blocks[4 * (size_t)i + 3] = d;
+  }
+}
+
+// ------------------------------------------------------------------------------------------------ host side
+static inline int cnblk(long n, int b) { return (int)((n + b - 1) / b); }
+
+static int contact_alloc(tsl_ctx* c, const tsl_scene_desc* d) {
+  int rc = 0;
+  const int NV = c->NV;
+  std::vector<int> faces;
+  if (d->tot_NF > 0 && d->faces_host) faces.assign(d->faces_host, d->faces_host + 3 * (size_t)d->tot_NF);
+  rc |= c->faces.upload(faces);
+  rc |= c->vn.alloc(3 * (size_t)NV);
+  const size_t nb = (size_t)std::max(c->n_body, 1);
+  rc |= c->proj_flag.alloc(nb * NV); rc |= c->proj_dir.alloc(nb * NV); rc |= c->proj_idx.alloc(nb * NV * 3); rc |= c->proj_w.alloc(nb * NV * 3);
+  rc |= c->nc_dev.alloc(1);
+  const size_t mc = (size_t)c->max_n_constraints;
+  rc |= c->c_idx.alloc(mc * 4); rc |= c->c_w.alloc(mc * 3); rc |= c->c_n.alloc(mc * 3); rc |= c->c_dx0.alloc(mc * 3);
+  rc |= c->c_k.alloc(mc); rc |= c->c_mu.alloc(mc); rc |= c->c_T.alloc(mc * 6);
+  rc |= c->c_H.alloc(mc * 144); rc |= c->c_Hfull.alloc(mc * 144); rc |= c->c_diag.alloc((size_t)NV * 9);
+  int mbf = 1;
+  for (auto& b : c->h_bodies) mbf = std::max(mbf, b.f_end - b.f_start);
+  c->max_body_faces = mbf;
+  rc |= c->grid_key.alloc(mbf); rc |= c->grid_val.alloc(mbf); rc |= c->grid_key2.alloc(mbf); rc |= c->grid_val2.alloc(mbf); rc |= c->grid_range.alloc(8);
+  size_t tmp_bytes = 0;
+  hipcub::DeviceRadixSort::SortPairs(nullptr, tmp_bytes, c->grid_key.p, c->grid_key2.p, c->grid_val.p, c->grid_val2.p, mbf);
+  rc |= c->sort_tmp.alloc(tmp_bytes + 256);
+  // border_flag (BaseScene.py:82): all zero unless imported
+  rc |= c->border.alloc(NV);
+  if (rc) return -1;
+  c->proj_flag.zero(); c->proj_dir.zero(); c->proj_idx.zero(); c->proj_w.zero(); c->border.zero(); c->nc_dev.zero();
+  c->nc = 0;
+  return 0;
+}
+
+extern "C" int tsl_contact_reset(tsl_ctx* c) { return c->proj_flag.zero(c->stream); }
+
+extern "C" int tsl_contact_detect(tsl_ctx* c, const double* pos, const double* prev, int32_t* nc_host) {
+  hipStream_t s = c->stream;
+  const int NV = c->NV;
+  c->nc = 0;
+  if (c->n_body < 2 || c->NF == 0) { if (nc_host) *nc_host = 0; return 0; }
+  // calc_vn
+  HIP_OK(hipMemsetAsync(c->vn.p, 0, 3 * (size_t)NV * sizeof(double), s));
+  hipLaunchKernelGGL(k_vn_accum, dim3(cnblk(c->NF, 256)), dim3(256), 0, s, c->NF, c->faces.p, pos, c->vn.p);
+  hipLaunchKernelGGL(k_vn_normalize, dim3(cnblk(NV, 256)), dim3(256), 0, s, NV, c->vn.p);
+  // projection_query
+  GridArgs G;
+  G.h = c->grid_h; G.n = (int)floor(0.2 / c->grid_h) * 2; G.bound = c->grid_h * (G.n - 1) / 2;
+  for (int b = 0; b < c->n_body; b++) {
+    const tsl_body& body = c->h_bodies[b];
+    const int nf = body.f_end - body.f_start;
+    if (nf <= 0) continue;
+    hipLaunchKernelGGL(k_grid_range_init, dim3(1), dim3(64), 0, s, c->grid_range.p, G.n);
+    hipLaunchKernelGGL(k_grid_keys, dim3(cnblk(nf, 256)), dim3(256), 0, s, G, body.f_start, nf, c->faces.p, pos, c->grid_key.p, c->grid_val.p, c->grid_range.p);
+    size_t tmp_bytes = c->sort_tmp.n;
+    HIP_OK(hipcub::DeviceRadixSort::SortPairs(c->sort_tmp.p, tmp_bytes, c->grid_key.p, c->grid_key2.p, c->grid_val.p, c->grid_val2.p, nf, 0, 32, s));
+    for (int b2 = 0; b2 < c->n_body; b2++) {
+      if (b2 == b) continue;
+      const tsl_body& q = c->h_bodies[b2];
+      const int nq = q.v_end - q.v_start;
+      if (nq <= 0) continue;
+      hipLaunchKernelGGL(k_project_pair, dim3(cnblk(nq, 64)), dim3(64), 0, s, G, q.v_start, q.v_end, b, NV, nf, c->grid_key2.p, c->grid_val2.p, c->grid_range.p, c->faces.p,
+                         pos, c->vn.p, c->border.p, c->proj_flag.p, c->proj_dir.p, c->proj_idx.p, c->proj_w.p);
+    }
+  }
+  // contact_analysis
+  HIP_OK(hipMemsetAsync(c->nc_dev.p, 0, sizeof(int), s));
+  for (const auto& pr : c->h_pairs) {
+    const int nq = pr.v_end - pr.v_start;
+    if (nq <= 0) continue;
+    const double mu = pr.mu_is_param ? c->mu_cloth_elastic : pr.mu;
+    hipLaunchKernelGGL(k_contact_pair, dim3(cnblk(nq, 128)), dim3(128), 0, s, pr.b_idx, pr.v_start, pr.v_end, mu, NV, c->max_n_constraints, c->k_contact, c->eps_contact, pos,
+                       prev, c->proj_flag.p, c->proj_dir.p, c->proj_idx.p, c->proj_w.p, c->nc_dev.p, c->c_idx.p, c->c_w.p, c->c_k.p, c->c_mu.p, c->c_dx0.p, c->c_T.p, c->c_n.p);
+  }
+  int nc = 0;
+  HIP_OK(hipMemcpyAsync(&nc, c->nc_dev.p, sizeof(int), hipMemcpyDeviceToHost, s));
+  HIP_OK(hipStreamSynchronize(s));
+  HIP_OK(hipGetLastError());
+  c->nc = std::min(nc, c->max_n_constraints);
+  if (nc_host) *nc_host = c->nc;
+  return 0;
+}
+
+static int contact_assemble(tsl_ctx* c, const double* pos, int spd, double* grad) {
+  if (c->nc <= 0) return 0;
+  hipStream_t s = c->stream;
+  ContactArgs A;
+  A.idx = c->c_idx.p; A.w = c->c_w.p; A.n = c->c_n.p; A.dx0 = c->c_dx0.p; A.k = c->c_k.p; A.mu = c->c_mu.p; A.T = c->c_T.p;
+  A.k_contact = c->k_contact; A.eps_contact = c->eps_contact; A.eps_vh = c->eps_v * c->dt;
+  hipLaunchKernelGGL(k_contact_assemble, dim3(cnblk(c->nc, 64)), dim3(64), 0, s, c->nc, A, pos, spd, grad, c->c_Hfull.p);
+  HIP_OK(hipMemsetAsync(c->c_diag.p, 0, c->c_diag.n * sizeof(double), s));
+  hipLaunchKernelGGL(k_contact_mask, dim3(cnblk(c->nc, 64)), dim3(64), 0, s, c->nc, c->c_idx.p, c->frozen.p, c->rowpos.p, c->c_Hfull.p, c->c_H.p, c->c_diag.p);
+  return 0;
+}
+
+extern "C" int tsl_constraints_export(tsl_ctx* c, int32_t* idx, double* w, double* k, double* dx0, double* T, double* n, double* mu, int32_t max_n) {
+  HIP_OK(hipStreamSynchronize(c->stream));
+  const int m = std::min(c->nc, (int)max_n);
+  if (m <= 0) return 0;
+  HIP_OK(hipMemcpy(idx, c->c_idx.p, (size_t)m * 4 * sizeof(int), hipMemcpyDeviceToHost));
+  HIP_OK(hipMemcpy(w, c->c_w.p, (size_t)m * 3 * sizeof(double), hipMemcpyDeviceToHost));
+  HIP_OK(hipMemcpy(k, c->c_k.p, (size_t)m * sizeof(double), hipMemcpyDeviceToHost));
+  HIP_OK(hipMemcpy(dx0, c->c_dx0.p, (size_t)m * 3 * sizeof(double), hipMemcpyDeviceToHost));
+  HIP_OK(hipMemcpy(T, c->c_T.p, (size_t)m * 6 * sizeof(double), hipMemcpyDeviceToHost));
+  HIP_OK(hipMemcpy(n, c->c_n.p, (size_t)m * 3 * sizeof(double), hipMemcpyDeviceToHost));
+  HIP_OK(hipMemcpy(mu, c->c_mu.p, (size_t)m * sizeof(double), hipMemcpyDeviceToHost));
+  return m;
+}
+
+extern "C" int tsl_proj_export(tsl_ctx* c, int32_t* flag, int32_t* dir, int32_t* pidx, double* pw) {
+  HIP_OK(hipStreamSynchronize(c->stream));
+  const size_t n = (size_t)std::max(c->n_body, 1) * c->NV;
+  HIP_OK(hipMemcpy(flag, c->proj_flag.p, n * sizeof(int), hipMemcpyDeviceToHost));
+  HIP_OK(hipMemcpy(dir, c->proj_dir.p, n * sizeof(int), hipMemcpyDeviceToHost));
+  if (pidx) HIP_OK(hipMemcpy(pidx, c->proj_idx.p, n * 3 * sizeof(int), hipMemcpyDeviceToHost));
+  if (pw) HIP_OK(hipMemcpy(pw, c->proj_w.p, n * 3 * sizeof(double), hipMemcpyDeviceToHost));
+  return 0;
+}
+
+extern "C" int tsl_proj_import(tsl_ctx* c, const int32_t* flag, const int32_t* dir) {
+  const size_t n = (size_t)std::max(c->n_body, 1) * c->NV;
+  HIP_OK(hipMemcpy(c->proj_flag.p, flag, n * sizeof(int), hipMemcpyHostToDevice));
+  HIP_OK(hipMemcpy(c->proj_dir.p, dir, n * sizeof(int), hipMemcpyHostToDevice));
+  return 0;
+}

@@ -1,0 +1,190 @@
+// Per-vertex (inertia / gravity / external force) and per-tetrahedron kernels.
+// Reference: /root/reference/code/engine/model_elastic_tactile.py (kind 0) and model_elastic_offset.py (kind 1),
+// vertex terms also model_fold_offset.py:193-200, :641-648, :468-470.
+#pragma once
+#include "tsl_ctx.hpp"
+#include "tsl_device.hpp"
+
+struct VertArgs {
+  int NV;
+  const double *mass, *grav, *fext;
+  double dt;
+};
+
+// E_v = -f_ext.x - m g.x + 1/2 m |x - x_prev - v dt|^2 / dt^2   (model_fold_offset.py:193-200, model_elastic_tactile.py:186-192)
+TSL_DEV double vert_energy(const VertArgs& A, int i, const double* __restrict__ pos, const double* __restrict__ prev, const double* __restrict__ vel) {
+  const d3 x = ld3(pos, i);
+  const double m = A.mass[i];
+  const d3 X = x - ld3(prev, i) - ld3(vel, i) * A.dt;
+  return -dot(ld3(A.fext, i), x) - m * dot(ld3(A.grav, i), x) + 0.5 * m * dot(X, X) / (A.dt * A.dt);
+}
+
+// gradient of the above, written (not accumulated) as the first contribution to F
+__global__ void k_vert_grad(VertArgs A, const double* __restrict__ pos, const double* __restrict__ prev, const double* __restrict__ vel, double* __restrict__ F) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= A.NV) return;
+  const double m = A.mass[i];
+  const d3 X = ld3(pos, i) - ld3(prev, i) - ld3(vel, i) * A.dt;
+  const d3 g = -m * ld3(A.grav, i) - ld3(A.fext, i) + X * (m / (A.dt * A.dt));
+  atomic_add3(F, i, g);
+}
+
+// mass diagonal m/dt^2 on every dof, frozen or not (H.H.add without frozen test, model_fold_offset.py:468-470,
+// model_elastic_tactile.py:84-86)
+__global__ void k_vert_hess(VertArgs A, const int* __restrict__ diag_blk, double* __restrict__ vals) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= A.NV) return;
+  const double d = A.mass[i] / (A.dt * A.dt);
+  const int base = diag_blk[i];
+  atomicAdd(&vals[(size_t)base + 64 * 0], d);
+  atomicAdd(&vals[(size_t)base + 64 * 4], d);
+  atomicAdd(&vals[(size_t)base + 64 * 8], d);
+}
+
+struct TetArgs {
+  int n_tet;
+  const ElasticDev* el;
+  const int *tv, *tel;
+  const double *B, *W;
+};
+
+TSL_DEV m3 tet_F(const TetArgs& A, int t, const double* __restrict__ pos, int v[4], m3& B) {
+#pragma unroll
+  for (int k = 0; k < 4; k++) v[k] = A.tv[4 * t + k];
+  const d3 x3 = ld3(pos, v[3]);
+  const d3 c0 = ld3(pos, v[0]) - x3, c1 = ld3(pos, v[1]) - x3, c2 = ld3(pos, v[2]) - x3;
+  m3 Ds;
+  Ds.m[0] = c0.x; Ds.m[1] = c1.x; Ds.m[2] = c2.x;
+  Ds.m[3] = c0.y; Ds.m[4] = c1.y; Ds.m[5] = c2.y;
+  Ds.m[6] = c0.z; Ds.m[7] = c1.z; Ds.m[8] = c2.z;
+#pragma unroll
+  for (int k = 0; k < 9; k++) B.m[k] = A.B[9 * (size_t)t + k];
+  return m3_mul(Ds, B);
+}
+
+// model_elastic_tactile.py:194-201 / model_elastic_offset.py:325-331
+TSL_DEV double tet_energy(const TetArgs& A, int t, const double* __restrict__ pos) {
+  int v[4]; m3 B;
+  const m3 F = tet_F(A, t, pos, v, B);
+  const ElasticDev e = A.el[A.tel[t]];
+  double I1 = 0;
+#pragma unroll
+  for (int k = 0; k < 9; k++) I1 += F.m[k] * F.m[k];
+  const double J = m3_det(F);
+  double phi;
+  if (e.kind == 0) {
+    phi = e.mu / 2 * (I1 - 3) + e.lam / 2 * (J - e.alpha) * (J - e.alpha);
+  } else {
+    const double lj = log(fmax(0.01, J));
+    phi = e.mu / 2 * (I1 - 3) - e.mu * lj + e.lam / 2 * lj * lj;
+  }
+  return A.W[t] * phi;
+}
+
+// forces: model_elastic_tactile.py:144-154 / model_elastic_offset.py:188-198 ; residual contribution is -force
+__global__ void k_tet_grad(TetArgs A, const double* __restrict__ pos, double* __restrict__ Fg) {
+  const int t = blockIdx.x * blockDim.x + threadIdx.x;
+  if (t >= A.n_tet) return;
+  int v[4]; m3 B;
+  const m3 F = tet_F(A, t, pos, v, B);
+  const ElasticDev e = A.el[A.tel[t]];
+  const m3 FiT = m3_T(m3_inv(F));
+  m3 P;
+  if (e.kind == 0) {
+    const double J = m3_det(F);
+    const double s = e.lam * (J - e.alpha) * J;
+#pragma unroll
+    for (int k = 0; k < 9; k++) P.m[k] = e.mu * F.m[k] + s * FiT.m[k];
+  } else {
+    const double J = fmax(m3_det(F), 0.01);
+    const double s = e.lam * log(J);
+#pragma unroll
+    for (int k = 0; k < 9; k++) P.m[k] = e.mu * (F.m[k] - FiT.m[k]) + s * FiT.m[k];
+  }
+  const m3 Hm = m3_mul(P, m3_T(B));  // force on vertex i = -W * column i
+  const double W = A.W[t];
+  d3 f3 = d3();
+#pragma unroll
+  for (int i = 0; i < 3; i++) {
+    const d3 gi = d3(W * Hm.m[i], W * Hm.m[3 + i], W * Hm.m[6 + i]);  // +W*col = -(force) = dE/dx_i
+    atomic_add3(Fg, v[i], gi);
+    f3 = f3 - gi;
+  }
+  atomic_add3(Fg, v[3], f3);
+}
+
+// dP(dF) for the two materials (energy Hessian direction), returns dE-Hessian column block dH = W * dP * B^T
+TSL_DEV m3 tet_dH(const ElasticDev& e, const m3& F, const m3& Fi, const m3& FiT, double J, double logJ, const m3& dF, const m3& BT, double W) {
+  m3 dP;
+  // tr(F^-1 dF)
+  const m3 FidF = m3_mul(Fi, dF);
+  const double dTr = FidF.m[0] + FidF.m[4] + FidF.m[8];
+  const m3 X = m3_mul(m3_mul(FiT, m3_T(dF)), FiT);  // F^-T dF^T F^-T
+  if (e.kind == 0) {
+    // P = mu F + lam (J - alpha) J F^-T  (model_elastic_tactile.py:104-107 with the sign folded in)
+    const double a = e.lam * (2.0 * J * J - e.alpha * J) * dTr;
+    const double b = e.lam * (J - e.alpha) * J;
+#pragma unroll
+    for (int k = 0; k < 9; k++) dP.m[k] = e.mu * dF.m[k] + a * FiT.m[k] - b * X.m[k];
+  } else {
+    // P = mu (F - F^-T) + lam log J F^-T  (model_elastic_offset.py:141-142)
+#pragma unroll
+    for (int k = 0; k < 9; k++) dP.m[k] = e.mu * dF.m[k] + (e.mu - e.lam * logJ) * X.m[k] + e.lam * dTr * FiT.m[k];
+  }
+  m3 r = m3_mul(dP, BT);
+#pragma unroll
+  for (int k = 0; k < 9; k++) r.m[k] *= W;
+  return r;
+}
+
+// Element Hessians: kind 0 = 9x9 over vertices 0..2 with optional SPD projection, vertex 3 = minus row/col sums
+// (model_elastic_tactile.py:88-124); kind 1 = direct 12x12 (model_elastic_offset.py:101-167, no projection).
+__global__ void __launch_bounds__(64)
+k_tet_hess(TetArgs A, const int* __restrict__ blk, const double* __restrict__ pos, int spd, double* __restrict__ vals) {
+  const int t = blockIdx.x * blockDim.x + threadIdx.x;
+  if (t >= A.n_tet) return;
+  int v[4]; m3 B;
+  const m3 F = tet_F(A, t, pos, v, B);
+  const ElasticDev e = A.el[A.tel[t]];
+  const m3 Fi = m3_inv(F), FiT = m3_T(Fi), BT = m3_T(B);
+  const double W = A.W[t];
+  const double Jraw = m3_det(F);
+  const double J = (e.kind == 0) ? Jraw : fmax(Jraw, 0.01);
+  const double logJ = (e.kind == 0) ? 0.0 : log(J);
+  // He[(n*3+dim)*9 + (i*3+j)] = d(grad of vertex i, comp j)/d(x_n,dim), n,i in 0..2
+  double He[81];
+  for (int n = 0; n < 3; n++)
+    for (int dim = 0; dim < 3; dim++) {
+      m3 dF;  // dD @ B with dD[dim][n] = 1  -> row dim of dF = row n of B
+#pragma unroll
+      for (int k = 0; k < 9; k++) dF.m[k] = 0;
+#pragma unroll
+      for (int c = 0; c < 3; c++) dF.m[dim * 3 + c] = B.m[n * 3 + c];
+      const m3 dH = tet_dH(e, F, Fi, FiT, J, logJ, dF, BT, W);
+#pragma unroll
+      for (int i = 0; i < 3; i++)
+#pragma unroll
+        for (int j = 0; j < 3; j++) He[(n * 3 + dim) * 9 + i * 3 + j] = dH.m[j * 3 + i];
+    }
+  if (e.kind == 0 && spd) spd_clamp<9>(He);
+  if (e.kind != 0) {
+    // model_elastic_offset.py:151-167 scatters row = (vertex j, comp r), column = (n, dim): the transpose of the
+    // tactile convention (identical whenever the block is symmetric, i.e. J > 0.01)
+    for (int a = 0; a < 9; a++)
+      for (int b = a + 1; b < 9; b++) { const double tmp = He[a * 9 + b]; He[a * 9 + b] = He[b * 9 + a]; He[b * 9 + a] = tmp; }
+  }
+  // scatter: 16 blocks; block (a,b) element (j,j2): a,b<3: He[(a*3+j)*9 + b*3+j2]; vertex 3 gets minus sums
+  for (int a = 0; a < 4; a++)
+    for (int b = 0; b < 4; b++) {
+      const int base = blk[16 * t + a * 4 + b];
+      for (int j = 0; j < 3; j++)
+        for (int j2 = 0; j2 < 3; j2++) {
+          double s = 0;
+          if (a < 3 && b < 3) s = He[(a * 3 + j) * 9 + b * 3 + j2];
+          else if (a < 3) { for (int bb = 0; bb < 3; bb++) s -= He[(a * 3 + j) * 9 + bb * 3 + j2]; }
+          else if (b < 3) { for (int aa = 0; aa < 3; aa++) s -= He[(aa * 3 + j) * 9 + b * 3 + j2]; }
+          else { for (int aa = 0; aa < 3; aa++) for (int bb = 0; bb < 3; bb++) s += He[(aa * 3 + j) * 9 + bb * 3 + j2]; }
+          atomicAdd(&vals[(size_t)base + 64 * (3 * j + j2)], s);
+        }
+    }
+}

@@ -1,0 +1,160 @@
+// Context of libtsl_hip.so: device-resident topology, the SELL-64 block matrix, solver scratch.
+// Host-side only (no kernels here).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include <algorithm>
+#include <cmath>
+#include <cstdio>
+#include <cstring>
+#include <string>
+#include <vector>
+
+#include "../../include/tsl_hip.h"
+
+#define TSL_SLICE 64  // rows per SELL slice == wavefront width on gfx950
+
+extern thread_local std::string g_tsl_err;
+int tsl_fail(const char* fmt, ...);
+
+#define HIP_OK(call)                                                                     \
+  do {                                                                                   \
+    hipError_t e__ = (call);                                                             \
+    if (e__ != hipSuccess) return tsl_fail("%s failed: %s (%s:%d)", #call, hipGetErrorString(e__), __FILE__, __LINE__); \
+  } while (0)
+
+template <class T>
+struct DevBuf {
+  T* p = nullptr;
+  size_t n = 0;
+  int alloc(size_t count) {
+    release();
+    n = count;
+    if (count == 0) return 0;
+    hipError_t e = hipMalloc((void**)&p, count * sizeof(T));
+    if (e != hipSuccess) { p = nullptr; return tsl_fail("hipMalloc(%zu B) failed: %s", count * sizeof(T), hipGetErrorString(e)); }
+    return 0;
+  }
+  int upload(const std::vector<T>& h) {
+    if (alloc(h.size())) return -1;
+    if (h.empty()) return 0;
+    hipError_t e = hipMemcpy(p, h.data(), h.size() * sizeof(T), hipMemcpyHostToDevice);
+    if (e != hipSuccess) return tsl_fail("hipMemcpy H2D failed: %s", hipGetErrorString(e));
+    return 0;
+  }
+  int zero(hipStream_t s = 0) {
+    if (!n) return 0;
+    hipError_t e = hipMemsetAsync(p, 0, n * sizeof(T), s);
+    if (e != hipSuccess) return tsl_fail("hipMemset failed: %s", hipGetErrorString(e));
+    return 0;
+  }
+  void release() { if (p) { (void)hipFree(p); p = nullptr; } n = 0; }
+  ~DevBuf() { release(); }
+};
+
+// per-cloth constants read by the kernels (device copy)
+struct ClothDev {
+  int face_start, NF, v_offset, NV;
+  double dx, mass, Kl, Ka, Kb, k_angle;
+};
+struct ElasticDev {
+  int kind, cell_start, n_cells, v_offset, n_verts;
+  double mu, lam, alpha;
+};
+
+// device scalars shared by the solver / Newton kernels: one 256-B record, viewed as CgScal (k_solver.hpp)
+struct SolverScalars {
+  double raw[32];
+};
+
+struct tsl_ctx {
+  hipStream_t stream = 0;
+  int NV = 0, NF = 0;  // tot_NV, tot_NF
+  double dt = 5e-3, k_contact = 1000, eps_contact = 1e-3, eps_v = 0.01, damping = 1.0, mu_cloth_elastic = 1.0;
+  int max_n_constraints = 10000;
+  int newton_cap = 1000, plastic = 0, contact_enable = 1;
+  double cg_tol = 1e-10;
+  int cg_maxit = 200000, cg_check = 32;
+  double grid_h = 0.003;
+
+  // ---- cloth
+  std::vector<ClothDev> h_cloth;
+  DevBuf<ClothDev> d_cloth;
+  int n_cface = 0, n_hinge = 0;
+  DevBuf<int> cf_f2v, cf_cf, cf_cp, cf_cloth;  // per cloth face (global ids): verts, counter_face, counter_point, cloth id
+  DevBuf<double> cf_V, cf_li;                   // rest area, rest lengths
+  DevBuf<int> cf_blk;                           // n_cface x 9 block offsets
+  DevBuf<int> hg_info;                          // n_hinge x 8: f1, l, f2, p4, p21, v[..] unused
+  DevBuf<int> hg_v;                             // n_hinge x 4 vertex ids (a,b,c,d)
+  DevBuf<int> hg_blk;                           // n_hinge x 16 block offsets
+  DevBuf<double> norm_dir;                      // n_cface x 3
+  DevBuf<double> quirk;                         // n_cloth x 3 faces x 3 slots x 10 (c_i, mat_N)
+  std::vector<int> h_cf_f2v, h_cf_cf, h_cf_cp;
+
+  // ---- tets
+  std::vector<ElasticDev> h_el;
+  DevBuf<ElasticDev> d_el;
+  int n_tet = 0;
+  DevBuf<int> tet_v, tet_el, tet_blk;  // 4 global verts, elastic id, 16 block offsets
+  DevBuf<double> tet_B, tet_W;
+
+  // ---- vertices
+  DevBuf<double> mass, grav, fext;  // NV, NV*3, NV*3
+  DevBuf<int> frozen;               // 3*NV (original order)
+  DevBuf<int> diag_blk;             // NV
+  std::vector<int> h_frozen;
+  std::vector<double> h_mass;
+
+  // ---- matrix (SELL-64 of 3x3 blocks, rows permuted by length)
+  int n_slices = 0;
+  long n_slots = 0;  // block slots incl. padding
+  std::vector<int> h_rowpos, h_perm, h_slice_off, h_slice_len, h_colidx;
+  std::vector<std::vector<int>> h_rows;  // original-order adjacency (sorted)
+  DevBuf<int> rowpos, perm, slice_off, slice_len, colidx, diag_perm;
+  DevBuf<double> vals, vals_full;  // masked (solver) and unmasked (adjoint) copies
+  DevBuf<double> Dinv;             // NV x 9 (permuted)
+  DevBuf<unsigned char> fzmask;    // NV (permuted) 3-bit frozen mask
+  DevBuf<double> mdt2;             // NV (permuted) m/dt^2
+  long nnzb = 0;
+
+  // ---- solver vectors (permuted AoS, 3*NV)
+  DevBuf<double> v_x, v_r, v_z, v_p, v_Ap, v_b, v_t0, v_t1, v_t2, v_t3, v_t4;
+  DevBuf<SolverScalars> scal;
+  SolverScalars* h_scal = nullptr;  // pinned
+
+  // ---- Newton scratch (original order)
+  DevBuf<double> F, pdir, x1;
+
+  // ---- contact
+  int n_body = 0, n_pair = 0;
+  std::vector<tsl_body> h_bodies;
+  std::vector<tsl_contact_pair> h_pairs;
+  DevBuf<int> faces;  // NF x 3
+  DevBuf<int> border; // NV (BaseScene.border_flag)
+  DevBuf<double> vn;
+  DevBuf<int> proj_flag, proj_dir, proj_idx;  // n_body x NV (x3)
+  DevBuf<double> proj_w;
+  DevBuf<int> nc_dev;
+  int nc = 0;
+  DevBuf<int> c_idx;                                  // max_nc x 4
+  DevBuf<double> c_w, c_n, c_dx0, c_k, c_mu, c_T;     // 3,3,3,1,1,6
+  DevBuf<double> c_H;                                 // max_nc x 144 (12x12, masked) for the matrix-free product
+  DevBuf<double> c_Hfull;                             // unmasked copy (adjoint)
+  DevBuf<double> c_diag;                              // NV x 9 (permuted): masked contact contribution to the diagonal blocks
+  DevBuf<double> c_G;                                 // max_nc x 12 scratch
+  DevBuf<int> grid_key, grid_val, grid_key2, grid_val2, grid_range;  // per target body: cell id / face id (sorted), active range (6 ints)
+  DevBuf<unsigned char> sort_tmp;
+  int max_body_faces = 0;
+
+  // ---- profiling of the dominant kernel
+  int prof_enable = 0;
+  hipEvent_t ev0 = nullptr, ev1 = nullptr;
+  double prof_ms = 0;
+  long prof_launches = 0, prof_samples = 0;
+  std::vector<std::pair<hipEvent_t, hipEvent_t>> ev_pool;
+  size_t ev_used = 0;
+
+  // stats
+  tsl_step_stats step_stats{};
+};

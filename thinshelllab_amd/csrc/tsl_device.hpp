@@ -1,0 +1,176 @@
+// Device-side fp64 helpers for the gfx950 thin-shell kernels (no reference counterpart: Taichi
+// supplies ti.Vector / ti.Matrix; here they are plain structs kept in VGPRs).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#define TSL_DEV __device__ __forceinline__
+#define TSL_HD __host__ __device__ __forceinline__
+
+struct d3 {
+  double x, y, z;
+  TSL_HD d3() : x(0), y(0), z(0) {}
+  TSL_HD d3(double a, double b, double c) : x(a), y(b), z(c) {}
+  TSL_HD double operator[](int i) const { return i == 0 ? x : (i == 1 ? y : z); }
+};
+TSL_HD d3 operator+(const d3& a, const d3& b) { return d3(a.x + b.x, a.y + b.y, a.z + b.z); }
+TSL_HD d3 operator-(const d3& a, const d3& b) { return d3(a.x - b.x, a.y - b.y, a.z - b.z); }
+TSL_HD d3 operator-(const d3& a) { return d3(-a.x, -a.y, -a.z); }
+TSL_HD d3 operator*(const d3& a, double s) { return d3(a.x * s, a.y * s, a.z * s); }
+TSL_HD d3 operator*(double s, const d3& a) { return d3(a.x * s, a.y * s, a.z * s); }
+TSL_HD d3 operator/(const d3& a, double s) { return d3(a.x / s, a.y / s, a.z / s); }
+TSL_HD double dot(const d3& a, const d3& b) { return a.x * b.x + a.y * b.y + a.z * b.z; }
+TSL_HD d3 cross(const d3& a, const d3& b) { return d3(a.y * b.z - a.z * b.y, a.z * b.x - a.x * b.z, a.x * b.y - a.y * b.x); }
+TSL_HD double norm(const d3& a) { return sqrt(dot(a, a)); }
+TSL_HD d3 normalized(const d3& a) { return a / norm(a); }
+
+TSL_DEV d3 ld3(const double* __restrict__ p, int i) { return d3(p[3 * (size_t)i], p[3 * (size_t)i + 1], p[3 * (size_t)i + 2]); }
+TSL_DEV void st3(double* p, int i, const d3& v) { p[3 * (size_t)i] = v.x; p[3 * (size_t)i + 1] = v.y; p[3 * (size_t)i + 2] = v.z; }
+TSL_DEV void atomic_add3(double* p, int i, const d3& v) {
+  atomicAdd(&p[3 * (size_t)i], v.x);
+  atomicAdd(&p[3 * (size_t)i + 1], v.y);
+  atomicAdd(&p[3 * (size_t)i + 2], v.z);
+}
+
+// row-major 3x3
+struct m3 {
+  double m[9];
+  TSL_HD double& operator()(int i, int j) { return m[i * 3 + j]; }
+  TSL_HD double operator()(int i, int j) const { return m[i * 3 + j]; }
+};
+TSL_HD m3 m3_zero() { m3 r; for (int i = 0; i < 9; i++) r.m[i] = 0; return r; }
+TSL_HD m3 m3_outer(const d3& a, const d3& b) {
+  m3 r;
+  r.m[0] = a.x * b.x; r.m[1] = a.x * b.y; r.m[2] = a.x * b.z;
+  r.m[3] = a.y * b.x; r.m[4] = a.y * b.y; r.m[5] = a.y * b.z;
+  r.m[6] = a.z * b.x; r.m[7] = a.z * b.y; r.m[8] = a.z * b.z;
+  return r;
+}
+TSL_HD m3 m3_mul(const m3& a, const m3& b) {
+  m3 r;
+  for (int i = 0; i < 3; i++)
+    for (int j = 0; j < 3; j++) r.m[i * 3 + j] = a.m[i * 3] * b.m[j] + a.m[i * 3 + 1] * b.m[3 + j] + a.m[i * 3 + 2] * b.m[6 + j];
+  return r;
+}
+TSL_HD m3 m3_T(const m3& a) { m3 r; for (int i = 0; i < 3; i++) for (int j = 0; j < 3; j++) r.m[i * 3 + j] = a.m[j * 3 + i]; return r; }
+TSL_HD double m3_det(const m3& a) {
+  return a.m[0] * (a.m[4] * a.m[8] - a.m[5] * a.m[7]) - a.m[1] * (a.m[3] * a.m[8] - a.m[5] * a.m[6]) + a.m[2] * (a.m[3] * a.m[7] - a.m[4] * a.m[6]);
+}
+TSL_HD m3 m3_inv(const m3& a) {
+  double d = m3_det(a);
+  m3 r;
+  r.m[0] = (a.m[4] * a.m[8] - a.m[5] * a.m[7]) / d;
+  r.m[1] = (a.m[2] * a.m[7] - a.m[1] * a.m[8]) / d;
+  r.m[2] = (a.m[1] * a.m[5] - a.m[2] * a.m[4]) / d;
+  r.m[3] = (a.m[5] * a.m[6] - a.m[3] * a.m[8]) / d;
+  r.m[4] = (a.m[0] * a.m[8] - a.m[2] * a.m[6]) / d;
+  r.m[5] = (a.m[2] * a.m[3] - a.m[0] * a.m[5]) / d;
+  r.m[6] = (a.m[3] * a.m[7] - a.m[4] * a.m[6]) / d;
+  r.m[7] = (a.m[1] * a.m[6] - a.m[0] * a.m[7]) / d;
+  r.m[8] = (a.m[0] * a.m[4] - a.m[1] * a.m[3]) / d;
+  return r;
+}
+TSL_HD d3 m3_mulv(const m3& a, const d3& v) {
+  return d3(a.m[0] * v.x + a.m[1] * v.y + a.m[2] * v.z, a.m[3] * v.x + a.m[4] * v.y + a.m[5] * v.z, a.m[6] * v.x + a.m[7] * v.y + a.m[8] * v.z);
+}
+
+// Symmetric eigen-clamp A <- sum_{lambda>0} lambda q q^T by cyclic Jacobi, D x D in a private array
+// with leading dimension D.  Replaces SPD_Projector.project (engine/linalg.py:132-148): the reference
+// runs Householder + K shifted-QR sweeps (not always converged); a converged eigen-solve agrees with it
+// wherever its QR converged.
+template <int D>
+TSL_DEV void spd_clamp(double* A) {
+  double V[D * D];
+#pragma unroll
+  for (int i = 0; i < D; i++)
+#pragma unroll
+    for (int j = 0; j < D; j++) V[i * D + j] = (i == j) ? 1.0 : 0.0;
+  // symmetrise (inputs are symmetric up to rounding)
+  for (int i = 0; i < D; i++)
+    for (int j = i + 1; j < D; j++) { double s = 0.5 * (A[i * D + j] + A[j * D + i]); A[i * D + j] = s; A[j * D + i] = s; }
+  const int max_sweeps = (D <= 3) ? 12 : 30;
+  for (int sweep = 0; sweep < max_sweeps; sweep++) {
+    double off = 0, diag = 0;
+    for (int i = 0; i < D; i++) {
+      diag += A[i * D + i] * A[i * D + i];
+      for (int j = i + 1; j < D; j++) off += A[i * D + j] * A[i * D + j];
+    }
+    if (off <= 1e-32 * (diag + off)) break;
+    for (int p = 0; p < D - 1; p++)
+      for (int q = p + 1; q < D; q++) {
+        double apq = A[p * D + q];
+        if (apq == 0.0) continue;
+        double theta = (A[q * D + q] - A[p * D + p]) / (2.0 * apq);
+        double t = (theta >= 0 ? 1.0 : -1.0) / (fabs(theta) + sqrt(theta * theta + 1.0));
+        double c = 1.0 / sqrt(t * t + 1.0), s = t * c;
+        for (int k = 0; k < D; k++) {
+          double akp = A[k * D + p], akq = A[k * D + q];
+          A[k * D + p] = c * akp - s * akq;
+          A[k * D + q] = s * akp + c * akq;
+        }
+        for (int k = 0; k < D; k++) {
+          double apk = A[p * D + k], aqk = A[q * D + k];
+          A[p * D + k] = c * apk - s * aqk;
+          A[q * D + k] = s * apk + c * aqk;
+        }
+        for (int k = 0; k < D; k++) {
+          double vkp = V[k * D + p], vkq = V[k * D + q];
+          V[k * D + p] = c * vkp - s * vkq;
+          V[k * D + q] = s * vkp + c * vkq;
+        }
+      }
+  }
+  double lam[D];
+  for (int e = 0; e < D; e++) lam[e] = A[e * D + e] > 0 ? A[e * D + e] : 0.0;
+  for (int i = 0; i < D; i++)
+    for (int j = 0; j < D; j++) {
+      double s = 0;
+      for (int e = 0; e < D; e++) s += lam[e] * V[i * D + e] * V[j * D + e];
+      A[i * D + j] = s;
+    }
+}
+
+// 2x2 symmetric PSD projection (engine/linalg.py:5-12, closed form of the ti.svd based rule)
+TSL_DEV void spd_clamp2(double& a, double& b, double& d) {
+  double tr = a + d, df = a - d;
+  double rad = sqrt(df * df * 0.25 + b * b);
+  double l1 = tr * 0.5 + rad, l2 = tr * 0.5 - rad;
+  double qx = 1, qy = 0;
+  if (rad > 0) {
+    double x0 = a - l2, y0 = b, x1 = b, y1 = d - l2;
+    if (x0 * x0 + y0 * y0 >= x1 * x1 + y1 * y1) { qx = x0; qy = y0; } else { qx = x1; qy = y1; }
+    double nn = sqrt(qx * qx + qy * qy);
+    if (nn > 0) { qx /= nn; qy /= nn; } else { qx = 1; qy = 0; }
+  }
+  double p1 = l1 > 0 ? l1 : 0, p2 = l2 > 0 ? l2 : 0;
+  a = p1 * qx * qx + p2 * qy * qy;
+  b = p1 * qx * qy - p2 * qy * qx;
+  d = p1 * qy * qy + p2 * qx * qx;
+}
+
+// 64-lane wave reduction, then one atomic per wave
+TSL_DEV double wave_sum(double v) {
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) v += __shfl_down(v, o, 64);
+  return v;
+}
+TSL_DEV double wave_max(double v) {
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) v = fmax(v, __shfl_down(v, o, 64));
+  return v;
+}
+// block (<=1024 threads) sum via LDS; result valid in thread 0
+TSL_DEV double block_sum(double v, double* sm) {
+  v = wave_sum(v);
+  int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+  if (lane == 0) sm[w] = v;
+  __syncthreads();
+  double r = 0;
+  if (threadIdx.x < 64) {
+    int nw = (blockDim.x + 63) >> 6;
+    r = (threadIdx.x < nw) ? sm[threadIdx.x] : 0.0;
+    r = wave_sum(r);
+  }
+  __syncthreads();
+  return r;
+}

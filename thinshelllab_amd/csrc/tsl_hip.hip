@@ -1,0 +1,683 @@
+// libtsl_hip.so -- C ABI (include/tsl_hip.h) over the gfx950 kernels.  Host orchestration of
+//   BaseScene.compute_energy / compute_residual_and_Hessian / newton_step / time_step
+//   (/root/reference/code/engine/BaseScene.py:427-451, :976-1040, :1159-1230, :1327-1370),
+//   SparseMatrix.solve (sparse_solver.py:85-105) and Grad.transfer_grad (analytic_grad_single.py:217-257).
+// There is no CPU fallback in this library: without a HIP device every entry point fails.
+#include <stdarg.h>
+
+#include <map>
+
+#include "k_cloth.hpp"
+#include "k_contact.hpp"
+#include "k_fem.hpp"
+#include "k_solver.hpp"
+#include "tsl_ctx.hpp"
+
+thread_local std::string g_tsl_err;
+int tsl_fail(const char* fmt, ...) {
+  char buf[1024];
+  va_list ap;
+  va_start(ap, fmt);
+  vsnprintf(buf, sizeof(buf), fmt, ap);
+  va_end(ap);
+  g_tsl_err = buf;
+  return -1;
+}
+
+#define TSL_TRY(x) do { if ((x) != 0) return -1; } while (0)
+static inline int nblk(long n, int b) { return (int)((n + b - 1) / b); }
+static inline int gsz(size_t n) { size_t b = (n + 255) / 256; return (int)std::min<size_t>(std::max<size_t>(b, 1), 4096); }
+
+// ------------------------------------------------------------------------------------------------
+struct Pattern {
+  std::vector<std::vector<int>> rows;  // original order
+  std::vector<int> perm, rowpos, slice_off, slice_len, colidx, diag_perm;
+  long n_slots = 0;
+  int n_slices = 0;
+  int lookup(int vi, int vj) const {
+    const auto& r = rows[vi];
+    auto it = std::lower_bound(r.begin(), r.end(), vj);
+    if (it == r.end() || *it != vj) return -1;
+    const int k = (int)(it - r.begin());
+    const int p = rowpos[vi], s = p >> 6, lane = p & 63;
+    return (int)(((long)slice_off[s] + 64L * k) * 9 + lane);
+  }
+};
+
+static void build_pattern(int NV, const std::vector<std::vector<int>>& cliques, Pattern& P) {
+  P.rows.assign(NV, {});
+  for (int i = 0; i < NV; i++) P.rows[i].push_back(i);
+  for (const auto& c : cliques)
+    for (int a : c)
+      for (int b : c) P.rows[a].push_back(b);
+  for (auto& r : P.rows) { std::sort(r.begin(), r.end()); r.erase(std::unique(r.begin(), r.end()), r.end()); }
+  P.perm.resize(NV);
+  for (int i = 0; i < NV; i++) P.perm[i] = i;
+  std::stable_sort(P.perm.begin(), P.perm.end(), [&](int a, int b) { return P.rows[a].size() > P.rows[b].size(); });
+  P.rowpos.resize(NV);
+  for (int p = 0; p < NV; p++) P.rowpos[P.perm[p]] = p;
+  P.n_slices = (NV + 63) / 64;
+  P.slice_off.assign(P.n_slices + 1, 0);
+  P.slice_len.assign(P.n_slices, 0);
+  long off = 0;
+  for (int s = 0; s < P.n_slices; s++) {
+    int len = 0;
+    for (int l = 0; l < 64 && s * 64 + l < NV; l++) len = std::max(len, (int)P.rows[P.perm[s * 64 + l]].size());
+    P.slice_len[s] = len;
+    P.slice_off[s] = (int)off;
+    off += 64L * len;
+  }
+  P.slice_off[P.n_slices] = (int)off;
+  P.n_slots = off;
+  P.colidx.assign(off, 0);
+  P.diag_perm.assign(NV, 0);
+  for (int p = 0; p < NV; p++) {
+    const int v = P.perm[p], s = p >> 6, lane = p & 63;
+    const auto& r = P.rows[v];
+    // padded slots (k >= row length) hold zero blocks; their column must not be the row itself, otherwise the
+    // frozen-diagonal rule of k_mask_matrix would hit them
+    const int pad_col = (p == 0) ? (NV > 1 ? 1 : 0) : 0;
+    for (int k = 0; k < P.slice_len[s]; k++) P.colidx[P.slice_off[s] + 64 * k + lane] = (k < (int)r.size()) ? P.rowpos[r[k]] : pad_col;
+    P.diag_perm[p] = P.lookup(v, v);
+  }
+}
+
+// ------------------------------------------------------------------------------------------------
+extern "C" const char* tsl_version(void) { return "tsl-hip 0.1 gfx950 fp64"; }
+extern "C" const char* tsl_last_error(void) { return g_tsl_err.c_str(); }
+
+static ClothArgs cloth_args(tsl_ctx* c) {
+  ClothArgs A;
+  A.n_cface = c->n_cface; A.n_hinge = c->n_hinge; A.cloth = c->d_cloth.p;
+  A.f2v = c->cf_f2v.p; A.cf = c->cf_cf.p; A.cp = c->cf_cp.p; A.cid = c->cf_cloth.p;
+  A.V = c->cf_V.p; A.li = c->cf_li.p; A.hg_info = c->hg_info.p; A.hg_v = c->hg_v.p; A.norm_dir = c->norm_dir.p;
+  return A;
+}
+static VertArgs vert_args(tsl_ctx* c) {
+  VertArgs A;
+  A.NV = c->NV; A.mass = c->mass.p; A.grav = c->grav.p; A.fext = c->fext.p; A.dt = c->dt;
+  return A;
+}
+static TetArgs tet_args(tsl_ctx* c) {
+  TetArgs A;
+  A.n_tet = c->n_tet; A.el = c->d_el.p; A.tv = c->tet_v.p; A.tel = c->tet_el.p; A.B = c->tet_B.p; A.W = c->tet_W.p;
+  return A;
+}
+static ContactArgs contact_args(tsl_ctx* c) {
+  ContactArgs A;
+  A.idx = c->c_idx.p; A.w = c->c_w.p; A.n = c->c_n.p; A.dx0 = c->c_dx0.p; A.k = c->c_k.p; A.mu = c->c_mu.p; A.T = c->c_T.p;
+  A.k_contact = c->k_contact; A.eps_contact = c->eps_contact; A.eps_vh = c->eps_v * c->dt;
+  return A;
+}
+
+static int upload_frozen(tsl_ctx* c) {
+  TSL_TRY(c->frozen.upload(c->h_frozen));
+  std::vector<unsigned char> fz(c->NV);
+  std::vector<double> md(c->NV);
+  for (int p = 0; p < c->NV; p++) {
+    const int v = c->h_perm[p];
+    fz[p] = (unsigned char)((c->h_frozen[3 * v] ? 1 : 0) | (c->h_frozen[3 * v + 1] ? 2 : 0) | (c->h_frozen[3 * v + 2] ? 4 : 0));
+    md[p] = c->h_mass[v] / (c->dt * c->dt);
+  }
+  TSL_TRY(c->fzmask.upload(fz));
+  TSL_TRY(c->mdt2.upload(md));
+  return 0;
+}
+
+extern "C" int tsl_ctx_create(const tsl_scene_desc* d, tsl_ctx** out) {
+  if (!d || !out) return tsl_fail("tsl_ctx_create: null argument");
+  int ndev = 0;
+  if (hipGetDeviceCount(&ndev) != hipSuccess || ndev == 0) return tsl_fail("tsl_ctx_create: no HIP device (this engine has no CPU path)");
+  tsl_ctx* c = new tsl_ctx();
+  c->NV = d->tot_NV; c->NF = d->tot_NF;
+  c->dt = d->dt; c->k_contact = d->k_contact; c->eps_contact = d->eps_contact; c->eps_v = d->eps_v; c->damping = d->damping;
+  c->max_n_constraints = d->max_n_constraints > 0 ? d->max_n_constraints : 10000;
+  c->grid_h = d->grid_h > 0 ? d->grid_h : 0.003;
+  const int NV = c->NV;
+  std::vector<std::vector<int>> cliques;
+
+  // ---- cloth tables (global ids)
+  std::vector<int> f2v, cf, cp, cid, hinfo, hv;
+  std::vector<double> V, li;
+  int face_start = 0;
+  for (int ci = 0; ci < d->n_cloth; ci++) {
+    const tsl_cloth_desc& cd = d->cloths[ci];
+    ClothDev cdv{face_start, cd.NF, cd.v_offset, cd.NV, cd.dx, cd.mass, cd.Kl, cd.Ka, cd.Kb, cd.k_angle};
+    c->h_cloth.push_back(cdv);
+    for (int i = 0; i < cd.NF; i++) {
+      for (int k = 0; k < 3; k++) {
+        f2v.push_back(cd.f2v_host[3 * i + k] + cd.v_offset);
+        const int nb = cd.counter_face_host[3 * i + k];
+        cf.push_back(nb < 0 ? -1 : nb + face_start);
+        cp.push_back(cd.counter_point_host[3 * i + k]);
+        li.push_back(cd.rest_len_host[3 * i + k]);
+      }
+      cid.push_back(ci);
+      V.push_back(cd.rest_area_host[i]);
+      cliques.push_back({cd.f2v_host[3 * i] + cd.v_offset, cd.f2v_host[3 * i + 1] + cd.v_offset, cd.f2v_host[3 * i + 2] + cd.v_offset});
+    }
+    for (int i = 0; i < cd.NF; i++)
+      for (int l = 0; l < 3; l++) {
+        const int nb = cd.counter_face_host[3 * i + l];
+        if (nb > i) {
+          const int p4 = cd.counter_point_host[3 * i + l];
+          const int p11 = (l + 1) % 3;
+          int p21 = (p4 + 1) % 3;
+          if (cd.f2v_host[3 * i + p11] != cd.f2v_host[3 * nb + p21]) p21 = (p4 + 2) % 3;
+          const int a = cd.f2v_host[3 * i + l] + cd.v_offset, b = cd.f2v_host[3 * i + (l + 1) % 3] + cd.v_offset;
+          const int cc = cd.f2v_host[3 * i + (l + 2) % 3] + cd.v_offset, dd = cd.f2v_host[3 * nb + p4] + cd.v_offset;
+          const int info[8] = {i + face_start, l, nb + face_start, p4, p21, 0, 0, 0};
+          hinfo.insert(hinfo.end(), info, info + 8);
+          hv.push_back(a); hv.push_back(b); hv.push_back(cc); hv.push_back(dd);
+          cliques.push_back({a, b, cc, dd});
+        }
+      }
+    face_start += cd.NF;
+  }
+  c->n_cface = face_start;
+  c->n_hinge = (int)hv.size() / 4;
+  c->h_cf_f2v = f2v; c->h_cf_cf = cf; c->h_cf_cp = cp;
+
+  // ---- tets
+  std::vector<int> tv, tel;
+  std::vector<double> tB, tW;
+  int cell_start = 0;
+  for (int ei = 0; ei < d->n_elastic; ei++) {
+    const tsl_elastic_desc& ed = d->elastics[ei];
+    ElasticDev edv{ed.kind, cell_start, ed.n_cells, ed.v_offset, ed.n_verts, ed.mu, ed.lam, ed.alpha};
+    c->h_el.push_back(edv);
+    for (int t = 0; t < ed.n_cells; t++) {
+      std::vector<int> cl;
+      for (int k = 0; k < 4; k++) { tv.push_back(ed.tets_host[4 * t + k] + ed.v_offset); cl.push_back(ed.tets_host[4 * t + k] + ed.v_offset); }
+      tel.push_back(ei);
+      for (int k = 0; k < 9; k++) tB.push_back(ed.B_host[9 * t + k]);
+      tW.push_back(ed.W_host[t]);
+      cliques.push_back(cl);
+    }
+    cell_start += ed.n_cells;
+  }
+  c->n_tet = cell_start;
+
+  // ---- matrix pattern
+  Pattern P;
+  build_pattern(NV, cliques, P);
+  c->h_rows = P.rows; c->h_perm = P.perm; c->h_rowpos = P.rowpos; c->h_slice_off = P.slice_off; c->h_slice_len = P.slice_len; c->h_colidx = P.colidx;
+  c->n_slices = P.n_slices; c->n_slots = P.n_slots;
+  c->nnzb = 0;
+  for (auto& r : P.rows) c->nnzb += (long)r.size();
+  if (P.n_slots * 9 >= (1L << 31)) { delete c; return tsl_fail("matrix too large for 32-bit slot offsets (%ld slots)", P.n_slots); }
+  std::vector<int> cfblk((size_t)c->n_cface * 9), hgblk((size_t)c->n_hinge * 16), tetblk((size_t)c->n_tet * 16), dblk(NV);
+  for (int f = 0; f < c->n_cface; f++)
+    for (int l = 0; l < 3; l++)
+      for (int m = 0; m < 3; m++) cfblk[(size_t)f * 9 + l * 3 + m] = P.lookup(f2v[3 * f + l], f2v[3 * f + m]);
+  for (int h = 0; h < c->n_hinge; h++)
+    for (int j = 0; j < 4; j++)
+      for (int k = 0; k < 4; k++) hgblk[(size_t)h * 16 + j * 4 + k] = P.lookup(hv[4 * h + j], hv[4 * h + k]);
+  for (int t = 0; t < c->n_tet; t++)
+    for (int j = 0; j < 4; j++)
+      for (int k = 0; k < 4; k++) tetblk[(size_t)t * 16 + j * 4 + k] = P.lookup(tv[4 * t + j], tv[4 * t + k]);
+  for (int v = 0; v < NV; v++) dblk[v] = P.lookup(v, v);
+
+#define UP(buf, vec) do { if (c->buf.upload(vec)) { delete c; return -1; } } while (0)
+  UP(d_cloth, c->h_cloth); UP(cf_f2v, f2v); UP(cf_cf, cf); UP(cf_cp, cp); UP(cf_cloth, cid); UP(cf_V, V); UP(cf_li, li);
+  UP(cf_blk, cfblk); UP(hg_info, hinfo); UP(hg_v, hv); UP(hg_blk, hgblk);
+  UP(d_el, c->h_el); UP(tet_v, tv); UP(tet_el, tel); UP(tet_blk, tetblk); UP(tet_B, tB); UP(tet_W, tW);
+  UP(diag_blk, dblk); UP(rowpos, P.rowpos); UP(perm, P.perm); UP(slice_off, P.slice_off); UP(slice_len, P.slice_len); UP(colidx, P.colidx);
+  UP(diag_perm, P.diag_perm);
+  c->h_mass.assign(d->mass_host, d->mass_host + NV);
+  std::vector<double> grav(d->gravity_host, d->gravity_host + 3 * (size_t)NV), fext(3 * (size_t)NV, 0.0);
+  UP(mass, c->h_mass); UP(grav, grav); UP(fext, fext);
+  c->h_frozen.assign(d->frozen_host, d->frozen_host + 3 * (size_t)NV);
+  if (upload_frozen(c)) { delete c; return -1; }
+#undef UP
+  int rc = 0;
+  rc |= c->norm_dir.alloc((size_t)std::max(c->n_cface, 1) * 3);
+  rc |= c->quirk.alloc((size_t)std::max(d->n_cloth, 1) * 90);
+  rc |= c->vals.alloc((size_t)P.n_slots * 9); rc |= c->vals_full.alloc((size_t)P.n_slots * 9);
+  rc |= c->Dinv.alloc((size_t)NV * 9);
+  const size_t n3 = (size_t)NV * 3;
+  rc |= c->v_x.alloc(n3); rc |= c->v_r.alloc(n3); rc |= c->v_z.alloc(n3); rc |= c->v_p.alloc(n3); rc |= c->v_Ap.alloc(n3); rc |= c->v_b.alloc(n3);
+  rc |= c->v_t0.alloc(n3); rc |= c->v_t1.alloc(n3); rc |= c->v_t2.alloc(n3); rc |= c->v_t3.alloc(n3); rc |= c->v_t4.alloc(n3);
+  rc |= c->F.alloc(n3); rc |= c->pdir.alloc(n3); rc |= c->x1.alloc(n3);
+  rc |= c->scal.alloc(1);
+  if (rc) { delete c; return -1; }
+  if (hipHostMalloc((void**)&c->h_scal, sizeof(SolverScalars) > sizeof(CgScal) ? sizeof(SolverScalars) : sizeof(CgScal)) != hipSuccess) { delete c; return tsl_fail("hipHostMalloc failed"); }
+  c->vals.zero(); c->vals_full.zero(); c->scal.zero();
+
+  // ---- contact tables
+  c->n_body = d->n_body; c->n_pair = d->n_pair;
+  if (d->n_body > 0) c->h_bodies.assign(d->bodies, d->bodies + d->n_body);
+  if (d->n_pair > 0) c->h_pairs.assign(d->pairs, d->pairs + d->n_pair);
+  if (contact_alloc(c, d)) { delete c; return -1; }
+  (void)hipDeviceSynchronize();
+  *out = c;
+  return 0;
+}
+
+extern "C" void tsl_ctx_destroy(tsl_ctx* c) {
+  if (!c) return;
+  (void)hipDeviceSynchronize();
+  if (c->h_scal) (void)hipHostFree(c->h_scal);
+  for (auto& e : c->ev_pool) { (void)hipEventDestroy(e.first); (void)hipEventDestroy(e.second); }
+  delete c;
+}
+
+extern "C" int tsl_set_stream(tsl_ctx* c, void* s) { c->stream = (hipStream_t)s; return 0; }
+
+extern "C" int tsl_set_param(tsl_ctx* c, const char* key, double v) {
+  std::string k(key);
+  if (k == "mu_cloth_elastic") c->mu_cloth_elastic = v;
+  else if (k == "k_contact") c->k_contact = v;
+  else if (k == "eps_contact") c->eps_contact = v;
+  else if (k == "eps_v") c->eps_v = v;
+  else if (k == "damping") c->damping = v;
+  else if (k == "cg_tol") c->cg_tol = v;
+  else if (k == "cg_maxit") c->cg_maxit = (int)v;
+  else if (k == "cg_check") c->cg_check = std::max(1, (int)v);
+  else if (k == "newton_cap") c->newton_cap = (int)v;
+  else if (k == "plastic") c->plastic = (int)v;
+  else if (k == "contact") c->contact_enable = (v != 0.0);
+  else if (k == "grid_h") c->grid_h = v;
+  else if (k.rfind("cloth", 0) == 0 && k.size() > 7) {
+    const int ci = k[5] - '0';
+    if (ci < 0 || ci >= (int)c->h_cloth.size()) return tsl_fail("tsl_set_param: bad cloth index in %s", key);
+    const std::string f = k.substr(7);
+    ClothDev& cd = c->h_cloth[ci];
+    if (f == "Kb") cd.Kb = v; else if (f == "Kl") cd.Kl = v; else if (f == "Ka") cd.Ka = v; else if (f == "k_angle") cd.k_angle = v;
+    else return tsl_fail("tsl_set_param: unknown key %s", key);
+    HIP_OK(hipMemcpy(c->d_cloth.p, c->h_cloth.data(), c->h_cloth.size() * sizeof(ClothDev), hipMemcpyHostToDevice));
+  } else return tsl_fail("tsl_set_param: unknown key %s", key);
+  return 0;
+}
+
+extern "C" int tsl_set_frozen(tsl_ctx* c, const int32_t* fr) {
+  c->h_frozen.assign(fr, fr + 3 * (size_t)c->NV);
+  return upload_frozen(c);
+}
+extern "C" int tsl_set_ext_force(tsl_ctx* c, const double* f) {
+  HIP_OK(hipMemcpy(c->fext.p, f, 3 * (size_t)c->NV * sizeof(double), hipMemcpyHostToDevice));
+  return 0;
+}
+extern "C" int tsl_set_gravity(tsl_ctx* c, const double* g) {
+  HIP_OK(hipMemcpy(c->grav.p, g, 3 * (size_t)c->NV * sizeof(double), hipMemcpyHostToDevice));
+  return 0;
+}
+
+// ------------------------------------------------------------------------------------------------
+__global__ void k_energy(VertArgs VA, ClothArgs CA, TetArgs TA, const double* __restrict__ pos, const double* __restrict__ prev,
+                         const double* __restrict__ vel, const double* __restrict__ ref_angle, double* e_out) {
+  const int t = blockIdx.x * blockDim.x + threadIdx.x;
+  double e = 0;
+  if (t < VA.NV) e += vert_energy(VA, t, pos, prev, vel);
+  if (t < CA.n_cface) {
+    int v[3]; d3 P[3];
+    load_face(pos, CA.f2v, t, v, P);
+    const double li[3] = {CA.li[3 * t], CA.li[3 * t + 1], CA.li[3 * t + 2]};
+    e += cface_energy(CA.cloth[CA.cid[t]], P, CA.V[t], li);
+  }
+  if (t < CA.n_hinge) e += hinge_energy(CA, t, pos, ref_angle);
+  if (t < TA.n_tet) e += tet_energy(TA, t, pos);
+  e = wave_sum(e);
+  if ((threadIdx.x & 63) == 0) atomicAdd(e_out, e);
+}
+
+static CgScal* SC(tsl_ctx* c) { return (CgScal*)c->scal.p; }
+static CgScal* HSC(tsl_ctx* c) { return (CgScal*)c->h_scal; }
+
+static int energy_async(tsl_ctx* c, const double* pos, const double* prev, const double* vel, const double* ref) {
+  hipStream_t s = c->stream;
+  HIP_OK(hipMemsetAsync(&SC(c)->energy, 0, sizeof(double), s));
+  if (c->n_cface) hipLaunchKernelGGL(k_cloth_normals, dim3(nblk(c->n_cface, 256)), dim3(256), 0, s, c->n_cface, pos, c->cf_f2v.p, c->norm_dir.p);
+  const int nmax = std::max(std::max(c->NV, c->n_cface), std::max(c->n_hinge, c->n_tet));
+  hipLaunchKernelGGL(k_energy, dim3(nblk(nmax, 256)), dim3(256), 0, s, vert_args(c), cloth_args(c), tet_args(c), pos, prev, vel, ref, &SC(c)->energy);
+  if (c->nc > 0) hipLaunchKernelGGL(k_contact_energy, dim3(nblk(c->nc, 64)), dim3(64), 0, s, c->nc, contact_args(c), pos, &SC(c)->energy);
+  return 0;
+}
+static int energy_sync(tsl_ctx* c, const double* pos, const double* prev, const double* vel, const double* ref, double* E) {
+  TSL_TRY(energy_async(c, pos, prev, vel, ref));
+  HIP_OK(hipMemcpyAsync(&HSC(c)->energy, &SC(c)->energy, sizeof(double), hipMemcpyDeviceToHost, c->stream));
+  HIP_OK(hipStreamSynchronize(c->stream));
+  *E = HSC(c)->energy;
+  return 0;
+}
+
+extern "C" int tsl_energy(tsl_ctx* c, const double* pos, const double* prev, const double* vel, const double* ref, double* E) {
+  return energy_sync(c, pos, prev, vel, ref, E);
+}
+
+static int assemble(tsl_ctx* c, const double* pos, const double* prev, const double* vel, const double* ref, int spd, double* grad) {
+  hipStream_t s = c->stream;
+  const int NV = c->NV;
+  HIP_OK(hipMemsetAsync(c->vals_full.p, 0, c->vals_full.n * sizeof(double), s));
+  if (c->n_cface) hipLaunchKernelGGL(k_cloth_normals, dim3(nblk(c->n_cface, 256)), dim3(256), 0, s, c->n_cface, pos, c->cf_f2v.p, c->norm_dir.p);
+  const ClothArgs CA = cloth_args(c);
+  const VertArgs VA = vert_args(c);
+  const TetArgs TA = tet_args(c);
+  if (grad) {
+    HIP_OK(hipMemsetAsync(grad, 0, 3 * (size_t)NV * sizeof(double), s));
+    hipLaunchKernelGGL(k_vert_grad, dim3(nblk(NV, 256)), dim3(256), 0, s, VA, pos, prev, vel, grad);
+    if (c->n_cface) hipLaunchKernelGGL(k_cloth_grad_face, dim3(nblk(c->n_cface, 256)), dim3(256), 0, s, CA, pos, grad);
+    if (c->n_hinge) hipLaunchKernelGGL(k_cloth_grad_hinge, dim3(nblk(c->n_hinge, 256)), dim3(256), 0, s, CA, pos, ref, grad);
+    if (c->n_tet) hipLaunchKernelGGL(k_tet_grad, dim3(nblk(c->n_tet, 256)), dim3(256), 0, s, TA, pos, grad);
+  }
+  hipLaunchKernelGGL(k_vert_hess, dim3(nblk(NV, 256)), dim3(256), 0, s, VA, c->diag_blk.p, c->vals_full.p);
+  if (c->n_cface) {
+    const int nq = (int)c->h_cloth.size() * 9;
+    hipLaunchKernelGGL(k_cloth_quirk, dim3(nblk(nq, 64)), dim3(64), 0, s, CA, (int)c->h_cloth.size(), pos, ref, c->quirk.p);
+    hipLaunchKernelGGL(k_cloth_hess_face, dim3(nblk(c->n_cface, 128)), dim3(128), 0, s, CA, c->cf_blk.p, pos, ref, c->quirk.p, spd, c->vals_full.p);
+  }
+  if (c->n_hinge) hipLaunchKernelGGL(k_cloth_hess_hinge, dim3(nblk(c->n_hinge, 256)), dim3(256), 0, s, CA, c->hg_blk.p, pos, c->vals_full.p);
+  if (c->n_tet) hipLaunchKernelGGL(k_tet_hess, dim3(nblk(c->n_tet, 64)), dim3(64), 0, s, TA, c->tet_blk.p, pos, spd, c->vals_full.p);
+  // contact: gradient into grad, per-constraint 12x12 into c_Hfull, masked copy + diagonal into c_H / cdiag
+  TSL_TRY(contact_assemble(c, pos, spd, grad));
+  if (grad) hipLaunchKernelGGL(k_mask_vec, dim3(gsz(3 * (size_t)NV)), dim3(256), 0, s, 3 * (size_t)NV, c->frozen.p, grad);
+  hipLaunchKernelGGL(k_mask_matrix, dim3(c->n_slices), dim3(256), 0, s, c->n_slices, c->slice_off.p, c->slice_len.p, c->colidx.p, c->fzmask.p, c->mdt2.p,
+                     c->vals_full.p, c->vals.p, NV);
+  hipLaunchKernelGGL(k_block_jacobi, dim3(nblk(NV, 256)), dim3(256), 0, s, NV, c->diag_perm.p, c->vals.p, c->nc > 0 ? c->c_diag.p : (const double*)nullptr, c->Dinv.p);
+  HIP_OK(hipGetLastError());
+  return 0;
+}
+
+extern "C" int tsl_assemble(tsl_ctx* c, const double* pos, const double* prev, const double* vel, const double* ref, int spd, double* grad) {
+  return assemble(c, pos, prev, vel, ref, spd, grad);
+}
+
+// ------------------------------------------------------------------------------------------------
+// y = H x in permuted space (matrix + matrix-free contact blocks); optional fused dot into pAp[slot]
+static void launch_spmv(tsl_ctx* c, const double* vals, const double* x, double* y, int slot, int check_flag, bool full_contact = false) {
+  hipStream_t s = c->stream;
+  const bool sample = c->prof_enable && slot >= 0 && (c->prof_launches % 16 == 0) && c->ev_used < c->ev_pool.size();
+  if (sample) (void)hipEventRecord(c->ev_pool[c->ev_used].first, s);
+  hipLaunchKernelGGL(k_spmv, dim3(nblk((long)c->n_slices * 64, 256)), dim3(256), 0, s, c->NV, c->n_slices, c->slice_off.p, c->slice_len.p, c->colidx.p, vals, x, y,
+                     SC(c), slot, check_flag);
+  if (sample) { (void)hipEventRecord(c->ev_pool[c->ev_used].second, s); c->ev_used++; }
+  if (slot >= 0) c->prof_launches++;
+  if (c->nc > 0)
+    hipLaunchKernelGGL(k_contact_matvec, dim3(nblk(c->nc, 64)), dim3(64), 0, s, c->nc, c->c_idx.p, c->rowpos.p, full_contact ? c->c_Hfull.p : c->c_H.p, x, y, SC(c), slot,
+                       check_flag);
+}
+
+static void prof_collect(tsl_ctx* c) {
+  for (size_t i = 0; i < c->ev_used; i++) {
+    float ms = 0;
+    if (hipEventElapsedTime(&ms, c->ev_pool[i].first, c->ev_pool[i].second) == hipSuccess) { c->prof_ms += ms; c->prof_samples++; }
+  }
+  c->ev_used = 0;
+}
+
+static int read_scal(tsl_ctx* c) {
+  HIP_OK(hipMemcpyAsync(c->h_scal, c->scal.p, sizeof(CgScal), hipMemcpyDeviceToHost, c->stream));
+  HIP_OK(hipStreamSynchronize(c->stream));
+  if (c->prof_enable) prof_collect(c);
+  return 0;
+}
+
+static int bicgstab(tsl_ctx* c, tsl_solve_stats* st);
+
+// Solve with rhs already in v_b (permuted); result in v_x (permuted).
+static int solve_perm(tsl_ctx* c, tsl_solve_stats* st) {
+  hipStream_t s = c->stream;
+  const int NV = c->NV;
+  const size_t n3 = 3 * (size_t)NV;
+  const int gb = nblk(NV, 256);
+  st->iters = 0; st->restarts = 0; st->flag = 0; st->rel_residual = 0;
+  HIP_OK(hipMemsetAsync(c->v_x.p, 0, n3 * sizeof(double), s));
+  HIP_OK(hipMemsetAsync(c->scal.p, 0, sizeof(CgScal), s));
+  hipLaunchKernelGGL(k_dot, dim3(gsz(n3)), dim3(256), 0, s, n3, c->v_b.p, c->v_b.p, &SC(c)->bb);
+  TSL_TRY(read_scal(c));
+  const double bb = HSC(c)->bb;
+  if (!(bb > 0)) return 0;  // zero rhs -> x = 0
+  const double tol2 = c->cg_tol * c->cg_tol * bb;
+  bool need_fallback = false;
+  int total_it = 0;
+  for (int outer = 0; outer < 20; outer++) {
+    // true residual, restart vectors
+    CgScal hs;
+    memset(&hs, 0, sizeof(hs));
+    hs.bb = bb; hs.thresh2 = 0.25 * tol2;
+    HIP_OK(hipMemcpyAsync(c->scal.p, &hs, sizeof(CgScal), hipMemcpyHostToDevice, s));
+    if (outer > 0) launch_spmv(c, c->vals.p, c->v_x.p, c->v_Ap.p, -1, 0);
+    hipLaunchKernelGGL(k_cg_init, dim3(gb), dim3(256), 0, s, NV, c->v_b.p, outer > 0 ? c->v_Ap.p : (const double*)nullptr, c->Dinv.p, c->v_r.p, c->v_z.p, c->v_p.p, SC(c));
+    TSL_TRY(read_scal(c));
+    const double rr0 = HSC(c)->rr[3];
+    st->rel_residual = sqrt(rr0 / bb);
+    if (rr0 <= tol2) { need_fallback = false; break; }
+    if (!(HSC(c)->rzn[3] > 0)) { need_fallback = true; break; }
+    if (outer > 0) st->restarts++;
+    need_fallback = true;
+    int flag = 0;
+    while (total_it < c->cg_maxit) {
+      const int chunk = std::min(c->cg_check, c->cg_maxit - total_it);
+      for (int i = 0; i < chunk; i++, total_it++) {
+        const int slot = total_it & 3;
+        launch_spmv(c, c->vals.p, c->v_p.p, c->v_Ap.p, slot, 1);
+        hipLaunchKernelGGL(k_cg_update, dim3(gb), dim3(256), 0, s, NV, c->v_p.p, c->v_Ap.p, c->Dinv.p, c->v_x.p, c->v_r.p, c->v_z.p, SC(c), slot);
+        hipLaunchKernelGGL(k_cg_p, dim3(gb), dim3(256), 0, s, NV, c->v_z.p, c->v_p.p, SC(c), slot, total_it);
+      }
+      TSL_TRY(read_scal(c));
+      flag = HSC(c)->flag;
+      if (flag) break;
+    }
+    // NOTE: slot bookkeeping restarts at 0 on every outer pass because k_cg_init rewrites slot 3 and the host
+    // clears the record; keep total_it aligned to a multiple of 4
+    if (flag == 2) st->iters += HSC(c)->iters - (st->iters); else st->iters = total_it;
+    total_it = (total_it + 3) & ~3;
+    if (flag == 1 || flag == 0) break;  // breakdown or iteration cap
+  }
+  st->iters = total_it;
+  if (!need_fallback) { st->flag = 0; return 0; }
+  return bicgstab(c, st);
+}
+
+// Block-Jacobi BiCGStab on H (used when PCG breaks down: un-projected adjoint Hessians can be indefinite)
+static int bicgstab(tsl_ctx* c, tsl_solve_stats* st) {
+  hipStream_t s = c->stream;
+  const int NV = c->NV;
+  const size_t n3 = 3 * (size_t)NV;
+  const int gb = nblk(NV, 256), gv = gsz(n3);
+  double *x = c->v_x.p, *r = c->v_r.p, *r0 = c->v_t0.p, *p = c->v_p.p, *v = c->v_Ap.p, *sv = c->v_t1.p, *t = c->v_t2.p, *ph = c->v_z.p, *sh = c->v_t3.p;
+  HIP_OK(hipMemsetAsync(x, 0, n3 * sizeof(double), s));
+  HIP_OK(hipMemcpyAsync(r, c->v_b.p, n3 * sizeof(double), hipMemcpyDeviceToDevice, s));
+  HIP_OK(hipMemcpyAsync(r0, c->v_b.p, n3 * sizeof(double), hipMemcpyDeviceToDevice, s));
+  HIP_OK(hipMemsetAsync(p, 0, n3 * sizeof(double), s));
+  HIP_OK(hipMemsetAsync(v, 0, n3 * sizeof(double), s));
+  CgScal* d = SC(c);
+  CgScal* h = HSC(c);
+  auto dots = [&](const double* a1, const double* b1, const double* a2, const double* b2, double* o1, double* o2) -> int {
+    HIP_OK(hipMemsetAsync(&d->aux[0], 0, 2 * sizeof(double), s));
+    hipLaunchKernelGGL(k_dot, dim3(gv), dim3(256), 0, s, n3, a1, b1, &d->aux[0]);
+    if (a2) hipLaunchKernelGGL(k_dot, dim3(gv), dim3(256), 0, s, n3, a2, b2, &d->aux[1]);
+    HIP_OK(hipMemcpyAsync(&h->aux[0], &d->aux[0], 2 * sizeof(double), hipMemcpyDeviceToHost, s));
+    HIP_OK(hipStreamSynchronize(s));
+    *o1 = h->aux[0];
+    if (o2) *o2 = h->aux[1];
+    return 0;
+  };
+  double bb;
+  TSL_TRY(dots(c->v_b.p, c->v_b.p, nullptr, nullptr, &bb, nullptr));
+  double rho = 1, alpha = 1, omega = 1;
+  const double tol2 = c->cg_tol * c->cg_tol * bb;
+  st->flag = 3;
+  for (int it = 0; it < c->cg_maxit; it++) {
+    double rho_new;
+    TSL_TRY(dots(r0, r, nullptr, nullptr, &rho_new, nullptr));
+    if (rho_new == 0 || omega == 0) break;
+    const double beta = (rho_new / rho) * (alpha / omega);
+    rho = rho_new;
+    // p = r + beta (p - omega v)
+    hipLaunchKernelGGL(k_axpby, dim3(gv), dim3(256), 0, s, n3, -omega, v, 1.0, p);
+    hipLaunchKernelGGL(k_axpby, dim3(gv), dim3(256), 0, s, n3, 1.0, r, beta, p);
+    hipLaunchKernelGGL(k_precond, dim3(gb), dim3(256), 0, s, NV, c->Dinv.p, p, ph);
+    launch_spmv(c, c->vals.p, ph, v, -1, 0);
+    double r0v;
+    TSL_TRY(dots(r0, v, nullptr, nullptr, &r0v, nullptr));
+    if (r0v == 0) break;
+    alpha = rho / r0v;
+    // s = r - alpha v
+    HIP_OK(hipMemcpyAsync(sv, r, n3 * sizeof(double), hipMemcpyDeviceToDevice, s));
+    hipLaunchKernelGGL(k_axpby, dim3(gv), dim3(256), 0, s, n3, -alpha, v, 1.0, sv);
+    hipLaunchKernelGGL(k_precond, dim3(gb), dim3(256), 0, s, NV, c->Dinv.p, sv, sh);
+    launch_spmv(c, c->vals.p, sh, t, -1, 0);
+    double tt, ts;
+    TSL_TRY(dots(t, t, t, sv, &tt, &ts));
+    omega = tt > 0 ? ts / tt : 0;
+    hipLaunchKernelGGL(k_axpby, dim3(gv), dim3(256), 0, s, n3, alpha, ph, 1.0, x);
+    hipLaunchKernelGGL(k_axpby, dim3(gv), dim3(256), 0, s, n3, omega, sh, 1.0, x);
+    HIP_OK(hipMemcpyAsync(r, sv, n3 * sizeof(double), hipMemcpyDeviceToDevice, s));
+    hipLaunchKernelGGL(k_axpby, dim3(gv), dim3(256), 0, s, n3, -omega, t, 1.0, r);
+    st->iters += 2;
+    double rr;
+    TSL_TRY(dots(r, r, nullptr, nullptr, &rr, nullptr));
+    st->rel_residual = sqrt(rr / bb);
+    if (rr <= 0.25 * tol2) {
+      // verify with the true residual
+      launch_spmv(c, c->vals.p, x, t, -1, 0);
+      HIP_OK(hipMemcpyAsync(sv, c->v_b.p, n3 * sizeof(double), hipMemcpyDeviceToDevice, s));
+      hipLaunchKernelGGL(k_axpby, dim3(gv), dim3(256), 0, s, n3, -1.0, t, 1.0, sv);
+      double tr;
+      TSL_TRY(dots(sv, sv, nullptr, nullptr, &tr, nullptr));
+      st->rel_residual = sqrt(tr / bb);
+      if (tr <= 100 * tol2) { st->flag = 1; break; }
+      HIP_OK(hipMemcpyAsync(r, sv, n3 * sizeof(double), hipMemcpyDeviceToDevice, s));
+    }
+  }
+  return 0;
+}
+
+static int solve_orig(tsl_ctx* c, const double* rhs, double* x, tsl_solve_stats* st) {
+  hipStream_t s = c->stream;
+  const int gb = nblk(c->NV, 256);
+  hipLaunchKernelGGL(k_gather_perm, dim3(gb), dim3(256), 0, s, c->NV, c->perm.p, rhs, c->v_b.p);
+  tsl_solve_stats local;
+  if (!st) st = &local;
+  TSL_TRY(solve_perm(c, st));
+  hipLaunchKernelGGL(k_scatter_perm, dim3(gb), dim3(256), 0, s, c->NV, c->perm.p, c->v_x.p, x);
+  HIP_OK(hipGetLastError());
+  return 0;
+}
+
+extern "C" int tsl_solve(tsl_ctx* c, const double* rhs, double* x, tsl_solve_stats* st) {
+  TSL_TRY(solve_orig(c, rhs, x, st));
+  HIP_OK(hipStreamSynchronize(c->stream));
+  return 0;
+}
+
+// ------------------------------------------------------------------------------------------------
+extern "C" int tsl_update_ref_angle(tsl_ctx* c, const double* pos, double* ref) {
+  if (!c->n_hinge) return 0;
+  hipStream_t s = c->stream;
+  hipLaunchKernelGGL(k_cloth_normals, dim3(nblk(c->n_cface, 256)), dim3(256), 0, s, c->n_cface, pos, c->cf_f2v.p, c->norm_dir.p);
+  hipLaunchKernelGGL(k_cloth_update_ref, dim3(nblk(c->n_hinge, 256)), dim3(256), 0, s, cloth_args(c), pos, ref);
+  HIP_OK(hipGetLastError());
+  return 0;
+}
+
+extern "C" int tsl_step(tsl_ctx* c, double* pos, double* prev, double* vel, double* ref, tsl_step_stats* stats) {
+  hipStream_t s = c->stream;
+  const size_t n3 = 3 * (size_t)c->NV;
+  tsl_step_stats st;
+  memset(&st, 0, sizeof(st));
+  // timestep_init: prev_pos <- pos (BaseScene.py:1291-1303)
+  HIP_OK(hipMemcpyAsync(prev, pos, n3 * sizeof(double), hipMemcpyDeviceToDevice, s));
+  // calc_vn + projection_query + contact_analysis
+  int nc = 0;
+  if (c->contact_enable) TSL_TRY(tsl_contact_detect(c, pos, prev, &nc));
+  else c->nc = 0;
+  st.nc = nc;
+  int iter = 0;
+  double delta = 1e5;
+  while (iter < c->newton_cap) {
+    iter++;
+    double E0;
+    TSL_TRY(energy_sync(c, pos, prev, vel, ref, &E0));
+    TSL_TRY(assemble(c, pos, prev, vel, ref, 1, c->F.p));
+    tsl_solve_stats ss;
+    TSL_TRY(solve_orig(c, c->F.p, c->pdir.p, &ss));
+    st.cg_iters += ss.iters; st.solves++; st.restarts += ss.restarts; st.fallback += (ss.flag != 0);
+    // p_norm = max |p|  (calc_p_norm :1096-1103)
+    HIP_OK(hipMemsetAsync(&SC(c)->pmax, 0, sizeof(double), s));
+    hipLaunchKernelGGL(k_absmax, dim3(gsz(n3)), dim3(256), 0, s, n3, c->pdir.p, &SC(c)->pmax);
+    HIP_OK(hipMemcpyAsync(c->x1.p, pos, n3 * sizeof(double), hipMemcpyDeviceToDevice, s));
+    double alpha = 1.0, E = 0;
+    while (alpha > 1e-8) {
+      hipLaunchKernelGGL(k_linesearch, dim3(gsz(n3)), dim3(256), 0, s, n3, c->x1.p, c->pdir.p, alpha, pos);
+      TSL_TRY(energy_sync(c, pos, prev, vel, ref, &E));
+      st.ls_evals++;
+      if (E < E0) break;
+      alpha /= 2;
+    }
+    HIP_OK(hipMemcpyAsync(&HSC(c)->pmax, &SC(c)->pmax, sizeof(double), hipMemcpyDeviceToHost, s));
+    HIP_OK(hipStreamSynchronize(s));
+    delta = HSC(c)->pmax / c->dt;
+    st.last_alpha = alpha; st.energy = E;
+    if (delta < 1e-7) break;
+  }
+  st.newton_iters = iter; st.last_delta = delta;
+  // timestep_finish: update_vel (+ plastic update_ref_angle, Scene_folding.py:227-231)
+  hipLaunchKernelGGL(k_update_vel, dim3(gsz(n3)), dim3(256), 0, s, n3, pos, prev, c->damping / c->dt, vel);
+  if (c->plastic) TSL_TRY(tsl_update_ref_angle(c, pos, ref));
+  HIP_OK(hipStreamSynchronize(s));
+  HIP_OK(hipGetLastError());
+  if (stats) *stats = st;
+  return 0;
+}
+
+// ------------------------------------------------------------------------------------------------
+extern "C" int tsl_matrix_nnzb(tsl_ctx* c, int32_t* nb, int32_t* nnzb) {
+  *nb = c->NV; *nnzb = (int32_t)c->nnzb;
+  return 0;
+}
+
+// masked system matrix (what tsl_solve inverts) + the matrix-free contact blocks, as BSR in the original ordering
+extern "C" int tsl_matrix_export(tsl_ctx* c, int32_t* row_ptr, int32_t* col, double* vals) {
+  HIP_OK(hipStreamSynchronize(c->stream));
+  std::vector<double> hv(c->vals.n);
+  HIP_OK(hipMemcpy(hv.data(), c->vals.p, hv.size() * sizeof(double), hipMemcpyDeviceToHost));
+  long k = 0;
+  row_ptr[0] = 0;
+  for (int v = 0; v < c->NV; v++) {
+    const auto& r = c->h_rows[v];
+    const int p = c->h_rowpos[v], s = p >> 6, lane = p & 63;
+    for (size_t j = 0; j < r.size(); j++, k++) {
+      col[k] = r[j];
+      const size_t base = ((size_t)c->h_slice_off[s] + 64 * j) * 9 + lane;
+      for (int e = 0; e < 9; e++) vals[9 * k + e] = hv[base + 64 * e];
+    }
+    row_ptr[v + 1] = (int32_t)k;
+  }
+  return 0;
+}
+
+extern "C" int tsl_profile_reset(tsl_ctx* c, int enable) {
+  c->prof_enable = enable; c->prof_ms = 0; c->prof_launches = 0; c->prof_samples = 0; c->ev_used = 0;
+  if (enable && c->ev_pool.empty()) {
+    for (int i = 0; i < 64; i++) {
+      hipEvent_t a, b;
+      HIP_OK(hipEventCreate(&a)); HIP_OK(hipEventCreate(&b));
+      c->ev_pool.push_back({a, b});
+    }
+  }
+  return 0;
+}
+
+extern "C" int tsl_profile_read(tsl_ctx* c, double* ms_per_launch, int64_t* launches, int64_t* bytes_per_launch) {
+  HIP_OK(hipStreamSynchronize(c->stream));
+  prof_collect(c);
+  *ms_per_launch = c->prof_samples ? c->prof_ms / c->prof_samples : 0.0;
+  *launches = c->prof_launches;
+  // algorithmic bytes of one SpMV: every stored block (72 B values + 4 B column id) + x gather + y store per row
+  *bytes_per_launch = (int64_t)c->nnzb * 76 + (int64_t)c->NV * (24 + 24);
+  return 0;
+}
+
+extern "C" int tsl_spd_project(tsl_ctx* c, double* blocks, int32_t n, int32_t D) {
+  if (D != 2 && D != 3 && D != 9) return tsl_fail("tsl_spd_project: D must be 2, 3 or 9");
+  hipLaunchKernelGGL(k_spd_batch, dim3(nblk(n, 64)), dim3(64), 0, c->stream, blocks, n, D);
+  HIP_OK(hipStreamSynchronize(c->stream));
+  return 0;
+}
+
+extern "C" int tsl_adjoint_step(tsl_ctx* c, int step, int T, const double* pos_buffer, double* pos_grad, const double* ref_buffer, double* angleref_grad,
+                                double* tmp_z_frozen, double adj_damping, tsl_solve_stats* st) {
+  return tsl_fail("tsl_adjoint_step: not implemented yet");
+}
