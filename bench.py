@@ -1,0 +1,177 @@
+#!/usr/bin/env python
+"""Headline benchmark: element-steps/s (fwd+adjoint) of the implicit thin-shell step on MI355X.
+
+    python bench.py --gpus N --steps K --warmup W          (N > 1: launched by torch.distributed.run)
+
+One "step" = one implicit-Euler time step of the workload scene (contact detection, Newton loop with PCG solves
+and line search, velocity / plastic update: BaseScene.time_step) PLUS its reverse-mode adjoint step
+(Grad.transfer_grad: un-projected Hessian, one linear solve, back-propagation kernels).  The timed region runs
+K forward steps onto the tape and then the K adjoint steps of the same rollout, all state resident in HBM.
+value = cloth triangles x K x n_gpus / wall seconds (max over ranks).  Ranks run independent scene rollouts
+(trajectory-optimisation batch): no data-path collective, "scaling": "weak".
+
+The JSON line also carries
+  roofline     -- dominant kernel (the SELL-64 block SpMV of one PCG iteration): algorithmic bytes per launch /
+                  average launch duration measured with HIP events on the engine's stream, against 8 TB/s HBM;
+  cpu_baseline -- the fp64 CPU restatement (oracle/, "port": the reference itself needs taichi + cupy/CUDA and
+                  cannot run) timed on this box's host cores on a bounded sample of the same workload.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+
+HBM_PEAK_GBS = 8000.0  # /opt/skills/guides/MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
+
+
+def build_scene(args, rank):
+    from thinshelllab_amd.task_scene.Scene_drape import Scene
+    s = Scene(cloth_size=args.cloth_size, N=args.grid, M=args.grid, Kb=100.0, k_angle=3.14, perturb=1e-4 * (1 + 0.01 * rank), device="cuda:0",
+              newton_cap=50)
+    s.init_all()
+    return s
+
+
+def run_rollout(scene, grad, K, timed=True):
+    """K forward steps onto the tape, loss seed on the last state, K adjoint steps."""
+    stats = dict(newton=0, cg_fwd=0, ls=0, cg_adj=0, fallback=0)
+    grad.copy_pos(scene, 0)
+    for f in range(1, K + 1):
+        st = scene.time_step(None, f)
+        grad.copy_pos(scene, f)
+        stats["newton"] += st["newton_iters"]; stats["cg_fwd"] += st["cg_iters"]; stats["ls"] += st["ls_evals"]; stats["fallback"] += st["fallback"]
+    c = scene.cloths[0]
+    grad.pos_grad.t.zero_(); grad.angleref_grad.t.zero_()
+    grad.pos_grad.t[K, c.offset:c.offset + c.NV, 2] = 1.0  # dL/dx_K: lift the cloth (sum of z)
+    for s in range(K, 0, -1):
+        grad.transfer_grad(s, scene, None)
+        stats["cg_adj"] += grad.last_stats["iters"]; stats["fallback"] += int(grad.last_stats["flag"] != 0)
+    return stats
+
+
+def cpu_baseline(args, gpu_stats, K):
+    """Oracle timed on a bounded sample: one energy evaluation, one gradient+Hessian assembly and a fixed number
+    of PCG iterations on the SAME mesh and state, scaled by the iteration counts the GPU run needed (the CPU
+    restatement runs the same algorithm; a full 100k-triangle step takes minutes on the host)."""
+    from oracle import pyoracle as po
+    cores = os.cpu_count() or 1
+    po.set_threads(cores)
+    N = args.grid
+    o = po.OracleScene(dt=5e-3, newton_cap=50)
+    ci = o.add_cloth(N, N, args.cloth_size)
+    o.cloth_init(ci, 0, 0, 0)
+    o.finalize()
+    import numpy as np
+    i, j = np.meshgrid(np.arange(N + 1), np.arange(N + 1), indexing="ij")
+    o.pos[:, 2] = (1e-4 * np.sin(7.0 * i) * np.cos(5.0 * j)).reshape(-1)
+    o.prev_pos[:] = o.pos
+    fr = o.frozen.reshape(-1, 3); fr[N * (N + 1):] = 1
+    o.push_down_all()
+    t0 = time.time(); o.newton_step_init(); o.compute_energy(); t_e = time.time() - t0
+    t0 = time.time(); o.compute_residual_and_Hessian(True); t_asm = time.time() - t0
+    n_it = args.cpu_cg_iters
+    o.set_solver(1e-30, n_it)
+    b = o.arr("F").copy()
+    t0 = time.time(); o.solve(b); t_cg = (time.time() - t0)
+    it_done = max(o.stats()["cg"], 1)
+    t_it = t_cg / it_done
+    n_asm = gpu_stats["newton"] + K          # forward assemblies + one per adjoint step
+    n_e = gpu_stats["newton"] + gpu_stats["ls"]
+    n_cg = gpu_stats["cg_fwd"] + gpu_stats["cg_adj"]
+    t_total = n_asm * t_asm + n_e * t_e + n_cg * t_it
+    T = 2 * N * N
+    return {"value": T * K / t_total, "unit": "element-steps/s", "cores": cores, "kind": "port",
+            "sample": f"oracle on the same {N}x{N} cloth: 1 energy ({t_e:.3f}s) + 1 assembly ({t_asm:.3f}s) + {it_done} PCG iterations "
+                      f"({t_it * 1e3:.2f} ms each), scaled by the GPU run's counts ({n_asm} assemblies, {n_e} energies, {n_cg} PCG iterations)"}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=3)
+    ap.add_argument("--warmup", type=int, default=1)
+    ap.add_argument("--grid", type=int, default=224, help="cloth grid N = M (224 -> 100,352 triangles)")
+    ap.add_argument("--cloth-size", type=float, default=0.1 / 15 * 224, help="edge length of the square cloth in m (default keeps the reference dx = 0.1/15)")
+    ap.add_argument("--cg-tol", type=float, default=1e-10)
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--cpu-cg-iters", type=int, default=300)
+    args = ap.parse_args()
+
+    import torch
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs an MI355X (no CPU path in thinshelllab_amd)")
+    torch.cuda.set_device(local_rank)
+    dist = None
+    if world > 1:
+        import torch.distributed as dist
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local_rank))
+    os.environ["HIP_VISIBLE_DEVICES"] = os.environ.get("HIP_VISIBLE_DEVICES", "")
+
+    from thinshelllab_amd.engine.analytic_grad_single import Grad
+    scene = build_scene(args, rank)
+    K, W = args.steps, args.warmup
+    ctx = scene._ensure_ctx()
+    ctx.set_param("cg_tol", args.cg_tol)
+    grad = Grad(scene, max(K, W) + 1, 0)
+    grad.init_mass(scene)
+    if W > 0:
+        run_rollout(scene, grad, W)
+
+    def barrier():
+        torch.cuda.synchronize()
+        if dist is not None:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    ctx.profile_reset(True)
+    barrier()
+    t0 = time.perf_counter()
+    stats = run_rollout(scene, grad, K)
+    barrier()
+    elapsed = time.perf_counter() - t0
+    prof = ctx.profile_read()
+    if dist is not None:
+        t = torch.tensor([elapsed], dtype=torch.float64, device="cuda")
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed = float(t.item())
+
+    T = 2 * args.grid * args.grid
+    value = T * K * world / elapsed
+    out = {
+        "metric": "element-steps/s (fwd+adjoint), 100k-tri cloth; 1/2/4/8-GPU scaling",
+        "value": value, "unit": "element-steps/s", "n_gpus": world, "steps": K, "warmup": W,
+        "ms_per_step": elapsed / K * 1e3, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+        "dtype": "f64", "data": "synthetic",
+        "config": {"workload": f"{args.grid}x{args.grid} square cloth ({T} triangles, dx={args.cloth_size / args.grid:.3e} m), one pinned row, gravity drape; "
+                               f"per step: implicit-Euler Newton+PCG time step + adjoint transfer_grad; one independent scene per GPU",
+                   "triangles": T, "cg_tol": args.cg_tol,
+                   "newton_iters_per_step": stats["newton"] / K, "pcg_iters_per_fwd_solve": stats["cg_fwd"] / max(stats["newton"], 1),
+                   "pcg_iters_per_adjoint_solve": stats["cg_adj"] / K, "line_search_evals_per_step": stats["ls"] / K, "solver_fallbacks": stats["fallback"]},
+    }
+    if prof["ms_per_launch"] > 0:
+        ach = prof["bytes_per_launch"] / (prof["ms_per_launch"] * 1e-3) / 1e9
+        out["roofline"] = {"bound": "hbm", "achieved": ach, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": ach / HBM_PEAK_GBS, "traffic": None,
+                           "kernel": "k_spmv (SELL-64 3x3-block SpMV, one launch per PCG iteration)",
+                           "bytes_per_launch": prof["bytes_per_launch"], "avg_launch_us": prof["ms_per_launch"] * 1e3, "launches": prof["launches"]}
+    if rank == 0:
+        if world == 1 and not args.no_cpu_baseline:
+            try:
+                out["cpu_baseline"] = cpu_baseline(args, stats, K)
+            except Exception as e:  # the oracle is optional test infrastructure; never fail the GPU number on it
+                out["cpu_baseline"] = {"value": None, "unit": "element-steps/s", "cores": os.cpu_count(), "kind": "port", "sample": f"failed: {e}"}
+        print(json.dumps(out), flush=True)
+    if dist is not None:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -677,7 +677,136 @@ extern "C" int tsl_spd_project(tsl_ctx* c, double* blocks, int32_t n, int32_t D)
   return 0;
 }
 
+// ------------------------------------------------------------------------------------------------ adjoint
+// Grad.clamp_grad (analytic_grad_single.py:176-185)
+__global__ void k_clamp(size_t n, double* __restrict__ v, double lim) {
+  for (size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x) v[i] = fmin(fmax(v[i], -lim), lim);
+}
+
+// Cloth.ref_angle_backprop_a2ax (model_fold_offset.py:1179-1206), one lane per hinge.
+// ag_s / ag_prev: angleref_grad[s], angleref_grad[s-1]; pg_s: pos_grad[s]; ref = ref_angle_{s-1}; pos = x_s
+__global__ void k_adj_a2ax(ClothArgs A, const double* __restrict__ pos, const double* __restrict__ ref, const double* __restrict__ ag_s, double* __restrict__ ag_prev,
+                           double* __restrict__ pg_s) {
+  const int h = blockIdx.x * blockDim.x + threadIdx.x;
+  if (h >= A.n_hinge) return;
+  const int f1 = A.hg_info[8 * h], l = A.hg_info[8 * h + 1], f2 = A.hg_info[8 * h + 2], p4 = A.hg_info[8 * h + 3], p21 = A.hg_info[8 * h + 4];
+  const ClothDev c = A.cloth[A.cid[f1]];
+  int v1[3], v2[3]; d3 P1[3], P2[3];
+  load_face(pos, A.f2v, f1, v1, P1);
+  load_face(pos, A.f2v, f2, v2, P2);
+  const FaceGeom g1 = face_geom(P1), g2 = face_geom(P2);
+  d3 g[4];
+  hinge_grad(g1, g2, l, p4, p21, g);
+  const double theta = dihedral(g1.n, g2.n, P1[(l + 1) % 2] - P1[l]);
+  const double a = ag_s[3 * f1 + l];
+  ag_prev[3 * f1 + l] += a;
+  const double sgn = (fabs(theta - ref[3 * f1 + l]) > c.k_angle) ? a : a * 0.1;
+  atomic_add3(pg_s, v1[l], sgn * g[0]);
+  atomic_add3(pg_s, v1[(l + 1) % 3], sgn * g[1]);
+  atomic_add3(pg_s, v1[(l + 2) % 3], sgn * g[2]);
+  atomic_add3(pg_s, v2[p4], sgn * g[3]);
+}
+
+// Cloth.ref_angle_backprop_x2a (model_fold_offset.py:1154-1168): angleref_grad[s-1] += -z . (d_ref * grad theta)
+__global__ void k_adj_x2a(ClothArgs A, const double* __restrict__ pos, const double* __restrict__ z, double* __restrict__ ag_prev) {
+  const int h = blockIdx.x * blockDim.x + threadIdx.x;
+  if (h >= A.n_hinge) return;
+  const int f1 = A.hg_info[8 * h], l = A.hg_info[8 * h + 1], f2 = A.hg_info[8 * h + 2], p4 = A.hg_info[8 * h + 3], p21 = A.hg_info[8 * h + 4];
+  const ClothDev c = A.cloth[A.cid[f1]];
+  int v1[3], v2[3]; d3 P1[3], P2[3];
+  load_face(pos, A.f2v, f1, v1, P1);
+  load_face(pos, A.f2v, f2, v2, P2);
+  const FaceGeom g1 = face_geom(P1), g2 = face_geom(P2);
+  d3 g[4];
+  hinge_grad(g1, g2, l, p4, p21, g);
+  const double d_ref = -2.0 * c.Kb * c.dx * c.dx * (1.0 / 3.0);
+  const double s = dot(ld3(z, v1[l]), g[0]) + dot(ld3(z, v1[(l + 1) % 3]), g[1]) + dot(ld3(z, v1[(l + 2) % 3]), g[2]) + dot(ld3(z, v2[p4]), g[3]);
+  ag_prev[3 * f1 + l] += -s * d_ref;
+}
+
+// tmp_z_frozen[j] -= H_ij z_i for every stored entry with i free, j frozen (BaseScene.add_H second pass, BaseScene.py:403-405).
+// vals = UNMASKED matrix; zp = z in permuted order; out in permuted order.
+__global__ void k_zfrozen_matrix(int NV, int n_slices, const int* __restrict__ slice_off, const int* __restrict__ slice_len, const int* __restrict__ colidx,
+                                 const unsigned char* __restrict__ fz, const double* __restrict__ vals, const double* __restrict__ zp, double* __restrict__ out) {
+  const int slice = blockIdx.x, lane = threadIdx.x & 63;
+  if (slice >= n_slices) return;
+  const int p = slice * 64 + lane;
+  if (p >= NV) return;
+  const unsigned rm = fz[p];
+  if (rm == 7u) return;
+  const d3 zi = ld3(zp, p);
+  const double zr[3] = {zi.x, zi.y, zi.z};
+  const int off = slice_off[slice], len = slice_len[slice];
+  for (int k = threadIdx.x >> 6; k < len; k += (blockDim.x >> 6)) {
+    const int c = colidx[off + 64 * k + lane];
+    const unsigned cm = fz[c];
+    if (!cm) continue;
+    const size_t base = ((size_t)off + 64 * (size_t)k) * 9 + lane;
+    for (int cc = 0; cc < 3; cc++) {
+      if (!((cm >> cc) & 1u)) continue;
+      double s = 0;
+      for (int r = 0; r < 3; r++) if (!((rm >> r) & 1u)) s += vals[base + 64 * (3 * r + cc)] * zr[r];
+      if (s != 0.0) atomicAdd(&out[3 * (size_t)c + cc], -s);
+    }
+  }
+}
+
+// x_hat_grad = z m / dt^2 ; pos_grad[s-1] += (1+d) x_hat_grad, pos_grad[s-2] -= d x_hat_grad on free dofs
+// (Grad.get_grad / get_prev_grad / get_prev_prev_grad, analytic_grad_single.py:81-106)
+__global__ void k_adj_prev(int NV, const double* __restrict__ z, const double* __restrict__ mass, const int* __restrict__ frozen, double dt, double d,
+                           double* __restrict__ pg_prev, double* __restrict__ pg_prev2) {
+  const size_t n = 3 * (size_t)NV;
+  for (size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x) {
+    if (frozen[i]) continue;
+    const double xh = z[i] * mass[i / 3] / (dt * dt);
+    if (pg_prev) pg_prev[i] += xh * (1.0 + d);
+    if (pg_prev2) pg_prev2[i] -= xh * d;
+  }
+}
+
+// Grad.transfer_grad (analytic_grad_single.py:217-257) without the gripper part (host: gripper.set / gather_grad).
 extern "C" int tsl_adjoint_step(tsl_ctx* c, int step, int T, const double* pos_buffer, double* pos_grad, const double* ref_buffer, double* angleref_grad,
                                 double* tmp_z_frozen, double adj_damping, tsl_solve_stats* st) {
-  return tsl_fail("tsl_adjoint_step: not implemented yet");
+  if (step < 1 || step >= T) return tsl_fail("tsl_adjoint_step: step %d outside [1, %d)", step, T);
+  hipStream_t s = c->stream;
+  const int NV = c->NV;
+  const size_t n3 = 3 * (size_t)NV, nr = 3 * (size_t)std::max(c->n_cface, 1);
+  double* pg_s = pos_grad + (size_t)step * n3;
+  double* pg_prev = pos_grad + (size_t)(step - 1) * n3;
+  double* pg_prev2 = step > 1 ? pos_grad + (size_t)(step - 2) * n3 : nullptr;
+  const double* x_s = pos_buffer + (size_t)step * n3;
+  const double* x_prev = pos_buffer + (size_t)(step - 1) * n3;
+  double* ag_s = angleref_grad + (size_t)step * nr;
+  double* ag_prev = angleref_grad + (size_t)(step - 1) * nr;
+  const double* ref_prev = ref_buffer + (size_t)(step - 1) * nr;
+  // clamp_grad
+  hipLaunchKernelGGL(k_clamp, dim3(gsz(n3)), dim3(256), 0, s, n3, pg_s, 1000.0);
+  if (c->n_cface) hipLaunchKernelGGL(k_clamp, dim3(gsz(3 * (size_t)c->n_cface)), dim3(256), 0, s, 3 * (size_t)c->n_cface, ag_s, 1000.0);
+  // contacts re-detected at pos = prev_pos = x_{s-1} (copy_pos_only + calc_vn + f_contact + contact_analysis)
+  int nc = 0;
+  if (c->contact_enable) TSL_TRY(tsl_contact_detect(c, x_prev, x_prev, &nc));
+  else c->nc = 0;
+  const ClothArgs CA = cloth_args(c);
+  // pos = x_s, ref_angle = ref_{s-1}: init_folding + ref_angle_backprop_a2ax
+  if (c->n_hinge) hipLaunchKernelGGL(k_adj_a2ax, dim3(nblk(c->n_hinge, 256)), dim3(256), 0, s, CA, x_s, ref_prev, ag_s, ag_prev, pg_s);
+  // H.clear_all + compute_Hessian(False)
+  TSL_TRY(assemble(c, x_s, x_prev, x_prev /*vel unused without gradient*/, ref_prev, 0, nullptr));
+  // p = H^-1 pos_grad[s]
+  tsl_solve_stats local;
+  if (!st) st = &local;
+  TSL_TRY(solve_orig(c, pg_s, c->pdir.p, st));
+  // tmp_z_frozen (second compute_Hessian pass with counting_z_frozen)
+  HIP_OK(hipMemsetAsync(c->v_t4.p, 0, n3 * sizeof(double), s));
+  hipLaunchKernelGGL(k_zfrozen_matrix, dim3(c->n_slices), dim3(256), 0, s, NV, c->n_slices, c->slice_off.p, c->slice_len.p, c->colidx.p, c->fzmask.p, c->vals_full.p, c->v_x.p,
+                     c->v_t4.p);
+  hipLaunchKernelGGL(k_scatter_perm, dim3(nblk(NV, 256)), dim3(256), 0, s, NV, c->perm.p, c->v_t4.p, tmp_z_frozen);
+  if (c->nc > 0) hipLaunchKernelGGL(k_contact_zfrozen, dim3(nblk(c->nc, 64)), dim3(64), 0, s, c->nc, c->c_idx.p, c->frozen.p, c->c_Hfull.p, c->pdir.p, tmp_z_frozen);
+  // contact_energy_backprop(step-1) ; ref_angle_backprop_x2a
+  if (c->nc > 0) hipLaunchKernelGGL(k_contact_backprop, dim3(nblk(c->nc, 64)), dim3(64), 0, s, c->nc, contact_args(c), x_s, c->pdir.p, pg_prev);
+  if (c->n_hinge) hipLaunchKernelGGL(k_adj_x2a, dim3(nblk(c->n_hinge, 256)), dim3(256), 0, s, CA, x_s, c->pdir.p, ag_prev);
+  // get_prev_grad / get_prev_prev_grad
+  hipLaunchKernelGGL(k_adj_prev, dim3(gsz(n3)), dim3(256), 0, s, NV, c->pdir.p, c->mass.p, c->frozen.p, c->dt, adj_damping, pg_prev, pg_prev2);
+  HIP_OK(hipStreamSynchronize(s));
+  HIP_OK(hipGetLastError());
+  return 0;
 }

@@ -403,10 +403,12 @@ class BaseScene:
     def copy_pos_and_refangle(self, analy_grad, step):
         self.copy_pos_kernel(analy_grad.pos_buffer, step)
         self.copy_prev_pos_kernel(analy_grad.pos_buffer, step)
-        self._ref_angle[: analy_grad.ref_angle_buffer.t.shape[1]].copy_(analy_grad.ref_angle_buffer.t[step - 1])
+        rb = analy_grad.ref_angle_buffer.t[step - 1].reshape(-1, 3)
+        self._ref_angle[: rb.shape[0]].copy_(rb)
 
     def copy_refangle(self, analy_grad, step):
-        self._ref_angle[: analy_grad.ref_angle_buffer.t.shape[1]].copy_(analy_grad.ref_angle_buffer.t[step])
+        rb = analy_grad.ref_angle_buffer.t[step].reshape(-1, 3)
+        self._ref_angle[: rb.shape[0]].copy_(rb)
 
     # ------------------------------------------------------------------ misc surface kept for the scripts
     def compute_reward(self):

@@ -1,0 +1,163 @@
+"""Trajectory adjoint: host-side counterpart of ``Grad``
+(/root/reference/code/engine/analytic_grad_single.py).
+
+The tape (``pos_buffer``, ``ref_angle_buffer``) and the gradient buffers live in HBM; one reverse step
+(``transfer_grad``, :217-257) is a single ``tsl_adjoint_step`` call -- contact re-detection, the un-projected
+Hessian, one linear solve, the frozen-dof coupling and the three back-propagation kernels -- followed by the
+(tiny) gripper reduction on the host (``get_gripper_grad``, :118-139).
+"""
+import numpy as np
+import torch
+
+from .field import Field
+
+
+class Grad:
+    def __init__(self, sys, tot_timestep, n_parts, friction_loss=False, f_loss_ratio=0.001, vertical_only=False):
+        # analytic_grad_single.py:5-26
+        self.n_part = n_parts
+        self.tot_NV = sys.tot_NV
+        dev = sys.device
+        T = tot_timestep
+        z = lambda *shape: Field(torch.zeros(shape, dtype=torch.float64, device=dev))
+        self.pos_buffer = z(T, sys.tot_NV, 3)
+        self.gripper_pos_buffer = Field(torch.zeros((T, max(n_parts, 1), 3), dtype=torch.float64))
+        self.gripper_rot_buffer = Field(torch.zeros((T, max(n_parts, 1), 4), dtype=torch.float64))
+        self.cloth_cnt = sys.cloth_cnt
+        self.NF = sys.cloths[0].NF
+        self.ref_angle_buffer = z(T, sys.cloth_cnt, self.NF, 3)
+        self.dt = sys.dt
+        self.pos_grad = z(T, sys.tot_NV, 3)
+        self.x_hat_grad = z(sys.tot_NV * 3)
+        self.gripper_grad = Field(torch.zeros((T, max(n_parts, 1), 6), dtype=torch.float64))
+        self.angleref_grad = z(T, sys.cloth_cnt, self.NF, 3)
+        self.mass = Field(torch.zeros(sys.tot_NV, dtype=torch.float64))
+        self.tot_timestep = T
+        self.damping = 1.0
+        self.friction_loss = friction_loss
+        self.f_loss_ratio = f_loss_ratio
+        self.vertical_only = vertical_only
+        self.last_stats = {}
+
+    def reset(self):
+        self.pos_buffer.fill(0)
+        self.pos_grad.fill(0)
+        self.angleref_grad.fill(0)
+
+    def init_mass(self, sys):
+        self.mass.copy_from(sys.mass)
+
+    # :37-51
+    def copy_pos(self, sys, step):
+        self.pos_buffer.t[step].copy_(sys.pos.t)
+        self.ref_angle_buffer.t[step].view(-1, 3).copy_(sys._ref_angle[: self.cloth_cnt * self.NF])
+        if self.n_part > 0 and hasattr(sys, "gripper"):
+            self.gripper_pos_buffer.t[step].copy_(sys.gripper.pos.t)
+            self.gripper_rot_buffer.t[step].copy_(sys.gripper.rot.t)
+
+    # :176-185
+    def clamp_grad(self, step):
+        self.pos_grad.t[step].clamp_(-1000, 1000)
+        self.angleref_grad.t[step].clamp_(-1000, 1000)
+
+    # :118-139
+    def get_gripper_grad(self, step, sys):
+        sys.gripper.get_rotmat()
+        sys.gripper.gather_grad(sys.tmp_z_frozen, sys)
+        dp = sys.gripper.d_pos.to_numpy(); da = sys.gripper.d_angle.to_numpy()
+        g = self.gripper_grad.t
+        for j in range(self.n_part):
+            if self.vertical_only:
+                g[step, j, 2] = float(dp[j][2])
+            else:
+                g[step, j, 0:3] = torch.as_tensor(dp[j]); g[step, j, 3:6] = torch.as_tensor(da[j])
+
+    # :217-257
+    def transfer_grad(self, step, sys, f_contact):
+        ctx = sys._ensure_ctx()
+        ctx.set_param("contact", 0.0 if f_contact is None else 1.0)
+        self.last_stats = ctx.adjoint_step(step, self.tot_timestep, self.pos_buffer.t, self.pos_grad.t, self.ref_angle_buffer.t, self.angleref_grad.t,
+                                           sys.tmp_z_frozen.t, self.damping)
+        # leave the scene in the state the reference leaves it in (copy_pos_and_refangle + gripper.set)
+        sys.copy_pos_and_refangle(self, step)
+        if self.n_part > 0 and hasattr(sys, "gripper"):
+            sys.gripper.set(self.gripper_pos_buffer, self.gripper_rot_buffer, step)
+            if step > 0:
+                self.get_gripper_grad(step, sys)
+
+    # ---- loss seeds
+    def get_loss(self, sys):  # :259-263
+        self.pos_grad.t[:, : sys.cloths[0].NV, 0] = -1
+
+    def get_loss_sheet(self, sys):  # :265-269
+        self.pos_grad.t[1:, : sys.cloths[0].NV, 0] = 1
+
+    def get_loss_book(self, sys):  # :274-278
+        self.pos_grad.t[1:, : sys.cloths[0].NV, 0] = -1
+
+    def _fold_rows(self, sys, row_a, row_b):
+        """hinges (f, l) of cloth 0 whose own wing lies on grid row ``row_a`` and the opposite wing on ``row_b``"""
+        c = sys.cloths[0]
+        f2v = c.f2v.to_numpy(); cf = c.counter_face.to_numpy(); cp = c.counter_point.to_numpy()
+        fi, l = np.nonzero(cf > np.arange(c.NF)[:, None])
+        p1 = f2v[fi, l]
+        p2 = f2v[cf[fi, l], cp[fi, l]]
+        m = (p1 // (c.M + 1) == row_a) & (p2 // (c.M + 1) == row_b)
+        return fi[m], l[m]
+
+    def get_loss_fold(self, sys, curve7, curve8, rows=((6, 8), (7, 9))):  # :280-294
+        ag = self.angleref_grad.t
+        for (ra, rb), val in zip(rows, (curve7, curve8)):
+            fi, l = self._fold_rows(sys, ra, rb)
+            ag[self.tot_timestep - 1, 0, torch.as_tensor(fi), torch.as_tensor(l)] = val
+
+    def get_loss_push(self, sys, target_pos):  # :296-300
+        c = sys.cloths[0]
+        j = self.tot_timestep - 1
+        t = torch.as_tensor(np.asarray(target_pos), dtype=torch.float64, device=self.pos_grad.t.device)
+        self.pos_grad.t[j, c.offset:c.offset + c.NV] = 2 * (self.pos_buffer.t[j, c.offset:c.offset + c.NV] - t)
+
+    def get_loss_lift(self, sys):  # :302-312
+        e = sys.elastics[0]
+        j = self.tot_timestep - 1
+        sl = slice(e.offset, e.offset + e.n_verts)
+        d = self.pos_buffer.t[j, sl] - self.pos_buffer.t[0, sl]
+        d[:, 0] += 0.012; d[:, 1] += 0.012
+        self.pos_grad.t[j, sl] = d
+
+    def get_loss_balance(self, sys):  # :428-443 (the cloth-centre entry keeps the value of the LAST ball vertex, like the kernel)
+        e = sys.elastics[0]
+        tt = sys.cloths[0].offset + (sys.cloth_N + 1) // 2 * (sys.cloth_M + 1) + (sys.cloth_M + 1) // 2
+        pb = self.pos_buffer.t
+        sl = slice(e.offset, e.offset + e.n_verts)
+        d = 2 * (pb[1:, sl, 0:2] - pb[1:, tt:tt + 1, 0:2])
+        self.pos_grad.t[1:, sl, 0:2] = d
+        self.pos_grad.t[1:, tt, 0:2] = -d[:, -1, :]
+
+    def get_loss_throwing(self, sys):  # :462-471
+        e = sys.elastics[0]; c = sys.cloths[0]
+        self.pos_grad.t[1:, e.offset:e.offset + e.n_verts, 2] = -1
+        pb = self.pos_buffer.t
+        i = torch.arange(sys.cloth_M)
+        self.pos_grad.t[1:, c.offset + i, 2] = 20 * pb[1:, c.offset + i, 2]
+        k = c.offset + i + sys.cloth_N * (sys.cloth_M + 1)
+        self.pos_grad.t[1:, k, 2] = 20 * pb[1:, k, 2]
+
+    # :492-516
+    def accumulate_gripper_grad(self, traj, max_dist):
+        g = self.gripper_grad.t
+        for step in range(self.tot_timestep - 2, 1, -1):
+            for j in range(self.n_part):
+                if traj.calculate_dist(step + 1, max_dist, j) > traj.max_moving_dist - 0.00005:
+                    g[step, j] += g[step + 1, j]
+
+    def apply_action_limit_grad(self, traj, max_dist):
+        g = self.gripper_grad.t
+        tr = traj.traj.t
+        for step in range(1, self.tot_timestep):
+            for j in range(self.n_part):
+                dist = traj.calculate_dist(step, max_dist, j)
+                if dist > traj.max_moving_dist:
+                    d = (tr[step, j] - tr[step - 1, j]).to(g.dtype)
+                    g[step, j, 0:3] += d[0:3] * (dist - traj.max_moving_dist) * 10000000
+                    g[step, j, 3:6] += d[3:6] * (dist - traj.max_moving_dist) * 100000
