@@ -59,24 +59,37 @@ def cpu_baseline(args, gpu_stats, K):
     of PCG iterations on the SAME mesh and state, scaled by the iteration counts the GPU run needed (the CPU
     restatement runs the same algorithm; a full 100k-triangle step takes minutes on the host)."""
     from oracle import pyoracle as po
-    cores = os.cpu_count() or 1
-    po.set_threads(cores)
+    import numpy as np
     N = args.grid
     o = po.OracleScene(dt=5e-3, newton_cap=50)
     ci = o.add_cloth(N, N, args.cloth_size)
     o.cloth_init(ci, 0, 0, 0)
     o.finalize()
-    import numpy as np
     i, j = np.meshgrid(np.arange(N + 1), np.arange(N + 1), indexing="ij")
     o.pos[:, 2] = (1e-4 * np.sin(7.0 * i) * np.cos(5.0 * j)).reshape(-1)
     o.prev_pos[:] = o.pos
     fr = o.frozen.reshape(-1, 3); fr[N * (N + 1):] = 1
     o.push_down_all()
+    # the OpenMP restatement is memory-bound: pick the thread count that runs the PCG iteration fastest on this host
+    ncpu = os.cpu_count() or 1
+    po.set_threads(min(ncpu, 8))
+    o.newton_step_init(); o.compute_energy(); o.compute_residual_and_Hessian(True)
+    b = o.arr("F").copy()
+    best = None
+    for th in sorted({min(ncpu, t) for t in (8, 16, 32, 64)}):
+        po.set_threads(th)
+        o.set_solver(1e-30, 20)
+        o.stats(reset=True)
+        t0 = time.time(); o.solve(b); dt_ = (time.time() - t0) / max(o.stats()["cg"], 1)
+        if best is None or dt_ < best[1]:
+            best = (th, dt_)
+    cores = best[0]
+    po.set_threads(cores)
     t0 = time.time(); o.newton_step_init(); o.compute_energy(); t_e = time.time() - t0
     t0 = time.time(); o.compute_residual_and_Hessian(True); t_asm = time.time() - t0
-    n_it = args.cpu_cg_iters
+    n_it = max(20, min(args.cpu_cg_iters, int(8.0 / best[1])))
     o.set_solver(1e-30, n_it)
-    b = o.arr("F").copy()
+    o.stats(reset=True)
     t0 = time.time(); o.solve(b); t_cg = (time.time() - t0)
     it_done = max(o.stats()["cg"], 1)
     t_it = t_cg / it_done
@@ -86,7 +99,7 @@ def cpu_baseline(args, gpu_stats, K):
     t_total = n_asm * t_asm + n_e * t_e + n_cg * t_it
     T = 2 * N * N
     return {"value": T * K / t_total, "unit": "element-steps/s", "cores": cores, "kind": "port",
-            "sample": f"oracle on the same {N}x{N} cloth: 1 energy ({t_e:.3f}s) + 1 assembly ({t_asm:.3f}s) + {it_done} PCG iterations "
+            "sample": f"oracle ({cores} OpenMP threads of {ncpu} host cpus) on the same {N}x{N} cloth: 1 energy ({t_e:.3f}s) + 1 assembly ({t_asm:.3f}s) + {it_done} PCG iterations "
                       f"({t_it * 1e3:.2f} ms each), scaled by the GPU run's counts ({n_asm} assemblies, {n_e} energies, {n_cg} PCG iterations)"}
 
 
@@ -114,7 +127,6 @@ def main():
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local_rank))
-    os.environ["HIP_VISIBLE_DEVICES"] = os.environ.get("HIP_VISIBLE_DEVICES", "")
 
     from thinshelllab_amd.engine.analytic_grad_single import Grad
     scene = build_scene(args, rank)

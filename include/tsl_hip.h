@@ -136,6 +136,8 @@ int tsl_matrix_nnzb(tsl_ctx* ctx, int32_t* nb_host, int32_t* nnzb_host);
 int tsl_matrix_export(tsl_ctx* ctx, int32_t* row_ptr_host, int32_t* col_host, double* vals_host);
 int tsl_constraints_export(tsl_ctx* ctx, int32_t* idx_host, double* w_host, double* k_host, double* dx0_host,
                            double* T_host, double* n_host, double* mu_host, int32_t max_n);
+/* per-constraint dense 12x12 blocks (vertex order idx0..idx3) of the last assemble; masked = frozen rule applied */
+int tsl_contact_blocks_export(tsl_ctx* ctx, double* blocks_host, int32_t max_n, int32_t masked);
 int tsl_proj_export(tsl_ctx* ctx, int32_t* proj_flag_host, int32_t* proj_dir_host, int32_t* proj_idx_host, double* proj_w_host);
 int tsl_proj_import(tsl_ctx* ctx, const int32_t* proj_flag_host, const int32_t* proj_dir_host);
 

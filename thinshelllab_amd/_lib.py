@@ -71,7 +71,7 @@ EXPORTS = [
     "tsl_version", "tsl_last_error", "tsl_ctx_create", "tsl_ctx_destroy", "tsl_set_stream", "tsl_set_param", "tsl_set_frozen",
     "tsl_set_ext_force", "tsl_set_gravity", "tsl_energy", "tsl_assemble", "tsl_solve", "tsl_step", "tsl_contact_detect",
     "tsl_contact_reset", "tsl_update_ref_angle", "tsl_adjoint_step", "tsl_matrix_nnzb", "tsl_matrix_export",
-    "tsl_constraints_export", "tsl_proj_export", "tsl_proj_import", "tsl_spd_project", "tsl_profile_reset", "tsl_profile_read",
+    "tsl_constraints_export", "tsl_contact_blocks_export", "tsl_proj_export", "tsl_proj_import", "tsl_spd_project", "tsl_profile_reset", "tsl_profile_read",
 ]
 
 _lib = None
@@ -82,6 +82,9 @@ def load():
     global _lib
     if _lib is not None:
         return _lib
+    # torch first: its wheel bundles the HIP runtime this process must share (device pointers come from torch
+    # tensors); loading libtsl_hip.so before it would pull a second libamdhip64 into the process.
+    import torch  # noqa: F401
     if not os.path.exists(LIB_PATH):
         raise TslLibraryError(
             f"{LIB_PATH} not found: build it with `python -c 'import __graft_entry__ as g; g.build()'` "
@@ -112,6 +115,7 @@ def load():
     L.tsl_matrix_nnzb.argtypes = [C.c_void_p, C.POINTER(C.c_int32), C.POINTER(C.c_int32)]
     L.tsl_matrix_export.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]
     L.tsl_constraints_export.argtypes = [C.c_void_p] + [C.c_void_p] * 7 + [C.c_int32]
+    L.tsl_contact_blocks_export.argtypes = [C.c_void_p, C.c_void_p, C.c_int32, C.c_int32]
     L.tsl_proj_export.argtypes = [C.c_void_p] + [C.c_void_p] * 4
     L.tsl_proj_import.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p]
     L.tsl_spd_project.argtypes = [C.c_void_p, C.c_void_p, C.c_int32, C.c_int32]

@@ -159,6 +159,27 @@ class TslContext:
                                                   mu.ctypes.data, m), "tsl_constraints_export")
         return dict(idx=idx[:cnt], w=w[:cnt], k=k[:cnt], dx0=dx0[:cnt], T=T[:cnt], n=n[:cnt], mu=mu[:cnt])
 
+    def contact_blocks(self, masked=True):
+        m = self.max_n_constraints
+        blk = np.zeros((m, 12, 12))
+        cnt = check(self.L.tsl_contact_blocks_export(self.h, blk.ctypes.data, m, int(masked)), "tsl_contact_blocks_export")
+        return blk[:cnt]
+
+    def operator_csr(self):
+        """full solve operator: static masked matrix + matrix-free contact blocks, as scipy CSR"""
+        import scipy.sparse as sp
+        A = self.matrix_csr().tolil()
+        cons = self.constraints()
+        blk = self.contact_blocks(True)
+        for c in range(len(blk)):
+            idx = cons["idx"][c]
+            dofs = np.concatenate([3 * idx[k] + np.arange(3) for k in range(4)])
+            for r in range(12):
+                for cc in range(12):
+                    if blk[c, r, cc] != 0.0:
+                        A[dofs[r], dofs[cc]] += blk[c, r, cc]
+        return A.tocsr()
+
     def proj_export(self):
         nb = max(self.n_body, 1)
         flag = np.zeros((nb, self.tot_NV), np.int32); dr = np.zeros((nb, self.tot_NV), np.int32)

@@ -549,6 +549,14 @@ extern "C" int tsl_constraints_export(tsl_ctx* c, int32_t* idx, double* w, doubl
   return m;
 }
 
+extern "C" int tsl_contact_blocks_export(tsl_ctx* c, double* blocks_host, int32_t max_n, int32_t masked) {
+  HIP_OK(hipStreamSynchronize(c->stream));
+  const int m = std::min(c->nc, (int)max_n);
+  if (m <= 0) return 0;
+  HIP_OK(hipMemcpy(blocks_host, masked ? c->c_H.p : c->c_Hfull.p, (size_t)m * 144 * sizeof(double), hipMemcpyDeviceToHost));
+  return m;
+}
+
 extern "C" int tsl_proj_export(tsl_ctx* c, int32_t* flag, int32_t* dir, int32_t* pidx, double* pw) {
   HIP_OK(hipStreamSynchronize(c->stream));
   const size_t n = (size_t)std::max(c->n_body, 1) * c->NV;

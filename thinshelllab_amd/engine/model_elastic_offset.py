@@ -129,6 +129,7 @@ class Elastic:
 
     # -- :395-405
     def init(self, offsetx, offsety, offsetz):
+        self._init_args = (offsetx, offsety, offsetz, False)
         if not self.load:
             self.get_vertices()
             self.init_pos(offsetx, offsety, offsetz)

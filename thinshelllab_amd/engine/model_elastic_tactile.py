@@ -87,6 +87,7 @@ class Elastic:
 
     # -- :214-230 init_pos, :265-291 init_surface_indices
     def init(self, offsetx, offsety, offsetz, flip):
+        self._init_args = (offsetx, offsety, offsetz, bool(flip))
         x = self.ratio * self.F_ox_array
         if flip:
             x = -x

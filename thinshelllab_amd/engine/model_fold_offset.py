@@ -166,11 +166,13 @@ class Cloth:
         self.ref_angle.from_numpy(ra)
 
     def init(self, offsetx, offsety, offsetz):
+        self._init_args = ("flat", offsetx, offsety, offsetz, 0)
         self.init_mesh()
         self.init_pos_offset(offsetx, offsety, offsetz)
         self.ref_angle.fill(0)
 
     def init_fold(self, offsetx, offsety, offsetz, curv_num, **kw):
+        self._init_args = ("fold" if not kw else "fold_scaled", offsetx, offsety, offsetz, curv_num)
         self.init_mesh()
         self.init_pos_offset_fold(offsetx, offsety, offsetz, curv_num, **kw)
         self.init_ref_angle()
