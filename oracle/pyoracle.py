@@ -130,6 +130,10 @@ class OracleScene:
         p = np.ascontiguousarray(pos_array, np.float64)
         self.L.tslo_gripper_reinit(self.h, _dp(p))
 
+    def set_body_gravity(self, is_elastic, idx, g):
+        g = np.ascontiguousarray(g, np.float64)
+        self.L.tslo_set_body_gravity(self.h, int(is_elastic), int(idx), _dp(g))
+
     def set_solver(self, tol, maxit=20000):
         self.L.tslo_set_solver(self.h, C.c_double(tol), int(maxit))
 

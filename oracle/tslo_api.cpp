@@ -104,6 +104,13 @@ void tslo_gripper_init(void* h, int paired, int n_part, const double* pos_array)
 }
 void tslo_gripper_reinit(void* h, const double* pos_array) { S(h).gripper.init(S(h), pos_array); }
 
+// per-body gravity override (scene-specific init_property, e.g. Scene_lifting.py:87-103)
+void tslo_set_body_gravity(void* h, int is_elastic, int idx, const double* g) {
+  Scene& s = S(h);
+  V3 gv(g[0], g[1], g[2]);
+  if (is_elastic) s.elastics[idx].gravity = gv; else s.cloths[idx].gravity = gv;
+}
+
 // state sync helpers
 void tslo_pushup_all(void* h) { S(h).pushup_all(); }
 void tslo_push_down_all(void* h) { S(h).push_down_pos(); S(h).push_down_vel(); S(h).push_down_prev(); }
