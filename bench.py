@@ -31,7 +31,7 @@ HBM_PEAK_GBS = 8000.0  # /opt/skills/guides/MI355X_MICROARCH.md: HBM3E 8.0 TB/s 
 
 def build_scene(args, rank):
     from thinshelllab_amd.task_scene.Scene_drape import Scene
-    s = Scene(cloth_size=args.cloth_size, N=args.grid, M=args.grid, Kb=100.0, k_angle=3.14, perturb=1e-4 * (1 + 0.01 * rank), device="cuda:0",
+    s = Scene(cloth_size=args.cloth_size, N=args.grid, M=args.grid, Kb=100.0, k_angle=3.14, perturb=1e-4 * (1 + 0.01 * rank), device=f"cuda:{int(os.environ.get('LOCAL_RANK', '0'))}",
               newton_cap=50)
     s.init_all()
     return s
@@ -116,17 +116,12 @@ def main():
     args = ap.parse_args()
 
     import torch
-    world = int(os.environ.get("WORLD_SIZE", "1"))
-    rank = int(os.environ.get("RANK", "0"))
-    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs an MI355X (no CPU path in thinshelllab_amd)")
-    torch.cuda.set_device(local_rank)
-    dist = None
-    if world > 1:
-        import torch.distributed as dist
-        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local_rank))
+    from thinshelllab_amd.batch import Batch
+    batch = Batch()  # one process per GPU (RANK / LOCAL_RANK / WORLD_SIZE from torch.distributed.run); backend nccl == RCCL
+    world, rank = batch.world, batch.rank
+    torch.cuda.set_device(batch.local_rank)
 
     from thinshelllab_amd.engine.analytic_grad_single import Grad
     scene = build_scene(args, rank)
@@ -138,11 +133,7 @@ def main():
     if W > 0:
         run_rollout(scene, grad, W)
 
-    def barrier():
-        torch.cuda.synchronize()
-        if dist is not None:
-            dist.barrier()
-        torch.cuda.synchronize()
+    barrier = batch.barrier
 
     ctx.profile_reset(True)
     barrier()
@@ -151,10 +142,7 @@ def main():
     barrier()
     elapsed = time.perf_counter() - t0
     prof = ctx.profile_read()
-    if dist is not None:
-        t = torch.tensor([elapsed], dtype=torch.float64, device="cuda")
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        elapsed = float(t.item())
+    elapsed = batch.max_over_ranks(elapsed)
 
     T = 2 * args.grid * args.grid
     value = T * K * world / elapsed
@@ -181,8 +169,7 @@ def main():
             except Exception as e:  # the oracle is optional test infrastructure; never fail the GPU number on it
                 out["cpu_baseline"] = {"value": None, "unit": "element-steps/s", "cores": os.cpu_count(), "kind": "port", "sample": f"failed: {e}"}
         print(json.dumps(out), flush=True)
-    if dist is not None:
-        dist.destroy_process_group()
+    batch.close()
 
 
 if __name__ == "__main__":
