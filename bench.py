@@ -161,7 +161,8 @@ def main():
         ach = prof["bytes_per_launch"] / (prof["ms_per_launch"] * 1e-3) / 1e9
         out["roofline"] = {"bound": "hbm", "achieved": ach, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": ach / HBM_PEAK_GBS, "traffic": None,
                            "kernel": "k_spmv (SELL-64 3x3-block SpMV, one launch per PCG iteration)",
-                           "bytes_per_launch": prof["bytes_per_launch"], "avg_launch_us": prof["ms_per_launch"] * 1e3, "launches": prof["launches"]}
+                           "bytes_per_launch": prof["bytes_per_launch"], "avg_launch_us": prof["ms_per_launch"] * 1e3,
+                           "avg_launch_us_hip_events": prof["ms_per_launch_events"] * 1e3, "launches": prof["launches"]}
     if rank == 0:
         if world == 1 and not args.no_cpu_baseline:
             try:

@@ -145,9 +145,12 @@ int tsl_proj_import(tsl_ctx* ctx, const int32_t* proj_flag_host, const int32_t* 
 int tsl_spd_project(tsl_ctx* ctx, double* blocks_dev, int32_t n_blocks, int32_t D);
 
 /* Timing of the dominant kernel for bench.py's roofline object: HIP-event time (ms) accumulated over the
- * PCG iteration kernels since the last reset, launch count and the bytes one iteration moves algorithmically. */
+ * PCG iteration kernels since the last reset, launch count and the bytes one iteration moves algorithmically.
+ * Sampled launches (1 in 16) are timed twice: by the device wall clock inside the kernel (min start / max end over waves =
+ * the duration a kernel trace reports) and by a hipEvent pair around the launch on the engine stream. */
 int tsl_profile_reset(tsl_ctx* ctx, int enable);
 int tsl_profile_read(tsl_ctx* ctx, double* spmv_ms_host, int64_t* spmv_launches_host, int64_t* spmv_bytes_per_launch_host);
+int tsl_profile_read_events(tsl_ctx* ctx, double* spmv_ms_hip_events_host); /* same launches bracketed by hipEvents (includes launch gaps) */
 
 #ifdef __cplusplus
 }

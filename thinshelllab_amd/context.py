@@ -200,4 +200,6 @@ class TslContext:
     def profile_read(self):
         ms = C.c_double(0); n = C.c_int64(0); b = C.c_int64(0)
         check(self.L.tsl_profile_read(self.h, C.byref(ms), C.byref(n), C.byref(b)), "tsl_profile_read")
-        return dict(ms_per_launch=ms.value, launches=n.value, bytes_per_launch=b.value)
+        ev = C.c_double(0)
+        check(self.L.tsl_profile_read_events(self.h, C.byref(ev)), "tsl_profile_read_events")
+        return dict(ms_per_launch=ms.value, launches=n.value, bytes_per_launch=b.value, ms_per_launch_events=ev.value)

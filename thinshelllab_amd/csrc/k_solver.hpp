@@ -73,8 +73,12 @@ __global__ void k_scatter_perm(int NV, const int* __restrict__ perm, const doubl
 // This is the dominant kernel of the engine (one launch per PCG iteration).
 __global__ void __launch_bounds__(256)
 k_spmv(int NV, int n_slices, const int* __restrict__ slice_off, const int* __restrict__ slice_len, const int* __restrict__ colidx,
-       const double* __restrict__ vals, const double* __restrict__ x, double* __restrict__ y, CgScal* sc, int slot, int check_flag) {
+       const double* __restrict__ vals, const double* __restrict__ x, double* __restrict__ y, CgScal* sc, int slot, int check_flag,
+       unsigned long long* prof) {
   if (check_flag && sc->flag) return;
+  // sampled launches record their own execution span with the constant-rate device clock (min start / max end over waves)
+  unsigned long long t_start = 0;
+  if (prof) t_start = wall_clock64();
   const int p = blockIdx.x * blockDim.x + threadIdx.x;
   const int slice = p >> 6, lane = p & 63;
   double acc = 0.0;
@@ -103,6 +107,11 @@ k_spmv(int NV, int n_slices, const int* __restrict__ slice_off, const int* __res
     acc = wave_sum(acc);
     if ((threadIdx.x & 63) == 0 && acc != 0.0) atomicAdd(&sc->pAp[slot], acc);
     if (p == 0) { const int z = (slot + 2) & 3; sc->pAp[z] = 0; sc->rzn[z] = 0; sc->rr[z] = 0; }
+  }
+  if (prof && (threadIdx.x & 63) == 0) {  // one slot pair per wave: plain stores, reduced on the host
+    const size_t w = (size_t)blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
+    prof[2 * w] = t_start;
+    prof[2 * w + 1] = (unsigned long long)wall_clock64();
   }
 }
 

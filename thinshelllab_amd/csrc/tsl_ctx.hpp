@@ -152,6 +152,10 @@ struct tsl_ctx {
   hipEvent_t ev0 = nullptr, ev1 = nullptr;
   double prof_ms = 0;
   long prof_launches = 0, prof_samples = 0;
+  DevBuf<unsigned long long> prof_dev;  // per sampled launch: min start / max end of the device wall clock
+  long prof_dev_used = 0, prof_dev_cap = 512;
+  size_t prof_waves = 0;
+  double prof_event_ms = 0;
   std::vector<std::pair<hipEvent_t, hipEvent_t>> ev_pool;
   size_t ev_used = 0;
 

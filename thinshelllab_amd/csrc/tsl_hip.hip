@@ -388,8 +388,10 @@ static void launch_spmv(tsl_ctx* c, const double* vals, const double* x, double*
   hipStream_t s = c->stream;
   const bool sample = c->prof_enable && slot >= 0 && (c->prof_launches % 16 == 0) && c->ev_used < c->ev_pool.size();
   if (sample) (void)hipEventRecord(c->ev_pool[c->ev_used].first, s);
+  unsigned long long* dprof = nullptr;
+  if (c->prof_enable && slot >= 0 && (c->prof_launches % 64 == 40) && c->prof_dev_used < c->prof_dev_cap) dprof = c->prof_dev.p + 2 * c->prof_waves * (c->prof_dev_used++);
   hipLaunchKernelGGL(k_spmv, dim3(nblk((long)c->n_slices * 64, 256)), dim3(256), 0, s, c->NV, c->n_slices, c->slice_off.p, c->slice_len.p, c->colidx.p, vals, x, y,
-                     SC(c), slot, check_flag);
+                     SC(c), slot, check_flag, dprof);
   if (sample) { (void)hipEventRecord(c->ev_pool[c->ev_used].second, s); c->ev_used++; }
   if (slot >= 0) c->prof_launches++;
   if (c->nc > 0)
@@ -498,10 +500,24 @@ static int bicgstab(tsl_ctx* c, tsl_solve_stats* st) {
   double rho = 1, alpha = 1, omega = 1;
   const double tol2 = c->cg_tol * c->cg_tol * bb;
   st->flag = 3;
+  int restarts_left = 50;
+  auto restart = [&]() -> int {  // breakdown (rho or omega vanished): restart the recurrence from the current residual
+    HIP_OK(hipMemcpyAsync(r0, r, n3 * sizeof(double), hipMemcpyDeviceToDevice, s));
+    HIP_OK(hipMemsetAsync(p, 0, n3 * sizeof(double), s));
+    HIP_OK(hipMemsetAsync(v, 0, n3 * sizeof(double), s));
+    rho = alpha = omega = 1;
+    st->restarts++;
+    return 0;
+  };
   for (int it = 0; it < c->cg_maxit; it++) {
     double rho_new;
     TSL_TRY(dots(r0, r, nullptr, nullptr, &rho_new, nullptr));
-    if (rho_new == 0 || omega == 0) break;
+    if (fabs(rho_new) < 1e-300 || omega == 0 || !std::isfinite(rho_new)) {
+      if (restarts_left-- <= 0 || !std::isfinite(rho_new)) break;
+      TSL_TRY(restart());
+      TSL_TRY(dots(r0, r, nullptr, nullptr, &rho_new, nullptr));
+      if (!(fabs(rho_new) > 0)) break;
+    }
     const double beta = (rho_new / rho) * (alpha / omega);
     rho = rho_new;
     // p = r + beta (p - omega v)
@@ -511,7 +527,7 @@ static int bicgstab(tsl_ctx* c, tsl_solve_stats* st) {
     launch_spmv(c, c->vals.p, ph, v, -1, 0);
     double r0v;
     TSL_TRY(dots(r0, v, nullptr, nullptr, &r0v, nullptr));
-    if (r0v == 0) break;
+    if (r0v == 0) { if (restarts_left-- <= 0) break; TSL_TRY(restart()); continue; }
     alpha = rho / r0v;
     // s = r - alpha v
     HIP_OK(hipMemcpyAsync(sv, r, n3 * sizeof(double), hipMemcpyDeviceToDevice, s));
@@ -649,7 +665,13 @@ extern "C" int tsl_matrix_export(tsl_ctx* c, int32_t* row_ptr, int32_t* col, dou
 }
 
 extern "C" int tsl_profile_reset(tsl_ctx* c, int enable) {
-  c->prof_enable = enable; c->prof_ms = 0; c->prof_launches = 0; c->prof_samples = 0; c->ev_used = 0;
+  c->prof_enable = enable; c->prof_ms = 0; c->prof_launches = 0; c->prof_samples = 0; c->ev_used = 0; c->prof_dev_used = 0;
+  if (enable) {
+    c->prof_waves = (size_t)nblk((long)c->n_slices * 64, 256) * 4;
+    c->prof_dev_cap = 512;
+    if (c->prof_dev.n == 0) TSL_TRY(c->prof_dev.alloc(2 * c->prof_waves * (size_t)c->prof_dev_cap));
+    HIP_OK(hipMemset(c->prof_dev.p, 0, c->prof_dev.n * sizeof(unsigned long long)));
+  }
   if (enable && c->ev_pool.empty()) {
     for (int i = 0; i < 64; i++) {
       hipEvent_t a, b;
@@ -663,10 +685,35 @@ extern "C" int tsl_profile_reset(tsl_ctx* c, int enable) {
 extern "C" int tsl_profile_read(tsl_ctx* c, double* ms_per_launch, int64_t* launches, int64_t* bytes_per_launch) {
   HIP_OK(hipStreamSynchronize(c->stream));
   prof_collect(c);
-  *ms_per_launch = c->prof_samples ? c->prof_ms / c->prof_samples : 0.0;
+  // device-clock spans of the sampled launches (what a kernel trace reports as the kernel duration)
+  double dev_ms = 0;
+  long n_dev = 0;
+  if (c->prof_dev_used > 0) {
+    std::vector<unsigned long long> h(2 * c->prof_waves * (size_t)c->prof_dev_used);
+    HIP_OK(hipMemcpy(h.data(), c->prof_dev.p, h.size() * sizeof(unsigned long long), hipMemcpyDeviceToHost));
+    int dev = 0, khz = 100000;
+    (void)hipGetDevice(&dev);
+    if (hipDeviceGetAttribute(&khz, hipDeviceAttributeWallClockRate, dev) != hipSuccess || khz <= 0) khz = 100000;
+    for (long i = 0; i < c->prof_dev_used; i++) {
+      unsigned long long t0 = ~0ull, t1 = 0;
+      for (size_t w = 0; w < c->prof_waves; w++) {
+        const unsigned long long a = h[2 * (i * c->prof_waves + w)], b = h[2 * (i * c->prof_waves + w) + 1];
+        if (b == 0) continue;  // wave of an early-returned launch
+        t0 = std::min(t0, a); t1 = std::max(t1, b);
+      }
+      if (t1 > t0) { dev_ms += (double)(t1 - t0) / (double)khz; n_dev++; }
+    }
+  }
+  c->prof_event_ms = c->prof_samples ? c->prof_ms / c->prof_samples : 0.0;
+  *ms_per_launch = n_dev ? dev_ms / n_dev : c->prof_event_ms;
   *launches = c->prof_launches;
   // algorithmic bytes of one SpMV: every stored block (72 B values + 4 B column id) + x gather + y store per row
   *bytes_per_launch = (int64_t)c->nnzb * 76 + (int64_t)c->NV * (24 + 24);
+  return 0;
+}
+
+extern "C" int tsl_profile_read_events(tsl_ctx* c, double* ms_per_launch_events) {
+  *ms_per_launch_events = c->prof_event_ms;
   return 0;
 }
 
