@@ -353,6 +353,33 @@ __global__ void k_contact_matvec(int nc, const int* __restrict__ idx, const int*
   }
 }
 
+// same product for the two-kernel PCG: dot(x, H_c x) goes to a per-block partial (deterministic reduction)
+__global__ void __launch_bounds__(64)
+k_contact_matvec_part(int nc, const int* __restrict__ idx, const int* __restrict__ rowpos, const double* __restrict__ Hm, const double* __restrict__ x,
+                      double* __restrict__ y, double* __restrict__ part, const int* __restrict__ flag) {
+  if (*flag) return;
+  const int ci = blockIdx.x * blockDim.x + threadIdx.x;
+  double acc = 0;
+  if (ci < nc) {
+    int pr[4];
+    double xv[12];
+    for (int k = 0; k < 4; k++) {
+      pr[k] = rowpos[idx[4 * ci + k]];
+      const d3 v = ld3(x, pr[k]);
+      xv[3 * k] = v.x; xv[3 * k + 1] = v.y; xv[3 * k + 2] = v.z;
+    }
+    const double* H = Hm + 144 * (size_t)ci;
+    for (int r = 0; r < 12; r++) {
+      double s = 0;
+      for (int c = 0; c < 12; c++) s += H[r * 12 + c] * xv[c];
+      if (s != 0.0) atomicAdd(&y[3 * (size_t)pr[r / 3] + (r % 3)], s);
+      acc += s * xv[r];
+    }
+  }
+  acc = wave_sum(acc);
+  if (threadIdx.x == 0) part[blockIdx.x] = acc;
+}
+
 // tmp_z_frozen[j] -= H_ij z_i for i free, j frozen (second compute_Hessian pass of transfer_grad,
 // BaseScene.py:403-405 / analytic_grad_single.py:239-243), contact part; z, out in ORIGINAL order
 __global__ void k_contact_zfrozen(int nc, const int* __restrict__ idx, const int* __restrict__ frozen, const double* __restrict__ Hfull, const double* __restrict__ z,

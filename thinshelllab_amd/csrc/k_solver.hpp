@@ -115,6 +115,245 @@ k_spmv(int NV, int n_slices, const int* __restrict__ slice_off, const int* __res
   }
 }
 
+// Variant with WPS waves per slice: wave w of a slice handles block columns k = w, w+WPS, ... (more loads in flight per
+// row: 784 single-wave slices cannot fill 1024 SIMDs at 100k triangles), partial row sums are combined through LDS.
+// NT: matrix values / column ids are streamed with non-temporal loads so that they do not evict the x vector from L2.
+// part != nullptr: the block's dot(x, y) partial is stored to part[blockIdx.x] (deterministic two-stage reduction, no
+// same-address atomics).  blockDim.x = 64 * WPS * SPB (SPB slices per block).
+template <int WPS, int SPB, bool NT>
+__global__ void __launch_bounds__(64 * WPS * SPB)
+k_spmv_mw(int NV, int n_slices, const int* __restrict__ slice_off, const int* __restrict__ slice_len, const int* __restrict__ colidx,
+          const double* __restrict__ vals, const double* __restrict__ x, double* __restrict__ y, double* __restrict__ part, const int* __restrict__ flag) {
+  __shared__ double red[SPB][WPS][3][64];
+  __shared__ double dred[SPB];
+  if (flag && *flag) return;
+  const int lane = threadIdx.x & 63;
+  const int wv = threadIdx.x >> 6;
+  const int sl = wv / WPS, w = wv % WPS;
+  const int slice = blockIdx.x * SPB + sl;
+  double y0 = 0, y1 = 0, y2 = 0;
+  if (slice < n_slices) {
+    const int off = slice_off[slice], len = slice_len[slice];
+    const int* cp = colidx + off + lane;
+    const double* vp = vals + (size_t)off * 9 + lane;
+#pragma unroll 2
+    for (int k = w; k < len; k += WPS) {
+      const double* a = vp + (size_t)k * 576;
+      int c;
+      double a0, a1, a2, a3, a4, a5, a6, a7, a8;
+      if (NT) {
+        c = __builtin_nontemporal_load(cp + 64 * k);
+        a0 = __builtin_nontemporal_load(a); a1 = __builtin_nontemporal_load(a + 64); a2 = __builtin_nontemporal_load(a + 128);
+        a3 = __builtin_nontemporal_load(a + 192); a4 = __builtin_nontemporal_load(a + 256); a5 = __builtin_nontemporal_load(a + 320);
+        a6 = __builtin_nontemporal_load(a + 384); a7 = __builtin_nontemporal_load(a + 448); a8 = __builtin_nontemporal_load(a + 512);
+      } else {
+        c = cp[64 * k];
+        a0 = a[0]; a1 = a[64]; a2 = a[128]; a3 = a[192]; a4 = a[256]; a5 = a[320]; a6 = a[384]; a7 = a[448]; a8 = a[512];
+      }
+      const d3 xj = ld3(x, c);
+      y0 += a0 * xj.x + a1 * xj.y + a2 * xj.z;
+      y1 += a3 * xj.x + a4 * xj.y + a5 * xj.z;
+      y2 += a6 * xj.x + a7 * xj.y + a8 * xj.z;
+    }
+  }
+  if (WPS > 1) {
+    red[sl][w][0][lane] = y0; red[sl][w][1][lane] = y1; red[sl][w][2][lane] = y2;
+    __syncthreads();
+  }
+  double acc = 0.0;
+  if (w == 0 && slice < n_slices) {
+    if (WPS > 1) {
+#pragma unroll
+      for (int q = 1; q < WPS; q++) { y0 += red[sl][q][0][lane]; y1 += red[sl][q][1][lane]; y2 += red[sl][q][2][lane]; }
+    }
+    const int p = slice * 64 + lane;
+    if (p < NV) {
+      st3(y, p, d3(y0, y1, y2));
+      const d3 xi = ld3(x, p);
+      acc = xi.x * y0 + xi.y * y1 + xi.z * y2;
+    }
+  }
+  if (part) {
+    acc = wave_sum(acc);
+    if (w == 0 && lane == 0) dred[sl] = acc;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+      double t = 0;
+#pragma unroll
+      for (int q = 0; q < SPB; q++) t += dred[q];
+      part[blockIdx.x] = t;
+    }
+  }
+}
+
+// ---------------------------------------------------------------------------------------------------------------------
+// Two-kernel PCG iteration with deterministic two-stage reductions (no same-address atomics: 784 waves adding into one
+// double cost 7 us per kernel on MI355X).  Iteration k:
+//   K1 = k_pcg_spmv  : rz_k = sum(part_rz), rr_k = sum(part_rr)  [every block re-reduces the <= PCG_MAXPART partials];
+//                      stop if rr_k <= thresh2;  beta = rz_k / rz_{k-1};  p_k = z_k + beta p_{k-1} formed on the fly for the
+//                      row and for every gathered neighbour (ping-pong p buffers);  Ap_k = H p_k;  part_pAp[block] = p_k.Ap_k
+//   K2 = k_pcg_update: pAp = sum(part_pAp); alpha = rz_k / pAp (breakdown if pAp <= 0);  x += alpha p_k;  r -= alpha Ap_k;
+//                      z_{k+1} = Dinv r;  part_rz[block] = r.z, part_rr[block] = r.r
+#define PCG_MAXPART 1024
+struct PcgScal {
+  double rzh[2];      // rz history, slot k & 1 written by K1(k)
+  double thresh2, bb;
+  double rr_last, rz_last, pAp_last;
+  int flag, iters;    // flag: 0 running, 1 breakdown, 2 converged
+  int n_part1, n_part2;
+};
+
+TSL_DEV double block_reduce_partials(const double* __restrict__ part, int n, double* sm) {
+  double v = 0;
+  for (int i = threadIdx.x; i < n; i += blockDim.x) v += part[i];
+  // fixed-order tree: wave shuffle then LDS
+  v = wave_sum(v);
+  const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+  if (lane == 0) sm[w] = v;
+  __syncthreads();
+  double t = 0;
+  const int nw = blockDim.x >> 6;
+  for (int q = 0; q < nw; q++) t += sm[q];
+  __syncthreads();
+  return t;
+}
+
+template <int WPS, bool NT>
+__global__ void __launch_bounds__(64 * WPS)
+k_pcg_spmv(int NV, int n_slices, const int* __restrict__ slice_off, const int* __restrict__ slice_len, const int* __restrict__ colidx,
+           const double* __restrict__ vals, const double* __restrict__ z, const double* __restrict__ p_old, double* __restrict__ p_new,
+           double* __restrict__ Ap, const double* __restrict__ part_rz, const double* __restrict__ part_rr, double* __restrict__ part_pAp,
+           PcgScal* sc, int it, unsigned long long* prof) {
+  __shared__ double red[WPS][3][64];
+  __shared__ double sm[WPS + 1];
+  if (sc->flag) return;
+  unsigned long long t_start = 0;
+  if (prof) t_start = wall_clock64();
+  double rz, rr;
+  {  // both reductions in one pass (one LDS round trip)
+    const int n = sc->n_part2;
+    double v0 = 0, v1 = 0;
+    for (int i = threadIdx.x; i < n; i += blockDim.x) { v0 += part_rz[i]; v1 += part_rr[i]; }
+    v0 = wave_sum(v0); v1 = wave_sum(v1);
+    __shared__ double s2[2][WPS];
+    if ((threadIdx.x & 63) == 0) { s2[0][threadIdx.x >> 6] = v0; s2[1][threadIdx.x >> 6] = v1; }
+    __syncthreads();
+    rz = 0; rr = 0;
+#pragma unroll
+    for (int q = 0; q < WPS; q++) { rz += s2[0][q]; rr += s2[1][q]; }
+  }
+  if (rr <= sc->thresh2) {
+    if (blockIdx.x == 0 && threadIdx.x == 0) { sc->flag = 2; sc->iters = it; sc->rr_last = rr; }
+    return;
+  }
+  const double beta = (it == 0) ? 0.0 : rz / sc->rzh[(it + 1) & 1];
+  if (blockIdx.x == 0 && threadIdx.x == 0) { sc->rzh[it & 1] = rz; sc->rr_last = rr; sc->rz_last = rz; }
+  const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+  const int slice = blockIdx.x;
+  const int off = slice_off[slice], len = slice_len[slice];
+  const int* cp = colidx + off + lane;
+  const double* vp = vals + (size_t)off * 9 + lane;
+  double y0 = 0, y1 = 0, y2 = 0;
+#pragma unroll 2
+  for (int k = w; k < len; k += WPS) {
+    const double* a = vp + (size_t)k * 576;
+    int c;
+    double a0, a1, a2, a3, a4, a5, a6, a7, a8;
+    if (NT) {
+      c = __builtin_nontemporal_load(cp + 64 * k);
+      a0 = __builtin_nontemporal_load(a); a1 = __builtin_nontemporal_load(a + 64); a2 = __builtin_nontemporal_load(a + 128);
+      a3 = __builtin_nontemporal_load(a + 192); a4 = __builtin_nontemporal_load(a + 256); a5 = __builtin_nontemporal_load(a + 320);
+      a6 = __builtin_nontemporal_load(a + 384); a7 = __builtin_nontemporal_load(a + 448); a8 = __builtin_nontemporal_load(a + 512);
+    } else {
+      c = cp[64 * k];
+      a0 = a[0]; a1 = a[64]; a2 = a[128]; a3 = a[192]; a4 = a[256]; a5 = a[320]; a6 = a[384]; a7 = a[448]; a8 = a[512];
+    }
+    d3 pj = ld3(z, c);
+    if (it != 0) pj = pj + beta * ld3(p_old, c);
+    y0 += a0 * pj.x + a1 * pj.y + a2 * pj.z;
+    y1 += a3 * pj.x + a4 * pj.y + a5 * pj.z;
+    y2 += a6 * pj.x + a7 * pj.y + a8 * pj.z;
+  }
+  if (WPS > 1) {
+    red[w][0][lane] = y0; red[w][1][lane] = y1; red[w][2][lane] = y2;
+    __syncthreads();
+  }
+  double acc = 0.0;
+  if (w == 0) {
+#pragma unroll
+    for (int q = 1; q < WPS; q++) { y0 += red[q][0][lane]; y1 += red[q][1][lane]; y2 += red[q][2][lane]; }
+    const int p = slice * 64 + lane;
+    if (p < NV) {
+      d3 pi = ld3(z, p);
+      if (it != 0) pi = pi + beta * ld3(p_old, p);
+      st3(p_new, p, pi);
+      st3(Ap, p, d3(y0, y1, y2));
+      acc = pi.x * y0 + pi.y * y1 + pi.z * y2;
+    }
+    acc = wave_sum(acc);
+    if (lane == 0) part_pAp[blockIdx.x] = acc;
+  }
+  if (prof && lane == 0) {
+    const size_t wi = (size_t)blockIdx.x * WPS + w;
+    prof[2 * wi] = t_start;
+    prof[2 * wi + 1] = (unsigned long long)wall_clock64();
+  }
+}
+
+// K2; also used (first = 1) to start / restart: r = b - Ax (Ax may be null), z = Dinv r, partials, no x update
+__global__ void __launch_bounds__(256)
+k_pcg_update(int NV, const double* __restrict__ pv, const double* __restrict__ Ap, const double* __restrict__ Dinv, double* __restrict__ x,
+             double* __restrict__ r, double* __restrict__ z, const double* __restrict__ part_pAp, double* __restrict__ part_rz, double* __restrict__ part_rr,
+             PcgScal* sc, int it, const double* __restrict__ b_init, const double* __restrict__ Ax_init) {
+  __shared__ double sm[8];
+  double alpha = 0;
+  if (!b_init) {
+    if (sc->flag) return;
+    const double pAp = block_reduce_partials(part_pAp, sc->n_part1, sm);
+    const double rz = sc->rzh[it & 1];
+    if (!(pAp > 0.0) || !(rz > 0.0)) {
+      if (blockIdx.x == 0 && threadIdx.x == 0) { sc->flag = 1; sc->iters = it; sc->pAp_last = pAp; }
+      return;
+    }
+    alpha = rz / pAp;
+  }
+  const int p = blockIdx.x * blockDim.x + threadIdx.x;
+  double rzn = 0, rr = 0;
+  if (p < NV) {
+    d3 rv;
+    if (b_init) {
+      rv = ld3(b_init, p);
+      if (Ax_init) rv = rv - ld3(Ax_init, p);
+    } else {
+      const d3 pp = ld3(pv, p);
+      st3(x, p, ld3(x, p) + alpha * pp);
+      rv = ld3(r, p) - alpha * ld3(Ap, p);
+    }
+    m3 D;
+#pragma unroll
+    for (int e = 0; e < 9; e++) D.m[e] = Dinv[9 * (size_t)p + e];
+    const d3 zv = m3_mulv(D, rv);
+    st3(r, p, rv); st3(z, p, zv);
+    rzn = dot(rv, zv); rr = dot(rv, rv);
+  }
+  rzn = wave_sum(rzn); rr = wave_sum(rr);
+  const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+  __shared__ double s1[4], s2[4];
+  if (lane == 0) { s1[w] = rzn; s2[w] = rr; }
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    part_rz[blockIdx.x] = s1[0] + s1[1] + s1[2] + s1[3];
+    part_rr[blockIdx.x] = s2[0] + s2[1] + s2[2] + s2[3];
+  }
+}
+
+// sum of a partial array into out[0] (host convergence probes)
+__global__ void k_sum_partials(const double* __restrict__ part, int n, double* out) {
+  __shared__ double sm[8];
+  const double t = block_reduce_partials(part, n, sm);
+  if (threadIdx.x == 0) out[0] = t;
+}
+
 // r = b - Ax ; z = Dinv r ; p = z ; rzn[3] = r.z ; rr[3] = r.r   (start / restart of PCG)
 __global__ void k_cg_init(int NV, const double* __restrict__ b, const double* __restrict__ Ax, const double* __restrict__ Dinv,
                           double* __restrict__ r, double* __restrict__ z, double* __restrict__ pv, CgScal* sc) {

@@ -121,6 +121,7 @@ struct tsl_ctx {
   // ---- solver vectors (permuted AoS, 3*NV)
   DevBuf<double> v_x, v_r, v_z, v_p, v_Ap, v_b, v_t0, v_t1, v_t2, v_t3, v_t4;
   DevBuf<SolverScalars> scal;
+  DevBuf<double> part_pAp, part_rz, part_rr;  // per-block partial sums of the two-kernel PCG iteration
   SolverScalars* h_scal = nullptr;  // pinned
 
   // ---- Newton scratch (original order)

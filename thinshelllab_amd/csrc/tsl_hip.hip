@@ -240,6 +240,7 @@ extern "C" int tsl_ctx_create(const tsl_scene_desc* d, tsl_ctx** out) {
   rc |= c->v_t0.alloc(n3); rc |= c->v_t1.alloc(n3); rc |= c->v_t2.alloc(n3); rc |= c->v_t3.alloc(n3); rc |= c->v_t4.alloc(n3);
   rc |= c->F.alloc(n3); rc |= c->pdir.alloc(n3); rc |= c->x1.alloc(n3);
   rc |= c->scal.alloc(1);
+  rc |= c->part_pAp.alloc((size_t)P.n_slices + (size_t)(c->max_n_constraints + 63) / 64 + 8); rc |= c->part_rz.alloc((size_t)NV / 256 + 8); rc |= c->part_rr.alloc((size_t)NV / 256 + 8);
   if (rc) { delete c; return -1; }
   if (hipHostMalloc((void**)&c->h_scal, sizeof(SolverScalars) > sizeof(CgScal) ? sizeof(SolverScalars) : sizeof(CgScal)) != hipSuccess) { delete c; return tsl_fail("hipHostMalloc failed"); }
   c->vals.zero(); c->vals_full.zero(); c->scal.zero();
@@ -416,6 +417,31 @@ static int read_scal(tsl_ctx* c) {
 
 static int bicgstab(tsl_ctx* c, tsl_solve_stats* st);
 
+#define PCG_WPS 4
+static PcgScal* PSC(tsl_ctx* c) { return (PcgScal*)c->scal.p; }
+static PcgScal* HPSC(tsl_ctx* c) { return (PcgScal*)c->h_scal; }
+
+// one PCG iteration = K1 (+ matrix-free contact product) + K2, see k_solver.hpp
+static void launch_pcg_iteration(tsl_ctx* c, int it) {
+  hipStream_t s = c->stream;
+  const int NV = c->NV, ns = c->n_slices;
+  double* p_new = (it & 1) ? c->v_t0.p : c->v_p.p;
+  const double* p_old = (it & 1) ? c->v_p.p : c->v_t0.p;
+  unsigned long long* dprof = nullptr;
+  if (c->prof_enable && (c->prof_launches % 64 == 40) && c->prof_dev_used < c->prof_dev_cap) dprof = c->prof_dev.p + 2 * c->prof_waves * (c->prof_dev_used++);
+  const bool sample = c->prof_enable && (c->prof_launches % 64 == 8) && c->ev_used < c->ev_pool.size();
+  if (sample) (void)hipEventRecord(c->ev_pool[c->ev_used].first, s);
+  hipLaunchKernelGGL((k_pcg_spmv<PCG_WPS, true>), dim3(ns), dim3(64 * PCG_WPS), 0, s, NV, ns, c->slice_off.p, c->slice_len.p, c->colidx.p, c->vals.p, c->v_z.p, p_old, p_new,
+                     c->v_Ap.p, c->part_rz.p, c->part_rr.p, c->part_pAp.p, PSC(c), it, dprof);
+  if (sample) { (void)hipEventRecord(c->ev_pool[c->ev_used].second, s); c->ev_used++; }
+  c->prof_launches++;
+  if (c->nc > 0)
+    hipLaunchKernelGGL(k_contact_matvec_part, dim3(nblk(c->nc, 64)), dim3(64), 0, s, c->nc, c->c_idx.p, c->rowpos.p, c->c_H.p, p_new, c->v_Ap.p, c->part_pAp.p + ns,
+                       &PSC(c)->flag);
+  hipLaunchKernelGGL(k_pcg_update, dim3(nblk(NV, 256)), dim3(256), 0, s, NV, p_new, c->v_Ap.p, c->Dinv.p, c->v_x.p, c->v_r.p, c->v_z.p, c->part_pAp.p, c->part_rz.p, c->part_rr.p,
+                     PSC(c), it, (const double*)nullptr, (const double*)nullptr);
+}
+
 // Solve with rhs already in v_b (permuted); result in v_x (permuted).
 static int solve_perm(tsl_ctx* c, tsl_solve_stats* st) {
   hipStream_t s = c->stream;
@@ -424,7 +450,7 @@ static int solve_perm(tsl_ctx* c, tsl_solve_stats* st) {
   const int gb = nblk(NV, 256);
   st->iters = 0; st->restarts = 0; st->flag = 0; st->rel_residual = 0;
   HIP_OK(hipMemsetAsync(c->v_x.p, 0, n3 * sizeof(double), s));
-  HIP_OK(hipMemsetAsync(c->scal.p, 0, sizeof(CgScal), s));
+  HIP_OK(hipMemsetAsync(c->scal.p, 0, sizeof(SolverScalars), s));
   hipLaunchKernelGGL(k_dot, dim3(gsz(n3)), dim3(256), 0, s, n3, c->v_b.p, c->v_b.p, &SC(c)->bb);
   TSL_TRY(read_scal(c));
   const double bb = HSC(c)->bb;
@@ -432,39 +458,35 @@ static int solve_perm(tsl_ctx* c, tsl_solve_stats* st) {
   const double tol2 = c->cg_tol * c->cg_tol * bb;
   bool need_fallback = false;
   int total_it = 0;
+  const int ncb = c->nc > 0 ? nblk(c->nc, 64) : 0;
   for (int outer = 0; outer < 20; outer++) {
-    // true residual, restart vectors
-    CgScal hs;
+    PcgScal hs;
     memset(&hs, 0, sizeof(hs));
-    hs.bb = bb; hs.thresh2 = 0.25 * tol2;
-    HIP_OK(hipMemcpyAsync(c->scal.p, &hs, sizeof(CgScal), hipMemcpyHostToDevice, s));
+    hs.bb = bb; hs.thresh2 = 0.25 * tol2; hs.n_part1 = c->n_slices + ncb; hs.n_part2 = gb;
+    HIP_OK(hipMemcpyAsync(c->scal.p, &hs, sizeof(PcgScal), hipMemcpyHostToDevice, s));
     if (outer > 0) launch_spmv(c, c->vals.p, c->v_x.p, c->v_Ap.p, -1, 0);
-    hipLaunchKernelGGL(k_cg_init, dim3(gb), dim3(256), 0, s, NV, c->v_b.p, outer > 0 ? c->v_Ap.p : (const double*)nullptr, c->Dinv.p, c->v_r.p, c->v_z.p, c->v_p.p, SC(c));
+    // true residual, z = Dinv r, partial r.z / r.r
+    hipLaunchKernelGGL(k_pcg_update, dim3(gb), dim3(256), 0, s, NV, (const double*)nullptr, (const double*)nullptr, c->Dinv.p, c->v_x.p, c->v_r.p, c->v_z.p, c->part_pAp.p,
+                       c->part_rz.p, c->part_rr.p, PSC(c), 0, c->v_b.p, outer > 0 ? c->v_Ap.p : (const double*)nullptr);
+    hipLaunchKernelGGL(k_sum_partials, dim3(1), dim3(256), 0, s, c->part_rr.p, gb, &PSC(c)->rr_last);
+    hipLaunchKernelGGL(k_sum_partials, dim3(1), dim3(256), 0, s, c->part_rz.p, gb, &PSC(c)->rz_last);
     TSL_TRY(read_scal(c));
-    const double rr0 = HSC(c)->rr[3];
+    const double rr0 = HPSC(c)->rr_last;
     st->rel_residual = sqrt(rr0 / bb);
     if (rr0 <= tol2) { need_fallback = false; break; }
-    if (!(HSC(c)->rzn[3] > 0)) { need_fallback = true; break; }
+    if (!(HPSC(c)->rz_last > 0)) { need_fallback = true; break; }
     if (outer > 0) st->restarts++;
     need_fallback = true;
-    int flag = 0;
+    int flag = 0, it = 0;
     while (total_it < c->cg_maxit) {
       const int chunk = std::min(c->cg_check, c->cg_maxit - total_it);
-      for (int i = 0; i < chunk; i++, total_it++) {
-        const int slot = total_it & 3;
-        launch_spmv(c, c->vals.p, c->v_p.p, c->v_Ap.p, slot, 1);
-        hipLaunchKernelGGL(k_cg_update, dim3(gb), dim3(256), 0, s, NV, c->v_p.p, c->v_Ap.p, c->Dinv.p, c->v_x.p, c->v_r.p, c->v_z.p, SC(c), slot);
-        hipLaunchKernelGGL(k_cg_p, dim3(gb), dim3(256), 0, s, NV, c->v_z.p, c->v_p.p, SC(c), slot, total_it);
-      }
+      for (int i = 0; i < chunk; i++, it++, total_it++) launch_pcg_iteration(c, it);
       TSL_TRY(read_scal(c));
-      flag = HSC(c)->flag;
+      flag = HPSC(c)->flag;
       if (flag) break;
     }
-    // NOTE: slot bookkeeping restarts at 0 on every outer pass because k_cg_init rewrites slot 3 and the host
-    // clears the record; keep total_it aligned to a multiple of 4
-    if (flag == 2) st->iters += HSC(c)->iters - (st->iters); else st->iters = total_it;
-    total_it = (total_it + 3) & ~3;
-    if (flag == 1 || flag == 0) break;  // breakdown or iteration cap
+    if (flag) total_it = total_it - it + HPSC(c)->iters;  // iterations actually executed before the kernels went idle
+    if (flag != 2) break;  // breakdown or iteration cap
   }
   st->iters = total_it;
   if (!need_fallback) { st->flag = 0; return 0; }
@@ -667,7 +689,7 @@ extern "C" int tsl_matrix_export(tsl_ctx* c, int32_t* row_ptr, int32_t* col, dou
 extern "C" int tsl_profile_reset(tsl_ctx* c, int enable) {
   c->prof_enable = enable; c->prof_ms = 0; c->prof_launches = 0; c->prof_samples = 0; c->ev_used = 0; c->prof_dev_used = 0;
   if (enable) {
-    c->prof_waves = (size_t)nblk((long)c->n_slices * 64, 256) * 4;
+    c->prof_waves = (size_t)c->n_slices * PCG_WPS;
     c->prof_dev_cap = 512;
     if (c->prof_dev.n == 0) TSL_TRY(c->prof_dev.alloc(2 * c->prof_waves * (size_t)c->prof_dev_cap));
     HIP_OK(hipMemset(c->prof_dev.p, 0, c->prof_dev.n * sizeof(unsigned long long)));
@@ -714,6 +736,58 @@ extern "C" int tsl_profile_read(tsl_ctx* c, double* ms_per_launch, int64_t* laun
 
 extern "C" int tsl_profile_read_events(tsl_ctx* c, double* ms_per_launch_events) {
   *ms_per_launch_events = c->prof_event_ms;
+  return 0;
+}
+
+// micro-benchmark of the SpMV variants on the currently assembled matrix: average microseconds per launch over reps
+// back-to-back launches bracketed by one hipEvent pair (includes ~1.5 us dependent-launch gaps)
+extern "C" int tsl_bench_spmv(tsl_ctx* c, int variant, int reps, double* us_per_launch) {
+  hipStream_t s = c->stream;
+  hipEvent_t e0, e1;
+  HIP_OK(hipEventCreate(&e0)); HIP_OK(hipEventCreate(&e1));
+  const int ns = c->n_slices;
+  if (c->v_t4.n < (size_t)ns) return tsl_fail("scratch too small");
+  auto launch = [&]() {
+    switch (variant) {
+      case 0: hipLaunchKernelGGL(k_spmv, dim3(nblk((long)ns * 64, 256)), dim3(256), 0, s, c->NV, ns, c->slice_off.p, c->slice_len.p, c->colidx.p, c->vals.p, c->v_p.p, c->v_Ap.p, SC(c), 0, 0, (unsigned long long*)nullptr); break;
+      case 1: hipLaunchKernelGGL((k_spmv_mw<1, 4, false>), dim3(nblk(ns, 4)), dim3(256), 0, s, c->NV, ns, c->slice_off.p, c->slice_len.p, c->colidx.p, c->vals.p, c->v_p.p, c->v_Ap.p, c->v_t4.p, (const int*)nullptr); break;
+      case 2: hipLaunchKernelGGL((k_spmv_mw<4, 1, false>), dim3(ns), dim3(256), 0, s, c->NV, ns, c->slice_off.p, c->slice_len.p, c->colidx.p, c->vals.p, c->v_p.p, c->v_Ap.p, c->v_t4.p, (const int*)nullptr); break;
+      case 3: hipLaunchKernelGGL((k_spmv_mw<4, 1, true>), dim3(ns), dim3(256), 0, s, c->NV, ns, c->slice_off.p, c->slice_len.p, c->colidx.p, c->vals.p, c->v_p.p, c->v_Ap.p, c->v_t4.p, (const int*)nullptr); break;
+      case 4: hipLaunchKernelGGL((k_spmv_mw<2, 2, false>), dim3(nblk(ns, 2)), dim3(256), 0, s, c->NV, ns, c->slice_off.p, c->slice_len.p, c->colidx.p, c->vals.p, c->v_p.p, c->v_Ap.p, c->v_t4.p, (const int*)nullptr); break;
+      case 5: hipLaunchKernelGGL((k_spmv_mw<8, 1, false>), dim3(ns), dim3(512), 0, s, c->NV, ns, c->slice_off.p, c->slice_len.p, c->colidx.p, c->vals.p, c->v_p.p, c->v_Ap.p, c->v_t4.p, (const int*)nullptr); break;
+      case 6: hipLaunchKernelGGL((k_spmv_mw<4, 2, false>), dim3(nblk(ns, 2)), dim3(512), 0, s, c->NV, ns, c->slice_off.p, c->slice_len.p, c->colidx.p, c->vals.p, c->v_p.p, c->v_Ap.p, c->v_t4.p, (const int*)nullptr); break;
+      case 7: hipLaunchKernelGGL((k_spmv_mw<2, 2, true>), dim3(nblk(ns, 2)), dim3(256), 0, s, c->NV, ns, c->slice_off.p, c->slice_len.p, c->colidx.p, c->vals.p, c->v_p.p, c->v_Ap.p, c->v_t4.p, (const int*)nullptr); break;
+      case 10: hipLaunchKernelGGL(k_spmv, dim3(nblk((long)ns * 64, 256)), dim3(256), 0, s, c->NV, ns, c->slice_off.p, c->slice_len.p, c->colidx.p, c->vals.p, c->v_p.p, c->v_Ap.p, SC(c), 0, 1, (unsigned long long*)nullptr); break;
+      case 11: hipLaunchKernelGGL(k_spmv, dim3(nblk((long)ns * 64, 256)), dim3(256), 0, s, c->NV, ns, c->slice_off.p, c->slice_len.p, c->colidx.p, c->vals.p, c->v_p.p, c->v_Ap.p, SC(c), -1, 0, (unsigned long long*)nullptr); break;
+      case 12: {  // one full PCG iteration body (never converges: thresh2 = 0)
+        hipLaunchKernelGGL(k_spmv, dim3(nblk((long)ns * 64, 256)), dim3(256), 0, s, c->NV, ns, c->slice_off.p, c->slice_len.p, c->colidx.p, c->vals.p, c->v_p.p, c->v_Ap.p, SC(c), 0, 1, (unsigned long long*)nullptr);
+        hipLaunchKernelGGL(k_cg_update, dim3(nblk(c->NV, 256)), dim3(256), 0, s, c->NV, c->v_p.p, c->v_Ap.p, c->Dinv.p, c->v_x.p, c->v_r.p, c->v_z.p, SC(c), 0);
+        hipLaunchKernelGGL(k_cg_p, dim3(nblk(c->NV, 256)), dim3(256), 0, s, c->NV, c->v_z.p, c->v_p.p, SC(c), 0, 0);
+      } break;
+      case 13: hipLaunchKernelGGL(k_cg_update, dim3(nblk(c->NV, 256)), dim3(256), 0, s, c->NV, c->v_p.p, c->v_Ap.p, c->Dinv.p, c->v_x.p, c->v_r.p, c->v_z.p, SC(c), 0); break;
+      case 14: hipLaunchKernelGGL(k_cg_p, dim3(nblk(c->NV, 256)), dim3(256), 0, s, c->NV, c->v_z.p, c->v_p.p, SC(c), 0, 0); break;
+      default: break;
+    }
+  };
+  {  // valid solver state: p = z = r = b (whatever v_b holds, must be non-zero), scalars of a running iteration
+    const size_t n3 = 3 * (size_t)c->NV;
+    HIP_OK(hipMemcpyAsync(c->v_p.p, c->v_b.p, n3 * sizeof(double), hipMemcpyDeviceToDevice, s));
+    HIP_OK(hipMemcpyAsync(c->v_r.p, c->v_b.p, n3 * sizeof(double), hipMemcpyDeviceToDevice, s));
+    HIP_OK(hipMemcpyAsync(c->v_z.p, c->v_b.p, n3 * sizeof(double), hipMemcpyDeviceToDevice, s));
+    CgScal hs;
+    memset(&hs, 0, sizeof(hs));
+    hs.rzn[3] = 1e-30; hs.rzn[0] = 1e-30; hs.pAp[0] = 1.0; hs.thresh2 = -1.0;
+    HIP_OK(hipMemcpyAsync(c->scal.p, &hs, sizeof(CgScal), hipMemcpyHostToDevice, s));
+  }
+  for (int i = 0; i < 10; i++) launch();
+  HIP_OK(hipEventRecord(e0, s));
+  for (int i = 0; i < reps; i++) launch();
+  HIP_OK(hipEventRecord(e1, s));
+  HIP_OK(hipEventSynchronize(e1));
+  float ms = 0;
+  HIP_OK(hipEventElapsedTime(&ms, e0, e1));
+  *us_per_launch = (double)ms * 1e3 / reps;
+  (void)hipEventDestroy(e0); (void)hipEventDestroy(e1);
   return 0;
 }
 
