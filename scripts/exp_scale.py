@@ -11,6 +11,9 @@ for a in sys.argv[1:] or ["32", "71"]:
     s.init_all()
     ctx = s._ensure_ctx()
     ctx.set_param("cg_maxit", 400000)
+    for kv in os.environ.get("TSL_PARAMS", "").split(","):
+        if "=" in kv:
+            ctx.set_param(kv.split("=")[0], float(kv.split("=")[1]))
     ctx.profile_reset(True)
     for step in range(2):
         torch.cuda.synchronize(); t = time.time()

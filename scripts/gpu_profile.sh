@@ -5,4 +5,4 @@ export TMPDIR=/tmp
 mkdir -p gpurun_out/prof
 rocprofv3 --kernel-trace --stats --output-format csv -d gpurun_out/prof -o bench -- python bench.py --steps 1 --warmup 0 --no-cpu-baseline > gpurun_out/prof/bench_stdout.log 2>&1
 tail -2 gpurun_out/prof/bench_stdout.log
-find gpurun_out/prof -name "*stats*" | head
+rm -f gpurun_out/prof/*kernel_trace.csv; ls gpurun_out/prof

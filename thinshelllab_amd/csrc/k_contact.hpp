@@ -501,9 +501,10 @@ static int contact_alloc(tsl_ctx* c, const tsl_scene_desc* d) {
   return 0;
 }
 
-extern "C" int tsl_contact_reset(tsl_ctx* c) { return c->proj_flag.zero(c->stream); }
+extern "C" int tsl_contact_reset(tsl_ctx* c) { Scope scope(c); return c->proj_flag.zero(c->stream); }
 
 extern "C" int tsl_contact_detect(tsl_ctx* c, const double* pos, const double* prev, int32_t* nc_host) {
+  Scope scope(c);
   hipStream_t s = c->stream;
   const int NV = c->NV;
   c->nc = 0;
@@ -563,6 +564,7 @@ static int contact_assemble(tsl_ctx* c, const double* pos, int spd, double* grad
 }
 
 extern "C" int tsl_constraints_export(tsl_ctx* c, int32_t* idx, double* w, double* k, double* dx0, double* T, double* n, double* mu, int32_t max_n) {
+  Scope scope(c);
   HIP_OK(hipStreamSynchronize(c->stream));
   const int m = std::min(c->nc, (int)max_n);
   if (m <= 0) return 0;
@@ -577,6 +579,7 @@ extern "C" int tsl_constraints_export(tsl_ctx* c, int32_t* idx, double* w, doubl
 }
 
 extern "C" int tsl_contact_blocks_export(tsl_ctx* c, double* blocks_host, int32_t max_n, int32_t masked) {
+  Scope scope(c);
   HIP_OK(hipStreamSynchronize(c->stream));
   const int m = std::min(c->nc, (int)max_n);
   if (m <= 0) return 0;
@@ -585,6 +588,7 @@ extern "C" int tsl_contact_blocks_export(tsl_ctx* c, double* blocks_host, int32_
 }
 
 extern "C" int tsl_proj_export(tsl_ctx* c, int32_t* flag, int32_t* dir, int32_t* pidx, double* pw) {
+  Scope scope(c);
   HIP_OK(hipStreamSynchronize(c->stream));
   const size_t n = (size_t)std::max(c->n_body, 1) * c->NV;
   HIP_OK(hipMemcpy(flag, c->proj_flag.p, n * sizeof(int), hipMemcpyDeviceToHost));
@@ -595,6 +599,8 @@ extern "C" int tsl_proj_export(tsl_ctx* c, int32_t* flag, int32_t* dir, int32_t*
 }
 
 extern "C" int tsl_proj_import(tsl_ctx* c, const int32_t* flag, const int32_t* dir) {
+  Scope scope(c);
+  (void)hipStreamSynchronize(c->stream);
   const size_t n = (size_t)std::max(c->n_body, 1) * c->NV;
   HIP_OK(hipMemcpy(c->proj_flag.p, flag, n * sizeof(int), hipMemcpyHostToDevice));
   HIP_OK(hipMemcpy(c->proj_dir.p, dir, n * sizeof(int), hipMemcpyHostToDevice));

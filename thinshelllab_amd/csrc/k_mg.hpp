@@ -1,0 +1,379 @@
+// Geometric multigrid preconditioner for the cloth block of the system matrix (no reference counterpart: the
+// reference factorises the matrix with cupyx spsolve, sparse_solver.py:85-105; block-Jacobi PCG needs O(N) iterations on
+// an N x N cloth because the membrane stiffness 2Kl/dx dominates the inertia m/dt^2 by ~0.01/dx^3).
+//
+// The cloth is a regular (N+1) x (M+1) vertex grid, so the hierarchy is geometric: level l+1 keeps every second
+// vertex, prolongation P is bilinear interpolation of the 3-vector displacement field, coarse operators are Galerkin
+// products A_{l+1} = P^T A_l P recomputed after every assembly.  Level 0 is the global SELL-64 operator (all bodies +
+// matrix-free contact blocks); FEM vertices and contact couplings are only smoothed there.  Levels >= 1 are stored as a
+// radius-2 block stencil (25 slots x 9 doubles per vertex, slot-major / SoA so that every load of a wave is contiguous).
+// Cycle: V(nu,nu) with damped block-Jacobi smoothing (symmetric => the preconditioner is SPD and PCG stays valid).
+#pragma once
+#include "k_solver.hpp"
+#include "tsl_ctx.hpp"
+#include "tsl_device.hpp"
+
+// bilinear weights of fine index i onto coarse indices: i even -> (i/2, 1); i odd -> (i/2, 1/2), (i/2 + 1, 1/2)
+TSL_DEV int mg_coarse(int i, int q, double& w) {
+  if ((i & 1) == 0) { w = (q == 0) ? 1.0 : 0.0; return i >> 1; }
+  w = 0.5;
+  return (i >> 1) + q;
+}
+
+struct MgGrid { int N, M; };  // cells; vertices (N+1) x (M+1), index i*(M+1)+j
+
+// ---- stencil-level kernels (levels >= 1).  A[(s*9+e)*n + row], s = (dI+2)*5 + (dJ+2)
+__global__ void k_st_spmv(MgGrid g, const double* __restrict__ A, const double* __restrict__ x, double* __restrict__ y) {
+  const int n = (g.N + 1) * (g.M + 1);
+  const int row = blockIdx.x * blockDim.x + threadIdx.x;
+  if (row >= n) return;
+  const int I = row / (g.M + 1), J = row % (g.M + 1);
+  double y0 = 0, y1 = 0, y2 = 0;
+#pragma unroll
+  for (int dI = -2; dI <= 2; dI++) {
+    const int I2 = I + dI;
+    if (I2 < 0 || I2 > g.N) continue;
+#pragma unroll
+    for (int dJ = -2; dJ <= 2; dJ++) {
+      const int J2 = J + dJ;
+      if (J2 < 0 || J2 > g.M) continue;
+      const int s = (dI + 2) * 5 + (dJ + 2);
+      const double* a = A + (size_t)s * 9 * n + row;
+      const d3 xj = ld3(x, I2 * (g.M + 1) + J2);
+      y0 += a[0] * xj.x + a[(size_t)n] * xj.y + a[2 * (size_t)n] * xj.z;
+      y1 += a[3 * (size_t)n] * xj.x + a[4 * (size_t)n] * xj.y + a[5 * (size_t)n] * xj.z;
+      y2 += a[6 * (size_t)n] * xj.x + a[7 * (size_t)n] * xj.y + a[8 * (size_t)n] * xj.z;
+    }
+  }
+  st3(y, row, d3(y0, y1, y2));
+}
+
+// 5 lanes per row (one per stencil row dI): 64 rows x 5 = 320 threads per block; partial sums meet in LDS.
+// FUSE = 0: y = A x.   FUSE = 1: x_out = x + omega * Dinv * (r - A x)  (one damped-Jacobi sweep, ping-pong buffers).
+template <int FUSE>
+__global__ void __launch_bounds__(320)
+k_st_spmv5(MgGrid g, const double* __restrict__ A, const double* __restrict__ x, double* __restrict__ y, const double* __restrict__ Dinv,
+           const double* __restrict__ r, const double* __restrict__ omega_dev) {
+  __shared__ double red[5][3][64];
+  const int n = (g.N + 1) * (g.M + 1);
+  const int lane = threadIdx.x & 63, q = threadIdx.x >> 6;  // q = dI + 2
+  const int row = blockIdx.x * 64 + lane;
+  double y0 = 0, y1 = 0, y2 = 0;
+  if (row < n) {
+    const int I = row / (g.M + 1), J = row % (g.M + 1);
+    const int I2 = I + q - 2;
+    if (I2 >= 0 && I2 <= g.N) {
+#pragma unroll
+      for (int dJ = -2; dJ <= 2; dJ++) {
+        const int J2 = J + dJ;
+        if (J2 < 0 || J2 > g.M) continue;
+        const int s = q * 5 + (dJ + 2);
+        const double* a = A + (size_t)s * 9 * n + row;
+        const d3 xj = ld3(x, I2 * (g.M + 1) + J2);
+        y0 += a[0] * xj.x + a[(size_t)n] * xj.y + a[2 * (size_t)n] * xj.z;
+        y1 += a[3 * (size_t)n] * xj.x + a[4 * (size_t)n] * xj.y + a[5 * (size_t)n] * xj.z;
+        y2 += a[6 * (size_t)n] * xj.x + a[7 * (size_t)n] * xj.y + a[8 * (size_t)n] * xj.z;
+      }
+    }
+  }
+  red[q][0][lane] = y0; red[q][1][lane] = y1; red[q][2][lane] = y2;
+  __syncthreads();
+  if (q == 0 && row < n) {
+#pragma unroll
+    for (int k = 1; k < 5; k++) { y0 += red[k][0][lane]; y1 += red[k][1][lane]; y2 += red[k][2][lane]; }
+    if (FUSE) {
+      m3 D;
+#pragma unroll
+      for (int e = 0; e < 9; e++) D.m[e] = Dinv[9 * (size_t)row + e];
+      const d3 res = ld3(r, row) - d3(y0, y1, y2);
+      st3(y, row, ld3(x, row) + (*omega_dev) * m3_mulv(D, res));
+    } else {
+      st3(y, row, d3(y0, y1, y2));
+    }
+  }
+}
+
+// x = omega * Dinv * r   (first smoothing sweep from a zero guess)
+__global__ void k_mg_jacobi_first(int n, const double* __restrict__ Dinv, const double* __restrict__ r, const double* __restrict__ omega_dev, double* __restrict__ x) {
+  const int p = blockIdx.x * blockDim.x + threadIdx.x;
+  if (p >= n) return;
+  const double omega = *omega_dev;
+  m3 D;
+#pragma unroll
+  for (int e = 0; e < 9; e++) D.m[e] = Dinv[9 * (size_t)p + e];
+  st3(x, p, omega * m3_mulv(D, ld3(r, p)));
+}
+
+// x += omega * Dinv * (r - t), t = A x_old  (further sweeps); optional partial dot(rdot, x_new) per block
+__global__ void __launch_bounds__(256)
+k_mg_jacobi_next(int n, const double* __restrict__ Dinv, const double* __restrict__ r, const double* __restrict__ t, const double* __restrict__ omega_dev, double* __restrict__ x,
+                 const double* __restrict__ rdot, double* __restrict__ part) {
+  const int p = blockIdx.x * blockDim.x + threadIdx.x;
+  const double omega = *omega_dev;
+  double acc = 0;
+  if (p < n) {
+    m3 D;
+#pragma unroll
+    for (int e = 0; e < 9; e++) D.m[e] = Dinv[9 * (size_t)p + e];
+    const d3 xn = ld3(x, p) + omega * m3_mulv(D, ld3(r, p) - ld3(t, p));
+    st3(x, p, xn);
+    if (rdot) acc = dot(ld3(rdot, p), xn);
+  }
+  if (part) {
+    __shared__ double s1[4];
+    acc = wave_sum(acc);
+    if ((threadIdx.x & 63) == 0) s1[threadIdx.x >> 6] = acc;
+    __syncthreads();
+    if (threadIdx.x == 0) part[blockIdx.x] = s1[0] + s1[1] + s1[2] + s1[3];
+  }
+}
+
+// rc = P^T (r - t) from a fine STENCIL level (t may be null)
+__global__ void k_st_restrict(MgGrid gf, const double* __restrict__ r, const double* __restrict__ t, double* __restrict__ rc) {
+  const int Nc = gf.N >> 1, Mc = gf.M >> 1;
+  const int nc = (Nc + 1) * (Mc + 1);
+  const int row = blockIdx.x * blockDim.x + threadIdx.x;
+  if (row >= nc) return;
+  const int I = row / (Mc + 1), J = row % (Mc + 1);
+  d3 acc = d3();
+#pragma unroll
+  for (int di = -1; di <= 1; di++) {
+    const int i = 2 * I + di;
+    if (i < 0 || i > gf.N) continue;
+#pragma unroll
+    for (int dj = -1; dj <= 1; dj++) {
+      const int j = 2 * J + dj;
+      if (j < 0 || j > gf.M) continue;
+      const double w = (di == 0 ? 1.0 : 0.5) * (dj == 0 ? 1.0 : 0.5);
+      const int f = i * (gf.M + 1) + j;
+      d3 v = ld3(r, f);
+      if (t) v = v - ld3(t, f);
+      acc = acc + w * v;
+    }
+  }
+  st3(rc, row, acc);
+}
+
+// x_f += P x_c on a fine STENCIL level
+__global__ void k_st_prolong_add(MgGrid gf, const double* __restrict__ xc, double* __restrict__ x) {
+  const int n = (gf.N + 1) * (gf.M + 1);
+  const int Mc = gf.M >> 1;
+  const int f = blockIdx.x * blockDim.x + threadIdx.x;
+  if (f >= n) return;
+  const int i = f / (gf.M + 1), j = f % (gf.M + 1);
+  d3 acc = d3();
+#pragma unroll
+  for (int a = 0; a < 2; a++) {
+    double wa; const int I = mg_coarse(i, a, wa);
+    if (wa == 0.0) continue;
+#pragma unroll
+    for (int b = 0; b < 2; b++) {
+      double wb; const int J = mg_coarse(j, b, wb);
+      if (wb == 0.0) continue;
+      acc = acc + (wa * wb) * ld3(xc, I * (Mc + 1) + J);
+    }
+  }
+  st3(x, f, ld3(x, f) + acc);
+}
+
+// same two transfers between level 0 (global permuted vectors) and level 1 of one cloth
+__global__ void k_mg_restrict0(MgGrid gf, int v_offset, const int* __restrict__ rowpos, const double* __restrict__ r, const double* __restrict__ t,
+                               double* __restrict__ rc) {
+  const int Nc = gf.N >> 1, Mc = gf.M >> 1;
+  const int nc = (Nc + 1) * (Mc + 1);
+  const int row = blockIdx.x * blockDim.x + threadIdx.x;
+  if (row >= nc) return;
+  const int I = row / (Mc + 1), J = row % (Mc + 1);
+  d3 acc = d3();
+#pragma unroll
+  for (int di = -1; di <= 1; di++) {
+    const int i = 2 * I + di;
+    if (i < 0 || i > gf.N) continue;
+#pragma unroll
+    for (int dj = -1; dj <= 1; dj++) {
+      const int j = 2 * J + dj;
+      if (j < 0 || j > gf.M) continue;
+      const double w = (di == 0 ? 1.0 : 0.5) * (dj == 0 ? 1.0 : 0.5);
+      const int p = rowpos[v_offset + i * (gf.M + 1) + j];
+      acc = acc + w * (ld3(r, p) - ld3(t, p));
+    }
+  }
+  st3(rc, row, acc);
+}
+__global__ void k_mg_prolong0_add(MgGrid gf, int v_offset, const int* __restrict__ rowpos, const double* __restrict__ xc, double* __restrict__ x) {
+  const int n = (gf.N + 1) * (gf.M + 1);
+  const int Mc = gf.M >> 1;
+  const int f = blockIdx.x * blockDim.x + threadIdx.x;
+  if (f >= n) return;
+  const int i = f / (gf.M + 1), j = f % (gf.M + 1);
+  d3 acc = d3();
+#pragma unroll
+  for (int a = 0; a < 2; a++) {
+    double wa; const int I = mg_coarse(i, a, wa);
+    if (wa == 0.0) continue;
+#pragma unroll
+    for (int b = 0; b < 2; b++) {
+      double wb; const int J = mg_coarse(j, b, wb);
+      if (wb == 0.0) continue;
+      acc = acc + (wa * wb) * ld3(xc, I * (Mc + 1) + J);
+    }
+  }
+  const int p = rowpos[v_offset + f];
+  st3(x, p, ld3(x, p) + acc);
+}
+
+// ---- Galerkin products
+TSL_DEV void galerkin_scatter(MgGrid gf, int i, int j, int i2, int j2, const double* B, double* __restrict__ Ac, int nc) {
+  const int Mc = gf.M >> 1;
+#pragma unroll
+  for (int a = 0; a < 2; a++) {
+    double wa; const int I = mg_coarse(i, a, wa);
+    if (wa == 0.0) continue;
+#pragma unroll
+    for (int b = 0; b < 2; b++) {
+      double wb; const int J = mg_coarse(j, b, wb);
+      if (wb == 0.0) continue;
+      const int row = I * (Mc + 1) + J;
+#pragma unroll
+      for (int a2 = 0; a2 < 2; a2++) {
+        double wa2; const int I2 = mg_coarse(i2, a2, wa2);
+        if (wa2 == 0.0) continue;
+#pragma unroll
+        for (int b2 = 0; b2 < 2; b2++) {
+          double wb2; const int J2 = mg_coarse(j2, b2, wb2);
+          if (wb2 == 0.0) continue;
+          const int s = (I2 - I + 2) * 5 + (J2 - J + 2);
+          const double w = wa * wb * wa2 * wb2;
+          double* dst = Ac + (size_t)s * 9 * nc + row;
+#pragma unroll
+          for (int e = 0; e < 9; e++) atomicAdd(dst + (size_t)e * nc, w * B[e]);
+        }
+      }
+    }
+  }
+}
+
+// level 0 (SELL-64, masked values) -> level 1 of the cloth occupying global vertices [v_offset, v_offset + (N+1)(M+1))
+__global__ void k_galerkin0(MgGrid gf, int v_offset, int NV, int n_slices, const int* __restrict__ slice_off, const int* __restrict__ slice_len,
+                            const int* __restrict__ colidx, const int* __restrict__ perm, const double* __restrict__ vals, double* __restrict__ Ac) {
+  const int slice = blockIdx.x, lane = threadIdx.x & 63;
+  if (slice >= n_slices) return;
+  const int p = slice * 64 + lane;
+  if (p >= NV) return;
+  const int nf = (gf.N + 1) * (gf.M + 1);
+  const int v = perm[p] - v_offset;
+  if (v < 0 || v >= nf) return;
+  const int i = v / (gf.M + 1), j = v % (gf.M + 1);
+  const int nc = ((gf.N >> 1) + 1) * ((gf.M >> 1) + 1);
+  const int off = slice_off[slice], len = slice_len[slice];
+  for (int k = threadIdx.x >> 6; k < len; k += (blockDim.x >> 6)) {
+    const int c = colidx[off + 64 * k + lane];
+    const int u = perm[c] - v_offset;
+    if (u < 0 || u >= nf) continue;
+    const int i2 = u / (gf.M + 1), j2 = u % (gf.M + 1);
+    if (abs(i2 - i) > 2 || abs(j2 - j) > 2) continue;  // padded slots point at row 0/1 with zero values
+    const size_t base = ((size_t)off + 64 * (size_t)k) * 9 + lane;
+    double B[9];
+    bool nz = false;
+#pragma unroll
+    for (int e = 0; e < 9; e++) { B[e] = vals[base + 64 * e]; nz |= (B[e] != 0.0); }
+    if (nz) galerkin_scatter(gf, i, j, i2, j2, B, Ac, nc);
+  }
+}
+
+// extra diagonal blocks of the fine level (masked contact contribution, permuted row order) into level 1
+__global__ void k_galerkin0_diag(MgGrid gf, int v_offset, const int* __restrict__ rowpos, const double* __restrict__ cdiag, double* __restrict__ Ac) {
+  const int nf = (gf.N + 1) * (gf.M + 1);
+  const int f = blockIdx.x * blockDim.x + threadIdx.x;
+  if (f >= nf) return;
+  const int i = f / (gf.M + 1), j = f % (gf.M + 1);
+  const int nc = ((gf.N >> 1) + 1) * ((gf.M >> 1) + 1);
+  double B[9];
+  bool nz = false;
+  const size_t p = (size_t)rowpos[v_offset + f];
+#pragma unroll
+  for (int e = 0; e < 9; e++) { B[e] = cdiag[9 * p + e]; nz |= (B[e] != 0.0); }
+  if (nz) galerkin_scatter(gf, i, j, i, j, B, Ac, nc);
+}
+
+// stencil level l -> l+1
+__global__ void k_galerkin_st(MgGrid gf, const double* __restrict__ Af, double* __restrict__ Ac) {
+  const int nf = (gf.N + 1) * (gf.M + 1);
+  const int t = blockIdx.x * blockDim.x + threadIdx.x;
+  const int row = t % nf, s = t / nf;
+  if (s >= 25) return;
+  const int i = row / (gf.M + 1), j = row % (gf.M + 1);
+  const int i2 = i + s / 5 - 2, j2 = j + s % 5 - 2;
+  if (i2 < 0 || i2 > gf.N || j2 < 0 || j2 > gf.M) return;
+  const int nc = ((gf.N >> 1) + 1) * ((gf.M >> 1) + 1);
+  double B[9];
+  bool nz = false;
+#pragma unroll
+  for (int e = 0; e < 9; e++) { B[e] = Af[((size_t)s * 9 + e) * nf + row]; nz |= (B[e] != 0.0); }
+  if (nz) galerkin_scatter(gf, i, j, i2, j2, B, Ac, nc);
+}
+
+// Dinv of a stencil level (centre slot 12)
+__global__ void k_st_diag_inv(int n, const double* __restrict__ A, double* __restrict__ Dinv) {
+  const int row = blockIdx.x * blockDim.x + threadIdx.x;
+  if (row >= n) return;
+  m3 D;
+#pragma unroll
+  for (int e = 0; e < 9; e++) D.m[e] = A[((size_t)12 * 9 + e) * n + row];
+  const m3 Di = m3_inv(D);
+#pragma unroll
+  for (int e = 0; e < 9; e++) Dinv[9 * (size_t)row + e] = Di.m[e];
+}
+
+// x (+)= alpha-free helpers on level-0 vectors
+__global__ void k_part_dot(int n, const double* __restrict__ a, const double* __restrict__ b, double* __restrict__ part) {
+  const int p = blockIdx.x * blockDim.x + threadIdx.x;
+  double acc = (p < n) ? dot(ld3(a, p), ld3(b, p)) : 0.0;
+  __shared__ double s1[4];
+  acc = wave_sum(acc);
+  if ((threadIdx.x & 63) == 0) s1[threadIdx.x >> 6] = acc;
+  __syncthreads();
+  if (threadIdx.x == 0) part[blockIdx.x] = s1[0] + s1[1] + s1[2] + s1[3];
+}
+
+// ---- damping factor from a power iteration on D^-1 A (device resident, no host round trip)
+// v0: deterministic pseudo-random start vector
+__global__ void k_pi_init(int n, double* __restrict__ v) {
+  const int p = blockIdx.x * blockDim.x + threadIdx.x;
+  if (p >= n) return;
+  const double a = sin(12.9898 * p + 1.0) * 43758.5453, b = sin(78.233 * p + 2.0) * 12345.678, c = sin(39.425 * p + 3.0) * 9876.543;
+  st3(v, p, d3(a - floor(a) - 0.5, b - floor(b) - 0.5, c - floor(c) - 0.5));
+}
+// w = Dinv t ; part[block] = |w|^2
+__global__ void __launch_bounds__(256)
+k_pi_apply(int n, const double* __restrict__ Dinv, const double* __restrict__ t, double* __restrict__ w, double* __restrict__ part) {
+  const int p = blockIdx.x * blockDim.x + threadIdx.x;
+  double acc = 0;
+  if (p < n) {
+    m3 D;
+#pragma unroll
+    for (int e = 0; e < 9; e++) D.m[e] = Dinv[9 * (size_t)p + e];
+    const d3 wv = m3_mulv(D, ld3(t, p));
+    st3(w, p, wv);
+    acc = dot(wv, wv);
+  }
+  __shared__ double s1[4];
+  acc = wave_sum(acc);
+  if ((threadIdx.x & 63) == 0) s1[threadIdx.x >> 6] = acc;
+  __syncthreads();
+  if (threadIdx.x == 0) part[blockIdx.x] = s1[0] + s1[1] + s1[2] + s1[3];
+}
+// norm2[k] = sum(part); on the last call omega = c_omega / sqrt(norm2[k] / norm2[k-1])
+__global__ void k_pi_finish(const double* __restrict__ part, int nparts, double* __restrict__ norm2, int k, int last, double c_omega, double omega_max, double* __restrict__ omega_out) {
+  __shared__ double sm[8];
+  const double t = block_reduce_partials(part, nparts, sm);
+  if (threadIdx.x == 0) {
+    norm2[k] = t;
+    if (last) {
+      const double lam = sqrt(t / norm2[k - 1]);
+      double om = (lam > 0.0 && isfinite(lam)) ? c_omega / lam : omega_max;
+      omega_out[0] = fmin(om, omega_max);
+      omega_out[1] = lam;
+    }
+  }
+}

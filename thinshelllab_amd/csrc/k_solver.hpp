@@ -223,7 +223,7 @@ __global__ void __launch_bounds__(64 * WPS)
 k_pcg_spmv(int NV, int n_slices, const int* __restrict__ slice_off, const int* __restrict__ slice_len, const int* __restrict__ colidx,
            const double* __restrict__ vals, const double* __restrict__ z, const double* __restrict__ p_old, double* __restrict__ p_new,
            double* __restrict__ Ap, const double* __restrict__ part_rz, const double* __restrict__ part_rr, double* __restrict__ part_pAp,
-           PcgScal* sc, int it, unsigned long long* prof) {
+           PcgScal* sc, int parity, int first, unsigned long long* prof) {
   __shared__ double red[WPS][3][64];
   __shared__ double sm[WPS + 1];
   if (sc->flag) return;
@@ -243,11 +243,11 @@ k_pcg_spmv(int NV, int n_slices, const int* __restrict__ slice_off, const int* _
     for (int q = 0; q < WPS; q++) { rz += s2[0][q]; rr += s2[1][q]; }
   }
   if (rr <= sc->thresh2) {
-    if (blockIdx.x == 0 && threadIdx.x == 0) { sc->flag = 2; sc->iters = it; sc->rr_last = rr; }
+    if (blockIdx.x == 0 && threadIdx.x == 0) { sc->flag = 2; sc->rr_last = rr; }
     return;
   }
-  const double beta = (it == 0) ? 0.0 : rz / sc->rzh[(it + 1) & 1];
-  if (blockIdx.x == 0 && threadIdx.x == 0) { sc->rzh[it & 1] = rz; sc->rr_last = rr; sc->rz_last = rz; }
+  const double beta = first ? 0.0 : rz / sc->rzh[parity ^ 1];
+  if (blockIdx.x == 0 && threadIdx.x == 0) { sc->rzh[parity] = rz; sc->rr_last = rr; sc->rz_last = rz; sc->iters = sc->iters + 1; }
   const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
   const int slice = blockIdx.x;
   const int off = slice_off[slice], len = slice_len[slice];
@@ -269,7 +269,7 @@ k_pcg_spmv(int NV, int n_slices, const int* __restrict__ slice_off, const int* _
       a0 = a[0]; a1 = a[64]; a2 = a[128]; a3 = a[192]; a4 = a[256]; a5 = a[320]; a6 = a[384]; a7 = a[448]; a8 = a[512];
     }
     d3 pj = ld3(z, c);
-    if (it != 0) pj = pj + beta * ld3(p_old, c);
+    if (!first) pj = pj + beta * ld3(p_old, c);
     y0 += a0 * pj.x + a1 * pj.y + a2 * pj.z;
     y1 += a3 * pj.x + a4 * pj.y + a5 * pj.z;
     y2 += a6 * pj.x + a7 * pj.y + a8 * pj.z;
@@ -285,7 +285,7 @@ k_pcg_spmv(int NV, int n_slices, const int* __restrict__ slice_off, const int* _
     const int p = slice * 64 + lane;
     if (p < NV) {
       d3 pi = ld3(z, p);
-      if (it != 0) pi = pi + beta * ld3(p_old, p);
+      if (!first) pi = pi + beta * ld3(p_old, p);
       st3(p_new, p, pi);
       st3(Ap, p, d3(y0, y1, y2));
       acc = pi.x * y0 + pi.y * y1 + pi.z * y2;
@@ -300,19 +300,28 @@ k_pcg_spmv(int NV, int n_slices, const int* __restrict__ slice_off, const int* _
   }
 }
 
+// end-of-chunk convergence test (one block): without it the converged state is only seen by K1 of the NEXT chunk,
+// i.e. after a whole chunk of idle launches
+__global__ void __launch_bounds__(256) k_pcg_check(const double* __restrict__ part_rr, PcgScal* sc) {
+  __shared__ double sm[8];
+  if (sc->flag) return;
+  const double rr = block_reduce_partials(part_rr, sc->n_part2, sm);
+  if (threadIdx.x == 0 && rr <= sc->thresh2) { sc->flag = 2; sc->rr_last = rr; }
+}
+
 // K2; also used (first = 1) to start / restart: r = b - Ax (Ax may be null), z = Dinv r, partials, no x update
 __global__ void __launch_bounds__(256)
 k_pcg_update(int NV, const double* __restrict__ pv, const double* __restrict__ Ap, const double* __restrict__ Dinv, double* __restrict__ x,
              double* __restrict__ r, double* __restrict__ z, const double* __restrict__ part_pAp, double* __restrict__ part_rz, double* __restrict__ part_rr,
-             PcgScal* sc, int it, const double* __restrict__ b_init, const double* __restrict__ Ax_init) {
+             PcgScal* sc, int parity, const double* __restrict__ b_init, const double* __restrict__ Ax_init, int use_dinv) {
   __shared__ double sm[8];
   double alpha = 0;
   if (!b_init) {
     if (sc->flag) return;
     const double pAp = block_reduce_partials(part_pAp, sc->n_part1, sm);
-    const double rz = sc->rzh[it & 1];
+    const double rz = sc->rzh[parity];
     if (!(pAp > 0.0) || !(rz > 0.0)) {
-      if (blockIdx.x == 0 && threadIdx.x == 0) { sc->flag = 1; sc->iters = it; sc->pAp_last = pAp; }
+      if (blockIdx.x == 0 && threadIdx.x == 0) { sc->flag = 1; sc->pAp_last = pAp; }
       return;
     }
     alpha = rz / pAp;
@@ -329,12 +338,16 @@ k_pcg_update(int NV, const double* __restrict__ pv, const double* __restrict__ A
       st3(x, p, ld3(x, p) + alpha * pp);
       rv = ld3(r, p) - alpha * ld3(Ap, p);
     }
-    m3 D;
+    st3(r, p, rv);
+    rr = dot(rv, rv);
+    if (use_dinv) {
+      m3 D;
 #pragma unroll
-    for (int e = 0; e < 9; e++) D.m[e] = Dinv[9 * (size_t)p + e];
-    const d3 zv = m3_mulv(D, rv);
-    st3(r, p, rv); st3(z, p, zv);
-    rzn = dot(rv, zv); rr = dot(rv, rv);
+      for (int e = 0; e < 9; e++) D.m[e] = Dinv[9 * (size_t)p + e];
+      const d3 zv = m3_mulv(D, rv);
+      st3(z, p, zv);
+      rzn = dot(rv, zv);
+    }
   }
   rzn = wave_sum(rzn); rr = wave_sum(rr);
   const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
@@ -342,7 +355,7 @@ k_pcg_update(int NV, const double* __restrict__ pv, const double* __restrict__ A
   if (lane == 0) { s1[w] = rzn; s2[w] = rr; }
   __syncthreads();
   if (threadIdx.x == 0) {
-    part_rz[blockIdx.x] = s1[0] + s1[1] + s1[2] + s1[3];
+    if (use_dinv) part_rz[blockIdx.x] = s1[0] + s1[1] + s1[2] + s1[3];  // otherwise the preconditioner's last kernel writes r.z
     part_rr[blockIdx.x] = s2[0] + s2[1] + s2[2] + s2[3];
   }
 }

@@ -68,8 +68,27 @@ struct SolverScalars {
   double raw[32];
 };
 
+// one stencil level (>= 1) of the cloth multigrid hierarchy (k_mg.hpp)
+struct MgLevel {
+  int N = 0, M = 0, n = 0;
+  DevBuf<double> A, Dinv, x, x2, r, t;
+  DevBuf<double> omega;  // [0] damping factor, [1] lambda_max estimate (device resident)
+};
+struct MgCloth {
+  int v_offset = 0, N0 = 0, M0 = 0;
+  std::vector<MgLevel*> lv;  // lv[0] = level 1
+  ~MgCloth() { for (auto* l : lv) delete l; }
+};
+
 struct tsl_ctx {
-  hipStream_t stream = 0;
+  hipStream_t stream = 0;       // internal non-blocking work stream (graph capture needs a real stream)
+  hipStream_t user_stream = 0;  // caller's stream (tsl_set_stream); ordered with `stream` through events at every entry point
+  hipEvent_t ev_in = nullptr, ev_out = nullptr;
+  int depth = 0;
+  // captured PCG iteration chunk
+  hipGraphExec_t pcg_graph = nullptr;
+  long pcg_graph_key = -1;
+  int use_graph = 1;
   int NV = 0, NF = 0;  // tot_NV, tot_NF
   double dt = 5e-3, k_contact = 1000, eps_contact = 1e-3, eps_v = 0.01, damping = 1.0, mu_cloth_elastic = 1.0;
   int max_n_constraints = 10000;
@@ -148,6 +167,15 @@ struct tsl_ctx {
   DevBuf<unsigned char> sort_tmp;
   int max_body_faces = 0;
 
+  // ---- multigrid preconditioner
+  std::vector<MgCloth*> mg;
+  int mg_enable = -1;  // -1 auto (on when a cloth hierarchy exists), 0 off, 1 on
+  double mg_omega = 0.0;   // > 0: fixed damping; 0: 1.5 / lambda_max(D^-1 A) per level from a power iteration
+  int mg_pi_iters = 12;
+  DevBuf<double> mg_omega0, mg_pi_part, mg_pi_norm;  // level 0
+  int mg_nu = 1, mg_coarse_sweeps = 8;
+  bool mg_ops_valid = false, mg_suspended = false;
+
   // ---- profiling of the dominant kernel
   int prof_enable = 0;
   hipEvent_t ev0 = nullptr, ev1 = nullptr;
@@ -156,10 +184,23 @@ struct tsl_ctx {
   DevBuf<unsigned long long> prof_dev;  // per sampled launch: min start / max end of the device wall clock
   long prof_dev_used = 0, prof_dev_cap = 512;
   size_t prof_waves = 0;
-  double prof_event_ms = 0;
+  double prof_event_ms = 0, prof_dev_ticks = 0;
+  long prof_dev_n = 0;
   std::vector<std::pair<hipEvent_t, hipEvent_t>> ev_pool;
   size_t ev_used = 0;
 
   // stats
   tsl_step_stats step_stats{};
+  ~tsl_ctx() { for (auto* m : mg) delete m; }
+};
+
+// Every entry point runs on the context's own stream; Enter/leave order it after / before the caller's stream.
+struct Scope {
+  tsl_ctx* c;
+  explicit Scope(tsl_ctx* c_) : c(c_) {
+    if (c->depth++ == 0) { (void)hipEventRecord(c->ev_in, c->user_stream); (void)hipStreamWaitEvent(c->stream, c->ev_in, 0); }
+  }
+  ~Scope() {
+    if (--c->depth == 0) { (void)hipEventRecord(c->ev_out, c->stream); (void)hipStreamWaitEvent(c->user_stream, c->ev_out, 0); }
+  }
 };

@@ -10,6 +10,7 @@
 #include "k_cloth.hpp"
 #include "k_contact.hpp"
 #include "k_fem.hpp"
+#include "k_mg.hpp"
 #include "k_solver.hpp"
 #include "tsl_ctx.hpp"
 
@@ -25,6 +26,7 @@ int tsl_fail(const char* fmt, ...) {
 }
 
 #define TSL_TRY(x) do { if ((x) != 0) return -1; } while (0)
+
 static inline int nblk(long n, int b) { return (int)((n + b - 1) / b); }
 static inline int gsz(size_t n) { size_t b = (n + 255) / 256; return (int)std::min<size_t>(std::max<size_t>(b, 1), 4096); }
 
@@ -83,6 +85,7 @@ static void build_pattern(int NV, const std::vector<std::vector<int>>& cliques, 
 }
 
 // ------------------------------------------------------------------------------------------------
+static int mg_build(tsl_ctx* c, const tsl_scene_desc* d);
 extern "C" const char* tsl_version(void) { return "tsl-hip 0.1 gfx950 fp64"; }
 extern "C" const char* tsl_last_error(void) { return g_tsl_err.c_str(); }
 
@@ -129,6 +132,8 @@ extern "C" int tsl_ctx_create(const tsl_scene_desc* d, tsl_ctx** out) {
   int ndev = 0;
   if (hipGetDeviceCount(&ndev) != hipSuccess || ndev == 0) return tsl_fail("tsl_ctx_create: no HIP device (this engine has no CPU path)");
   tsl_ctx* c = new tsl_ctx();
+  if (hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking) != hipSuccess || hipEventCreateWithFlags(&c->ev_in, hipEventDisableTiming) != hipSuccess ||
+      hipEventCreateWithFlags(&c->ev_out, hipEventDisableTiming) != hipSuccess) { delete c; return tsl_fail("stream / event creation failed"); }
   c->NV = d->tot_NV; c->NF = d->tot_NF;
   c->dt = d->dt; c->k_contact = d->k_contact; c->eps_contact = d->eps_contact; c->eps_v = d->eps_v; c->damping = d->damping;
   c->max_n_constraints = d->max_n_constraints > 0 ? d->max_n_constraints : 10000;
@@ -250,6 +255,7 @@ extern "C" int tsl_ctx_create(const tsl_scene_desc* d, tsl_ctx** out) {
   if (d->n_body > 0) c->h_bodies.assign(d->bodies, d->bodies + d->n_body);
   if (d->n_pair > 0) c->h_pairs.assign(d->pairs, d->pairs + d->n_pair);
   if (contact_alloc(c, d)) { delete c; return -1; }
+  if (mg_build(c, d)) { delete c; return -1; }
   (void)hipDeviceSynchronize();
   *out = c;
   return 0;
@@ -259,13 +265,19 @@ extern "C" void tsl_ctx_destroy(tsl_ctx* c) {
   if (!c) return;
   (void)hipDeviceSynchronize();
   if (c->h_scal) (void)hipHostFree(c->h_scal);
+  if (c->pcg_graph) (void)hipGraphExecDestroy(c->pcg_graph);
+  if (c->ev_in) (void)hipEventDestroy(c->ev_in);
+  if (c->ev_out) (void)hipEventDestroy(c->ev_out);
+  if (c->stream) (void)hipStreamDestroy(c->stream);
   for (auto& e : c->ev_pool) { (void)hipEventDestroy(e.first); (void)hipEventDestroy(e.second); }
   delete c;
 }
 
-extern "C" int tsl_set_stream(tsl_ctx* c, void* s) { c->stream = (hipStream_t)s; return 0; }
+extern "C" int tsl_set_stream(tsl_ctx* c, void* s) { c->user_stream = (hipStream_t)s; return 0; }
 
 extern "C" int tsl_set_param(tsl_ctx* c, const char* key, double v) {
+  Scope scope(c);
+  (void)hipStreamSynchronize(c->stream);
   std::string k(key);
   if (k == "mu_cloth_elastic") c->mu_cloth_elastic = v;
   else if (k == "k_contact") c->k_contact = v;
@@ -279,6 +291,12 @@ extern "C" int tsl_set_param(tsl_ctx* c, const char* key, double v) {
   else if (k == "plastic") c->plastic = (int)v;
   else if (k == "contact") c->contact_enable = (v != 0.0);
   else if (k == "grid_h") c->grid_h = v;
+  else if (k == "mg") c->mg_enable = (int)v;
+  else if (k == "mg_omega") c->mg_omega = v;
+  else if (k == "mg_pi_iters") c->mg_pi_iters = (int)v;
+  else if (k == "graph") c->use_graph = (int)v;
+  else if (k == "mg_nu") c->mg_nu = std::max(1, (int)v);
+  else if (k == "mg_coarse_sweeps") c->mg_coarse_sweeps = std::max(1, (int)v);
   else if (k.rfind("cloth", 0) == 0 && k.size() > 7) {
     const int ci = k[5] - '0';
     if (ci < 0 || ci >= (int)c->h_cloth.size()) return tsl_fail("tsl_set_param: bad cloth index in %s", key);
@@ -292,14 +310,20 @@ extern "C" int tsl_set_param(tsl_ctx* c, const char* key, double v) {
 }
 
 extern "C" int tsl_set_frozen(tsl_ctx* c, const int32_t* fr) {
+  Scope scope(c);
+  (void)hipStreamSynchronize(c->stream);
   c->h_frozen.assign(fr, fr + 3 * (size_t)c->NV);
   return upload_frozen(c);
 }
 extern "C" int tsl_set_ext_force(tsl_ctx* c, const double* f) {
+  Scope scope(c);
+  (void)hipStreamSynchronize(c->stream);
   HIP_OK(hipMemcpy(c->fext.p, f, 3 * (size_t)c->NV * sizeof(double), hipMemcpyHostToDevice));
   return 0;
 }
 extern "C" int tsl_set_gravity(tsl_ctx* c, const double* g) {
+  Scope scope(c);
+  (void)hipStreamSynchronize(c->stream);
   HIP_OK(hipMemcpy(c->grav.p, g, 3 * (size_t)c->NV * sizeof(double), hipMemcpyHostToDevice));
   return 0;
 }
@@ -343,6 +367,7 @@ static int energy_sync(tsl_ctx* c, const double* pos, const double* prev, const 
 }
 
 extern "C" int tsl_energy(tsl_ctx* c, const double* pos, const double* prev, const double* vel, const double* ref, double* E) {
+  Scope scope(c);
   return energy_sync(c, pos, prev, vel, ref, E);
 }
 
@@ -375,11 +400,13 @@ static int assemble(tsl_ctx* c, const double* pos, const double* prev, const dou
   hipLaunchKernelGGL(k_mask_matrix, dim3(c->n_slices), dim3(256), 0, s, c->n_slices, c->slice_off.p, c->slice_len.p, c->colidx.p, c->fzmask.p, c->mdt2.p,
                      c->vals_full.p, c->vals.p, NV);
   hipLaunchKernelGGL(k_block_jacobi, dim3(nblk(NV, 256)), dim3(256), 0, s, NV, c->diag_perm.p, c->vals.p, c->nc > 0 ? c->c_diag.p : (const double*)nullptr, c->Dinv.p);
+  c->mg_ops_valid = false;
   HIP_OK(hipGetLastError());
   return 0;
 }
 
 extern "C" int tsl_assemble(tsl_ctx* c, const double* pos, const double* prev, const double* vel, const double* ref, int spd, double* grad) {
+  Scope scope(c);
   return assemble(c, pos, prev, vel, ref, spd, grad);
 }
 
@@ -417,29 +444,198 @@ static int read_scal(tsl_ctx* c) {
 
 static int bicgstab(tsl_ctx* c, tsl_solve_stats* st);
 
+// ------------------------------------------------------------------------------------------------ multigrid (k_mg.hpp)
+static int mg_build(tsl_ctx* c, const tsl_scene_desc* d) {
+  for (int ci = 0; ci < d->n_cloth; ci++) {
+    const tsl_cloth_desc& cd = d->cloths[ci];
+    int N = cd.N, M = cd.M;
+    if (N < 8 || M < 8 || (N & 1) || (M & 1)) continue;
+    MgCloth* mc = new MgCloth();
+    mc->v_offset = cd.v_offset; mc->N0 = N; mc->M0 = M;
+    while (!(N & 1) && !(M & 1) && std::min(N, M) >= 4) {
+      N >>= 1; M >>= 1;
+      MgLevel* L = new MgLevel();
+      L->N = N; L->M = M; L->n = (N + 1) * (M + 1);
+      int rc = L->A.alloc((size_t)225 * L->n) | L->Dinv.alloc((size_t)9 * L->n) | L->x.alloc((size_t)3 * L->n) | L->x2.alloc((size_t)3 * L->n) | L->r.alloc((size_t)3 * L->n) | L->t.alloc((size_t)3 * L->n) | L->omega.alloc(2);
+      mc->lv.push_back(L);
+      if (rc) { delete mc; return -1; }
+    }
+    c->mg.push_back(mc);
+  }
+  if (!c->mg.empty()) {
+    if (c->mg_omega0.alloc(2) | c->mg_pi_part.alloc((size_t)c->NV / 256 + 8) | c->mg_pi_norm.alloc(64)) return -1;
+  }
+  return 0;
+}
+
+static bool mg_active(tsl_ctx* c) { return !c->mg.empty() && c->mg_enable != 0 && !c->mg_suspended; }
+
+// plain y = H x on level 0 (matrix + matrix-free contact), no scalar side effects
+static void mg_spmv0(tsl_ctx* c, const double* x, double* y) {
+  hipStream_t s = c->stream;
+  hipLaunchKernelGGL((k_spmv_mw<4, 1, true>), dim3(c->n_slices), dim3(256), 0, s, c->NV, c->n_slices, c->slice_off.p, c->slice_len.p, c->colidx.p, c->vals.p, x, y,
+                     (double*)nullptr, (const int*)nullptr);
+  if (c->nc > 0) hipLaunchKernelGGL(k_contact_matvec, dim3(nblk(c->nc, 64)), dim3(64), 0, s, c->nc, c->c_idx.p, c->rowpos.p, c->c_H.p, x, y, SC(c), -1, 0);
+}
+
+// Galerkin coarse operators of the current (masked) matrix; called once per assembly when the preconditioner is active
+static int mg_setup_operators(tsl_ctx* c) {
+  hipStream_t s = c->stream;
+  for (MgCloth* mc : c->mg) {
+    MgGrid gf{mc->N0, mc->M0};
+    MgLevel* L1 = mc->lv[0];
+    HIP_OK(hipMemsetAsync(L1->A.p, 0, L1->A.n * sizeof(double), s));
+    hipLaunchKernelGGL(k_galerkin0, dim3(c->n_slices), dim3(256), 0, s, gf, mc->v_offset, c->NV, c->n_slices, c->slice_off.p, c->slice_len.p, c->colidx.p, c->perm.p, c->vals.p,
+                       L1->A.p);
+    if (c->nc > 0) hipLaunchKernelGGL(k_galerkin0_diag, dim3(nblk((gf.N + 1) * (gf.M + 1), 256)), dim3(256), 0, s, gf, mc->v_offset, c->rowpos.p, c->c_diag.p, L1->A.p);
+    hipLaunchKernelGGL(k_st_diag_inv, dim3(nblk(L1->n, 256)), dim3(256), 0, s, L1->n, L1->A.p, L1->Dinv.p);
+    for (size_t l = 0; l + 1 < mc->lv.size(); l++) {
+      MgLevel* Lf = mc->lv[l];
+      MgLevel* Lc = mc->lv[l + 1];
+      HIP_OK(hipMemsetAsync(Lc->A.p, 0, Lc->A.n * sizeof(double), s));
+      hipLaunchKernelGGL(k_galerkin_st, dim3(nblk((long)Lf->n * 25, 256)), dim3(256), 0, s, MgGrid{Lf->N, Lf->M}, Lf->A.p, Lc->A.p);
+      hipLaunchKernelGGL(k_st_diag_inv, dim3(nblk(Lc->n, 256)), dim3(256), 0, s, Lc->n, Lc->A.p, Lc->Dinv.p);
+    }
+  }
+  // damping factors
+  const double c_om = 1.5, om_max = 0.8;
+  auto set_fixed = [&](double* dst) -> int {
+    const double h[2] = {c->mg_omega, 0.0};
+    HIP_OK(hipMemcpyAsync(dst, h, 2 * sizeof(double), hipMemcpyHostToDevice, s));
+    return 0;
+  };
+  if (c->mg_omega > 0) {
+    TSL_TRY(set_fixed(c->mg_omega0.p));
+    for (MgCloth* mc : c->mg) for (MgLevel* L : mc->lv) TSL_TRY(set_fixed(L->omega.p));
+  } else {
+    const int K = std::min(std::max(c->mg_pi_iters, 2), 60);
+    {  // level 0: v in v_t2, t in v_t3
+      const int NV = c->NV, gb = nblk(NV, 256);
+      hipLaunchKernelGGL(k_pi_init, dim3(gb), dim3(256), 0, s, NV, c->v_t2.p);
+      for (int k = 0; k < K; k++) {
+        mg_spmv0(c, c->v_t2.p, c->v_t3.p);
+        hipLaunchKernelGGL(k_pi_apply, dim3(gb), dim3(256), 0, s, NV, c->Dinv.p, c->v_t3.p, c->v_t2.p, c->mg_pi_part.p);
+        hipLaunchKernelGGL(k_pi_finish, dim3(1), dim3(256), 0, s, c->mg_pi_part.p, gb, c->mg_pi_norm.p, k, (k == K - 1) ? 1 : 0, c_om, om_max, c->mg_omega0.p);
+      }
+    }
+    for (MgCloth* mc : c->mg)
+      for (MgLevel* L : mc->lv) {
+        const int gb = nblk(L->n, 256);
+        hipLaunchKernelGGL(k_pi_init, dim3(gb), dim3(256), 0, s, L->n, L->x.p);
+        for (int k = 0; k < K; k++) {
+          hipLaunchKernelGGL((k_st_spmv5<0>), dim3(nblk(L->n, 64)), dim3(320), 0, s, MgGrid{L->N, L->M}, L->A.p, L->x.p, L->t.p, (const double*)nullptr, (const double*)nullptr,
+                             (const double*)nullptr);
+          hipLaunchKernelGGL(k_pi_apply, dim3(gb), dim3(256), 0, s, L->n, L->Dinv.p, L->t.p, L->x.p, c->mg_pi_part.p);
+          hipLaunchKernelGGL(k_pi_finish, dim3(1), dim3(256), 0, s, c->mg_pi_part.p, gb, c->mg_pi_norm.p, k, (k == K - 1) ? 1 : 0, c_om, om_max, L->omega.p);
+        }
+      }
+  }
+  c->mg_ops_valid = true;
+  return 0;
+}
+
+// One V-cycle on stencil level l; returns the buffer (L->x or L->x2) holding the result.  Buffer roles are a pure function
+// of (nu, coarse_sweeps), so the launch sequence is identical for every cycle (required for hipGraph replay).
+static double* mg_stencil_cycle(tsl_ctx* c, MgCloth* mc, size_t l) {
+  hipStream_t s = c->stream;
+  MgLevel* L = mc->lv[l];
+  const MgGrid g{L->N, L->M};
+  const int gb = nblk(L->n, 256), gb5 = nblk(L->n, 64);
+  double* xa = L->x.p;
+  double* xb = L->x2.p;
+  auto sweep = [&]() {  // xb = xa + omega Dinv (r - A xa); swap roles
+    hipLaunchKernelGGL((k_st_spmv5<1>), dim3(gb5), dim3(320), 0, s, g, L->A.p, xa, xb, L->Dinv.p, L->r.p, L->omega.p);
+    std::swap(xa, xb);
+  };
+  hipLaunchKernelGGL(k_mg_jacobi_first, dim3(gb), dim3(256), 0, s, L->n, L->Dinv.p, L->r.p, L->omega.p, xa);
+  const bool last = (l + 1 == mc->lv.size());
+  const int extra = last ? c->mg_coarse_sweeps - 1 : c->mg_nu - 1;
+  for (int k = 0; k < extra; k++) sweep();
+  if (last) return xa;
+  MgLevel* Lc = mc->lv[l + 1];
+  hipLaunchKernelGGL((k_st_spmv5<0>), dim3(gb5), dim3(320), 0, s, g, L->A.p, xa, L->t.p, (const double*)nullptr, (const double*)nullptr, (const double*)nullptr);
+  hipLaunchKernelGGL(k_st_restrict, dim3(nblk(Lc->n, 256)), dim3(256), 0, s, g, L->r.p, L->t.p, Lc->r.p);
+  const double* xc = mg_stencil_cycle(c, mc, l + 1);
+  hipLaunchKernelGGL(k_st_prolong_add, dim3(gb), dim3(256), 0, s, g, xc, xa);
+  for (int k = 0; k < c->mg_nu; k++) sweep();
+  return xa;
+}
+
+// z = M^-1 r (one V(nu,nu) cycle); part_rz receives the per-block partials of r.z
+static void mg_vcycle(tsl_ctx* c, const double* r, double* z, double* part_rz) {
+  hipStream_t s = c->stream;
+  const int NV = c->NV, gb = nblk(NV, 256);
+  const double* om = c->mg_omega0.p;
+  double* t = c->v_t1.p;
+  hipLaunchKernelGGL(k_mg_jacobi_first, dim3(gb), dim3(256), 0, s, NV, c->Dinv.p, r, om, z);
+  for (int k = 0; k < c->mg_nu - 1; k++) {
+    mg_spmv0(c, z, t);
+    hipLaunchKernelGGL(k_mg_jacobi_next, dim3(gb), dim3(256), 0, s, NV, c->Dinv.p, r, t, om, z, (const double*)nullptr, (double*)nullptr);
+  }
+  mg_spmv0(c, z, t);
+  for (MgCloth* mc : c->mg) {
+    MgLevel* L1 = mc->lv[0];
+    hipLaunchKernelGGL(k_mg_restrict0, dim3(nblk(L1->n, 256)), dim3(256), 0, s, MgGrid{mc->N0, mc->M0}, mc->v_offset, c->rowpos.p, r, t, L1->r.p);
+    const double* x1 = mg_stencil_cycle(c, mc, 0);
+    hipLaunchKernelGGL(k_mg_prolong0_add, dim3(nblk((mc->N0 + 1) * (mc->M0 + 1), 256)), dim3(256), 0, s, MgGrid{mc->N0, mc->M0}, mc->v_offset, c->rowpos.p, x1, z);
+  }
+  for (int k = 0; k < c->mg_nu; k++) {
+    mg_spmv0(c, z, t);
+    const bool lastk = (k == c->mg_nu - 1);
+    hipLaunchKernelGGL(k_mg_jacobi_next, dim3(gb), dim3(256), 0, s, NV, c->Dinv.p, r, t, om, z, lastk ? r : (const double*)nullptr, lastk ? part_rz : (double*)nullptr);
+  }
+}
+
 #define PCG_WPS 4
 static PcgScal* PSC(tsl_ctx* c) { return (PcgScal*)c->scal.p; }
 static PcgScal* HPSC(tsl_ctx* c) { return (PcgScal*)c->h_scal; }
 
-// one PCG iteration = K1 (+ matrix-free contact product) + K2, see k_solver.hpp
-static void launch_pcg_iteration(tsl_ctx* c, int it) {
+// one PCG iteration = K1 (+ matrix-free contact product) + K2 (+ V-cycle), see k_solver.hpp.  parity selects the p
+// ping-pong buffers and the rz history slot; prof (optional) receives per-wave device-clock stamps of K1.
+static void launch_pcg_iteration(tsl_ctx* c, int parity, int first, unsigned long long* dprof) {
   hipStream_t s = c->stream;
   const int NV = c->NV, ns = c->n_slices;
-  double* p_new = (it & 1) ? c->v_t0.p : c->v_p.p;
-  const double* p_old = (it & 1) ? c->v_p.p : c->v_t0.p;
-  unsigned long long* dprof = nullptr;
-  if (c->prof_enable && (c->prof_launches % 64 == 40) && c->prof_dev_used < c->prof_dev_cap) dprof = c->prof_dev.p + 2 * c->prof_waves * (c->prof_dev_used++);
-  const bool sample = c->prof_enable && (c->prof_launches % 64 == 8) && c->ev_used < c->ev_pool.size();
-  if (sample) (void)hipEventRecord(c->ev_pool[c->ev_used].first, s);
+  double* p_new = parity ? c->v_t0.p : c->v_p.p;
+  const double* p_old = parity ? c->v_p.p : c->v_t0.p;
   hipLaunchKernelGGL((k_pcg_spmv<PCG_WPS, true>), dim3(ns), dim3(64 * PCG_WPS), 0, s, NV, ns, c->slice_off.p, c->slice_len.p, c->colidx.p, c->vals.p, c->v_z.p, p_old, p_new,
-                     c->v_Ap.p, c->part_rz.p, c->part_rr.p, c->part_pAp.p, PSC(c), it, dprof);
-  if (sample) { (void)hipEventRecord(c->ev_pool[c->ev_used].second, s); c->ev_used++; }
-  c->prof_launches++;
+                     c->v_Ap.p, c->part_rz.p, c->part_rr.p, c->part_pAp.p, PSC(c), parity, first, dprof);
   if (c->nc > 0)
     hipLaunchKernelGGL(k_contact_matvec_part, dim3(nblk(c->nc, 64)), dim3(64), 0, s, c->nc, c->c_idx.p, c->rowpos.p, c->c_H.p, p_new, c->v_Ap.p, c->part_pAp.p + ns,
                        &PSC(c)->flag);
+  const bool mg = mg_active(c);
   hipLaunchKernelGGL(k_pcg_update, dim3(nblk(NV, 256)), dim3(256), 0, s, NV, p_new, c->v_Ap.p, c->Dinv.p, c->v_x.p, c->v_r.p, c->v_z.p, c->part_pAp.p, c->part_rz.p, c->part_rr.p,
-                     PSC(c), it, (const double*)nullptr, (const double*)nullptr);
+                     PSC(c), parity, (const double*)nullptr, (const double*)nullptr, mg ? 0 : 1);
+  if (mg) mg_vcycle(c, c->v_r.p, c->v_z.p, c->part_rz.p);
+}
+
+// Chunk of `chunk` (even) iterations with parities 1,0,1,0,... captured once as a hipGraph and replayed: a multigrid-PCG
+// iteration is ~45 short kernels, eager launches leave the GPU idle ~30 % of the time.  The first K1 of the chunk stamps
+// the device clock into a fixed buffer when profiling is on.
+static int pcg_chunk_graph(tsl_ctx* c, int chunk) {
+  const long key = ((long)(mg_active(c) ? 1 : 0) << 40) | ((long)c->nc << 8) | ((long)(c->prof_enable ? 1 : 0) << 7) | (long)chunk | ((long)c->mg_nu << 44) | ((long)c->mg_coarse_sweeps << 48);
+  if (c->pcg_graph && c->pcg_graph_key == key) return 0;
+  if (c->pcg_graph) { (void)hipGraphExecDestroy(c->pcg_graph); c->pcg_graph = nullptr; }
+  hipGraph_t g = nullptr;
+  HIP_OK(hipStreamBeginCapture(c->stream, hipStreamCaptureModeThreadLocal));
+  for (int i = 0; i < chunk; i++) launch_pcg_iteration(c, (i & 1) ^ 1, 0, (i == 0 && c->prof_enable) ? c->prof_dev.p : (unsigned long long*)nullptr);
+  hipLaunchKernelGGL(k_pcg_check, dim3(1), dim3(256), 0, c->stream, c->part_rr.p, PSC(c));
+  HIP_OK(hipStreamEndCapture(c->stream, &g));
+  HIP_OK(hipGraphInstantiate(&c->pcg_graph, g, nullptr, nullptr, 0));
+  (void)hipGraphDestroy(g);
+  c->pcg_graph_key = key;
+  return 0;
+}
+
+// device-clock span of the stamped K1 launch of the last graph replay (sampled on the host every few chunks)
+static int prof_sample_graph(tsl_ctx* c) {
+  const size_t nw = c->prof_waves;
+  std::vector<unsigned long long> h(2 * nw);
+  HIP_OK(hipMemcpyAsync(h.data(), c->prof_dev.p, h.size() * sizeof(unsigned long long), hipMemcpyDeviceToHost, c->stream));
+  HIP_OK(hipStreamSynchronize(c->stream));
+  unsigned long long t0 = ~0ull, t1 = 0;
+  for (size_t w = 0; w < nw; w++) { if (h[2 * w + 1] == 0) continue; t0 = std::min(t0, h[2 * w]); t1 = std::max(t1, h[2 * w + 1]); }
+  if (t1 > t0) { c->prof_dev_ticks += (double)(t1 - t0); c->prof_dev_n++; }
+  return 0;
 }
 
 // Solve with rhs already in v_b (permuted); result in v_x (permuted).
@@ -459,29 +655,51 @@ static int solve_perm(tsl_ctx* c, tsl_solve_stats* st) {
   bool need_fallback = false;
   int total_it = 0;
   const int ncb = c->nc > 0 ? nblk(c->nc, 64) : 0;
+  double rr_prev_outer = 1e300;
   for (int outer = 0; outer < 20; outer++) {
     PcgScal hs;
     memset(&hs, 0, sizeof(hs));
     hs.bb = bb; hs.thresh2 = 0.25 * tol2; hs.n_part1 = c->n_slices + ncb; hs.n_part2 = gb;
     HIP_OK(hipMemcpyAsync(c->scal.p, &hs, sizeof(PcgScal), hipMemcpyHostToDevice, s));
     if (outer > 0) launch_spmv(c, c->vals.p, c->v_x.p, c->v_Ap.p, -1, 0);
-    // true residual, z = Dinv r, partial r.z / r.r
+    // true residual, z = M^-1 r, partial r.z / r.r
     hipLaunchKernelGGL(k_pcg_update, dim3(gb), dim3(256), 0, s, NV, (const double*)nullptr, (const double*)nullptr, c->Dinv.p, c->v_x.p, c->v_r.p, c->v_z.p, c->part_pAp.p,
-                       c->part_rz.p, c->part_rr.p, PSC(c), 0, c->v_b.p, outer > 0 ? c->v_Ap.p : (const double*)nullptr);
+                       c->part_rz.p, c->part_rr.p, PSC(c), 0, c->v_b.p, outer > 0 ? c->v_Ap.p : (const double*)nullptr, mg_active(c) ? 0 : 1);
+    if (mg_active(c)) {
+      if (!c->mg_ops_valid) TSL_TRY(mg_setup_operators(c));
+      mg_vcycle(c, c->v_r.p, c->v_z.p, c->part_rz.p);
+    }
     hipLaunchKernelGGL(k_sum_partials, dim3(1), dim3(256), 0, s, c->part_rr.p, gb, &PSC(c)->rr_last);
     hipLaunchKernelGGL(k_sum_partials, dim3(1), dim3(256), 0, s, c->part_rz.p, gb, &PSC(c)->rz_last);
     TSL_TRY(read_scal(c));
     const double rr0 = HPSC(c)->rr_last;
     st->rel_residual = sqrt(rr0 / bb);
     if (rr0 <= tol2) { need_fallback = false; break; }
+    // attainable accuracy: when a restart no longer halves the true residual the solve has reached what fp64 allows for
+    // this conditioning (a direct solver has the same backward error); accept if within 1e3 of the requested tolerance
+    if (outer > 0 && rr0 > 0.25 * rr_prev_outer && rr0 <= 1e6 * tol2) { need_fallback = false; break; }
+    rr_prev_outer = rr0;
     if (!(HPSC(c)->rz_last > 0)) { need_fallback = true; break; }
     if (outer > 0) st->restarts++;
     need_fallback = true;
     int flag = 0, it = 0;
+    // iteration 0 (beta = 0) eagerly, then graph replays of `chunk` iterations (parities 1,0,...)
+    launch_pcg_iteration(c, 0, 1, nullptr);
+    it++; total_it++; c->prof_launches++;
+    int chunk = mg_active(c) ? std::min(c->cg_check, 4) : c->cg_check;
+    chunk = std::max(2, chunk & ~1);
+    const bool graph = c->use_graph != 0;
+    if (graph) TSL_TRY(pcg_chunk_graph(c, chunk));
+    int n_chunks = 0;
     while (total_it < c->cg_maxit) {
-      const int chunk = std::min(c->cg_check, c->cg_maxit - total_it);
-      for (int i = 0; i < chunk; i++, it++, total_it++) launch_pcg_iteration(c, it);
+      if (graph) HIP_OK(hipGraphLaunch(c->pcg_graph, s));
+      else {
+        for (int i = 0; i < chunk; i++) launch_pcg_iteration(c, (i & 1) ^ 1, 0, nullptr);
+        hipLaunchKernelGGL(k_pcg_check, dim3(1), dim3(256), 0, s, c->part_rr.p, PSC(c));
+      }
+      it += chunk; total_it += chunk; c->prof_launches += chunk;
       TSL_TRY(read_scal(c));
+      if (graph && c->prof_enable && (n_chunks++ % 8 == 0)) TSL_TRY(prof_sample_graph(c));
       flag = HPSC(c)->flag;
       if (flag) break;
     }
@@ -490,6 +708,15 @@ static int solve_perm(tsl_ctx* c, tsl_solve_stats* st) {
   }
   st->iters = total_it;
   if (!need_fallback) { st->flag = 0; return 0; }
+  if (mg_active(c)) {
+    // multigrid-PCG failed (H or the cycle not positive definite along some direction): retry with plain block-Jacobi PCG
+    c->mg_suspended = true;
+    tsl_solve_stats st2;
+    const int rc = solve_perm(c, &st2);
+    c->mg_suspended = false;
+    st->iters += st2.iters; st->restarts += st2.restarts + 1; st->flag = st2.flag; st->rel_residual = st2.rel_residual;
+    return rc;
+  }
   return bicgstab(c, st);
 }
 
@@ -595,6 +822,7 @@ static int solve_orig(tsl_ctx* c, const double* rhs, double* x, tsl_solve_stats*
 }
 
 extern "C" int tsl_solve(tsl_ctx* c, const double* rhs, double* x, tsl_solve_stats* st) {
+  Scope scope(c);
   TSL_TRY(solve_orig(c, rhs, x, st));
   HIP_OK(hipStreamSynchronize(c->stream));
   return 0;
@@ -602,6 +830,7 @@ extern "C" int tsl_solve(tsl_ctx* c, const double* rhs, double* x, tsl_solve_sta
 
 // ------------------------------------------------------------------------------------------------
 extern "C" int tsl_update_ref_angle(tsl_ctx* c, const double* pos, double* ref) {
+  Scope scope(c);
   if (!c->n_hinge) return 0;
   hipStream_t s = c->stream;
   hipLaunchKernelGGL(k_cloth_normals, dim3(nblk(c->n_cface, 256)), dim3(256), 0, s, c->n_cface, pos, c->cf_f2v.p, c->norm_dir.p);
@@ -611,6 +840,7 @@ extern "C" int tsl_update_ref_angle(tsl_ctx* c, const double* pos, double* ref) 
 }
 
 extern "C" int tsl_step(tsl_ctx* c, double* pos, double* prev, double* vel, double* ref, tsl_step_stats* stats) {
+  Scope scope(c);
   hipStream_t s = c->stream;
   const size_t n3 = 3 * (size_t)c->NV;
   tsl_step_stats st;
@@ -668,6 +898,7 @@ extern "C" int tsl_matrix_nnzb(tsl_ctx* c, int32_t* nb, int32_t* nnzb) {
 
 // masked system matrix (what tsl_solve inverts) + the matrix-free contact blocks, as BSR in the original ordering
 extern "C" int tsl_matrix_export(tsl_ctx* c, int32_t* row_ptr, int32_t* col, double* vals) {
+  Scope scope(c);
   HIP_OK(hipStreamSynchronize(c->stream));
   std::vector<double> hv(c->vals.n);
   HIP_OK(hipMemcpy(hv.data(), c->vals.p, hv.size() * sizeof(double), hipMemcpyDeviceToHost));
@@ -687,10 +918,10 @@ extern "C" int tsl_matrix_export(tsl_ctx* c, int32_t* row_ptr, int32_t* col, dou
 }
 
 extern "C" int tsl_profile_reset(tsl_ctx* c, int enable) {
-  c->prof_enable = enable; c->prof_ms = 0; c->prof_launches = 0; c->prof_samples = 0; c->ev_used = 0; c->prof_dev_used = 0;
+  c->prof_enable = enable; c->prof_ms = 0; c->prof_launches = 0; c->prof_samples = 0; c->ev_used = 0; c->prof_dev_used = 0; c->prof_dev_ticks = 0; c->prof_dev_n = 0;
   if (enable) {
     c->prof_waves = (size_t)c->n_slices * PCG_WPS;
-    c->prof_dev_cap = 512;
+    c->prof_dev_cap = 1;
     if (c->prof_dev.n == 0) TSL_TRY(c->prof_dev.alloc(2 * c->prof_waves * (size_t)c->prof_dev_cap));
     HIP_OK(hipMemset(c->prof_dev.p, 0, c->prof_dev.n * sizeof(unsigned long long)));
   }
@@ -705,26 +936,17 @@ extern "C" int tsl_profile_reset(tsl_ctx* c, int enable) {
 }
 
 extern "C" int tsl_profile_read(tsl_ctx* c, double* ms_per_launch, int64_t* launches, int64_t* bytes_per_launch) {
+  Scope scope(c);
   HIP_OK(hipStreamSynchronize(c->stream));
   prof_collect(c);
   // device-clock spans of the sampled launches (what a kernel trace reports as the kernel duration)
   double dev_ms = 0;
-  long n_dev = 0;
-  if (c->prof_dev_used > 0) {
-    std::vector<unsigned long long> h(2 * c->prof_waves * (size_t)c->prof_dev_used);
-    HIP_OK(hipMemcpy(h.data(), c->prof_dev.p, h.size() * sizeof(unsigned long long), hipMemcpyDeviceToHost));
+  long n_dev = c->prof_dev_n;
+  {
     int dev = 0, khz = 100000;
     (void)hipGetDevice(&dev);
     if (hipDeviceGetAttribute(&khz, hipDeviceAttributeWallClockRate, dev) != hipSuccess || khz <= 0) khz = 100000;
-    for (long i = 0; i < c->prof_dev_used; i++) {
-      unsigned long long t0 = ~0ull, t1 = 0;
-      for (size_t w = 0; w < c->prof_waves; w++) {
-        const unsigned long long a = h[2 * (i * c->prof_waves + w)], b = h[2 * (i * c->prof_waves + w) + 1];
-        if (b == 0) continue;  // wave of an early-returned launch
-        t0 = std::min(t0, a); t1 = std::max(t1, b);
-      }
-      if (t1 > t0) { dev_ms += (double)(t1 - t0) / (double)khz; n_dev++; }
-    }
+    dev_ms = c->prof_dev_ticks / (double)khz;
   }
   c->prof_event_ms = c->prof_samples ? c->prof_ms / c->prof_samples : 0.0;
   *ms_per_launch = n_dev ? dev_ms / n_dev : c->prof_event_ms;
@@ -742,6 +964,7 @@ extern "C" int tsl_profile_read_events(tsl_ctx* c, double* ms_per_launch_events)
 // micro-benchmark of the SpMV variants on the currently assembled matrix: average microseconds per launch over reps
 // back-to-back launches bracketed by one hipEvent pair (includes ~1.5 us dependent-launch gaps)
 extern "C" int tsl_bench_spmv(tsl_ctx* c, int variant, int reps, double* us_per_launch) {
+  Scope scope(c);
   hipStream_t s = c->stream;
   hipEvent_t e0, e1;
   HIP_OK(hipEventCreate(&e0)); HIP_OK(hipEventCreate(&e1));
@@ -792,6 +1015,7 @@ extern "C" int tsl_bench_spmv(tsl_ctx* c, int variant, int reps, double* us_per_
 }
 
 extern "C" int tsl_spd_project(tsl_ctx* c, double* blocks, int32_t n, int32_t D) {
+  Scope scope(c);
   if (D != 2 && D != 3 && D != 9) return tsl_fail("tsl_spd_project: D must be 2, 3 or 9");
   hipLaunchKernelGGL(k_spd_batch, dim3(nblk(n, 64)), dim3(64), 0, c->stream, blocks, n, D);
   HIP_OK(hipStreamSynchronize(c->stream));
@@ -888,6 +1112,7 @@ __global__ void k_adj_prev(int NV, const double* __restrict__ z, const double* _
 // Grad.transfer_grad (analytic_grad_single.py:217-257) without the gripper part (host: gripper.set / gather_grad).
 extern "C" int tsl_adjoint_step(tsl_ctx* c, int step, int T, const double* pos_buffer, double* pos_grad, const double* ref_buffer, double* angleref_grad,
                                 double* tmp_z_frozen, double adj_damping, tsl_solve_stats* st) {
+  Scope scope(c);
   if (step < 1 || step >= T) return tsl_fail("tsl_adjoint_step: step %d outside [1, %d)", step, T);
   hipStream_t s = c->stream;
   const int NV = c->NV;
