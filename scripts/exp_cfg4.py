@@ -1,0 +1,43 @@
+"""Probe (not part of the product): cfg4-like workload = Scene_balancing with a 224x224 cloth (ball + 4 tactile pads).
+usage: exp_cfg4.py [N] [cloth_size] [steps]"""
+import sys, time, os
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import numpy as np
+import torch
+from thinshelllab_amd.task_scene.Scene_balancing import Scene
+from thinshelllab_amd.engine.geometry import projection_query
+from thinshelllab_amd.engine.analytic_grad_single import Grad
+
+N = int(sys.argv[1]) if len(sys.argv) > 1 else 224
+size = float(sys.argv[2]) if len(sys.argv) > 2 else 0.12
+T = int(sys.argv[3]) if len(sys.argv) > 3 else 3
+t0 = time.time()
+gs = float(sys.argv[4]) if len(sys.argv) > 4 else 1.0
+s = Scene(cloth_size=size, cloth_N=N, cloth_M=N, geom_scale=gs)
+s.init_all()
+s.mu_cloth_elastic[None] = 5.0
+s.prev_pos.copy_from(s.pos)
+ctx = s._ensure_ctx()
+for kv in os.environ.get("TSL_PARAMS", "").split(","):
+    if "=" in kv:
+        ctx.set_param(kv.split("=")[0], float(kv.split("=")[1]))
+print(f"setup {time.time()-t0:.1f} s  tot_NV={s.tot_NV}", flush=True)
+n_part = s.gripper.n_part
+g = Grad(s, T + 1, n_part); g.init_mass(s)
+g.copy_pos(s, 0)
+dpos = np.zeros((n_part, 3)); drot = np.zeros((n_part, 3))
+dpos[:, 2] = 5e-5 * gs; drot[:, 1] = 2e-3
+for f in range(1, T + 1):
+    s.action(f, dpos, drot)
+    torch.cuda.synchronize(); t = time.time()
+    st = s.time_step(projection_query, f)
+    torch.cuda.synchronize(); dt = time.time() - t
+    g.copy_pos(s, f)
+    print(f"step {f}: {dt*1e3:.1f} ms nc={st['nc']} newton={st['newton_iters']} cg={st['cg_iters']} ls={st['ls_evals']} restarts={st['restarts']} fb={st['fallback']} "
+          f"delta={st['last_delta']:.2e}", flush=True)
+g.get_loss_balance(s) if hasattr(g, "get_loss_balance") else None
+for f in range(T, 0, -1):
+    torch.cuda.synchronize(); t = time.time()
+    g.transfer_grad(f, s, projection_query); st = g.last_stats
+    torch.cuda.synchronize(); dt = time.time() - t
+    print(f"adjoint {f}: {dt*1e3:.1f} ms {st}", flush=True)

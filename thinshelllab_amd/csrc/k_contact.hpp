@@ -515,7 +515,7 @@ extern "C" int tsl_contact_detect(tsl_ctx* c, const double* pos, const double* p
   hipLaunchKernelGGL(k_vn_normalize, dim3(cnblk(NV, 256)), dim3(256), 0, s, NV, c->vn.p);
   // projection_query
   GridArgs G;
-  G.h = c->grid_h; G.n = (int)floor(0.2 / c->grid_h) * 2; G.bound = c->grid_h * (G.n - 1) / 2;
+  G.h = c->grid_h; G.n = (int)floor(c->grid_extent / c->grid_h) * 2; G.bound = c->grid_h * (G.n - 1) / 2;
   for (int b = 0; b < c->n_body; b++) {
     const tsl_body& body = c->h_bodies[b];
     const int nf = body.f_end - body.f_start;

@@ -96,6 +96,7 @@ struct tsl_ctx {
   double cg_tol = 1e-10;
   int cg_maxit = 200000, cg_check = 32;
   double grid_h = 0.003;
+  double grid_extent = 0.2;  // half-width of the broad-phase box (geometry.py:8-19 hard-codes 0.2 m)
 
   // ---- cloth
   std::vector<ClothDev> h_cloth;
@@ -138,7 +139,11 @@ struct tsl_ctx {
   long nnzb = 0;
 
   // ---- solver vectors (permuted AoS, 3*NV)
-  DevBuf<double> v_x, v_r, v_z, v_p, v_Ap, v_b, v_t0, v_t1, v_t2, v_t3, v_t4;
+  DevBuf<double> v_x, v_r, v_z, v_p, v_Ap, v_b, v_t0, v_t1, v_t2, v_t3, v_t4, v_mg;
+  // preconditioner built from a different (SPD-projected) assembly than the operator: adjoint solves (un-projected H)
+  DevBuf<double> vals_pc, c_H_pc;
+  bool pc_separate = false, pc_frozen = false;
+  int adj_spd_pc = 1;
   DevBuf<SolverScalars> scal;
   DevBuf<double> part_pAp, part_rz, part_rr;  // per-block partial sums of the two-kernel PCG iteration
   SolverScalars* h_scal = nullptr;  // pinned

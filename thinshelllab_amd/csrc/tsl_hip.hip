@@ -242,7 +242,7 @@ extern "C" int tsl_ctx_create(const tsl_scene_desc* d, tsl_ctx** out) {
   rc |= c->Dinv.alloc((size_t)NV * 9);
   const size_t n3 = (size_t)NV * 3;
   rc |= c->v_x.alloc(n3); rc |= c->v_r.alloc(n3); rc |= c->v_z.alloc(n3); rc |= c->v_p.alloc(n3); rc |= c->v_Ap.alloc(n3); rc |= c->v_b.alloc(n3);
-  rc |= c->v_t0.alloc(n3); rc |= c->v_t1.alloc(n3); rc |= c->v_t2.alloc(n3); rc |= c->v_t3.alloc(n3); rc |= c->v_t4.alloc(n3);
+  rc |= c->v_t0.alloc(n3); rc |= c->v_t1.alloc(n3); rc |= c->v_t2.alloc(n3); rc |= c->v_t3.alloc(n3); rc |= c->v_t4.alloc(n3); rc |= c->v_mg.alloc(n3);
   rc |= c->F.alloc(n3); rc |= c->pdir.alloc(n3); rc |= c->x1.alloc(n3);
   rc |= c->scal.alloc(1);
   rc |= c->part_pAp.alloc((size_t)P.n_slices + (size_t)(c->max_n_constraints + 63) / 64 + 8); rc |= c->part_rz.alloc((size_t)NV / 256 + 8); rc |= c->part_rr.alloc((size_t)NV / 256 + 8);
@@ -291,6 +291,8 @@ extern "C" int tsl_set_param(tsl_ctx* c, const char* key, double v) {
   else if (k == "plastic") c->plastic = (int)v;
   else if (k == "contact") c->contact_enable = (v != 0.0);
   else if (k == "grid_h") c->grid_h = v;
+  else if (k == "grid_extent") c->grid_extent = v;
+  else if (k == "adj_spd_pc") c->adj_spd_pc = (int)v;
   else if (k == "mg") c->mg_enable = (int)v;
   else if (k == "mg_omega") c->mg_omega = v;
   else if (k == "mg_pi_iters") c->mg_pi_iters = (int)v;
@@ -399,8 +401,11 @@ static int assemble(tsl_ctx* c, const double* pos, const double* prev, const dou
   if (grad) hipLaunchKernelGGL(k_mask_vec, dim3(gsz(3 * (size_t)NV)), dim3(256), 0, s, 3 * (size_t)NV, c->frozen.p, grad);
   hipLaunchKernelGGL(k_mask_matrix, dim3(c->n_slices), dim3(256), 0, s, c->n_slices, c->slice_off.p, c->slice_len.p, c->colidx.p, c->fzmask.p, c->mdt2.p,
                      c->vals_full.p, c->vals.p, NV);
-  hipLaunchKernelGGL(k_block_jacobi, dim3(nblk(NV, 256)), dim3(256), 0, s, NV, c->diag_perm.p, c->vals.p, c->nc > 0 ? c->c_diag.p : (const double*)nullptr, c->Dinv.p);
-  c->mg_ops_valid = false;
+  if (!c->pc_frozen) {
+    hipLaunchKernelGGL(k_block_jacobi, dim3(nblk(NV, 256)), dim3(256), 0, s, NV, c->diag_perm.p, c->vals.p, c->nc > 0 ? c->c_diag.p : (const double*)nullptr, c->Dinv.p);
+    c->mg_ops_valid = false;
+    c->pc_separate = false;
+  }
   HIP_OK(hipGetLastError());
   return 0;
 }
@@ -473,9 +478,11 @@ static bool mg_active(tsl_ctx* c) { return !c->mg.empty() && c->mg_enable != 0 &
 // plain y = H x on level 0 (matrix + matrix-free contact), no scalar side effects
 static void mg_spmv0(tsl_ctx* c, const double* x, double* y) {
   hipStream_t s = c->stream;
-  hipLaunchKernelGGL((k_spmv_mw<4, 1, true>), dim3(c->n_slices), dim3(256), 0, s, c->NV, c->n_slices, c->slice_off.p, c->slice_len.p, c->colidx.p, c->vals.p, x, y,
+  const double* vals = c->pc_separate ? c->vals_pc.p : c->vals.p;
+  const double* cH = c->pc_separate ? c->c_H_pc.p : c->c_H.p;
+  hipLaunchKernelGGL((k_spmv_mw<4, 1, true>), dim3(c->n_slices), dim3(256), 0, s, c->NV, c->n_slices, c->slice_off.p, c->slice_len.p, c->colidx.p, vals, x, y,
                      (double*)nullptr, (const int*)nullptr);
-  if (c->nc > 0) hipLaunchKernelGGL(k_contact_matvec, dim3(nblk(c->nc, 64)), dim3(64), 0, s, c->nc, c->c_idx.p, c->rowpos.p, c->c_H.p, x, y, SC(c), -1, 0);
+  if (c->nc > 0) hipLaunchKernelGGL(k_contact_matvec, dim3(nblk(c->nc, 64)), dim3(64), 0, s, c->nc, c->c_idx.p, c->rowpos.p, cH, x, y, SC(c), -1, 0);
 }
 
 // Galerkin coarse operators of the current (masked) matrix; called once per assembly when the preconditioner is active
@@ -566,7 +573,7 @@ static void mg_vcycle(tsl_ctx* c, const double* r, double* z, double* part_rz) {
   hipStream_t s = c->stream;
   const int NV = c->NV, gb = nblk(NV, 256);
   const double* om = c->mg_omega0.p;
-  double* t = c->v_t1.p;
+  double* t = c->v_mg.p;
   hipLaunchKernelGGL(k_mg_jacobi_first, dim3(gb), dim3(256), 0, s, NV, c->Dinv.p, r, om, z);
   for (int k = 0; k < c->mg_nu - 1; k++) {
     mg_spmv0(c, z, t);
@@ -612,7 +619,7 @@ static void launch_pcg_iteration(tsl_ctx* c, int parity, int first, unsigned lon
 // iteration is ~45 short kernels, eager launches leave the GPU idle ~30 % of the time.  The first K1 of the chunk stamps
 // the device clock into a fixed buffer when profiling is on.
 static int pcg_chunk_graph(tsl_ctx* c, int chunk) {
-  const long key = ((long)(mg_active(c) ? 1 : 0) << 40) | ((long)c->nc << 8) | ((long)(c->prof_enable ? 1 : 0) << 7) | (long)chunk | ((long)c->mg_nu << 44) | ((long)c->mg_coarse_sweeps << 48);
+  const long key = ((long)(mg_active(c) ? 1 : 0) << 40) | ((long)c->nc << 8) | ((long)(c->prof_enable ? 1 : 0) << 7) | (long)chunk | ((long)c->mg_nu << 44) | ((long)c->mg_coarse_sweeps << 48) | ((long)(c->pc_separate ? 1 : 0) << 41);
   if (c->pcg_graph && c->pcg_graph_key == key) return 0;
   if (c->pcg_graph) { (void)hipGraphExecDestroy(c->pcg_graph); c->pcg_graph = nullptr; }
   hipGraph_t g = nullptr;
@@ -652,7 +659,7 @@ static int solve_perm(tsl_ctx* c, tsl_solve_stats* st) {
   const double bb = HSC(c)->bb;
   if (!(bb > 0)) return 0;  // zero rhs -> x = 0
   const double tol2 = c->cg_tol * c->cg_tol * bb;
-  bool need_fallback = false;
+  bool need_fallback = false, indefinite = false;
   int total_it = 0;
   const int ncb = c->nc > 0 ? nblk(c->nc, 64) : 0;
   double rr_prev_outer = 1e300;
@@ -704,12 +711,13 @@ static int solve_perm(tsl_ctx* c, tsl_solve_stats* st) {
       if (flag) break;
     }
     if (flag) total_it = total_it - it + HPSC(c)->iters;  // iterations actually executed before the kernels went idle
+    if (flag == 1) indefinite = true;
     if (flag != 2) break;  // breakdown or iteration cap
   }
   st->iters = total_it;
   if (!need_fallback) { st->flag = 0; return 0; }
-  if (mg_active(c)) {
-    // multigrid-PCG failed (H or the cycle not positive definite along some direction): retry with plain block-Jacobi PCG
+  if (mg_active(c) && !indefinite) {
+    // multigrid-PCG stalled: retry with plain block-Jacobi PCG (an indefinite H goes straight to BiCGStab)
     c->mg_suspended = true;
     tsl_solve_stats st2;
     const int rc = solve_perm(c, &st2);
@@ -744,6 +752,12 @@ static int bicgstab(tsl_ctx* c, tsl_solve_stats* st) {
     if (o2) *o2 = h->aux[1];
     return 0;
   };
+  const bool mg = mg_active(c);
+  if (mg && !c->mg_ops_valid) TSL_TRY(mg_setup_operators(c));
+  auto precond = [&](const double* in, double* out) {  // right preconditioner: multigrid V-cycle when available, else block Jacobi
+    if (mg) mg_vcycle(c, in, out, c->part_rz.p);
+    else hipLaunchKernelGGL(k_precond, dim3(gb), dim3(256), 0, s, NV, c->Dinv.p, in, out);
+  };
   double bb;
   TSL_TRY(dots(c->v_b.p, c->v_b.p, nullptr, nullptr, &bb, nullptr));
   double rho = 1, alpha = 1, omega = 1;
@@ -772,7 +786,7 @@ static int bicgstab(tsl_ctx* c, tsl_solve_stats* st) {
     // p = r + beta (p - omega v)
     hipLaunchKernelGGL(k_axpby, dim3(gv), dim3(256), 0, s, n3, -omega, v, 1.0, p);
     hipLaunchKernelGGL(k_axpby, dim3(gv), dim3(256), 0, s, n3, 1.0, r, beta, p);
-    hipLaunchKernelGGL(k_precond, dim3(gb), dim3(256), 0, s, NV, c->Dinv.p, p, ph);
+    precond(p, ph);
     launch_spmv(c, c->vals.p, ph, v, -1, 0);
     double r0v;
     TSL_TRY(dots(r0, v, nullptr, nullptr, &r0v, nullptr));
@@ -781,7 +795,7 @@ static int bicgstab(tsl_ctx* c, tsl_solve_stats* st) {
     // s = r - alpha v
     HIP_OK(hipMemcpyAsync(sv, r, n3 * sizeof(double), hipMemcpyDeviceToDevice, s));
     hipLaunchKernelGGL(k_axpby, dim3(gv), dim3(256), 0, s, n3, -alpha, v, 1.0, sv);
-    hipLaunchKernelGGL(k_precond, dim3(gb), dim3(256), 0, s, NV, c->Dinv.p, sv, sh);
+    precond(sv, sh);
     launch_spmv(c, c->vals.p, sh, t, -1, 0);
     double tt, ts;
     TSL_TRY(dots(t, t, t, sv, &tt, &ts));
@@ -1135,8 +1149,25 @@ extern "C" int tsl_adjoint_step(tsl_ctx* c, int step, int T, const double* pos_b
   const ClothArgs CA = cloth_args(c);
   // pos = x_s, ref_angle = ref_{s-1}: init_folding + ref_angle_backprop_a2ax
   if (c->n_hinge) hipLaunchKernelGGL(k_adj_a2ax, dim3(nblk(c->n_hinge, 256)), dim3(256), 0, s, CA, x_s, ref_prev, ag_s, ag_prev, pg_s);
+  // preconditioner from the SPD-projected Hessian of the same state (block Jacobi + multigrid hierarchy): the operator
+  // below is the un-projected H, which may be indefinite, and smoothers / coarse operators built from it are not safe
+  const bool spd_pc = c->adj_spd_pc && !c->mg.empty() && c->mg_enable != 0;
+  if (spd_pc) {
+    TSL_TRY(assemble(c, x_s, x_prev, x_prev, ref_prev, 1, nullptr));
+    TSL_TRY(mg_setup_operators(c));
+    if (c->vals_pc.n == 0 && c->vals_pc.alloc(c->vals.n)) return tsl_fail("out of device memory (vals_pc)");
+    HIP_OK(hipMemcpyAsync(c->vals_pc.p, c->vals.p, c->vals.n * sizeof(double), hipMemcpyDeviceToDevice, s));
+    if (c->nc > 0) {
+      if (c->c_H_pc.n == 0 && c->c_H_pc.alloc(c->c_H.n)) return tsl_fail("out of device memory (c_H_pc)");
+      HIP_OK(hipMemcpyAsync(c->c_H_pc.p, c->c_H.p, (size_t)c->nc * 144 * sizeof(double), hipMemcpyDeviceToDevice, s));
+    }
+    c->pc_frozen = true;
+  }
   // H.clear_all + compute_Hessian(False)
-  TSL_TRY(assemble(c, x_s, x_prev, x_prev /*vel unused without gradient*/, ref_prev, 0, nullptr));
+  const int rc_asm = assemble(c, x_s, x_prev, x_prev /*vel unused without gradient*/, ref_prev, 0, nullptr);
+  c->pc_frozen = false;
+  if (rc_asm) return rc_asm;
+  if (spd_pc) c->pc_separate = true;
   // p = H^-1 pos_grad[s]
   tsl_solve_stats local;
   if (!st) st = &local;

@@ -1,6 +1,7 @@
 """Balancing task: counterpart of ``Scene`` in /root/reference/code/task_scene/Scene_balancing.py
 (15x7 cloth held by two paired tactile grippers, a heavy ball resting on it).  ``cloth_N``/``cloth_M`` scale
-the grid for the 100k-triangle BASELINE config."""
+the grid for the 100k-triangle BASELINE config; ``geom_scale`` enlarges the whole scene
+(bodies, offsets, contact shell, broad-phase cell) by one factor so that a refined cloth keeps the native 4 mm spacing."""
 import os
 
 import numpy as np
@@ -16,8 +17,9 @@ class Scene(BaseScene):
     _newton_cap = 50  # Scene_balancing.py:251
     _plastic = 0
 
-    def __init__(self, cloth_size=0.06, device="cuda:0", cloth_N=15, cloth_M=7):
+    def __init__(self, cloth_size=0.06, device="cuda:0", cloth_N=15, cloth_M=7, geom_scale=1.0):
         self._cN, self._cM = cloth_N, cloth_M
+        self._gs = float(geom_scale)
         super().__init__(cloth_size=cloth_size, enable_gripper=True, device=device)
         self.cloths[0].k_angle[None] = 3.14
 
@@ -27,14 +29,16 @@ class Scene(BaseScene):
         self.h = self.dt
         self.cloth_cnt = 1
         self.elastic_cnt = 5
-        self.elastic_size = [0.007, 0.015, 0.015, 0.015, 0.015]
+        self.elastic_size = [0.007 * self._gs] + [0.015 * self._gs] * 4
         self.elastic_Nx = 5
         self.elastic_Ny = 5
         self.elastic_Nz = 5
         self.cloth_N = self._cN
         self.cloth_M = self._cM
         self.k_contact = 10000
-        self.eps_contact = 0.00041
+        self.eps_contact = 0.00041 * self._gs
+        self.grid_h = 0.003 * self._gs
+        self.grid_extent = 0.2 * self._gs
         self.eps_v = 0.01
         self.max_n_constraints = 10000 if self._cN <= 15 else 400000
         self.damping = 1.0
@@ -45,7 +49,9 @@ class Scene(BaseScene):
         self.cloths.append(Cloth(self.cloth_N, self.dt, self.cloth_size, self.tot_NV, rho, 0, is_square=False, M=self.cloth_M))
         self.elastic_offset = (self.cloth_N + 1) * (self.cloth_M + 1)
         tmp_tot = self.elastic_offset
-        self.elastics.append(Elastic(self.dt, self.elastic_size[0], tmp_tot, self.elastic_Nx, self.elastic_Ny, self.elastic_Nz, 10000.0, load=True))
+        self.elastics.append(Elastic(self.dt, self.elastic_size[0], tmp_tot, self.elastic_Nx, self.elastic_Ny, self.elastic_Nz, 10000.0 / self._gs, load=True))
+        if self._gs != 1.0:
+            self.elastics[0].vertex = self.elastics[0].vertex * self._gs  # the loaded ball mesh is in absolute coordinates
         tmp_tot += self.elastics[0].n_verts
         for i in range(1, self.elastic_cnt):
             self.elastics.append(tactile(self.dt, tmp_tot, self.elastic_size[i] / 0.03))
@@ -56,12 +62,13 @@ class Scene(BaseScene):
         # Scene_balancing.py:78-86 (cloth centred like the native 0.06 x 0.028 sheet)
         c = self.cloths[0]
         self.cloths[0].init(-0.5 * c.dx * c.N, -0.5 * c.dx * c.M if (self._cN, self._cM) != (15, 7) else -0.015, 0.)
-        self.elastics[0].init(0., 0., 0.0039)
-        self.elastics[1].init(0.023, 0., 0.0079, True)
-        self.elastics[2].init(0.023, 0., -0.0079, False)
-        self.elastics[3].init(-0.023, 0, 0.0079, True)
-        self.elastics[4].init(-0.023, 0, -0.0079, False)
-        self.gripper.init(self, np.array([[0.023, 0., 0.0], [-0.023, 0., 0.0]]))
+        g = self._gs
+        self.elastics[0].init(0., 0., 0.0039 * g)
+        self.elastics[1].init(0.023 * g, 0., 0.0079 * g, True)
+        self.elastics[2].init(0.023 * g, 0., -0.0079 * g, False)
+        self.elastics[3].init(-0.023 * g, 0, 0.0079 * g, True)
+        self.elastics[4].init(-0.023 * g, 0, -0.0079 * g, False)
+        self.gripper.init(self, np.array([[0.023 * g, 0., 0.0], [-0.023 * g, 0., 0.0]]))
 
     def reset_pos(self):
         self.init()
