@@ -17,6 +17,10 @@ s = Scene(cloth_size=size, cloth_N=N, cloth_M=N, geom_scale=gs)
 s.init_all()
 s.mu_cloth_elastic[None] = 5.0
 s.prev_pos.copy_from(s.pos)
+if os.environ.get("FREEZE_BODIES"):
+    fr = s.frozen.t.view(-1, 3)
+    for e in s.elastics:
+        fr[e.offset:e.offset + e.n_verts] = 1
 ctx = s._ensure_ctx()
 for kv in os.environ.get("TSL_PARAMS", "").split(","):
     if "=" in kv:

@@ -508,6 +508,7 @@ extern "C" int tsl_contact_detect(tsl_ctx* c, const double* pos, const double* p
   hipStream_t s = c->stream;
   const int NV = c->NV;
   c->nc = 0;
+  c->bd_valid = false;
   if (c->n_body < 2 || c->NF == 0) { if (nc_host) *nc_host = 0; return 0; }
   // calc_vn
   HIP_OK(hipMemsetAsync(c->vn.p, 0, 3 * (size_t)NV * sizeof(double), s));

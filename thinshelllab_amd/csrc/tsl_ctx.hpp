@@ -12,6 +12,7 @@
 #include <vector>
 
 #include "../../include/tsl_hip.h"
+#include "k_body.hpp"
 
 #define TSL_SLICE 64  // rows per SELL slice == wavefront width on gfx950
 
@@ -140,6 +141,14 @@ struct tsl_ctx {
 
   // ---- solver vectors (permuted AoS, 3*NV)
   DevBuf<double> v_x, v_r, v_z, v_p, v_Ap, v_b, v_t0, v_t1, v_t2, v_t3, v_t4, v_mg;
+  // dense inverse of the small FEM-body diagonal blocks (k_body.hpp)
+  BodyDenseArgs bd_args{};
+  int bd_rows_n = 0, bd_n3max = 0, bd_wg = 0, bd_scr_n = 0, bd_enable = -1;
+  size_t bd_w_total = 0;
+  bool bd_valid = false;
+  DevBuf<int> bd_rows, bd_body_of, bd_local_of, bd_bad;
+  DevBuf<double> bd_W, bd_scr;
+  DevBuf<float> bd_Binv;
   // preconditioner built from a different (SPD-projected) assembly than the operator: adjoint solves (un-projected H)
   DevBuf<double> vals_pc, c_H_pc;
   bool pc_separate = false, pc_frozen = false;

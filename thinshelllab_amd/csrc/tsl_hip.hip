@@ -86,6 +86,9 @@ static void build_pattern(int NV, const std::vector<std::vector<int>>& cliques, 
 
 // ------------------------------------------------------------------------------------------------
 static int mg_build(tsl_ctx* c, const tsl_scene_desc* d);
+static int body_dense_setup(tsl_ctx* c);
+static bool body_active(tsl_ctx* c);
+static void body_zero_dinv(tsl_ctx* c);
 extern "C" const char* tsl_version(void) { return "tsl-hip 0.1 gfx950 fp64"; }
 extern "C" const char* tsl_last_error(void) { return g_tsl_err.c_str(); }
 
@@ -245,10 +248,10 @@ extern "C" int tsl_ctx_create(const tsl_scene_desc* d, tsl_ctx** out) {
   rc |= c->v_t0.alloc(n3); rc |= c->v_t1.alloc(n3); rc |= c->v_t2.alloc(n3); rc |= c->v_t3.alloc(n3); rc |= c->v_t4.alloc(n3); rc |= c->v_mg.alloc(n3);
   rc |= c->F.alloc(n3); rc |= c->pdir.alloc(n3); rc |= c->x1.alloc(n3);
   rc |= c->scal.alloc(1);
-  rc |= c->part_pAp.alloc((size_t)P.n_slices + (size_t)(c->max_n_constraints + 63) / 64 + 8); rc |= c->part_rz.alloc((size_t)NV / 256 + 8); rc |= c->part_rr.alloc((size_t)NV / 256 + 8);
+  rc |= c->part_pAp.alloc((size_t)P.n_slices + (size_t)(c->max_n_constraints + 63) / 64 + 8); rc |= c->part_rz.alloc((size_t)NV / 256 + 8 + 1024); rc |= c->part_rr.alloc((size_t)NV / 256 + 8 + 1024);
   if (rc) { delete c; return -1; }
   if (hipHostMalloc((void**)&c->h_scal, sizeof(SolverScalars) > sizeof(CgScal) ? sizeof(SolverScalars) : sizeof(CgScal)) != hipSuccess) { delete c; return tsl_fail("hipHostMalloc failed"); }
-  c->vals.zero(); c->vals_full.zero(); c->scal.zero();
+  c->vals.zero(); c->vals_full.zero(); c->scal.zero(); c->part_rz.zero(); c->part_rr.zero();
 
   // ---- contact tables
   c->n_body = d->n_body; c->n_pair = d->n_pair;
@@ -256,6 +259,7 @@ extern "C" int tsl_ctx_create(const tsl_scene_desc* d, tsl_ctx** out) {
   if (d->n_pair > 0) c->h_pairs.assign(d->pairs, d->pairs + d->n_pair);
   if (contact_alloc(c, d)) { delete c; return -1; }
   if (mg_build(c, d)) { delete c; return -1; }
+  if (body_dense_setup(c)) { delete c; return -1; }
   (void)hipDeviceSynchronize();
   *out = c;
   return 0;
@@ -293,6 +297,7 @@ extern "C" int tsl_set_param(tsl_ctx* c, const char* key, double v) {
   else if (k == "grid_h") c->grid_h = v;
   else if (k == "grid_extent") c->grid_extent = v;
   else if (k == "adj_spd_pc") c->adj_spd_pc = (int)v;
+  else if (k == "body_inv") { c->bd_enable = (int)v; c->bd_valid = false; }
   else if (k == "mg") c->mg_enable = (int)v;
   else if (k == "mg_omega") c->mg_omega = v;
   else if (k == "mg_pi_iters") c->mg_pi_iters = (int)v;
@@ -315,7 +320,9 @@ extern "C" int tsl_set_frozen(tsl_ctx* c, const int32_t* fr) {
   Scope scope(c);
   (void)hipStreamSynchronize(c->stream);
   c->h_frozen.assign(fr, fr + 3 * (size_t)c->NV);
-  return upload_frozen(c);
+  TSL_TRY(upload_frozen(c));
+  if (c->pcg_graph) { (void)hipGraphExecDestroy(c->pcg_graph); c->pcg_graph = nullptr; }
+  return body_dense_setup(c);
 }
 extern "C" int tsl_set_ext_force(tsl_ctx* c, const double* f) {
   Scope scope(c);
@@ -403,6 +410,7 @@ static int assemble(tsl_ctx* c, const double* pos, const double* prev, const dou
                      c->vals_full.p, c->vals.p, NV);
   if (!c->pc_frozen) {
     hipLaunchKernelGGL(k_block_jacobi, dim3(nblk(NV, 256)), dim3(256), 0, s, NV, c->diag_perm.p, c->vals.p, c->nc > 0 ? c->c_diag.p : (const double*)nullptr, c->Dinv.p);
+    if (body_active(c) && c->bd_valid) body_zero_dinv(c);  // those rows are served by the (lagged) dense inverse
     c->mg_ops_valid = false;
     c->pc_separate = false;
   }
@@ -412,6 +420,7 @@ static int assemble(tsl_ctx* c, const double* pos, const double* prev, const dou
 
 extern "C" int tsl_assemble(tsl_ctx* c, const double* pos, const double* prev, const double* vel, const double* ref, int spd, double* grad) {
   Scope scope(c);
+  c->bd_valid = false;
   return assemble(c, pos, prev, vel, ref, spd, grad);
 }
 
@@ -448,6 +457,80 @@ static int read_scal(tsl_ctx* c) {
 }
 
 static int bicgstab(tsl_ctx* c, tsl_solve_stats* st);
+
+// ------------------------------------------------------------------------------------------------ dense body blocks (k_body.hpp)
+// which elastic bodies get an exact block: at most 512 vertices, at least one free dof
+static int body_dense_setup(tsl_ctx* c) {
+  BodyDenseArgs& A = c->bd_args;
+  A = BodyDenseArgs{};
+  c->bd_valid = false; c->bd_rows_n = 0; c->bd_n3max = 0; c->bd_wg = 0; c->bd_scr_n = 0; c->bd_w_total = 0;
+  std::vector<int> rows, body_of(c->NV, -1), local_of(c->NV, 0);
+  for (const ElasticDev& e : c->h_el) {
+    if (A.nb >= TSL_MAX_DENSE_BODIES || e.n_verts > 512 || e.n_verts < 2) continue;
+    bool any_free = false;
+    for (int v = e.v_offset; v < e.v_offset + e.n_verts && !any_free; v++)
+      any_free = !(c->h_frozen[3 * v] && c->h_frozen[3 * v + 1] && c->h_frozen[3 * v + 2]);
+    if (!any_free) continue;
+    const int b = A.nb++;
+    A.n3[b] = 3 * e.n_verts;
+    A.rows_off[b] = (int)rows.size();
+    A.w_off[b] = (long)c->bd_w_total;
+    A.scr_off[b] = c->bd_scr_n;
+    A.wg_off[b] = c->bd_wg;
+    for (int k = 0; k < e.n_verts; k++) {
+      const int v = e.v_offset + k;
+      rows.push_back(c->h_rowpos[v]); body_of[v] = b; local_of[v] = k;
+    }
+    c->bd_w_total += (size_t)A.n3[b] * A.n3[b];
+    c->bd_scr_n += A.n3[b];
+    c->bd_wg += (A.n3[b] + BODY_APPLY_ROWS - 1) / BODY_APPLY_ROWS;
+    c->bd_n3max = std::max(c->bd_n3max, A.n3[b]);
+  }
+  A.wg_off[A.nb] = c->bd_wg;
+  c->bd_rows_n = (int)rows.size();
+  if (!A.nb) return 0;
+  TSL_TRY(c->bd_rows.upload(rows)); TSL_TRY(c->bd_body_of.upload(body_of)); TSL_TRY(c->bd_local_of.upload(local_of));
+  if (c->bd_bad.alloc(TSL_MAX_DENSE_BODIES) | c->bd_W.alloc(c->bd_w_total) | c->bd_Binv.alloc(c->bd_w_total) | c->bd_scr.alloc(4 * (size_t)c->bd_scr_n)) return -1;
+  A.rows = c->bd_rows.p; A.body_of = c->bd_body_of.p; A.local_of = c->bd_local_of.p;
+  return 0;
+}
+
+// auto (-1): only together with the cloth multigrid -- on the reference-size scenes the coarse 15x7 cloth, not the bodies,
+// limits PCG and the dense apply (27 MB per sweep) costs more than it saves
+static bool body_active(tsl_ctx* c) {
+  if (c->bd_args.nb <= 0 || c->bd_enable == 0) return false;
+  return c->bd_enable > 0 || (!c->mg.empty() && c->mg_enable != 0);
+}
+
+static void body_zero_dinv(tsl_ctx* c) {
+  hipLaunchKernelGGL(k_body_zero_dinv, dim3(nblk(c->bd_rows_n, 256)), dim3(256), 0, c->stream, c->bd_args, c->bd_rows_n, c->Dinv.p);
+}
+
+// (re)build the dense inverses from the current masked matrix + contact blocks; Dinv must hold the point-Jacobi blocks
+static int body_build_inverse(tsl_ctx* c) {
+  hipStream_t s = c->stream;
+  const BodyDenseArgs& A = c->bd_args;
+  HIP_OK(hipMemsetAsync(c->bd_W.p, 0, c->bd_w_total * sizeof(double), s));
+  HIP_OK(hipMemsetAsync(c->bd_bad.p, 0, TSL_MAX_DENSE_BODIES * sizeof(int), s));
+  for (int b = 0; b < A.nb; b++)
+    hipLaunchKernelGGL(k_body_gather, dim3(A.n3[b] / 3), dim3(64), 0, s, A, b, c->slice_off.p, c->slice_len.p, c->colidx.p, c->perm.p, c->vals.p, c->bd_W.p);
+  if (c->nc > 0) hipLaunchKernelGGL(k_body_contact, dim3(nblk(c->nc, 64)), dim3(64), 0, s, A, c->nc, c->c_idx.p, c->c_H.p, c->bd_W.p);
+  double* col[2] = {c->bd_scr.p, c->bd_scr.p + 2 * (size_t)c->bd_scr_n};
+  double* row[2] = {c->bd_scr.p + c->bd_scr_n, c->bd_scr.p + 3 * (size_t)c->bd_scr_n};
+  hipLaunchKernelGGL(k_body_gj_init, dim3(nblk(c->bd_n3max, 256), A.nb), dim3(256), 0, s, A, c->bd_W.p, col[0], row[0]);
+  const dim3 grid(nblk((long)c->bd_n3max * c->bd_n3max, 256), A.nb);
+  for (int k = 0; k < c->bd_n3max; k++)
+    hipLaunchKernelGGL(k_body_gj, grid, dim3(256), 0, s, A, k, c->bd_W.p, col[k & 1], row[k & 1], col[(k & 1) ^ 1], row[(k & 1) ^ 1], c->bd_bad.p);
+  hipLaunchKernelGGL(k_body_finalize, grid, dim3(256), 0, s, A, c->bd_W.p, c->bd_bad.p, c->Dinv.p, c->bd_Binv.p);
+  body_zero_dinv(c);
+  c->bd_valid = true;
+  HIP_OK(hipGetLastError());
+  return 0;
+}
+
+static void body_apply(tsl_ctx* c, int mode, const double* r, const double* t, double* z, const double* rdot, double* part) {
+  hipLaunchKernelGGL(k_body_apply, dim3(c->bd_wg), dim3(256), 0, c->stream, c->bd_args, c->bd_Binv.p, mode, r, t, z, rdot, part);
+}
 
 // ------------------------------------------------------------------------------------------------ multigrid (k_mg.hpp)
 static int mg_build(tsl_ctx* c, const tsl_scene_desc* d) {
@@ -574,10 +657,13 @@ static void mg_vcycle(tsl_ctx* c, const double* r, double* z, double* part_rz) {
   const int NV = c->NV, gb = nblk(NV, 256);
   const double* om = c->mg_omega0.p;
   double* t = c->v_mg.p;
+  const bool bd = body_active(c) && c->bd_valid;
   hipLaunchKernelGGL(k_mg_jacobi_first, dim3(gb), dim3(256), 0, s, NV, c->Dinv.p, r, om, z);
+  if (bd) body_apply(c, 0, r, nullptr, z, nullptr, nullptr);
   for (int k = 0; k < c->mg_nu - 1; k++) {
     mg_spmv0(c, z, t);
     hipLaunchKernelGGL(k_mg_jacobi_next, dim3(gb), dim3(256), 0, s, NV, c->Dinv.p, r, t, om, z, (const double*)nullptr, (double*)nullptr);
+    if (bd) body_apply(c, 1, r, t, z, nullptr, nullptr);
   }
   mg_spmv0(c, z, t);
   for (MgCloth* mc : c->mg) {
@@ -590,6 +676,7 @@ static void mg_vcycle(tsl_ctx* c, const double* r, double* z, double* part_rz) {
     mg_spmv0(c, z, t);
     const bool lastk = (k == c->mg_nu - 1);
     hipLaunchKernelGGL(k_mg_jacobi_next, dim3(gb), dim3(256), 0, s, NV, c->Dinv.p, r, t, om, z, lastk ? r : (const double*)nullptr, lastk ? part_rz : (double*)nullptr);
+    if (bd) body_apply(c, 1, r, t, z, lastk ? r : (const double*)nullptr, lastk ? part_rz + gb : (double*)nullptr);
   }
 }
 
@@ -613,13 +700,14 @@ static void launch_pcg_iteration(tsl_ctx* c, int parity, int first, unsigned lon
   hipLaunchKernelGGL(k_pcg_update, dim3(nblk(NV, 256)), dim3(256), 0, s, NV, p_new, c->v_Ap.p, c->Dinv.p, c->v_x.p, c->v_r.p, c->v_z.p, c->part_pAp.p, c->part_rz.p, c->part_rr.p,
                      PSC(c), parity, (const double*)nullptr, (const double*)nullptr, mg ? 0 : 1);
   if (mg) mg_vcycle(c, c->v_r.p, c->v_z.p, c->part_rz.p);
+  else if (body_active(c) && c->bd_valid) body_apply(c, 0, c->v_r.p, nullptr, c->v_z.p, c->v_r.p, c->part_rz.p + nblk(NV, 256));
 }
 
 // Chunk of `chunk` (even) iterations with parities 1,0,1,0,... captured once as a hipGraph and replayed: a multigrid-PCG
 // iteration is ~45 short kernels, eager launches leave the GPU idle ~30 % of the time.  The first K1 of the chunk stamps
 // the device clock into a fixed buffer when profiling is on.
 static int pcg_chunk_graph(tsl_ctx* c, int chunk) {
-  const long key = ((long)(mg_active(c) ? 1 : 0) << 40) | ((long)c->nc << 8) | ((long)(c->prof_enable ? 1 : 0) << 7) | (long)chunk | ((long)c->mg_nu << 44) | ((long)c->mg_coarse_sweeps << 48) | ((long)(c->pc_separate ? 1 : 0) << 41);
+  const long key = ((long)(mg_active(c) ? 1 : 0) << 40) | ((long)c->nc << 8) | ((long)(c->prof_enable ? 1 : 0) << 7) | (long)chunk | ((long)c->mg_nu << 44) | ((long)c->mg_coarse_sweeps << 48) | ((long)(c->pc_separate ? 1 : 0) << 41) | ((long)((body_active(c) && c->bd_valid) ? 1 : 0) << 42);
   if (c->pcg_graph && c->pcg_graph_key == key) return 0;
   if (c->pcg_graph) { (void)hipGraphExecDestroy(c->pcg_graph); c->pcg_graph = nullptr; }
   hipGraph_t g = nullptr;
@@ -662,11 +750,14 @@ static int solve_perm(tsl_ctx* c, tsl_solve_stats* st) {
   bool need_fallback = false, indefinite = false;
   int total_it = 0;
   const int ncb = c->nc > 0 ? nblk(c->nc, 64) : 0;
+  if (body_active(c) && !c->bd_valid) TSL_TRY(body_build_inverse(c));
+  const bool bd = body_active(c) && c->bd_valid;
+  const int n_rz = gb + (bd ? c->bd_wg : 0);
   double rr_prev_outer = 1e300;
   for (int outer = 0; outer < 20; outer++) {
     PcgScal hs;
     memset(&hs, 0, sizeof(hs));
-    hs.bb = bb; hs.thresh2 = 0.25 * tol2; hs.n_part1 = c->n_slices + ncb; hs.n_part2 = gb;
+    hs.bb = bb; hs.thresh2 = 0.25 * tol2; hs.n_part1 = c->n_slices + ncb; hs.n_part2 = n_rz;
     HIP_OK(hipMemcpyAsync(c->scal.p, &hs, sizeof(PcgScal), hipMemcpyHostToDevice, s));
     if (outer > 0) launch_spmv(c, c->vals.p, c->v_x.p, c->v_Ap.p, -1, 0);
     // true residual, z = M^-1 r, partial r.z / r.r
@@ -675,9 +766,9 @@ static int solve_perm(tsl_ctx* c, tsl_solve_stats* st) {
     if (mg_active(c)) {
       if (!c->mg_ops_valid) TSL_TRY(mg_setup_operators(c));
       mg_vcycle(c, c->v_r.p, c->v_z.p, c->part_rz.p);
-    }
+    } else if (bd) body_apply(c, 0, c->v_r.p, nullptr, c->v_z.p, c->v_r.p, c->part_rz.p + gb);
     hipLaunchKernelGGL(k_sum_partials, dim3(1), dim3(256), 0, s, c->part_rr.p, gb, &PSC(c)->rr_last);
-    hipLaunchKernelGGL(k_sum_partials, dim3(1), dim3(256), 0, s, c->part_rz.p, gb, &PSC(c)->rz_last);
+    hipLaunchKernelGGL(k_sum_partials, dim3(1), dim3(256), 0, s, c->part_rz.p, n_rz, &PSC(c)->rz_last);
     TSL_TRY(read_scal(c));
     const double rr0 = HPSC(c)->rr_last;
     st->rel_residual = sqrt(rr0 / bb);
@@ -753,10 +844,14 @@ static int bicgstab(tsl_ctx* c, tsl_solve_stats* st) {
     return 0;
   };
   const bool mg = mg_active(c);
+  if (body_active(c) && !c->bd_valid) TSL_TRY(body_build_inverse(c));
   if (mg && !c->mg_ops_valid) TSL_TRY(mg_setup_operators(c));
   auto precond = [&](const double* in, double* out) {  // right preconditioner: multigrid V-cycle when available, else block Jacobi
     if (mg) mg_vcycle(c, in, out, c->part_rz.p);
-    else hipLaunchKernelGGL(k_precond, dim3(gb), dim3(256), 0, s, NV, c->Dinv.p, in, out);
+    else {
+      hipLaunchKernelGGL(k_precond, dim3(gb), dim3(256), 0, s, NV, c->Dinv.p, in, out);
+      if (body_active(c) && c->bd_valid) body_apply(c, 0, in, nullptr, out, nullptr, nullptr);
+    }
   };
   double bb;
   TSL_TRY(dots(c->v_b.p, c->v_b.p, nullptr, nullptr, &bb, nullptr));
@@ -859,6 +954,7 @@ extern "C" int tsl_step(tsl_ctx* c, double* pos, double* prev, double* vel, doub
   const size_t n3 = 3 * (size_t)c->NV;
   tsl_step_stats st;
   memset(&st, 0, sizeof(st));
+  c->bd_valid = false;  // dense body inverses are rebuilt once per step (first solve) and lagged over its Newton iterations
   // timestep_init: prev_pos <- pos (BaseScene.py:1291-1303)
   HIP_OK(hipMemcpyAsync(prev, pos, n3 * sizeof(double), hipMemcpyDeviceToDevice, s));
   // calc_vn + projection_query + contact_analysis
@@ -1151,10 +1247,13 @@ extern "C" int tsl_adjoint_step(tsl_ctx* c, int step, int T, const double* pos_b
   if (c->n_hinge) hipLaunchKernelGGL(k_adj_a2ax, dim3(nblk(c->n_hinge, 256)), dim3(256), 0, s, CA, x_s, ref_prev, ag_s, ag_prev, pg_s);
   // preconditioner from the SPD-projected Hessian of the same state (block Jacobi + multigrid hierarchy): the operator
   // below is the un-projected H, which may be indefinite, and smoothers / coarse operators built from it are not safe
-  const bool spd_pc = c->adj_spd_pc && !c->mg.empty() && c->mg_enable != 0;
+  const bool have_mg = !c->mg.empty() && c->mg_enable != 0;
+  const bool spd_pc = c->adj_spd_pc && (have_mg || body_active(c));
+  c->bd_valid = false;
   if (spd_pc) {
     TSL_TRY(assemble(c, x_s, x_prev, x_prev, ref_prev, 1, nullptr));
-    TSL_TRY(mg_setup_operators(c));
+    if (body_active(c)) TSL_TRY(body_build_inverse(c));
+    if (have_mg) TSL_TRY(mg_setup_operators(c));
     if (c->vals_pc.n == 0 && c->vals_pc.alloc(c->vals.n)) return tsl_fail("out of device memory (vals_pc)");
     HIP_OK(hipMemcpyAsync(c->vals_pc.p, c->vals.p, c->vals.n * sizeof(double), hipMemcpyDeviceToDevice, s));
     if (c->nc > 0) {
