@@ -3,16 +3,19 @@
 
     python bench.py --gpus N --steps K --warmup W          (N > 1: launched by torch.distributed.run)
 
-One "step" = one implicit-Euler time step of the workload scene (contact detection, Newton loop with PCG solves
-and line search, velocity / plastic update: BaseScene.time_step) PLUS its reverse-mode adjoint step
-(Grad.transfer_grad: un-projected Hessian, one linear solve, back-propagation kernels).  The timed region runs
+Default workload = BASELINE.json configs[3] ("cfg4": cloth on ball + 4 tactile pads, 100k triangles, contact), the
+configuration the metric is quoted on; --workload drape runs the contact-free pinned cloth of the same size.
+One "step" = one implicit-Euler time step of the workload scene (gripper drive, contact detection, Newton loop with
+PCG solves and line search, velocity / plastic update: BaseScene.time_step) PLUS its reverse-mode adjoint step
+(Grad.transfer_grad: contact re-detection, un-projected Hessian, one linear solve, back-propagation kernels).  The timed region runs
 K forward steps onto the tape and then the K adjoint steps of the same rollout, all state resident in HBM.
 value = cloth triangles x K x n_gpus / wall seconds (max over ranks).  Ranks run independent scene rollouts
 (trajectory-optimisation batch): no data-path collective, "scaling": "weak".
 
 The JSON line also carries
-  roofline     -- dominant kernel (the SELL-64 block SpMV of one PCG iteration): algorithmic bytes per launch /
-                  average launch duration measured with HIP events on the engine's stream, against 8 TB/s HBM;
+  roofline     -- the HBM-bound kernel of the PCG iteration (SELL-64 block SpMV fused with the direction update):
+                  algorithmic bytes per launch / average launch duration measured on the device clock inside sampled
+                  launches of the timed region (agrees with the rocprofv3 kernel trace), against 8 TB/s HBM;
   cpu_baseline -- the fp64 CPU restatement (oracle/, "port": the reference itself needs taichi + cupy/CUDA and
                   cannot run) timed on this box's host cores on a bounded sample of the same workload.
 """
@@ -29,54 +32,90 @@ if ROOT not in sys.path:
 HBM_PEAK_GBS = 8000.0  # /opt/skills/guides/MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
 
 
+GS_CFG4 = 224 * 0.004 / 0.06  # similarity factor that keeps the native 4 mm cloth spacing of Scene_balancing at 224x224
+
+
 def build_scene(args, rank):
-    from thinshelllab_amd.task_scene.Scene_drape import Scene
-    s = Scene(cloth_size=args.cloth_size, N=args.grid, M=args.grid, Kb=100.0, k_angle=3.14, perturb=1e-4 * (1 + 0.01 * rank), device=f"cuda:{int(os.environ.get('LOCAL_RANK', '0'))}",
-              newton_cap=50)
+    dev = f"cuda:{int(os.environ.get('LOCAL_RANK', '0'))}"
+    if args.workload == "drape":
+        from thinshelllab_amd.task_scene.Scene_drape import Scene
+        s = Scene(cloth_size=args.cloth_size, N=args.grid, M=args.grid, Kb=100.0, k_angle=3.14, perturb=1e-4 * (1 + 0.01 * rank), device=dev, newton_cap=50)
+        s.init_all()
+        return s
+    # cfg4: cloth on ball + 4 tactile pads, 224x224 cloth, heavy collision path
+    from thinshelllab_amd.task_scene.Scene_balancing import Scene
+    gs = args.grid * 0.004 / 0.06
+    s = Scene(cloth_size=args.grid * 0.004, cloth_N=args.grid, cloth_M=args.grid, geom_scale=gs, device=dev)
     s.init_all()
+    s.mu_cloth_elastic[None] = 5.0  # trajopt_balancing.py:42
+    s.prev_pos.copy_from(s.pos)
+    s._bench_gs = gs
+    s._bench_rank = rank
     return s
 
 
-def run_rollout(scene, grad, K, timed=True):
+def _action(scene, f):
+    """gripper drive of the cfg4 rollout: both paired grippers rise and tilt a little every step (the rank only changes
+    the amplitude by 1 %, so the ranks run different but equally expensive rollouts)"""
+    import numpy as np
+    n_part = scene.gripper.n_part
+    a = 1.0 + 0.01 * scene._bench_rank
+    dpos = np.zeros((n_part, 3)); drot = np.zeros((n_part, 3))
+    dpos[:, 2] = 5e-5 * scene._bench_gs * a
+    drot[:, 1] = 2e-3 * a
+    scene.action(f, dpos, drot)
+
+
+def run_rollout(scene, grad, K, args):
     """K forward steps onto the tape, loss seed on the last state, K adjoint steps."""
-    stats = dict(newton=0, cg_fwd=0, ls=0, cg_adj=0, fallback=0)
+    contact = None
+    if args.workload == "cfg4":
+        from thinshelllab_amd.engine.geometry import projection_query as contact
+    stats = dict(newton=0, cg_fwd=0, ls=0, cg_adj=0, fallback=0, nc=0)
     grad.copy_pos(scene, 0)
     for f in range(1, K + 1):
-        st = scene.time_step(None, f)
+        if contact is not None:
+            _action(scene, f)
+        st = scene.time_step(contact, f)
         grad.copy_pos(scene, f)
         stats["newton"] += st["newton_iters"]; stats["cg_fwd"] += st["cg_iters"]; stats["ls"] += st["ls_evals"]; stats["fallback"] += st["fallback"]
+        stats["nc"] += st.get("nc", 0)
     c = scene.cloths[0]
     grad.pos_grad.t.zero_(); grad.angleref_grad.t.zero_()
     grad.pos_grad.t[K, c.offset:c.offset + c.NV, 2] = 1.0  # dL/dx_K: lift the cloth (sum of z)
     for s in range(K, 0, -1):
-        grad.transfer_grad(s, scene, None)
+        grad.transfer_grad(s, scene, contact)
         stats["cg_adj"] += grad.last_stats["iters"]; stats["fallback"] += int(grad.last_stats["flag"] != 0)
     return stats
 
 
-def cpu_baseline(args, gpu_stats, K):
-    """Oracle timed on a bounded sample: one energy evaluation, one gradient+Hessian assembly and a fixed number
-    of PCG iterations on the SAME mesh and state, scaled by the iteration counts the GPU run needed (the CPU
-    restatement runs the same algorithm; a full 100k-triangle step takes minutes on the host)."""
+def cpu_baseline(args, scene, gpu_stats, K):
+    """Oracle timed on a bounded sample of the SAME scene and state: one contact detection, one energy evaluation, one
+    gradient+Hessian assembly and a fixed number of PCG iterations, extrapolated to a full fwd+adjoint step with the
+    Newton / line-search counts of the GPU run and the iteration count of the oracle's own solver (block-Jacobi PCG),
+    which the GPU library measures by solving one system of the run in block-Jacobi mode (a full step of this size
+    takes the host tens of minutes)."""
     from oracle import pyoracle as po
-    import numpy as np
-    N = args.grid
-    o = po.OracleScene(dt=5e-3, newton_cap=50)
-    ci = o.add_cloth(N, N, args.cloth_size)
-    o.cloth_init(ci, 0, 0, 0)
-    o.finalize()
-    i, j = np.meshgrid(np.arange(N + 1), np.arange(N + 1), indexing="ij")
-    o.pos[:, 2] = (1e-4 * np.sin(7.0 * i) * np.cos(5.0 * j)).reshape(-1)
-    o.prev_pos[:] = o.pos
-    fr = o.frozen.reshape(-1, 3); fr[N * (N + 1):] = 1
-    o.push_down_all()
-    # the OpenMP restatement is memory-bound: pick the thread count that runs the PCG iteration fastest on this host
+    from oracle.mirror import oracle_from_scene
+    import torch
+    ctx = scene._ensure_ctx()
+    # iterations per solve of the oracle's algorithm on this system
+    ctx.set_param("mg", 0); ctx.set_param("body_inv", 0); ctx.set_param("cg_maxit", 200000)
+    scene.compute_residual_and_Hessian(spd=True)
+    _, st = ctx.solve(scene.F.to_torch())
+    its_bj = max(int(st["iters"]), 1)
+    ctx.set_param("mg", -1); ctx.set_param("body_inv", -1)
+    torch.cuda.synchronize()
+    o = oracle_from_scene(po, scene, check_init=False)
     ncpu = os.cpu_count() or 1
     po.set_threads(min(ncpu, 8))
+    t_contact = 0.0
+    if args.workload == "cfg4":
+        t0 = time.time(); o.calc_vn(); o.projection_query(); o.contact_analysis(); t_contact = time.time() - t0
     o.newton_step_init(); o.compute_energy(); o.compute_residual_and_Hessian(True)
     b = o.arr("F").copy()
     best = None
-    for th in sorted({min(ncpu, t) for t in (8, 16, 32, 64)}):
+    for th in sorted({min(ncpu, t) for t in (8, 16, 32, 64)}):  # memory-bound OpenMP code: pick the fastest thread count
         po.set_threads(th)
         o.set_solver(1e-30, 20)
         o.stats(reset=True)
@@ -95,19 +134,23 @@ def cpu_baseline(args, gpu_stats, K):
     t_it = t_cg / it_done
     n_asm = gpu_stats["newton"] + K          # forward assemblies + one per adjoint step
     n_e = gpu_stats["newton"] + gpu_stats["ls"]
-    n_cg = gpu_stats["cg_fwd"] + gpu_stats["cg_adj"]
-    t_total = n_asm * t_asm + n_e * t_e + n_cg * t_it
-    T = 2 * N * N
+    n_solve = gpu_stats["newton"] + K
+    t_total = 2 * K * t_contact + n_asm * t_asm + n_e * t_e + n_solve * its_bj * t_it
+    T = 2 * args.grid * args.grid
     return {"value": T * K / t_total, "unit": "element-steps/s", "cores": cores, "kind": "port",
-            "sample": f"oracle ({cores} OpenMP threads of {ncpu} host cpus) on the same {N}x{N} cloth: 1 energy ({t_e:.3f}s) + 1 assembly ({t_asm:.3f}s) + {it_done} PCG iterations "
-                      f"({t_it * 1e3:.2f} ms each), scaled by the GPU run's counts ({n_asm} assemblies, {n_e} energies, {n_cg} PCG iterations)"}
+            "sample": f"oracle ({cores} OpenMP threads of {ncpu} host cpus) on the same scene and state: 1 contact detection ({t_contact:.3f}s) + 1 energy ({t_e:.3f}s) + "
+                      f"1 assembly ({t_asm:.3f}s) + {it_done} PCG iterations ({t_it * 1e3:.2f} ms each); extrapolated to {K} fwd+adjoint steps with the GPU run's "
+                      f"{n_asm} assemblies / {n_e} energy evaluations / {n_solve} solves and {its_bj} block-Jacobi PCG iterations per solve (the oracle's solver, "
+                      f"count measured by the GPU library in block-Jacobi mode on one system of the run)"}
 
 
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=3)
-    ap.add_argument("--warmup", type=int, default=1)
+    ap.add_argument("--warmup", type=int, default=2)
+    ap.add_argument("--workload", choices=["cfg4", "drape"], default="cfg4",
+                    help="cfg4: cloth on ball + 4 tactile pads with contact (the configuration the metric is quoted on); drape: contact-free pinned cloth")
     ap.add_argument("--grid", type=int, default=224, help="cloth grid N = M (224 -> 100,352 triangles)")
     ap.add_argument("--cloth-size", type=float, default=0.1 / 15 * 224, help="edge length of the square cloth in m (default keeps the reference dx = 0.1/15)")
     ap.add_argument("--cg-tol", type=float, default=1e-10)
@@ -128,17 +171,18 @@ def main():
     K, W = args.steps, args.warmup
     ctx = scene._ensure_ctx()
     ctx.set_param("cg_tol", args.cg_tol)
-    grad = Grad(scene, max(K, W) + 1, 0)
+    n_part = scene.gripper.n_part if args.workload == "cfg4" else 0
+    grad = Grad(scene, max(K, W) + 1, n_part)
     grad.init_mass(scene)
     if W > 0:
-        run_rollout(scene, grad, W)
+        run_rollout(scene, grad, W, args)
 
     barrier = batch.barrier
 
     ctx.profile_reset(True)
     barrier()
     t0 = time.perf_counter()
-    stats = run_rollout(scene, grad, K)
+    stats = run_rollout(scene, grad, K, args)
     barrier()
     elapsed = time.perf_counter() - t0
     prof = ctx.profile_read()
@@ -151,22 +195,25 @@ def main():
         "value": value, "unit": "element-steps/s", "n_gpus": world, "steps": K, "warmup": W,
         "ms_per_step": elapsed / K * 1e3, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
         "dtype": "f64", "data": "synthetic",
-        "config": {"workload": f"{args.grid}x{args.grid} square cloth ({T} triangles, dx={args.cloth_size / args.grid:.3e} m), one pinned row, gravity drape; "
-                               f"per step: implicit-Euler Newton+PCG time step + adjoint transfer_grad; one independent scene per GPU",
-                   "triangles": T, "cg_tol": args.cg_tol,
+        "config": {"workload": (f"cfg4: Scene_balancing (cloth on ball + 4 tactile pads, paired grippers driven every step) with a {args.grid}x{args.grid} cloth "
+                                f"({T} triangles) and the whole scene enlarged x{args.grid * 0.004 / 0.06:.2f} so that the cloth keeps its native 4 mm spacing; "
+                                if args.workload == "cfg4" else
+                                f"drape: {args.grid}x{args.grid} square cloth ({T} triangles, dx={args.cloth_size / args.grid:.3e} m), one pinned row, no contact; ") +
+                               "per step: implicit-Euler Newton+PCG time step (contact detection, friction) + adjoint transfer_grad; one independent scene per GPU",
+                   "triangles": T, "tot_NV": scene.tot_NV, "cg_tol": args.cg_tol, "active_contacts_per_step": stats["nc"] / K,
                    "newton_iters_per_step": stats["newton"] / K, "pcg_iters_per_fwd_solve": stats["cg_fwd"] / max(stats["newton"], 1),
                    "pcg_iters_per_adjoint_solve": stats["cg_adj"] / K, "line_search_evals_per_step": stats["ls"] / K, "solver_fallbacks": stats["fallback"]},
     }
     if prof["ms_per_launch"] > 0:
         ach = prof["bytes_per_launch"] / (prof["ms_per_launch"] * 1e-3) / 1e9
         out["roofline"] = {"bound": "hbm", "achieved": ach, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": ach / HBM_PEAK_GBS, "traffic": None,
-                           "kernel": "k_spmv (SELL-64 3x3-block SpMV, one launch per PCG iteration)",
+                           "kernel": "k_pcg_spmv (SELL-64 3x3-block SpMV fused with the PCG direction update and p.Ap, one launch per PCG iteration)",
                            "bytes_per_launch": prof["bytes_per_launch"], "avg_launch_us": prof["ms_per_launch"] * 1e3,
                            "avg_launch_us_hip_events": prof["ms_per_launch_events"] * 1e3, "launches": prof["launches"]}
     if rank == 0:
         if world == 1 and not args.no_cpu_baseline:
             try:
-                out["cpu_baseline"] = cpu_baseline(args, stats, K)
+                out["cpu_baseline"] = cpu_baseline(args, scene, stats, K)
             except Exception as e:  # the oracle is optional test infrastructure; never fail the GPU number on it
                 out["cpu_baseline"] = {"value": None, "unit": "element-steps/s", "cores": os.cpu_count(), "kind": "port", "sample": f"failed: {e}"}
         print(json.dumps(out), flush=True)

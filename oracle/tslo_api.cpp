@@ -44,7 +44,8 @@ void tslo_set_scalar(void* h, const char* name, double v) {
   else if (n == "damping") s.damping = v;
   else if (n == "newton_cap") s.newton_cap = (int)v;
   else if (n == "plastic") s.plastic = (int)v;
-  else if (n == "grid_h") { s.grid_h = v; s.grid_n = (int)std::floor(0.2 / v) * 2; s.grid_bound = v * (s.grid_n - 1) / 2; }
+  else if (n == "grid_h") { s.grid_h = v; s.grid_n = (int)std::floor(s.grid_extent / v) * 2; s.grid_bound = v * (s.grid_n - 1) / 2; }
+  else if (n == "grid_extent") { s.grid_extent = v; s.grid_n = (int)std::floor(v / s.grid_h) * 2; s.grid_bound = s.grid_h * (s.grid_n - 1) / 2; }
   else if (n.rfind("cloth", 0) == 0) {
     int ci = n[5] - '0';
     std::string f = n.substr(7);

@@ -169,6 +169,7 @@ struct Scene {
   int last_solve_flag = 0;
   // geometry.py:8-19 (uniform grid)
   double grid_h = 0.003;
+  double grid_extent = 0.2;  // half-width of the broad-phase box (geometry.py:8-19 hard-codes 0.2 m; scaled scenes enlarge it)
   int grid_n = 0;
   double grid_bound = 0;
 

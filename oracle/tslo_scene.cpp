@@ -41,7 +41,7 @@ void Scene::finalize() {
   force_T.assign(mc, V3()); force_f.assign(mc, V3());
   tmp_z_not_frozen.assign((size_t)tot_NV * 3, 0.0); tmp_z_frozen.assign((size_t)tot_NV * 3, 0.0);
   // geometry.py:8-10
-  grid_n = (int)std::floor(0.2 / grid_h) * 2;
+  grid_n = (int)std::floor(grid_extent / grid_h) * 2;
   grid_bound = grid_h * (grid_n - 1) / 2;
   // static sparsity: every vertex set one element couples
   static_cliques.clear();

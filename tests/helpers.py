@@ -1,80 +1,6 @@
-"""Shared builders: the same scene in the product (thinshelllab_amd, HIP) and in the oracle (CPU restatement)."""
-import numpy as np
+"""Shared builders for the parity tests (the implementation lives with the oracle: oracle/mirror.py)."""
+import os
+import sys
 
-
-def oracle_from_scene(po, sys, check_init=True):
-    """Build an OracleScene mirroring a product scene (after ``init_all``): same bodies, parameters, contact
-    pairs, gripper and state.  With ``check_init`` the oracle runs ITS OWN initialisation code (mesh tables, poses,
-    rest matrices, masses, surface orientation) and the result is compared with the product's host code."""
-    g = np.asarray(sys.gravity[None], dtype=np.float64)
-    o = po.OracleScene(dt=sys.dt, k_contact=sys.k_contact, eps_contact=sys.eps_contact, eps_v=sys.eps_v, damping=sys.damping,
-                       max_n_constraints=sys.max_n_constraints, newton_cap=sys._newton_cap, plastic=sys._plastic,
-                       effector_cnt=sys.effector_cnt, gravity=tuple(g), mu_cloth_elastic=sys.mu_cloth_elastic.value)
-    for i, c in enumerate(sys.cloths):
-        ci = o.add_cloth(c.N, c.M, c.dx * c.N, rho=c.rho, is_square=False)
-        for k in ("Kb", "Kl", "Ka", "k_angle"):
-            o.set_scalar(f"cloth{i}.{k}", getattr(c, k).value)
-        kind, ox, oy, oz, curv = c._init_args
-        if kind == "flat":
-            o.cloth_init(ci, ox, oy, oz)
-        elif kind == "fold":
-            o.cloth_init(ci, ox, oy, oz, fold=True, curv=curv)
-        else:
-            o.L.tslo_cloth_init_mesh(o.h, ci)
-    for e in sys.elastics:
-        if e.kind == 0:
-            ei = o.add_tactile(e.ratio, e.F_ox_array, e.F_vertices_array, e.f2v_array)
-        elif getattr(e, "load", False):
-            ei = o.add_loaded(e.density, e.vertex, e.tet_mesh, e.surface_mesh)
-        else:
-            ei = o.add_box(e.dx * (int(e.n_cube.max()) - 1), *[int(x) for x in e.n_cube], density=e.density)
-        o.elastic_init(ei, *e._init_args)
-    o.finalize()
-    for i, c in enumerate(sys.cloths):
-        o.set_body_gravity(0, i, c.gravity.to_numpy())
-    for i, e in enumerate(sys.elastics):
-        o.set_body_gravity(1, i, e.gravity.to_numpy())
-    if check_init:
-        for i, c in enumerate(sys.cloths):
-            assert np.array_equal(c.f2v.to_numpy(), o.arr(f"cloth{i}.f2v", (-1, 3)))
-            assert np.array_equal(c.counter_face.to_numpy(), o.arr(f"cloth{i}.counter_face", (-1, 3)))
-            assert np.array_equal(c.counter_point.to_numpy(), o.arr(f"cloth{i}.counter_point", (-1, 3)))
-            if c._init_args[0] != "fold_scaled":
-                assert np.abs(c.pos.to_numpy() - o.arr(f"cloth{i}.pos", (-1, 3))).max() < 1e-15
-                assert np.abs(c.ref_angle.to_numpy() - o.arr(f"cloth{i}.ref_angle", (-1, 3))).max() < 1e-12
-        for i, e in enumerate(sys.elastics):
-            assert np.abs(e.F_x.to_numpy() - o.arr(f"elastic{i}.F_x", (-1, 3))).max() < 1e-15, f"elastic {i} pose"
-            assert rel_err(e.F_m.to_numpy(), o.arr(f"elastic{i}.F_m")) < 1e-12
-            assert rel_err(e.F_W.to_numpy(), o.arr(f"elastic{i}.F_W")) < 1e-12
-            assert rel_err(e.F_B.to_numpy().reshape(-1), o.arr(f"elastic{i}.F_B")) < 1e-10
-            assert np.array_equal(e.F_vertices.to_numpy(), o.arr(f"elastic{i}.F_vertices", (-1, 4)))
-            fo = o.arr(f"elastic{i}.f2v", (-1, 3)); fp = e.f2v.to_numpy()
-            assert np.array_equal(np.sort(np.sort(fo, 1), 0), np.sort(np.sort(fp, 1), 0)), f"elastic {i} surface set"
-        assert rel_err(sys.mass.to_numpy(), o.arr("mass")) < 1e-12
-    # identical surface triangle order / orientation on both sides (the box surface order is arbitrary in the reference)
-    o.arr("faces", (-1, 3))[:] = sys.faces.to_numpy()
-    for i, e in enumerate(sys.elastics):
-        o.arr(f"elastic{i}.f2v", (-1, 3))[:] = e.f2v.to_numpy()
-    for p in sys.contact_pairs():
-        o.add_pair(*p)
-    if hasattr(sys, "gripper") and sys.elastic_cnt > 1:
-        o.gripper_init(1 if sys.gripper.paired else 0, sys.gripper.n_part, sys.gripper.pos.to_numpy())
-    sync_oracle_state(o, sys)
-    return o
-
-
-def sync_oracle_state(o, sys):
-    """copy pos / vel / prev_pos / ref_angle / frozen / params from the product scene into a finalized oracle scene"""
-    o.pos[:] = sys.pos.to_numpy(); o.vel[:] = sys.vel.to_numpy(); o.prev_pos[:] = sys.prev_pos.to_numpy()
-    o.frozen[:] = sys.frozen.to_numpy()
-    for i, c in enumerate(sys.cloths):
-        o.arr(f"cloth{i}.ref_angle", (-1, 3))[:] = c.ref_angle.to_numpy()
-        for k in ("Kb", "Kl", "Ka", "k_angle"):
-            o.set_scalar(f"cloth{i}.{k}", getattr(c, k).value)
-    o.set_scalar("mu_cloth_elastic", sys.mu_cloth_elastic.value)
-    o.push_down_all()
-
-
-def rel_err(a, b):
-    a = np.asarray(a, dtype=np.float64); b = np.asarray(b, dtype=np.float64)
-    return float(np.abs(a - b).max() / max(np.abs(b).max(), 1e-300))
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+from oracle.mirror import oracle_from_scene, rel_err, sync_oracle_state  # noqa: E402,F401

@@ -13,13 +13,13 @@
 #include "tsl_device.hpp"
 
 #define TSL_MAX_DENSE_BODIES 8
-#define BODY_APPLY_ROWS 16
+#define BODY_APPLY_ROWS 8
 
 struct BodyDenseArgs {
   int nb;                              // dense bodies
   int n3[TSL_MAX_DENSE_BODIES];        // dofs (3 * vertices)
   int rows_off[TSL_MAX_DENSE_BODIES];  // offset into rows[] (permuted row of local vertex k)
-  long w_off[TSL_MAX_DENSE_BODIES];    // offset into W / Binv (n3^2 entries each)
+  long w_off[TSL_MAX_DENSE_BODIES];    // offset into W / Binv (n3 * ld entries each, ld = n3 rounded up to 4)
   int scr_off[TSL_MAX_DENSE_BODIES];   // offset into the pivot scratch (n3 entries per array)
   int wg_off[TSL_MAX_DENSE_BODIES + 1];  // workgroup prefix of k_body_apply
   const int* rows;
@@ -123,7 +123,7 @@ k_body_finalize(BodyDenseArgs A, const double* __restrict__ W, const int* __rest
   if (!bad[b]) v = 0.5 * (Wb[(size_t)i * n3 + j] + Wb[(size_t)j * n3 + i]);
   else if (i / 3 == j / 3) v = Dinv[9 * (size_t)A.rows[A.rows_off[b] + i / 3] + 3 * (i % 3) + j % 3];
   else v = 0.0;
-  Binv[A.w_off[b] + t] = (float)v;
+  Binv[A.w_off[b] + (size_t)i * ((n3 + 3) & ~3) + j] = (float)v;  // row stride padded to a multiple of 4 (16-byte loads)
 }
 
 // point-Jacobi blocks of the dense-body rows are switched off (their rows are served by k_body_apply)
@@ -135,37 +135,56 @@ __global__ void k_body_zero_dinv(BodyDenseArgs A, int n_rows, double* __restrict
   for (int e = 0; e < 9; e++) d[e] = 0.0;
 }
 
-// mode 0: z_b = Binv r_b ; mode 1: z_b += Binv (r - t)_b ; optional per-workgroup partial of rdot . (Binv v)
+// mode 0: z_b = Binv r_b ; mode 1: z_b += Binv (r - t)_b ; optional per-workgroup partial of rdot . (Binv v).
+// One wave per matrix row pair, 16-byte loads (the row length 3*n_verts is padded to a multiple of 4 in storage:
+// ld = (n3 + 3) & ~3), BODY_APPLY_ROWS rows per 256-thread workgroup.
 __global__ void __launch_bounds__(256)
 k_body_apply(BodyDenseArgs A, const float* __restrict__ Binv, int mode, const double* __restrict__ r, const double* __restrict__ t, double* __restrict__ z,
              const double* __restrict__ rdot, double* __restrict__ part) {
-  __shared__ double v[3 * 512];
+  __shared__ double v[3 * 512 + 4];
   __shared__ double s1[4];
   int b = 0;
   while (b + 1 < A.nb && (int)blockIdx.x >= A.wg_off[b + 1]) b++;
   const int n3 = A.n3[b];
+  const int ld = (n3 + 3) & ~3;
   const int* rows = A.rows + A.rows_off[b];
-  for (int i = threadIdx.x; i < n3; i += 256) {
-    const size_t g = 3 * (size_t)rows[i / 3] + i % 3;
-    v[i] = mode ? r[g] - t[g] : r[g];
+  for (int i = threadIdx.x; i < ld; i += 256) {
+    double x = 0.0;
+    if (i < n3) {
+      const size_t g = 3 * (size_t)rows[i / 3] + i % 3;
+      x = mode ? r[g] - t[g] : r[g];
+    }
+    v[i] = x;
   }
   __syncthreads();
   const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
   const int row0 = ((int)blockIdx.x - A.wg_off[b]) * BODY_APPLY_ROWS;
   const float* Bb = Binv + A.w_off[b];
+  const int nq = ld >> 2;
   double acc = 0;
-  for (int q = w; q < BODY_APPLY_ROWS; q += 4) {
-    const int i = row0 + q;
-    if (i >= n3) break;
-    const float* br = Bb + (size_t)i * n3;
-    double sum = 0;
-    for (int j = lane; j < n3; j += 64) sum += (double)br[j] * v[j];
-    sum = wave_sum(sum);
+#pragma unroll
+  for (int q = 0; q < BODY_APPLY_ROWS / 4; q += 2) {  // two rows in flight per wave
+    const int i0 = row0 + w * (BODY_APPLY_ROWS / 4) + q, i1 = i0 + 1;
+    if (i0 >= n3) break;
+    const float4* b0 = (const float4*)(Bb + (size_t)i0 * ld);
+    const float4* b1 = (const float4*)(Bb + (size_t)(i1 < n3 ? i1 : i0) * ld);
+    double sum0 = 0, sum1 = 0;
+    for (int j = lane; j < nq; j += 64) {
+      const float4 a0 = b0[j], a1 = b1[j];
+      const double v0 = v[4 * j], v1 = v[4 * j + 1], v2 = v[4 * j + 2], v3 = v[4 * j + 3];
+      sum0 += (double)a0.x * v0 + (double)a0.y * v1 + (double)a0.z * v2 + (double)a0.w * v3;
+      sum1 += (double)a1.x * v0 + (double)a1.y * v1 + (double)a1.z * v2 + (double)a1.w * v3;
+    }
+    sum0 = wave_sum(sum0); sum1 = wave_sum(sum1);
     if (lane == 0) {
-      const size_t g = 3 * (size_t)rows[i / 3] + i % 3;
-      const double zn = mode ? z[g] + sum : sum;
-      z[g] = zn;
-      if (rdot) acc += rdot[g] * sum;  // mode 1: the Jacobi kernel already counted rdot . z_old of these rows
+      const size_t g0 = 3 * (size_t)rows[i0 / 3] + i0 % 3;
+      z[g0] = mode ? z[g0] + sum0 : sum0;
+      if (rdot) acc += rdot[g0] * sum0;  // mode 1: the Jacobi kernel already counted rdot . z_old of these rows
+      if (i1 < n3) {
+        const size_t g1 = 3 * (size_t)rows[i1 / 3] + i1 % 3;
+        z[g1] = mode ? z[g1] + sum1 : sum1;
+        if (rdot) acc += rdot[g1] * sum1;
+      }
     }
   }
   if (part) {

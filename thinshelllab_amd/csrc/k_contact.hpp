@@ -94,46 +94,77 @@ TSL_DEV int lower_bound_dev(const int* __restrict__ a, int n, int key) {
   return lo;
 }
 
-// geometry.project_pair (:165-221): one lane per query vertex
-__global__ void k_project_pair(GridArgs G, int v_start, int v_end, int body_idx, int NV, int nf, const int* __restrict__ skey, const int* __restrict__ sval,
-                               const int* __restrict__ range, const int* __restrict__ faces, const double* __restrict__ pos, const double* __restrict__ vn,
-                               const int* __restrict__ border, int* __restrict__ proj_flag, int* __restrict__ proj_dir, int* __restrict__ proj_idx,
-                               double* __restrict__ proj_w) {
-  const int i = v_start + blockIdx.x * blockDim.x + threadIdx.x;
-  if (i >= v_end) return;
-  const d3 xq = ld3(pos, i);
+// geometry.project_pair (:165-221).  G lanes (a power of two <= 64) share one query vertex: the candidates of each of the
+// <= 27 cells are dealt round-robin to the lanes, every lane applies the reference's running selection rule (closer by more
+// than 1e-5, or within 1e-5 and larger cosine) to its own subsequence, and the lane results are merged with the same rule
+// taken in scan order.  This equals the sequential scan whenever the near-minimum candidates form a cluster much tighter
+// than the 1e-5 tolerance (shared edges / vertices: the case the rule exists for); the reference's own candidate order is
+// an atomic-append order and not deterministic either.  One lane per query (G = 1 behaviour) left 19 waves on the GPU for
+// the pad-vertices-against-cloth query of the 100k-triangle scene (0.9 ms per launch).
+struct ProjBest { double d, cs; int pos; };
+TSL_DEV bool proj_replaces(const ProjBest& cur, const ProjBest& cand) {  // cand comes later in scan order
+  return cand.d < cur.d - 1e-5 || (cand.d < cur.d + 1e-5 && cand.cs > cur.cs);
+}
+template <int G>
+__global__ void __launch_bounds__(256)
+k_project_pair(GridArgs Gr, int v_start, int v_end, int body_idx, int NV, int nf, const int* __restrict__ skey, const int* __restrict__ sval,
+               const int* __restrict__ range, const int* __restrict__ faces, const double* __restrict__ pos, const double* __restrict__ vn,
+               const int* __restrict__ border, int* __restrict__ proj_flag, int* __restrict__ proj_dir, int* __restrict__ proj_idx,
+               double* __restrict__ proj_w) {
+  const int i = v_start + (blockIdx.x * blockDim.x + threadIdx.x) / G;
+  const int g = threadIdx.x & (G - 1);
+  const bool live = i < v_end;
+  const d3 xq = live ? ld3(pos, i) : d3();
   int q[3];
-  grid_idx3(G, xq, q);
+  grid_idx3(Gr, xq, q);
   int r0[3], r1[3];
   for (int a = 0; a < 3; a++) { r0[a] = max(q[a] - 1, range[a]); r1[a] = min(q[a] + 1, range[3 + a]) + 1; }
-  double d_min = 1e6, cos_max = -1e6;
-  int pflag = 0, pi0 = 0, pi1 = 0, pi2 = 0;
+  ProjBest best{1e6, -1e6, 0x7fffffff};
+  int bc = 0, ba = 0, bb = 0, bc3 = 0;
   d3 pw = d3();
-  for (int gi = r0[0]; gi < r1[0]; gi++)
-    for (int gj = r0[1]; gj < r1[1]; gj++)
-      for (int gk = r0[2]; gk < r1[2]; gk++) {
-        const int cell = (gi * G.n + gj) * G.n + gk;
-        for (int s = lower_bound_dev(skey, nf, cell); s < nf && skey[s] == cell; s++) {
-          const int f = sval[s];
-          const int a = faces[3 * f], b = faces[3 * f + 1], c3 = faces[3 * f + 2];
-          const d3 v1 = ld3(pos, a), v2 = ld3(pos, b), v3 = ld3(pos, c3);
-          int c; double d; d3 w;
-          pt2tri(xq, v1, v2, v3, c, d, w);
-          const d3 vt = v1 * w.x + v2 * w.y + v3 * w.z;
-          const d3 nt = normalized(cross(v2 - v1, v3 - v1));
-          const double cs = dot(xq - vt, nt);
-          if (d < d_min - 1e-5 || (d < d_min + 1e-5 && cs > cos_max)) {
-            d_min = d; cos_max = cs; pi0 = a; pi1 = b; pi2 = c3; pw = w;
-            if (c == 0) pflag = 1;
-            else if (c > 0) { const int pv = (c == 1) ? a : ((c == 2) ? b : c3); pflag = !border[pv]; }
-            else {
-              const int p1 = (c != -3) ? c3 : a;
-              const int p2 = (c == -3) ? b : ((c == -1) ? b : a);  // particle_idx[pid, 2 + c]
-              pflag = !(border[p1] && border[p2]);
-            }
+  int base = 0;
+  if (live)
+    for (int gi = r0[0]; gi < r1[0]; gi++)
+      for (int gj = r0[1]; gj < r1[1]; gj++)
+        for (int gk = r0[2]; gk < r1[2]; gk++) {
+          const int cell = (gi * Gr.n + gj) * Gr.n + gk;
+          const int s0 = lower_bound_dev(skey, nf, cell), s1 = lower_bound_dev(skey, nf, cell + 1);
+          for (int s = s0 + g; s < s1; s += G) {
+            const int f = sval[s];
+            const int a = faces[3 * f], b = faces[3 * f + 1], c3 = faces[3 * f + 2];
+            const d3 v1 = ld3(pos, a), v2 = ld3(pos, b), v3 = ld3(pos, c3);
+            int c; double d; d3 w;
+            pt2tri(xq, v1, v2, v3, c, d, w);
+            const d3 vt = v1 * w.x + v2 * w.y + v3 * w.z;
+            const d3 nt = normalized(cross(v2 - v1, v3 - v1));
+            const ProjBest cand{d, dot(xq - vt, nt), base + (s - s0)};
+            if (proj_replaces(best, cand)) { best = cand; bc = c; ba = a; bb = b; bc3 = c3; pw = w; }
           }
+          base += s1 - s0;
         }
-      }
+  // merge the lane results in scan order (all lanes of the group end up with the same winner)
+  ProjBest win = best;
+#pragma unroll
+  for (int m = 1; m < G; m <<= 1) {
+    ProjBest o;
+    o.d = __shfl_xor(win.d, m, G); o.cs = __shfl_xor(win.cs, m, G); o.pos = __shfl_xor(win.pos, m, G);
+    const bool o_later = o.pos > win.pos;
+    if (o_later ? proj_replaces(win, o) : (o.pos != win.pos && !proj_replaces(o, win))) win = o;
+  }
+  if (!live) return;
+  const bool none = win.pos == 0x7fffffff;
+  if (none ? (g != 0) : (best.pos != win.pos)) return;
+  int pflag = 0, pi0 = 0, pi1 = 0, pi2 = 0;
+  if (!none) {
+    pi0 = ba; pi1 = bb; pi2 = bc3;
+    if (bc == 0) pflag = 1;
+    else if (bc > 0) { const int pv = (bc == 1) ? ba : ((bc == 2) ? bb : bc3); pflag = !border[pv]; }
+    else {
+      const int p1 = (bc != -3) ? bc3 : ba;
+      const int p2 = (bc == -3) ? bb : ((bc == -1) ? bb : ba);  // particle_idx[pid, 2 + c]
+      pflag = !(border[p1] && border[p2]);
+    }
+  }
   const d3 v = pw.x * ld3(pos, pi0) + pw.y * ld3(pos, pi1) + pw.z * ld3(pos, pi2);
   const d3 n = pw.x * ld3(vn, pi0) + pw.y * ld3(vn, pi1) + pw.z * ld3(vn, pi2);
   const size_t bi = (size_t)body_idx * NV + i;
@@ -325,28 +356,35 @@ __global__ void k_contact_mask(int nc, const int* __restrict__ idx, const int* _
     }
 }
 
-// y += sum_c P_c^T H_c P_c x  (permuted vectors); dot(x, that) added to pAp[slot]
-__global__ void k_contact_matvec(int nc, const int* __restrict__ idx, const int* __restrict__ rowpos, const double* __restrict__ Hm, const double* __restrict__ x,
-                                 double* __restrict__ y, CgScal* sc, int slot, int check_flag) {
-  if (check_flag && sc->flag) return;
-  const int ci = blockIdx.x * blockDim.x + threadIdx.x;
-  double acc = 0;
-  if (ci < nc) {
-    int pr[4];
-    double xv[12];
-    for (int k = 0; k < 4; k++) {
-      pr[k] = rowpos[idx[4 * ci + k]];
-      const d3 v = ld3(x, pr[k]);
-      xv[3 * k] = v.x; xv[3 * k + 1] = v.y; xv[3 * k + 2] = v.z;
-    }
-    const double* H = Hm + 144 * (size_t)ci;
-    for (int r = 0; r < 12; r++) {
-      double s = 0;
-      for (int c = 0; c < 12; c++) s += H[r * 12 + c] * xv[c];
-      if (s != 0.0) atomicAdd(&y[3 * (size_t)pr[r / 3] + (r % 3)], s);
-      acc += s * xv[r];
-    }
+// y += sum_c P_c^T H_c P_c x  (permuted vectors).  16 lanes per constraint (12 active, one per block row), 64 constraints
+// per 1024-thread workgroup: one lane per constraint (12x12 serial product behind dependent loads) took 12 us for a
+// hundred constraints.  Returns this lane's share of x . H_c x.
+#define CONTACT_MV_THREADS 1024
+TSL_DEV double contact_matvec_lane(int nc, const int* __restrict__ idx, const int* __restrict__ rowpos, const double* __restrict__ Hm, const double* __restrict__ x,
+                                   double* __restrict__ y) {
+  const int ci = blockIdx.x * 64 + (threadIdx.x >> 4);
+  const int r = threadIdx.x & 15;
+  if (ci >= nc || r >= 12) return 0.0;
+  const double* H = Hm + 144 * (size_t)ci + 12 * r;
+  double s = 0, xr = 0;
+  int prr = 0;
+#pragma unroll
+  for (int k = 0; k < 4; k++) {
+    const int pk = rowpos[idx[4 * ci + k]];
+    const d3 v = ld3(x, pk);
+    s += H[3 * k] * v.x + H[3 * k + 1] * v.y + H[3 * k + 2] * v.z;
+    if (k == r / 3) { prr = pk; xr = (r % 3 == 0) ? v.x : (r % 3 == 1) ? v.y : v.z; }
   }
+  if (s != 0.0) atomicAdd(&y[3 * (size_t)prr + (r % 3)], s);
+  return s * xr;
+}
+
+// dot(x, H_c x) added to pAp[slot] (slot < 0: product only)
+__global__ void __launch_bounds__(CONTACT_MV_THREADS)
+k_contact_matvec(int nc, const int* __restrict__ idx, const int* __restrict__ rowpos, const double* __restrict__ Hm, const double* __restrict__ x,
+                 double* __restrict__ y, CgScal* sc, int slot, int check_flag) {
+  if (check_flag && sc->flag) return;
+  double acc = contact_matvec_lane(nc, idx, rowpos, Hm, x, y);
   if (slot >= 0) {
     acc = wave_sum(acc);
     if ((threadIdx.x & 63) == 0 && acc != 0.0) atomicAdd(&sc->pAp[slot], acc);
@@ -354,30 +392,21 @@ __global__ void k_contact_matvec(int nc, const int* __restrict__ idx, const int*
 }
 
 // same product for the two-kernel PCG: dot(x, H_c x) goes to a per-block partial (deterministic reduction)
-__global__ void __launch_bounds__(64)
+__global__ void __launch_bounds__(CONTACT_MV_THREADS)
 k_contact_matvec_part(int nc, const int* __restrict__ idx, const int* __restrict__ rowpos, const double* __restrict__ Hm, const double* __restrict__ x,
                       double* __restrict__ y, double* __restrict__ part, const int* __restrict__ flag) {
+  __shared__ double sw[CONTACT_MV_THREADS / 64];
   if (*flag) return;
-  const int ci = blockIdx.x * blockDim.x + threadIdx.x;
-  double acc = 0;
-  if (ci < nc) {
-    int pr[4];
-    double xv[12];
-    for (int k = 0; k < 4; k++) {
-      pr[k] = rowpos[idx[4 * ci + k]];
-      const d3 v = ld3(x, pr[k]);
-      xv[3 * k] = v.x; xv[3 * k + 1] = v.y; xv[3 * k + 2] = v.z;
-    }
-    const double* H = Hm + 144 * (size_t)ci;
-    for (int r = 0; r < 12; r++) {
-      double s = 0;
-      for (int c = 0; c < 12; c++) s += H[r * 12 + c] * xv[c];
-      if (s != 0.0) atomicAdd(&y[3 * (size_t)pr[r / 3] + (r % 3)], s);
-      acc += s * xv[r];
-    }
-  }
+  double acc = contact_matvec_lane(nc, idx, rowpos, Hm, x, y);
   acc = wave_sum(acc);
-  if (threadIdx.x == 0) part[blockIdx.x] = acc;
+  if ((threadIdx.x & 63) == 0) sw[threadIdx.x >> 6] = acc;
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    double t = 0;
+#pragma unroll
+    for (int q = 0; q < CONTACT_MV_THREADS / 64; q++) t += sw[q];
+    part[blockIdx.x] = t;
+  }
 }
 
 // tmp_z_frozen[j] -= H_ij z_i for i free, j frozen (second compute_Hessian pass of transfer_grad,
@@ -530,8 +559,14 @@ extern "C" int tsl_contact_detect(tsl_ctx* c, const double* pos, const double* p
       const tsl_body& q = c->h_bodies[b2];
       const int nq = q.v_end - q.v_start;
       if (nq <= 0) continue;
-      hipLaunchKernelGGL(k_project_pair, dim3(cnblk(nq, 64)), dim3(64), 0, s, G, q.v_start, q.v_end, b, NV, nf, c->grid_key2.p, c->grid_val2.p, c->grid_range.p, c->faces.p,
-                         pos, c->vn.p, c->border.p, c->proj_flag.p, c->proj_dir.p, c->proj_idx.p, c->proj_w.p);
+#define TSL_PROJ_LAUNCH(GW)                                                                                                                                     \
+  hipLaunchKernelGGL((k_project_pair<GW>), dim3(cnblk((long)nq * GW, 256)), dim3(256), 0, s, G, q.v_start, q.v_end, b, NV, nf, c->grid_key2.p, c->grid_val2.p, \
+                     c->grid_range.p, c->faces.p, pos, c->vn.p, c->border.p, c->proj_flag.p, c->proj_dir.p, c->proj_idx.p, c->proj_w.p)
+      // lanes per query vertex by the size of the triangle set it scans (many triangles per cell on refined cloths)
+      if (nf >= 8192) TSL_PROJ_LAUNCH(64);
+      else if (nf >= 512) TSL_PROJ_LAUNCH(8);
+      else TSL_PROJ_LAUNCH(1);
+#undef TSL_PROJ_LAUNCH
     }
   }
   // contact_analysis

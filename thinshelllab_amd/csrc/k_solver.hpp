@@ -441,6 +441,22 @@ __global__ void k_absmax(size_t n, const double* __restrict__ a, double* out) {
   s = wave_max(s);
   if ((threadIdx.x & 63) == 0) atomicMax((unsigned long long*)out, (unsigned long long)__double_as_longlong(s));
 }
+// out[j] += V_j . w for j < k (V: k vectors of stride ld); grid (chunks, k)
+__global__ void __launch_bounds__(256) k_multi_dot(size_t n, const double* __restrict__ V, size_t ld, const double* __restrict__ w, double* __restrict__ out) {
+  const double* v = V + (size_t)blockIdx.y * ld;
+  double s = 0;
+  for (size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x) s += v[i] * w[i];
+  s = wave_sum(s);
+  if ((threadIdx.x & 63) == 0) atomicAdd(&out[blockIdx.y], s);
+}
+// w += sign * sum_j h[j] V_j  (h on the device: no host round trip between the projection and the update)
+__global__ void __launch_bounds__(256) k_multi_axpy(size_t n, const double* __restrict__ V, size_t ld, int k, const double* __restrict__ h, double sign, double* __restrict__ w) {
+  for (size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x) {
+    double acc = 0;
+    for (int j = 0; j < k; j++) acc += h[j] * V[(size_t)j * ld + i];
+    w[i] += sign * acc;
+  }
+}
 // y = a*x + b*y (b == 0 ignores old y)
 __global__ void k_axpby(size_t n, double a, const double* __restrict__ x, double b, double* __restrict__ y) {
   for (size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x) y[i] = (b == 0.0) ? a * x[i] : a * x[i] + b * y[i];

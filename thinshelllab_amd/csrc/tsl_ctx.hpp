@@ -149,6 +149,8 @@ struct tsl_ctx {
   DevBuf<int> bd_rows, bd_body_of, bd_local_of, bd_bad;
   DevBuf<double> bd_W, bd_scr;
   DevBuf<float> bd_Binv;
+  DevBuf<double> gm_V, gm_h;  // GMRES basis ((m+1) vectors) and projection coefficients
+  int gmres_m = 300, use_gmres = 1;
   // preconditioner built from a different (SPD-projected) assembly than the operator: adjoint solves (un-projected H)
   DevBuf<double> vals_pc, c_H_pc;
   bool pc_separate = false, pc_frozen = false;

@@ -297,6 +297,8 @@ extern "C" int tsl_set_param(tsl_ctx* c, const char* key, double v) {
   else if (k == "grid_h") c->grid_h = v;
   else if (k == "grid_extent") c->grid_extent = v;
   else if (k == "adj_spd_pc") c->adj_spd_pc = (int)v;
+  else if (k == "gmres") c->use_gmres = (int)v;
+  else if (k == "gmres_m") c->gmres_m = (int)v;
   else if (k == "body_inv") { c->bd_enable = (int)v; c->bd_valid = false; }
   else if (k == "mg") c->mg_enable = (int)v;
   else if (k == "mg_omega") c->mg_omega = v;
@@ -437,7 +439,7 @@ static void launch_spmv(tsl_ctx* c, const double* vals, const double* x, double*
   if (sample) { (void)hipEventRecord(c->ev_pool[c->ev_used].second, s); c->ev_used++; }
   if (slot >= 0) c->prof_launches++;
   if (c->nc > 0)
-    hipLaunchKernelGGL(k_contact_matvec, dim3(nblk(c->nc, 64)), dim3(64), 0, s, c->nc, c->c_idx.p, c->rowpos.p, full_contact ? c->c_Hfull.p : c->c_H.p, x, y, SC(c), slot,
+    hipLaunchKernelGGL(k_contact_matvec, dim3(nblk(c->nc, 64)), dim3(CONTACT_MV_THREADS), 0, s, c->nc, c->c_idx.p, c->rowpos.p, full_contact ? c->c_Hfull.p : c->c_H.p, x, y, SC(c), slot,
                        check_flag);
 }
 
@@ -457,6 +459,7 @@ static int read_scal(tsl_ctx* c) {
 }
 
 static int bicgstab(tsl_ctx* c, tsl_solve_stats* st);
+static int gmres(tsl_ctx* c, tsl_solve_stats* st);
 
 // ------------------------------------------------------------------------------------------------ dense body blocks (k_body.hpp)
 // which elastic bodies get an exact block: at most 512 vertices, at least one free dof
@@ -481,7 +484,7 @@ static int body_dense_setup(tsl_ctx* c) {
       const int v = e.v_offset + k;
       rows.push_back(c->h_rowpos[v]); body_of[v] = b; local_of[v] = k;
     }
-    c->bd_w_total += (size_t)A.n3[b] * A.n3[b];
+    c->bd_w_total += (size_t)A.n3[b] * ((A.n3[b] + 3) & ~3);  // multiple of 4: every body block starts 16-byte aligned
     c->bd_scr_n += A.n3[b];
     c->bd_wg += (A.n3[b] + BODY_APPLY_ROWS - 1) / BODY_APPLY_ROWS;
     c->bd_n3max = std::max(c->bd_n3max, A.n3[b]);
@@ -492,6 +495,7 @@ static int body_dense_setup(tsl_ctx* c) {
   TSL_TRY(c->bd_rows.upload(rows)); TSL_TRY(c->bd_body_of.upload(body_of)); TSL_TRY(c->bd_local_of.upload(local_of));
   if (c->bd_bad.alloc(TSL_MAX_DENSE_BODIES) | c->bd_W.alloc(c->bd_w_total) | c->bd_Binv.alloc(c->bd_w_total) | c->bd_scr.alloc(4 * (size_t)c->bd_scr_n)) return -1;
   A.rows = c->bd_rows.p; A.body_of = c->bd_body_of.p; A.local_of = c->bd_local_of.p;
+  HIP_OK(hipMemset(c->bd_Binv.p, 0, c->bd_w_total * sizeof(float)));  // the row padding must stay finite (it multiplies zeros)
   return 0;
 }
 
@@ -565,7 +569,7 @@ static void mg_spmv0(tsl_ctx* c, const double* x, double* y) {
   const double* cH = c->pc_separate ? c->c_H_pc.p : c->c_H.p;
   hipLaunchKernelGGL((k_spmv_mw<4, 1, true>), dim3(c->n_slices), dim3(256), 0, s, c->NV, c->n_slices, c->slice_off.p, c->slice_len.p, c->colidx.p, vals, x, y,
                      (double*)nullptr, (const int*)nullptr);
-  if (c->nc > 0) hipLaunchKernelGGL(k_contact_matvec, dim3(nblk(c->nc, 64)), dim3(64), 0, s, c->nc, c->c_idx.p, c->rowpos.p, cH, x, y, SC(c), -1, 0);
+  if (c->nc > 0) hipLaunchKernelGGL(k_contact_matvec, dim3(nblk(c->nc, 64)), dim3(CONTACT_MV_THREADS), 0, s, c->nc, c->c_idx.p, c->rowpos.p, cH, x, y, SC(c), -1, 0);
 }
 
 // Galerkin coarse operators of the current (masked) matrix; called once per assembly when the preconditioner is active
@@ -694,7 +698,7 @@ static void launch_pcg_iteration(tsl_ctx* c, int parity, int first, unsigned lon
   hipLaunchKernelGGL((k_pcg_spmv<PCG_WPS, true>), dim3(ns), dim3(64 * PCG_WPS), 0, s, NV, ns, c->slice_off.p, c->slice_len.p, c->colidx.p, c->vals.p, c->v_z.p, p_old, p_new,
                      c->v_Ap.p, c->part_rz.p, c->part_rr.p, c->part_pAp.p, PSC(c), parity, first, dprof);
   if (c->nc > 0)
-    hipLaunchKernelGGL(k_contact_matvec_part, dim3(nblk(c->nc, 64)), dim3(64), 0, s, c->nc, c->c_idx.p, c->rowpos.p, c->c_H.p, p_new, c->v_Ap.p, c->part_pAp.p + ns,
+    hipLaunchKernelGGL(k_contact_matvec_part, dim3(nblk(c->nc, 64)), dim3(CONTACT_MV_THREADS), 0, s, c->nc, c->c_idx.p, c->rowpos.p, c->c_H.p, p_new, c->v_Ap.p, c->part_pAp.p + ns,
                        &PSC(c)->flag);
   const bool mg = mg_active(c);
   hipLaunchKernelGGL(k_pcg_update, dim3(nblk(NV, 256)), dim3(256), 0, s, NV, p_new, c->v_Ap.p, c->Dinv.p, c->v_x.p, c->v_r.p, c->v_z.p, c->part_pAp.p, c->part_rz.p, c->part_rr.p,
@@ -816,7 +820,131 @@ static int solve_perm(tsl_ctx* c, tsl_solve_stats* st) {
     st->iters += st2.iters; st->restarts += st2.restarts + 1; st->flag = st2.flag; st->rel_residual = st2.rel_residual;
     return rc;
   }
+  if (c->use_gmres) {
+    TSL_TRY(gmres(c, st));
+    if (st->flag == 1) return 0;
+    return bicgstab(c, st);  // last resort
+  }
   return bicgstab(c, st);
+}
+
+// Right-preconditioned restarted GMRES(m) on H for indefinite / non-symmetric systems (un-projected adjoint Hessians):
+// minimal residual over the Krylov space, so it cannot diverge the way BiCGStab does on strongly indefinite matrices.
+// Preconditioner: multigrid V-cycle (+ dense body blocks) when available, else block Jacobi.  Classical Gram-Schmidt applied
+// twice with the coefficients kept on the device; one host read (h, h2, |w|^2) per iteration for the Givens rotations.
+static int gmres(tsl_ctx* c, tsl_solve_stats* st) {
+  hipStream_t s = c->stream;
+  const int NV = c->NV;
+  const size_t n3 = 3 * (size_t)NV;
+  const int gb = nblk(NV, 256), gv = gsz(n3);
+  const int m = (int)std::min<size_t>((size_t)std::max(5, std::min(c->gmres_m, 400)), n3);
+  if (c->gm_V.n < (size_t)(m + 1) * n3 && c->gm_V.alloc((size_t)(m + 1) * n3)) return tsl_fail("out of device memory (GMRES basis)");
+  if (c->gm_h.n < (size_t)(2 * (m + 1) + 2) && c->gm_h.alloc(2 * (size_t)(m + 1) + 2)) return -1;
+  double* V = c->gm_V.p;
+  double* dh = c->gm_h.p;  // [0, m+1): h ; [m+1, 2m+2): h2 ; [2m+2]: |w|^2
+  const int o2 = m + 1, on = 2 * (m + 1);
+  double *x = c->v_x.p, *r = c->v_r.p, *w = c->v_Ap.p, *z = c->v_z.p, *u = c->v_t0.p;
+  const bool mg = mg_active(c);
+  if (body_active(c) && !c->bd_valid) TSL_TRY(body_build_inverse(c));
+  if (mg && !c->mg_ops_valid) TSL_TRY(mg_setup_operators(c));
+  auto precond = [&](const double* in, double* out) {
+    if (mg) mg_vcycle(c, in, out, c->part_rz.p);
+    else {
+      hipLaunchKernelGGL(k_precond, dim3(gb), dim3(256), 0, s, NV, c->Dinv.p, in, out);
+      if (body_active(c) && c->bd_valid) body_apply(c, 0, in, nullptr, out, nullptr, nullptr);
+    }
+  };
+  std::vector<double> hh(2 * (size_t)(m + 1) + 2);
+  auto read_h = [&](int cnt) -> int {
+    HIP_OK(hipMemcpyAsync(hh.data(), dh, (size_t)cnt * sizeof(double), hipMemcpyDeviceToHost, s));
+    HIP_OK(hipStreamSynchronize(s));
+    return 0;
+  };
+  auto norm2 = [&](const double* a, double* out) -> int {
+    HIP_OK(hipMemsetAsync(dh + on, 0, sizeof(double), s));
+    hipLaunchKernelGGL(k_dot, dim3(gv), dim3(256), 0, s, n3, a, a, dh + on);
+    HIP_OK(hipMemcpyAsync(out, dh + on, sizeof(double), hipMemcpyDeviceToHost, s));
+    HIP_OK(hipStreamSynchronize(s));
+    return 0;
+  };
+  HIP_OK(hipMemsetAsync(x, 0, n3 * sizeof(double), s));
+  HIP_OK(hipMemcpyAsync(r, c->v_b.p, n3 * sizeof(double), hipMemcpyDeviceToDevice, s));
+  double bb;
+  TSL_TRY(norm2(r, &bb));
+  if (!(bb > 0)) { st->flag = 1; return 0; }
+  const double tol = c->cg_tol * sqrt(bb);
+  double beta = sqrt(bb);
+  st->flag = 3;
+  std::vector<double> H((size_t)(m + 1) * m), cs(m), sn(m), g(m + 1), y(m);
+  int total = 0;
+  double beta_prev = 1e300;
+  for (int cycle = 0; cycle < 1000 && total < c->cg_maxit; cycle++) {
+    hipLaunchKernelGGL(k_axpby, dim3(gv), dim3(256), 0, s, n3, 1.0 / beta, r, 0.0, V);
+    std::fill(g.begin(), g.end(), 0.0);
+    g[0] = beta;
+    int j = 0;
+    for (; j < m; j++) {
+      double* vj1 = V + (size_t)(j + 1) * n3;
+      precond(V + (size_t)j * n3, z);
+      launch_spmv(c, c->vals.p, z, w, -1, 0);
+      HIP_OK(hipMemsetAsync(dh, 0, (size_t)(on + 1) * sizeof(double), s));
+      hipLaunchKernelGGL(k_multi_dot, dim3(64, j + 1), dim3(256), 0, s, n3, V, n3, w, dh);
+      hipLaunchKernelGGL(k_multi_axpy, dim3(gv), dim3(256), 0, s, n3, V, n3, j + 1, dh, -1.0, w);
+      hipLaunchKernelGGL(k_multi_dot, dim3(64, j + 1), dim3(256), 0, s, n3, V, n3, w, dh + o2);
+      hipLaunchKernelGGL(k_multi_axpy, dim3(gv), dim3(256), 0, s, n3, V, n3, j + 1, dh + o2, -1.0, w);
+      hipLaunchKernelGGL(k_dot, dim3(gv), dim3(256), 0, s, n3, w, w, dh + on);
+      TSL_TRY(read_h(on + 1));
+      total++; st->iters++;
+      const double hn = sqrt(std::max(hh[on], 0.0));
+      double* Hj = &H[(size_t)j * (m + 1)];  // column j
+      for (int i = 0; i <= j; i++) Hj[i] = hh[i] + hh[o2 + i];
+      Hj[j + 1] = hn;
+      for (int i = 0; i < j; i++) {  // previous rotations
+        const double t0 = cs[i] * Hj[i] + sn[i] * Hj[i + 1];
+        Hj[i + 1] = -sn[i] * Hj[i] + cs[i] * Hj[i + 1];
+        Hj[i] = t0;
+      }
+      const double den = hypot(Hj[j], Hj[j + 1]);
+      if (!(den > 0) || !std::isfinite(den)) { j++; break; }
+      cs[j] = Hj[j] / den; sn[j] = Hj[j + 1] / den;
+      Hj[j] = den; Hj[j + 1] = 0;
+      g[j + 1] = -sn[j] * g[j];
+      g[j] = cs[j] * g[j];
+      st->rel_residual = fabs(g[j + 1]) / sqrt(bb);
+      if (fabs(g[j + 1]) <= 0.5 * tol || !(hn > 0)) { j++; break; }
+      hipLaunchKernelGGL(k_axpby, dim3(gv), dim3(256), 0, s, n3, 1.0 / hn, w, 0.0, vj1);
+    }
+    // y = R^-1 g ; x += M^-1 (V y)
+    const int k = j;
+    for (int i = k - 1; i >= 0; i--) {
+      double t0 = g[i];
+      for (int l = i + 1; l < k; l++) t0 -= H[(size_t)l * (m + 1) + i] * y[l];
+      const double d = H[(size_t)i * (m + 1) + i];
+      y[i] = d != 0 ? t0 / d : 0.0;
+    }
+    HIP_OK(hipMemcpyAsync(dh, y.data(), (size_t)k * sizeof(double), hipMemcpyHostToDevice, s));
+    HIP_OK(hipMemsetAsync(u, 0, n3 * sizeof(double), s));
+    hipLaunchKernelGGL(k_multi_axpy, dim3(gv), dim3(256), 0, s, n3, V, n3, k, dh, 1.0, u);
+    precond(u, z);
+    hipLaunchKernelGGL(k_axpby, dim3(gv), dim3(256), 0, s, n3, 1.0, z, 1.0, x);
+    HIP_OK(hipStreamSynchronize(s));  // y (host vector) is reused by the next cycle
+    // true residual
+    launch_spmv(c, c->vals.p, x, w, -1, 0);
+    HIP_OK(hipMemcpyAsync(r, c->v_b.p, n3 * sizeof(double), hipMemcpyDeviceToDevice, s));
+    hipLaunchKernelGGL(k_axpby, dim3(gv), dim3(256), 0, s, n3, -1.0, w, 1.0, r);
+    double rr;
+    TSL_TRY(norm2(r, &rr));
+    beta = sqrt(rr);
+    st->rel_residual = beta / sqrt(bb);
+    if (!std::isfinite(beta)) break;
+    if (beta <= tol) { st->flag = 1; break; }
+    // attainable accuracy (same rule as the PCG restarts)
+    if (cycle > 0 && beta > 0.5 * beta_prev && beta <= 50 * tol) { st->flag = 1; break; }
+    if (cycle > 20 && beta > 0.9 * beta_prev) break;  // stagnating restarts: hand over to BiCGStab
+    beta_prev = beta;
+    st->restarts++;
+  }
+  return 0;
 }
 
 // Block-Jacobi BiCGStab on H (used when PCG breaks down: un-projected adjoint Hessians can be indefinite)
