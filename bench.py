@@ -204,9 +204,16 @@ def main():
                    "newton_iters_per_step": stats["newton"] / K, "pcg_iters_per_fwd_solve": stats["cg_fwd"] / max(stats["newton"], 1),
                    "pcg_iters_per_adjoint_solve": stats["cg_adj"] / K, "line_search_evals_per_step": stats["ls"] / K, "solver_fallbacks": stats["fallback"]},
     }
+    traffic = None
+    try:  # HBM bytes per launch from the committed rocprofv3 --pmc passes of this workload (scripts/gpu_profile.sh)
+        with open(os.path.join(ROOT, "profiles", f"r01b_{args.workload}_pmc_k_pcg_spmv.json")) as fh:
+            if args.grid == 224:
+                traffic = json.load(fh)["traffic_bytes_per_launch"]
+    except (OSError, KeyError, ValueError):
+        pass
     if prof["ms_per_launch"] > 0:
         ach = prof["bytes_per_launch"] / (prof["ms_per_launch"] * 1e-3) / 1e9
-        out["roofline"] = {"bound": "hbm", "achieved": ach, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": ach / HBM_PEAK_GBS, "traffic": None,
+        out["roofline"] = {"bound": "hbm", "achieved": ach, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": ach / HBM_PEAK_GBS, "traffic": traffic,
                            "kernel": "k_pcg_spmv (SELL-64 3x3-block SpMV fused with the PCG direction update and p.Ap, one launch per PCG iteration)",
                            "bytes_per_launch": prof["bytes_per_launch"], "avg_launch_us": prof["ms_per_launch"] * 1e3,
                            "avg_launch_us_hip_events": prof["ms_per_launch_events"] * 1e3, "launches": prof["launches"]}
