@@ -93,7 +93,10 @@ void tsl_ctx_destroy(tsl_ctx* ctx);
 int tsl_set_stream(tsl_ctx* ctx, void* hip_stream);
 
 /* 0-d field writes: "cloth<i>.Kb|Kl|Ka|k_angle", "mu_cloth_elastic", "k_contact", "eps_contact", "damping",
- * "cg_tol", "cg_maxit", "newton_cap", "plastic", "cg_check" (trajopt_folding.py:50,66; Scene_folding.py:30-31). */
+ * "newton_cap", "plastic", "contact" (trajopt_folding.py:50,66; Scene_folding.py:30-31), the broad-phase box
+ * "grid_h", "grid_extent" (geometry.py:8-19), and the solver knobs that have no reference counterpart (the reference
+ * calls a direct solver): "cg_tol", "cg_maxit", "cg_check", "mg" (-1 auto / 0 / 1), "mg_nu", "mg_coarse_sweeps",
+ * "mg_omega", "mg_pi_iters", "body_inv" (-1 auto / 0 / 1), "adj_spd_pc", "gmres", "gmres_m", "graph". */
 int tsl_set_param(tsl_ctx* ctx, const char* key, double value);
 int tsl_set_frozen(tsl_ctx* ctx, const int32_t* frozen_host);          /* BaseScene.set_frozen */
 int tsl_set_ext_force(tsl_ctx* ctx, const double* ext_force_host);      /* BaseScene.ext_force / manipulate_force */
