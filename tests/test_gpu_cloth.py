@@ -60,9 +60,11 @@ def test_energy_gradient_hessian(oracle, N, M):
         assert o.stats()["missing"] == 0
 
 
-def test_solve_matches_spsolve(oracle):
+@pytest.mark.parametrize("N,M", [(12, 12), (15, 9), (32, 16)])
+def test_solve_matches_spsolve(oracle, N, M):
+    """(12,12), (32,16): multigrid-preconditioned PCG (2 and 3 levels); (15,9): block-Jacobi PCG"""
     import scipy.sparse.linalg as spl
-    sys, o = _pair(oracle, 12, 12, amp=5e-5)
+    sys, o = _pair(oracle, N, M, amp=5e-5)
     sys.compute_residual_and_Hessian(spd=True)
     b = sys.F.to_torch()
     x, st = sys._ctx.solve(b)
@@ -71,10 +73,12 @@ def test_solve_matches_spsolve(oracle):
     assert rel_err(x.cpu().numpy(), xs) < 1e-7
 
 
-def test_indefinite_solve_falls_back(oracle):
+@pytest.mark.parametrize("N,M", [(10, 6), (16, 12)])
+def test_indefinite_solve_falls_back(oracle, N, M):
     """un-projected Hessian of a strongly perturbed cloth is indefinite: PCG must detect the breakdown and the
-    BiCGStab fallback must still deliver H x = b (checked through the residual: H is close to singular)."""
-    sys, o = _pair(oracle, 10, 6, amp=2e-4)
+    GMRES / BiCGStab fallback must still deliver H x = b (checked through the residual: H is close to singular).
+    10x6: block-Jacobi preconditioner; 16x12: multigrid hierarchy active."""
+    sys, o = _pair(oracle, N, M, amp=2e-4)
     sys.compute_Hessian(spd=False)
     H = sys.H.to_csr()
     w = np.linalg.eigvalsh(0.5 * (H + H.T).toarray())
