@@ -93,6 +93,164 @@ k_st_spmv5(MgGrid g, const double* __restrict__ A, const double* __restrict__ x,
   }
 }
 
+// ---- fused variants: a V-cycle is a chain of dependent launches of 4-5 us each on a few thousand nodes, so the number
+// of launches, not the arithmetic, sets its cost.
+// (1) first sweep from a zero guess + residual product: x = omega Dinv r, t = A x with the neighbours' x recomputed on the fly
+__global__ void __launch_bounds__(320)
+k_st_first_resid(MgGrid g, const double* __restrict__ A, const double* __restrict__ Dinv, const double* __restrict__ r, const double* __restrict__ omega_dev,
+                 double* __restrict__ x, double* __restrict__ t) {
+  __shared__ double red[5][3][64];
+  const int n = (g.N + 1) * (g.M + 1);
+  const int lane = threadIdx.x & 63, q = threadIdx.x >> 6;
+  const int row = blockIdx.x * 64 + lane;
+  const double omega = *omega_dev;
+  double y0 = 0, y1 = 0, y2 = 0;
+  if (row < n) {
+    const int I = row / (g.M + 1), J = row % (g.M + 1);
+    const int I2 = I + q - 2;
+    if (I2 >= 0 && I2 <= g.N) {
+#pragma unroll
+      for (int dJ = -2; dJ <= 2; dJ++) {
+        const int J2 = J + dJ;
+        if (J2 < 0 || J2 > g.M) continue;
+        const int s = q * 5 + (dJ + 2);
+        const double* a = A + (size_t)s * 9 * n + row;
+        const int c = I2 * (g.M + 1) + J2;
+        m3 D;
+#pragma unroll
+        for (int e = 0; e < 9; e++) D.m[e] = Dinv[9 * (size_t)c + e];
+        const d3 xj = omega * m3_mulv(D, ld3(r, c));
+        y0 += a[0] * xj.x + a[(size_t)n] * xj.y + a[2 * (size_t)n] * xj.z;
+        y1 += a[3 * (size_t)n] * xj.x + a[4 * (size_t)n] * xj.y + a[5 * (size_t)n] * xj.z;
+        y2 += a[6 * (size_t)n] * xj.x + a[7 * (size_t)n] * xj.y + a[8 * (size_t)n] * xj.z;
+      }
+    }
+  }
+  red[q][0][lane] = y0; red[q][1][lane] = y1; red[q][2][lane] = y2;
+  __syncthreads();
+  if (q == 0 && row < n) {
+#pragma unroll
+    for (int k = 1; k < 5; k++) { y0 += red[k][0][lane]; y1 += red[k][1][lane]; y2 += red[k][2][lane]; }
+    st3(t, row, d3(y0, y1, y2));
+    m3 D;
+#pragma unroll
+    for (int e = 0; e < 9; e++) D.m[e] = Dinv[9 * (size_t)row + e];
+    st3(x, row, omega * m3_mulv(D, ld3(r, row)));
+  }
+}
+
+// (x + P xc) at fine node (i, j) of grid gf
+TSL_DEV d3 st_prolonged(MgGrid gf, const double* __restrict__ x, const double* __restrict__ xc, int i, int j) {
+  const int Mc = gf.M >> 1;
+  d3 acc = ld3(x, i * (gf.M + 1) + j);
+#pragma unroll
+  for (int a = 0; a < 2; a++) {
+    double wa; const int I = mg_coarse(i, a, wa);
+    if (wa == 0.0) continue;
+#pragma unroll
+    for (int b = 0; b < 2; b++) {
+      double wb; const int J = mg_coarse(j, b, wb);
+      if (wb == 0.0) continue;
+      acc = acc + (wa * wb) * ld3(xc, I * (Mc + 1) + J);
+    }
+  }
+  return acc;
+}
+
+// (2) prolongation + first post-smoothing sweep: xt = x + P xc (never stored), y = xt + omega Dinv (r - A xt)
+__global__ void __launch_bounds__(320)
+k_st_prolong_sweep(MgGrid g, const double* __restrict__ A, const double* __restrict__ x, const double* __restrict__ xc, double* __restrict__ y,
+                   const double* __restrict__ Dinv, const double* __restrict__ r, const double* __restrict__ omega_dev) {
+  __shared__ double red[5][3][64];
+  const int n = (g.N + 1) * (g.M + 1);
+  const int lane = threadIdx.x & 63, q = threadIdx.x >> 6;
+  const int row = blockIdx.x * 64 + lane;
+  double y0 = 0, y1 = 0, y2 = 0;
+  int I = 0, J = 0;
+  if (row < n) {
+    I = row / (g.M + 1); J = row % (g.M + 1);
+    const int I2 = I + q - 2;
+    if (I2 >= 0 && I2 <= g.N) {
+#pragma unroll
+      for (int dJ = -2; dJ <= 2; dJ++) {
+        const int J2 = J + dJ;
+        if (J2 < 0 || J2 > g.M) continue;
+        const int s = q * 5 + (dJ + 2);
+        const double* a = A + (size_t)s * 9 * n + row;
+        const d3 xj = st_prolonged(g, x, xc, I2, J2);
+        y0 += a[0] * xj.x + a[(size_t)n] * xj.y + a[2 * (size_t)n] * xj.z;
+        y1 += a[3 * (size_t)n] * xj.x + a[4 * (size_t)n] * xj.y + a[5 * (size_t)n] * xj.z;
+        y2 += a[6 * (size_t)n] * xj.x + a[7 * (size_t)n] * xj.y + a[8 * (size_t)n] * xj.z;
+      }
+    }
+  }
+  red[q][0][lane] = y0; red[q][1][lane] = y1; red[q][2][lane] = y2;
+  __syncthreads();
+  if (q == 0 && row < n) {
+#pragma unroll
+    for (int k = 1; k < 5; k++) { y0 += red[k][0][lane]; y1 += red[k][1][lane]; y2 += red[k][2][lane]; }
+    m3 D;
+#pragma unroll
+    for (int e = 0; e < 9; e++) D.m[e] = Dinv[9 * (size_t)row + e];
+    const d3 res = ld3(r, row) - d3(y0, y1, y2);
+    st3(y, row, st_prolonged(g, x, xc, I, J) + (*omega_dev) * m3_mulv(D, res));
+  }
+}
+
+// (3) the whole coarsest level (<= 64 nodes) in one workgroup: x = omega Dinv r, then sweeps - 1 damped-Jacobi sweeps with the
+// iterate in LDS (ping-pong) and the 25-slot operator streamed from L2
+__global__ void __launch_bounds__(320)
+k_st_coarse(MgGrid g, const double* __restrict__ A, const double* __restrict__ Dinv, const double* __restrict__ r, const double* __restrict__ omega_dev, int sweeps,
+            double* __restrict__ out) {
+  __shared__ double red[5][3][64];
+  __shared__ double xs[2][3][64];
+  const int n = (g.N + 1) * (g.M + 1);
+  const int lane = threadIdx.x & 63, q = threadIdx.x >> 6;
+  const int row = lane;
+  const double omega = *omega_dev;
+  m3 D;
+  d3 rv = d3();
+  const bool own = q == 0 && row < n;
+  if (own) {
+#pragma unroll
+    for (int e = 0; e < 9; e++) D.m[e] = Dinv[9 * (size_t)row + e];
+    rv = ld3(r, row);
+    const d3 x0 = omega * m3_mulv(D, rv);
+    xs[0][0][lane] = x0.x; xs[0][1][lane] = x0.y; xs[0][2][lane] = x0.z;
+  }
+  const int I = row / (g.M + 1), J = row % (g.M + 1);
+  const int I2 = I + q - 2;
+  int cur = 0;
+  for (int it = 1; it < sweeps; it++) {
+    __syncthreads();
+    double y0 = 0, y1 = 0, y2 = 0;
+    if (row < n && I2 >= 0 && I2 <= g.N) {
+#pragma unroll
+      for (int dJ = -2; dJ <= 2; dJ++) {
+        const int J2 = J + dJ;
+        if (J2 < 0 || J2 > g.M) continue;
+        const int s = q * 5 + (dJ + 2);
+        const double* a = A + (size_t)s * 9 * n + row;
+        const int c = I2 * (g.M + 1) + J2;
+        const double xx = xs[cur][0][c], xy = xs[cur][1][c], xz = xs[cur][2][c];
+        y0 += a[0] * xx + a[(size_t)n] * xy + a[2 * (size_t)n] * xz;
+        y1 += a[3 * (size_t)n] * xx + a[4 * (size_t)n] * xy + a[5 * (size_t)n] * xz;
+        y2 += a[6 * (size_t)n] * xx + a[7 * (size_t)n] * xy + a[8 * (size_t)n] * xz;
+      }
+    }
+    red[q][0][lane] = y0; red[q][1][lane] = y1; red[q][2][lane] = y2;
+    __syncthreads();
+    if (own) {
+#pragma unroll
+      for (int k = 1; k < 5; k++) { y0 += red[k][0][lane]; y1 += red[k][1][lane]; y2 += red[k][2][lane]; }
+      const d3 xn = d3(xs[cur][0][lane], xs[cur][1][lane], xs[cur][2][lane]) + omega * m3_mulv(D, rv - d3(y0, y1, y2));
+      xs[cur ^ 1][0][lane] = xn.x; xs[cur ^ 1][1][lane] = xn.y; xs[cur ^ 1][2][lane] = xn.z;
+    }
+    cur ^= 1;
+  }
+  if (own) st3(out, row, d3(xs[cur][0][lane], xs[cur][1][lane], xs[cur][2][lane]));
+}
+
 // x = omega * Dinv * r   (first smoothing sweep from a zero guess)
 __global__ void k_mg_jacobi_first(int n, const double* __restrict__ Dinv, const double* __restrict__ r, const double* __restrict__ omega_dev, double* __restrict__ x) {
   const int p = blockIdx.x * blockDim.x + threadIdx.x;

@@ -302,6 +302,7 @@ extern "C" int tsl_set_param(tsl_ctx* c, const char* key, double v) {
   else if (k == "body_inv") { c->bd_enable = (int)v; c->bd_valid = false; }
   else if (k == "mg") c->mg_enable = (int)v;
   else if (k == "mg_omega") c->mg_omega = v;
+  else if (k == "mg_fuse") c->mg_fuse = (int)v;
   else if (k == "mg_pi_iters") c->mg_pi_iters = (int)v;
   else if (k == "graph") c->use_graph = (int)v;
   else if (k == "mg_nu") c->mg_nu = std::max(1, (int)v);
@@ -641,17 +642,30 @@ static double* mg_stencil_cycle(tsl_ctx* c, MgCloth* mc, size_t l) {
     hipLaunchKernelGGL((k_st_spmv5<1>), dim3(gb5), dim3(320), 0, s, g, L->A.p, xa, xb, L->Dinv.p, L->r.p, L->omega.p);
     std::swap(xa, xb);
   };
-  hipLaunchKernelGGL(k_mg_jacobi_first, dim3(gb), dim3(256), 0, s, L->n, L->Dinv.p, L->r.p, L->omega.p, xa);
   const bool last = (l + 1 == mc->lv.size());
+  if (c->mg_fuse && last && L->n <= 64) {  // whole coarsest level in one workgroup
+    hipLaunchKernelGGL(k_st_coarse, dim3(1), dim3(320), 0, s, g, L->A.p, L->Dinv.p, L->r.p, L->omega.p, c->mg_coarse_sweeps, xa);
+    return xa;
+  }
+  const bool fuse_down = c->mg_fuse && !last && c->mg_nu == 1;
+  if (fuse_down) hipLaunchKernelGGL(k_st_first_resid, dim3(gb5), dim3(320), 0, s, g, L->A.p, L->Dinv.p, L->r.p, L->omega.p, xa, L->t.p);
+  else hipLaunchKernelGGL(k_mg_jacobi_first, dim3(gb), dim3(256), 0, s, L->n, L->Dinv.p, L->r.p, L->omega.p, xa);
   const int extra = last ? c->mg_coarse_sweeps - 1 : c->mg_nu - 1;
   for (int k = 0; k < extra; k++) sweep();
   if (last) return xa;
   MgLevel* Lc = mc->lv[l + 1];
-  hipLaunchKernelGGL((k_st_spmv5<0>), dim3(gb5), dim3(320), 0, s, g, L->A.p, xa, L->t.p, (const double*)nullptr, (const double*)nullptr, (const double*)nullptr);
+  if (!fuse_down)
+    hipLaunchKernelGGL((k_st_spmv5<0>), dim3(gb5), dim3(320), 0, s, g, L->A.p, xa, L->t.p, (const double*)nullptr, (const double*)nullptr, (const double*)nullptr);
   hipLaunchKernelGGL(k_st_restrict, dim3(nblk(Lc->n, 256)), dim3(256), 0, s, g, L->r.p, L->t.p, Lc->r.p);
   const double* xc = mg_stencil_cycle(c, mc, l + 1);
-  hipLaunchKernelGGL(k_st_prolong_add, dim3(gb), dim3(256), 0, s, g, xc, xa);
-  for (int k = 0; k < c->mg_nu; k++) sweep();
+  if (c->mg_fuse) {  // prolongation folded into the first post-sweep
+    hipLaunchKernelGGL(k_st_prolong_sweep, dim3(gb5), dim3(320), 0, s, g, L->A.p, xa, xc, xb, L->Dinv.p, L->r.p, L->omega.p);
+    std::swap(xa, xb);
+    for (int k = 1; k < c->mg_nu; k++) sweep();
+  } else {
+    hipLaunchKernelGGL(k_st_prolong_add, dim3(gb), dim3(256), 0, s, g, xc, xa);
+    for (int k = 0; k < c->mg_nu; k++) sweep();
+  }
   return xa;
 }
 
@@ -711,7 +725,7 @@ static void launch_pcg_iteration(tsl_ctx* c, int parity, int first, unsigned lon
 // iteration is ~45 short kernels, eager launches leave the GPU idle ~30 % of the time.  The first K1 of the chunk stamps
 // the device clock into a fixed buffer when profiling is on.
 static int pcg_chunk_graph(tsl_ctx* c, int chunk) {
-  const long key = ((long)(mg_active(c) ? 1 : 0) << 40) | ((long)c->nc << 8) | ((long)(c->prof_enable ? 1 : 0) << 7) | (long)chunk | ((long)c->mg_nu << 44) | ((long)c->mg_coarse_sweeps << 48) | ((long)(c->pc_separate ? 1 : 0) << 41) | ((long)((body_active(c) && c->bd_valid) ? 1 : 0) << 42);
+  const long key = ((long)(mg_active(c) ? 1 : 0) << 40) | ((long)c->nc << 8) | ((long)(c->prof_enable ? 1 : 0) << 7) | (long)chunk | ((long)c->mg_nu << 44) | ((long)c->mg_coarse_sweeps << 48) | ((long)(c->pc_separate ? 1 : 0) << 41) | ((long)((body_active(c) && c->bd_valid) ? 1 : 0) << 42) | ((long)(c->mg_fuse ? 1 : 0) << 43);
   if (c->pcg_graph && c->pcg_graph_key == key) return 0;
   if (c->pcg_graph) { (void)hipGraphExecDestroy(c->pcg_graph); c->pcg_graph = nullptr; }
   hipGraph_t g = nullptr;
