@@ -190,7 +190,7 @@ struct tsl_ctx {
   int mg_pi_iters = 12;
   DevBuf<double> mg_omega0, mg_pi_part, mg_pi_norm;  // level 0
   int mg_nu = 1, mg_coarse_sweeps = 8, mg_fuse = 1;
-  bool mg_ops_valid = false, mg_suspended = false;
+  bool mg_ops_valid = false, mg_suspended = false, mg_omega_valid = false;
 
   // ---- profiling of the dominant kernel
   int prof_enable = 0;

@@ -282,6 +282,7 @@ extern "C" int tsl_set_stream(tsl_ctx* c, void* s) { c->user_stream = (hipStream
 extern "C" int tsl_set_param(tsl_ctx* c, const char* key, double v) {
   Scope scope(c);
   (void)hipStreamSynchronize(c->stream);
+  c->mg_omega_valid = false;
   std::string k(key);
   if (k == "mu_cloth_elastic") c->mu_cloth_elastic = v;
   else if (k == "k_contact") c->k_contact = v;
@@ -323,6 +324,7 @@ extern "C" int tsl_set_frozen(tsl_ctx* c, const int32_t* fr) {
   Scope scope(c);
   (void)hipStreamSynchronize(c->stream);
   c->h_frozen.assign(fr, fr + 3 * (size_t)c->NV);
+  c->mg_omega_valid = false;
   TSL_TRY(upload_frozen(c));
   if (c->pcg_graph) { (void)hipGraphExecDestroy(c->pcg_graph); c->pcg_graph = nullptr; }
   return body_dense_setup(c);
@@ -424,6 +426,7 @@ static int assemble(tsl_ctx* c, const double* pos, const double* prev, const dou
 extern "C" int tsl_assemble(tsl_ctx* c, const double* pos, const double* prev, const double* vel, const double* ref, int spd, double* grad) {
   Scope scope(c);
   c->bd_valid = false;
+  c->mg_omega_valid = false;
   return assemble(c, pos, prev, vel, ref, spd, grad);
 }
 
@@ -602,7 +605,10 @@ static int mg_setup_operators(tsl_ctx* c) {
   if (c->mg_omega > 0) {
     TSL_TRY(set_fixed(c->mg_omega0.p));
     for (MgCloth* mc : c->mg) for (MgLevel* L : mc->lv) TSL_TRY(set_fixed(L->omega.p));
-  } else {
+  } else if (!c->mg_omega_valid) {
+    // lambda_max(D^-1 A) moves little over the Newton iterations of one step and omega = 1.5 / lambda_max keeps a 33 % margin:
+    // the power iterations (~220 launches) run at the first assembly of a time / adjoint step only, and again after a breakdown
+    c->mg_omega_valid = true;
     const int K = std::min(std::max(c->mg_pi_iters, 2), 60);
     {  // level 0: v in v_t2, t in v_t3
       const int NV = c->NV, gb = nblk(NV, 256);
@@ -820,7 +826,7 @@ static int solve_perm(tsl_ctx* c, tsl_solve_stats* st) {
       if (flag) break;
     }
     if (flag) total_it = total_it - it + HPSC(c)->iters;  // iterations actually executed before the kernels went idle
-    if (flag == 1) indefinite = true;
+    if (flag == 1) { indefinite = true; c->mg_omega_valid = false; }
     if (flag != 2) break;  // breakdown or iteration cap
   }
   st->iters = total_it;
@@ -1096,6 +1102,7 @@ extern "C" int tsl_step(tsl_ctx* c, double* pos, double* prev, double* vel, doub
   const size_t n3 = 3 * (size_t)c->NV;
   tsl_step_stats st;
   memset(&st, 0, sizeof(st));
+  c->mg_omega_valid = false;
   c->bd_valid = false;  // dense body inverses are rebuilt once per step (first solve) and lagged over its Newton iterations
   // timestep_init: prev_pos <- pos (BaseScene.py:1291-1303)
   HIP_OK(hipMemcpyAsync(prev, pos, n3 * sizeof(double), hipMemcpyDeviceToDevice, s));
@@ -1392,6 +1399,7 @@ extern "C" int tsl_adjoint_step(tsl_ctx* c, int step, int T, const double* pos_b
   const bool have_mg = !c->mg.empty() && c->mg_enable != 0;
   const bool spd_pc = c->adj_spd_pc && (have_mg || body_active(c));
   c->bd_valid = false;
+  c->mg_omega_valid = false;
   if (spd_pc) {
     TSL_TRY(assemble(c, x_s, x_prev, x_prev, ref_prev, 1, nullptr));
     if (body_active(c)) TSL_TRY(body_build_inverse(c));
