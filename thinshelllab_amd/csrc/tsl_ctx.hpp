@@ -150,7 +150,7 @@ struct tsl_ctx {
   DevBuf<double> bd_W, bd_scr;
   DevBuf<float> bd_Binv;
   DevBuf<double> gm_V, gm_h;  // GMRES basis ((m+1) vectors) and projection coefficients
-  int gmres_m = 300, use_gmres = 1;
+  int gmres_m = 300, use_gmres = 1, use_minres = 1;
   // preconditioner built from a different (SPD-projected) assembly than the operator: adjoint solves (un-projected H)
   DevBuf<double> vals_pc, c_H_pc;
   bool pc_separate = false, pc_frozen = false;

@@ -299,6 +299,7 @@ extern "C" int tsl_set_param(tsl_ctx* c, const char* key, double v) {
   else if (k == "grid_extent") c->grid_extent = v;
   else if (k == "adj_spd_pc") c->adj_spd_pc = (int)v;
   else if (k == "gmres") c->use_gmres = (int)v;
+  else if (k == "minres") c->use_minres = (int)v;
   else if (k == "gmres_m") c->gmres_m = (int)v;
   else if (k == "body_inv") { c->bd_enable = (int)v; c->bd_valid = false; }
   else if (k == "mg") c->mg_enable = (int)v;
@@ -464,6 +465,7 @@ static int read_scal(tsl_ctx* c) {
 
 static int bicgstab(tsl_ctx* c, tsl_solve_stats* st);
 static int gmres(tsl_ctx* c, tsl_solve_stats* st);
+static int minres(tsl_ctx* c, tsl_solve_stats* st);
 
 // ------------------------------------------------------------------------------------------------ dense body blocks (k_body.hpp)
 // which elastic bodies get an exact block: at most 512 vertices, at least one free dof
@@ -840,12 +842,134 @@ static int solve_perm(tsl_ctx* c, tsl_solve_stats* st) {
     st->iters += st2.iters; st->restarts += st2.restarts + 1; st->flag = st2.flag; st->rel_residual = st2.rel_residual;
     return rc;
   }
+  if (c->use_minres) {  // symmetric indefinite: short recurrences
+    tsl_solve_stats st2 = *st;
+    TSL_TRY(minres(c, &st2));
+    st->iters = st2.iters; st->restarts = st2.restarts; st->rel_residual = st2.rel_residual;
+    if (st2.flag == 1) { st->flag = 1; return 0; }
+  }
   if (c->use_gmres) {
+    const int it0 = st->iters;
     TSL_TRY(gmres(c, st));
+    (void)it0;
     if (st->flag == 1) return 0;
     return bicgstab(c, st);  // last resort
   }
   return bicgstab(c, st);
+}
+
+// Preconditioned MINRES for symmetric indefinite H with an SPD preconditioner (adjoint systems: un-projected H, preconditioner
+// built from the SPD-projected assembly).  Three-term recurrence: one operator product and one preconditioner application
+// per iteration like PCG, no basis to orthogonalise against, and for a symmetric H the iterates are those of un-restarted
+// GMRES.  H is symmetric only up to the reference's area-Hessian quirk, so the recurrence residual is checked against the true
+// residual b - Hx and the recurrence is restarted from it (same rule as the PCG restarts).  st->flag = 1 on success, 3 else.
+static int minres(tsl_ctx* c, tsl_solve_stats* st) {
+  hipStream_t s = c->stream;
+  const int NV = c->NV;
+  const size_t n3 = 3 * (size_t)NV;
+  const int gb = nblk(NV, 256), gv = gsz(n3);
+  double *x = c->v_x.p, *v_prev = c->v_t0.p, *v_cur = c->v_r.p, *v_next = c->v_Ap.p, *z_cur = c->v_z.p, *z_next = c->v_t1.p, *w_prev = c->v_t2.p, *w_cur = c->v_t3.p,
+         *w_next = c->v_p.p;
+  const bool mg = mg_active(c);
+  if (body_active(c) && !c->bd_valid) TSL_TRY(body_build_inverse(c));
+  if (mg && !c->mg_ops_valid) TSL_TRY(mg_setup_operators(c));
+  auto precond = [&](const double* in, double* out) {
+    if (mg) mg_vcycle(c, in, out, c->part_rz.p);
+    else {
+      hipLaunchKernelGGL(k_precond, dim3(gb), dim3(256), 0, s, NV, c->Dinv.p, in, out);
+      if (body_active(c) && c->bd_valid) body_apply(c, 0, in, nullptr, out, nullptr, nullptr);
+    }
+  };
+  CgScal* d = SC(c);
+  CgScal* h = HSC(c);
+  auto dot2 = [&](const double* a1, const double* b1, const double* a2, const double* b2, double* o1, double* o2) -> int {
+    HIP_OK(hipMemsetAsync(&d->aux[0], 0, 2 * sizeof(double), s));
+    hipLaunchKernelGGL(k_dot, dim3(gv), dim3(256), 0, s, n3, a1, b1, &d->aux[0]);
+    if (a2) hipLaunchKernelGGL(k_dot, dim3(gv), dim3(256), 0, s, n3, a2, b2, &d->aux[1]);
+    HIP_OK(hipMemcpyAsync(&h->aux[0], &d->aux[0], 2 * sizeof(double), hipMemcpyDeviceToHost, s));
+    HIP_OK(hipStreamSynchronize(s));
+    *o1 = h->aux[0];
+    if (o2) *o2 = h->aux[1];
+    return 0;
+  };
+  double bb;
+  TSL_TRY(dot2(c->v_b.p, c->v_b.p, nullptr, nullptr, &bb, nullptr));
+  st->flag = 3;
+  if (!(bb > 0)) { st->flag = 1; return 0; }
+  const double tol = c->cg_tol * sqrt(bb);
+  HIP_OK(hipMemsetAsync(x, 0, n3 * sizeof(double), s));
+  HIP_OK(hipMemcpyAsync(v_cur, c->v_b.p, n3 * sizeof(double), hipMemcpyDeviceToDevice, s));
+  double true_prev = 1e300;
+  int total = 0;
+  for (int cycle = 0; cycle < 40 && total < c->cg_maxit; cycle++) {
+    // (re)start from the true residual held in v_cur
+    double rr, g2;
+    precond(v_cur, z_cur);
+    TSL_TRY(dot2(v_cur, v_cur, z_cur, v_cur, &rr, &g2));
+    const double rnorm0 = sqrt(rr);
+    st->rel_residual = rnorm0 / sqrt(bb);
+    if (rnorm0 <= tol) { st->flag = 1; break; }
+    if (cycle > 0 && rnorm0 > 0.25 * true_prev && rnorm0 <= 1e3 * tol) { st->flag = 1; break; }  // attainable accuracy
+    if (cycle > 3 && rnorm0 > 0.9 * true_prev) break;                                            // stagnating: hand over
+    true_prev = rnorm0;
+    if (!(g2 > 0) || !std::isfinite(g2)) break;  // preconditioner not positive definite
+    if (cycle > 0) st->restarts++;
+    double gamma = sqrt(g2), gamma_prev = 1.0, eta = gamma, s_prev = 0, s_cur = 0, c_prev = 1, c_cur = 1;
+    const double eta0 = eta;
+    HIP_OK(hipMemsetAsync(v_prev, 0, n3 * sizeof(double), s));
+    HIP_OK(hipMemsetAsync(w_prev, 0, n3 * sizeof(double), s));
+    HIP_OK(hipMemsetAsync(w_cur, 0, n3 * sizeof(double), s));
+    bool ok = true;
+    for (int j = 0; total < c->cg_maxit; j++) {
+      // z_j /= gamma_j ; v_next = A z_j ; delta = <A z_j, z_j>
+      hipLaunchKernelGGL(k_axpby, dim3(gv), dim3(256), 0, s, n3, 1.0 / gamma, z_cur, 0.0, z_cur);
+      launch_spmv(c, c->vals.p, z_cur, v_next, -1, 0);
+      double delta;
+      TSL_TRY(dot2(v_next, z_cur, nullptr, nullptr, &delta, nullptr));
+      // v_next -= (delta / gamma) v_cur + (gamma / gamma_prev) v_prev
+      hipLaunchKernelGGL(k_axpby, dim3(gv), dim3(256), 0, s, n3, -delta / gamma, v_cur, 1.0, v_next);
+      if (j > 0) hipLaunchKernelGGL(k_axpby, dim3(gv), dim3(256), 0, s, n3, -gamma / gamma_prev, v_prev, 1.0, v_next);
+      precond(v_next, z_next);
+      double g2n;
+      TSL_TRY(dot2(z_next, v_next, nullptr, nullptr, &g2n, nullptr));
+      total++; st->iters++;
+      if (!(g2n >= 0) || !std::isfinite(g2n) || !std::isfinite(delta)) { ok = false; break; }
+      const double gamma_next = sqrt(g2n);
+      const double a0 = c_cur * delta - c_prev * s_cur * gamma;
+      const double a1 = sqrt(a0 * a0 + gamma_next * gamma_next);
+      const double a2 = s_cur * delta + c_prev * c_cur * gamma;
+      const double a3 = s_prev * gamma;
+      if (!(a1 > 0)) { ok = false; break; }
+      const double c_next = a0 / a1, s_next = gamma_next / a1;
+      // w_next = (z_j - a3 w_prev - a2 w_cur) / a1 ; x += c_next eta w_next
+      hipLaunchKernelGGL(k_axpby, dim3(gv), dim3(256), 0, s, n3, 1.0 / a1, z_cur, 0.0, w_next);
+      hipLaunchKernelGGL(k_axpby, dim3(gv), dim3(256), 0, s, n3, -a3 / a1, w_prev, 1.0, w_next);
+      hipLaunchKernelGGL(k_axpby, dim3(gv), dim3(256), 0, s, n3, -a2 / a1, w_cur, 1.0, w_next);
+      hipLaunchKernelGGL(k_axpby, dim3(gv), dim3(256), 0, s, n3, c_next * eta, w_next, 1.0, x);
+      eta = -s_next * eta;
+      // rotate the buffers
+      { double* t0 = v_prev; v_prev = v_cur; v_cur = v_next; v_next = t0; }
+      { double* t0 = z_cur; z_cur = z_next; z_next = t0; }
+      { double* t0 = w_prev; w_prev = w_cur; w_cur = w_next; w_next = t0; }
+      gamma_prev = gamma; gamma = gamma_next;
+      s_prev = s_cur; s_cur = s_next; c_prev = c_cur; c_cur = c_next;
+      // |eta| is the residual in the M^-1 norm; scale the test by the start of the cycle
+      if (fabs(eta) <= 0.3 * (tol / rnorm0) * eta0 || gamma_next == 0.0) break;
+    }
+    // true residual into v_cur
+    launch_spmv(c, c->vals.p, x, v_next, -1, 0);
+    HIP_OK(hipMemcpyAsync(v_cur, c->v_b.p, n3 * sizeof(double), hipMemcpyDeviceToDevice, s));
+    hipLaunchKernelGGL(k_axpby, dim3(gv), dim3(256), 0, s, n3, -1.0, v_next, 1.0, v_cur);
+    if (!ok) {
+      double tr;
+      TSL_TRY(dot2(v_cur, v_cur, nullptr, nullptr, &tr, nullptr));
+      st->rel_residual = sqrt(tr / bb);
+      if (sqrt(tr) <= tol) st->flag = 1;
+      break;
+    }
+  }
+  HIP_OK(hipGetLastError());
+  return 0;
 }
 
 // Right-preconditioned restarted GMRES(m) on H for indefinite / non-symmetric systems (un-projected adjoint Hessians):
