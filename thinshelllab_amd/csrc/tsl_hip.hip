@@ -305,6 +305,7 @@ extern "C" int tsl_set_param(tsl_ctx* c, const char* key, double v) {
   else if (k == "mg") c->mg_enable = (int)v;
   else if (k == "mg_omega") c->mg_omega = v;
   else if (k == "mg_fuse") c->mg_fuse = (int)v;
+  else if (k == "mg_max_levels") c->mg_max_levels = (int)v;
   else if (k == "mg_pi_iters") c->mg_pi_iters = (int)v;
   else if (k == "graph") c->use_graph = (int)v;
   else if (k == "mg_nu") c->mg_nu = std::max(1, (int)v);
@@ -566,6 +567,7 @@ static int mg_build(tsl_ctx* c, const tsl_scene_desc* d) {
   return 0;
 }
 
+static size_t mg_levels(tsl_ctx* c, MgCloth* mc) { return std::min<size_t>(mc->lv.size(), (size_t)std::max(1, c->mg_max_levels)); }
 static bool mg_active(tsl_ctx* c) { return !c->mg.empty() && c->mg_enable != 0 && !c->mg_suspended; }
 
 // plain y = H x on level 0 (matrix + matrix-free contact), no scalar side effects
@@ -589,7 +591,7 @@ static int mg_setup_operators(tsl_ctx* c) {
                        L1->A.p);
     if (c->nc > 0) hipLaunchKernelGGL(k_galerkin0_diag, dim3(nblk((gf.N + 1) * (gf.M + 1), 256)), dim3(256), 0, s, gf, mc->v_offset, c->rowpos.p, c->c_diag.p, L1->A.p);
     hipLaunchKernelGGL(k_st_diag_inv, dim3(nblk(L1->n, 256)), dim3(256), 0, s, L1->n, L1->A.p, L1->Dinv.p);
-    for (size_t l = 0; l + 1 < mc->lv.size(); l++) {
+    for (size_t l = 0; l + 1 < mg_levels(c, mc); l++) {
       MgLevel* Lf = mc->lv[l];
       MgLevel* Lc = mc->lv[l + 1];
       HIP_OK(hipMemsetAsync(Lc->A.p, 0, Lc->A.n * sizeof(double), s));
@@ -650,7 +652,7 @@ static double* mg_stencil_cycle(tsl_ctx* c, MgCloth* mc, size_t l) {
     hipLaunchKernelGGL((k_st_spmv5<1>), dim3(gb5), dim3(320), 0, s, g, L->A.p, xa, xb, L->Dinv.p, L->r.p, L->omega.p);
     std::swap(xa, xb);
   };
-  const bool last = (l + 1 == mc->lv.size());
+  const bool last = (l + 1 == mg_levels(c, mc));
   if (c->mg_fuse && last && L->n <= 64) {  // whole coarsest level in one workgroup
     hipLaunchKernelGGL(k_st_coarse, dim3(1), dim3(320), 0, s, g, L->A.p, L->Dinv.p, L->r.p, L->omega.p, c->mg_coarse_sweeps, xa);
     return xa;
@@ -733,7 +735,7 @@ static void launch_pcg_iteration(tsl_ctx* c, int parity, int first, unsigned lon
 // iteration is ~45 short kernels, eager launches leave the GPU idle ~30 % of the time.  The first K1 of the chunk stamps
 // the device clock into a fixed buffer when profiling is on.
 static int pcg_chunk_graph(tsl_ctx* c, int chunk) {
-  const long key = ((long)(mg_active(c) ? 1 : 0) << 40) | ((long)c->nc << 8) | ((long)(c->prof_enable ? 1 : 0) << 7) | (long)chunk | ((long)c->mg_nu << 44) | ((long)c->mg_coarse_sweeps << 48) | ((long)(c->pc_separate ? 1 : 0) << 41) | ((long)((body_active(c) && c->bd_valid) ? 1 : 0) << 42) | ((long)(c->mg_fuse ? 1 : 0) << 43);
+  const long key = ((long)(mg_active(c) ? 1 : 0) << 40) | ((long)c->nc << 8) | ((long)(c->prof_enable ? 1 : 0) << 7) | (long)chunk | ((long)c->mg_nu << 44) | ((long)c->mg_coarse_sweeps << 48) | ((long)(c->pc_separate ? 1 : 0) << 41) | ((long)((body_active(c) && c->bd_valid) ? 1 : 0) << 42) | ((long)(c->mg_fuse ? 1 : 0) << 43) | ((long)c->mg_max_levels << 52);
   if (c->pcg_graph && c->pcg_graph_key == key) return 0;
   if (c->pcg_graph) { (void)hipGraphExecDestroy(c->pcg_graph); c->pcg_graph = nullptr; }
   hipGraph_t g = nullptr;
