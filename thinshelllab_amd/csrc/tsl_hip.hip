@@ -27,6 +27,7 @@ int tsl_fail(const char* fmt, ...) {
 
 #define TSL_TRY(x) do { if ((x) != 0) return -1; } while (0)
 
+#define DOT_BLOCKS 120  // one f64 atomic per wave into a single address: more blocks only add contention (30 us at 600 blocks)
 static inline int nblk(long n, int b) { return (int)((n + b - 1) / b); }
 static inline int gsz(size_t n) { size_t b = (n + 255) / 256; return (int)std::min<size_t>(std::max<size_t>(b, 1), 4096); }
 
@@ -770,7 +771,7 @@ static int solve_perm(tsl_ctx* c, tsl_solve_stats* st) {
   st->iters = 0; st->restarts = 0; st->flag = 0; st->rel_residual = 0;
   HIP_OK(hipMemsetAsync(c->v_x.p, 0, n3 * sizeof(double), s));
   HIP_OK(hipMemsetAsync(c->scal.p, 0, sizeof(SolverScalars), s));
-  hipLaunchKernelGGL(k_dot, dim3(gsz(n3)), dim3(256), 0, s, n3, c->v_b.p, c->v_b.p, &SC(c)->bb);
+  hipLaunchKernelGGL(k_dot, dim3(DOT_BLOCKS), dim3(256), 0, s, n3, c->v_b.p, c->v_b.p, &SC(c)->bb);
   TSL_TRY(read_scal(c));
   const double bb = HSC(c)->bb;
   if (!(bb > 0)) return 0;  // zero rhs -> x = 0
@@ -886,8 +887,8 @@ static int minres(tsl_ctx* c, tsl_solve_stats* st) {
   CgScal* h = HSC(c);
   auto dot2 = [&](const double* a1, const double* b1, const double* a2, const double* b2, double* o1, double* o2) -> int {
     HIP_OK(hipMemsetAsync(&d->aux[0], 0, 2 * sizeof(double), s));
-    hipLaunchKernelGGL(k_dot, dim3(gv), dim3(256), 0, s, n3, a1, b1, &d->aux[0]);
-    if (a2) hipLaunchKernelGGL(k_dot, dim3(gv), dim3(256), 0, s, n3, a2, b2, &d->aux[1]);
+    hipLaunchKernelGGL(k_dot, dim3(DOT_BLOCKS), dim3(256), 0, s, n3, a1, b1, &d->aux[0]);
+    if (a2) hipLaunchKernelGGL(k_dot, dim3(DOT_BLOCKS), dim3(256), 0, s, n3, a2, b2, &d->aux[1]);
     HIP_OK(hipMemcpyAsync(&h->aux[0], &d->aux[0], 2 * sizeof(double), hipMemcpyDeviceToHost, s));
     HIP_OK(hipStreamSynchronize(s));
     *o1 = h->aux[0];
@@ -1008,7 +1009,7 @@ static int gmres(tsl_ctx* c, tsl_solve_stats* st) {
   };
   auto norm2 = [&](const double* a, double* out) -> int {
     HIP_OK(hipMemsetAsync(dh + on, 0, sizeof(double), s));
-    hipLaunchKernelGGL(k_dot, dim3(gv), dim3(256), 0, s, n3, a, a, dh + on);
+    hipLaunchKernelGGL(k_dot, dim3(DOT_BLOCKS), dim3(256), 0, s, n3, a, a, dh + on);
     HIP_OK(hipMemcpyAsync(out, dh + on, sizeof(double), hipMemcpyDeviceToHost, s));
     HIP_OK(hipStreamSynchronize(s));
     return 0;
@@ -1038,7 +1039,7 @@ static int gmres(tsl_ctx* c, tsl_solve_stats* st) {
       hipLaunchKernelGGL(k_multi_axpy, dim3(gv), dim3(256), 0, s, n3, V, n3, j + 1, dh, -1.0, w);
       hipLaunchKernelGGL(k_multi_dot, dim3(64, j + 1), dim3(256), 0, s, n3, V, n3, w, dh + o2);
       hipLaunchKernelGGL(k_multi_axpy, dim3(gv), dim3(256), 0, s, n3, V, n3, j + 1, dh + o2, -1.0, w);
-      hipLaunchKernelGGL(k_dot, dim3(gv), dim3(256), 0, s, n3, w, w, dh + on);
+      hipLaunchKernelGGL(k_dot, dim3(DOT_BLOCKS), dim3(256), 0, s, n3, w, w, dh + on);
       TSL_TRY(read_h(on + 1));
       total++; st->iters++;
       const double hn = sqrt(std::max(hh[on], 0.0));
@@ -1109,8 +1110,8 @@ static int bicgstab(tsl_ctx* c, tsl_solve_stats* st) {
   CgScal* h = HSC(c);
   auto dots = [&](const double* a1, const double* b1, const double* a2, const double* b2, double* o1, double* o2) -> int {
     HIP_OK(hipMemsetAsync(&d->aux[0], 0, 2 * sizeof(double), s));
-    hipLaunchKernelGGL(k_dot, dim3(gv), dim3(256), 0, s, n3, a1, b1, &d->aux[0]);
-    if (a2) hipLaunchKernelGGL(k_dot, dim3(gv), dim3(256), 0, s, n3, a2, b2, &d->aux[1]);
+    hipLaunchKernelGGL(k_dot, dim3(DOT_BLOCKS), dim3(256), 0, s, n3, a1, b1, &d->aux[0]);
+    if (a2) hipLaunchKernelGGL(k_dot, dim3(DOT_BLOCKS), dim3(256), 0, s, n3, a2, b2, &d->aux[1]);
     HIP_OK(hipMemcpyAsync(&h->aux[0], &d->aux[0], 2 * sizeof(double), hipMemcpyDeviceToHost, s));
     HIP_OK(hipStreamSynchronize(s));
     *o1 = h->aux[0];
