@@ -441,6 +441,62 @@ __global__ void k_absmax(size_t n, const double* __restrict__ a, double* out) {
   s = wave_max(s);
   if ((threadIdx.x & 63) == 0) atomicMax((unsigned long long*)out, (unsigned long long)__double_as_longlong(s));
 }
+// ---- preconditioned MINRES with device-resident recurrence scalars (host reads one record per chunk of iterations)
+struct MrScal {
+  double gamma, gamma_prev, eta, s_prev, s_cur, c_prev, c_cur;  // recurrence state
+  double delta, g2n;                                            // dot-product accumulators of the running iteration
+  double a1, a2, a3, cx;                                        // coefficients of the w / x update
+  double thresh_eta;                                            // stop when |eta| <= thresh_eta
+  int flag, iters;                                              // 0 running, 2 converged, 1 breakdown
+};
+// z /= gamma
+__global__ void k_mr_zscale(size_t n, double* __restrict__ z, const MrScal* __restrict__ sc) {
+  if (sc->flag) return;
+  const double f = 1.0 / sc->gamma;
+  for (size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x) z[i] *= f;
+}
+// v_next -= (delta / gamma) v_cur + (gamma / gamma_prev) v_prev
+__global__ void k_mr_vnext(size_t n, double* __restrict__ v_next, const double* __restrict__ v_cur, const double* __restrict__ v_prev, const MrScal* __restrict__ sc) {
+  if (sc->flag) return;
+  const double a = sc->delta / sc->gamma, b = sc->gamma / sc->gamma_prev;
+  for (size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x) v_next[i] -= a * v_cur[i] + b * v_prev[i];
+}
+// Givens update of the Lanczos tridiagonal (one thread)
+__global__ void k_mr_scal(MrScal* sc) {
+  if (sc->flag) return;
+  const double delta = sc->delta, g2n = sc->g2n, gamma = sc->gamma;
+  sc->delta = 0.0; sc->g2n = 0.0;
+  if (!(g2n >= 0.0) || !isfinite(g2n) || !isfinite(delta)) { sc->flag = 1; return; }
+  const double gamma_next = sqrt(g2n);
+  const double a0 = sc->c_cur * delta - sc->c_prev * sc->s_cur * gamma;
+  const double a1 = sqrt(a0 * a0 + gamma_next * gamma_next);
+  if (!(a1 > 0.0)) { sc->flag = 1; return; }
+  sc->a1 = a1;
+  sc->a2 = sc->s_cur * delta + sc->c_prev * sc->c_cur * gamma;
+  sc->a3 = sc->s_prev * gamma;
+  const double c_next = a0 / a1, s_next = gamma_next / a1;
+  sc->cx = c_next * sc->eta;
+  sc->eta = -s_next * sc->eta;
+  sc->gamma_prev = gamma; sc->gamma = gamma_next;
+  sc->s_prev = sc->s_cur; sc->s_cur = s_next; sc->c_prev = sc->c_cur; sc->c_cur = c_next;
+  sc->iters = sc->iters + 1;
+  // flag 3: the update of this iteration still has to run (k_mr_wx turns it into 2)
+  if (fabs(sc->eta) <= sc->thresh_eta || gamma_next == 0.0) sc->flag = 3;
+}
+// w_next = (z - a3 w_prev - a2 w_cur) / a1 ; x += cx w_next
+__global__ void k_mr_wx(size_t n, const double* __restrict__ z, const double* __restrict__ w_prev, const double* __restrict__ w_cur, double* __restrict__ w_next,
+                        double* __restrict__ x, MrScal* sc) {
+  const int flag = sc->flag;
+  if (flag == 1 || flag == 2) return;
+  const double i1 = 1.0 / sc->a1, a2 = sc->a2, a3 = sc->a3, cx = sc->cx;
+  for (size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x) {
+    const double w = (z[i] - a3 * w_prev[i] - a2 * w_cur[i]) * i1;
+    w_next[i] = w;
+    x[i] += cx * w;
+  }
+}
+__global__ void k_mr_seal(MrScal* sc) { if (sc->flag == 3) sc->flag = 2; }
+
 // out[j] += V_j . w for j < k (V: k vectors of stride ld); grid (chunks, k)
 __global__ void __launch_bounds__(256) k_multi_dot(size_t n, const double* __restrict__ V, size_t ld, const double* __restrict__ w, double* __restrict__ out) {
   const double* v = V + (size_t)blockIdx.y * ld;

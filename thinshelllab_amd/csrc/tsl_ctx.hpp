@@ -89,6 +89,8 @@ struct tsl_ctx {
   // captured PCG iteration chunk
   hipGraphExec_t pcg_graph = nullptr;
   long pcg_graph_key = -1;
+  hipGraphExec_t mr_graph = nullptr;  // six MINRES iterations
+  long mr_graph_key = -1;
   int use_graph = 1;
   int NV = 0, NF = 0;  // tot_NV, tot_NF
   double dt = 5e-3, k_contact = 1000, eps_contact = 1e-3, eps_v = 0.01, damping = 1.0, mu_cloth_elastic = 1.0;

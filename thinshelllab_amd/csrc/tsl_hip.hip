@@ -271,6 +271,7 @@ extern "C" void tsl_ctx_destroy(tsl_ctx* c) {
   (void)hipDeviceSynchronize();
   if (c->h_scal) (void)hipHostFree(c->h_scal);
   if (c->pcg_graph) (void)hipGraphExecDestroy(c->pcg_graph);
+  if (c->mr_graph) (void)hipGraphExecDestroy(c->mr_graph);
   if (c->ev_in) (void)hipEventDestroy(c->ev_in);
   if (c->ev_out) (void)hipEventDestroy(c->ev_out);
   if (c->stream) (void)hipStreamDestroy(c->stream);
@@ -330,6 +331,7 @@ extern "C" int tsl_set_frozen(tsl_ctx* c, const int32_t* fr) {
   c->mg_omega_valid = false;
   TSL_TRY(upload_frozen(c));
   if (c->pcg_graph) { (void)hipGraphExecDestroy(c->pcg_graph); c->pcg_graph = nullptr; }
+  if (c->mr_graph) { (void)hipGraphExecDestroy(c->mr_graph); c->mr_graph = nullptr; }
   return body_dense_setup(c);
 }
 extern "C" int tsl_set_ext_force(tsl_ctx* c, const double* f) {
@@ -865,14 +867,66 @@ static int solve_perm(tsl_ctx* c, tsl_solve_stats* st) {
 // built from the SPD-projected assembly).  Three-term recurrence: one operator product and one preconditioner application
 // per iteration like PCG, no basis to orthogonalise against, and for a symmetric H the iterates are those of un-restarted
 // GMRES.  H is symmetric only up to the reference's area-Hessian quirk, so the recurrence residual is checked against the true
-// residual b - Hx and the recurrence is restarted from it (same rule as the PCG restarts).  st->flag = 1 on success, 3 else.
+// residual b - Hx and the recurrence is restarted from it (same rule as the PCG restarts).  The recurrence scalars live on the
+// device (MrScal) and six iterations (the period of the buffer rotation) are replayed as one hipGraph; the host reads one
+// record per replay.  st->flag = 1 on success, 3 else.
+struct MrBufs { double *V[3], *Z[2], *W[3], *x; };
+
+static MrScal* MSC(tsl_ctx* c) { return (MrScal*)c->scal.p; }
+
+static void launch_minres_iteration(tsl_ctx* c, const MrBufs& B, int j) {
+  hipStream_t s = c->stream;
+  const size_t n3 = 3 * (size_t)c->NV;
+  const int gv = gsz(n3);
+  double *v_prev = B.V[j % 3], *v_cur = B.V[(j + 1) % 3], *v_next = B.V[(j + 2) % 3];
+  double *z_cur = B.Z[j % 2], *z_next = B.Z[(j + 1) % 2];
+  double *w_prev = B.W[j % 3], *w_cur = B.W[(j + 1) % 3], *w_next = B.W[(j + 2) % 3];
+  MrScal* sc = MSC(c);
+  hipLaunchKernelGGL(k_mr_zscale, dim3(gv), dim3(256), 0, s, n3, z_cur, sc);
+  launch_spmv(c, c->vals.p, z_cur, v_next, -1, 0);
+  hipLaunchKernelGGL(k_dot, dim3(DOT_BLOCKS), dim3(256), 0, s, n3, v_next, z_cur, &sc->delta);
+  hipLaunchKernelGGL(k_mr_vnext, dim3(gv), dim3(256), 0, s, n3, v_next, v_cur, v_prev, sc);
+  if (mg_active(c)) mg_vcycle(c, v_next, z_next, c->part_rz.p);
+  else {
+    hipLaunchKernelGGL(k_precond, dim3(nblk(c->NV, 256)), dim3(256), 0, s, c->NV, c->Dinv.p, v_next, z_next);
+    if (body_active(c) && c->bd_valid) body_apply(c, 0, v_next, nullptr, z_next, nullptr, nullptr);
+  }
+  hipLaunchKernelGGL(k_dot, dim3(DOT_BLOCKS), dim3(256), 0, s, n3, z_next, v_next, &sc->g2n);
+  hipLaunchKernelGGL(k_mr_scal, dim3(1), dim3(1), 0, s, sc);
+  hipLaunchKernelGGL(k_mr_wx, dim3(gv), dim3(256), 0, s, n3, z_cur, w_prev, w_cur, w_next, B.x, sc);
+  hipLaunchKernelGGL(k_mr_seal, dim3(1), dim3(1), 0, s, sc);
+}
+
+static long solver_graph_key(tsl_ctx* c) {
+  return ((long)(mg_active(c) ? 1 : 0) << 40) | ((long)c->nc << 8) | ((long)(c->prof_enable ? 1 : 0) << 7) | ((long)c->mg_nu << 44) | ((long)c->mg_coarse_sweeps << 48) |
+         ((long)(c->pc_separate ? 1 : 0) << 41) | ((long)((body_active(c) && c->bd_valid) ? 1 : 0) << 42) | ((long)(c->mg_fuse ? 1 : 0) << 43) | ((long)c->mg_max_levels << 52);
+}
+
+static int minres_graph(tsl_ctx* c, const MrBufs& B) {
+  const long key = solver_graph_key(c);
+  if (c->mr_graph && c->mr_graph_key == key) return 0;
+  if (c->mr_graph) { (void)hipGraphExecDestroy(c->mr_graph); c->mr_graph = nullptr; }
+  hipGraph_t g = nullptr;
+  HIP_OK(hipStreamBeginCapture(c->stream, hipStreamCaptureModeThreadLocal));
+  for (int j = 0; j < 6; j++) launch_minres_iteration(c, B, j);
+  HIP_OK(hipStreamEndCapture(c->stream, &g));
+  HIP_OK(hipGraphInstantiate(&c->mr_graph, g, nullptr, nullptr, 0));
+  (void)hipGraphDestroy(g);
+  c->mr_graph_key = key;
+  return 0;
+}
+
 static int minres(tsl_ctx* c, tsl_solve_stats* st) {
   hipStream_t s = c->stream;
   const int NV = c->NV;
   const size_t n3 = 3 * (size_t)NV;
   const int gb = nblk(NV, 256), gv = gsz(n3);
-  double *x = c->v_x.p, *v_prev = c->v_t0.p, *v_cur = c->v_r.p, *v_next = c->v_Ap.p, *z_cur = c->v_z.p, *z_next = c->v_t1.p, *w_prev = c->v_t2.p, *w_cur = c->v_t3.p,
-         *w_next = c->v_p.p;
+  MrBufs B;
+  B.V[0] = c->v_t0.p; B.V[1] = c->v_r.p; B.V[2] = c->v_Ap.p;
+  B.Z[0] = c->v_z.p; B.Z[1] = c->v_t1.p;
+  B.W[0] = c->v_t2.p; B.W[1] = c->v_t3.p; B.W[2] = c->v_p.p;
+  B.x = c->v_x.p;
+  double* x = B.x;
   const bool mg = mg_active(c);
   if (body_active(c) && !c->bd_valid) TSL_TRY(body_build_inverse(c));
   if (mg && !c->mg_ops_valid) TSL_TRY(mg_setup_operators(c));
@@ -883,16 +937,16 @@ static int minres(tsl_ctx* c, tsl_solve_stats* st) {
       if (body_active(c) && c->bd_valid) body_apply(c, 0, in, nullptr, out, nullptr, nullptr);
     }
   };
-  CgScal* d = SC(c);
-  CgScal* h = HSC(c);
+  MrScal* d = MSC(c);
+  MrScal* h = (MrScal*)c->h_scal;
   auto dot2 = [&](const double* a1, const double* b1, const double* a2, const double* b2, double* o1, double* o2) -> int {
-    HIP_OK(hipMemsetAsync(&d->aux[0], 0, 2 * sizeof(double), s));
-    hipLaunchKernelGGL(k_dot, dim3(DOT_BLOCKS), dim3(256), 0, s, n3, a1, b1, &d->aux[0]);
-    if (a2) hipLaunchKernelGGL(k_dot, dim3(DOT_BLOCKS), dim3(256), 0, s, n3, a2, b2, &d->aux[1]);
-    HIP_OK(hipMemcpyAsync(&h->aux[0], &d->aux[0], 2 * sizeof(double), hipMemcpyDeviceToHost, s));
+    HIP_OK(hipMemsetAsync(&d->delta, 0, 2 * sizeof(double), s));
+    hipLaunchKernelGGL(k_dot, dim3(DOT_BLOCKS), dim3(256), 0, s, n3, a1, b1, &d->delta);
+    if (a2) hipLaunchKernelGGL(k_dot, dim3(DOT_BLOCKS), dim3(256), 0, s, n3, a2, b2, &d->g2n);
+    HIP_OK(hipMemcpyAsync(&h->delta, &d->delta, 2 * sizeof(double), hipMemcpyDeviceToHost, s));
     HIP_OK(hipStreamSynchronize(s));
-    *o1 = h->aux[0];
-    if (o2) *o2 = h->aux[1];
+    *o1 = h->delta;
+    if (o2) *o2 = h->g2n;
     return 0;
   };
   double bb;
@@ -901,14 +955,15 @@ static int minres(tsl_ctx* c, tsl_solve_stats* st) {
   if (!(bb > 0)) { st->flag = 1; return 0; }
   const double tol = c->cg_tol * sqrt(bb);
   HIP_OK(hipMemsetAsync(x, 0, n3 * sizeof(double), s));
-  HIP_OK(hipMemcpyAsync(v_cur, c->v_b.p, n3 * sizeof(double), hipMemcpyDeviceToDevice, s));
+  HIP_OK(hipMemcpyAsync(B.V[1], c->v_b.p, n3 * sizeof(double), hipMemcpyDeviceToDevice, s));
+  const bool graph = c->use_graph != 0;
   double true_prev = 1e300;
   int total = 0;
   for (int cycle = 0; cycle < 40 && total < c->cg_maxit; cycle++) {
-    // (re)start from the true residual held in v_cur
+    // (re)start from the true residual held in V[1]
     double rr, g2;
-    precond(v_cur, z_cur);
-    TSL_TRY(dot2(v_cur, v_cur, z_cur, v_cur, &rr, &g2));
+    precond(B.V[1], B.Z[0]);
+    TSL_TRY(dot2(B.V[1], B.V[1], B.Z[0], B.V[1], &rr, &g2));
     const double rnorm0 = sqrt(rr);
     st->rel_residual = rnorm0 / sqrt(bb);
     if (rnorm0 <= tol) { st->flag = 1; break; }
@@ -917,55 +972,34 @@ static int minres(tsl_ctx* c, tsl_solve_stats* st) {
     true_prev = rnorm0;
     if (!(g2 > 0) || !std::isfinite(g2)) break;  // preconditioner not positive definite
     if (cycle > 0) st->restarts++;
-    double gamma = sqrt(g2), gamma_prev = 1.0, eta = gamma, s_prev = 0, s_cur = 0, c_prev = 1, c_cur = 1;
-    const double eta0 = eta;
-    HIP_OK(hipMemsetAsync(v_prev, 0, n3 * sizeof(double), s));
-    HIP_OK(hipMemsetAsync(w_prev, 0, n3 * sizeof(double), s));
-    HIP_OK(hipMemsetAsync(w_cur, 0, n3 * sizeof(double), s));
-    bool ok = true;
-    for (int j = 0; total < c->cg_maxit; j++) {
-      // z_j /= gamma_j ; v_next = A z_j ; delta = <A z_j, z_j>
-      hipLaunchKernelGGL(k_axpby, dim3(gv), dim3(256), 0, s, n3, 1.0 / gamma, z_cur, 0.0, z_cur);
-      launch_spmv(c, c->vals.p, z_cur, v_next, -1, 0);
-      double delta;
-      TSL_TRY(dot2(v_next, z_cur, nullptr, nullptr, &delta, nullptr));
-      // v_next -= (delta / gamma) v_cur + (gamma / gamma_prev) v_prev
-      hipLaunchKernelGGL(k_axpby, dim3(gv), dim3(256), 0, s, n3, -delta / gamma, v_cur, 1.0, v_next);
-      if (j > 0) hipLaunchKernelGGL(k_axpby, dim3(gv), dim3(256), 0, s, n3, -gamma / gamma_prev, v_prev, 1.0, v_next);
-      precond(v_next, z_next);
-      double g2n;
-      TSL_TRY(dot2(z_next, v_next, nullptr, nullptr, &g2n, nullptr));
-      total++; st->iters++;
-      if (!(g2n >= 0) || !std::isfinite(g2n) || !std::isfinite(delta)) { ok = false; break; }
-      const double gamma_next = sqrt(g2n);
-      const double a0 = c_cur * delta - c_prev * s_cur * gamma;
-      const double a1 = sqrt(a0 * a0 + gamma_next * gamma_next);
-      const double a2 = s_cur * delta + c_prev * c_cur * gamma;
-      const double a3 = s_prev * gamma;
-      if (!(a1 > 0)) { ok = false; break; }
-      const double c_next = a0 / a1, s_next = gamma_next / a1;
-      // w_next = (z_j - a3 w_prev - a2 w_cur) / a1 ; x += c_next eta w_next
-      hipLaunchKernelGGL(k_axpby, dim3(gv), dim3(256), 0, s, n3, 1.0 / a1, z_cur, 0.0, w_next);
-      hipLaunchKernelGGL(k_axpby, dim3(gv), dim3(256), 0, s, n3, -a3 / a1, w_prev, 1.0, w_next);
-      hipLaunchKernelGGL(k_axpby, dim3(gv), dim3(256), 0, s, n3, -a2 / a1, w_cur, 1.0, w_next);
-      hipLaunchKernelGGL(k_axpby, dim3(gv), dim3(256), 0, s, n3, c_next * eta, w_next, 1.0, x);
-      eta = -s_next * eta;
-      // rotate the buffers
-      { double* t0 = v_prev; v_prev = v_cur; v_cur = v_next; v_next = t0; }
-      { double* t0 = z_cur; z_cur = z_next; z_next = t0; }
-      { double* t0 = w_prev; w_prev = w_cur; w_cur = w_next; w_next = t0; }
-      gamma_prev = gamma; gamma = gamma_next;
-      s_prev = s_cur; s_cur = s_next; c_prev = c_cur; c_cur = c_next;
-      // |eta| is the residual in the M^-1 norm; scale the test by the start of the cycle
-      if (fabs(eta) <= 0.3 * (tol / rnorm0) * eta0 || gamma_next == 0.0) break;
+    MrScal hs;
+    memset(&hs, 0, sizeof(hs));
+    hs.gamma = sqrt(g2); hs.gamma_prev = 1.0; hs.eta = hs.gamma; hs.c_prev = 1.0; hs.c_cur = 1.0;
+    hs.thresh_eta = 0.3 * (tol / rnorm0) * hs.gamma;  // |eta| is the residual in the M^-1 norm, scaled by the start of the cycle
+    HIP_OK(hipMemcpyAsync(d, &hs, sizeof(MrScal), hipMemcpyHostToDevice, s));
+    HIP_OK(hipMemsetAsync(B.V[0], 0, n3 * sizeof(double), s));
+    HIP_OK(hipMemsetAsync(B.W[0], 0, n3 * sizeof(double), s));
+    HIP_OK(hipMemsetAsync(B.W[1], 0, n3 * sizeof(double), s));
+    if (graph) TSL_TRY(minres_graph(c, B));
+    int flag = 0;
+    const int base = total;
+    while (total < c->cg_maxit) {
+      if (graph) HIP_OK(hipGraphLaunch(c->mr_graph, s));
+      else for (int j = 0; j < 6; j++) launch_minres_iteration(c, B, j);
+      HIP_OK(hipMemcpyAsync(h, d, sizeof(MrScal), hipMemcpyDeviceToHost, s));
+      HIP_OK(hipStreamSynchronize(s));
+      flag = h->flag;
+      total = base + h->iters;
+      if (flag) break;
     }
-    // true residual into v_cur
-    launch_spmv(c, c->vals.p, x, v_next, -1, 0);
-    HIP_OK(hipMemcpyAsync(v_cur, c->v_b.p, n3 * sizeof(double), hipMemcpyDeviceToDevice, s));
-    hipLaunchKernelGGL(k_axpby, dim3(gv), dim3(256), 0, s, n3, -1.0, v_next, 1.0, v_cur);
-    if (!ok) {
+    st->iters += h->iters;
+    // true residual into V[1]
+    launch_spmv(c, c->vals.p, x, B.V[2], -1, 0);
+    HIP_OK(hipMemcpyAsync(B.V[1], c->v_b.p, n3 * sizeof(double), hipMemcpyDeviceToDevice, s));
+    hipLaunchKernelGGL(k_axpby, dim3(gv), dim3(256), 0, s, n3, -1.0, B.V[2], 1.0, B.V[1]);
+    if (flag != 2) {  // breakdown or iteration cap
       double tr;
-      TSL_TRY(dot2(v_cur, v_cur, nullptr, nullptr, &tr, nullptr));
+      TSL_TRY(dot2(B.V[1], B.V[1], nullptr, nullptr, &tr, nullptr));
       st->rel_residual = sqrt(tr / bb);
       if (sqrt(tr) <= tol) st->flag = 1;
       break;
