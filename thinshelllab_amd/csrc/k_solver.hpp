@@ -313,7 +313,8 @@ __global__ void __launch_bounds__(256) k_pcg_check(const double* __restrict__ pa
 __global__ void __launch_bounds__(256)
 k_pcg_update(int NV, const double* __restrict__ pv, const double* __restrict__ Ap, const double* __restrict__ Dinv, double* __restrict__ x,
              double* __restrict__ r, double* __restrict__ z, const double* __restrict__ part_pAp, double* __restrict__ part_rz, double* __restrict__ part_rr,
-             PcgScal* sc, int parity, const double* __restrict__ b_init, const double* __restrict__ Ax_init, int use_dinv) {
+             PcgScal* sc, int parity, const double* __restrict__ b_init, const double* __restrict__ Ax_init, int use_dinv,
+             const double* __restrict__ omega_dev = nullptr) {
   __shared__ double sm[8];
   double alpha = 0;
   if (!b_init) {
@@ -344,7 +345,8 @@ k_pcg_update(int NV, const double* __restrict__ pv, const double* __restrict__ A
       m3 D;
 #pragma unroll
       for (int e = 0; e < 9; e++) D.m[e] = Dinv[9 * (size_t)p + e];
-      const d3 zv = m3_mulv(D, rv);
+      // use_dinv 2: z = omega Dinv r is the first smoothing sweep of the multigrid cycle that follows (it owns r.z)
+      const d3 zv = (use_dinv == 2 ? *omega_dev : 1.0) * m3_mulv(D, rv);
       st3(z, p, zv);
       rzn = dot(rv, zv);
     }
@@ -355,7 +357,7 @@ k_pcg_update(int NV, const double* __restrict__ pv, const double* __restrict__ A
   if (lane == 0) { s1[w] = rzn; s2[w] = rr; }
   __syncthreads();
   if (threadIdx.x == 0) {
-    if (use_dinv) part_rz[blockIdx.x] = s1[0] + s1[1] + s1[2] + s1[3];  // otherwise the preconditioner's last kernel writes r.z
+    if (use_dinv == 1) part_rz[blockIdx.x] = s1[0] + s1[1] + s1[2] + s1[3];  // otherwise the preconditioner's last kernel writes r.z
     part_rr[blockIdx.x] = s2[0] + s2[1] + s2[2] + s2[3];
   }
 }

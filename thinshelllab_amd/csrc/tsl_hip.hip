@@ -683,13 +683,13 @@ static double* mg_stencil_cycle(tsl_ctx* c, MgCloth* mc, size_t l) {
 }
 
 // z = M^-1 r (one V(nu,nu) cycle); part_rz receives the per-block partials of r.z
-static void mg_vcycle(tsl_ctx* c, const double* r, double* z, double* part_rz) {
+static void mg_vcycle(tsl_ctx* c, const double* r, double* z, double* part_rz, bool first_sweep_done = false) {
   hipStream_t s = c->stream;
   const int NV = c->NV, gb = nblk(NV, 256);
   const double* om = c->mg_omega0.p;
   double* t = c->v_mg.p;
   const bool bd = body_active(c) && c->bd_valid;
-  hipLaunchKernelGGL(k_mg_jacobi_first, dim3(gb), dim3(256), 0, s, NV, c->Dinv.p, r, om, z);
+  if (!first_sweep_done) hipLaunchKernelGGL(k_mg_jacobi_first, dim3(gb), dim3(256), 0, s, NV, c->Dinv.p, r, om, z);
   if (bd) body_apply(c, 0, r, nullptr, z, nullptr, nullptr);
   for (int k = 0; k < c->mg_nu - 1; k++) {
     mg_spmv0(c, z, t);
@@ -729,8 +729,8 @@ static void launch_pcg_iteration(tsl_ctx* c, int parity, int first, unsigned lon
                        &PSC(c)->flag);
   const bool mg = mg_active(c);
   hipLaunchKernelGGL(k_pcg_update, dim3(nblk(NV, 256)), dim3(256), 0, s, NV, p_new, c->v_Ap.p, c->Dinv.p, c->v_x.p, c->v_r.p, c->v_z.p, c->part_pAp.p, c->part_rz.p, c->part_rr.p,
-                     PSC(c), parity, (const double*)nullptr, (const double*)nullptr, mg ? 0 : 1);
-  if (mg) mg_vcycle(c, c->v_r.p, c->v_z.p, c->part_rz.p);
+                     PSC(c), parity, (const double*)nullptr, (const double*)nullptr, mg ? 2 : 1, c->mg_omega0.p);
+  if (mg) mg_vcycle(c, c->v_r.p, c->v_z.p, c->part_rz.p, true);
   else if (body_active(c) && c->bd_valid) body_apply(c, 0, c->v_r.p, nullptr, c->v_z.p, c->v_r.p, c->part_rz.p + nblk(NV, 256));
 }
 
