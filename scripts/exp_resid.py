@@ -32,3 +32,23 @@ for tol in (1e-2, 1e-4, 1e-6, 1e-8):
     rn = np.linalg.norm(r, axis=1)
     tot = np.linalg.norm(rn)
     print(f"tol {tol:g}: iters {st['iters']} |r|/|b| {tot/np.linalg.norm(bn):.2e} share by group:", " ".join(f"{g}:{np.linalg.norm(rn[grp==g])/tot:.2f}" for g in range(2 + len(s.elastics))), flush=True)
+import time
+ctx.set_param("cg_tol", 1e-10)
+for kv in os.environ.get("TSL_PARAMS", "").split(","):
+    if "=" in kv:
+        ctx.set_param(kv.split("=")[0], float(kv.split("=")[1]))
+s.compute_residual_and_Hessian(spd=True)
+x, st = ctx.solve(b)
+for rep in range(3):
+    torch.cuda.synchronize(); t0 = time.time()
+    x, st = ctx.solve(b)
+    torch.cuda.synchronize(); dt = time.time() - t0
+    print(f"solve: {dt*1e3:.2f} ms, {st['iters']} iterations, {dt*1e6/st['iters']:.1f} us per iteration", flush=True)
+torch.cuda.synchronize(); t0 = time.time()
+for rep in range(5):
+    s.compute_residual_and_Hessian(spd=True)
+torch.cuda.synchronize(); print(f"assemble: {(time.time()-t0)/5*1e3:.2f} ms", flush=True)
+torch.cuda.synchronize(); t0 = time.time()
+for rep in range(5):
+    s.compute_energy()
+torch.cuda.synchronize(); print(f"energy: {(time.time()-t0)/5*1e3:.2f} ms", flush=True)

@@ -27,6 +27,14 @@ int tsl_fail(const char* fmt, ...) {
 
 #define TSL_TRY(x) do { if ((x) != 0) return -1; } while (0)
 
+#ifndef PCG_WPS
+#define PCG_WPS 4
+#endif
+// matrix values: plain (temporal) loads -- the three operator products of a multigrid-PCG iteration re-read the same 41 MB,
+// which stay in the 256 MB Infinity Cache; nontemporal loads were 2 % slower here (they won for the one-product block-Jacobi loop)
+#ifndef TSL_NT
+#define TSL_NT false
+#endif
 #define DOT_BLOCKS 120  // one f64 atomic per wave into a single address: more blocks only add contention (30 us at 600 blocks)
 static inline int nblk(long n, int b) { return (int)((n + b - 1) / b); }
 static inline int gsz(size_t n) { size_t b = (n + 255) / 256; return (int)std::min<size_t>(std::max<size_t>(b, 1), 4096); }
@@ -578,7 +586,7 @@ static void mg_spmv0(tsl_ctx* c, const double* x, double* y) {
   hipStream_t s = c->stream;
   const double* vals = c->pc_separate ? c->vals_pc.p : c->vals.p;
   const double* cH = c->pc_separate ? c->c_H_pc.p : c->c_H.p;
-  hipLaunchKernelGGL((k_spmv_mw<4, 1, true>), dim3(c->n_slices), dim3(256), 0, s, c->NV, c->n_slices, c->slice_off.p, c->slice_len.p, c->colidx.p, vals, x, y,
+  hipLaunchKernelGGL((k_spmv_mw<4, 1, TSL_NT>), dim3(c->n_slices), dim3(256), 0, s, c->NV, c->n_slices, c->slice_off.p, c->slice_len.p, c->colidx.p, vals, x, y,
                      (double*)nullptr, (const int*)nullptr);
   if (c->nc > 0) hipLaunchKernelGGL(k_contact_matvec, dim3(nblk(c->nc, 64)), dim3(CONTACT_MV_THREADS), 0, s, c->nc, c->c_idx.p, c->rowpos.p, cH, x, y, SC(c), -1, 0);
 }
@@ -711,7 +719,7 @@ static void mg_vcycle(tsl_ctx* c, const double* r, double* z, double* part_rz, b
   }
 }
 
-#define PCG_WPS 4
+
 static PcgScal* PSC(tsl_ctx* c) { return (PcgScal*)c->scal.p; }
 static PcgScal* HPSC(tsl_ctx* c) { return (PcgScal*)c->h_scal; }
 
@@ -722,7 +730,7 @@ static void launch_pcg_iteration(tsl_ctx* c, int parity, int first, unsigned lon
   const int NV = c->NV, ns = c->n_slices;
   double* p_new = parity ? c->v_t0.p : c->v_p.p;
   const double* p_old = parity ? c->v_p.p : c->v_t0.p;
-  hipLaunchKernelGGL((k_pcg_spmv<PCG_WPS, true>), dim3(ns), dim3(64 * PCG_WPS), 0, s, NV, ns, c->slice_off.p, c->slice_len.p, c->colidx.p, c->vals.p, c->v_z.p, p_old, p_new,
+  hipLaunchKernelGGL((k_pcg_spmv<PCG_WPS, TSL_NT>), dim3(ns), dim3(64 * PCG_WPS), 0, s, NV, ns, c->slice_off.p, c->slice_len.p, c->colidx.p, c->vals.p, c->v_z.p, p_old, p_new,
                      c->v_Ap.p, c->part_rz.p, c->part_rr.p, c->part_pAp.p, PSC(c), parity, first, dprof);
   if (c->nc > 0)
     hipLaunchKernelGGL(k_contact_matvec_part, dim3(nblk(c->nc, 64)), dim3(CONTACT_MV_THREADS), 0, s, c->nc, c->c_idx.p, c->rowpos.p, c->c_H.p, p_new, c->v_Ap.p, c->part_pAp.p + ns,
