@@ -5,13 +5,16 @@ import numpy as np, torch
 from thinshelllab_amd.task_scene.Scene_balancing import Scene
 from thinshelllab_amd.engine.geometry import projection_query
 N = int(sys.argv[1]) if len(sys.argv) > 1 else 224
-gs = N * 0.004 / 0.06
-s = Scene(cloth_size=N * 0.004, cloth_N=N, cloth_M=N, geom_scale=gs)
+lit = len(sys.argv) > 2 and sys.argv[2] == "literal"
+gs = 1.0 if lit else N * 0.004 / 0.06
+s = Scene(cloth_size=0.12 * N / 224 if lit else N * 0.004, cloth_N=N, cloth_M=N, geom_scale=gs)
 s.init_all(); s.mu_cloth_elastic[None] = 5.0; s.prev_pos.copy_from(s.pos)
 ctx = s._ensure_ctx()
 n_part = s.gripper.n_part
 dpos = np.zeros((n_part, 3)); drot = np.zeros((n_part, 3)); dpos[:, 2] = 5e-5 * gs; drot[:, 1] = 2e-3
-for f in range(1, 4):
+if lit:
+    drot[:] = 0; dpos[:, 2] = 1e-4 * np.where(np.arange(n_part) % 2 == 0, 1.0, -1.0)
+for f in range(1, int(os.environ.get('STEPS', '3')) + 1):
     s.action(f, dpos, drot); st = s.time_step(projection_query, f)
     print(f, st["nc"], st["newton_iters"], st["cg_iters"], flush=True)
 projection_query(s)
