@@ -96,7 +96,9 @@ int tsl_set_stream(tsl_ctx* ctx, void* hip_stream);
  * "newton_cap", "plastic", "contact" (trajopt_folding.py:50,66; Scene_folding.py:30-31), the broad-phase box
  * "grid_h", "grid_extent" (geometry.py:8-19), and the solver knobs that have no reference counterpart (the reference
  * calls a direct solver): "cg_tol", "cg_maxit", "cg_check", "mg" (-1 auto / 0 / 1), "mg_nu", "mg_coarse_sweeps",
- * "mg_omega", "mg_pi_iters", "body_inv" (-1 auto / 0 / 1), "adj_spd_pc", "gmres", "gmres_m", "graph". */
+ * "mg_omega", "mg_pi_iters", "mg_fuse", "mg_max_levels", "body_inv" (-1 auto / 0 / 1), "adj_spd_pc", "minres", "gmres",
+ * "gmres_m", "graph"; "adj_clamp", "adj_clamp_angleref" select the clamping of analytic_grad_single (1000, on) or
+ * analytic_grad_system (1, off). */
 int tsl_set_param(tsl_ctx* ctx, const char* key, double value);
 int tsl_set_frozen(tsl_ctx* ctx, const int32_t* frozen_host);          /* BaseScene.set_frozen */
 int tsl_set_ext_force(tsl_ctx* ctx, const double* ext_force_host);      /* BaseScene.ext_force / manipulate_force */
@@ -133,6 +135,15 @@ int tsl_update_ref_angle(tsl_ctx* ctx, const double* pos_dev, double* ref_angle_
 int tsl_adjoint_step(tsl_ctx* ctx, int step, int tot_timestep, const double* pos_buffer_dev, double* pos_grad_dev,
                      const double* ref_angle_buffer_dev, double* angleref_grad_dev, double* tmp_z_frozen_dev,
                      double adjoint_damping, tsl_solve_stats* stats_host);
+
+/* System identification (engine/analytic_grad_system.py:112-160): the reverse step is tsl_adjoint_step with
+ * tsl_set_param "adj_clamp" = 1 and "adj_clamp_angleref" = 0 (that class clamps pos_grad to +-1 and nothing else, :104-109);
+ * this call then returns the sums over the free dofs of p . d(force)/d(parameter) with p the solution of that step
+ * (get_parameters_grad :69-80 with BaseScene.get_paramters_grad BaseScene.py:1513-1525, Cloth.compute_deri
+ * model_fold_offset.py:1082-1127, Elastic.compute_deri model_elastic_tactile.py:329-347 / model_elastic_offset.py:415-431).
+ * pos = tape state x_s, ref_angle = tape rest angles of step s-1 (copy_pos_and_refangle, BaseScene.py:284-292).
+ * out_host = {grad_kb, grad_mu, grad_lam} contributions of this step (grad_lam is 0: the reference never pushes d_lam up). */
+int tsl_param_grad(tsl_ctx* ctx, const double* pos_dev, const double* ref_angle_dev, double* out_host);
 
 /* Introspection used by the parity tests (tests/ only): assembled matrix as BSR on the host. */
 int tsl_matrix_nnzb(tsl_ctx* ctx, int32_t* nb_host, int32_t* nnzb_host);

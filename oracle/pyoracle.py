@@ -268,6 +268,18 @@ class OracleScene:
     def grad_transfer(self, step):
         self.L.tslo_grad_transfer(self.h, int(step))
 
+    def grad_system(self, system_mode=True, count_kb=True, count_mu_lam=False):
+        """switch the reverse step to analytic_grad_system.Grad semantics (pos_grad clamp +-1, parameter gradients)"""
+        self.L.tslo_grad_system(self.h, int(system_mode), int(count_kb), int(count_mu_lam))
+
+    def grad_params(self, reset=False):
+        out = np.zeros(3)
+        self.L.tslo_grad_params(self.h, _dp(out), int(reset))
+        return dict(kb=out[0], mu=out[1], lam=out[2])
+
+    def get_paramters_grad(self):
+        self.L.tslo_get_paramters_grad(self.h)
+
 
 def set_threads(n):
     lib().tslo_set_threads(int(n))

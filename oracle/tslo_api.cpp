@@ -51,6 +51,12 @@ void tslo_set_scalar(void* h, const char* name, double v) {
     std::string f = n.substr(7);
     Cloth& c = s.cloths[ci];
     if (f == "Kb") c.Kb = v; else if (f == "Kl") c.Kl = v; else if (f == "Ka") c.Ka = v; else if (f == "k_angle") c.k_angle = v;
+  } else if (n.rfind("elastic", 0) == 0) {
+    int ei = n[7] - '0';
+    std::string f = n.substr(9);
+    Elastic& e = s.elastics[ei];
+    if (f == "mu") e.mu = v; else if (f == "lam") e.lam = v;
+    if (e.kind == 0) e.alpha = 1 + e.mu / e.lam;  // model_elastic_tactile.py:20-23
   }
 }
 
@@ -142,6 +148,13 @@ void tslo_grad_new(void* h, int T, int n_parts) { G(h).construct(S(h), T, n_part
 void tslo_grad_reset(void* h) { G(h).reset(); }
 void tslo_grad_copy_pos(void* h, int step) { G(h).copy_pos(S(h), step); }
 void tslo_grad_transfer(void* h, int step) { G(h).transfer_grad(step, S(h)); }
+// analytic_grad_system.Grad: mode switch, flags, accumulated parameter gradients (kb, mu, lam)
+void tslo_grad_system(void* h, int system_mode, int count_kb, int count_mu_lam) { G(h).system_mode = system_mode; G(h).count_kb_grad = count_kb; G(h).count_mu_lam_grad = count_mu_lam; }
+void tslo_grad_params(void* h, double* out, int reset) {
+  out[0] = G(h).grad_kb; out[1] = G(h).grad_mu; out[2] = G(h).grad_lam;
+  if (reset) { G(h).grad_kb = 0; G(h).grad_mu = 0; G(h).grad_lam = 0; }
+}
+void tslo_get_paramters_grad(void* h) { S(h).get_paramters_grad(); }
 
 // stats: [newton, cg, ls, solves, refine, last_solve_flag, H.missing]
 void tslo_stats(void* h, long* out, int reset) {
@@ -183,6 +196,10 @@ void* tslo_array(void* h, const char* name, long* count, int* type) {
   if (n == "x1") RET_V3(s.x1);
   if (n == "vn") RET_V3(s.vn);
   if (n == "ext_force") RET_V3(s.ext_force);
+  if (n == "d_ka") RET_V3(s.d_ka);
+  if (n == "d_kl") RET_V3(s.d_kl);
+  if (n == "d_kb") RET_V3(s.d_kb);
+  if (n == "d_mu") RET_V3(s.d_mu);
   if (n == "mass") RET_D(s.mass);
   if (n == "F") RET_D(s.F);
   if (n == "frozen") RET_I(s.frozen, 1);

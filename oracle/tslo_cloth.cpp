@@ -385,6 +385,40 @@ void Cloth::compute_residual() {
   }
 }
 
+// model_fold_offset.py:1082-1127: elastic force per unit stiffness, d_k* = -(d E_* / d x) / K_*
+void Cloth::compute_deri() {
+  d_ka.assign(NV, V3()); d_kl.assign(NV, V3()); d_kb.assign(NV, V3());
+  for (int i = 0; i < NF; i++) {
+    V3 a = pos[f2v[i][0]], b = pos[f2v[i][1]], c = pos[f2v[i][2]];
+    for (int l = 0; l < 3; l++) {
+      int xx = f2v[i][l], yy = f2v[i][(l + 1) % 3];
+      double base_len = l_i[i][l];
+      V3 delta = pos[xx] - pos[yy];
+      double l_tau = norm(delta);
+      d_kl[xx] += -delta * compute_membrane_dl(l_tau, base_len) / l_tau;
+      d_kl[yy] += delta * compute_membrane_dl(l_tau, base_len) / l_tau;
+    }
+    double base_area = V[i];
+    double area = 0.5 * norm(cross(b - a, c - a));
+    for (int l = 0; l < 3; l++)
+      for (int j = 0; j < 3; j++)
+        d_ka[f2v[i][l]].v[j] -= compute_membrane_darea(area, base_area) *
+                                 compute_area_dx(area, pos[f2v[i][l]], pos[f2v[i][(l + 1) % 3]], pos[f2v[i][(l + 2) % 3]], j);
+    for (int l = 0; l < 3; l++)
+      if (counter_face[i][l] > i) {
+        V3 ga, gb, gc, gd;
+        compute_bending_grad(i, l, ga, gb, gc, gd);
+        double theta = compute_angle(i, counter_face[i][l], l);
+        double d_theta = compute_bending_dtheta_ref(theta, ref_angle[i][l]);
+        d_kb[f2v[i][l]] -= d_theta * ga;
+        d_kb[f2v[i][(l + 1) % 3]] -= d_theta * gb;
+        d_kb[f2v[i][(l + 2) % 3]] -= d_theta * gc;
+        d_kb[f2v[counter_face[i][l]][counter_point[i][l]]] -= d_theta * gd;
+      }
+  }
+  for (int i = 0; i < NV; i++) { d_ka[i] = d_ka[i] / Ka; d_kl[i] = d_kl[i] / Kl; d_kb[i] = d_kb[i] / Kb; }
+}
+
 // model_fold_offset.py:466-524
 void Cloth::compute_Hessian_me(Scene& H, int spd) {
 #pragma omp parallel for schedule(static)

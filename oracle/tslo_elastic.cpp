@@ -248,6 +248,38 @@ void Elastic::get_force() {
   }
 }
 
+// model_elastic_tactile.py:329-347 (clears the fields, P1 = mu (F - J F^-T), P2 = lam (J - 1) J F^-T) and
+// model_elastic_offset.py:415-431 (clears F_f instead of d_mu / d_lam, so they accumulate over the calls; lam = 0 there
+// makes d_lam 0/0)
+void Elastic::compute_deri() {
+  if (d_mu.size() != (size_t)n_verts) { d_mu.assign(n_verts, V3()); d_lam.assign(n_verts, V3()); }
+  if (kind == 0) { d_mu.assign(n_verts, V3()); d_lam.assign(n_verts, V3()); }
+  else for (int i = 0; i < n_verts; i++) F_f[i] = V3();
+  for (int c = 0; c < n_cells; c++) {
+    const I4& verts = F_vertices[c];
+    M3 F = Ds(verts) * F_B[c];
+    M3 F_T = transpose(inverse(F));
+    M3 P1, P2;
+    if (kind == 0) {
+      double J = det(F);
+      P1 = mu * (F - J * F_T);
+      P2 = lam * (J - 1) * J * F_T;
+    } else {
+      double J = std::max(det(F), 0.01);
+      P1 = mu * (F - F_T);
+      P2 = lam * std::log(J) * F_T;
+    }
+    M3 H1 = -F_W[c] * (P1 * transpose(F_B[c]));
+    M3 H2 = -F_W[c] * (P2 * transpose(F_B[c]));
+    for (int i = 0; i < 3; i++) {
+      V3 f1(H1[0][i], H1[1][i], H1[2][i]);
+      d_mu[verts[i]] += f1 / mu; d_mu[verts[3]] -= f1 / mu;
+      V3 f2(H2[0][i], H2[1][i], H2[2][i]);
+      d_lam[verts[i]] += f2 / lam; d_lam[verts[3]] -= f2 / lam;
+    }
+  }
+}
+
 // model_elastic_tactile.py:166-169 / model_elastic_offset.py:210-213
 void Elastic::compute_residual() {
   for (int i = 0; i < n_verts; i++) F_b[i] = F_m[i] * (F_x[i] - F_x_prev[i] - F_v[i] * dt) / (dt * dt) - F_f[i];

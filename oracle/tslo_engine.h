@@ -60,6 +60,9 @@ struct Cloth {
   void compute_Hessian_bending(Scene& H);
   void ref_angle_backprop_x2a(Grad& g, int step, const double* p, int cnt);
   void ref_angle_backprop_a2ax(Grad& g, int step, int cnt);
+  // model_fold_offset.py:1082-1127: force per unit stiffness (system identification)
+  std::vector<V3> d_ka, d_kl, d_kb;
+  void compute_deri();
 
   // scalar helpers model_fold_offset.py:260-377
   double compute_membrane_dl(double l_tau, double l_base) const { return -Kl * 2.0 * (1.0 - l_tau / l_base); }
@@ -100,6 +103,9 @@ struct Elastic {
   void get_force();
   void compute_residual();
   void compute_Hessian(Scene& A, int spd);
+  // model_elastic_tactile.py:329-347 / model_elastic_offset.py:415-431 (the latter never clears d_mu / d_lam)
+  std::vector<V3> d_mu, d_lam;
+  void compute_deri();
 };
 
 struct Gripper {
@@ -161,6 +167,8 @@ struct Scene {
   long H_static_cliques = 0;
   std::vector<std::vector<int>> static_cliques;
   std::vector<double> tmp_z_not_frozen, tmp_z_frozen;
+  std::vector<V3> d_ka, d_kl, d_kb, d_mu, d_lam;  // BaseScene.py:160-164
+  void get_paramters_grad();                      // BaseScene.py:1513-1525 (sic)
   int counting_z_frozen = 0;
   // solver controls (the reference calls cupyx spsolve, sparse_solver.py:85-105)
   double cg_tol = 1e-12;
@@ -228,6 +236,9 @@ struct Grad {
   void reset();
   void copy_pos(Scene& sys, int step);
   void transfer_grad(int step, Scene& sys);
+  // analytic_grad_system.py: same reverse step with pos_grad clamped to +-1, no gripper gradient, and the parameter gradients
+  int system_mode = 0, count_kb_grad = 1, count_mu_lam_grad = 0;
+  double grad_kb = 0, grad_mu = 0, grad_lam = 0;
   double& PG(int s, int i, int j) { return pos_grad[((size_t)s * tot_NV + i) * 3 + j]; }
   double& PB(int s, int i, int j) { return pos_buffer[((size_t)s * tot_NV + i) * 3 + j]; }
   double& AG(int s, int c, int f, int l) { return angleref_grad[(((size_t)s * cloth_cnt + c) * NF + f) * 3 + l]; }

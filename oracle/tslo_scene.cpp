@@ -511,10 +511,26 @@ void Grad::copy_pos(Scene& sys, int step) {
 }
 
 // analytic_grad_single.py:217-257
+// BaseScene.py:1513-1525: only d_mu of the elastic bodies is pushed up (d_lam stays zero at scene level)
+void Scene::get_paramters_grad() {
+  d_ka.assign(tot_NV, V3()); d_kl.assign(tot_NV, V3()); d_kb.assign(tot_NV, V3()); d_mu.assign(tot_NV, V3());
+  if (d_lam.size() != (size_t)tot_NV) d_lam.assign(tot_NV, V3());
+  for (auto& c : cloths) {
+    c.compute_deri();
+    for (int i = 0; i < c.NV; i++) { d_ka[i + c.offset] = c.d_ka[i]; d_kb[i + c.offset] = c.d_kb[i]; d_kl[i + c.offset] = c.d_kl[i]; }
+  }
+  for (auto& e : elastics) {
+    e.compute_deri();
+    for (int i = 0; i < e.n_verts; i++) d_mu[i + e.offset] = e.d_mu[i];
+  }
+}
+
 void Grad::transfer_grad(int step, Scene& sys) {
   // clamp_grad :176-185
-  for (int i = 0; i < tot_NV; i++) for (int j = 0; j < 3; j++) PG(step, i, j) = std::min(std::max(PG(step, i, j), -1000.0), 1000.0);
-  for (int i = 0; i < NF; i++) for (int c = 0; c < cloth_cnt; c++) for (int l = 0; l < 3; l++) AG(step, c, i, l) = std::min(std::max(AG(step, c, i, l), -1000.0), 1000.0);
+  const double clampv = system_mode ? 1.0 : 1000.0;  // analytic_grad_system.py:104-109 clamps pos_grad to +-1 and nothing else
+  for (int i = 0; i < tot_NV; i++) for (int j = 0; j < 3; j++) PG(step, i, j) = std::min(std::max(PG(step, i, j), -clampv), clampv);
+  if (!system_mode)
+    for (int i = 0; i < NF; i++) for (int c = 0; c < cloth_cnt; c++) for (int l = 0; l < 3; l++) AG(step, c, i, l) = std::min(std::max(AG(step, c, i, l), -1000.0), 1000.0);
   // sys.copy_pos_only(pos_buffer, step-1)  BaseScene.py:308-315 : pos = prev_pos = x_{s-1}
   for (int i = 0; i < tot_NV; i++) for (int j = 0; j < 3; j++) { sys.pos[i][j] = PB(step - 1, i, j); sys.prev_pos[i][j] = PB(step - 1, i, j); }
   sys.push_down_pos();
@@ -537,6 +553,7 @@ void Grad::transfer_grad(int step, Scene& sys) {
   // sys.init_folding()  BaseScene.py:1527-1530
   for (auto& c : sys.cloths) { c.compute_normal_dir(); c.prepare_bending(); }
   for (int c = 0; c < cloth_cnt; c++) sys.cloths[c].ref_angle_backprop_a2ax(*this, step, c);
+  if (system_mode) sys.get_paramters_grad();  // analytic_grad_system.py:128
   sys.H.clear_all();
   sys.compute_Hessian(0);
   for (int i = 0; i < tot_NV * 3; i++) F[i] = pos_grad[(size_t)step * tot_NV * 3 + i];  // get_F :55-60
@@ -550,10 +567,18 @@ void Grad::transfer_grad(int step, Scene& sys) {
   for (int i = 0; i < tot_NV; i++) for (int j = 0; j < 3; j++) x_hat_grad[i * 3 + j] = p[i * 3 + j] * mass[i] / (dt * dt);  // get_grad :81-92
   sys.contact_energy_backprop(*this, step - 1, p.data());
   for (int c = 0; c < cloth_cnt; c++) sys.cloths[c].ref_angle_backprop_x2a(*this, step, p.data(), c);
+  if (system_mode) {  // get_parameters_grad :69-80
+    for (int i = 0; i < tot_NV; i++)
+      for (int j = 0; j < 3; j++) {
+        if (sys.frozen[i * 3 + j]) continue;
+        if (count_mu_lam_grad) { grad_mu += p[i * 3 + j] * sys.d_mu[i][j]; grad_lam += p[i * 3 + j] * sys.d_lam[i][j]; }
+        if (count_kb_grad) grad_kb += p[i * 3 + j] * sys.d_kb[i][j];
+      }
+  }
   if (step > 0) {
     for (int i = 0; i < tot_NV; i++) for (int j = 0; j < 3; j++)
       if (!sys.frozen[i * 3 + j]) PG(step - 1, i, j) += x_hat_grad[i * 3 + j] * (1 + damping);  // get_prev_grad :94-99
-    if (sys.has_gripper) {
+    if (sys.has_gripper && !system_mode) {
       // get_gripper_grad :118-139
       sys.gripper.get_rotmat();
       sys.gripper.gather_grad(sys.tmp_z_frozen.data(), sys);

@@ -76,3 +76,41 @@ def test_adjoint_sweep_matches(oracle):
             assert rel_err(ag_g[s], ag_o[s]) < 1e-6, f"angleref_grad step {s}"
     tz_o = o.arr("tmp_z_frozen")
     assert rel_err(sys.tmp_z_frozen.to_numpy(), tz_o) < 1e-6
+
+
+def test_system_identification_gradient_matches_finite_difference():
+    """grad_kb of analytic_grad_system.Grad against central differences of L(Kb) over complete forward rollouts (no oracle
+    involved): sign and size of the reference's parameter gradient.  It is not the exact derivative -- the adjoint solves
+    with the reference's own Hessian (spurious factor 2 in the area block, slot-indexed bending terms)
+    while the forward steps converge to the true stationary points -- measured 6 % apart.  Seeds are scaled so that the
+    +-1 clamp of that class stays inactive."""
+    from thinshelllab_amd.engine.analytic_grad_system import Grad
+    from thinshelllab_amd.task_scene.Scene_drape import Scene
+    T, N, Kb0, scale = 5, 12, 100.0, 1e-4
+
+    def rollout(Kb, grad=False):
+        s = Scene(cloth_size=0.1 / 15 * N, N=N, M=N, Kb=Kb, k_angle=3.14, perturb=2e-3, newton_cap=200)
+        s.init_all()
+        s._ensure_ctx().set_param("cg_tol", 1e-13)
+        g = Grad(s, T, 0); g.init_mass(s)
+        g.copy_pos(s, 0)
+        for f in range(1, T):
+            s.time_step(None, f)
+            g.copy_pos(s, f)
+        c = s.cloths[0]
+        z = g.pos_buffer.t[T - 1, c.offset:c.offset + c.NV, 2]
+        L = float(scale * (z * z).sum().item() * 1e4 + scale * z.sum().item())
+        if not grad:
+            return L
+        g.pos_grad.t[T - 1, c.offset:c.offset + c.NV, 2] = scale * (2e4 * z + 1.0)
+        assert g.pos_grad.t.abs().max().item() < 1.0
+        for st in range(T - 1, 0, -1):
+            g.transfer_grad(st, s, None)
+            assert g.pos_grad.t[st - 1].abs().max().item() < 1.0, "clamp would be active"
+        return L, g.grad_kb.value
+
+    L0, gk = rollout(Kb0, True)
+    h = 0.02 * Kb0
+    fd = (rollout(Kb0 + h) - rollout(Kb0 - h)) / (2 * h)
+    assert abs(gk) > 0
+    assert gk * fd > 0 and abs(gk - fd) <= 0.15 * abs(fd), (gk, fd)

@@ -207,6 +207,45 @@ def test_full_scene_gradient_is_derivative_of_energy(oracle):
     assert o.stats()["missing"] == 0
 
 
+def test_parameter_derivative_fields_are_derivatives_of_the_force(oracle):
+    """System identification (analytic_grad_system.py / compute_deri): d_kb, d_kl, d_ka, d_mu are the derivatives of the
+    elastic force (= -gradient) with respect to the stiffness parameters; checked by central differences of the
+    oracle's own gradient.  The tactile derivative is exact for its energy (alpha = 1 + mu/lam moves with mu)."""
+    o = _full_scene(oracle)
+    rng = np.random.default_rng(4)
+    o.pos[:] += rng.normal(0, 1e-5, o.pos.shape) * (o.frozen.reshape(-1, 3) == 0)
+    o.prev_pos[:] = o.pos; o.push_down_all()
+    nv_c, nv_b = o.int("cloth0.NV"), o.int("elastic0.n_verts")
+    pad = slice(nv_c + nv_b, o.tot_NV)
+
+    def grad():
+        o.newton_step_init(); o.compute_energy(); o.compute_residual_and_Hessian(False)
+        return o.arr("F").copy().reshape(-1, 3)
+
+    grad()                     # normals / prepare_bending of the current pose (the reference calls init_folding first)
+    o.get_paramters_grad()
+    d = {k: o.arr(k, (-1, 3)).copy() for k in ("d_kb", "d_kl", "d_ka", "d_mu")}
+    free = o.frozen.reshape(-1, 3) == 0
+    for key, name, val in (("d_kb", "cloth0.Kb", 400.0), ("d_kl", "cloth0.Kl", 1000.0), ("d_ka", "cloth0.Ka", 1000.0)):
+        h = 1e-3 * val
+        o.set_scalar(name, val + h); gp = grad()
+        o.set_scalar(name, val - h); gm = grad()
+        o.set_scalar(name, val)
+        fd = -(gp - gm) / (2 * h)
+        m = free[:nv_c]
+        assert np.abs(d[key][:nv_c][m]).max() > 0
+        assert np.abs(fd[:nv_c][m] - d[key][:nv_c][m]).max() <= 1e-7 * np.abs(d[key][:nv_c]).max(), key
+    mu0 = o.double("elastic1.mu")
+    h = 1e-4 * mu0
+    o.set_scalar("elastic1.mu", mu0 + h); gp = grad()
+    o.set_scalar("elastic1.mu", mu0 - h); gm = grad()
+    o.set_scalar("elastic1.mu", mu0)
+    fd = -(gp - gm) / (2 * h)
+    m = free[pad]
+    assert np.abs(d["d_mu"][pad][m]).max() > 0
+    assert np.abs(fd[pad][m] - d["d_mu"][pad][m]).max() <= 1e-6 * np.abs(d["d_mu"][pad]).max()
+
+
 def test_hessian_matches_fd_where_the_reference_is_exact(oracle):
     """FEM (both materials) and contact blocks are exact second derivatives; the cloth terms are not
     (edge off-diagonal sign, area factor 2, bending second-order term) and are excluded by zeroing their stiffness."""

@@ -137,6 +137,12 @@ class TslContext:
                                       _ptr(tmp_z_frozen), float(damping), C.byref(st)), "tsl_adjoint_step")
         return st.as_dict()
 
+    def param_grad(self, pos, ref_angle):
+        """{kb, mu, lam} contributions of the last adjoint_step (system identification)"""
+        out = (C.c_double * 3)()
+        check(self.L.tsl_param_grad(self.h, _ptr(pos), _ptr(ref_angle), out), "tsl_param_grad")
+        return dict(kb=out[0], mu=out[1], lam=out[2])
+
     # ---- introspection (tests)
     def matrix(self):
         """(row_ptr, col, vals[nnzb,3,3]) of the masked system matrix of the last assemble (static part)."""

@@ -113,6 +113,33 @@ __global__ void k_tet_grad(TetArgs A, const double* __restrict__ pos, double* __
   atomic_add3(Fg, v[3], f3);
 }
 
+// d(force)/d(mu): model_elastic_tactile.py:329-347 (P1 / mu = F - J F^-T) and model_elastic_offset.py:415-431 (P1 / mu = F - F^-T).
+// Tactile contributions go to d_tact (cleared by the caller on every call), box / ball contributions to d_accum, which the
+// reference never clears (it zeroes F_f instead), so it keeps growing over the calls.
+__global__ void k_tet_deri_mu(TetArgs A, const double* __restrict__ pos, double* __restrict__ d_tact, double* __restrict__ d_accum) {
+  const int t = blockIdx.x * blockDim.x + threadIdx.x;
+  if (t >= A.n_tet) return;
+  int v[4]; m3 B;
+  const m3 F = tet_F(A, t, pos, v, B);
+  const ElasticDev e = A.el[A.tel[t]];
+  const m3 FiT = m3_T(m3_inv(F));
+  const double J = (e.kind == 0) ? m3_det(F) : 1.0;
+  m3 P;
+#pragma unroll
+  for (int k = 0; k < 9; k++) P.m[k] = F.m[k] - J * FiT.m[k];
+  const m3 Hm = m3_mul(P, m3_T(B));
+  const double W = A.W[t];
+  double* out = (e.kind == 0) ? d_tact : d_accum;
+  d3 f3 = d3();
+#pragma unroll
+  for (int i = 0; i < 3; i++) {
+    const d3 fi = d3(-W * Hm.m[i], -W * Hm.m[3 + i], -W * Hm.m[6 + i]);
+    atomic_add3(out, v[i], fi);
+    f3 = f3 - fi;
+  }
+  atomic_add3(out, v[3], f3);
+}
+
 // dP(dF) for the two materials (energy Hessian direction), returns dE-Hessian column block dH = W * dP * B^T
 TSL_DEV m3 tet_dH(const ElasticDev& e, const m3& F, const m3& Fi, const m3& FiT, double J, double logJ, const m3& dF, const m3& BT, double W) {
   m3 dP;

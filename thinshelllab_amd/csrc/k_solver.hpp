@@ -515,6 +515,14 @@ __global__ void __launch_bounds__(256) k_multi_axpy(size_t n, const double* __re
     w[i] += sign * acc;
   }
 }
+// out += sum over free dofs of scale * a_i * b_i for i in [i0, i1)  (parameter gradients of the system-identification adjoint)
+__global__ void k_dot_free(size_t i0, size_t i1, const double* __restrict__ a, const double* __restrict__ b, const int* __restrict__ frozen, double scale, double* out) {
+  double s = 0;
+  for (size_t i = i0 + blockIdx.x * (size_t)blockDim.x + threadIdx.x; i < i1; i += (size_t)gridDim.x * blockDim.x)
+    if (!frozen[i]) s += a[i] * b[i];
+  s = wave_sum(s);
+  if ((threadIdx.x & 63) == 0 && s != 0.0) atomicAdd(out, scale * s);
+}
 // y = a*x + b*y (b == 0 ignores old y)
 __global__ void k_axpby(size_t n, double a, const double* __restrict__ x, double b, double* __restrict__ y) {
   for (size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x) y[i] = (b == 0.0) ? a * x[i] : a * x[i] + b * y[i];

@@ -308,6 +308,8 @@ extern "C" int tsl_set_param(tsl_ctx* c, const char* key, double v) {
   else if (k == "grid_h") c->grid_h = v;
   else if (k == "grid_extent") c->grid_extent = v;
   else if (k == "adj_spd_pc") c->adj_spd_pc = (int)v;
+  else if (k == "adj_clamp") c->adj_clamp = v;
+  else if (k == "adj_clamp_angleref") c->adj_clamp_angleref = (int)v;
   else if (k == "gmres") c->use_gmres = (int)v;
   else if (k == "minres") c->use_minres = (int)v;
   else if (k == "gmres_m") c->gmres_m = (int)v;
@@ -1255,6 +1257,42 @@ extern "C" int tsl_solve(tsl_ctx* c, const double* rhs, double* x, tsl_solve_sta
 }
 
 // ------------------------------------------------------------------------------------------------
+// Parameter gradients of the system-identification adjoint (analytic_grad_system.py:69-80 with BaseScene.get_paramters_grad
+// :1513-1525, Cloth.compute_deri model_fold_offset.py:1082-1127, Elastic.compute_deri): sum over the free dofs of
+// p . d(force)/d(parameter), p = the solution of the last tsl_adjoint_step.  out = {kb, mu, lam}; lam is always 0
+// because the reference never pushes d_lam up to the scene.
+extern "C" int tsl_param_grad(tsl_ctx* c, const double* pos, const double* ref, double* out_host) {
+  Scope scope(c);
+  hipStream_t s = c->stream;
+  const int NV = c->NV;
+  const size_t n3 = 3 * (size_t)NV;
+  double* tmp = c->v_t4.p;
+  double* acc = &SC(c)->aux[0];
+  HIP_OK(hipMemsetAsync(acc, 0, 2 * sizeof(double), s));
+  // d_kb = -(bending gradient) / Kb per cloth
+  if (c->n_hinge) {
+    HIP_OK(hipMemsetAsync(tmp, 0, n3 * sizeof(double), s));
+    hipLaunchKernelGGL(k_cloth_normals, dim3(nblk(c->n_cface, 256)), dim3(256), 0, s, c->n_cface, pos, c->cf_f2v.p, c->norm_dir.p);
+    hipLaunchKernelGGL(k_cloth_grad_hinge, dim3(nblk(c->n_hinge, 256)), dim3(256), 0, s, cloth_args(c), pos, ref, tmp);
+    for (const ClothDev& cd : c->h_cloth)
+      hipLaunchKernelGGL(k_dot_free, dim3(DOT_BLOCKS), dim3(256), 0, s, 3 * (size_t)cd.v_offset, 3 * (size_t)(cd.v_offset + cd.NV), c->pdir.p, tmp, c->frozen.p, -1.0 / cd.Kb, acc);
+  }
+  // d_mu
+  if (c->n_tet) {
+    if (c->dmu_accum.n == 0) { TSL_TRY(c->dmu_accum.alloc(n3)); HIP_OK(hipMemsetAsync(c->dmu_accum.p, 0, n3 * sizeof(double), s)); }
+    HIP_OK(hipMemsetAsync(tmp, 0, n3 * sizeof(double), s));
+    hipLaunchKernelGGL(k_tet_deri_mu, dim3(nblk(c->n_tet, 64)), dim3(64), 0, s, tet_args(c), pos, tmp, c->dmu_accum.p);
+    hipLaunchKernelGGL(k_dot_free, dim3(DOT_BLOCKS), dim3(256), 0, s, (size_t)0, n3, c->pdir.p, tmp, c->frozen.p, 1.0, acc + 1);
+    hipLaunchKernelGGL(k_dot_free, dim3(DOT_BLOCKS), dim3(256), 0, s, (size_t)0, n3, c->pdir.p, c->dmu_accum.p, c->frozen.p, 1.0, acc + 1);
+  }
+  double h[2];
+  HIP_OK(hipMemcpyAsync(h, acc, 2 * sizeof(double), hipMemcpyDeviceToHost, s));
+  HIP_OK(hipStreamSynchronize(s));
+  out_host[0] = h[0]; out_host[1] = h[1]; out_host[2] = 0.0;
+  return 0;
+}
+
+// ------------------------------------------------------------------------------------------------
 extern "C" int tsl_update_ref_angle(tsl_ctx* c, const double* pos, double* ref) {
   Scope scope(c);
   if (!c->n_hinge) return 0;
@@ -1554,8 +1592,9 @@ extern "C" int tsl_adjoint_step(tsl_ctx* c, int step, int T, const double* pos_b
   double* ag_prev = angleref_grad + (size_t)(step - 1) * nr;
   const double* ref_prev = ref_buffer + (size_t)(step - 1) * nr;
   // clamp_grad
-  hipLaunchKernelGGL(k_clamp, dim3(gsz(n3)), dim3(256), 0, s, n3, pg_s, 1000.0);
-  if (c->n_cface) hipLaunchKernelGGL(k_clamp, dim3(gsz(3 * (size_t)c->n_cface)), dim3(256), 0, s, 3 * (size_t)c->n_cface, ag_s, 1000.0);
+  hipLaunchKernelGGL(k_clamp, dim3(gsz(n3)), dim3(256), 0, s, n3, pg_s, c->adj_clamp);
+  if (c->n_cface && c->adj_clamp_angleref)
+    hipLaunchKernelGGL(k_clamp, dim3(gsz(3 * (size_t)c->n_cface)), dim3(256), 0, s, 3 * (size_t)c->n_cface, ag_s, 1000.0);
   // contacts re-detected at pos = prev_pos = x_{s-1} (copy_pos_only + calc_vn + f_contact + contact_analysis)
   int nc = 0;
   if (c->contact_enable) TSL_TRY(tsl_contact_detect(c, x_prev, x_prev, &nc));
