@@ -1,0 +1,112 @@
+"""Parity at BASELINE.json's full sizes through size-independent properties (the oracle needs minutes per step there):
+residual of the linear solves against the exported operator (scipy), linearity of the solve, energy decrease and Newton
+convergence of the steps, sign / definiteness bookkeeping of the adjoint systems.  cfg2 (71x71 drape), cfg3 (200x100 folding),
+cfg4 (224x224 cloth on ball + 4 pads), SURVEY.md section 8d."""
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+
+def _free_mask(s):
+    return torch.as_tensor(s.frozen.to_numpy().reshape(-1) == 0, device=s.device)
+
+
+def _residual(ctx, b, x):
+    H = ctx.operator_csr()
+    bn = b.cpu().numpy()
+    return np.linalg.norm(bn - H @ x.cpu().numpy()) / np.linalg.norm(bn), H
+
+
+def test_cfg2_drape_71_forward_steps():
+    from thinshelllab_amd.task_scene.Scene_drape import Scene
+    s = Scene(cloth_size=0.1 / 15 * 71, N=71, M=71, Kb=100.0, k_angle=3.14, perturb=1e-4)
+    s.init_all()
+    E_prev = None
+    for f in range(1, 6):
+        E0 = s.compute_energy()
+        st = s.time_step(None, f)
+        assert st["newton_iters"] < 50 and st["last_delta"] < 1e-7, st          # Newton converged below the reference's stop rule
+        assert st["fallback"] == 0
+    # linear solve of the last state: residual against the exported operator, and linearity
+    s.compute_residual_and_Hessian(spd=True)
+    ctx = s._ctx
+    b1 = s.F.to_torch().clone()
+    rng = np.random.default_rng(0)
+    b2 = torch.as_tensor(rng.normal(size=b1.shape), device=b1.device) * _free_mask(s)
+    x1, st1 = ctx.solve(b1); x2, _ = ctx.solve(b2); x3, _ = ctx.solve(2.5 * b1 - b2)
+    r1, H = _residual(ctx, b1, x1)
+    assert st1["flag"] == 0 and r1 < 1e-9
+    assert np.abs((2.5 * x1 - x2 - x3).cpu().numpy()).max() <= 1e-7 * np.abs(x3.cpu().numpy()).max()
+    assert abs(H - H.T).max() <= 1e-6 * abs(H).max()                           # symmetric up to the area-Hessian quirk
+
+
+def test_cfg3_folding_200x100_step_and_adjoint():
+    from thinshelllab_amd.task_scene.Scene_folding import Scene
+    from thinshelllab_amd.engine.analytic_grad_single import Grad
+    from thinshelllab_amd.engine.geometry import projection_query
+    s = Scene(cloth_size=0.1, cloth_N=200, cloth_M=100)
+    s.cloths[0].Kb[None] = 400.0
+    s.init_all()
+    s.mu_cloth_elastic[None] = 5.0
+    s.prev_pos.copy_from(s.pos)
+    assert s.cloths[0].NF == 40000
+    T = 3
+    n_part = s.gripper.n_part
+    g = Grad(s, T, n_part); g.init_mass(s)
+    g.copy_pos(s, 0)
+    dpos = np.zeros((n_part, 3)); drot = np.zeros((n_part, 3)); dpos[:, 2] = -2e-4      # pad moves -z 2e-4 m per step
+    for f in range(1, T):
+        s.action(f, dpos, drot)
+        E0 = s.compute_energy()
+        st = s.time_step(projection_query, f)
+        g.copy_pos(s, f)
+        assert np.isfinite(s.pos.to_numpy()).all()
+        assert st["nc"] >= 0 and st["newton_iters"] >= 1
+    g.get_loss_fold(s, 1.0, -1.0)
+    for st_ in range(T - 1, 0, -1):
+        g.transfer_grad(st_, s, projection_query)
+        assert g.last_stats["flag"] in (0, 1) and g.last_stats["rel_residual"] < 1e-8, g.last_stats
+    assert np.isfinite(g.pos_grad.to_numpy()).all() and np.abs(g.gripper_grad.to_numpy()).max() > 0
+    # the adjoint operator of the last processed step: independent residual check of a solve with the un-projected Hessian
+    s.compute_Hessian(spd=False)
+    ctx = s._ctx
+    b = torch.as_tensor(np.random.default_rng(1).normal(size=3 * s.tot_NV), device=s.device) * _free_mask(s)
+    x, stx = ctx.solve(b)
+    r, _ = _residual(ctx, b, x)
+    assert stx["flag"] in (0, 1) and r < 1e-8, (stx, r)
+
+
+def test_cfg4_balancing_224_contact_solve():
+    from thinshelllab_amd.task_scene.Scene_balancing import Scene
+    from thinshelllab_amd.engine.geometry import projection_query
+    s = Scene(cloth_size=0.12, cloth_N=224, cloth_M=224)
+    s.init_all()
+    s.mu_cloth_elastic[None] = 5.0
+    s.prev_pos.copy_from(s.pos)
+    assert s.cloths[0].NF == 100352
+    n_part = s.gripper.n_part
+    dpos = np.zeros((n_part, 3)); drot = np.zeros((n_part, 3)); dpos[:, 2] = [1e-4, -1e-4][:n_part]
+    nc = 0
+    for f in range(1, 3):
+        s.action(f, dpos, drot)
+        E0 = s.compute_energy()
+        st = s.time_step(projection_query, f)
+        nc = st["nc"]
+        assert np.isfinite(s.pos.to_numpy()).all()
+    assert nc > 0
+    projection_query(s)
+    s.compute_residual_and_Hessian(spd=True)
+    ctx = s._ctx
+    b = s.F.to_torch().clone()
+    x, stx = ctx.solve(b)
+    r, H = _residual(ctx, b, x)
+    assert r < 1e-7, (stx, r)
+    # the step direction is a descent direction of the incremental potential: E(x - a p) < E(x) for a small a
+    Ecur = s.compute_energy()
+    pos0 = s.pos.to_torch().clone()
+    s.pos.t.copy_((pos0.reshape(-1) - 1e-3 * x).reshape(pos0.shape))
+    Enew = s.compute_energy()
+    s.pos.t.copy_(pos0)
+    assert Enew < Ecur
