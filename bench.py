@@ -169,6 +169,7 @@ def main():
     ap.add_argument("--cloth-size", type=float, default=0.1 / 15 * 224, help="edge length of the square cloth in m (default keeps the reference dx = 0.1/15)")
     ap.add_argument("--cg-tol", type=float, default=1e-10)
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--param", action="append", default=[], metavar="KEY=VALUE", help="extra tsl_set_param settings (solver experiments)")
     ap.add_argument("--cpu-cg-iters", type=int, default=300)
     args = ap.parse_args()
 
@@ -185,6 +186,9 @@ def main():
     K, W = args.steps, args.warmup
     ctx = scene._ensure_ctx()
     ctx.set_param("cg_tol", args.cg_tol)
+    for kv in args.param:
+        k, v = kv.split("=")
+        ctx.set_param(k, float(v))
     n_part = scene.gripper.n_part if args.workload != "drape" else 0
     grad = Grad(scene, max(K, W) + 1, n_part)
     grad.init_mass(scene)

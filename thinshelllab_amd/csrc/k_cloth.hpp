@@ -201,6 +201,9 @@ __global__ void k_cloth_quirk(ClothArgs A, int n_cloth, const double* __restrict
 // One lane per face: edge springs (compute_Hessian_me :472-522), area term (compute_Hessian_ma :526-580),
 // second-order bending part H_lm (compute_Hessian_bending :585-614); all land in the face's own 3x3 grid
 // of blocks, accumulated in registers and flushed once.
+// CLAMP_ALL: the whole 9x9 face block (springs + un-projected area and bending parts) is projected as well -- used only to
+// build an SPD preconditioner when the reference's partially projected Hessian turns out indefinite.
+template <bool CLAMP_ALL>
 __global__ void __launch_bounds__(128)
 k_cloth_hess_face(ClothArgs A, const int* __restrict__ blk, const double* __restrict__ pos, const double* __restrict__ ref_angle,
                   const double* __restrict__ Q, int spd, double* __restrict__ vals) {
@@ -352,6 +355,7 @@ k_cloth_hess_face(ClothArgs A, const int* __restrict__ blk, const double* __rest
       }
   }
 
+  if (CLAMP_ALL) spd_clamp<9>(L);
   // ---- flush the 3x3 grid of blocks
 #pragma unroll
   for (int l = 0; l < 3; l++)

@@ -193,7 +193,7 @@ k_tet_hess(TetArgs A, const int* __restrict__ blk, const double* __restrict__ po
 #pragma unroll
         for (int j = 0; j < 3; j++) He[(n * 3 + dim) * 9 + i * 3 + j] = dH.m[j * 3 + i];
     }
-  if (e.kind == 0 && spd) spd_clamp<9>(He);
+  if ((e.kind == 0 && spd) || spd == 2) spd_clamp<9>(He);  // spd 2: preconditioner-only assembly, every element block projected
   if (e.kind != 0) {
     // model_elastic_offset.py:151-167 scatters row = (vertex j, comp r), column = (n, dim): the transpose of the
     // tactile convention (identical whenever the block is symmetric, i.e. J > 0.01)

@@ -468,7 +468,7 @@ __global__ void k_mr_scal(MrScal* sc) {
   if (sc->flag) return;
   const double delta = sc->delta, g2n = sc->g2n, gamma = sc->gamma;
   sc->delta = 0.0; sc->g2n = 0.0;
-  if (!(g2n >= 0.0) || !isfinite(g2n) || !isfinite(delta)) { sc->flag = 1; return; }
+  if (!(g2n >= 0.0) || !isfinite(g2n) || !isfinite(delta)) { sc->flag = 1; sc->delta = delta; sc->g2n = g2n; return; }
   const double gamma_next = sqrt(g2n);
   const double a0 = sc->c_cur * delta - sc->c_prev * sc->s_cur * gamma;
   const double a1 = sqrt(a0 * a0 + gamma_next * gamma_next);

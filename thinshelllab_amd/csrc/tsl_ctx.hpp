@@ -152,14 +152,16 @@ struct tsl_ctx {
   DevBuf<double> bd_W, bd_scr;
   DevBuf<float> bd_Binv;
   DevBuf<double> gm_V, gm_h;  // GMRES basis ((m+1) vectors) and projection coefficients
-  int gmres_m = 300, use_gmres = 1, use_minres = 1;
+  int gmres_m = 300, use_gmres = 1, use_minres = 1, verbose = 0;
   // analytic_grad_system.Grad: pos_grad clamp (1 there, 1000 in analytic_grad_single) and whether angleref_grad is clamped too
   double adj_clamp = 1000.0;
   int adj_clamp_angleref = 1;
   DevBuf<double> dmu_accum;  // d_mu of the box / ball bodies (accumulates like the reference's field)
   // preconditioner built from a different (SPD-projected) assembly than the operator: adjoint solves (un-projected H)
   DevBuf<double> vals_pc, c_H_pc;
-  bool pc_separate = false, pc_frozen = false;
+  bool pc_separate = false, pc_frozen = false, in_step = false;
+  const double *st_pos = nullptr, *st_prev = nullptr, *st_vel = nullptr, *st_ref = nullptr;  // state of the last assemble
+  int fwd_spd_pc = 1;
   int adj_spd_pc = 1;
   DevBuf<SolverScalars> scal;
   DevBuf<double> part_pAp, part_rz, part_rr;  // per-block partial sums of the two-kernel PCG iteration

@@ -312,6 +312,8 @@ extern "C" int tsl_set_param(tsl_ctx* c, const char* key, double v) {
   else if (k == "adj_clamp_angleref") c->adj_clamp_angleref = (int)v;
   else if (k == "gmres") c->use_gmres = (int)v;
   else if (k == "minres") c->use_minres = (int)v;
+  else if (k == "verbose") c->verbose = (int)v;
+  else if (k == "fwd_spd_pc") c->fwd_spd_pc = (int)v;
   else if (k == "gmres_m") c->gmres_m = (int)v;
   else if (k == "body_inv") { c->bd_enable = (int)v; c->bd_valid = false; }
   else if (k == "mg") c->mg_enable = (int)v;
@@ -403,6 +405,7 @@ extern "C" int tsl_energy(tsl_ctx* c, const double* pos, const double* prev, con
 static int assemble(tsl_ctx* c, const double* pos, const double* prev, const double* vel, const double* ref, int spd, double* grad) {
   hipStream_t s = c->stream;
   const int NV = c->NV;
+  c->st_pos = pos; c->st_prev = prev; c->st_vel = vel; c->st_ref = ref;  // for forward_spd_pc (valid while tsl_step runs)
   HIP_OK(hipMemsetAsync(c->vals_full.p, 0, c->vals_full.n * sizeof(double), s));
   if (c->n_cface) hipLaunchKernelGGL(k_cloth_normals, dim3(nblk(c->n_cface, 256)), dim3(256), 0, s, c->n_cface, pos, c->cf_f2v.p, c->norm_dir.p);
   const ClothArgs CA = cloth_args(c);
@@ -419,7 +422,8 @@ static int assemble(tsl_ctx* c, const double* pos, const double* prev, const dou
   if (c->n_cface) {
     const int nq = (int)c->h_cloth.size() * 9;
     hipLaunchKernelGGL(k_cloth_quirk, dim3(nblk(nq, 64)), dim3(64), 0, s, CA, (int)c->h_cloth.size(), pos, ref, c->quirk.p);
-    hipLaunchKernelGGL(k_cloth_hess_face, dim3(nblk(c->n_cface, 128)), dim3(128), 0, s, CA, c->cf_blk.p, pos, ref, c->quirk.p, spd, c->vals_full.p);
+    if (spd == 2) hipLaunchKernelGGL((k_cloth_hess_face<true>), dim3(nblk(c->n_cface, 128)), dim3(128), 0, s, CA, c->cf_blk.p, pos, ref, c->quirk.p, spd, c->vals_full.p);
+    else hipLaunchKernelGGL((k_cloth_hess_face<false>), dim3(nblk(c->n_cface, 128)), dim3(128), 0, s, CA, c->cf_blk.p, pos, ref, c->quirk.p, spd, c->vals_full.p);
   }
   if (c->n_hinge) hipLaunchKernelGGL(k_cloth_hess_hinge, dim3(nblk(c->n_hinge, 256)), dim3(256), 0, s, CA, c->hg_blk.p, pos, c->vals_full.p);
   if (c->n_tet) hipLaunchKernelGGL(k_tet_hess, dim3(nblk(c->n_tet, 64)), dim3(64), 0, s, TA, c->tet_blk.p, pos, spd, c->vals_full.p);
@@ -774,6 +778,35 @@ static int prof_sample_graph(tsl_ctx* c) {
   return 0;
 }
 
+// The forward Hessian is only partially projected by the reference (area and bending blocks go in raw), so a Newton system
+// can be indefinite and the preconditioner built from it is then not positive definite either (MINRES breaks down, leaving
+// restarted GMRES at ~2.5x the cost per iteration).  Inside tsl_step the state is still at hand: assemble once more with
+// EVERY element block projected (spd = 2) into the preconditioner copy and keep the operator untouched -- the same
+// separate-preconditioner set-up the adjoint step uses.
+static int forward_spd_pc(tsl_ctx* c) {
+  if (!c->in_step || c->pc_separate || !c->st_pos || c->mg.empty() || c->mg_enable == 0) return 1;
+  hipStream_t s = c->stream;
+  if (c->vals_pc.n == 0 && c->vals_pc.alloc(c->vals.n)) return tsl_fail("out of device memory (vals_pc)");
+  if (c->nc > 0 && c->c_H_pc.n == 0 && c->c_H_pc.alloc(c->c_H.n)) return tsl_fail("out of device memory (c_H_pc)");
+  // operator -> the "pc" buffers, assemble the SPD variant into the regular ones, then swap the roles back
+  std::swap(c->vals.p, c->vals_pc.p);
+  if (c->nc > 0) std::swap(c->c_H.p, c->c_H_pc.p);
+  const int rc = assemble(c, c->st_pos, c->st_prev, c->st_vel, c->st_ref, 2, nullptr);
+  c->mg_omega_valid = false;  // damping factors and dense body blocks of THIS matrix (the lagged ones may be indefinite)
+  c->bd_valid = false;
+  int rc2 = 0;
+  if (!rc) {
+    if (body_active(c) && !c->bd_valid) rc2 = body_build_inverse(c);
+    if (!rc2) rc2 = mg_setup_operators(c);
+  }
+  std::swap(c->vals.p, c->vals_pc.p);
+  if (c->nc > 0) std::swap(c->c_H.p, c->c_H_pc.p);
+  (void)s;
+  if (rc || rc2) return -1;
+  c->pc_separate = true;
+  return 0;
+}
+
 // Solve with rhs already in v_b (permuted); result in v_x (permuted).
 static int solve_perm(tsl_ctx* c, tsl_solve_stats* st) {
   hipStream_t s = c->stream;
@@ -857,16 +890,23 @@ static int solve_perm(tsl_ctx* c, tsl_solve_stats* st) {
     st->iters += st2.iters; st->restarts += st2.restarts + 1; st->flag = st2.flag; st->rel_residual = st2.rel_residual;
     return rc;
   }
+  if (c->verbose) fprintf(stderr, "[tsl] PCG gave up: iters %d restarts %d rel_residual %.2e indefinite %d\n", st->iters, st->restarts, st->rel_residual, (int)indefinite);
+  if (indefinite && c->use_minres && c->fwd_spd_pc) {
+    const int rcp = forward_spd_pc(c);
+    if (rcp < 0) return -1;
+    if (c->verbose && rcp == 0) fprintf(stderr, "[tsl] forward system indefinite: preconditioner rebuilt from the fully projected assembly\n");
+  }
   if (c->use_minres) {  // symmetric indefinite: short recurrences
     tsl_solve_stats st2 = *st;
     TSL_TRY(minres(c, &st2));
+    if (c->verbose) fprintf(stderr, "[tsl] MINRES: flag %d iters %d restarts %d rel_residual %.2e\n", st2.flag, st2.iters - st->iters, st2.restarts, st2.rel_residual);
     st->iters = st2.iters; st->restarts = st2.restarts; st->rel_residual = st2.rel_residual;
     if (st2.flag == 1) { st->flag = 1; return 0; }
   }
   if (c->use_gmres) {
     const int it0 = st->iters;
     TSL_TRY(gmres(c, st));
-    (void)it0;
+    if (c->verbose) fprintf(stderr, "[tsl] GMRES: flag %d iters %d rel_residual %.2e\n", st->flag, st->iters - it0, st->rel_residual);
     if (st->flag == 1) return 0;
     return bicgstab(c, st);  // last resort
   }
@@ -1007,6 +1047,7 @@ static int minres(tsl_ctx* c, tsl_solve_stats* st) {
     launch_spmv(c, c->vals.p, x, B.V[2], -1, 0);
     HIP_OK(hipMemcpyAsync(B.V[1], c->v_b.p, n3 * sizeof(double), hipMemcpyDeviceToDevice, s));
     hipLaunchKernelGGL(k_axpby, dim3(gv), dim3(256), 0, s, n3, -1.0, B.V[2], 1.0, B.V[1]);
+    if (c->verbose && flag != 2) fprintf(stderr, "[tsl] MINRES stopped: flag %d iters %d gamma %.3e delta %.3e g2n %.3e eta %.3e\n", flag, h->iters, h->gamma, h->delta, h->g2n, h->eta);
     if (flag != 2) {  // breakdown or iteration cap
       double tr;
       TSL_TRY(dot2(B.V[1], B.V[1], nullptr, nullptr, &tr, nullptr));
@@ -1309,6 +1350,8 @@ extern "C" int tsl_step(tsl_ctx* c, double* pos, double* prev, double* vel, doub
   const size_t n3 = 3 * (size_t)c->NV;
   tsl_step_stats st;
   memset(&st, 0, sizeof(st));
+  struct InStep { tsl_ctx* c; ~InStep() { c->in_step = false; c->st_pos = nullptr; } } in_step_guard{c};
+  c->in_step = true;
   c->mg_omega_valid = false;
   c->bd_valid = false;  // dense body inverses are rebuilt once per step (first solve) and lagged over its Newton iterations
   // timestep_init: prev_pos <- pos (BaseScene.py:1291-1303)
