@@ -51,7 +51,7 @@ typedef struct {
  * (BaseScene.py:818-835, Scene_folding.py:99-108): query vertices [v_start, v_end) against body b_idx. */
 typedef struct {
   int32_t b_idx, v_start, v_end;
-  int32_t mu_is_param; /* 1: use the live mu_cloth_elastic parameter, 0: use mu */
+  int32_t mu_is_param; /* 1: use the live mu_cloth_elastic parameter (times mu when mu > 0), 0: use mu */
   double mu;
 } tsl_contact_pair;
 

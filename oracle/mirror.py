@@ -39,6 +39,12 @@ def oracle_from_scene(po, sys, check_init=True):
         o.set_body_gravity(0, i, c.gravity.to_numpy())
     for i, e in enumerate(sys.elastics):
         o.set_body_gravity(1, i, e.gravity.to_numpy())
+    if hasattr(sys, "gripper") and sys.elastic_cnt > 1:
+        o.gripper_init(1 if sys.gripper.paired else 0, sys.gripper.n_part, sys.gripper.pos.to_numpy())
+        rot = sys.gripper.rot.to_numpy()
+        if not sys.gripper.paired and np.abs(rot[:, 1:]).max() > 0:   # scenes that start with rotated pads (Scene_card.py:89-94)
+            o.arr("gripper.rot", (-1, 4))[:] = rot
+            o.gripper_update_all()
     if check_init:
         for i, c in enumerate(sys.cloths):
             assert np.array_equal(c.f2v.to_numpy(), o.arr(f"cloth{i}.f2v", (-1, 3)))
@@ -62,8 +68,6 @@ def oracle_from_scene(po, sys, check_init=True):
         o.arr(f"elastic{i}.f2v", (-1, 3))[:] = e.f2v.to_numpy()
     for p in sys.contact_pairs():
         o.add_pair(*p)
-    if hasattr(sys, "gripper") and sys.elastic_cnt > 1:
-        o.gripper_init(1 if sys.gripper.paired else 0, sys.gripper.n_part, sys.gripper.pos.to_numpy())
     sync_oracle_state(o, sys)
     return o
 

@@ -119,12 +119,17 @@ class OracleScene:
     def finalize(self):
         self.L.tslo_finalize(self.h)
 
-    def add_pair(self, b_idx, v_start, v_end, mu=None):
-        self.L.tslo_add_pair(self.h, int(b_idx), int(v_start), int(v_end), 1 if mu is None else 0, C.c_double(0.0 if mu is None else mu))
+    def add_pair(self, b_idx, v_start, v_end, mu=None, factor=0.0):
+        """mu None: the live mu_cloth_elastic parameter (times ``factor`` when > 0)"""
+        self.L.tslo_add_pair(self.h, int(b_idx), int(v_start), int(v_end), 1 if mu is None else 0, C.c_double(float(factor) if mu is None else mu))
 
     def gripper_init(self, paired, n_part, pos_array):
         p = np.ascontiguousarray(pos_array, np.float64)
         self.L.tslo_gripper_init(self.h, int(paired), int(n_part), _dp(p))
+
+    def gripper_update_all(self):
+        """after writing ``gripper.rot``: rotation matrices, world vertices, and ALL pad vertices overwritten (gripper_single.py:158-162)"""
+        self.L.tslo_gripper_update_all(self.h)
 
     def gripper_reinit(self, pos_array):
         p = np.ascontiguousarray(pos_array, np.float64)

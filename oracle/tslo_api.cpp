@@ -110,6 +110,15 @@ void tslo_gripper_init(void* h, int paired, int n_part, const double* pos_array)
   s.has_gripper = 1;
 }
 void tslo_gripper_reinit(void* h, const double* pos_array) { S(h).gripper.init(S(h), pos_array); }
+void tslo_gripper_update_all(void* h) {
+  Scene& s = S(h);
+  s.gripper.get_rotmat(); s.gripper.get_vert_pos(); s.gripper.update_all(s);
+  for (size_t j = 1; j < s.elastics.size(); j++) {
+    auto& e = s.elastics[j];
+    if (e.kind != 0) continue;
+    for (int i = 0; i < e.n_verts; i++) s.pos[e.offset + i] = e.F_x[i];
+  }
+}
 
 // per-body gravity override (scene-specific init_property, e.g. Scene_lifting.py:87-103)
 void tslo_set_body_gravity(void* h, int is_elastic, int idx, const double* g) {

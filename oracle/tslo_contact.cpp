@@ -319,7 +319,7 @@ void Scene::contact_pair_analysis(int b_idx, int v_start, int v_end, double mu) 
 
 void Scene::contact_analysis() {
   nc = 0;
-  for (const auto& ps : pairs) contact_pair_analysis(ps.b_idx, ps.v_start, ps.v_end, ps.mu_is_param ? mu_cloth_elastic : ps.mu);
+  for (const auto& ps : pairs) contact_pair_analysis(ps.b_idx, ps.v_start, ps.v_end, ps.mu_is_param ? mu_cloth_elastic * (ps.mu > 0 ? ps.mu : 1.0) : ps.mu);  // factor: Scene_card.py:122-126
   rebuild_pattern();
 }
 

@@ -123,6 +123,7 @@ struct Gripper {
   void get_vert_pos();
   void step_simple(const double* delta_pos, const double* delta_rot);
   void update_bound(Scene& sys);
+  void update_all(Scene& sys);  // gripper_single.py:158-162
   void gather_grad(const double* grad, Scene& sys);
 };
 

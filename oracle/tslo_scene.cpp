@@ -446,6 +446,12 @@ void Gripper::update_bound(Scene& sys) {
     }
 }
 
+// gripper_single.py:158-162
+void Gripper::update_all(Scene& sys) {
+  for (int i = 0; i < n_verts; i++)
+    for (int j = 0; j < n_part; j++) sys.elastics[j + 1].F_x[i] = F_x_world[(size_t)j * n_verts + i];
+}
+
 // gripper_single.py:133-150 / gripper_tactile.py:220-242
 void Gripper::gather_grad(const double* grad, Scene& sys) {
   for (int j = 0; j < n_part; j++) { d_pos[j] = V3(); d_angle[j] = V3(); }

@@ -277,3 +277,78 @@ def test_system_identification_adjoint(oracle, name):
     assert abs(g.grad_kb.value - po_["kb"]) <= 1e-5 * abs(po_["kb"])
     assert abs(g.grad_mu.value - po_["mu"]) <= 1e-5 * abs(po_["mu"])
     assert g.grad_lam.value == 0.0 and po_["lam"] == 0.0
+
+
+def _card_pair(oracle):
+    from thinshelllab_amd.task_scene.Scene_card import Scene
+    s = Scene(cloth_size=0.06)
+    s.cloths[0].Kb[None] = 1400.0                 # run_dp_card.sh
+    s.init_all()
+    s.mu_cloth_elastic[None] = 1.0                # trajopt_card.py:55
+    s.prev_pos.copy_from(s.pos)
+    o = oracle_from_scene(oracle, s)
+    x = s.pos.to_numpy()
+    for k, c in enumerate(s.cloths):
+        x[c.offset:c.offset + c.NV, 2] += 2e-6 * np.sin(0.7 * np.arange(c.NV) + 0.3 + k)
+    s.pos.from_numpy(x); s.prev_pos.from_numpy(x)
+    o.pos[:] = x; o.prev_pos[:] = x; o.push_down_all()
+    return s, o
+
+
+def test_card_scene_three_cloths(oracle):
+    """Scene_card: three stacked cards (one multigrid hierarchy each), cloth-cloth contact, rotated pads of a three-part
+    gripper, friction factors per pair; contact sets, energy / gradient / Hessian, gripper-driven steps and the
+    system-identification reverse sweep (grad_kb) against the oracle."""
+    from thinshelllab_amd.engine.analytic_grad_system import Grad
+    from thinshelllab_amd.engine.geometry import projection_query
+    from thinshelllab_amd.agent.traj_opt_single import agent_trajopt
+    s, o = _card_pair(oracle)
+    assert s.cloth_cnt == 3 and s.gripper.n_part == 3
+    # contacts + assembled system at the start pose
+    nc = projection_query(s)
+    o.calc_vn(); o.projection_query(); o.contact_analysis()
+    assert nc == o.nc and nc > 0
+    oracle.set_spd_mode(1)
+    try:
+        o.newton_step_init()
+        Eo = o.compute_energy(); Eg = s.compute_energy()
+        assert abs(Eg - Eo) <= 1e-11 * abs(Eo)
+        o.newton_step_init(); o.compute_energy(); o.compute_residual_and_Hessian(True)
+        s.compute_residual_and_Hessian(spd=True)
+        # The cards are flat up to the 2e-6 m ripple: dihedral angles of 1e-6..1e-4 rad, where the reference's small-angle
+        # formula 2 sqrt(1 - c) / sqrt(1 + c) (model_fold_offset.py:127-138, restated literally by the oracle) loses half of
+        # its digits (1 - c ~ 1e-12 out of doubles); the GPU evaluates the angle from the four vertex positions without that
+        # cancellation.  With Kb = 1400 the bending forces therefore agree to 1e-4 relative only, 4e-7 N in absolute terms.
+        assert np.abs(s.F.to_numpy() - o.arr("F")).max() < 2e-6
+        assert rel_err(s._ctx.operator_csr().toarray(), o.H_csr().toarray()) < 1e-8
+    finally:
+        oracle.set_spd_mode(0)
+    # rollout driven by the scripted card trajectory, then the reverse sweep
+    T = 4
+    n_part = s.gripper.n_part
+    s._ensure_ctx().set_param("cg_tol", 1e-11); o.set_solver(1e-11)
+    agent = agent_trajopt(T, n_part, max_moving_dist=0.001)
+    agent.init_traj_card(); agent.fix_action(0.015)
+    g = Grad(s, T, n_part); g.init_mass(s)
+    o.grad_new(T, n_part); o.grad_system(True, True, False)
+    g.copy_pos(s, 0); o.grad_copy_pos(0)
+    for f in range(1, T):
+        agent.get_action(f)
+        s.action(f, agent.delta_pos, agent.delta_rot); o.action(agent.delta_pos.to_numpy(), agent.delta_rot.to_numpy())
+        st = s.time_step(projection_query, f); o.time_step()
+        g.copy_pos(s, f); o.grad_copy_pos(f)
+        assert st["nc"] == o.nc
+        assert np.abs(s.pos.to_numpy() - o.pos).max() < 5e-8
+    NV = s.tot_NV
+    g.pos_buffer.from_numpy(o.arr("grad.pos_buffer", (T, NV, 3))); g.ref_angle_buffer.from_numpy(o.arr("grad.ref_angle_buffer").reshape(g.ref_angle_buffer.shape))
+    g.get_loss_card(s)
+    c0 = s.cloths[0]
+    o.arr("grad.pos_grad", (T, NV, 3))[T - 1, c0.offset:c0.offset + c0.NV, 0] = 1
+    for st_ in range(T - 1, 0, -1):
+        g.transfer_grad(st_, s, projection_query)
+        o.grad_transfer(st_)
+    pg_o = o.arr("grad.pos_grad", (T, NV, 3)); pg_g = g.pos_grad.to_numpy()
+    for k in range(T):
+        assert rel_err(pg_g[k], pg_o[k]) < 1e-5, f"pos_grad[{k}]"
+    kb_o = o.grad_params()["kb"]
+    assert abs(kb_o) > 0 and abs(g.grad_kb.value - kb_o) <= 1e-5 * abs(kb_o)

@@ -69,6 +69,18 @@ class agent_trajopt:
             t[i, 0, 2] = t[i - 1, 0, 2]; t[i, 1, 2] = t[i - 1, 1, 2]
             t[i, 0, 0] = t[i - 1, 0, 0]; t[i, 1, 0] = t[i - 1, 1, 0]
 
+    def init_traj_card(self):  # traj_opt_single.py:75-102 (i - 1 wraps to the last row for i = 0, like the Taichi field;
+        t = self.traj.t        # rows beyond tot_timestep are out-of-range writes in the reference and are dropped here)
+        for i in range(min(5, t.shape[0])):
+            t[i, 0, 0] = t[i - 1, 0, 0] + 0.0003
+            t[i, 1, 0] = t[i - 1, 1, 0] - 0.0003
+        for lo, hi, dx, dz, dr in ((5, 20, 0.0001, 0.0003, 0.0), (20, 35, 0.0001, 0.0002, 0.0), (35, 50, 0.0002, 0.0005, 0.02), (50, 150, 0.0, 0.0, 0.0)):
+            for i in range(lo, min(hi, t.shape[0])):
+                t[i, 0, 0] = t[i - 1, 0, 0] + dx
+                t[i, 0, 2] = t[i - 1, 0, 2] + dz
+                t[i, 0, 4] = t[i - 1, 0, 4] + dr
+                t[i, 1, 0] = t[i - 1, 1, 0]
+
     def init_traj_slide(self):
         t = self.traj.t
         for i in range(10):

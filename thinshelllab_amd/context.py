@@ -31,7 +31,7 @@ class TslContext:
                  k_contact=1000.0, eps_contact=1e-3, eps_v=0.01, damping=1.0, max_n_constraints=10000, grid_h=0.003, device="cuda:0"):
         """cloths: dicts with N, M, NV, NF, v_offset, dx, mass, Kl, Ka, Kb, k_angle, f2v, counter_face, counter_point, rest_area, rest_len
         elastics: dicts with kind, n_verts, n_cells, v_offset, mu, lam, alpha, tets, B, W
-        bodies: (v_start, v_end, f_start, f_end); pairs: (b_idx, v_start, v_end, mu or None)"""
+        bodies: (v_start, v_end, f_start, f_end); pairs: (b_idx, v_start, v_end, mu or None[, factor on mu_cloth_elastic])"""
         self.L = _lib.load()
         if not torch.cuda.is_available():
             raise _lib.TslLibraryError("no HIP device visible: thinshelllab_amd has no CPU path")
@@ -57,7 +57,8 @@ class TslContext:
         pr = (ContactPair * max(len(pairs), 1))()
         for i, p in enumerate(pairs):
             mu = p[3]
-            pr[i] = ContactPair(int(p[0]), int(p[1]), int(p[2]), 1 if mu is None else 0, 0.0 if mu is None else float(mu))
+            factor = float(p[4]) if len(p) > 4 else 0.0
+            pr[i] = ContactPair(int(p[0]), int(p[1]), int(p[2]), 1 if mu is None else 0, factor if mu is None else float(mu))
         faces = _np(faces if faces is not None else np.zeros((0, 3)), np.int32)
         mass = _np(mass, np.float64); gravity = _np(gravity, np.float64); frozen = _np(frozen, np.int32)
         assert mass.shape == (tot_NV,) and gravity.shape == (tot_NV, 3) and frozen.shape == (3 * tot_NV,)

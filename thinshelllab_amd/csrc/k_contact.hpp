@@ -574,7 +574,8 @@ extern "C" int tsl_contact_detect(tsl_ctx* c, const double* pos, const double* p
   for (const auto& pr : c->h_pairs) {
     const int nq = pr.v_end - pr.v_start;
     if (nq <= 0) continue;
-    const double mu = pr.mu_is_param ? c->mu_cloth_elastic : pr.mu;
+    // parameter-driven pairs may carry a factor in mu (Scene_card.py:122-126: mu_cloth_elastic * 10 for the upper cards)
+    const double mu = pr.mu_is_param ? c->mu_cloth_elastic * (pr.mu > 0 ? pr.mu : 1.0) : pr.mu;
     hipLaunchKernelGGL(k_contact_pair, dim3(cnblk(nq, 128)), dim3(128), 0, s, pr.b_idx, pr.v_start, pr.v_end, mu, NV, c->max_n_constraints, c->k_contact, c->eps_contact, pos,
                        prev, c->proj_flag.p, c->proj_dir.p, c->proj_idx.p, c->proj_w.p, c->nc_dev.p, c->c_idx.p, c->c_w.p, c->c_k.p, c->c_mu.p, c->c_dx0.p, c->c_T.p, c->c_n.p);
   }

@@ -97,6 +97,13 @@ class gripper:
             e = self._pads(sys, j)[0]
             e.F_x.t[torch.as_tensor(b, device=e.F_x.t.device)] = torch.as_tensor(w[j, b], device=e.F_x.t.device)
 
+    # :158-162
+    def update_all(self, sys):
+        w = self.F_x_world.to_numpy()
+        for j in range(self.n_part):
+            e = self._pads(sys, j)[0]
+            e.F_x.from_numpy(w[j])
+
     # :133-150
     def gather_grad(self, grad, sys):
         g = (grad.to_numpy() if isinstance(grad, Field) else np.asarray(grad)).reshape(-1, 3)
