@@ -18,6 +18,8 @@ def oracle_from_scene(po, sys, check_init=True):
         kind, ox, oy, oz, curv = c._init_args
         if kind == "flat":
             o.cloth_init(ci, ox, oy, oz)
+        elif kind == "bridge":
+            o.cloth_init(ci, ox, oy, oz, bridge=True)
         elif kind == "fold":
             o.cloth_init(ci, ox, oy, oz, fold=True, curv=curv)
         else:

@@ -110,8 +110,8 @@ class OracleScene:
         nodes = np.ascontiguousarray(nodes, np.float64); tets = np.ascontiguousarray(tets, np.int32); faces = np.ascontiguousarray(faces, np.int32)
         return self.L.tslo_add_loaded(self.h, C.c_double(density), len(nodes), _dp(nodes), len(tets), _ip(tets), len(faces), _ip(faces))
 
-    def cloth_init(self, ci, ox, oy, oz, fold=False, curv=2):
-        self.L.tslo_cloth_init(self.h, ci, 1 if fold else 0, C.c_double(ox), C.c_double(oy), C.c_double(oz), int(curv))
+    def cloth_init(self, ci, ox, oy, oz, fold=False, curv=2, bridge=False):
+        self.L.tslo_cloth_init(self.h, ci, 2 if bridge else (1 if fold else 0), C.c_double(ox), C.c_double(oy), C.c_double(oz), int(curv))
 
     def elastic_init(self, ei, ox, oy, oz, flip=False):
         self.L.tslo_elastic_init(self.h, ei, C.c_double(ox), C.c_double(oy), C.c_double(oz), int(bool(flip)))

@@ -95,7 +95,7 @@ int tslo_add_loaded(void* h, double density, int nv, const double* nodes, int nc
 // mode 0: Cloth.init (flat), 1: Cloth.init_fold
 void tslo_cloth_init(void* h, int ci, int mode, double ox, double oy, double oz, int curv) {
   Cloth& c = S(h).cloths[ci];
-  if (mode == 0) c.init(ox, oy, oz); else c.init_fold(ox, oy, oz, curv);
+  if (mode == 0) c.init(ox, oy, oz); else if (mode == 2) { c.init(ox, oy, oz); c.init_ref_angle_bridge(); } else c.init_fold(ox, oy, oz, curv);
 }
 void tslo_cloth_init_mesh(void* h, int ci) { S(h).cloths[ci].init_mesh(); }
 void tslo_elastic_init(void* h, int ei, double ox, double oy, double oz, int flip) { S(h).elastics[ei].init(ox, oy, oz, flip); }

@@ -162,6 +162,18 @@ void Cloth::init_ref_angle() {
       }
 }
 
+// model_fold_offset.py:812-822
+void Cloth::init_ref_angle_bridge() {
+  for (int i = 0; i < NF; i++)
+    for (int l = 0; l < 3; l++)
+      if (counter_face[i][l] > i) {
+        int p = f2v[counter_face[i][l]][counter_point[i][l]];
+        int r1 = f2v[i][l] / (M + 1), r2 = p / (M + 1);
+        if (r1 == 4 && r2 == 6) ref_angle[i][l] = 1.7;
+        if (r1 == 9 && r2 == 11) ref_angle[i][l] = 1.7;
+      }
+}
+
 // model_fold_offset.py:176-185
 void Cloth::update_ref_angle() {
 #pragma omp parallel for schedule(static)

@@ -44,6 +44,7 @@ struct Cloth {
   void init_pos_offset(double ox, double oy, double oz);
   void init_pos_offset_fold(double ox, double oy, double oz, int half_curv_num);
   void init_ref_angle();
+  void init_ref_angle_bridge();  // model_fold_offset.py:812-822
   void init(double ox, double oy, double oz) { init_mesh(); init_pos_offset(ox, oy, oz); for (auto& r : ref_angle) r = D3{{0, 0, 0}}; }
   void init_fold(double ox, double oy, double oz, int curv) { init_mesh(); init_pos_offset_fold(ox, oy, oz, curv); compute_normal_dir(); init_ref_angle(); }
 

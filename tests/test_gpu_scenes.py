@@ -352,3 +352,46 @@ def test_card_scene_three_cloths(oracle):
         assert rel_err(pg_g[k], pg_o[k]) < 1e-5, f"pos_grad[{k}]"
     kb_o = o.grad_params()["kb"]
     assert abs(kb_o) > 0 and abs(g.grad_kb.value - kb_o) <= 1e-5 * abs(kb_o)
+
+
+def test_bouncing_scene_system_identification(oracle):
+    """Scene_bouncing: bridge rest angles, dt = 2 ms, k_contact 4e4, plastic hinges; rollout from the start pose (inside the
+    contact shell of the table) and the system-identification reverse sweep with get_loss_table against the oracle."""
+    from thinshelllab_amd.task_scene.Scene_bouncing import Scene
+    from thinshelllab_amd.engine.analytic_grad_system import Grad
+    from thinshelllab_amd.engine.geometry import projection_query
+    s = Scene(cloth_size=0.06)
+    s.cloths[0].Kb[None] = 1400.0
+    s.init_all()
+    s.mu_cloth_elastic[None] = 0.5
+    s.prev_pos.copy_from(s.pos)
+    o = oracle_from_scene(oracle, s)
+    assert (s.cloths[0].ref_angle.to_numpy() == 1.7).sum() > 0
+    T = 5
+    s._ensure_ctx().set_param("cg_tol", 1e-11); o.set_solver(1e-11)
+    g = Grad(s, T, 0); g.init_mass(s)
+    o.grad_new(T, 0); o.grad_system(True, True, False)
+    g.copy_pos(s, 0); o.grad_copy_pos(0)
+    for f in range(1, T):
+        st = s.time_step(projection_query, f); o.time_step()
+        g.copy_pos(s, f); o.grad_copy_pos(f)
+        assert st["nc"] == o.nc and st["nc"] > 0
+        assert np.abs(s.pos.to_numpy() - o.pos).max() < 5e-8
+    assert abs(s.compute_reward() - o.pos.reshape(-1, 3)[:256][(np.arange(256) // 16 == 5) | (np.arange(256) // 16 == 10), 2].sum()) < 1e-6
+    NV = s.tot_NV
+    g.pos_buffer.from_numpy(o.arr("grad.pos_buffer", (T, NV, 3))); g.ref_angle_buffer.from_numpy(o.arr("grad.ref_angle_buffer").reshape(g.ref_angle_buffer.shape))
+    g.get_loss_table(s)
+    c0 = s.cloths[0]
+    rows = np.arange(c0.NV) // (c0.N + 1)
+    sel = c0.offset + np.nonzero((rows == 5) | (rows == 10))[0]
+    pgo = o.arr("grad.pos_grad", (T, NV, 3))
+    pgo[1:, sel, 2] = -1
+    for st_ in range(T - 1, 0, -1):
+        g.transfer_grad(st_, s, projection_query)
+        o.grad_transfer(st_)
+    pg_g = g.pos_grad.to_numpy()
+    for k in range(T):
+        assert rel_err(pg_g[k], pgo[k]) < 1e-5, f"pos_grad[{k}]"
+    assert rel_err(g.angleref_grad.to_numpy().reshape(-1), o.arr("grad.angleref_grad")) < 1e-5
+    kb_o = o.grad_params()["kb"]
+    assert abs(kb_o) > 0 and abs(g.grad_kb.value - kb_o) <= 1e-5 * abs(kb_o)

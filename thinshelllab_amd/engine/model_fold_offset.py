@@ -165,6 +165,18 @@ class Cloth:
         ra[fi[m], l[m]] += (ad[m] - ka) * dis[m] / ad[m]
         self.ref_angle.from_numpy(ra)
 
+    # :812-822: rest angle 1.7 rad on the hinges whose wings sit on grid rows (4, 6) and (9, 11)
+    def init_ref_angle_bridge(self):
+        f2v = self.f2v.to_numpy(); cf = self.counter_face.to_numpy(); cp = self.counter_point.to_numpy()
+        fi, l = np.nonzero(cf > np.arange(self.NF)[:, None])
+        r1 = f2v[fi, l] // (self.M + 1)
+        r2 = f2v[cf[fi, l], cp[fi, l]] // (self.M + 1)
+        m = ((r1 == 4) & (r2 == 6)) | ((r1 == 9) & (r2 == 11))
+        ra = self.ref_angle.to_numpy()
+        ra[fi[m], l[m]] = 1.7
+        self.ref_angle.from_numpy(ra)
+        self._init_args = ("bridge",) + tuple(self._init_args[1:])
+
     def init(self, offsetx, offsety, offsetz):
         self._init_args = ("flat", offsetx, offsety, offsetz, 0)
         self.init_mesh()
