@@ -136,6 +136,11 @@ int tsl_adjoint_step(tsl_ctx* ctx, int step, int tot_timestep, const double* pos
                      const double* ref_angle_buffer_dev, double* angleref_grad_dev, double* tmp_z_frozen_dev,
                      double adjoint_damping, tsl_solve_stats* stats_host);
 
+/* Elastic.get_force of every FEM body (model_elastic_tactile.py:144-164, model_elastic_offset.py:188-208): internal force +
+ * gravity + external force per vertex; consumed by BaseScene.check_early_stop / gather_force (BaseScene.py:1541-1584).
+ * force_dev: tot_NV x 3, rows of the cloths are zero. */
+int tsl_elastic_force(tsl_ctx* ctx, const double* pos_dev, double* force_dev);
+
 /* System identification (engine/analytic_grad_system.py:112-160): the reverse step is tsl_adjoint_step with
  * tsl_set_param "adj_clamp" = 1 and "adj_clamp_angleref" = 0 (that class clamps pos_grad to +-1 and nothing else, :104-109);
  * this call then returns the sums over the free dofs of p . d(force)/d(parameter) with p the solution of that step

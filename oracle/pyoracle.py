@@ -285,6 +285,16 @@ class OracleScene:
     def get_paramters_grad(self):
         self.L.tslo_get_paramters_grad(self.h)
 
+    def gather_force(self, n_eff):
+        out = np.zeros((n_eff, 3))
+        self.L.tslo_gather_force(self.h, _dp(out))
+        return out
+
+    def observation(self, dim):
+        out = np.zeros(dim)
+        self.L.tslo_observation(self.h, _dp(out))
+        return out
+
 
 def set_threads(n):
     lib().tslo_set_threads(int(n))

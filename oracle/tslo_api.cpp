@@ -164,6 +164,46 @@ void tslo_grad_params(void* h, double* out, int reset) {
   if (reset) { G(h).grad_kb = 0; G(h).grad_mu = 0; G(h).grad_lam = 0; }
 }
 void tslo_get_paramters_grad(void* h) { S(h).get_paramters_grad(); }
+// BaseScene.gather_force after Elastic.get_force of the effector pads (BaseScene.py:1541-1549, :1566-1570); out: (effector_cnt - 1) x 3
+void tslo_gather_force(void* h, double* out) {
+  Scene& s = S(h);
+  for (int j = 1; j < s.effector_cnt; j++) {
+    Elastic& e = s.elastics[j];
+    e.get_force();
+    V3 t;
+    for (int i = 0; i < e.n_verts; i++)
+      if (e.is_bottom(i) || e.is_inner_circle(i)) t += e.F_f[i];
+    for (int k = 0; k < 3; k++) out[(j - 1) * 3 + k] = t[k];
+  }
+}
+// BaseScene.get_observation_kernel (BaseScene.py:1586-1619) with n_obs_cloth = 4, n_obs_elastic = 16 (:184-188)
+void tslo_observation(void* h, double* obs) {
+  Scene& s = S(h);
+  const int no = 4, ne = 16;
+  const int ns = s.cloths[0].N / 4, ms = s.cloths[0].M / 4, cN = s.cloths[0].N;
+  const int ccnt = (int)s.cloths.size(), ecnt = (int)s.elastics.size();
+  for (int j = 0; j < no; j++)
+    for (int k = 0; k < no; k++)
+      for (int i = 0; i < ccnt; i++) {
+        int xx = i * no * no + j * no + k;
+        int jj = ns / 2 + j * ns, kk = ms / 2 + k * ms;
+        const int q = jj * cN + kk;  // runs past NV on non-square cloths (unchecked read in the reference): zeros
+        for (int d = 0; d < 3; d++) { obs[xx * 6 + d] = q < s.cloths[i].NV ? s.cloths[i].pos[q][d] : 0.0; obs[xx * 6 + 3 + d] = q < s.cloths[i].NV ? s.cloths[i].vel[q][d] : 0.0; }
+      }
+  for (int j = 0; j < ne; j++)
+    for (int i = 0; i < ecnt; i++) {
+      int xx = no * no * ccnt + i * ne + j;
+      int nv = s.elastics[i].n_verts;
+      int ii = (nv / ne) * j - 1;
+      if (ii < 0) ii += nv;  // Taichi / numpy negative index: the last vertex
+      for (int d = 0; d < 3; d++) { obs[xx * 6 + d] = s.elastics[i].F_x[ii][d]; obs[xx * 6 + 3 + d] = s.elastics[i].F_v[ii][d]; }
+    }
+  int base = (no * no * ccnt + ecnt * ne) * 6;
+  for (int j = 0; j < s.gripper.n_part; j++) {
+    for (int d = 0; d < 3; d++) obs[base + j * 7 + d] = s.gripper.pos[j][d];
+    for (int d = 0; d < 4; d++) obs[base + j * 7 + 3 + d] = s.gripper.rot[j * 4 + d];
+  }
+}
 
 // stats: [newton, cg, ls, solves, refine, last_solve_flag, H.missing]
 void tslo_stats(void* h, long* out, int reset) {

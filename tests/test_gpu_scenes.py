@@ -395,3 +395,25 @@ def test_bouncing_scene_system_identification(oracle):
     assert rel_err(g.angleref_grad.to_numpy().reshape(-1), o.arr("grad.angleref_grad")) < 1e-5
     kb_o = o.grad_params()["kb"]
     assert abs(kb_o) > 0 and abs(g.grad_kb.value - kb_o) <= 1e-5 * abs(kb_o)
+
+
+@pytest.mark.parametrize("name", ["lifting", "balancing"])
+def test_forward_consumer_surface(oracle, name):
+    """What the forward-only harnesses (CMA-ES, RL env) read after every step: the observation vector
+    (get_observation_kernel) and the effector forces behind check_early_stop (Elastic.get_force + gather_force)."""
+    from thinshelllab_amd.engine.geometry import projection_query
+    s, o = _pair(oracle, name)
+    n_part = s.gripper.n_part
+    dpos = np.zeros((n_part, 3)); drot = np.zeros((n_part, 3))
+    dpos[:, 2] = -1e-4 if name != "balancing" else 5e-5
+    for f in range(1, 3):
+        s.action(f, dpos, drot); o.action(dpos, drot)
+        s.time_step(projection_query, f); o.time_step()
+    obs = s.get_observation_kernel()
+    assert obs.shape == (s.obs_dim,)
+    assert np.abs(obs - o.observation(s.obs_dim)).max() < 1e-6
+    tf = s.gather_force(); tfo = o.gather_force(s.effector_cnt - 1)
+    assert np.abs(tfo).max() > 0 and np.abs(tf - tfo).max() <= 1e-6 * np.abs(tfo).max()
+    assert s.check_early_stop(2) in (True, False)
+    x = s.pos.to_numpy(); x[0, 0] = np.nan; s.pos.from_numpy(x)
+    assert s.check_early_stop(2) is True

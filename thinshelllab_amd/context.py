@@ -138,6 +138,10 @@ class TslContext:
                                       _ptr(tmp_z_frozen), float(damping), C.byref(st)), "tsl_adjoint_step")
         return st.as_dict()
 
+    def elastic_force(self, pos, out):
+        check(self.L.tsl_elastic_force(self.h, _ptr(pos), _ptr(out)), "tsl_elastic_force")
+        return out
+
     def param_grad(self, pos, ref_angle):
         """{kb, mu, lam} contributions of the last adjoint_step (system identification)"""
         out = (C.c_double * 3)()

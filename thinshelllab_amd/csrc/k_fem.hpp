@@ -113,6 +113,15 @@ __global__ void k_tet_grad(TetArgs A, const double* __restrict__ pos, double* __
   atomic_add3(Fg, v[3], f3);
 }
 
+// F_f = -(elastic gradient) + m g + f_ext on the vertices of the FEM bodies (Elastic.get_force, model_elastic_tactile.py:144-164 /
+// model_elastic_offset.py:188-208); f holds the elastic gradient on entry
+__global__ void k_elastic_force_finish(VertArgs A, int v0, int v1, double* __restrict__ f) {
+  const int i = v0 + blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= v1) return;
+  const d3 g = ld3(A.grav, i), e = ld3(A.fext, i);
+  st3(f, i, A.mass[i] * g + e - ld3(f, i));
+}
+
 // d(force)/d(mu): model_elastic_tactile.py:329-347 (P1 / mu = F - J F^-T) and model_elastic_offset.py:415-431 (P1 / mu = F - F^-T).
 // Tactile contributions go to d_tact (cleared by the caller on every call), box / ball contributions to d_accum, which the
 // reference never clears (it zeroes F_f instead), so it keeps growing over the calls.

@@ -1298,6 +1298,24 @@ extern "C" int tsl_solve(tsl_ctx* c, const double* rhs, double* x, tsl_solve_sta
 }
 
 // ------------------------------------------------------------------------------------------------
+// Internal force field of the FEM bodies (Elastic.get_force): consumed by BaseScene.check_early_stop / gather_force
+// (BaseScene.py:1541-1584).  force_dev: tot_NV x 3 (only the rows of elastic bodies are written, the rest is zeroed).
+extern "C" int tsl_elastic_force(tsl_ctx* c, const double* pos, double* force) {
+  Scope scope(c);
+  hipStream_t s = c->stream;
+  const size_t n3 = 3 * (size_t)c->NV;
+  HIP_OK(hipMemsetAsync(force, 0, n3 * sizeof(double), s));
+  if (c->n_tet) {
+    hipLaunchKernelGGL(k_tet_grad, dim3(nblk(c->n_tet, 256)), dim3(256), 0, s, tet_args(c), pos, force);
+    for (const ElasticDev& e : c->h_el)
+      hipLaunchKernelGGL(k_elastic_force_finish, dim3(nblk(e.n_verts, 256)), dim3(256), 0, s, vert_args(c), e.v_offset, e.v_offset + e.n_verts, force);
+  }
+  HIP_OK(hipStreamSynchronize(s));
+  HIP_OK(hipGetLastError());
+  return 0;
+}
+
+// ------------------------------------------------------------------------------------------------
 // Parameter gradients of the system-identification adjoint (analytic_grad_system.py:69-80 with BaseScene.get_paramters_grad
 // :1513-1525, Cloth.compute_deri model_fold_offset.py:1082-1127, Elastic.compute_deri): sum over the free dofs of
 // p . d(force)/d(parameter), p = the solution of the last tsl_adjoint_step.  out = {kb, mu, lam}; lam is always 0

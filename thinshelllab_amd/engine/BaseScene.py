@@ -142,7 +142,11 @@ class BaseScene:
         if self.effector_cnt - 1 > 0:
             self.n_obs_cloth = 4
             self.n_obs_elastic = 16
+            self.n_sample_cloth = self.cloths[0].N // 4   # BaseScene.py:187-191
+            self.m_sample_cloth = self.cloths[0].M // 4
             self.obs_dim = (self.n_obs_cloth * self.n_obs_cloth * self.cloth_cnt + self.n_obs_elastic * self.elastic_cnt) * 6 + 7 * self.gripper.n_part
+            self.observation = Field(torch.zeros(self.obs_dim, dtype=torch.float64))
+            self.tot_force = Field(torch.zeros((self.effector_cnt - 1, 3), dtype=torch.float64))
 
     # ------------------------------------------------------------------ construction helpers
     def _bind_bodies(self):
@@ -420,8 +424,70 @@ class BaseScene:
     def check_pos_nan(self):
         return bool(torch.isnan(self.pos.t).any().item())
 
+    def gather_force(self):
+        """BaseScene.py:1541-1549: sum of Elastic.get_force over the gripper-driven vertices of every effector pad"""
+        f = self._ensure_ctx().elastic_force(self.pos.t, torch.empty_like(self.pos.t)).cpu().numpy()
+        tot = np.zeros((self.effector_cnt - 1, 3))
+        for j in range(1, self.effector_cnt):
+            e = self.elastics[j]
+            tot[j - 1] = f[e.offset:e.offset + e.n_verts][e.bound_mask()].sum(0)
+        self.tot_force.from_numpy(tot)
+        return tot
+
     def check_early_stop(self, frame, ifprint=False, RL=False):
-        return self.check_pos_nan()
+        # BaseScene.py:1559-1584
+        if self.check_pos_nan():
+            if ifprint:
+                print("exist nan")
+            return True
+        if self.effector_cnt - 1 <= 0:
+            return False
+        tot = self.gather_force()
+        for i in range(self.effector_cnt - 1):
+            if (np.abs(tot[i]) > 10).any():
+                if ifprint:
+                    print("too much force")
+                return True
+            if np.sqrt((tot[i] ** 2).sum()) < 0.2 and frame > 10 and not RL:
+                if ifprint:
+                    print("no contact")
+                return True
+        return False
+
+    def get_observation_kernel(self):
+        # BaseScene.py:1586-1619 (cloth samples index pos[jj * cloth_N + kk] -- cloth_N, not M + 1 -- and the elastic sample
+        # index (n_verts // n_obs_elastic) * j - 1 is -1 for j = 0, i.e. the last vertex: both kept; on non-square cloths such as
+        # the 15x7 balancing sheet the cloth index runs past NV -- an unchecked out-of-range read in the reference, zeros here)
+        obs = np.zeros(self.obs_dim)
+        no = self.n_obs_cloth
+        for i, c in enumerate(self.cloths):
+            x = c.pos.to_numpy(); v = c.vel.to_numpy()
+            for j in range(no):
+                for k in range(no):
+                    xx = i * no * no + j * no + k
+                    jj = self.n_sample_cloth // 2 + j * self.n_sample_cloth
+                    kk = self.m_sample_cloth // 2 + k * self.m_sample_cloth
+                    q = jj * self.cloth_N + kk
+                    if q < c.NV:
+                        obs[xx * 6:xx * 6 + 3] = x[q]
+                        obs[xx * 6 + 3:xx * 6 + 6] = v[q]
+        for i, e in enumerate(self.elastics):
+            x = e.F_x.to_numpy(); v = e.F_v.to_numpy()
+            for j in range(self.n_obs_elastic):
+                xx = no * no * self.cloth_cnt + i * self.n_obs_elastic + j
+                ii = (e.n_verts // self.n_obs_elastic) * j - 1
+                obs[xx * 6:xx * 6 + 3] = x[ii]
+                obs[xx * 6 + 3:xx * 6 + 6] = v[ii]
+        base = (no * no * self.cloth_cnt + self.elastic_cnt * self.n_obs_elastic) * 6
+        gp = self.gripper.pos.to_numpy(); gr = self.gripper.rot.to_numpy()
+        for j in range(self.gripper.n_part):
+            obs[base + j * 7: base + j * 7 + 3] = gp[j]
+            obs[base + j * 7 + 3: base + j * 7 + 7] = gr[j]
+        self.observation.from_numpy(obs)
+        return obs
+
+    def get_observation(self):
+        return self.get_observation_kernel()
 
     def save_state(self, save_path):
         torch.save({'pos': self.pos.to_torch('cpu'), 'vel': self.vel.to_torch('cpu')}, save_path)
