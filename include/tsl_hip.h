@@ -51,7 +51,7 @@ typedef struct {
  * (BaseScene.py:818-835, Scene_folding.py:99-108): query vertices [v_start, v_end) against body b_idx. */
 typedef struct {
   int32_t b_idx, v_start, v_end;
-  int32_t mu_is_param; /* 1: use the live mu_cloth_elastic parameter (times mu when mu > 0), 0: use mu */
+  int32_t mu_is_param; /* 0: use mu; 1 / 2: the live mu_cloth_elastic / mu_cloth_cloth parameter (times mu when mu > 0) */
   double mu;
 } tsl_contact_pair;
 
@@ -92,7 +92,7 @@ int tsl_ctx_create(const tsl_scene_desc* desc, tsl_ctx** out);
 void tsl_ctx_destroy(tsl_ctx* ctx);
 int tsl_set_stream(tsl_ctx* ctx, void* hip_stream);
 
-/* 0-d field writes: "cloth<i>.Kb|Kl|Ka|k_angle", "mu_cloth_elastic", "k_contact", "eps_contact", "damping",
+/* 0-d field writes: "cloth<i>.Kb|Kl|Ka|k_angle", "mu_cloth_elastic", "mu_cloth_cloth", "k_contact", "eps_contact", "damping",
  * "newton_cap", "plastic", "contact" (trajopt_folding.py:50,66; Scene_folding.py:30-31), the broad-phase box
  * "grid_h", "grid_extent" (geometry.py:8-19), and the solver knobs that have no reference counterpart (the reference
  * calls a direct solver): "cg_tol", "cg_maxit", "cg_check", "mg" (-1 auto / 0 / 1), "mg_nu", "mg_coarse_sweeps",
@@ -149,6 +149,10 @@ int tsl_elastic_force(tsl_ctx* ctx, const double* pos_dev, double* force_dev);
  * pos = tape state x_s, ref_angle = tape rest angles of step s-1 (copy_pos_and_refangle, BaseScene.py:284-292).
  * out_host = {grad_kb, grad_mu, grad_lam} contributions of this step (grad_lam is 0: the reference never pushes d_lam up). */
 int tsl_param_grad(tsl_ctx* ctx, const double* pos_dev, const double* ref_angle_dev, double* out_host);
+
+/* Scene_sliding.contact_energy_backprop_friction (Scene_sliding.py:139-176): contribution of the last tsl_adjoint_step to
+ * d(loss)/d(mu_cloth_cloth), summed over the constraints of the pairs that use that parameter. pos = tape state x_s. */
+int tsl_friction_grad(tsl_ctx* ctx, const double* pos_dev, double* out_host);
 
 /* Introspection used by the parity tests (tests/ only): assembled matrix as BSR on the host. */
 int tsl_matrix_nnzb(tsl_ctx* ctx, int32_t* nb_host, int32_t* nnzb_host);

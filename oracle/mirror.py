@@ -82,7 +82,13 @@ def sync_oracle_state(o, sys):
         o.arr(f"cloth{i}.ref_angle", (-1, 3))[:] = c.ref_angle.to_numpy()
         for k in ("Kb", "Kl", "Ka", "k_angle"):
             o.set_scalar(f"cloth{i}.{k}", getattr(c, k).value)
+    for i, e in enumerate(sys.elastics):   # scenes may retune a body after construction (Scene_sliding.py:27-32)
+        o.set_scalar(f"elastic{i}.mu", e.mu.value)
+        if e.lam.value != 0:
+            o.set_scalar(f"elastic{i}.lam", e.lam.value)
     o.set_scalar("mu_cloth_elastic", sys.mu_cloth_elastic.value)
+    if hasattr(sys, "mu_cloth_cloth"):
+        o.set_scalar("mu_cloth_cloth", sys.mu_cloth_cloth.value)
     o.push_down_all()
 
 

@@ -120,8 +120,9 @@ class OracleScene:
         self.L.tslo_finalize(self.h)
 
     def add_pair(self, b_idx, v_start, v_end, mu=None, factor=0.0):
-        """mu None: the live mu_cloth_elastic parameter (times ``factor`` when > 0)"""
-        self.L.tslo_add_pair(self.h, int(b_idx), int(v_start), int(v_end), 1 if mu is None else 0, C.c_double(float(factor) if mu is None else mu))
+        """mu float: fixed; None: the live mu_cloth_elastic parameter; "cloth_cloth": the live mu_cloth_cloth (times ``factor`` when > 0)"""
+        kind = 0 if isinstance(mu, (int, float)) else (2 if mu == "cloth_cloth" else 1)
+        self.L.tslo_add_pair(self.h, int(b_idx), int(v_start), int(v_end), kind, C.c_double(float(mu) if kind == 0 else float(factor)))
 
     def gripper_init(self, paired, n_part, pos_array):
         p = np.ascontiguousarray(pos_array, np.float64)
@@ -273,14 +274,14 @@ class OracleScene:
     def grad_transfer(self, step):
         self.L.tslo_grad_transfer(self.h, int(step))
 
-    def grad_system(self, system_mode=True, count_kb=True, count_mu_lam=False):
+    def grad_system(self, system_mode=True, count_kb=True, count_mu_lam=False, count_friction=False):
         """switch the reverse step to analytic_grad_system.Grad semantics (pos_grad clamp +-1, parameter gradients)"""
-        self.L.tslo_grad_system(self.h, int(system_mode), int(count_kb), int(count_mu_lam))
+        self.L.tslo_grad_system(self.h, int(system_mode), int(count_kb), int(count_mu_lam), int(count_friction))
 
     def grad_params(self, reset=False):
-        out = np.zeros(3)
+        out = np.zeros(4)
         self.L.tslo_grad_params(self.h, _dp(out), int(reset))
-        return dict(kb=out[0], mu=out[1], lam=out[2])
+        return dict(kb=out[0], mu=out[1], lam=out[2], friction=out[3])
 
     def get_paramters_grad(self):
         self.L.tslo_get_paramters_grad(self.h)

@@ -39,6 +39,7 @@ void tslo_set_scalar(void* h, const char* name, double v) {
   Scene& s = S(h);
   std::string n(name);
   if (n == "mu_cloth_elastic") s.mu_cloth_elastic = v;
+  else if (n == "mu_cloth_cloth") s.mu_cloth_cloth = v;
   else if (n == "k_contact") s.k_contact = v;
   else if (n == "eps_contact") s.eps_contact = v;
   else if (n == "damping") s.damping = v;
@@ -158,10 +159,12 @@ void tslo_grad_reset(void* h) { G(h).reset(); }
 void tslo_grad_copy_pos(void* h, int step) { G(h).copy_pos(S(h), step); }
 void tslo_grad_transfer(void* h, int step) { G(h).transfer_grad(step, S(h)); }
 // analytic_grad_system.Grad: mode switch, flags, accumulated parameter gradients (kb, mu, lam)
-void tslo_grad_system(void* h, int system_mode, int count_kb, int count_mu_lam) { G(h).system_mode = system_mode; G(h).count_kb_grad = count_kb; G(h).count_mu_lam_grad = count_mu_lam; }
+void tslo_grad_system(void* h, int system_mode, int count_kb, int count_mu_lam, int count_friction) {
+  G(h).system_mode = system_mode; G(h).count_kb_grad = count_kb; G(h).count_mu_lam_grad = count_mu_lam; G(h).count_friction_grad = count_friction;
+}
 void tslo_grad_params(void* h, double* out, int reset) {
-  out[0] = G(h).grad_kb; out[1] = G(h).grad_mu; out[2] = G(h).grad_lam;
-  if (reset) { G(h).grad_kb = 0; G(h).grad_mu = 0; G(h).grad_lam = 0; }
+  out[0] = G(h).grad_kb; out[1] = G(h).grad_mu; out[2] = G(h).grad_lam; out[3] = G(h).grad_friction_coef;
+  if (reset) { G(h).grad_kb = 0; G(h).grad_mu = 0; G(h).grad_lam = 0; G(h).grad_friction_coef = 0; }
 }
 void tslo_get_paramters_grad(void* h) { S(h).get_paramters_grad(); }
 // BaseScene.gather_force after Elastic.get_force of the effector pads (BaseScene.py:1541-1549, :1566-1570); out: (effector_cnt - 1) x 3

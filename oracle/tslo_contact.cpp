@@ -280,6 +280,31 @@ void Scene::contact_energy_backprop(Grad& g, int step, const double* p_array) {
 }
 
 // BaseScene.py:778-816 (serial: the reference's atomic counter gives an arbitrary constraint
+// Scene_sliding.py:139-176: d(loss)/d(mu_cloth_cloth) from the first nc1 (cloth-cloth) constraints
+void Scene::contact_energy_backprop_friction(Grad& g, int step, const double* p_array) {
+  (void)step;
+  for (int i = 0; i < nc1; i++) {
+    const I4& idx = const_idx[i];
+    const V3& w = const_w[i];
+    double k = const_k[i];
+    const double* T = &const_T[(size_t)i * 6];
+    V3 x_c = pos[idx[0]] * w[0] + pos[idx[1]] * w[1] + pos[idx[2]] * w[2];
+    V3 dxv = pos[idx[3]] - x_c - const_dx0[i];
+    double u[2] = {T[0] * dxv[0] + T[1] * dxv[1] + T[2] * dxv[2], T[3] * dxv[0] + T[4] * dxv[1] + T[5] * dxv[2]};
+    double r = std::sqrt(u[0] * u[0] + u[1] * u[1]);
+    double gg[2] = {u[0] * k * f1(r), u[1] * k * f1(r)};
+    double g1[3];
+    for (int j = 0; j < 3; j++) g1[j] = gg[0] * T[j] + gg[1] * T[3 + j];
+    const double w1[4] = {w[0], w[1], w[2], -1.0};
+    for (int i1 = 0; i1 < 4; i1++)
+      for (int j1 = 0; j1 < 3; j1++) {
+        double dfdmu = w1[i1] * g1[j1] / mu_cloth_cloth;
+        double zT = p_array[idx[i1] * 3 + j1];
+        if (!frozen[idx[i1] * 3 + j1]) g.grad_friction_coef += zT * dfdmu;
+      }
+  }
+}
+
 // order; vertex order is used here)
 void Scene::contact_pair_analysis(int b_idx, int v_start, int v_end, double mu) {
   for (int i = v_start; i < v_end; i++) {
@@ -319,7 +344,12 @@ void Scene::contact_pair_analysis(int b_idx, int v_start, int v_end, double mu) 
 
 void Scene::contact_analysis() {
   nc = 0;
-  for (const auto& ps : pairs) contact_pair_analysis(ps.b_idx, ps.v_start, ps.v_end, ps.mu_is_param ? mu_cloth_elastic * (ps.mu > 0 ? ps.mu : 1.0) : ps.mu);  // factor: Scene_card.py:122-126
+  nc1 = 0;
+  for (const auto& ps : pairs) {
+    const double live = ps.mu_is_param == 2 ? mu_cloth_cloth : mu_cloth_elastic;  // Scene_sliding.py:78-85
+    contact_pair_analysis(ps.b_idx, ps.v_start, ps.v_end, ps.mu_is_param ? live * (ps.mu > 0 ? ps.mu : 1.0) : ps.mu);  // factor: Scene_card.py:122-126
+    if (ps.mu_is_param == 2) nc1 = nc;  // the cloth-cloth pairs come first in Scene_sliding.contact_analysis (:87)
+  }
   rebuild_pattern();
 }
 

@@ -141,6 +141,8 @@ struct Scene {
   int effector_cnt = -1;
   V3 gravity = V3(0, 0, -9.8);
   double mu_cloth_elastic = 1.0;
+  double mu_cloth_cloth = 1.0;  // Scene_sliding.py:25-27: second live friction parameter, nc1 = constraints of the cloth-cloth pairs
+  int nc1 = 0;
   std::vector<Cloth> cloths;
   std::vector<Elastic> elastics;
   Gripper gripper;
@@ -210,6 +212,7 @@ struct Scene {
   void compute_energy();
   void contact_energy(int diff, int spd);
   void contact_energy_backprop(Grad& g, int step, const double* p);
+  void contact_energy_backprop_friction(Grad& g, int step, const double* p);  // Scene_sliding.py:139-176
   void contact_pair_analysis(int b_idx, int v_start, int v_end, double mu);
   void contact_analysis();
   void calc_vn();
@@ -240,7 +243,8 @@ struct Grad {
   void transfer_grad(int step, Scene& sys);
   // analytic_grad_system.py: same reverse step with pos_grad clamped to +-1, no gripper gradient, and the parameter gradients
   int system_mode = 0, count_kb_grad = 1, count_mu_lam_grad = 0;
-  double grad_kb = 0, grad_mu = 0, grad_lam = 0;
+  double grad_kb = 0, grad_mu = 0, grad_lam = 0, grad_friction_coef = 0;
+  int count_friction_grad = 0;
   double& PG(int s, int i, int j) { return pos_grad[((size_t)s * tot_NV + i) * 3 + j]; }
   double& PB(int s, int i, int j) { return pos_buffer[((size_t)s * tot_NV + i) * 3 + j]; }
   double& AG(int s, int c, int f, int l) { return angleref_grad[(((size_t)s * cloth_cnt + c) * NF + f) * 3 + l]; }

@@ -573,7 +573,8 @@ void Grad::transfer_grad(int step, Scene& sys) {
   for (int i = 0; i < tot_NV; i++) for (int j = 0; j < 3; j++) x_hat_grad[i * 3 + j] = p[i * 3 + j] * mass[i] / (dt * dt);  // get_grad :81-92
   sys.contact_energy_backprop(*this, step - 1, p.data());
   for (int c = 0; c < cloth_cnt; c++) sys.cloths[c].ref_angle_backprop_x2a(*this, step, p.data(), c);
-  if (system_mode) {  // get_parameters_grad :69-80
+  if (system_mode && count_friction_grad) sys.contact_energy_backprop_friction(*this, step - 1, p.data());  // :150-151
+  else if (system_mode) {  // get_parameters_grad :69-80
     for (int i = 0; i < tot_NV; i++)
       for (int j = 0; j < 3; j++) {
         if (sys.frozen[i * 3 + j]) continue;

@@ -70,7 +70,7 @@ class SolveStats(C.Structure):
 EXPORTS = [
     "tsl_version", "tsl_last_error", "tsl_ctx_create", "tsl_ctx_destroy", "tsl_set_stream", "tsl_set_param", "tsl_set_frozen",
     "tsl_set_ext_force", "tsl_set_gravity", "tsl_energy", "tsl_assemble", "tsl_solve", "tsl_step", "tsl_contact_detect",
-    "tsl_contact_reset", "tsl_update_ref_angle", "tsl_adjoint_step", "tsl_param_grad", "tsl_elastic_force", "tsl_matrix_nnzb", "tsl_matrix_export",
+    "tsl_contact_reset", "tsl_update_ref_angle", "tsl_adjoint_step", "tsl_param_grad", "tsl_friction_grad", "tsl_elastic_force", "tsl_matrix_nnzb", "tsl_matrix_export",
     "tsl_constraints_export", "tsl_contact_blocks_export", "tsl_proj_export", "tsl_proj_import", "tsl_spd_project", "tsl_profile_reset", "tsl_profile_read", "tsl_profile_read_events",
 ]
 

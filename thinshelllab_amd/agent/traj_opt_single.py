@@ -45,27 +45,28 @@ class agent_trajopt:
             self.delta_pos.t[j] = dp
             self.delta_rot.t[j] = dr
 
-    # hand-scripted initial trajectories (traj_opt_single.py:50-109)
+    # hand-scripted initial trajectories (traj_opt_single.py:50-109); rows beyond tot_timestep are out-of-range writes in the
+    # reference and are dropped here
     def init_traj_forming(self):
         t = self.traj.t
-        for i in range(1, 20):
+        for i in range(1, min(20, t.shape[0])):
             t[i, 0, 2] = -0.00011 * i
             t[i, 0, 0] = t[i - 1, 0, 0] + 0.00023
-        for i in range(20, 35):
+        for i in range(20, min(35, t.shape[0])):
             t[i, 0, 2] = t[i - 1, 0, 2] - 0.0002
             t[i, 0, 0] = t[i - 1, 0, 0] + 0.00027
-        for i in range(35, 50):
+        for i in range(35, min(50, t.shape[0])):
             t[i, 0, 2] = t[i - 1, 0, 2]
             t[i, 0, 0] = t[i - 1, 0, 0] + 0.0002
 
     def init_traj_pick_fold(self):
         t = self.traj.t
-        for i in range(8):
+        for i in range(min(8, t.shape[0])):
             t[i, 0, 2] = -0.0006 * i
             t[i, 1, 2] = -0.0006 * i
             t[i, 0, 0] = t[i - 1, 0, 0]
             t[i, 1, 0] = t[i - 1, 1, 0]
-        for i in range(8, 50):
+        for i in range(8, min(50, t.shape[0])):
             t[i, 0, 2] = t[i - 1, 0, 2]; t[i, 1, 2] = t[i - 1, 1, 2]
             t[i, 0, 0] = t[i - 1, 0, 0]; t[i, 1, 0] = t[i - 1, 1, 0]
 
@@ -83,8 +84,8 @@ class agent_trajopt:
 
     def init_traj_slide(self):
         t = self.traj.t
-        for i in range(10):
+        for i in range(min(10, t.shape[0])):
             t[i, 0, 2] = -0.00035 * i
-        for i in range(10, 50):
+        for i in range(10, min(50, t.shape[0])):
             t[i, 0, 0] = t[i - 1, 0, 0] - 0.0005
             t[i, 0, 2] = t[i - 1, 0, 2]

@@ -56,9 +56,10 @@ class TslContext:
             bd[i] = Body(*[int(x) for x in b])
         pr = (ContactPair * max(len(pairs), 1))()
         for i, p in enumerate(pairs):
-            mu = p[3]
+            mu = p[3]   # float: fixed; None: live mu_cloth_elastic; "cloth_cloth": live mu_cloth_cloth
             factor = float(p[4]) if len(p) > 4 else 0.0
-            pr[i] = ContactPair(int(p[0]), int(p[1]), int(p[2]), 1 if mu is None else 0, factor if mu is None else float(mu))
+            kind = 0 if isinstance(mu, (int, float)) else (2 if mu == "cloth_cloth" else 1)
+            pr[i] = ContactPair(int(p[0]), int(p[1]), int(p[2]), kind, float(mu) if kind == 0 else factor)
         faces = _np(faces if faces is not None else np.zeros((0, 3)), np.int32)
         mass = _np(mass, np.float64); gravity = _np(gravity, np.float64); frozen = _np(frozen, np.int32)
         assert mass.shape == (tot_NV,) and gravity.shape == (tot_NV, 3) and frozen.shape == (3 * tot_NV,)
@@ -141,6 +142,11 @@ class TslContext:
     def elastic_force(self, pos, out):
         check(self.L.tsl_elastic_force(self.h, _ptr(pos), _ptr(out)), "tsl_elastic_force")
         return out
+
+    def friction_grad(self, pos):
+        out = C.c_double(0)
+        check(self.L.tsl_friction_grad(self.h, _ptr(pos), C.byref(out)), "tsl_friction_grad")
+        return out.value
 
     def param_grad(self, pos, ref_angle):
         """{kb, mu, lam} contributions of the last adjoint_step (system identification)"""

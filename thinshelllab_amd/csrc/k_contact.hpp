@@ -178,7 +178,8 @@ k_project_pair(GridArgs Gr, int v_start, int v_end, int body_idx, int NV, int nf
 __global__ void k_contact_pair(int b_idx, int v_start, int v_end, double mu, int NV, int max_nc, double k_contact, double eps_contact,
                                const double* __restrict__ pos, const double* __restrict__ prev, const int* __restrict__ proj_flag, const int* __restrict__ proj_dir,
                                const int* __restrict__ proj_idx, const double* __restrict__ proj_w, int* nc, int* __restrict__ c_idx, double* __restrict__ c_w,
-                               double* __restrict__ c_k, double* __restrict__ c_mu, double* __restrict__ c_dx0, double* __restrict__ c_T, double* __restrict__ c_n) {
+                               double* __restrict__ c_k, double* __restrict__ c_mu, double* __restrict__ c_dx0, double* __restrict__ c_T, double* __restrict__ c_n, int kind,
+                               int* __restrict__ c_kind) {
   const int i = v_start + blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= v_end) return;
   const size_t bi = (size_t)b_idx * NV + i;
@@ -202,6 +203,7 @@ __global__ void k_contact_pair(int b_idx, int v_start, int v_end, double mu, int
     c_w[3 * c] = w0; c_w[3 * c + 1] = w1; c_w[3 * c + 2] = w2;
     c_k[c] = -mu * cforce;
     c_mu[c] = mu;
+    c_kind[c] = kind;  // which friction parameter the pair uses (0 fixed, 1 mu_cloth_elastic, 2 mu_cloth_cloth)
     st3(c_dx0, c, ld3(prev, i) - x0_c);
     d3 t1 = (fabs(n_c.x) < 0.5) ? d3(n_c.x, n_c.z, -n_c.y) : d3(n_c.y, -n_c.x, n_c.z);
     const d3 t2 = cross(n_c, t1);
@@ -477,6 +479,36 @@ __global__ void k_contact_backprop(int nc, ContactArgs A, const double* __restri
   for (int k = 0; k < 4; k++) atomic_add3(pg, id[k], d3(acc[3 * k], acc[3 * k + 1], acc[3 * k + 2]));
 }
 
+// Scene_sliding.contact_energy_backprop_friction (Scene_sliding.py:139-176): d(loss)/d(mu_cloth_cloth) contribution of the
+// constraints whose pair uses that parameter (the reference loops over the first nc1 constraints = the cloth-cloth pairs):
+// sum over the free dofs of z * w1 * g1 / mu_cloth_cloth, g1 = T^T (k f1(r) u), w1 = (w0, w1, w2, -1).
+__global__ void k_contact_friction_grad(int nc, ContactArgs A, const int* __restrict__ kind, const int* __restrict__ frozen, const double* __restrict__ pos,
+                                        const double* __restrict__ z, double mu_cc, double* out) {
+  const int ci = blockIdx.x * blockDim.x + threadIdx.x;
+  double s = 0;
+  if (ci < nc && kind[ci] == 2) {
+    int id[4];
+    for (int k = 0; k < 4; k++) id[k] = A.idx[4 * ci + k];
+    const d3 x0 = ld3(pos, id[0]), xa = ld3(pos, id[1]), xb = ld3(pos, id[2]), xp = ld3(pos, id[3]);
+    const double w[3] = {A.w[3 * ci], A.w[3 * ci + 1], A.w[3 * ci + 2]};
+    const double kf = A.k[ci];
+    const double* T = A.T + 6 * (size_t)ci;
+    const d3 dx = xp - (x0 * w[0] + xa * w[1] + xb * w[2]) - ld3(A.dx0, ci);
+    const double u[2] = {T[0] * dx.x + T[1] * dx.y + T[2] * dx.z, T[3] * dx.x + T[4] * dx.y + T[5] * dx.z};
+    const double r = sqrt(u[0] * u[0] + u[1] * u[1]);
+    const double f1 = fr_f1(r, A.eps_vh);
+    const double wp[4] = {w[0], w[1], w[2], -1.0};
+    for (int i1 = 0; i1 < 4; i1++)
+      for (int j1 = 0; j1 < 3; j1++) {
+        if (frozen[3 * id[i1] + j1]) continue;
+        const double g1 = kf * f1 * (u[0] * T[j1] + u[1] * T[3 + j1]);
+        s += z[3 * (size_t)id[i1] + j1] * wp[i1] * g1 / mu_cc;
+      }
+  }
+  s = wave_sum(s);
+  if ((threadIdx.x & 63) == 0 && s != 0.0) atomicAdd(out, s);
+}
+
 // batched projections for unit tests
 __global__ void k_spd_batch(double* blocks, int n, int D) {
   const int i = blockIdx.x * blockDim.x + threadIdx.x;
@@ -513,7 +545,7 @@ static int contact_alloc(tsl_ctx* c, const tsl_scene_desc* d) {
   rc |= c->nc_dev.alloc(1);
   const size_t mc = (size_t)c->max_n_constraints;
   rc |= c->c_idx.alloc(mc * 4); rc |= c->c_w.alloc(mc * 3); rc |= c->c_n.alloc(mc * 3); rc |= c->c_dx0.alloc(mc * 3);
-  rc |= c->c_k.alloc(mc); rc |= c->c_mu.alloc(mc); rc |= c->c_T.alloc(mc * 6);
+  rc |= c->c_k.alloc(mc); rc |= c->c_mu.alloc(mc); rc |= c->c_T.alloc(mc * 6); rc |= c->c_kind.alloc(mc);
   rc |= c->c_H.alloc(mc * 144); rc |= c->c_Hfull.alloc(mc * 144); rc |= c->c_diag.alloc((size_t)NV * 9);
   int mbf = 1;
   for (auto& b : c->h_bodies) mbf = std::max(mbf, b.f_end - b.f_start);
@@ -575,9 +607,11 @@ extern "C" int tsl_contact_detect(tsl_ctx* c, const double* pos, const double* p
     const int nq = pr.v_end - pr.v_start;
     if (nq <= 0) continue;
     // parameter-driven pairs may carry a factor in mu (Scene_card.py:122-126: mu_cloth_elastic * 10 for the upper cards)
-    const double mu = pr.mu_is_param ? c->mu_cloth_elastic * (pr.mu > 0 ? pr.mu : 1.0) : pr.mu;
+    const double live = pr.mu_is_param == 2 ? c->mu_cloth_cloth : c->mu_cloth_elastic;  // Scene_sliding.py:80 has a second live parameter
+    const double mu = pr.mu_is_param ? live * (pr.mu > 0 ? pr.mu : 1.0) : pr.mu;
     hipLaunchKernelGGL(k_contact_pair, dim3(cnblk(nq, 128)), dim3(128), 0, s, pr.b_idx, pr.v_start, pr.v_end, mu, NV, c->max_n_constraints, c->k_contact, c->eps_contact, pos,
-                       prev, c->proj_flag.p, c->proj_dir.p, c->proj_idx.p, c->proj_w.p, c->nc_dev.p, c->c_idx.p, c->c_w.p, c->c_k.p, c->c_mu.p, c->c_dx0.p, c->c_T.p, c->c_n.p);
+                       prev, c->proj_flag.p, c->proj_dir.p, c->proj_idx.p, c->proj_w.p, c->nc_dev.p, c->c_idx.p, c->c_w.p, c->c_k.p, c->c_mu.p, c->c_dx0.p, c->c_T.p, c->c_n.p, pr.mu_is_param,
+                       c->c_kind.p);
   }
   int nc = 0;
   HIP_OK(hipMemcpyAsync(&nc, c->nc_dev.p, sizeof(int), hipMemcpyDeviceToHost, s));

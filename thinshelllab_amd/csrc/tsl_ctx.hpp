@@ -93,7 +93,7 @@ struct tsl_ctx {
   long mr_graph_key = -1;
   int use_graph = 1;
   int NV = 0, NF = 0;  // tot_NV, tot_NF
-  double dt = 5e-3, k_contact = 1000, eps_contact = 1e-3, eps_v = 0.01, damping = 1.0, mu_cloth_elastic = 1.0;
+  double dt = 5e-3, k_contact = 1000, eps_contact = 1e-3, eps_v = 0.01, damping = 1.0, mu_cloth_elastic = 1.0, mu_cloth_cloth = 1.0;
   int max_n_constraints = 10000;
   int newton_cap = 1000, plastic = 0, contact_enable = 1;
   double cg_tol = 1e-10;
@@ -183,6 +183,7 @@ struct tsl_ctx {
   int nc = 0;
   DevBuf<int> c_idx;                                  // max_nc x 4
   DevBuf<double> c_w, c_n, c_dx0, c_k, c_mu, c_T;     // 3,3,3,1,1,6
+  DevBuf<int> c_kind;                                 // friction parameter of the constraint's pair (0 fixed, 1 / 2 live)
   DevBuf<double> c_H;                                 // max_nc x 144 (12x12, masked) for the matrix-free product
   DevBuf<double> c_Hfull;                             // unmasked copy (adjoint)
   DevBuf<double> c_diag;                              // NV x 9 (permuted): masked contact contribution to the diagonal blocks

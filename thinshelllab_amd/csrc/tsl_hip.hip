@@ -295,6 +295,7 @@ extern "C" int tsl_set_param(tsl_ctx* c, const char* key, double v) {
   c->mg_omega_valid = false;
   std::string k(key);
   if (k == "mu_cloth_elastic") c->mu_cloth_elastic = v;
+  else if (k == "mu_cloth_cloth") c->mu_cloth_cloth = v;
   else if (k == "k_contact") c->k_contact = v;
   else if (k == "eps_contact") c->eps_contact = v;
   else if (k == "eps_v") c->eps_v = v;
@@ -1312,6 +1313,22 @@ extern "C" int tsl_elastic_force(tsl_ctx* c, const double* pos, double* force) {
   }
   HIP_OK(hipStreamSynchronize(s));
   HIP_OK(hipGetLastError());
+  return 0;
+}
+
+// ------------------------------------------------------------------------------------------------
+// Friction-coefficient gradient of the system-identification adjoint (Scene_sliding.contact_energy_backprop_friction,
+// Scene_sliding.py:139-176; called from analytic_grad_system.transfer_grad :150-151 instead of get_parameters_grad):
+// contribution of the last tsl_adjoint_step to d(loss)/d(mu_cloth_cloth).  pos = tape state x_s.
+extern "C" int tsl_friction_grad(tsl_ctx* c, const double* pos, double* out_host) {
+  Scope scope(c);
+  hipStream_t s = c->stream;
+  double* acc = &SC(c)->aux[0];
+  HIP_OK(hipMemsetAsync(acc, 0, sizeof(double), s));
+  if (c->nc > 0)
+    hipLaunchKernelGGL(k_contact_friction_grad, dim3(nblk(c->nc, 64)), dim3(64), 0, s, c->nc, contact_args(c), c->c_kind.p, c->frozen.p, pos, c->pdir.p, c->mu_cloth_cloth, acc);
+  HIP_OK(hipMemcpyAsync(out_host, acc, sizeof(double), hipMemcpyDeviceToHost, s));
+  HIP_OK(hipStreamSynchronize(s));
   return 0;
 }
 

@@ -300,6 +300,8 @@ class BaseScene:
                 k_contact=self.k_contact, eps_contact=self.eps_contact, eps_v=self.eps_v, damping=self.damping,
                 max_n_constraints=self.max_n_constraints, grid_h=self.grid_h, device=str(self.device))
             self._ctx.set_param("mu_cloth_elastic", self.mu_cloth_elastic.value)
+            if hasattr(self, "mu_cloth_cloth"):
+                self._ctx.set_param("mu_cloth_cloth", self.mu_cloth_cloth.value)
             if getattr(self, "grid_extent", None):
                 self._ctx.set_param("grid_extent", self.grid_extent)
             self._ctx.set_param("newton_cap", self._newton_cap)

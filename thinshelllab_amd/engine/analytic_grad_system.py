@@ -4,8 +4,8 @@
 Same tape and reverse step as ``analytic_grad_single.Grad`` (one ``tsl_adjoint_step`` per step) with the differences of the
 reference class: ``pos_grad`` is clamped to +-1 and nothing else (:104-109), there is no gripper gradient, and every step
 accumulates the parameter gradients ``grad_kb`` / ``grad_mu`` / ``grad_lam`` = sum over the free dofs of
-``p . d(force)/d(parameter)`` (:69-80, ``tsl_param_grad``).  ``grad_friction_coef`` belongs to ``Scene_sliding`` (:139-176 of that
-scene), which is outside the path built here; ``count_friction_grad`` therefore raises.
+``p . d(force)/d(parameter)`` (:69-80, ``tsl_param_grad``) or, with ``count_friction_grad``, the friction-coefficient gradient of
+``Scene_sliding`` (``contact_energy_backprop_friction``, Scene_sliding.py:139-176, ``tsl_friction_grad``).
 """
 import torch
 
@@ -66,22 +66,25 @@ class Grad:
         self.pos_grad.t[step].clamp_(-1, 1)
 
     def transfer_grad(self, step, sys, f_contact):  # :112-160
-        if self.count_friction_grad:
-            raise NotImplementedError("grad_friction_coef is computed by Scene_sliding.contact_energy_backprop_friction, which is not part of this build")
         ctx = sys._ensure_ctx()
         ctx.set_param("contact", 0.0 if f_contact is None else 1.0)
         ctx.set_param("adj_clamp", 1.0); ctx.set_param("adj_clamp_angleref", 0.0)
         try:
             self.last_stats = ctx.adjoint_step(step, self.tot_timestep, self.pos_buffer.t, self.pos_grad.t, self.ref_angle_buffer.t, self.angleref_grad.t,
                                                sys.tmp_z_frozen.t, self.damping)
-            g = ctx.param_grad(self.pos_buffer.t[step], self.ref_angle_buffer.t[step - 1])
+            if self.count_friction_grad:   # :150-153: either the friction coefficient or the stiffness parameters
+                self.grad_friction_coef[None] = self.grad_friction_coef[None] + ctx.friction_grad(self.pos_buffer.t[step])
+                g = dict(kb=0.0, mu=0.0, lam=0.0)
+            else:
+                g = ctx.param_grad(self.pos_buffer.t[step], self.ref_angle_buffer.t[step - 1])
         finally:
             ctx.set_param("adj_clamp", 1000.0); ctx.set_param("adj_clamp_angleref", 1.0)
-        if self.count_mu_lam_grad:
-            self.grad_mu[None] = self.grad_mu[None] + g["mu"]
-            self.grad_lam[None] = self.grad_lam[None] + g["lam"]
-        if self.count_kb_grad:
-            self.grad_kb[None] = self.grad_kb[None] + g["kb"]
+        if not self.count_friction_grad:
+            if self.count_mu_lam_grad:
+                self.grad_mu[None] = self.grad_mu[None] + g["mu"]
+                self.grad_lam[None] = self.grad_lam[None] + g["lam"]
+            if self.count_kb_grad:
+                self.grad_kb[None] = self.grad_kb[None] + g["kb"]
         sys.copy_pos_and_refangle(self, step)
 
     # ---- loss seeds
