@@ -16,6 +16,12 @@ def _scene(name):
         s.cloths[0].Kb[None] = 400.0          # trajopt_folding.py:50
         s.init_all()
         s.mu_cloth_elastic[None] = 5.0        # trajopt_folding.py:66
+    elif name == "forming":
+        from thinshelllab_amd.task_scene.Scene_forming import Scene
+        s = Scene(cloth_size=0.1)
+        s.cloths[0].Kb[None] = 200.0          # trajopt_forming.py:48
+        s.init_all()
+        s.mu_cloth_elastic[None] = 5.0        # trajopt_forming.py:66
     elif name == "lifting":
         from thinshelllab_amd.task_scene.Scene_lifting import Scene
         s = Scene(cloth_size=0.06)
@@ -107,7 +113,7 @@ def test_energy_gradient_hessian_with_contact(oracle, name, spd):
         oracle.set_spd_mode(0)
 
 
-@pytest.mark.parametrize("name", ["folding", "lifting", "balancing"])
+@pytest.mark.parametrize("name", ["folding", "lifting", "balancing", "forming"])
 def test_rollout_and_adjoint(oracle, name):
     """T steps with a moving gripper, then the reverse sweep: tape, pos_grad, angleref_grad and gripper_grad."""
     from thinshelllab_amd.engine.analytic_grad_single import Grad
@@ -138,6 +144,11 @@ def test_rollout_and_adjoint(oracle, name):
     if name == "folding":
         g.get_loss_fold(s, 1.0, -1.0)
         o.arr("grad.angleref_grad").reshape(g.angleref_grad.shape)[:] = g.angleref_grad.to_numpy()
+    if name == "forming":   # get_loss_push towards a shifted copy of the final pose overwrites the random seed on the cloth rows
+        c = s.cloths[0]
+        target = g.pos_buffer.to_numpy()[T - 1, c.offset:c.offset + c.NV] + np.array([1e-3, 0.0, -5e-4])
+        g.get_loss_push(s, target)
+        o.arr("grad.pos_grad", (T, NV, 3))[T - 1] = g.pos_grad.to_numpy()[T - 1]
     for st_ in range(T - 1, 0, -1):
         g.transfer_grad(st_, s, projection_query)
         o.grad_transfer(st_)
