@@ -218,42 +218,34 @@ TSL_DEV double block_reduce_partials(const double* __restrict__ part, int n, dou
   return t;
 }
 
+// beta = rz / rz_old is only known after the partial sums of the previous update kernel have been reduced; instead of reducing
+// first (1.5-2 us during which no matrix load is in flight) the kernel accumulates A z and A p_old separately, starts the loads of
+// the partials before the matrix loop and combines y = A z + beta A p_old afterwards.
 template <int WPS, bool NT>
 __global__ void __launch_bounds__(64 * WPS)
 k_pcg_spmv(int NV, int n_slices, const int* __restrict__ slice_off, const int* __restrict__ slice_len, const int* __restrict__ colidx,
            const double* __restrict__ vals, const double* __restrict__ z, const double* __restrict__ p_old, double* __restrict__ p_new,
            double* __restrict__ Ap, const double* __restrict__ part_rz, const double* __restrict__ part_rr, double* __restrict__ part_pAp,
            PcgScal* sc, int parity, int first, unsigned long long* prof) {
-  __shared__ double red[WPS][3][64];
-  __shared__ double sm[WPS + 1];
+  __shared__ double red[WPS][6][64];
+  __shared__ double s2[2][WPS];
   if (sc->flag) return;
   unsigned long long t_start = 0;
   if (prof) t_start = wall_clock64();
-  double rz, rr;
-  {  // both reductions in one pass (one LDS round trip)
+  // partial sums of r.z and r.r: loads issued now, consumed after the matrix loop
+  double v0 = 0, v1 = 0;
+  {
     const int n = sc->n_part2;
-    double v0 = 0, v1 = 0;
     for (int i = threadIdx.x; i < n; i += blockDim.x) { v0 += part_rz[i]; v1 += part_rr[i]; }
-    v0 = wave_sum(v0); v1 = wave_sum(v1);
-    __shared__ double s2[2][WPS];
-    if ((threadIdx.x & 63) == 0) { s2[0][threadIdx.x >> 6] = v0; s2[1][threadIdx.x >> 6] = v1; }
-    __syncthreads();
-    rz = 0; rr = 0;
-#pragma unroll
-    for (int q = 0; q < WPS; q++) { rz += s2[0][q]; rr += s2[1][q]; }
   }
-  if (rr <= sc->thresh2) {
-    if (blockIdx.x == 0 && threadIdx.x == 0) { sc->flag = 2; sc->rr_last = rr; }
-    return;
-  }
-  const double beta = first ? 0.0 : rz / sc->rzh[parity ^ 1];
-  if (blockIdx.x == 0 && threadIdx.x == 0) { sc->rzh[parity] = rz; sc->rr_last = rr; sc->rz_last = rz; sc->iters = sc->iters + 1; }
+  const double rz_old = first ? 1.0 : sc->rzh[parity ^ 1];
+  const double thresh2 = sc->thresh2;
   const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
   const int slice = blockIdx.x;
   const int off = slice_off[slice], len = slice_len[slice];
   const int* cp = colidx + off + lane;
   const double* vp = vals + (size_t)off * 9 + lane;
-  double y0 = 0, y1 = 0, y2 = 0;
+  double y0 = 0, y1 = 0, y2 = 0, q0 = 0, q1 = 0, q2 = 0;  // A z and A p_old
 #pragma unroll 2
   for (int k = w; k < len; k += WPS) {
     const double* a = vp + (size_t)k * 576;
@@ -268,20 +260,42 @@ k_pcg_spmv(int NV, int n_slices, const int* __restrict__ slice_off, const int* _
       c = cp[64 * k];
       a0 = a[0]; a1 = a[64]; a2 = a[128]; a3 = a[192]; a4 = a[256]; a5 = a[320]; a6 = a[384]; a7 = a[448]; a8 = a[512];
     }
-    d3 pj = ld3(z, c);
-    if (!first) pj = pj + beta * ld3(p_old, c);
-    y0 += a0 * pj.x + a1 * pj.y + a2 * pj.z;
-    y1 += a3 * pj.x + a4 * pj.y + a5 * pj.z;
-    y2 += a6 * pj.x + a7 * pj.y + a8 * pj.z;
+    const d3 zj = ld3(z, c);
+    y0 += a0 * zj.x + a1 * zj.y + a2 * zj.z;
+    y1 += a3 * zj.x + a4 * zj.y + a5 * zj.z;
+    y2 += a6 * zj.x + a7 * zj.y + a8 * zj.z;
+    if (!first) {
+      const d3 pj = ld3(p_old, c);
+      q0 += a0 * pj.x + a1 * pj.y + a2 * pj.z;
+      q1 += a3 * pj.x + a4 * pj.y + a5 * pj.z;
+      q2 += a6 * pj.x + a7 * pj.y + a8 * pj.z;
+    }
   }
-  if (WPS > 1) {
+  // finish the two reductions (one LDS round trip shared with the wave partials of the product)
+  v0 = wave_sum(v0); v1 = wave_sum(v1);
+  if (lane == 0) { s2[0][w] = v0; s2[1][w] = v1; }
+  if (WPS > 1 && w > 0) {
     red[w][0][lane] = y0; red[w][1][lane] = y1; red[w][2][lane] = y2;
-    __syncthreads();
+    red[w][3][lane] = q0; red[w][4][lane] = q1; red[w][5][lane] = q2;
   }
+  __syncthreads();
+  double rz = 0, rr = 0;
+#pragma unroll
+  for (int q = 0; q < WPS; q++) { rz += s2[0][q]; rr += s2[1][q]; }
+  if (rr <= thresh2) {
+    if (blockIdx.x == 0 && threadIdx.x == 0) { sc->flag = 2; sc->rr_last = rr; }
+    return;
+  }
+  const double beta = first ? 0.0 : rz / rz_old;
+  if (blockIdx.x == 0 && threadIdx.x == 0) { sc->rzh[parity] = rz; sc->rr_last = rr; sc->rz_last = rz; sc->iters = sc->iters + 1; }
   double acc = 0.0;
   if (w == 0) {
 #pragma unroll
-    for (int q = 1; q < WPS; q++) { y0 += red[q][0][lane]; y1 += red[q][1][lane]; y2 += red[q][2][lane]; }
+    for (int q = 1; q < WPS; q++) {
+      y0 += red[q][0][lane]; y1 += red[q][1][lane]; y2 += red[q][2][lane];
+      q0 += red[q][3][lane]; q1 += red[q][4][lane]; q2 += red[q][5][lane];
+    }
+    y0 += beta * q0; y1 += beta * q1; y2 += beta * q2;
     const int p = slice * 64 + lane;
     if (p < NV) {
       d3 pi = ld3(z, p);
