@@ -31,7 +31,10 @@ def oracle_from_scene(po, sys, check_init=True):
             ei = o.add_loaded(e.density, e.vertex, e.tet_mesh, e.surface_mesh)
         else:
             ei = o.add_box(e.dx * (int(e.n_cube.max()) - 1), *[int(x) for x in e.n_cube], density=e.density)
-        o.elastic_init(ei, *e._init_args)
+        if getattr(e, "_arch", 0.0):
+            o.elastic_init_arch(ei, *e._init_args[:3], e._arch)
+        else:
+            o.elastic_init(ei, *e._init_args)
     o.finalize()
     if getattr(sys, "grid_extent", None):
         o.set_scalar("grid_extent", sys.grid_extent)

@@ -116,6 +116,9 @@ class OracleScene:
     def elastic_init(self, ei, ox, oy, oz, flip=False):
         self.L.tslo_elastic_init(self.h, ei, C.c_double(ox), C.c_double(oy), C.c_double(oz), int(bool(flip)))
 
+    def elastic_init_arch(self, ei, ox, oy, oz, arch):
+        self.L.tslo_elastic_init_arch(self.h, ei, C.c_double(ox), C.c_double(oy), C.c_double(oz), C.c_double(arch))
+
     def finalize(self):
         self.L.tslo_finalize(self.h)
 

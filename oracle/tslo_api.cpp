@@ -100,6 +100,7 @@ void tslo_cloth_init(void* h, int ci, int mode, double ox, double oy, double oz,
 }
 void tslo_cloth_init_mesh(void* h, int ci) { S(h).cloths[ci].init_mesh(); }
 void tslo_elastic_init(void* h, int ei, double ox, double oy, double oz, int flip) { S(h).elastics[ei].init(ox, oy, oz, flip); }
+void tslo_elastic_init_arch(void* h, int ei, double ox, double oy, double oz, double arch) { S(h).elastics[ei].arch = arch; S(h).elastics[ei].init(ox, oy, oz, 0); }
 void tslo_finalize(void* h) { S(h).finalize(); S(h).init_property(); ((Handle*)h)->finalized = true; }
 void tslo_init_property(void* h) { S(h).init_property(); }
 void tslo_add_pair(void* h, int b_idx, int v_start, int v_end, int mu_is_param, double mu) { S(h).pairs.push_back(PairSpec{b_idx, v_start, v_end, mu_is_param, mu}); }

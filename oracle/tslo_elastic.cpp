@@ -140,6 +140,10 @@ void Elastic::init(double ox, double oy, double oz, int flip) {
   }
   // model_elastic_offset.py:232-250 init_pos
   for (int u = 0; u < n_verts; u++) { F_x[u] = F_ox[u]; F_v[u] = V3(); F_f[u] = V3(); F_m[u] = 0.0; }
+  if (kind == 1 && arch != 0.0)  // init_pos_arch (:259-260)
+    for (int x = 0; x < n_cube[0]; x++)
+      for (int y = 0; y < n_cube[1]; y++)
+        for (int z = 0; z < n_cube[2]; z++) F_x[(x * n_cube[1] + y) * n_cube[2] + z][2] += arch * std::sin((double)x / (double)(n_cube[0] - 1) * 3.1415926);
   for (int c = 0; c < n_cells; c++) {
     M3 F = Ds(F_vertices[c]);
     F_B[c] = inverse(F);

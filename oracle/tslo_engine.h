@@ -96,6 +96,7 @@ struct Elastic {
   void construct_box(double dt_, double Len, int offset_, int Nx, int Ny, int Nz, double density_);
   void construct_loaded(double dt_, int offset_, double density_, int nv, const double* nodes, int nc, const int* tets, int ns, const int* faces);
   void init(double ox, double oy, double oz, int flip);
+  double arch = 0;  // model_elastic_offset.py:253-270 init_pos_arch: z += arch sin(pi x / (Nx - 1)) before the rest matrices
   M3 Ds(const I4& verts) const { return from_cols(F_x[verts[0]] - F_x[verts[3]], F_x[verts[1]] - F_x[verts[3]], F_x[verts[2]] - F_x[verts[3]]); }
   bool is_bottom(int i) const { return F_ox[i][2] < 0.001 && is_surface[i]; }
   bool is_inner_circle(int i) const { return norm(F_ox[i]) < 0.0076 && is_surface[i]; }

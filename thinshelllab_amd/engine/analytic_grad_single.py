@@ -111,6 +111,15 @@ class Grad:
             fi, l = self._fold_rows(sys, ra, rb)
             ag[self.tot_timestep - 1, 0, torch.as_tensor(fi), torch.as_tensor(l)] = val
 
+    def get_loss_pick(self, sys):  # :323-327
+        c = sys.cloths[0]
+        sel = c.offset + np.nonzero(np.arange(c.NV) // (c.M + 1) == 8)[0]
+        self.pos_grad.t[:, torch.as_tensor(sel), 2] = -1
+
+    def get_loss_pick_fold(self, sys):  # :373-382
+        fi, l = self._fold_rows(sys, 7, 9)
+        self.angleref_grad.t[:, 0, torch.as_tensor(fi), torch.as_tensor(l)] = -1
+
     def get_loss_push(self, sys, target_pos):  # :296-300
         c = sys.cloths[0]
         j = self.tot_timestep - 1

@@ -141,6 +141,20 @@ class Elastic:
             self.init_pos(offsetx, offsety, offsetz)
             self.init_normal(offsetx, offsety, offsetz)
 
+    # -- :406-409 init_arch with init_pos_arch (:253-270): the rest configuration is an arch, z += arch sin(pi x / (Nx - 1))
+    def init_arch(self, offsetx, offsety, offsetz, arch):
+        self._init_args = (offsetx, offsety, offsetz, False)
+        self._arch = float(arch)
+        self.get_vertices()
+        ox = self.F_ox.to_numpy().copy()
+        I = np.arange(self.n_verts) // (self.n_cube[1] * self.n_cube[2])
+        ox[:, 2] += arch * np.sin(I.astype(np.float64) / float(self.n_cube[0] - 1) * 3.1415926)
+        flat = self.F_ox.to_numpy().copy()
+        self.F_ox.from_numpy(ox)          # init_pos computes the rest matrices and masses from F_ox
+        self.init_pos(offsetx, offsety, offsetz)
+        self.F_ox.from_numpy(flat)        # the reference leaves F_ox flat (only F_x carries the arch)
+        self.get_surface_indices()
+
     def _desc(self):
         return dict(kind=1, n_verts=self.n_verts, n_cells=self.n_cells, v_offset=self.offset, mu=self.mu.value, lam=self.lam.value, alpha=0.0,
                     tets=self.F_vertices.to_numpy(), B=self.F_B.to_numpy().reshape(-1, 9), W=self.F_W.to_numpy())
