@@ -249,6 +249,10 @@ class OracleScene:
         dp = np.ascontiguousarray(dpos, np.float64); dr = np.ascontiguousarray(drot, np.float64)
         self.L.tslo_action(self.h, _dp(dp), _dp(dr))
 
+    def action_dist(self, delta_pos, delta_rot, delta_dis):
+        dp = np.ascontiguousarray(delta_pos, np.float64); dr = np.ascontiguousarray(delta_rot, np.float64); dd = np.ascontiguousarray(delta_dis, np.float64)
+        self.L.tslo_action_dist(self.h, _dp(dp), _dp(dr), _dp(dd))
+
     def prepare_bending(self):
         self.L.tslo_prepare_bending(self.h)
 

@@ -151,6 +151,7 @@ void tslo_projection_query(void* h) { S(h).projection_query(); }
 void tslo_contact_analysis(void* h) { S(h).contact_analysis(); }
 int tslo_nc(void* h) { return S(h).nc; }
 void tslo_action(void* h, const double* dpos, const double* drot) { S(h).action(dpos, drot); }
+void tslo_action_dist(void* h, const double* dpos, const double* drot, const double* ddis) { S(h).action_dist(dpos, drot, ddis); }
 void tslo_update_ref_angle(void* h) { for (auto& c : S(h).cloths) c.update_ref_angle(); }
 void tslo_prepare_bending(void* h) { for (auto& c : S(h).cloths) { c.compute_normal_dir(); c.prepare_bending(); } }
 

@@ -126,6 +126,8 @@ struct Gripper {
   void step_simple(const double* delta_pos, const double* delta_rot);
   void update_bound(Scene& sys);
   void update_all(Scene& sys);  // gripper_single.py:158-162
+  std::vector<double> half_gripper_dist;
+  void step(const double* delta_pos, const double* delta_rot, const double* delta_dis);  // gripper_tactile.py:196-218
   void gather_grad(const double* grad, Scene& sys);
 };
 
@@ -228,6 +230,7 @@ struct Scene {
   void time_step();
   void update_vel();
   void action(const double* delta_pos, const double* delta_rot);
+  void action_dist(const double* delta_pos, const double* delta_rot, const double* delta_dis);  // Scene_interact.py:176-180 (step < 5)
 };
 
 struct Grad {

@@ -359,6 +359,16 @@ void Scene::action(const double* delta_pos, const double* delta_rot) {
   }
 }
 
+void Scene::action_dist(const double* delta_pos, const double* delta_rot, const double* delta_dis) {
+  gripper.step(delta_pos, delta_rot, delta_dis);
+  gripper.update_bound(*this);
+  for (size_t j = 1; j < elastics.size(); j++) {
+    auto& e = elastics[j];
+    if (e.kind != 0) continue;
+    for (int i = 0; i < e.n_verts; i++) pos[e.offset + i] = e.F_x[i];
+  }
+}
+
 // ---------------------------------------------------------------- grippers
 void Gripper::construct(int paired_, int n_verts_, int n_bound_, int n_surf_, int cnt) {
   paired = paired_; n_verts = n_verts_; n_bound = n_bound_; n_surf = n_surf_; n_part = cnt;
@@ -444,6 +454,19 @@ void Gripper::update_bound(Scene& sys) {
         sys.elastics[j * 2 + 2].F_x[bound_idx[i]] = F_x_lower_world[(size_t)j * n_verts + bound_idx[i]];
       }
     }
+}
+
+// gripper_tactile.py:196-218: rigid step plus open_gripper (local z of the upper pad += d, of the lower pad -= d)
+void Gripper::step(const double* delta_pos, const double* delta_rot, const double* delta_dis) {
+  if (half_gripper_dist.size() != (size_t)n_part) half_gripper_dist.assign(n_part, 0.0);
+  for (int j = 0; j < n_part; j++) {
+    half_gripper_dist[j] += delta_dis[j];
+    for (int i = 0; i < n_verts; i++) {
+      F_x[(size_t)j * n_verts + i][2] += delta_dis[j];
+      if (paired) F_x_lower[(size_t)j * n_verts + i][2] -= delta_dis[j];
+    }
+  }
+  step_simple(delta_pos, delta_rot);
 }
 
 // gripper_single.py:158-162

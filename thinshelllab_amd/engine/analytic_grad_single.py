@@ -111,6 +111,16 @@ class Grad:
             fi, l = self._fold_rows(sys, ra, rb)
             ag[self.tot_timestep - 1, 0, torch.as_tensor(fi), torch.as_tensor(l)] = val
 
+    def get_loss_interact(self, sys):  # :408-420
+        c = sys.cloths[0]; e = sys.elastics[3]
+        j = self.tot_timestep - 1
+        self.pos_grad.t[j, c.offset:c.offset + c.NV, 0] = 1
+        self.pos_grad.t[j, e.offset:e.offset + e.n_verts, 0] = -1 * 256.0 / 144.0
+
+    def get_loss_interact_1(self, sys):  # :422-426
+        e = sys.elastics[3]
+        self.pos_grad.t[self.tot_timestep - 1, e.offset:e.offset + e.n_verts, 0] = 1
+
     def get_loss_pick(self, sys):  # :323-327
         c = sys.cloths[0]
         sel = c.offset + np.nonzero(np.arange(c.NV) // (c.M + 1) == 8)[0]

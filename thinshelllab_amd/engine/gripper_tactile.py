@@ -76,6 +76,17 @@ class gripper:
         self.get_rotmat()
         self.get_vert_pos()
 
+    # :196-218 step + open_gripper: rigid motion plus a change of the pad distance (local z of the upper / lower pad)
+    def step(self, delta_pos, delta_rot, delta_dis):
+        dd = np.asarray(delta_dis.to_numpy() if isinstance(delta_dis, Field) else delta_dis, dtype=np.float64).reshape(-1)
+        up = self.F_x_upper.to_numpy(); lo = self.F_x_lower.to_numpy(); hd = self.half_gripper_dist.to_numpy()
+        for j in range(self.n_part):
+            hd[j] += dd[j]
+            up[j, :, 2] += dd[j]
+            lo[j, :, 2] -= dd[j]
+        self.F_x_upper.from_numpy(up); self.F_x_lower.from_numpy(lo); self.half_gripper_dist.from_numpy(hd)
+        self.step_simple(delta_pos, delta_rot)
+
     # :244-249
     def update_bound(self, sys):
         b = self.bound_idx.to_numpy().astype(np.int64)
