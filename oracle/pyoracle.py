@@ -280,6 +280,8 @@ class OracleScene:
 
     def grad_transfer(self, step):
         self.L.tslo_grad_transfer(self.h, int(step))
+        if self.stats()["flag"] == 3:   # PCG, BiCGStab and (n <= 4500) dense LU all failed: nothing to compare against
+            raise RuntimeError(f"oracle: the adjoint solve of step {step} did not converge")
 
     def grad_system(self, system_mode=True, count_kb=True, count_mu_lam=False, count_friction=False):
         """switch the reverse step to analytic_grad_system.Grad semantics (pos_grad clamp +-1, parameter gradients)"""

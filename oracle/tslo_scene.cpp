@@ -153,8 +153,12 @@ void Scene::newton_step_init() {
 // Solve H x = b.  Returns 0 ok, 1 fell back to BiCGStab, 2 fell back to dense LU, 3 not converged.
 // Stage 1: block-Jacobi PCG run directly on the assembled H (its non-symmetric part -- the area
 // block's factor-2 quirk -- is O(strain) small), restarted from the true residual until
-// |b - Hx| <= cg_tol |b|.  Stage 2 (CG breakdown p^T H p <= 0 or stagnation: the un-projected
-// adjoint Hessian may be indefinite): block-Jacobi BiCGStab.  Stage 3 (n <= 3000): dense LU.
+// |b - Hx| <= cg_tol |b|.  When cg_tol sits below the accuracy the system admits (the recurrence
+// residual converges, the true one stalls a little above the tolerance) the restarts run out: the best
+// iterate is kept and accepted within 10 cg_tol, the bound the BiCGStab stage applies as well.
+// Stage 2 (CG breakdown p^T H p <= 0 or no such iterate: the un-projected adjoint Hessian may be
+// indefinite): block-Jacobi BiCGStab.  Stage 3 (n <= 4500): dense LU.  A failed solve (3) returns the
+// best iterate seen; pyoracle raises on it so that a test never compares against it silently.
 int Scene::solve(const double* b, double* x) {
   int n = tot_NV * 3;
   stat_solves++;
@@ -189,11 +193,15 @@ int Scene::solve(const double* b, double* x) {
   if (bnorm == 0) return 0;
   bool need_fallback = false;
   int total_it = 0;
-  for (int outer = 0; outer < 20; outer++) {
+  std::vector<double> xbest(n, 0.0);
+  double rbest = bnorm;
+  for (int outer = 0; outer < 21; outer++) {
     H.matvec(x, Ap.data());
     for (int i = 0; i < n; i++) r[i] = b[i] - Ap[i];
     double rn = std::sqrt(ddot(r.data(), r.data()));
+    if (rn < rbest) { rbest = rn; std::copy(x, x + n, xbest.begin()); }
     if (rn <= cg_tol * bnorm) { need_fallback = false; break; }
+    if (outer == 20) break;
     if (outer > 0) stat_refine++;
     need_fallback = true;  // cleared when the true residual passes the test above
     precond(r.data(), z.data());
@@ -220,6 +228,7 @@ int Scene::solve(const double* b, double* x) {
     if (broke || total_it >= cg_maxit) break;
   }
   if (!need_fallback) return 0;
+  if (rbest <= 10 * cg_tol * bnorm) { std::copy(xbest.begin(), xbest.end(), x); return 0; }
   // ---- stage 2: preconditioned BiCGStab on H, restarted from x = 0
   {
     std::vector<double> r0(n), v(n), s(n), t(n), ph(n), sh(n);
@@ -255,7 +264,7 @@ int Scene::solve(const double* b, double* x) {
     if (ok) { last_solve_flag = 1; return 1; }
   }
   // ---- stage 3: dense LU with partial pivoting (small systems only)
-  if (n <= 3000) {
+  if (n <= 4500) {
     std::vector<double> A((size_t)n * n, 0.0), y(b, b + n);
     for (int bi = 0; bi < tot_NV; bi++)
       for (int k = H.row_ptr[bi]; k < H.row_ptr[bi + 1]; k++)
@@ -280,6 +289,12 @@ int Scene::solve(const double* b, double* x) {
     }
     last_solve_flag = 2;
     return 2;
+  }
+  {  // not converged: hand back the better of the two iterates
+    H.matvec(x, Ap.data());
+    double tr = 0;
+    for (int i = 0; i < n; i++) tr += (b[i] - Ap[i]) * (b[i] - Ap[i]);
+    if (!(std::sqrt(tr) < rbest)) std::copy(xbest.begin(), xbest.end(), x);
   }
   last_solve_flag = 3;
   return 3;

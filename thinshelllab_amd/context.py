@@ -4,6 +4,7 @@ State (pos / prev_pos / vel / ref_angle) stays in caller-owned torch tensors res
 class only passes ``data_ptr()``s.  torch is plumbing here (device memory, streams), not compute.
 """
 import ctypes as C
+import os
 
 import numpy as np
 import torch
@@ -73,6 +74,11 @@ class TslContext:
         self.dt = dt
         self.max_n_constraints = int(max_n_constraints)
         self.L.tsl_set_stream(self.h, C.c_void_p(torch.cuda.current_stream(self.device).cuda_stream))
+        # solver switches for A/B runs of unchanged drivers: TSL_PARAMS="key=value,key=value" (keys of tsl_set_param)
+        for kv in os.environ.get("TSL_PARAMS", "").split(","):
+            if "=" in kv:
+                k, v = kv.split("=", 1)
+                self.set_param(k.strip(), float(v))
 
     def close(self):
         if getattr(self, "h", None) is not None and self.h:

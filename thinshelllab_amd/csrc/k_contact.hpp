@@ -381,6 +381,24 @@ TSL_DEV double contact_matvec_lane(int nc, const int* __restrict__ idx, const in
   return s * xr;
 }
 
+// row -> (constraint, slot) lists for the SpMV kernels (ContactRows, k_solver.hpp): count, exclusive scan, fill
+__global__ void k_cr_count(int nc, const int* __restrict__ idx, const int* __restrict__ rowpos, int* __restrict__ cnt) {
+  const int q = blockIdx.x * blockDim.x + threadIdx.x;
+  if (q >= 4 * nc) return;
+  atomicAdd(&cnt[rowpos[idx[q]]], 1);
+}
+__global__ void k_cr_fill(int nc, const int* __restrict__ idx, const int* __restrict__ rowpos, const int* __restrict__ ptr, int* __restrict__ fill, int* __restrict__ ent,
+                          int4* __restrict__ rows) {
+  const int q = blockIdx.x * blockDim.x + threadIdx.x;
+  if (q >= 4 * nc) return;
+  const int c4 = q & ~3;
+  const int4 r = make_int4(rowpos[idx[c4]], rowpos[idx[c4 + 1]], rowpos[idx[c4 + 2]], rowpos[idx[c4 + 3]]);
+  const int p = (q & 3) == 0 ? r.x : (q & 3) == 1 ? r.y : (q & 3) == 2 ? r.z : r.w;
+  const int e = ptr[p] + atomicAdd(&fill[p], 1);
+  ent[e] = q;  // (constraint << 2) | slot
+  rows[e] = r;
+}
+
 // dot(x, H_c x) added to pAp[slot] (slot < 0: product only)
 __global__ void __launch_bounds__(CONTACT_MV_THREADS)
 k_contact_matvec(int nc, const int* __restrict__ idx, const int* __restrict__ rowpos, const double* __restrict__ Hm, const double* __restrict__ x,
@@ -619,6 +637,21 @@ extern "C" int tsl_contact_detect(tsl_ctx* c, const double* pos, const double* p
   HIP_OK(hipGetLastError());
   c->nc = std::min(nc, c->max_n_constraints);
   if (nc_host) *nc_host = c->nc;
+  if (c->nc > 0) {
+    const int n1 = NV + 1;
+    if (c->cr_ptr.n == 0) {
+      size_t tb = 0;
+      (void)hipcub::DeviceScan::ExclusiveSum(nullptr, tb, (int*)nullptr, (int*)nullptr, n1, s);
+      if (c->cr_ptr.alloc(n1) | c->cr_cnt.alloc(n1) | c->cr_fill.alloc(n1) | c->cr_ent.alloc(4 * (size_t)c->max_n_constraints) | c->cr_rows.alloc(4 * (size_t)c->max_n_constraints) | c->cr_tmp.alloc(tb + 16)) return -1;
+    }
+    HIP_OK(hipMemsetAsync(c->cr_cnt.p, 0, n1 * sizeof(int), s));
+    HIP_OK(hipMemsetAsync(c->cr_fill.p, 0, n1 * sizeof(int), s));
+    hipLaunchKernelGGL(k_cr_count, dim3(cnblk(4 * (long)c->nc, 256)), dim3(256), 0, s, c->nc, c->c_idx.p, c->rowpos.p, c->cr_cnt.p);
+    size_t tb = c->cr_tmp.n;
+    HIP_OK(hipcub::DeviceScan::ExclusiveSum(c->cr_tmp.p, tb, c->cr_cnt.p, c->cr_ptr.p, n1, s));
+    hipLaunchKernelGGL(k_cr_fill, dim3(cnblk(4 * (long)c->nc, 256)), dim3(256), 0, s, c->nc, c->c_idx.p, c->rowpos.p, c->cr_ptr.p, c->cr_fill.p, c->cr_ent.p, c->cr_rows.p);
+    HIP_OK(hipGetLastError());
+  }
   return 0;
 }
 

@@ -69,6 +69,48 @@ __global__ void k_scatter_perm(int NV, const int* __restrict__ perm, const doubl
   st3(out, perm[p], ld3(in, p));
 }
 
+// Matrix-free contact blocks folded into the SpMV kernels.  The constraint list is fixed within a time step, so contact detection
+// builds a row -> (constraint, slot) CSR once per step (k_contact.hpp).  The entries of the 64 rows of a slice are contiguous in
+// that CSR: ALL threads of the slice's workgroup share them (a pad vertex sits in ~100 constraints -- one lane per row serialises
+// them, measured 68-164 us) and accumulate into per-row LDS sums with ds atomics.  Three launches per PCG iteration (product, its
+// p.Ap partial, the two products of the V-cycle) disappear.  ptr == nullptr: no contacts.
+struct ContactRows {
+  const int* ptr;      // NV + 1 (permuted rows)
+  const int* ent;      // (constraint << 2) | slot, grouped by row
+  const int4* rows;    // permuted rows of the entry's four constraint vertices
+  const double* H;     // masked 12x12 blocks
+};
+// adds sum_b H_c[a][b] x[row_c[b]] of entries [e0, e1) (the rows [row0, row0 + 64) of the slice) into acc[k][row - row0] (k = 0..2),
+// optionally the same product with a second vector into acc[3 + k]; called by all threads of the workgroup, acc zeroed and
+// synchronised by the caller.  e0 / e1 are fetched at kernel entry so that slices without contacts pay one barrier only.
+template <int NVEC>
+TSL_DEV void contact_slice_add(const ContactRows& C, int e0, int e1, int row0, const double* __restrict__ x, const double* __restrict__ x2, double (*acc)[64]) {
+  for (int e = e0 + (int)threadIdx.x; e < e1; e += (int)blockDim.x) {
+    const int q = C.ent[e];
+    const int4 r4 = C.rows[e];
+    const int c = q >> 2, a = q & 3;
+    const double* H = C.H + 144 * (size_t)c + 36 * a;
+    const int pb[4] = {r4.x, r4.y, r4.z, r4.w};
+    const int l = pb[a] - row0;
+    double y0 = 0, y1 = 0, y2 = 0, q0 = 0, q1 = 0, q2 = 0;
+#pragma unroll
+    for (int b = 0; b < 4; b++) {
+      const d3 xb = ld3(x, pb[b]);
+      y0 += H[3 * b] * xb.x + H[3 * b + 1] * xb.y + H[3 * b + 2] * xb.z;
+      y1 += H[12 + 3 * b] * xb.x + H[12 + 3 * b + 1] * xb.y + H[12 + 3 * b + 2] * xb.z;
+      y2 += H[24 + 3 * b] * xb.x + H[24 + 3 * b + 1] * xb.y + H[24 + 3 * b + 2] * xb.z;
+      if (NVEC == 2) {
+        const d3 wb = ld3(x2, pb[b]);
+        q0 += H[3 * b] * wb.x + H[3 * b + 1] * wb.y + H[3 * b + 2] * wb.z;
+        q1 += H[12 + 3 * b] * wb.x + H[12 + 3 * b + 1] * wb.y + H[12 + 3 * b + 2] * wb.z;
+        q2 += H[24 + 3 * b] * wb.x + H[24 + 3 * b + 1] * wb.y + H[24 + 3 * b + 2] * wb.z;
+      }
+    }
+    atomicAdd(&acc[0][l], y0); atomicAdd(&acc[1][l], y1); atomicAdd(&acc[2][l], y2);
+    if (NVEC == 2) { atomicAdd(&acc[3][l], q0); atomicAdd(&acc[4][l], q1); atomicAdd(&acc[5][l], q2); }
+  }
+}
+
 // y = A x ; optionally accumulates dot(x, y) into *dot_out.  One lane per row, one wave per slice.
 // This is the dominant kernel of the engine (one launch per PCG iteration).
 __global__ void __launch_bounds__(256)
@@ -123,10 +165,17 @@ k_spmv(int NV, int n_slices, const int* __restrict__ slice_off, const int* __res
 template <int WPS, int SPB, bool NT>
 __global__ void __launch_bounds__(64 * WPS * SPB)
 k_spmv_mw(int NV, int n_slices, const int* __restrict__ slice_off, const int* __restrict__ slice_len, const int* __restrict__ colidx,
-          const double* __restrict__ vals, const double* __restrict__ x, double* __restrict__ y, double* __restrict__ part, const int* __restrict__ flag) {
+          const double* __restrict__ vals, const double* __restrict__ x, double* __restrict__ y, double* __restrict__ part, const int* __restrict__ flag,
+          ContactRows CR) {
   __shared__ double red[SPB][WPS][3][64];
   __shared__ double dred[SPB];
+  __shared__ double cacc[3][64];   // contact part (SPB == 1 only)
   if (flag && *flag) return;
+  int ce0 = 0, ce1 = 0;
+  if (SPB == 1 && CR.ptr) {
+    ce0 = CR.ptr[blockIdx.x * 64]; ce1 = CR.ptr[min((int)blockIdx.x * 64 + 64, NV)];
+    if (threadIdx.x < 192) cacc[threadIdx.x >> 6][threadIdx.x & 63] = 0.0;
+  }
   const int lane = threadIdx.x & 63;
   const int wv = threadIdx.x >> 6;
   const int sl = wv / WPS, w = wv % WPS;
@@ -160,12 +209,18 @@ k_spmv_mw(int NV, int n_slices, const int* __restrict__ slice_off, const int* __
     red[sl][w][0][lane] = y0; red[sl][w][1][lane] = y1; red[sl][w][2][lane] = y2;
     __syncthreads();
   }
+  if (SPB == 1 && ce1 > ce0) {   // uniform over the workgroup
+    if (WPS == 1) __syncthreads();
+    contact_slice_add<1>(CR, ce0, ce1, blockIdx.x * 64, x, nullptr, cacc);
+    __syncthreads();
+  }
   double acc = 0.0;
   if (w == 0 && slice < n_slices) {
     if (WPS > 1) {
 #pragma unroll
       for (int q = 1; q < WPS; q++) { y0 += red[sl][q][0][lane]; y1 += red[sl][q][1][lane]; y2 += red[sl][q][2][lane]; }
     }
+    if (SPB == 1 && ce1 > ce0) { y0 += cacc[0][lane]; y1 += cacc[1][lane]; y2 += cacc[2][lane]; }
     const int p = slice * 64 + lane;
     if (p < NV) {
       st3(y, p, d3(y0, y1, y2));
@@ -226,10 +281,16 @@ __global__ void __launch_bounds__(64 * WPS)
 k_pcg_spmv(int NV, int n_slices, const int* __restrict__ slice_off, const int* __restrict__ slice_len, const int* __restrict__ colidx,
            const double* __restrict__ vals, const double* __restrict__ z, const double* __restrict__ p_old, double* __restrict__ p_new,
            double* __restrict__ Ap, const double* __restrict__ part_rz, const double* __restrict__ part_rr, double* __restrict__ part_pAp,
-           PcgScal* sc, int parity, int first, unsigned long long* prof) {
+           PcgScal* sc, int parity, int first, unsigned long long* prof, ContactRows CR) {
   __shared__ double red[WPS][6][64];
   __shared__ double s2[2][WPS];
+  __shared__ double cacc[6][64];
   if (sc->flag) return;
+  int ce0 = 0, ce1 = 0;
+  if (CR.ptr) {
+    ce0 = CR.ptr[blockIdx.x * 64]; ce1 = CR.ptr[min((int)blockIdx.x * 64 + 64, NV)];
+    for (int i = threadIdx.x; i < 384; i += blockDim.x) cacc[i >> 6][i & 63] = 0.0;
+  }
   unsigned long long t_start = 0;
   if (prof) t_start = wall_clock64();
   // partial sums of r.z and r.r: loads issued now, consumed after the matrix loop
@@ -286,6 +347,11 @@ k_pcg_spmv(int NV, int n_slices, const int* __restrict__ slice_off, const int* _
     if (blockIdx.x == 0 && threadIdx.x == 0) { sc->flag = 2; sc->rr_last = rr; }
     return;
   }
+  if (ce1 > ce0) {   // uniform over the workgroup
+    if (first) contact_slice_add<1>(CR, ce0, ce1, slice * 64, z, nullptr, cacc);
+    else contact_slice_add<2>(CR, ce0, ce1, slice * 64, z, p_old, cacc);
+    __syncthreads();
+  }
   const double beta = first ? 0.0 : rz / rz_old;
   if (blockIdx.x == 0 && threadIdx.x == 0) { sc->rzh[parity] = rz; sc->rr_last = rr; sc->rz_last = rz; sc->iters = sc->iters + 1; }
   double acc = 0.0;
@@ -294,6 +360,10 @@ k_pcg_spmv(int NV, int n_slices, const int* __restrict__ slice_off, const int* _
     for (int q = 1; q < WPS; q++) {
       y0 += red[q][0][lane]; y1 += red[q][1][lane]; y2 += red[q][2][lane];
       q0 += red[q][3][lane]; q1 += red[q][4][lane]; q2 += red[q][5][lane];
+    }
+    if (ce1 > ce0) {
+      y0 += cacc[0][lane]; y1 += cacc[1][lane]; y2 += cacc[2][lane];
+      q0 += cacc[3][lane]; q1 += cacc[4][lane]; q2 += cacc[5][lane];
     }
     y0 += beta * q0; y1 += beta * q1; y2 += beta * q2;
     const int p = slice * 64 + lane;

@@ -183,6 +183,9 @@ struct tsl_ctx {
   int nc = 0;
   DevBuf<int> c_idx;                                  // max_nc x 4
   DevBuf<double> c_w, c_n, c_dx0, c_k, c_mu, c_T;     // 3,3,3,1,1,6
+  DevBuf<int> cr_ptr, cr_cnt, cr_fill, cr_ent;        // row -> (constraint, slot) CSR of the step's constraints (ContactRows)
+  DevBuf<int4> cr_rows;
+  DevBuf<unsigned char> cr_tmp;
   DevBuf<int> c_kind;                                 // friction parameter of the constraint's pair (0 fixed, 1 / 2 live)
   DevBuf<double> c_H;                                 // max_nc x 144 (12x12, masked) for the matrix-free product
   DevBuf<double> c_Hfull;                             // unmasked copy (adjoint)
@@ -199,6 +202,7 @@ struct tsl_ctx {
   int mg_pi_iters = 12;
   DevBuf<double> mg_omega0, mg_pi_part, mg_pi_norm;  // level 0
   int mg_nu = 1, mg_coarse_sweeps = 8, mg_fuse = 1, mg_max_levels = 16;
+  int contact_rows = 1;   // contact blocks folded into the SpMV kernels (0: separate k_contact_matvec launches)
   bool mg_ops_valid = false, mg_suspended = false, mg_omega_valid = false;
 
   // ---- profiling of the dominant kernel
