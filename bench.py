@@ -238,7 +238,11 @@ def main():
         out["roofline"] = {"bound": "hbm", "achieved": ach, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": ach / HBM_PEAK_GBS, "traffic": traffic,
                            "kernel": "k_pcg_spmv (SELL-64 3x3-block SpMV fused with the PCG direction update and p.Ap, one launch per PCG iteration)",
                            "bytes_per_launch": prof["bytes_per_launch"], "avg_launch_us": prof["ms_per_launch"] * 1e3,
-                           "avg_launch_us_hip_events": prof["ms_per_launch_events"] * 1e3, "launches": prof["launches"]}
+                           "avg_launch_us_hip_events": prof["ms_per_launch_events"] * 1e3, "launches": prof["launches"],
+                           "timing": "avg_launch_us = min wave start -> max wave end of sampled launches on the constant-rate device clock (inside the "
+                                     "hipGraph replays, agrees with the rocprofv3 kernel-trace average under profiles/); avg_launch_us_hip_events = "
+                                     "hipEvent pairs on the library's stream around single K1 launches of eagerly issued sample chunks, which adds the "
+                                     "event / dispatch overhead of a 15 us kernel"}
     if rank == 0:
         if world == 1 and not args.no_cpu_baseline:
             try:

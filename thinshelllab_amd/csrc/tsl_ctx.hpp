@@ -217,6 +217,8 @@ struct tsl_ctx {
   long prof_dev_n = 0;
   std::vector<std::pair<hipEvent_t, hipEvent_t>> ev_pool;
   size_t ev_used = 0;
+  long prof_chunks = 0;
+  bool ev_sample_next = false;
 
   // stats
   tsl_step_stats step_stats{};

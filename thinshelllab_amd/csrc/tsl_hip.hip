@@ -751,8 +751,13 @@ static void launch_pcg_iteration(tsl_ctx* c, int parity, int first, unsigned lon
   const int NV = c->NV, ns = c->n_slices;
   double* p_new = parity ? c->v_t0.p : c->v_p.p;
   const double* p_old = parity ? c->v_p.p : c->v_t0.p;
+  // profiling: a chunk launched eagerly for that purpose brackets its first K1 with a hipEvent pair on this stream
+  const bool ev = c->ev_sample_next && c->ev_used < c->ev_pool.size();
+  c->ev_sample_next = false;
+  if (ev) (void)hipEventRecord(c->ev_pool[c->ev_used].first, s);
   hipLaunchKernelGGL((k_pcg_spmv<PCG_WPS, TSL_NT>), dim3(ns), dim3(64 * PCG_WPS), 0, s, NV, ns, c->slice_off.p, c->slice_len.p, c->colidx.p, c->vals.p, c->v_z.p, p_old, p_new,
                      c->v_Ap.p, c->part_rz.p, c->part_rr.p, c->part_pAp.p, PSC(c), parity, first, dprof, contact_rows(c, c->c_H.p));
+  if (ev) { (void)hipEventRecord(c->ev_pool[c->ev_used].second, s); c->ev_used++; }
   if (c->nc > 0 && !c->contact_rows)  // separate launch (A/B switch "contact_rows" = 0)
     hipLaunchKernelGGL(k_contact_matvec_part, dim3(nblk(c->nc, 64)), dim3(CONTACT_MV_THREADS), 0, s, c->nc, c->c_idx.p, c->rowpos.p, c->c_H.p, p_new, c->v_Ap.p, c->part_pAp.p + ns,
                        &PSC(c)->flag);
@@ -879,14 +884,18 @@ static int solve_perm(tsl_ctx* c, tsl_solve_stats* st) {
     if (graph) TSL_TRY(pcg_chunk_graph(c, chunk));
     int n_chunks = 0;
     while (total_it < c->cg_maxit) {
-      if (graph) HIP_OK(hipGraphLaunch(c->pcg_graph, s));
+      // every 32nd chunk of a profiled run is launched kernel by kernel so that one K1 can be timed with hipEvents
+      const bool ev_chunk = graph && c->prof_enable && (c->prof_chunks++ % 32 == 16);
+      if (graph && !ev_chunk) HIP_OK(hipGraphLaunch(c->pcg_graph, s));
       else {
+        c->ev_sample_next = ev_chunk;
         for (int i = 0; i < chunk; i++) launch_pcg_iteration(c, (i & 1) ^ 1, 0, nullptr);
         hipLaunchKernelGGL(k_pcg_check, dim3(1), dim3(256), 0, s, c->part_rr.p, PSC(c));
       }
       it += chunk; total_it += chunk; c->prof_launches += chunk;
       TSL_TRY(read_scal(c));
-      if (graph && c->prof_enable && (n_chunks++ % 8 == 0)) TSL_TRY(prof_sample_graph(c));
+      if (c->ev_used >= c->ev_pool.size() / 2) prof_collect(c);
+      if (graph && !ev_chunk && c->prof_enable && (n_chunks++ % 8 == 0)) TSL_TRY(prof_sample_graph(c));
       flag = HPSC(c)->flag;
       if (flag) break;
     }
@@ -1476,7 +1485,7 @@ extern "C" int tsl_matrix_export(tsl_ctx* c, int32_t* row_ptr, int32_t* col, dou
 }
 
 extern "C" int tsl_profile_reset(tsl_ctx* c, int enable) {
-  c->prof_enable = enable; c->prof_ms = 0; c->prof_launches = 0; c->prof_samples = 0; c->ev_used = 0; c->prof_dev_used = 0; c->prof_dev_ticks = 0; c->prof_dev_n = 0;
+  c->prof_enable = enable; c->prof_ms = 0; c->prof_chunks = 0; c->ev_sample_next = false; c->prof_launches = 0; c->prof_samples = 0; c->ev_used = 0; c->prof_dev_used = 0; c->prof_dev_ticks = 0; c->prof_dev_n = 0;
   if (enable) {
     c->prof_waves = (size_t)c->n_slices * PCG_WPS;
     c->prof_dev_cap = 1;
