@@ -411,23 +411,6 @@ k_contact_matvec(int nc, const int* __restrict__ idx, const int* __restrict__ ro
   }
 }
 
-// same product for the two-kernel PCG: dot(x, H_c x) goes to a per-block partial (deterministic reduction)
-__global__ void __launch_bounds__(CONTACT_MV_THREADS)
-k_contact_matvec_part(int nc, const int* __restrict__ idx, const int* __restrict__ rowpos, const double* __restrict__ Hm, const double* __restrict__ x,
-                      double* __restrict__ y, double* __restrict__ part, const int* __restrict__ flag) {
-  __shared__ double sw[CONTACT_MV_THREADS / 64];
-  if (*flag) return;
-  double acc = contact_matvec_lane(nc, idx, rowpos, Hm, x, y);
-  acc = wave_sum(acc);
-  if ((threadIdx.x & 63) == 0) sw[threadIdx.x >> 6] = acc;
-  __syncthreads();
-  if (threadIdx.x == 0) {
-    double t = 0;
-#pragma unroll
-    for (int q = 0; q < CONTACT_MV_THREADS / 64; q++) t += sw[q];
-    part[blockIdx.x] = t;
-  }
-}
 
 // tmp_z_frozen[j] -= H_ij z_i for i free, j frozen (second compute_Hessian pass of transfer_grad,
 // BaseScene.py:403-405 / analytic_grad_single.py:239-243), contact part; z, out in ORIGINAL order

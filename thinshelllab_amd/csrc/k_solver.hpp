@@ -157,6 +157,53 @@ k_spmv(int NV, int n_slices, const int* __restrict__ slice_off, const int* __res
   }
 }
 
+// Product of one wave's share of a SELL slice (block columns k = w, w + WPS, ...) in explicit phases: the column ids of SELL_U
+// columns, then their 9 * SELL_U value loads, then the gathers, then the arithmetic.  Written as a plain loop the compiler waits for
+// the gathers of column k before it issues the loads of column k + WPS (vmcnt counts in order), which costs two memory latencies per
+// column on rows that only have 9-13 blocks (3-4 columns per wave): measured 16 us for the fused PCG kernel against ~10 us phased.
+// Columns past the end of the slice repeat a valid one with weight 0 (cached reloads, no branches).  NVEC = 2 also accumulates
+// the product with a second vector (q).
+#define SELL_U 4
+template <int NVEC, int WPS, bool NT>
+TSL_DEV void sell_wave_product(const int* __restrict__ cp, const double* __restrict__ vp, int len, int w, const double* __restrict__ x, const double* __restrict__ x2,
+                               double& y0, double& y1, double& y2, double& q0, double& q1, double& q2) {
+  for (int k0 = w; k0 < len; k0 += SELL_U * WPS) {
+    int kk[SELL_U], c[SELL_U];
+    double m[SELL_U];
+#pragma unroll
+    for (int u = 0; u < SELL_U; u++) {
+      const int k = k0 + u * WPS;
+      kk[u] = k < len ? k : k0;
+      m[u] = k < len ? 1.0 : 0.0;
+      c[u] = NT ? __builtin_nontemporal_load(cp + 64 * kk[u]) : cp[64 * kk[u]];
+    }
+    double a[SELL_U][9];
+#pragma unroll
+    for (int u = 0; u < SELL_U; u++) {
+      const double* ap = vp + (size_t)kk[u] * 576;
+#pragma unroll
+      for (int e = 0; e < 9; e++) a[u][e] = NT ? __builtin_nontemporal_load(ap + 64 * e) : ap[64 * e];
+    }
+    d3 xj[SELL_U], wj[SELL_U];
+#pragma unroll
+    for (int u = 0; u < SELL_U; u++) {
+      xj[u] = ld3(x, c[u]);
+      if (NVEC == 2) wj[u] = ld3(x2, c[u]);
+    }
+#pragma unroll
+    for (int u = 0; u < SELL_U; u++) {
+      y0 += m[u] * (a[u][0] * xj[u].x + a[u][1] * xj[u].y + a[u][2] * xj[u].z);
+      y1 += m[u] * (a[u][3] * xj[u].x + a[u][4] * xj[u].y + a[u][5] * xj[u].z);
+      y2 += m[u] * (a[u][6] * xj[u].x + a[u][7] * xj[u].y + a[u][8] * xj[u].z);
+      if (NVEC == 2) {
+        q0 += m[u] * (a[u][0] * wj[u].x + a[u][1] * wj[u].y + a[u][2] * wj[u].z);
+        q1 += m[u] * (a[u][3] * wj[u].x + a[u][4] * wj[u].y + a[u][5] * wj[u].z);
+        q2 += m[u] * (a[u][6] * wj[u].x + a[u][7] * wj[u].y + a[u][8] * wj[u].z);
+      }
+    }
+  }
+}
+
 // Variant with WPS waves per slice: wave w of a slice handles block columns k = w, w+WPS, ... (more loads in flight per
 // row: 784 single-wave slices cannot fill 1024 SIMDs at 100k triangles), partial row sums are combined through LDS.
 // NT: matrix values / column ids are streamed with non-temporal loads so that they do not evict the x vector from L2.
@@ -185,25 +232,8 @@ k_spmv_mw(int NV, int n_slices, const int* __restrict__ slice_off, const int* __
     const int off = slice_off[slice], len = slice_len[slice];
     const int* cp = colidx + off + lane;
     const double* vp = vals + (size_t)off * 9 + lane;
-#pragma unroll 2
-    for (int k = w; k < len; k += WPS) {
-      const double* a = vp + (size_t)k * 576;
-      int c;
-      double a0, a1, a2, a3, a4, a5, a6, a7, a8;
-      if (NT) {
-        c = __builtin_nontemporal_load(cp + 64 * k);
-        a0 = __builtin_nontemporal_load(a); a1 = __builtin_nontemporal_load(a + 64); a2 = __builtin_nontemporal_load(a + 128);
-        a3 = __builtin_nontemporal_load(a + 192); a4 = __builtin_nontemporal_load(a + 256); a5 = __builtin_nontemporal_load(a + 320);
-        a6 = __builtin_nontemporal_load(a + 384); a7 = __builtin_nontemporal_load(a + 448); a8 = __builtin_nontemporal_load(a + 512);
-      } else {
-        c = cp[64 * k];
-        a0 = a[0]; a1 = a[64]; a2 = a[128]; a3 = a[192]; a4 = a[256]; a5 = a[320]; a6 = a[384]; a7 = a[448]; a8 = a[512];
-      }
-      const d3 xj = ld3(x, c);
-      y0 += a0 * xj.x + a1 * xj.y + a2 * xj.z;
-      y1 += a3 * xj.x + a4 * xj.y + a5 * xj.z;
-      y2 += a6 * xj.x + a7 * xj.y + a8 * xj.z;
-    }
+    double u0 = 0, u1 = 0, u2 = 0;
+    sell_wave_product<1, WPS, NT>(cp, vp, len, w, x, nullptr, y0, y1, y2, u0, u1, u2);
   }
   if (WPS > 1) {
     red[sl][w][0][lane] = y0; red[sl][w][1][lane] = y1; red[sl][w][2][lane] = y2;
@@ -273,23 +303,26 @@ TSL_DEV double block_reduce_partials(const double* __restrict__ part, int n, dou
   return t;
 }
 
-// beta = rz / rz_old is only known after the partial sums of the previous update kernel have been reduced; instead of reducing
-// first (1.5-2 us during which no matrix load is in flight) the kernel accumulates A z and A p_old separately, starts the loads of
-// the partials before the matrix loop and combines y = A z + beta A p_old afterwards.
+// beta = rz / rz_old is only known after the partial sums of the previous update kernel have been reduced.  Instead of reducing
+// first (1.5-2 us during which no matrix load is in flight) the kernel starts the loads of the partials before the matrix loop,
+// forms A z, and finishes with the recurrence  A p_new = A z + beta A p_old  on its own rows (Ap still holds A p_old from the
+// previous iteration; the first iteration of every (re)start writes A z itself, so the recurrence never runs longer than one
+// restart interval and the true-residual test of the restart loop bounds its drift).  Gathering p_old a second time to form
+// A p_old from scratch cost 3.5 us per launch (13.7 MB of L2 traffic).
 template <int WPS, bool NT>
 __global__ void __launch_bounds__(64 * WPS)
 k_pcg_spmv(int NV, int n_slices, const int* __restrict__ slice_off, const int* __restrict__ slice_len, const int* __restrict__ colidx,
            const double* __restrict__ vals, const double* __restrict__ z, const double* __restrict__ p_old, double* __restrict__ p_new,
            double* __restrict__ Ap, const double* __restrict__ part_rz, const double* __restrict__ part_rr, double* __restrict__ part_pAp,
            PcgScal* sc, int parity, int first, unsigned long long* prof, ContactRows CR) {
-  __shared__ double red[WPS][6][64];
+  __shared__ double red[WPS][3][64];
   __shared__ double s2[2][WPS];
-  __shared__ double cacc[6][64];
+  __shared__ double cacc[3][64];
   if (sc->flag) return;
   int ce0 = 0, ce1 = 0;
   if (CR.ptr) {
     ce0 = CR.ptr[blockIdx.x * 64]; ce1 = CR.ptr[min((int)blockIdx.x * 64 + 64, NV)];
-    for (int i = threadIdx.x; i < 384; i += blockDim.x) cacc[i >> 6][i & 63] = 0.0;
+    if (threadIdx.x < 192) cacc[threadIdx.x >> 6][threadIdx.x & 63] = 0.0;
   }
   unsigned long long t_start = 0;
   if (prof) t_start = wall_clock64();
@@ -303,42 +336,22 @@ k_pcg_spmv(int NV, int n_slices, const int* __restrict__ slice_off, const int* _
   const double thresh2 = sc->thresh2;
   const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
   const int slice = blockIdx.x;
+  const int prow = slice * 64 + lane;
+  // own-row operands of the final combine (wave 0): in flight during the matrix loop
+  d3 zi(0, 0, 0), poi(0, 0, 0), apo(0, 0, 0);
+  if (w == 0 && prow < NV) {
+    zi = ld3(z, prow);
+    if (!first) { poi = ld3(p_old, prow); apo = ld3(Ap, prow); }
+  }
   const int off = slice_off[slice], len = slice_len[slice];
   const int* cp = colidx + off + lane;
   const double* vp = vals + (size_t)off * 9 + lane;
-  double y0 = 0, y1 = 0, y2 = 0, q0 = 0, q1 = 0, q2 = 0;  // A z and A p_old
-#pragma unroll 2
-  for (int k = w; k < len; k += WPS) {
-    const double* a = vp + (size_t)k * 576;
-    int c;
-    double a0, a1, a2, a3, a4, a5, a6, a7, a8;
-    if (NT) {
-      c = __builtin_nontemporal_load(cp + 64 * k);
-      a0 = __builtin_nontemporal_load(a); a1 = __builtin_nontemporal_load(a + 64); a2 = __builtin_nontemporal_load(a + 128);
-      a3 = __builtin_nontemporal_load(a + 192); a4 = __builtin_nontemporal_load(a + 256); a5 = __builtin_nontemporal_load(a + 320);
-      a6 = __builtin_nontemporal_load(a + 384); a7 = __builtin_nontemporal_load(a + 448); a8 = __builtin_nontemporal_load(a + 512);
-    } else {
-      c = cp[64 * k];
-      a0 = a[0]; a1 = a[64]; a2 = a[128]; a3 = a[192]; a4 = a[256]; a5 = a[320]; a6 = a[384]; a7 = a[448]; a8 = a[512];
-    }
-    const d3 zj = ld3(z, c);
-    y0 += a0 * zj.x + a1 * zj.y + a2 * zj.z;
-    y1 += a3 * zj.x + a4 * zj.y + a5 * zj.z;
-    y2 += a6 * zj.x + a7 * zj.y + a8 * zj.z;
-    if (!first) {
-      const d3 pj = ld3(p_old, c);
-      q0 += a0 * pj.x + a1 * pj.y + a2 * pj.z;
-      q1 += a3 * pj.x + a4 * pj.y + a5 * pj.z;
-      q2 += a6 * pj.x + a7 * pj.y + a8 * pj.z;
-    }
-  }
+  double y0 = 0, y1 = 0, y2 = 0, u0 = 0, u1 = 0, u2 = 0;
+  sell_wave_product<1, WPS, NT>(cp, vp, len, w, z, nullptr, y0, y1, y2, u0, u1, u2);
   // finish the two reductions (one LDS round trip shared with the wave partials of the product)
   v0 = wave_sum(v0); v1 = wave_sum(v1);
   if (lane == 0) { s2[0][w] = v0; s2[1][w] = v1; }
-  if (WPS > 1 && w > 0) {
-    red[w][0][lane] = y0; red[w][1][lane] = y1; red[w][2][lane] = y2;
-    red[w][3][lane] = q0; red[w][4][lane] = q1; red[w][5][lane] = q2;
-  }
+  if (WPS > 1 && w > 0) { red[w][0][lane] = y0; red[w][1][lane] = y1; red[w][2][lane] = y2; }
   __syncthreads();
   double rz = 0, rr = 0;
 #pragma unroll
@@ -348,8 +361,7 @@ k_pcg_spmv(int NV, int n_slices, const int* __restrict__ slice_off, const int* _
     return;
   }
   if (ce1 > ce0) {   // uniform over the workgroup
-    if (first) contact_slice_add<1>(CR, ce0, ce1, slice * 64, z, nullptr, cacc);
-    else contact_slice_add<2>(CR, ce0, ce1, slice * 64, z, p_old, cacc);
+    contact_slice_add<1>(CR, ce0, ce1, slice * 64, z, nullptr, cacc);
     __syncthreads();
   }
   const double beta = first ? 0.0 : rz / rz_old;
@@ -357,22 +369,14 @@ k_pcg_spmv(int NV, int n_slices, const int* __restrict__ slice_off, const int* _
   double acc = 0.0;
   if (w == 0) {
 #pragma unroll
-    for (int q = 1; q < WPS; q++) {
-      y0 += red[q][0][lane]; y1 += red[q][1][lane]; y2 += red[q][2][lane];
-      q0 += red[q][3][lane]; q1 += red[q][4][lane]; q2 += red[q][5][lane];
-    }
-    if (ce1 > ce0) {
-      y0 += cacc[0][lane]; y1 += cacc[1][lane]; y2 += cacc[2][lane];
-      q0 += cacc[3][lane]; q1 += cacc[4][lane]; q2 += cacc[5][lane];
-    }
-    y0 += beta * q0; y1 += beta * q1; y2 += beta * q2;
-    const int p = slice * 64 + lane;
-    if (p < NV) {
-      d3 pi = ld3(z, p);
-      if (!first) pi = pi + beta * ld3(p_old, p);
-      st3(p_new, p, pi);
-      st3(Ap, p, d3(y0, y1, y2));
-      acc = pi.x * y0 + pi.y * y1 + pi.z * y2;
+    for (int q = 1; q < WPS; q++) { y0 += red[q][0][lane]; y1 += red[q][1][lane]; y2 += red[q][2][lane]; }
+    if (ce1 > ce0) { y0 += cacc[0][lane]; y1 += cacc[1][lane]; y2 += cacc[2][lane]; }
+    if (prow < NV) {
+      const d3 pi = zi + beta * poi;
+      const d3 ap = d3(y0, y1, y2) + beta * apo;
+      st3(p_new, prow, pi);
+      st3(Ap, prow, ap);
+      acc = dot(pi, ap);
     }
     acc = wave_sum(acc);
     if (lane == 0) part_pAp[blockIdx.x] = acc;

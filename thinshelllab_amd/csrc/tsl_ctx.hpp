@@ -202,7 +202,6 @@ struct tsl_ctx {
   int mg_pi_iters = 12;
   DevBuf<double> mg_omega0, mg_pi_part, mg_pi_norm;  // level 0
   int mg_nu = 1, mg_coarse_sweeps = 8, mg_fuse = 1, mg_max_levels = 16;
-  int contact_rows = 1;   // contact blocks folded into the SpMV kernels (0: separate k_contact_matvec launches)
   bool mg_ops_valid = false, mg_suspended = false, mg_omega_valid = false;
 
   // ---- profiling of the dominant kernel

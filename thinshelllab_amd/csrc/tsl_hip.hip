@@ -320,7 +320,6 @@ extern "C" int tsl_set_param(tsl_ctx* c, const char* key, double v) {
   else if (k == "mg") c->mg_enable = (int)v;
   else if (k == "mg_omega") c->mg_omega = v;
   else if (k == "mg_fuse") c->mg_fuse = (int)v;
-  else if (k == "contact_rows") c->contact_rows = (int)v;
   else if (k == "mg_max_levels") c->mg_max_levels = (int)v;
   else if (k == "mg_pi_iters") c->mg_pi_iters = (int)v;
   else if (k == "graph") c->use_graph = (int)v;
@@ -456,14 +455,14 @@ extern "C" int tsl_assemble(tsl_ctx* c, const double* pos, const double* prev, c
 // contact rows of the current constraint set with the given 12x12 blocks (ptr = null: no contacts)
 static ContactRows contact_rows(tsl_ctx* c, const double* blocks) {
   ContactRows R;
-  R.ptr = (c->nc > 0 && c->contact_rows) ? c->cr_ptr.p : (const int*)nullptr;
+  R.ptr = c->nc > 0 ? c->cr_ptr.p : (const int*)nullptr;
   R.ent = c->cr_ent.p; R.rows = c->cr_rows.p; R.H = blocks;
   return R;
 }
 
 static void launch_spmv(tsl_ctx* c, const double* vals, const double* x, double* y, int slot, int check_flag, bool full_contact = false) {
   hipStream_t s = c->stream;
-  if (slot < 0 && !check_flag && c->contact_rows) {  // plain product (residuals, MINRES / GMRES / BiCGStab): multi-wave kernel with the contact rows folded in
+  if (slot < 0 && !check_flag) {  // plain product (residuals, MINRES / GMRES / BiCGStab): multi-wave kernel with the contact rows folded in
     hipLaunchKernelGGL((k_spmv_mw<4, 1, TSL_NT>), dim3(c->n_slices), dim3(256), 0, s, c->NV, c->n_slices, c->slice_off.p, c->slice_len.p, c->colidx.p, vals, x, y,
                        (double*)nullptr, (const int*)nullptr, contact_rows(c, full_contact ? c->c_Hfull.p : c->c_H.p));
     return;
@@ -609,7 +608,6 @@ static void mg_spmv0(tsl_ctx* c, const double* x, double* y) {
   const double* cH = c->pc_separate ? c->c_H_pc.p : c->c_H.p;
   hipLaunchKernelGGL((k_spmv_mw<4, 1, TSL_NT>), dim3(c->n_slices), dim3(256), 0, s, c->NV, c->n_slices, c->slice_off.p, c->slice_len.p, c->colidx.p, vals, x, y,
                      (double*)nullptr, (const int*)nullptr, contact_rows(c, cH));
-  if (c->nc > 0 && !c->contact_rows) hipLaunchKernelGGL(k_contact_matvec, dim3(nblk(c->nc, 64)), dim3(CONTACT_MV_THREADS), 0, s, c->nc, c->c_idx.p, c->rowpos.p, cH, x, y, SC(c), -1, 0);
 }
 
 // Galerkin coarse operators of the current (masked) matrix; called once per assembly when the preconditioner is active
@@ -758,9 +756,6 @@ static void launch_pcg_iteration(tsl_ctx* c, int parity, int first, unsigned lon
   hipLaunchKernelGGL((k_pcg_spmv<PCG_WPS, TSL_NT>), dim3(ns), dim3(64 * PCG_WPS), 0, s, NV, ns, c->slice_off.p, c->slice_len.p, c->colidx.p, c->vals.p, c->v_z.p, p_old, p_new,
                      c->v_Ap.p, c->part_rz.p, c->part_rr.p, c->part_pAp.p, PSC(c), parity, first, dprof, contact_rows(c, c->c_H.p));
   if (ev) { (void)hipEventRecord(c->ev_pool[c->ev_used].second, s); c->ev_used++; }
-  if (c->nc > 0 && !c->contact_rows)  // separate launch (A/B switch "contact_rows" = 0)
-    hipLaunchKernelGGL(k_contact_matvec_part, dim3(nblk(c->nc, 64)), dim3(CONTACT_MV_THREADS), 0, s, c->nc, c->c_idx.p, c->rowpos.p, c->c_H.p, p_new, c->v_Ap.p, c->part_pAp.p + ns,
-                       &PSC(c)->flag);
   const bool mg = mg_active(c);
   hipLaunchKernelGGL(k_pcg_update, dim3(nblk(NV, 256)), dim3(256), 0, s, NV, p_new, c->v_Ap.p, c->Dinv.p, c->v_x.p, c->v_r.p, c->v_z.p, c->part_pAp.p, c->part_rz.p, c->part_rr.p,
                      PSC(c), parity, (const double*)nullptr, (const double*)nullptr, mg ? 2 : 1, c->mg_omega0.p);
@@ -772,7 +767,7 @@ static void launch_pcg_iteration(tsl_ctx* c, int parity, int first, unsigned lon
 // iteration is ~45 short kernels, eager launches leave the GPU idle ~30 % of the time.  The first K1 of the chunk stamps
 // the device clock into a fixed buffer when profiling is on.
 static int pcg_chunk_graph(tsl_ctx* c, int chunk) {
-  const long key = ((long)(mg_active(c) ? 1 : 0) << 40) | ((long)c->nc << 8) | ((long)(c->prof_enable ? 1 : 0) << 7) | (long)chunk | ((long)c->mg_nu << 44) | ((long)c->mg_coarse_sweeps << 48) | ((long)(c->pc_separate ? 1 : 0) << 41) | ((long)((body_active(c) && c->bd_valid) ? 1 : 0) << 42) | ((long)(c->mg_fuse ? 1 : 0) << 43) | ((long)c->mg_max_levels << 52) | ((long)(c->contact_rows ? 1 : 0) << 39);
+  const long key = ((long)(mg_active(c) ? 1 : 0) << 40) | ((long)c->nc << 8) | ((long)(c->prof_enable ? 1 : 0) << 7) | (long)chunk | ((long)c->mg_nu << 44) | ((long)c->mg_coarse_sweeps << 48) | ((long)(c->pc_separate ? 1 : 0) << 41) | ((long)((body_active(c) && c->bd_valid) ? 1 : 0) << 42) | ((long)(c->mg_fuse ? 1 : 0) << 43) | ((long)c->mg_max_levels << 52);
   if (c->pcg_graph && c->pcg_graph_key == key) return 0;
   if (c->pcg_graph) { (void)hipGraphExecDestroy(c->pcg_graph); c->pcg_graph = nullptr; }
   hipGraph_t g = nullptr;
@@ -851,7 +846,7 @@ static int solve_perm(tsl_ctx* c, tsl_solve_stats* st) {
   for (int outer = 0; outer < 20; outer++) {
     PcgScal hs;
     memset(&hs, 0, sizeof(hs));
-    hs.bb = bb; hs.thresh2 = 0.25 * tol2; hs.n_part1 = c->n_slices + (c->contact_rows ? 0 : ncb); hs.n_part2 = n_rz;
+    hs.bb = bb; hs.thresh2 = 0.25 * tol2; hs.n_part1 = c->n_slices; hs.n_part2 = n_rz;
     HIP_OK(hipMemcpyAsync(c->scal.p, &hs, sizeof(PcgScal), hipMemcpyHostToDevice, s));
     if (outer > 0) launch_spmv(c, c->vals.p, c->v_x.p, c->v_Ap.p, -1, 0);
     // true residual, z = M^-1 r, partial r.z / r.r
@@ -973,7 +968,7 @@ static void launch_minres_iteration(tsl_ctx* c, const MrBufs& B, int j) {
 
 static long solver_graph_key(tsl_ctx* c) {
   return ((long)(mg_active(c) ? 1 : 0) << 40) | ((long)c->nc << 8) | ((long)(c->prof_enable ? 1 : 0) << 7) | ((long)c->mg_nu << 44) | ((long)c->mg_coarse_sweeps << 48) |
-         ((long)(c->pc_separate ? 1 : 0) << 41) | ((long)((body_active(c) && c->bd_valid) ? 1 : 0) << 42) | ((long)(c->mg_fuse ? 1 : 0) << 43) | ((long)c->mg_max_levels << 52) | ((long)(c->contact_rows ? 1 : 0) << 39);
+         ((long)(c->pc_separate ? 1 : 0) << 41) | ((long)((body_active(c) && c->bd_valid) ? 1 : 0) << 42) | ((long)(c->mg_fuse ? 1 : 0) << 43) | ((long)c->mg_max_levels << 52);
 }
 
 static int minres_graph(tsl_ctx* c, const MrBufs& B) {
