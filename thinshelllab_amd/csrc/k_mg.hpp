@@ -197,6 +197,94 @@ k_st_prolong_sweep(MgGrid g, const double* __restrict__ A, const double* __restr
   }
 }
 
+// Exact solve on the coarsest level (<= 64 nodes, <= 192 unknowns).  Eight damped-Jacobi sweeps leave most of the smooth error
+// there (measured on cfg4: 436 PCG iterations per solve with 8 sweeps, 392 with 16) and cost 15 us per cycle; the dense inverse
+// costs one single-workgroup kernel per assembly and a 192 x 192 product (k_st_coarse_apply) per cycle.
+// k_st_coarse_invert: the 25-slot operator is expanded to a dense matrix held in registers (thread (ti, j) owns column j, rows
+// ti + 5 m), inverted in place by Gauss-Jordan without pivoting (the level operator is the Galerkin product of an SPD matrix;
+// rows of fully frozen unknowns are empty and become identity rows), pivot row / column passed through LDS, one barrier per
+// pivot.  A non-positive pivot (bad[0] = 1) stores one damped block-Jacobi sweep instead of the inverse.
+#define ST_DENSE_MAX 192
+#define ST_DENSE_RPT 39   // rows per thread: 5 * 39 >= 192
+__global__ void __launch_bounds__(960)
+k_st_coarse_invert(MgGrid g, const double* __restrict__ A, const double* __restrict__ Dinv, double* __restrict__ Cinv, int* __restrict__ bad) {
+  __shared__ double colb[2][ST_DENSE_MAX], rowb[2][ST_DENSE_MAX];
+  __shared__ int sbad;
+  const int n = (g.N + 1) * (g.M + 1), n3 = 3 * n;
+  const int j = threadIdx.x % ST_DENSE_MAX, ti = threadIdx.x / ST_DENSE_MAX;
+  const bool colok = j < n3;
+  const int nj = j / 3, cj = j % 3, Ij = nj / (g.M + 1), Jj = nj % (g.M + 1);
+  if (threadIdx.x == 0) sbad = 0;
+  double a[ST_DENSE_RPT];
+#pragma unroll
+  for (int m = 0; m < ST_DENSE_RPT; m++) {
+    const int i = ti + 5 * m;
+    double v = 0.0;
+    if (colok && i < n3) {
+      const int ni = i / 3, ci = i % 3, Ii = ni / (g.M + 1), Ji = ni % (g.M + 1);
+      const int dI = Ij - Ii, dJ = Jj - Ji;
+      if (dI >= -2 && dI <= 2 && dJ >= -2 && dJ <= 2) v = A[((size_t)((dI + 2) * 5 + (dJ + 2)) * 9 + ci * 3 + cj) * n + ni];
+      if (i == j && v == 0.0) v = 1.0;
+      if (j == 0) colb[0][i] = v;
+      if (i == 0) rowb[0][j] = v;
+    }
+    a[m] = v;
+  }
+  __syncthreads();
+  for (int k = 0; k < n3; k++) {
+    const int cur = k & 1;
+    const double piv = colb[cur][k];
+    if (threadIdx.x == 0 && !(piv > 0.0)) sbad = 1;
+    const double ip = 1.0 / piv;
+    const double rj = colok ? rowb[cur][j] : 0.0;
+#pragma unroll
+    for (int m = 0; m < ST_DENSE_RPT; m++) {
+      const int i = ti + 5 * m;
+      if (colok && i < n3) {
+        const double ci = colb[cur][i];
+        double v;
+        if (i == k) v = (j == k) ? ip : rj * ip;
+        else if (j == k) v = -ci * ip;
+        else v = a[m] - ci * rj * ip;
+        a[m] = v;
+        if (j == k + 1) colb[cur ^ 1][i] = v;
+        if (i == k + 1) rowb[cur ^ 1][j] = v;
+      }
+    }
+    __syncthreads();
+  }
+  const bool isbad = sbad != 0;  // a non-positive pivot: one damped block-Jacobi sweep instead (0.5 Dinv on the diagonal blocks)
+  const double omega = 0.5;
+#pragma unroll
+  for (int m = 0; m < ST_DENSE_RPT; m++) {
+    const int i = ti + 5 * m;
+    if (colok && i < n3) {
+      double v = a[m];
+      if (isbad) v = (i / 3 == nj) ? omega * Dinv[9 * (size_t)nj + 3 * (i % 3) + cj] : 0.0;
+      Cinv[(size_t)i * n3 + j] = v;
+    }
+  }
+  if (threadIdx.x == 0) bad[0] = sbad;
+}
+
+// x = Cinv r: one wave per two rows (row-major rows are contiguous: coalesced), 8 rows per workgroup, every load independent
+__global__ void __launch_bounds__(256)
+k_st_coarse_apply(int n3, const double* __restrict__ Cinv, const double* __restrict__ r, double* __restrict__ out) {
+  const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+  const int i0 = blockIdx.x * 8 + 2 * w, i1 = i0 + 1;
+  if (i0 >= n3) return;
+  const double* c0 = Cinv + (size_t)i0 * n3;
+  const double* c1 = Cinv + (size_t)(i1 < n3 ? i1 : i0) * n3;
+  double s0 = 0, s1 = 0;
+#pragma unroll
+  for (int t = 0; t < ST_DENSE_MAX / 64; t++) {
+    const int jj = lane + 64 * t;
+    if (jj < n3) { const double rj = r[jj]; s0 += c0[jj] * rj; s1 += c1[jj] * rj; }
+  }
+  s0 = wave_sum(s0); s1 = wave_sum(s1);
+  if (lane == 0) { out[i0] = s0; if (i1 < n3) out[i1] = s1; }
+}
+
 // (3) the whole coarsest level (<= 64 nodes) in one workgroup: x = omega Dinv r, then sweeps - 1 damped-Jacobi sweeps with the
 // iterate in LDS (ping-pong) and the 25-slot operator streamed from L2
 __global__ void __launch_bounds__(320)

@@ -74,6 +74,8 @@ struct MgLevel {
   int N = 0, M = 0, n = 0;
   DevBuf<double> A, Dinv, x, x2, r, t;
   DevBuf<double> omega;  // [0] damping factor, [1] lambda_max estimate (device resident)
+  DevBuf<double> Cinv;   // dense inverse of the coarsest level (k_st_coarse_invert), n <= 64 nodes only
+  DevBuf<int> cbad;
 };
 struct MgCloth {
   int v_offset = 0, N0 = 0, M0 = 0;
@@ -201,7 +203,7 @@ struct tsl_ctx {
   double mg_omega = 0.0;   // > 0: fixed damping; 0: 1.5 / lambda_max(D^-1 A) per level from a power iteration
   int mg_pi_iters = 12;
   DevBuf<double> mg_omega0, mg_pi_part, mg_pi_norm;  // level 0
-  int mg_nu = 1, mg_coarse_sweeps = 8, mg_fuse = 1, mg_max_levels = 16;
+  int mg_nu = 1, mg_coarse_sweeps = 8, mg_fuse = 1, mg_max_levels = 16, mg_coarse_exact = 1;
   bool mg_ops_valid = false, mg_suspended = false, mg_omega_valid = false;
 
   // ---- profiling of the dominant kernel

@@ -320,6 +320,7 @@ extern "C" int tsl_set_param(tsl_ctx* c, const char* key, double v) {
   else if (k == "mg") c->mg_enable = (int)v;
   else if (k == "mg_omega") c->mg_omega = v;
   else if (k == "mg_fuse") c->mg_fuse = (int)v;
+  else if (k == "mg_coarse_exact") c->mg_coarse_exact = (int)v;
   else if (k == "mg_max_levels") c->mg_max_levels = (int)v;
   else if (k == "mg_pi_iters") c->mg_pi_iters = (int)v;
   else if (k == "graph") c->use_graph = (int)v;
@@ -628,6 +629,13 @@ static int mg_setup_operators(tsl_ctx* c) {
       hipLaunchKernelGGL(k_galerkin_st, dim3(nblk((long)Lf->n * 25, 256)), dim3(256), 0, s, MgGrid{Lf->N, Lf->M}, Lf->A.p, Lc->A.p);
       hipLaunchKernelGGL(k_st_diag_inv, dim3(nblk(Lc->n, 256)), dim3(256), 0, s, Lc->n, Lc->A.p, Lc->Dinv.p);
     }
+    MgLevel* Ll = mc->lv[mg_levels(c, mc) - 1];
+    if (c->mg_fuse && c->mg_coarse_exact && Ll->n <= 64) {  // dense inverse of the coarsest level
+      if (Ll->Cinv.n == 0) {
+        if (Ll->Cinv.alloc(9 * (size_t)Ll->n * Ll->n) | Ll->cbad.alloc(1)) return tsl_fail("out of device memory (coarse inverse)");
+      }
+      hipLaunchKernelGGL(k_st_coarse_invert, dim3(1), dim3(960), 0, s, MgGrid{Ll->N, Ll->M}, Ll->A.p, Ll->Dinv.p, Ll->Cinv.p, Ll->cbad.p);
+    }
   }
   // damping factors
   const double c_om = 1.5, om_max = 0.8;
@@ -684,7 +692,8 @@ static double* mg_stencil_cycle(tsl_ctx* c, MgCloth* mc, size_t l) {
   };
   const bool last = (l + 1 == mg_levels(c, mc));
   if (c->mg_fuse && last && L->n <= 64) {  // whole coarsest level in one workgroup
-    hipLaunchKernelGGL(k_st_coarse, dim3(1), dim3(320), 0, s, g, L->A.p, L->Dinv.p, L->r.p, L->omega.p, c->mg_coarse_sweeps, xa);
+    if (c->mg_coarse_exact && L->Cinv.n > 0) hipLaunchKernelGGL(k_st_coarse_apply, dim3(nblk(3 * L->n, 8)), dim3(256), 0, s, 3 * L->n, L->Cinv.p, L->r.p, xa);
+    else hipLaunchKernelGGL(k_st_coarse, dim3(1), dim3(320), 0, s, g, L->A.p, L->Dinv.p, L->r.p, L->omega.p, c->mg_coarse_sweeps, xa);
     return xa;
   }
   const bool fuse_down = c->mg_fuse && !last && c->mg_nu == 1;
@@ -767,7 +776,7 @@ static void launch_pcg_iteration(tsl_ctx* c, int parity, int first, unsigned lon
 // iteration is ~45 short kernels, eager launches leave the GPU idle ~30 % of the time.  The first K1 of the chunk stamps
 // the device clock into a fixed buffer when profiling is on.
 static int pcg_chunk_graph(tsl_ctx* c, int chunk) {
-  const long key = ((long)(mg_active(c) ? 1 : 0) << 40) | ((long)c->nc << 8) | ((long)(c->prof_enable ? 1 : 0) << 7) | (long)chunk | ((long)c->mg_nu << 44) | ((long)c->mg_coarse_sweeps << 48) | ((long)(c->pc_separate ? 1 : 0) << 41) | ((long)((body_active(c) && c->bd_valid) ? 1 : 0) << 42) | ((long)(c->mg_fuse ? 1 : 0) << 43) | ((long)c->mg_max_levels << 52);
+  const long key = ((long)(mg_active(c) ? 1 : 0) << 40) | ((long)c->nc << 8) | ((long)(c->prof_enable ? 1 : 0) << 7) | (long)chunk | ((long)c->mg_nu << 44) | ((long)c->mg_coarse_sweeps << 48) | ((long)(c->pc_separate ? 1 : 0) << 41) | ((long)((body_active(c) && c->bd_valid) ? 1 : 0) << 42) | ((long)(c->mg_fuse ? 1 : 0) << 43) | ((long)c->mg_max_levels << 52) | ((long)(c->mg_coarse_exact ? 1 : 0) << 39);
   if (c->pcg_graph && c->pcg_graph_key == key) return 0;
   if (c->pcg_graph) { (void)hipGraphExecDestroy(c->pcg_graph); c->pcg_graph = nullptr; }
   hipGraph_t g = nullptr;
@@ -968,7 +977,7 @@ static void launch_minres_iteration(tsl_ctx* c, const MrBufs& B, int j) {
 
 static long solver_graph_key(tsl_ctx* c) {
   return ((long)(mg_active(c) ? 1 : 0) << 40) | ((long)c->nc << 8) | ((long)(c->prof_enable ? 1 : 0) << 7) | ((long)c->mg_nu << 44) | ((long)c->mg_coarse_sweeps << 48) |
-         ((long)(c->pc_separate ? 1 : 0) << 41) | ((long)((body_active(c) && c->bd_valid) ? 1 : 0) << 42) | ((long)(c->mg_fuse ? 1 : 0) << 43) | ((long)c->mg_max_levels << 52);
+         ((long)(c->pc_separate ? 1 : 0) << 41) | ((long)((body_active(c) && c->bd_valid) ? 1 : 0) << 42) | ((long)(c->mg_fuse ? 1 : 0) << 43) | ((long)c->mg_max_levels << 52) | ((long)(c->mg_coarse_exact ? 1 : 0) << 39);
 }
 
 static int minres_graph(tsl_ctx* c, const MrBufs& B) {
