@@ -276,13 +276,126 @@ k_st_coarse_apply(int n3, const double* __restrict__ Cinv, const double* __restr
   const double* c0 = Cinv + (size_t)i0 * n3;
   const double* c1 = Cinv + (size_t)(i1 < n3 ? i1 : i0) * n3;
   double s0 = 0, s1 = 0;
-#pragma unroll
-  for (int t = 0; t < ST_DENSE_MAX / 64; t++) {
-    const int jj = lane + 64 * t;
-    if (jj < n3) { const double rj = r[jj]; s0 += c0[jj] * rj; s1 += c1[jj] * rj; }
-  }
+#pragma unroll 4
+  for (int jj = lane; jj < n3; jj += 64) { const double rj = r[jj]; s0 += c0[jj] * rj; s1 += c1[jj] * rj; }
   s0 = wave_sum(s0); s1 = wave_sum(s1);
   if (lane == 0) { out[i0] = s0; if (i1 < n3) out[i1] = s1; }
+}
+
+// ---- dense level with more than 192 unknowns (e.g. 15 x 15 nodes: 675): blocked in-place Gauss-Jordan, two launches per block
+// of GJ_B pivots instead of one per pivot.  The matrix is n x n (ld = n, n a multiple of GJ_B; padding rows are identity rows).
+// Block step k with K = [k B, k B + B):   P = inv(A_KK);  R' = P A_K,: ;  C = A_:,K (saved);
+//   A_ij -= C_i R'_j (i, j outside K),  A_Kj = R'_j,  A_iK = -C_i P,  A_KK = P.
+#define GJ_B 32
+// expands the 25-slot operator into the dense matrix (zeroed by the caller): one thread per (node, slot, 3x3 entry)
+__global__ void k_st_dense_build(MgGrid g, int ld, const double* __restrict__ A, double* __restrict__ D) {
+  const int n = (g.N + 1) * (g.M + 1);
+  const long t = (long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (t >= (long)n * 225) return;
+  const int row = (int)(t % n), se = (int)(t / n), s = se / 9, e = se % 9;
+  const int I = row / (g.M + 1), J = row % (g.M + 1);
+  const int I2 = I + s / 5 - 2, J2 = J + s % 5 - 2;
+  if (I2 < 0 || I2 > g.N || J2 < 0 || J2 > g.M) return;
+  const double v = A[(size_t)se * n + row];
+  D[(size_t)(3 * row + e / 3) * ld + 3 * (I2 * (g.M + 1) + J2) + e % 3] = v;
+}
+// empty rows (frozen unknowns) and the padding become identity rows
+__global__ void k_st_dense_diag(int n3, int ld, double* __restrict__ D) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= ld) return;
+  if (i >= n3 || D[(size_t)i * ld + i] == 0.0) D[(size_t)i * ld + i] = 1.0;
+}
+// panel kernel of block step k: every workgroup inverts the pivot block itself (32 x 32 Gauss-Jordan in LDS, cheaper than another
+// launch), then workgroup b writes R'[:, chunk b] = P A[K, chunk b] and the saved column panel C[chunk b, :] = A[chunk b, K]
+__global__ void __launch_bounds__(256)
+k_gj_panel(int ld, int k, const double* __restrict__ D, double* __restrict__ Rn, double* __restrict__ Cs, double* __restrict__ Pout, int* __restrict__ bad) {
+  __shared__ double P[GJ_B][GJ_B + 1];
+  __shared__ double T[GJ_B][GJ_B + 1];
+  __shared__ double colb[GJ_B], rowb[GJ_B];
+  const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;  // 32 x 8
+  const int k0 = k * GJ_B, b0 = blockIdx.x * GJ_B;
+#pragma unroll
+  for (int q = 0; q < 4; q++) P[ty + 8 * q][tx] = D[(size_t)(k0 + ty + 8 * q) * ld + k0 + tx];
+  __syncthreads();
+  for (int p = 0; p < GJ_B; p++) {
+    if (threadIdx.x < GJ_B) { colb[threadIdx.x] = P[threadIdx.x][p]; rowb[threadIdx.x] = P[p][threadIdx.x]; }
+    __syncthreads();
+    const double piv = colb[p], ip = 1.0 / piv;
+    if (threadIdx.x == 0 && blockIdx.x == 0 && !(piv > 0.0)) bad[0] = 1;
+#pragma unroll
+    for (int q = 0; q < 4; q++) {
+      const int i = ty + 8 * q, j = tx;
+      double v;
+      if (i == p) v = (j == p) ? ip : rowb[j] * ip;
+      else if (j == p) v = -colb[i] * ip;
+      else v = P[i][j] - colb[i] * rowb[j] * ip;
+      P[i][j] = v;
+    }
+    __syncthreads();
+  }
+  // R' chunk
+#pragma unroll
+  for (int q = 0; q < 4; q++) T[ty + 8 * q][tx] = D[(size_t)(k0 + ty + 8 * q) * ld + b0 + tx];
+  __syncthreads();
+#pragma unroll
+  for (int q = 0; q < 4; q++) {
+    const int i = ty + 8 * q;
+    double acc = 0;
+#pragma unroll 8
+    for (int m = 0; m < GJ_B; m++) acc += P[i][m] * T[m][tx];
+    Rn[(size_t)i * ld + b0 + tx] = acc;
+  }
+  // saved column panel chunk
+#pragma unroll
+  for (int q = 0; q < 4; q++) Cs[(size_t)(b0 + ty + 8 * q) * GJ_B + tx] = D[(size_t)(b0 + ty + 8 * q) * ld + k0 + tx];
+  if (blockIdx.x == 0) {
+#pragma unroll
+    for (int q = 0; q < 4; q++) Pout[(ty + 8 * q) * GJ_B + tx] = P[ty + 8 * q][tx];
+  }
+}
+// update kernel of block step k: one 32 x 32 tile of the matrix per workgroup
+__global__ void __launch_bounds__(256)
+k_gj_update(int ld, int k, double* __restrict__ D, const double* __restrict__ Rn, const double* __restrict__ Cs, const double* __restrict__ Pin) {
+  __shared__ double Ct[GJ_B][GJ_B + 1];
+  __shared__ double Rt[GJ_B][GJ_B + 1];
+  const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;
+  const int bi = blockIdx.y, bj = blockIdx.x;
+  const int i0 = bi * GJ_B, j0 = bj * GJ_B;
+  if (bi == k && bj == k) {
+#pragma unroll
+    for (int q = 0; q < 4; q++) D[(size_t)(i0 + ty + 8 * q) * ld + j0 + tx] = Pin[(ty + 8 * q) * GJ_B + tx];
+    return;
+  }
+  if (bi == k) {  // row panel: R'
+#pragma unroll
+    for (int q = 0; q < 4; q++) D[(size_t)(i0 + ty + 8 * q) * ld + j0 + tx] = Rn[(size_t)(ty + 8 * q) * ld + j0 + tx];
+    return;
+  }
+#pragma unroll
+  for (int q = 0; q < 4; q++) {
+    Ct[ty + 8 * q][tx] = Cs[(size_t)(i0 + ty + 8 * q) * GJ_B + tx];
+    Rt[ty + 8 * q][tx] = (bj == k) ? Pin[(ty + 8 * q) * GJ_B + tx] : Rn[(size_t)(ty + 8 * q) * ld + j0 + tx];
+  }
+  __syncthreads();
+#pragma unroll
+  for (int q = 0; q < 4; q++) {
+    const int i = ty + 8 * q;
+    double acc = 0;
+#pragma unroll 8
+    for (int m = 0; m < GJ_B; m++) acc += Ct[i][m] * Rt[m][tx];
+    double* d = D + (size_t)(i0 + i) * ld + j0 + tx;
+    *d = (bj == k) ? -acc : *d - acc;
+  }
+}
+// after the last block step: symmetrise into the inverse buffer (row stride n3), or the block-Jacobi fallback on a bad pivot
+__global__ void k_gj_finish(int n3, int ld, const double* __restrict__ D, const int* __restrict__ bad, const double* __restrict__ Dinv, double* __restrict__ Cinv) {
+  const long t = (long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (t >= (long)n3 * n3) return;
+  const int i = (int)(t / n3), j = (int)(t % n3);
+  double v;
+  if (!bad[0]) v = 0.5 * (D[(size_t)i * ld + j] + D[(size_t)j * ld + i]);
+  else v = (i / 3 == j / 3) ? 0.5 * Dinv[9 * (size_t)(i / 3) + 3 * (i % 3) + j % 3] : 0.0;
+  Cinv[t] = v;
 }
 
 // (3) the whole coarsest level (<= 64 nodes) in one workgroup: x = omega Dinv r, then sweeps - 1 damped-Jacobi sweeps with the

@@ -76,10 +76,13 @@ struct MgLevel {
   DevBuf<double> omega;  // [0] damping factor, [1] lambda_max estimate (device resident)
   DevBuf<double> Cinv;   // dense inverse of the coarsest level (k_st_coarse_invert), n <= 64 nodes only
   DevBuf<int> cbad;
+  DevBuf<double> gjD, gjR, gjC, gjP;  // blocked Gauss-Jordan workspace (dense levels with more than 192 unknowns)
+  int gj_ld = 0;
 };
 struct MgCloth {
   int v_offset = 0, N0 = 0, M0 = 0;
   std::vector<MgLevel*> lv;  // lv[0] = level 1
+  int dense_lv = -1;         // index into lv of the level that is solved exactly (dense inverse), -1: none
   ~MgCloth() { for (auto* l : lv) delete l; }
 };
 
@@ -203,7 +206,9 @@ struct tsl_ctx {
   double mg_omega = 0.0;   // > 0: fixed damping; 0: 1.5 / lambda_max(D^-1 A) per level from a power iteration
   int mg_pi_iters = 12;
   DevBuf<double> mg_omega0, mg_pi_part, mg_pi_norm;  // level 0
-  int mg_nu = 1, mg_coarse_sweeps = 8, mg_fuse = 1, mg_max_levels = 16, mg_coarse_exact = 1;
+  int mg_nu = 1, mg_coarse_sweeps = 8, mg_fuse = 1, mg_max_levels = 16, mg_coarse_exact = 1, mg_coarse_lag = 0, mg_dense_nodes = 256, mg_dense_auto = 1;
+  double last_step_iters_per_solve = 0.0;
+  bool mg_cinv_valid = false;
   bool mg_ops_valid = false, mg_suspended = false, mg_omega_valid = false;
 
   // ---- profiling of the dominant kernel

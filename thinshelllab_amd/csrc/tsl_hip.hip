@@ -292,7 +292,7 @@ extern "C" int tsl_set_stream(tsl_ctx* c, void* s) { c->user_stream = (hipStream
 extern "C" int tsl_set_param(tsl_ctx* c, const char* key, double v) {
   Scope scope(c);
   (void)hipStreamSynchronize(c->stream);
-  c->mg_omega_valid = false;
+  c->mg_omega_valid = false; c->mg_cinv_valid = false;
   std::string k(key);
   if (k == "mu_cloth_elastic") c->mu_cloth_elastic = v;
   else if (k == "mu_cloth_cloth") c->mu_cloth_cloth = v;
@@ -321,6 +321,8 @@ extern "C" int tsl_set_param(tsl_ctx* c, const char* key, double v) {
   else if (k == "mg_omega") c->mg_omega = v;
   else if (k == "mg_fuse") c->mg_fuse = (int)v;
   else if (k == "mg_coarse_exact") c->mg_coarse_exact = (int)v;
+  else if (k == "mg_coarse_lag") c->mg_coarse_lag = (int)v;
+  else if (k == "mg_dense_nodes") { c->mg_dense_auto = v < 0; if (v >= 0) c->mg_dense_nodes = (int)v; c->mg_ops_valid = false; }
   else if (k == "mg_max_levels") c->mg_max_levels = (int)v;
   else if (k == "mg_pi_iters") c->mg_pi_iters = (int)v;
   else if (k == "graph") c->use_graph = (int)v;
@@ -342,7 +344,7 @@ extern "C" int tsl_set_frozen(tsl_ctx* c, const int32_t* fr) {
   Scope scope(c);
   (void)hipStreamSynchronize(c->stream);
   c->h_frozen.assign(fr, fr + 3 * (size_t)c->NV);
-  c->mg_omega_valid = false;
+  c->mg_omega_valid = false; c->mg_cinv_valid = false;
   TSL_TRY(upload_frozen(c));
   if (c->pcg_graph) { (void)hipGraphExecDestroy(c->pcg_graph); c->pcg_graph = nullptr; }
   if (c->mr_graph) { (void)hipGraphExecDestroy(c->mr_graph); c->mr_graph = nullptr; }
@@ -447,7 +449,7 @@ static int assemble(tsl_ctx* c, const double* pos, const double* prev, const dou
 extern "C" int tsl_assemble(tsl_ctx* c, const double* pos, const double* prev, const double* vel, const double* ref, int spd, double* grad) {
   Scope scope(c);
   c->bd_valid = false;
-  c->mg_omega_valid = false;
+  c->mg_omega_valid = false; c->mg_cinv_valid = false;
   return assemble(c, pos, prev, vel, ref, spd, grad);
 }
 
@@ -599,7 +601,14 @@ static int mg_build(tsl_ctx* c, const tsl_scene_desc* d) {
   return 0;
 }
 
-static size_t mg_levels(tsl_ctx* c, MgCloth* mc) { return std::min<size_t>(mc->lv.size(), (size_t)std::max(1, c->mg_max_levels)); }
+static size_t mg_levels(tsl_ctx* c, MgCloth* mc) {
+  size_t nl = std::min<size_t>(mc->lv.size(), (size_t)std::max(1, c->mg_max_levels));
+  if (c->mg_fuse && c->mg_coarse_exact)  // the hierarchy ends at the first level small enough for a dense inverse
+    for (size_t l = 0; l < nl; l++)
+      if (mc->lv[l]->n <= std::max(c->mg_dense_nodes, 1)) { nl = l + 1; break; }
+  return nl;
+}
+static bool mg_level_dense(tsl_ctx* c, MgLevel* L) { return c->mg_fuse && c->mg_coarse_exact && (L->n <= 64 || L->n <= c->mg_dense_nodes); }
 static bool mg_active(tsl_ctx* c) { return !c->mg.empty() && c->mg_enable != 0 && !c->mg_suspended; }
 
 // plain y = H x on level 0 (matrix + matrix-free contact), no scalar side effects
@@ -630,13 +639,53 @@ static int mg_setup_operators(tsl_ctx* c) {
       hipLaunchKernelGGL(k_st_diag_inv, dim3(nblk(Lc->n, 256)), dim3(256), 0, s, Lc->n, Lc->A.p, Lc->Dinv.p);
     }
     MgLevel* Ll = mc->lv[mg_levels(c, mc) - 1];
-    if (c->mg_fuse && c->mg_coarse_exact && Ll->n <= 64) {  // dense inverse of the coarsest level
+    if (mg_level_dense(c, Ll) && !(c->mg_coarse_lag && c->mg_cinv_valid && Ll->Cinv.n > 0)) {  // dense inverse of the last level
+      const int n3 = 3 * Ll->n;
       if (Ll->Cinv.n == 0) {
-        if (Ll->Cinv.alloc(9 * (size_t)Ll->n * Ll->n) | Ll->cbad.alloc(1)) return tsl_fail("out of device memory (coarse inverse)");
+        if (Ll->Cinv.alloc((size_t)n3 * n3) | Ll->cbad.alloc(1)) return tsl_fail("out of device memory (coarse inverse)");
       }
-      hipLaunchKernelGGL(k_st_coarse_invert, dim3(1), dim3(960), 0, s, MgGrid{Ll->N, Ll->M}, Ll->A.p, Ll->Dinv.p, Ll->Cinv.p, Ll->cbad.p);
+      if (n3 <= ST_DENSE_MAX) hipLaunchKernelGGL(k_st_coarse_invert, dim3(1), dim3(960), 0, s, MgGrid{Ll->N, Ll->M}, Ll->A.p, Ll->Dinv.p, Ll->Cinv.p, Ll->cbad.p);
+      else {
+        const int ld = (n3 + GJ_B - 1) / GJ_B * GJ_B, nbk = ld / GJ_B;
+        if (Ll->gj_ld != ld) {
+          if (Ll->gjD.alloc((size_t)ld * ld) | Ll->gjR.alloc((size_t)GJ_B * ld) | Ll->gjC.alloc((size_t)ld * GJ_B) | Ll->gjP.alloc(GJ_B * GJ_B))
+            return tsl_fail("out of device memory (coarse inverse workspace)");
+          Ll->gj_ld = ld;
+        }
+        HIP_OK(hipMemsetAsync(Ll->gjD.p, 0, (size_t)ld * ld * sizeof(double), s));
+        HIP_OK(hipMemsetAsync(Ll->cbad.p, 0, sizeof(int), s));
+        hipLaunchKernelGGL(k_st_dense_build, dim3(nblk((long)Ll->n * 225, 256)), dim3(256), 0, s, MgGrid{Ll->N, Ll->M}, ld, Ll->A.p, Ll->gjD.p);
+        hipLaunchKernelGGL(k_st_dense_diag, dim3(nblk(ld, 256)), dim3(256), 0, s, n3, ld, Ll->gjD.p);
+        std::vector<double> h_orig;
+        if (c->verbose >= 2) {  // diagnostic: keep the matrix to check the inverse on the host
+          h_orig.resize((size_t)ld * ld);
+          HIP_OK(hipMemcpyAsync(h_orig.data(), Ll->gjD.p, h_orig.size() * sizeof(double), hipMemcpyDeviceToHost, s));
+          HIP_OK(hipStreamSynchronize(s));
+        }
+        for (int k = 0; k < nbk; k++) {
+          hipLaunchKernelGGL(k_gj_panel, dim3(nbk), dim3(256), 0, s, ld, k, Ll->gjD.p, Ll->gjR.p, Ll->gjC.p, Ll->gjP.p, Ll->cbad.p);
+          hipLaunchKernelGGL(k_gj_update, dim3(nbk, nbk), dim3(256), 0, s, ld, k, Ll->gjD.p, Ll->gjR.p, Ll->gjC.p, Ll->gjP.p);
+        }
+        hipLaunchKernelGGL(k_gj_finish, dim3(nblk((long)n3 * n3, 256)), dim3(256), 0, s, n3, ld, Ll->gjD.p, Ll->cbad.p, Ll->Dinv.p, Ll->Cinv.p);
+        if (c->verbose >= 2) {
+          std::vector<double> h_inv((size_t)n3 * n3);
+          int hb = 0;
+          HIP_OK(hipMemcpyAsync(h_inv.data(), Ll->Cinv.p, h_inv.size() * sizeof(double), hipMemcpyDeviceToHost, s));
+          HIP_OK(hipMemcpyAsync(&hb, Ll->cbad.p, sizeof(int), hipMemcpyDeviceToHost, s));
+          HIP_OK(hipStreamSynchronize(s));
+          double worst = 0;
+          for (int i = 0; i < n3; i++)
+            for (int j = 0; j < n3; j++) {
+              double acc = 0;
+              for (int m = 0; m < n3; m++) acc += h_inv[(size_t)i * n3 + m] * h_orig[(size_t)m * ld + j];
+              worst = std::max(worst, fabs(acc - (i == j ? 1.0 : 0.0)));
+            }
+          fprintf(stderr, "[tsl] dense coarse level %d x %d: n3 %d, max |Cinv A - I| = %.3e, bad pivot flag %d\n", Ll->N + 1, Ll->M + 1, n3, worst, hb);
+        }
+      }
     }
   }
+  c->mg_cinv_valid = true;
   // damping factors
   const double c_om = 1.5, om_max = 0.8;
   auto set_fixed = [&](double* dst) -> int {
@@ -662,7 +711,9 @@ static int mg_setup_operators(tsl_ctx* c) {
       }
     }
     for (MgCloth* mc : c->mg)
-      for (MgLevel* L : mc->lv) {
+      for (size_t l = 0; l < mg_levels(c, mc); l++) {
+        MgLevel* L = mc->lv[l];
+        if (l + 1 == mg_levels(c, mc) && mg_level_dense(c, L)) continue;  // solved exactly: no smoother there
         const int gb = nblk(L->n, 256);
         hipLaunchKernelGGL(k_pi_init, dim3(gb), dim3(256), 0, s, L->n, L->x.p);
         for (int k = 0; k < K; k++) {
@@ -691,8 +742,8 @@ static double* mg_stencil_cycle(tsl_ctx* c, MgCloth* mc, size_t l) {
     std::swap(xa, xb);
   };
   const bool last = (l + 1 == mg_levels(c, mc));
-  if (c->mg_fuse && last && L->n <= 64) {  // whole coarsest level in one workgroup
-    if (c->mg_coarse_exact && L->Cinv.n > 0) hipLaunchKernelGGL(k_st_coarse_apply, dim3(nblk(3 * L->n, 8)), dim3(256), 0, s, 3 * L->n, L->Cinv.p, L->r.p, xa);
+  if (c->mg_fuse && last && (L->n <= 64 || mg_level_dense(c, L))) {  // whole coarsest level in one launch
+    if (mg_level_dense(c, L) && L->Cinv.n > 0) hipLaunchKernelGGL(k_st_coarse_apply, dim3(nblk(3 * L->n, 8)), dim3(256), 0, s, 3 * L->n, L->Cinv.p, L->r.p, xa);
     else hipLaunchKernelGGL(k_st_coarse, dim3(1), dim3(320), 0, s, g, L->A.p, L->Dinv.p, L->r.p, L->omega.p, c->mg_coarse_sweeps, xa);
     return xa;
   }
@@ -776,7 +827,7 @@ static void launch_pcg_iteration(tsl_ctx* c, int parity, int first, unsigned lon
 // iteration is ~45 short kernels, eager launches leave the GPU idle ~30 % of the time.  The first K1 of the chunk stamps
 // the device clock into a fixed buffer when profiling is on.
 static int pcg_chunk_graph(tsl_ctx* c, int chunk) {
-  const long key = ((long)(mg_active(c) ? 1 : 0) << 40) | ((long)c->nc << 8) | ((long)(c->prof_enable ? 1 : 0) << 7) | (long)chunk | ((long)c->mg_nu << 44) | ((long)c->mg_coarse_sweeps << 48) | ((long)(c->pc_separate ? 1 : 0) << 41) | ((long)((body_active(c) && c->bd_valid) ? 1 : 0) << 42) | ((long)(c->mg_fuse ? 1 : 0) << 43) | ((long)c->mg_max_levels << 52) | ((long)(c->mg_coarse_exact ? 1 : 0) << 39);
+  const long key = ((long)(mg_active(c) ? 1 : 0) << 40) | ((long)c->nc << 8) | ((long)(c->prof_enable ? 1 : 0) << 7) | (long)chunk | ((long)c->mg_nu << 44) | ((long)c->mg_coarse_sweeps << 48) | ((long)(c->pc_separate ? 1 : 0) << 41) | ((long)((body_active(c) && c->bd_valid) ? 1 : 0) << 42) | ((long)(c->mg_fuse ? 1 : 0) << 43) | ((long)c->mg_max_levels << 52) | ((long)(c->mg_coarse_exact ? 1 : 0) << 39) | ((long)(c->mg_dense_nodes & 0xfff) << 24);
   if (c->pcg_graph && c->pcg_graph_key == key) return 0;
   if (c->pcg_graph) { (void)hipGraphExecDestroy(c->pcg_graph); c->pcg_graph = nullptr; }
   hipGraph_t g = nullptr;
@@ -816,7 +867,7 @@ static int forward_spd_pc(tsl_ctx* c) {
   std::swap(c->vals.p, c->vals_pc.p);
   if (c->nc > 0) std::swap(c->c_H.p, c->c_H_pc.p);
   const int rc = assemble(c, c->st_pos, c->st_prev, c->st_vel, c->st_ref, 2, nullptr);
-  c->mg_omega_valid = false;  // damping factors and dense body blocks of THIS matrix (the lagged ones may be indefinite)
+  c->mg_omega_valid = false; c->mg_cinv_valid = false;  // damping factors and dense body blocks of THIS matrix (the lagged ones may be indefinite)
   c->bd_valid = false;
   int rc2 = 0;
   if (!rc) {
@@ -904,7 +955,7 @@ static int solve_perm(tsl_ctx* c, tsl_solve_stats* st) {
       if (flag) break;
     }
     if (flag) total_it = total_it - it + HPSC(c)->iters;  // iterations actually executed before the kernels went idle
-    if (flag == 1) { indefinite = true; c->mg_omega_valid = false; }
+    if (flag == 1) { indefinite = true; c->mg_omega_valid = false; c->mg_cinv_valid = false; }
     if (flag != 2) break;  // breakdown or iteration cap
   }
   st->iters = total_it;
@@ -977,7 +1028,7 @@ static void launch_minres_iteration(tsl_ctx* c, const MrBufs& B, int j) {
 
 static long solver_graph_key(tsl_ctx* c) {
   return ((long)(mg_active(c) ? 1 : 0) << 40) | ((long)c->nc << 8) | ((long)(c->prof_enable ? 1 : 0) << 7) | ((long)c->mg_nu << 44) | ((long)c->mg_coarse_sweeps << 48) |
-         ((long)(c->pc_separate ? 1 : 0) << 41) | ((long)((body_active(c) && c->bd_valid) ? 1 : 0) << 42) | ((long)(c->mg_fuse ? 1 : 0) << 43) | ((long)c->mg_max_levels << 52) | ((long)(c->mg_coarse_exact ? 1 : 0) << 39);
+         ((long)(c->pc_separate ? 1 : 0) << 41) | ((long)((body_active(c) && c->bd_valid) ? 1 : 0) << 42) | ((long)(c->mg_fuse ? 1 : 0) << 43) | ((long)c->mg_max_levels << 52) | ((long)(c->mg_coarse_exact ? 1 : 0) << 39) | ((long)(c->mg_dense_nodes & 0xfff) << 24);
 }
 
 static int minres_graph(tsl_ctx* c, const MrBufs& B) {
@@ -1414,7 +1465,11 @@ extern "C" int tsl_step(tsl_ctx* c, double* pos, double* prev, double* vel, doub
   memset(&st, 0, sizeof(st));
   struct InStep { tsl_ctx* c; ~InStep() { c->in_step = false; c->st_pos = nullptr; } } in_step_guard{c};
   c->in_step = true;
-  c->mg_omega_valid = false;
+  c->mg_omega_valid = false; c->mg_cinv_valid = false;
+  // level solved exactly by the multigrid cycle: a dense inverse per assembly pays for a ~840-node level (2.5k unknowns, some ms
+  // per inversion) only when the solves are long -- decided from the previous time step (cfg4: 300 -> 220 iterations per solve
+  // at +4.5 ms per assembly; the scaled scene with ~100 iterations per solve keeps the 225-node level)
+  if (c->mg_dense_auto) c->mg_dense_nodes = c->last_step_iters_per_solve > 200.0 ? 900 : 256;
   c->bd_valid = false;  // dense body inverses are rebuilt once per step (first solve) and lagged over its Newton iterations
   // timestep_init: prev_pos <- pos (BaseScene.py:1291-1303)
   HIP_OK(hipMemcpyAsync(prev, pos, n3 * sizeof(double), hipMemcpyDeviceToDevice, s));
@@ -1457,6 +1512,7 @@ extern "C" int tsl_step(tsl_ctx* c, double* pos, double* prev, double* vel, doub
   if (c->plastic) TSL_TRY(tsl_update_ref_angle(c, pos, ref));
   HIP_OK(hipStreamSynchronize(s));
   HIP_OK(hipGetLastError());
+  if (st.solves > 0) c->last_step_iters_per_solve = (double)st.cg_iters / st.solves;
   if (stats) *stats = st;
   return 0;
 }
@@ -1712,7 +1768,7 @@ extern "C" int tsl_adjoint_step(tsl_ctx* c, int step, int T, const double* pos_b
   const bool have_mg = !c->mg.empty() && c->mg_enable != 0;
   const bool spd_pc = c->adj_spd_pc && (have_mg || body_active(c));
   c->bd_valid = false;
-  c->mg_omega_valid = false;
+  c->mg_omega_valid = false; c->mg_cinv_valid = false;
   if (spd_pc) {
     TSL_TRY(assemble(c, x_s, x_prev, x_prev, ref_prev, 1, nullptr));
     if (body_active(c)) TSL_TRY(body_build_inverse(c));
