@@ -138,13 +138,14 @@ __global__ void k_body_zero_dinv(BodyDenseArgs A, int n_rows, double* __restrict
 // mode 0: z_b = Binv r_b ; mode 1: z_b += Binv (r - t)_b ; optional per-workgroup partial of rdot . (Binv v).
 // One wave per matrix row pair, 16-byte loads (the row length 3*n_verts is padded to a multiple of 4 in storage:
 // ld = (n3 + 3) & ~3), BODY_APPLY_ROWS rows per 256-thread workgroup.
-__global__ void __launch_bounds__(256)
-k_body_apply(BodyDenseArgs A, const float* __restrict__ Binv, int mode, const double* __restrict__ r, const double* __restrict__ t, double* __restrict__ z,
-             const double* __restrict__ rdot, double* __restrict__ part) {
+// bid: workgroup index within the body part of the launch; full_dot: the partial is rdot . z_new (the fused post-smoothing
+// launch, where the Jacobi part leaves the body rows alone) instead of rdot . (z_new - z_old)
+TSL_DEV void body_apply_block(const BodyDenseArgs& A, const float* __restrict__ Binv, int mode, const double* __restrict__ r, const double* __restrict__ t,
+                              double* __restrict__ z, const double* __restrict__ rdot, double* __restrict__ part, int bid, bool full_dot) {
   __shared__ double v[3 * 512 + 4];
   __shared__ double s1[4];
   int b = 0;
-  while (b + 1 < A.nb && (int)blockIdx.x >= A.wg_off[b + 1]) b++;
+  while (b + 1 < A.nb && bid >= A.wg_off[b + 1]) b++;
   const int n3 = A.n3[b];
   const int ld = (n3 + 3) & ~3;
   const int* rows = A.rows + A.rows_off[b];
@@ -158,7 +159,7 @@ k_body_apply(BodyDenseArgs A, const float* __restrict__ Binv, int mode, const do
   }
   __syncthreads();
   const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
-  const int row0 = ((int)blockIdx.x - A.wg_off[b]) * BODY_APPLY_ROWS;
+  const int row0 = (bid - A.wg_off[b]) * BODY_APPLY_ROWS;
   const float* Bb = Binv + A.w_off[b];
   const int nq = ld >> 2;
   double acc = 0;
@@ -178,18 +179,26 @@ k_body_apply(BodyDenseArgs A, const float* __restrict__ Binv, int mode, const do
     sum0 = wave_sum(sum0); sum1 = wave_sum(sum1);
     if (lane == 0) {
       const size_t g0 = 3 * (size_t)rows[i0 / 3] + i0 % 3;
-      z[g0] = mode ? z[g0] + sum0 : sum0;
-      if (rdot) acc += rdot[g0] * sum0;  // mode 1: the Jacobi kernel already counted rdot . z_old of these rows
+      const double z0 = mode ? z[g0] + sum0 : sum0;
+      z[g0] = z0;
+      if (rdot) acc += rdot[g0] * (full_dot ? z0 : sum0);  // separate launches in mode 1: the Jacobi kernel already counted rdot . z_old
       if (i1 < n3) {
         const size_t g1 = 3 * (size_t)rows[i1 / 3] + i1 % 3;
-        z[g1] = mode ? z[g1] + sum1 : sum1;
-        if (rdot) acc += rdot[g1] * sum1;
+        const double z1 = mode ? z[g1] + sum1 : sum1;
+        z[g1] = z1;
+        if (rdot) acc += rdot[g1] * (full_dot ? z1 : sum1);
       }
     }
   }
   if (part) {
     if (lane == 0) s1[w] = acc;
     __syncthreads();
-    if (threadIdx.x == 0) part[blockIdx.x] = s1[0] + s1[1] + s1[2] + s1[3];
+    if (threadIdx.x == 0) part[bid] = s1[0] + s1[1] + s1[2] + s1[3];
   }
+}
+
+__global__ void __launch_bounds__(256)
+k_body_apply(BodyDenseArgs A, const float* __restrict__ Binv, int mode, const double* __restrict__ r, const double* __restrict__ t, double* __restrict__ z,
+             const double* __restrict__ rdot, double* __restrict__ part) {
+  body_apply_block(A, Binv, mode, r, t, z, rdot, part, (int)blockIdx.x, false);
 }

@@ -452,6 +452,39 @@ k_st_coarse(MgGrid g, const double* __restrict__ A, const double* __restrict__ D
   if (own) st3(out, row, d3(xs[cur][0][lane], xs[cur][1][lane], xs[cur][2][lane]));
 }
 
+// Level-0 post-smoothing in one launch: workgroups [0, gb) do the damped block-Jacobi update of the rows that are not served by a
+// dense body block (those have a zero Dinv block and are left alone), workgroups [gb, gb + bodies) the dense body update
+// z_b += Binv (r - t)_b.  Partials of rdot . z_new: part[0, gb) and part[gb, ...).
+__global__ void __launch_bounds__(256)
+k_post_smooth(BodyDenseArgs B, const float* __restrict__ Binv, int gb, int n, const double* __restrict__ Dinv, const double* __restrict__ r, const double* __restrict__ t,
+              const double* __restrict__ omega_dev, double* __restrict__ x, const double* __restrict__ rdot, double* __restrict__ part) {
+  if ((int)blockIdx.x >= gb) {
+    body_apply_block(B, Binv, 1, r, t, x, rdot, part ? part + gb : nullptr, (int)blockIdx.x - gb, true);
+    return;
+  }
+  const int p = blockIdx.x * blockDim.x + threadIdx.x;
+  const double omega = *omega_dev;
+  double acc = 0;
+  if (p < n) {
+    m3 D;
+    bool any = false;
+#pragma unroll
+    for (int e = 0; e < 9; e++) { D.m[e] = Dinv[9 * (size_t)p + e]; any = any || D.m[e] != 0.0; }
+    if (any) {
+      const d3 xn = ld3(x, p) + omega * m3_mulv(D, ld3(r, p) - ld3(t, p));
+      st3(x, p, xn);
+      if (rdot) acc = dot(ld3(rdot, p), xn);
+    }
+  }
+  if (part) {
+    __shared__ double s1[4];
+    acc = wave_sum(acc);
+    if ((threadIdx.x & 63) == 0) s1[threadIdx.x >> 6] = acc;
+    __syncthreads();
+    if (threadIdx.x == 0) part[blockIdx.x] = s1[0] + s1[1] + s1[2] + s1[3];
+  }
+}
+
 // x = omega * Dinv * r   (first smoothing sweep from a zero guess)
 __global__ void k_mg_jacobi_first(int n, const double* __restrict__ Dinv, const double* __restrict__ r, const double* __restrict__ omega_dev, double* __restrict__ x) {
   const int p = blockIdx.x * blockDim.x + threadIdx.x;

@@ -171,6 +171,8 @@ struct tsl_ctx {
   DevBuf<SolverScalars> scal;
   DevBuf<double> part_pAp, part_rz, part_rr;  // per-block partial sums of the two-kernel PCG iteration
   SolverScalars* h_scal = nullptr;  // pinned
+  SolverScalars* h_scal2 = nullptr; // pinned, two records: read-back slots of the PCG chunks in flight
+  hipEvent_t rb_event[2] = {nullptr, nullptr};
 
   // ---- Newton scratch (original order)
   DevBuf<double> F, pdir, x1;

@@ -4,6 +4,7 @@
 //   SparseMatrix.solve (sparse_solver.py:85-105) and Grad.transfer_grad (analytic_grad_single.py:217-257).
 // There is no CPU fallback in this library: without a HIP device every entry point fails.
 #include <stdarg.h>
+#include <chrono>
 
 #include <map>
 
@@ -260,6 +261,9 @@ extern "C" int tsl_ctx_create(const tsl_scene_desc* d, tsl_ctx** out) {
   rc |= c->part_pAp.alloc((size_t)P.n_slices + (size_t)(c->max_n_constraints + 63) / 64 + 8); rc |= c->part_rz.alloc((size_t)NV / 256 + 8 + 1024); rc |= c->part_rr.alloc((size_t)NV / 256 + 8 + 1024);
   if (rc) { delete c; return -1; }
   if (hipHostMalloc((void**)&c->h_scal, sizeof(SolverScalars) > sizeof(CgScal) ? sizeof(SolverScalars) : sizeof(CgScal)) != hipSuccess) { delete c; return tsl_fail("hipHostMalloc failed"); }
+  if (hipHostMalloc((void**)&c->h_scal2, 2 * sizeof(SolverScalars)) != hipSuccess) { delete c; return tsl_fail("hipHostMalloc failed"); }
+  for (int i = 0; i < 2; i++)
+    if (hipEventCreateWithFlags(&c->rb_event[i], hipEventDisableTiming) != hipSuccess) { delete c; return tsl_fail("hipEventCreate failed"); }
   c->vals.zero(); c->vals_full.zero(); c->scal.zero(); c->part_rz.zero(); c->part_rr.zero();
 
   // ---- contact tables
@@ -278,6 +282,8 @@ extern "C" void tsl_ctx_destroy(tsl_ctx* c) {
   if (!c) return;
   (void)hipDeviceSynchronize();
   if (c->h_scal) (void)hipHostFree(c->h_scal);
+  if (c->h_scal2) (void)hipHostFree(c->h_scal2);
+  for (int i = 0; i < 2; i++) if (c->rb_event[i]) (void)hipEventDestroy(c->rb_event[i]);
   if (c->pcg_graph) (void)hipGraphExecDestroy(c->pcg_graph);
   if (c->mr_graph) (void)hipGraphExecDestroy(c->mr_graph);
   if (c->ev_in) (void)hipEventDestroy(c->ev_in);
@@ -793,8 +799,13 @@ static void mg_vcycle(tsl_ctx* c, const double* r, double* z, double* part_rz, b
   for (int k = 0; k < c->mg_nu; k++) {
     mg_spmv0(c, z, t);
     const bool lastk = (k == c->mg_nu - 1);
-    hipLaunchKernelGGL(k_mg_jacobi_next, dim3(gb), dim3(256), 0, s, NV, c->Dinv.p, r, t, om, z, lastk ? r : (const double*)nullptr, lastk ? part_rz : (double*)nullptr);
-    if (bd) body_apply(c, 1, r, t, z, lastk ? r : (const double*)nullptr, lastk ? part_rz + gb : (double*)nullptr);
+    if (bd && c->mg_fuse)
+      hipLaunchKernelGGL(k_post_smooth, dim3(gb + c->bd_wg), dim3(256), 0, s, c->bd_args, c->bd_Binv.p, gb, NV, c->Dinv.p, r, t, om, z, lastk ? r : (const double*)nullptr,
+                         lastk ? part_rz : (double*)nullptr);
+    else {
+      hipLaunchKernelGGL(k_mg_jacobi_next, dim3(gb), dim3(256), 0, s, NV, c->Dinv.p, r, t, om, z, lastk ? r : (const double*)nullptr, lastk ? part_rz : (double*)nullptr);
+      if (bd) body_apply(c, 1, r, t, z, lastk ? r : (const double*)nullptr, lastk ? part_rz + gb : (double*)nullptr);
+    }
   }
 }
 
@@ -938,7 +949,13 @@ static int solve_perm(tsl_ctx* c, tsl_solve_stats* st) {
     const bool graph = c->use_graph != 0;
     if (graph) TSL_TRY(pcg_chunk_graph(c, chunk));
     int n_chunks = 0;
-    while (total_it < c->cg_maxit) {
+    // One chunk is kept in flight behind the one whose convergence record the host waits for (a graph launch plus the read-back
+    // round trip leaves the GPU idle for tens of microseconds per 4-iteration chunk otherwise); after convergence the extra chunk
+    // runs idle kernels (flag set).  A chunk whose device-clock stamps are sampled for the profile gets no successor until read.
+    int inflight = 0, head = 0;
+    bool sampled[2] = {false, false};
+    auto launch_chunk = [&]() -> int {
+      const int sl = (head + inflight) & 1;
       // every 32nd chunk of a profiled run is launched kernel by kernel so that one K1 can be timed with hipEvents
       const bool ev_chunk = graph && c->prof_enable && (c->prof_chunks++ % 32 == 16);
       if (graph && !ev_chunk) HIP_OK(hipGraphLaunch(c->pcg_graph, s));
@@ -947,13 +964,24 @@ static int solve_perm(tsl_ctx* c, tsl_solve_stats* st) {
         for (int i = 0; i < chunk; i++) launch_pcg_iteration(c, (i & 1) ^ 1, 0, nullptr);
         hipLaunchKernelGGL(k_pcg_check, dim3(1), dim3(256), 0, s, c->part_rr.p, PSC(c));
       }
-      it += chunk; total_it += chunk; c->prof_launches += chunk;
-      TSL_TRY(read_scal(c));
-      if (c->ev_used >= c->ev_pool.size() / 2) prof_collect(c);
-      if (graph && !ev_chunk && c->prof_enable && (n_chunks++ % 8 == 0)) TSL_TRY(prof_sample_graph(c));
+      HIP_OK(hipMemcpyAsync(&c->h_scal2[sl], c->scal.p, sizeof(CgScal), hipMemcpyDeviceToHost, s));
+      HIP_OK(hipEventRecord(c->rb_event[sl], s));
+      sampled[sl] = graph && !ev_chunk && c->prof_enable && (n_chunks++ % 8 == 0);
+      inflight++; it += chunk; total_it += chunk; c->prof_launches += chunk;
+      return 0;
+    };
+    while (true) {
+      while (inflight < 2 && total_it < c->cg_maxit && !(inflight == 1 && sampled[head])) TSL_TRY(launch_chunk());
+      if (inflight == 0) break;  // iteration cap
+      HIP_OK(hipEventSynchronize(c->rb_event[head]));
+      if (sampled[head]) TSL_TRY(prof_sample_graph(c));
+      memcpy(c->h_scal, &c->h_scal2[head], sizeof(CgScal));
+      inflight--; head ^= 1;
       flag = HPSC(c)->flag;
       if (flag) break;
     }
+    if (inflight) HIP_OK(hipStreamSynchronize(s));
+    if (c->prof_enable) prof_collect(c);
     if (flag) total_it = total_it - it + HPSC(c)->iters;  // iterations actually executed before the kernels went idle
     if (flag == 1) { indefinite = true; c->mg_omega_valid = false; c->mg_cinv_valid = false; }
     if (flag != 2) break;  // breakdown or iteration cap
@@ -1480,13 +1508,23 @@ extern "C" int tsl_step(tsl_ctx* c, double* pos, double* prev, double* vel, doub
   st.nc = nc;
   int iter = 0;
   double delta = 1e5;
+  // verbose: host wall time per phase (each phase ends in a stream synchronisation when timed)
+  double t_energy = 0, t_asm = 0, t_solve = 0, t_ls = 0;
+  const bool timed = c->verbose >= 1;
+  auto now = [&]() { if (timed) (void)hipStreamSynchronize(s); return std::chrono::steady_clock::now(); };
+  auto secs = [](std::chrono::steady_clock::time_point a, std::chrono::steady_clock::time_point b) { return std::chrono::duration<double>(b - a).count(); };
   while (iter < c->newton_cap) {
     iter++;
     double E0;
+    auto t0 = now();
     TSL_TRY(energy_sync(c, pos, prev, vel, ref, &E0));
+    auto t1 = now();
     TSL_TRY(assemble(c, pos, prev, vel, ref, 1, c->F.p));
+    auto t2 = now();
     tsl_solve_stats ss;
     TSL_TRY(solve_orig(c, c->F.p, c->pdir.p, &ss));
+    auto t3 = now();
+    t_energy += secs(t0, t1); t_asm += secs(t1, t2); t_solve += secs(t2, t3);
     st.cg_iters += ss.iters; st.solves++; st.restarts += ss.restarts; st.fallback += (ss.flag != 0);
     // p_norm = max |p|  (calc_p_norm :1096-1103)
     HIP_OK(hipMemsetAsync(&SC(c)->pmax, 0, sizeof(double), s));
@@ -1504,8 +1542,11 @@ extern "C" int tsl_step(tsl_ctx* c, double* pos, double* prev, double* vel, doub
     HIP_OK(hipStreamSynchronize(s));
     delta = HSC(c)->pmax / c->dt;
     st.last_alpha = alpha; st.energy = E;
+    t_ls += secs(t3, now());
     if (delta < 1e-7) break;
   }
+  if (timed) fprintf(stderr, "[tsl] step: %d Newton iterations, %ld PCG iterations; energy %.3f s, assembly + preconditioner set-up %.3f s, solves %.3f s, line search %.3f s\n",
+                     iter, (long)st.cg_iters, t_energy, t_asm, t_solve, t_ls);
   st.newton_iters = iter; st.last_delta = delta;
   // timestep_finish: update_vel (+ plastic update_ref_angle, Scene_folding.py:227-231)
   hipLaunchKernelGGL(k_update_vel, dim3(gsz(n3)), dim3(256), 0, s, n3, pos, prev, c->damping / c->dt, vel);
