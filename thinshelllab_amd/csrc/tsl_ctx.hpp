@@ -208,7 +208,7 @@ struct tsl_ctx {
   double mg_omega = 0.0;   // > 0: fixed damping; 0: 1.5 / lambda_max(D^-1 A) per level from a power iteration
   int mg_pi_iters = 12;
   DevBuf<double> mg_omega0, mg_pi_part, mg_pi_norm;  // level 0
-  int mg_nu = 1, mg_coarse_sweeps = 8, mg_fuse = 1, mg_max_levels = 16, mg_coarse_exact = 1, mg_coarse_lag = 0, mg_dense_nodes = 256, mg_dense_auto = 1;
+  int mg_nu = 1, mg_coarse_sweeps = 8, mg_fuse = 1, mg_max_levels = 16, mg_coarse_exact = 1, mg_coarse_lag = 0, mg_dense_nodes = 64, mg_dense_auto = 1;
   double last_step_iters_per_solve = 0.0;
   bool mg_cinv_valid = false;
   bool mg_ops_valid = false, mg_suspended = false, mg_omega_valid = false;
@@ -226,6 +226,7 @@ struct tsl_ctx {
   std::vector<std::pair<hipEvent_t, hipEvent_t>> ev_pool;
   size_t ev_used = 0;
   long prof_chunks = 0;
+  double tm_loop = 0;  // verbose: host time spent in the PCG iteration loops of the current step
   bool ev_sample_next = false;
 
   // stats

@@ -654,7 +654,7 @@ static int mg_setup_operators(tsl_ctx* c) {
       else {
         const int ld = (n3 + GJ_B - 1) / GJ_B * GJ_B, nbk = ld / GJ_B;
         if (Ll->gj_ld != ld) {
-          if (Ll->gjD.alloc((size_t)ld * ld) | Ll->gjR.alloc((size_t)GJ_B * ld) | Ll->gjC.alloc((size_t)ld * GJ_B) | Ll->gjP.alloc(GJ_B * GJ_B))
+          if (Ll->gjD.alloc((size_t)ld * ld) | Ll->gjR.alloc((size_t)GJ_B * ld) | Ll->gjC.alloc((size_t)ld * GJ_B) | Ll->gjP.alloc(2 * GJ_B * GJ_B))
             return tsl_fail("out of device memory (coarse inverse workspace)");
           Ll->gj_ld = ld;
         }
@@ -668,9 +668,11 @@ static int mg_setup_operators(tsl_ctx* c) {
           HIP_OK(hipMemcpyAsync(h_orig.data(), Ll->gjD.p, h_orig.size() * sizeof(double), hipMemcpyDeviceToHost, s));
           HIP_OK(hipStreamSynchronize(s));
         }
+        double* Pb[2] = {Ll->gjP.p, Ll->gjP.p + GJ_B * GJ_B};  // pivot-block inverses of step k (k & 1) and k + 1
+        hipLaunchKernelGGL(k_gj_pivot0, dim3(1), dim3(256), 0, s, ld, Ll->gjD.p, Pb[0], Ll->cbad.p);
         for (int k = 0; k < nbk; k++) {
-          hipLaunchKernelGGL(k_gj_panel, dim3(nbk), dim3(256), 0, s, ld, k, Ll->gjD.p, Ll->gjR.p, Ll->gjC.p, Ll->gjP.p, Ll->cbad.p);
-          hipLaunchKernelGGL(k_gj_update, dim3(nbk, nbk), dim3(256), 0, s, ld, k, Ll->gjD.p, Ll->gjR.p, Ll->gjC.p, Ll->gjP.p);
+          hipLaunchKernelGGL(k_gj_panel, dim3(nbk), dim3(256), 0, s, ld, k, Ll->gjD.p, Pb[k & 1], Ll->gjR.p, Ll->gjC.p);
+          hipLaunchKernelGGL(k_gj_update, dim3(nbk, nbk), dim3(256), 0, s, ld, k, Ll->gjD.p, Ll->gjR.p, Ll->gjC.p, Pb[k & 1], Pb[(k + 1) & 1], Ll->cbad.p);
         }
         hipLaunchKernelGGL(k_gj_finish, dim3(nblk((long)n3 * n3, 256)), dim3(256), 0, s, n3, ld, Ll->gjD.p, Ll->cbad.p, Ll->Dinv.p, Ll->Cinv.p);
         if (c->verbose >= 2) {
@@ -941,6 +943,7 @@ static int solve_perm(tsl_ctx* c, tsl_solve_stats* st) {
     if (outer > 0) st->restarts++;
     need_fallback = true;
     int flag = 0, it = 0;
+    const auto tm0 = std::chrono::steady_clock::now();
     // iteration 0 (beta = 0) eagerly, then graph replays of `chunk` iterations (parities 1,0,...)
     launch_pcg_iteration(c, 0, 1, nullptr);
     it++; total_it++; c->prof_launches++;
@@ -982,6 +985,7 @@ static int solve_perm(tsl_ctx* c, tsl_solve_stats* st) {
     }
     if (inflight) HIP_OK(hipStreamSynchronize(s));
     if (c->prof_enable) prof_collect(c);
+    c->tm_loop += std::chrono::duration<double>(std::chrono::steady_clock::now() - tm0).count();
     if (flag) total_it = total_it - it + HPSC(c)->iters;  // iterations actually executed before the kernels went idle
     if (flag == 1) { indefinite = true; c->mg_omega_valid = false; c->mg_cinv_valid = false; }
     if (flag != 2) break;  // breakdown or iteration cap
@@ -1497,7 +1501,9 @@ extern "C" int tsl_step(tsl_ctx* c, double* pos, double* prev, double* vel, doub
   // level solved exactly by the multigrid cycle: a dense inverse per assembly pays for a ~840-node level (2.5k unknowns, some ms
   // per inversion) only when the solves are long -- decided from the previous time step (cfg4: 300 -> 220 iterations per solve
   // at +4.5 ms per assembly; the scaled scene with ~100 iterations per solve keeps the 225-node level)
-  if (c->mg_dense_auto) c->mg_dense_nodes = c->last_step_iters_per_solve > 200.0 ? 900 : 256;
+  // -- and a step whose predecessor needed fewer than 60 keeps the hierarchy down to the 64-node level, whose inverse is one
+  // single-workgroup kernel (drape: 25 iterations per solve, a 1 ms inversion per assembly would cost 15 % of the step)
+  if (c->mg_dense_auto) c->mg_dense_nodes = c->last_step_iters_per_solve > 200.0 ? 900 : c->last_step_iters_per_solve > 60.0 ? 256 : 64;
   c->bd_valid = false;  // dense body inverses are rebuilt once per step (first solve) and lagged over its Newton iterations
   // timestep_init: prev_pos <- pos (BaseScene.py:1291-1303)
   HIP_OK(hipMemcpyAsync(prev, pos, n3 * sizeof(double), hipMemcpyDeviceToDevice, s));
@@ -1510,6 +1516,7 @@ extern "C" int tsl_step(tsl_ctx* c, double* pos, double* prev, double* vel, doub
   double delta = 1e5;
   // verbose: host wall time per phase (each phase ends in a stream synchronisation when timed)
   double t_energy = 0, t_asm = 0, t_solve = 0, t_ls = 0;
+  c->tm_loop = 0;
   const bool timed = c->verbose >= 1;
   auto now = [&]() { if (timed) (void)hipStreamSynchronize(s); return std::chrono::steady_clock::now(); };
   auto secs = [](std::chrono::steady_clock::time_point a, std::chrono::steady_clock::time_point b) { return std::chrono::duration<double>(b - a).count(); };
@@ -1545,8 +1552,8 @@ extern "C" int tsl_step(tsl_ctx* c, double* pos, double* prev, double* vel, doub
     t_ls += secs(t3, now());
     if (delta < 1e-7) break;
   }
-  if (timed) fprintf(stderr, "[tsl] step: %d Newton iterations, %ld PCG iterations; energy %.3f s, assembly + preconditioner set-up %.3f s, solves %.3f s, line search %.3f s\n",
-                     iter, (long)st.cg_iters, t_energy, t_asm, t_solve, t_ls);
+  if (timed) fprintf(stderr, "[tsl] step: %d Newton iterations, %ld PCG iterations; energy %.3f s, assembly + preconditioner set-up %.3f s, solves %.3f s (iteration loops %.3f s), line search %.3f s\n",
+                     iter, (long)st.cg_iters, t_energy, t_asm, t_solve, c->tm_loop, t_ls);
   st.newton_iters = iter; st.last_delta = delta;
   // timestep_finish: update_vel (+ plastic update_ref_angle, Scene_folding.py:227-231)
   hipLaunchKernelGGL(k_update_vel, dim3(gsz(n3)), dim3(256), 0, s, n3, pos, prev, c->damping / c->dt, vel);
