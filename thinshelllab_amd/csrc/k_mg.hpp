@@ -197,75 +197,11 @@ k_st_prolong_sweep(MgGrid g, const double* __restrict__ A, const double* __restr
   }
 }
 
-// Exact solve on the coarsest level (<= 64 nodes, <= 192 unknowns).  Eight damped-Jacobi sweeps leave most of the smooth error
-// there (measured on cfg4: 436 PCG iterations per solve with 8 sweeps, 392 with 16) and cost 15 us per cycle; the dense inverse
-// costs one single-workgroup kernel per assembly and a 192 x 192 product (k_st_coarse_apply) per cycle.
-// k_st_coarse_invert: the 25-slot operator is expanded to a dense matrix held in registers (thread (ti, j) owns column j, rows
-// ti + 5 m), inverted in place by Gauss-Jordan without pivoting (the level operator is the Galerkin product of an SPD matrix;
-// rows of fully frozen unknowns are empty and become identity rows), pivot row / column passed through LDS, one barrier per
-// pivot.  A non-positive pivot (bad[0] = 1) stores one damped block-Jacobi sweep instead of the inverse.
-#define ST_DENSE_MAX 192
-#define ST_DENSE_RPT 39   // rows per thread: 5 * 39 >= 192
-__global__ void __launch_bounds__(960)
-k_st_coarse_invert(MgGrid g, const double* __restrict__ A, const double* __restrict__ Dinv, double* __restrict__ Cinv, int* __restrict__ bad) {
-  __shared__ double colb[2][ST_DENSE_MAX], rowb[2][ST_DENSE_MAX];
-  __shared__ int sbad;
-  const int n = (g.N + 1) * (g.M + 1), n3 = 3 * n;
-  const int j = threadIdx.x % ST_DENSE_MAX, ti = threadIdx.x / ST_DENSE_MAX;
-  const bool colok = j < n3;
-  const int nj = j / 3, cj = j % 3, Ij = nj / (g.M + 1), Jj = nj % (g.M + 1);
-  if (threadIdx.x == 0) sbad = 0;
-  double a[ST_DENSE_RPT];
-#pragma unroll
-  for (int m = 0; m < ST_DENSE_RPT; m++) {
-    const int i = ti + 5 * m;
-    double v = 0.0;
-    if (colok && i < n3) {
-      const int ni = i / 3, ci = i % 3, Ii = ni / (g.M + 1), Ji = ni % (g.M + 1);
-      const int dI = Ij - Ii, dJ = Jj - Ji;
-      if (dI >= -2 && dI <= 2 && dJ >= -2 && dJ <= 2) v = A[((size_t)((dI + 2) * 5 + (dJ + 2)) * 9 + ci * 3 + cj) * n + ni];
-      if (i == j && v == 0.0) v = 1.0;
-      if (j == 0) colb[0][i] = v;
-      if (i == 0) rowb[0][j] = v;
-    }
-    a[m] = v;
-  }
-  __syncthreads();
-  for (int k = 0; k < n3; k++) {
-    const int cur = k & 1;
-    const double piv = colb[cur][k];
-    if (threadIdx.x == 0 && !(piv > 0.0)) sbad = 1;
-    const double ip = 1.0 / piv;
-    const double rj = colok ? rowb[cur][j] : 0.0;
-#pragma unroll
-    for (int m = 0; m < ST_DENSE_RPT; m++) {
-      const int i = ti + 5 * m;
-      if (colok && i < n3) {
-        const double ci = colb[cur][i];
-        double v;
-        if (i == k) v = (j == k) ? ip : rj * ip;
-        else if (j == k) v = -ci * ip;
-        else v = a[m] - ci * rj * ip;
-        a[m] = v;
-        if (j == k + 1) colb[cur ^ 1][i] = v;
-        if (i == k + 1) rowb[cur ^ 1][j] = v;
-      }
-    }
-    __syncthreads();
-  }
-  const bool isbad = sbad != 0;  // a non-positive pivot: one damped block-Jacobi sweep instead (0.5 Dinv on the diagonal blocks)
-  const double omega = 0.5;
-#pragma unroll
-  for (int m = 0; m < ST_DENSE_RPT; m++) {
-    const int i = ti + 5 * m;
-    if (colok && i < n3) {
-      double v = a[m];
-      if (isbad) v = (i / 3 == nj) ? omega * Dinv[9 * (size_t)nj + 3 * (i % 3) + cj] : 0.0;
-      Cinv[(size_t)i * n3 + j] = v;
-    }
-  }
-  if (threadIdx.x == 0) bad[0] = sbad;
-}
+// Exact solve on the last level of the hierarchy.  Eight damped-Jacobi sweeps leave most of the smooth error there (measured on
+// cfg4: 436 PCG iterations per solve with 8 sweeps on the 64-node level, 392 with 16, 322 with the exact solve) and cost 15 us per
+// cycle; the dense inverse is rebuilt at every assembly by the blocked Gauss-Jordan below and applied as one dense product per cycle.
+// (A single-workgroup Gauss-Jordan with the 192 x 192 matrix in registers was tried for the 64-node level: 1.1 ms per call, 192
+// barrier-separated pivots, against 0.2 ms for the blocked version.)
 
 // x = Cinv r: one wave per two rows (row-major rows are contiguous: coalesced), 8 rows per workgroup, every load independent
 __global__ void __launch_bounds__(256)
@@ -309,28 +245,45 @@ __global__ void k_st_dense_diag(int n3, int ld, double* __restrict__ D) {
 // lockstep and its LDS accesses complete in order, so the 32 pivot steps need no workgroup barriers: ~5 us against 25 us for the
 // 256-thread version with two barriers per pivot).  Called by wave 0 of a workgroup; the caller synchronises before and after.
 TSL_DEV void gj_invert_tile_wave(double (*T)[GJ_B + 1], int* __restrict__ bad) {
+  // lane = (column c, row half h) keeps its 16 elements in registers; per pivot only the pivot row and column go through LDS
+  // (rowb / colb live in the last two rows' padding-free scratch below), the loop is fully unrolled so that register indices are static
+  __shared__ double colb[GJ_B], rowb[GJ_B];
   const int lane = threadIdx.x & 63;
   const int c = lane & 31, h = lane >> 5;
+  double a[GJ_B / 2];
+#pragma unroll
+  for (int m = 0; m < GJ_B / 2; m++) a[m] = T[h * (GJ_B / 2) + m][c];
+  bool isbad = false;
+#pragma unroll
   for (int p = 0; p < GJ_B; p++) {
-    const double piv = T[p][p];
-    const double rj = T[p][c];
+    if (c == p) {
+#pragma unroll
+      for (int m = 0; m < GJ_B / 2; m++) colb[h * (GJ_B / 2) + m] = a[m];
+    }
+    if (h == p / (GJ_B / 2)) rowb[c] = a[p % (GJ_B / 2)];
+    __builtin_amdgcn_wave_barrier();
+    const double piv = rowb[p];
+    const double rj = rowb[c];
     double ci[GJ_B / 2];
 #pragma unroll
-    for (int m = 0; m < GJ_B / 2; m++) ci[m] = T[h * (GJ_B / 2) + m][p];
+    for (int m = 0; m < GJ_B / 2; m++) ci[m] = colb[h * (GJ_B / 2) + m];
     __builtin_amdgcn_wave_barrier();
-    if (lane == 0 && !(piv > 0.0)) bad[0] = 1;
+    isbad = isbad || !(piv > 0.0);
     const double ip = 1.0 / piv;
+    const double rs = rj * ip;
 #pragma unroll
     for (int m = 0; m < GJ_B / 2; m++) {
       const int i = h * (GJ_B / 2) + m;
       double v;
-      if (i == p) v = (c == p) ? ip : rj * ip;
+      if (i == p) v = (c == p) ? ip : rs;
       else if (c == p) v = -ci[m] * ip;
-      else v = T[i][c] - ci[m] * rj * ip;
-      T[i][c] = v;
+      else v = a[m] - ci[m] * rs;
+      a[m] = v;
     }
-    __builtin_amdgcn_wave_barrier();
   }
+#pragma unroll
+  for (int m = 0; m < GJ_B / 2; m++) T[h * (GJ_B / 2) + m][c] = a[m];
+  if (lane == 0 && isbad) bad[0] = 1;
 }
 // inverse of the first pivot block -> Pout (the later ones come out of k_gj_update)
 __global__ void __launch_bounds__(256)

@@ -650,8 +650,7 @@ static int mg_setup_operators(tsl_ctx* c) {
       if (Ll->Cinv.n == 0) {
         if (Ll->Cinv.alloc((size_t)n3 * n3) | Ll->cbad.alloc(1)) return tsl_fail("out of device memory (coarse inverse)");
       }
-      if (n3 <= ST_DENSE_MAX) hipLaunchKernelGGL(k_st_coarse_invert, dim3(1), dim3(960), 0, s, MgGrid{Ll->N, Ll->M}, Ll->A.p, Ll->Dinv.p, Ll->Cinv.p, Ll->cbad.p);
-      else {
+      {
         const int ld = (n3 + GJ_B - 1) / GJ_B * GJ_B, nbk = ld / GJ_B;
         if (Ll->gj_ld != ld) {
           if (Ll->gjD.alloc((size_t)ld * ld) | Ll->gjR.alloc((size_t)GJ_B * ld) | Ll->gjC.alloc((size_t)ld * GJ_B) | Ll->gjP.alloc(2 * GJ_B * GJ_B))
