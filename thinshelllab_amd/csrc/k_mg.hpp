@@ -326,7 +326,7 @@ k_gj_panel(int ld, int k, const double* __restrict__ D, const double* __restrict
 }
 // update kernel of block step k: one 32 x 32 tile of the matrix per workgroup; the workgroup of tile (k+1, k+1) also inverts its
 // updated tile (the next pivot block) into Pnext
-__global__ void __launch_bounds__(256)
+__global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(4, 8)))  // the rare inversion path may spill, the tile path must keep its occupancy
 k_gj_update(int ld, int k, double* __restrict__ D, const double* __restrict__ Rn, const double* __restrict__ Cs, const double* __restrict__ Pin, double* __restrict__ Pnext,
             int* __restrict__ bad) {
   __shared__ double Ct[GJ_B][GJ_B + 1];
