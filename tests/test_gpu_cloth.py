@@ -73,6 +73,34 @@ def test_solve_matches_spsolve(oracle, N, M):
     assert rel_err(x.cpu().numpy(), xs) < 1e-7
 
 
+@pytest.mark.parametrize("N,M", [(64, 64), (48, 32)])
+def test_dense_coarse_level_sizes(oracle, N, M):
+    """The multigrid hierarchy ends in a dense exact solve (blocked Gauss-Jordan per assembly).  Every admissible last level
+    -- 64x64: 5x5 (75 unknowns, padded tile), 9x9 (243), 17x17 (867), 33x33 (3267); Jacobi sweeps with mg_coarse_exact = 0 --
+    must give the spsolve solution, and a larger exact level must not need more iterations than a smaller one."""
+    import scipy.sparse.linalg as spl
+    sys, o = _pair(oracle, N, M, amp=5e-5)
+    sys.compute_residual_and_Hessian(spd=True)
+    b = sys.F.to_torch()
+    xs = spl.spsolve(sys.H.to_csr().tocsc(), b.cpu().numpy())
+    ctx = sys._ctx
+    its = {}
+    for nodes in (30, 100, 300, 1200):
+        ctx.set_param("mg_dense_nodes", nodes)
+        sys.compute_residual_and_Hessian(spd=True)   # the inverse is rebuilt with the operators of an assembly
+        x, st = ctx.solve(b)
+        assert st["flag"] == 0, nodes
+        assert rel_err(x.cpu().numpy(), xs) < 1e-7, nodes
+        its[nodes] = st["iters"]
+    ctx.set_param("mg_coarse_exact", 0)
+    sys.compute_residual_and_Hessian(spd=True)
+    x, st = ctx.solve(b)
+    assert st["flag"] == 0 and rel_err(x.cpu().numpy(), xs) < 1e-7
+    ctx.set_param("mg_coarse_exact", 1); ctx.set_param("mg_dense_nodes", -1)
+    assert its[1200] <= its[300] + 1 <= its[100] + 2 <= its[30] + 3, its
+    assert its[30] <= st["iters"] + 1, (its, st["iters"])
+
+
 @pytest.mark.parametrize("N,M", [(10, 6), (16, 12)])
 def test_indefinite_solve_falls_back(oracle, N, M):
     """un-projected Hessian of a strongly perturbed cloth is indefinite: PCG must detect the breakdown and the
