@@ -356,21 +356,27 @@ k_gj_update(int ld, int k, double* __restrict__ D, const double* __restrict__ Rn
     Rt[ty + 8 * q][tx] = (bj == k) ? Pin[(ty + 8 * q) * GJ_B + tx] : Rn[(size_t)(ty + 8 * q) * ld + j0 + tx];
   }
   __syncthreads();
-  double out[4];
+  // rank-32 update of the tile on the f64 matrix cores: wave (wi, wj) owns a 16 x 16 quadrant, eight v_mfma_f64_16x16x4_f64 per
+  // quadrant (A: lane l holds C[l & 15][4 kk + (l >> 4)], B: R'[4 kk + (l >> 4)][l & 15]; result reg r of lane l is element
+  // (row (l >> 4) + 4 r, column l & 15)).  The vector-FMA version of this loop was LDS-bound (two ds_read per FMA).
+  typedef double d4 __attribute__((ext_vector_type(4)));
+  const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+  const int wi = w >> 1, wj = w & 1;
+  const int lr = lane & 15, lk = lane >> 4;
+  d4 acc = {0.0, 0.0, 0.0, 0.0};
 #pragma unroll
-  for (int q = 0; q < 4; q++) {
-    const int i = ty + 8 * q;
-    double acc = 0;
-#pragma unroll 8
-    for (int m = 0; m < GJ_B; m++) acc += Ct[i][m] * Rt[m][tx];
-    double* d = D + (size_t)(i0 + i) * ld + j0 + tx;
-    out[q] = (bj == k) ? -acc : *d - acc;
-    *d = out[q];
+  for (int kk = 0; kk < GJ_B / 4; kk++) acc = __builtin_amdgcn_mfma_f64_16x16x4f64(Ct[16 * wi + lr][4 * kk + lk], Rt[4 * kk + lk][16 * wj + lr], acc, 0, 0, 0);
+  const bool next_pivot = (bi == k + 1 && bj == k + 1);
+  if (next_pivot) __syncthreads();  // all quadrants done with Ct before it receives the updated tile
+#pragma unroll
+  for (int r = 0; r < 4; r++) {
+    const int row = 16 * wi + lk + 4 * r, col = 16 * wj + lr;
+    double* d = D + (size_t)(i0 + row) * ld + j0 + col;
+    const double v = (bj == k) ? -acc[r] : *d - acc[r];
+    *d = v;
+    if (next_pivot) Ct[row][col] = v;
   }
-  if (bi == k + 1 && bj == k + 1) {  // next pivot block
-    __syncthreads();
-#pragma unroll
-    for (int q = 0; q < 4; q++) Ct[ty + 8 * q][tx] = out[q];
+  if (next_pivot) {  // next pivot block
     __syncthreads();
     if (threadIdx.x < 64) gj_invert_tile_wave(Ct, bad);
     __syncthreads();
