@@ -210,6 +210,8 @@ struct tsl_ctx {
   DevBuf<double> mg_omega0, mg_pi_part, mg_pi_norm;  // level 0
   int mg_nu = 1, mg_coarse_sweeps = 8, mg_fuse = 1, mg_max_levels = 16, mg_coarse_exact = 1, mg_coarse_lag = 0, mg_dense_nodes = 64, mg_dense_auto = 1;
   double last_step_iters_per_solve = 0.0;
+  int warm_start = 0;       // PCG of a Newton iteration starts from the previous iteration's direction (optional, see solve_perm)
+  bool warm_valid = false;
   bool mg_cinv_valid = false;
   bool mg_ops_valid = false, mg_suspended = false, mg_omega_valid = false;
 
