@@ -212,6 +212,7 @@ struct tsl_ctx {
   double last_step_iters_per_solve = 0.0;
   int warm_start = 0;       // PCG of a Newton iteration starts from the previous iteration's direction (optional, see solve_perm)
   bool warm_valid = false;
+  int pcg_ahead = 0;        // 1: a second PCG chunk is launched before the convergence record of the first is read
   bool mg_cinv_valid = false;
   bool mg_ops_valid = false, mg_suspended = false, mg_omega_valid = false;
 

@@ -329,6 +329,7 @@ extern "C" int tsl_set_param(tsl_ctx* c, const char* key, double v) {
   else if (k == "mg_coarse_exact") c->mg_coarse_exact = (int)v;
   else if (k == "mg_coarse_lag") c->mg_coarse_lag = (int)v;
   else if (k == "warm_start") c->warm_start = (int)v;
+  else if (k == "pcg_ahead") c->pcg_ahead = (int)v;
   else if (k == "mg_dense_nodes") { c->mg_dense_auto = v < 0; if (v >= 0) c->mg_dense_nodes = (int)v; c->mg_ops_valid = false; }
   else if (k == "mg_max_levels") c->mg_max_levels = (int)v;
   else if (k == "mg_pi_iters") c->mg_pi_iters = (int)v;
@@ -956,9 +957,10 @@ static int solve_perm(tsl_ctx* c, tsl_solve_stats* st) {
     const bool graph = c->use_graph != 0;
     if (graph) TSL_TRY(pcg_chunk_graph(c, chunk));
     int n_chunks = 0;
-    // One chunk is kept in flight behind the one whose convergence record the host waits for (a graph launch plus the read-back
-    // round trip leaves the GPU idle for tens of microseconds per 4-iteration chunk otherwise); after convergence the extra chunk
-    // runs idle kernels (flag set).  A chunk whose device-clock stamps are sampled for the profile gets no successor until read.
+    // "pcg_ahead" = 1 keeps one more chunk in flight behind the one whose convergence record the host waits for; after
+    // convergence that extra chunk runs idle kernels (flag set).  Off by default: measured, the time per iteration does not change
+    // (the gaps are between dependent kernels inside the graph, not host round trips) and the idle chunk costs ~0.2 ms per solve.
+    // A chunk whose device-clock stamps are sampled for the profile gets no successor until read.
     int inflight = 0, head = 0;
     bool sampled[2] = {false, false};
     auto launch_chunk = [&]() -> int {
@@ -978,7 +980,7 @@ static int solve_perm(tsl_ctx* c, tsl_solve_stats* st) {
       return 0;
     };
     while (true) {
-      while (inflight < 2 && total_it < c->cg_maxit && !(inflight == 1 && sampled[head])) TSL_TRY(launch_chunk());
+      while (inflight < 1 + (c->pcg_ahead ? 1 : 0) && total_it < c->cg_maxit && !(inflight == 1 && sampled[head])) TSL_TRY(launch_chunk());
       if (inflight == 0) break;  // iteration cap
       HIP_OK(hipEventSynchronize(c->rb_event[head]));
       if (sampled[head]) TSL_TRY(prof_sample_graph(c));
