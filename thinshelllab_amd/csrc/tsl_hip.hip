@@ -930,19 +930,25 @@ static int solve_perm(tsl_ctx* c, tsl_solve_stats* st) {
     // true residual, z = M^-1 r, partial r.z / r.r
     hipLaunchKernelGGL(k_pcg_update, dim3(gb), dim3(256), 0, s, NV, (const double*)nullptr, (const double*)nullptr, c->Dinv.p, c->v_x.p, c->v_r.p, c->v_z.p, c->part_pAp.p,
                        c->part_rz.p, c->part_rr.p, PSC(c), 0, c->v_b.p, (outer > 0 || warm) ? c->v_Ap.p : (const double*)nullptr, mg_active(c) ? 0 : 1);
+    hipLaunchKernelGGL(k_sum_partials, dim3(1), dim3(256), 0, s, c->part_rr.p, gb, &PSC(c)->rr_last);
+    if (outer > 0) {  // verification of a converged recurrence: the true residual decides before a V-cycle is spent on it
+      TSL_TRY(read_scal(c));
+      const double rr1 = HPSC(c)->rr_last;
+      st->rel_residual = sqrt(rr1 / bb);
+      if (rr1 <= tol2) { need_fallback = false; break; }
+      // attainable accuracy: when a restart no longer halves the true residual the solve has reached what fp64 allows for
+      // this conditioning (a direct solver has the same backward error); accept if within 1e3 of the requested tolerance
+      if (rr1 > 0.25 * rr_prev_outer && rr1 <= 1e6 * tol2) { need_fallback = false; break; }
+    }
     if (mg_active(c)) {
       if (!c->mg_ops_valid) TSL_TRY(mg_setup_operators(c));
       mg_vcycle(c, c->v_r.p, c->v_z.p, c->part_rz.p);
     } else if (bd) body_apply(c, 0, c->v_r.p, nullptr, c->v_z.p, c->v_r.p, c->part_rz.p + gb);
-    hipLaunchKernelGGL(k_sum_partials, dim3(1), dim3(256), 0, s, c->part_rr.p, gb, &PSC(c)->rr_last);
     hipLaunchKernelGGL(k_sum_partials, dim3(1), dim3(256), 0, s, c->part_rz.p, n_rz, &PSC(c)->rz_last);
     TSL_TRY(read_scal(c));
     const double rr0 = HPSC(c)->rr_last;
     st->rel_residual = sqrt(rr0 / bb);
     if (rr0 <= tol2) { need_fallback = false; break; }
-    // attainable accuracy: when a restart no longer halves the true residual the solve has reached what fp64 allows for
-    // this conditioning (a direct solver has the same backward error); accept if within 1e3 of the requested tolerance
-    if (outer > 0 && rr0 > 0.25 * rr_prev_outer && rr0 <= 1e6 * tol2) { need_fallback = false; break; }
     rr_prev_outer = rr0;
     if (!(HPSC(c)->rz_last > 0)) { need_fallback = true; break; }
     if (outer > 0) st->restarts++;
