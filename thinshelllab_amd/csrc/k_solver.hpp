@@ -164,8 +164,8 @@ k_spmv(int NV, int n_slices, const int* __restrict__ slice_off, const int* __res
 // Columns past the end of the slice repeat a valid one with weight 0 (cached reloads, no branches).  NVEC = 2 also accumulates
 // the product with a second vector (q).
 #define SELL_U 4
-template <int NVEC, int WPS, bool NT>
-TSL_DEV void sell_wave_product(const int* __restrict__ cp, const double* __restrict__ vp, int len, int w, const double* __restrict__ x, const double* __restrict__ x2,
+template <int NVEC, int WPS, bool NT, typename VT = double>
+TSL_DEV void sell_wave_product(const int* __restrict__ cp, const VT* __restrict__ vp, int len, int w, const double* __restrict__ x, const double* __restrict__ x2,
                                double& y0, double& y1, double& y2, double& q0, double& q1, double& q2) {
   for (int k0 = w; k0 < len; k0 += SELL_U * WPS) {
     int kk[SELL_U], c[SELL_U];
@@ -180,9 +180,9 @@ TSL_DEV void sell_wave_product(const int* __restrict__ cp, const double* __restr
     double a[SELL_U][9];
 #pragma unroll
     for (int u = 0; u < SELL_U; u++) {
-      const double* ap = vp + (size_t)kk[u] * 576;
+      const VT* ap = vp + (size_t)kk[u] * 576;
 #pragma unroll
-      for (int e = 0; e < 9; e++) a[u][e] = NT ? __builtin_nontemporal_load(ap + 64 * e) : ap[64 * e];
+      for (int e = 0; e < 9; e++) a[u][e] = (double)(NT ? __builtin_nontemporal_load(ap + 64 * e) : ap[64 * e]);
     }
     d3 xj[SELL_U], wj[SELL_U];
 #pragma unroll
@@ -204,15 +204,21 @@ TSL_DEV void sell_wave_product(const int* __restrict__ cp, const double* __restr
   }
 }
 
+__global__ void k_vals_to_f32(size_t n, const double* __restrict__ src, float* __restrict__ dst) {
+  for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x) dst[i] = (float)src[i];
+}
+
 // Variant with WPS waves per slice: wave w of a slice handles block columns k = w, w+WPS, ... (more loads in flight per
 // row: 784 single-wave slices cannot fill 1024 SIMDs at 100k triangles), partial row sums are combined through LDS.
 // NT: matrix values / column ids are streamed with non-temporal loads so that they do not evict the x vector from L2.
 // part != nullptr: the block's dot(x, y) partial is stored to part[blockIdx.x] (deterministic two-stage reduction, no
 // same-address atomics).  blockDim.x = 64 * WPS * SPB (SPB slices per block).
-template <int WPS, int SPB, bool NT>
+// VT = float: the single-precision copy of the matrix that the multigrid smoother uses (k_vals_to_f32); products that define the
+// solution (PCG operator, true residuals, MINRES / GMRES) always read the double-precision matrix.
+template <int WPS, int SPB, bool NT, typename VT = double>
 __global__ void __launch_bounds__(64 * WPS * SPB)
 k_spmv_mw(int NV, int n_slices, const int* __restrict__ slice_off, const int* __restrict__ slice_len, const int* __restrict__ colidx,
-          const double* __restrict__ vals, const double* __restrict__ x, double* __restrict__ y, double* __restrict__ part, const int* __restrict__ flag,
+          const VT* __restrict__ vals, const double* __restrict__ x, double* __restrict__ y, double* __restrict__ part, const int* __restrict__ flag,
           ContactRows CR) {
   __shared__ double red[SPB][WPS][3][64];
   __shared__ double dred[SPB];
@@ -231,9 +237,9 @@ k_spmv_mw(int NV, int n_slices, const int* __restrict__ slice_off, const int* __
   if (slice < n_slices) {
     const int off = slice_off[slice], len = slice_len[slice];
     const int* cp = colidx + off + lane;
-    const double* vp = vals + (size_t)off * 9 + lane;
+    const VT* vp = vals + (size_t)off * 9 + lane;
     double u0 = 0, u1 = 0, u2 = 0;
-    sell_wave_product<1, WPS, NT>(cp, vp, len, w, x, nullptr, y0, y1, y2, u0, u1, u2);
+    sell_wave_product<1, WPS, NT, VT>(cp, vp, len, w, x, nullptr, y0, y1, y2, u0, u1, u2);
   }
   if (WPS > 1) {
     red[sl][w][0][lane] = y0; red[sl][w][1][lane] = y1; red[sl][w][2][lane] = y2;

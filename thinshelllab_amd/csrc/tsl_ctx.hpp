@@ -141,6 +141,9 @@ struct tsl_ctx {
   std::vector<std::vector<int>> h_rows;  // original-order adjacency (sorted)
   DevBuf<int> rowpos, perm, slice_off, slice_len, colidx, diag_perm;
   DevBuf<double> vals, vals_full;  // masked (solver) and unmasked (adjoint) copies
+  DevBuf<float> vals32;            // single-precision copy of the preconditioner's matrix for the multigrid smoother products
+  bool vals32_valid = false;
+  int mg_f32 = 1;
   DevBuf<double> Dinv;             // NV x 9 (permuted)
   DevBuf<unsigned char> fzmask;    // NV (permuted) 3-bit frozen mask
   DevBuf<double> mdt2;             // NV (permuted) m/dt^2

@@ -329,6 +329,7 @@ extern "C" int tsl_set_param(tsl_ctx* c, const char* key, double v) {
   else if (k == "mg_coarse_exact") c->mg_coarse_exact = (int)v;
   else if (k == "mg_coarse_lag") c->mg_coarse_lag = (int)v;
   else if (k == "warm_start") c->warm_start = (int)v;
+  else if (k == "mg_f32") { c->mg_f32 = (int)v; c->vals32_valid = false; c->mg_ops_valid = false; }
   else if (k == "pcg_ahead") c->pcg_ahead = (int)v;
   else if (k == "mg_dense_nodes") { c->mg_dense_auto = v < 0; if (v >= 0) c->mg_dense_nodes = (int)v; c->mg_ops_valid = false; }
   else if (k == "mg_max_levels") c->mg_max_levels = (int)v;
@@ -624,13 +625,23 @@ static void mg_spmv0(tsl_ctx* c, const double* x, double* y) {
   hipStream_t s = c->stream;
   const double* vals = c->pc_separate ? c->vals_pc.p : c->vals.p;
   const double* cH = c->pc_separate ? c->c_H_pc.p : c->c_H.p;
-  hipLaunchKernelGGL((k_spmv_mw<4, 1, TSL_NT>), dim3(c->n_slices), dim3(256), 0, s, c->NV, c->n_slices, c->slice_off.p, c->slice_len.p, c->colidx.p, vals, x, y,
-                     (double*)nullptr, (const int*)nullptr, contact_rows(c, cH));
+  if (c->mg_f32 && c->vals32_valid)  // smoother products read the single-precision copy made by mg_setup_operators (half the bytes)
+    hipLaunchKernelGGL((k_spmv_mw<4, 1, TSL_NT, float>), dim3(c->n_slices), dim3(256), 0, s, c->NV, c->n_slices, c->slice_off.p, c->slice_len.p, c->colidx.p, c->vals32.p, x, y,
+                       (double*)nullptr, (const int*)nullptr, contact_rows(c, cH));
+  else
+    hipLaunchKernelGGL((k_spmv_mw<4, 1, TSL_NT>), dim3(c->n_slices), dim3(256), 0, s, c->NV, c->n_slices, c->slice_off.p, c->slice_len.p, c->colidx.p, vals, x, y,
+                       (double*)nullptr, (const int*)nullptr, contact_rows(c, cH));
 }
 
 // Galerkin coarse operators of the current (masked) matrix; called once per assembly when the preconditioner is active
 static int mg_setup_operators(tsl_ctx* c) {
   hipStream_t s = c->stream;
+  c->vals32_valid = false;
+  if (c->mg_f32) {  // the matrix in c->vals at this point is the one the preconditioner is built from (also in the separate-pc set-ups)
+    if (c->vals32.n == 0 && c->vals32.alloc(c->vals.n)) return tsl_fail("out of device memory (vals32)");
+    hipLaunchKernelGGL(k_vals_to_f32, dim3(gsz(c->vals.n)), dim3(256), 0, s, c->vals.n, c->vals.p, c->vals32.p);
+    c->vals32_valid = true;
+  }
   for (MgCloth* mc : c->mg) {
     MgGrid gf{mc->N0, mc->M0};
     MgLevel* L1 = mc->lv[0];
@@ -841,7 +852,7 @@ static void launch_pcg_iteration(tsl_ctx* c, int parity, int first, unsigned lon
 // iteration is ~45 short kernels, eager launches leave the GPU idle ~30 % of the time.  The first K1 of the chunk stamps
 // the device clock into a fixed buffer when profiling is on.
 static int pcg_chunk_graph(tsl_ctx* c, int chunk) {
-  const long key = ((long)(mg_active(c) ? 1 : 0) << 40) | ((long)c->nc << 8) | ((long)(c->prof_enable ? 1 : 0) << 7) | (long)chunk | ((long)c->mg_nu << 44) | ((long)c->mg_coarse_sweeps << 48) | ((long)(c->pc_separate ? 1 : 0) << 41) | ((long)((body_active(c) && c->bd_valid) ? 1 : 0) << 42) | ((long)(c->mg_fuse ? 1 : 0) << 43) | ((long)c->mg_max_levels << 52) | ((long)(c->mg_coarse_exact ? 1 : 0) << 39) | ((long)(c->mg_dense_nodes & 0xfff) << 24);
+  const long key = ((long)(mg_active(c) ? 1 : 0) << 40) | ((long)c->nc << 8) | ((long)(c->prof_enable ? 1 : 0) << 7) | (long)chunk | ((long)c->mg_nu << 44) | ((long)c->mg_coarse_sweeps << 48) | ((long)(c->pc_separate ? 1 : 0) << 41) | ((long)((body_active(c) && c->bd_valid) ? 1 : 0) << 42) | ((long)(c->mg_fuse ? 1 : 0) << 43) | ((long)c->mg_max_levels << 52) | ((long)(c->mg_coarse_exact ? 1 : 0) << 39) | ((long)((c->mg_f32 && c->vals32_valid) ? 1 : 0) << 38) | ((long)(c->mg_dense_nodes & 0xfff) << 24);
   if (c->pcg_graph && c->pcg_graph_key == key) return 0;
   if (c->pcg_graph) { (void)hipGraphExecDestroy(c->pcg_graph); c->pcg_graph = nullptr; }
   hipGraph_t g = nullptr;
@@ -1073,7 +1084,7 @@ static void launch_minres_iteration(tsl_ctx* c, const MrBufs& B, int j) {
 
 static long solver_graph_key(tsl_ctx* c) {
   return ((long)(mg_active(c) ? 1 : 0) << 40) | ((long)c->nc << 8) | ((long)(c->prof_enable ? 1 : 0) << 7) | ((long)c->mg_nu << 44) | ((long)c->mg_coarse_sweeps << 48) |
-         ((long)(c->pc_separate ? 1 : 0) << 41) | ((long)((body_active(c) && c->bd_valid) ? 1 : 0) << 42) | ((long)(c->mg_fuse ? 1 : 0) << 43) | ((long)c->mg_max_levels << 52) | ((long)(c->mg_coarse_exact ? 1 : 0) << 39) | ((long)(c->mg_dense_nodes & 0xfff) << 24);
+         ((long)(c->pc_separate ? 1 : 0) << 41) | ((long)((body_active(c) && c->bd_valid) ? 1 : 0) << 42) | ((long)(c->mg_fuse ? 1 : 0) << 43) | ((long)c->mg_max_levels << 52) | ((long)(c->mg_coarse_exact ? 1 : 0) << 39) | ((long)((c->mg_f32 && c->vals32_valid) ? 1 : 0) << 38) | ((long)(c->mg_dense_nodes & 0xfff) << 24);
 }
 
 static int minres_graph(tsl_ctx* c, const MrBufs& B) {
