@@ -203,17 +203,18 @@ k_st_prolong_sweep(MgGrid g, const double* __restrict__ A, const double* __restr
 // (A single-workgroup Gauss-Jordan with the 192 x 192 matrix in registers was tried for the 64-node level: 1.1 ms per call, 192
 // barrier-separated pivots, against 0.2 ms for the blocked version.)
 
-// x = Cinv r: one wave per two rows (row-major rows are contiguous: coalesced), 8 rows per workgroup, every load independent
+// x = Cinv r: one wave per two rows (row-major rows are contiguous: coalesced), 8 rows per workgroup, every load independent.
+// The inverse is stored symmetrised in single precision (it is a preconditioner component; the inversion itself runs in double).
 __global__ void __launch_bounds__(256)
-k_st_coarse_apply(int n3, const double* __restrict__ Cinv, const double* __restrict__ r, double* __restrict__ out) {
+k_st_coarse_apply(int n3, const float* __restrict__ Cinv, const double* __restrict__ r, double* __restrict__ out) {
   const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
   const int i0 = blockIdx.x * 8 + 2 * w, i1 = i0 + 1;
   if (i0 >= n3) return;
-  const double* c0 = Cinv + (size_t)i0 * n3;
-  const double* c1 = Cinv + (size_t)(i1 < n3 ? i1 : i0) * n3;
+  const float* c0 = Cinv + (size_t)i0 * n3;
+  const float* c1 = Cinv + (size_t)(i1 < n3 ? i1 : i0) * n3;
   double s0 = 0, s1 = 0;
 #pragma unroll 4
-  for (int jj = lane; jj < n3; jj += 64) { const double rj = r[jj]; s0 += c0[jj] * rj; s1 += c1[jj] * rj; }
+  for (int jj = lane; jj < n3; jj += 64) { const double rj = r[jj]; s0 += (double)c0[jj] * rj; s1 += (double)c1[jj] * rj; }
   s0 = wave_sum(s0); s1 = wave_sum(s1);
   if (lane == 0) { out[i0] = s0; if (i1 < n3) out[i1] = s1; }
 }
@@ -385,14 +386,14 @@ k_gj_update(int ld, int k, double* __restrict__ D, const double* __restrict__ Rn
   }
 }
 // after the last block step: symmetrise into the inverse buffer (row stride n3), or the block-Jacobi fallback on a bad pivot
-__global__ void k_gj_finish(int n3, int ld, const double* __restrict__ D, const int* __restrict__ bad, const double* __restrict__ Dinv, double* __restrict__ Cinv) {
+__global__ void k_gj_finish(int n3, int ld, const double* __restrict__ D, const int* __restrict__ bad, const double* __restrict__ Dinv, float* __restrict__ Cinv) {
   const long t = (long)blockIdx.x * blockDim.x + threadIdx.x;
   if (t >= (long)n3 * n3) return;
   const int i = (int)(t / n3), j = (int)(t % n3);
   double v;
   if (!bad[0]) v = 0.5 * (D[(size_t)i * ld + j] + D[(size_t)j * ld + i]);
   else v = (i / 3 == j / 3) ? 0.5 * Dinv[9 * (size_t)(i / 3) + 3 * (i % 3) + j % 3] : 0.0;
-  Cinv[t] = v;
+  Cinv[t] = (float)v;
 }
 
 // (3) the whole coarsest level (<= 64 nodes) in one workgroup: x = omega Dinv r, then sweeps - 1 damped-Jacobi sweeps with the

@@ -74,7 +74,7 @@ struct MgLevel {
   int N = 0, M = 0, n = 0;
   DevBuf<double> A, Dinv, x, x2, r, t;
   DevBuf<double> omega;  // [0] damping factor, [1] lambda_max estimate (device resident)
-  DevBuf<double> Cinv;   // dense inverse of the last level of the hierarchy (blocked Gauss-Jordan per assembly)
+  DevBuf<float> Cinv;    // dense inverse of the last level of the hierarchy (blocked Gauss-Jordan per assembly), symmetrised, fp32
   DevBuf<int> cbad;
   DevBuf<double> gjD, gjR, gjC, gjP;  // blocked Gauss-Jordan workspace (dense levels with more than 192 unknowns)
   int gj_ld = 0;

@@ -688,16 +688,16 @@ static int mg_setup_operators(tsl_ctx* c) {
         }
         hipLaunchKernelGGL(k_gj_finish, dim3(nblk((long)n3 * n3, 256)), dim3(256), 0, s, n3, ld, Ll->gjD.p, Ll->cbad.p, Ll->Dinv.p, Ll->Cinv.p);
         if (c->verbose >= 2) {
-          std::vector<double> h_inv((size_t)n3 * n3);
+          std::vector<float> h_inv((size_t)n3 * n3);
           int hb = 0;
-          HIP_OK(hipMemcpyAsync(h_inv.data(), Ll->Cinv.p, h_inv.size() * sizeof(double), hipMemcpyDeviceToHost, s));
+          HIP_OK(hipMemcpyAsync(h_inv.data(), Ll->Cinv.p, h_inv.size() * sizeof(float), hipMemcpyDeviceToHost, s));
           HIP_OK(hipMemcpyAsync(&hb, Ll->cbad.p, sizeof(int), hipMemcpyDeviceToHost, s));
           HIP_OK(hipStreamSynchronize(s));
           double worst = 0;
           for (int i = 0; i < n3; i++)
             for (int j = 0; j < n3; j++) {
               double acc = 0;
-              for (int m = 0; m < n3; m++) acc += h_inv[(size_t)i * n3 + m] * h_orig[(size_t)m * ld + j];
+              for (int m = 0; m < n3; m++) acc += (double)h_inv[(size_t)i * n3 + m] * h_orig[(size_t)m * ld + j];
               worst = std::max(worst, fabs(acc - (i == j ? 1.0 : 0.0)));
             }
           fprintf(stderr, "[tsl] dense coarse level %d x %d: n3 %d, max |Cinv A - I| = %.3e, bad pivot flag %d\n", Ll->N + 1, Ll->M + 1, n3, worst, hb);
