@@ -299,22 +299,30 @@ k_gj_pivot0(int ld, const double* __restrict__ D, double* __restrict__ Pout, int
 #pragma unroll
   for (int q = 0; q < 4; q++) Pout[(ty + 8 * q) * GJ_B + tx] = T[ty + 8 * q][tx];
 }
-// panel kernel of block step k: workgroup b writes R'[:, chunk b] = P A[K, chunk b] and the saved column panel
-// C[chunk b, :] = A[chunk b, K]  (P = inverse of the pivot block, from k_gj_pivot0 / the previous k_gj_update)
+// Only the tiles on and above the block diagonal are stored and updated (half the traffic and flops): with P the set of pivot
+// blocks already processed, the Gauss-Jordan iterate satisfies M_ji = s M_ij^T, s = -1 when exactly one of the two blocks is in P,
+// +1 otherwise (scalar check: pivot k turns a_kj into a_kj / p and a_ik into -a_ik / p).
+// panel kernel of block step k: workgroup b reads the one stored tile that couples chunk b with the pivot block and writes
+// R'[:, chunk b] = P M[K, chunk b] and the saved column panel C[chunk b, :] = M[chunk b, K]
+// (P = inverse of the pivot block, from k_gj_pivot0 / the previous k_gj_update)
 __global__ void __launch_bounds__(256)
 k_gj_panel(int ld, int k, const double* __restrict__ D, const double* __restrict__ Pin, double* __restrict__ Rn, double* __restrict__ Cs) {
   __shared__ double P[GJ_B][GJ_B + 1];
-  __shared__ double T[GJ_B][GJ_B + 1];
+  __shared__ double T[GJ_B][GJ_B + 1];   // M[K, chunk b]
   const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;  // 32 x 8
-  const int k0 = k * GJ_B, b0 = blockIdx.x * GJ_B;
+  const int b = blockIdx.x;
+  const int k0 = k * GJ_B, b0 = b * GJ_B;
+  const int r0 = b < k ? b0 : k0, c0 = b < k ? k0 : b0;   // stored tile (min, max)
 #pragma unroll
   for (int q = 0; q < 4; q++) {
-    P[ty + 8 * q][tx] = Pin[(ty + 8 * q) * GJ_B + tx];
-    T[ty + 8 * q][tx] = D[(size_t)(k0 + ty + 8 * q) * ld + b0 + tx];
+    const int i = ty + 8 * q;
+    P[i][tx] = Pin[i * GJ_B + tx];
+    const double sv = D[(size_t)(r0 + i) * ld + c0 + tx];
+    // b >= k: stored tile is M[K, b] itself and M[b, K] = +its transpose (both blocks unprocessed);
+    // b <  k: stored tile is M[b, K] and M[K, b] = -its transpose (b processed, k not)
+    if (b >= k) { T[i][tx] = sv; Cs[(size_t)(b0 + tx) * GJ_B + i] = sv; }
+    else { T[tx][i] = -sv; Cs[(size_t)(b0 + i) * GJ_B + tx] = sv; }
   }
-  // saved column panel chunk
-#pragma unroll
-  for (int q = 0; q < 4; q++) Cs[(size_t)(b0 + ty + 8 * q) * GJ_B + tx] = D[(size_t)(b0 + ty + 8 * q) * ld + k0 + tx];
   __syncthreads();
 #pragma unroll
   for (int q = 0; q < 4; q++) {
@@ -340,6 +348,7 @@ k_gj_update(int ld, int k, double* __restrict__ D, const double* __restrict__ Rn
     if (bi == 0 && bj == 0) bi = bj = k + 1;
     else if (bi == k + 1 && bj == k + 1) bi = bj = 0;
   }
+  if (bi > bj) return;  // tiles below the block diagonal are implied by the ones above (see k_gj_panel)
   const int i0 = bi * GJ_B, j0 = bj * GJ_B;
   if (bi == k && bj == k) {
 #pragma unroll
@@ -391,7 +400,10 @@ __global__ void k_gj_finish(int n3, int ld, const double* __restrict__ D, const 
   if (t >= (long)n3 * n3) return;
   const int i = (int)(t / n3), j = (int)(t % n3);
   double v;
-  if (!bad[0]) v = 0.5 * (D[(size_t)i * ld + j] + D[(size_t)j * ld + i]);
+  if (!bad[0]) {
+    const int ti = i / GJ_B, tj = j / GJ_B;  // only tiles on / above the block diagonal hold the result
+    v = ti == tj ? 0.5 * (D[(size_t)i * ld + j] + D[(size_t)j * ld + i]) : ti < tj ? D[(size_t)i * ld + j] : D[(size_t)j * ld + i];
+  }
   else v = (i / 3 == j / 3) ? 0.5 * Dinv[9 * (size_t)(i / 3) + 3 * (i % 3) + j % 3] : 0.0;
   Cinv[t] = (float)v;
 }
