@@ -849,7 +849,7 @@ static void launch_pcg_iteration(tsl_ctx* c, int parity, int first, unsigned lon
 }
 
 // Chunk of `chunk` (even) iterations with parities 1,0,1,0,... captured once as a hipGraph and replayed: a multigrid-PCG
-// iteration is ~45 short kernels, eager launches leave the GPU idle ~30 % of the time.  The first K1 of the chunk stamps
+// iteration is ~20 short kernels.  The first K1 of the chunk stamps
 // the device clock into a fixed buffer when profiling is on.
 static int pcg_chunk_graph(tsl_ctx* c, int chunk) {
   const long key = ((long)(mg_active(c) ? 1 : 0) << 40) | ((long)c->nc << 8) | ((long)(c->prof_enable ? 1 : 0) << 7) | (long)chunk | ((long)c->mg_nu << 44) | ((long)c->mg_coarse_sweeps << 48) | ((long)(c->pc_separate ? 1 : 0) << 41) | ((long)((body_active(c) && c->bd_valid) ? 1 : 0) << 42) | ((long)(c->mg_fuse ? 1 : 0) << 43) | ((long)c->mg_max_levels << 52) | ((long)(c->mg_coarse_exact ? 1 : 0) << 39) | ((long)((c->mg_f32 && c->vals32_valid) ? 1 : 0) << 38) | ((long)(c->mg_dense_nodes & 0xfff) << 24);
