@@ -149,6 +149,38 @@ TSL_DEV void body_apply_block(const BodyDenseArgs& A, const float* __restrict__ 
   const int n3 = A.n3[b];
   const int ld = (n3 + 3) & ~3;
   const int* rows = A.rows + A.rows_off[b];
+  const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+  const int row0 = (bid - A.wg_off[b]) * BODY_APPLY_ROWS;
+  const float* Bb = Binv + A.w_off[b];
+  const int nq = ld >> 2;
+  // Everything that does not depend on the staged vector is requested first (matrix rows of this wave, the old z / rdot of its two
+  // output rows): the kernel is a chain of dependent round trips otherwise (row ids -> r, t -> matrix -> row ids -> z), 6.8 us.
+  const int i0 = row0 + w * (BODY_APPLY_ROWS / 4), i1 = i0 + 1;  // two rows per wave
+  const bool live = i0 < n3, live1 = i1 < n3;
+  constexpr int MAXQ = (3 * 512 / 4 + 63) / 64;
+  float4 a0[MAXQ], a1[MAXQ];
+  size_t g0 = 0, g1 = 0;
+  double zo0 = 0, zo1 = 0, rd0 = 0, rd1 = 0;
+  if (live) {
+    const float4* b0 = (const float4*)(Bb + (size_t)i0 * ld);
+    const float4* b1 = (const float4*)(Bb + (size_t)(live1 ? i1 : i0) * ld);
+#pragma unroll
+    for (int u = 0; u < MAXQ; u++) {
+      const int j = lane + 64 * u;
+      a0[u] = j < nq ? b0[j] : make_float4(0, 0, 0, 0);
+      a1[u] = j < nq ? b1[j] : make_float4(0, 0, 0, 0);
+    }
+    if (lane == 0) {
+      g0 = 3 * (size_t)rows[i0 / 3] + i0 % 3;
+      if (mode) zo0 = z[g0];
+      if (rdot) rd0 = rdot[g0];
+      if (live1) {
+        g1 = 3 * (size_t)rows[i1 / 3] + i1 % 3;
+        if (mode) zo1 = z[g1];
+        if (rdot) rd1 = rdot[g1];
+      }
+    }
+  }
   for (int i = threadIdx.x; i < ld; i += 256) {
     double x = 0.0;
     if (i < n3) {
@@ -158,35 +190,27 @@ TSL_DEV void body_apply_block(const BodyDenseArgs& A, const float* __restrict__ 
     v[i] = x;
   }
   __syncthreads();
-  const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
-  const int row0 = (bid - A.wg_off[b]) * BODY_APPLY_ROWS;
-  const float* Bb = Binv + A.w_off[b];
-  const int nq = ld >> 2;
   double acc = 0;
-#pragma unroll
-  for (int q = 0; q < BODY_APPLY_ROWS / 4; q += 2) {  // two rows in flight per wave
-    const int i0 = row0 + w * (BODY_APPLY_ROWS / 4) + q, i1 = i0 + 1;
-    if (i0 >= n3) break;
-    const float4* b0 = (const float4*)(Bb + (size_t)i0 * ld);
-    const float4* b1 = (const float4*)(Bb + (size_t)(i1 < n3 ? i1 : i0) * ld);
+  if (live) {
     double sum0 = 0, sum1 = 0;
-    for (int j = lane; j < nq; j += 64) {
-      const float4 a0 = b0[j], a1 = b1[j];
-      const double v0 = v[4 * j], v1 = v[4 * j + 1], v2 = v[4 * j + 2], v3 = v[4 * j + 3];
-      sum0 += (double)a0.x * v0 + (double)a0.y * v1 + (double)a0.z * v2 + (double)a0.w * v3;
-      sum1 += (double)a1.x * v0 + (double)a1.y * v1 + (double)a1.z * v2 + (double)a1.w * v3;
+#pragma unroll
+    for (int u = 0; u < MAXQ; u++) {
+      const int j = lane + 64 * u;
+      if (j < nq) {
+        const double v0 = v[4 * j], v1 = v[4 * j + 1], v2 = v[4 * j + 2], v3 = v[4 * j + 3];
+        sum0 += (double)a0[u].x * v0 + (double)a0[u].y * v1 + (double)a0[u].z * v2 + (double)a0[u].w * v3;
+        sum1 += (double)a1[u].x * v0 + (double)a1[u].y * v1 + (double)a1[u].z * v2 + (double)a1[u].w * v3;
+      }
     }
     sum0 = wave_sum(sum0); sum1 = wave_sum(sum1);
     if (lane == 0) {
-      const size_t g0 = 3 * (size_t)rows[i0 / 3] + i0 % 3;
-      const double z0 = mode ? z[g0] + sum0 : sum0;
+      const double z0 = zo0 + sum0;   // zo = 0 in mode 0
       z[g0] = z0;
-      if (rdot) acc += rdot[g0] * (full_dot ? z0 : sum0);  // separate launches in mode 1: the Jacobi kernel already counted rdot . z_old
-      if (i1 < n3) {
-        const size_t g1 = 3 * (size_t)rows[i1 / 3] + i1 % 3;
-        const double z1 = mode ? z[g1] + sum1 : sum1;
+      acc += rd0 * (full_dot ? z0 : sum0);  // separate launches in mode 1: the Jacobi kernel already counted rdot . z_old
+      if (live1) {
+        const double z1 = zo1 + sum1;
         z[g1] = z1;
-        if (rdot) acc += rdot[g1] * (full_dot ? z1 : sum1);
+        acc += rd1 * (full_dot ? z1 : sum1);
       }
     }
   }

@@ -411,6 +411,22 @@ k_pcg_update(int NV, const double* __restrict__ pv, const double* __restrict__ A
              const double* __restrict__ omega_dev = nullptr) {
   __shared__ double sm[8];
   double alpha = 0;
+  const int p = blockIdx.x * blockDim.x + threadIdx.x;
+  // operands of the update: loaded before the reduction of the p.Ap partials so that the two memory round trips overlap
+  d3 pp(0, 0, 0), xv(0, 0, 0), rv(0, 0, 0), apv(0, 0, 0);
+  m3 D;
+  if (p < NV) {
+    if (b_init) {
+      rv = ld3(b_init, p);
+      if (Ax_init) rv = rv - ld3(Ax_init, p);
+    } else {
+      pp = ld3(pv, p); xv = ld3(x, p); rv = ld3(r, p); apv = ld3(Ap, p);
+    }
+    if (use_dinv) {
+#pragma unroll
+      for (int e = 0; e < 9; e++) D.m[e] = Dinv[9 * (size_t)p + e];
+    }
+  }
   if (!b_init) {
     if (sc->flag) return;
     const double pAp = block_reduce_partials(part_pAp, sc->n_part1, sm);
@@ -421,24 +437,15 @@ k_pcg_update(int NV, const double* __restrict__ pv, const double* __restrict__ A
     }
     alpha = rz / pAp;
   }
-  const int p = blockIdx.x * blockDim.x + threadIdx.x;
   double rzn = 0, rr = 0;
   if (p < NV) {
-    d3 rv;
-    if (b_init) {
-      rv = ld3(b_init, p);
-      if (Ax_init) rv = rv - ld3(Ax_init, p);
-    } else {
-      const d3 pp = ld3(pv, p);
-      st3(x, p, ld3(x, p) + alpha * pp);
-      rv = ld3(r, p) - alpha * ld3(Ap, p);
+    if (!b_init) {
+      st3(x, p, xv + alpha * pp);
+      rv = rv - alpha * apv;
     }
     st3(r, p, rv);
     rr = dot(rv, rv);
     if (use_dinv) {
-      m3 D;
-#pragma unroll
-      for (int e = 0; e < 9; e++) D.m[e] = Dinv[9 * (size_t)p + e];
       // use_dinv 2: z = omega Dinv r is the first smoothing sweep of the multigrid cycle that follows (it owns r.z)
       const d3 zv = (use_dinv == 2 ? *omega_dev : 1.0) * m3_mulv(D, rv);
       st3(z, p, zv);
