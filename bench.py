@@ -170,7 +170,7 @@ def main():
     ap.add_argument("--cg-tol", type=float, default=1e-10)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--param", action="append", default=[], metavar="KEY=VALUE", help="extra tsl_set_param settings (solver experiments)")
-    ap.add_argument("--cpu-cg-iters", type=int, default=300)
+    ap.add_argument("--cpu-cg-iters", type=int, default=6000, help="PCG iterations of the timed oracle sample (about 10 s of host work on cfg4)")
     args = ap.parse_args()
 
     import torch
@@ -205,6 +205,9 @@ def main():
     elapsed = time.perf_counter() - t0
     prof = ctx.profile_read()
     elapsed = batch.max_over_ranks(elapsed)
+    # HIP-event timing of the dominant kernel: 500 back-to-back launches of k_pcg_spmv on the run's last matrix and contact set,
+    # one hipEvent pair on the library's stream (after the timed region: a pair around every launch inside it would time the events)
+    k1_us = ctx.bench_spmv(20, 500)
 
     T = 2 * args.grid * args.grid
     value = T * K * world / elapsed
@@ -233,16 +236,19 @@ def main():
                 traffic = json.load(fh)["traffic_bytes_per_launch"]
     except (OSError, KeyError, ValueError):
         pass
-    if prof["ms_per_launch"] > 0:
-        ach = prof["bytes_per_launch"] / (prof["ms_per_launch"] * 1e-3) / 1e9
+    if k1_us > 0:
+        ach = prof["bytes_per_launch"] / (k1_us * 1e-6) / 1e9
         out["roofline"] = {"bound": "hbm", "achieved": ach, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": ach / HBM_PEAK_GBS, "traffic": traffic,
                            "kernel": "k_pcg_spmv (SELL-64 3x3-block SpMV fused with the PCG direction update and p.Ap, one launch per PCG iteration)",
-                           "bytes_per_launch": prof["bytes_per_launch"], "avg_launch_us": prof["ms_per_launch"] * 1e3,
-                           "avg_launch_us_hip_events": prof["ms_per_launch_events"] * 1e3, "launches": prof["launches"],
-                           "timing": "avg_launch_us = min wave start -> max wave end of sampled launches on the constant-rate device clock (inside the "
-                                     "hipGraph replays, agrees with the rocprofv3 kernel-trace average under profiles/); avg_launch_us_hip_events = "
-                                     "hipEvent pairs on the library's stream around single K1 launches of eagerly issued sample chunks, which adds the "
-                                     "event / dispatch overhead of a 15 us kernel"}
+                           "bytes_per_launch": prof["bytes_per_launch"], "avg_launch_us": k1_us,
+                           "avg_launch_us_device_clock": prof["ms_per_launch"] * 1e3,
+                           "avg_launch_us_single_event_pairs": prof["ms_per_launch_events"] * 1e3, "launches": prof["launches"],
+                           "timing": "avg_launch_us (what `achieved` is priced on) = HIP events on the library's stream around 500 back-to-back launches "
+                                     "of the kernel on the run's last matrix / contact set, divided by 500 (includes the gap between dependent "
+                                     "launches; compare the rocprofv3 kernel-trace average under profiles/); avg_launch_us_device_clock = min wave "
+                                     "start -> max wave end of launches sampled inside the timed region's hipGraph replays; "
+                                     "avg_launch_us_single_event_pairs = hipEvent pairs around single eagerly issued launches inside the timed "
+                                     "region, which adds the event / dispatch overhead of a 15 us kernel"}
     if rank == 0:
         if world == 1 and not args.no_cpu_baseline:
             try:

@@ -175,6 +175,10 @@ int tsl_spd_project(tsl_ctx* ctx, double* blocks_dev, int32_t n_blocks, int32_t 
 int tsl_profile_reset(tsl_ctx* ctx, int enable);
 int tsl_profile_read(tsl_ctx* ctx, double* spmv_ms_host, int64_t* spmv_launches_host, int64_t* spmv_bytes_per_launch_host);
 int tsl_profile_read_events(tsl_ctx* ctx, double* spmv_ms_hip_events_host); /* same launches bracketed by hipEvents (includes launch gaps) */
+/* `reps` back-to-back launches of one operator kernel on the currently assembled matrix (and the current step's contact rows),
+ * bracketed by ONE hipEvent pair on the engine stream: average microseconds per launch.  variant 20 = k_pcg_spmv exactly as a
+ * PCG iteration launches it (what bench.py's roofline object is priced on), 2 = the plain SELL-64 product k_spmv_mw. */
+int tsl_bench_spmv(tsl_ctx* ctx, int variant, int reps, double* us_per_launch_host);
 
 #ifdef __cplusplus
 }

@@ -17,7 +17,9 @@ class Batch:
         self.local_rank = int(os.environ.get("LOCAL_RANK", "0"))
         self.dist = None
         self.device = device
-        if self.world > 1:
+        # under torch.distributed.run the process group is formed even for one rank, so that `--nproc-per-node 1` exercises the same
+        # RCCL path (init, barrier, all_reduce / all_gather) as the 2/4/8-GPU launches
+        if self.world > 1 or ("RANK" in os.environ and "MASTER_ADDR" in os.environ):
             import torch.distributed as dist
             os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
             os.environ.setdefault("MASTER_PORT", "29533")

@@ -226,3 +226,9 @@ class TslContext:
         ev = C.c_double(0)
         check(self.L.tsl_profile_read_events(self.h, C.byref(ev)), "tsl_profile_read_events")
         return dict(ms_per_launch=ms.value, launches=n.value, bytes_per_launch=b.value, ms_per_launch_events=ev.value)
+
+    def bench_spmv(self, variant=20, reps=500):
+        """microseconds per launch of `reps` back-to-back operator launches between one hipEvent pair (20 = k_pcg_spmv)"""
+        us = C.c_double(0)
+        check(self.L.tsl_bench_spmv(self.h, int(variant), int(reps), C.byref(us)), "tsl_bench_spmv")
+        return us.value

@@ -1670,6 +1670,7 @@ extern "C" int tsl_bench_spmv(tsl_ctx* c, int variant, int reps, double* us_per_
   HIP_OK(hipEventCreate(&e0)); HIP_OK(hipEventCreate(&e1));
   const int ns = c->n_slices;
   if (c->v_t4.n < (size_t)ns) return tsl_fail("scratch too small");
+  int k1_count = 0;
   auto launch = [&]() {
     switch (variant) {
       case 0: hipLaunchKernelGGL(k_spmv, dim3(nblk((long)ns * 64, 256)), dim3(256), 0, s, c->NV, ns, c->slice_off.p, c->slice_len.p, c->colidx.p, c->vals.p, c->v_p.p, c->v_Ap.p, SC(c), 0, 0, (unsigned long long*)nullptr); break;
@@ -1689,9 +1690,32 @@ extern "C" int tsl_bench_spmv(tsl_ctx* c, int variant, int reps, double* us_per_
       } break;
       case 13: hipLaunchKernelGGL(k_cg_update, dim3(nblk(c->NV, 256)), dim3(256), 0, s, c->NV, c->v_p.p, c->v_Ap.p, c->Dinv.p, c->v_x.p, c->v_r.p, c->v_z.p, SC(c), 0); break;
       case 14: hipLaunchKernelGGL(k_cg_p, dim3(nblk(c->NV, 256)), dim3(256), 0, s, c->NV, c->v_z.p, c->v_p.p, SC(c), 0, 0); break;
+      case 20: {  // the PCG operator kernel exactly as an iteration launches it (recurrence form, contact rows of the current step)
+        const int par = (k1_count++) & 1;
+        hipLaunchKernelGGL((k_pcg_spmv<PCG_WPS, TSL_NT>), dim3(ns), dim3(64 * PCG_WPS), 0, s, c->NV, ns, c->slice_off.p, c->slice_len.p, c->colidx.p, c->vals.p, c->v_z.p,
+                           par ? c->v_p.p : c->v_t0.p, par ? c->v_t0.p : c->v_p.p, c->v_Ap.p, c->part_rz.p, c->part_rr.p, c->part_pAp.p, PSC(c), par, 0,
+                           (unsigned long long*)nullptr, contact_rows(c, c->c_H.p));
+      } break;
       default: break;
     }
   };
+  if (variant == 20) {  // state of a running PCG (never converges: thresh2 < 0; beta = 1/2 keeps the direction bounded)
+    const size_t n3 = 3 * (size_t)c->NV;
+    const int gb = nblk(c->NV, 256);
+    std::vector<double> one((size_t)gb, 0.0);
+    one[0] = 1.0;
+    HIP_OK(hipMemcpyAsync(c->part_rz.p, one.data(), one.size() * sizeof(double), hipMemcpyHostToDevice, s));
+    HIP_OK(hipMemcpyAsync(c->part_rr.p, one.data(), one.size() * sizeof(double), hipMemcpyHostToDevice, s));
+    HIP_OK(hipMemcpyAsync(c->v_z.p, c->v_b.p, n3 * sizeof(double), hipMemcpyDeviceToDevice, s));
+    HIP_OK(hipMemsetAsync(c->v_p.p, 0, n3 * sizeof(double), s));
+    HIP_OK(hipMemsetAsync(c->v_t0.p, 0, n3 * sizeof(double), s));
+    HIP_OK(hipMemsetAsync(c->v_Ap.p, 0, n3 * sizeof(double), s));
+    PcgScal hs;
+    memset(&hs, 0, sizeof(hs));
+    hs.rzh[0] = hs.rzh[1] = 2.0; hs.thresh2 = -1.0; hs.bb = 1.0; hs.n_part1 = ns; hs.n_part2 = gb;
+    HIP_OK(hipMemcpyAsync(c->scal.p, &hs, sizeof(PcgScal), hipMemcpyHostToDevice, s));
+    HIP_OK(hipStreamSynchronize(s));
+  } else
   {  // valid solver state: p = z = r = b (whatever v_b holds, must be non-zero), scalars of a running iteration
     const size_t n3 = 3 * (size_t)c->NV;
     HIP_OK(hipMemcpyAsync(c->v_p.p, c->v_b.p, n3 * sizeof(double), hipMemcpyDeviceToDevice, s));
