@@ -139,6 +139,123 @@ k_st_first_resid(MgGrid g, const double* __restrict__ A, const double* __restric
   }
 }
 
+// (1b) first sweep + residual + restriction in ONE launch.  With x = omega Dinv r the restricted residual is
+//   rc = P^T (r - A x) = P^T r - omega (P^T A Dinv) r,
+// so the operator S = P^T A Dinv is formed once per assembly (k_st_build_ra): 49 slots per COARSE node (restriction radius 1 +
+// stencil radius 2 on the fine grid), i.e. 12.25 blocks per fine node instead of the 25 of A, and the fine-level residual is never
+// formed (the post-sweep recomputes A x from scratch anyway).  One launch and half the bytes less per level and cycle.
+// S[(s*9+e)*nc + crow], s = (dI+3)*7 + (dJ+3), column = fine node (2I+dI, 2J+dJ)
+__global__ void k_st_build_ra(MgGrid gf, const double* __restrict__ A, const double* __restrict__ Dinv, double* __restrict__ S) {
+  const int Nc = gf.N >> 1, Mc = gf.M >> 1;
+  const int nc = (Nc + 1) * (Mc + 1), nf = (gf.N + 1) * (gf.M + 1);
+  const int t = blockIdx.x * blockDim.x + threadIdx.x;
+  const int crow = t % nc, s = t / nc;
+  if (s >= 49) return;
+  const int I = crow / (Mc + 1), J = crow % (Mc + 1);
+  const int dI = s / 7 - 3, dJ = s % 7 - 3;
+  const int ci = 2 * I + dI, cj = 2 * J + dJ;
+  double acc[9];
+#pragma unroll
+  for (int e = 0; e < 9; e++) acc[e] = 0.0;
+  double* dst = S + (size_t)s * 9 * nc + crow;
+  if (ci < 0 || ci > gf.N || cj < 0 || cj > gf.M) {
+#pragma unroll
+    for (int e = 0; e < 9; e++) dst[(size_t)e * nc] = 0.0;
+    return;
+  }
+#pragma unroll
+  for (int di = -1; di <= 1; di++) {
+    const int i = 2 * I + di, a = dI - di;
+    if (i < 0 || i > gf.N || a < -2 || a > 2) continue;
+#pragma unroll
+    for (int dj = -1; dj <= 1; dj++) {
+      const int j = 2 * J + dj, b = dJ - dj;
+      if (j < 0 || j > gf.M || b < -2 || b > 2) continue;
+      const double w = (di == 0 ? 1.0 : 0.5) * (dj == 0 ? 1.0 : 0.5);
+      const double* src = A + (size_t)((a + 2) * 5 + (b + 2)) * 9 * nf + (i * (gf.M + 1) + j);
+#pragma unroll
+      for (int e = 0; e < 9; e++) acc[e] += w * src[(size_t)e * nf];
+    }
+  }
+  const double* D = Dinv + 9 * (size_t)(ci * (gf.M + 1) + cj);
+  double d[9];
+#pragma unroll
+  for (int e = 0; e < 9; e++) d[e] = D[e];
+#pragma unroll
+  for (int r = 0; r < 3; r++)
+#pragma unroll
+    for (int cc = 0; cc < 3; cc++) dst[(size_t)(3 * r + cc) * nc] = acc[3 * r] * d[cc] + acc[3 * r + 1] * d[3 + cc] + acc[3 * r + 2] * d[6 + cc];
+}
+
+// ROWS coarse nodes per workgroup, 7 threads per node (one per fine row offset dI); threads 1..4 of a node also write the
+// smoothed iterate x = omega Dinv r of its four fine nodes (2I + {0,1}, 2J + {0,1}), thread 0 the coarse right-hand side.
+template <int ROWS>
+__global__ void __launch_bounds__(7 * ROWS)
+k_st_first_restrict(MgGrid g, const double* __restrict__ S, const double* __restrict__ Dinv, const double* __restrict__ r, const double* __restrict__ omega_dev,
+                    double* __restrict__ x, double* __restrict__ rc) {
+  __shared__ double red[7][3][ROWS];
+  const int Nc = g.N >> 1, Mc = g.M >> 1;
+  const int nc = (Nc + 1) * (Mc + 1);
+  const int lane = threadIdx.x % ROWS, q = threadIdx.x / ROWS;
+  const int crow = blockIdx.x * ROWS + lane;
+  const double omega = *omega_dev;
+  double y0 = 0, y1 = 0, y2 = 0;
+  int I = 0, J = 0;
+  if (crow < nc) {
+    I = crow / (Mc + 1); J = crow % (Mc + 1);
+    const int i2 = 2 * I + q - 3;
+    if (i2 >= 0 && i2 <= g.N) {
+#pragma unroll
+      for (int dJ = -3; dJ <= 3; dJ++) {
+        const int j2 = 2 * J + dJ;
+        if (j2 < 0 || j2 > g.M) continue;
+        const double* a = S + (size_t)(q * 7 + dJ + 3) * 9 * nc + crow;
+        const d3 rj = ld3(r, i2 * (g.M + 1) + j2);
+        y0 += a[0] * rj.x + a[(size_t)nc] * rj.y + a[2 * (size_t)nc] * rj.z;
+        y1 += a[3 * (size_t)nc] * rj.x + a[4 * (size_t)nc] * rj.y + a[5 * (size_t)nc] * rj.z;
+        y2 += a[6 * (size_t)nc] * rj.x + a[7 * (size_t)nc] * rj.y + a[8 * (size_t)nc] * rj.z;
+      }
+    }
+  }
+  // own work of the node's threads that does not depend on the partial sums: issued before the barrier
+  d3 own = d3();
+  int f_own = -1;
+  if (crow < nc) {
+    if (q == 0) {  // P^T r
+#pragma unroll
+      for (int di = -1; di <= 1; di++) {
+        const int i = 2 * I + di;
+        if (i < 0 || i > g.N) continue;
+#pragma unroll
+        for (int dj = -1; dj <= 1; dj++) {
+          const int j = 2 * J + dj;
+          if (j < 0 || j > g.M) continue;
+          own = own + ((di == 0 ? 1.0 : 0.5) * (dj == 0 ? 1.0 : 0.5)) * ld3(r, i * (g.M + 1) + j);
+        }
+      }
+    } else if (q <= 4) {
+      const int i = 2 * I + ((q - 1) >> 1), j = 2 * J + ((q - 1) & 1);
+      if (i <= g.N && j <= g.M) {
+        f_own = i * (g.M + 1) + j;
+        m3 D;
+#pragma unroll
+        for (int e = 0; e < 9; e++) D.m[e] = Dinv[9 * (size_t)f_own + e];
+        own = omega * m3_mulv(D, ld3(r, f_own));
+      }
+    }
+  }
+  red[q][0][lane] = y0; red[q][1][lane] = y1; red[q][2][lane] = y2;
+  __syncthreads();
+  if (crow >= nc) return;
+  if (q == 0) {
+#pragma unroll
+    for (int k = 1; k < 7; k++) { y0 += red[k][0][lane]; y1 += red[k][1][lane]; y2 += red[k][2][lane]; }
+    st3(rc, crow, own - omega * d3(y0, y1, y2));
+  } else if (f_own >= 0) {
+    st3(x, f_own, own);
+  }
+}
+
 // (x + P xc) at fine node (i, j) of grid gf
 TSL_DEV d3 st_prolonged(MgGrid gf, const double* __restrict__ x, const double* __restrict__ xc, int i, int j) {
   const int Mc = gf.M >> 1;

@@ -73,6 +73,7 @@ struct SolverScalars {
 struct MgLevel {
   int N = 0, M = 0, n = 0;
   DevBuf<double> A, Dinv, x, x2, r, t;
+  DevBuf<double> S;      // P^T A Dinv towards the next level (49 slots per coarse node, k_st_build_ra); empty on the last level
   DevBuf<double> omega;  // [0] damping factor, [1] lambda_max estimate (device resident)
   DevBuf<float> Cinv;    // dense inverse of the last level of the hierarchy (blocked Gauss-Jordan per assembly), symmetrised, fp32
   DevBuf<int> cbad;
@@ -211,7 +212,7 @@ struct tsl_ctx {
   double mg_omega = 0.0;   // > 0: fixed damping; 0: 1.5 / lambda_max(D^-1 A) per level from a power iteration
   int mg_pi_iters = 12;
   DevBuf<double> mg_omega0, mg_pi_part, mg_pi_norm;  // level 0
-  int mg_nu = 1, mg_coarse_sweeps = 8, mg_fuse = 1, mg_max_levels = 16, mg_coarse_exact = 1, mg_coarse_lag = 0, mg_dense_nodes = 64, mg_dense_auto = 1;
+  int mg_nu = 1, mg_coarse_sweeps = 8, mg_fuse = 1, mg_fuse_restrict = 1, mg_max_levels = 16, mg_coarse_exact = 1, mg_coarse_lag = 0, mg_dense_nodes = 64, mg_dense_auto = 1;
   double last_step_iters_per_solve = 0.0;
   int warm_start = 0;       // PCG of a Newton iteration starts from the previous iteration's direction (optional, see solve_perm)
   bool warm_valid = false;

@@ -326,6 +326,7 @@ extern "C" int tsl_set_param(tsl_ctx* c, const char* key, double v) {
   else if (k == "mg") c->mg_enable = (int)v;
   else if (k == "mg_omega") c->mg_omega = v;
   else if (k == "mg_fuse") c->mg_fuse = (int)v;
+  else if (k == "mg_fuse_restrict") { c->mg_fuse_restrict = (int)v; c->mg_ops_valid = false; }
   else if (k == "mg_coarse_exact") c->mg_coarse_exact = (int)v;
   else if (k == "mg_coarse_lag") c->mg_coarse_lag = (int)v;
   else if (k == "warm_start") c->warm_start = (int)v;
@@ -602,6 +603,8 @@ static int mg_build(tsl_ctx* c, const tsl_scene_desc* d) {
       mc->lv.push_back(L);
       if (rc) { delete mc; return -1; }
     }
+    for (size_t l = 0; l + 1 < mc->lv.size(); l++)
+      if (mc->lv[l]->S.alloc((size_t)441 * mc->lv[l + 1]->n)) { delete mc; return -1; }
     c->mg.push_back(mc);
   }
   if (!c->mg.empty()) {
@@ -656,6 +659,8 @@ static int mg_setup_operators(tsl_ctx* c) {
       HIP_OK(hipMemsetAsync(Lc->A.p, 0, Lc->A.n * sizeof(double), s));
       hipLaunchKernelGGL(k_galerkin_st, dim3(nblk((long)Lf->n * 25, 256)), dim3(256), 0, s, MgGrid{Lf->N, Lf->M}, Lf->A.p, Lc->A.p);
       hipLaunchKernelGGL(k_st_diag_inv, dim3(nblk(Lc->n, 256)), dim3(256), 0, s, Lc->n, Lc->A.p, Lc->Dinv.p);
+      if (c->mg_fuse && c->mg_fuse_restrict)  // S = P^T A Dinv of the fine level: its first sweep, residual and restriction become one launch
+        hipLaunchKernelGGL(k_st_build_ra, dim3(nblk((long)Lc->n * 49, 256)), dim3(256), 0, s, MgGrid{Lf->N, Lf->M}, Lf->A.p, Lf->Dinv.p, Lf->S.p);
     }
     MgLevel* Ll = mc->lv[mg_levels(c, mc) - 1];
     if (mg_level_dense(c, Ll) && !(c->mg_coarse_lag && c->mg_cinv_valid && Ll->Cinv.n > 0)) {  // dense inverse of the last level
@@ -768,6 +773,13 @@ static double* mg_stencil_cycle(tsl_ctx* c, MgCloth* mc, size_t l) {
     return xa;
   }
   const bool fuse_down = c->mg_fuse && !last && c->mg_nu == 1;
+  if (fuse_down && c->mg_fuse_restrict) {  // x = omega Dinv r and the coarse right-hand side in one launch (k_mg.hpp (1b))
+    MgLevel* Lc = mc->lv[l + 1];
+    hipLaunchKernelGGL((k_st_first_restrict<32>), dim3(nblk(Lc->n, 32)), dim3(7 * 32), 0, s, g, L->S.p, L->Dinv.p, L->r.p, L->omega.p, xa, Lc->r.p);
+    const double* xc = mg_stencil_cycle(c, mc, l + 1);
+    hipLaunchKernelGGL(k_st_prolong_sweep, dim3(gb5), dim3(320), 0, s, g, L->A.p, xa, xc, xb, L->Dinv.p, L->r.p, L->omega.p);
+    return xb;
+  }
   if (fuse_down) hipLaunchKernelGGL(k_st_first_resid, dim3(gb5), dim3(320), 0, s, g, L->A.p, L->Dinv.p, L->r.p, L->omega.p, xa, L->t.p);
   else hipLaunchKernelGGL(k_mg_jacobi_first, dim3(gb), dim3(256), 0, s, L->n, L->Dinv.p, L->r.p, L->omega.p, xa);
   const int extra = last ? c->mg_coarse_sweeps - 1 : c->mg_nu - 1;
@@ -852,7 +864,7 @@ static void launch_pcg_iteration(tsl_ctx* c, int parity, int first, unsigned lon
 // iteration is ~20 short kernels.  The first K1 of the chunk stamps
 // the device clock into a fixed buffer when profiling is on.
 static int pcg_chunk_graph(tsl_ctx* c, int chunk) {
-  const long key = ((long)(mg_active(c) ? 1 : 0) << 40) | ((long)c->nc << 8) | ((long)(c->prof_enable ? 1 : 0) << 7) | (long)chunk | ((long)c->mg_nu << 44) | ((long)c->mg_coarse_sweeps << 48) | ((long)(c->pc_separate ? 1 : 0) << 41) | ((long)((body_active(c) && c->bd_valid) ? 1 : 0) << 42) | ((long)(c->mg_fuse ? 1 : 0) << 43) | ((long)c->mg_max_levels << 52) | ((long)(c->mg_coarse_exact ? 1 : 0) << 39) | ((long)((c->mg_f32 && c->vals32_valid) ? 1 : 0) << 38) | ((long)(c->mg_dense_nodes & 0xfff) << 24);
+  const long key = ((long)(mg_active(c) ? 1 : 0) << 40) | ((long)c->nc << 8) | ((long)(c->prof_enable ? 1 : 0) << 7) | (long)chunk | ((long)c->mg_nu << 44) | ((long)c->mg_coarse_sweeps << 48) | ((long)(c->pc_separate ? 1 : 0) << 41) | ((long)((body_active(c) && c->bd_valid) ? 1 : 0) << 42) | ((long)(c->mg_fuse ? 1 : 0) << 43) | ((long)(c->mg_fuse_restrict ? 1 : 0) << 36) | ((long)c->mg_max_levels << 52) | ((long)(c->mg_coarse_exact ? 1 : 0) << 39) | ((long)((c->mg_f32 && c->vals32_valid) ? 1 : 0) << 38) | ((long)(c->mg_dense_nodes & 0xfff) << 24);
   if (c->pcg_graph && c->pcg_graph_key == key) return 0;
   if (c->pcg_graph) { (void)hipGraphExecDestroy(c->pcg_graph); c->pcg_graph = nullptr; }
   hipGraph_t g = nullptr;
@@ -1084,7 +1096,7 @@ static void launch_minres_iteration(tsl_ctx* c, const MrBufs& B, int j) {
 
 static long solver_graph_key(tsl_ctx* c) {
   return ((long)(mg_active(c) ? 1 : 0) << 40) | ((long)c->nc << 8) | ((long)(c->prof_enable ? 1 : 0) << 7) | ((long)c->mg_nu << 44) | ((long)c->mg_coarse_sweeps << 48) |
-         ((long)(c->pc_separate ? 1 : 0) << 41) | ((long)((body_active(c) && c->bd_valid) ? 1 : 0) << 42) | ((long)(c->mg_fuse ? 1 : 0) << 43) | ((long)c->mg_max_levels << 52) | ((long)(c->mg_coarse_exact ? 1 : 0) << 39) | ((long)((c->mg_f32 && c->vals32_valid) ? 1 : 0) << 38) | ((long)(c->mg_dense_nodes & 0xfff) << 24);
+         ((long)(c->pc_separate ? 1 : 0) << 41) | ((long)((body_active(c) && c->bd_valid) ? 1 : 0) << 42) | ((long)(c->mg_fuse ? 1 : 0) << 43) | ((long)(c->mg_fuse_restrict ? 1 : 0) << 36) | ((long)c->mg_max_levels << 52) | ((long)(c->mg_coarse_exact ? 1 : 0) << 39) | ((long)((c->mg_f32 && c->vals32_valid) ? 1 : 0) << 38) | ((long)(c->mg_dense_nodes & 0xfff) << 24);
 }
 
 static int minres_graph(tsl_ctx* c, const MrBufs& B) {
