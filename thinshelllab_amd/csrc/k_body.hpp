@@ -221,6 +221,79 @@ TSL_DEV void body_apply_block(const BodyDenseArgs& A, const float* __restrict__ 
   }
 }
 
+// Body part of the PCG update launch (k_pcg_update, workgroups behind the vertex part): the first smoothing sweep z_b = Binv r_b of
+// the multigrid cycle that follows, without a launch of its own.  The vertex part updates r in place in the same launch, so the
+// body workgroups never read r: they keep a compact ping-pong copy rb of the residual on the body rows, rebuilt here as
+// rb_new = rb_old - alpha Ap (bitwise the values the vertex part writes), or as b - Ax when the solve (re)starts.
+// start mode (b_init != null): only rb_new is written (the cycle of a start runs its own first sweep).
+TSL_DEV void body_update_block(const BodyDenseArgs& A, const float* __restrict__ Binv, double alpha, const double* __restrict__ Ap, const double* __restrict__ rb_old,
+                               double* __restrict__ rb_new, const double* __restrict__ b_init, const double* __restrict__ Ax_init, double* __restrict__ z, int bid,
+                               double* v /* LDS, 3 * 512 + 4 */) {
+  int b = 0;
+  while (b + 1 < A.nb && bid >= A.wg_off[b + 1]) b++;
+  const int n3 = A.n3[b];
+  const int ld = (n3 + 3) & ~3;
+  const int* rows = A.rows + A.rows_off[b];
+  const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+  const int row0 = (bid - A.wg_off[b]) * BODY_APPLY_ROWS;
+  const int so = A.scr_off[b];
+  if (b_init) {  // compact residual of this workgroup's rows
+    const int i = row0 + (int)threadIdx.x;
+    if (threadIdx.x < BODY_APPLY_ROWS && i < n3) {
+      const size_t g = 3 * (size_t)rows[i / 3] + i % 3;
+      rb_new[so + i] = Ax_init ? b_init[g] - Ax_init[g] : b_init[g];
+    }
+    return;
+  }
+  const float* Bb = Binv + A.w_off[b];
+  const int nq = ld >> 2;
+  const int i0 = row0 + w * (BODY_APPLY_ROWS / 4), i1 = i0 + 1;  // two rows per wave
+  const bool live = i0 < n3, live1 = i1 < n3;
+  constexpr int MAXQ = (3 * 512 / 4 + 63) / 64;
+  float4 a0[MAXQ], a1[MAXQ];
+  size_t g0 = 0, g1 = 0;
+  if (live) {
+    const float4* b0 = (const float4*)(Bb + (size_t)i0 * ld);
+    const float4* b1 = (const float4*)(Bb + (size_t)(live1 ? i1 : i0) * ld);
+#pragma unroll
+    for (int u = 0; u < MAXQ; u++) {
+      const int j = lane + 64 * u;
+      a0[u] = j < nq ? b0[j] : make_float4(0, 0, 0, 0);
+      a1[u] = j < nq ? b1[j] : make_float4(0, 0, 0, 0);
+    }
+    if (lane == 0) {
+      g0 = 3 * (size_t)rows[i0 / 3] + i0 % 3;
+      if (live1) g1 = 3 * (size_t)rows[i1 / 3] + i1 % 3;
+    }
+  }
+  for (int i = threadIdx.x; i < ld; i += 256) {
+    double x = 0.0;
+    if (i < n3) {
+      const size_t g = 3 * (size_t)rows[i / 3] + i % 3;
+      x = rb_old[so + i] - alpha * Ap[g];
+    }
+    v[i] = x;
+  }
+  __syncthreads();
+  if (live) {
+    double sum0 = 0, sum1 = 0;
+#pragma unroll
+    for (int u = 0; u < MAXQ; u++) {
+      const int j = lane + 64 * u;
+      if (j < nq) {
+        const double v0 = v[4 * j], v1 = v[4 * j + 1], v2 = v[4 * j + 2], v3 = v[4 * j + 3];
+        sum0 += (double)a0[u].x * v0 + (double)a0[u].y * v1 + (double)a0[u].z * v2 + (double)a0[u].w * v3;
+        sum1 += (double)a1[u].x * v0 + (double)a1[u].y * v1 + (double)a1[u].z * v2 + (double)a1[u].w * v3;
+      }
+    }
+    sum0 = wave_sum(sum0); sum1 = wave_sum(sum1);
+    if (lane == 0) {
+      z[g0] = sum0; rb_new[so + i0] = v[i0];
+      if (live1) { z[g1] = sum1; rb_new[so + i1] = v[i1]; }
+    }
+  }
+}
+
 __global__ void __launch_bounds__(256)
 k_body_apply(BodyDenseArgs A, const float* __restrict__ Binv, int mode, const double* __restrict__ r, const double* __restrict__ t, double* __restrict__ z,
              const double* __restrict__ rdot, double* __restrict__ part) {

@@ -408,9 +408,24 @@ __global__ void __launch_bounds__(256)
 k_pcg_update(int NV, const double* __restrict__ pv, const double* __restrict__ Ap, const double* __restrict__ Dinv, double* __restrict__ x,
              double* __restrict__ r, double* __restrict__ z, const double* __restrict__ part_pAp, double* __restrict__ part_rz, double* __restrict__ part_rr,
              PcgScal* sc, int parity, const double* __restrict__ b_init, const double* __restrict__ Ax_init, int use_dinv,
-             const double* __restrict__ omega_dev = nullptr) {
+             const double* __restrict__ omega_dev = nullptr, int gb = 0, BodyDenseArgs BD = BodyDenseArgs{}, const float* __restrict__ Binv = nullptr,
+             double* __restrict__ rb = nullptr, int rb_n = 0) {
   __shared__ double sm[8];
   double alpha = 0;
+  if (rb && (int)blockIdx.x >= gb) {  // dense-body workgroups (k_body.hpp): z_b = Binv r_b of the updated residual, compact residual ping-pong
+    __shared__ double vb[3 * 512 + 4];
+    double* rb_new = rb + (size_t)(b_init ? parity ^ 1 : parity) * rb_n;
+    const double* rb_old = rb + (size_t)(parity ^ 1) * rb_n;
+    if (!b_init) {
+      if (sc->flag) return;
+      const double pAp = block_reduce_partials(part_pAp, sc->n_part1, sm);
+      const double rz = sc->rzh[parity];
+      if (!(pAp > 0.0) || !(rz > 0.0)) return;
+      alpha = rz / pAp;
+    }
+    body_update_block(BD, Binv, alpha, Ap, rb_old, rb_new, b_init, Ax_init, z, (int)blockIdx.x - gb, vb);
+    return;
+  }
   const int p = blockIdx.x * blockDim.x + threadIdx.x;
   // operands of the update: loaded before the reduction of the p.Ap partials so that the two memory round trips overlap
   d3 pp(0, 0, 0), xv(0, 0, 0), rv(0, 0, 0), apv(0, 0, 0);
@@ -448,7 +463,13 @@ k_pcg_update(int NV, const double* __restrict__ pv, const double* __restrict__ A
     if (use_dinv) {
       // use_dinv 2: z = omega Dinv r is the first smoothing sweep of the multigrid cycle that follows (it owns r.z)
       const d3 zv = (use_dinv == 2 ? *omega_dev : 1.0) * m3_mulv(D, rv);
-      st3(z, p, zv);
+      bool own = true;
+      if (rb) {  // rows of a dense body (zero Dinv block) get their z from the body workgroups of this launch
+        own = false;
+#pragma unroll
+        for (int e = 0; e < 9; e++) own = own || D.m[e] != 0.0;
+      }
+      if (own) st3(z, p, zv);
       rzn = dot(rv, zv);
     }
   }

@@ -159,6 +159,8 @@ struct tsl_ctx {
   bool bd_valid = false;
   DevBuf<int> bd_rows, bd_body_of, bd_local_of, bd_bad;
   DevBuf<double> bd_W, bd_scr;
+  DevBuf<double> bd_rb;  // compact ping-pong copy of the PCG residual on the dense-body rows (body part of k_pcg_update)
+  int pcg_body_fold = 1;
   DevBuf<float> bd_Binv;
   DevBuf<double> gm_V, gm_h;  // GMRES basis ((m+1) vectors) and projection coefficients
   int gmres_m = 300, use_gmres = 1, use_minres = 1, verbose = 0;

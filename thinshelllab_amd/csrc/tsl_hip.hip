@@ -326,6 +326,7 @@ extern "C" int tsl_set_param(tsl_ctx* c, const char* key, double v) {
   else if (k == "mg") c->mg_enable = (int)v;
   else if (k == "mg_omega") c->mg_omega = v;
   else if (k == "mg_fuse") c->mg_fuse = (int)v;
+  else if (k == "pcg_body_fold") c->pcg_body_fold = (int)v;
   else if (k == "mg_fuse_restrict") { c->mg_fuse_restrict = (int)v; c->mg_ops_valid = false; }
   else if (k == "mg_coarse_exact") c->mg_coarse_exact = (int)v;
   else if (k == "mg_coarse_lag") c->mg_coarse_lag = (int)v;
@@ -544,7 +545,7 @@ static int body_dense_setup(tsl_ctx* c) {
   c->bd_rows_n = (int)rows.size();
   if (!A.nb) return 0;
   TSL_TRY(c->bd_rows.upload(rows)); TSL_TRY(c->bd_body_of.upload(body_of)); TSL_TRY(c->bd_local_of.upload(local_of));
-  if (c->bd_bad.alloc(TSL_MAX_DENSE_BODIES) | c->bd_W.alloc(c->bd_w_total) | c->bd_Binv.alloc(c->bd_w_total) | c->bd_scr.alloc(4 * (size_t)c->bd_scr_n)) return -1;
+  if (c->bd_bad.alloc(TSL_MAX_DENSE_BODIES) | c->bd_W.alloc(c->bd_w_total) | c->bd_Binv.alloc(c->bd_w_total) | c->bd_scr.alloc(4 * (size_t)c->bd_scr_n) | c->bd_rb.alloc(2 * (size_t)c->bd_scr_n)) return -1;
   A.rows = c->bd_rows.p; A.body_of = c->bd_body_of.p; A.local_of = c->bd_local_of.p;
   HIP_OK(hipMemset(c->bd_Binv.p, 0, c->bd_w_total * sizeof(float)));  // the row padding must stay finite (it multiplies zeros)
   return 0;
@@ -801,15 +802,17 @@ static double* mg_stencil_cycle(tsl_ctx* c, MgCloth* mc, size_t l) {
   return xa;
 }
 
+static bool pcg_fold(tsl_ctx* c) { return c->pcg_body_fold && mg_active(c) && body_active(c) && c->bd_valid; }
+
 // z = M^-1 r (one V(nu,nu) cycle); part_rz receives the per-block partials of r.z
-static void mg_vcycle(tsl_ctx* c, const double* r, double* z, double* part_rz, bool first_sweep_done = false) {
+static void mg_vcycle(tsl_ctx* c, const double* r, double* z, double* part_rz, bool first_sweep_done = false, bool body_sweep_done = false) {
   hipStream_t s = c->stream;
   const int NV = c->NV, gb = nblk(NV, 256);
   const double* om = c->mg_omega0.p;
   double* t = c->v_mg.p;
   const bool bd = body_active(c) && c->bd_valid;
   if (!first_sweep_done) hipLaunchKernelGGL(k_mg_jacobi_first, dim3(gb), dim3(256), 0, s, NV, c->Dinv.p, r, om, z);
-  if (bd) body_apply(c, 0, r, nullptr, z, nullptr, nullptr);
+  if (bd && !body_sweep_done) body_apply(c, 0, r, nullptr, z, nullptr, nullptr);
   for (int k = 0; k < c->mg_nu - 1; k++) {
     mg_spmv0(c, z, t);
     hipLaunchKernelGGL(k_mg_jacobi_next, dim3(gb), dim3(256), 0, s, NV, c->Dinv.p, r, t, om, z, (const double*)nullptr, (double*)nullptr);
@@ -854,9 +857,12 @@ static void launch_pcg_iteration(tsl_ctx* c, int parity, int first, unsigned lon
                      c->v_Ap.p, c->part_rz.p, c->part_rr.p, c->part_pAp.p, PSC(c), parity, first, dprof, contact_rows(c, c->c_H.p));
   if (ev) { (void)hipEventRecord(c->ev_pool[c->ev_used].second, s); c->ev_used++; }
   const bool mg = mg_active(c);
-  hipLaunchKernelGGL(k_pcg_update, dim3(nblk(NV, 256)), dim3(256), 0, s, NV, p_new, c->v_Ap.p, c->Dinv.p, c->v_x.p, c->v_r.p, c->v_z.p, c->part_pAp.p, c->part_rz.p, c->part_rr.p,
-                     PSC(c), parity, (const double*)nullptr, (const double*)nullptr, mg ? 2 : 1, c->mg_omega0.p);
-  if (mg) mg_vcycle(c, c->v_r.p, c->v_z.p, c->part_rz.p, true);
+  const bool fold = pcg_fold(c);  // dense-body first sweep inside the update launch
+  const int gb = nblk(NV, 256);
+  hipLaunchKernelGGL(k_pcg_update, dim3(gb + (fold ? c->bd_wg : 0)), dim3(256), 0, s, NV, p_new, c->v_Ap.p, c->Dinv.p, c->v_x.p, c->v_r.p, c->v_z.p, c->part_pAp.p, c->part_rz.p,
+                     c->part_rr.p, PSC(c), parity, (const double*)nullptr, (const double*)nullptr, mg ? 2 : 1, c->mg_omega0.p, gb, c->bd_args, c->bd_Binv.p,
+                     fold ? c->bd_rb.p : (double*)nullptr, c->bd_scr_n);
+  if (mg) mg_vcycle(c, c->v_r.p, c->v_z.p, c->part_rz.p, true, fold);
   else if (body_active(c) && c->bd_valid) body_apply(c, 0, c->v_r.p, nullptr, c->v_z.p, c->v_r.p, c->part_rz.p + nblk(NV, 256));
 }
 
@@ -864,7 +870,7 @@ static void launch_pcg_iteration(tsl_ctx* c, int parity, int first, unsigned lon
 // iteration is ~20 short kernels.  The first K1 of the chunk stamps
 // the device clock into a fixed buffer when profiling is on.
 static int pcg_chunk_graph(tsl_ctx* c, int chunk) {
-  const long key = ((long)(mg_active(c) ? 1 : 0) << 40) | ((long)c->nc << 8) | ((long)(c->prof_enable ? 1 : 0) << 7) | (long)chunk | ((long)c->mg_nu << 44) | ((long)c->mg_coarse_sweeps << 48) | ((long)(c->pc_separate ? 1 : 0) << 41) | ((long)((body_active(c) && c->bd_valid) ? 1 : 0) << 42) | ((long)(c->mg_fuse ? 1 : 0) << 43) | ((long)(c->mg_fuse_restrict ? 1 : 0) << 36) | ((long)c->mg_max_levels << 52) | ((long)(c->mg_coarse_exact ? 1 : 0) << 39) | ((long)((c->mg_f32 && c->vals32_valid) ? 1 : 0) << 38) | ((long)(c->mg_dense_nodes & 0xfff) << 24);
+  const long key = ((long)(mg_active(c) ? 1 : 0) << 40) | ((long)c->nc << 8) | ((long)(c->prof_enable ? 1 : 0) << 7) | (long)chunk | ((long)c->mg_nu << 44) | ((long)c->mg_coarse_sweeps << 48) | ((long)(c->pc_separate ? 1 : 0) << 41) | ((long)((body_active(c) && c->bd_valid) ? 1 : 0) << 42) | ((long)(c->mg_fuse ? 1 : 0) << 43) | ((long)(c->mg_fuse_restrict ? 1 : 0) << 36) | ((long)(c->pcg_body_fold ? 1 : 0) << 37) | ((long)c->mg_max_levels << 52) | ((long)(c->mg_coarse_exact ? 1 : 0) << 39) | ((long)((c->mg_f32 && c->vals32_valid) ? 1 : 0) << 38) | ((long)(c->mg_dense_nodes & 0xfff) << 24);
   if (c->pcg_graph && c->pcg_graph_key == key) return 0;
   if (c->pcg_graph) { (void)hipGraphExecDestroy(c->pcg_graph); c->pcg_graph = nullptr; }
   hipGraph_t g = nullptr;
@@ -951,8 +957,9 @@ static int solve_perm(tsl_ctx* c, tsl_solve_stats* st) {
     HIP_OK(hipMemcpyAsync(c->scal.p, &hs, sizeof(PcgScal), hipMemcpyHostToDevice, s));
     if (outer > 0 || warm) launch_spmv(c, c->vals.p, c->v_x.p, c->v_Ap.p, -1, 0);
     // true residual, z = M^-1 r, partial r.z / r.r
-    hipLaunchKernelGGL(k_pcg_update, dim3(gb), dim3(256), 0, s, NV, (const double*)nullptr, (const double*)nullptr, c->Dinv.p, c->v_x.p, c->v_r.p, c->v_z.p, c->part_pAp.p,
-                       c->part_rz.p, c->part_rr.p, PSC(c), 0, c->v_b.p, (outer > 0 || warm) ? c->v_Ap.p : (const double*)nullptr, mg_active(c) ? 0 : 1);
+    hipLaunchKernelGGL(k_pcg_update, dim3(gb + (pcg_fold(c) ? c->bd_wg : 0)), dim3(256), 0, s, NV, (const double*)nullptr, (const double*)nullptr, c->Dinv.p, c->v_x.p, c->v_r.p,
+                       c->v_z.p, c->part_pAp.p, c->part_rz.p, c->part_rr.p, PSC(c), 0, c->v_b.p, (outer > 0 || warm) ? c->v_Ap.p : (const double*)nullptr, mg_active(c) ? 0 : 1,
+                       (const double*)nullptr, gb, c->bd_args, c->bd_Binv.p, pcg_fold(c) ? c->bd_rb.p : (double*)nullptr, c->bd_scr_n);
     hipLaunchKernelGGL(k_sum_partials, dim3(1), dim3(256), 0, s, c->part_rr.p, gb, &PSC(c)->rr_last);
     if (outer > 0) {  // verification of a converged recurrence: the true residual decides before a V-cycle is spent on it
       TSL_TRY(read_scal(c));
@@ -1096,7 +1103,7 @@ static void launch_minres_iteration(tsl_ctx* c, const MrBufs& B, int j) {
 
 static long solver_graph_key(tsl_ctx* c) {
   return ((long)(mg_active(c) ? 1 : 0) << 40) | ((long)c->nc << 8) | ((long)(c->prof_enable ? 1 : 0) << 7) | ((long)c->mg_nu << 44) | ((long)c->mg_coarse_sweeps << 48) |
-         ((long)(c->pc_separate ? 1 : 0) << 41) | ((long)((body_active(c) && c->bd_valid) ? 1 : 0) << 42) | ((long)(c->mg_fuse ? 1 : 0) << 43) | ((long)(c->mg_fuse_restrict ? 1 : 0) << 36) | ((long)c->mg_max_levels << 52) | ((long)(c->mg_coarse_exact ? 1 : 0) << 39) | ((long)((c->mg_f32 && c->vals32_valid) ? 1 : 0) << 38) | ((long)(c->mg_dense_nodes & 0xfff) << 24);
+         ((long)(c->pc_separate ? 1 : 0) << 41) | ((long)((body_active(c) && c->bd_valid) ? 1 : 0) << 42) | ((long)(c->mg_fuse ? 1 : 0) << 43) | ((long)(c->mg_fuse_restrict ? 1 : 0) << 36) | ((long)(c->pcg_body_fold ? 1 : 0) << 37) | ((long)c->mg_max_levels << 52) | ((long)(c->mg_coarse_exact ? 1 : 0) << 39) | ((long)((c->mg_f32 && c->vals32_valid) ? 1 : 0) << 38) | ((long)(c->mg_dense_nodes & 0xfff) << 24);
 }
 
 static int minres_graph(tsl_ctx* c, const MrBufs& B) {
@@ -1540,7 +1547,15 @@ extern "C" int tsl_step(tsl_ctx* c, double* pos, double* prev, double* vel, doub
   // at +4.5 ms per assembly; the scaled scene with ~100 iterations per solve keeps the 225-node level)
   // -- and a step whose predecessor needed fewer than 60 keeps the hierarchy down to the 64-node level, whose inverse is one
   // single-workgroup kernel (drape: 25 iterations per solve, a 1 ms inversion per assembly would cost 15 % of the step)
-  if (c->mg_dense_auto) c->mg_dense_nodes = c->last_step_iters_per_solve > 200.0 ? 900 : c->last_step_iters_per_solve > 60.0 ? 256 : 64;
+  // The thresholds to LEAVE a tier downwards are 40 % lower than the ones to enter it: the larger dense level itself lowers the
+  // count (cfg4: 257 iterations per solve on the 225-node tier, 197 on the 841-node tier), and a rule without hysteresis flips
+  // between the tiers from step to step (measured: 55.8k element-steps/s flipping, 62.7k staying on the 841-node level).
+  if (c->mg_dense_auto) {
+    const double it = c->last_step_iters_per_solve;
+    const int cur = c->mg_dense_nodes;
+    const double to_900 = cur >= 900 ? 120.0 : 200.0, to_256 = cur >= 256 ? 36.0 : 60.0;
+    c->mg_dense_nodes = it > to_900 ? 900 : it > to_256 ? 256 : 64;
+  }
   c->bd_valid = false;  // dense body inverses are rebuilt once per step (first solve) and lagged over its Newton iterations
   // timestep_init: prev_pos <- pos (BaseScene.py:1291-1303)
   HIP_OK(hipMemcpyAsync(prev, pos, n3 * sizeof(double), hipMemcpyDeviceToDevice, s));
