@@ -573,22 +573,31 @@ struct MrScal {
   double thresh_eta;                                            // stop when |eta| <= thresh_eta
   int flag, iters;                                              // 0 running, 2 converged, 1 breakdown
 };
-// z /= gamma
-__global__ void k_mr_zscale(size_t n, double* __restrict__ z, const MrScal* __restrict__ sc) {
+// The Lanczos vectors z_j = M^-1 v_j are kept UNSCALED (z~_j = gamma_j z_j): the scaling 1 / gamma_j is applied where they are consumed
+// (operator product: here; direction update: k_mr_wx) instead of by a pass of its own, and delta_j = (H z~_j . z~_j) / gamma_j^2 comes
+// from the per-slice partials that the product kernel writes (every block re-reduces them, as the PCG update kernel does).
+// v_next = (H z~) / gamma - (delta / gamma) v_cur - (gamma / gamma_prev) v_prev
+__global__ void __launch_bounds__(256)
+k_mr_vnext(size_t n, double* __restrict__ v_next, const double* __restrict__ v_cur, const double* __restrict__ v_prev, MrScal* __restrict__ sc,
+           const double* __restrict__ part, int n_part) {
+  __shared__ double sm[8];
   if (sc->flag) return;
-  const double f = 1.0 / sc->gamma;
-  for (size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x) z[i] *= f;
+  const double draw = block_reduce_partials(part, n_part, sm);
+  const double g = sc->gamma, ig = 1.0 / g;
+  const double delta = draw * ig * ig;
+  const double a = delta * ig, b = g / sc->gamma_prev;
+  for (size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x) v_next[i] = v_next[i] * ig - a * v_cur[i] - b * v_prev[i];
+  if (blockIdx.x == 0 && threadIdx.x == 0) sc->delta = delta;
 }
-// v_next -= (delta / gamma) v_cur + (gamma / gamma_prev) v_prev
-__global__ void k_mr_vnext(size_t n, double* __restrict__ v_next, const double* __restrict__ v_cur, const double* __restrict__ v_prev, const MrScal* __restrict__ sc) {
+// Givens update of the Lanczos tridiagonal (one workgroup; g2n = v_next . M^-1 v_next from the per-workgroup partials of the
+// preconditioner's last kernel when part != null, else from the accumulator a k_dot launch filled)
+__global__ void __launch_bounds__(256) k_mr_scal(MrScal* sc, const double* __restrict__ part, int n_part) {
+  __shared__ double sm[8];
   if (sc->flag) return;
-  const double a = sc->delta / sc->gamma, b = sc->gamma / sc->gamma_prev;
-  for (size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x) v_next[i] -= a * v_cur[i] + b * v_prev[i];
-}
-// Givens update of the Lanczos tridiagonal (one thread)
-__global__ void k_mr_scal(MrScal* sc) {
-  if (sc->flag) return;
-  const double delta = sc->delta, g2n = sc->g2n, gamma = sc->gamma;
+  double g2n_part = 0.0;
+  if (part) g2n_part = block_reduce_partials(part, n_part, sm);
+  if (threadIdx.x != 0) return;
+  const double delta = sc->delta, g2n = part ? g2n_part : sc->g2n, gamma = sc->gamma;
   sc->delta = 0.0; sc->g2n = 0.0;
   if (!(g2n >= 0.0) || !isfinite(g2n) || !isfinite(delta)) { sc->flag = 1; sc->delta = delta; sc->g2n = g2n; return; }
   const double gamma_next = sqrt(g2n);
@@ -607,14 +616,15 @@ __global__ void k_mr_scal(MrScal* sc) {
   // flag 3: the update of this iteration still has to run (k_mr_wx turns it into 2)
   if (fabs(sc->eta) <= sc->thresh_eta || gamma_next == 0.0) sc->flag = 3;
 }
-// w_next = (z - a3 w_prev - a2 w_cur) / a1 ; x += cx w_next
+// w_next = (z~ / gamma - a3 w_prev - a2 w_cur) / a1 ; x += cx w_next
 __global__ void k_mr_wx(size_t n, const double* __restrict__ z, const double* __restrict__ w_prev, const double* __restrict__ w_cur, double* __restrict__ w_next,
                         double* __restrict__ x, MrScal* sc) {
   const int flag = sc->flag;
   if (flag == 1 || flag == 2) return;
   const double i1 = 1.0 / sc->a1, a2 = sc->a2, a3 = sc->a3, cx = sc->cx;
+  const double ig = 1.0 / sc->gamma_prev;  // z is unscaled; k_mr_scal has already advanced gamma -> gamma_prev
   for (size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x) {
-    const double w = (z[i] - a3 * w_prev[i] - a2 * w_cur[i]) * i1;
+    const double w = (z[i] * ig - a3 * w_prev[i] - a2 * w_cur[i]) * i1;
     w_next[i] = w;
     x[i] += cx * w;
   }

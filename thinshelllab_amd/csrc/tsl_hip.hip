@@ -1086,17 +1086,19 @@ static void launch_minres_iteration(tsl_ctx* c, const MrBufs& B, int j) {
   double *z_cur = B.Z[j % 2], *z_next = B.Z[(j + 1) % 2];
   double *w_prev = B.W[j % 3], *w_cur = B.W[(j + 1) % 3], *w_next = B.W[(j + 2) % 3];
   MrScal* sc = MSC(c);
-  hipLaunchKernelGGL(k_mr_zscale, dim3(gv), dim3(256), 0, s, n3, z_cur, sc);
-  launch_spmv(c, c->vals.p, z_cur, v_next, -1, 0);
-  hipLaunchKernelGGL(k_dot, dim3(DOT_BLOCKS), dim3(256), 0, s, n3, v_next, z_cur, &sc->delta);
-  hipLaunchKernelGGL(k_mr_vnext, dim3(gv), dim3(256), 0, s, n3, v_next, v_cur, v_prev, sc);
-  if (mg_active(c)) mg_vcycle(c, v_next, z_next, c->part_rz.p);
+  // v_next = H z~_cur with the per-slice partials of z~ . H z~ (no scaling pass, no separate dot launch)
+  hipLaunchKernelGGL((k_spmv_mw<4, 1, TSL_NT>), dim3(c->n_slices), dim3(256), 0, s, c->NV, c->n_slices, c->slice_off.p, c->slice_len.p, c->colidx.p, c->vals.p, z_cur, v_next,
+                     c->part_pAp.p, &sc->flag, contact_rows(c, c->c_H.p));
+  hipLaunchKernelGGL(k_mr_vnext, dim3(gv), dim3(256), 0, s, n3, v_next, v_cur, v_prev, sc, c->part_pAp.p, c->n_slices);
+  const bool mg = mg_active(c);
+  const bool bd = body_active(c) && c->bd_valid;
+  if (mg) mg_vcycle(c, v_next, z_next, c->part_rz.p);  // its last kernel leaves the partials of v_next . z_next in part_rz
   else {
     hipLaunchKernelGGL(k_precond, dim3(nblk(c->NV, 256)), dim3(256), 0, s, c->NV, c->Dinv.p, v_next, z_next);
-    if (body_active(c) && c->bd_valid) body_apply(c, 0, v_next, nullptr, z_next, nullptr, nullptr);
+    if (bd) body_apply(c, 0, v_next, nullptr, z_next, nullptr, nullptr);
+    hipLaunchKernelGGL(k_dot, dim3(DOT_BLOCKS), dim3(256), 0, s, n3, z_next, v_next, &sc->g2n);
   }
-  hipLaunchKernelGGL(k_dot, dim3(DOT_BLOCKS), dim3(256), 0, s, n3, z_next, v_next, &sc->g2n);
-  hipLaunchKernelGGL(k_mr_scal, dim3(1), dim3(1), 0, s, sc);
+  hipLaunchKernelGGL(k_mr_scal, dim3(1), dim3(256), 0, s, sc, mg ? c->part_rz.p : (const double*)nullptr, nblk(c->NV, 256) + (bd ? c->bd_wg : 0));
   hipLaunchKernelGGL(k_mr_wx, dim3(gv), dim3(256), 0, s, n3, z_cur, w_prev, w_cur, w_next, B.x, sc);
   hipLaunchKernelGGL(k_mr_seal, dim3(1), dim3(1), 0, s, sc);
 }
