@@ -231,9 +231,12 @@ def main():
     }
     traffic = None
     try:  # HBM bytes per launch from the committed rocprofv3 --pmc passes of this workload (scripts/gpu_profile.sh)
-        with open(os.path.join(ROOT, "profiles", f"r01b_{args.workload.replace('-', '_')}_pmc_k_pcg_spmv.json")) as fh:
-            if args.grid == 224:
-                traffic = json.load(fh)["traffic_bytes_per_launch"]
+        for tag in ("r01c", "r01b"):  # newest committed counter pass first
+            path = os.path.join(ROOT, "profiles", f"{tag}_{args.workload.replace('-', '_')}_pmc_k_pcg_spmv.json")
+            if os.path.exists(path) and args.grid == 224:
+                with open(path) as fh:
+                    traffic = json.load(fh)["traffic_bytes_per_launch"]
+                break
     except (OSError, KeyError, ValueError):
         pass
     if k1_us > 0:

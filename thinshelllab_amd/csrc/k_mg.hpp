@@ -274,18 +274,40 @@ TSL_DEV d3 st_prolonged(MgGrid gf, const double* __restrict__ x, const double* _
   return acc;
 }
 
-// (2) prolongation + first post-smoothing sweep: xt = x + P xc (never stored), y = xt + omega Dinv (r - A xt)
+// (2) prolongation + first post-smoothing sweep: xt = x + P xc (never stored), y = xt + omega Dinv (r - A xt).
+// The 25 neighbours of the workgroup's 64 consecutive nodes lie in five runs of 68 consecutive linear indices (one per stencil row
+// dI; a linear index that wraps into the adjacent grid row is never used: those slots fail the bounds test), so xt is formed ONCE
+// per run entry and staged in LDS (340 prolongations per workgroup instead of 1600 gathers of up to five vectors each).
 __global__ void __launch_bounds__(320)
 k_st_prolong_sweep(MgGrid g, const double* __restrict__ A, const double* __restrict__ x, const double* __restrict__ xc, double* __restrict__ y,
                    const double* __restrict__ Dinv, const double* __restrict__ r, const double* __restrict__ omega_dev) {
   __shared__ double red[5][3][64];
+  __shared__ double xt[5][68][3];
   const int n = (g.N + 1) * (g.M + 1);
   const int lane = threadIdx.x & 63, q = threadIdx.x >> 6;
-  const int row = blockIdx.x * 64 + lane;
+  const int row0 = blockIdx.x * 64;
+  const int row = row0 + lane;
+  // operands of the final combine that do not depend on the staged vector: requested first
+  m3 D;
+  d3 rv = d3();
+  if (q == 0 && row < n) {
+#pragma unroll
+    for (int e = 0; e < 9; e++) D.m[e] = Dinv[9 * (size_t)row + e];
+    rv = ld3(r, row);
+  }
+  {
+    const int base = row0 + (q - 2) * (g.M + 1) - 2;
+    for (int k = lane; k < 68; k += 64) {
+      const int f = base + k;
+      d3 v = d3();
+      if (f >= 0 && f < n) v = st_prolonged(g, x, xc, f / (g.M + 1), f % (g.M + 1));
+      xt[q][k][0] = v.x; xt[q][k][1] = v.y; xt[q][k][2] = v.z;
+    }
+  }
+  __syncthreads();
   double y0 = 0, y1 = 0, y2 = 0;
-  int I = 0, J = 0;
   if (row < n) {
-    I = row / (g.M + 1); J = row % (g.M + 1);
+    const int I = row / (g.M + 1), J = row % (g.M + 1);
     const int I2 = I + q - 2;
     if (I2 >= 0 && I2 <= g.N) {
 #pragma unroll
@@ -294,10 +316,11 @@ k_st_prolong_sweep(MgGrid g, const double* __restrict__ A, const double* __restr
         if (J2 < 0 || J2 > g.M) continue;
         const int s = q * 5 + (dJ + 2);
         const double* a = A + (size_t)s * 9 * n + row;
-        const d3 xj = st_prolonged(g, x, xc, I2, J2);
-        y0 += a[0] * xj.x + a[(size_t)n] * xj.y + a[2 * (size_t)n] * xj.z;
-        y1 += a[3 * (size_t)n] * xj.x + a[4 * (size_t)n] * xj.y + a[5 * (size_t)n] * xj.z;
-        y2 += a[6 * (size_t)n] * xj.x + a[7 * (size_t)n] * xj.y + a[8 * (size_t)n] * xj.z;
+        const double* xv = xt[q][lane + dJ + 2];
+        const double x0 = xv[0], x1 = xv[1], x2 = xv[2];
+        y0 += a[0] * x0 + a[(size_t)n] * x1 + a[2 * (size_t)n] * x2;
+        y1 += a[3 * (size_t)n] * x0 + a[4 * (size_t)n] * x1 + a[5 * (size_t)n] * x2;
+        y2 += a[6 * (size_t)n] * x0 + a[7 * (size_t)n] * x1 + a[8 * (size_t)n] * x2;
       }
     }
   }
@@ -306,11 +329,9 @@ k_st_prolong_sweep(MgGrid g, const double* __restrict__ A, const double* __restr
   if (q == 0 && row < n) {
 #pragma unroll
     for (int k = 1; k < 5; k++) { y0 += red[k][0][lane]; y1 += red[k][1][lane]; y2 += red[k][2][lane]; }
-    m3 D;
-#pragma unroll
-    for (int e = 0; e < 9; e++) D.m[e] = Dinv[9 * (size_t)row + e];
-    const d3 res = ld3(r, row) - d3(y0, y1, y2);
-    st3(y, row, st_prolonged(g, x, xc, I, J) + (*omega_dev) * m3_mulv(D, res));
+    const d3 res = rv - d3(y0, y1, y2);
+    const double* xo = xt[2][lane + 2];
+    st3(y, row, d3(xo[0], xo[1], xo[2]) + (*omega_dev) * m3_mulv(D, res));
   }
 }
 
