@@ -3,7 +3,7 @@
 # HBM counters of the PCG SpMV kernel in their own passes (FETCH_SIZE and WRITE_SIZE do not fit one pass).
 cd $GRAFT_REPO_ROOT
 export TMPDIR=/tmp
-TAG=${1:-r01b}
+TAG=${1:-r01c}
 ARGS=${BENCH_ARGS:---steps 2 --warmup 2 --no-cpu-baseline}
 mkdir -p gpurun_out/prof
 rocprofv3 --kernel-trace --stats --output-format csv -d gpurun_out/prof -o ${TAG}_bench -- python bench.py $ARGS > gpurun_out/prof/${TAG}_bench_stdout.log 2>&1

@@ -14,7 +14,7 @@ def last_json_line(path):
     return [l for l in open(path) if l.startswith('{"metric"')][-1]
 
 
-for tag, name in (("r01b", "cfg4"), ("r01bs", "cfg4_scaled")):
+for tag, name in ((OUT, "cfg4"), (OUT + "s", "cfg4_scaled")):
     shutil.copy(src + f"{tag}_bench_kernel_stats.csv", dst + f"{OUT}_{name}_kernel_stats.csv")
     line = last_json_line(src + f"{tag}_bench_stdout.log")
     open(dst + f"{OUT}_{name}_bench.json", "w").write(line)

@@ -161,6 +161,7 @@ struct tsl_ctx {
   DevBuf<double> bd_W, bd_scr;
   DevBuf<double> bd_rb;  // compact ping-pong copy of the PCG residual on the dense-body rows (body part of k_pcg_update)
   int pcg_body_fold = 1;
+  int mg_fr_rows = 32;   // coarse nodes per workgroup of k_st_first_restrict (16 / 32 / 64)
   DevBuf<float> bd_Binv;
   DevBuf<double> gm_V, gm_h;  // GMRES basis ((m+1) vectors) and projection coefficients
   int gmres_m = 300, use_gmres = 1, use_minres = 1, verbose = 0;

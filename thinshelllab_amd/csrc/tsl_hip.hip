@@ -327,6 +327,7 @@ extern "C" int tsl_set_param(tsl_ctx* c, const char* key, double v) {
   else if (k == "mg_omega") c->mg_omega = v;
   else if (k == "mg_fuse") c->mg_fuse = (int)v;
   else if (k == "pcg_body_fold") c->pcg_body_fold = (int)v;
+  else if (k == "mg_fr_rows") { c->mg_fr_rows = (int)v; if (c->pcg_graph) { (void)hipGraphExecDestroy(c->pcg_graph); c->pcg_graph = nullptr; } if (c->mr_graph) { (void)hipGraphExecDestroy(c->mr_graph); c->mr_graph = nullptr; } }
   else if (k == "mg_fuse_restrict") { c->mg_fuse_restrict = (int)v; c->mg_ops_valid = false; }
   else if (k == "mg_coarse_exact") c->mg_coarse_exact = (int)v;
   else if (k == "mg_coarse_lag") c->mg_coarse_lag = (int)v;
@@ -776,7 +777,9 @@ static double* mg_stencil_cycle(tsl_ctx* c, MgCloth* mc, size_t l) {
   const bool fuse_down = c->mg_fuse && !last && c->mg_nu == 1;
   if (fuse_down && c->mg_fuse_restrict) {  // x = omega Dinv r and the coarse right-hand side in one launch (k_mg.hpp (1b))
     MgLevel* Lc = mc->lv[l + 1];
-    hipLaunchKernelGGL((k_st_first_restrict<32>), dim3(nblk(Lc->n, 32)), dim3(7 * 32), 0, s, g, L->S.p, L->Dinv.p, L->r.p, L->omega.p, xa, Lc->r.p);
+    if (c->mg_fr_rows == 16) hipLaunchKernelGGL((k_st_first_restrict<16>), dim3(nblk(Lc->n, 16)), dim3(7 * 16), 0, s, g, L->S.p, L->Dinv.p, L->r.p, L->omega.p, xa, Lc->r.p);
+    else if (c->mg_fr_rows == 64) hipLaunchKernelGGL((k_st_first_restrict<64>), dim3(nblk(Lc->n, 64)), dim3(7 * 64), 0, s, g, L->S.p, L->Dinv.p, L->r.p, L->omega.p, xa, Lc->r.p);
+    else hipLaunchKernelGGL((k_st_first_restrict<32>), dim3(nblk(Lc->n, 32)), dim3(7 * 32), 0, s, g, L->S.p, L->Dinv.p, L->r.p, L->omega.p, xa, Lc->r.p);
     const double* xc = mg_stencil_cycle(c, mc, l + 1);
     hipLaunchKernelGGL(k_st_prolong_sweep, dim3(gb5), dim3(320), 0, s, g, L->A.p, xa, xc, xb, L->Dinv.p, L->r.p, L->omega.p);
     return xb;
