@@ -638,9 +638,8 @@ extern "C" int tsl_contact_detect(tsl_ctx* c, const double* pos, const double* p
   return 0;
 }
 
-static int contact_assemble(tsl_ctx* c, const double* pos, int spd, double* grad) {
+static int contact_assemble(tsl_ctx* c, const double* pos, int spd, double* grad, hipStream_t s) {
   if (c->nc <= 0) return 0;
-  hipStream_t s = c->stream;
   ContactArgs A;
   A.idx = c->c_idx.p; A.w = c->c_w.p; A.n = c->c_n.p; A.dx0 = c->c_dx0.p; A.k = c->c_k.p; A.mu = c->c_mu.p; A.T = c->c_T.p;
   A.k_contact = c->k_contact; A.eps_contact = c->eps_contact; A.eps_vh = c->eps_v * c->dt;

@@ -180,6 +180,9 @@ struct tsl_ctx {
   SolverScalars* h_scal = nullptr;  // pinned
   SolverScalars* h_scal2 = nullptr; // pinned, two records: read-back slots of the PCG chunks in flight
   hipEvent_t rb_event[2] = {nullptr, nullptr};
+  hipStream_t side = 0;                         // second stream: contact blocks of an assembly run next to the cloth / tet kernels
+  hipEvent_t ev_fork = nullptr, ev_join = nullptr;
+  int asm_overlap = 1;
 
   // ---- Newton scratch (original order)
   DevBuf<double> F, pdir, x1;

@@ -264,6 +264,8 @@ extern "C" int tsl_ctx_create(const tsl_scene_desc* d, tsl_ctx** out) {
   if (hipHostMalloc((void**)&c->h_scal2, 2 * sizeof(SolverScalars)) != hipSuccess) { delete c; return tsl_fail("hipHostMalloc failed"); }
   for (int i = 0; i < 2; i++)
     if (hipEventCreateWithFlags(&c->rb_event[i], hipEventDisableTiming) != hipSuccess) { delete c; return tsl_fail("hipEventCreate failed"); }
+  if (hipStreamCreateWithFlags(&c->side, hipStreamNonBlocking) != hipSuccess || hipEventCreateWithFlags(&c->ev_fork, hipEventDisableTiming) != hipSuccess ||
+      hipEventCreateWithFlags(&c->ev_join, hipEventDisableTiming) != hipSuccess) { delete c; return tsl_fail("side stream / event creation failed"); }
   c->vals.zero(); c->vals_full.zero(); c->scal.zero(); c->part_rz.zero(); c->part_rr.zero();
 
   // ---- contact tables
@@ -288,6 +290,9 @@ extern "C" void tsl_ctx_destroy(tsl_ctx* c) {
   if (c->mr_graph) (void)hipGraphExecDestroy(c->mr_graph);
   if (c->ev_in) (void)hipEventDestroy(c->ev_in);
   if (c->ev_out) (void)hipEventDestroy(c->ev_out);
+  if (c->ev_fork) (void)hipEventDestroy(c->ev_fork);
+  if (c->ev_join) (void)hipEventDestroy(c->ev_join);
+  if (c->side) (void)hipStreamDestroy(c->side);
   if (c->stream) (void)hipStreamDestroy(c->stream);
   for (auto& e : c->ev_pool) { (void)hipEventDestroy(e.first); (void)hipEventDestroy(e.second); }
   delete c;
@@ -327,6 +332,7 @@ extern "C" int tsl_set_param(tsl_ctx* c, const char* key, double v) {
   else if (k == "mg_omega") c->mg_omega = v;
   else if (k == "mg_fuse") c->mg_fuse = (int)v;
   else if (k == "pcg_body_fold") c->pcg_body_fold = (int)v;
+  else if (k == "asm_overlap") c->asm_overlap = (int)v;
   else if (k == "mg_fr_rows") { c->mg_fr_rows = (int)v; if (c->pcg_graph) { (void)hipGraphExecDestroy(c->pcg_graph); c->pcg_graph = nullptr; } if (c->mr_graph) { (void)hipGraphExecDestroy(c->mr_graph); c->mr_graph = nullptr; } }
   else if (k == "mg_fuse_restrict") { c->mg_fuse_restrict = (int)v; c->mg_ops_valid = false; }
   else if (k == "mg_coarse_exact") c->mg_coarse_exact = (int)v;
@@ -427,8 +433,18 @@ static int assemble(tsl_ctx* c, const double* pos, const double* prev, const dou
   const ClothArgs CA = cloth_args(c);
   const VertArgs VA = vert_args(c);
   const TetArgs TA = tet_args(c);
+  if (grad) HIP_OK(hipMemsetAsync(grad, 0, 3 * (size_t)NV * sizeof(double), s));
+  // contact: gradient into grad (atomics), per-constraint 12x12 into c_Hfull, masked copy + diagonal into c_H / cdiag.  One lane per
+  // constraint with a 9x9 eigen-clamp each: 0.7 ms of latency for ~100 constraints, so the three launches go to a second stream next to
+  // the cloth / tet kernels (they share nothing but the zeroed gradient, which both sides only add to).
+  const bool fork = c->asm_overlap && c->nc > 0;
+  if (fork) {
+    HIP_OK(hipEventRecord(c->ev_fork, s));
+    HIP_OK(hipStreamWaitEvent(c->side, c->ev_fork, 0));
+    TSL_TRY(contact_assemble(c, pos, spd, grad, c->side));
+    HIP_OK(hipEventRecord(c->ev_join, c->side));
+  }
   if (grad) {
-    HIP_OK(hipMemsetAsync(grad, 0, 3 * (size_t)NV * sizeof(double), s));
     hipLaunchKernelGGL(k_vert_grad, dim3(nblk(NV, 256)), dim3(256), 0, s, VA, pos, prev, vel, grad);
     if (c->n_cface) hipLaunchKernelGGL(k_cloth_grad_face, dim3(nblk(c->n_cface, 256)), dim3(256), 0, s, CA, pos, grad);
     if (c->n_hinge) hipLaunchKernelGGL(k_cloth_grad_hinge, dim3(nblk(c->n_hinge, 256)), dim3(256), 0, s, CA, pos, ref, grad);
@@ -443,8 +459,8 @@ static int assemble(tsl_ctx* c, const double* pos, const double* prev, const dou
   }
   if (c->n_hinge) hipLaunchKernelGGL(k_cloth_hess_hinge, dim3(nblk(c->n_hinge, 256)), dim3(256), 0, s, CA, c->hg_blk.p, pos, c->vals_full.p);
   if (c->n_tet) hipLaunchKernelGGL(k_tet_hess, dim3(nblk(c->n_tet, 64)), dim3(64), 0, s, TA, c->tet_blk.p, pos, spd, c->vals_full.p);
-  // contact: gradient into grad, per-constraint 12x12 into c_Hfull, masked copy + diagonal into c_H / cdiag
-  TSL_TRY(contact_assemble(c, pos, spd, grad));
+  if (fork) HIP_OK(hipStreamWaitEvent(s, c->ev_join, 0));
+  else TSL_TRY(contact_assemble(c, pos, spd, grad, s));
   if (grad) hipLaunchKernelGGL(k_mask_vec, dim3(gsz(3 * (size_t)NV)), dim3(256), 0, s, 3 * (size_t)NV, c->frozen.p, grad);
   hipLaunchKernelGGL(k_mask_matrix, dim3(c->n_slices), dim3(256), 0, s, c->n_slices, c->slice_off.p, c->slice_len.p, c->colidx.p, c->fzmask.p, c->mdt2.p,
                      c->vals_full.p, c->vals.p, NV);
