@@ -1,5 +1,7 @@
 """GPU parity of the full task scenes (cloth + FEM bodies + contact + gripper drive + adjoint) against the oracle.
 Native reference sizes: folding (502 nodes), lifting (1209), balancing (1332)."""
+import os
+
 import numpy as np
 import pytest
 import torch
@@ -539,3 +541,50 @@ def test_interact_scene(oracle):
         assert rel_err(pg_g[k], pg_o[k]) < 1e-4, f"pos_grad[{k}]"
     gg_o = o.arr("grad.gripper_grad", (T, n_part, 6)); gg_g = g.gripper_grad.to_numpy()[:, :n_part]
     assert np.abs(gg_o).max() > 0 and rel_err(gg_g[2:], gg_o[2:]) < 1e-4
+
+
+def test_rl_env_matches_direct_stepping(tmp_path):
+    """training/RL_env.Env (reference RL_env.py:31-236): an episode driven through reset / step gives the observations and rewards
+    of the same actions applied to a scene directly; termination at the time limit returns zeros and done."""
+    from thinshelllab_amd.training.RL_env import Env
+    from thinshelllab_amd.task_scene.Scene_lifting import Scene
+    from thinshelllab_amd.engine.geometry import projection_query
+    env = Env("lifting", 3, Kb=100.0, mu=5.0, model=None, task_name="lift")
+    assert env.action_space.shape == (env.sys.action_dim,) and env.observation_space.shape == (env.sys.obs_dim,)
+    s = Scene(cloth_size=0.06)
+    s.init_all()
+    s.cloths[0].Kb[None] = 100.0
+    s.mu_cloth_elastic[None] = 5.0
+    s.reset()
+    obs0, info = env.reset()
+    assert np.abs(obs0 - s.get_observation_kernel()).max() == 0.0
+    n_part = s.gripper.n_part
+    rng = np.random.default_rng(7)
+    for k in range(1, 4):
+        a = rng.uniform(-2e-4, 2e-4, size=env.sys.action_dim)
+        obs, rew, done, trunc, info = env.step(a)
+        aa = a.reshape(n_part, 6)
+        s.action(k, aa[:, :3].copy(), aa[:, 3:].copy())
+        s.time_step(projection_query, k)
+        if k < 3:
+            assert not done
+            # two contexts: atomic summation order differs, and the observation holds velocities (position differences / dt)
+            assert np.abs(obs - s.get_observation_kernel()).max() < 1e-6
+            assert abs(rew - np.exp(s.compute_reward())) < 1e-8 * abs(rew)
+        else:
+            assert done and trunc and rew == 0 and not obs.any()
+    assert len(env.rewards) == 1
+
+
+def test_cmaes_driver_runs_forward_only(tmp_path, monkeypatch):
+    """training/run_cmaes_all (reference run_cmaes_all.py): two generations of four candidates on the lifting scene; the best
+    fitness never gets worse, outputs are written, every evaluation is a forward-only rollout."""
+    monkeypatch.setenv("TSL_OUT", str(tmp_path))
+    from thinshelllab_amd.training import run_cmaes_all
+    out = run_cmaes_all.main(["--env", "lifting", "--tot_step", "4", "--abs_step", "2", "--pop_size", "4", "--iter", "2", "--mu", "5", "--seed", "11"])
+    h = np.array(out["history"])
+    assert h.shape == (8,) and np.isfinite(h).all()
+    assert out["fbest"] == h.min()
+    assert os.path.exists(os.path.join(out["save_path"], "plot_Data.npy")) and os.path.exists(os.path.join(out["save_path"], "traj_1.npy"))
+    tr = np.load(os.path.join(out["save_path"], "traj_1.npy"))
+    assert tr.shape[0] == 4 and tr.shape[2] == 6 and np.abs(tr[0]).max() == 0.0

@@ -206,3 +206,50 @@ def test_batch_helpers_world_size_2_gloo(tmp_path):
         out, err = p.communicate(timeout=240)
         assert p.returncode == 0, err[-2000:]
         assert "ok" in out
+
+
+def test_cmaes_restatement_converges():
+    """optimizer/cmaes.py (stand-in for the un-vendored `cma` of run_cmaes_all.py): ask / tell / result / stop surface, convergence on
+    the sphere and on Rosenbrock, candidate count checks."""
+    from thinshelllab_amd.optimizer.cmaes import CMAEvolutionStrategy
+    es = CMAEvolutionStrategy(10 * [5.0], 1.0, {"popsize": 8, "seed": 3})
+    X = es.ask()
+    assert len(X) == 8 and X[0].shape == (10,)
+    with pytest.raises(ValueError):
+        es.tell(X[:3], [0.0, 1.0, 2.0])
+    for _ in range(150):
+        X = es.ask(); es.tell(X, [float(np.sum((x - 2.0) ** 2)) for x in X])
+    assert es.result.fbest < 1e-6 and np.abs(es.result.xbest - 2.0).max() < 1e-2
+    rosen = lambda x: float(np.sum(100 * (x[1:] - x[:-1] ** 2) ** 2 + (1 - x[:-1]) ** 2))
+    es = CMAEvolutionStrategy(6 * [0.0], 0.5, {"popsize": 12, "seed": 1, "maxiter": 500})
+    while not es.stop():
+        X = es.ask(); es.tell(X, [rosen(x) for x in X])
+    assert es.result.fbest < 1e-8 and es.result.evaluations == 12 * es.result.iterations
+
+
+def test_cmaes_candidate_decoding():
+    """run_cmaes_all.decode (reference run_cmaes_all.py:98-114): a constant candidate of 5 is the zero trajectory; an offset on one
+    component gives a linear ramp of slope (x - 5) / sub_steps / scaling, clipped by fix_action."""
+    from types import SimpleNamespace
+    from thinshelllab_amd.agent.traj_opt_single import agent_trajopt
+    from thinshelllab_amd.training.run_cmaes_all import decode
+    T, abs_step, cnt = 12, 4, 2
+    sub = T // abs_step
+    scaling = 5.0 / (sub * 0.0003); scaling_angle = 5.0 / (sub * 0.01)
+    args = SimpleNamespace(abs_step=abs_step, env="folding")
+    agent = agent_trajopt(T, cnt, max_moving_dist=0.002)
+    decode(agent, np.full(abs_step * 6 * cnt, 5.0), args, cnt, sub, scaling, scaling_angle)
+    assert float(agent.traj.t.abs().max()) == 0.0
+    x = np.full(abs_step * 6 * cnt, 5.0); x[1 * 6 * cnt + 1 * 6 + 2] = 6.0   # segment 1, gripper 1, z
+    decode(agent, x, args, cnt, sub, scaling, scaling_angle)
+    tr = agent.traj.to_numpy()
+    step = 1.0 / sub / scaling
+    assert np.allclose(tr[sub - 1], 0) and np.allclose(tr[2 * sub - 1, 1, 2], sub * step) and np.allclose(tr[-1, 1, 2], sub * step)
+    assert np.allclose(np.delete(tr.reshape(T, -1), 1 * 6 + 2, axis=1), 0)
+
+
+def test_rl_env_box_fallback():
+    from thinshelllab_amd.training.RL_env import Box
+    b = Box(low=-0.001, high=0.001, shape=(12,), dtype=np.float32)
+    a = b.sample(np.random.default_rng(0)) if not hasattr(b, "np_random") else b.sample()
+    assert a.shape == (12,) and b.contains(a)
