@@ -189,6 +189,9 @@ assert b.max_over_ranks(1.0 + b.rank) == 2.0
 assert b.sum_over_ranks(10.0) == 20.0
 rs, gs = b.gather_results(100.0 + b.rank, torch.full((4, 1, 6), float(b.rank), dtype=torch.float64))
 assert rs == [100.0, 101.0] and gs[1].sum().item() == 24.0 and gs[0].sum().item() == 0.0
+calls = []
+f = b.share_population(5, lambda k: (calls.append(k), 10.0 * k + 1.0)[1])
+assert f == [1.0, 11.0, 21.0, 31.0, 41.0] and calls == ids
 b.close()
 print("ok", b.rank)
 '''

@@ -62,6 +62,16 @@ class Batch:
         self.dist.all_reduce(t, op=self.dist.ReduceOp.SUM)
         return float(t.item())
 
+    def share_population(self, n, evaluate):
+        """fitness of n independent candidates (CMA-ES population, run_cmaes_all): candidate k runs on rank k % world, the values
+        are combined with one all_reduce of an n-vector; every rank returns the full list"""
+        f = torch.zeros(n, dtype=torch.float64, device=self.device)
+        for k in self.scene_ids(n):
+            f[k] = float(evaluate(k))
+        if self.dist is not None:
+            self.dist.all_reduce(f, op=self.dist.ReduceOp.SUM)
+        return [float(v) for v in f.cpu()]
+
     def gather_results(self, reward, gripper_grad):
         """all_gather of (reward, gripper_grad) -> list over ranks; the only exchange of a batched trajopt iteration"""
         g = gripper_grad.to(self.device, torch.float64).contiguous()

@@ -61,10 +61,11 @@ def main(argv=None):
 
     tot_timestep = args.tot_step
     cloth_size = 0.1 if args.env in ("folding_2", "forming") else 0.06
+    dev = f"cuda:{int(os.environ.get('LOCAL_RANK', '0'))}"   # one scene per GPU under torch.distributed.run
     if args.env == "interact":
-        sys = Scene.Scene(cloth_size=cloth_size, soft=args.Kb < 2, dense=args.dense)
+        sys = Scene.Scene(cloth_size=cloth_size, soft=args.Kb < 2, dense=args.dense, device=dev)
     else:
-        sys = Scene.Scene(cloth_size=cloth_size)
+        sys = Scene.Scene(cloth_size=cloth_size, device=dev)
     sys.cloths[0].Kb[None] = args.Kb
     sys.init_all()
     sys.mu_cloth_elastic[None] = args.mu
@@ -132,18 +133,25 @@ def main(argv=None):
             reward += reward_of(sys)
         return -reward
 
+    # Under torch.distributed.run the population is the embarrassingly parallel batch of SURVEY.md section 8e: candidate k of a
+    # generation is rolled out on rank k % world (one scene and one engine context per GPU), one all_reduce of the fitness vector
+    # per generation; every rank keeps an identical strategy state, which needs a common --seed.
+    from ..batch import Batch
+    batch = Batch(device=sys.device if hasattr(sys, "device") else None)
+    if batch.world > 1 and args.seed is None:
+        raise SystemExit("run_cmaes_all: --seed is required when the population is shared between ranks")
     plot_y = []
     for ww in range(args.iter):
         X = es.ask()
-        tell_list = []
-        for x in X:
-            tell_list.append(evaluate(x))
-            plot_y.append(tell_list[-1])
+        tell_list = batch.share_population(len(X), lambda k: evaluate(X[k]))
+        plot_y.extend(tell_list)
         es.tell(X, tell_list)
-        es.disp()
-        np.save(os.path.join(save_path, "plot_Data.npy"), np.array(plot_y))
-        decode(agent, es.result.xbest, args, gripper_cnt, sub_steps, scaling, scaling_angle)
-        np.save(os.path.join(save_path, f"traj_{ww}.npy"), agent.traj.to_numpy())
+        if batch.rank == 0:
+            es.disp()
+            np.save(os.path.join(save_path, "plot_Data.npy"), np.array(plot_y))
+            decode(agent, es.result.xbest, args, gripper_cnt, sub_steps, scaling, scaling_angle)
+            np.save(os.path.join(save_path, f"traj_{ww}.npy"), agent.traj.to_numpy())
+    batch.close()
     return dict(fbest=es.result.fbest, history=plot_y, save_path=save_path)
 
 
