@@ -145,7 +145,8 @@ k_st_first_resid(MgGrid g, const double* __restrict__ A, const double* __restric
 // stencil radius 2 on the fine grid), i.e. 12.25 blocks per fine node instead of the 25 of A, and the fine-level residual is never
 // formed (the post-sweep recomputes A x from scratch anyway).  One launch and half the bytes less per level and cycle.
 // S[(s*9+e)*nc + crow], s = (dI+3)*7 + (dJ+3), column = fine node (2I+dI, 2J+dJ)
-__global__ void k_st_build_ra(MgGrid gf, const double* __restrict__ A, const double* __restrict__ Dinv, double* __restrict__ S) {
+template <typename VT>
+__global__ void k_st_build_ra(MgGrid gf, const VT* __restrict__ A, const double* __restrict__ Dinv, VT* __restrict__ S) {
   const int Nc = gf.N >> 1, Mc = gf.M >> 1;
   const int nc = (Nc + 1) * (Mc + 1), nf = (gf.N + 1) * (gf.M + 1);
   const int t = blockIdx.x * blockDim.x + threadIdx.x;
@@ -157,10 +158,10 @@ __global__ void k_st_build_ra(MgGrid gf, const double* __restrict__ A, const dou
   double acc[9];
 #pragma unroll
   for (int e = 0; e < 9; e++) acc[e] = 0.0;
-  double* dst = S + (size_t)s * 9 * nc + crow;
+  VT* dst = S + (size_t)s * 9 * nc + crow;
   if (ci < 0 || ci > gf.N || cj < 0 || cj > gf.M) {
 #pragma unroll
-    for (int e = 0; e < 9; e++) dst[(size_t)e * nc] = 0.0;
+    for (int e = 0; e < 9; e++) dst[(size_t)e * nc] = (VT)0;
     return;
   }
 #pragma unroll
@@ -172,9 +173,9 @@ __global__ void k_st_build_ra(MgGrid gf, const double* __restrict__ A, const dou
       const int j = 2 * J + dj, b = dJ - dj;
       if (j < 0 || j > gf.M || b < -2 || b > 2) continue;
       const double w = (di == 0 ? 1.0 : 0.5) * (dj == 0 ? 1.0 : 0.5);
-      const double* src = A + (size_t)((a + 2) * 5 + (b + 2)) * 9 * nf + (i * (gf.M + 1) + j);
+      const VT* src = A + (size_t)((a + 2) * 5 + (b + 2)) * 9 * nf + (i * (gf.M + 1) + j);
 #pragma unroll
-      for (int e = 0; e < 9; e++) acc[e] += w * src[(size_t)e * nf];
+      for (int e = 0; e < 9; e++) acc[e] += w * (double)src[(size_t)e * nf];
     }
   }
   const double* D = Dinv + 9 * (size_t)(ci * (gf.M + 1) + cj);
@@ -184,14 +185,14 @@ __global__ void k_st_build_ra(MgGrid gf, const double* __restrict__ A, const dou
 #pragma unroll
   for (int r = 0; r < 3; r++)
 #pragma unroll
-    for (int cc = 0; cc < 3; cc++) dst[(size_t)(3 * r + cc) * nc] = acc[3 * r] * d[cc] + acc[3 * r + 1] * d[3 + cc] + acc[3 * r + 2] * d[6 + cc];
+    for (int cc = 0; cc < 3; cc++) dst[(size_t)(3 * r + cc) * nc] = (VT)(acc[3 * r] * d[cc] + acc[3 * r + 1] * d[3 + cc] + acc[3 * r + 2] * d[6 + cc]);
 }
 
 // ROWS coarse nodes per workgroup, 7 threads per node (one per fine row offset dI); threads 1..4 of a node also write the
 // smoothed iterate x = omega Dinv r of its four fine nodes (2I + {0,1}, 2J + {0,1}), thread 0 the coarse right-hand side.
-template <int ROWS>
+template <int ROWS, typename VT>
 __global__ void __launch_bounds__(7 * ROWS)
-k_st_first_restrict(MgGrid g, const double* __restrict__ S, const double* __restrict__ Dinv, const double* __restrict__ r, const double* __restrict__ omega_dev,
+k_st_first_restrict(MgGrid g, const VT* __restrict__ S, const double* __restrict__ Dinv, const double* __restrict__ r, const double* __restrict__ omega_dev,
                     double* __restrict__ x, double* __restrict__ rc) {
   __shared__ double red[7][3][ROWS];
   const int Nc = g.N >> 1, Mc = g.M >> 1;
@@ -209,7 +210,7 @@ k_st_first_restrict(MgGrid g, const double* __restrict__ S, const double* __rest
       for (int dJ = -3; dJ <= 3; dJ++) {
         const int j2 = 2 * J + dJ;
         if (j2 < 0 || j2 > g.M) continue;
-        const double* a = S + (size_t)(q * 7 + dJ + 3) * 9 * nc + crow;
+        const VT* a = S + (size_t)(q * 7 + dJ + 3) * 9 * nc + crow;
         const d3 rj = ld3(r, i2 * (g.M + 1) + j2);
         y0 += a[0] * rj.x + a[(size_t)nc] * rj.y + a[2 * (size_t)nc] * rj.z;
         y1 += a[3 * (size_t)nc] * rj.x + a[4 * (size_t)nc] * rj.y + a[5 * (size_t)nc] * rj.z;
@@ -278,8 +279,9 @@ TSL_DEV d3 st_prolonged(MgGrid gf, const double* __restrict__ x, const double* _
 // The 25 neighbours of the workgroup's 64 consecutive nodes lie in five runs of 68 consecutive linear indices (one per stencil row
 // dI; a linear index that wraps into the adjacent grid row is never used: those slots fail the bounds test), so xt is formed ONCE
 // per run entry and staged in LDS (340 prolongations per workgroup instead of 1600 gathers of up to five vectors each).
+template <typename VT>
 __global__ void __launch_bounds__(320)
-k_st_prolong_sweep(MgGrid g, const double* __restrict__ A, const double* __restrict__ x, const double* __restrict__ xc, double* __restrict__ y,
+k_st_prolong_sweep(MgGrid g, const VT* __restrict__ A, const double* __restrict__ x, const double* __restrict__ xc, double* __restrict__ y,
                    const double* __restrict__ Dinv, const double* __restrict__ r, const double* __restrict__ omega_dev) {
   __shared__ double red[5][3][64];
   __shared__ double xt[5][68][3];
@@ -315,7 +317,7 @@ k_st_prolong_sweep(MgGrid g, const double* __restrict__ A, const double* __restr
         const int J2 = J + dJ;
         if (J2 < 0 || J2 > g.M) continue;
         const int s = q * 5 + (dJ + 2);
-        const double* a = A + (size_t)s * 9 * n + row;
+        const VT* a = A + (size_t)s * 9 * n + row;
         const double* xv = xt[q][lane + dJ + 2];
         const double x0 = xv[0], x1 = xv[1], x2 = xv[2];
         y0 += a[0] * x0 + a[(size_t)n] * x1 + a[2 * (size_t)n] * x2;

@@ -73,6 +73,7 @@ struct SolverScalars {
 struct MgLevel {
   int N = 0, M = 0, n = 0;
   DevBuf<double> A, Dinv, x, x2, r, t;
+  DevBuf<float> A32, S32;  // single-precision copies for the two cycle kernels of the level (mg_st_f32)
   DevBuf<double> S;      // P^T A Dinv towards the next level (49 slots per coarse node, k_st_build_ra); empty on the last level
   DevBuf<double> omega;  // [0] damping factor, [1] lambda_max estimate (device resident)
   DevBuf<float> Cinv;    // dense inverse of the last level of the hierarchy (blocked Gauss-Jordan per assembly), symmetrised, fp32
@@ -161,6 +162,7 @@ struct tsl_ctx {
   DevBuf<double> bd_W, bd_scr;
   DevBuf<double> bd_rb;  // compact ping-pong copy of the PCG residual on the dense-body rows (body part of k_pcg_update)
   int pcg_body_fold = 1;
+  int mg_st_f32 = 1;
   int mg_fr_rows = 32;   // coarse nodes per workgroup of k_st_first_restrict (16 / 32 / 64)
   DevBuf<float> bd_Binv;
   DevBuf<double> gm_V, gm_h;  // GMRES basis ((m+1) vectors) and projection coefficients

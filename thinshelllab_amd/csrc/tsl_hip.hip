@@ -333,6 +333,7 @@ extern "C" int tsl_set_param(tsl_ctx* c, const char* key, double v) {
   else if (k == "mg_fuse") c->mg_fuse = (int)v;
   else if (k == "pcg_body_fold") c->pcg_body_fold = (int)v;
   else if (k == "asm_overlap") c->asm_overlap = (int)v;
+  else if (k == "mg_st_f32") { c->mg_st_f32 = (int)v; c->mg_ops_valid = false; }
   else if (k == "mg_fr_rows") { c->mg_fr_rows = (int)v; if (c->pcg_graph) { (void)hipGraphExecDestroy(c->pcg_graph); c->pcg_graph = nullptr; } if (c->mr_graph) { (void)hipGraphExecDestroy(c->mr_graph); c->mr_graph = nullptr; } }
   else if (k == "mg_fuse_restrict") { c->mg_fuse_restrict = (int)v; c->mg_ops_valid = false; }
   else if (k == "mg_coarse_exact") c->mg_coarse_exact = (int)v;
@@ -677,8 +678,14 @@ static int mg_setup_operators(tsl_ctx* c) {
       HIP_OK(hipMemsetAsync(Lc->A.p, 0, Lc->A.n * sizeof(double), s));
       hipLaunchKernelGGL(k_galerkin_st, dim3(nblk((long)Lf->n * 25, 256)), dim3(256), 0, s, MgGrid{Lf->N, Lf->M}, Lf->A.p, Lc->A.p);
       hipLaunchKernelGGL(k_st_diag_inv, dim3(nblk(Lc->n, 256)), dim3(256), 0, s, Lc->n, Lc->A.p, Lc->Dinv.p);
-      if (c->mg_fuse && c->mg_fuse_restrict)  // S = P^T A Dinv of the fine level: its first sweep, residual and restriction become one launch
-        hipLaunchKernelGGL(k_st_build_ra, dim3(nblk((long)Lc->n * 49, 256)), dim3(256), 0, s, MgGrid{Lf->N, Lf->M}, Lf->A.p, Lf->Dinv.p, Lf->S.p);
+      if (c->mg_fuse && c->mg_fuse_restrict) {  // S = P^T A Dinv of the fine level: its first sweep, residual and restriction become one launch
+        if (c->mg_st_f32) {  // both cycle kernels of the level read single-precision copies; S is formed from the ROUNDED A so that the pair stays adjoint up to the rounding of S
+          if (Lf->A32.n == 0 && (Lf->A32.alloc(Lf->A.n) | Lf->S32.alloc(Lf->S.n))) return tsl_fail("out of device memory (stencil f32 copies)");
+          hipLaunchKernelGGL(k_vals_to_f32, dim3(gsz(Lf->A.n)), dim3(256), 0, s, Lf->A.n, Lf->A.p, Lf->A32.p);
+          hipLaunchKernelGGL((k_st_build_ra<float>), dim3(nblk((long)Lc->n * 49, 256)), dim3(256), 0, s, MgGrid{Lf->N, Lf->M}, Lf->A32.p, Lf->Dinv.p, Lf->S32.p);
+        } else
+          hipLaunchKernelGGL((k_st_build_ra<double>), dim3(nblk((long)Lc->n * 49, 256)), dim3(256), 0, s, MgGrid{Lf->N, Lf->M}, Lf->A.p, Lf->Dinv.p, Lf->S.p);
+      }
     }
     MgLevel* Ll = mc->lv[mg_levels(c, mc) - 1];
     if (mg_level_dense(c, Ll) && !(c->mg_coarse_lag && c->mg_cinv_valid && Ll->Cinv.n > 0)) {  // dense inverse of the last level
@@ -793,11 +800,17 @@ static double* mg_stencil_cycle(tsl_ctx* c, MgCloth* mc, size_t l) {
   const bool fuse_down = c->mg_fuse && !last && c->mg_nu == 1;
   if (fuse_down && c->mg_fuse_restrict) {  // x = omega Dinv r and the coarse right-hand side in one launch (k_mg.hpp (1b))
     MgLevel* Lc = mc->lv[l + 1];
-    if (c->mg_fr_rows == 16) hipLaunchKernelGGL((k_st_first_restrict<16>), dim3(nblk(Lc->n, 16)), dim3(7 * 16), 0, s, g, L->S.p, L->Dinv.p, L->r.p, L->omega.p, xa, Lc->r.p);
-    else if (c->mg_fr_rows == 64) hipLaunchKernelGGL((k_st_first_restrict<64>), dim3(nblk(Lc->n, 64)), dim3(7 * 64), 0, s, g, L->S.p, L->Dinv.p, L->r.p, L->omega.p, xa, Lc->r.p);
-    else hipLaunchKernelGGL((k_st_first_restrict<32>), dim3(nblk(Lc->n, 32)), dim3(7 * 32), 0, s, g, L->S.p, L->Dinv.p, L->r.p, L->omega.p, xa, Lc->r.p);
+    if (c->mg_st_f32 && L->S32.n) {
+      hipLaunchKernelGGL((k_st_first_restrict<32, float>), dim3(nblk(Lc->n, 32)), dim3(7 * 32), 0, s, g, L->S32.p, L->Dinv.p, L->r.p, L->omega.p, xa, Lc->r.p);
+      const double* xc = mg_stencil_cycle(c, mc, l + 1);
+      hipLaunchKernelGGL((k_st_prolong_sweep<float>), dim3(gb5), dim3(320), 0, s, g, L->A32.p, xa, xc, xb, L->Dinv.p, L->r.p, L->omega.p);
+      return xb;
+    }
+    if (c->mg_fr_rows == 16) hipLaunchKernelGGL((k_st_first_restrict<16, double>), dim3(nblk(Lc->n, 16)), dim3(7 * 16), 0, s, g, L->S.p, L->Dinv.p, L->r.p, L->omega.p, xa, Lc->r.p);
+    else if (c->mg_fr_rows == 64) hipLaunchKernelGGL((k_st_first_restrict<64, double>), dim3(nblk(Lc->n, 64)), dim3(7 * 64), 0, s, g, L->S.p, L->Dinv.p, L->r.p, L->omega.p, xa, Lc->r.p);
+    else hipLaunchKernelGGL((k_st_first_restrict<32, double>), dim3(nblk(Lc->n, 32)), dim3(7 * 32), 0, s, g, L->S.p, L->Dinv.p, L->r.p, L->omega.p, xa, Lc->r.p);
     const double* xc = mg_stencil_cycle(c, mc, l + 1);
-    hipLaunchKernelGGL(k_st_prolong_sweep, dim3(gb5), dim3(320), 0, s, g, L->A.p, xa, xc, xb, L->Dinv.p, L->r.p, L->omega.p);
+    hipLaunchKernelGGL((k_st_prolong_sweep<double>), dim3(gb5), dim3(320), 0, s, g, L->A.p, xa, xc, xb, L->Dinv.p, L->r.p, L->omega.p);
     return xb;
   }
   if (fuse_down) hipLaunchKernelGGL(k_st_first_resid, dim3(gb5), dim3(320), 0, s, g, L->A.p, L->Dinv.p, L->r.p, L->omega.p, xa, L->t.p);
@@ -811,7 +824,7 @@ static double* mg_stencil_cycle(tsl_ctx* c, MgCloth* mc, size_t l) {
   hipLaunchKernelGGL(k_st_restrict, dim3(nblk(Lc->n, 256)), dim3(256), 0, s, g, L->r.p, L->t.p, Lc->r.p);
   const double* xc = mg_stencil_cycle(c, mc, l + 1);
   if (c->mg_fuse) {  // prolongation folded into the first post-sweep
-    hipLaunchKernelGGL(k_st_prolong_sweep, dim3(gb5), dim3(320), 0, s, g, L->A.p, xa, xc, xb, L->Dinv.p, L->r.p, L->omega.p);
+    hipLaunchKernelGGL((k_st_prolong_sweep<double>), dim3(gb5), dim3(320), 0, s, g, L->A.p, xa, xc, xb, L->Dinv.p, L->r.p, L->omega.p);
     std::swap(xa, xb);
     for (int k = 1; k < c->mg_nu; k++) sweep();
   } else {
@@ -889,7 +902,7 @@ static void launch_pcg_iteration(tsl_ctx* c, int parity, int first, unsigned lon
 // iteration is ~20 short kernels.  The first K1 of the chunk stamps
 // the device clock into a fixed buffer when profiling is on.
 static int pcg_chunk_graph(tsl_ctx* c, int chunk) {
-  const long key = ((long)(mg_active(c) ? 1 : 0) << 40) | ((long)c->nc << 8) | ((long)(c->prof_enable ? 1 : 0) << 7) | (long)chunk | ((long)c->mg_nu << 44) | ((long)c->mg_coarse_sweeps << 48) | ((long)(c->pc_separate ? 1 : 0) << 41) | ((long)((body_active(c) && c->bd_valid) ? 1 : 0) << 42) | ((long)(c->mg_fuse ? 1 : 0) << 43) | ((long)(c->mg_fuse_restrict ? 1 : 0) << 36) | ((long)(c->pcg_body_fold ? 1 : 0) << 37) | ((long)c->mg_max_levels << 52) | ((long)(c->mg_coarse_exact ? 1 : 0) << 39) | ((long)((c->mg_f32 && c->vals32_valid) ? 1 : 0) << 38) | ((long)(c->mg_dense_nodes & 0xfff) << 24);
+  const long key = ((long)(mg_active(c) ? 1 : 0) << 40) | ((long)c->nc << 8) | ((long)(c->prof_enable ? 1 : 0) << 7) | (long)chunk | ((long)c->mg_nu << 44) | ((long)c->mg_coarse_sweeps << 48) | ((long)(c->pc_separate ? 1 : 0) << 41) | ((long)((body_active(c) && c->bd_valid) ? 1 : 0) << 42) | ((long)(c->mg_fuse ? 1 : 0) << 43) | ((long)(c->mg_fuse_restrict ? 1 : 0) << 36) | ((long)(c->pcg_body_fold ? 1 : 0) << 37) | ((long)(c->mg_st_f32 ? 1 : 0) << 22) | ((long)c->mg_max_levels << 52) | ((long)(c->mg_coarse_exact ? 1 : 0) << 39) | ((long)((c->mg_f32 && c->vals32_valid) ? 1 : 0) << 38) | ((long)(c->mg_dense_nodes & 0xfff) << 24);
   if (c->pcg_graph && c->pcg_graph_key == key) return 0;
   if (c->pcg_graph) { (void)hipGraphExecDestroy(c->pcg_graph); c->pcg_graph = nullptr; }
   hipGraph_t g = nullptr;
@@ -1124,7 +1137,7 @@ static void launch_minres_iteration(tsl_ctx* c, const MrBufs& B, int j) {
 
 static long solver_graph_key(tsl_ctx* c) {
   return ((long)(mg_active(c) ? 1 : 0) << 40) | ((long)c->nc << 8) | ((long)(c->prof_enable ? 1 : 0) << 7) | ((long)c->mg_nu << 44) | ((long)c->mg_coarse_sweeps << 48) |
-         ((long)(c->pc_separate ? 1 : 0) << 41) | ((long)((body_active(c) && c->bd_valid) ? 1 : 0) << 42) | ((long)(c->mg_fuse ? 1 : 0) << 43) | ((long)(c->mg_fuse_restrict ? 1 : 0) << 36) | ((long)(c->pcg_body_fold ? 1 : 0) << 37) | ((long)c->mg_max_levels << 52) | ((long)(c->mg_coarse_exact ? 1 : 0) << 39) | ((long)((c->mg_f32 && c->vals32_valid) ? 1 : 0) << 38) | ((long)(c->mg_dense_nodes & 0xfff) << 24);
+         ((long)(c->pc_separate ? 1 : 0) << 41) | ((long)((body_active(c) && c->bd_valid) ? 1 : 0) << 42) | ((long)(c->mg_fuse ? 1 : 0) << 43) | ((long)(c->mg_fuse_restrict ? 1 : 0) << 36) | ((long)(c->pcg_body_fold ? 1 : 0) << 37) | ((long)(c->mg_st_f32 ? 1 : 0) << 22) | ((long)c->mg_max_levels << 52) | ((long)(c->mg_coarse_exact ? 1 : 0) << 39) | ((long)((c->mg_f32 && c->vals32_valid) ? 1 : 0) << 38) | ((long)(c->mg_dense_nodes & 0xfff) << 24);
 }
 
 static int minres_graph(tsl_ctx* c, const MrBufs& B) {
