@@ -333,6 +333,7 @@ extern "C" int tsl_set_param(tsl_ctx* c, const char* key, double v) {
   else if (k == "mg_fuse") c->mg_fuse = (int)v;
   else if (k == "pcg_body_fold") c->pcg_body_fold = (int)v;
   else if (k == "asm_overlap") c->asm_overlap = (int)v;
+  else if (k == "mr_eta") c->mr_eta = v;
   else if (k == "mg_st_f32") { c->mg_st_f32 = (int)v; c->mg_ops_valid = false; }
   else if (k == "mg_fr_rows") { c->mg_fr_rows = (int)v; if (c->pcg_graph) { (void)hipGraphExecDestroy(c->pcg_graph); c->pcg_graph = nullptr; } if (c->mr_graph) { (void)hipGraphExecDestroy(c->mr_graph); c->mr_graph = nullptr; } }
   else if (k == "mg_fuse_restrict") { c->mg_fuse_restrict = (int)v; c->mg_ops_valid = false; }
@@ -1213,7 +1214,7 @@ static int minres(tsl_ctx* c, tsl_solve_stats* st) {
     MrScal hs;
     memset(&hs, 0, sizeof(hs));
     hs.gamma = sqrt(g2); hs.gamma_prev = 1.0; hs.eta = hs.gamma; hs.c_prev = 1.0; hs.c_cur = 1.0;
-    hs.thresh_eta = 0.3 * (tol / rnorm0) * hs.gamma;  // |eta| is the residual in the M^-1 norm, scaled by the start of the cycle
+    hs.thresh_eta = c->mr_eta * (tol / rnorm0) * hs.gamma;  // |eta| is the residual in the M^-1 norm, scaled by the start of the cycle
     HIP_OK(hipMemcpyAsync(d, &hs, sizeof(MrScal), hipMemcpyHostToDevice, s));
     HIP_OK(hipMemsetAsync(B.V[0], 0, n3 * sizeof(double), s));
     HIP_OK(hipMemsetAsync(B.W[0], 0, n3 * sizeof(double), s));
@@ -1231,6 +1232,7 @@ static int minres(tsl_ctx* c, tsl_solve_stats* st) {
       if (flag) break;
     }
     st->iters += h->iters;
+    if (c->verbose) fprintf(stderr, "[tsl] MINRES cycle %d: %d iterations from true residual %.3e (tol %.3e), recurrence |eta| %.3e\n", cycle, h->iters, rnorm0, tol, fabs(h->eta));
     // true residual into V[1]
     launch_spmv(c, c->vals.p, x, B.V[2], -1, 0);
     HIP_OK(hipMemcpyAsync(B.V[1], c->v_b.p, n3 * sizeof(double), hipMemcpyDeviceToDevice, s));
