@@ -226,7 +226,8 @@ TSL_DEV void body_apply_block(const BodyDenseArgs& A, const float* __restrict__ 
 // body workgroups never read r: they keep a compact ping-pong copy rb of the residual on the body rows, rebuilt here as
 // rb_new = rb_old - alpha Ap (bitwise the values the vertex part writes), or as b - Ax when the solve (re)starts.
 // start mode (b_init != null): only rb_new is written (the cycle of a start runs its own first sweep).
-TSL_DEV void body_update_block(const BodyDenseArgs& A, const float* __restrict__ Binv, double alpha, const double* __restrict__ Ap, const double* __restrict__ rb_old,
+template <class AlphaFn>
+TSL_DEV void body_update_block(const BodyDenseArgs& A, const float* __restrict__ Binv, AlphaFn alpha_fn, const double* __restrict__ Ap, const double* __restrict__ rb_old,
                                double* __restrict__ rb_new, const double* __restrict__ b_init, const double* __restrict__ Ax_init, double* __restrict__ z, int bid,
                                double* v /* LDS, 3 * 512 + 4 */) {
   int b = 0;
@@ -266,13 +267,25 @@ TSL_DEV void body_update_block(const BodyDenseArgs& A, const float* __restrict__
       if (live1) g1 = 3 * (size_t)rows[i1 / 3] + i1 % 3;
     }
   }
-  for (int i = threadIdx.x; i < ld; i += 256) {
-    double x = 0.0;
+  // the old residual and A p of the body rows are requested before alpha is known (alpha_fn reduces the p.Ap partials: one more
+  // memory round trip and two barriers that these loads and the matrix rows above now overlap)
+  constexpr int MAXV = (3 * 512 + 4 + 255) / 256;
+  double rbv[MAXV], apv[MAXV];
+#pragma unroll
+  for (int u = 0; u < MAXV; u++) {
+    const int i = (int)threadIdx.x + 256 * u;
+    rbv[u] = 0.0; apv[u] = 0.0;
     if (i < n3) {
       const size_t g = 3 * (size_t)rows[i / 3] + i % 3;
-      x = rb_old[so + i] - alpha * Ap[g];
+      rbv[u] = rb_old[so + i]; apv[u] = Ap[g];
     }
-    v[i] = x;
+  }
+  const double alpha = alpha_fn();  // NaN: the solve has stopped (uniform over the workgroup)
+  if (alpha != alpha) return;
+#pragma unroll
+  for (int u = 0; u < MAXV; u++) {
+    const int i = (int)threadIdx.x + 256 * u;
+    if (i < ld) v[i] = rbv[u] - alpha * apv[u];
   }
   __syncthreads();
   if (live) {

@@ -416,14 +416,15 @@ k_pcg_update(int NV, const double* __restrict__ pv, const double* __restrict__ A
     __shared__ double vb[3 * 512 + 4];
     double* rb_new = rb + (size_t)(b_init ? parity ^ 1 : parity) * rb_n;
     const double* rb_old = rb + (size_t)(parity ^ 1) * rb_n;
-    if (!b_init) {
-      if (sc->flag) return;
+    auto alpha_fn = [&]() -> double {
+      const double nan = __longlong_as_double(0x7ff8000000000000LL);
+      if (sc->flag) return nan;
       const double pAp = block_reduce_partials(part_pAp, sc->n_part1, sm);
       const double rz = sc->rzh[parity];
-      if (!(pAp > 0.0) || !(rz > 0.0)) return;
-      alpha = rz / pAp;
-    }
-    body_update_block(BD, Binv, alpha, Ap, rb_old, rb_new, b_init, Ax_init, z, (int)blockIdx.x - gb, vb);
+      if (!(pAp > 0.0) || !(rz > 0.0)) return nan;
+      return rz / pAp;
+    };
+    body_update_block(BD, Binv, alpha_fn, Ap, rb_old, rb_new, b_init, Ax_init, z, (int)blockIdx.x - gb, vb);
     return;
   }
   const int p = blockIdx.x * blockDim.x + threadIdx.x;
