@@ -588,3 +588,14 @@ def test_cmaes_driver_runs_forward_only(tmp_path, monkeypatch):
     assert os.path.exists(os.path.join(out["save_path"], "plot_Data.npy")) and os.path.exists(os.path.join(out["save_path"], "traj_1.npy"))
     tr = np.load(os.path.join(out["save_path"], "traj_1.npy"))
     assert tr.shape[0] == 4 and tr.shape[2] == 6 and np.abs(tr[0]).max() == 0.0
+
+
+def test_cmaes_parameter_driver(tmp_path, monkeypatch):
+    """training/run_cmaes_parameter (reference run_cmaes_parameter.py): CMA-ES over the bending stiffness offset of the bouncing scene,
+    forward rollouts only; one generation of three candidates."""
+    monkeypatch.setenv("TSL_OUT", str(tmp_path))
+    from thinshelllab_amd.training import run_cmaes_parameter
+    out = run_cmaes_parameter.main(["--env", "bouncing", "--tot_step", "3", "--pop_size", "3", "--iter", "1", "--sigma", "0.2", "--Kb", "100", "--mu", "0.5", "--seed", "2"])
+    h = np.array(out["history"])
+    assert h.shape == (3,) and np.isfinite(h).all() and out["fbest"] == h.min() and len(out["xbest"]) == 2
+    assert os.path.exists(os.path.join(out["save_path"], "plot_Data.npy"))
