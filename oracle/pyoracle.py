@@ -5,10 +5,12 @@ ThinShellLab engine (reference: /root/reference/code/engine, see the .cpp files 
 citations).  Only ``tests/``, ``__graft_entry__.smoke()`` and ``bench.py``'s ``cpu_baseline`` leg
 may import this module; the product package ``thinshelllab_amd`` never does.
 
-Parity status: **unpinned** by the reference (it ships no tests / golden vectors and cannot be
-imported here: taichi + cupy are absent).  The restatement is pinned instead by independent
-checks in tests/test_oracle_*.py (finite differences, numpy eigh, scipy spsolve, mesh facts from
-SURVEY.md App. A/C).
+Parity status: the reference ships no tests / golden vectors and cannot be imported here (taichi +
+cupy are absent).  Pinned by REFERENCE OUTPUT (its saved state data/balance_state): pad placement, gripper
+frames, vertex layout, contact-candidate flags of projection_query (tests/test_oracle_pinning.py::
+test_reference_state_*).  Energies, derivatives, solver and adjoint remain **unpinned** by the reference
+and are pinned by independent checks in tests/test_oracle_*.py (finite differences, numpy eigh, scipy
+spsolve, mesh facts from SURVEY.md App. A/C).
 """
 import ctypes as C
 import os

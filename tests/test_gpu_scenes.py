@@ -599,3 +599,34 @@ def test_cmaes_parameter_driver(tmp_path, monkeypatch):
     h = np.array(out["history"])
     assert h.shape == (3,) and np.isfinite(h).all() and out["fbest"] == h.min() and len(out["xbest"]) == 2
     assert os.path.exists(os.path.join(out["save_path"], "plot_Data.npy"))
+
+
+def test_reference_state_projection_query_on_gpu():
+    """REFERENCE OUTPUT through the C ABI: the reference's saved balancing state (tests/golden/balance_state, written by
+    Scene_balancing.save_all of the reference engine) with the flags its projection_query left (geometry.py:96-229).  The HIP broad /
+    narrow phase on the saved positions reproduces the flags of the five FEM bodies exactly and proj_dir on every vertex flagged in
+    both; on the cloth body a handful of entries differ (the flags belong to the start of the reference's last step, the positions
+    to its end) -- the same entries as in the CPU restatement (tests/test_oracle_pinning.py)."""
+    from thinshelllab_amd.task_scene.Scene_balancing import Scene
+    from thinshelllab_amd.engine.geometry import projection_query
+    g = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "balance_state")
+    s = Scene(cloth_size=0.06)
+    s.init_all()
+    s.load_state(os.path.join(g, "state"))
+    s.prev_pos.copy_from(s.pos)
+    ctx = s._ensure_ctx()
+    ctx.contact_reset()
+    projection_query(s)
+    flag, dr, _, _ = ctx.proj_export()
+    F = np.load(os.path.join(g, "proj_flag.npy")); D = np.load(os.path.join(g, "proj_dir.npy"))
+    assert flag.shape == F.shape == (6, 1332)
+    assert np.array_equal(flag[1:], F[1:]) and flag[1:].sum(1).tolist() == [14, 151, 159, 153, 155]
+    assert (flag[0] != F[0]).sum() <= 20
+    both = (flag == 1) & (F == 1)
+    assert both.sum() >= 1600 and np.array_equal(dr[both], D[both])
+    # load_all restores the reference's latched flags for a continued rollout
+    s.load_all(g)
+    f2, d2, _, _ = s._ensure_ctx().proj_export()
+    assert np.array_equal(f2, F) and np.array_equal(d2, D)
+    st = s.time_step(projection_query, 1)
+    assert np.isfinite(s.pos.to_numpy()).all() and st["nc"] > 0
