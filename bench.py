@@ -208,6 +208,8 @@ def main():
     # HIP-event timing of the dominant kernel: 500 back-to-back launches of k_pcg_spmv on the run's last matrix and contact set,
     # one hipEvent pair on the library's stream (after the timed region: a pair around every launch inside it would time the events)
     k1_us = ctx.bench_spmv(20, 500)
+    # yardstick, not a target: a kernel that only streams the matrix values once (no column-id -> vector gather chain, no reduction)
+    stream_us = ctx.bench_spmv(30, 500)
 
     T = 2 * args.grid * args.grid
     value = T * K * world / elapsed
@@ -245,6 +247,9 @@ def main():
                            "kernel": "k_pcg_spmv (SELL-64 3x3-block SpMV fused with the PCG direction update and p.Ap, one launch per PCG iteration)",
                            "bytes_per_launch": prof["bytes_per_launch"], "avg_launch_us": k1_us,
                            "avg_launch_us_device_clock": prof["ms_per_launch"] * 1e3,
+                           "streaming_read_yardstick": {"bytes": (prof["bytes_per_launch"] - 48 * scene.tot_NV) // 76 * 72, "avg_launch_us": stream_us,
+                                                        "GB/s": (prof["bytes_per_launch"] - 48 * scene.tot_NV) // 76 * 72 / (stream_us * 1e-6) / 1e9 if stream_us > 0 else None,
+                                                        "what": "k_stream_read over the matrix values only (the 72 of 76 B per block that k_pcg_spmv streams), same back-to-back HIP-event timing"},
                            "avg_launch_us_single_event_pairs": prof["ms_per_launch_events"] * 1e3, "launches": prof["launches"],
                            "timing": "avg_launch_us (what `achieved` is priced on) = HIP events on the library's stream around 500 back-to-back launches "
                                      "of the kernel on the run's last matrix / contact set, divided by 500 (includes the gap between dependent "

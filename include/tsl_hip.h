@@ -180,7 +180,8 @@ int tsl_profile_read(tsl_ctx* ctx, double* spmv_ms_host, int64_t* spmv_launches_
 int tsl_profile_read_events(tsl_ctx* ctx, double* spmv_ms_hip_events_host); /* same launches bracketed by hipEvents (includes launch gaps) */
 /* `reps` back-to-back launches of one operator kernel on the currently assembled matrix (and the current step's contact rows),
  * bracketed by ONE hipEvent pair on the engine stream: average microseconds per launch.  variant 20 = k_pcg_spmv exactly as a
- * PCG iteration launches it (what bench.py's roofline object is priced on), 2 = the plain SELL-64 product k_spmv_mw. */
+ * PCG iteration launches it (what bench.py's roofline object is priced on), 2 = the plain SELL-64 product k_spmv_mw,
+ * 30 = k_stream_read over the matrix values only (streaming-read yardstick for the same bytes). */
 int tsl_bench_spmv(tsl_ctx* ctx, int variant, int reps, double* us_per_launch_host);
 
 #ifdef __cplusplus

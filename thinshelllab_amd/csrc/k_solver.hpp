@@ -208,6 +208,24 @@ __global__ void k_vals_to_f32(size_t n, const double* __restrict__ src, float* _
   for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x) dst[i] = (float)src[i];
 }
 
+// Streaming-read yardstick for bench.py: reads n 16-byte words once (grid-stride, 4 independent loads in flight per lane) and leaves
+// one partial per block -- what a kernel with NO index chain, gather or reduction needs for the bytes k_pcg_spmv reads.
+__global__ void __launch_bounds__(256) k_stream_read(const double2* __restrict__ p, size_t n, double* __restrict__ part) {
+  double a0 = 0, a1 = 0, a2 = 0, a3 = 0;
+  const size_t stride = (size_t)gridDim.x * blockDim.x;
+  size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  for (; i + 3 * stride < n; i += 4 * stride) {
+    const double2 v0 = p[i], v1 = p[i + stride], v2 = p[i + 2 * stride], v3 = p[i + 3 * stride];
+    a0 += v0.x + v0.y; a1 += v1.x + v1.y; a2 += v2.x + v2.y; a3 += v3.x + v3.y;
+  }
+  for (; i < n; i += stride) { const double2 v = p[i]; a0 += v.x + v.y; }
+  double a = wave_sum((a0 + a1) + (a2 + a3));
+  __shared__ double sm[4];
+  if ((threadIdx.x & 63) == 0) sm[threadIdx.x >> 6] = a;
+  __syncthreads();
+  if (threadIdx.x == 0) part[blockIdx.x] = sm[0] + sm[1] + sm[2] + sm[3];
+}
+
 // Variant with WPS waves per slice: wave w of a slice handles block columns k = w, w+WPS, ... (more loads in flight per
 // row: 784 single-wave slices cannot fill 1024 SIMDs at 100k triangles), partial row sums are combined through LDS.
 // NT: matrix values / column ids are streamed with non-temporal loads so that they do not evict the x vector from L2.

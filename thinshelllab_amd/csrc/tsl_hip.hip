@@ -854,7 +854,7 @@ static void mg_vcycle(tsl_ctx* c, const double* r, double* z, double* part_rz, b
   mg_spmv0(c, z, t);
   for (MgCloth* mc : c->mg) {
     MgLevel* L1 = mc->lv[0];
-    hipLaunchKernelGGL(k_mg_restrict0, dim3(nblk(L1->n, 256)), dim3(256), 0, s, MgGrid{mc->N0, mc->M0}, mc->v_offset, c->rowpos.p, r, t, L1->r.p);
+    hipLaunchKernelGGL(k_mg_restrict0, dim3(nblk(L1->n, 64)), dim3(64), 0, s, MgGrid{mc->N0, mc->M0}, mc->v_offset, c->rowpos.p, r, t, L1->r.p);
     const double* x1 = mg_stencil_cycle(c, mc, 0);
     hipLaunchKernelGGL(k_mg_prolong0_add, dim3(nblk((mc->N0 + 1) * (mc->M0 + 1), 256)), dim3(256), 0, s, MgGrid{mc->N0, mc->M0}, mc->v_offset, c->rowpos.p, x1, z);
   }
@@ -1734,6 +1734,7 @@ extern "C" int tsl_bench_spmv(tsl_ctx* c, int variant, int reps, double* us_per_
   const int ns = c->n_slices;
   if (c->v_t4.n < (size_t)ns) return tsl_fail("scratch too small");
   int k1_count = 0;
+  const int variant30_grid = std::min<long>(std::max<long>((long)c->v_t4.n, 1), 2048);
   auto launch = [&]() {
     switch (variant) {
       case 0: hipLaunchKernelGGL(k_spmv, dim3(nblk((long)ns * 64, 256)), dim3(256), 0, s, c->NV, ns, c->slice_off.p, c->slice_len.p, c->colidx.p, c->vals.p, c->v_p.p, c->v_Ap.p, SC(c), 0, 0, (unsigned long long*)nullptr); break;
@@ -1753,6 +1754,11 @@ extern "C" int tsl_bench_spmv(tsl_ctx* c, int variant, int reps, double* us_per_
       } break;
       case 13: hipLaunchKernelGGL(k_cg_update, dim3(nblk(c->NV, 256)), dim3(256), 0, s, c->NV, c->v_p.p, c->v_Ap.p, c->Dinv.p, c->v_x.p, c->v_r.p, c->v_z.p, SC(c), 0); break;
       case 14: hipLaunchKernelGGL(k_cg_p, dim3(nblk(c->NV, 256)), dim3(256), 0, s, c->NV, c->v_z.p, c->v_p.p, SC(c), 0, 0); break;
+      case 30: {  // streaming read of the matrix values + column ids (the bytes K1 streams), no index chain / gather / reduction
+        const size_t nw = c->vals.n / 2;
+        const int grid = variant30_grid;
+        hipLaunchKernelGGL(k_stream_read, dim3(grid), dim3(256), 0, s, (const double2*)c->vals.p, nw, c->v_t4.p);
+      } break;
       case 20: {  // the PCG operator kernel exactly as an iteration launches it (recurrence form, contact rows of the current step)
         const int par = (k1_count++) & 1;
         hipLaunchKernelGGL((k_pcg_spmv<PCG_WPS, TSL_NT>), dim3(ns), dim3(64 * PCG_WPS), 0, s, c->NV, ns, c->slice_off.p, c->slice_len.p, c->colidx.p, c->vals.p, c->v_z.p,
