@@ -164,44 +164,64 @@ k_spmv(int NV, int n_slices, const int* __restrict__ slice_off, const int* __res
 // Columns past the end of the slice repeat a valid one with weight 0 (cached reloads, no branches).  NVEC = 2 also accumulates
 // the product with a second vector (q).
 #define SELL_U 4
+// one phased trip over U block columns k0, k0 + WPS, ... of the wave
+template <int U, int NVEC, int WPS, bool NT, typename VT>
+TSL_DEV void sell_wave_trip(const int* __restrict__ cp, const VT* __restrict__ vp, int len, int k0, const double* __restrict__ x, const double* __restrict__ x2,
+                            double& y0, double& y1, double& y2, double& q0, double& q1, double& q2) {
+  int kk[U], c[U];
+  double m[U];
+#pragma unroll
+  for (int u = 0; u < U; u++) {
+    const int k = k0 + u * WPS;
+    kk[u] = k < len ? k : k0;
+    m[u] = k < len ? 1.0 : 0.0;
+    c[u] = NT ? __builtin_nontemporal_load(cp + 64 * kk[u]) : cp[64 * kk[u]];
+  }
+  double a[U][9];
+#pragma unroll
+  for (int u = 0; u < U; u++) {
+    const VT* ap = vp + (size_t)kk[u] * 576;
+#pragma unroll
+    for (int e = 0; e < 9; e++) a[u][e] = (double)(NT ? __builtin_nontemporal_load(ap + 64 * e) : ap[64 * e]);
+  }
+  d3 xj[U], wj[U];
+#pragma unroll
+  for (int u = 0; u < U; u++) {
+    xj[u] = ld3(x, c[u]);
+    if (NVEC == 2) wj[u] = ld3(x2, c[u]);
+  }
+#pragma unroll
+  for (int u = 0; u < U; u++) {
+    y0 += m[u] * (a[u][0] * xj[u].x + a[u][1] * xj[u].y + a[u][2] * xj[u].z);
+    y1 += m[u] * (a[u][3] * xj[u].x + a[u][4] * xj[u].y + a[u][5] * xj[u].z);
+    y2 += m[u] * (a[u][6] * xj[u].x + a[u][7] * xj[u].y + a[u][8] * xj[u].z);
+    if (NVEC == 2) {
+      q0 += m[u] * (a[u][0] * wj[u].x + a[u][1] * wj[u].y + a[u][2] * wj[u].z);
+      q1 += m[u] * (a[u][3] * wj[u].x + a[u][4] * wj[u].y + a[u][5] * wj[u].z);
+      q2 += m[u] * (a[u][6] * wj[u].x + a[u][7] * wj[u].y + a[u][8] * wj[u].z);
+    }
+  }
+}
+// The interior cloth rows have 17 blocks: with four waves per slice wave 0 owns five of them, and a second trip for the fifth would
+// put a whole extra index -> value -> gather chain behind the first (the other three waves idle meanwhile).  A wave with exactly
+// five columns takes them in one trip; longer rows (FEM bodies) loop over trips of four.
 template <int NVEC, int WPS, bool NT, typename VT = double>
 TSL_DEV void sell_wave_product(const int* __restrict__ cp, const VT* __restrict__ vp, int len, int w, const double* __restrict__ x, const double* __restrict__ x2,
                                double& y0, double& y1, double& y2, double& q0, double& q1, double& q2) {
-  for (int k0 = w; k0 < len; k0 += SELL_U * WPS) {
-    int kk[SELL_U], c[SELL_U];
-    double m[SELL_U];
-#pragma unroll
-    for (int u = 0; u < SELL_U; u++) {
-      const int k = k0 + u * WPS;
-      kk[u] = k < len ? k : k0;
-      m[u] = k < len ? 1.0 : 0.0;
-      c[u] = NT ? __builtin_nontemporal_load(cp + 64 * kk[u]) : cp[64 * kk[u]];
-    }
-    double a[SELL_U][9];
-#pragma unroll
-    for (int u = 0; u < SELL_U; u++) {
-      const VT* ap = vp + (size_t)kk[u] * 576;
-#pragma unroll
-      for (int e = 0; e < 9; e++) a[u][e] = (double)(NT ? __builtin_nontemporal_load(ap + 64 * e) : ap[64 * e]);
-    }
-    d3 xj[SELL_U], wj[SELL_U];
-#pragma unroll
-    for (int u = 0; u < SELL_U; u++) {
-      xj[u] = ld3(x, c[u]);
-      if (NVEC == 2) wj[u] = ld3(x2, c[u]);
-    }
-#pragma unroll
-    for (int u = 0; u < SELL_U; u++) {
-      y0 += m[u] * (a[u][0] * xj[u].x + a[u][1] * xj[u].y + a[u][2] * xj[u].z);
-      y1 += m[u] * (a[u][3] * xj[u].x + a[u][4] * xj[u].y + a[u][5] * xj[u].z);
-      y2 += m[u] * (a[u][6] * xj[u].x + a[u][7] * xj[u].y + a[u][8] * xj[u].z);
-      if (NVEC == 2) {
-        q0 += m[u] * (a[u][0] * wj[u].x + a[u][1] * wj[u].y + a[u][2] * wj[u].z);
-        q1 += m[u] * (a[u][3] * wj[u].x + a[u][4] * wj[u].y + a[u][5] * wj[u].z);
-        q2 += m[u] * (a[u][6] * wj[u].x + a[u][7] * wj[u].y + a[u][8] * wj[u].z);
-      }
-    }
+  const int nk = (len - w + WPS - 1) / WPS;   // columns of this wave (wave-uniform)
+  if (nk == SELL_U + 1) {
+    sell_wave_trip<SELL_U + 1, NVEC, WPS, NT, VT>(cp, vp, len, w, x, x2, y0, y1, y2, q0, q1, q2);
+    return;
   }
+  if (nk == 2) {  // the nine-block rows of the cloth: no masked repeats of the first column (cached, but they occupy the load path)
+    sell_wave_trip<2, NVEC, WPS, NT, VT>(cp, vp, len, w, x, x2, y0, y1, y2, q0, q1, q2);
+    return;
+  }
+  if (nk == 3) {
+    sell_wave_trip<3, NVEC, WPS, NT, VT>(cp, vp, len, w, x, x2, y0, y1, y2, q0, q1, q2);
+    return;
+  }
+  for (int k0 = w; k0 < len; k0 += SELL_U * WPS) sell_wave_trip<SELL_U, NVEC, WPS, NT, VT>(cp, vp, len, k0, x, x2, y0, y1, y2, q0, q1, q2);
 }
 
 __global__ void k_vals_to_f32(size_t n, const double* __restrict__ src, float* __restrict__ dst) {
@@ -342,7 +362,8 @@ k_pcg_spmv(int NV, int n_slices, const int* __restrict__ slice_off, const int* _
   __shared__ double red[WPS][3][64];
   __shared__ double s2[2][WPS];
   __shared__ double cacc[3][64];
-  if (sc->flag) return;
+  // the stop flag is only acted on after the matrix loop: a branch on it here would put one more memory round trip in front of every load
+  const int stop = sc->flag;
   int ce0 = 0, ce1 = 0;
   if (CR.ptr) {
     ce0 = CR.ptr[blockIdx.x * 64]; ce1 = CR.ptr[min((int)blockIdx.x * 64 + 64, NV)];
@@ -351,10 +372,18 @@ k_pcg_spmv(int NV, int n_slices, const int* __restrict__ slice_off, const int* _
   unsigned long long t_start = 0;
   if (prof) t_start = wall_clock64();
   // partial sums of r.z and r.r: loads issued now, consumed after the matrix loop
-  double v0 = 0, v1 = 0;
+  // (held in registers un-added: an in-order wave would wait for them at the first addition, i.e. before the matrix loads go out)
+  constexpr int MAXU = PCG_MAXPART / (64 * WPS);
+  double pz[MAXU], pr[MAXU];
   {
-    const int n = sc->n_part2;
-    for (int i = threadIdx.x; i < n; i += blockDim.x) { v0 += part_rz[i]; v1 += part_rr[i]; }
+    const int n = sc->n_part2;   // <= PCG_MAXPART (solve_perm)
+#pragma unroll
+    for (int u = 0; u < MAXU; u++) {
+      const int i = (int)threadIdx.x + 64 * WPS * u;
+      pz[u] = i < n ? part_rz[i] : 0.0;
+      pr[u] = i < n ? part_rr[i] : 0.0;
+    }
+    for (int i = (int)threadIdx.x + 64 * WPS * MAXU; i < n; i += 64 * WPS) { pz[0] += part_rz[i]; pr[0] += part_rr[i]; }  // more than PCG_MAXPART partials (> 200k vertices)
   }
   const double rz_old = first ? 1.0 : sc->rzh[parity ^ 1];
   const double thresh2 = sc->thresh2;
@@ -372,7 +401,11 @@ k_pcg_spmv(int NV, int n_slices, const int* __restrict__ slice_off, const int* _
   const double* vp = vals + (size_t)off * 9 + lane;
   double y0 = 0, y1 = 0, y2 = 0, u0 = 0, u1 = 0, u2 = 0;
   sell_wave_product<1, WPS, NT>(cp, vp, len, w, z, nullptr, y0, y1, y2, u0, u1, u2);
+  if (stop) return;  // uniform over the grid; nothing has been written yet
   // finish the two reductions (one LDS round trip shared with the wave partials of the product)
+  double v0 = 0, v1 = 0;
+#pragma unroll
+  for (int u = 0; u < MAXU; u++) { v0 += pz[u]; v1 += pr[u]; }
   v0 = wave_sum(v0); v1 = wave_sum(v1);
   if (lane == 0) { s2[0][w] = v0; s2[1][w] = v1; }
   if (WPS > 1 && w > 0) { red[w][0][lane] = y0; red[w][1][lane] = y1; red[w][2][lane] = y2; }
