@@ -618,12 +618,15 @@ k_post_smooth(BodyDenseArgs B, const float* __restrict__ Binv, int gb, int n, co
   if (p < n) {
     m3 D;
     bool any = false;
+    // all operands are requested together with the block (the test on the block would put their round trip behind its own)
+    const d3 xo = ld3(x, p), ro = ld3(r, p), to = ld3(t, p);
+    const d3 rd = rdot ? ld3(rdot, p) : d3();
 #pragma unroll
     for (int e = 0; e < 9; e++) { D.m[e] = Dinv[9 * (size_t)p + e]; any = any || D.m[e] != 0.0; }
     if (any) {
-      const d3 xn = ld3(x, p) + omega * m3_mulv(D, ld3(r, p) - ld3(t, p));
+      const d3 xn = xo + omega * m3_mulv(D, ro - to);
       st3(x, p, xn);
-      if (rdot) acc = dot(ld3(rdot, p), xn);
+      if (rdot) acc = dot(rd, xn);
     }
   }
   if (part) {

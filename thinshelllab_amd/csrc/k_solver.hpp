@@ -213,6 +213,10 @@ TSL_DEV void sell_wave_product(const int* __restrict__ cp, const VT* __restrict_
     sell_wave_trip<SELL_U + 1, NVEC, WPS, NT, VT>(cp, vp, len, w, x, x2, y0, y1, y2, q0, q1, q2);
     return;
   }
+  if (nk == 1) {
+    sell_wave_trip<1, NVEC, WPS, NT, VT>(cp, vp, len, w, x, x2, y0, y1, y2, q0, q1, q2);
+    return;
+  }
   if (nk == 2) {  // the nine-block rows of the cloth: no masked repeats of the first column (cached, but they occupy the load path)
     sell_wave_trip<2, NVEC, WPS, NT, VT>(cp, vp, len, w, x, x2, y0, y1, y2, q0, q1, q2);
     return;
@@ -298,8 +302,10 @@ k_spmv_mw(int NV, int n_slices, const int* __restrict__ slice_off, const int* __
     const int p = slice * 64 + lane;
     if (p < NV) {
       st3(y, p, d3(y0, y1, y2));
-      const d3 xi = ld3(x, p);
-      acc = xi.x * y0 + xi.y * y1 + xi.z * y2;
+      if (part) {  // the own-row gather is a dependent load at the tail of the kernel: only when the dot product is wanted
+        const d3 xi = ld3(x, p);
+        acc = xi.x * y0 + xi.y * y1 + xi.z * y2;
+      }
     }
   }
   if (part) {
