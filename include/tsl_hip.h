@@ -100,7 +100,7 @@ int tsl_set_stream(tsl_ctx* ctx, void* hip_stream);
  * "mg_dense_nodes" (largest level solved exactly; -1 = chosen per time step, default), "mg_coarse_lag", "warm_start", "pcg_ahead", "body_inv"
  * "mg_fuse_restrict" (first sweep + residual + restriction of a stencil level in one launch), "mg_st_f32" (single-precision stencil
  * operators), "mg_fr_rows", "pcg_body_fold" (dense-body first sweep inside the PCG update launch), "asm_overlap" (contact blocks on a
- * second stream), "mr_eta" (stop factor of a MINRES recurrence cycle),
+ * second stream), "mr_eta" (stop factor of a MINRES recurrence cycle), "mg_chunk" (multigrid-PCG iterations per graph replay; 0 = 8 on long solves, else 4),
  * (-1 auto / 0 / 1), "adj_spd_pc", "fwd_spd_pc", "minres", "gmres", "gmres_m", "graph", "verbose"; "adj_clamp", "adj_clamp_angleref" select the clamping of analytic_grad_single (1000, on) or
  * analytic_grad_system (1, off). */
 int tsl_set_param(tsl_ctx* ctx, const char* key, double value);

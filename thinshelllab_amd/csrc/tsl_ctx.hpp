@@ -163,6 +163,7 @@ struct tsl_ctx {
   DevBuf<double> bd_rb;  // compact ping-pong copy of the PCG residual on the dense-body rows (body part of k_pcg_update)
   int pcg_body_fold = 1;
   int mg_st_f32 = 1;
+  int mg_chunk = 0;      // multigrid-PCG iterations per hipGraph replay / host convergence read (0: 8 on long solves, else 4)
   double mr_eta = 0.3;   // MINRES stops a recurrence cycle at |eta| <= mr_eta * tol (scaled); the true residual decides afterwards
   int mg_fr_rows = 32;   // coarse nodes per workgroup of k_st_first_restrict (16 / 32 / 64)
   DevBuf<float> bd_Binv;
