@@ -76,11 +76,19 @@ typedef struct {
 typedef struct {
   int32_t newton_iters, ls_evals, cg_iters, solves, restarts, fallback, nc;
   double last_delta, last_alpha, energy;
+  /* convergence accounting of the step's linear solves (the reference's spsolve is exact every time, sparse_solver.py:85-105):
+   * fallback = solves that needed a second solver and converged there (flag 1); unconverged = solves that ended with flag 3;
+   * attained = solves accepted by the attainable-accuracy rule (true residual stagnating within 100x of cg_tol);
+   * factorizations = numeric factorisations of the direct preconditioner; max_rel_residual over the step's solves */
+  int32_t unconverged, attained, factorizations, plans;
+  double max_rel_residual;
 } tsl_step_stats;
 
 typedef struct {
-  int32_t iters, restarts, flag; /* flag 0 converged PCG, 1 BiCGStab fallback, 3 not converged */
-  double rel_residual;
+  int32_t iters, restarts, flag; /* flag 0 converged with the primary solver, 1 converged with a fallback solver, 3 NOT converged */
+  double rel_residual;           /* true residual |b - Hx| / |b| of the returned solution */
+  int32_t method;                /* solver that produced x: 0 PCG, 1 MINRES, 2 GMRES, 3 BiCGStab, 4 sparse LU + GMRES refinement */
+  int32_t attained;              /* 1: accepted by the attainable-accuracy rule instead of rel_residual <= cg_tol */
 } tsl_solve_stats;
 
 const char* tsl_version(void);
@@ -98,6 +106,8 @@ int tsl_set_stream(tsl_ctx* ctx, void* hip_stream);
  * calls a direct solver): "cg_tol", "cg_maxit", "cg_check", "mg" (-1 auto / 0 / 1), "mg_nu", "mg_coarse_sweeps",
  * "mg_omega", "mg_pi_iters", "mg_fuse", "mg_max_levels", "mg_coarse_exact" (dense inverse of the last multigrid level),
  * "mg_dense_nodes" (largest level solved exactly; -1 = chosen per time step, default), "mg_coarse_lag", "warm_start", "pcg_ahead", "body_inv"
+ * "direct" (-1 auto / 0 / 1: multifrontal LU of the operator as preconditioner, on by default for cloth grids of >= 1024 cells),
+ * "direct_leaf" (vertices per nested-dissection leaf),
  * "mg_fuse_restrict" (first sweep + residual + restriction of a stencil level in one launch), "mg_st_f32" (single-precision stencil
  * operators), "mg_fr_rows", "pcg_body_fold" (dense-body first sweep inside the PCG update launch), "asm_overlap" (contact blocks on a
  * second stream), "mr_eta" (stop factor of a MINRES recurrence cycle), "mg_chunk" (multigrid-PCG iterations per graph replay; 0 = 8 on long solves, else 4),

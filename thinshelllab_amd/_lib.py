@@ -53,14 +53,17 @@ class SceneDesc(C.Structure):
 class StepStats(C.Structure):
     _fields_ = [("newton_iters", C.c_int32), ("ls_evals", C.c_int32), ("cg_iters", C.c_int32), ("solves", C.c_int32),
                 ("restarts", C.c_int32), ("fallback", C.c_int32), ("nc", C.c_int32),
-                ("last_delta", C.c_double), ("last_alpha", C.c_double), ("energy", C.c_double)]
+                ("last_delta", C.c_double), ("last_alpha", C.c_double), ("energy", C.c_double),
+                ("unconverged", C.c_int32), ("attained", C.c_int32), ("factorizations", C.c_int32), ("plans", C.c_int32),
+                ("max_rel_residual", C.c_double)]
 
     def as_dict(self):
         return {k: getattr(self, k) for k, _ in self._fields_}
 
 
 class SolveStats(C.Structure):
-    _fields_ = [("iters", C.c_int32), ("restarts", C.c_int32), ("flag", C.c_int32), ("rel_residual", C.c_double)]
+    _fields_ = [("iters", C.c_int32), ("restarts", C.c_int32), ("flag", C.c_int32), ("rel_residual", C.c_double),
+                ("method", C.c_int32), ("attained", C.c_int32)]
 
     def as_dict(self):
         return {k: getattr(self, k) for k, _ in self._fields_}

@@ -1,0 +1,144 @@
+// Host orchestration of the sparse direct preconditioner (included by tsl_hip.hip after k_direct.hpp):
+//   direct_factor(c)       plan (if the constraint set changed) + numeric factorisation of the current operator (vals + c_H)
+//   direct_apply(c, r, z)  z = (LU)^-1 r on permuted solver vectors
+#pragma once
+#include <chrono>
+
+#include "k_direct.hpp"
+#include "tsl_ctx.hpp"
+
+static inline int ds_nblk(long n, int b) { return (int)((n + b - 1) / b); }
+
+static bool direct_enabled(tsl_ctx* c) {
+  DirectSolver& d = c->ds;
+  if (d.enable == 0) return false;
+  if (d.enable == 1) return true;
+  for (const DsGrid& g : d.grids) if ((long)g.N * g.M >= 1024) return true;
+  return false;
+}
+
+static DsDev ds_dev(tsl_ctx* c) {
+  DirectSolver& d = c->ds;
+  DsDev D;
+  D.fr = d.fr.p; D.level_sn = d.level_sn.p; D.A = d.arena.p; D.scr = d.scr.p; D.rel = d.rel.p; D.vtx = d.vtx.p; D.bad = d.bad.p;
+  return D;
+}
+
+template <class T>
+static int ds_upload_grow(DevBuf<T>& buf, const std::vector<T>& h, hipStream_t s) {
+  if (buf.n < h.size()) { if (buf.alloc(h.size() + h.size() / 4 + 16)) return -1; }
+  if (h.empty()) return 0;
+  HIP_OK(hipMemcpyAsync(buf.p, h.data(), h.size() * sizeof(T), hipMemcpyHostToDevice, s));
+  return 0;
+}
+
+// once per context: CSR numbering of the static pattern, its SELL addresses, the nested-dissection partition
+static int direct_static(tsl_ctx* c) {
+  DirectSolver& d = c->ds;
+  if (d.static_ready) return 0;
+  const int NV = c->NV;
+  d.row_ptr.assign(NV + 1, 0);
+  for (int v = 0; v < NV; v++) d.row_ptr[v + 1] = d.row_ptr[v] + (int)c->h_rows[v].size();
+  std::vector<int> c2s(d.row_ptr[NV]);
+  for (int v = 0; v < NV; v++) {
+    const int p = c->h_rowpos[v], s = p >> 6, lane = p & 63;
+    for (int k = 0; k < (int)c->h_rows[v].size(); k++) c2s[d.row_ptr[v] + k] = (int)(((long)c->h_slice_off[s] + 64L * k) * 9 + lane);
+  }
+  if (d.csr2sell.upload(c2s)) return -1;
+  if (d.bad.alloc(4)) return -1;
+  d.plan.sym.build_partition(NV, c->h_rows, d.grids, d.blocks, d.leaf);
+  d.static_ready = true;
+  d.plan_valid = false;
+  return 0;
+}
+
+// plan for the current constraint set (rebuilt only when the set differs from the one the plan was made for)
+static int direct_plan(tsl_ctx* c) {
+  DirectSolver& d = c->ds;
+  hipStream_t s = c->stream;
+  TSL_TRY(direct_static(c));
+  std::vector<int> cons((size_t)c->nc * 4);
+  if (c->nc > 0) {
+    HIP_OK(hipMemcpyAsync(cons.data(), c->c_idx.p, cons.size() * sizeof(int), hipMemcpyDeviceToHost, s));
+    HIP_OK(hipStreamSynchronize(s));
+  }
+  if (d.plan_valid && cons == d.h_cons) return 0;
+  const auto t0 = std::chrono::steady_clock::now();
+  const int rc = d.plan.build(c->h_rows, d.row_ptr, cons.data(), c->nc);
+  if (rc) return tsl_fail("direct solver: inconsistent elimination tree (code %d)", rc);
+  DirectPlan& P = d.plan;
+  // local vertex -> permuted row of the solver vectors
+  std::vector<int> vtxp(P.vtx.size());
+  for (size_t i = 0; i < vtxp.size(); i++) vtxp[i] = c->h_rowpos[P.vtx[i]];
+  HIP_OK(hipStreamSynchronize(s));  // the previous plan's arrays may still be in use
+  TSL_TRY(ds_upload_grow(d.fr, P.fr, s)); TSL_TRY(ds_upload_grow(d.level_sn, P.level_sn, s)); TSL_TRY(ds_upload_grow(d.rel, P.rel, s));
+  TSL_TRY(ds_upload_grow(d.vtx, vtxp, s)); TSL_TRY(ds_upload_grow(d.blk_dst, P.blk_dst, s)); TSL_TRY(ds_upload_grow(d.blk_ld, P.blk_ld, s));
+  TSL_TRY(ds_upload_grow(d.con_dst, P.con_dst, s)); TSL_TRY(ds_upload_grow(d.con_ld, P.con_ld, s));
+  if (d.arena.n < (size_t)P.arena) { if (d.arena.alloc((size_t)P.arena + (size_t)P.arena / 8)) return tsl_fail("direct solver: out of device memory (%.2f GB of fronts)", P.arena * 8e-9); }
+  if (d.scr.n < (size_t)P.scratch) { if (d.scr.alloc((size_t)P.scratch + (size_t)P.scratch / 8)) return -1; }
+  const size_t n3 = 3 * (size_t)c->NV;
+  if (d.w.n < n3) { if (d.w.alloc(n3)) return -1; }
+  HIP_OK(hipStreamSynchronize(s));  // host vectors of this function go out of scope
+  d.h_cons.swap(cons);
+  d.plan_valid = true;
+  d.numeric_valid = false;
+  d.n_plans++;
+  d.t_plan += std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
+  if (c->verbose >= 2)
+    fprintf(stderr, "[tsl] direct plan: %d supernodes, %d levels, %.2f GB of fronts, %.1f GFLOP per factorisation, nc %d\n", P.sym.n_sn, P.sym.n_levels, P.arena * 8e-9, P.flops * 1e-9, c->nc);
+  return 0;
+}
+
+// numeric factorisation of the operator of the last assemble (c->vals + masked contact blocks c->c_H)
+static int direct_factor(tsl_ctx* c) {
+  DirectSolver& d = c->ds;
+  hipStream_t s = c->stream;
+  TSL_TRY(direct_plan(c));
+  if (d.numeric_valid) return 0;
+  const DirectPlan& P = d.plan;
+  const DsDev D = ds_dev(c);
+  HIP_OK(hipMemsetAsync(d.arena.p, 0, (size_t)P.arena * sizeof(double), s));
+  HIP_OK(hipMemsetAsync(d.bad.p, 0, 4 * sizeof(int), s));
+  const long nnzb = d.row_ptr[c->NV];
+  hipLaunchKernelGGL(k_ds_assemble_blocks, dim3(ds_nblk(nnzb * 9, 256)), dim3(256), 0, s, nnzb, d.csr2sell.p, c->vals.p, d.blk_dst.p, d.blk_ld.p, d.arena.p);
+  if (c->nc > 0) hipLaunchKernelGGL(k_ds_assemble_contacts, dim3(ds_nblk((long)c->nc * 144, 256)), dim3(256), 0, s, c->nc, c->c_H.p, d.con_dst.p, d.con_ld.p, d.arena.p);
+  hipLaunchKernelGGL(k_ds_pad_diag, dim3(P.sym.n_sn), dim3(64), 0, s, P.sym.n_sn, d.fr.p, d.arena.p);
+  for (int l = 0; l < P.sym.n_levels; l++) {
+    const int lv0 = P.level_ptr[l], nf = P.level_ptr[l + 1] - lv0;
+    const int tp = P.level_max_pp[l] / DS_T, tl = P.level_max_ld[l] / DS_T, tb = P.level_max_bp[l] / DS_T;
+    hipLaunchKernelGGL(k_ds_pivot0, dim3(nf), dim3(256), 0, s, D, lv0);
+    for (int k = 0; k < tp; k++) {
+      hipLaunchKernelGGL(k_ds_panel, dim3(tl, nf), dim3(256), 0, s, D, lv0, k);
+      hipLaunchKernelGGL(k_ds_update, dim3(tl, tp, nf), dim3(256), 0, s, D, lv0, k);
+    }
+    if (tb > 0) {
+      hipLaunchKernelGGL(k_ds_schur, dim3((tb + 1) / 2, (tb + 1) / 2, nf), dim3(256), 0, s, D, lv0);
+      hipLaunchKernelGGL(k_ds_extend, dim3(tb, tb, nf), dim3(256), 0, s, D, lv0);
+    }
+  }
+  HIP_OK(hipGetLastError());
+  d.numeric_valid = true;
+  d.n_factor++;
+  return 0;
+}
+
+// z = (LU)^-1 r, permuted solver vectors (r is not modified; z may not alias r)
+static int direct_apply(tsl_ctx* c, const double* r, double* z) {
+  DirectSolver& d = c->ds;
+  hipStream_t s = c->stream;
+  const DirectPlan& P = d.plan;
+  const DsDev D = ds_dev(c);
+  const size_t n3 = 3 * (size_t)c->NV;
+  HIP_OK(hipMemcpyAsync(d.w.p, r, n3 * sizeof(double), hipMemcpyDeviceToDevice, s));
+  for (int l = 0; l < P.sym.n_levels; l++) {
+    const int lv0 = P.level_ptr[l], nf = P.level_ptr[l + 1] - lv0;
+    hipLaunchKernelGGL(k_ds_gemv, dim3(ds_nblk(P.level_max_pp[l], 16), nf), dim3(256), 0, s, D, lv0, 0, (const double*)d.w.p, z);
+    if (P.level_max_bp[l] > 0) hipLaunchKernelGGL(k_ds_gemv, dim3(ds_nblk(P.level_max_bp[l], 16), nf), dim3(256), 0, s, D, lv0, 1, (const double*)z, d.w.p);
+  }
+  for (int l = P.sym.n_levels - 1; l >= 0; l--) {
+    const int lv0 = P.level_ptr[l], nf = P.level_ptr[l + 1] - lv0;
+    if (P.level_max_bp[l] > 0) hipLaunchKernelGGL(k_ds_gemv, dim3(ds_nblk(P.level_max_pp[l], 16), nf), dim3(256), 0, s, D, lv0, 2, (const double*)z, z);
+  }
+  d.n_apply++;
+  return 0;
+}

@@ -1,0 +1,344 @@
+// Numeric kernels of the multifrontal LU that preconditions the Newton / adjoint solves (layout: direct_plan.hpp).
+// The reference calls a direct sparse solver for every system (sparse_solver.py:85-105); at 100k triangles its dense-backed
+// storage is impossible, and the iterative solvers of k_solver.hpp need 10^2..10^5 iterations on the wrinkled cfg4 states, so the
+// same operator is factorised here: one dense front per supernode of the nested-dissection tree, fronts of one tree level
+// batched into the same launches.  Per front:  [F11 F12; F21 F22] -> [W = F11^-1, G = W F12; F21, S = F22 - F21 G].
+//   * W, G: blocked in-place Gauss-Jordan on the pp x ld top block rows (DS_T pivots per step, two launches per step; the pivot
+//     block of the next step is inverted by one wave inside the update kernel).  No pivoting: measured on the cfg4 operators
+//     (forward and un-projected adjoint) a nested-dissection LU with diagonal pivots reaches a 1e-10 relative residual.
+//   * S: a K = pp GEMM on the f64 matrix cores (v_mfma_f64_16x16x4_f64), the bulk of the flops.
+//   * S is added into the parent front through the child's boundary -> parent index map (f64 atomics: siblings overlap).
+// A solve is three matrix-vector passes per level (W, F21 upwards; G downwards), no triangular recurrences.
+#pragma once
+#include "direct_plan.hpp"
+#include "tsl_device.hpp"
+
+typedef double ds_d4 __attribute__((ext_vector_type(4)));
+
+struct DsDev {                 // device views shared by the kernels
+  const DsFrontDesc* fr;
+  const int* level_sn;         // front ids, level after level
+  double* A;                   // front arena
+  double* scr;                 // per-level scratch (pivot-block inverses, row panel, column panel per front)
+  const int* rel;
+  const int* vtx;              // local vertex -> PERMUTED vertex position (rows of the solver vectors)
+  int* bad;                    // [0]: number of perturbed pivots of the last factorisation
+};
+
+// ---- assembly -------------------------------------------------------------------------------------------------------------
+// static pattern: block q of the CSR numbering lives at vals[csr2sell[q] + 64 e] (SELL-64, element e of the 3 x 3 block)
+__global__ void k_ds_assemble_blocks(long nnzb, const int* __restrict__ csr2sell, const double* __restrict__ vals, const long long* __restrict__ blk_dst,
+                                     const int* __restrict__ blk_ld, double* __restrict__ A) {
+  const long t = (long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (t >= nnzb * 9) return;
+  const long q = t / 9;
+  const int e = (int)(t % 9);
+  const long long d = blk_dst[q];
+  if (d < 0) return;
+  A[d + (long long)(e / 3) * blk_ld[q] + e % 3] = vals[(size_t)csr2sell[q] + 64 * e];
+}
+// contact blocks: 16 vertex-pair sub-blocks per constraint (several constraints may share a vertex pair: atomics)
+__global__ void k_ds_assemble_contacts(int nc, const double* __restrict__ H, const long long* __restrict__ con_dst, const int* __restrict__ con_ld, double* __restrict__ A) {
+  const long t = (long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (t >= (long)nc * 144) return;
+  const int c = (int)(t / 144), e = (int)(t % 144), r = e / 12, cc = e % 12;
+  const double v = H[t];
+  if (v == 0.0) return;
+  const int sub = (r / 3) * 4 + cc / 3;
+  const long long d = con_dst[(size_t)c * 16 + sub];
+  atomicAdd(&A[d + (long long)(r % 3) * con_ld[(size_t)c * 16 + sub] + cc % 3], v);
+}
+// identity on the padding of the pivot block
+__global__ void k_ds_pad_diag(int n_sn, const DsFrontDesc* __restrict__ fr, double* __restrict__ A) {
+  const int s = blockIdx.x;
+  if (s >= n_sn) return;
+  const DsFrontDesc f = fr[s];
+  for (int i = f.p + threadIdx.x; i < f.pp; i += blockDim.x) A[f.off + (long long)i * f.ld + i] = 1.0;
+}
+
+// ---- blocked Gauss-Jordan on the top block rows ---------------------------------------------------------------------------
+// In-place inversion of one DS_T x DS_T tile held in LDS by ONE wave: lane = (column c, row half h) keeps its 16 elements in
+// registers, per pivot only the pivot row and column go through LDS; a single wave runs in lockstep, so the 32 pivot steps need no
+// workgroup barrier.  Pivots below 1e-13 of the tile's largest entry are replaced by that bound (counted in bad[0]).
+TSL_DEV void ds_invert_tile_wave(double (*T)[DS_T + 1], int* __restrict__ bad) {
+  __shared__ double colb[DS_T], rowb[DS_T];
+  const int lane = threadIdx.x & 63;
+  const int c = lane & 31, h = lane >> 5;
+  double a[DS_T / 2];
+  double amax = 0.0;
+#pragma unroll
+  for (int m = 0; m < DS_T / 2; m++) { a[m] = T[h * (DS_T / 2) + m][c]; amax = fmax(amax, fabs(a[m])); }
+  amax = wave_max(amax);
+  const double tiny = fmax(amax * 1e-13, 1e-300);
+  int nbad = 0;
+#pragma unroll
+  for (int p = 0; p < DS_T; p++) {
+    if (c == p) {
+#pragma unroll
+      for (int m = 0; m < DS_T / 2; m++) colb[h * (DS_T / 2) + m] = a[m];
+    }
+    if (h == p / (DS_T / 2)) rowb[c] = a[p % (DS_T / 2)];
+    __builtin_amdgcn_wave_barrier();
+    double piv = rowb[p];
+    const double rj = rowb[c];
+    double ci[DS_T / 2];
+#pragma unroll
+    for (int m = 0; m < DS_T / 2; m++) ci[m] = colb[h * (DS_T / 2) + m];
+    __builtin_amdgcn_wave_barrier();
+    if (!(fabs(piv) >= tiny)) { piv = (piv < 0.0) ? -tiny : tiny; nbad++; }
+    const double ip = 1.0 / piv;
+    const double rs = rj * ip;
+#pragma unroll
+    for (int m = 0; m < DS_T / 2; m++) {
+      const int i = h * (DS_T / 2) + m;
+      double v;
+      if (i == p) v = (c == p) ? ip : rs;
+      else if (c == p) v = -ci[m] * ip;
+      else v = a[m] - ci[m] * rs;
+      a[m] = v;
+    }
+  }
+#pragma unroll
+  for (int m = 0; m < DS_T / 2; m++) T[h * (DS_T / 2) + m][c] = a[m];
+  if (lane == 0 && nbad) atomicAdd(bad, nbad);
+}
+
+// scratch of a front inside the level scratch: P0, P1 (pivot-block inverses, ping-pong), row panel R' (DS_T x ld), column panel C (pp x DS_T)
+TSL_DEV double* ds_scr_P(const DsDev& D, const DsFrontDesc& f, int which) { return D.scr + f.scr_off + which * DS_T * DS_T; }
+TSL_DEV double* ds_scr_R(const DsDev& D, const DsFrontDesc& f) { return D.scr + f.scr_off + 2 * DS_T * DS_T; }
+TSL_DEV double* ds_scr_C(const DsDev& D, const DsFrontDesc& f) { return D.scr + f.scr_off + 2 * DS_T * DS_T + (size_t)DS_T * f.ld; }
+
+// inverse of the first pivot block of every front of the level -> P0
+__global__ void __launch_bounds__(256) k_ds_pivot0(DsDev D, int lv0) {
+  __shared__ double T[DS_T][DS_T + 1];
+  const DsFrontDesc f = D.fr[D.level_sn[lv0 + blockIdx.x]];
+  const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;
+  const double* A = D.A + f.off;
+#pragma unroll
+  for (int q = 0; q < 4; q++) T[ty + 8 * q][tx] = A[(size_t)(ty + 8 * q) * f.ld + tx];
+  __syncthreads();
+  if (threadIdx.x < 64) ds_invert_tile_wave(T, D.bad);
+  __syncthreads();
+  double* P = ds_scr_P(D, f, 0);
+#pragma unroll
+  for (int q = 0; q < 4; q++) P[(ty + 8 * q) * DS_T + tx] = T[ty + 8 * q][tx];
+}
+
+// panel kernel of block step k: workgroup b writes the row panel R'[:, chunk b] = P A[K, chunk b] (all ld / DS_T column chunks) and
+// saves the column panel C[chunk b, :] = A[chunk b, K] (the pp / DS_T row chunks)
+__global__ void __launch_bounds__(256) k_ds_panel(DsDev D, int lv0, int k) {
+  __shared__ double P[DS_T][DS_T + 1];
+  __shared__ double T[DS_T][DS_T + 1];
+  const DsFrontDesc f = D.fr[D.level_sn[lv0 + blockIdx.y]];
+  const int k0 = k * DS_T, b = blockIdx.x, b0 = b * DS_T;
+  if (k0 >= f.pp || b0 >= f.ld) return;
+  const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;
+  double* A = D.A + f.off;
+  const double* Pin = ds_scr_P(D, f, k & 1);
+  double* Rn = ds_scr_R(D, f);
+  double* Cs = ds_scr_C(D, f);
+#pragma unroll
+  for (int q = 0; q < 4; q++) {
+    const int i = ty + 8 * q;
+    P[i][tx] = Pin[i * DS_T + tx];
+    T[i][tx] = A[(size_t)(k0 + i) * f.ld + b0 + tx];
+    if (b0 < f.pp) Cs[(size_t)(b0 + i) * DS_T + tx] = A[(size_t)(b0 + i) * f.ld + k0 + tx];
+  }
+  __syncthreads();
+#pragma unroll
+  for (int q = 0; q < 4; q++) {
+    const int i = ty + 8 * q;
+    double acc = 0;
+#pragma unroll 8
+    for (int m = 0; m < DS_T; m++) acc += P[i][m] * T[m][tx];
+    Rn[(size_t)i * f.ld + b0 + tx] = acc;
+  }
+}
+
+// update kernel of block step k: one DS_T x DS_T tile of the top block rows per workgroup,
+//   A_ij -= C_i R'_j (i, j outside K),  A_Kj = R'_j,  A_iK = -C_i P,  A_KK = P;
+// the workgroup of tile (k+1, k+1) also inverts its updated tile (the next pivot block) into the other P buffer
+__global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(4, 8))) k_ds_update(DsDev D, int lv0, int k) {
+  __shared__ double Ct[DS_T][DS_T + 1];
+  __shared__ double Rt[DS_T][DS_T + 1];
+  const DsFrontDesc f = D.fr[D.level_sn[lv0 + blockIdx.z]];
+  const int k0 = k * DS_T;
+  if (k0 >= f.pp) return;
+  int bi = blockIdx.y, bj = blockIdx.x;
+  const bool has_next = (k + 1) * DS_T < f.pp;
+  if (has_next) {  // the tile that carries the single-wave inversion is dispatched first
+    if (bi == 0 && bj == 0) bi = bj = k + 1;
+    else if (bi == k + 1 && bj == k + 1) bi = bj = 0;
+  }
+  const int i0 = bi * DS_T, j0 = bj * DS_T;
+  if (i0 >= f.pp || j0 >= f.ld) return;
+  const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;
+  double* A = D.A + f.off;
+  const double* Pin = ds_scr_P(D, f, k & 1);
+  const double* Rn = ds_scr_R(D, f);
+  const double* Cs = ds_scr_C(D, f);
+  if (bi == k) {
+#pragma unroll
+    for (int q = 0; q < 4; q++) A[(size_t)(i0 + ty + 8 * q) * f.ld + j0 + tx] = (bj == k) ? Pin[(ty + 8 * q) * DS_T + tx] : Rn[(size_t)(ty + 8 * q) * f.ld + j0 + tx];
+    return;
+  }
+#pragma unroll
+  for (int q = 0; q < 4; q++) {
+    Ct[ty + 8 * q][tx] = Cs[(size_t)(i0 + ty + 8 * q) * DS_T + tx];
+    Rt[ty + 8 * q][tx] = (bj == k) ? Pin[(ty + 8 * q) * DS_T + tx] : Rn[(size_t)(ty + 8 * q) * f.ld + j0 + tx];
+  }
+  __syncthreads();
+  // rank-32 update on the f64 matrix cores: wave (wi, wj) owns a 16 x 16 quadrant (A operand: lane l holds C[l & 15][4 kk + (l >> 4)],
+  // B operand: R'[4 kk + (l >> 4)][l & 15]; result register r of lane l is element (row (l >> 4) + 4 r, column l & 15))
+  const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+  const int wi = w >> 1, wj = w & 1;
+  const int lr = lane & 15, lk = lane >> 4;
+  ds_d4 acc = {0.0, 0.0, 0.0, 0.0};
+#pragma unroll
+  for (int kk = 0; kk < DS_T / 4; kk++) acc = __builtin_amdgcn_mfma_f64_16x16x4f64(Ct[16 * wi + lr][4 * kk + lk], Rt[4 * kk + lk][16 * wj + lr], acc, 0, 0, 0);
+  const bool next_pivot = has_next && bi == k + 1 && bj == k + 1;
+  if (next_pivot) __syncthreads();
+#pragma unroll
+  for (int r = 0; r < 4; r++) {
+    const int row = 16 * wi + lk + 4 * r, col = 16 * wj + lr;
+    double* d = A + (size_t)(i0 + row) * f.ld + j0 + col;
+    const double v = (bj == k) ? -acc[r] : *d - acc[r];
+    *d = v;
+    if (next_pivot) Ct[row][col] = v;
+  }
+  if (next_pivot) {
+    __syncthreads();
+    if (threadIdx.x < 64) ds_invert_tile_wave(Ct, D.bad);
+    __syncthreads();
+    double* Pn = ds_scr_P(D, f, (k + 1) & 1);
+#pragma unroll
+    for (int q = 0; q < 4; q++) Pn[(ty + 8 * q) * DS_T + tx] = Ct[ty + 8 * q][tx];
+  }
+}
+
+// ---- Schur complement S = F22 - F21 G on the f64 matrix cores ----------------------------------------------------------------
+// one 64 x 64 tile of S per workgroup (four waves, each a 32 x 32 quadrant = 2 x 2 MFMA tiles), K = pp in chunks of 32 through LDS
+#define DS_SK 32
+__global__ void __launch_bounds__(256) k_ds_schur(DsDev D, int lv0) {
+  __shared__ double As[64][DS_SK + 1];   // F21[I, kchunk]
+  __shared__ double Bs[DS_SK][64 + 1];   // G[kchunk, J]
+  const DsFrontDesc f = D.fr[D.level_sn[lv0 + blockIdx.z]];
+  const int I0 = blockIdx.y * 64, J0 = blockIdx.x * 64;
+  if (I0 >= f.bp || J0 >= f.bp) return;
+  double* A = D.A + f.off;
+  const int ld = f.ld, pp = f.pp;
+  const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+  const int wi = w >> 1, wj = w & 1;
+  const int lr = lane & 15, lk = lane >> 4;
+  const bool rows_hi = I0 + 32 < f.bp, cols_hi = J0 + 32 < f.bp;   // bp is a multiple of 32: the second half of the tile may lie outside
+  ds_d4 acc[2][2];
+#pragma unroll
+  for (int a = 0; a < 2; a++)
+#pragma unroll
+    for (int b = 0; b < 2; b++) acc[a][b] = ds_d4{0.0, 0.0, 0.0, 0.0};
+  const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;  // 32 x 8
+  for (int k0 = 0; k0 < pp; k0 += DS_SK) {
+    // F21 chunk: 64 rows x 32 columns (thread: column tx, rows ty + 8 q)
+#pragma unroll
+    for (int q = 0; q < 8; q++) {
+      const int r = ty + 8 * q;
+      As[r][tx] = (r < 32 || rows_hi) ? A[(size_t)(pp + I0 + r) * ld + k0 + tx] : 0.0;
+    }
+    // G chunk: 32 rows x 64 columns (thread: columns tx, tx + 32; rows ty + 8 q)
+#pragma unroll
+    for (int q = 0; q < 4; q++) {
+      const int r = ty + 8 * q;
+      Bs[r][tx] = A[(size_t)(k0 + r) * ld + pp + J0 + tx];
+      Bs[r][tx + 32] = cols_hi ? A[(size_t)(k0 + r) * ld + pp + J0 + 32 + tx] : 0.0;
+    }
+    __syncthreads();
+#pragma unroll
+    for (int kk = 0; kk < DS_SK / 4; kk++) {
+      const double a0 = As[32 * wi + lr][4 * kk + lk], a1 = As[32 * wi + 16 + lr][4 * kk + lk];
+      const double b0 = Bs[4 * kk + lk][32 * wj + lr], b1 = Bs[4 * kk + lk][32 * wj + 16 + lr];
+      acc[0][0] = __builtin_amdgcn_mfma_f64_16x16x4f64(a0, b0, acc[0][0], 0, 0, 0);
+      acc[0][1] = __builtin_amdgcn_mfma_f64_16x16x4f64(a0, b1, acc[0][1], 0, 0, 0);
+      acc[1][0] = __builtin_amdgcn_mfma_f64_16x16x4f64(a1, b0, acc[1][0], 0, 0, 0);
+      acc[1][1] = __builtin_amdgcn_mfma_f64_16x16x4f64(a1, b1, acc[1][1], 0, 0, 0);
+    }
+    __syncthreads();
+  }
+#pragma unroll
+  for (int a = 0; a < 2; a++)
+#pragma unroll
+    for (int b = 0; b < 2; b++)
+#pragma unroll
+      for (int r = 0; r < 4; r++) {
+        const int row = I0 + 32 * wi + 16 * a + lk + 4 * r, col = J0 + 32 * wj + 16 * b + lr;
+        if (row < f.bp && col < f.bp) A[(size_t)(pp + row) * ld + pp + col] -= acc[a][b][r];
+      }
+}
+
+// ---- extend-add: S of every front of the level into its parent ----------------------------------------------------------------
+__global__ void __launch_bounds__(256) k_ds_extend(DsDev D, int lv0) {
+  const DsFrontDesc f = D.fr[D.level_sn[lv0 + blockIdx.z]];
+  if (f.parent < 0) return;
+  const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;
+  const int j = blockIdx.x * 32 + tx;
+  if (j >= f.b) return;
+  const DsFrontDesc pf = D.fr[f.parent];
+  const double* S = D.A + f.off + (size_t)f.pp * f.ld + f.pp;
+  double* PA = D.A + pf.off;
+  const int* rel = D.rel + f.rel_off;
+  const int pj = rel[j / 3] + j % 3;
+#pragma unroll
+  for (int q = 0; q < 4; q++) {
+    const int i = blockIdx.y * 32 + ty + 8 * q;
+    if (i >= f.b) continue;
+    const int pi = rel[i / 3] + i % 3;
+    const double v = S[(size_t)i * f.ld + j];
+    if (v != 0.0) atomicAdd(&PA[(size_t)pi * pf.ld + pj], v);
+  }
+}
+
+// ---- solve ----------------------------------------------------------------------------------------------------------------
+// One matrix-vector pass over the fronts of a level; a workgroup owns 16 rows of one front (4 per wave), the input vector of the
+// front is staged in LDS in chunks.
+//   mode 0 (up, W):    t[own i]  = sum_j W[i, j] w[own j]
+//   mode 1 (up, F21):  w[bnd i] -= sum_j F21[i, j] t[own j]          (atomic: sibling fronts share boundary vertices)
+//   mode 2 (down, G):  x[own i]  = t[own i] - sum_j G[i, j] x[bnd j]  (x and t may alias)
+#define DS_VCHUNK 2048
+__global__ void __launch_bounds__(256) k_ds_gemv(DsDev D, int lv0, int mode, const double* vin, double* vout) {
+  __shared__ double xs[DS_VCHUNK];
+  const DsFrontDesc f = D.fr[D.level_sn[lv0 + blockIdx.y]];
+  const int nrows = mode == 1 ? f.b : f.p, ncols = mode == 2 ? f.b : f.p;
+  const int r0 = blockIdx.x * 16;
+  if (r0 >= nrows) return;
+  const int* vt = D.vtx + f.vtx_off;
+  const int in_v0 = mode == 2 ? f.nv_own : 0, out_v0 = mode == 1 ? f.nv_own : 0;
+  const double* M = D.A + f.off + (mode == 1 ? (size_t)f.pp * f.ld : 0) + (mode == 2 ? f.pp : 0);
+  const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+  double acc[4] = {0.0, 0.0, 0.0, 0.0};
+  for (int c0 = 0; c0 < ncols; c0 += DS_VCHUNK) {
+    const int cn = min(DS_VCHUNK, ncols - c0);
+    __syncthreads();
+    for (int j = threadIdx.x; j < cn; j += 256) { const int jj = c0 + j; xs[j] = vin[3 * (size_t)vt[in_v0 + jj / 3] + jj % 3]; }
+    __syncthreads();
+#pragma unroll
+    for (int q = 0; q < 4; q++) {
+      const int i = r0 + 4 * w + q;
+      if (i < nrows) {
+        const double* row = M + (size_t)i * f.ld + c0;
+        double a = 0;
+        for (int j = lane; j < cn; j += 64) a += row[j] * xs[j];
+        acc[q] += a;
+      }
+    }
+  }
+#pragma unroll
+  for (int q = 0; q < 4; q++) {
+    const int i = r0 + 4 * w + q;
+    const double a = wave_sum(acc[q]);
+    if (lane == 0 && i < nrows) {
+      const size_t o = 3 * (size_t)vt[out_v0 + i / 3] + i % 3;
+      if (mode == 0) vout[o] = a;
+      else if (mode == 1) atomicAdd(&vout[o], -a);
+      else vout[o] = vout[o] - a;
+    }
+  }
+}

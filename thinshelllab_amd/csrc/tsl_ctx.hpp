@@ -13,6 +13,7 @@
 
 #include "../../include/tsl_hip.h"
 #include "k_body.hpp"
+#include "direct_plan.hpp"
 
 #define TSL_SLICE 64  // rows per SELL slice == wavefront width on gfx950
 
@@ -86,6 +87,25 @@ struct MgCloth {
   std::vector<MgLevel*> lv;  // lv[0] = level 1
   int dense_lv = -1;         // index into lv of the level that is solved exactly (dense inverse), -1: none
   ~MgCloth() { for (auto* l : lv) delete l; }
+};
+
+// sparse direct preconditioner (direct_sym.hpp / direct_plan.hpp / k_direct.hpp): multifrontal LU of the assembled operator
+struct DirectSolver {
+  int enable = -1;          // -1 auto (on when a cloth grid has >= 1024 cells), 0 off, 1 on
+  int leaf = 32;            // vertices per leaf of the nested dissection
+  bool static_ready = false, numeric_valid = false;
+  DirectPlan plan;
+  std::vector<DsGrid> grids;
+  std::vector<DsBlock> blocks;
+  std::vector<int> row_ptr;   // CSR numbering of the static block pattern (rows of h_rows)
+  std::vector<int> h_cons;    // constraint vertices the current plan was built for
+  bool plan_valid = false;
+  DevBuf<int> csr2sell, level_sn, rel, vtx, blk_ld, con_ld, bad;
+  DevBuf<long long> blk_dst, con_dst;
+  DevBuf<DsFrontDesc> fr;
+  DevBuf<double> arena, scr, w;
+  long n_plans = 0, n_factor = 0, n_apply = 0, n_perturbed = 0;
+  double t_plan = 0;          // host seconds spent in plan builds
 };
 
 struct tsl_ctx {
@@ -246,6 +266,8 @@ struct tsl_ctx {
   double tm_loop = 0;  // verbose: host time spent in the PCG iteration loops of the current step
   bool ev_sample_next = false;
 
+  DirectSolver ds;
+  bool ds_suspended = false;  // set while the iterative hierarchy runs as the fallback of a failed direct solve
   // stats
   tsl_step_stats step_stats{};
   ~tsl_ctx() { for (auto* m : mg) delete m; }
