@@ -78,10 +78,11 @@ typedef struct {
   double last_delta, last_alpha, energy;
   /* convergence accounting of the step's linear solves (the reference's spsolve is exact every time, sparse_solver.py:85-105):
    * fallback = solves that needed a second solver and converged there (flag 1); unconverged = solves that ended with flag 3;
-   * attained = solves accepted by the attainable-accuracy rule (true residual stagnating within 100x of cg_tol);
+   * attained = solves accepted by the attainable-accuracy rule (iterative solvers: true residual stagnating within 100x of cg_tol;
+ * direct path: stagnating with a normwise backward error <= 1e-13, what a backward-stable direct solver delivers);
    * factorizations = numeric factorisations of the direct preconditioner; max_rel_residual over the step's solves */
   int32_t unconverged, attained, factorizations, plans;
-  double max_rel_residual;
+  double max_rel_residual, max_backward_error;
 } tsl_step_stats;
 
 typedef struct {
@@ -89,6 +90,7 @@ typedef struct {
   double rel_residual;           /* true residual |b - Hx| / |b| of the returned solution */
   int32_t method;                /* solver that produced x: 0 PCG, 1 MINRES, 2 GMRES, 3 BiCGStab, 4 sparse LU + GMRES refinement */
   int32_t attained;              /* 1: accepted by the attainable-accuracy rule instead of rel_residual <= cg_tol */
+  double backward_error;         /* method 4: |b - Hx| / (|H|_inf |x| + |b|) of the returned solution (0 if not evaluated) */
 } tsl_solve_stats;
 
 const char* tsl_version(void);

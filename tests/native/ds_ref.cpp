@@ -30,8 +30,9 @@ extern "C" int dsref_solve(int NV, const int* row_ptr, const int* col, const dou
   const int S = P.sym.n_sn;
   for (int s = 0; s < S; s++) { const DsFrontDesc& f = P.fr[s]; for (int i = f.p; i < f.pp; i++) A[f.off + (long long)i * f.ld + i] = 1.0; }
   double min_piv = 1e300;
-  for (int l = 0; l < P.sym.n_levels; l++)
-    for (int s : P.sym.by_level[l]) {
+  for (int l = 0; l < P.n_levels; l++)
+    for (int q = P.level_ptr[l]; q < P.level_ptr[l + 1]; q++) {
+      const int s = P.level_sn[q];
       const DsFrontDesc& f = P.fr[s];
       double* F = A.data() + f.off;
       const int ld = f.ld;
@@ -69,8 +70,9 @@ extern "C" int dsref_solve(int NV, const int* row_ptr, const int* col, const dou
     }
   // solve
   std::vector<double> w(rhs, rhs + 3 * (size_t)NV), t(3 * (size_t)NV, 0.0);
-  for (int l = 0; l < P.sym.n_levels; l++)
-    for (int s : P.sym.by_level[l]) {
+  for (int l = 0; l < P.n_levels; l++)
+    for (int q = P.level_ptr[l]; q < P.level_ptr[l + 1]; q++) {
+      const int s = P.level_sn[q];
       const DsFrontDesc& f = P.fr[s];
       const double* F = A.data() + f.off;
       const int* vt = P.vtx.data() + f.vtx_off;
@@ -85,8 +87,9 @@ extern "C" int dsref_solve(int NV, const int* row_ptr, const int* col, const dou
         w[3 * (size_t)vt[f.nv_own + i / 3] + i % 3] -= acc;
       }
     }
-  for (int l = P.sym.n_levels - 1; l >= 0; l--)
-    for (int s : P.sym.by_level[l]) {
+  for (int l = P.n_levels - 1; l >= 0; l--)
+    for (int q = P.level_ptr[l]; q < P.level_ptr[l + 1]; q++) {
+      const int s = P.level_sn[q];
       const DsFrontDesc& f = P.fr[s];
       const double* F = A.data() + f.off;
       const int* vt = P.vtx.data() + f.vtx_off;
@@ -96,6 +99,6 @@ extern "C" int dsref_solve(int NV, const int* row_ptr, const int* col, const dou
         x[3 * (size_t)vt[i / 3] + i % 3] = acc;
       }
     }
-  if (stats) { stats[0] = S; stats[1] = P.sym.n_levels; stats[2] = (double)P.arena; stats[3] = P.flops; stats[4] = min_piv; }
+  if (stats) { stats[0] = S; stats[1] = P.n_levels; stats[2] = (double)P.arena; stats[3] = P.flops; stats[4] = min_piv; }
   return 0;
 }

@@ -55,7 +55,7 @@ class StepStats(C.Structure):
                 ("restarts", C.c_int32), ("fallback", C.c_int32), ("nc", C.c_int32),
                 ("last_delta", C.c_double), ("last_alpha", C.c_double), ("energy", C.c_double),
                 ("unconverged", C.c_int32), ("attained", C.c_int32), ("factorizations", C.c_int32), ("plans", C.c_int32),
-                ("max_rel_residual", C.c_double)]
+                ("max_rel_residual", C.c_double), ("max_backward_error", C.c_double)]
 
     def as_dict(self):
         return {k: getattr(self, k) for k, _ in self._fields_}
@@ -63,7 +63,7 @@ class StepStats(C.Structure):
 
 class SolveStats(C.Structure):
     _fields_ = [("iters", C.c_int32), ("restarts", C.c_int32), ("flag", C.c_int32), ("rel_residual", C.c_double),
-                ("method", C.c_int32), ("attained", C.c_int32)]
+                ("method", C.c_int32), ("attained", C.c_int32), ("backward_error", C.c_double)]
 
     def as_dict(self):
         return {k: getattr(self, k) for k, _ in self._fields_}

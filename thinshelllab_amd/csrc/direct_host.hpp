@@ -74,6 +74,7 @@ static int direct_plan(tsl_ctx* c) {
   TSL_TRY(ds_upload_grow(d.fr, P.fr, s)); TSL_TRY(ds_upload_grow(d.level_sn, P.level_sn, s)); TSL_TRY(ds_upload_grow(d.rel, P.rel, s));
   TSL_TRY(ds_upload_grow(d.vtx, vtxp, s)); TSL_TRY(ds_upload_grow(d.blk_dst, P.blk_dst, s)); TSL_TRY(ds_upload_grow(d.blk_ld, P.blk_ld, s));
   TSL_TRY(ds_upload_grow(d.con_dst, P.con_dst, s)); TSL_TRY(ds_upload_grow(d.con_ld, P.con_ld, s));
+  TSL_TRY(ds_upload_grow(d.wl_front, P.wl_front, s)); TSL_TRY(ds_upload_grow(d.wl_row, P.wl_row, s));
   if (d.arena.n < (size_t)P.arena) { if (d.arena.alloc((size_t)P.arena + (size_t)P.arena / 8)) return tsl_fail("direct solver: out of device memory (%.2f GB of fronts)", P.arena * 8e-9); }
   if (d.scr.n < (size_t)P.scratch) { if (d.scr.alloc((size_t)P.scratch + (size_t)P.scratch / 8)) return -1; }
   const size_t n3 = 3 * (size_t)c->NV;
@@ -85,7 +86,7 @@ static int direct_plan(tsl_ctx* c) {
   d.n_plans++;
   d.t_plan += std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
   if (c->verbose >= 2)
-    fprintf(stderr, "[tsl] direct plan: %d supernodes, %d levels, %.2f GB of fronts, %.1f GFLOP per factorisation, nc %d\n", P.sym.n_sn, P.sym.n_levels, P.arena * 8e-9, P.flops * 1e-9, c->nc);
+    fprintf(stderr, "[tsl] direct plan: %d supernodes, %d levels, %.2f GB of fronts, %.1f GFLOP per factorisation, nc %d\n", P.sym.n_sn, P.n_levels, P.arena * 8e-9, P.flops * 1e-9, c->nc);
   return 0;
 }
 
@@ -103,19 +104,25 @@ static int direct_factor(tsl_ctx* c) {
   hipLaunchKernelGGL(k_ds_assemble_blocks, dim3(ds_nblk(nnzb * 9, 256)), dim3(256), 0, s, nnzb, d.csr2sell.p, c->vals.p, d.blk_dst.p, d.blk_ld.p, d.arena.p);
   if (c->nc > 0) hipLaunchKernelGGL(k_ds_assemble_contacts, dim3(ds_nblk((long)c->nc * 144, 256)), dim3(256), 0, s, c->nc, c->c_H.p, d.con_dst.p, d.con_ld.p, d.arena.p);
   hipLaunchKernelGGL(k_ds_pad_diag, dim3(P.sym.n_sn), dim3(64), 0, s, P.sym.n_sn, d.fr.p, d.arena.p);
-  for (int l = 0; l < P.sym.n_levels; l++) {
-    const int lv0 = P.level_ptr[l], nf = P.level_ptr[l + 1] - lv0;
-    const int tp = P.level_max_pp[l] / DS_T, tl = P.level_max_ld[l] / DS_T, tb = P.level_max_bp[l] / DS_T;
+  for (const DsBatch& b : P.batches) {
+    const int lv0 = b.first, nf = b.count;
+    const int tp = b.max_pp / DS_T, tb = b.max_bp / DS_T;
     hipLaunchKernelGGL(k_ds_pivot0, dim3(nf), dim3(256), 0, s, D, lv0);
     for (int k = 0; k < tp; k++) {
-      hipLaunchKernelGGL(k_ds_panel, dim3(tl, nf), dim3(256), 0, s, D, lv0, k);
-      hipLaunchKernelGGL(k_ds_update, dim3(tl, tp, nf), dim3(256), 0, s, D, lv0, k);
+      const int na = P.act_n[b.act_off + k], tl = P.act_ld[b.act_off + k] / DS_T;   // fronts are sorted by pp: the active ones are a prefix
+      hipLaunchKernelGGL(k_ds_panel, dim3(tl, na), dim3(256), 0, s, D, lv0, k);
+      hipLaunchKernelGGL(k_ds_update, dim3(tl, tp, na), dim3(256), 0, s, D, lv0, k);
     }
     if (tb > 0) {
       hipLaunchKernelGGL(k_ds_schur, dim3((tb + 1) / 2, (tb + 1) / 2, nf), dim3(256), 0, s, D, lv0);
       hipLaunchKernelGGL(k_ds_extend, dim3(tb, tb, nf), dim3(256), 0, s, D, lv0);
     }
   }
+  if (d.anorm_dev.n == 0 && d.anorm_dev.alloc(1)) return -1;
+  HIP_OK(hipMemsetAsync(d.anorm_dev.p, 0, sizeof(double), s));
+  hipLaunchKernelGGL(k_ds_rownorm, dim3(ds_nblk(c->NV, 256)), dim3(256), 0, s, c->NV, c->slice_off.p, c->slice_len.p, c->vals.p, d.anorm_dev.p);
+  HIP_OK(hipMemcpyAsync(&d.anorm, d.anorm_dev.p, sizeof(double), hipMemcpyDeviceToHost, s));
+  HIP_OK(hipStreamSynchronize(s));
   HIP_OK(hipGetLastError());
   d.numeric_valid = true;
   d.n_factor++;
@@ -130,14 +137,14 @@ static int direct_apply(tsl_ctx* c, const double* r, double* z) {
   const DsDev D = ds_dev(c);
   const size_t n3 = 3 * (size_t)c->NV;
   HIP_OK(hipMemcpyAsync(d.w.p, r, n3 * sizeof(double), hipMemcpyDeviceToDevice, s));
-  for (int l = 0; l < P.sym.n_levels; l++) {
-    const int lv0 = P.level_ptr[l], nf = P.level_ptr[l + 1] - lv0;
-    hipLaunchKernelGGL(k_ds_gemv, dim3(ds_nblk(P.level_max_pp[l], 16), nf), dim3(256), 0, s, D, lv0, 0, (const double*)d.w.p, z);
-    if (P.level_max_bp[l] > 0) hipLaunchKernelGGL(k_ds_gemv, dim3(ds_nblk(P.level_max_bp[l], 16), nf), dim3(256), 0, s, D, lv0, 1, (const double*)z, d.w.p);
+  for (int l = 0; l < P.n_levels; l++) {
+    const int o0 = P.wl_own_ptr[l], b0 = P.wl_bnd_ptr[l], o1 = P.wl_own_ptr[l + 1];
+    hipLaunchKernelGGL(k_ds_gemv, dim3(b0 - o0), dim3(256), 0, s, D, d.wl_front.p, d.wl_row.p, o0, 0, (const double*)d.w.p, z);
+    if (o1 > b0) hipLaunchKernelGGL(k_ds_gemv, dim3(o1 - b0), dim3(256), 0, s, D, d.wl_front.p, d.wl_row.p, b0, 1, (const double*)z, d.w.p);
   }
-  for (int l = P.sym.n_levels - 1; l >= 0; l--) {
-    const int lv0 = P.level_ptr[l], nf = P.level_ptr[l + 1] - lv0;
-    if (P.level_max_bp[l] > 0) hipLaunchKernelGGL(k_ds_gemv, dim3(ds_nblk(P.level_max_pp[l], 16), nf), dim3(256), 0, s, D, lv0, 2, (const double*)z, z);
+  for (int l = P.n_levels - 2; l >= 0; l--) {   // the top level has no boundary
+    const int o0 = P.wl_own_ptr[l], b0 = P.wl_bnd_ptr[l];
+    hipLaunchKernelGGL(k_ds_gemv, dim3(b0 - o0), dim3(256), 0, s, D, d.wl_front.p, d.wl_row.p, o0, 2, (const double*)z, z);
   }
   d.n_apply++;
   return 0;

@@ -20,6 +20,13 @@ struct DsFrontDesc {
   int scr_off;               // offset of this front's scratch inside the per-level scratch (doubles)
 };
 
+// fronts of one tree level with pivot blocks of similar size: one set of launches (level_sn[first .. first + count), sorted by pp descending)
+struct DsBatch {
+  int first, count, level;
+  int max_pp, max_ld, max_bp;
+  int act_off;   // act_n / act_ld [act_off + k]: fronts still active at block step k (a prefix) and their largest ld
+};
+
 struct DirectPlan {
   DirectSym sym;
   std::vector<DsFrontDesc> fr;
@@ -28,8 +35,12 @@ struct DirectPlan {
   std::vector<int> blk_ld;
   std::vector<long long> con_dst;  // per constraint x 16 (vertex pair a, b)
   std::vector<int> con_ld;
-  std::vector<int> level_ptr, level_sn;          // fronts per level (level 0 = leaves)
-  std::vector<int> level_max_pp, level_max_ld, level_max_bp;
+  std::vector<int> level_ptr, level_sn;          // fronts per level (level 0 = leaves), as-late-as-possible levels
+  std::vector<DsBatch> batches;                  // in level order
+  std::vector<int> act_n, act_ld;
+  // solve work lists: (front, first row) of every 16-row chunk of the own rows / boundary rows, level after level
+  std::vector<int> wl_front, wl_row, wl_own_ptr, wl_bnd_ptr;   // own chunks of level l: [wl_own_ptr[l], wl_bnd_ptr[l]); boundary chunks: [wl_bnd_ptr[l], wl_own_ptr[l + 1])
+  int n_levels = 0;
   long long arena = 0;      // doubles
   long long scratch = 0;    // doubles, max over the levels
   double flops = 0;
@@ -75,22 +86,53 @@ struct DirectPlan {
         rel.push_back(l);
       }
     }
-    // levels
+    // levels: as late as possible (a front sits one level below its parent), so that the dense FEM bodies and shallow subtrees
+    // are batched with fronts of their parent's neighbourhood instead of with the ~10^3 small leaves
     const int L = sym.n_levels;
+    n_levels = L;
+    std::vector<int> alap(S, L - 1);
+    for (int s = S - 1; s >= 0; s--) if (sym.parent[s] >= 0) alap[s] = alap[sym.parent[s]] - 1;
+    std::vector<std::vector<int>> by_level(L);
+    for (int s = 0; s < S; s++) by_level[alap[s]].push_back(s);
     level_ptr.assign(L + 1, 0); level_sn.clear();
-    level_max_pp.assign(L, 0); level_max_ld.assign(L, 0); level_max_bp.assign(L, 0);
+    batches.clear(); act_n.clear(); act_ld.clear();
+    wl_front.clear(); wl_row.clear(); wl_own_ptr.assign(L + 1, 0); wl_bnd_ptr.assign(L, 0);
     scratch = 0;
+    auto size_class = [](int pp) { int t = pp / DS_T - 1, c = 0; while (t > 0) { c++; t >>= 1; } return c; };  // 32 | 64 | 96-128 | 160-256 | ...
     for (int l = 0; l < L; l++) {
+      std::vector<int>& fl = by_level[l];
+      std::stable_sort(fl.begin(), fl.end(), [&](int a, int b) { return fr[a].pp > fr[b].pp; });
       long long scr = 0;
-      for (int s : sym.by_level[l]) {
-        level_sn.push_back(s);
+      for (size_t i = 0; i < fl.size(); i++) {
+        const int s = fl[i];
         DsFrontDesc& f = fr[s];
-        level_max_pp[l] = std::max(level_max_pp[l], f.pp); level_max_ld[l] = std::max(level_max_ld[l], f.ld); level_max_bp[l] = std::max(level_max_bp[l], f.bp);
+        if (i == 0 || size_class(f.pp) != size_class(fr[fl[i - 1]].pp)) {
+          DsBatch b{};
+          b.first = (int)level_sn.size(); b.count = 0; b.level = l;
+          batches.push_back(b);
+        }
+        DsBatch& b = batches.back();
+        b.count++;
+        b.max_pp = std::max(b.max_pp, f.pp); b.max_ld = std::max(b.max_ld, f.ld); b.max_bp = std::max(b.max_bp, f.bp);
+        level_sn.push_back(s);
         f.scr_off = (int)scr;
         scr += 2LL * DS_T * DS_T + (long long)DS_T * f.ld + (long long)f.pp * DS_T;  // pivot-block inverses (ping-pong), row panel, column panel
       }
       level_ptr[l + 1] = (int)level_sn.size();
       scratch = std::max(scratch, scr);
+      wl_own_ptr[l] = (int)wl_front.size();
+      for (int s : fl) for (int r = 0; r < fr[s].p; r += 16) { wl_front.push_back(s); wl_row.push_back(r); }
+      wl_bnd_ptr[l] = (int)wl_front.size();
+      for (int s : fl) for (int r = 0; r < fr[s].b; r += 16) { wl_front.push_back(s); wl_row.push_back(r); }
+    }
+    wl_own_ptr[L] = (int)wl_front.size();
+    for (DsBatch& b : batches) {
+      b.act_off = (int)act_n.size();
+      for (int k = 0; k * DS_T < b.max_pp; k++) {
+        int n = 0, mld = 0;
+        while (n < b.count && fr[level_sn[b.first + n]].pp > k * DS_T) { mld = std::max(mld, fr[level_sn[b.first + n]].ld); n++; }
+        act_n.push_back(n); act_ld.push_back(mld);
+      }
     }
     // static blocks
     const int NV = sym.NV;

@@ -25,6 +25,26 @@ struct DsDev {                 // device views shared by the kernels
   int* bad;                    // [0]: number of perturbed pivots of the last factorisation
 };
 
+// infinity norm of the SELL-64 matrix (largest absolute row sum), the yardstick of the solve's backward error; out must be zeroed
+__global__ void k_ds_rownorm(int NV, const int* __restrict__ slice_off, const int* __restrict__ slice_len, const double* __restrict__ vals, double* out) {
+  const int p = blockIdx.x * blockDim.x + threadIdx.x;
+  double m = 0.0;
+  if (p < NV) {
+    const int s = p >> 6, lane = p & 63;
+    const size_t base = (size_t)slice_off[s] * 9 + lane;
+    double r0 = 0, r1 = 0, r2 = 0;
+    for (int k = 0; k < slice_len[s]; k++) {
+      const double* b = vals + base + (size_t)k * 64 * 9;
+      r0 += fabs(b[0]) + fabs(b[64]) + fabs(b[128]);
+      r1 += fabs(b[192]) + fabs(b[256]) + fabs(b[320]);
+      r2 += fabs(b[384]) + fabs(b[448]) + fabs(b[512]);
+    }
+    m = fmax(r0, fmax(r1, r2));
+  }
+  m = wave_max(m);
+  if ((threadIdx.x & 63) == 0) atomicMax((unsigned long long*)out, (unsigned long long)__double_as_longlong(m));
+}
+
 // ---- assembly -------------------------------------------------------------------------------------------------------------
 // static pattern: block q of the CSR numbering lives at vals[csr2sell[q] + 64 e] (SELL-64, element e of the 3 x 3 block)
 __global__ void k_ds_assemble_blocks(long nnzb, const int* __restrict__ csr2sell, const double* __restrict__ vals, const long long* __restrict__ blk_dst,
@@ -303,12 +323,11 @@ __global__ void __launch_bounds__(256) k_ds_extend(DsDev D, int lv0) {
 //   mode 1 (up, F21):  w[bnd i] -= sum_j F21[i, j] t[own j]          (atomic: sibling fronts share boundary vertices)
 //   mode 2 (down, G):  x[own i]  = t[own i] - sum_j G[i, j] x[bnd j]  (x and t may alias)
 #define DS_VCHUNK 2048
-__global__ void __launch_bounds__(256) k_ds_gemv(DsDev D, int lv0, int mode, const double* vin, double* vout) {
+__global__ void __launch_bounds__(256) k_ds_gemv(DsDev D, const int* __restrict__ wl_front, const int* __restrict__ wl_row, int wl0, int mode, const double* vin, double* vout) {
   __shared__ double xs[DS_VCHUNK];
-  const DsFrontDesc f = D.fr[D.level_sn[lv0 + blockIdx.y]];
+  const DsFrontDesc f = D.fr[wl_front[wl0 + blockIdx.x]];
   const int nrows = mode == 1 ? f.b : f.p, ncols = mode == 2 ? f.b : f.p;
-  const int r0 = blockIdx.x * 16;
-  if (r0 >= nrows) return;
+  const int r0 = wl_row[wl0 + blockIdx.x];
   const int* vt = D.vtx + f.vtx_off;
   const int in_v0 = mode == 2 ? f.nv_own : 0, out_v0 = mode == 1 ? f.nv_own : 0;
   const double* M = D.A + f.off + (mode == 1 ? (size_t)f.pp * f.ld : 0) + (mode == 2 ? f.pp : 0);

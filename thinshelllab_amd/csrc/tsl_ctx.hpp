@@ -100,12 +100,14 @@ struct DirectSolver {
   std::vector<int> row_ptr;   // CSR numbering of the static block pattern (rows of h_rows)
   std::vector<int> h_cons;    // constraint vertices the current plan was built for
   bool plan_valid = false;
-  DevBuf<int> csr2sell, level_sn, rel, vtx, blk_ld, con_ld, bad;
+  DevBuf<int> csr2sell, level_sn, rel, vtx, blk_ld, con_ld, bad, wl_front, wl_row;
   DevBuf<long long> blk_dst, con_dst;
   DevBuf<DsFrontDesc> fr;
   DevBuf<double> arena, scr, w;
   long n_plans = 0, n_factor = 0, n_apply = 0, n_perturbed = 0;
   double t_plan = 0;          // host seconds spent in plan builds
+  double anorm = 0;           // infinity norm of the factorised operator's static part (backward-error yardstick)
+  DevBuf<double> anorm_dev;
 };
 
 struct tsl_ctx {
@@ -188,6 +190,7 @@ struct tsl_ctx {
   int mg_fr_rows = 32;   // coarse nodes per workgroup of k_st_first_restrict (16 / 32 / 64)
   DevBuf<float> bd_Binv;
   DevBuf<double> gm_V, gm_h;  // GMRES basis ((m+1) vectors) and projection coefficients
+  DevBuf<double> gm_Z;        // preconditioned basis of the flexible variant (direct preconditioner)
   int gmres_m = 300, use_gmres = 1, use_minres = 1, verbose = 0;
   // analytic_grad_system.Grad: pos_grad clamp (1 there, 1000 in analytic_grad_single) and whether angleref_grad is clamped too
   double adj_clamp = 1000.0;

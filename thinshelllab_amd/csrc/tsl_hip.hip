@@ -971,7 +971,7 @@ static int solve_perm(tsl_ctx* c, tsl_solve_stats* st) {
   const int NV = c->NV;
   const size_t n3 = 3 * (size_t)NV;
   const int gb = nblk(NV, 256);
-  st->iters = 0; st->restarts = 0; st->flag = 0; st->rel_residual = 0; st->method = 0; st->attained = 0;
+  st->iters = 0; st->restarts = 0; st->flag = 0; st->rel_residual = 0; st->method = 0; st->attained = 0; st->backward_error = 0;
   if (direct_enabled(c) && !c->ds_suspended) {
     // primary path on refined cloths: multifrontal LU of the operator (like the reference's spsolve) + GMRES refinement
     // against the operator product; the iterative hierarchy below only runs if that fails
@@ -982,8 +982,17 @@ static int solve_perm(tsl_ctx* c, tsl_solve_stats* st) {
     if (c->verbose) fprintf(stderr, "[tsl] direct factorisation + GMRES did not converge (rel_residual %.2e after %d iterations): iterative fallback\n", sd.rel_residual, sd.iters);
     c->ds_suspended = true;
     tsl_solve_stats s2;
+    const int maxit_keep = c->cg_maxit;
+    c->cg_maxit = std::min(c->cg_maxit, 20000);  // the hierarchy needs 1e4..1e5 iterations on the systems the factorisation is for
+    HIP_OK(hipMemcpyAsync(c->v_t4.p, c->v_x.p, 3 * (size_t)c->NV * sizeof(double), hipMemcpyDeviceToDevice, c->stream));  // the refined direct solution
     const int rc = solve_perm(c, &s2);
+    c->cg_maxit = maxit_keep;
     c->ds_suspended = false;
+    if (rc == 0 && s2.flag == 3 && !(s2.rel_residual < sd.rel_residual)) {  // keep the better of the two answers, flagged as not converged
+      HIP_OK(hipMemcpyAsync(c->v_x.p, c->v_t4.p, 3 * (size_t)c->NV * sizeof(double), hipMemcpyDeviceToDevice, c->stream));
+      *st = sd; st->iters = sd.iters + s2.iters; st->flag = 3; st->method = 4;
+      return 0;
+    }
     st->iters = sd.iters + s2.iters; st->restarts = s2.restarts + 1; st->rel_residual = s2.rel_residual; st->method = s2.method; st->attained = s2.attained;
     st->flag = s2.flag == 0 ? 1 : s2.flag;
     return rc;
@@ -1295,6 +1304,9 @@ static int gmres(tsl_ctx* c, tsl_solve_stats* st, bool direct) {
   double* dh = c->gm_h.p;  // [0, m+1): h ; [m+1, 2m+2): h2 ; [2m+2]: |w|^2
   const int o2 = m + 1, on = 2 * (m + 1);
   double *x = c->v_x.p, *r = c->v_r.p, *w = c->v_Ap.p, *z = c->v_z.p, *u = c->v_t0.p;
+  // direct mode keeps the preconditioned basis Z_j = M^-1 V_j (flexible GMRES): the update x += Z y needs no second application
+  if (direct && c->gm_Z.n < (size_t)m * n3 && c->gm_Z.alloc((size_t)m * n3)) return tsl_fail("out of device memory (GMRES Z basis)");
+  double* Zb = c->gm_Z.p;
   const bool mg = !direct && mg_active(c);
   if (!direct) {
     if (body_active(c) && !c->bd_valid) TSL_TRY(body_build_inverse(c));
@@ -1339,6 +1351,7 @@ static int gmres(tsl_ctx* c, tsl_solve_stats* st, bool direct) {
     int j = 0;
     for (; j < m; j++) {
       double* vj1 = V + (size_t)(j + 1) * n3;
+      if (direct) z = Zb + (size_t)j * n3;
       precond(V + (size_t)j * n3, z);
       launch_spmv(c, c->vals.p, z, w, -1, 0);
       HIP_OK(hipMemsetAsync(dh, 0, (size_t)(on + 1) * sizeof(double), s));
@@ -1377,10 +1390,13 @@ static int gmres(tsl_ctx* c, tsl_solve_stats* st, bool direct) {
       y[i] = d != 0 ? t0 / d : 0.0;
     }
     HIP_OK(hipMemcpyAsync(dh, y.data(), (size_t)k * sizeof(double), hipMemcpyHostToDevice, s));
-    HIP_OK(hipMemsetAsync(u, 0, n3 * sizeof(double), s));
-    hipLaunchKernelGGL(k_multi_axpy, dim3(gv), dim3(256), 0, s, n3, V, n3, k, dh, 1.0, u);
-    precond(u, z);
-    hipLaunchKernelGGL(k_axpby, dim3(gv), dim3(256), 0, s, n3, 1.0, z, 1.0, x);
+    if (direct) hipLaunchKernelGGL(k_multi_axpy, dim3(gv), dim3(256), 0, s, n3, Zb, n3, k, dh, 1.0, x);
+    else {
+      HIP_OK(hipMemsetAsync(u, 0, n3 * sizeof(double), s));
+      hipLaunchKernelGGL(k_multi_axpy, dim3(gv), dim3(256), 0, s, n3, V, n3, k, dh, 1.0, u);
+      precond(u, z);
+      hipLaunchKernelGGL(k_axpby, dim3(gv), dim3(256), 0, s, n3, 1.0, z, 1.0, x);
+    }
     HIP_OK(hipStreamSynchronize(s));  // y (host vector) is reused by the next cycle
     // true residual
     launch_spmv(c, c->vals.p, x, w, -1, 0);
@@ -1392,9 +1408,21 @@ static int gmres(tsl_ctx* c, tsl_solve_stats* st, bool direct) {
     st->rel_residual = beta / sqrt(bb);
     if (!std::isfinite(beta)) break;
     if (beta <= tol) { st->flag = 1; break; }
-    // attainable accuracy (same rule as the PCG restarts)
-    if (cycle > 0 && beta > 0.5 * beta_prev && beta <= 50 * tol) { st->flag = 1; st->attained = 1; break; }
-    if (cycle > (direct ? 3 : 20) && beta > 0.9 * beta_prev) break;  // stagnating restarts: hand over to the next solver
+    if (direct) {
+      // Attainable accuracy of a factorisation-based solve: the reference's spsolve returns a backward-stable solution, i.e. a
+      // residual of the order eps |H| |x|, which on the near-singular adjoint operators of a long rollout (|H| |x| / |b| up to
+      // 1e9) is ABOVE cg_tol |b|.  When refinement no longer halves the true residual the normwise backward error
+      // |b - Hx| / (|H|_inf |x| + |b|) decides: below 1e-13 the solution is what a direct solver delivers (reported as attained).
+      double xx;
+      TSL_TRY(norm2(x, &xx));
+      st->backward_error = beta / (c->ds.anorm * sqrt(xx) + sqrt(bb));
+      if (cycle > 0 && beta > 0.5 * beta_prev && st->backward_error <= 1e-13) { st->flag = 1; st->attained = 1; break; }
+      if (cycle >= 8) break;
+    } else {
+      // attainable accuracy (same rule as the PCG restarts)
+      if (cycle > 0 && beta > 0.5 * beta_prev && beta <= 50 * tol) { st->flag = 1; st->attained = 1; break; }
+      if (cycle > 20 && beta > 0.9 * beta_prev) break;  // stagnating restarts: hand over to BiCGStab
+    }
     beta_prev = beta;
     st->restarts++;
   }
@@ -1654,7 +1682,7 @@ extern "C" int tsl_step(tsl_ctx* c, double* pos, double* prev, double* vel, doub
     auto t3 = now();
     t_energy += secs(t0, t1); t_asm += secs(t1, t2); t_solve += secs(t2, t3);
     st.cg_iters += ss.iters; st.solves++; st.restarts += ss.restarts; st.fallback += (ss.flag == 1); st.unconverged += (ss.flag == 3); st.attained += ss.attained;
-    st.max_rel_residual = std::max(st.max_rel_residual, ss.rel_residual);
+    st.max_rel_residual = std::max(st.max_rel_residual, ss.rel_residual); st.max_backward_error = std::max(st.max_backward_error, ss.backward_error);
     // p_norm = max |p|  (calc_p_norm :1096-1103)
     HIP_OK(hipMemsetAsync(&SC(c)->pmax, 0, sizeof(double), s));
     hipLaunchKernelGGL(k_absmax, dim3(gsz(n3)), dim3(256), 0, s, n3, c->pdir.p, &SC(c)->pmax);
