@@ -102,3 +102,27 @@ extern "C" int dsref_solve(int NV, const int* row_ptr, const int* col, const dou
   if (stats) { stats[0] = S; stats[1] = P.n_levels; stats[2] = (double)P.arena; stats[3] = P.flops; stats[4] = min_piv; }
   return 0;
 }
+
+// plan statistics for a pattern + constraint set (scripts / tests): prints the batches of the factorisation
+extern "C" int dsref_plan_stats(int NV, const int* row_ptr, const int* col, int n_grids, const int* grids, int n_blocks, const int* blocks, int n_cons, const int* cons, int leaf,
+                                int verbose, double* out) {
+  std::vector<std::vector<int>> adj(NV);
+  for (int r = 0; r < NV; r++) adj[r].assign(col + row_ptr[r], col + row_ptr[r + 1]);
+  std::vector<int> rp(row_ptr, row_ptr + NV + 1);
+  std::vector<DsGrid> G; std::vector<DsBlock> B;
+  for (int i = 0; i < n_grids; i++) G.push_back({grids[3 * i], grids[3 * i + 1], grids[3 * i + 2]});
+  for (int i = 0; i < n_blocks; i++) B.push_back({blocks[2 * i], blocks[2 * i + 1]});
+  DirectPlan P;
+  P.sym.build_partition(NV, adj, G, B, leaf);
+  const int rc = P.build(adj, rp, cons, n_cons);
+  if (rc) return rc;
+  int steps = 0;
+  double solve_bytes = 0;
+  for (const DsFrontDesc& f : P.fr) solve_bytes += 8.0 * ((double)f.p * f.p + 2.0 * f.p * f.b);
+  for (const DsBatch& b : P.batches) {
+    steps += b.max_pp / DS_T;
+    if (verbose) printf("level %2d: %5d fronts  max pp %4d  max ld %4d  max bp %4d\n", b.level, b.count, b.max_pp, b.max_ld, b.max_bp);
+  }
+  out[0] = P.sym.n_sn; out[1] = P.n_levels; out[2] = (double)P.batches.size(); out[3] = steps; out[4] = P.flops; out[5] = (double)P.arena * 8; out[6] = solve_bytes;
+  return 0;
+}

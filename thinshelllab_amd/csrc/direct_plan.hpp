@@ -98,7 +98,8 @@ struct DirectPlan {
     batches.clear(); act_n.clear(); act_ld.clear();
     wl_front.clear(); wl_row.clear(); wl_own_ptr.assign(L + 1, 0); wl_bnd_ptr.assign(L, 0);
     scratch = 0;
-    auto size_class = [](int pp) { int t = pp / DS_T - 1, c = 0; while (t > 0) { c++; t >>= 1; } return c; };  // 32 | 64 | 96-128 | 160-256 | ...
+    // a new batch starts where the pivot block falls below a quarter of the batch's largest (empty workgroups of the smaller
+    // fronts are cheap, an extra batch costs its block steps in sequence)
     for (int l = 0; l < L; l++) {
       std::vector<int>& fl = by_level[l];
       std::stable_sort(fl.begin(), fl.end(), [&](int a, int b) { return fr[a].pp > fr[b].pp; });
@@ -106,7 +107,7 @@ struct DirectPlan {
       for (size_t i = 0; i < fl.size(); i++) {
         const int s = fl[i];
         DsFrontDesc& f = fr[s];
-        if (i == 0 || size_class(f.pp) != size_class(fr[fl[i - 1]].pp)) {
+        if (i == 0 || 4 * f.pp <= batches.back().max_pp) {
           DsBatch b{};
           b.first = (int)level_sn.size(); b.count = 0; b.level = l;
           batches.push_back(b);

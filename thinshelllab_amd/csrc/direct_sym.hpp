@@ -4,7 +4,8 @@
 // Here the Krylov solvers of tsl_solve are preconditioned by a multifrontal LU of the same operator:
 //   * cloth vertices are ordered by geometric nested dissection of their (N+1) x (M+1) grid (separators two grid lines wide, then
 //     trimmed against the real adjacency: the hinge stencil reaches two lines only from every second vertex),
-//   * every FEM body is one dense supernode ordered before the cloth (its contacts make the touched cloth vertices its boundary),
+//   * every FEM body is dense: its unconstrained vertices are one supernode eliminated first, its constrained vertices are
+//     eliminated in front of the dissection subtree that holds the cloth vertices they touch,
 //   * the contact constraints of the current step add cliques to the adjacency, so boundaries, the elimination tree and the
 //     front layout are recomputed whenever the constraint set changes (a few ms of host work per time step).
 // Granularity: vertices (3 x 3 blocks).  A front of supernode s holds its own vertices followed by its boundary vertices
@@ -20,13 +21,21 @@ struct DsBlock { int v_offset, n_verts; };  // a dense body
 
 struct DirectSym {
   int NV = 0;
-  // ---- static partition
+  // ---- static partition of the cloth grids (build_partition): supernodes in postorder of the dissection trees
+  std::vector<int> c_order;   // cloth vertices in static elimination order
+  std::vector<int> c_ptr;     // static supernode -> [first, last) in c_order
+  std::vector<int> c_lo;      // static supernode -> first position of its whole subtree (the subtree ends with the supernode itself)
+  std::vector<int> c_grid;    // static supernode -> grid
+  std::vector<int> c_pos;     // vertex -> position in c_order, -1 for vertices outside the grids
+  std::vector<int> c_sn;      // vertex -> static supernode, -1 outside the grids
+  std::vector<DsBlock> blocks;
+  std::vector<int> body_of;   // vertex -> dense body, -1 if none
+  std::vector<int> loose;     // vertices in no grid and no body
+  // ---- per constraint set (build_tree)
   std::vector<int> order, epos, sn_of, sn_ptr;  // position -> vertex, vertex -> position, vertex -> supernode, supernode -> [first, last) position
   int n_sn = 0;
-  // ---- per constraint set
   std::vector<std::vector<int>> bnd;  // boundary vertices per supernode, sorted by elimination position
   std::vector<int> parent, level;
-  std::vector<std::vector<int>> by_level;
   int n_levels = 0;
 
   int own(int s) const { return sn_ptr[s + 1] - sn_ptr[s]; }
@@ -42,43 +51,43 @@ struct DirectSym {
     return -1;
   }
 
-  // ------------------------------------------------------------------------------------------ static: ordering
+  // ------------------------------------------------------------------------------------------ static: dissection of the grids
   // adj: sorted adjacency of every vertex (may include the vertex itself)
-  void build_partition(int nv, const std::vector<std::vector<int>>& adj, const std::vector<DsGrid>& grids, const std::vector<DsBlock>& blocks, int leaf_verts) {
+  void build_partition(int nv, const std::vector<std::vector<int>>& adj, const std::vector<DsGrid>& grids, const std::vector<DsBlock>& blocks_in, int leaf_verts) {
     NV = nv;
-    order.clear(); sn_ptr.assign(1, 0);
-    std::vector<char> placed(nv, 0);
-    auto close_sn = [&]() { if ((int)order.size() > sn_ptr.back()) sn_ptr.push_back((int)order.size()); };
-    for (const DsBlock& b : blocks) {
-      for (int v = b.v_offset; v < b.v_offset + b.n_verts; v++) { order.push_back(v); placed[v] = 1; }
-      close_sn();
-    }
+    blocks = blocks_in;
+    c_order.clear(); c_ptr.assign(1, 0); c_lo.clear(); c_grid.clear();
+    c_pos.assign(nv, -1); c_sn.assign(nv, -1); body_of.assign(nv, -1); loose.clear();
+    for (size_t b = 0; b < blocks.size(); b++)
+      for (int v = blocks[b].v_offset; v < blocks[b].v_offset + blocks[b].n_verts; v++) body_of[v] = (int)b;
     std::vector<int> side(nv, 0);  // scratch of the bisection: 1 left, 2 right, 3 separator
-    for (const DsGrid& g : grids) {
+    for (size_t gi = 0; gi < grids.size(); gi++) {
+      const DsGrid& g = grids[gi];
       std::vector<int> region((size_t)(g.N + 1) * (g.M + 1));
-      for (size_t k = 0; k < region.size(); k++) { region[k] = g.v_offset + (int)k; placed[region[k]] = 1; }
-      dissect(g, adj, region, leaf_verts, side, close_sn);
+      for (size_t k = 0; k < region.size(); k++) region[k] = g.v_offset + (int)k;
+      dissect(g, (int)gi, adj, region, leaf_verts, side);
     }
-    for (int v = 0; v < nv; v++)
-      if (!placed[v]) { order.push_back(v); close_sn(); }
-    n_sn = (int)sn_ptr.size() - 1;
-    epos.assign(nv, 0); sn_of.assign(nv, 0);
-    for (int p = 0; p < nv; p++) epos[order[p]] = p;
-    for (int s = 0; s < n_sn; s++)
-      for (int p = sn_ptr[s]; p < sn_ptr[s + 1]; p++) sn_of[order[p]] = s;
+    for (size_t q = 0; q < c_order.size(); q++) c_pos[c_order[q]] = (int)q;
+    for (size_t s = 0; s + 1 < c_ptr.size(); s++)
+      for (int q = c_ptr[s]; q < c_ptr[s + 1]; q++) c_sn[c_order[q]] = (int)s;
+    for (int v = 0; v < nv; v++) if (c_pos[v] < 0 && body_of[v] < 0) loose.push_back(v);
   }
 
-  template <class F>
-  void dissect(const DsGrid& g, const std::vector<std::vector<int>>& adj, std::vector<int>& region, int leaf_verts, std::vector<int>& side, F&& close_sn) {
+  void close_static(int lo, int grid) {
+    if ((int)c_order.size() > c_ptr.back()) { c_ptr.push_back((int)c_order.size()); c_lo.push_back(lo); c_grid.push_back(grid); }
+  }
+
+  void dissect(const DsGrid& g, int gi, const std::vector<std::vector<int>>& adj, std::vector<int>& region, int leaf_verts, std::vector<int>& side) {
     if (region.empty()) return;
+    const int lo = (int)c_order.size();
     const int W = g.M + 1;
     int i0 = 1 << 30, i1 = -1, j0 = 1 << 30, j1 = -1;
     for (int v : region) { const int i = (v - g.v_offset) / W, j = (v - g.v_offset) % W; i0 = std::min(i0, i); i1 = std::max(i1, i); j0 = std::min(j0, j); j1 = std::max(j1, j); }
     const int ni = i1 - i0 + 1, nj = j1 - j0 + 1;
     if ((int)region.size() <= leaf_verts || (ni <= 3 && nj <= 3)) {
       std::sort(region.begin(), region.end());
-      for (int v : region) order.push_back(v);
-      close_sn();
+      for (int v : region) c_order.push_back(v);
+      close_static(lo, gi);
       return;
     }
     const bool along_i = ni >= nj;
@@ -99,15 +108,19 @@ struct DirectSym {
     for (int v : region) { if (side[v] == 1) L.push_back(v); else if (side[v] == 2) R.push_back(v); else S.push_back(v); }
     for (int v : region) side[v] = 0;
     std::vector<int>().swap(region);
-    dissect(g, adj, L, leaf_verts, side, close_sn);
-    dissect(g, adj, R, leaf_verts, side, close_sn);
+    dissect(g, gi, adj, L, leaf_verts, side);
+    dissect(g, gi, adj, R, leaf_verts, side);
     std::sort(S.begin(), S.end(), [&](int a, int b) { return other(a) != other(b) ? other(a) < other(b) : coord(a) < coord(b); });
-    for (int v : S) order.push_back(v);
-    close_sn();
+    for (int v : S) c_order.push_back(v);
+    close_static(lo, gi);
   }
 
-  // ------------------------------------------------------------------------------------------ per constraint set: boundaries and tree
-  // extra: additional cliques (the 4 vertices of every contact constraint), flattened, `clique` vertices each
+  // ------------------------------------------------------------------------------------------ per constraint set: order, boundaries, tree
+  // extra: additional cliques (the 4 vertices of every contact constraint), flattened, `clique` vertices each.
+  // Dense bodies: the vertices of a body that sit in no constraint (its interior) form one supernode eliminated first -- its
+  // boundary is inside the body --, the constrained ones are eliminated right before the smallest dissection subtree that holds
+  // every grid vertex they are coupled to (they ride in the fronts between those leaves and that separator), merged per such
+  // place; coupled to anything else, they go to the end of the order.
   void build_tree(const std::vector<std::vector<int>>& adj, const int* extra, int n_extra, int clique) {
     std::vector<std::vector<int>> xadj;  // contact adjacency, only for touched vertices
     std::vector<int> xidx(NV, -1);
@@ -117,6 +130,49 @@ struct DirectSym {
         if (xidx[va] < 0) { xidx[va] = (int)xadj.size(); xadj.emplace_back(); }
         for (int b = 0; b < clique; b++) if (b != a) xadj[xidx[va]].push_back(extra[e * clique + b]);
       }
+    // ---- order
+    const int n_static = (int)c_ptr.size() - 1, END = n_static;
+    const int nb = (int)blocks.size();
+    std::vector<int> ins(nb, -1);                 // static supernode the constrained vertices of the body are placed in front of
+    std::vector<std::vector<int>> K(nb), I(nb);
+    for (int b = 0; b < nb; b++) {
+      int pmin = 1 << 30, pmax = -1, grid = -1;
+      bool to_end = false;
+      for (int v = blocks[b].v_offset; v < blocks[b].v_offset + blocks[b].n_verts; v++) {
+        if (xidx[v] < 0) { I[b].push_back(v); continue; }
+        K[b].push_back(v);
+        for (int u : xadj[xidx[v]]) {
+          if (body_of[u] == b) continue;
+          if (c_pos[u] < 0) { to_end = true; continue; }
+          const int gu = c_grid[c_sn[u]];
+          if (grid >= 0 && gu != grid) to_end = true;
+          grid = gu;
+          pmin = std::min(pmin, c_pos[u]); pmax = std::max(pmax, c_pos[u]);
+        }
+      }
+      if (K[b].empty()) continue;
+      if (to_end || pmax < 0) { ins[b] = END; continue; }
+      int s = c_sn[c_order[pmax]];
+      while (s < n_static && !(c_lo[s] <= pmin && c_ptr[s + 1] > pmax && c_grid[s] == grid)) s++;
+      ins[b] = s;  // == END if nothing qualifies
+    }
+    order.clear(); sn_ptr.assign(1, 0);
+    auto close_sn = [&]() { if ((int)order.size() > sn_ptr.back()) sn_ptr.push_back((int)order.size()); };
+    for (int b = 0; b < nb; b++) { for (int v : I[b]) order.push_back(v); close_sn(); }
+    for (int v : loose) { order.push_back(v); close_sn(); }
+    std::vector<std::vector<int>> at(n_static + 1);
+    for (int b = 0; b < nb; b++) if (ins[b] >= 0) at[ins[b]].push_back(b);
+    for (int s = 0; s <= n_static; s++) {
+      for (int b : at[s]) for (int v : K[b]) order.push_back(v);
+      close_sn();
+      if (s < n_static) { for (int q = c_ptr[s]; q < c_ptr[s + 1]; q++) order.push_back(c_order[q]); close_sn(); }
+    }
+    n_sn = (int)sn_ptr.size() - 1;
+    epos.assign(NV, 0); sn_of.assign(NV, 0);
+    for (int p = 0; p < NV; p++) epos[order[p]] = p;
+    for (int s = 0; s < n_sn; s++)
+      for (int p = sn_ptr[s]; p < sn_ptr[s + 1]; p++) sn_of[order[p]] = s;
+    // ---- boundaries and elimination tree
     bnd.assign(n_sn, {});
     parent.assign(n_sn, -1);
     level.assign(n_sn, 0);
@@ -141,8 +197,6 @@ struct DirectSym {
       level[s] = lv;
       n_levels = std::max(n_levels, lv + 1);
     }
-    by_level.assign(n_levels, {});
-    for (int s = 0; s < n_sn; s++) by_level[level[s]].push_back(s);
   }
 
   // factorisation flops (inverse of the pivot block, G = W F12, Schur complement) and front storage in doubles

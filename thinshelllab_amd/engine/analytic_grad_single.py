@@ -78,12 +78,25 @@ class Grad:
         ctx.set_param("contact", 0.0 if f_contact is None else 1.0)
         self.last_stats = ctx.adjoint_step(step, self.tot_timestep, self.pos_buffer.t, self.pos_grad.t, self.ref_angle_buffer.t, self.angleref_grad.t,
                                            sys.tmp_z_frozen.t, self.damping)
+        self.check_solve(step)
         # leave the scene in the state the reference leaves it in (copy_pos_and_refangle + gripper.set)
         sys.copy_pos_and_refangle(self, step)
         if self.n_part > 0 and hasattr(sys, "gripper"):
             sys.gripper.set(self.gripper_pos_buffer, self.gripper_rot_buffer, step)
             if step > 0:
                 self.get_gripper_grad(step, sys)
+
+    def check_solve(self, step):
+        """The reference's H.solve is an exact sparse solve (sparse_solver.py:85-105); an adjoint solve that did NOT converge would
+        silently corrupt pos_grad / gripper_grad of every earlier step, so it raises (set ``allow_unconverged`` to collect instead)."""
+        st = self.last_stats
+        self.worst_rel_residual = max(getattr(self, "worst_rel_residual", 0.0), st["rel_residual"])
+        if st["flag"] == 3:
+            self.unconverged = getattr(self, "unconverged", 0) + 1
+            if not getattr(self, "allow_unconverged", False):
+                from .._lib import TslError
+                raise TslError(f"transfer_grad(step {step}): linear solve not converged (rel_residual {st['rel_residual']:.3e} after {st['iters']} iterations, "
+                               f"method {st['method']}); the gradients of earlier steps would be wrong")
 
     # ---- loss seeds
     def get_loss(self, sys):  # :259-263

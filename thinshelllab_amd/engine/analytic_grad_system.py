@@ -62,6 +62,10 @@ class Grad:
             self.gripper_pos_buffer.t[step].copy_(sys.gripper.pos.t)
             self.gripper_rot_buffer.t[step].copy_(sys.gripper.rot.t)
 
+    def check_solve(self, step):
+        from .analytic_grad_single import Grad as _G
+        _G.check_solve(self, step)
+
     def clamp_grad(self, step):  # :104-109
         self.pos_grad.t[step].clamp_(-1, 1)
 
@@ -72,6 +76,7 @@ class Grad:
         try:
             self.last_stats = ctx.adjoint_step(step, self.tot_timestep, self.pos_buffer.t, self.pos_grad.t, self.ref_angle_buffer.t, self.angleref_grad.t,
                                                sys.tmp_z_frozen.t, self.damping)
+            self.check_solve(step)
             if self.count_friction_grad:   # :150-153: either the friction coefficient or the stiffness parameters
                 self.grad_friction_coef[None] = self.grad_friction_coef[None] + ctx.friction_grad(self.pos_buffer.t[step])
                 g = dict(kb=0.0, mu=0.0, lam=0.0)
