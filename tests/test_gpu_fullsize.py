@@ -20,15 +20,18 @@ def _residual(ctx, b, x):
 
 
 def test_cfg2_drape_71_forward_steps():
+    """SURVEY 8d cfg2 at its full length: 50 forward steps of the pinned 71 x 71 drape"""
     from thinshelllab_amd.task_scene.Scene_drape import Scene
     s = Scene(cloth_size=0.1 / 15 * 71, N=71, M=71, Kb=100.0, k_angle=3.14, perturb=1e-4)
     s.init_all()
     E_prev = None
-    for f in range(1, 6):
+    for f in range(1, 51):
         E0 = s.compute_energy()
         st = s.time_step(None, f)
-        assert st["newton_iters"] < 50 and st["last_delta"] < 1e-7, st          # Newton converged below the reference's stop rule
-        assert st["fallback"] == 0
+        if f <= 5:  # the first steps converge below the reference's stop rule; later the falling sheet runs into the cap of 50 like the reference
+            assert st["newton_iters"] < 50 and st["last_delta"] < 1e-7, st
+        assert st["fallback"] == 0 and st["unconverged"] == 0 and st["max_rel_residual"] < 1e-9, (f, st)
+        assert np.isfinite(s.pos.to_numpy()).all()
     # linear solve of the last state: residual against the exported operator, and linearity
     s.compute_residual_and_Hessian(spd=True)
     ctx = s._ctx
@@ -52,22 +55,27 @@ def test_cfg3_folding_200x100_step_and_adjoint():
     s.mu_cloth_elastic[None] = 5.0
     s.prev_pos.copy_from(s.pos)
     assert s.cloths[0].NF == 40000
-    T = 3
+    T = 26   # half of SURVEY 8d's T = 50: ten steps of -z, then +x (the full length doubles the run time of this test, nothing else)
     n_part = s.gripper.n_part
     g = Grad(s, T, n_part); g.init_mass(s)
     g.copy_pos(s, 0)
-    dpos = np.zeros((n_part, 3)); drot = np.zeros((n_part, 3)); dpos[:, 2] = -2e-4      # pad moves -z 2e-4 m per step
     for f in range(1, T):
+        dpos = np.zeros((n_part, 3)); drot = np.zeros((n_part, 3))
+        if f <= 10:
+            dpos[:, 2] = -2e-4      # pad moves -z 2e-4 m per step for ten steps,
+        else:
+            dpos[:, 0] = 2e-4       # then +x 2e-4 m per step
         s.action(f, dpos, drot)
-        E0 = s.compute_energy()
         st = s.time_step(projection_query, f)
         g.copy_pos(s, f)
         assert np.isfinite(s.pos.to_numpy()).all()
         assert st["nc"] >= 0 and st["newton_iters"] >= 1
+        assert st["unconverged"] == 0 and st["max_rel_residual"] < 1e-8, (f, st)
     g.get_loss_fold(s, 1.0, -1.0)
     for st_ in range(T - 1, 0, -1):
-        g.transfer_grad(st_, s, projection_query)
-        assert g.last_stats["flag"] in (0, 1) and g.last_stats["rel_residual"] < 1e-8, g.last_stats
+        g.transfer_grad(st_, s, projection_query)   # raises on an unconverged solve
+        ls = g.last_stats
+        assert ls["flag"] in (0, 1) and (ls["rel_residual"] < 1e-8 or ls["backward_error"] < 1e-13), (st_, ls)
     assert np.isfinite(g.pos_grad.to_numpy()).all() and np.abs(g.gripper_grad.to_numpy()).max() > 0
     # the adjoint operator of the last processed step: independent residual check of a solve with the un-projected Hessian
     s.compute_Hessian(spd=False)
@@ -78,13 +86,65 @@ def test_cfg3_folding_200x100_step_and_adjoint():
     assert stx["flag"] in (0, 1) and r < 1e-8, (stx, r)
 
 
+def test_cfg4_balancing_224_rollout_and_adjoint():
+    """cfg4 at the bench's drive for 14 steps (contacts build up to ~200) and the complete reverse sweep: every linear solve of the
+    forward Newton loops and of the adjoint steps converged (the reference's spsolve is exact every time), and one adjoint solution
+    is checked independently against the exported un-projected operator."""
+    import scipy.sparse.linalg as spl
+    from thinshelllab_amd.engine.analytic_grad_single import Grad
+    from thinshelllab_amd.engine.geometry import projection_query
+    from thinshelllab_amd.task_scene.Scene_balancing import Scene
+    s = Scene(cloth_size=0.12, cloth_N=224, cloth_M=224)
+    s.init_all()
+    s.mu_cloth_elastic[None] = 5.0
+    s.prev_pos.copy_from(s.pos)
+    T = 15
+    n_part = s.gripper.n_part
+    g = Grad(s, T, n_part); g.init_mass(s)
+    g.copy_pos(s, 0)
+    dpos = np.zeros((n_part, 3)); drot = np.zeros((n_part, 3)); dpos[:, 2] = [1e-4, -1e-4][:n_part]
+    nc_max = 0
+    for f in range(1, T):
+        s.action(f, dpos, drot)
+        st = s.time_step(projection_query, f)
+        g.copy_pos(s, f)
+        nc_max = max(nc_max, st["nc"])
+        assert np.isfinite(s.pos.to_numpy()).all()
+        assert st["unconverged"] == 0 and st["fallback"] == 0, (f, st)
+        assert st["max_rel_residual"] < 1e-8 and st["energy"] == st["energy"], (f, st)
+    assert nc_max > 100
+    g.get_loss_balance(s)
+    worst = 0.0
+    for st_ in range(T - 1, 0, -1):
+        g.transfer_grad(st_, s, projection_query)   # raises on an unconverged solve
+        ls = g.last_stats
+        assert ls["flag"] == 0 and ls["method"] == 4 and ls["iters"] <= 12, (st_, ls)
+        # near-singular un-projected operators (|H| |x| / |b| up to 1e9 late in the sweep): the relative residual a backward-stable
+        # direct solve -- the reference's spsolve -- can reach is eps |H| |x| / |b|; those solves are accepted on their normwise
+        # backward error (attained = 1), everything else on rel_residual <= cg_tol
+        assert ls["rel_residual"] < 1e-8 or (ls["attained"] == 1 and ls["backward_error"] < 1e-14), (st_, ls)
+        worst = max(worst, ls["rel_residual"])
+    assert np.isfinite(g.pos_grad.to_numpy()).all() and np.abs(g.gripper_grad.to_numpy()).max() > 0
+    # independent check: the un-projected operator of the current state, a random right-hand side on the free dofs, scipy's sparse LU
+    s.compute_Hessian(spd=False)
+    ctx = s._ctx
+    b = torch.as_tensor(np.random.default_rng(2).normal(size=3 * s.tot_NV), device=s.device) * _free_mask(s)
+    x, stx = ctx.solve(b)
+    r, H = _residual(ctx, b, x)
+    assert stx["flag"] == 0 and r < 1e-9, (stx, r)
+    xs = spl.splu(H.tocsc()).solve(b.cpu().numpy())
+    assert np.linalg.norm(x.cpu().numpy() - xs) <= 1e-5 * np.linalg.norm(xs)
+
+
 def test_cfg4_balancing_224_contact_solve():
+    """the iterative hierarchy (multigrid PCG), which stays the solver of coarse scenes and the fallback of the direct path"""
     from thinshelllab_amd.task_scene.Scene_balancing import Scene
     from thinshelllab_amd.engine.geometry import projection_query
     s = Scene(cloth_size=0.12, cloth_N=224, cloth_M=224)
     s.init_all()
     s.mu_cloth_elastic[None] = 5.0
     s.prev_pos.copy_from(s.pos)
+    s._ensure_ctx().set_param("direct", 0)
     assert s.cloths[0].NF == 100352
     n_part = s.gripper.n_part
     dpos = np.zeros((n_part, 3)); drot = np.zeros((n_part, 3)); dpos[:, 2] = [1e-4, -1e-4][:n_part]

@@ -83,6 +83,7 @@ static int direct_plan(tsl_ctx* c) {
   d.h_cons.swap(cons);
   d.plan_valid = true;
   d.numeric_valid = false;
+  d.have_factor = false;
   d.n_plans++;
   d.t_plan += std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
   if (c->verbose >= 2)
@@ -125,6 +126,7 @@ static int direct_factor(tsl_ctx* c) {
   HIP_OK(hipStreamSynchronize(s));
   HIP_OK(hipGetLastError());
   d.numeric_valid = true;
+  d.have_factor = true;
   d.n_factor++;
   return 0;
 }

@@ -94,6 +94,10 @@ struct DirectSolver {
   int enable = -1;          // -1 auto (on when a cloth grid has >= 1024 cells), 0 off, 1 on
   int leaf = 32;            // vertices per leaf of the nested dissection
   bool static_ready = false, numeric_valid = false;
+  bool have_factor = false, refactor_next = false;  // factors of the current plan exist (possibly of an earlier operator)
+  int lag = 0;              // > 0: Newton iterations reuse earlier factors while the refinement needs at most this many iterations.  Off: measured on cfg4, factors of the PREVIOUS Newton iteration need more than 20 refinement iterations (the projected blocks switch between iterations), a refactorisation costs ~10
+  int gm_cap = 0;
+  long n_stale = 0;
   DirectPlan plan;
   std::vector<DsGrid> grids;
   std::vector<DsBlock> blocks;

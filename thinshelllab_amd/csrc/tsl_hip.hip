@@ -329,6 +329,7 @@ extern "C" int tsl_set_param(tsl_ctx* c, const char* key, double v) {
   else if (k == "minres") c->use_minres = (int)v;
   else if (k == "verbose") c->verbose = (int)v;
   else if (k == "direct") { c->ds.enable = (int)v; c->ds.numeric_valid = false; }
+  else if (k == "direct_lag") c->ds.lag = (int)v;
   else if (k == "direct_leaf") { c->ds.leaf = std::max(4, (int)v); c->ds.static_ready = false; c->ds.plan_valid = false; c->ds.numeric_valid = false; }
   else if (k == "fwd_spd_pc") c->fwd_spd_pc = (int)v;
   else if (k == "gmres_m") c->gmres_m = (int)v;
@@ -974,10 +975,33 @@ static int solve_perm(tsl_ctx* c, tsl_solve_stats* st) {
   st->iters = 0; st->restarts = 0; st->flag = 0; st->rel_residual = 0; st->method = 0; st->attained = 0; st->backward_error = 0;
   if (direct_enabled(c) && !c->ds_suspended) {
     // primary path on refined cloths: multifrontal LU of the operator (like the reference's spsolve) + GMRES refinement
-    // against the operator product; the iterative hierarchy below only runs if that fails
-    TSL_TRY(direct_factor(c));
+    // against the operator product; the iterative hierarchy below only runs if that fails.
+    // Inside a time step the factors of an earlier Newton iteration of the same constraint set are reused as long as the
+    // refinement converges within `lag` iterations (the operator changes little between iterations; a refactorisation costs
+    // ~10 applications); the solution is always refined against the CURRENT operator to the same tolerance.
+    DirectSolver& d = c->ds;
     tsl_solve_stats sd = *st;
+    bool stale = false;
+    if (!d.numeric_valid) {
+      TSL_TRY(direct_plan(c));
+      stale = c->in_step && d.lag > 0 && d.have_factor && !d.refactor_next;
+      if (!stale) TSL_TRY(direct_factor(c));
+    }
+    d.refactor_next = false;
+    d.gm_cap = stale ? d.lag : 0;
     TSL_TRY(gmres(c, &sd, true));
+    d.gm_cap = 0;
+    if (stale) {
+      d.n_stale++;
+      if (sd.flag != 1 || sd.iters > (2 * d.lag) / 3) d.refactor_next = true;   // the next iteration starts from fresh factors
+      if (sd.flag != 1) {
+        const int it0 = sd.iters;
+        TSL_TRY(direct_factor(c));
+        sd = *st;
+        TSL_TRY(gmres(c, &sd, true));
+        sd.iters += it0;
+      }
+    }
     if (sd.flag == 1) { *st = sd; st->flag = 0; st->method = 4; return 0; }
     if (c->verbose) fprintf(stderr, "[tsl] direct factorisation + GMRES did not converge (rel_residual %.2e after %d iterations): iterative fallback\n", sd.rel_residual, sd.iters);
     c->ds_suspended = true;
@@ -1362,6 +1386,7 @@ static int gmres(tsl_ctx* c, tsl_solve_stats* st, bool direct) {
       hipLaunchKernelGGL(k_dot, dim3(DOT_BLOCKS), dim3(256), 0, s, n3, w, w, dh + on);
       TSL_TRY(read_h(on + 1));
       total++; st->iters++;
+      if (direct && c->ds.gm_cap > 0 && total > c->ds.gm_cap) return 0;  // stale factors: give up, the caller refactorises (flag stays 3)
       const double hn = sqrt(std::max(hh[on], 0.0));
       double* Hj = &H[(size_t)j * (m + 1)];  // column j
       for (int i = 0; i <= j; i++) Hj[i] = hh[i] + hh[o2 + i];
