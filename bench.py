@@ -1,27 +1,31 @@
 #!/usr/bin/env python
 """Headline benchmark: element-steps/s (fwd+adjoint) of the implicit thin-shell step on MI355X.
 
-    python bench.py --gpus N --steps K --warmup W          (N > 1: launched by torch.distributed.run)
+    python bench.py --gpus N --steps K --warmup W      (N > 1: re-executes itself under torch.distributed.run, one rank per GPU;
+                                                        under an external launcher the ranks are taken from the environment)
 
 Default workload = BASELINE.json configs[3] ("cfg4": cloth on ball + 4 tactile pads, 100k triangles, contact), the
 configuration the metric is quoted on; --workload drape runs the contact-free pinned cloth of the same size.
-One "step" = one implicit-Euler time step of the workload scene (gripper drive, contact detection, Newton loop with
-PCG solves and line search, velocity / plastic update: BaseScene.time_step) PLUS its reverse-mode adjoint step
-(Grad.transfer_grad: contact re-detection, un-projected Hessian, one linear solve, back-propagation kernels).  The timed region runs
-K forward steps onto the tape and then the K adjoint steps of the same rollout, all state resident in HBM.
-value = cloth triangles x K x n_gpus / wall seconds (max over ranks).  Ranks run independent scene rollouts
+One "step" = one implicit-Euler time step of the workload scene (gripper drive, contact detection, Newton loop with one sparse
+factorisation + refined solve per iteration and the halving line search, velocity / plastic update: BaseScene.time_step) PLUS its
+reverse-mode adjoint step (Grad.transfer_grad: contact re-detection, un-projected Hessian, one linear solve, back-propagation
+kernels).  The timed region runs K forward steps onto the tape and then the K adjoint steps of the same rollout, all state
+resident in HBM.  value = cloth triangles x K x n_gpus / wall seconds (max over ranks).  Ranks run independent scene rollouts
 (trajectory-optimisation batch): no data-path collective, "scaling": "weak".
 
 The JSON line also carries
-  roofline     -- the HBM-bound kernel of the PCG iteration (SELL-64 block SpMV fused with the direction update):
-                  algorithmic bytes per launch / average launch duration measured on the device clock inside sampled
-                  launches of the timed region (agrees with the rocprofv3 kernel trace), against 8 TB/s HBM;
-  cpu_baseline -- the fp64 CPU restatement (oracle/, "port": the reference itself needs taichi + cupy/CUDA and
-                  cannot run) timed on this box's host cores on a bounded sample of the same workload.
+  roofline      -- the kernel class of the sparse direct solve that takes the most time per Newton iteration (named in the object):
+                   algorithmic flops (or bytes) per launch / average launch duration between one HIP-event pair around back-to-back
+                   replays of that class's launches on the run's last plan, against the f64 matrix-core peak (or 8 TB/s);
+  roofline_step -- SURVEY.md section 8d's whole-step figures from the measured counts;
+  cpu_baseline  -- the fp64 CPU restatement (oracle/, "port": the reference itself needs taichi + cupy/CUDA and cannot run) timed on
+                   this box's host cores: complete fwd+adjoint steps of the same scene with a coarser cloth next to the GPU on that
+                   scene, and the cfg4-size extrapolation of a bounded sample (labelled as such).
 """
 import argparse
 import json
 import os
+import subprocess
 import sys
 import time
 
@@ -29,17 +33,18 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 if ROOT not in sys.path:
     sys.path.insert(0, ROOT)
 
-HBM_PEAK_GBS = 8000.0  # /opt/skills/guides/MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
-
+HBM_PEAK_GBS = 8000.0     # /opt/skills/guides/MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
+F64_MFMA_PEAK_TF = 78.6   # v_mfma_f64_16x16x4_f64: half the f32 MFMA rate the guide lists (157.3 TF) = the f64 vector rate (AMD MI355X datasheet: 78.6 TF)
 
 GS_CFG4 = 224 * 0.004 / 0.06  # similarity factor that keeps the native 4 mm cloth spacing of Scene_balancing at 224x224
 
 
-def build_scene(args, rank):
+def build_scene(args, rank, grid=None, cloth_size=None):
     dev = f"cuda:{int(os.environ.get('LOCAL_RANK', '0'))}"
+    grid = grid or args.grid
     if args.workload == "drape":
         from thinshelllab_amd.task_scene.Scene_drape import Scene
-        s = Scene(cloth_size=args.cloth_size, N=args.grid, M=args.grid, Kb=100.0, k_angle=3.14, perturb=1e-4 * (1 + 0.01 * rank), device=dev, newton_cap=50)
+        s = Scene(cloth_size=args.cloth_size, N=grid, M=grid, Kb=100.0, k_angle=3.14, perturb=1e-4 * (1 + 0.01 * rank), device=dev, newton_cap=50)
         s.init_all()
         return s
     # cfg4: balancing topology, cloth N = M = 224 with cloth_size = 0.12 m (dx = 5.4e-4 m) on the ball and the
@@ -48,10 +53,10 @@ def build_scene(args, rank):
     from thinshelllab_amd.task_scene.Scene_balancing import Scene
     if args.workload == "cfg4":
         gs = 1.0
-        s = Scene(cloth_size=0.12 * args.grid / 224, cloth_N=args.grid, cloth_M=args.grid, device=dev)
+        s = Scene(cloth_size=cloth_size or 0.12 * grid / 224, cloth_N=grid, cloth_M=grid, device=dev)
     else:
-        gs = args.grid * 0.004 / 0.06
-        s = Scene(cloth_size=args.grid * 0.004, cloth_N=args.grid, cloth_M=args.grid, geom_scale=gs, device=dev)
+        gs = grid * 0.004 / 0.06
+        s = Scene(cloth_size=grid * 0.004, cloth_N=grid, cloth_M=grid, geom_scale=gs, device=dev)
     s.init_all()
     s.mu_cloth_elastic[None] = 5.0  # trajopt_balancing.py:42
     s.prev_pos.copy_from(s.pos)
@@ -60,20 +65,19 @@ def build_scene(args, rank):
     return s
 
 
-def _action(scene, f):
+def _drive(n_part, gs, rank):
     """gripper drive.  cfg4: the active phase of SURVEY section 8d's trajectory, +-z 1e-4 m per step on the two paired grippers
     (the balancing task tilts the cloth).  cfg4-scaled: both grippers rise and tilt a little every step.  The rank only changes
     the amplitude by 1 %, so the ranks run different but equally expensive rollouts."""
     import numpy as np
-    n_part = scene.gripper.n_part
-    a = 1.0 + 0.01 * scene._bench_rank
+    a = 1.0 + 0.01 * rank
     dpos = np.zeros((n_part, 3)); drot = np.zeros((n_part, 3))
-    if scene._bench_gs == 1.0:
+    if gs == 1.0:
         dpos[:, 2] = 1e-4 * a * np.where(np.arange(n_part) % 2 == 0, 1.0, -1.0)
     else:
-        dpos[:, 2] = 5e-5 * scene._bench_gs * a
+        dpos[:, 2] = 5e-5 * gs * a
         drot[:, 1] = 2e-3 * a
-    scene.action(f, dpos, drot)
+    return dpos, drot
 
 
 def run_rollout(scene, grad, K, args):
@@ -81,15 +85,19 @@ def run_rollout(scene, grad, K, args):
     contact = None
     if args.workload != "drape":
         from thinshelllab_amd.engine.geometry import projection_query as contact
-    stats = dict(newton=0, cg_fwd=0, ls=0, cg_adj=0, fallback=0, nc=0)
+    S = dict(newton=0, it_fwd=0, ls=0, it_adj=0, nc=0, fwd_fallback=0, fwd_unconverged=0, fwd_attained=0, factorizations=0, plans=0, max_res_fwd=0.0,
+             adj_fallback=0, adj_unconverged=0, adj_attained=0, max_res_adj=0.0, max_be_adj=0.0, last_delta=[], methods={})
+    grad.allow_unconverged = True   # counted and reported below instead of raising in the middle of the timed region
     grad.copy_pos(scene, 0)
     for f in range(1, K + 1):
         if contact is not None:
-            _action(scene, f)
+            scene.action(f, *_drive(scene.gripper.n_part, scene._bench_gs, scene._bench_rank))
         st = scene.time_step(contact, f)
         grad.copy_pos(scene, f)
-        stats["newton"] += st["newton_iters"]; stats["cg_fwd"] += st["cg_iters"]; stats["ls"] += st["ls_evals"]; stats["fallback"] += st["fallback"]
-        stats["nc"] += st.get("nc", 0)
+        S["newton"] += st["newton_iters"]; S["it_fwd"] += st["cg_iters"]; S["ls"] += st["ls_evals"]; S["nc"] += st.get("nc", 0)
+        S["fwd_fallback"] += st["fallback"]; S["fwd_unconverged"] += st["unconverged"]; S["fwd_attained"] += st["attained"]
+        S["factorizations"] += st["factorizations"]; S["plans"] += st["plans"]
+        S["max_res_fwd"] = max(S["max_res_fwd"], st["max_rel_residual"]); S["last_delta"].append(st["last_delta"])
     c = scene.cloths[0]
     grad.pos_grad.t.zero_(); grad.angleref_grad.t.zero_()
     if contact is not None:
@@ -98,70 +106,165 @@ def run_rollout(scene, grad, K, args):
         grad.pos_grad.t[K, c.offset:c.offset + c.NV, 2] = 1.0  # dL/dx_K: lift the cloth (sum of z)
     for s in range(K, 0, -1):
         grad.transfer_grad(s, scene, contact)
-        stats["cg_adj"] += grad.last_stats["iters"]; stats["fallback"] += int(grad.last_stats["flag"] != 0)
-    return stats
+        ls = grad.last_stats
+        S["it_adj"] += ls["iters"]; S["adj_fallback"] += int(ls["flag"] == 1); S["adj_unconverged"] += int(ls["flag"] == 3); S["adj_attained"] += ls["attained"]
+        S["max_res_adj"] = max(S["max_res_adj"], ls["rel_residual"]); S["max_be_adj"] = max(S["max_be_adj"], ls["backward_error"])
+        S["methods"][ls["method"]] = S["methods"].get(ls["method"], 0) + 1
+    return S
 
 
-def cpu_baseline(args, scene, gpu_stats, K):
-    """Oracle timed on a bounded sample of the SAME scene and state: one contact detection, one energy evaluation, one
-    gradient+Hessian assembly and a fixed number of PCG iterations, extrapolated to a full fwd+adjoint step with the
-    Newton / line-search counts of the GPU run and the iteration count of the oracle's own solver (block-Jacobi PCG),
-    which the GPU library measures by solving one system of the run in block-Jacobi mode (a full step of this size
-    takes the host tens of minutes)."""
+def cpu_baseline(args, scene, gpu_stats, K, rank):
+    """(a) Complete fwd+adjoint steps of the oracle on the host cores, next to the GPU on the SAME scene: the bench scene with a
+    coarser cloth (same bodies, poses, drive, loss), sized so that the host needs some tens of seconds.
+    (b) The cfg4-size figure stays an extrapolation -- one contact detection, one energy, one assembly and a bounded number of PCG
+    iterations of the oracle on the bench state, scaled with the GPU run's Newton / line-search counts and the iteration count of the
+    oracle's own solver (block-Jacobi PCG) on one system of the run -- because a full step of the oracle at 100k triangles takes the
+    host tens of minutes."""
+    import numpy as np
+    import torch
     from oracle import pyoracle as po
     from oracle.mirror import oracle_from_scene
-    import torch
-    ctx = scene._ensure_ctx()
-    # iterations per solve of the oracle's algorithm on this system
-    ctx.set_param("mg", 0); ctx.set_param("body_inv", 0); ctx.set_param("cg_maxit", 200000)
-    scene.compute_residual_and_Hessian(spd=True)
-    _, st = ctx.solve(scene.F.to_torch())
-    its_bj = max(int(st["iters"]), 1)
-    ctx.set_param("mg", -1); ctx.set_param("body_inv", -1)
-    torch.cuda.synchronize()
-    o = oracle_from_scene(po, scene, check_init=False)
+    from thinshelllab_amd.engine.analytic_grad_single import Grad
+    from thinshelllab_amd.engine.geometry import projection_query
     ncpu = os.cpu_count() or 1
-    po.set_threads(min(ncpu, 8))
-    t_contact = 0.0
+    threads = min(ncpu, args.cpu_threads)
+    po.set_threads(threads)
+    out = {"unit": "element-steps/s", "cores": threads, "kind": "port"}
     if args.workload != "drape":
-        t0 = time.time(); o.calc_vn(); o.projection_query(); o.contact_analysis(); t_contact = time.time() - t0
-    o.newton_step_init(); o.compute_energy(); o.compute_residual_and_Hessian(True)
-    b = o.arr("F").copy()
-    best = None
-    for th in sorted({min(ncpu, t) for t in (8, 16, 32, 64)}):  # memory-bound OpenMP code: pick the fastest thread count
-        po.set_threads(th)
-        o.set_solver(1e-30, 20)
+        G, Kc = args.cpu_grid, args.cpu_steps
+        small = build_scene(args, rank, grid=G, cloth_size=0.12 if args.workload == "cfg4" else None)
+        o = oracle_from_scene(po, small, check_init=False)
+        o.set_solver(args.cg_tol)
+        n_part = small.gripper.n_part
+        o.grad_new(Kc + 1, n_part)
+        tc0 = time.time()
+        o.grad_copy_pos(0)
+        for f in range(1, Kc + 1):
+            o.action(*_drive(n_part, small._bench_gs, rank))
+            o.time_step()
+            o.grad_copy_pos(f)
+        pg = o.arr("grad.pos_grad", (Kc + 1, -1, 3))
+        e = small.elastics[0]; tt = small.cloths[0].offset + (G + 1) // 2 * (G + 1) + (G + 1) // 2
+        pb = o.arr("grad.pos_buffer", (Kc + 1, -1, 3))
+        d = 2 * (pb[1:, e.offset:e.offset + e.n_verts, 0:2] - pb[1:, tt:tt + 1, 0:2])   # get_loss_balance (analytic_grad_single.py:428-443)
+        pg[1:, e.offset:e.offset + e.n_verts, 0:2] = d; pg[1:, tt, 0:2] = -d[:, -1, :]
+        for s_ in range(Kc, 0, -1):
+            o.grad_transfer(s_)
+        t_cpu = time.time() - tc0
+        # the same rollout on the GPU
+        g2 = Grad(small, Kc + 1, n_part); g2.init_mass(small)
+        sm_args = argparse.Namespace(**vars(args))
+        run_rollout(small, g2, Kc, sm_args)   # warm-up (plans, allocations)
+        small2 = build_scene(args, rank, grid=G, cloth_size=0.12 if args.workload == "cfg4" else None)
+        g3 = Grad(small2, Kc + 1, n_part); g3.init_mass(small2)
+        torch.cuda.synchronize(); tg0 = time.time()
+        run_rollout(small2, g3, Kc, sm_args)
+        torch.cuda.synchronize(); t_gpu = time.time() - tg0
+        Ts = 2 * G * G
+        out.update({"value": Ts * Kc / t_cpu, "gpu_value_same_scene": Ts * Kc / t_gpu,
+                    "sample": f"complete fwd+adjoint steps: the bench scene with a {G}x{G} cloth ({Ts} triangles, cloth_size 0.12 m; same bodies, drive and loss), "
+                              f"{Kc} steps forward + {Kc} adjoint steps of the oracle on {threads} OpenMP threads of {ncpu} host cpus in {t_cpu:.1f} s "
+                              f"(Newton / line-search / solver statistics {o.stats()}); the GPU engine ran the same rollout in {t_gpu:.2f} s"})
+        del small, small2
+    # (b) extrapolation at the bench size
+    try:
+        ctx = scene._ensure_ctx()
+        ctx.set_param("direct", 0); ctx.set_param("mg", 0); ctx.set_param("body_inv", 0); ctx.set_param("cg_maxit", 200000)
+        scene.compute_residual_and_Hessian(spd=True)
+        _, st = ctx.solve(scene.F.to_torch())
+        its_bj = max(int(st["iters"]), 1)
+        ctx.set_param("mg", -1); ctx.set_param("body_inv", -1); ctx.set_param("direct", -1)
+        torch.cuda.synchronize()
+        o = oracle_from_scene(po, scene, check_init=False)
+        t_contact = 0.0
+        if args.workload != "drape":
+            t0 = time.time(); o.calc_vn(); o.projection_query(); o.contact_analysis(); t_contact = time.time() - t0
+        o.newton_step_init(); o.compute_energy(); o.compute_residual_and_Hessian(True)
+        b = o.arr("F").copy()
+        t0 = time.time(); o.newton_step_init(); o.compute_energy(); t_e = time.time() - t0
+        t0 = time.time(); o.compute_residual_and_Hessian(True); t_asm = time.time() - t0
+        o.set_solver(1e-30, args.cpu_cg_iters)
         o.stats(reset=True)
-        t0 = time.time(); o.solve(b); dt_ = (time.time() - t0) / max(o.stats()["cg"], 1)
-        if best is None or dt_ < best[1]:
-            best = (th, dt_)
-    cores = best[0]
-    po.set_threads(cores)
-    t0 = time.time(); o.newton_step_init(); o.compute_energy(); t_e = time.time() - t0
-    t0 = time.time(); o.compute_residual_and_Hessian(True); t_asm = time.time() - t0
-    n_it = max(20, min(args.cpu_cg_iters, int(8.0 / best[1])))
-    o.set_solver(1e-30, n_it)
-    o.stats(reset=True)
-    t0 = time.time(); o.solve(b); t_cg = (time.time() - t0)
-    it_done = max(o.stats()["cg"], 1)
-    t_it = t_cg / it_done
-    n_asm = gpu_stats["newton"] + K          # forward assemblies + one per adjoint step
-    n_e = gpu_stats["newton"] + gpu_stats["ls"]
-    n_solve = gpu_stats["newton"] + K
-    t_total = 2 * K * t_contact + n_asm * t_asm + n_e * t_e + n_solve * its_bj * t_it
+        t0 = time.time(); o.solve(b); t_cg = time.time() - t0
+        it_done = max(o.stats()["cg"], 1)
+        t_it = t_cg / it_done
+        n_asm = gpu_stats["newton"] + K
+        n_e = gpu_stats["newton"] + gpu_stats["ls"]
+        t_total = 2 * K * t_contact + n_asm * t_asm + n_e * t_e + n_asm * its_bj * t_it
+        T = 2 * args.grid * args.grid
+        out["extrapolated_at_bench_size"] = {
+            "value": T * K / t_total,
+            "what": f"EXTRAPOLATION, not a timed run: oracle on the bench scene and state, 1 contact detection ({t_contact:.3f} s) + 1 energy ({t_e:.3f} s) + 1 assembly "
+                    f"({t_asm:.3f} s) + {it_done} PCG iterations ({t_it * 1e3:.2f} ms each) on {threads} threads, scaled to {K} fwd+adjoint steps with the GPU run's {n_asm} "
+                    f"assemblies / {n_e} energy evaluations and {its_bj} block-Jacobi PCG iterations per solve (the oracle's solver; count measured by the GPU "
+                    f"library in block-Jacobi mode on one system of the run)"}
+        if "value" not in out:
+            out["value"] = out["extrapolated_at_bench_size"]["value"]; out["sample"] = out["extrapolated_at_bench_size"]["what"]
+    except Exception as e:  # keep (a)
+        out["extrapolated_at_bench_size"] = {"value": None, "what": f"failed: {e}"}
+    return out
+
+
+def roofline(ctx, scene, elapsed, K, stats, args):
+    """dominant kernel class of the sparse direct solve, measured live with HIP events (tsl_bench_direct), + section 8d's whole-step model"""
+    names = {0: "k_ds_update (rank-32 Gauss-Jordan update of the pivot block rows [F11 | F12] of every front of a batch, f64 MFMA tiles)",
+             1: "k_ds_schur (Schur complement S = F22 - F21 G of every front of a batch: K = pp GEMM on v_mfma_f64_16x16x4_f64)",
+             2: "k_ds_panel (row panel P A[K, :] and column panel copy of a Gauss-Jordan block step)",
+             3: "k_ds_extend (extend-add of a batch's Schur complements into the parent fronts, f64 atomics)",
+             4: "k_ds_gemv (level sweeps of one application of the factors: W, F21 upwards, G downwards)"}
+    cls = {}
+    for k in names:
+        try:
+            cls[k] = ctx.bench_direct(k, 10)
+        except Exception as e:
+            print(f"roofline: tsl_bench_direct({k}) failed: {e!r}", file=sys.stderr)
+            return None, None
+    info = ctx.direct_info()
+    per_fact = {k: v["us_per_launch"] * v["launches"] for k, v in cls.items()}
+    apply_per_iter = max(1.0, (stats["it_fwd"] + stats["it_adj"]) / max(stats["newton"] + K, 1))
+    share = dict(per_fact); share[4] = per_fact[4] * apply_per_iter     # applications per factorisation
+    dom = max(share, key=share.get)
+    v = cls[dom]
+    if dom in (1,):
+        ach = v["flops_per_launch"] / (v["us_per_launch"] * 1e-6) / 1e12
+        rf = {"bound": "mfma", "achieved": ach, "peak": F64_MFMA_PEAK_TF, "unit": "TFLOP/s", "frac": ach / F64_MFMA_PEAK_TF, "traffic": None}
+    else:
+        ach = v["bytes_per_launch"] / (v["us_per_launch"] * 1e-6) / 1e9
+        rf = {"bound": "hbm", "achieved": ach, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": ach / HBM_PEAK_GBS, "traffic": None}
+    try:  # HBM bytes per launch from the committed rocprofv3 --pmc passes (scripts/gpu_profile.sh), if present for this kernel
+        path = os.path.join(ROOT, "profiles", f"r02_{args.workload.replace('-', '_')}_pmc_{names[dom].split(' ')[0]}.json")
+        if os.path.exists(path) and args.grid == 224:
+            with open(path) as fh:
+                rf["traffic"] = json.load(fh)["traffic_bytes_per_launch"]
+    except (OSError, KeyError, ValueError):
+        pass
+    tot = sum(share.values())
+    rf.update({"kernel": names[dom], "flops_per_launch": v["flops_per_launch"], "bytes_per_launch": v["bytes_per_launch"], "avg_launch_us": v["us_per_launch"],
+               "launches_per_factorization": v["launches"], "share_of_direct_solve_time": share[dom] / tot,
+               "classes_us_per_newton_iteration": {names[k].split(" ")[0]: share[k] for k in share},
+               "timing": "avg_launch_us = one HIP-event pair on the library's stream around 10 back-to-back replays of every launch of this kernel class of one "
+                         "factorisation (one application for k_ds_gemv) on the run's last plan, divided by the launches (includes the gaps between dependent "
+                         "launches; compare the rocprofv3 kernel-trace averages under profiles/)",
+               "plan": {k: info[k] for k in ("supernodes", "levels", "batches", "flops_per_factorization", "front_bytes")}})
+    # SURVEY 8d: bytes_model(measured counts) / wall / 8e12 with the per-triangle figures of the assembled-matrix algorithm (fp64)
     T = 2 * args.grid * args.grid
-    return {"value": T * K / t_total, "unit": "element-steps/s", "cores": cores, "kind": "port",
-            "sample": f"oracle ({cores} OpenMP threads of {ncpu} host cpus) on the same scene and state: 1 contact detection ({t_contact:.3f}s) + 1 energy ({t_e:.3f}s) + "
-                      f"1 assembly ({t_asm:.3f}s) + {it_done} PCG iterations ({t_it * 1e3:.2f} ms each); extrapolated to {K} fwd+adjoint steps with the GPU run's "
-                      f"{n_asm} assemblies / {n_e} energy evaluations / {n_solve} solves and {its_bj} block-Jacobi PCG iterations per solve (the oracle's solver, "
-                      f"count measured by the GPU library in block-Jacobi mode on one system of the run)"}
+    B_cg, B_asm, B_E = 686.0, 600.0, 128.0
+    n_asm = stats["newton"] + K
+    bytes_model = T * (n_asm * B_asm + (stats["it_fwd"] + stats["it_adj"]) * B_cg + (stats["newton"] + stats["ls"]) * B_E + K * 150.0)
+    flops_fact = info["flops_per_factorization"] * stats["factorizations_total"]
+    step = {"bytes_model": bytes_model, "achieved_GBs": bytes_model / elapsed / 1e9, "frac_of_hbm_peak": bytes_model / elapsed / 8e12,
+            "note": "section 8d prices a step as assemblies + PCG iterations + energy evaluations; the solves are now one sparse factorisation + ~1 refinement iteration "
+                    "each (the reference's own algorithm: a direct sparse solve per Newton iteration), so the model's iteration term is nearly empty and the "
+                    "factorisation flops are the whole-step yardstick instead",
+            "factorization_flops": flops_fact, "factorization_TFLOPs_over_wall": flops_fact / elapsed / 1e12, "frac_of_f64_mfma_peak": flops_fact / elapsed / 1e12 / F64_MFMA_PEAK_TF}
+    return rf, step
 
 
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=3)
-    ap.add_argument("--warmup", type=int, default=2)
+    ap.add_argument("--steps", type=int, default=10)
+    ap.add_argument("--warmup", type=int, default=3)
     ap.add_argument("--workload", choices=["cfg4", "cfg4-scaled", "drape"], default="cfg4",
                     help="cfg4: cloth on ball + 4 tactile pads with contact, cloth_size 0.12 m (the configuration the metric is quoted on); "
                          "cfg4-scaled: same scene enlarged so that the cloth keeps its native 4 mm spacing; drape: contact-free pinned cloth")
@@ -170,8 +273,18 @@ def main():
     ap.add_argument("--cg-tol", type=float, default=1e-10)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--param", action="append", default=[], metavar="KEY=VALUE", help="extra tsl_set_param settings (solver experiments)")
-    ap.add_argument("--cpu-cg-iters", type=int, default=6000, help="PCG iterations of the timed oracle sample (about 10 s of host work on cfg4)")
+    ap.add_argument("--cpu-cg-iters", type=int, default=4000, help="PCG iterations of the extrapolation sample of the oracle")
+    ap.add_argument("--cpu-grid", type=int, default=71, help="cloth grid of the complete oracle steps of cpu_baseline")
+    ap.add_argument("--cpu-steps", type=int, default=3)
+    ap.add_argument("--cpu-threads", type=int, default=16)
     args = ap.parse_args()
+
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        # one rank per GPU of this node over RCCL: re-execute under torch.distributed.run (the driver's own launcher sets WORLD_SIZE)
+        port = 29500 + os.getpid() % 2000
+        cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={args.gpus}", "--master-addr", "127.0.0.1", "--master-port", str(port),
+               os.path.abspath(__file__)] + sys.argv[1:]
+        raise SystemExit(subprocess.call(cmd))
 
     import torch
     if not torch.cuda.is_available():
@@ -179,6 +292,8 @@ def main():
     from thinshelllab_amd.batch import Batch
     batch = Batch()  # one process per GPU (RANK / LOCAL_RANK / WORLD_SIZE from torch.distributed.run); backend nccl == RCCL
     world, rank = batch.world, batch.rank
+    if world != args.gpus:
+        raise SystemExit(f"bench.py --gpus {args.gpus} but the process group has {world} ranks")
     torch.cuda.set_device(batch.local_rank)
 
     from thinshelllab_amd.engine.analytic_grad_single import Grad
@@ -195,24 +310,21 @@ def main():
     if W > 0:
         run_rollout(scene, grad, W, args)
 
-    barrier = batch.barrier
-
-    ctx.profile_reset(True)
-    barrier()
+    info0 = ctx.direct_info()
+    batch.barrier()
+    torch.cuda.synchronize()
     t0 = time.perf_counter()
     stats = run_rollout(scene, grad, K, args)
-    barrier()
+    torch.cuda.synchronize()
+    batch.barrier()
     elapsed = time.perf_counter() - t0
-    prof = ctx.profile_read()
     elapsed = batch.max_over_ranks(elapsed)
-    # HIP-event timing of the dominant kernel: 500 back-to-back launches of k_pcg_spmv on the run's last matrix and contact set,
-    # one hipEvent pair on the library's stream (after the timed region: a pair around every launch inside it would time the events)
-    k1_us = ctx.bench_spmv(20, 500)
-    # yardstick, not a target: a kernel that only streams the matrix values once (no column-id -> vector gather chain, no reduction)
-    stream_us = ctx.bench_spmv(30, 500)
+    info1 = ctx.direct_info()
+    stats["factorizations_total"] = info1["factorizations"] - info0["factorizations"]
 
     T = 2 * args.grid * args.grid
     value = T * K * world / elapsed
+    n_solves_fwd = max(stats["newton"], 1)
     out = {
         "metric": "element-steps/s (fwd+adjoint), 100k-tri cloth; 1/2/4/8-GPU scaling",
         "value": value, "unit": "element-steps/s", "n_gpus": world, "steps": K, "warmup": W,
@@ -226,43 +338,30 @@ def main():
                                 f"({T} triangles) and the whole scene enlarged x{args.grid * 0.004 / 0.06:.2f} so that the cloth keeps its native 4 mm spacing; "
                                 if args.workload == "cfg4-scaled" else
                                 f"drape: {args.grid}x{args.grid} square cloth ({T} triangles, dx={args.cloth_size / args.grid:.3e} m), one pinned row, no contact; ") +
-                               "per step: implicit-Euler Newton+PCG time step (contact detection, friction) + adjoint transfer_grad; one independent scene per GPU",
+                               "per step: implicit-Euler Newton time step (contact detection, friction; per Newton iteration one multifrontal LU of the "
+                               "operator + GMRES refinement to cg_tol) + adjoint transfer_grad; one independent scene per GPU",
                    "triangles": T, "tot_NV": scene.tot_NV, "cg_tol": args.cg_tol, "active_contacts_per_step": stats["nc"] / K,
-                   "newton_iters_per_step": stats["newton"] / K, "pcg_iters_per_fwd_solve": stats["cg_fwd"] / max(stats["newton"], 1),
-                   "pcg_iters_per_adjoint_solve": stats["cg_adj"] / K, "line_search_evals_per_step": stats["ls"] / K, "solver_fallbacks": stats["fallback"]},
+                   "newton_iters_per_step": stats["newton"] / K, "line_search_evals_per_step": stats["ls"] / K,
+                   "newton_last_delta_per_step": [float(f"{d:.3g}") for d in stats["last_delta"]],
+                   "refinement_iters_per_fwd_solve": stats["it_fwd"] / n_solves_fwd, "refinement_iters_per_adjoint_solve": stats["it_adj"] / K,
+                   "pcg_iters_per_fwd_solve": stats["it_fwd"] / n_solves_fwd, "pcg_iters_per_adjoint_solve": stats["it_adj"] / K,
+                   "factorizations": stats["factorizations_total"], "symbolic_plans": info1["plans"] - info0["plans"], "plan_host_seconds": info1["plan_seconds"] - info0["plan_seconds"],
+                   "solves_unconverged": stats["fwd_unconverged"] + stats["adj_unconverged"],
+                   "solver_fallbacks": {"forward": stats["fwd_fallback"], "adjoint": stats["adj_fallback"]},
+                   "solves_accepted_at_attainable_accuracy": {"forward": stats["fwd_attained"], "adjoint": stats["adj_attained"]},
+                   "max_rel_residual_fwd": stats["max_res_fwd"], "max_rel_residual_adjoint": stats["max_res_adj"], "max_backward_error_adjoint": stats["max_be_adj"],
+                   "adjoint_solve_methods": {str(k): v for k, v in stats["methods"].items()}},
     }
-    traffic = None
-    try:  # HBM bytes per launch from the committed rocprofv3 --pmc passes of this workload (scripts/gpu_profile.sh)
-        for tag in ("r01c", "r01b"):  # newest committed counter pass first
-            path = os.path.join(ROOT, "profiles", f"{tag}_{args.workload.replace('-', '_')}_pmc_k_pcg_spmv.json")
-            if os.path.exists(path) and args.grid == 224:
-                with open(path) as fh:
-                    traffic = json.load(fh)["traffic_bytes_per_launch"]
-                break
-    except (OSError, KeyError, ValueError):
-        pass
-    if k1_us > 0:
-        ach = prof["bytes_per_launch"] / (k1_us * 1e-6) / 1e9
-        out["roofline"] = {"bound": "hbm", "achieved": ach, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": ach / HBM_PEAK_GBS, "traffic": traffic,
-                           "kernel": "k_pcg_spmv (SELL-64 3x3-block SpMV fused with the PCG direction update and p.Ap, one launch per PCG iteration)",
-                           "bytes_per_launch": prof["bytes_per_launch"], "avg_launch_us": k1_us,
-                           "avg_launch_us_device_clock": prof["ms_per_launch"] * 1e3,
-                           "streaming_read_yardstick": {"bytes": (prof["bytes_per_launch"] - 48 * scene.tot_NV) // 76 * 72, "avg_launch_us": stream_us,
-                                                        "GB/s": (prof["bytes_per_launch"] - 48 * scene.tot_NV) // 76 * 72 / (stream_us * 1e-6) / 1e9 if stream_us > 0 else None,
-                                                        "what": "k_stream_read over the matrix values only (the 72 of 76 B per block that k_pcg_spmv streams), same back-to-back HIP-event timing"},
-                           "avg_launch_us_single_event_pairs": prof["ms_per_launch_events"] * 1e3, "launches": prof["launches"],
-                           "timing": "avg_launch_us (what `achieved` is priced on) = HIP events on the library's stream around 500 back-to-back launches "
-                                     "of the kernel on the run's last matrix / contact set, divided by 500 (includes the gap between dependent "
-                                     "launches; compare the rocprofv3 kernel-trace average under profiles/); avg_launch_us_device_clock = min wave "
-                                     "start -> max wave end of launches sampled inside the timed region's hipGraph replays; "
-                                     "avg_launch_us_single_event_pairs = hipEvent pairs around single eagerly issued launches inside the timed "
-                                     "region, which adds the event / dispatch overhead of a 15 us kernel"}
+    rf, step = roofline(ctx, scene, elapsed, K, stats, args)
+    if rf is not None:
+        out["roofline"] = rf
+        out["roofline_step"] = step
     if rank == 0:
         if world == 1 and not args.no_cpu_baseline:
             try:
-                out["cpu_baseline"] = cpu_baseline(args, scene, stats, K)
+                out["cpu_baseline"] = cpu_baseline(args, scene, stats, K, rank)
             except Exception as e:  # the oracle is optional test infrastructure; never fail the GPU number on it
-                out["cpu_baseline"] = {"value": None, "unit": "element-steps/s", "cores": os.cpu_count(), "kind": "port", "sample": f"failed: {e}"}
+                out["cpu_baseline"] = {"value": None, "unit": "element-steps/s", "cores": os.cpu_count(), "kind": "port", "sample": f"failed: {e!r}"}
         print(json.dumps(out), flush=True)
     batch.close()
 

@@ -197,6 +197,15 @@ int tsl_profile_read_events(tsl_ctx* ctx, double* spmv_ms_hip_events_host); /* s
  * 30 = k_stream_read over the matrix values only (streaming-read yardstick for the same bytes). */
 int tsl_bench_spmv(tsl_ctx* ctx, int variant, int reps, double* us_per_launch_host);
 
+/* Sparse direct path (multifrontal LU of the operator, the counterpart of the reference's spsolve, sparse_solver.py:85-105).
+ * tsl_bench_direct: the launches of one kernel class of ONE factorisation (cls 0 k_ds_update, 1 k_ds_schur, 2 k_ds_panel,
+ * 3 k_ds_extend) or of one application (4 k_ds_gemv) on the current plan, replayed `reps` times between one hipEvent pair;
+ * out4 = {us per launch, algorithmic flops per launch, algorithmic bytes per launch, launches per factorisation}.  The factors are
+ * invalid afterwards.  tsl_direct_info: {plans, factorisations, applications, perturbed pivots of the last factorisation, host
+ * seconds in plan builds, supernodes, levels, batches, flops per factorisation, bytes of fronts}. */
+int tsl_bench_direct(tsl_ctx* ctx, int cls, int reps, double* out4_host);
+int tsl_direct_info(tsl_ctx* ctx, double* out10_host);
+
 #ifdef __cplusplus
 }
 #endif

@@ -227,6 +227,18 @@ class TslContext:
         check(self.L.tsl_profile_read_events(self.h, C.byref(ev)), "tsl_profile_read_events")
         return dict(ms_per_launch=ms.value, launches=n.value, bytes_per_launch=b.value, ms_per_launch_events=ev.value)
 
+    def bench_direct(self, cls, reps=20):
+        """kernel class of the sparse direct path replayed back to back (0 update, 1 schur, 2 panel, 3 extend, 4 gemv sweeps)"""
+        out = (C.c_double * 4)()
+        check(self.L.tsl_bench_direct(self.h, int(cls), int(reps), out), "tsl_bench_direct")
+        return dict(us_per_launch=out[0], flops_per_launch=out[1], bytes_per_launch=out[2], launches=int(out[3]))
+
+    def direct_info(self):
+        out = (C.c_double * 10)()
+        check(self.L.tsl_direct_info(self.h, out), "tsl_direct_info")
+        keys = ("plans", "factorizations", "applications", "perturbed_pivots", "plan_seconds", "supernodes", "levels", "batches", "flops_per_factorization", "front_bytes")
+        return dict(zip(keys, [float(v) for v in out]))
+
     def bench_spmv(self, variant=20, reps=500):
         """microseconds per launch of `reps` back-to-back operator launches between one hipEvent pair (20 = k_pcg_spmv)"""
         us = C.c_double(0)

@@ -151,3 +151,80 @@ static int direct_apply(tsl_ctx* c, const double* r, double* z) {
   d.n_apply++;
   return 0;
 }
+
+// Timing of one kernel class of the factorisation / solve for bench.py's roofline object: the launches of that class of ONE
+// factorisation (or one application), exactly as direct_factor / direct_apply issue them on the current plan, replayed `reps` times
+// back to back between one hipEvent pair on the engine stream.  cls: 0 k_ds_update, 1 k_ds_schur, 2 k_ds_panel, 3 k_ds_extend,
+// 4 k_ds_gemv (all sweeps of one application).  The replays overwrite the factors (marked invalid afterwards).
+// out: {us per launch, algorithmic flops per launch, algorithmic bytes per launch, launches per factorisation / application}
+static int direct_bench(tsl_ctx* c, int cls, int reps, double* out) {
+  DirectSolver& d = c->ds;
+  hipStream_t s = c->stream;
+  if (!d.plan_valid || d.arena.n == 0) return tsl_fail("tsl_bench_direct: no factorisation yet");
+  const DirectPlan& P = d.plan;
+  const DsDev D = ds_dev(c);
+  double flops = 0, bytes = 0;
+  long launches = 0;
+  auto issue = [&](bool count) {
+    if (cls == 4) {
+      for (int l = 0; l < P.n_levels; l++) {
+        const int o0 = P.wl_own_ptr[l], b0 = P.wl_bnd_ptr[l], o1 = P.wl_own_ptr[l + 1];
+        hipLaunchKernelGGL(k_ds_gemv, dim3(b0 - o0), dim3(256), 0, s, D, d.wl_front.p, d.wl_row.p, o0, 0, (const double*)d.w.p, c->v_t4.p);
+        if (o1 > b0) hipLaunchKernelGGL(k_ds_gemv, dim3(o1 - b0), dim3(256), 0, s, D, d.wl_front.p, d.wl_row.p, b0, 1, (const double*)c->v_t4.p, d.w.p);
+        if (count) launches += 1 + (o1 > b0);
+      }
+      for (int l = P.n_levels - 2; l >= 0; l--) {
+        const int o0 = P.wl_own_ptr[l], b0 = P.wl_bnd_ptr[l];
+        hipLaunchKernelGGL(k_ds_gemv, dim3(b0 - o0), dim3(256), 0, s, D, d.wl_front.p, d.wl_row.p, o0, 2, (const double*)c->v_t4.p, c->v_t4.p);
+        if (count) launches++;
+      }
+      if (count) for (const DsFrontDesc& f : P.fr) { bytes += 8.0 * ((double)f.p * f.p + 2.0 * (double)f.p * f.b); flops += 2.0 * ((double)f.p * f.p + 2.0 * (double)f.p * f.b); }
+      return;
+    }
+    for (const DsBatch& b : P.batches) {
+      const int lv0 = b.first, nf = b.count;
+      const int tp = b.max_pp / DS_T, tb = b.max_bp / DS_T;
+      if (cls == 0 || cls == 2) {
+        for (int k = 0; k < tp; k++) {
+          const int na = P.act_n[b.act_off + k], tl = P.act_ld[b.act_off + k] / DS_T;
+          if (cls == 2) hipLaunchKernelGGL(k_ds_panel, dim3(tl, na), dim3(256), 0, s, D, lv0, k);
+          else hipLaunchKernelGGL(k_ds_update, dim3(tl, tp, na), dim3(256), 0, s, D, lv0, k);
+          if (count) {
+            launches++;
+            for (int i = 0; i < na; i++) {
+              const DsFrontDesc& f = P.fr[P.level_sn[lv0 + i]];
+              if (cls == 2) { flops += 2.0 * DS_T * DS_T * f.ld; bytes += 8.0 * (2.0 * DS_T * f.ld + 2.0 * DS_T * f.pp + DS_T * DS_T); }
+              else { flops += 2.0 * DS_T * (double)f.pp * f.ld; bytes += 8.0 * (2.0 * (double)f.pp * f.ld + (double)DS_T * f.ld + (double)f.pp * DS_T); }  // read + write of the block rows, both panels once
+            }
+          }
+        }
+      } else if (tb > 0) {
+        if (cls == 1) hipLaunchKernelGGL(k_ds_schur, dim3((tb + 1) / 2, (tb + 1) / 2, nf), dim3(256), 0, s, D, lv0);
+        else hipLaunchKernelGGL(k_ds_extend, dim3(tb, tb, nf), dim3(256), 0, s, D, lv0);
+        if (count) {
+          launches++;
+          for (int i = 0; i < nf; i++) {
+            const DsFrontDesc& f = P.fr[P.level_sn[lv0 + i]];
+            if (cls == 1) { flops += 2.0 * (double)f.bp * f.bp * f.pp; bytes += 8.0 * (2.0 * (double)f.bp * f.pp + 2.0 * (double)f.bp * f.bp); }
+            else if (f.parent >= 0) bytes += 8.0 * 3.0 * (double)f.b * f.b;   // S read, parent entries read + written
+          }
+        }
+      }
+    }
+  };
+  if (d.ev0 == nullptr) { HIP_OK(hipEventCreate(&d.ev0)); HIP_OK(hipEventCreate(&d.ev1)); }
+  issue(true);  // warm-up and accounting
+  HIP_OK(hipEventRecord(d.ev0, s));
+  for (int r = 0; r < reps; r++) issue(false);
+  HIP_OK(hipEventRecord(d.ev1, s));
+  HIP_OK(hipEventSynchronize(d.ev1));
+  HIP_OK(hipGetLastError());
+  float ms = 0;
+  HIP_OK(hipEventElapsedTime(&ms, d.ev0, d.ev1));
+  d.numeric_valid = false; d.have_factor = false;
+  out[0] = launches > 0 ? ms * 1e3 / ((double)launches * reps) : 0.0;
+  out[1] = launches > 0 ? flops / launches : 0.0;
+  out[2] = launches > 0 ? bytes / launches : 0.0;
+  out[3] = (double)launches;
+  return 0;
+}

@@ -112,6 +112,7 @@ struct DirectSolver {
   double t_plan = 0;          // host seconds spent in plan builds
   double anorm = 0;           // infinity norm of the factorised operator's static part (backward-error yardstick)
   DevBuf<double> anorm_dev;
+  hipEvent_t ev0 = nullptr, ev1 = nullptr;
 };
 
 struct tsl_ctx {

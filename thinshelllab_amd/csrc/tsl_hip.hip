@@ -1895,6 +1895,25 @@ extern "C" int tsl_bench_spmv(tsl_ctx* c, int variant, int reps, double* us_per_
   return 0;
 }
 
+extern "C" int tsl_bench_direct(tsl_ctx* c, int cls, int reps, double* out4) {
+  Scope scope(c);
+  return direct_bench(c, cls, std::max(1, reps), out4);
+}
+
+// counters of the direct path since context creation: {plans, factorisations, applications, perturbed pivots of the last
+// factorisation, host seconds in plan builds, supernodes, levels, batches, flops per factorisation, bytes of fronts}
+extern "C" int tsl_direct_info(tsl_ctx* c, double* out10) {
+  Scope scope(c);
+  HIP_OK(hipStreamSynchronize(c->stream));
+  const DirectSolver& d = c->ds;
+  int bad[4] = {0, 0, 0, 0};
+  if (d.bad.p) HIP_OK(hipMemcpy(bad, d.bad.p, sizeof(bad), hipMemcpyDeviceToHost));
+  out10[0] = (double)d.n_plans; out10[1] = (double)d.n_factor; out10[2] = (double)d.n_apply; out10[3] = bad[0]; out10[4] = d.t_plan;
+  out10[5] = d.plan_valid ? d.plan.sym.n_sn : 0; out10[6] = d.plan_valid ? d.plan.n_levels : 0; out10[7] = d.plan_valid ? (double)d.plan.batches.size() : 0;
+  out10[8] = d.plan_valid ? d.plan.flops : 0; out10[9] = d.plan_valid ? 8.0 * (double)d.plan.arena : 0;
+  return 0;
+}
+
 extern "C" int tsl_spd_project(tsl_ctx* c, double* blocks, int32_t n, int32_t D) {
   Scope scope(c);
   if (D != 2 && D != 3 && D != 9) return tsl_fail("tsl_spd_project: D must be 2, 3 or 9");
