@@ -9,6 +9,8 @@
 
 static inline int ds_nblk(long n, int b) { return (int)((n + b - 1) / b); }
 
+static inline size_t ds_small_lds(int max_pp) { return ((size_t)max_pp * (max_pp + 1) + (size_t)DS_T * (DS_T + 1)) * sizeof(double); }
+
 static bool direct_enabled(tsl_ctx* c) {
   DirectSolver& d = c->ds;
   if (d.enable == 0) return false;
@@ -20,7 +22,7 @@ static bool direct_enabled(tsl_ctx* c) {
 static DsDev ds_dev(tsl_ctx* c) {
   DirectSolver& d = c->ds;
   DsDev D;
-  D.fr = d.fr.p; D.level_sn = d.level_sn.p; D.A = d.arena.p; D.scr = d.scr.p; D.rel = d.rel.p; D.vtx = d.vtx.p; D.bad = d.bad.p;
+  D.fr = d.fr.p; D.level_sn = d.level_sn.p; D.A = d.arena.p; D.G = d.garena.p; D.scr = d.scr.p; D.rel = d.rel.p; D.vtx = d.vtx.p; D.bad = d.bad.p;
   return D;
 }
 
@@ -46,6 +48,7 @@ static int direct_static(tsl_ctx* c) {
   }
   if (d.csr2sell.upload(c2s)) return -1;
   if (d.bad.alloc(4)) return -1;
+  HIP_OK(hipFuncSetAttribute((const void*)k_ds_inv_small, hipFuncAttributeMaxDynamicSharedMemorySize, (int)ds_small_lds(DS_SMALL)));
   d.plan.sym.build_partition(NV, c->h_rows, d.grids, d.blocks, d.leaf);
   d.static_ready = true;
   d.plan_valid = false;
@@ -76,6 +79,7 @@ static int direct_plan(tsl_ctx* c) {
   TSL_TRY(ds_upload_grow(d.con_dst, P.con_dst, s)); TSL_TRY(ds_upload_grow(d.con_ld, P.con_ld, s));
   TSL_TRY(ds_upload_grow(d.wl_front, P.wl_front, s)); TSL_TRY(ds_upload_grow(d.wl_row, P.wl_row, s));
   if (d.arena.n < (size_t)P.arena) { if (d.arena.alloc((size_t)P.arena + (size_t)P.arena / 8)) return tsl_fail("direct solver: out of device memory (%.2f GB of fronts)", P.arena * 8e-9); }
+  if (d.garena.n < (size_t)P.garena) { if (d.garena.alloc((size_t)P.garena + (size_t)P.garena / 8 + 16)) return tsl_fail("direct solver: out of device memory (G arena)"); }
   if (d.scr.n < (size_t)P.scratch) { if (d.scr.alloc((size_t)P.scratch + (size_t)P.scratch / 8)) return -1; }
   const size_t n3 = 3 * (size_t)c->NV;
   if (d.w.n < n3) { if (d.w.alloc(n3)) return -1; }
@@ -108,14 +112,15 @@ static int direct_factor(tsl_ctx* c) {
   for (const DsBatch& b : P.batches) {
     const int lv0 = b.first, nf = b.count;
     const int tp = b.max_pp / DS_T, tb = b.max_bp / DS_T;
-    hipLaunchKernelGGL(k_ds_pivot0, dim3(nf), dim3(256), 0, s, D, lv0);
-    for (int k = 0; k < tp; k++) {
-      const int na = P.act_n[b.act_off + k], tl = P.act_ld[b.act_off + k] / DS_T;   // fronts are sorted by pp: the active ones are a prefix
-      hipLaunchKernelGGL(k_ds_panel, dim3(tl, na), dim3(256), 0, s, D, lv0, k);
-      hipLaunchKernelGGL(k_ds_update, dim3(tl, tp, na), dim3(256), 0, s, D, lv0, k);
+    if (b.max_pp <= DS_SMALL) hipLaunchKernelGGL(k_ds_inv_small, dim3(nf), dim3(256), ds_small_lds(b.max_pp), s, D, lv0, b.max_pp + 1);
+    else {
+      hipLaunchKernelGGL(k_ds_pivot0, dim3(nf), dim3(256), 0, s, D, lv0);
+      for (int k = 0; k < tp; k++) hipLaunchKernelGGL(k_ds_gj_step, dim3(tp, tp, P.act_n[b.act_off + k]), dim3(256), 0, s, D, lv0, k);   // fronts are sorted by pp: the active ones are a prefix
+      hipLaunchKernelGGL(k_ds_gj_finish, dim3(tp, nf), dim3(256), 0, s, D, lv0);
     }
     if (tb > 0) {
-      hipLaunchKernelGGL(k_ds_schur, dim3((tb + 1) / 2, (tb + 1) / 2, nf), dim3(256), 0, s, D, lv0);
+      hipLaunchKernelGGL(k_ds_gemm, dim3((tb + 1) / 2, (tp + 1) / 2, nf), dim3(256), 0, s, D, lv0, 0);
+      hipLaunchKernelGGL(k_ds_gemm, dim3((tb + 1) / 2, (tb + 1) / 2, nf), dim3(256), 0, s, D, lv0, 1);
       hipLaunchKernelGGL(k_ds_extend, dim3(tb, tb, nf), dim3(256), 0, s, D, lv0);
     }
   }
@@ -154,7 +159,8 @@ static int direct_apply(tsl_ctx* c, const double* r, double* z) {
 
 // Timing of one kernel class of the factorisation / solve for bench.py's roofline object: the launches of that class of ONE
 // factorisation (or one application), exactly as direct_factor / direct_apply issue them on the current plan, replayed `reps` times
-// back to back between one hipEvent pair on the engine stream.  cls: 0 k_ds_update, 1 k_ds_schur, 2 k_ds_panel, 3 k_ds_extend,
+// back to back between one hipEvent pair on the engine stream.  cls: 0 the Gauss-Jordan inversions W = F11^-1 (k_ds_inv_small /
+// k_ds_pivot0 + k_ds_gj_step + k_ds_gj_finish), 1 k_ds_gemm mode 1 (Schur complements), 2 k_ds_gemm mode 0 (G = W F12), 3 k_ds_extend,
 // 4 k_ds_gemv (all sweeps of one application).  The replays overwrite the factors (marked invalid afterwards).
 // out: {us per launch, algorithmic flops per launch, algorithmic bytes per launch, launches per factorisation / application}
 static int direct_bench(tsl_ctx* c, int cls, int reps, double* out) {
@@ -184,28 +190,28 @@ static int direct_bench(tsl_ctx* c, int cls, int reps, double* out) {
     for (const DsBatch& b : P.batches) {
       const int lv0 = b.first, nf = b.count;
       const int tp = b.max_pp / DS_T, tb = b.max_bp / DS_T;
-      if (cls == 0 || cls == 2) {
-        for (int k = 0; k < tp; k++) {
-          const int na = P.act_n[b.act_off + k], tl = P.act_ld[b.act_off + k] / DS_T;
-          if (cls == 2) hipLaunchKernelGGL(k_ds_panel, dim3(tl, na), dim3(256), 0, s, D, lv0, k);
-          else hipLaunchKernelGGL(k_ds_update, dim3(tl, tp, na), dim3(256), 0, s, D, lv0, k);
-          if (count) {
-            launches++;
-            for (int i = 0; i < na; i++) {
-              const DsFrontDesc& f = P.fr[P.level_sn[lv0 + i]];
-              if (cls == 2) { flops += 2.0 * DS_T * DS_T * f.ld; bytes += 8.0 * (2.0 * DS_T * f.ld + 2.0 * DS_T * f.pp + DS_T * DS_T); }
-              else { flops += 2.0 * DS_T * (double)f.pp * f.ld; bytes += 8.0 * (2.0 * (double)f.pp * f.ld + (double)DS_T * f.ld + (double)f.pp * DS_T); }  // read + write of the block rows, both panels once
-            }
-          }
+      if (cls == 0) {   // W = F11^-1: the LDS kernel or pivot0 + block steps + finish
+        if (b.max_pp <= DS_SMALL) { hipLaunchKernelGGL(k_ds_inv_small, dim3(nf), dim3(256), ds_small_lds(b.max_pp), s, D, lv0, b.max_pp + 1); if (count) launches++; }
+        else {
+          hipLaunchKernelGGL(k_ds_pivot0, dim3(nf), dim3(256), 0, s, D, lv0);
+          for (int k = 0; k < tp; k++) hipLaunchKernelGGL(k_ds_gj_step, dim3(tp, tp, P.act_n[b.act_off + k]), dim3(256), 0, s, D, lv0, k);
+          hipLaunchKernelGGL(k_ds_gj_finish, dim3(tp, nf), dim3(256), 0, s, D, lv0);
+          if (count) launches += tp + 2;
+        }
+        if (count) for (int i = 0; i < nf; i++) {
+          const DsFrontDesc& f = P.fr[P.level_sn[lv0 + i]];
+          flops += 2.0 * (double)f.pp * f.pp * f.pp;
+          bytes += 16.0 * (double)f.pp * f.pp * (f.pp <= DS_SMALL ? 1.0 : f.pp / (double)DS_T);   // the block read and written once per launch that touches it
         }
       } else if (tb > 0) {
-        if (cls == 1) hipLaunchKernelGGL(k_ds_schur, dim3((tb + 1) / 2, (tb + 1) / 2, nf), dim3(256), 0, s, D, lv0);
+        if (cls == 1 || cls == 2) hipLaunchKernelGGL(k_ds_gemm, dim3((tb + 1) / 2, ((cls == 2 ? tp : tb) + 1) / 2, nf), dim3(256), 0, s, D, lv0, cls == 2 ? 0 : 1);
         else hipLaunchKernelGGL(k_ds_extend, dim3(tb, tb, nf), dim3(256), 0, s, D, lv0);
         if (count) {
           launches++;
           for (int i = 0; i < nf; i++) {
             const DsFrontDesc& f = P.fr[P.level_sn[lv0 + i]];
             if (cls == 1) { flops += 2.0 * (double)f.bp * f.bp * f.pp; bytes += 8.0 * (2.0 * (double)f.bp * f.pp + 2.0 * (double)f.bp * f.bp); }
+            else if (cls == 2) { flops += 2.0 * (double)f.pp * f.pp * f.bp; bytes += 8.0 * ((double)f.pp * f.pp + 2.0 * (double)f.pp * f.bp); }
             else if (f.parent >= 0) bytes += 8.0 * 3.0 * (double)f.b * f.b;   // S read, parent entries read + written
           }
         }

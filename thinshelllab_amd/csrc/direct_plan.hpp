@@ -12,6 +12,7 @@
 
 struct DsFrontDesc {
   long long off;             // first element of the front in the arena (doubles)
+  long long goff;            // first element of G = W F12 (pp x bp, row stride bp) in the G arena
   int p, pp, b, bp, ld;      // own dofs, padded; boundary dofs, padded; leading dimension
   int parent;                // supernode of the parent front, -1 at a root
   int rel_off;               // rel[rel_off + iv]: local dof index (in the parent front) of the first dof of boundary vertex iv
@@ -42,6 +43,7 @@ struct DirectPlan {
   std::vector<int> wl_front, wl_row, wl_own_ptr, wl_bnd_ptr;   // own chunks of level l: [wl_own_ptr[l], wl_bnd_ptr[l]); boundary chunks: [wl_bnd_ptr[l], wl_own_ptr[l + 1])
   int n_levels = 0;
   long long arena = 0;      // doubles
+  long long garena = 0;     // doubles
   long long scratch = 0;    // doubles, max over the levels
   double flops = 0;
 
@@ -62,7 +64,7 @@ struct DirectPlan {
     const int S = sym.n_sn;
     fr.assign(S, DsFrontDesc{});
     rel.clear(); vtx.clear();
-    arena = 0; flops = 0;
+    arena = 0; garena = 0; flops = 0;
     for (int s = 0; s < S; s++) {
       DsFrontDesc& f = fr[s];
       f.nv_own = sym.own(s); f.nv_bnd = (int)sym.bnd[s].size();
@@ -70,6 +72,8 @@ struct DirectPlan {
       f.pp = pad(f.p); f.bp = pad(f.b); f.ld = f.pp + f.bp;
       f.off = arena;
       arena += (long long)f.ld * f.ld;
+      f.goff = garena;
+      garena += (long long)f.pp * f.bp;
       f.parent = sym.parent[s];
       f.vtx_off = (int)vtx.size();
       for (int q = sym.sn_ptr[s]; q < sym.sn_ptr[s + 1]; q++) vtx.push_back(sym.order[q]);
@@ -117,7 +121,7 @@ struct DirectPlan {
         b.max_pp = std::max(b.max_pp, f.pp); b.max_ld = std::max(b.max_ld, f.ld); b.max_bp = std::max(b.max_bp, f.bp);
         level_sn.push_back(s);
         f.scr_off = (int)scr;
-        scr += 2LL * DS_T * DS_T + (long long)DS_T * f.ld + (long long)f.pp * DS_T;  // pivot-block inverses (ping-pong), row panel, column panel
+        scr += 2LL * DS_T * DS_T + 4LL * DS_T * f.pp;  // pivot-block inverses, row and column side panels (ping-pong each)
       }
       level_ptr[l + 1] = (int)level_sn.size();
       scratch = std::max(scratch, scr);

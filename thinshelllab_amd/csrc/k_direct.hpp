@@ -3,10 +3,11 @@
 // storage is impossible, and the iterative solvers of k_solver.hpp need 10^2..10^5 iterations on the wrinkled cfg4 states, so the
 // same operator is factorised here: one dense front per supernode of the nested-dissection tree, fronts of one tree level
 // batched into the same launches.  Per front:  [F11 F12; F21 F22] -> [W = F11^-1, G = W F12; F21, S = F22 - F21 G].
-//   * W, G: blocked in-place Gauss-Jordan on the pp x ld top block rows (DS_T pivots per step, two launches per step; the pivot
-//     block of the next step is inverted by one wave inside the update kernel).  No pivoting: measured on the cfg4 operators
-//     (forward and un-projected adjoint) a nested-dissection LU with diagonal pivots reaches a 1e-10 relative residual.
-//   * S: a K = pp GEMM on the f64 matrix cores (v_mfma_f64_16x16x4_f64), the bulk of the flops.
+//   * W: blocked in-place Gauss-Jordan on F11 (DS_T pivots per step): fronts with at most DS_SMALL pivots by one workgroup with
+//     the block in LDS, larger ones with one launch per block step (the pivot block of the next step is inverted by one wave inside
+//     the step kernel).  No pivoting: measured on the cfg4 operators (forward and un-projected adjoint) a nested-dissection LU with
+//     diagonal pivots reaches a 1e-10 relative residual.
+//   * G = W F12 and S = F22 - F21 G: K = pp GEMMs on the f64 matrix cores (v_mfma_f64_16x16x4_f64), the bulk of the flops.
 //   * S is added into the parent front through the child's boundary -> parent index map (f64 atomics: siblings overlap).
 // A solve is three matrix-vector passes per level (W, F21 upwards; G downwards), no triangular recurrences.
 #pragma once
@@ -19,6 +20,7 @@ struct DsDev {                 // device views shared by the kernels
   const DsFrontDesc* fr;
   const int* level_sn;         // front ids, level after level
   double* A;                   // front arena
+  double* G;                   // G = W F12 of every front (pp x bp, row stride bp)
   double* scr;                 // per-level scratch (pivot-block inverses, row panel, column panel per front)
   const int* rel;
   const int* vtx;              // local vertex -> PERMUTED vertex position (rows of the solver vectors)
@@ -123,12 +125,13 @@ TSL_DEV void ds_invert_tile_wave(double (*T)[DS_T + 1], int* __restrict__ bad) {
   if (lane == 0 && nbad) atomicAdd(bad, nbad);
 }
 
-// scratch of a front inside the level scratch: P0, P1 (pivot-block inverses, ping-pong), row panel R' (DS_T x ld), column panel C (pp x DS_T)
+// scratch of a front inside the level scratch (fronts with more than DS_SMALL pivots): pivot-block inverses P[2] (ping-pong) and the
+// side panels of the merged Gauss-Jordan step, row panel R[2] (DS_T x pp) and column panel C[2] (pp x DS_T)
 TSL_DEV double* ds_scr_P(const DsDev& D, const DsFrontDesc& f, int which) { return D.scr + f.scr_off + which * DS_T * DS_T; }
-TSL_DEV double* ds_scr_R(const DsDev& D, const DsFrontDesc& f) { return D.scr + f.scr_off + 2 * DS_T * DS_T; }
-TSL_DEV double* ds_scr_C(const DsDev& D, const DsFrontDesc& f) { return D.scr + f.scr_off + 2 * DS_T * DS_T + (size_t)DS_T * f.ld; }
+TSL_DEV double* ds_scr_R(const DsDev& D, const DsFrontDesc& f, int which) { return D.scr + f.scr_off + 2 * DS_T * DS_T + (size_t)which * DS_T * f.pp; }
+TSL_DEV double* ds_scr_C(const DsDev& D, const DsFrontDesc& f, int which) { return D.scr + f.scr_off + 2 * DS_T * DS_T + (size_t)(2 + which) * DS_T * f.pp; }
 
-// inverse of the first pivot block of every front of the level -> P0
+// inverse of the first pivot block of every front of the batch -> P[0]
 __global__ void __launch_bounds__(256) k_ds_pivot0(DsDev D, int lv0) {
   __shared__ double T[DS_T][DS_T + 1];
   const DsFrontDesc f = D.fr[D.level_sn[lv0 + blockIdx.x]];
@@ -144,132 +147,246 @@ __global__ void __launch_bounds__(256) k_ds_pivot0(DsDev D, int lv0) {
   for (int q = 0; q < 4; q++) P[(ty + 8 * q) * DS_T + tx] = T[ty + 8 * q][tx];
 }
 
-// panel kernel of block step k: workgroup b writes the row panel R'[:, chunk b] = P A[K, chunk b] (all ld / DS_T column chunks) and
-// saves the column panel C[chunk b, :] = A[chunk b, K] (the pp / DS_T row chunks)
-__global__ void __launch_bounds__(256) k_ds_panel(DsDev D, int lv0, int k) {
-  __shared__ double P[DS_T][DS_T + 1];
-  __shared__ double T[DS_T][DS_T + 1];
-  const DsFrontDesc f = D.fr[D.level_sn[lv0 + blockIdx.y]];
-  const int k0 = k * DS_T, b = blockIdx.x, b0 = b * DS_T;
-  if (k0 >= f.pp || b0 >= f.ld) return;
-  const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;
-  double* A = D.A + f.off;
-  const double* Pin = ds_scr_P(D, f, k & 1);
-  double* Rn = ds_scr_R(D, f);
-  double* Cs = ds_scr_C(D, f);
-#pragma unroll
-  for (int q = 0; q < 4; q++) {
-    const int i = ty + 8 * q;
-    P[i][tx] = Pin[i * DS_T + tx];
-    T[i][tx] = A[(size_t)(k0 + i) * f.ld + b0 + tx];
-    if (b0 < f.pp) Cs[(size_t)(b0 + i) * DS_T + tx] = A[(size_t)(b0 + i) * f.ld + k0 + tx];
-  }
-  __syncthreads();
-#pragma unroll
-  for (int q = 0; q < 4; q++) {
-    const int i = ty + 8 * q;
-    double acc = 0;
-#pragma unroll 8
-    for (int m = 0; m < DS_T; m++) acc += P[i][m] * T[m][tx];
-    Rn[(size_t)i * f.ld + b0 + tx] = acc;
-  }
+// Block step k of the in-place Gauss-Jordan inversion W = F11^-1 as ONE launch (pivot rows K = [k T, k T + T)):
+//   A_KK = P = inv(A_KK),  A_Kj = R'_j = P A_Kj,  A_iK = -A_iK P,  A_ij -= A_iK R'_j   (i, j outside K).
+// Every workgroup owns one T x T tile and forms the R'_j it needs itself (one extra 32^3 product), so there is no panel launch.  The
+// tiles of row K and column K are read by the other workgroups of the same launch, hence their new values go to side panels
+// (R[k & 1], C[k & 1]) and the NEXT step reads row / column K from there; whoever owns such a tile in step k + 1 writes its updated
+// value back into the front.  The workgroup of tile (k+1, k+1) also inverts its result (the next pivot block) into P[(k+1) & 1];
+// it is dispatched first so that the single-wave inversion overlaps with the other tiles.  k_ds_gj_finish copies the side
+// panels of the last step back.
+TSL_DEV double ds_tile_elem(const double* __restrict__ A, int ld, const double* __restrict__ Rs, const double* __restrict__ Cs, int pp, int kp, int ti, int tj, int r, int c) {
+  if (ti == kp) return Rs[(size_t)r * pp + tj * DS_T + c];
+  if (tj == kp) return Cs[(size_t)(ti * DS_T + r) * DS_T + c];
+  return A[(size_t)(ti * DS_T + r) * ld + tj * DS_T + c];
 }
-
-// update kernel of block step k: one DS_T x DS_T tile of the top block rows per workgroup,
-//   A_ij -= C_i R'_j (i, j outside K),  A_Kj = R'_j,  A_iK = -C_i P,  A_KK = P;
-// the workgroup of tile (k+1, k+1) also inverts its updated tile (the next pivot block) into the other P buffer
-__global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(4, 8))) k_ds_update(DsDev D, int lv0, int k) {
-  __shared__ double Ct[DS_T][DS_T + 1];
-  __shared__ double Rt[DS_T][DS_T + 1];
+__global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(4, 8))) k_ds_gj_step(DsDev D, int lv0, int k) {
+  __shared__ double Ps[DS_T][DS_T + 1];
+  __shared__ double T1[DS_T][DS_T + 1];   // A[K, j], later R'_j
+  __shared__ double T2[DS_T][DS_T + 1];   // A[i, K], later the next pivot block
   const DsFrontDesc f = D.fr[D.level_sn[lv0 + blockIdx.z]];
-  const int k0 = k * DS_T;
-  if (k0 >= f.pp) return;
+  const int pp = f.pp, k0 = k * DS_T;
+  if (k0 >= pp) return;
   int bi = blockIdx.y, bj = blockIdx.x;
-  const bool has_next = (k + 1) * DS_T < f.pp;
-  if (has_next) {  // the tile that carries the single-wave inversion is dispatched first
+  const bool has_next = k0 + DS_T < pp;
+  if (has_next) {
     if (bi == 0 && bj == 0) bi = bj = k + 1;
     else if (bi == k + 1 && bj == k + 1) bi = bj = 0;
   }
-  const int i0 = bi * DS_T, j0 = bj * DS_T;
-  if (i0 >= f.pp || j0 >= f.ld) return;
+  if (bi * DS_T >= pp || bj * DS_T >= pp) return;
   const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;
+  const int lane = threadIdx.x & 63, w = threadIdx.x >> 6, wi = w >> 1, wj = w & 1, lr = lane & 15, lk = lane >> 4;
   double* A = D.A + f.off;
+  const int ld = f.ld, kp = k - 1;
   const double* Pin = ds_scr_P(D, f, k & 1);
-  const double* Rn = ds_scr_R(D, f);
-  const double* Cs = ds_scr_C(D, f);
-  if (bi == k) {
-#pragma unroll
-    for (int q = 0; q < 4; q++) A[(size_t)(i0 + ty + 8 * q) * f.ld + j0 + tx] = (bj == k) ? Pin[(ty + 8 * q) * DS_T + tx] : Rn[(size_t)(ty + 8 * q) * f.ld + j0 + tx];
-    return;
-  }
+  const double* Rs = ds_scr_R(D, f, kp & 1);
+  const double* Cs = ds_scr_C(D, f, kp & 1);
+  double* Rn = ds_scr_R(D, f, k & 1);
+  double* Cn = ds_scr_C(D, f, k & 1);
 #pragma unroll
   for (int q = 0; q < 4; q++) {
-    Ct[ty + 8 * q][tx] = Cs[(size_t)(i0 + ty + 8 * q) * DS_T + tx];
-    Rt[ty + 8 * q][tx] = (bj == k) ? Pin[(ty + 8 * q) * DS_T + tx] : Rn[(size_t)(ty + 8 * q) * f.ld + j0 + tx];
+    const int r = ty + 8 * q;
+    Ps[r][tx] = Pin[r * DS_T + tx];
+    if (bj != k) T1[r][tx] = ds_tile_elem(A, ld, Rs, Cs, pp, kp, k, bj, r, tx);
+    if (bi != k) T2[r][tx] = ds_tile_elem(A, ld, Rs, Cs, pp, kp, bi, k, r, tx);
   }
   __syncthreads();
-  // rank-32 update on the f64 matrix cores: wave (wi, wj) owns a 16 x 16 quadrant (A operand: lane l holds C[l & 15][4 kk + (l >> 4)],
-  // B operand: R'[4 kk + (l >> 4)][l & 15]; result register r of lane l is element (row (l >> 4) + 4 r, column l & 15))
-  const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
-  const int wi = w >> 1, wj = w & 1;
-  const int lr = lane & 15, lk = lane >> 4;
-  ds_d4 acc = {0.0, 0.0, 0.0, 0.0};
+  if (bi == k && bj == k) {  // A_KK = P
 #pragma unroll
-  for (int kk = 0; kk < DS_T / 4; kk++) acc = __builtin_amdgcn_mfma_f64_16x16x4f64(Ct[16 * wi + lr][4 * kk + lk], Rt[4 * kk + lk][16 * wj + lr], acc, 0, 0, 0);
+    for (int q = 0; q < 4; q++) Rn[(size_t)(ty + 8 * q) * pp + k0 + tx] = Ps[ty + 8 * q][tx];
+    return;
+  }
+  ds_d4 acc = {0.0, 0.0, 0.0, 0.0};
+  if (bj == k) {  // A_iK = -A_iK P
+#pragma unroll
+    for (int kk = 0; kk < DS_T / 4; kk++) acc = __builtin_amdgcn_mfma_f64_16x16x4f64(T2[16 * wi + lr][4 * kk + lk], Ps[4 * kk + lk][16 * wj + lr], acc, 0, 0, 0);
+#pragma unroll
+    for (int r = 0; r < 4; r++) Cn[(size_t)(bi * DS_T + 16 * wi + lk + 4 * r) * DS_T + 16 * wj + lr] = -acc[r];
+    return;
+  }
+  // R'_j = P A_Kj (quadrant (wi, wj))
+#pragma unroll
+  for (int kk = 0; kk < DS_T / 4; kk++) acc = __builtin_amdgcn_mfma_f64_16x16x4f64(Ps[16 * wi + lr][4 * kk + lk], T1[4 * kk + lk][16 * wj + lr], acc, 0, 0, 0);
+  if (bi == k) {
+#pragma unroll
+    for (int r = 0; r < 4; r++) Rn[(size_t)(16 * wi + lk + 4 * r) * pp + bj * DS_T + 16 * wj + lr] = acc[r];
+    return;
+  }
+  __syncthreads();   // every quadrant has read T1
+#pragma unroll
+  for (int r = 0; r < 4; r++) T1[16 * wi + lk + 4 * r][16 * wj + lr] = acc[r];
+  __syncthreads();
+  acc = ds_d4{0.0, 0.0, 0.0, 0.0};
+#pragma unroll
+  for (int kk = 0; kk < DS_T / 4; kk++) acc = __builtin_amdgcn_mfma_f64_16x16x4f64(T2[16 * wi + lr][4 * kk + lk], T1[4 * kk + lk][16 * wj + lr], acc, 0, 0, 0);
   const bool next_pivot = has_next && bi == k + 1 && bj == k + 1;
-  if (next_pivot) __syncthreads();
+  if (next_pivot) __syncthreads();   // every quadrant has read T2
 #pragma unroll
   for (int r = 0; r < 4; r++) {
     const int row = 16 * wi + lk + 4 * r, col = 16 * wj + lr;
-    double* d = A + (size_t)(i0 + row) * f.ld + j0 + col;
-    const double v = (bj == k) ? -acc[r] : *d - acc[r];
-    *d = v;
-    if (next_pivot) Ct[row][col] = v;
+    const double v = ds_tile_elem(A, ld, Rs, Cs, pp, kp, bi, bj, row, col) - acc[r];
+    A[(size_t)(bi * DS_T + row) * ld + bj * DS_T + col] = v;
+    if (next_pivot) T2[row][col] = v;
   }
   if (next_pivot) {
     __syncthreads();
-    if (threadIdx.x < 64) ds_invert_tile_wave(Ct, D.bad);
+    if (threadIdx.x < 64) ds_invert_tile_wave(T2, D.bad);
     __syncthreads();
     double* Pn = ds_scr_P(D, f, (k + 1) & 1);
 #pragma unroll
-    for (int q = 0; q < 4; q++) Pn[(ty + 8 * q) * DS_T + tx] = Ct[ty + 8 * q][tx];
+    for (int q = 0; q < 4; q++) Pn[(ty + 8 * q) * DS_T + tx] = T2[ty + 8 * q][tx];
+  }
+}
+// side panels of the last block step back into the front: workgroup (b, front) copies row-panel chunk b and column-panel chunk b
+__global__ void __launch_bounds__(256) k_ds_gj_finish(DsDev D, int lv0) {
+  const DsFrontDesc f = D.fr[D.level_sn[lv0 + blockIdx.y]];
+  const int pp = f.pp, b0 = blockIdx.x * DS_T;
+  if (b0 >= pp) return;
+  const int kl = pp / DS_T - 1;
+  const double* Rs = ds_scr_R(D, f, kl & 1);
+  const double* Cs = ds_scr_C(D, f, kl & 1);
+  double* A = D.A + f.off;
+  const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;
+#pragma unroll
+  for (int q = 0; q < 4; q++) {
+    const int r = ty + 8 * q;
+    A[(size_t)(kl * DS_T + r) * f.ld + b0 + tx] = Rs[(size_t)r * pp + b0 + tx];
+    if ((int)blockIdx.x != kl) A[(size_t)(b0 + r) * f.ld + kl * DS_T + tx] = Cs[(size_t)(b0 + r) * DS_T + tx];
   }
 }
 
-// ---- Schur complement S = F22 - F21 G on the f64 matrix cores ----------------------------------------------------------------
-// one 64 x 64 tile of S per workgroup (four waves, each a 32 x 32 quadrant = 2 x 2 MFMA tiles), K = pp in chunks of 32 through LDS
-#define DS_SK 32
-__global__ void __launch_bounds__(256) k_ds_schur(DsDev D, int lv0) {
-  __shared__ double As[64][DS_SK + 1];   // F21[I, kchunk]
-  __shared__ double Bs[DS_SK][64 + 1];   // G[kchunk, J]
-  const DsFrontDesc f = D.fr[D.level_sn[lv0 + blockIdx.z]];
-  const int I0 = blockIdx.y * 64, J0 = blockIdx.x * 64;
-  if (I0 >= f.bp || J0 >= f.bp) return;
+// W = F11^-1 of a front with at most DS_SMALL pivots by ONE workgroup with the block in LDS (row stride ls = batch maximum + 1):
+// the same blocked Gauss-Jordan, all block steps inside the launch -- wave 0 inverts the pivot block, every wave owns row chunks of
+// the rank-T update on the matrix cores (its column-panel fragment lives in registers while the chunk is rewritten).
+#define DS_SMALL 128
+__global__ void __launch_bounds__(256) k_ds_inv_small(DsDev D, int lv0, int ls) {
+  extern __shared__ double ds_sm[];
+  double* M = ds_sm;
+  double (*Tt)[DS_T + 1] = (double (*)[DS_T + 1])(ds_sm + (size_t)(ls - 1) * ls);
+  const DsFrontDesc f = D.fr[D.level_sn[lv0 + blockIdx.x]];
+  const int pp = f.pp, nt = pp / DS_T;
   double* A = D.A + f.off;
+  const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;
+  const int lane = threadIdx.x & 63, w = threadIdx.x >> 6, lr = lane & 15, lk = lane >> 4;
+  for (int i = ty; i < pp; i += 8)
+    for (int j = tx; j < pp; j += 32) M[i * ls + j] = A[(size_t)i * f.ld + j];
+  __syncthreads();
+  for (int k = 0; k < nt; k++) {
+    const int k0 = k * DS_T;
+#pragma unroll
+    for (int q = 0; q < 4; q++) Tt[ty + 8 * q][tx] = M[(k0 + ty + 8 * q) * ls + k0 + tx];
+    __syncthreads();
+    if (threadIdx.x < 64) ds_invert_tile_wave(Tt, D.bad);
+    __syncthreads();
+    // R'_j = P A_Kj in place (a wave owns whole tiles: all its reads of a tile precede its writes)
+    for (int j = w; j < nt; j += 4) {
+      if (j == k) continue;
+      const int j0 = j * DS_T;
+      ds_d4 acc[2][2];
+#pragma unroll
+      for (int a = 0; a < 2; a++)
+#pragma unroll
+        for (int b = 0; b < 2; b++) acc[a][b] = ds_d4{0.0, 0.0, 0.0, 0.0};
+#pragma unroll
+      for (int kk = 0; kk < DS_T / 4; kk++) {
+        const double a0 = Tt[lr][4 * kk + lk], a1 = Tt[16 + lr][4 * kk + lk];
+        const double b0 = M[(k0 + 4 * kk + lk) * ls + j0 + lr], b1 = M[(k0 + 4 * kk + lk) * ls + j0 + 16 + lr];
+        acc[0][0] = __builtin_amdgcn_mfma_f64_16x16x4f64(a0, b0, acc[0][0], 0, 0, 0);
+        acc[0][1] = __builtin_amdgcn_mfma_f64_16x16x4f64(a0, b1, acc[0][1], 0, 0, 0);
+        acc[1][0] = __builtin_amdgcn_mfma_f64_16x16x4f64(a1, b0, acc[1][0], 0, 0, 0);
+        acc[1][1] = __builtin_amdgcn_mfma_f64_16x16x4f64(a1, b1, acc[1][1], 0, 0, 0);
+      }
+      __builtin_amdgcn_wave_barrier();
+#pragma unroll
+      for (int a = 0; a < 2; a++)
+#pragma unroll
+        for (int b = 0; b < 2; b++)
+#pragma unroll
+          for (int r = 0; r < 4; r++) M[(k0 + 16 * a + lk + 4 * r) * ls + j0 + 16 * b + lr] = acc[a][b][r];
+    }
+    __syncthreads();
+    // A_ij -= A_iK R'_j, A_iK = -A_iK P for the row chunks i != k
+    for (int i = w; i < nt; i += 4) {
+      if (i == k) continue;
+      const int i0 = i * DS_T;
+      double c0[DS_T / 4], c1[DS_T / 4];
+#pragma unroll
+      for (int kk = 0; kk < DS_T / 4; kk++) { c0[kk] = -M[(i0 + lr) * ls + k0 + 4 * kk + lk]; c1[kk] = -M[(i0 + 16 + lr) * ls + k0 + 4 * kk + lk]; }
+      __builtin_amdgcn_wave_barrier();
+      for (int j = 0; j < nt; j++) {
+        const int j0 = j * DS_T;
+        ds_d4 acc[2][2];
+#pragma unroll
+        for (int a = 0; a < 2; a++)
+#pragma unroll
+          for (int b = 0; b < 2; b++)
+#pragma unroll
+            for (int r = 0; r < 4; r++) acc[a][b][r] = (j == k) ? 0.0 : M[(i0 + 16 * a + lk + 4 * r) * ls + j0 + 16 * b + lr];
+#pragma unroll
+        for (int kk = 0; kk < DS_T / 4; kk++) {
+          const double b0 = (j == k) ? Tt[4 * kk + lk][lr] : M[(k0 + 4 * kk + lk) * ls + j0 + lr];
+          const double b1 = (j == k) ? Tt[4 * kk + lk][16 + lr] : M[(k0 + 4 * kk + lk) * ls + j0 + 16 + lr];
+          acc[0][0] = __builtin_amdgcn_mfma_f64_16x16x4f64(c0[kk], b0, acc[0][0], 0, 0, 0);
+          acc[0][1] = __builtin_amdgcn_mfma_f64_16x16x4f64(c0[kk], b1, acc[0][1], 0, 0, 0);
+          acc[1][0] = __builtin_amdgcn_mfma_f64_16x16x4f64(c1[kk], b0, acc[1][0], 0, 0, 0);
+          acc[1][1] = __builtin_amdgcn_mfma_f64_16x16x4f64(c1[kk], b1, acc[1][1], 0, 0, 0);
+        }
+#pragma unroll
+        for (int a = 0; a < 2; a++)
+#pragma unroll
+          for (int b = 0; b < 2; b++)
+#pragma unroll
+            for (int r = 0; r < 4; r++) M[(i0 + 16 * a + lk + 4 * r) * ls + j0 + 16 * b + lr] = acc[a][b][r];
+      }
+    }
+    __syncthreads();
+#pragma unroll
+    for (int q = 0; q < 4; q++) M[(k0 + ty + 8 * q) * ls + k0 + tx] = Tt[ty + 8 * q][tx];
+    __syncthreads();
+  }
+  for (int i = ty; i < pp; i += 8)
+    for (int j = tx; j < pp; j += 32) A[(size_t)i * f.ld + j] = M[i * ls + j];
+}
+
+// ---- the two GEMMs of a front on the f64 matrix cores -------------------------------------------------------------------------
+//   mode 0:  G = W F12            (pp x bp, K = pp)  into the G arena (row stride bp)
+//   mode 1:  S = F22 - F21 G      (bp x bp, K = pp)  in place
+// one 64 x 64 output tile per workgroup (four waves, each a 32 x 32 quadrant = 2 x 2 MFMA tiles), K in chunks of 32 through LDS
+#define DS_SK 32
+__global__ void __launch_bounds__(256) k_ds_gemm(DsDev D, int lv0, int mode) {
+  __shared__ double As[64][DS_SK + 1];
+  __shared__ double Bs[DS_SK][64 + 1];
+  const DsFrontDesc f = D.fr[D.level_sn[lv0 + blockIdx.z]];
+  const int Mr = mode == 0 ? f.pp : f.bp, Nc = f.bp, K = f.pp;
+  const int I0 = blockIdx.y * 64, J0 = blockIdx.x * 64;
+  if (I0 >= Mr || J0 >= Nc) return;
+  double* F = D.A + f.off;
+  double* G = D.G + f.goff;
   const int ld = f.ld, pp = f.pp;
+  const double* Am = mode == 0 ? F : F + (size_t)pp * ld;          // W rows / F21 rows, row stride ld
+  const double* Bm = mode == 0 ? F + pp : G;                          // F12 (row stride ld) / G (row stride bp)
+  const int ldb = mode == 0 ? ld : f.bp;
   const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
   const int wi = w >> 1, wj = w & 1;
   const int lr = lane & 15, lk = lane >> 4;
-  const bool rows_hi = I0 + 32 < f.bp, cols_hi = J0 + 32 < f.bp;   // bp is a multiple of 32: the second half of the tile may lie outside
+  const bool rows_hi = I0 + 32 < Mr, cols_hi = J0 + 32 < Nc;   // Mr, Nc are multiples of 32: the second half of the tile may lie outside
   ds_d4 acc[2][2];
 #pragma unroll
   for (int a = 0; a < 2; a++)
 #pragma unroll
     for (int b = 0; b < 2; b++) acc[a][b] = ds_d4{0.0, 0.0, 0.0, 0.0};
   const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;  // 32 x 8
-  for (int k0 = 0; k0 < pp; k0 += DS_SK) {
-    // F21 chunk: 64 rows x 32 columns (thread: column tx, rows ty + 8 q)
+  for (int k0 = 0; k0 < K; k0 += DS_SK) {
 #pragma unroll
     for (int q = 0; q < 8; q++) {
       const int r = ty + 8 * q;
-      As[r][tx] = (r < 32 || rows_hi) ? A[(size_t)(pp + I0 + r) * ld + k0 + tx] : 0.0;
+      As[r][tx] = (r < 32 || rows_hi) ? Am[(size_t)(I0 + r) * ld + k0 + tx] : 0.0;
     }
-    // G chunk: 32 rows x 64 columns (thread: columns tx, tx + 32; rows ty + 8 q)
 #pragma unroll
     for (int q = 0; q < 4; q++) {
       const int r = ty + 8 * q;
-      Bs[r][tx] = A[(size_t)(k0 + r) * ld + pp + J0 + tx];
-      Bs[r][tx + 32] = cols_hi ? A[(size_t)(k0 + r) * ld + pp + J0 + 32 + tx] : 0.0;
+      Bs[r][tx] = Bm[(size_t)(k0 + r) * ldb + J0 + tx];
+      Bs[r][tx + 32] = cols_hi ? Bm[(size_t)(k0 + r) * ldb + J0 + 32 + tx] : 0.0;
     }
     __syncthreads();
 #pragma unroll
@@ -290,7 +407,10 @@ __global__ void __launch_bounds__(256) k_ds_schur(DsDev D, int lv0) {
 #pragma unroll
       for (int r = 0; r < 4; r++) {
         const int row = I0 + 32 * wi + 16 * a + lk + 4 * r, col = J0 + 32 * wj + 16 * b + lr;
-        if (row < f.bp && col < f.bp) A[(size_t)(pp + row) * ld + pp + col] -= acc[a][b][r];
+        if (row < Mr && col < Nc) {
+          if (mode == 0) G[(size_t)row * f.bp + col] = acc[a][b][r];
+          else F[(size_t)(pp + row) * ld + pp + col] -= acc[a][b][r];
+        }
       }
 }
 
@@ -330,16 +450,17 @@ __global__ void __launch_bounds__(256) k_ds_gemv(DsDev D, const int* __restrict_
   const int r0 = wl_row[wl0 + blockIdx.x];
   const int* vt = D.vtx + f.vtx_off;
   const int in_v0 = mode == 2 ? f.nv_own : 0, out_v0 = mode == 1 ? f.nv_own : 0;
-  const double* M = D.A + f.off + (mode == 1 ? (size_t)f.pp * f.ld : 0) + (mode == 2 ? f.pp : 0);
+  const double* M = mode == 2 ? D.G + f.goff : D.A + f.off + (mode == 1 ? (size_t)f.pp * f.ld : 0);
+  const int rs = mode == 2 ? f.bp : f.ld;
   const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
   double acc[4] = {0.0, 0.0, 0.0, 0.0};
   // the four rows of a wave advance together and the column loop is unrolled: 16 independent loads in flight per wave (one row at
   // a time with a dependent accumulation ran at the memory latency: 30 us for a 832 x 832 block)
   const int ib = r0 + 4 * w;
-  const double* row0 = M + (size_t)min(ib, nrows - 1) * f.ld;
-  const double* row1 = M + (size_t)min(ib + 1, nrows - 1) * f.ld;
-  const double* row2 = M + (size_t)min(ib + 2, nrows - 1) * f.ld;
-  const double* row3 = M + (size_t)min(ib + 3, nrows - 1) * f.ld;
+  const double* row0 = M + (size_t)min(ib, nrows - 1) * rs;
+  const double* row1 = M + (size_t)min(ib + 1, nrows - 1) * rs;
+  const double* row2 = M + (size_t)min(ib + 2, nrows - 1) * rs;
+  const double* row3 = M + (size_t)min(ib + 3, nrows - 1) * rs;
   for (int c0 = 0; c0 < ncols; c0 += DS_VCHUNK) {
     const int cn = min(DS_VCHUNK, ncols - c0);
     __syncthreads();

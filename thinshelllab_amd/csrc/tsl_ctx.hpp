@@ -107,7 +107,7 @@ struct DirectSolver {
   DevBuf<int> csr2sell, level_sn, rel, vtx, blk_ld, con_ld, bad, wl_front, wl_row;
   DevBuf<long long> blk_dst, con_dst;
   DevBuf<DsFrontDesc> fr;
-  DevBuf<double> arena, scr, w;
+  DevBuf<double> arena, garena, scr, w;
   long n_plans = 0, n_factor = 0, n_apply = 0, n_perturbed = 0;
   double t_plan = 0;          // host seconds spent in plan builds
   double anorm = 0;           // infinity norm of the factorised operator's static part (backward-error yardstick)
