@@ -208,9 +208,8 @@ def cpu_baseline(args, scene, gpu_stats, K, rank):
 def roofline(ctx, scene, elapsed, K, stats, args):
     """dominant kernel class of the sparse direct solve, measured live with HIP events (tsl_bench_direct), + section 8d's whole-step model"""
     names = {0: "k_ds_gj_step (+ k_ds_inv_small / k_ds_pivot0 / k_ds_gj_finish: blocked Gauss-Jordan inversion W = F11^-1 of every front of a batch, f64 MFMA tiles)",
-             1: "k_ds_gemm[schur] (Schur complement S = F22 - F21 G of every front of a batch: K = pp GEMM on v_mfma_f64_16x16x4_f64)",
+             1: "k_ds_gemm[schur] (Schur complement S = F22 - F21 G of every front of a batch, K = pp GEMM on v_mfma_f64_16x16x4_f64, added into the parent fronts by the epilogue)",
              2: "k_ds_gemm[g] (G = W F12 of every front of a batch: K = pp GEMM on v_mfma_f64_16x16x4_f64)",
-             3: "k_ds_extend (extend-add of a batch's Schur complements into the parent fronts, f64 atomics)",
              4: "k_ds_gemv (level sweeps of one application of the factors: W, F21 upwards, G downwards)"}
     cls = {}
     for k in names:

@@ -10,6 +10,20 @@
 static inline int ds_nblk(long n, int b) { return (int)((n + b - 1) / b); }
 
 static inline size_t ds_small_lds(int max_pp) { return ((size_t)max_pp * (max_pp + 1) + (size_t)DS_T * (DS_T + 1)) * sizeof(double); }
+// a batch goes to the LDS kernel (all block steps in one launch, one workgroup per front) when its fronts fit the chip in one round;
+// a larger batch has enough tile parallelism for the block-step kernel (measured: 1024 fronts of 96 pivots 322 us against ~100)
+static inline bool ds_use_small(const DsBatch& b) {
+  if (b.max_pp > DS_SMALL) return false;
+  const size_t per_cu = std::min<size_t>(8, (160 * 1024) / (ds_small_lds(b.max_pp) + 1024));
+  return (size_t)b.count <= 256 * std::max<size_t>(per_cu, 1);
+}
+
+// G = W F12 (mode 0) / S = F22 - F21 G added into the parents (mode 1) of a batch.  A 128 x 128-tile variant (64 accumulator
+// registers per lane, one wave per SIMD) was 2.5x slower than these 64 x 64 tiles, which reach 25-49 TFLOP/s per level on cfg4.
+static void ds_launch_gemm(hipStream_t s, const DsDev& D, const DsBatch& b, int mode) {
+  const int rows = mode == 0 ? b.max_pp : b.max_bp, cols = b.max_bp;
+  hipLaunchKernelGGL(k_ds_gemm, dim3((cols + 63) / 64, (rows + 63) / 64, b.count), dim3(256), 0, s, D, b.first, mode);
+}
 
 static bool direct_enabled(tsl_ctx* c) {
   DirectSolver& d = c->ds;
@@ -112,16 +126,15 @@ static int direct_factor(tsl_ctx* c) {
   for (const DsBatch& b : P.batches) {
     const int lv0 = b.first, nf = b.count;
     const int tp = b.max_pp / DS_T, tb = b.max_bp / DS_T;
-    if (b.max_pp <= DS_SMALL) hipLaunchKernelGGL(k_ds_inv_small, dim3(nf), dim3(256), ds_small_lds(b.max_pp), s, D, lv0, b.max_pp + 1);
+    if (ds_use_small(b)) hipLaunchKernelGGL(k_ds_inv_small, dim3(nf), dim3(256), ds_small_lds(b.max_pp), s, D, lv0, b.max_pp + 1);
     else {
       hipLaunchKernelGGL(k_ds_pivot0, dim3(nf), dim3(256), 0, s, D, lv0);
       for (int k = 0; k < tp; k++) hipLaunchKernelGGL(k_ds_gj_step, dim3(tp, tp, P.act_n[b.act_off + k]), dim3(256), 0, s, D, lv0, k);   // fronts are sorted by pp: the active ones are a prefix
       hipLaunchKernelGGL(k_ds_gj_finish, dim3(tp, nf), dim3(256), 0, s, D, lv0);
     }
     if (tb > 0) {
-      hipLaunchKernelGGL(k_ds_gemm, dim3((tb + 1) / 2, (tp + 1) / 2, nf), dim3(256), 0, s, D, lv0, 0);
-      hipLaunchKernelGGL(k_ds_gemm, dim3((tb + 1) / 2, (tb + 1) / 2, nf), dim3(256), 0, s, D, lv0, 1);
-      hipLaunchKernelGGL(k_ds_extend, dim3(tb, tb, nf), dim3(256), 0, s, D, lv0);
+      ds_launch_gemm(s, D, b, 0);
+      ds_launch_gemm(s, D, b, 1);   // + extend-add into the parents
     }
   }
   if (d.anorm_dev.n == 0 && d.anorm_dev.alloc(1)) return -1;
@@ -160,7 +173,7 @@ static int direct_apply(tsl_ctx* c, const double* r, double* z) {
 // Timing of one kernel class of the factorisation / solve for bench.py's roofline object: the launches of that class of ONE
 // factorisation (or one application), exactly as direct_factor / direct_apply issue them on the current plan, replayed `reps` times
 // back to back between one hipEvent pair on the engine stream.  cls: 0 the Gauss-Jordan inversions W = F11^-1 (k_ds_inv_small /
-// k_ds_pivot0 + k_ds_gj_step + k_ds_gj_finish), 1 k_ds_gemm mode 1 (Schur complements), 2 k_ds_gemm mode 0 (G = W F12), 3 k_ds_extend,
+// k_ds_pivot0 + k_ds_gj_step + k_ds_gj_finish), 1 k_ds_gemm mode 1 (Schur complements + extend-add), 2 k_ds_gemm mode 0 (G = W F12), 3 unused,
 // 4 k_ds_gemv (all sweeps of one application).  The replays overwrite the factors (marked invalid afterwards).
 // out: {us per launch, algorithmic flops per launch, algorithmic bytes per launch, launches per factorisation / application}
 static int direct_bench(tsl_ctx* c, int cls, int reps, double* out) {
@@ -191,7 +204,7 @@ static int direct_bench(tsl_ctx* c, int cls, int reps, double* out) {
       const int lv0 = b.first, nf = b.count;
       const int tp = b.max_pp / DS_T, tb = b.max_bp / DS_T;
       if (cls == 0) {   // W = F11^-1: the LDS kernel or pivot0 + block steps + finish
-        if (b.max_pp <= DS_SMALL) { hipLaunchKernelGGL(k_ds_inv_small, dim3(nf), dim3(256), ds_small_lds(b.max_pp), s, D, lv0, b.max_pp + 1); if (count) launches++; }
+        if (ds_use_small(b)) { hipLaunchKernelGGL(k_ds_inv_small, dim3(nf), dim3(256), ds_small_lds(b.max_pp), s, D, lv0, b.max_pp + 1); if (count) launches++; }
         else {
           hipLaunchKernelGGL(k_ds_pivot0, dim3(nf), dim3(256), 0, s, D, lv0);
           for (int k = 0; k < tp; k++) hipLaunchKernelGGL(k_ds_gj_step, dim3(tp, tp, P.act_n[b.act_off + k]), dim3(256), 0, s, D, lv0, k);
@@ -201,18 +214,17 @@ static int direct_bench(tsl_ctx* c, int cls, int reps, double* out) {
         if (count) for (int i = 0; i < nf; i++) {
           const DsFrontDesc& f = P.fr[P.level_sn[lv0 + i]];
           flops += 2.0 * (double)f.pp * f.pp * f.pp;
-          bytes += 16.0 * (double)f.pp * f.pp * (f.pp <= DS_SMALL ? 1.0 : f.pp / (double)DS_T);   // the block read and written once per launch that touches it
+          bytes += 16.0 * (double)f.pp * f.pp * (ds_use_small(b) ? 1.0 : f.pp / (double)DS_T);   // the block read and written once per launch that touches it
         }
       } else if (tb > 0) {
-        if (cls == 1 || cls == 2) hipLaunchKernelGGL(k_ds_gemm, dim3((tb + 1) / 2, ((cls == 2 ? tp : tb) + 1) / 2, nf), dim3(256), 0, s, D, lv0, cls == 2 ? 0 : 1);
-        else hipLaunchKernelGGL(k_ds_extend, dim3(tb, tb, nf), dim3(256), 0, s, D, lv0);
+        if (cls == 1 || cls == 2) ds_launch_gemm(s, D, b, cls == 2 ? 0 : 1);
+        else continue;
         if (count) {
           launches++;
           for (int i = 0; i < nf; i++) {
             const DsFrontDesc& f = P.fr[P.level_sn[lv0 + i]];
-            if (cls == 1) { flops += 2.0 * (double)f.bp * f.bp * f.pp; bytes += 8.0 * (2.0 * (double)f.bp * f.pp + 2.0 * (double)f.bp * f.bp); }
+            if (cls == 1) { flops += 2.0 * (double)f.bp * f.bp * f.pp; bytes += 8.0 * (2.0 * (double)f.bp * f.pp + (double)f.bp * f.bp + 2.0 * (double)f.b * f.b); }  // F21, G, F22 read, parent entries read + written
             else if (cls == 2) { flops += 2.0 * (double)f.pp * f.pp * f.bp; bytes += 8.0 * ((double)f.pp * f.pp + 2.0 * (double)f.pp * f.bp); }
-            else if (f.parent >= 0) bytes += 8.0 * 3.0 * (double)f.b * f.b;   // S read, parent entries read + written
           }
         }
       }

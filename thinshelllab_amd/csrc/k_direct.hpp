@@ -8,7 +8,8 @@
 //     the step kernel).  No pivoting: measured on the cfg4 operators (forward and un-projected adjoint) a nested-dissection LU with
 //     diagonal pivots reaches a 1e-10 relative residual.
 //   * G = W F12 and S = F22 - F21 G: K = pp GEMMs on the f64 matrix cores (v_mfma_f64_16x16x4_f64), the bulk of the flops.
-//   * S is added into the parent front through the child's boundary -> parent index map (f64 atomics: siblings overlap).
+//   * S is never stored: the GEMM's epilogue adds it into the parent front through the child's boundary -> parent index map
+//     (extend-add, f64 atomics: siblings overlap).
 // A solve is three matrix-vector passes per level (W, F21 upwards; G downwards), no triangular recurrences.
 #pragma once
 #include "direct_plan.hpp"
@@ -79,50 +80,54 @@ __global__ void k_ds_pad_diag(int n_sn, const DsFrontDesc* __restrict__ fr, doub
 }
 
 // ---- blocked Gauss-Jordan on the top block rows ---------------------------------------------------------------------------
-// In-place inversion of one DS_T x DS_T tile held in LDS by ONE wave: lane = (column c, row half h) keeps its 16 elements in
-// registers, per pivot only the pivot row and column go through LDS; a single wave runs in lockstep, so the 32 pivot steps need no
-// workgroup barrier.  Pivots below 1e-13 of the tile's largest entry are replaced by that bound (counted in bad[0]).
-TSL_DEV void ds_invert_tile_wave(double (*T)[DS_T + 1], int* __restrict__ bad) {
-  __shared__ double colb[DS_T], rowb[DS_T];
-  const int lane = threadIdx.x & 63;
-  const int c = lane & 31, h = lane >> 5;
-  double a[DS_T / 2];
+// In-place Gauss-Jordan inversion of one DS_T x DS_T tile in LDS by the whole 256-thread workgroup: thread (tx, ty) keeps the four
+// elements (ty + 8 q, tx) in registers, per pivot the pivot row and column go through double-buffered LDS vectors (one barrier per
+// pivot).  Measured against one wave holding the tile in registers (16 elements per lane, no barriers): the same ~6 us, but 30
+// instead of 130 registers, which every workgroup of the block-step kernel would otherwise pay in occupancy.
+// Pivots below 1e-13 of the tile's largest entry are replaced by that bound (counted in bad[0]).  All 256 threads must call it;
+// the tile is complete in LDS on return (the function ends with a barrier).
+TSL_DEV void ds_invert_tile_wg(double (*T)[DS_T + 1], int* __restrict__ bad) {
+  __shared__ double colb[2][DS_T], rowb[2][DS_T], red[4];
+  const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;
+  double a[4];
   double amax = 0.0;
 #pragma unroll
-  for (int m = 0; m < DS_T / 2; m++) { a[m] = T[h * (DS_T / 2) + m][c]; amax = fmax(amax, fabs(a[m])); }
+  for (int q = 0; q < 4; q++) { a[q] = T[ty + 8 * q][tx]; amax = fmax(amax, fabs(a[q])); }
   amax = wave_max(amax);
-  const double tiny = fmax(amax * 1e-13, 1e-300);
+  if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = amax;
+  __syncthreads();
+  const double tiny = fmax(fmax(fmax(red[0], red[1]), fmax(red[2], red[3])) * 1e-13, 1e-300);
   int nbad = 0;
 #pragma unroll
   for (int p = 0; p < DS_T; p++) {
-    if (c == p) {
+    const int buf = p & 1;
+    const int qp = p >> 3;   // the pivot row p = ty + 8 qp belongs to the threads with ty == (p & 7)
+    if (ty == (p & 7)) rowb[buf][tx] = a[qp];
+    if (tx == p) {
 #pragma unroll
-      for (int m = 0; m < DS_T / 2; m++) colb[h * (DS_T / 2) + m] = a[m];
+      for (int q = 0; q < 4; q++) colb[buf][ty + 8 * q] = a[q];
     }
-    if (h == p / (DS_T / 2)) rowb[c] = a[p % (DS_T / 2)];
-    __builtin_amdgcn_wave_barrier();
-    double piv = rowb[p];
-    const double rj = rowb[c];
-    double ci[DS_T / 2];
-#pragma unroll
-    for (int m = 0; m < DS_T / 2; m++) ci[m] = colb[h * (DS_T / 2) + m];
-    __builtin_amdgcn_wave_barrier();
+    __syncthreads();
+    double piv = rowb[buf][p];
+    const double rj = rowb[buf][tx];
     if (!(fabs(piv) >= tiny)) { piv = (piv < 0.0) ? -tiny : tiny; nbad++; }
     const double ip = 1.0 / piv;
     const double rs = rj * ip;
 #pragma unroll
-    for (int m = 0; m < DS_T / 2; m++) {
-      const int i = h * (DS_T / 2) + m;
+    for (int q = 0; q < 4; q++) {
+      const int i = ty + 8 * q;
+      const double ci = colb[buf][i];
       double v;
-      if (i == p) v = (c == p) ? ip : rs;
-      else if (c == p) v = -ci[m] * ip;
-      else v = a[m] - ci[m] * rs;
-      a[m] = v;
+      if (i == p) v = (tx == p) ? ip : rs;
+      else if (tx == p) v = -ci * ip;
+      else v = a[q] - ci * rs;
+      a[q] = v;
     }
   }
 #pragma unroll
-  for (int m = 0; m < DS_T / 2; m++) T[h * (DS_T / 2) + m][c] = a[m];
-  if (lane == 0 && nbad) atomicAdd(bad, nbad);
+  for (int q = 0; q < 4; q++) T[ty + 8 * q][tx] = a[q];
+  if (threadIdx.x == 0 && nbad) atomicAdd(bad, nbad);
+  __syncthreads();
 }
 
 // scratch of a front inside the level scratch (fronts with more than DS_SMALL pivots): pivot-block inverses P[2] (ping-pong) and the
@@ -140,8 +145,7 @@ __global__ void __launch_bounds__(256) k_ds_pivot0(DsDev D, int lv0) {
 #pragma unroll
   for (int q = 0; q < 4; q++) T[ty + 8 * q][tx] = A[(size_t)(ty + 8 * q) * f.ld + tx];
   __syncthreads();
-  if (threadIdx.x < 64) ds_invert_tile_wave(T, D.bad);
-  __syncthreads();
+  ds_invert_tile_wg(T, D.bad);
   double* P = ds_scr_P(D, f, 0);
 #pragma unroll
   for (int q = 0; q < 4; q++) P[(ty + 8 * q) * DS_T + tx] = T[ty + 8 * q][tx];
@@ -160,7 +164,7 @@ TSL_DEV double ds_tile_elem(const double* __restrict__ A, int ld, const double* 
   if (tj == kp) return Cs[(size_t)(ti * DS_T + r) * DS_T + c];
   return A[(size_t)(ti * DS_T + r) * ld + tj * DS_T + c];
 }
-__global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(4, 8))) k_ds_gj_step(DsDev D, int lv0, int k) {
+__global__ void __launch_bounds__(256) k_ds_gj_step(DsDev D, int lv0, int k) {
   __shared__ double Ps[DS_T][DS_T + 1];
   __shared__ double T1[DS_T][DS_T + 1];   // A[K, j], later R'_j
   __shared__ double T2[DS_T][DS_T + 1];   // A[i, K], later the next pivot block
@@ -196,6 +200,12 @@ __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(4, 8))
     for (int q = 0; q < 4; q++) Rn[(size_t)(ty + 8 * q) * pp + k0 + tx] = Ps[ty + 8 * q][tx];
     return;
   }
+  // the tile's own entries (quadrant layout of the matrix-core result) are requested before the products
+  ds_d4 old = {0.0, 0.0, 0.0, 0.0};
+  if (bi != k && bj != k) {
+#pragma unroll
+    for (int r = 0; r < 4; r++) old[r] = ds_tile_elem(A, ld, Rs, Cs, pp, kp, bi, bj, 16 * wi + lk + 4 * r, 16 * wj + lr);
+  }
   ds_d4 acc = {0.0, 0.0, 0.0, 0.0};
   if (bj == k) {  // A_iK = -A_iK P
 #pragma unroll
@@ -224,14 +234,13 @@ __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(4, 8))
 #pragma unroll
   for (int r = 0; r < 4; r++) {
     const int row = 16 * wi + lk + 4 * r, col = 16 * wj + lr;
-    const double v = ds_tile_elem(A, ld, Rs, Cs, pp, kp, bi, bj, row, col) - acc[r];
+    const double v = old[r] - acc[r];
     A[(size_t)(bi * DS_T + row) * ld + bj * DS_T + col] = v;
     if (next_pivot) T2[row][col] = v;
   }
   if (next_pivot) {
     __syncthreads();
-    if (threadIdx.x < 64) ds_invert_tile_wave(T2, D.bad);
-    __syncthreads();
+    ds_invert_tile_wg(T2, D.bad);
     double* Pn = ds_scr_P(D, f, (k + 1) & 1);
 #pragma unroll
     for (int q = 0; q < 4; q++) Pn[(ty + 8 * q) * DS_T + tx] = T2[ty + 8 * q][tx];
@@ -276,8 +285,7 @@ __global__ void __launch_bounds__(256) k_ds_inv_small(DsDev D, int lv0, int ls) 
 #pragma unroll
     for (int q = 0; q < 4; q++) Tt[ty + 8 * q][tx] = M[(k0 + ty + 8 * q) * ls + k0 + tx];
     __syncthreads();
-    if (threadIdx.x < 64) ds_invert_tile_wave(Tt, D.bad);
-    __syncthreads();
+    ds_invert_tile_wg(Tt, D.bad);
     // R'_j = P A_Kj in place (a wave owns whole tiles: all its reads of a tile precede its writes)
     for (int j = w; j < nt; j += 4) {
       if (j == k) continue;
@@ -400,39 +408,38 @@ __global__ void __launch_bounds__(256) k_ds_gemm(DsDev D, int lv0, int mode) {
     }
     __syncthreads();
   }
+  if (mode == 0) {
 #pragma unroll
-  for (int a = 0; a < 2; a++)
+    for (int a = 0; a < 2; a++)
 #pragma unroll
-    for (int b = 0; b < 2; b++)
+      for (int b = 0; b < 2; b++)
 #pragma unroll
-      for (int r = 0; r < 4; r++) {
-        const int row = I0 + 32 * wi + 16 * a + lk + 4 * r, col = J0 + 32 * wj + 16 * b + lr;
-        if (row < Mr && col < Nc) {
-          if (mode == 0) G[(size_t)row * f.bp + col] = acc[a][b][r];
-          else F[(size_t)(pp + row) * ld + pp + col] -= acc[a][b][r];
+        for (int r = 0; r < 4; r++) {
+          const int row = I0 + 32 * wi + 16 * a + lk + 4 * r, col = J0 + 32 * wj + 16 * b + lr;
+          if (row < Mr && col < Nc) G[(size_t)row * f.bp + col] = acc[a][b][r];
         }
-      }
-}
-
-// ---- extend-add: S of every front of the level into its parent ----------------------------------------------------------------
-__global__ void __launch_bounds__(256) k_ds_extend(DsDev D, int lv0) {
-  const DsFrontDesc f = D.fr[D.level_sn[lv0 + blockIdx.z]];
+    return;
+  }
+  // Schur complement: S is needed by nobody but the parent front, so the entries go straight into it through the child's
+  // boundary -> parent index map (extend-add; f64 atomics: sibling fronts overlap) instead of being stored and re-read
   if (f.parent < 0) return;
-  const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;
-  const int j = blockIdx.x * 32 + tx;
-  if (j >= f.b) return;
   const DsFrontDesc pf = D.fr[f.parent];
-  const double* S = D.A + f.off + (size_t)f.pp * f.ld + f.pp;
   double* PA = D.A + pf.off;
   const int* rel = D.rel + f.rel_off;
-  const int pj = rel[j / 3] + j % 3;
 #pragma unroll
-  for (int q = 0; q < 4; q++) {
-    const int i = blockIdx.y * 32 + ty + 8 * q;
-    if (i >= f.b) continue;
-    const int pi = rel[i / 3] + i % 3;
-    const double v = S[(size_t)i * f.ld + j];
-    if (v != 0.0) atomicAdd(&PA[(size_t)pi * pf.ld + pj], v);
+  for (int b = 0; b < 2; b++) {
+    const int col = J0 + 32 * wj + 16 * b + lr;
+    if (col >= f.b) continue;
+    const int pj = rel[col / 3] + col % 3;
+#pragma unroll
+    for (int a = 0; a < 2; a++)
+#pragma unroll
+      for (int r = 0; r < 4; r++) {
+        const int row = I0 + 32 * wi + 16 * a + lk + 4 * r;
+        if (row >= f.b) continue;
+        const double v = F[(size_t)(pp + row) * ld + pp + col] - acc[a][b][r];
+        if (v != 0.0) atomicAdd(&PA[(size_t)(rel[row / 3] + row % 3) * pf.ld + pj], v);
+      }
   }
 }
 
