@@ -36,7 +36,7 @@ struct DirectPlan {
   std::vector<int> blk_ld;
   std::vector<long long> con_dst;  // per constraint x 16 (vertex pair a, b)
   std::vector<int> con_ld;
-  std::vector<int> level_ptr, level_sn;          // fronts per level (level 0 = leaves), as-late-as-possible levels
+  std::vector<int> level_ptr, level_sn;          // fronts per level (level 0 = leaves)
   std::vector<DsBatch> batches;                  // in level order
   std::vector<int> act_n, act_ld;
   // solve work lists: (front, first row) of every 16-row chunk of the own rows / boundary rows, level after level
@@ -90,12 +90,12 @@ struct DirectPlan {
         rel.push_back(l);
       }
     }
-    // levels: as late as possible (a front sits one level below its parent), so that the dense FEM bodies and shallow subtrees
-    // are batched with fronts of their parent's neighbourhood instead of with the ~10^3 small leaves
+    // levels: as soon as possible (a front sits one level above its deepest child): the small fronts of the FEM bodies' own
+    // dissection trees and of shallow subtrees then share the batches of the ~10^3 cloth leaves instead of adding batches of their
+    // own next to the few large fronts near the root, where every batch costs its block steps in sequence
     const int L = sym.n_levels;
     n_levels = L;
-    std::vector<int> alap(S, L - 1);
-    for (int s = S - 1; s >= 0; s--) if (sym.parent[s] >= 0) alap[s] = alap[sym.parent[s]] - 1;
+    const std::vector<int>& alap = sym.level;
     std::vector<std::vector<int>> by_level(L);
     for (int s = 0; s < S; s++) by_level[alap[s]].push_back(s);
     level_ptr.assign(L + 1, 0); level_sn.clear();
@@ -103,7 +103,8 @@ struct DirectPlan {
     wl_front.clear(); wl_row.clear(); wl_own_ptr.assign(L + 1, 0); wl_bnd_ptr.assign(L, 0);
     scratch = 0;
     // a new batch starts where the pivot block falls below a quarter of the batch's largest (empty workgroups of the smaller
-    // fronts are cheap, an extra batch costs its block steps in sequence)
+    // fronts are cheap, an extra batch costs its block steps in sequence); on a level with hundreds of fronts a batch of 32 or
+    // more also ends where the pivot block shrinks at all (a handful of larger fronts must not size the grid of a thousand leaves)
     for (int l = 0; l < L; l++) {
       std::vector<int>& fl = by_level[l];
       std::stable_sort(fl.begin(), fl.end(), [&](int a, int b) { return fr[a].pp > fr[b].pp; });
@@ -111,7 +112,7 @@ struct DirectPlan {
       for (size_t i = 0; i < fl.size(); i++) {
         const int s = fl[i];
         DsFrontDesc& f = fr[s];
-        if (i == 0 || 4 * f.pp <= batches.back().max_pp) {
+        if (i == 0 || 4 * f.pp <= batches.back().max_pp || (fl.size() > 256 && batches.back().count >= 32 && f.pp < fr[fl[i - 1]].pp)) {
           DsBatch b{};
           b.first = (int)level_sn.size(); b.count = 0; b.level = l;
           batches.push_back(b);

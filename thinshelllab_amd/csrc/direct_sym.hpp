@@ -4,8 +4,8 @@
 // Here the Krylov solvers of tsl_solve are preconditioned by a multifrontal LU of the same operator:
 //   * cloth vertices are ordered by geometric nested dissection of their (N+1) x (M+1) grid (separators two grid lines wide, then
 //     trimmed against the real adjacency: the hinge stencil reaches two lines only from every second vertex),
-//   * every FEM body is dense: its unconstrained vertices are one supernode eliminated first, its constrained vertices are
-//     eliminated in front of the dissection subtree that holds the cloth vertices they touch,
+//   * every FEM body gets its own dissection tree (breadth-first level structures of the tet mesh); its vertices without contact
+//     are eliminated first in that order, its constrained vertices in front of the cloth subtree that holds the vertices they touch,
 //   * the contact constraints of the current step add cliques to the adjacency, so boundaries, the elimination tree and the
 //     front layout are recomputed whenever the constraint set changes (a few ms of host work per time step).
 // Granularity: vertices (3 x 3 blocks).  A front of supernode s holds its own vertices followed by its boundary vertices
@@ -29,7 +29,8 @@ struct DirectSym {
   std::vector<int> c_pos;     // vertex -> position in c_order, -1 for vertices outside the grids
   std::vector<int> c_sn;      // vertex -> static supernode, -1 outside the grids
   std::vector<DsBlock> blocks;
-  std::vector<int> body_of;   // vertex -> dense body, -1 if none
+  std::vector<int> body_of;   // vertex -> FEM body, -1 if none
+  std::vector<std::vector<std::vector<int>>> b_sn;  // per body: its supernodes (graph dissection of the tet mesh), postorder
   std::vector<int> loose;     // vertices in no grid and no body
   // ---- per constraint set (build_tree)
   std::vector<int> order, epos, sn_of, sn_ptr;  // position -> vertex, vertex -> position, vertex -> supernode, supernode -> [first, last) position
@@ -60,6 +61,15 @@ struct DirectSym {
     c_pos.assign(nv, -1); c_sn.assign(nv, -1); body_of.assign(nv, -1); loose.clear();
     for (size_t b = 0; b < blocks.size(); b++)
       for (int v = blocks[b].v_offset; v < blocks[b].v_offset + blocks[b].n_verts; v++) body_of[v] = (int)b;
+    b_sn.assign(blocks.size(), {});
+    {
+      std::vector<int> lab(nv, -1);
+      for (size_t b = 0; b < blocks.size(); b++) {
+        std::vector<int> region(blocks[b].n_verts);
+        for (int k = 0; k < blocks[b].n_verts; k++) region[k] = blocks[b].v_offset + k;
+        dissect_graph(adj, region, std::max(leaf_verts, 40), lab, b_sn[b]);
+      }
+    }
     std::vector<int> side(nv, 0);  // scratch of the bisection: 1 left, 2 right, 3 separator
     for (size_t gi = 0; gi < grids.size(); gi++) {
       const DsGrid& g = grids[gi];
@@ -71,6 +81,44 @@ struct DirectSym {
     for (size_t s = 0; s + 1 < c_ptr.size(); s++)
       for (int q = c_ptr[s]; q < c_ptr[s + 1]; q++) c_sn[c_order[q]] = (int)s;
     for (int v = 0; v < nv; v++) if (c_pos[v] < 0 && body_of[v] < 0) loose.push_back(v);
+  }
+
+  // nested dissection of a general vertex set (the tet mesh of a FEM body): the separator is the middle level of a breadth-first
+  // level structure rooted at a pseudo-peripheral vertex.  lab: scratch, -1 outside the current region.
+  void dissect_graph(const std::vector<std::vector<int>>& adj, std::vector<int>& region, int leaf, std::vector<int>& lab, std::vector<std::vector<int>>& out) {
+    if (region.empty()) return;
+    if ((int)region.size() <= leaf) { std::sort(region.begin(), region.end()); out.push_back(region); return; }
+    std::vector<int> q;
+    auto bfs = [&](int start) {
+      for (int v : region) lab[v] = 0;
+      q.clear(); q.push_back(start); lab[start] = 1;
+      for (size_t h = 0; h < q.size(); h++)
+        for (int u : adj[q[h]]) if (lab[u] == 0) { lab[u] = lab[q[h]] + 1; q.push_back(u); }
+    };
+    bfs(region[0]);
+    if (q.size() < region.size()) {  // disconnected: the reached component and the rest are independent
+      std::vector<int> comp(q), rest;
+      for (int v : region) if (lab[v] == 0) rest.push_back(v);
+      for (int v : region) lab[v] = -1;
+      dissect_graph(adj, comp, leaf, lab, out);
+      dissect_graph(adj, rest, leaf, lab, out);
+      return;
+    }
+    bfs(q.back());
+    const int nl = lab[q.back()];
+    if (nl < 3) { for (int v : region) lab[v] = -1; std::sort(region.begin(), region.end()); out.push_back(region); return; }
+    std::vector<int> cnt(nl + 2, 0);
+    for (int v : region) cnt[lab[v]]++;
+    int m = 2, acc = cnt[1];
+    while (m < nl - 1 && 2 * (acc + cnt[m]) < (int)region.size()) { acc += cnt[m]; m++; }
+    std::vector<int> A, B, S;
+    for (int v : region) { if (lab[v] < m) A.push_back(v); else if (lab[v] > m) B.push_back(v); else S.push_back(v); }
+    for (int v : region) lab[v] = -1;
+    std::vector<int>().swap(region);
+    dissect_graph(adj, A, leaf, lab, out);
+    dissect_graph(adj, B, leaf, lab, out);
+    std::sort(S.begin(), S.end());
+    out.push_back(S);
   }
 
   void close_static(int lo, int grid) {
@@ -117,8 +165,8 @@ struct DirectSym {
 
   // ------------------------------------------------------------------------------------------ per constraint set: order, boundaries, tree
   // extra: additional cliques (the 4 vertices of every contact constraint), flattened, `clique` vertices each.
-  // Dense bodies: the vertices of a body that sit in no constraint (its interior) form one supernode eliminated first -- its
-  // boundary is inside the body --, the constrained ones are eliminated right before the smallest dissection subtree that holds
+  // FEM bodies: the vertices of a body that sit in no constraint keep the body's own dissection tree and are eliminated first
+  // (their boundaries stay inside the body), the constrained ones are eliminated right before the smallest dissection subtree that holds
   // every grid vertex they are coupled to (they ride in the fronts between those leaves and that separator), merged per such
   // place; coupled to anything else, they go to the end of the order.
   void build_tree(const std::vector<std::vector<int>>& adj, const int* extra, int n_extra, int clique) {
@@ -134,12 +182,12 @@ struct DirectSym {
     const int n_static = (int)c_ptr.size() - 1, END = n_static;
     const int nb = (int)blocks.size();
     std::vector<int> ins(nb, -1);                 // static supernode the constrained vertices of the body are placed in front of
-    std::vector<std::vector<int>> K(nb), I(nb);
+    std::vector<std::vector<int>> K(nb);
     for (int b = 0; b < nb; b++) {
       int pmin = 1 << 30, pmax = -1, grid = -1;
       bool to_end = false;
       for (int v = blocks[b].v_offset; v < blocks[b].v_offset + blocks[b].n_verts; v++) {
-        if (xidx[v] < 0) { I[b].push_back(v); continue; }
+        if (xidx[v] < 0) continue;
         K[b].push_back(v);
         for (int u : xadj[xidx[v]]) {
           if (body_of[u] == b) continue;
@@ -158,7 +206,8 @@ struct DirectSym {
     }
     order.clear(); sn_ptr.assign(1, 0);
     auto close_sn = [&]() { if ((int)order.size() > sn_ptr.back()) sn_ptr.push_back((int)order.size()); };
-    for (int b = 0; b < nb; b++) { for (int v : I[b]) order.push_back(v); close_sn(); }
+    for (int b = 0; b < nb; b++)
+      for (const auto& sn : b_sn[b]) { for (int v : sn) if (xidx[v] < 0) order.push_back(v); close_sn(); }
     for (int v : loose) { order.push_back(v); close_sn(); }
     std::vector<std::vector<int>> at(n_static + 1);
     for (int b = 0; b < nb; b++) if (ins[b] >= 0) at[ins[b]].push_back(b);
