@@ -340,6 +340,208 @@ k_contact_assemble(int nc, ContactArgs A, const double* __restrict__ pos, int sp
   for (int k = 0; k < 144; k++) out[k] = Hc[k];
 }
 
+// ---- the same blocks with 16 lanes per constraint -----------------------------------------------------------------------------
+// k_contact_assemble keeps a constraint's 12 x 12 block, the 9 x 9 derivative tables and the eigenvector matrix of the 9 x 9
+// eigen-clamp in per-lane arrays (private memory) and runs ~10 Jacobi sweeps serially: 0.9 ms per launch at 200 constraints, the
+// longest kernel of an assembly.  Here lane l < 9 of a 16-lane group owns ROW l of the 9 x 9 normal block (relative coordinate
+// l = 3 (vertex - 1) + axis), lanes 9..11 the three rows of vertex 0; the cyclic Jacobi eigen-clamp runs on the group's matrix in LDS,
+// one lane per row / column of a rotation.
+TSL_DEV d3 c_unit(int a) { return d3(a == 0 ? 1.0 : 0.0, a == 1 ? 1.0 : 0.0, a == 2 ? 1.0 : 0.0); }
+TSL_DEV double c_comp(const d3& v, int a) { return a == 0 ? v.x : (a == 1 ? v.y : v.z); }
+// cyclic Jacobi eigen-clamp A <- sum_{lambda > 0} lambda v v^T of the symmetric 9 x 9 matrix of a 16-lane group, matrix and
+// eigenvectors in LDS (sa, sv: 81 doubles each), lane k < 9 works on row k / column k; same rotation order, threshold and sweep
+// limit as spd_clamp<9>.  The four groups of a wave run in lockstep (a wave's LDS operations complete in order), `on` is uniform
+// within the group.  A version with the rows in registers and lane shuffles needed 256 + 125 registers and 1.4 ms per launch.
+TSL_DEV void spd_clamp9_lds(double* __restrict__ sa, double* __restrict__ sv, int l, bool on) {
+  const bool row = l < 9;
+  if (row) {
+#pragma unroll
+    for (int k = 0; k < 9; k++) sv[l * 9 + k] = (k == l) ? 1.0 : 0.0;
+  }
+  __builtin_amdgcn_wave_barrier();
+  if (row) {  // symmetrise (lane l rewrites the upper part of its row and the mirrored entries)
+    for (int k = l + 1; k < 9; k++) { const double t = 0.5 * (sa[l * 9 + k] + sa[k * 9 + l]); sa[l * 9 + k] = t; sa[k * 9 + l] = t; }
+  }
+  __builtin_amdgcn_wave_barrier();
+  bool done = !on;
+  for (int sweep = 0; sweep < 30; sweep++) {
+    double off = 0.0, diag = 0.0;
+    if (row) {
+      for (int k = 0; k < 9; k++) { const double v = sa[l * 9 + k]; if (k == l) diag = v * v; else off += v * v; }
+    }
+#pragma unroll
+    for (int o = 8; o > 0; o >>= 1) { off += __shfl_xor(off, o, 16); diag += __shfl_xor(diag, o, 16); }
+    if (0.5 * off <= 1e-32 * (diag + 0.5 * off)) done = true;
+    if (!__any(!done)) break;
+    for (int p = 0; p < 8; p++)
+      for (int q = p + 1; q < 9; q++) {
+        const double apq = sa[p * 9 + q], app = sa[p * 9 + p], aqq = sa[q * 9 + q];
+        double c = 1.0, s = 0.0;
+        if (apq != 0.0 && !done) {
+          const double theta = (aqq - app) / (2.0 * apq);
+          const double t = (theta >= 0 ? 1.0 : -1.0) / (fabs(theta) + sqrt(theta * theta + 1.0));
+          c = 1.0 / sqrt(t * t + 1.0); s = t * c;
+        }
+        __builtin_amdgcn_wave_barrier();
+        if (row) {  // columns p, q of row l (matrix and eigenvectors)
+          const double akp = sa[l * 9 + p], akq = sa[l * 9 + q];
+          sa[l * 9 + p] = c * akp - s * akq; sa[l * 9 + q] = s * akp + c * akq;
+          const double vkp = sv[l * 9 + p], vkq = sv[l * 9 + q];
+          sv[l * 9 + p] = c * vkp - s * vkq; sv[l * 9 + q] = s * vkp + c * vkq;
+        }
+        __builtin_amdgcn_wave_barrier();
+        if (row) {  // rows p, q, column l
+          const double apk = sa[p * 9 + l], aqk = sa[q * 9 + l];
+          sa[p * 9 + l] = c * apk - s * aqk; sa[q * 9 + l] = s * apk + c * aqk;
+        }
+        __builtin_amdgcn_wave_barrier();
+      }
+  }
+  // A = sum_e max(lambda_e, 0) v_e v_e^T, row l
+  double outr[9];
+  if (row) {
+#pragma unroll
+    for (int j = 0; j < 9; j++) outr[j] = 0.0;
+    for (int e = 0; e < 9; e++) {
+      const double d = sa[e * 9 + e];
+      const double lam = d > 0.0 ? d : 0.0;
+      const double vl = lam * sv[l * 9 + e];
+#pragma unroll
+      for (int j = 0; j < 9; j++) outr[j] += vl * sv[j * 9 + e];
+    }
+  }
+  __builtin_amdgcn_wave_barrier();
+  if (row && on) {
+#pragma unroll
+    for (int j = 0; j < 9; j++) sa[l * 9 + j] = outr[j];
+  }
+  __builtin_amdgcn_wave_barrier();
+}
+
+__global__ void __launch_bounds__(256)
+k_contact_assemble_coop(int nc, ContactArgs A, const double* __restrict__ pos, int spd, double* __restrict__ grad, double* __restrict__ Hfull) {
+  const int l = threadIdx.x & 15;
+  int ci = (int)((blockIdx.x * (size_t)blockDim.x + threadIdx.x) >> 4);
+  const bool valid = ci < nc;
+  if (!valid) ci = nc - 1;   // whole groups beyond the list still take part in the wave-wide shuffles
+  int id[4];
+  for (int k = 0; k < 4; k++) id[k] = A.idx[4 * ci + k];
+  const d3 x0 = ld3(pos, id[0]), xa = ld3(pos, id[1]), xb = ld3(pos, id[2]), xp = ld3(pos, id[3]);
+  const d3 a = xa - x0, b = xb - x0, p = xp - x0;
+  const d3 cr = cross(a, b);
+  const double D = dot(cr, p), C = norm(cr);
+  const bool active = D / C < A.eps_contact;
+  double h[9], g9 = 0.0;   // row l of the normal block in relative coordinates, gradient entry l
+#pragma unroll
+  for (int k = 0; k < 9; k++) h[k] = 0.0;
+  if (active && l < 9) {
+    const d3 nh = cr / C;
+    const int jb = l / 3, ja = l % 3;
+    const d3 ej = c_unit(ja);
+    const d3 gD0 = cross(b, p), gD1 = cross(p, a), gD2 = cr;
+    const d3 gC0 = cross(b, nh), gC1 = cross(nh, a), gC2 = d3(0, 0, 0);
+    const double gDj = c_comp(jb == 0 ? gD0 : (jb == 1 ? gD1 : gD2), ja), gCj = c_comp(jb == 0 ? gC0 : (jb == 1 ? gC1 : gC2), ja);
+    const double pe_pd = A.k_contact * (D / C - A.eps_contact);
+    const double G9j = gDj / C - D * gCj / (C * C);
+    const d3 ejb = cross(ej, b), aej = cross(a, ej);
+#pragma unroll
+    for (int k = 0; k < 9; k++) {
+      const int kb = k / 3, ka = k % 3;
+      const d3 ek = c_unit(ka);
+      const double gDk = c_comp(kb == 0 ? gD0 : (kb == 1 ? gD1 : gD2), ka), gCk = c_comp(kb == 0 ? gC0 : (kb == 1 ? gC1 : gC2), ka);
+      const d3 ekb = cross(ek, b), aek = cross(a, ek), ejk = cross(ej, ek);
+      double HCv = 0.0, HDv = 0.0;
+      if (jb == 0 && kb == 0) HCv = (dot(ejb, ekb) - dot(nh, ejb) * dot(nh, ekb)) / C;
+      else if (jb == 1 && kb == 1) HCv = (dot(aej, aek) - dot(nh, aej) * dot(nh, aek)) / C;
+      else if (jb == 0 && kb == 1) HCv = (dot(ejb, aek) - dot(nh, ejb) * dot(nh, aek)) / C + dot(nh, ejk);
+      else if (jb == 1 && kb == 0) HCv = (dot(ekb, aej) - dot(nh, ekb) * dot(nh, aej)) / C - dot(nh, ejk);   // hab(k, j): e_k x e_j = -e_j x e_k
+      // D = a . (b x p): mixed second derivatives (e_j x e_k) . third vector, antisymmetric in (j, k)
+      if (jb == 0 && kb == 1) HDv = dot(ejk, p);
+      else if (jb == 1 && kb == 0) HDv = -dot(ejk, p);
+      else if (jb == 1 && kb == 2) HDv = dot(ejk, a);
+      else if (jb == 2 && kb == 1) HDv = -dot(ejk, a);
+      else if (jb == 2 && kb == 0) HDv = dot(ejk, b);
+      else if (jb == 0 && kb == 2) HDv = -dot(ejk, b);
+      const double G9k = gDk / C - D * gCk / (C * C);
+      const double H9 = HDv / C - gDj * gCk / (C * C) - gDk * gCj / (C * C) - D * HCv / (C * C) + 2 * D * gCj * gCk / (C * C * C);
+      h[k] = A.k_contact * G9j * G9k + pe_pd * H9;
+    }
+    g9 = G9j * pe_pd;
+  }
+  if (spd) {
+    __shared__ double sA[16][81], sV[16][81];
+    const int g = threadIdx.x >> 4;
+    if (l < 9) {
+#pragma unroll
+      for (int k = 0; k < 9; k++) sA[g][l * 9 + k] = h[k];
+    }
+    spd_clamp9_lds(sA[g], sV[g], l, active);
+    if (l < 9) {
+#pragma unroll
+      for (int k = 0; k < 9; k++) h[k] = sA[g][l * 9 + k];
+    }
+  }
+  // 12 x 12 block: lane l < 9 -> row 3 + l; lanes 9..11 -> rows 0..2 of vertex 0 (minus the sums over the three other vertices)
+  double out[12];
+  double gout = 0.0;
+  const int axis = l < 9 ? l % 3 : l - 9;
+  {
+    double s0[9], sg = 0.0;   // sums over the rows l', l' % 3 == axis (for the vertex-0 rows)
+#pragma unroll
+    for (int k = 0; k < 9; k++) {
+      const int base = (l >= 9 && l < 12) ? l - 9 : 0;
+      s0[k] = __shfl(h[k], base, 16) + __shfl(h[k], base + 3, 16) + __shfl(h[k], base + 6, 16);
+    }
+    {
+      const int base = (l >= 9 && l < 12) ? l - 9 : 0;
+      sg = __shfl(g9, base, 16) + __shfl(g9, base + 3, 16) + __shfl(g9, base + 6, 16);
+    }
+    if (l < 9) {
+#pragma unroll
+      for (int k = 0; k < 9; k++) out[3 + k] = h[k];
+#pragma unroll
+      for (int j2 = 0; j2 < 3; j2++) out[j2] = -(h[j2] + h[3 + j2] + h[6 + j2]);
+      gout = g9;
+    } else {
+#pragma unroll
+      for (int k = 0; k < 9; k++) out[3 + k] = -s0[k];
+#pragma unroll
+      for (int j2 = 0; j2 < 3; j2++) out[j2] = s0[j2] + s0[3 + j2] + s0[6 + j2];
+      gout = -sg;
+    }
+  }
+  // friction (BaseScene.py:548-593)
+  {
+    const double w[3] = {A.w[3 * ci], A.w[3 * ci + 1], A.w[3 * ci + 2]};
+    const double kf = A.k[ci];
+    const double* T = A.T + 6 * (size_t)ci;
+    const d3 x_c = x0 * w[0] + xa * w[1] + xb * w[2];
+    const d3 dx = xp - x_c - ld3(A.dx0, ci);
+    const double u[2] = {T[0] * dx.x + T[1] * dx.y + T[2] * dx.z, T[3] * dx.x + T[4] * dx.y + T[5] * dx.z};
+    const double r = sqrt(u[0] * u[0] + u[1] * u[1]);
+    const double f1 = fr_f1(r, A.eps_vh), f2 = fr_f2(r, A.eps_vh);
+    double ha = f1, hb = 0, hd = f1;
+    if (r > 1e-9) { ha += f2 * u[0] * u[0] / r; hb += f2 * u[0] * u[1] / r; hd += f2 * u[1] * u[1] / r; }
+    if (spd) spd_clamp2(ha, hb, hd);
+    const double w1[4] = {-w[0], -w[1], -w[2], 1.0};
+    const int i1 = l < 9 ? 1 + l / 3 : 0;
+    const double wi = i1 == 0 ? w1[0] : (i1 == 1 ? w1[1] : (i1 == 2 ? w1[2] : w1[3]));
+    const double Ta = T[axis], Tb = T[3 + axis];
+    gout += wi * kf * f1 * (u[0] * Ta + u[1] * Tb);
+#pragma unroll
+    for (int i2 = 0; i2 < 4; i2++)
+#pragma unroll
+      for (int j2 = 0; j2 < 3; j2++)
+        out[i2 * 3 + j2] += wi * w1[i2] * kf * (Ta * (ha * T[j2] + hb * T[3 + j2]) + Tb * (hb * T[j2] + hd * T[3 + j2]));
+  }
+  if (!valid || l >= 12) return;
+  const int rowi = l < 9 ? 3 + l : l - 9;
+  if (grad) atomicAdd(&grad[3 * (size_t)id[rowi / 3] + rowi % 3], gout);
+  double* dst = Hfull + 144 * (size_t)ci + 12 * rowi;
+#pragma unroll
+  for (int k = 0; k < 12; k++) dst[k] = out[k];
+}
+
 // masked copy of the per-constraint blocks (add_H frozen rule, BaseScene.py:399-405) + their diagonal 3x3 blocks
 // accumulated for the block-Jacobi preconditioner
 __global__ void k_contact_mask(int nc, const int* __restrict__ idx, const int* __restrict__ frozen, const int* __restrict__ rowpos, const double* __restrict__ Hfull,
@@ -643,7 +845,8 @@ static int contact_assemble(tsl_ctx* c, const double* pos, int spd, double* grad
   ContactArgs A;
   A.idx = c->c_idx.p; A.w = c->c_w.p; A.n = c->c_n.p; A.dx0 = c->c_dx0.p; A.k = c->c_k.p; A.mu = c->c_mu.p; A.T = c->c_T.p;
   A.k_contact = c->k_contact; A.eps_contact = c->eps_contact; A.eps_vh = c->eps_v * c->dt;
-  hipLaunchKernelGGL(k_contact_assemble, dim3(cnblk(c->nc, 64)), dim3(64), 0, s, c->nc, A, pos, spd, grad, c->c_Hfull.p);
+  if (c->contact_coop) hipLaunchKernelGGL(k_contact_assemble_coop, dim3(cnblk((long)c->nc * 16, 256)), dim3(256), 0, s, c->nc, A, pos, spd, grad, c->c_Hfull.p);
+  else hipLaunchKernelGGL(k_contact_assemble, dim3(cnblk(c->nc, 64)), dim3(64), 0, s, c->nc, A, pos, spd, grad, c->c_Hfull.p);
   HIP_OK(hipMemsetAsync(c->c_diag.p, 0, c->c_diag.n * sizeof(double), s));
   hipLaunchKernelGGL(k_contact_mask, dim3(cnblk(c->nc, 64)), dim3(64), 0, s, c->nc, c->c_idx.p, c->frozen.p, c->rowpos.p, c->c_Hfull.p, c->c_H.p, c->c_diag.p);
   return 0;

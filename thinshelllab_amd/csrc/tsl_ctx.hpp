@@ -215,6 +215,7 @@ struct tsl_ctx {
   hipStream_t side = 0;                         // second stream: contact blocks of an assembly run next to the cloth / tet kernels
   hipEvent_t ev_fork = nullptr, ev_join = nullptr;
   int asm_overlap = 1;
+  int contact_coop = 1;  // 16 lanes per constraint in the contact block assembly (0: one lane per constraint)
 
   // ---- Newton scratch (original order)
   DevBuf<double> F, pdir, x1;

@@ -339,6 +339,7 @@ extern "C" int tsl_set_param(tsl_ctx* c, const char* key, double v) {
   else if (k == "mg_fuse") c->mg_fuse = (int)v;
   else if (k == "pcg_body_fold") c->pcg_body_fold = (int)v;
   else if (k == "asm_overlap") c->asm_overlap = (int)v;
+  else if (k == "contact_coop") c->contact_coop = (int)v;
   else if (k == "mg_chunk") c->mg_chunk = (int)v;  // 0 = chosen from the previous step's iterations per solve
   else if (k == "mr_eta") c->mr_eta = v;
   else if (k == "mg_st_f32") { c->mg_st_f32 = (int)v; c->mg_ops_valid = false; }
@@ -444,21 +445,25 @@ static int assemble(tsl_ctx* c, const double* pos, const double* prev, const dou
   const VertArgs VA = vert_args(c);
   const TetArgs TA = tet_args(c);
   if (grad) HIP_OK(hipMemsetAsync(grad, 0, 3 * (size_t)NV * sizeof(double), s));
-  // contact: gradient into grad (atomics), per-constraint 12x12 into c_Hfull, masked copy + diagonal into c_H / cdiag.  One lane per
-  // constraint with a 9x9 eigen-clamp each: 0.7 ms of latency for ~100 constraints, so the three launches go to a second stream next to
-  // the cloth / tet kernels (they share nothing but the zeroed gradient, which both sides only add to).
-  const bool fork = c->asm_overlap && c->nc > 0;
+  // contact: gradient into grad (atomics), per-constraint 12x12 into c_Hfull, masked copy + diagonal into c_H / cdiag.  The contact
+  // launches (0.15 + 0.11 ms at 200 constraints) and the tet kernels (0.23 ms) go to a second stream next to the cloth kernels
+  // (face 0.15 ms + hinge 0.28 ms): they share nothing but the zeroed gradient / matrix, which both sides only add to.
+  const bool fork = c->asm_overlap && (c->nc > 0 || c->n_tet > 0);
+  if (grad) hipLaunchKernelGGL(k_vert_grad, dim3(nblk(NV, 256)), dim3(256), 0, s, VA, pos, prev, vel, grad);   // before the fork: it may store, the others add
+  hipStream_t st = fork ? c->side : s;   // stream of the tet and contact kernels
   if (fork) {
     HIP_OK(hipEventRecord(c->ev_fork, s));
     HIP_OK(hipStreamWaitEvent(c->side, c->ev_fork, 0));
-    TSL_TRY(contact_assemble(c, pos, spd, grad, c->side));
-    HIP_OK(hipEventRecord(c->ev_join, c->side));
   }
+  if (c->n_tet) {
+    if (grad) hipLaunchKernelGGL(k_tet_grad, dim3(nblk(c->n_tet, 256)), dim3(256), 0, st, TA, pos, grad);
+    hipLaunchKernelGGL(k_tet_hess, dim3(nblk(c->n_tet, 64)), dim3(64), 0, st, TA, c->tet_blk.p, pos, spd, c->vals_full.p);
+  }
+  TSL_TRY(contact_assemble(c, pos, spd, grad, st));
+  if (fork) HIP_OK(hipEventRecord(c->ev_join, c->side));
   if (grad) {
-    hipLaunchKernelGGL(k_vert_grad, dim3(nblk(NV, 256)), dim3(256), 0, s, VA, pos, prev, vel, grad);
     if (c->n_cface) hipLaunchKernelGGL(k_cloth_grad_face, dim3(nblk(c->n_cface, 256)), dim3(256), 0, s, CA, pos, grad);
     if (c->n_hinge) hipLaunchKernelGGL(k_cloth_grad_hinge, dim3(nblk(c->n_hinge, 256)), dim3(256), 0, s, CA, pos, ref, grad);
-    if (c->n_tet) hipLaunchKernelGGL(k_tet_grad, dim3(nblk(c->n_tet, 256)), dim3(256), 0, s, TA, pos, grad);
   }
   hipLaunchKernelGGL(k_vert_hess, dim3(nblk(NV, 256)), dim3(256), 0, s, VA, c->diag_blk.p, c->vals_full.p);
   if (c->n_cface) {
@@ -468,9 +473,7 @@ static int assemble(tsl_ctx* c, const double* pos, const double* prev, const dou
     else hipLaunchKernelGGL((k_cloth_hess_face<false>), dim3(nblk(c->n_cface, 128)), dim3(128), 0, s, CA, c->cf_blk.p, pos, ref, c->quirk.p, spd, c->vals_full.p);
   }
   if (c->n_hinge) hipLaunchKernelGGL(k_cloth_hess_hinge, dim3(nblk(c->n_hinge, 256)), dim3(256), 0, s, CA, c->hg_blk.p, pos, c->vals_full.p);
-  if (c->n_tet) hipLaunchKernelGGL(k_tet_hess, dim3(nblk(c->n_tet, 64)), dim3(64), 0, s, TA, c->tet_blk.p, pos, spd, c->vals_full.p);
   if (fork) HIP_OK(hipStreamWaitEvent(s, c->ev_join, 0));
-  else TSL_TRY(contact_assemble(c, pos, spd, grad, s));
   if (grad) hipLaunchKernelGGL(k_mask_vec, dim3(gsz(3 * (size_t)NV)), dim3(256), 0, s, 3 * (size_t)NV, c->frozen.p, grad);
   hipLaunchKernelGGL(k_mask_matrix, dim3(c->n_slices), dim3(256), 0, s, c->n_slices, c->slice_off.p, c->slice_len.p, c->colidx.p, c->fzmask.p, c->mdt2.p,
                      c->vals_full.p, c->vals.p, NV);
