@@ -211,6 +211,61 @@ def test_batch_helpers_world_size_2_gloo(tmp_path):
         assert "ok" in out
 
 
+_BATCH_WORKER = r'''
+import os, sys
+sys.path.insert(0, sys.argv[1])
+import numpy as np, torch
+from thinshelllab_amd.batch import Batch
+from thinshelllab_amd.training.trajopt_batch import run_batch
+
+class Quad:
+    """stand-in for a scene rollout: reward -|traj - target_s|^2 with its gradient; plain gradient ascent"""
+    def __init__(self, s):
+        self.s = s
+        self.traj = torch.zeros((4, 1, 6), dtype=torch.float64)
+        self.target = torch.full((4, 1, 6), 0.1 * (s + 1), dtype=torch.float64)
+    def rollout(self):
+        d = self.traj - self.target
+        return -float((d * d).sum()), 2 * d
+    def step(self, g):
+        self.traj -= 0.25 * g
+
+b = Batch(backend="gloo", device=torch.device("cpu"))
+out = sys.argv[2]
+hist, best = run_batch(b, 3, 6, Quad, out_dir=out, log=lambda *a: None)     # 3 scenes on 2 ranks: rank 0 runs scenes 0 and 2, rank 1 scene 1
+assert sorted(hist) == [0, 1, 2] and all(len(v) == 6 for v in hist.values()), hist
+for s in range(3):
+    r0 = -24 * (0.1 * (s + 1)) ** 2
+    assert abs(hist[s][0] - r0) < 1e-12 and hist[s][-1] > r0 * 1e-3, (s, hist[s])   # every rank holds the rewards of the whole batch
+    assert all(hist[s][k + 1] > hist[s][k] for k in range(5))
+assert best[1] == 0 and best[2] == 5, best                                        # the smallest target converges fastest
+b.barrier()
+if b.rank == 0:
+    assert np.load(os.path.join(out, "plot_data.npy")).shape == (3, 6)
+    assert os.path.exists(os.path.join(out, "traj_scene0.npy")) and os.path.exists(os.path.join(out, "traj_scene2.npy"))
+b.close()
+print("ok", b.rank)
+'''
+
+
+def test_trajopt_batch_gather_world_size_2_gloo(tmp_path):
+    """cfg5 driver (training/trajopt_batch.py): scene -> rank placement, the per-iteration all_gather of (reward, gripper_grad)
+    and the outputs, with a stand-in rollout (the engine needs a GPU), two gloo ranks on the CPU"""
+    script = tmp_path / "worker.py"
+    script.write_text(_BATCH_WORKER)
+    out = tmp_path / "out"
+    out.mkdir()
+    env = dict(os.environ, MASTER_ADDR="127.0.0.1", MASTER_PORT="29613")
+    procs = []
+    for r in range(2):
+        e = dict(env, RANK=str(r), WORLD_SIZE="2", LOCAL_RANK=str(r))
+        procs.append(subprocess.Popen([sys.executable, str(script), ROOT, str(out)], env=e, stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True))
+    for p in procs:
+        o, err = p.communicate(timeout=240)
+        assert p.returncode == 0, err[-2000:]
+        assert "ok" in o
+
+
 def test_cmaes_restatement_converges():
     """optimizer/cmaes.py (stand-in for the un-vendored `cma` of run_cmaes_all.py): ask / tell / result / stop surface, convergence on
     the sphere and on Rosenbrock, candidate count checks."""
