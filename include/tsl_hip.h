@@ -102,7 +102,7 @@ int tsl_ctx_create(const tsl_scene_desc* desc, tsl_ctx** out);
 void tsl_ctx_destroy(tsl_ctx* ctx);
 int tsl_set_stream(tsl_ctx* ctx, void* hip_stream);
 
-/* 0-d field writes: "cloth<i>.Kb|Kl|Ka|k_angle", "mu_cloth_elastic", "mu_cloth_cloth", "k_contact", "eps_contact", "damping",
+/* 0-d field writes: "cloth<i>.Kb|Kl|Ka|k_angle", "elastic<i>.mu|lam|alpha", "mu_cloth_elastic", "mu_cloth_cloth", "k_contact", "eps_contact", "damping",
  * "newton_cap", "plastic", "contact" (trajopt_folding.py:50,66; Scene_folding.py:30-31), the broad-phase box
  * "grid_h", "grid_extent" (geometry.py:8-19), and the solver knobs that have no reference counterpart (the reference
  * calls a direct solver): "cg_tol", "cg_maxit", "cg_check", "mg" (-1 auto / 0 / 1), "mg_nu", "mg_coarse_sweeps",
@@ -180,6 +180,8 @@ int tsl_constraints_export(tsl_ctx* ctx, int32_t* idx_host, double* w_host, doub
 int tsl_contact_blocks_export(tsl_ctx* ctx, double* blocks_host, int32_t max_n, int32_t masked);
 int tsl_proj_export(tsl_ctx* ctx, int32_t* proj_flag_host, int32_t* proj_dir_host, int32_t* proj_idx_host, double* proj_w_host);
 int tsl_proj_import(tsl_ctx* ctx, const int32_t* proj_flag_host, const int32_t* proj_dir_host);
+/* BaseScene.border_flag (tot_NV; BaseScene.py:104, restored by Scene_balancing.load_all :213-222, read by project_pair geometry.py:194-201) */
+int tsl_set_border(tsl_ctx* ctx, const int32_t* border_flag_host);
 
 /* Batched SPD projections (linalg.py:5-12 and :15-148) on device arrays of D x D blocks, D in {2,3,9}. */
 int tsl_spd_project(tsl_ctx* ctx, double* blocks_dev, int32_t n_blocks, int32_t D);

@@ -96,3 +96,66 @@ def test_direct_solve_with_contacts_and_bodies():
         xs = spl.splu(H).solve(b.cpu().numpy())
         assert stx["flag"] == 0 and stx["method"] == 4 and stx["iters"] <= 4, stx
         assert rel_err(x.cpu().numpy(), xs) < 1e-7, (spd, stx)
+
+
+def test_unconverged_solve_fails_loudly():
+    """the reference's spsolve is exact every time (sparse_solver.py:85-105): a solve that ends without convergence must not be
+    consumed silently.  Direct path off and 5 iterations allowed: tsl_solve reports flag 3, tsl_step counts it, transfer_grad raises."""
+    from thinshelllab_amd._lib import TslError
+    from thinshelllab_amd.engine.analytic_grad_single import Grad
+    s = _drape(24, 24, 1e-4)
+    ctx = s._ensure_ctx()
+    ctx.set_param("direct", 0); ctx.set_param("cg_maxit", 5); ctx.set_param("gmres_m", 5)
+    s.compute_residual_and_Hessian(spd=True)
+    x, st = ctx.solve(s.F.to_torch().clone())
+    assert st["flag"] == 3 and st["rel_residual"] > 1e-8, st
+    g = Grad(s, 3, 0); g.init_mass(s)
+    g.copy_pos(s, 0)
+    st1 = s.time_step(None, 1)
+    assert st1["unconverged"] > 0 and st1["unconverged"] + st1["fallback"] <= st1["solves"], st1
+    g.copy_pos(s, 1)
+    g.pos_grad.t[1, :, 2] = 1.0
+    with pytest.raises(TslError, match="not converged"):
+        g.transfer_grad(1, s, None)
+    # with the solver's normal budget the same sweep goes through
+    ctx.set_param("cg_maxit", 200000); ctx.set_param("gmres_m", 300)
+    g.transfer_grad(1, s, None)
+    assert g.last_stats["flag"] in (0, 1)
+
+
+def test_constraint_overflow_is_an_error():
+    """constraints beyond max_n_constraints would be dropped in atomic-append order (non-deterministic physics): an error instead"""
+    from thinshelllab_amd._lib import TslError
+    from thinshelllab_amd.engine.geometry import projection_query
+    from thinshelllab_amd.task_scene.Scene_balancing import Scene
+    s = Scene(cloth_size=0.06, cloth_N=32, cloth_M=32)
+    s.max_n_constraints = 3
+    s.init_all()
+    s.prev_pos.copy_from(s.pos)
+    n_part = s.gripper.n_part
+    dpos = np.zeros((n_part, 3)); drot = np.zeros((n_part, 3)); dpos[:, 2] = [1e-4, -1e-4][:n_part]
+    with pytest.raises(TslError, match="max_n_constraints"):
+        for f in range(1, 4):
+            s.action(f, dpos, drot)
+            s.time_step(projection_query, f)
+
+
+def test_elastic_parameters_reach_the_engine_after_context_creation():
+    """Elastic.mu / lam / alpha are 0-d fields like Cloth.Kb: a write after the first engine call must change the engine's material"""
+    from thinshelllab_amd.task_scene.Scene_balancing import Scene
+    s = Scene(cloth_size=0.06)
+    s.init_all()
+    rng = np.random.default_rng(0)
+    x = s.pos.to_numpy(); x += rng.normal(0, 2e-5, x.shape); s.pos.from_numpy(x)
+    E0 = s.compute_energy()
+    ball = s.elastics[0]; pad = s.elastics[1]
+    ball.mu[None] = 2.0 * ball.mu[None]
+    E1 = s.compute_energy()
+    pad.lam[None] = 3.0 * pad.lam[None]
+    E2 = s.compute_energy()
+    assert abs(E1 - E0) > 1e-9 * abs(E0) and abs(E2 - E1) > 1e-9 * abs(E1), (E0, E1, E2)
+    with pytest.raises(Exception):
+        s._ctx.set_param("elastic99.mu", 1.0)
+    s._ctx.set_param("cloth0.Kb", 123.0)     # index parsed up to the dot
+    with pytest.raises(Exception):
+        s._ctx.set_param("cloth10.Kb", 1.0)

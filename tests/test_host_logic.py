@@ -27,6 +27,13 @@ def test_library_exports_every_declared_symbol():
         assert hasattr(L, sym), sym
     L.tsl_version.restype = ctypes.c_char_p
     assert b"gfx950" in L.tsl_version()
+    # the binding declares the argument types of every entry point that takes arguments (a raw int pointer would otherwise be
+    # truncated to 32 bits)
+    B = _lib.load()
+    for sym in declared:
+        if sym in ("tsl_version", "tsl_last_error"):
+            continue
+        assert getattr(B, sym).argtypes is not None, sym
 
 
 @pytest.mark.skipif(torch.cuda.is_available(), reason="checks the no-GPU failure mode")

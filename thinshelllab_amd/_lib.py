@@ -74,7 +74,7 @@ EXPORTS = [
     "tsl_version", "tsl_last_error", "tsl_ctx_create", "tsl_ctx_destroy", "tsl_set_stream", "tsl_set_param", "tsl_set_frozen",
     "tsl_set_ext_force", "tsl_set_gravity", "tsl_energy", "tsl_assemble", "tsl_solve", "tsl_step", "tsl_contact_detect",
     "tsl_contact_reset", "tsl_update_ref_angle", "tsl_adjoint_step", "tsl_param_grad", "tsl_friction_grad", "tsl_elastic_force", "tsl_matrix_nnzb", "tsl_matrix_export",
-    "tsl_constraints_export", "tsl_contact_blocks_export", "tsl_proj_export", "tsl_proj_import", "tsl_spd_project", "tsl_profile_reset", "tsl_profile_read", "tsl_profile_read_events",
+    "tsl_constraints_export", "tsl_contact_blocks_export", "tsl_proj_export", "tsl_proj_import", "tsl_set_border", "tsl_spd_project", "tsl_profile_reset", "tsl_profile_read", "tsl_profile_read_events",
     "tsl_bench_spmv", "tsl_bench_direct", "tsl_direct_info",
 ]
 
@@ -122,6 +122,7 @@ def load():
     L.tsl_contact_blocks_export.argtypes = [C.c_void_p, C.c_void_p, C.c_int32, C.c_int32]
     L.tsl_proj_export.argtypes = [C.c_void_p] + [C.c_void_p] * 4
     L.tsl_proj_import.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p]
+    L.tsl_set_border.argtypes = [C.c_void_p, C.c_void_p]
     L.tsl_spd_project.argtypes = [C.c_void_p, C.c_void_p, C.c_int32, C.c_int32]
     L.tsl_profile_reset.argtypes = [C.c_void_p, C.c_int]
     L.tsl_profile_read.argtypes = [C.c_void_p, C.POINTER(C.c_double), C.POINTER(C.c_int64), C.POINTER(C.c_int64)]

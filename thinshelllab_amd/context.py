@@ -109,14 +109,17 @@ class TslContext:
 
     # ---- engine calls
     def energy(self, pos, prev_pos, vel, ref_angle):
+        self.refresh_stream()
         e = C.c_double(0)
         check(self.L.tsl_energy(self.h, _ptr(pos), _ptr(prev_pos), _ptr(vel), _ptr(ref_angle), C.byref(e)), "tsl_energy")
         return e.value
 
     def assemble(self, pos, prev_pos, vel, ref_angle, spd=True, grad=None):
+        self.refresh_stream()
         check(self.L.tsl_assemble(self.h, _ptr(pos), _ptr(prev_pos), _ptr(vel), _ptr(ref_angle), int(bool(spd)), _ptr(grad)), "tsl_assemble")
 
     def solve(self, rhs, x=None):
+        self.refresh_stream()
         if x is None:
             x = torch.empty_like(rhs)
         st = SolveStats()
@@ -124,11 +127,13 @@ class TslContext:
         return x, st.as_dict()
 
     def step(self, pos, prev_pos, vel, ref_angle):
+        self.refresh_stream()
         st = StepStats()
         check(self.L.tsl_step(self.h, _ptr(pos), _ptr(prev_pos), _ptr(vel), _ptr(ref_angle), C.byref(st)), "tsl_step")
         return st.as_dict()
 
     def contact_detect(self, pos, prev_pos):
+        self.refresh_stream()
         nc = C.c_int32(0)
         check(self.L.tsl_contact_detect(self.h, _ptr(pos), _ptr(prev_pos), C.byref(nc)), "tsl_contact_detect")
         return nc.value
@@ -140,6 +145,7 @@ class TslContext:
         check(self.L.tsl_update_ref_angle(self.h, _ptr(pos), _ptr(ref_angle)), "tsl_update_ref_angle")
 
     def adjoint_step(self, step, T, pos_buffer, pos_grad, ref_angle_buffer, angleref_grad, tmp_z_frozen, damping=1.0):
+        self.refresh_stream()
         st = SolveStats()
         check(self.L.tsl_adjoint_step(self.h, int(step), int(T), _ptr(pos_buffer), _ptr(pos_grad), _ptr(ref_angle_buffer), _ptr(angleref_grad),
                                       _ptr(tmp_z_frozen), float(damping), C.byref(st)), "tsl_adjoint_step")
@@ -213,6 +219,15 @@ class TslContext:
     def proj_import(self, flag, dr):
         flag = _np(flag, np.int32); dr = _np(dr, np.int32)
         check(self.L.tsl_proj_import(self.h, flag.ctypes.data, dr.ctypes.data), "tsl_proj_import")
+
+    def set_border(self, border):
+        b = _np(border, np.int32)
+        assert b.shape == (self.tot_NV,)
+        check(self.L.tsl_set_border(self.h, b.ctypes.data), "tsl_set_border")
+
+    def refresh_stream(self):
+        """engine calls are ordered against torch's CURRENT stream of the context's device (it may change between calls)"""
+        self.L.tsl_set_stream(self.h, C.c_void_p(torch.cuda.current_stream(self.device).cuda_stream))
 
     def spd_project(self, blocks, D):
         check(self.L.tsl_spd_project(self.h, _ptr(blocks), blocks.numel() // (D * D), D), "tsl_spd_project")

@@ -105,7 +105,10 @@ static int direct_plan(tsl_ctx* c) {
   d.n_plans++;
   d.t_plan += std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
   if (c->verbose >= 2)
-    fprintf(stderr, "[tsl] direct plan: %d supernodes, %d levels, %.2f GB of fronts, %.1f GFLOP per factorisation, nc %d\n", P.sym.n_sn, P.n_levels, P.arena * 8e-9, P.flops * 1e-9, c->nc);
+    fprintf(stderr, "[tsl] direct plan: %d supernodes, %d levels, %zu batches, %.2f GB of fronts, %.1f GFLOP per factorisation, nc %d\n", P.sym.n_sn, P.n_levels, P.batches.size(), P.arena * 8e-9,
+            P.flops * 1e-9, c->nc);
+  if (c->verbose >= 3)
+    for (const DsBatch& b : P.batches) fprintf(stderr, "[tsl]   level %2d: %5d fronts, pivots <= %4d, boundary <= %4d%s\n", b.level, b.count, b.max_pp, b.max_bp, ds_use_small(b) ? " (LDS kernel)" : "");
   return 0;
 }
 

@@ -820,7 +820,12 @@ extern "C" int tsl_contact_detect(tsl_ctx* c, const double* pos, const double* p
   HIP_OK(hipMemcpyAsync(&nc, c->nc_dev.p, sizeof(int), hipMemcpyDeviceToHost, s));
   HIP_OK(hipStreamSynchronize(s));
   HIP_OK(hipGetLastError());
-  c->nc = std::min(nc, c->max_n_constraints);
+  if (nc > c->max_n_constraints) {
+    // the surplus constraints were dropped in atomic-append order: which ones survive is not deterministic, so this is an error
+    c->nc = 0;
+    return tsl_fail("contact detection: %d active constraints exceed max_n_constraints = %d (raise the scene's max_n_constraints)", nc, c->max_n_constraints);
+  }
+  c->nc = nc;
   if (nc_host) *nc_host = c->nc;
   if (c->nc > 0) {
     const int n1 = NV + 1;
@@ -884,6 +889,14 @@ extern "C" int tsl_proj_export(tsl_ctx* c, int32_t* flag, int32_t* dir, int32_t*
   HIP_OK(hipMemcpy(dir, c->proj_dir.p, n * sizeof(int), hipMemcpyDeviceToHost));
   if (pidx) HIP_OK(hipMemcpy(pidx, c->proj_idx.p, n * 3 * sizeof(int), hipMemcpyDeviceToHost));
   if (pw) HIP_OK(hipMemcpy(pw, c->proj_w.p, n * 3 * sizeof(double), hipMemcpyDeviceToHost));
+  return 0;
+}
+
+// BaseScene.border_flag (BaseScene.py:104; written only by Scene_balancing.load_all :213-222, read by project_pair geometry.py:194-201)
+extern "C" int tsl_set_border(tsl_ctx* c, const int32_t* border_host) {
+  Scope scope(c);
+  (void)hipStreamSynchronize(c->stream);
+  HIP_OK(hipMemcpy(c->border.p, border_host, (size_t)c->NV * sizeof(int), hipMemcpyHostToDevice));
   return 0;
 }
 

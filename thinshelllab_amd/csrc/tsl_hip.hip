@@ -356,14 +356,28 @@ extern "C" int tsl_set_param(tsl_ctx* c, const char* key, double v) {
   else if (k == "graph") c->use_graph = (int)v;
   else if (k == "mg_nu") c->mg_nu = std::max(1, (int)v);
   else if (k == "mg_coarse_sweeps") c->mg_coarse_sweeps = std::max(1, (int)v);
-  else if (k.rfind("cloth", 0) == 0 && k.size() > 7) {
-    const int ci = k[5] - '0';
-    if (ci < 0 || ci >= (int)c->h_cloth.size()) return tsl_fail("tsl_set_param: bad cloth index in %s", key);
-    const std::string f = k.substr(7);
-    ClothDev& cd = c->h_cloth[ci];
-    if (f == "Kb") cd.Kb = v; else if (f == "Kl") cd.Kl = v; else if (f == "Ka") cd.Ka = v; else if (f == "k_angle") cd.k_angle = v;
-    else return tsl_fail("tsl_set_param: unknown key %s", key);
-    HIP_OK(hipMemcpy(c->d_cloth.p, c->h_cloth.data(), c->h_cloth.size() * sizeof(ClothDev), hipMemcpyHostToDevice));
+  else if ((k.rfind("cloth", 0) == 0 || k.rfind("elastic", 0) == 0) && k.find('.') != std::string::npos) {
+    // "cloth<i>.Kb|Kl|Ka|k_angle", "elastic<i>.mu|lam|alpha" (0-d field writes after the context exists)
+    const bool is_cloth = k[0] == 'c';
+    const size_t p0 = is_cloth ? 5 : 7, dot = k.find('.');
+    char* endp = nullptr;
+    const long idx = strtol(k.c_str() + p0, &endp, 10);
+    if (endp != k.c_str() + dot || dot == p0) return tsl_fail("tsl_set_param: bad index in %s", key);
+    const std::string f = k.substr(dot + 1);
+    if (is_cloth) {
+      if (idx < 0 || idx >= (long)c->h_cloth.size()) return tsl_fail("tsl_set_param: bad cloth index in %s", key);
+      ClothDev& cd = c->h_cloth[idx];
+      if (f == "Kb") cd.Kb = v; else if (f == "Kl") cd.Kl = v; else if (f == "Ka") cd.Ka = v; else if (f == "k_angle") cd.k_angle = v;
+      else return tsl_fail("tsl_set_param: unknown key %s", key);
+      HIP_OK(hipMemcpy(c->d_cloth.p, c->h_cloth.data(), c->h_cloth.size() * sizeof(ClothDev), hipMemcpyHostToDevice));
+    } else {
+      if (idx < 0 || idx >= (long)c->h_el.size()) return tsl_fail("tsl_set_param: bad elastic index in %s", key);
+      ElasticDev& ed = c->h_el[idx];
+      if (f == "mu") ed.mu = v; else if (f == "lam") ed.lam = v; else if (f == "alpha") ed.alpha = v;
+      else return tsl_fail("tsl_set_param: unknown key %s", key);
+      HIP_OK(hipMemcpy(c->d_el.p, c->h_el.data(), c->h_el.size() * sizeof(ElasticDev), hipMemcpyHostToDevice));
+      c->bd_valid = false;
+    }
   } else return tsl_fail("tsl_set_param: unknown key %s", key);
   return 0;
 }

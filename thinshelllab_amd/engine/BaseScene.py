@@ -106,7 +106,7 @@ class BaseScene:
             self.tot_NF += e.n_surfaces
         self.frozen = Field(torch.zeros(NV * 3, dtype=torch.int32), lambda f: self._dirty.add("frozen"))
         self.faces = Field(torch.zeros((self.tot_NF, 3), dtype=torch.int32))
-        self.border_flag = Field(torch.zeros(NV, dtype=torch.int32))
+        self.border_flag = Field(torch.zeros(NV, dtype=torch.int32), lambda f: self._dirty.add("border"))
         self.ext_force = Field(torch.zeros((NV, 3), dtype=torch.float64), lambda f: self._dirty.add("ext_force"))
         self.x32 = Field(torch.zeros((NV, 3), dtype=torch.float32))
         self.f_vis = Field(torch.zeros(self.tot_NF * 3, dtype=torch.int32))
@@ -311,6 +311,8 @@ class BaseScene:
         if self._dirty:
             if "frozen" in self._dirty:
                 self._ctx.set_frozen(self.frozen.to_numpy())
+            if "border" in self._dirty:
+                self._ctx.set_border(self.border_flag.to_numpy())
             if "ext_force" in self._dirty:
                 self._ctx.set_ext_force(self._ext_force_array())
             if "gravity" in self._dirty:

@@ -17,7 +17,7 @@ class Elastic:
         self.E = 300000
         self.nu = 0.2
         mu, lam = self.E / (2 * (1 + self.nu)), self.E * self.nu / ((1 + self.nu) * (1 - 2 * self.nu))
-        self.mu = ScalarField(mu); self.lam = ScalarField(lam); self.alpha = ScalarField(1 + mu / lam)
+        self.mu = ScalarField(mu, self._param("mu")); self.lam = ScalarField(lam, self._param("lam")); self.alpha = ScalarField(1 + mu / lam, self._param("alpha"))
         self.density = 2000.0
         self.dt = dt
         self.offset = offset
@@ -45,6 +45,14 @@ class Elastic:
         self.f2v = Field(torch.zeros((self.n_surfaces, 3), dtype=torch.int32))
         self.offset_faces = 0
         self.body_idx = 0
+
+    def _param(self, name):
+        """writes after the engine context exists are forwarded (tsl_set_param "elastic<i>.mu|lam|alpha"), like the cloth's Kb / Kl / Ka"""
+        def cb(field):
+            sys = getattr(self, "_sys", None)
+            if sys is not None and sys._ctx is not None:
+                sys._ctx.set_param(f"elastic{sys.elastics.index(self)}.{name}", field.value)
+        return cb
 
     def _gravity_written(self, field):
         if self._sys is not None:
