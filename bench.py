@@ -231,7 +231,8 @@ def roofline(ctx, scene, elapsed, K, stats, args):
         ach = v["bytes_per_launch"] / (v["us_per_launch"] * 1e-6) / 1e9
         rf = {"bound": "hbm", "achieved": ach, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": ach / HBM_PEAK_GBS, "traffic": None}
     try:  # HBM bytes per launch from the committed rocprofv3 --pmc passes (scripts/gpu_profile.sh), if present for this kernel
-        path = os.path.join(ROOT, "profiles", f"r02_{args.workload.replace('-', '_')}_pmc_{names[dom].split(' ')[0]}.json")
+        key = {0: "k_ds_gj_step", 1: "k_ds_gemm1", 2: "k_ds_gemm0", 4: "k_ds_gemv"}[dom]
+        path = os.path.join(ROOT, "profiles", f"r02_{args.workload.replace('-', '_')}_pmc_{key}.json")
         if os.path.exists(path) and args.grid == 224:
             with open(path) as fh:
                 rf["traffic"] = json.load(fh)["traffic_bytes_per_launch"]
@@ -241,6 +242,10 @@ def roofline(ctx, scene, elapsed, K, stats, args):
     rf.update({"kernel": names[dom], "flops_per_launch": v["flops_per_launch"], "bytes_per_launch": v["bytes_per_launch"], "avg_launch_us": v["us_per_launch"],
                "launches_per_factorization": v["launches"], "share_of_direct_solve_time": share[dom] / tot,
                "classes_us_per_newton_iteration": {names[k].split(" ")[0]: share[k] for k in share},
+               "classes": {names[k].split(" ")[0]: {"avg_launch_us": cls[k]["us_per_launch"], "launches_per_factorization": cls[k]["launches"],
+                                                    "flops_per_launch": cls[k]["flops_per_launch"], "bytes_per_launch": cls[k]["bytes_per_launch"],
+                                                    "TFLOPs": cls[k]["flops_per_launch"] / max(cls[k]["us_per_launch"], 1e-9) / 1e6,
+                                                    "GBs": cls[k]["bytes_per_launch"] / max(cls[k]["us_per_launch"], 1e-9) / 1e3} for k in cls},
                "timing": "avg_launch_us = one HIP-event pair on the library's stream around 10 back-to-back replays of every launch of this kernel class of one "
                          "factorisation (one application for k_ds_gemv) on the run's last plan, divided by the launches (includes the gaps between dependent "
                          "launches; compare the rocprofv3 kernel-trace averages under profiles/)",
@@ -274,7 +279,7 @@ def main():
     ap.add_argument("--param", action="append", default=[], metavar="KEY=VALUE", help="extra tsl_set_param settings (solver experiments)")
     ap.add_argument("--cpu-cg-iters", type=int, default=4000, help="PCG iterations of the extrapolation sample of the oracle")
     ap.add_argument("--cpu-grid", type=int, default=71, help="cloth grid of the complete oracle steps of cpu_baseline")
-    ap.add_argument("--cpu-steps", type=int, default=3)
+    ap.add_argument("--cpu-steps", type=int, default=2)
     ap.add_argument("--cpu-threads", type=int, default=16)
     args = ap.parse_args()
 

@@ -1,27 +1,36 @@
 #!/bin/bash
-# rocprofv3 summaries of the bench workload (run on the GPU box through gpurun): kernel trace + stats, then the two
-# HBM counters of the PCG SpMV kernel in their own passes (FETCH_SIZE and WRITE_SIZE do not fit one pass).
+# rocprofv3 summaries of the bench workload (run on the GPU box through gpurun):
+#   1. kernel trace + stats of the driver's command (python bench.py --steps 20 --warmup 5), 2. the two HBM counters of the kernels
+#   of the direct solve in their own passes on a shorter run (FETCH_SIZE and WRITE_SIZE do not fit one pass; counters are never
+#   combined with tracing), 3. the bench lines with cpu_baseline (default command and the driver's command).
 cd $GRAFT_REPO_ROOT
 export TMPDIR=/tmp
-TAG=${1:-r01c}
-ARGS=${BENCH_ARGS:---steps 2 --warmup 2 --no-cpu-baseline}
+TAG=${1:-r02}
+WL=${WORKLOAD:-cfg4}
+ARGS=${BENCH_ARGS:---steps 20 --warmup 5 --no-cpu-baseline}
+PMC_ARGS=${PMC_ARGS:---steps 3 --warmup 1 --no-cpu-baseline}
 mkdir -p gpurun_out/prof
-rocprofv3 --kernel-trace --stats --output-format csv -d gpurun_out/prof -o ${TAG}_bench -- python bench.py $ARGS > gpurun_out/prof/${TAG}_bench_stdout.log 2>&1
-tail -1 gpurun_out/prof/${TAG}_bench_stdout.log
+rocprofv3 --kernel-trace --stats --output-format csv -d gpurun_out/prof -o ${TAG}_bench -- python bench.py --workload $WL $ARGS > gpurun_out/prof/${TAG}_bench_stdout.log 2>&1
+tail -1 gpurun_out/prof/${TAG}_bench_stdout.log | cut -c1-300
 rm -f gpurun_out/prof/*kernel_trace.csv
-for CNT in FETCH_SIZE WRITE_SIZE; do
-  rocprofv3 --pmc $CNT --kernel-include-regex "k_pcg_spmv" --output-format csv -d gpurun_out/prof -o ${TAG}_pmc_$CNT -- python bench.py $ARGS > gpurun_out/prof/${TAG}_pmc_${CNT}_stdout.log 2>&1
-  python - <<PY
+for KRN in "k_ds_gemm<1>" "k_ds_gemm<0>" "k_ds_gj_step" "k_ds_gemv"; do
+  KN=$(echo $KRN | tr -d '<>')
+  for CNT in FETCH_SIZE WRITE_SIZE; do
+    rocprofv3 --pmc $CNT --kernel-include-regex "$KRN" --output-format csv -d gpurun_out/prof -o ${TAG}_pmc_${KN}_$CNT -- python bench.py --workload $WL $PMC_ARGS > gpurun_out/prof/${TAG}_pmc_stdout.log 2>&1
+    python - <<PY
 import csv, glob
-for f in glob.glob("gpurun_out/prof/**/${TAG}_pmc_${CNT}_counter_collection.csv", recursive=True) + glob.glob("gpurun_out/prof/${TAG}_pmc_${CNT}_counter_collection.csv"):
+for f in glob.glob("gpurun_out/prof/**/${TAG}_pmc_${KN}_${CNT}_counter_collection.csv", recursive=True):
     rows = list(csv.DictReader(open(f)))
     vals = [float(r["Counter_Value"]) for r in rows if r.get("Counter_Name") == "$CNT"]
     if vals:
-        print("$CNT", "dispatches", len(vals), "mean", sum(vals) / len(vals), "min", min(vals), "max", max(vals))
-        open("gpurun_out/prof/${TAG}_pmc_${CNT}_summary.txt", "w").write(f"$CNT kernel=k_pcg_spmv dispatches={len(vals)} mean={sum(vals)/len(vals)} min={min(vals)} max={max(vals)}\n")
+        line = f"$CNT kernel=$KRN dispatches={len(vals)} mean={sum(vals)/len(vals)} min={min(vals)} max={max(vals)} sum={sum(vals)}"
+        print(line)
+        open("gpurun_out/prof/${TAG}_pmc_${KN}_${CNT}_summary.txt", "w").write(line + "\n")
     break
 PY
+    find gpurun_out/prof -name "*counter_collection.csv" -delete
+  done
 done
-rm -f gpurun_out/prof/*counter_collection.csv
-find gpurun_out/prof -name "*counter_collection.csv" -delete
+python bench.py --workload $WL > gpurun_out/prof/${TAG}_full_default.json 2> gpurun_out/prof/${TAG}_full_default.err
+python bench.py --workload $WL --steps 20 --warmup 5 > gpurun_out/prof/${TAG}_full_driver.json 2> gpurun_out/prof/${TAG}_full_driver.err
 ls gpurun_out/prof

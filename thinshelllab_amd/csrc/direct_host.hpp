@@ -22,7 +22,8 @@ static inline bool ds_use_small(const DsBatch& b) {
 // registers per lane, one wave per SIMD) was 2.5x slower than these 64 x 64 tiles, which reach 25-49 TFLOP/s per level on cfg4.
 static void ds_launch_gemm(hipStream_t s, const DsDev& D, const DsBatch& b, int mode) {
   const int rows = mode == 0 ? b.max_pp : b.max_bp, cols = b.max_bp;
-  hipLaunchKernelGGL(k_ds_gemm, dim3((cols + 63) / 64, (rows + 63) / 64, b.count), dim3(256), 0, s, D, b.first, mode);
+  if (mode == 0) hipLaunchKernelGGL((k_ds_gemm<0>), dim3((cols + 63) / 64, (rows + 63) / 64, b.count), dim3(256), 0, s, D, b.first);
+  else hipLaunchKernelGGL((k_ds_gemm<1>), dim3((cols + 63) / 64, (rows + 63) / 64, b.count), dim3(256), 0, s, D, b.first);
 }
 
 static bool direct_enabled(tsl_ctx* c) {

@@ -111,7 +111,11 @@ TSL_DEV void ds_invert_tile_wg(double (*T)[DS_T + 1], int* __restrict__ bad) {
     double piv = rowb[buf][p];
     const double rj = rowb[buf][tx];
     if (!(fabs(piv) >= tiny)) { piv = (piv < 0.0) ? -tiny : tiny; nbad++; }
-    const double ip = 1.0 / piv;
+    // reciprocal of the pivot on the critical path of 32 dependent steps: hardware estimate + two Newton steps (full precision)
+    // instead of the ~20-instruction IEEE division sequence
+    double ip = __builtin_amdgcn_rcp(piv);
+    ip = fma(fma(-piv, ip, 1.0), ip, ip);
+    ip = fma(fma(-piv, ip, 1.0), ip, ip);
     const double rs = rj * ip;
 #pragma unroll
     for (int q = 0; q < 4; q++) {
@@ -361,7 +365,8 @@ __global__ void __launch_bounds__(256) k_ds_inv_small(DsDev D, int lv0, int ls) 
 //   mode 1:  S = F22 - F21 G      (bp x bp, K = pp)  in place
 // one 64 x 64 output tile per workgroup (four waves, each a 32 x 32 quadrant = 2 x 2 MFMA tiles), K in chunks of 32 through LDS
 #define DS_SK 32
-__global__ void __launch_bounds__(256) k_ds_gemm(DsDev D, int lv0, int mode) {
+template <int mode>
+__global__ void __launch_bounds__(256) k_ds_gemm(DsDev D, int lv0) {
   __shared__ double As[64][DS_SK + 1];
   __shared__ double Bs[DS_SK][64 + 1];
   const DsFrontDesc f = D.fr[D.level_sn[lv0 + blockIdx.z]];
