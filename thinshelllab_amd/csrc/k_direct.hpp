@@ -80,56 +80,98 @@ __global__ void k_ds_pad_diag(int n_sn, const DsFrontDesc* __restrict__ fr, doub
 }
 
 // ---- blocked Gauss-Jordan on the top block rows ---------------------------------------------------------------------------
-// In-place Gauss-Jordan inversion of one DS_T x DS_T tile in LDS by the whole 256-thread workgroup: thread (tx, ty) keeps the four
-// elements (ty + 8 q, tx) in registers, per pivot the pivot row and column go through double-buffered LDS vectors (one barrier per
-// pivot).  Measured against one wave holding the tile in registers (16 elements per lane, no barriers): the same ~6 us, but 30
-// instead of 130 registers, which every workgroup of the block-step kernel would otherwise pay in occupancy.
-// Pivots below 1e-13 of the tile's largest entry are replaced by that bound (counted in bad[0]).  All 256 threads must call it;
-// the tile is complete in LDS on return (the function ends with a barrier).
+// In-place Gauss-Jordan inversion of one DS_T x DS_T tile in LDS by the whole 256-thread workgroup with 4 x 4 BLOCK pivots on the
+// matrix cores: wave (wi, wj) keeps its 16 x 16 quadrant in the accumulator layout of v_mfma_f64_16x16x4_f64 (lane l, register r
+// = element (16 wi + (l >> 4) + 4 r, 16 wj + (l & 15))), so that the rank-4 update of a block step is ONE matrix instruction per
+// wave; per step the four pivot rows and columns go through double-buffered LDS panels (one barrier per step) and every lane inverts
+// the 4 x 4 pivot block itself.  Eight dependent steps instead of 32 scalar pivots: the tile inversion sits on the critical path
+// of every block step of the factorisation (measured inside a kernel: 10.7 us for the scalar-pivot version -- one LDS round
+// trip, one reciprocal and a chain of selects per pivot -- and for a 4 x 4-block version on the vector units alike).
+// Scalar pivots below 1e-13 of the tile's largest entry are replaced by that bound (counted in bad[0]).  All 256 threads must call
+// it; the tile is complete in LDS on return (the function ends with a barrier).
+#define DS_PB 4
+TSL_DEV double ds_rcp(double x) {
+  double r = __builtin_amdgcn_rcp(x);   // hardware estimate + two Newton steps: full precision without the IEEE division sequence
+  r = fma(fma(-x, r, 1.0), r, r);
+  return fma(fma(-x, r, 1.0), r, r);
+}
 TSL_DEV void ds_invert_tile_wg(double (*T)[DS_T + 1], int* __restrict__ bad) {
-  __shared__ double colb[2][DS_T], rowb[2][DS_T], red[4];
-  const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;
-  double a[4];
+  __shared__ double rowp[2][DS_PB][DS_T], colp[2][DS_PB][DS_T + 1], red[4];
+  const int lane = threadIdx.x & 63, w = threadIdx.x >> 6, wi = w >> 1, wj = w & 1, lr = lane & 15, lk = lane >> 4;
+  ds_d4 acc;
   double amax = 0.0;
 #pragma unroll
-  for (int q = 0; q < 4; q++) { a[q] = T[ty + 8 * q][tx]; amax = fmax(amax, fabs(a[q])); }
+  for (int r = 0; r < 4; r++) { acc[r] = T[16 * wi + lk + 4 * r][16 * wj + lr]; amax = fmax(amax, fabs(acc[r])); }
   amax = wave_max(amax);
-  if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = amax;
+  if (lane == 0) red[w] = amax;
   __syncthreads();
   const double tiny = fmax(fmax(fmax(red[0], red[1]), fmax(red[2], red[3])) * 1e-13, 1e-300);
   int nbad = 0;
 #pragma unroll
-  for (int p = 0; p < DS_T; p++) {
-    const int buf = p & 1;
-    const int qp = p >> 3;   // the pivot row p = ty + 8 qp belongs to the threads with ty == (p & 7)
-    if (ty == (p & 7)) rowb[buf][tx] = a[qp];
-    if (tx == p) {
+  for (int s = 0; s < DS_T / DS_PB; s++) {
+    const int buf = s & 1, p0 = DS_PB * s;
+    const int wp = p0 >> 4;             // quadrant row / column that holds the pivots
+    const int rp = (p0 & 15) >> 2;      // their accumulator register (rows) ...
+    const int lc = p0 & 15;             // ... and first lane column (columns)
+    // pivot rows: local row (p0 & 15) + j sits in lanes lk == j, register rp
+    if (wi == wp) rowp[buf][lk][16 * wj + lr] = acc[rp];
+    if (wj == wp && lr >= lc && lr < lc + DS_PB) {
 #pragma unroll
-      for (int q = 0; q < 4; q++) colb[buf][ty + 8 * q] = a[q];
+      for (int r = 0; r < 4; r++) colp[buf][lr - lc][16 * wi + lk + 4 * r] = acc[r];
     }
     __syncthreads();
-    double piv = rowb[buf][p];
-    const double rj = rowb[buf][tx];
-    if (!(fabs(piv) >= tiny)) { piv = (piv < 0.0) ? -tiny : tiny; nbad++; }
-    // reciprocal of the pivot on the critical path of 32 dependent steps: hardware estimate + two Newton steps (full precision)
-    // instead of the ~20-instruction IEEE division sequence
-    double ip = __builtin_amdgcn_rcp(piv);
-    ip = fma(fma(-piv, ip, 1.0), ip, ip);
-    ip = fma(fma(-piv, ip, 1.0), ip, ip);
-    const double rs = rj * ip;
+    // inverse of the 4 x 4 pivot block (every lane, registers).  Everything below is written without data-dependent control
+    // flow: the compiler turned conditional loads / updates into hundreds of exec-mask branches (4 x slower than this form).
+    double d[DS_PB][DS_PB];
 #pragma unroll
-    for (int q = 0; q < 4; q++) {
-      const int i = ty + 8 * q;
-      const double ci = colb[buf][i];
-      double v;
-      if (i == p) v = (tx == p) ? ip : rs;
-      else if (tx == p) v = -ci * ip;
-      else v = a[q] - ci * rs;
-      a[q] = v;
+    for (int i = 0; i < DS_PB; i++)
+#pragma unroll
+      for (int j = 0; j < DS_PB; j++) d[i][j] = rowp[buf][i][p0 + j];
+#pragma unroll
+    for (int p = 0; p < DS_PB; p++) {
+      const double piv0 = d[p][p];
+      const bool small = !(fabs(piv0) >= tiny);
+      const double piv = small ? copysign(tiny, piv0) : piv0;
+      nbad += small ? 1 : 0;
+      const double ip = ds_rcp(piv);
+#pragma unroll
+      for (int j = 0; j < DS_PB; j++) d[p][j] = (j == p) ? ip : d[p][j] * ip;
+#pragma unroll
+      for (int i = 0; i < DS_PB; i++) {
+        if (i == p) continue;
+        const double f = d[i][p];
+#pragma unroll
+        for (int j = 0; j < DS_PB; j++) d[i][j] = (j == p) ? -f * ip : fma(-f, d[p][j], d[i][j]);
+      }
+    }
+    // (Dinv R)[j][column of this lane] for the four pivot rows; the lane's own k index of the matrix-core operands is lk
+    double rcol[DS_PB], bj[DS_PB];
+#pragma unroll
+    for (int m = 0; m < DS_PB; m++) rcol[m] = rowp[buf][m][16 * wj + lr];
+#pragma unroll
+    for (int j = 0; j < DS_PB; j++) bj[j] = d[j][0] * rcol[0] + d[j][1] * rcol[1] + d[j][2] * rcol[2] + d[j][3] * rcol[3];
+    const double bop = lk == 0 ? bj[0] : (lk == 1 ? bj[1] : (lk == 2 ? bj[2] : bj[3]));
+    const double aop = -colp[buf][lk][16 * wi + lr];
+    const ds_d4 upd = __builtin_amdgcn_mfma_f64_16x16x4f64(aop, bop, acc, 0, 0, 0);   // acc - C (Dinv R)
+    // fix-ups: pivot rows become Dinv R (Dinv inside the pivot columns), pivot columns become -C Dinv
+    const bool col_in = wj == wp && lr >= lc && lr < lc + DS_PB;
+    const int mc = (lr - lc) & 3;   // pivot column index of this lane (meaningful if col_in)
+    double dcol[DS_PB];            // column mc of Dinv
+#pragma unroll
+    for (int j = 0; j < DS_PB; j++) dcol[j] = mc == 0 ? d[j][0] : (mc == 1 ? d[j][1] : (mc == 2 ? d[j][2] : d[j][3]));
+    const double dsel = lk == 0 ? dcol[0] : (lk == 1 ? dcol[1] : (lk == 2 ? dcol[2] : dcol[3]));   // Dinv[lk][mc]
+#pragma unroll
+    for (int r = 0; r < 4; r++) {
+      const bool row_in = wi == wp && r == rp;   // local row lk + 4 r with r == rp: pivot row j = lk
+      const int row = 16 * wi + lk + 4 * r;
+      const double t = colp[buf][0][row] * dcol[0] + colp[buf][1][row] * dcol[1] + colp[buf][2][row] * dcol[2] + colp[buf][3][row] * dcol[3];
+      const double v_row = col_in ? dsel : bop;
+      const double v_else = col_in ? -t : upd[r];
+      acc[r] = row_in ? v_row : v_else;
     }
   }
 #pragma unroll
-  for (int q = 0; q < 4; q++) T[ty + 8 * q][tx] = a[q];
+  for (int r = 0; r < 4; r++) T[16 * wi + lk + 4 * r][16 * wj + lr] = acc[r];
   if (threadIdx.x == 0 && nbad) atomicAdd(bad, nbad);
   __syncthreads();
 }
