@@ -104,7 +104,8 @@ int tsl_set_stream(tsl_ctx* ctx, void* hip_stream);
 
 /* 0-d field writes: "cloth<i>.Kb|Kl|Ka|k_angle", "elastic<i>.mu|lam|alpha", "mu_cloth_elastic", "mu_cloth_cloth", "k_contact", "eps_contact", "damping",
  * "newton_cap", "plastic", "contact" (trajopt_folding.py:50,66; Scene_folding.py:30-31), the broad-phase box
- * "grid_h", "grid_extent" (geometry.py:8-19), and the solver knobs that have no reference counterpart (the reference
+ * "grid_h", "grid_extent" (geometry.py:8-19), "self_contact<body>" (0 / 1: the body's vertices are also projected onto its own
+ * triangles, geometry_self.project_pair_self, geometry_self.py:166-230), and the solver knobs that have no reference counterpart (the reference
  * calls a direct solver): "cg_tol", "cg_maxit", "cg_check", "mg" (-1 auto / 0 / 1), "mg_nu", "mg_coarse_sweeps",
  * "mg_omega", "mg_pi_iters", "mg_fuse", "mg_max_levels", "mg_coarse_exact" (dense inverse of the last multigrid level),
  * "mg_dense_nodes" (largest level solved exactly; -1 = chosen per time step, default), "mg_coarse_lag", "warm_start", "pcg_ahead", "body_inv"

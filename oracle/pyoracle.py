@@ -244,6 +244,10 @@ class OracleScene:
     def projection_query(self):
         self.L.tslo_projection_query(self.h)
 
+    def set_self_contact(self, body, on=True):
+        """geometry_self.projection_query(self_contact=[...]): project the body's vertices onto its own triangles too"""
+        self.L.tslo_set_self_contact(self.h, int(body), int(bool(on)))
+
     def contact_analysis(self):
         self.L.tslo_contact_analysis(self.h)
 

@@ -148,6 +148,11 @@ void tslo_timestep_init(void* h) { S(h).timestep_init(); }
 void tslo_timestep_finish(void* h) { S(h).timestep_finish(); }
 void tslo_calc_vn(void* h) { S(h).calc_vn(); }
 void tslo_projection_query(void* h) { S(h).projection_query(); }
+void tslo_set_self_contact(void* h, int body, int on) {
+  Scene& s = S(h);
+  if ((int)s.self_contact.size() < (int)s.body_list.size()) s.self_contact.assign(s.body_list.size(), 0);
+  if (body >= 0 && body < (int)s.self_contact.size()) s.self_contact[body] = on;
+}
 void tslo_contact_analysis(void* h) { S(h).contact_analysis(); }
 int tslo_nc(void* h) { return S(h).nc; }
 void tslo_action(void* h, const double* dpos, const double* drot) { S(h).action(dpos, drot); }

@@ -510,6 +510,54 @@ void Scene::projection_query() {
         proj_w[bi] = pw;
       }
     }
+    // geometry_self.project_pair_self (geometry_self.py:166-230), called for the bodies in self_contact (:295-296)
+    if (body_idx < (int)self_contact.size() && self_contact[body_idx]) {
+#pragma omp parallel for schedule(dynamic, 64)
+      for (int i = body.v_start; i < body.v_end; i++) {
+        V3 xq = pos[i];
+        int q[3];
+        grid_idx(*this, xq, q);
+        int r0[3], r1[3];
+        for (int a = 0; a < 3; a++) {
+          r0[a] = std::max(q[a] - 1, amin[a]);
+          r1[a] = std::min(q[a] + 1, amax[a]) + 1;
+        }
+        double d_min = 1e6, cos_max = -1e6;
+        int pflag = 0;
+        I3 pidx{{0, 0, 0}};
+        V3 pw;
+        for (int gi = r0[0]; gi < r1[0]; gi++)
+          for (int gj = r0[1]; gj < r1[1]; gj++)
+            for (int gk = r0[2]; gk < r1[2]; gk++) {
+              int cell = ((gi - amin[0]) * ext[1] + (gj - amin[1])) * ext[2] + (gk - amin[2]);
+              for (int s = cell_start[cell]; s < cell_start[cell + 1]; s++) {
+                const I3& f = faces[body.f_start + order[s]];
+                if (i == f[0] || i == f[1] || i == f[2]) continue;   // :186-187
+                V3 v1 = pos[f[0]], v2 = pos[f[1]], v3 = pos[f[2]];
+                int c; double d; V3 w;
+                pt2tri(xq, v1, v2, v3, c, d, w);
+                if (c != 0) continue;                                  // :194-195
+                V3 vt = v1 * w[0] + v2 * w[1] + v3 * w[2];
+                V3 nt = normalized(cross(v2 - v1, v3 - v1));
+                double cs = dot(xq - vt, nt);
+                if (d < d_min - 1e-5 || (d < d_min + 1e-5 && cs > cos_max)) {
+                  d_min = d; cos_max = cs;
+                  pidx = f; pw = w;
+                  pflag = 1;
+                }
+              }
+            }
+        V3 v1 = pos[pidx[0]], v2 = pos[pidx[1]], v3 = pos[pidx[2]];
+        V3 n1 = vn[pidx[0]], n2 = vn[pidx[1]], n3 = vn[pidx[2]];
+        V3 v = pw[0] * v1 + pw[1] * v2 + pw[2] * v3;
+        V3 n = pw[0] * n1 + pw[1] * n2 + pw[2] * n3;
+        size_t bi = (size_t)body_idx * tot_NV + i;
+        if (proj_flag[bi] == 0 && pflag == 1) proj_dir[bi] = dot(xq - v, n) > 0;
+        proj_flag[bi] = pflag;
+        proj_idx[bi] = pidx;
+        proj_w[bi] = pw;
+      }
+    }
   }
 }
 

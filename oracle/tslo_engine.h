@@ -220,6 +220,7 @@ struct Scene {
   void contact_analysis();
   void calc_vn();
   void projection_query();
+  std::vector<int> self_contact;  // geometry_self.projection_query(self_contact=[...]): bodies queried against their own triangles
   void compute_residual_and_Hessian(int spd);
   void compute_Hessian(int spd);
   void newton_step_init();

@@ -630,3 +630,35 @@ def test_reference_state_projection_query_on_gpu():
     assert np.array_equal(f2, F) and np.array_equal(d2, D)
     st = s.time_step(projection_query, 1)
     assert np.isfinite(s.pos.to_numpy()).all() and st["nc"] > 0
+
+
+def test_self_contact_projection_query(oracle):
+    """geometry_self.projection_query(self_contact=[0]) (/root/reference/code/engine/geometry_self.py:166-230, 290-297): the folded
+    cloth of the folding scene projected onto ITSELF -- coarse 0.1 m grid, own triangles of a vertex skipped, only projections inside
+    a triangle -- next to the ordinary body pairs; GPU against the oracle's literal restatement."""
+    from thinshelllab_amd.engine import geometry_self
+    s, o = _pair(oracle, "folding")
+    nc = geometry_self.projection_query(s, self_contact=[0])
+    o.set_scalar("grid_h", geometry_self.grid_h); o.set_scalar("grid_extent", 0.2)
+    o.set_self_contact(0, True)
+    o.calc_vn(); o.projection_query(); o.contact_analysis()
+    flag, dr, pidx, pw = s._ctx.proj_export()
+    nb = len(s.body_list)
+    fo = o.arr("proj_flag", (nb, -1)); do = o.arr("proj_dir", (nb, -1)); io = o.arr("proj_idx", (nb, -1, 3)); wo = o.arr("proj_w", (nb, -1, 3))
+    c = s.cloths[0]
+    own = slice(c.offset, c.offset + c.NV)
+    assert fo[0, own].sum() > 20                       # the top layer sees the bottom layer (and vice versa)
+    assert np.array_equal(flag, fo)
+    assert np.array_equal(dr[fo == 1], do[fo == 1])
+    assert np.array_equal(pidx[fo == 1], io[fo == 1])
+    assert np.abs(pw[fo == 1] - wo[fo == 1]).max() < 1e-9
+    # a self-projection never lands on a triangle of the vertex itself and always inside the triangle
+    sel = np.nonzero(flag[0, own])[0] + c.offset
+    assert all(v not in pidx[0, v] for v in sel)
+    assert (pw[0, sel] > -1e-12).all() and np.abs(pw[0, sel].sum(1) - 1).max() < 1e-12
+    assert nc == o.nc
+    # without the self list the other bodies' rows are the same and the cloth's own rows are not rewritten (the flags persist, as in
+    # the reference: geometry_self.py:226-228 only runs for the listed bodies)
+    geometry_self.projection_query(s, self_contact=[])
+    flag2, _, _, _ = s._ctx.proj_export()
+    assert np.array_equal(flag2, flag)

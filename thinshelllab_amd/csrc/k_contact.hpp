@@ -105,7 +105,9 @@ struct ProjBest { double d, cs; int pos; };
 TSL_DEV bool proj_replaces(const ProjBest& cur, const ProjBest& cand) {  // cand comes later in scan order
   return cand.d < cur.d - 1e-5 || (cand.d < cur.d + 1e-5 && cand.cs > cur.cs);
 }
-template <int G>
+// SELF: geometry_self.project_pair_self (geometry_self.py:166-230) -- the query vertices are the body's own vertices: triangles that
+// contain the vertex are skipped, only projections INSIDE a triangle (c == 0) are candidates, the flag is "a candidate exists"
+template <int G, bool SELF>
 __global__ void __launch_bounds__(256)
 k_project_pair(GridArgs Gr, int v_start, int v_end, int body_idx, int NV, int nf, const int* __restrict__ skey, const int* __restrict__ sval,
                const int* __restrict__ range, const int* __restrict__ faces, const double* __restrict__ pos, const double* __restrict__ vn,
@@ -132,9 +134,11 @@ k_project_pair(GridArgs Gr, int v_start, int v_end, int body_idx, int NV, int nf
           for (int s = s0 + g; s < s1; s += G) {
             const int f = sval[s];
             const int a = faces[3 * f], b = faces[3 * f + 1], c3 = faces[3 * f + 2];
+            if (SELF && (i == a || i == b || i == c3)) continue;
             const d3 v1 = ld3(pos, a), v2 = ld3(pos, b), v3 = ld3(pos, c3);
             int c; double d; d3 w;
             pt2tri(xq, v1, v2, v3, c, d, w);
+            if (SELF && c != 0) continue;
             const d3 vt = v1 * w.x + v2 * w.y + v3 * w.z;
             const d3 nt = normalized(cross(v2 - v1, v3 - v1));
             const ProjBest cand{d, dot(xq - vt, nt), base + (s - s0)};
@@ -157,7 +161,7 @@ k_project_pair(GridArgs Gr, int v_start, int v_end, int body_idx, int NV, int nf
   int pflag = 0, pi0 = 0, pi1 = 0, pi2 = 0;
   if (!none) {
     pi0 = ba; pi1 = bb; pi2 = bc3;
-    if (bc == 0) pflag = 1;
+    if (SELF || bc == 0) pflag = 1;
     else if (bc > 0) { const int pv = (bc == 1) ? ba : ((bc == 2) ? bb : bc3); pflag = !border[pv]; }
     else {
       const int p1 = (bc != -3) ? bc3 : ba;
@@ -794,15 +798,24 @@ extern "C" int tsl_contact_detect(tsl_ctx* c, const double* pos, const double* p
       const tsl_body& q = c->h_bodies[b2];
       const int nq = q.v_end - q.v_start;
       if (nq <= 0) continue;
-#define TSL_PROJ_LAUNCH(GW)                                                                                                                                     \
-  hipLaunchKernelGGL((k_project_pair<GW>), dim3(cnblk((long)nq * GW, 256)), dim3(256), 0, s, G, q.v_start, q.v_end, b, NV, nf, c->grid_key2.p, c->grid_val2.p, \
+#define TSL_PROJ_LAUNCH(GW, SF)                                                                                                                                      \
+  hipLaunchKernelGGL((k_project_pair<GW, SF>), dim3(cnblk((long)nq * GW, 256)), dim3(256), 0, s, G, q.v_start, q.v_end, b, NV, nf, c->grid_key2.p, c->grid_val2.p, \
                      c->grid_range.p, c->faces.p, pos, c->vn.p, c->border.p, c->proj_flag.p, c->proj_dir.p, c->proj_idx.p, c->proj_w.p)
       // lanes per query vertex by the size of the triangle set it scans (many triangles per cell on refined cloths)
-      if (nf >= 8192) TSL_PROJ_LAUNCH(64);
-      else if (nf >= 512) TSL_PROJ_LAUNCH(8);
-      else TSL_PROJ_LAUNCH(1);
-#undef TSL_PROJ_LAUNCH
+      if (nf >= 8192) TSL_PROJ_LAUNCH(64, false);
+      else if (nf >= 512) TSL_PROJ_LAUNCH(8, false);
+      else TSL_PROJ_LAUNCH(1, false);
     }
+    if (b < (int)c->self_contact.size() && c->self_contact[b]) {   // geometry_self.projection_query (geometry_self.py:290-297)
+      const tsl_body& q = body;
+      const int nq = q.v_end - q.v_start;
+      if (nq > 0) {
+        if (nf >= 8192) TSL_PROJ_LAUNCH(64, true);
+        else if (nf >= 512) TSL_PROJ_LAUNCH(8, true);
+        else TSL_PROJ_LAUNCH(1, true);
+      }
+    }
+#undef TSL_PROJ_LAUNCH
   }
   // contact_analysis
   HIP_OK(hipMemsetAsync(c->nc_dev.p, 0, sizeof(int), s));

@@ -224,6 +224,7 @@ struct tsl_ctx {
   int n_body = 0, n_pair = 0;
   std::vector<tsl_body> h_bodies;
   std::vector<tsl_contact_pair> h_pairs;
+  std::vector<int> self_contact;  // per body: query its own vertices against its own triangles (geometry_self.project_pair_self)
   DevBuf<int> faces;  // NF x 3
   DevBuf<int> border; // NV (BaseScene.border_flag)
   DevBuf<double> vn;

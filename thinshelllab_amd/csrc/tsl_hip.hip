@@ -340,6 +340,13 @@ extern "C" int tsl_set_param(tsl_ctx* c, const char* key, double v) {
   else if (k == "pcg_body_fold") c->pcg_body_fold = (int)v;
   else if (k == "asm_overlap") c->asm_overlap = (int)v;
   else if (k == "contact_coop") c->contact_coop = (int)v;
+  else if (k.rfind("self_contact", 0) == 0 && k.size() > 12) {   // "self_contact<body>" (geometry_self.projection_query(self_contact=[...]))
+    char* endp = nullptr;
+    const long b = strtol(k.c_str() + 12, &endp, 10);
+    if (*endp != 0 || b < 0 || b >= c->n_body) return tsl_fail("tsl_set_param: bad body index in %s", key);
+    if ((long)c->self_contact.size() < c->n_body) c->self_contact.assign(c->n_body, 0);
+    c->self_contact[b] = (v != 0.0);
+  }
   else if (k == "mg_chunk") c->mg_chunk = (int)v;  // 0 = chosen from the previous step's iterations per solve
   else if (k == "mr_eta") c->mr_eta = v;
   else if (k == "mg_st_f32") { c->mg_st_f32 = (int)v; c->mg_ops_valid = false; }
