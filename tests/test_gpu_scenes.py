@@ -662,3 +662,36 @@ def test_self_contact_projection_query(oracle):
     geometry_self.projection_query(s, self_contact=[])
     flag2, _, _, _ = s._ctx.proj_export()
     assert np.array_equal(flag2, flag)
+
+
+def test_state_and_mesh_export_formats(oracle, tmp_path):
+    """SURVEY section 8f row 4, export formats: BaseScene.save_state / load_state (torch pickle {'pos', 'vel'}, BaseScene.py:1376-1392,
+    load_state re-applies update_ref_angle) and readfile.save_cloth_mesh (reference: open3d write_triangle_mesh, readfile.py:117-128;
+    here an ASCII PLY with the same vertices / faces) after two driven steps of the folding scene."""
+    from thinshelllab_amd.engine import readfile
+    from thinshelllab_amd.engine.geometry import projection_query
+    s, o = _pair(oracle, "folding")
+    n_part = s.gripper.n_part
+    dpos = np.zeros((n_part, 3)); drot = np.zeros((n_part, 3)); dpos[:, 2] = -1e-4
+    for f in range(1, 3):
+        s.action(f, dpos, drot)
+        s.time_step(projection_query, f)
+    st = tmp_path / "state"
+    s.save_state(str(st))
+    data = torch.load(str(st))
+    assert set(data) == {"pos", "vel"} and data["pos"].shape == (s.tot_NV, 3) and data["pos"].dtype == torch.float64 and data["pos"].device.type == "cpu"
+    pos0, vel0, ref0 = s.pos.to_numpy(), s.vel.to_numpy(), s.cloths[0].ref_angle.to_numpy()
+    s.pos.fill(0.0); s.vel.fill(1.0)
+    s.load_state(str(st))
+    assert np.array_equal(s.pos.to_numpy(), pos0) and np.array_equal(s.vel.to_numpy(), vel0)
+    # update_ref_angle at the loaded pose is idempotent here (the step that produced the pose already applied the plastic update)
+    assert np.abs(s.cloths[0].ref_angle.to_numpy() - ref0).max() < 1e-12
+    ply = tmp_path / "cloth.ply"
+    readfile.save_cloth_mesh(s.cloths[0], str(ply))
+    lines = open(ply).read().split("\n")
+    c = s.cloths[0]
+    assert lines[0] == "ply" and f"element vertex {c.NV}" in lines and f"element face {c.NF}" in lines
+    h = lines.index("end_header")
+    v = np.array([[float(x) for x in ln.split()] for ln in lines[h + 1:h + 1 + c.NV]])
+    f = np.array([[int(x) for x in ln.split()] for ln in lines[h + 1 + c.NV:h + 1 + c.NV + c.NF]])
+    assert np.array_equal(v, c.pos.to_numpy()) and np.array_equal(f[:, 1:], c.f2v.to_numpy()) and (f[:, 0] == 3).all()

@@ -500,4 +500,5 @@ class BaseScene:
         data = torch.load(save_path)
         self.pos.t.copy_(data['pos'].to(self.pos.t.device))
         self.vel.t.copy_(data['vel'].to(self.vel.t.device))
+        self.update_ref_angle()   # BaseScene.py:1376-1384: the loaded pose also moves the plastic rest angles
         self.update_visual()
