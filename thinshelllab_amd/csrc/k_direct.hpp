@@ -91,9 +91,16 @@ __global__ void k_ds_pad_diag(int n_sn, const DsFrontDesc* __restrict__ fr, doub
 // it; the tile is complete in LDS on return (the function ends with a barrier).
 #define DS_PB 4
 TSL_DEV double ds_rcp(double x) {
-  double r = __builtin_amdgcn_rcp(x);   // hardware estimate + two Newton steps: full precision without the IEEE division sequence
-  r = fma(fma(-x, r, 1.0), r, r);
+  double r = __builtin_amdgcn_rcp(x);   // hardware estimate (~2^-27 relative) + one Newton step: 2^-53 without the IEEE division sequence
   return fma(fma(-x, r, 1.0), r, r);
+}
+// lane-dependent choice among four registers as a chain of conditional moves (a nested ?: is lowered to exec-mask branches)
+TSL_DEV double ds_sel4(bool k1, bool k2, bool k3, double a0, double a1, double a2, double a3) {
+  double r = a0;
+  r = k1 ? a1 : r;
+  r = k2 ? a2 : r;
+  r = k3 ? a3 : r;
+  return r;
 }
 TSL_DEV void ds_invert_tile_wg(double (*T)[DS_T + 1], int* __restrict__ bad) {
   __shared__ double rowp[2][DS_PB][DS_T], colp[2][DS_PB][DS_T + 1], red[4];
@@ -149,22 +156,28 @@ TSL_DEV void ds_invert_tile_wg(double (*T)[DS_T + 1], int* __restrict__ bad) {
 #pragma unroll
     for (int m = 0; m < DS_PB; m++) rcol[m] = rowp[buf][m][16 * wj + lr];
 #pragma unroll
-    for (int j = 0; j < DS_PB; j++) bj[j] = d[j][0] * rcol[0] + d[j][1] * rcol[1] + d[j][2] * rcol[2] + d[j][3] * rcol[3];
-    const double bop = lk == 0 ? bj[0] : (lk == 1 ? bj[1] : (lk == 2 ? bj[2] : bj[3]));
+    for (int j = 0; j < DS_PB; j++) {
+      bj[j] = d[j][0] * rcol[0] + d[j][1] * rcol[1] + d[j][2] * rcol[2] + d[j][3] * rcol[3];
+      asm volatile("" : "+v"(bj[j]));   // keep the four products out of the lane-dependent selects below (the compiler otherwise sinks them into exec-mask branches)
+    }
+    const bool k1 = lk == 1, k2 = lk == 2, k3 = lk == 3;
+    const double bop = ds_sel4(k1, k2, k3, bj[0], bj[1], bj[2], bj[3]);
     const double aop = -colp[buf][lk][16 * wi + lr];
     const ds_d4 upd = __builtin_amdgcn_mfma_f64_16x16x4f64(aop, bop, acc, 0, 0, 0);   // acc - C (Dinv R)
     // fix-ups: pivot rows become Dinv R (Dinv inside the pivot columns), pivot columns become -C Dinv
     const bool col_in = wj == wp && lr >= lc && lr < lc + DS_PB;
     const int mc = (lr - lc) & 3;   // pivot column index of this lane (meaningful if col_in)
     double dcol[DS_PB];            // column mc of Dinv
+    const bool m1 = mc == 1, m2 = mc == 2, m3 = mc == 3;
 #pragma unroll
-    for (int j = 0; j < DS_PB; j++) dcol[j] = mc == 0 ? d[j][0] : (mc == 1 ? d[j][1] : (mc == 2 ? d[j][2] : d[j][3]));
-    const double dsel = lk == 0 ? dcol[0] : (lk == 1 ? dcol[1] : (lk == 2 ? dcol[2] : dcol[3]));   // Dinv[lk][mc]
+    for (int j = 0; j < DS_PB; j++) dcol[j] = ds_sel4(m1, m2, m3, d[j][0], d[j][1], d[j][2], d[j][3]);
+    const double dsel = ds_sel4(k1, k2, k3, dcol[0], dcol[1], dcol[2], dcol[3]);   // Dinv[lk][mc]
 #pragma unroll
     for (int r = 0; r < 4; r++) {
       const bool row_in = wi == wp && r == rp;   // local row lk + 4 r with r == rp: pivot row j = lk
       const int row = 16 * wi + lk + 4 * r;
-      const double t = colp[buf][0][row] * dcol[0] + colp[buf][1][row] * dcol[1] + colp[buf][2][row] * dcol[2] + colp[buf][3][row] * dcol[3];
+      double t = colp[buf][0][row] * dcol[0] + colp[buf][1][row] * dcol[1] + colp[buf][2][row] * dcol[2] + colp[buf][3][row] * dcol[3];
+      asm volatile("" : "+v"(t));
       const double v_row = col_in ? dsel : bop;
       const double v_else = col_in ? -t : upd[r];
       acc[r] = row_in ? v_row : v_else;
