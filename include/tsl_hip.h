@@ -109,7 +109,8 @@ int tsl_set_stream(tsl_ctx* ctx, void* hip_stream);
  * calls a direct solver): "cg_tol", "cg_maxit", "cg_check", "mg" (-1 auto / 0 / 1), "mg_nu", "mg_coarse_sweeps",
  * "mg_omega", "mg_pi_iters", "mg_fuse", "mg_max_levels", "mg_coarse_exact" (dense inverse of the last multigrid level),
  * "mg_dense_nodes" (largest level solved exactly; -1 = chosen per time step, default), "mg_coarse_lag", "warm_start", "pcg_ahead", "body_inv"
- * "direct" (-1 auto / 0 / 1: multifrontal LU of the operator as preconditioner, on by default for cloth grids of >= 1024 cells),
+ * "direct" (-1 auto / 0 / 1: multifrontal LU of the operator as preconditioner; auto = cloth grids of >= 1024 cells, after a probe of
+ * the iterative hierarchy capped at "direct_probe_cap" iterations failed -- re-probed every "direct_probe_every" time steps),
  * "direct_leaf" (vertices per nested-dissection leaf), "direct_lag" (Newton iterations of a time step reuse earlier factors while the
  * refinement converges within this many iterations; 0 = refactorise for every solve),
  * "mg_fuse_restrict" (first sweep + residual + restriction of a stencil level in one launch), "mg_st_f32" (single-precision stencil

@@ -91,7 +91,9 @@ struct MgCloth {
 
 // sparse direct preconditioner (direct_sym.hpp / direct_plan.hpp / k_direct.hpp): multifrontal LU of the assembled operator
 struct DirectSolver {
-  int enable = -1;          // -1 auto (on when a cloth grid has >= 1024 cells), 0 off, 1 on
+  int enable = -1;          // -1 auto (cloth grids of >= 1024 cells: the iterative hierarchy is probed first, the factorisation takes over when it fails), 0 off, 1 always
+  bool hard = false;        // auto mode: the last probe of the iterative hierarchy failed
+  int hard_steps = 0, probe_cap = 60, probe_every = 16;
   int leaf = 32;            // vertices per leaf of the nested dissection
   bool static_ready = false, numeric_valid = false;
   bool have_factor = false, refactor_next = false;  // factors of the current plan exist (possibly of an earlier operator)
@@ -277,6 +279,7 @@ struct tsl_ctx {
   bool ev_sample_next = false;
 
   DirectSolver ds;
+  bool ds_probe = false;      // set while the iterative hierarchy runs as the capped probe of the auto mode
   bool ds_suspended = false;  // set while the iterative hierarchy runs as the fallback of a failed direct solve
   // stats
   tsl_step_stats step_stats{};

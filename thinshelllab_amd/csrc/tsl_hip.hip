@@ -328,8 +328,10 @@ extern "C" int tsl_set_param(tsl_ctx* c, const char* key, double v) {
   else if (k == "gmres") c->use_gmres = (int)v;
   else if (k == "minres") c->use_minres = (int)v;
   else if (k == "verbose") c->verbose = (int)v;
-  else if (k == "direct") { c->ds.enable = (int)v; c->ds.numeric_valid = false; }
+  else if (k == "direct") { c->ds.enable = (int)v; c->ds.numeric_valid = false; c->ds.hard = false; }
   else if (k == "direct_lag") c->ds.lag = (int)v;
+  else if (k == "direct_probe_cap") c->ds.probe_cap = std::max(1, (int)v);
+  else if (k == "direct_probe_every") c->ds.probe_every = std::max(1, (int)v);
   else if (k == "direct_leaf") { c->ds.leaf = std::max(4, (int)v); c->ds.static_ready = false; c->ds.plan_valid = false; c->ds.numeric_valid = false; }
   else if (k == "fwd_spd_pc") c->fwd_spd_pc = (int)v;
   else if (k == "gmres_m") c->gmres_m = (int)v;
@@ -1004,6 +1006,23 @@ static int solve_perm(tsl_ctx* c, tsl_solve_stats* st) {
     // refinement converges within `lag` iterations (the operator changes little between iterations; a refactorisation costs
     // ~10 applications); the solution is always refined against the CURRENT operator to the same tolerance.
     DirectSolver& d = c->ds;
+    // "direct" = -1 (auto): easy systems stay with the iterative hierarchy -- the contact-free 224 x 224 drape needs 26 multigrid-PCG
+    // iterations per solve (46 ms per step) against one 6 ms factorisation per solve (86 ms per step).  A solve first probes the
+    // hierarchy with a cap of `probe_cap` iterations (the cost of one factorisation); the first failure marks the scene hard and
+    // the following `probe_every` time steps go straight to the factorisation.
+    if (d.enable < 0 && !d.hard) {
+      c->ds_suspended = true; c->ds_probe = true;
+      const int maxit_keep = c->cg_maxit;
+      c->cg_maxit = std::min(c->cg_maxit, d.probe_cap);
+      tsl_solve_stats s2;
+      const int rc = solve_perm(c, &s2);
+      c->cg_maxit = maxit_keep;
+      c->ds_suspended = false; c->ds_probe = false;
+      if (rc) return rc;
+      if (s2.flag == 0) { *st = s2; return 0; }
+      d.hard = true; d.hard_steps = 0;
+      st->iters = s2.iters;   // counted with the solve that follows
+    }
     tsl_solve_stats sd = *st;
     bool stale = false;
     if (!d.numeric_valid) {
@@ -1151,6 +1170,7 @@ static int solve_perm(tsl_ctx* c, tsl_solve_stats* st) {
   st->iters = total_it;
   if (!need_fallback) { st->flag = 0; c->warm_valid = c->in_step; return 0; }
   c->warm_valid = false;
+  if (c->ds_probe) { st->flag = 3; return 0; }   // probe of the iterative hierarchy failed: the caller factorises
   if (mg_active(c) && !indefinite) {
     // multigrid-PCG stalled: retry with plain block-Jacobi PCG (an indefinite H goes straight to BiCGStab)
     c->mg_suspended = true;
@@ -1702,6 +1722,7 @@ extern "C" int tsl_step(tsl_ctx* c, double* pos, double* prev, double* vel, doub
     const double to_900 = cur >= 900 ? 120.0 : 200.0, to_256 = cur >= 256 ? 36.0 : 60.0;
     c->mg_dense_nodes = it > to_900 ? 900 : it > to_256 ? 256 : 64;
   }
+  if (c->ds.hard && ++c->ds.hard_steps > c->ds.probe_every) c->ds.hard = false;   // probe the iterative hierarchy again
   c->bd_valid = false;  // dense body inverses are rebuilt once per step (first solve) and lagged over its Newton iterations
   // timestep_init: prev_pos <- pos (BaseScene.py:1291-1303)
   HIP_OK(hipMemcpyAsync(prev, pos, n3 * sizeof(double), hipMemcpyDeviceToDevice, s));
@@ -2063,7 +2084,8 @@ extern "C" int tsl_adjoint_step(tsl_ctx* c, int step, int T, const double* pos_b
   // preconditioner from the SPD-projected Hessian of the same state (block Jacobi + multigrid hierarchy): the operator
   // below is the un-projected H, which may be indefinite, and smoothers / coarse operators built from it are not safe
   const bool have_mg = !c->mg.empty() && c->mg_enable != 0;
-  const bool spd_pc = c->adj_spd_pc && (have_mg || body_active(c)) && !direct_enabled(c);  // the direct path factorises the un-projected operator itself
+  // the direct path factorises the un-projected operator itself; its auto mode may still probe the hierarchy first (not marked hard)
+  const bool spd_pc = c->adj_spd_pc && (have_mg || body_active(c)) && !(direct_enabled(c) && (c->ds.enable == 1 || c->ds.hard));
   c->bd_valid = false;
   c->mg_omega_valid = false; c->mg_cinv_valid = false;
   if (spd_pc) {
