@@ -65,13 +65,16 @@ def build_scene(args, rank, grid=None, cloth_size=None):
     return s
 
 
-def _drive(n_part, gs, rank):
-    """gripper drive.  cfg4: the active phase of SURVEY section 8d's trajectory, +-z 1e-4 m per step on the two paired grippers
-    (the balancing task tilts the cloth).  cfg4-scaled: both grippers rise and tilt a little every step.  The rank only changes
-    the amplitude by 1 %, so the ranks run different but equally expensive rollouts."""
+def _drive(n_part, gs, rank, frame=1, idle=0):
+    """gripper drive of global time step `frame` (1-based, warm-up included).  cfg4: SURVEY section 8d's trajectory -- `idle` steps
+    of zero trajectory (--idle, default 0: every timed step is an active one), then +-z 1e-4 m per step on the two paired grippers,
+    opposite signs (the balancing task tilts the cloth).  cfg4-scaled: both grippers rise and tilt a little every step.  The rank
+    only changes the amplitude by 1 %, so the ranks run different but equally expensive rollouts."""
     import numpy as np
     a = 1.0 + 0.01 * rank
     dpos = np.zeros((n_part, 3)); drot = np.zeros((n_part, 3))
+    if frame <= idle:
+        return dpos, drot
     if gs == 1.0:
         dpos[:, 2] = 1e-4 * a * np.where(np.arange(n_part) % 2 == 0, 1.0, -1.0)
     else:
@@ -91,7 +94,8 @@ def run_rollout(scene, grad, K, args):
     grad.copy_pos(scene, 0)
     for f in range(1, K + 1):
         if contact is not None:
-            scene.action(f, *_drive(scene.gripper.n_part, scene._bench_gs, scene._bench_rank))
+            scene._bench_frame = getattr(scene, "_bench_frame", 0) + 1
+            scene.action(f, *_drive(scene.gripper.n_part, scene._bench_gs, scene._bench_rank, scene._bench_frame, args.idle))
         st = scene.time_step(contact, f)
         grad.copy_pos(scene, f)
         S["newton"] += st["newton_iters"]; S["it_fwd"] += st["cg_iters"]; S["ls"] += st["ls_evals"]; S["nc"] += st.get("nc", 0)
@@ -140,7 +144,7 @@ def cpu_baseline(args, scene, gpu_stats, K, rank):
         tc0 = time.time()
         o.grad_copy_pos(0)
         for f in range(1, Kc + 1):
-            o.action(*_drive(n_part, small._bench_gs, rank))
+            o.action(*_drive(n_part, small._bench_gs, rank, f))
             o.time_step()
             o.grad_copy_pos(f)
         pg = o.arr("grad.pos_grad", (Kc + 1, -1, 3))
@@ -269,6 +273,7 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=10)
     ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--idle", type=int, default=0, help="cfg4: leading steps with the zero trajectory (SURVEY section 8d: 10 of T = 50); default 0, every step active")
     ap.add_argument("--workload", choices=["cfg4", "cfg4-scaled", "drape"], default="cfg4",
                     help="cfg4: cloth on ball + 4 tactile pads with contact, cloth_size 0.12 m (the configuration the metric is quoted on); "
                          "cfg4-scaled: same scene enlarged so that the cloth keeps its native 4 mm spacing; drape: contact-free pinned cloth")
@@ -336,7 +341,7 @@ def main():
         "dtype": "f64", "data": "synthetic",
         "config": {"workload": (f"cfg4 (SURVEY.md section 8d): Scene_balancing topology, {args.grid}x{args.grid} cloth ({T} triangles, cloth_size "
                                 f"{0.12 * args.grid / 224:.3f} m, dx {0.12 / 224:.2e} m) on the ball + 4 tactile pads at their native poses, paired grippers driven "
-                                f"+-1e-4 m in z every step, loss get_loss_balance; "
+                                f"+-1e-4 m in z every step" + (f" after {args.idle} idle steps" if args.idle else "") + ", loss get_loss_balance; "
                                 if args.workload == "cfg4" else
                                 f"cfg4-scaled: Scene_balancing (cloth on ball + 4 tactile pads, paired grippers driven every step) with a {args.grid}x{args.grid} cloth "
                                 f"({T} triangles) and the whole scene enlarged x{args.grid * 0.004 / 0.06:.2f} so that the cloth keeps its native 4 mm spacing; "

@@ -112,7 +112,8 @@ int tsl_set_stream(tsl_ctx* ctx, void* hip_stream);
  * "direct" (-1 auto / 0 / 1: multifrontal LU of the operator as preconditioner; auto = cloth grids of >= 1024 cells, after a probe of
  * the iterative hierarchy capped at "direct_probe_cap" iterations failed -- re-probed every "direct_probe_every" time steps),
  * "direct_leaf" (vertices per nested-dissection leaf), "direct_lag" (Newton iterations of a time step reuse earlier factors while the
- * refinement converges within this many iterations; 0 = refactorise for every solve),
+ * refinement converges within this many iterations; 0 = refactorise for every solve), "direct_fallback_cap" (a refined factorisation
+ * that stalls within 1e-3 of the right-hand side is returned flagged not converged; above that the hierarchy gets this many iterations),
  * "mg_fuse_restrict" (first sweep + residual + restriction of a stencil level in one launch), "mg_st_f32" (single-precision stencil
  * operators), "mg_fr_rows", "pcg_body_fold" (dense-body first sweep inside the PCG update launch), "asm_overlap" (contact blocks on a
  * second stream), "mr_eta" (stop factor of a MINRES recurrence cycle), "mg_chunk" (multigrid-PCG iterations per graph replay; 0 = 8 on long solves, else 4),

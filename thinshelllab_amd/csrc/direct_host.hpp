@@ -37,7 +37,7 @@ static bool direct_enabled(tsl_ctx* c) {
 static DsDev ds_dev(tsl_ctx* c) {
   DirectSolver& d = c->ds;
   DsDev D;
-  D.fr = d.fr.p; D.level_sn = d.level_sn.p; D.A = d.arena.p; D.G = d.garena.p; D.scr = d.scr.p; D.rel = d.rel.p; D.vtx = d.vtx.p; D.bad = d.bad.p;
+  D.fr = d.fr.p; D.level_sn = d.level_sn.p; D.A = d.arena.p; D.G = d.garena.p; D.scr = d.scr.p; D.rel = d.rel.p; D.vtx = d.vtx.p; D.bad = d.bad.p; D.dbg = d.dbg; D.piv_tol = d.piv_tol;
   return D;
 }
 
@@ -62,7 +62,7 @@ static int direct_static(tsl_ctx* c) {
     for (int k = 0; k < (int)c->h_rows[v].size(); k++) c2s[d.row_ptr[v] + k] = (int)(((long)c->h_slice_off[s] + 64L * k) * 9 + lane);
   }
   if (d.csr2sell.upload(c2s)) return -1;
-  if (d.bad.alloc(4)) return -1;
+  if (d.bad.alloc(8 + 4 * DS_BADLOG)) return -1;
   HIP_OK(hipFuncSetAttribute((const void*)k_ds_inv_small, hipFuncAttributeMaxDynamicSharedMemorySize, (int)ds_small_lds(DS_SMALL)));
   d.plan.sym.build_partition(NV, c->h_rows, d.grids, d.blocks, d.leaf);
   d.static_ready = true;
@@ -114,7 +114,7 @@ static int direct_plan(tsl_ctx* c) {
 }
 
 // numeric factorisation of the operator of the last assemble (c->vals + masked contact blocks c->c_H)
-static int direct_factor(tsl_ctx* c) {
+static int direct_factor(tsl_ctx* c, int stop_sn = -1, const char* dump_path = nullptr) {
   DirectSolver& d = c->ds;
   hipStream_t s = c->stream;
   TSL_TRY(direct_plan(c));
@@ -122,7 +122,7 @@ static int direct_factor(tsl_ctx* c) {
   const DirectPlan& P = d.plan;
   const DsDev D = ds_dev(c);
   HIP_OK(hipMemsetAsync(d.arena.p, 0, (size_t)P.arena * sizeof(double), s));
-  HIP_OK(hipMemsetAsync(d.bad.p, 0, 4 * sizeof(int), s));
+  HIP_OK(hipMemsetAsync(d.bad.p, 0, 8 * sizeof(int), s));
   const long nnzb = d.row_ptr[c->NV];
   hipLaunchKernelGGL(k_ds_assemble_blocks, dim3(ds_nblk(nnzb * 9, 256)), dim3(256), 0, s, nnzb, d.csr2sell.p, c->vals.p, d.blk_dst.p, d.blk_ld.p, d.arena.p);
   if (c->nc > 0) hipLaunchKernelGGL(k_ds_assemble_contacts, dim3(ds_nblk((long)c->nc * 144, 256)), dim3(256), 0, s, c->nc, c->c_H.p, d.con_dst.p, d.con_ld.p, d.arena.p);
@@ -130,6 +130,25 @@ static int direct_factor(tsl_ctx* c) {
   for (const DsBatch& b : P.batches) {
     const int lv0 = b.first, nf = b.count;
     const int tp = b.max_pp / DS_T, tb = b.max_bp / DS_T;
+    if (stop_sn >= 0) {   // diagnostic: the assembled front stop_sn (children added, not yet factorised) -> file
+      bool here = false;
+      for (int q = lv0; q < lv0 + nf; q++) here |= P.level_sn[q] == stop_sn;
+      if (here) {
+        const DsFrontDesc& f = P.fr[stop_sn];
+        std::vector<double> h((size_t)f.pp * f.ld);
+        HIP_OK(hipStreamSynchronize(s));
+        HIP_OK(hipMemcpy(h.data(), d.arena.p + f.off, h.size() * sizeof(double), hipMemcpyDeviceToHost));
+        if (FILE* fp = fopen(dump_path, "wb")) {
+          const int hdr[8] = {f.p, f.pp, f.b, f.bp, f.ld, f.nv_own, f.nv_bnd, 0};
+          fwrite(hdr, sizeof(int), 8, fp);
+          fwrite(&P.vtx[f.vtx_off], sizeof(int), (size_t)f.nv_own + f.nv_bnd, fp);
+          fwrite(h.data(), sizeof(double), h.size(), fp);
+          fclose(fp);
+        }
+        d.numeric_valid = false; d.have_factor = false;
+        return 0;
+      }
+    }
     if (ds_use_small(b)) hipLaunchKernelGGL(k_ds_inv_small, dim3(nf), dim3(256), ds_small_lds(b.max_pp), s, D, lv0, b.max_pp + 1);
     else {
       hipLaunchKernelGGL(k_ds_pivot0, dim3(nf), dim3(256), 0, s, D, lv0);

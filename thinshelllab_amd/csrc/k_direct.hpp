@@ -25,7 +25,9 @@ struct DsDev {                 // device views shared by the kernels
   double* scr;                 // per-level scratch (pivot-block inverses, row panel, column panel per front)
   const int* rel;
   const int* vtx;              // local vertex -> PERMUTED vertex position (rows of the solver vectors)
-  int* bad;                    // [0]: number of perturbed pivots of the last factorisation
+  int* bad;                    // [1..3]: perturbed pivots of the last factorisation by front size class, [4] + [8..]: log of the first ones
+  double piv_tol;              // a pivot below piv_tol x its own scale is replaced by that bound
+  int dbg;                     // timing experiments only ("ds_dbg"): 1 = the block-step kernel skips the pivot-tile inversion
 };
 
 // infinity norm of the SELL-64 matrix (largest absolute row sum), the yardstick of the solve's backward error; out must be zeroed
@@ -87,9 +89,13 @@ __global__ void k_ds_pad_diag(int n_sn, const DsFrontDesc* __restrict__ fr, doub
 // the 4 x 4 pivot block itself.  Eight dependent steps instead of 32 scalar pivots: the tile inversion sits on the critical path
 // of every block step of the factorisation (measured inside a kernel: 10.7 us for the scalar-pivot version -- one LDS round
 // trip, one reciprocal and a chain of selects per pivot -- and for a 4 x 4-block version on the vector units alike).
-// Scalar pivots below 1e-13 of the tile's largest entry are replaced by that bound (counted in bad[0]).  All 256 threads must call
+// Static pivoting: a scalar pivot that fell below tol (DsDev.piv_tol, 1e-8) x its own scale -- the diagonal entry the tile came in
+// with -- is replaced by that bound and counted in bad[cls]; the refinement outside absorbs the perturbation.  (NOT measured against
+// the largest entry of the tile: contact blocks on degenerate triangles put 1e13 next to the m/dt^2 = 0.3 of a frozen dof, both exact.)  All 256 threads must call
 // it; the tile is complete in LDS on return (the function ends with a barrier).
 #define DS_PB 4
+#define DS_BADLOG 64
+#define DS_CLS(f) ((f).pp > 512 ? 3 : ((f).pp > 128 ? 2 : 1))
 TSL_DEV double ds_rcp(double x) {
   double r = __builtin_amdgcn_rcp(x);   // hardware estimate (~2^-27 relative) + one Newton step: 2^-53 without the IEEE division sequence
   return fma(fma(-x, r, 1.0), r, r);
@@ -102,18 +108,28 @@ TSL_DEV double ds_sel4(bool k1, bool k2, bool k3, double a0, double a1, double a
   r = k3 ? a3 : r;
   return r;
 }
-TSL_DEV void ds_invert_tile_wg(double (*T)[DS_T + 1], int* __restrict__ bad) {
-  __shared__ double rowp[2][DS_PB][DS_T], colp[2][DS_PB][DS_T + 1], red[4];
+TSL_DEV double ds_readlane_d(double v, int l) {
+  const int lo = __builtin_amdgcn_readlane(__double2loint(v), l), hi = __builtin_amdgcn_readlane(__double2hiint(v), l);
+  return __hiloint2double(hi, lo);
+}
+TSL_DEV void ds_invert_tile_wg(double (*T)[DS_T + 1], int* __restrict__ bad, int cls, int tag, double tol) {
+  __shared__ double rowp[2][DS_PB][DS_T], colp[2][DS_PB][DS_T + 1], red[4], dg0[DS_T];
   const int lane = threadIdx.x & 63, w = threadIdx.x >> 6, wi = w >> 1, wj = w & 1, lr = lane & 15, lk = lane >> 4;
   ds_d4 acc;
   double amax = 0.0;
 #pragma unroll
-  for (int r = 0; r < 4; r++) { acc[r] = T[16 * wi + lk + 4 * r][16 * wj + lr]; amax = fmax(amax, fabs(acc[r])); }
+  for (int r = 0; r < 4; r++) {
+    acc[r] = T[16 * wi + lk + 4 * r][16 * wj + lr];
+    amax = fmax(amax, fabs(acc[r]));
+    if (wi == wj && lk + 4 * r == lr) dg0[16 * wi + lr] = fabs(acc[r]);   // the diagonal on entry: the scale a pivot is measured against
+  }
   amax = wave_max(amax);
   if (lane == 0) red[w] = amax;
   __syncthreads();
-  const double tiny = fmax(fmax(fmax(red[0], red[1]), fmax(red[2], red[3])) * 1e-13, 1e-300);
-  int nbad = 0;
+  const double tmax = fmax(fmax(red[0], red[1]), fmax(red[2], red[3]));
+  const double floor0 = fmax(tmax * 1e-20, 1e-300);
+  const double mydg = dg0[lane & 31];   // lane l keeps entry diagonal l: the pivot loop fetches its four with v_readlane (no LDS traffic, two registers)
+  unsigned badmask = 0;   // perturbed pivots of the tile
 #pragma unroll
   for (int s = 0; s < DS_T / DS_PB; s++) {
     const int buf = s & 1, p0 = DS_PB * s;
@@ -134,12 +150,16 @@ TSL_DEV void ds_invert_tile_wg(double (*T)[DS_T + 1], int* __restrict__ bad) {
     for (int i = 0; i < DS_PB; i++)
 #pragma unroll
       for (int j = 0; j < DS_PB; j++) d[i][j] = rowp[buf][i][p0 + j];
+    double thr[DS_PB];
+#pragma unroll
+    for (int p = 0; p < DS_PB; p++) thr[p] = fmax(tol * ds_readlane_d(mydg, p0 + p), floor0);
 #pragma unroll
     for (int p = 0; p < DS_PB; p++) {
       const double piv0 = d[p][p];
+      const double tiny = thr[p];
       const bool small = !(fabs(piv0) >= tiny);
       const double piv = small ? copysign(tiny, piv0) : piv0;
-      nbad += small ? 1 : 0;
+      badmask |= small ? (1u << (p0 + p)) : 0u;
       const double ip = ds_rcp(piv);
 #pragma unroll
       for (int j = 0; j < DS_PB; j++) d[p][j] = (j == p) ? ip : d[p][j] * ip;
@@ -185,7 +205,11 @@ TSL_DEV void ds_invert_tile_wg(double (*T)[DS_T + 1], int* __restrict__ bad) {
   }
 #pragma unroll
   for (int r = 0; r < 4; r++) T[16 * wi + lk + 4 * r][16 * wj + lr] = acc[r];
-  if (threadIdx.x == 0 && nbad) atomicAdd(bad, nbad);
+  if (threadIdx.x == 0 && badmask) {
+    atomicAdd(bad + cls, __popc(badmask));
+    const int slot = atomicAdd(bad + 4, 1);   // log of the first perturbed tiles (verbose >= 2)
+    if (slot < DS_BADLOG) { int* L = bad + 8 + 4 * slot; L[0] = tag; L[1] = (int)badmask; L[2] = 0; L[3] = __float_as_int((float)tmax); }
+  }
   __syncthreads();
 }
 
@@ -204,7 +228,7 @@ __global__ void __launch_bounds__(256) k_ds_pivot0(DsDev D, int lv0) {
 #pragma unroll
   for (int q = 0; q < 4; q++) T[ty + 8 * q][tx] = A[(size_t)(ty + 8 * q) * f.ld + tx];
   __syncthreads();
-  ds_invert_tile_wg(T, D.bad);
+  ds_invert_tile_wg(T, D.bad, DS_CLS(f), D.level_sn[lv0 + blockIdx.x] << 6, D.piv_tol);
   double* P = ds_scr_P(D, f, 0);
 #pragma unroll
   for (int q = 0; q < 4; q++) P[(ty + 8 * q) * DS_T + tx] = T[ty + 8 * q][tx];
@@ -299,7 +323,7 @@ __global__ void __launch_bounds__(256) k_ds_gj_step(DsDev D, int lv0, int k) {
   }
   if (next_pivot) {
     __syncthreads();
-    ds_invert_tile_wg(T2, D.bad);
+    if (D.dbg != 1) ds_invert_tile_wg(T2, D.bad, DS_CLS(f), (D.level_sn[lv0 + blockIdx.z] << 6) | (k + 1), D.piv_tol);
     double* Pn = ds_scr_P(D, f, (k + 1) & 1);
 #pragma unroll
     for (int q = 0; q < 4; q++) Pn[(ty + 8 * q) * DS_T + tx] = T2[ty + 8 * q][tx];
@@ -344,7 +368,7 @@ __global__ void __launch_bounds__(256) k_ds_inv_small(DsDev D, int lv0, int ls) 
 #pragma unroll
     for (int q = 0; q < 4; q++) Tt[ty + 8 * q][tx] = M[(k0 + ty + 8 * q) * ls + k0 + tx];
     __syncthreads();
-    ds_invert_tile_wg(Tt, D.bad);
+    ds_invert_tile_wg(Tt, D.bad, 1, (D.level_sn[lv0 + blockIdx.x] << 6) | k, D.piv_tol);
     // R'_j = P A_Kj in place (a wave owns whole tiles: all its reads of a tile precede its writes)
     for (int j = w; j < nt; j += 4) {
       if (j == k) continue;

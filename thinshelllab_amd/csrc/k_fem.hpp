@@ -88,14 +88,17 @@ __global__ void k_tet_grad(TetArgs A, const double* __restrict__ pos, double* __
   int v[4]; m3 B;
   const m3 F = tet_F(A, t, pos, v, B);
   const ElasticDev e = A.el[A.tel[t]];
-  const m3 FiT = m3_T(m3_inv(F));
   m3 P;
   if (e.kind == 0) {
+    // P = mu F + lam (J - alpha) J F^-T with J F^-T taken as the cofactor matrix: the same polynomial in F, without the division
+    // by a determinant that passes through zero when a pad element is crushed flat (the energy is finite there)
     const double J = m3_det(F);
-    const double s = e.lam * (J - e.alpha) * J;
+    const m3 C = m3_cof2(F, F);
+    const double s = e.lam * (J - e.alpha);
 #pragma unroll
-    for (int k = 0; k < 9; k++) P.m[k] = e.mu * F.m[k] + s * FiT.m[k];
+    for (int k = 0; k < 9; k++) P.m[k] = e.mu * F.m[k] + s * C.m[k];
   } else {
+    const m3 FiT = m3_T(m3_inv(F));
     const double J = fmax(m3_det(F), 0.01);
     const double s = e.lam * log(J);
 #pragma unroll
@@ -131,11 +134,10 @@ __global__ void k_tet_deri_mu(TetArgs A, const double* __restrict__ pos, double*
   int v[4]; m3 B;
   const m3 F = tet_F(A, t, pos, v, B);
   const ElasticDev e = A.el[A.tel[t]];
-  const m3 FiT = m3_T(m3_inv(F));
-  const double J = (e.kind == 0) ? m3_det(F) : 1.0;
+  const m3 JFiT = (e.kind == 0) ? m3_cof2(F, F) : m3_T(m3_inv(F));   // J F^-T as the cofactor matrix (tactile) / F^-T (J = 1 in the formula of the box model)
   m3 P;
 #pragma unroll
-  for (int k = 0; k < 9; k++) P.m[k] = F.m[k] - J * FiT.m[k];
+  for (int k = 0; k < 9; k++) P.m[k] = F.m[k] - JFiT.m[k];
   const m3 Hm = m3_mul(P, m3_T(B));
   const double W = A.W[t];
   double* out = (e.kind == 0) ? d_tact : d_accum;
@@ -152,17 +154,25 @@ __global__ void k_tet_deri_mu(TetArgs A, const double* __restrict__ pos, double*
 // dP(dF) for the two materials (energy Hessian direction), returns dE-Hessian column block dH = W * dP * B^T
 TSL_DEV m3 tet_dH(const ElasticDev& e, const m3& F, const m3& Fi, const m3& FiT, double J, double logJ, const m3& dF, const m3& BT, double W) {
   m3 dP;
-  // tr(F^-1 dF)
-  const m3 FidF = m3_mul(Fi, dF);
-  const double dTr = FidF.m[0] + FidF.m[4] + FidF.m[8];
-  const m3 X = m3_mul(m3_mul(FiT, m3_T(dF)), FiT);  // F^-T dF^T F^-T
   if (e.kind == 0) {
-    // P = mu F + lam (J - alpha) J F^-T  (model_elastic_tactile.py:104-107 with the sign folded in)
-    const double a = e.lam * (2.0 * J * J - e.alpha * J) * dTr;
-    const double b = e.lam * (J - e.alpha) * J;
+    // P = mu F + lam (J - alpha) C, C = J F^-T = cof F  (model_elastic_tactile.py:104-107 with the sign folded in).  The reference
+    // writes dP = mu dF + lam (2 J^2 - alpha J) tr(F^-1 dF) F^-T - lam (J - alpha) J F^-T dF^T F^-T; with dJ = C : dF = J tr(F^-1 dF)
+    // and dC = (dJ C - C dF^T C) / J that is dP = mu dF + lam dJ C + lam (J - alpha) dC -- the same polynomial, evaluated here
+    // from cofactors (Fi, FiT unused): the two 1 / J terms of the reference's form cancel only analytically, and pad elements
+    // do pass through J = 0 late in the cfg4 rollout (entries of 1e15 in the operator before this form).
+    const m3 C = m3_cof2(F, F);
+    const m3 dC1 = m3_cof2(F, dF), dC2 = m3_cof2(dF, F);
+    double dJ = 0;
 #pragma unroll
-    for (int k = 0; k < 9; k++) dP.m[k] = e.mu * dF.m[k] + a * FiT.m[k] - b * X.m[k];
+    for (int k = 0; k < 9; k++) dJ += C.m[k] * dF.m[k];
+    const double a = e.lam * dJ, b = e.lam * (J - e.alpha);
+#pragma unroll
+    for (int k = 0; k < 9; k++) dP.m[k] = e.mu * dF.m[k] + a * C.m[k] + b * (dC1.m[k] + dC2.m[k]);
   } else {
+    // tr(F^-1 dF)
+    const m3 FidF = m3_mul(Fi, dF);
+    const double dTr = FidF.m[0] + FidF.m[4] + FidF.m[8];
+    const m3 X = m3_mul(m3_mul(FiT, m3_T(dF)), FiT);  // F^-T dF^T F^-T
     // P = mu (F - F^-T) + lam log J F^-T  (model_elastic_offset.py:141-142)
 #pragma unroll
     for (int k = 0; k < 9; k++) dP.m[k] = e.mu * dF.m[k] + (e.mu - e.lam * logJ) * X.m[k] + e.lam * dTr * FiT.m[k];
@@ -182,7 +192,7 @@ k_tet_hess(TetArgs A, const int* __restrict__ blk, const double* __restrict__ po
   int v[4]; m3 B;
   const m3 F = tet_F(A, t, pos, v, B);
   const ElasticDev e = A.el[A.tel[t]];
-  const m3 Fi = m3_inv(F), FiT = m3_T(Fi), BT = m3_T(B);
+  const m3 Fi = (e.kind == 0) ? F : m3_inv(F), FiT = m3_T(Fi), BT = m3_T(B);   // the tactile material works from cofactors (tet_dH)
   const double W = A.W[t];
   const double Jraw = m3_det(F);
   const double J = (e.kind == 0) ? Jraw : fmax(Jraw, 0.01);

@@ -70,6 +70,22 @@ TSL_HD m3 m3_inv(const m3& a) {
   r.m[8] = (a.m[0] * a.m[4] - a.m[1] * a.m[3]) / d;
   return r;
 }
+// cofactor products: m3_cof2(a, b)[i][j] = the 2 x 2 minor products of cof with the first factor taken from a and the second from b;
+// cof(F) = det(F) F^-T = m3_cof2(F, F), and its differential in the direction dF is m3_cof2(F, dF) + m3_cof2(dF, F) (no division:
+// exact where det F passes through zero, which F^-1 is not)
+TSL_HD m3 m3_cof2(const m3& a, const m3& b) {
+  m3 r;
+  r.m[0] = a.m[4] * b.m[8] - a.m[5] * b.m[7];
+  r.m[1] = a.m[5] * b.m[6] - a.m[3] * b.m[8];
+  r.m[2] = a.m[3] * b.m[7] - a.m[4] * b.m[6];
+  r.m[3] = a.m[2] * b.m[7] - a.m[1] * b.m[8];
+  r.m[4] = a.m[0] * b.m[8] - a.m[2] * b.m[6];
+  r.m[5] = a.m[1] * b.m[6] - a.m[0] * b.m[7];
+  r.m[6] = a.m[1] * b.m[5] - a.m[2] * b.m[4];
+  r.m[7] = a.m[2] * b.m[3] - a.m[0] * b.m[5];
+  r.m[8] = a.m[0] * b.m[4] - a.m[1] * b.m[3];
+  return r;
+}
 TSL_HD d3 m3_mulv(const m3& a, const d3& v) {
   return d3(a.m[0] * v.x + a.m[1] * v.y + a.m[2] * v.z, a.m[3] * v.x + a.m[4] * v.y + a.m[5] * v.z, a.m[6] * v.x + a.m[7] * v.y + a.m[8] * v.z);
 }

@@ -330,6 +330,9 @@ extern "C" int tsl_set_param(tsl_ctx* c, const char* key, double v) {
   else if (k == "verbose") c->verbose = (int)v;
   else if (k == "direct") { c->ds.enable = (int)v; c->ds.numeric_valid = false; c->ds.hard = false; }
   else if (k == "direct_lag") c->ds.lag = (int)v;
+  else if (k == "ds_dbg") c->ds.dbg = (int)v;
+  else if (k == "direct_fallback_cap") c->ds.fallback_cap = (int)v;
+  else if (k == "direct_piv_tol") { c->ds.piv_tol = v; c->ds.numeric_valid = false; }
   else if (k == "direct_probe_cap") c->ds.probe_cap = std::max(1, (int)v);
   else if (k == "direct_probe_every") c->ds.probe_every = std::max(1, (int)v);
   else if (k == "direct_leaf") { c->ds.leaf = std::max(4, (int)v); c->ds.static_ready = false; c->ds.plan_valid = false; c->ds.numeric_valid = false; }
@@ -1046,11 +1049,44 @@ static int solve_perm(tsl_ctx* c, tsl_solve_stats* st) {
       }
     }
     if (sd.flag == 1) { *st = sd; st->flag = 0; st->method = 4; return 0; }
-    if (c->verbose) fprintf(stderr, "[tsl] direct factorisation + GMRES did not converge (rel_residual %.2e after %d iterations): iterative fallback\n", sd.rel_residual, sd.iters);
+    if (c->verbose) {
+      int nb[4] = {0, 0, 0, 0};
+      (void)hipMemcpy(nb, d.bad.p, sizeof(nb), hipMemcpyDeviceToHost);
+      fprintf(stderr, "[tsl] direct factorisation + GMRES did not converge (rel_residual %.2e, backward error %.2e after %d iterations, perturbed pivots %d / %d / %d in fronts of <= 128 / <= 512 / more pivots, nc %d): iterative fallback\n",
+              sd.rel_residual, sd.backward_error, sd.iters, nb[1], nb[2], nb[3], c->nc);
+      if (c->verbose > 1) {
+        std::vector<int> lg(8 + 4 * DS_BADLOG);
+        (void)hipMemcpy(lg.data(), d.bad.p, lg.size() * sizeof(int), hipMemcpyDeviceToHost);
+        const int nl = std::min(lg[4], DS_BADLOG);
+        static int n_dump = 0;
+        if (const char* dir = getenv("TSL_DUMP_DIR")) if (nl > 0 && n_dump < 3) {
+          char path[512];
+          snprintf(path, sizeof(path), "%s/front_%d.bin", dir, n_dump++);
+          d.numeric_valid = false;
+          TSL_TRY(direct_factor(c, lg[8] >> 6, path));
+        }
+        for (int i = 0; i < nl; i++) {
+          const int* L = &lg[8 + 4 * i];
+          const int sn = L[0] >> 6, kt = L[0] & 63;
+          const DsFrontDesc& f = d.plan.fr[sn];
+          float am; memcpy(&am, L + 3, 4);
+          const unsigned mask = (unsigned)L[1];
+          const int first = __builtin_ctz(mask | 0x80000000u), row = kt * DS_T + first;
+          const int vtx = row < f.p ? d.plan.vtx[f.vtx_off + row / 3] : -1;
+          fprintf(stderr, "[tsl]   perturbed pivots: front %d (level %d, p %d, b %d, own verts %d) tile %d rows mask %08x, first row %d (vertex %d dof %d%s), tile max %.3e\n",
+                  sn, d.plan.sym.level[sn], f.p, f.b, f.nv_own, kt, mask, row, vtx, row % 3, vtx >= 0 && d.plan.sym.body_of[vtx] >= 0 ? ", body" : "", am);
+        }
+      }
+    }
+    // Where the refined factorisation stalls, the iterative hierarchy does not do better (it needs 1e4..1e5 iterations on the
+    // systems the factorisation is for, and the stalls seen are operators with entries of 1e15 beside 1e3 -- an element of a pad
+    // crushed flat late in a rollout): an answer within 1e-3 is returned as it is, flagged not converged; only a broken
+    // factorisation (residual above that) is worth a bounded attempt of the hierarchy.
+    if (sd.rel_residual <= 1e-3) { *st = sd; st->flag = 3; st->method = 4; return 0; }
     c->ds_suspended = true;
     tsl_solve_stats s2;
     const int maxit_keep = c->cg_maxit;
-    c->cg_maxit = std::min(c->cg_maxit, 20000);  // the hierarchy needs 1e4..1e5 iterations on the systems the factorisation is for
+    c->cg_maxit = std::min(c->cg_maxit, d.fallback_cap);
     HIP_OK(hipMemcpyAsync(c->v_t4.p, c->v_x.p, 3 * (size_t)c->NV * sizeof(double), hipMemcpyDeviceToDevice, c->stream));  // the refined direct solution
     const int rc = solve_perm(c, &s2);
     c->cg_maxit = maxit_keep;
@@ -1481,11 +1517,12 @@ static int gmres(tsl_ctx* c, tsl_solve_stats* st, bool direct) {
       // Attainable accuracy of a factorisation-based solve: the reference's spsolve returns a backward-stable solution, i.e. a
       // residual of the order eps |H| |x|, which on the near-singular adjoint operators of a long rollout (|H| |x| / |b| up to
       // 1e9) is ABOVE cg_tol |b|.  When refinement no longer halves the true residual the normwise backward error
-      // |b - Hx| / (|H|_inf |x| + |b|) decides: below 1e-13 the solution is what a direct solver delivers (reported as attained).
+      // |b - Hx| / (|H|_inf |x| + |b|) decides: below 1e-12 (a few thousand eps, the n eps growth bound of a pivoted sparse LU in
+      // practice) the solution is what a direct solver delivers (reported as attained).
       double xx;
       TSL_TRY(norm2(x, &xx));
       st->backward_error = beta / (c->ds.anorm * sqrt(xx) + sqrt(bb));
-      if (cycle > 0 && beta > 0.5 * beta_prev && st->backward_error <= 1e-13) { st->flag = 1; st->attained = 1; break; }
+      if (cycle > 0 && beta > 0.5 * beta_prev && st->backward_error <= 1e-12) { st->flag = 1; st->attained = 1; break; }
       if (cycle >= 8) break;
     } else {
       // attainable accuracy (same rule as the PCG restarts)
@@ -1953,7 +1990,7 @@ extern "C" int tsl_direct_info(tsl_ctx* c, double* out10) {
   const DirectSolver& d = c->ds;
   int bad[4] = {0, 0, 0, 0};
   if (d.bad.p) HIP_OK(hipMemcpy(bad, d.bad.p, sizeof(bad), hipMemcpyDeviceToHost));
-  out10[0] = (double)d.n_plans; out10[1] = (double)d.n_factor; out10[2] = (double)d.n_apply; out10[3] = bad[0]; out10[4] = d.t_plan;
+  out10[0] = (double)d.n_plans; out10[1] = (double)d.n_factor; out10[2] = (double)d.n_apply; out10[3] = bad[1] + bad[2] + bad[3]; out10[4] = d.t_plan;
   out10[5] = d.plan_valid ? d.plan.sym.n_sn : 0; out10[6] = d.plan_valid ? d.plan.n_levels : 0; out10[7] = d.plan_valid ? (double)d.plan.batches.size() : 0;
   out10[8] = d.plan_valid ? d.plan.flops : 0; out10[9] = d.plan_valid ? 8.0 * (double)d.plan.arena : 0;
   return 0;
