@@ -223,7 +223,10 @@ static int direct_bench(tsl_ctx* c, int cls, int reps, double* out) {
       if (count) for (const DsFrontDesc& f : P.fr) { bytes += 8.0 * ((double)f.p * f.p + 2.0 * (double)f.p * f.b); flops += 2.0 * ((double)f.p * f.p + 2.0 * (double)f.p * f.b); }
       return;
     }
+    int bi = -1;
     for (const DsBatch& b : P.batches) {
+      bi++;
+      if (d.bench_batch >= 0 && bi != d.bench_batch) continue;   // "ds_bench_batch": one batch only (scripts/exp_batches.py)
       const int lv0 = b.first, nf = b.count;
       const int tp = b.max_pp / DS_T, tb = b.max_bp / DS_T;
       if (cls == 0) {   // W = F11^-1: the LDS kernel or pivot0 + block steps + finish

@@ -94,9 +94,10 @@ struct DirectSolver {
   int enable = -1;          // -1 auto (cloth grids of >= 1024 cells: the iterative hierarchy is probed first, the factorisation takes over when it fails), 0 off, 1 always
   bool hard = false;        // auto mode: the last probe of the iterative hierarchy failed
   int hard_steps = 0, probe_cap = 60, probe_every = 16;
+  int bench_batch = -1;     // tsl_bench_direct: restrict the replay to one batch (-1: all)
   double piv_tol = 1e-8;    // static pivoting: pivots below piv_tol x their own scale are perturbed to that bound ("direct_piv_tol")
   int fallback_cap = 1000;  // iteration cap of the hierarchy when the factorisation broke down ("direct_fallback_cap")
-  int leaf = 32;            // vertices per leaf of the nested dissection
+  int leaf = 64;            // vertices per leaf of the nested dissection (cfg4 sweep: 32 -> 452, 48 -> 420, 56 / 64 -> 407, 80 -> 538 ms per step)
   bool static_ready = false, numeric_valid = false;
   bool have_factor = false, refactor_next = false;  // factors of the current plan exist (possibly of an earlier operator)
   int lag = 0;              // > 0: Newton iterations reuse earlier factors while the refinement needs at most this many iterations.  Off: measured on cfg4, factors of the PREVIOUS Newton iteration need more than 20 refinement iterations (the projected blocks switch between iterations), a refactorisation costs ~10

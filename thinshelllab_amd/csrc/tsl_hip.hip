@@ -332,6 +332,7 @@ extern "C" int tsl_set_param(tsl_ctx* c, const char* key, double v) {
   else if (k == "direct_lag") c->ds.lag = (int)v;
   else if (k == "ds_dbg") c->ds.dbg = (int)v;
   else if (k == "direct_fallback_cap") c->ds.fallback_cap = (int)v;
+  else if (k == "ds_bench_batch") c->ds.bench_batch = (int)v;
   else if (k == "direct_piv_tol") { c->ds.piv_tol = v; c->ds.numeric_valid = false; }
   else if (k == "direct_probe_cap") c->ds.probe_cap = std::max(1, (int)v);
   else if (k == "direct_probe_every") c->ds.probe_every = std::max(1, (int)v);
