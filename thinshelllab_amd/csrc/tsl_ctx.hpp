@@ -94,6 +94,11 @@ struct DirectSolver {
   int enable = -1;          // -1 auto (cloth grids of >= 1024 cells: the iterative hierarchy is probed first, the factorisation takes over when it fails), 0 off, 1 always
   bool hard = false;        // auto mode: the last probe of the iterative hierarchy failed
   int hard_steps = 0, probe_cap = 60, probe_every = 16;
+  hipStream_t zstream = 0;  // the arena of the NEXT factorisation is cleared here, next to the line search and the assembly (direct_prezero)
+  hipEvent_t ev_zfork = nullptr, ev_zero = nullptr;
+  bool prezero_pending = false;
+  size_t prezero_n = 0;
+  int prezero = 1;          // "direct_prezero"
   int bench_batch = -1;     // tsl_bench_direct: restrict the replay to one batch (-1: all)
   double piv_tol = 1e-8;    // static pivoting: pivots below piv_tol x their own scale are perturbed to that bound ("direct_piv_tol")
   int fallback_cap = 1000;  // iteration cap of the hierarchy when the factorisation broke down ("direct_fallback_cap")

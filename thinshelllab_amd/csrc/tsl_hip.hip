@@ -293,6 +293,7 @@ extern "C" void tsl_ctx_destroy(tsl_ctx* c) {
   if (c->mr_graph) (void)hipGraphExecDestroy(c->mr_graph);
   if (c->ev_in) (void)hipEventDestroy(c->ev_in);
   if (c->ev_out) (void)hipEventDestroy(c->ev_out);
+  if (c->ds.zstream) { (void)hipStreamSynchronize(c->ds.zstream); (void)hipEventDestroy(c->ds.ev_zfork); (void)hipEventDestroy(c->ds.ev_zero); (void)hipStreamDestroy(c->ds.zstream); }
   if (c->ev_fork) (void)hipEventDestroy(c->ev_fork);
   if (c->ev_join) (void)hipEventDestroy(c->ev_join);
   if (c->side) (void)hipStreamDestroy(c->side);
@@ -333,6 +334,7 @@ extern "C" int tsl_set_param(tsl_ctx* c, const char* key, double v) {
   else if (k == "ds_dbg") c->ds.dbg = (int)v;
   else if (k == "direct_fallback_cap") c->ds.fallback_cap = (int)v;
   else if (k == "ds_bench_batch") c->ds.bench_batch = (int)v;
+  else if (k == "direct_prezero") c->ds.prezero = (int)v;
   else if (k == "direct_piv_tol") { c->ds.piv_tol = v; c->ds.numeric_valid = false; }
   else if (k == "direct_probe_cap") c->ds.probe_cap = std::max(1, (int)v);
   else if (k == "direct_probe_every") c->ds.probe_every = std::max(1, (int)v);
@@ -1770,7 +1772,7 @@ extern "C" int tsl_step(tsl_ctx* c, double* pos, double* prev, double* vel, doub
   else c->nc = 0;
   st.nc = nc;
   int iter = 0;
-  double delta = 1e5;
+  double delta = 1e5, E_last = 0;
   // verbose: host wall time per phase (each phase ends in a stream synchronisation when timed)
   double t_energy = 0, t_asm = 0, t_solve = 0, t_ls = 0;
   c->tm_loop = 0;
@@ -1781,12 +1783,16 @@ extern "C" int tsl_step(tsl_ctx* c, double* pos, double* prev, double* vel, doub
     iter++;
     double E0;
     auto t0 = now();
-    TSL_TRY(energy_sync(c, pos, prev, vel, ref, &E0));
+    // compute_energy at the top of an iteration (BaseScene time_step): the state is the one the previous line search ended on, whose
+    // energy is known (same kernel, same positions) -- evaluated anew only in the first iteration
+    if (iter == 1) TSL_TRY(energy_sync(c, pos, prev, vel, ref, &E0));
+    else E0 = E_last;
     auto t1 = now();
     TSL_TRY(assemble(c, pos, prev, vel, ref, 1, c->F.p));
     auto t2 = now();
     tsl_solve_stats ss;
     TSL_TRY(solve_orig(c, c->F.p, c->pdir.p, &ss));
+    if (ss.method == 4) TSL_TRY(direct_prezero(c));   // the factors are not needed again: clear the arena for the next iteration next to the line search
     auto t3 = now();
     t_energy += secs(t0, t1); t_asm += secs(t1, t2); t_solve += secs(t2, t3);
     st.cg_iters += ss.iters; st.solves++; st.restarts += ss.restarts; st.fallback += (ss.flag == 1); st.unconverged += (ss.flag == 3); st.attained += ss.attained;
@@ -1806,7 +1812,7 @@ extern "C" int tsl_step(tsl_ctx* c, double* pos, double* prev, double* vel, doub
     HIP_OK(hipMemcpyAsync(&HSC(c)->pmax, &SC(c)->pmax, sizeof(double), hipMemcpyDeviceToHost, s));
     HIP_OK(hipStreamSynchronize(s));
     delta = HSC(c)->pmax / c->dt;
-    st.last_alpha = alpha; st.energy = E;
+    st.last_alpha = alpha; st.energy = E; E_last = E;
     t_ls += secs(t3, now());
     if (delta < 1e-7) break;
   }
@@ -2147,6 +2153,7 @@ extern "C" int tsl_adjoint_step(tsl_ctx* c, int step, int T, const double* pos_b
   tsl_solve_stats local;
   if (!st) st = &local;
   TSL_TRY(solve_orig(c, pg_s, c->pdir.p, st));
+  if (st->method == 4) TSL_TRY(direct_prezero(c));   // the next adjoint step assembles another operator
   if (c->verbose) fprintf(stderr, "[tsl] adjoint step %d: nc %d solver flag %d iters %d restarts %d rel_residual %.2e\n", step, c->nc, st->flag, st->iters, st->restarts, st->rel_residual);
   // tmp_z_frozen (second compute_Hessian pass with counting_z_frozen)
   HIP_OK(hipMemsetAsync(c->v_t4.p, 0, n3 * sizeof(double), s));
