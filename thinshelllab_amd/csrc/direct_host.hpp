@@ -153,12 +153,29 @@ static int direct_factor(tsl_ctx* c, int stop_sn = -1, const char* dump_path = n
   hipLaunchKernelGGL(k_ds_assemble_blocks, dim3(ds_nblk(nnzb * 9, 256)), dim3(256), 0, s, nnzb, d.csr2sell.p, c->vals.p, d.blk_dst.p, d.blk_ld.p, d.arena.p);
   if (c->nc > 0) hipLaunchKernelGGL(k_ds_assemble_contacts, dim3(ds_nblk((long)c->nc * 144, 256)), dim3(256), 0, s, c->nc, c->c_H.p, d.con_dst.p, d.con_ld.p, d.arena.p);
   hipLaunchKernelGGL(k_ds_pad_diag, dim3(P.sym.n_sn), dim3(64), 0, s, P.sym.n_sn, d.fr.p, d.arena.p);
-  for (const DsBatch& b : P.batches) {
+  auto run_batch = [&](const DsBatch& b, hipStream_t bs) {
     const int lv0 = b.first, nf = b.count;
     const int tp = b.max_pp / DS_T, tb = b.max_bp / DS_T;
+    if (ds_use_small(b)) hipLaunchKernelGGL(k_ds_inv_small, dim3(nf), dim3(256), ds_small_lds(b.max_pp), bs, D, lv0, b.max_pp + 1);
+    else {
+      hipLaunchKernelGGL(k_ds_pivot0, dim3(nf), dim3(256), 0, bs, D, lv0);
+      for (int k = 0; k < tp; k++) hipLaunchKernelGGL(k_ds_gj_step, dim3(tp, tp, P.act_n[b.act_off + k]), dim3(256), 0, bs, D, lv0, k);   // fronts are sorted by pp: the active ones are a prefix
+      hipLaunchKernelGGL(k_ds_gj_finish, dim3(tp, nf), dim3(256), 0, bs, D, lv0);
+    }
+    if (tb > 0) {
+      ds_launch_gemm(bs, D, b, 0);
+      ds_launch_gemm(bs, D, b, 1);   // + extend-add into the parents
+    }
+  };
+  // The fronts of a level are independent: where a level was split into batches (by pivot-block size) the batches run on parallel
+  // streams -- the latency-bound one (a few fronts in the LDS kernel, or the block steps of a handful of larger fronts) next to the
+  // throughput-bound one (a thousand leaves); the extend-add into the parents is atomic anyway.
+  for (size_t bi = 0; bi < P.batches.size();) {
+    size_t be = bi;
+    while (be < P.batches.size() && P.batches[be].level == P.batches[bi].level) be++;
     if (stop_sn >= 0) {   // diagnostic: the assembled front stop_sn (children added, not yet factorised) -> file
       bool here = false;
-      for (int q = lv0; q < lv0 + nf; q++) here |= P.level_sn[q] == stop_sn;
+      for (int q = P.batches[bi].first; q < P.batches[be - 1].first + P.batches[be - 1].count; q++) here |= P.level_sn[q] == stop_sn;
       if (here) {
         const DsFrontDesc& f = P.fr[stop_sn];
         std::vector<double> h((size_t)f.pp * f.ld);
@@ -175,16 +192,20 @@ static int direct_factor(tsl_ctx* c, int stop_sn = -1, const char* dump_path = n
         return 0;
       }
     }
-    if (ds_use_small(b)) hipLaunchKernelGGL(k_ds_inv_small, dim3(nf), dim3(256), ds_small_lds(b.max_pp), s, D, lv0, b.max_pp + 1);
-    else {
-      hipLaunchKernelGGL(k_ds_pivot0, dim3(nf), dim3(256), 0, s, D, lv0);
-      for (int k = 0; k < tp; k++) hipLaunchKernelGGL(k_ds_gj_step, dim3(tp, tp, P.act_n[b.act_off + k]), dim3(256), 0, s, D, lv0, k);   // fronts are sorted by pp: the active ones are a prefix
-      hipLaunchKernelGGL(k_ds_gj_finish, dim3(tp, nf), dim3(256), 0, s, D, lv0);
+    const int nside = d.par_batches ? (int)std::min<size_t>(be - bi - 1, DS_NSIDE) : 0;
+    if (nside > 0) {
+      if (d.fstream[0] == nullptr)
+        for (int k = 0; k < DS_NSIDE; k++) { HIP_OK(hipStreamCreateWithFlags(&d.fstream[k], hipStreamNonBlocking)); HIP_OK(hipEventCreateWithFlags(&d.ev_fjoin[k], hipEventDisableTiming)); }
+      if (d.ev_ffork == nullptr) HIP_OK(hipEventCreateWithFlags(&d.ev_ffork, hipEventDisableTiming));
+      HIP_OK(hipEventRecord(d.ev_ffork, s));
+      for (int k = 0; k < nside; k++) HIP_OK(hipStreamWaitEvent(d.fstream[k], d.ev_ffork, 0));
     }
-    if (tb > 0) {
-      ds_launch_gemm(s, D, b, 0);
-      ds_launch_gemm(s, D, b, 1);   // + extend-add into the parents
+    for (size_t q = bi; q < be; q++) {
+      const int k = (int)(q - bi);   // batch 0 of the level (the largest pivot blocks: the longest chain of block steps) stays on the engine stream
+      run_batch(P.batches[q], (nside > 0 && k > 0) ? d.fstream[(k - 1) % nside] : s);
     }
+    for (int k = 0; k < nside; k++) { HIP_OK(hipEventRecord(d.ev_fjoin[k], d.fstream[k])); HIP_OK(hipStreamWaitEvent(s, d.ev_fjoin[k], 0)); }
+    bi = be;
   }
   if (d.anorm_dev.n == 0 && d.anorm_dev.alloc(1)) return -1;
   HIP_OK(hipMemsetAsync(d.anorm_dev.p, 0, sizeof(double), s));

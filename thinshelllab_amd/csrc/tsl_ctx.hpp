@@ -90,6 +90,7 @@ struct MgCloth {
 };
 
 // sparse direct preconditioner (direct_sym.hpp / direct_plan.hpp / k_direct.hpp): multifrontal LU of the assembled operator
+#define DS_NSIDE 2
 struct DirectSolver {
   int enable = -1;          // -1 auto (cloth grids of >= 1024 cells: the iterative hierarchy is probed first, the factorisation takes over when it fails), 0 off, 1 always
   bool hard = false;        // auto mode: the last probe of the iterative hierarchy failed
@@ -99,6 +100,9 @@ struct DirectSolver {
   bool prezero_pending = false;
   size_t prezero_n = 0;
   int prezero = 1;          // "direct_prezero"
+  hipStream_t fstream[2] = {nullptr, nullptr};   // batches of one level run next to each other (direct_factor)
+  hipEvent_t ev_ffork = nullptr, ev_fjoin[2] = {nullptr, nullptr};
+  int par_batches = 1;      // "direct_par_batches"
   int bench_batch = -1;     // tsl_bench_direct: restrict the replay to one batch (-1: all)
   double piv_tol = 1e-8;    // static pivoting: pivots below piv_tol x their own scale are perturbed to that bound ("direct_piv_tol")
   int fallback_cap = 1000;  // iteration cap of the hierarchy when the factorisation broke down ("direct_fallback_cap")

@@ -293,6 +293,8 @@ extern "C" void tsl_ctx_destroy(tsl_ctx* c) {
   if (c->mr_graph) (void)hipGraphExecDestroy(c->mr_graph);
   if (c->ev_in) (void)hipEventDestroy(c->ev_in);
   if (c->ev_out) (void)hipEventDestroy(c->ev_out);
+  for (int k = 0; k < DS_NSIDE; k++) if (c->ds.fstream[k]) { (void)hipStreamSynchronize(c->ds.fstream[k]); (void)hipEventDestroy(c->ds.ev_fjoin[k]); (void)hipStreamDestroy(c->ds.fstream[k]); }
+  if (c->ds.ev_ffork) (void)hipEventDestroy(c->ds.ev_ffork);
   if (c->ds.zstream) { (void)hipStreamSynchronize(c->ds.zstream); (void)hipEventDestroy(c->ds.ev_zfork); (void)hipEventDestroy(c->ds.ev_zero); (void)hipStreamDestroy(c->ds.zstream); }
   if (c->ev_fork) (void)hipEventDestroy(c->ev_fork);
   if (c->ev_join) (void)hipEventDestroy(c->ev_join);
@@ -335,6 +337,7 @@ extern "C" int tsl_set_param(tsl_ctx* c, const char* key, double v) {
   else if (k == "direct_fallback_cap") c->ds.fallback_cap = (int)v;
   else if (k == "ds_bench_batch") c->ds.bench_batch = (int)v;
   else if (k == "direct_prezero") c->ds.prezero = (int)v;
+  else if (k == "direct_par_batches") c->ds.par_batches = (int)v;
   else if (k == "direct_piv_tol") { c->ds.piv_tol = v; c->ds.numeric_valid = false; }
   else if (k == "direct_probe_cap") c->ds.probe_cap = std::max(1, (int)v);
   else if (k == "direct_probe_every") c->ds.probe_every = std::max(1, (int)v);
