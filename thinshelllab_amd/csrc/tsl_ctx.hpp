@@ -231,6 +231,9 @@ struct tsl_ctx {
   hipEvent_t ev_fork = nullptr, ev_join = nullptr;
   int asm_overlap = 1;
   int contact_coop = 1;  // 16 lanes per constraint in the contact block assembly (0: one lane per constraint)
+  int tet_coop = 0;      // 1: 16 lanes per tetrahedron in the element Hessians (k_tet_hess_coop).  Off: the one-lane-per-element kernel runs in the
+                         // shadow of the cloth kernels on the second stream with ninety waves; the cooperative one (360 waves, Jacobi in LDS) takes
+                         // their CUs: cfg4 386 -> 398 ms per step
 
   // ---- Newton scratch (original order)
   DevBuf<double> F, pdir, x1;

@@ -351,6 +351,7 @@ extern "C" int tsl_set_param(tsl_ctx* c, const char* key, double v) {
   else if (k == "pcg_body_fold") c->pcg_body_fold = (int)v;
   else if (k == "asm_overlap") c->asm_overlap = (int)v;
   else if (k == "contact_coop") c->contact_coop = (int)v;
+  else if (k == "tet_coop") c->tet_coop = (int)v;
   else if (k.rfind("self_contact", 0) == 0 && k.size() > 12) {   // "self_contact<body>" (geometry_self.projection_query(self_contact=[...]))
     char* endp = nullptr;
     const long b = strtol(k.c_str() + 12, &endp, 10);
@@ -489,7 +490,8 @@ static int assemble(tsl_ctx* c, const double* pos, const double* prev, const dou
   }
   if (c->n_tet) {
     if (grad) hipLaunchKernelGGL(k_tet_grad, dim3(nblk(c->n_tet, 256)), dim3(256), 0, st, TA, pos, grad);
-    hipLaunchKernelGGL(k_tet_hess, dim3(nblk(c->n_tet, 64)), dim3(64), 0, st, TA, c->tet_blk.p, pos, spd, c->vals_full.p);
+    if (c->tet_coop) hipLaunchKernelGGL(k_tet_hess_coop, dim3(nblk((long)c->n_tet * 16, 256)), dim3(256), 0, st, TA, c->tet_blk.p, pos, spd, c->vals_full.p);
+    else hipLaunchKernelGGL(k_tet_hess, dim3(nblk(c->n_tet, 64)), dim3(64), 0, st, TA, c->tet_blk.p, pos, spd, c->vals_full.p);
   }
   TSL_TRY(contact_assemble(c, pos, spd, grad, st));
   if (fork) HIP_OK(hipEventRecord(c->ev_join, c->side));
