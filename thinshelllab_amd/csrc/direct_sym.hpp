@@ -35,6 +35,10 @@ struct DirectSym {
   // ---- per constraint set (build_tree)
   std::vector<int> order, epos, sn_of, sn_ptr;  // position -> vertex, vertex -> position, vertex -> supernode, supernode -> [first, last) position
   int n_sn = 0;
+  int merge_sep = 0;     // "direct_merge_sep": separators of at most this many vertices join the supernode of the enclosing separator (0: off;
+                         // measured on cfg4: 12 -> one level and 500 fronts less, 6 % more flops, the same 383 ms per step; 20 -> 388 ms)
+  bool merge_k = true;   // constrained body vertices share the supernode of the separator they are placed at ("direct_merge_k"; a supernode of their own
+                         // adds two elimination levels with one or two small fronts each: cfg4 391 -> 377 ms per step)
   std::vector<std::vector<int>> bnd;  // boundary vertices per supernode, sorted by elimination position
   std::vector<int> parent, level;
   int n_levels = 0;
@@ -125,7 +129,7 @@ struct DirectSym {
     if ((int)c_order.size() > c_ptr.back()) { c_ptr.push_back((int)c_order.size()); c_lo.push_back(lo); c_grid.push_back(grid); }
   }
 
-  void dissect(const DsGrid& g, int gi, const std::vector<std::vector<int>>& adj, std::vector<int>& region, int leaf_verts, std::vector<int>& side) {
+  void dissect(const DsGrid& g, int gi, const std::vector<std::vector<int>>& adj, std::vector<int>& region, int leaf_verts, std::vector<int>& side, std::vector<int>* up = nullptr) {
     if (region.empty()) return;
     const int lo = (int)c_order.size();
     const int W = g.M + 1;
@@ -156,9 +160,15 @@ struct DirectSym {
     for (int v : region) { if (side[v] == 1) L.push_back(v); else if (side[v] == 2) R.push_back(v); else S.push_back(v); }
     for (int v : region) side[v] = 0;
     std::vector<int>().swap(region);
-    dissect(g, gi, adj, L, leaf_verts, side);
-    dissect(g, gi, adj, R, leaf_verts, side);
+    // Optional (merge_sep > 0): a small separator (the last split above the leaves) gets no supernode of its own, it is handed to the
+    // enclosing region and opens the supernode of that region's separator (a front of 32 pivots with a 224-wide boundary is all
+    // extend-add traffic and costs an elimination level in every sweep; the larger parent fronts cost the same again).
+    std::vector<int> handed;
+    dissect(g, gi, adj, L, leaf_verts, side, &handed);
+    dissect(g, gi, adj, R, leaf_verts, side, &handed);
     std::sort(S.begin(), S.end(), [&](int a, int b) { return other(a) != other(b) ? other(a) < other(b) : coord(a) < coord(b); });
+    if (up != nullptr && handed.empty() && (int)S.size() <= merge_sep) { up->insert(up->end(), S.begin(), S.end()); return; }
+    for (int v : handed) c_order.push_back(v);
     for (int v : S) c_order.push_back(v);
     close_static(lo, gi);
   }
@@ -213,7 +223,7 @@ struct DirectSym {
     for (int b = 0; b < nb; b++) if (ins[b] >= 0) at[ins[b]].push_back(b);
     for (int s = 0; s <= n_static; s++) {
       for (int b : at[s]) for (int v : K[b]) order.push_back(v);
-      close_sn();
+      if (!merge_k || s == n_static) close_sn();   // merge_k: the constrained body vertices open the supernode of the separator they sit in front of
       if (s < n_static) { for (int q = c_ptr[s]; q < c_ptr[s + 1]; q++) order.push_back(c_order[q]); close_sn(); }
     }
     n_sn = (int)sn_ptr.size() - 1;
