@@ -75,14 +75,17 @@ static int direct_plan(tsl_ctx* c) {
   DirectSolver& d = c->ds;
   hipStream_t s = c->stream;
   TSL_TRY(direct_static(c));
+  if (d.plan_valid && d.cons_checked) return 0;   // every Newton iteration of a step factorises on the step's constraint set
   std::vector<int> cons((size_t)c->nc * 4);
   if (c->nc > 0) {
     HIP_OK(hipMemcpyAsync(cons.data(), c->c_idx.p, cons.size() * sizeof(int), hipMemcpyDeviceToHost, s));
     HIP_OK(hipStreamSynchronize(s));
   }
+  d.cons_checked = true;
   if (d.plan_valid && cons == d.h_cons) return 0;
   const auto t0 = std::chrono::steady_clock::now();
   const int rc = d.plan.build(c->h_rows, d.row_ptr, cons.data(), c->nc);
+  const auto t_build = std::chrono::steady_clock::now();
   if (rc) return tsl_fail("direct solver: inconsistent elimination tree (code %d)", rc);
   DirectPlan& P = d.plan;
   // local vertex -> permuted row of the solver vectors
@@ -107,8 +110,8 @@ static int direct_plan(tsl_ctx* c) {
   d.n_plans++;
   d.t_plan += std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
   if (c->verbose >= 2)
-    fprintf(stderr, "[tsl] direct plan: %d supernodes, %d levels, %zu batches, %.2f GB of fronts, %.1f GFLOP per factorisation, nc %d\n", P.sym.n_sn, P.n_levels, P.batches.size(), P.arena * 8e-9,
-            P.flops * 1e-9, c->nc);
+    fprintf(stderr, "[tsl] direct plan: %d supernodes, %d levels, %zu batches, %.2f GB of fronts, %.1f GFLOP per factorisation, nc %d; host %.2f ms (tree + maps %.2f)\n", P.sym.n_sn, P.n_levels, P.batches.size(), P.arena * 8e-9,
+            P.flops * 1e-9, c->nc, 1e3 * std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count(), 1e3 * std::chrono::duration<double>(t_build - t0).count());
   if (c->verbose >= 3)
     for (const DsBatch& b : P.batches) fprintf(stderr, "[tsl]   level %2d: %5d fronts, pivots <= %4d, boundary <= %4d%s\n", b.level, b.count, b.max_pp, b.max_bp, ds_use_small(b) ? " (LDS kernel)" : "");
   return 0;

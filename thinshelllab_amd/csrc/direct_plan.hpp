@@ -6,6 +6,9 @@
 //      [ F21 (bp x pp) | F22 (bp x bp) ]      boundary dofs pp..pp+b-1 (padding is zero)
 // after the factorisation:  [ W = F11^-1 | G = W F12 ] / [ F21 | S = F22 - F21 G ];  S is added into the parent's front.
 #pragma once
+#include <atomic>
+#include <chrono>
+#include <thread>
 #include "direct_sym.hpp"
 
 #define DS_T 32  // tile edge of the dense kernels; p and b are padded to multiples of it
@@ -28,6 +31,25 @@ struct DsBatch {
   int act_off;   // act_n / act_ld [act_off + k]: fronts still active at block step k (a prefix) and their largest ld
 };
 
+// dynamic parallel loop over [0, n) on up to `nt` host threads (chunks handed out by an atomic counter); body(thread, index)
+template <class F>
+static void ds_parallel_for(int n, int nt, int chunk, F body) {
+  nt = std::max(1, std::min(nt, (n + chunk - 1) / chunk));
+  if (nt == 1) { for (int i = 0; i < n; i++) body(0, i); return; }
+  std::atomic<int> next{0};
+  auto work = [&](int t) {
+    for (;;) {
+      const int i0 = next.fetch_add(chunk);
+      if (i0 >= n) break;
+      for (int i = i0; i < std::min(n, i0 + chunk); i++) body(t, i);
+    }
+  };
+  std::vector<std::thread> th;
+  for (int t = 1; t < nt; t++) th.emplace_back(work, t);
+  work(0);
+  for (auto& x : th) x.join();
+}
+
 struct DirectPlan {
   DirectSym sym;
   std::vector<DsFrontDesc> fr;
@@ -45,6 +67,11 @@ struct DirectPlan {
   long long arena = 0;      // doubles
   long long garena = 0;     // doubles
   long long scratch = 0;    // doubles, max over the levels
+  double phase_ms[6] = {0, 0, 0, 0, 0, 0};   // host time of the last build: tree, descriptors + parent maps, levels / batches / work lists, static block map, contact map
+  std::vector<int> tpos;                 // static: index of the mirrored block of every pattern block
+  std::vector<std::vector<int>> locs;    // per host thread: vertex -> local dof of the front being scattered (-1 outside)
+  int threads = 0;                       // host threads of the map construction (0: min(8, hardware))
+  int n_threads() const { return threads > 0 ? threads : (int)std::max(1u, std::min(8u, std::thread::hardware_concurrency())); }
   double flops = 0;
 
   static int pad(int n) { return (n + DS_T - 1) / DS_T * DS_T; }
@@ -60,7 +87,10 @@ struct DirectPlan {
   // adj: sorted adjacency (with or without self); row_ptr: CSR offsets of adj (blocks are numbered row by row);
   // cons: n_cons x 4 vertex ids of the contact constraints
   int build(const std::vector<std::vector<int>>& adj, const std::vector<int>& row_ptr, const int* cons, int n_cons) {
+    auto tick = std::chrono::steady_clock::now();
+    auto lap = [&](int k) { const auto n = std::chrono::steady_clock::now(); phase_ms[k] = 1e3 * std::chrono::duration<double>(n - tick).count(); tick = n; };
     sym.build_tree(adj, cons, n_cons, 4);
+    lap(0);
     const int S = sym.n_sn;
     fr.assign(S, DsFrontDesc{});
     rel.clear(); vtx.clear();
@@ -81,15 +111,38 @@ struct DirectPlan {
       const double p = f.pp, b = f.bp;
       flops += 2.0 * p * p * p + 2.0 * p * p * b + 2.0 * p * b * b;
     }
-    for (int s = 0; s < S; s++) {
-      DsFrontDesc& f = fr[s];
-      f.rel_off = (int)rel.size();
-      for (int v : sym.bnd[s]) {
-        const int l = local_dof(f.parent, v);
-        if (l < 0) return -1;  // the boundary of a child is contained in the front of its parent
-        rel.push_back(l);
-      }
+    // child boundary -> local dof in the parent's front: per parent, its front is scattered into a vertex table once and every
+    // child reads its boundary from it
+    {
+      int total = 0;
+      for (int s = 0; s < S; s++) { fr[s].rel_off = total; total += fr[s].nv_bnd; }
+      rel.assign(total, -1);
+      std::vector<int> cptr(S + 1, 0), clist(S);
+      for (int s = 0; s < S; s++) if (fr[s].parent >= 0) cptr[fr[s].parent + 1]++;
+      for (int s = 0; s < S; s++) cptr[s + 1] += cptr[s];
+      { std::vector<int> fill(cptr.begin(), cptr.end() - 1); for (int s = 0; s < S; s++) if (fr[s].parent >= 0) clist[fill[fr[s].parent]++] = s; }
+      const int nt = 1;   // 0.3 ms on one thread (MI355X host); starting threads costs more than they save here
+      if ((int)locs.size() < nt) locs.resize(nt);
+      std::atomic<int> bad{0};
+      ds_parallel_for(S, nt, 16, [&](int t, int p) {
+        if (cptr[p] == cptr[p + 1]) return;
+        std::vector<int>& lc = locs[t];
+        if ((int)lc.size() != sym.NV) lc.assign(sym.NV, -1);
+        const DsFrontDesc& f = fr[p];
+        const int* fv = &vtx[f.vtx_off];
+        for (int i = 0; i < f.nv_own; i++) lc[fv[i]] = 3 * i;
+        for (int i = 0; i < f.nv_bnd; i++) lc[fv[f.nv_own + i]] = f.pp + 3 * i;
+        for (int q = cptr[p]; q < cptr[p + 1]; q++) {
+          const DsFrontDesc& ch = fr[clist[q]];
+          const int* cv = &vtx[ch.vtx_off + ch.nv_own];
+          for (int i = 0; i < ch.nv_bnd; i++) { const int l = lc[cv[i]]; if (l < 0) bad = 1; rel[ch.rel_off + i] = l; }   // the boundary of a child is contained in the front of its parent
+        }
+        for (int i = 0; i < f.nv_own + f.nv_bnd; i++) lc[fv[i]] = -1;
+      });
+      if (bad) return -1;
+      for (int s = 0; s < S; s++) if (fr[s].parent < 0 && fr[s].nv_bnd > 0) return -1;
     }
+    lap(1);
     // levels: as soon as possible (a front sits one level above its deepest child): the small fronts of the FEM bodies' own
     // dissection trees and of shallow subtrees then share the batches of the ~10^3 cloth leaves instead of adding batches of their
     // own next to the few large fronts near the root, where every batch costs its block steps in sequence
@@ -140,20 +193,59 @@ struct DirectPlan {
         act_n.push_back(n); act_ld.push_back(mld);
       }
     }
-    // static blocks
+    lap(2);
+    // static blocks: block (r, c) of the pattern lives in the front of the earlier-eliminated of its two vertices.  One pass over
+    // the supernodes with a scattered vertex -> local index table (own vertices and boundary of the current front) and the static
+    // index of the mirrored block (c, r): no searches (the first version looked both vertices up by bisection per block: 4.5 of
+    // the 6.5 ms a plan cost on cfg4, twice per time step)
     const int NV = sym.NV;
-    blk_dst.assign(row_ptr[NV], -1); blk_ld.assign(row_ptr[NV], 0);
-    for (int r = 0; r < NV; r++) {
-      const auto& row = adj[r];
-      for (int k = 0; k < (int)row.size(); k++) {
-        const int c = row[k];
-        const int s = std::min(sym.sn_of[r], sym.sn_of[c]);
-        const int lr = local_dof(s, r), lc = local_dof(s, c);
-        if (lr < 0 || lc < 0) return -2;
-        blk_dst[row_ptr[r] + k] = fr[s].off + (long long)lr * fr[s].ld + lc;
-        blk_ld[row_ptr[r] + k] = fr[s].ld;
-      }
+    if ((int)tpos.size() != row_ptr[NV]) {   // pattern is static: position of r in the row of c, once
+      tpos.assign(row_ptr[NV], -1);
+      for (int r = 0; r < NV; r++)
+        for (int k = 0; k < (int)adj[r].size(); k++) {
+          const int c = adj[r][k];
+          const auto& rc = adj[c];
+          const auto it = std::lower_bound(rc.begin(), rc.end(), r);
+          if (it != rc.end() && *it == r) tpos[row_ptr[r] + k] = row_ptr[c] + (int)(it - rc.begin());
+        }
     }
+    blk_dst.resize(row_ptr[NV]); blk_ld.resize(row_ptr[NV]);   // every entry is written below (counted), no refill
+    {
+      const int nt = n_threads();
+      if ((int)locs.size() < nt) locs.resize(nt);
+      std::atomic<int> bad{0};
+      std::atomic<long long> written{0};
+      ds_parallel_for(S, nt, 16, [&](int t, int s) {
+        std::vector<int>& loc = locs[t];
+        if ((int)loc.size() != NV) loc.assign(NV, -1);
+        const DsFrontDesc& f = fr[s];
+        const int no = f.nv_own;
+        long long nw = 0;
+        const int* fv = &vtx[f.vtx_off];
+        for (int i = 0; i < no; i++) loc[fv[i]] = 3 * i;
+        for (int i = 0; i < f.nv_bnd; i++) loc[fv[no + i]] = f.pp + 3 * i;
+        for (int i = 0; i < no; i++) {
+          const int r = fv[i];
+          const auto& row = adj[r];
+          for (int k = 0; k < (int)row.size(); k++) {
+            const int c = row[k];
+            if (sym.sn_of[c] < s) continue;   // placed from the front of c
+            const int lc = loc[c];
+            if (lc < 0) { bad = 1; continue; }
+            const int q = row_ptr[r] + k;
+            blk_dst[q] = f.off + (long long)(3 * i) * f.ld + lc; blk_ld[q] = f.ld; nw++;
+            if (sym.sn_of[c] > s) {
+              const int qt = tpos[q];
+              if (qt >= 0) { blk_dst[qt] = f.off + (long long)lc * f.ld + 3 * i; blk_ld[qt] = f.ld; nw++; }
+            }
+          }
+        }
+        for (int i = 0; i < no + f.nv_bnd; i++) loc[fv[i]] = -1;
+        written += nw;
+      });
+      if (bad || written != row_ptr[NV]) return -2;
+    }
+    lap(3);
     con_dst.assign((size_t)n_cons * 16, -1); con_ld.assign((size_t)n_cons * 16, 0);
     for (int e = 0; e < n_cons; e++)
       for (int a = 0; a < 4; a++)

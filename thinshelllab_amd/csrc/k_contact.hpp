@@ -777,6 +777,7 @@ extern "C" int tsl_contact_detect(tsl_ctx* c, const double* pos, const double* p
   const int NV = c->NV;
   c->nc = 0;
   c->bd_valid = false;
+  c->ds.cons_checked = false;   // the factorisation plan compares the new constraint list with the one it was made for
   if (c->n_body < 2 || c->NF == 0) { if (nc_host) *nc_host = 0; return 0; }
   // calc_vn
   HIP_OK(hipMemsetAsync(c->vn.p, 0, 3 * (size_t)NV * sizeof(double), s));

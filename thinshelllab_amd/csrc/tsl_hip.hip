@@ -1776,7 +1776,7 @@ extern "C" int tsl_step(tsl_ctx* c, double* pos, double* prev, double* vel, doub
   // calc_vn + projection_query + contact_analysis
   int nc = 0;
   if (c->contact_enable) TSL_TRY(tsl_contact_detect(c, pos, prev, &nc));
-  else c->nc = 0;
+  else { c->nc = 0; c->ds.cons_checked = false; }
   st.nc = nc;
   int iter = 0;
   double delta = 1e5, E_last = 0;
@@ -1820,6 +1820,7 @@ extern "C" int tsl_step(tsl_ctx* c, double* pos, double* prev, double* vel, doub
     HIP_OK(hipStreamSynchronize(s));
     delta = HSC(c)->pmax / c->dt;
     st.last_alpha = alpha; st.energy = E; E_last = E;
+    if (c->verbose >= 4) fprintf(stderr, "[tsl]   newton %2d: E0 %.12e  E - E0 %+.3e  alpha %.3g  |p|max %.3e  delta %.3e  (solve: %d its, rel_residual %.1e)\n", iter, E0, E - E0, alpha, HSC(c)->pmax, delta, ss.iters, ss.rel_residual);
     t_ls += secs(t3, now());
     if (delta < 1e-7) break;
   }
@@ -2128,7 +2129,7 @@ extern "C" int tsl_adjoint_step(tsl_ctx* c, int step, int T, const double* pos_b
   // contacts re-detected at pos = prev_pos = x_{s-1} (copy_pos_only + calc_vn + f_contact + contact_analysis)
   int nc = 0;
   if (c->contact_enable) TSL_TRY(tsl_contact_detect(c, x_prev, x_prev, &nc));
-  else c->nc = 0;
+  else { c->nc = 0; c->ds.cons_checked = false; }
   const ClothArgs CA = cloth_args(c);
   // pos = x_s, ref_angle = ref_{s-1}: init_folding + ref_angle_backprop_a2ax
   if (c->n_hinge) hipLaunchKernelGGL(k_adj_a2ax, dim3(nblk(c->n_hinge, 256)), dim3(256), 0, s, CA, x_s, ref_prev, ag_s, ag_prev, pg_s);
