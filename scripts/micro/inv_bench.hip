@@ -12,7 +12,7 @@ __global__ void __launch_bounds__(256) k_bench(const double* __restrict__ in, do
     for (int q = 0; q < 4; q++) T[ty + 8 * q][tx] = in[(ty + 8 * q) * DS_T + tx];
     __syncthreads();
     t0 = clock64();
-    ds_invert_tile_wg(T, bad);
+    ds_invert_tile_wg(T, bad, 1, 0, 1e-8);
     acc += clock64() - t0;
   }
   for (int q = 0; q < 4; q++) out[(ty + 8 * q) * DS_T + tx] = T[ty + 8 * q][tx];
