@@ -213,8 +213,11 @@ static int direct_factor(tsl_ctx* c, int stop_sn = -1, const char* dump_path = n
   if (d.anorm_dev.n == 0 && d.anorm_dev.alloc(1)) return -1;
   HIP_OK(hipMemsetAsync(d.anorm_dev.p, 0, sizeof(double), s));
   hipLaunchKernelGGL(k_ds_rownorm, dim3(ds_nblk(c->NV, 256)), dim3(256), 0, s, c->NV, c->slice_off.p, c->slice_len.p, c->vals.p, d.anorm_dev.p);
-  HIP_OK(hipMemcpyAsync(&d.anorm, d.anorm_dev.p, sizeof(double), hipMemcpyDeviceToHost, s));
-  HIP_OK(hipStreamSynchronize(s));
+  // |H|_inf goes to pinned host memory without a synchronisation of its own: the refinement reads it after its first one (a
+  // host wait here left the GPU idle for ~0.1 ms between the last Schur launch and the first sweep of every solve)
+  if (d.h_anorm == nullptr) HIP_OK(hipHostMalloc((void**)&d.h_anorm, sizeof(double)));
+  HIP_OK(hipMemcpyAsync(d.h_anorm, d.anorm_dev.p, sizeof(double), hipMemcpyDeviceToHost, s));
+  if (stop_sn >= 0 || c->verbose >= 2) HIP_OK(hipStreamSynchronize(s));
   HIP_OK(hipGetLastError());
   d.numeric_valid = true;
   d.have_factor = true;

@@ -104,6 +104,7 @@ struct DirectSolver {
   hipEvent_t ev_ffork = nullptr, ev_fjoin[2] = {nullptr, nullptr};
   int par_batches = 1;      // "direct_par_batches"
   bool cons_checked = false; // the constraint list has not changed since direct_plan last looked (reset by tsl_contact_detect)
+  double* h_anorm = nullptr; // pinned: |H|_inf of the last factorisation (valid after the next stream synchronisation)
   int bench_batch = -1;     // tsl_bench_direct: restrict the replay to one batch (-1: all)
   double piv_tol = 1e-8;    // static pivoting: pivots below piv_tol x their own scale are perturbed to that bound ("direct_piv_tol")
   int fallback_cap = 1000;  // iteration cap of the hierarchy when the factorisation broke down ("direct_fallback_cap")

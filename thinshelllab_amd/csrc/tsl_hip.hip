@@ -295,6 +295,7 @@ extern "C" void tsl_ctx_destroy(tsl_ctx* c) {
   if (c->ev_out) (void)hipEventDestroy(c->ev_out);
   for (int k = 0; k < DS_NSIDE; k++) if (c->ds.fstream[k]) { (void)hipStreamSynchronize(c->ds.fstream[k]); (void)hipEventDestroy(c->ds.ev_fjoin[k]); (void)hipStreamDestroy(c->ds.fstream[k]); }
   if (c->ds.ev_ffork) (void)hipEventDestroy(c->ds.ev_ffork);
+  if (c->ds.h_anorm) (void)hipHostFree(c->ds.h_anorm);
   if (c->ds.zstream) { (void)hipStreamSynchronize(c->ds.zstream); (void)hipEventDestroy(c->ds.ev_zfork); (void)hipEventDestroy(c->ds.ev_zero); (void)hipStreamDestroy(c->ds.zstream); }
   if (c->ev_fork) (void)hipEventDestroy(c->ev_fork);
   if (c->ev_join) (void)hipEventDestroy(c->ev_join);
@@ -1512,13 +1513,21 @@ static int gmres(tsl_ctx* c, tsl_solve_stats* st, bool direct) {
       precond(u, z);
       hipLaunchKernelGGL(k_axpby, dim3(gv), dim3(256), 0, s, n3, 1.0, z, 1.0, x);
     }
-    HIP_OK(hipStreamSynchronize(s));  // y (host vector) is reused by the next cycle
-    // true residual
+    // true residual (and |x| for the backward error of the direct mode) behind ONE host synchronisation, which also covers the
+    // upload of y above (the host vector is reused by the next cycle only after it)
     launch_spmv(c, c->vals.p, x, w, -1, 0);
     HIP_OK(hipMemcpyAsync(r, c->v_b.p, n3 * sizeof(double), hipMemcpyDeviceToDevice, s));
     hipLaunchKernelGGL(k_axpby, dim3(gv), dim3(256), 0, s, n3, -1.0, w, 1.0, r);
-    double rr;
-    TSL_TRY(norm2(r, &rr));
+    double rr, xx = 0.0;
+    {
+      HIP_OK(hipMemsetAsync(dh + on, 0, 2 * sizeof(double), s));
+      hipLaunchKernelGGL(k_dot, dim3(DOT_BLOCKS), dim3(256), 0, s, n3, (const double*)r, (const double*)r, dh + on);
+      if (direct) hipLaunchKernelGGL(k_dot, dim3(DOT_BLOCKS), dim3(256), 0, s, n3, (const double*)x, (const double*)x, dh + on + 1);
+      double two[2];
+      HIP_OK(hipMemcpyAsync(two, dh + on, 2 * sizeof(double), hipMemcpyDeviceToHost, s));
+      HIP_OK(hipStreamSynchronize(s));
+      rr = two[0]; xx = two[1];
+    }
     beta = sqrt(rr);
     st->rel_residual = beta / sqrt(bb);
     if (!std::isfinite(beta)) break;
@@ -1529,8 +1538,7 @@ static int gmres(tsl_ctx* c, tsl_solve_stats* st, bool direct) {
       // 1e9) is ABOVE cg_tol |b|.  When refinement no longer halves the true residual the normwise backward error
       // |b - Hx| / (|H|_inf |x| + |b|) decides: below 1e-12 (a few thousand eps, the n eps growth bound of a pivoted sparse LU in
       // practice) the solution is what a direct solver delivers (reported as attained).
-      double xx;
-      TSL_TRY(norm2(x, &xx));
+      c->ds.anorm = c->ds.h_anorm ? *c->ds.h_anorm : 0.0;
       st->backward_error = beta / (c->ds.anorm * sqrt(xx) + sqrt(bb));
       if (cycle > 0 && beta > 0.5 * beta_prev && st->backward_error <= 1e-12) { st->flag = 1; st->attained = 1; break; }
       if (cycle >= 8) break;
@@ -1807,6 +1815,7 @@ extern "C" int tsl_step(tsl_ctx* c, double* pos, double* prev, double* vel, doub
     // p_norm = max |p|  (calc_p_norm :1096-1103)
     HIP_OK(hipMemsetAsync(&SC(c)->pmax, 0, sizeof(double), s));
     hipLaunchKernelGGL(k_absmax, dim3(gsz(n3)), dim3(256), 0, s, n3, c->pdir.p, &SC(c)->pmax);
+    HIP_OK(hipMemcpyAsync(&HSC(c)->pmax, &SC(c)->pmax, sizeof(double), hipMemcpyDeviceToHost, s));
     HIP_OK(hipMemcpyAsync(c->x1.p, pos, n3 * sizeof(double), hipMemcpyDeviceToDevice, s));
     double alpha = 1.0, E = 0;
     while (alpha > 1e-8) {
@@ -1816,9 +1825,7 @@ extern "C" int tsl_step(tsl_ctx* c, double* pos, double* prev, double* vel, doub
       if (E < E0) break;
       alpha /= 2;
     }
-    HIP_OK(hipMemcpyAsync(&HSC(c)->pmax, &SC(c)->pmax, sizeof(double), hipMemcpyDeviceToHost, s));
-    HIP_OK(hipStreamSynchronize(s));
-    delta = HSC(c)->pmax / c->dt;
+    delta = HSC(c)->pmax / c->dt;   // copied before the line search; its energy evaluations synchronised the stream since
     st.last_alpha = alpha; st.energy = E; E_last = E;
     if (c->verbose >= 4) fprintf(stderr, "[tsl]   newton %2d: E0 %.12e  E - E0 %+.3e  alpha %.3g  |p|max %.3e  delta %.3e  (solve: %d its, rel_residual %.1e)\n", iter, E0, E - E0, alpha, HSC(c)->pmax, delta, ss.iters, ss.rel_residual);
     t_ls += secs(t3, now());
