@@ -111,9 +111,14 @@ int tsl_set_stream(tsl_ctx* ctx, void* hip_stream);
  * "mg_dense_nodes" (largest level solved exactly; -1 = chosen per time step, default), "mg_coarse_lag", "warm_start", "pcg_ahead", "body_inv"
  * "direct" (-1 auto / 0 / 1: multifrontal LU of the operator as preconditioner; auto = cloth grids of >= 1024 cells, after a probe of
  * the iterative hierarchy capped at "direct_probe_cap" iterations failed -- re-probed every "direct_probe_every" time steps),
- * "direct_leaf" (vertices per nested-dissection leaf), "direct_lag" (Newton iterations of a time step reuse earlier factors while the
+ * "direct_leaf" (vertices per nested-dissection leaf, default 64), "direct_lag" (Newton iterations of a time step reuse earlier factors while the
  * refinement converges within this many iterations; 0 = refactorise for every solve), "direct_fallback_cap" (a refined factorisation
  * that stalls within 1e-3 of the right-hand side is returned flagged not converged; above that the hierarchy gets this many iterations),
+ * "direct_piv_tol" (static pivoting: pivots below this fraction of their entry diagonal are perturbed to it, default 1e-8),
+ * "direct_prezero" (1: the front arena of the next factorisation is cleared on a side stream after each solve of a time step),
+ * "direct_par_batches" (1: batches of one elimination level on parallel streams), "direct_merge_k" (1: constrained body vertices share the
+ * supernode of their separator), "direct_merge_sep" (separators of at most this many vertices join the enclosing separator's supernode; 0),
+ * "tet_coop" (1: 16 lanes per tetrahedron in the element Hessians), "ds_dbg" / "ds_bench_batch" (timing experiments of tsl_bench_direct),
  * "mg_fuse_restrict" (first sweep + residual + restriction of a stencil level in one launch), "mg_st_f32" (single-precision stencil
  * operators), "mg_fr_rows", "pcg_body_fold" (dense-body first sweep inside the PCG update launch), "asm_overlap" (contact blocks on a
  * second stream), "mr_eta" (stop factor of a MINRES recurrence cycle), "mg_chunk" (multigrid-PCG iterations per graph replay; 0 = 8 on long solves, else 4),
