@@ -171,35 +171,29 @@ TSL_DEV void ds_invert_tile_wg(double (*T)[DS_T + 1], int* __restrict__ bad, int
         for (int j = 0; j < DS_PB; j++) d[i][j] = (j == p) ? -f * ip : fma(-f, d[p][j], d[i][j]);
       }
     }
-    // (Dinv R)[j][column of this lane] for the four pivot rows; the lane's own k index of the matrix-core operands is lk
-    double rcol[DS_PB], bj[DS_PB];
-#pragma unroll
-    for (int m = 0; m < DS_PB; m++) rcol[m] = rowp[buf][m][16 * wj + lr];
-#pragma unroll
-    for (int j = 0; j < DS_PB; j++) {
-      bj[j] = d[j][0] * rcol[0] + d[j][1] * rcol[1] + d[j][2] * rcol[2] + d[j][3] * rcol[3];
-      asm volatile("" : "+v"(bj[j]));   // keep the four products out of the lane-dependent selects below (the compiler otherwise sinks them into exec-mask branches)
-    }
+    // row lk of Dinv (lk = the lane's k index of the matrix-core operands), then (Dinv R)[lk][column of this lane]
     const bool k1 = lk == 1, k2 = lk == 2, k3 = lk == 3;
-    const double bop = ds_sel4(k1, k2, k3, bj[0], bj[1], bj[2], bj[3]);
+    double drow[DS_PB];
+#pragma unroll
+    for (int j = 0; j < DS_PB; j++) drow[j] = ds_sel4(k1, k2, k3, d[0][j], d[1][j], d[2][j], d[3][j]);
+    double bop = drow[0] * rowp[buf][0][16 * wj + lr] + drow[1] * rowp[buf][1][16 * wj + lr] + drow[2] * rowp[buf][2][16 * wj + lr] + drow[3] * rowp[buf][3][16 * wj + lr];
+    asm volatile("" : "+v"(bop));   // keep the product out of the lane-dependent selects below (the compiler otherwise sinks it into exec-mask branches)
     const double aop = -colp[buf][lk][16 * wi + lr];
     const ds_d4 upd = __builtin_amdgcn_mfma_f64_16x16x4f64(aop, bop, acc, 0, 0, 0);   // acc - C (Dinv R)
-    // fix-ups: pivot rows become Dinv R (Dinv inside the pivot columns), pivot columns become -C Dinv
+    // fix-ups: pivot rows become Dinv R (Dinv inside the pivot columns), pivot columns become -C Dinv.  The latter is a second
+    // matrix-core product with the operand Dinv[lk][mc] in the four pivot-column lanes and zero elsewhere (one instruction instead of
+    // 16 multiply-adds, 16 LDS reads and a column select of Dinv per lane: the block steps are bound by their instruction stream)
     const bool col_in = wj == wp && lr >= lc && lr < lc + DS_PB;
     const int mc = (lr - lc) & 3;   // pivot column index of this lane (meaningful if col_in)
-    double dcol[DS_PB];            // column mc of Dinv
     const bool m1 = mc == 1, m2 = mc == 2, m3 = mc == 3;
-#pragma unroll
-    for (int j = 0; j < DS_PB; j++) dcol[j] = ds_sel4(m1, m2, m3, d[j][0], d[j][1], d[j][2], d[j][3]);
-    const double dsel = ds_sel4(k1, k2, k3, dcol[0], dcol[1], dcol[2], dcol[3]);   // Dinv[lk][mc]
+    const double dsel = ds_sel4(m1, m2, m3, drow[0], drow[1], drow[2], drow[3]);   // Dinv[lk][mc]
+    const double bop2 = col_in ? dsel : 0.0;
+    const ds_d4 pc = __builtin_amdgcn_mfma_f64_16x16x4f64(aop, bop2, ds_d4{0.0, 0.0, 0.0, 0.0}, 0, 0, 0);   // -C Dinv in the pivot columns
 #pragma unroll
     for (int r = 0; r < 4; r++) {
       const bool row_in = wi == wp && r == rp;   // local row lk + 4 r with r == rp: pivot row j = lk
-      const int row = 16 * wi + lk + 4 * r;
-      double t = colp[buf][0][row] * dcol[0] + colp[buf][1][row] * dcol[1] + colp[buf][2][row] * dcol[2] + colp[buf][3][row] * dcol[3];
-      asm volatile("" : "+v"(t));
       const double v_row = col_in ? dsel : bop;
-      const double v_else = col_in ? -t : upd[r];
+      const double v_else = col_in ? pc[r] : upd[r];
       acc[r] = row_in ? v_row : v_else;
     }
   }
