@@ -90,6 +90,7 @@ struct ClothArgs {
   const double *V, *li;
   const int *hg_info, *hg_v;
   const double* norm_dir;
+  const int* f_order;   // processing order of the faces in the kernels that scatter with atomics: faces of one stencil class in a row (coalesced)
 };
 
 // hinge energy (Cloth.compute_bending_energy :108-120)
@@ -105,8 +106,9 @@ TSL_DEV double hinge_energy(const ClothArgs& A, int h, const double* __restrict_
 // ---------------------------------------------------------------------------------------------
 // gradient: per face (edges + area, Cloth.compute_residual :653-677), per hinge (:679-687)
 __global__ void k_cloth_grad_face(ClothArgs A, const double* __restrict__ pos, double* __restrict__ F) {
-  const int f = blockIdx.x * blockDim.x + threadIdx.x;
-  if (f >= A.n_cface) return;
+  const int t = blockIdx.x * blockDim.x + threadIdx.x;
+  if (t >= A.n_cface) return;
+  const int f = A.f_order[t];
   const ClothDev c = A.cloth[A.cid[f]];
   int v[3]; d3 P[3];
   load_face(pos, A.f2v, f, v, P);
@@ -207,8 +209,9 @@ template <bool CLAMP_ALL>
 __global__ void __launch_bounds__(128)
 k_cloth_hess_face(ClothArgs A, const int* __restrict__ blk, const double* __restrict__ pos, const double* __restrict__ ref_angle,
                   const double* __restrict__ Q, int spd, double* __restrict__ vals) {
-  const int f = blockIdx.x * blockDim.x + threadIdx.x;
-  if (f >= A.n_cface) return;
+  const int t = blockIdx.x * blockDim.x + threadIdx.x;
+  if (t >= A.n_cface) return;
+  const int f = A.f_order[t];
   const int cid = A.cid[f];
   const ClothDev c = A.cloth[cid];
   int v[3]; d3 P[3];

@@ -159,6 +159,7 @@ struct tsl_ctx {
   DevBuf<int> cf_f2v, cf_cf, cf_cp, cf_cloth;  // per cloth face (global ids): verts, counter_face, counter_point, cloth id
   DevBuf<double> cf_V, cf_li;                   // rest area, rest lengths
   DevBuf<int> cf_blk;                           // n_cface x 9 block offsets
+  DevBuf<int> cf_order;                         // faces in the order the scattering kernels take them (one stencil class after the other)
   DevBuf<int> hg_info;                          // n_hinge x 8: f1, l, f2, p4, p21, v[..] unused
   DevBuf<int> hg_v;                             // n_hinge x 4 vertex ids (a,b,c,d)
   DevBuf<int> hg_blk;                           // n_hinge x 16 block offsets
@@ -230,12 +231,12 @@ struct tsl_ctx {
   SolverScalars* h_scal2 = nullptr; // pinned, two records: read-back slots of the PCG chunks in flight
   hipEvent_t rb_event[2] = {nullptr, nullptr};
   hipStream_t side = 0;                         // second stream: contact blocks of an assembly run next to the cloth / tet kernels
-  hipEvent_t ev_fork = nullptr, ev_join = nullptr;
+  hipEvent_t ev_fork = nullptr, ev_join = nullptr, ev_join2 = nullptr;
+  hipStream_t side2 = 0;                        // third stream: the tet kernels next to the contact kernels (side) and the cloth kernels
   int asm_overlap = 1;
   int contact_coop = 1;  // 16 lanes per constraint in the contact block assembly (0: one lane per constraint)
-  int tet_coop = 0;      // 1: 16 lanes per tetrahedron in the element Hessians (k_tet_hess_coop).  Off: the one-lane-per-element kernel runs in the
-                         // shadow of the cloth kernels on the second stream with ninety waves; the cooperative one (360 waves, Jacobi in LDS) takes
-                         // their CUs: cfg4 386 -> 398 ms per step
+  int tet_coop = 0;      // 1: 16 lanes per tetrahedron in the element Hessians (k_tet_hess_coop): measured 0.76 ms per launch against 0.40 ms of the
+                         // one-lane-per-element kernel on cfg4 (5.8k elements; the group-cooperative Jacobi pays for contacts, not here): off
 
   // ---- Newton scratch (original order)
   DevBuf<double> F, pdir, x1;

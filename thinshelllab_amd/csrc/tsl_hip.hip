@@ -6,6 +6,7 @@
 #include <stdarg.h>
 #include <chrono>
 
+#include <array>
 #include <map>
 
 #include "k_cloth.hpp"
@@ -107,7 +108,7 @@ static ClothArgs cloth_args(tsl_ctx* c) {
   ClothArgs A;
   A.n_cface = c->n_cface; A.n_hinge = c->n_hinge; A.cloth = c->d_cloth.p;
   A.f2v = c->cf_f2v.p; A.cf = c->cf_cf.p; A.cp = c->cf_cp.p; A.cid = c->cf_cloth.p;
-  A.V = c->cf_V.p; A.li = c->cf_li.p; A.hg_info = c->hg_info.p; A.hg_v = c->hg_v.p; A.norm_dir = c->norm_dir.p;
+  A.V = c->cf_V.p; A.li = c->cf_li.p; A.hg_info = c->hg_info.p; A.hg_v = c->hg_v.p; A.norm_dir = c->norm_dir.p; A.f_order = c->cf_order.p;
   return A;
 }
 static VertArgs vert_args(tsl_ctx* c) {
@@ -196,6 +197,27 @@ extern "C" int tsl_ctx_create(const tsl_scene_desc* d, tsl_ctx** out) {
   }
   c->n_cface = face_start;
   c->n_hinge = (int)hv.size() / 4;
+  {
+    // Hinges sorted by stencil class (the offsets of their four vertices relative to the first), then by first vertex: the lanes of
+    // a wave then add into CONSECUTIVE matrix rows (same block slot, neighbouring SELL lanes) -- 144 coalesced atomics per lane
+    // instead of scattered ones.  Every hinge-indexed quantity is addressed through (face, edge), so the order is free.
+    const int nh = c->n_hinge;
+    std::map<std::array<int, 3>, int> cls;
+    std::vector<int> key(nh), idx(nh);
+    for (int h = 0; h < nh; h++) {
+      const std::array<int, 3> t{hv[4 * h + 1] - hv[4 * h], hv[4 * h + 2] - hv[4 * h], hv[4 * h + 3] - hv[4 * h]};
+      auto it = cls.find(t);
+      if (it == cls.end()) it = cls.emplace(t, (int)cls.size()).first;
+      key[h] = it->second; idx[h] = h;
+    }
+    std::stable_sort(idx.begin(), idx.end(), [&](int x, int y) { return key[x] != key[y] ? key[x] < key[y] : hv[4 * x] < hv[4 * y]; });
+    std::vector<int> hinfo2(hinfo.size()), hv2(hv.size());
+    for (int h = 0; h < nh; h++) {
+      std::copy(hinfo.begin() + 8 * (size_t)idx[h], hinfo.begin() + 8 * (size_t)idx[h] + 8, hinfo2.begin() + 8 * (size_t)h);
+      std::copy(hv.begin() + 4 * (size_t)idx[h], hv.begin() + 4 * (size_t)idx[h] + 4, hv2.begin() + 4 * (size_t)h);
+    }
+    hinfo.swap(hinfo2); hv.swap(hv2);
+  }
   c->h_cf_f2v = f2v; c->h_cf_cf = cf; c->h_cf_cp = cp;
 
   // ---- tets
@@ -241,6 +263,19 @@ extern "C" int tsl_ctx_create(const tsl_scene_desc* d, tsl_ctx** out) {
 
 #define UP(buf, vec) do { if (c->buf.upload(vec)) { delete c; return -1; } } while (0)
   UP(d_cloth, c->h_cloth); UP(cf_f2v, f2v); UP(cf_cf, cf); UP(cf_cp, cp); UP(cf_cloth, cid); UP(cf_V, V); UP(cf_li, li);
+  std::vector<int> forder(c->n_cface);
+  {
+    std::map<std::array<int, 3>, int> cls;
+    std::vector<int> key(c->n_cface);
+    for (int f = 0; f < c->n_cface; f++) {
+      const std::array<int, 3> t{f2v[3 * f + 1] - f2v[3 * f], f2v[3 * f + 2] - f2v[3 * f], 0};
+      auto it = cls.find(t);
+      if (it == cls.end()) it = cls.emplace(t, (int)cls.size()).first;
+      key[f] = it->second; forder[f] = f;
+    }
+    std::stable_sort(forder.begin(), forder.end(), [&](int x, int y) { return key[x] != key[y] ? key[x] < key[y] : f2v[3 * x] < f2v[3 * y]; });
+  }
+  UP(cf_order, forder);
   UP(cf_blk, cfblk); UP(hg_info, hinfo); UP(hg_v, hv); UP(hg_blk, hgblk);
   UP(d_el, c->h_el); UP(tet_v, tv); UP(tet_el, tel); UP(tet_blk, tetblk); UP(tet_B, tB); UP(tet_W, tW);
   UP(diag_blk, dblk); UP(rowpos, P.rowpos); UP(perm, P.perm); UP(slice_off, P.slice_off); UP(slice_len, P.slice_len); UP(colidx, P.colidx);
@@ -267,7 +302,8 @@ extern "C" int tsl_ctx_create(const tsl_scene_desc* d, tsl_ctx** out) {
   if (hipHostMalloc((void**)&c->h_scal2, 2 * sizeof(SolverScalars)) != hipSuccess) { delete c; return tsl_fail("hipHostMalloc failed"); }
   for (int i = 0; i < 2; i++)
     if (hipEventCreateWithFlags(&c->rb_event[i], hipEventDisableTiming) != hipSuccess) { delete c; return tsl_fail("hipEventCreate failed"); }
-  if (hipStreamCreateWithFlags(&c->side, hipStreamNonBlocking) != hipSuccess || hipEventCreateWithFlags(&c->ev_fork, hipEventDisableTiming) != hipSuccess ||
+  if (hipStreamCreateWithFlags(&c->side, hipStreamNonBlocking) != hipSuccess || hipStreamCreateWithFlags(&c->side2, hipStreamNonBlocking) != hipSuccess ||
+      hipEventCreateWithFlags(&c->ev_join2, hipEventDisableTiming) != hipSuccess || hipEventCreateWithFlags(&c->ev_fork, hipEventDisableTiming) != hipSuccess ||
       hipEventCreateWithFlags(&c->ev_join, hipEventDisableTiming) != hipSuccess) { delete c; return tsl_fail("side stream / event creation failed"); }
   c->vals.zero(); c->vals_full.zero(); c->scal.zero(); c->part_rz.zero(); c->part_rr.zero();
 
@@ -300,6 +336,8 @@ extern "C" void tsl_ctx_destroy(tsl_ctx* c) {
   if (c->ev_fork) (void)hipEventDestroy(c->ev_fork);
   if (c->ev_join) (void)hipEventDestroy(c->ev_join);
   if (c->side) (void)hipStreamDestroy(c->side);
+  if (c->ev_join2) (void)hipEventDestroy(c->ev_join2);
+  if (c->side2) (void)hipStreamDestroy(c->side2);
   if (c->stream) (void)hipStreamDestroy(c->stream);
   for (auto& e : c->ev_pool) { (void)hipEventDestroy(e.first); (void)hipEventDestroy(e.second); }
   delete c;
@@ -486,18 +524,22 @@ static int assemble(tsl_ctx* c, const double* pos, const double* prev, const dou
   // (face 0.15 ms + hinge 0.28 ms): they share nothing but the zeroed gradient / matrix, which both sides only add to.
   const bool fork = c->asm_overlap && (c->nc > 0 || c->n_tet > 0);
   if (grad) hipLaunchKernelGGL(k_vert_grad, dim3(nblk(NV, 256)), dim3(256), 0, s, VA, pos, prev, vel, grad);   // before the fork: it may store, the others add
-  hipStream_t st = fork ? c->side : s;   // stream of the tet and contact kernels
+  hipStream_t st = fork ? c->side : s;   // stream of the contact kernels
+  const bool fork_t = fork && c->n_tet > 0 && c->nc > 0;   // the element kernels of the FEM bodies on a stream of their own (0.4 ms: one lane per element, latency-bound)
+  hipStream_t stt = fork_t ? c->side2 : st;
   if (fork) {
     HIP_OK(hipEventRecord(c->ev_fork, s));
     HIP_OK(hipStreamWaitEvent(c->side, c->ev_fork, 0));
+    if (fork_t) HIP_OK(hipStreamWaitEvent(c->side2, c->ev_fork, 0));
   }
   if (c->n_tet) {
-    if (grad) hipLaunchKernelGGL(k_tet_grad, dim3(nblk(c->n_tet, 256)), dim3(256), 0, st, TA, pos, grad);
-    if (c->tet_coop) hipLaunchKernelGGL(k_tet_hess_coop, dim3(nblk((long)c->n_tet * 16, 256)), dim3(256), 0, st, TA, c->tet_blk.p, pos, spd, c->vals_full.p);
-    else hipLaunchKernelGGL(k_tet_hess, dim3(nblk(c->n_tet, 64)), dim3(64), 0, st, TA, c->tet_blk.p, pos, spd, c->vals_full.p);
+    if (grad) hipLaunchKernelGGL(k_tet_grad, dim3(nblk(c->n_tet, 256)), dim3(256), 0, stt, TA, pos, grad);
+    if (c->tet_coop) hipLaunchKernelGGL(k_tet_hess_coop, dim3(nblk((long)c->n_tet * 16, 256)), dim3(256), 0, stt, TA, c->tet_blk.p, pos, spd, c->vals_full.p);
+    else hipLaunchKernelGGL(k_tet_hess, dim3(nblk(c->n_tet, 64)), dim3(64), 0, stt, TA, c->tet_blk.p, pos, spd, c->vals_full.p);
   }
   TSL_TRY(contact_assemble(c, pos, spd, grad, st));
   if (fork) HIP_OK(hipEventRecord(c->ev_join, c->side));
+  if (fork_t) HIP_OK(hipEventRecord(c->ev_join2, c->side2));
   if (grad) {
     if (c->n_cface) hipLaunchKernelGGL(k_cloth_grad_face, dim3(nblk(c->n_cface, 256)), dim3(256), 0, s, CA, pos, grad);
     if (c->n_hinge) hipLaunchKernelGGL(k_cloth_grad_hinge, dim3(nblk(c->n_hinge, 256)), dim3(256), 0, s, CA, pos, ref, grad);
@@ -511,6 +553,7 @@ static int assemble(tsl_ctx* c, const double* pos, const double* prev, const dou
   }
   if (c->n_hinge) hipLaunchKernelGGL(k_cloth_hess_hinge, dim3(nblk(c->n_hinge, 256)), dim3(256), 0, s, CA, c->hg_blk.p, pos, c->vals_full.p);
   if (fork) HIP_OK(hipStreamWaitEvent(s, c->ev_join, 0));
+  if (fork_t) HIP_OK(hipStreamWaitEvent(s, c->ev_join2, 0));
   if (grad) hipLaunchKernelGGL(k_mask_vec, dim3(gsz(3 * (size_t)NV)), dim3(256), 0, s, 3 * (size_t)NV, c->frozen.p, grad);
   hipLaunchKernelGGL(k_mask_matrix, dim3(c->n_slices), dim3(256), 0, s, c->n_slices, c->slice_off.p, c->slice_len.p, c->colidx.p, c->fzmask.p, c->mdt2.p,
                      c->vals_full.p, c->vals.p, NV);
