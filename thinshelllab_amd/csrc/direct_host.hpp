@@ -20,10 +20,11 @@ static inline bool ds_use_small(const DsBatch& b) {
 
 // G = W F12 (mode 0) / S = F22 - F21 G added into the parents (mode 1) of a batch.  A 128 x 128-tile variant (64 accumulator
 // registers per lane, one wave per SIMD) was 2.5x slower than these 64 x 64 tiles, which reach 25-49 TFLOP/s per level on cfg4.
-static void ds_launch_gemm(hipStream_t s, const DsDev& D, const DsBatch& b, int mode) {
+static void ds_launch_gemm(hipStream_t s, const DsDev& D, const DsBatch& b, int mode, int wpc) {
   const int rows = mode == 0 ? b.max_pp : b.max_bp, cols = b.max_bp;
-  if (mode == 0) hipLaunchKernelGGL((k_ds_gemm<0>), dim3((cols + 63) / 64, (rows + 63) / 64, b.count), dim3(256), 0, s, D, b.first);
-  else hipLaunchKernelGGL((k_ds_gemm<1>), dim3((cols + 63) / 64, (rows + 63) / 64, b.count), dim3(256), 0, s, D, b.first);
+  const dim3 grid((cols + 63) / 64, (rows + 63) / 64, b.count);
+  if (mode == 0) { if (wpc >= 4) hipLaunchKernelGGL((k_ds_gemm<0, 4>), grid, dim3(256), 0, s, D, b.first); else hipLaunchKernelGGL((k_ds_gemm<0, 3>), grid, dim3(256), 0, s, D, b.first); }
+  else { if (wpc >= 4) hipLaunchKernelGGL((k_ds_gemm<1, 4>), grid, dim3(256), 0, s, D, b.first); else hipLaunchKernelGGL((k_ds_gemm<1, 3>), grid, dim3(256), 0, s, D, b.first); }
 }
 
 static bool direct_enabled(tsl_ctx* c) {
@@ -162,12 +163,12 @@ static int direct_factor(tsl_ctx* c, int stop_sn = -1, const char* dump_path = n
     if (ds_use_small(b)) hipLaunchKernelGGL(k_ds_inv_small, dim3(nf), dim3(256), ds_small_lds(b.max_pp), bs, D, lv0, b.max_pp + 1);
     else {
       hipLaunchKernelGGL(k_ds_pivot0, dim3(nf), dim3(256), 0, bs, D, lv0);
-      for (int k = 0; k < tp; k++) hipLaunchKernelGGL(k_ds_gj_step, dim3(tp, tp, P.act_n[b.act_off + k]), dim3(256), 0, bs, D, lv0, k);   // fronts are sorted by pp: the active ones are a prefix
+      for (int k = 0; k < tp; k++) { const int na = P.act_n[b.act_off + k]; hipLaunchKernelGGL(k_ds_gj_step, dim3(na + na * tp * tp), dim3(256), 0, bs, D, lv0, k, tp, na); }   // fronts are sorted by pp: the active ones are a prefix
       hipLaunchKernelGGL(k_ds_gj_finish, dim3(tp, nf), dim3(256), 0, bs, D, lv0);
     }
     if (tb > 0) {
-      ds_launch_gemm(bs, D, b, 0);
-      ds_launch_gemm(bs, D, b, 1);   // + extend-add into the parents
+      ds_launch_gemm(bs, D, b, 0, d.gemm_wpc);
+      ds_launch_gemm(bs, D, b, 1, d.gemm_wpc);   // + extend-add into the parents
     }
   };
   // The fronts of a level are independent: where a level was split into batches (by pivot-block size) the batches run on parallel
@@ -287,7 +288,7 @@ static int direct_bench(tsl_ctx* c, int cls, int reps, double* out) {
         if (ds_use_small(b)) { hipLaunchKernelGGL(k_ds_inv_small, dim3(nf), dim3(256), ds_small_lds(b.max_pp), s, D, lv0, b.max_pp + 1); if (count) launches++; }
         else {
           hipLaunchKernelGGL(k_ds_pivot0, dim3(nf), dim3(256), 0, s, D, lv0);
-          for (int k = 0; k < tp; k++) hipLaunchKernelGGL(k_ds_gj_step, dim3(tp, tp, P.act_n[b.act_off + k]), dim3(256), 0, s, D, lv0, k);
+          for (int k = 0; k < tp; k++) { const int na = P.act_n[b.act_off + k]; hipLaunchKernelGGL(k_ds_gj_step, dim3(na + na * tp * tp), dim3(256), 0, s, D, lv0, k, tp, na); }
           hipLaunchKernelGGL(k_ds_gj_finish, dim3(tp, nf), dim3(256), 0, s, D, lv0);
           if (count) launches += tp + 2;
         }
@@ -297,7 +298,7 @@ static int direct_bench(tsl_ctx* c, int cls, int reps, double* out) {
           bytes += 16.0 * (double)f.pp * f.pp * (ds_use_small(b) ? 1.0 : f.pp / (double)DS_T);   // the block read and written once per launch that touches it
         }
       } else if (tb > 0) {
-        if (cls == 1 || cls == 2) ds_launch_gemm(s, D, b, cls == 2 ? 0 : 1);
+        if (cls == 1 || cls == 2) ds_launch_gemm(s, D, b, cls == 2 ? 0 : 1, d.gemm_wpc);
         else continue;
         if (count) {
           launches++;

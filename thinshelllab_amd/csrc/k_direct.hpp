@@ -241,19 +241,22 @@ TSL_DEV double ds_tile_elem(const double* __restrict__ A, int ld, const double* 
   if (tj == kp) return Cs[(size_t)(ti * DS_T + r) * DS_T + c];
   return A[(size_t)(ti * DS_T + r) * ld + tj * DS_T + c];
 }
-__global__ void __launch_bounds__(256) k_ds_gj_step(DsDev D, int lv0, int k) {
+// Launch shape: 1-D grid of nf + nf tp^2 workgroups -- the first nf are the pivot workgroups (tile (k+1, k+1)) of the nf fronts, so
+// that the longest workgroup of EVERY front is dispatched before any of the update tiles (with a (tp, tp, nf) grid the pivot
+// workgroup of front z sat behind z tp^2 others, and the launch ended one dispatch round later), then the tiles front by front.
+__global__ void __launch_bounds__(256) k_ds_gj_step(DsDev D, int lv0, int k, int tp, int nf) {
   __shared__ double Ps[DS_T][DS_T + 1];
   __shared__ double T1[DS_T][DS_T + 1];   // A[K, j], later R'_j
   __shared__ double T2[DS_T][DS_T + 1];   // A[i, K], later the next pivot block
-  const DsFrontDesc f = D.fr[D.level_sn[lv0 + blockIdx.z]];
+  const int L = blockIdx.x;
+  int fz = L, bi = k + 1, bj = k + 1;
+  if (L >= nf) { const int q = L - nf, t2 = tp * tp; fz = q / t2; const int t = q - fz * t2; bi = t / tp; bj = t - bi * tp; }
+  const DsFrontDesc f = D.fr[D.level_sn[lv0 + fz]];
   const int pp = f.pp, k0 = k * DS_T;
   if (k0 >= pp) return;
-  int bi = blockIdx.y, bj = blockIdx.x;
   const bool has_next = k0 + DS_T < pp;
-  if (has_next) {
-    if (bi == 0 && bj == 0) bi = bj = k + 1;
-    else if (bi == k + 1 && bj == k + 1) bi = bj = 0;
-  }
+  if (L < nf) { if (!has_next) return; }
+  else if (has_next && bi == k + 1 && bj == k + 1) return;   // done by the pivot workgroup
   if (bi * DS_T >= pp || bj * DS_T >= pp) return;
   const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;
   const int lane = threadIdx.x & 63, w = threadIdx.x >> 6, wi = w >> 1, wj = w & 1, lr = lane & 15, lk = lane >> 4;
@@ -317,7 +320,7 @@ __global__ void __launch_bounds__(256) k_ds_gj_step(DsDev D, int lv0, int k) {
   }
   if (next_pivot) {
     __syncthreads();
-    if (D.dbg != 1) ds_invert_tile_wg(T2, D.bad, DS_CLS(f), (D.level_sn[lv0 + blockIdx.z] << 6) | (k + 1), D.piv_tol);
+    if (D.dbg != 1) ds_invert_tile_wg(T2, D.bad, DS_CLS(f), (D.level_sn[lv0 + fz] << 6) | (k + 1), D.piv_tol);
     double* Pn = ds_scr_P(D, f, (k + 1) & 1);
 #pragma unroll
     for (int q = 0; q < 4; q++) Pn[(ty + 8 * q) * DS_T + tx] = T2[ty + 8 * q][tx];
@@ -436,12 +439,22 @@ __global__ void __launch_bounds__(256) k_ds_inv_small(DsDev D, int lv0, int ls) 
 // ---- the two GEMMs of a front on the f64 matrix cores -------------------------------------------------------------------------
 //   mode 0:  G = W F12            (pp x bp, K = pp)  into the G arena (row stride bp)
 //   mode 1:  S = F22 - F21 G      (bp x bp, K = pp)  in place
-// one 64 x 64 output tile per workgroup (four waves, each a 32 x 32 quadrant = 2 x 2 MFMA tiles), K in chunks of 32 through LDS
+// one 64 x 64 output tile per workgroup (four waves, each a 32 x 32 quadrant = 2 x 2 MFMA tiles), K in slabs of 32 through LDS.
+// LDS strides: the A operand of v_mfma_f64_16x16x4_f64 is read by lane (lr, lk) at [row lr][k lk], the B operand at [k lk][col lr];
+// ds_read_b64 serves lanes 0-31 and 32-63 in one cycle each when their 32 doubles fall into 32 different 8-byte bank pairs: row
+// stride == 2 (mod 32) doubles for A (2 lr + lk), == 16 (mod 32) for B (16 lk + lr); strides 33 / 65 were 2-way conflicts.
+// WPC = workgroups per CU the register allocation aims at (one wave of each per SIMD): 3 with the F22 tile of the Schur mode
+// prefetched before the product, 4 with that tile fetched in the epilogue ("direct_gemm_wpc").
+// Measured and dropped (round 2, cfg4 plan, per-batch replays): K slabs of 64 (half the barriers and load round trips, two
+// workgroups per CU: 2-4 % slower on every level), an XCD-aware workgroup -> tile map (each XCD a contiguous tile range: no change
+// on the levels above the leaves, the leaf batch 77 instead of 49 us) -- the launches are bound neither by the LDS nor by the L2.
 #define DS_SK 32
-template <int mode>
-__global__ void __launch_bounds__(256) k_ds_gemm(DsDev D, int lv0) {
-  __shared__ double As[64][DS_SK + 1];
-  __shared__ double Bs[DS_SK][64 + 1];
+template <int mode, int WPC>
+__global__ void __launch_bounds__(256, WPC) k_ds_gemm(DsDev D, int lv0) {
+  constexpr int SA = DS_SK + 2, SB = 64 + 16;
+  constexpr bool PF = WPC <= 3;
+  __shared__ double As[64 * SA];
+  __shared__ double Bs[DS_SK * SB];
   const DsFrontDesc f = D.fr[D.level_sn[lv0 + blockIdx.z]];
   const int Mr = mode == 0 ? f.pp : f.bp, Nc = f.bp, K = f.pp;
   const int I0 = blockIdx.y * 64, J0 = blockIdx.x * 64;
@@ -464,7 +477,7 @@ __global__ void __launch_bounds__(256) k_ds_gemm(DsDev D, int lv0) {
   const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;  // 32 x 8
   // Schur mode: the F22 entries of this workgroup's tile are fetched before the product (their latency hides behind it)
   double f22[2][2][4];
-  if (mode == 1) {
+  auto load_f22 = [&]() {
 #pragma unroll
     for (int a = 0; a < 2; a++)
 #pragma unroll
@@ -474,7 +487,8 @@ __global__ void __launch_bounds__(256) k_ds_gemm(DsDev D, int lv0) {
           const int row = I0 + 32 * wi + 16 * a + lk + 4 * r, col = J0 + 32 * wj + 16 * b + lr;
           f22[a][b][r] = (row < f.b && col < f.b) ? F[(size_t)(pp + row) * ld + pp + col] : 0.0;
         }
-  }
+  };
+  if (mode == 1 && PF) load_f22();
   // K loop, software-pipelined: the global loads of slab k + 1 are in flight (registers) while the matrix cores work on slab k in LDS
   double pa[8], pb0[4], pb1[4];
   auto gload = [&](int k0) {
@@ -493,15 +507,15 @@ __global__ void __launch_bounds__(256) k_ds_gemm(DsDev D, int lv0) {
   gload(0);
   for (int k0 = 0; k0 < K; k0 += DS_SK) {
 #pragma unroll
-    for (int q = 0; q < 8; q++) As[ty + 8 * q][tx] = pa[q];
+    for (int q = 0; q < 8; q++) As[(ty + 8 * q) * SA + tx] = pa[q];
 #pragma unroll
-    for (int q = 0; q < 4; q++) { Bs[ty + 8 * q][tx] = pb0[q]; Bs[ty + 8 * q][tx + 32] = pb1[q]; }
+    for (int q = 0; q < 4; q++) { Bs[(ty + 8 * q) * SB + tx] = pb0[q]; Bs[(ty + 8 * q) * SB + tx + 32] = pb1[q]; }
     __syncthreads();
     if (k0 + DS_SK < K) gload(k0 + DS_SK);
 #pragma unroll
     for (int kk = 0; kk < DS_SK / 4; kk++) {
-      const double a0 = As[32 * wi + lr][4 * kk + lk], a1 = As[32 * wi + 16 + lr][4 * kk + lk];
-      const double b0 = Bs[4 * kk + lk][32 * wj + lr], b1 = Bs[4 * kk + lk][32 * wj + 16 + lr];
+      const double a0 = As[(32 * wi + lr) * SA + 4 * kk + lk], a1 = As[(32 * wi + 16 + lr) * SA + 4 * kk + lk];
+      const double b0 = Bs[(4 * kk + lk) * SB + 32 * wj + lr], b1 = Bs[(4 * kk + lk) * SB + 32 * wj + 16 + lr];
       acc[0][0] = __builtin_amdgcn_mfma_f64_16x16x4f64(a0, b0, acc[0][0], 0, 0, 0);
       acc[0][1] = __builtin_amdgcn_mfma_f64_16x16x4f64(a0, b1, acc[0][1], 0, 0, 0);
       acc[1][0] = __builtin_amdgcn_mfma_f64_16x16x4f64(a1, b0, acc[1][0], 0, 0, 0);
@@ -524,6 +538,7 @@ __global__ void __launch_bounds__(256) k_ds_gemm(DsDev D, int lv0) {
   // Schur complement: S is needed by nobody but the parent front, so the entries go straight into it through the child's
   // boundary -> parent index map (extend-add; f64 atomics: sibling fronts overlap) instead of being stored and re-read
   if (f.parent < 0) return;
+  if (!PF) load_f22();
   const DsFrontDesc pf = D.fr[f.parent];
   double* PA = D.A + pf.off;
   const int* rel = D.rel + f.rel_off;

@@ -103,6 +103,7 @@ struct DirectSolver {
   hipStream_t fstream[2] = {nullptr, nullptr};   // batches of one level run next to each other (direct_factor)
   hipEvent_t ev_ffork = nullptr, ev_fjoin[2] = {nullptr, nullptr};
   int par_batches = 1;      // "direct_par_batches"
+  int gemm_wpc = 4;         // "direct_gemm_wpc": workgroups per CU the GEMM kernels are compiled for (3: F22 tile prefetched, 4: fetched in the epilogue)
   bool cons_checked = false; // the constraint list has not changed since direct_plan last looked (reset by tsl_contact_detect)
   double* h_anorm = nullptr; // pinned: |H|_inf of the last factorisation (valid after the next stream synchronisation)
   int bench_batch = -1;     // tsl_bench_direct: restrict the replay to one batch (-1: all)
