@@ -1538,7 +1538,8 @@ static int gmres(tsl_ctx* c, tsl_solve_stats* st, bool direct) {
       g[j + 1] = -sn[j] * g[j];
       g[j] = cs[j] * g[j];
       st->rel_residual = fabs(g[j + 1]) / sqrt(bb);
-      if (fabs(g[j + 1]) <= 0.5 * tol || !(hn > 0)) { j++; break; }
+      if (direct && c->verbose >= 5) fprintf(stderr, "[tsl]     refinement %d: rel_residual %.2e\n", total, st->rel_residual);
+      if (fabs(g[j + 1]) <= (direct ? 1.0 : 0.5) * tol || !(hn > 0)) { j++; break; }   // the true residual is checked below either way
       hipLaunchKernelGGL(k_axpby, dim3(gv), dim3(256), 0, s, n3, 1.0 / hn, w, 0.0, vj1);
     }
     // y = R^-1 g ; x += M^-1 (V y)
