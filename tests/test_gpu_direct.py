@@ -42,6 +42,22 @@ def test_direct_solve_matches_sparse_lu(N, M, leaf):
     assert st2["method"] == 0 and rel_err(x2.cpu().numpy(), xs) < 1e-7
 
 
+@pytest.mark.parametrize("wpc", [3, 4])
+def test_direct_gemm_occupancy_variants_agree(wpc):
+    """k_ds_gemm is compiled for three (F22 tile prefetched) and four (fetched in the epilogue) workgroups per CU
+    ("direct_gemm_wpc"); both factorise a grid with several levels of Schur complements to the same answer as scipy's LU"""
+    import scipy.sparse.linalg as spl
+    s = _drape(70, 45, 5e-5, seed=2)
+    ctx = s._ensure_ctx()
+    ctx.set_param("direct", 1); ctx.set_param("direct_leaf", 16); ctx.set_param("direct_gemm_wpc", wpc)
+    s.compute_residual_and_Hessian(spd=True)
+    b = s.F.to_torch().clone()
+    x, st = ctx.solve(b)
+    xs = spl.splu(ctx.operator_csr().tocsc()).solve(b.cpu().numpy())
+    assert st["flag"] == 0 and st["method"] == 4 and st["iters"] <= 3, st
+    assert rel_err(x.cpu().numpy(), xs) < 1e-9
+
+
 def test_direct_solve_indefinite_operator():
     """un-projected Hessian of a strongly perturbed cloth (adjoint systems): indefinite, no pivoting inside the factorisation"""
     import scipy.sparse.linalg as spl
