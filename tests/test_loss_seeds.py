@@ -101,3 +101,81 @@ def test_apply_action_limit_grad_matches_reference_loop():
             if np.sqrt(dp @ dp) + np.sqrt(dr @ dr) * 0.015 > agent.max_moving_dist - 0.00005:
                 ref[step, j] += ref[step + 1, j]
     assert np.allclose(g.gripper_grad.to_numpy(), ref, rtol=1e-13, atol=0)
+
+
+def _fake_constraints(s, n=40, seed=3):
+    rng = np.random.default_rng(seed)
+    idx = rng.integers(0, s.tot_NV, size=(n, 4)).astype(np.int32)
+    w = rng.random((n, 3))   # NOT normalised: with barycentric weights the pick variant's sum over w1 = (w, -1) cancels to rounding noise
+    T = rng.normal(size=(n, 2, 3))
+    return dict(idx=idx, w=w, k=rng.random(n) * 50, dx0=rng.normal(size=(n, 3)) * 1e-5, T=T.reshape(n, 6), n=rng.normal(size=(n, 3)),
+                mu=0.1 + rng.random(n))
+
+
+def _slip_scene(s):
+    s.eps_v = 0.01; s.k_contact = 500.0; s.h = s.dt
+    return s
+
+
+def test_static_friction_loss_matches_reference_loops():
+    """BaseScene.static_friction_loss (BaseScene.py:732-775) and the Scene_pick override (Scene_pick.py:193-236) against literal
+    restatements of the two kernels on synthetic constraints: sliding and sticking contacts, constraints on the table body"""
+    from thinshelllab_amd.engine.BaseScene import BaseScene
+    from thinshelllab_amd.task_scene.Scene_pick import Scene as PickScene
+    s, g = _grad(T=4)
+    _slip_scene(s)
+    s._friction_slip = lambda c=None, p=None: BaseScene._friction_slip(s, c, p)
+    c = _fake_constraints(s)
+    rng = np.random.default_rng(9)
+    pos = rng.normal(size=(s.tot_NV, 3)) * 3e-5      # slips around dt eps_v = 5e-5: both branches of the threshold and of f1
+    g.f_loss_ratio = 0.37
+    step = 2
+    thr = s.dt * s.eps_v * 0.9
+
+    def slip(i):
+        idx, w = c["idx"][i], c["w"][i]
+        x_c = pos[idx[0]] * w[0] + pos[idx[1]] * w[1] + pos[idx[2]] * w[2]
+        T = c["T"][i].reshape(2, 3)
+        u = T @ (pos[idx[3]] - x_c - c["dx0"][i])
+        return idx, w, T, u, np.linalg.norm(u)
+
+    # BaseScene variant
+    g.pos_grad.fill(0)
+    BaseScene.static_friction_loss(s, g, step, constraints=c, pos=pos)
+    ref = np.zeros((4, s.tot_NV, 3)); n_sl = 0
+    for i in range(len(c["k"])):
+        idx, w, T, u, r = slip(i)
+        if r > thr:
+            n_sl += 1
+            w1 = np.array([-w[0], -w[1], -w[2], 1.0])
+            u3 = np.array([u[0] * T[0, j] + u[1] * T[1, j] for j in range(3)])
+            for i1 in range(4):
+                for j1 in range(3):
+                    ref[step, idx[i1], j1] += u3[j1] * w1[i1] * g.f_loss_ratio * c["k"][i]
+    assert 0 < n_sl < len(c["k"])
+    assert np.allclose(g.pos_grad.to_numpy(), ref, rtol=1e-13, atol=1e-18)
+
+    # Scene_pick variant: constraints that touch elastics[0] (the table pair, i < nc1 in the reference) are skipped
+    e0 = s.elastics[0]
+    g.pos_grad.fill(0)
+    PickScene.static_friction_loss(s, g, step, constraints=c, pos=pos)
+    ref = np.zeros((4, s.tot_NV, 3)); n_used = 0
+    h = s.eps_v * s.dt
+    for i in range(len(c["k"])):
+        idx, w, T, u, r = slip(i)
+        if any(e0.offset <= v < e0.offset + e0.n_verts for v in idx):
+            continue
+        if r > thr:
+            n_used += 1
+            f1 = 1.0 / r if r > h else -r / h ** 2 + 2.0 / h
+            pressure = c["k"][i] / c["mu"][i]
+            g1 = (u * c["k"][i] * f1) @ T
+            w1 = np.array([w[0], w[1], w[2], -1.0])
+            for i1 in range(4):
+                for j1 in range(3):
+                    dfdp = w1[i1] * g1[j1] / pressure
+                    for i2 in range(4):
+                        for j2 in range(3):
+                            ref[step - 1, idx[i2], j2] += -dfdp * w1[i2] * c["n"][i][j2] * s.k_contact * g.f_loss_ratio
+    assert n_used > 0
+    assert np.allclose(g.pos_grad.to_numpy(), ref, rtol=1e-11, atol=1e-16)

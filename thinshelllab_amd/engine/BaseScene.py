@@ -269,6 +269,37 @@ class BaseScene:
             f[e.offset:e.offset + e.n_verts] += e.ext_force.to_numpy()
         return f
 
+    # ------------------------------------------------------------------ static-friction loss (BaseScene.py:732-775)
+    def _friction_slip(self, constraints=None, pos=None):
+        """tangential slip of every constraint of the current step: (constraints, u (nc, 2), r (nc,), sliding mask r > 0.9 dt eps_v)
+        -- the quantities both static_friction_loss variants start from (BaseScene.py:745-750, Scene_pick.py:205-211).  Host side:
+        the reference never calls these kernels (analytic_grad_single.py:231 is commented out), they complete the named surface."""
+        import numpy as np
+        c = self._ensure_ctx().constraints() if constraints is None else constraints
+        x = self.pos.to_numpy() if pos is None else pos
+        idx, w = c["idx"], c["w"]
+        T = c["T"].reshape(-1, 2, 3)
+        x_c = (x[idx[:, :3]] * w[:, :, None]).sum(1)
+        dx = x[idx[:, 3]] - x_c - c["dx0"]
+        u = np.einsum("nij,nj->ni", T, dx)
+        r = np.linalg.norm(u, axis=1)
+        return c, T, u, r, r > self.dt * self.eps_v * 0.9
+
+    def static_friction_loss(self, analy_grad, step, constraints=None, pos=None):
+        """BaseScene.py:732-775: pos_grad[step, idx[i1]] += u_3d w1[i1] f_loss_ratio k for every sliding constraint,
+        u_3d = T^T u, w1 = (-w0, -w1, -w2, 1)"""
+        import numpy as np
+        c, T, u, r, sl = self._friction_slip(constraints, pos)
+        if not sl.any():
+            return
+        u3 = np.einsum("nij,ni->nj", T, u)
+        w1 = np.concatenate([-c["w"], np.ones((len(r), 1))], 1)
+        g = analy_grad.pos_grad.to_numpy()
+        add = u3[:, None, :] * w1[:, :, None] * (analy_grad.f_loss_ratio * c["k"])[:, None, None]
+        for i1 in range(4):
+            np.add.at(g[step], c["idx"][sl, i1], add[sl, i1])
+        analy_grad.pos_grad.from_numpy(g)
+
     # contact relationship of contact_analysis (BaseScene.py:818-835); scenes override
     def contact_pairs(self):
         pairs = []

@@ -70,6 +70,32 @@ class Scene(BaseScene):
                 pairs.append((e.body_idx, c.offset, c.offset + c.NV, mu))
         return pairs
 
+    def static_friction_loss(self, analy_grad, step, constraints=None, pos=None):
+        """Scene_pick.py:193-236 (call site commented out in the reference, analytic_grad_single.py:231): for the sliding
+        constraints recorded after the table pair (i >= nc1, i.e. every constraint that does not touch elastics[0]) the friction
+        force per unit pressure, pushed onto the contact normals of the PREVIOUS step:
+        pos_grad[step - 1, idx[i2]] += -dfdp w1[i2] n k_contact f_loss_ratio, dfdp = w1[i1] (T^T (u k f1(r)))[j1] / (k / mu) summed
+        over (i1, j1), w1 = (w0, w1, w2, -1).  The engine appends constraints in no fixed order, so the nc1 split is taken from the
+        vertices: a constraint of the table pair has a vertex inside elastics[0]."""
+        import numpy as np
+        c, T, u, r, sl = self._friction_slip(constraints, pos)
+        e0 = self.elastics[0]
+        table = ((c["idx"] >= e0.offset) & (c["idx"] < e0.offset + e0.n_verts)).any(1)
+        sl = sl & ~table
+        if not sl.any():
+            return
+        h = self.eps_v * self.dt
+        f1 = np.where(r > h, 1.0 / np.maximum(r, 1e-300), -r / h ** 2 + 2.0 / h)   # BaseScene.f1 (:463-469)
+        g1 = np.einsum("nij,ni->nj", T, u * (c["k"] * f1)[:, None])
+        w1 = np.concatenate([c["w"], -np.ones((len(r), 1))], 1)
+        pressure = c["k"] / c["mu"]
+        dfdp = (w1.sum(1) * g1.sum(1)) / pressure          # the reference accumulates over every (i1, j1)
+        g = analy_grad.pos_grad.to_numpy()
+        add = -(dfdp * self.k_contact * analy_grad.f_loss_ratio)[:, None, None] * w1[:, :, None] * c["n"][:, None, :]
+        for i2 in range(4):
+            np.add.at(g[step - 1], c["idx"][sl, i2], add[sl, i2])
+        analy_grad.pos_grad.from_numpy(g)
+
     def set_frozen_kernel(self):
         # Scene_pick.py:91-109
         fr = self.frozen.t.view(-1, 3)
