@@ -440,9 +440,10 @@ __global__ void __launch_bounds__(256) k_ds_inv_small(DsDev D, int lv0, int ls) 
 //   mode 0:  G = W F12            (pp x bp, K = pp)  into the G arena (row stride bp)
 //   mode 1:  S = F22 - F21 G      (bp x bp, K = pp)  in place
 // one 64 x 64 output tile per workgroup (four waves, each a 32 x 32 quadrant = 2 x 2 MFMA tiles), K in slabs of 32 through LDS.
-// LDS strides: the A operand of v_mfma_f64_16x16x4_f64 is read by lane (lr, lk) at [row lr][k lk], the B operand at [k lk][col lr];
-// ds_read_b64 serves lanes 0-31 and 32-63 in one cycle each when their 32 doubles fall into 32 different 8-byte bank pairs: row
-// stride == 2 (mod 32) doubles for A (2 lr + lk), == 16 (mod 32) for B (16 lk + lr); strides 33 / 65 were 2-way conflicts.
+// LDS strides 33 / 65 doubles: the compiler fetches the operands with ds_read2_b64 (two doubles of one lane per instruction), which
+// is served in groups of 16 consecutive lanes against 32 four-byte banks: the 16 rows lr of the A operand must fall on 16 different
+// bank pairs, i.e. row stride == 1 (mod 16) doubles; the B operand's 16 lanes are contiguous.  (Strides 34 / 80, conflict-free
+// under the ds_read_b64 rule -- 32 lanes against 64 banks --, measured 25 % SQ_LDS_BANK_CONFLICT of SQ_LDS_IDX_ACTIVE.)
 // WPC = workgroups per CU the register allocation aims at (one wave of each per SIMD): 3 with the F22 tile of the Schur mode
 // prefetched before the product, 4 with that tile fetched in the epilogue ("direct_gemm_wpc").
 // Measured and dropped (round 2, cfg4 plan, per-batch replays): K slabs of 64 (half the barriers and load round trips, two
@@ -451,7 +452,7 @@ __global__ void __launch_bounds__(256) k_ds_inv_small(DsDev D, int lv0, int ls) 
 #define DS_SK 32
 template <int mode, int WPC>
 __global__ void __launch_bounds__(256, WPC) k_ds_gemm(DsDev D, int lv0) {
-  constexpr int SA = DS_SK + 2, SB = 64 + 16;
+  constexpr int SA = DS_SK + 1, SB = 64 + 1;
   constexpr bool PF = WPC <= 3;
   __shared__ double As[64 * SA];
   __shared__ double Bs[DS_SK * SB];
