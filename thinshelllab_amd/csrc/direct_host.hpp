@@ -211,18 +211,30 @@ static int direct_factor(tsl_ctx* c, int stop_sn = -1, const char* dump_path = n
     for (int k = 0; k < nside; k++) { HIP_OK(hipEventRecord(d.ev_fjoin[k], d.fstream[k])); HIP_OK(hipStreamWaitEvent(s, d.ev_fjoin[k], 0)); }
     bi = be;
   }
-  if (d.anorm_dev.n == 0 && d.anorm_dev.alloc(1)) return -1;
-  HIP_OK(hipMemsetAsync(d.anorm_dev.p, 0, sizeof(double), s));
-  hipLaunchKernelGGL(k_ds_rownorm, dim3(ds_nblk(c->NV, 256)), dim3(256), 0, s, c->NV, c->slice_off.p, c->slice_len.p, c->vals.p, d.anorm_dev.p);
-  // |H|_inf goes to pinned host memory without a synchronisation of its own: the refinement reads it after its first one (a
-  // host wait here left the GPU idle for ~0.1 ms between the last Schur launch and the first sweep of every solve)
-  if (d.h_anorm == nullptr) HIP_OK(hipHostMalloc((void**)&d.h_anorm, sizeof(double)));
-  HIP_OK(hipMemcpyAsync(d.h_anorm, d.anorm_dev.p, sizeof(double), hipMemcpyDeviceToHost, s));
+  d.anorm_valid = false;   // |H|_inf is formed when a refinement first asks for a backward error (direct_anorm): most solves never do
   if (stop_sn >= 0 || c->verbose >= 2) HIP_OK(hipStreamSynchronize(s));
   HIP_OK(hipGetLastError());
   d.numeric_valid = true;
   d.have_factor = true;
   d.n_factor++;
+  return 0;
+}
+
+// |H|_inf of the operator of the last assemble (static part): the yardstick of the solve's normwise backward error.  Only
+// refinements that stall above cg_tol need it (a few adjoint solves of a rollout), so it is computed on demand -- 23 us of kernel
+// plus a clear and a copy at the end of EVERY factorisation before.
+static int direct_anorm(tsl_ctx* c) {
+  DirectSolver& d = c->ds;
+  if (d.anorm_valid) return 0;
+  hipStream_t s = c->stream;
+  if (d.anorm_dev.n == 0 && d.anorm_dev.alloc(1)) return -1;
+  if (d.h_anorm == nullptr) HIP_OK(hipHostMalloc((void**)&d.h_anorm, sizeof(double)));
+  HIP_OK(hipMemsetAsync(d.anorm_dev.p, 0, sizeof(double), s));
+  hipLaunchKernelGGL(k_ds_rownorm, dim3(ds_nblk(c->NV, 256)), dim3(256), 0, s, c->NV, c->slice_off.p, c->slice_len.p, c->vals.p, d.anorm_dev.p);
+  HIP_OK(hipMemcpyAsync(d.h_anorm, d.anorm_dev.p, sizeof(double), hipMemcpyDeviceToHost, s));
+  HIP_OK(hipStreamSynchronize(s));
+  d.anorm = *d.h_anorm;
+  d.anorm_valid = true;
   return 0;
 }
 

@@ -129,6 +129,7 @@ struct DirectSolver {
   long n_plans = 0, n_factor = 0, n_apply = 0, n_perturbed = 0;
   double t_plan = 0;          // host seconds spent in plan builds
   double anorm = 0;           // infinity norm of the factorised operator's static part (backward-error yardstick)
+  bool anorm_valid = false;   // anorm belongs to the operator of the last factorisation
   DevBuf<double> anorm_dev;
   hipEvent_t ev0 = nullptr, ev1 = nullptr;
 };

@@ -513,7 +513,7 @@ static int assemble(tsl_ctx* c, const double* pos, const double* prev, const dou
   hipStream_t s = c->stream;
   const int NV = c->NV;
   c->st_pos = pos; c->st_prev = prev; c->st_vel = vel; c->st_ref = ref;  // for forward_spd_pc (valid while tsl_step runs)
-  c->ds.numeric_valid = false;
+  c->ds.numeric_valid = false; c->ds.anorm_valid = false;
   HIP_OK(hipMemsetAsync(c->vals_full.p, 0, c->vals_full.n * sizeof(double), s));
   if (c->n_cface) hipLaunchKernelGGL(k_cloth_normals, dim3(nblk(c->n_cface, 256)), dim3(256), 0, s, c->n_cface, pos, c->cf_f2v.p, c->norm_dir.p);
   const ClothArgs CA = cloth_args(c);
@@ -1583,7 +1583,7 @@ static int gmres(tsl_ctx* c, tsl_solve_stats* st, bool direct) {
       // 1e9) is ABOVE cg_tol |b|.  When refinement no longer halves the true residual the normwise backward error
       // |b - Hx| / (|H|_inf |x| + |b|) decides: below 1e-12 (a few thousand eps, the n eps growth bound of a pivoted sparse LU in
       // practice) the solution is what a direct solver delivers (reported as attained).
-      c->ds.anorm = c->ds.h_anorm ? *c->ds.h_anorm : 0.0;
+      TSL_TRY(direct_anorm(c));
       st->backward_error = beta / (c->ds.anorm * sqrt(xx) + sqrt(bb));
       if (cycle > 0 && beta > 0.5 * beta_prev && st->backward_error <= 1e-12) { st->flag = 1; st->attained = 1; break; }
       if (cycle >= 8) break;
