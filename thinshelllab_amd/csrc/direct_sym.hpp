@@ -35,8 +35,10 @@ struct DirectSym {
   // ---- per constraint set (build_tree)
   std::vector<int> order, epos, sn_of, sn_ptr;  // position -> vertex, vertex -> position, vertex -> supernode, supernode -> [first, last) position
   int n_sn = 0;
-  int merge_sep = 0;     // "direct_merge_sep": separators of at most this many vertices join the supernode of the enclosing separator (0: off;
-                         // measured on cfg4: 12 -> one level and 500 fronts less, 6 % more flops, the same 383 ms per step; 20 -> 388 ms)
+  int merge_sep = 16;    // "direct_merge_sep": separators of at most this many vertices join the supernode of the enclosing separator (0: off).
+                         // cfg4: one level and 500 fronts less, 6 % more flops, 25 M extend-add atomics less per factorisation.  Measured when
+                         // the Schur launches ran at two workgroups per CU: the same 383 ms per step (12), 388 (20); with the final GEMMs,
+                         // three runs each: 316.2 (0) / 313.0 (12) / 310.4 (16) ms per step, 311.5 (24), 320.5 (48)
   bool merge_k = true;   // constrained body vertices share the supernode of the separator they are placed at ("direct_merge_k"; a supernode of their own
                          // adds two elimination levels with one or two small fronts each: cfg4 391 -> 377 ms per step)
   std::vector<std::vector<int>> bnd;  // boundary vertices per supernode, sorted by elimination position
