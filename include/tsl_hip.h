@@ -118,7 +118,7 @@ int tsl_set_stream(tsl_ctx* ctx, void* hip_stream);
  * "direct_prezero" (1: the front arena of the next factorisation is cleared on a side stream after each solve of a time step),
  * "direct_gemm_wpc" (4 / 3: workgroups per CU the factorisation GEMMs are compiled for; 3 prefetches the F22 tile, default 4),
  * "direct_par_batches" (1: batches of one elimination level on parallel streams), "direct_merge_k" (1: constrained body vertices share the
- * supernode of their separator), "direct_merge_sep" (separators of at most this many vertices join the enclosing separator's supernode; 0),
+ * supernode of their separator), "direct_merge_sep" (separators of at most this many vertices join the enclosing separator's supernode; 16, 0 = off),
  * "tet_coop" (1: 16 lanes per tetrahedron in the element Hessians), "ds_dbg" / "ds_bench_batch" (timing experiments of tsl_bench_direct),
  * "mg_fuse_restrict" (first sweep + residual + restriction of a stencil level in one launch), "mg_st_f32" (single-precision stencil
  * operators), "mg_fr_rows", "pcg_body_fold" (dense-body first sweep inside the PCG update launch), "asm_overlap" (contact blocks on a
