@@ -22,8 +22,9 @@ def oracle_from_scene(po, sys, check_init=True):
             o.cloth_init(ci, ox, oy, oz, bridge=True)
         elif kind == "fold":
             o.cloth_init(ci, ox, oy, oz, fold=True, curv=curv)
-        else:
-            o.L.tslo_cloth_init_mesh(o.h, ci)
+        else:   # "fold_scaled" (refined folding grids): mesh tables + rest data (V, l_i: model_fold_offset.py:863-868) from the flat
+            # initialisation; the pose itself (a generalisation the reference does not have) comes from the product scene below
+            o.cloth_init(ci, ox, oy, oz)
     for e in sys.elastics:
         if e.kind == 0:
             ei = o.add_tactile(e.ratio, e.F_ox_array, e.F_vertices_array, e.f2v_array)

@@ -46,8 +46,40 @@ def lib():
         L.tslo_compute_energy.restype = C.c_double
         L.tslo_newton_step.restype = C.c_double
         L.tslo_set_scalar.argtypes = [C.c_void_p, C.c_char_p, C.c_double]
+        L.tslo_set_direct.argtypes = [C.c_void_p, _DIRECT_CB, C.c_int]
         _lib = L
     return _lib
+
+
+# sparse direct solve for the oracle: the reference's SparseMatrix.solve is cupyx's spsolve (sparse_solver.py:85-105); here scipy's
+# SuperLU on the oracle's own assembled block-CSR matrix
+_DIRECT_CB = C.CFUNCTYPE(C.c_int, C.c_int, C.POINTER(C.c_int), C.POINTER(C.c_int), C.POINTER(C.c_double), C.POINTER(C.c_double), C.POINTER(C.c_double))
+direct_seconds = [0.0, 0]   # [time spent in SuperLU, calls] (bench.py's cpu_baseline reports it)
+
+
+def _direct_solve(nb, row_ptr, col, vals, b, x):
+    try:
+        import time
+        import scipy.sparse as sp
+        import scipy.sparse.linalg as spl
+        t0 = time.time()
+        rp = np.ctypeslib.as_array(row_ptr, shape=(nb + 1,))
+        nnzb = int(rp[nb])
+        cc = np.ctypeslib.as_array(col, shape=(nnzb,))
+        vv = np.ctypeslib.as_array(vals, shape=(nnzb * 9,)).reshape(nnzb, 3, 3)
+        A = sp.bsr_matrix((vv, cc, rp), shape=(3 * nb, 3 * nb)).tocsc()
+        bb = np.ctypeslib.as_array(b, shape=(3 * nb,))
+        xx = spl.splu(A).solve(bb)
+        if not np.isfinite(xx).all():
+            return 1
+        np.ctypeslib.as_array(x, shape=(3 * nb,))[:] = xx
+        direct_seconds[0] += time.time() - t0; direct_seconds[1] += 1
+        return 0
+    except Exception:   # noqa: BLE001 -- a Python exception must not unwind through the C frame
+        return 2
+
+
+_direct_cb = _DIRECT_CB(_direct_solve)
 
 
 def _dp(a):
@@ -90,6 +122,7 @@ class OracleScene:
                                C.c_double(damping), int(max_n_constraints), int(newton_cap), int(plastic), int(effector_cnt),
                                _dp(g), C.c_double(mu_cloth_elastic))
         self.dt = dt
+        self.set_direct(2)
 
     def __del__(self):
         try:
@@ -147,6 +180,11 @@ class OracleScene:
 
     def set_solver(self, tol, maxit=20000):
         self.L.tslo_set_solver(self.h, C.c_double(tol), int(maxit))
+
+    def set_direct(self, mode):
+        """0: iterative stages only (+ dense LU for n <= 4500); 1: scipy's SuperLU is THE solver (what the reference does:
+        spsolve, sparse_solver.py:85-105); 2 (default): SuperLU as the last resort after PCG and BiCGStab"""
+        self.L.tslo_set_direct(self.h, _direct_cb, int(mode))
 
     def set_scalar(self, name, v):
         self.L.tslo_set_scalar(self.h, name.encode(), C.c_double(v))
@@ -265,7 +303,7 @@ class OracleScene:
     def stats(self, reset=False):
         out = (C.c_long * 7)()
         self.L.tslo_stats(self.h, out, int(reset))
-        return dict(newton=out[0], cg=out[1], ls=out[2], solves=out[3], refine=out[4], flag=out[5], missing=out[6])
+        return dict(newton=out[0], cg=out[1], ls=out[2], solves=out[3], refine=out[4], flag=out[5], missing=out[6])   # flag 4: sparse direct solve
 
     def H_csr(self):
         """Assembled system matrix as scipy CSR (n = 3*tot_NV)."""

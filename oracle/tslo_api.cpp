@@ -35,6 +35,7 @@ void tslo_set_params(void* h, double dt, double k_contact, double eps_contact, d
   s.gravity = V3(gravity[0], gravity[1], gravity[2]); s.mu_cloth_elastic = mu_cloth_elastic;
 }
 void tslo_set_solver(void* h, double cg_tol, int cg_maxit) { S(h).cg_tol = cg_tol; S(h).cg_maxit = cg_maxit; }
+void tslo_set_direct(void* h, Scene::direct_cb_t cb, int mode) { S(h).direct_cb = cb; S(h).direct_mode = cb ? mode : 0; }
 void tslo_set_scalar(void* h, const char* name, double v) {
   Scene& s = S(h);
   std::string n(name);

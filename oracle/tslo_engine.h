@@ -182,6 +182,12 @@ struct Scene {
   int cg_maxit = 20000;
   long stat_newton = 0, stat_cg = 0, stat_ls = 0, stat_solves = 0, stat_refine = 0;
   int last_solve_flag = 0;
+  // sparse direct solve supplied by the test harness (scipy's SuperLU): the reference's SparseMatrix.solve IS a direct solve
+  // (cupyx spsolve, sparse_solver.py:85-105).  direct_mode 0: never, 1: primary solver, 2: last resort after PCG and BiCGStab
+  // (replaces the dense LU above n = 4500).  Arguments: block rows, row_ptr, col, 3x3 block values, rhs, solution; returns 0 on success.
+  typedef int (*direct_cb_t)(int nb, const int* row_ptr, const int* col, const double* vals, const double* b, double* x);
+  direct_cb_t direct_cb = nullptr;
+  int direct_mode = 0;
   // geometry.py:8-19 (uniform grid)
   double grid_h = 0.003;
   double grid_extent = 0.2;  // half-width of the broad-phase box (geometry.py:8-19 hard-codes 0.2 m; scaled scenes enlarge it)

@@ -150,7 +150,7 @@ void Scene::newton_step_init() {
   for (auto& v : F_b) v = V3();
 }
 
-// Solve H x = b.  Returns 0 ok, 1 fell back to BiCGStab, 2 fell back to dense LU, 3 not converged.
+// Solve H x = b.  Returns 0 ok, 1 fell back to BiCGStab, 2 fell back to dense LU, 3 not converged, 4 sparse direct solve of the harness.
 // Stage 1: block-Jacobi PCG run directly on the assembled H (its non-symmetric part -- the area
 // block's factor-2 quirk -- is O(strain) small), restarted from the true residual until
 // |b - Hx| <= cg_tol |b|.  When cg_tol sits below the accuracy the system admits (the recurrence
@@ -191,6 +191,18 @@ int Scene::solve(const double* b, double* x) {
   double bnorm = std::sqrt(ddot(b, b));
   last_solve_flag = 0;
   if (bnorm == 0) return 0;
+  auto direct = [&]() -> bool {   // true when the callback delivered a solution with a true residual within 1e3 cg_tol
+    if (!direct_cb) return false;
+    std::vector<double> xd(n, 0.0);
+    if (direct_cb(tot_NV, H.row_ptr.data(), H.col.data(), H.vals.data(), b, xd.data()) != 0) return false;
+    H.matvec(xd.data(), Ap.data());
+    double tr = 0;
+    for (int i = 0; i < n; i++) tr += (b[i] - Ap[i]) * (b[i] - Ap[i]);
+    if (!(std::sqrt(tr) <= std::max(1e3 * cg_tol, 1e-9) * bnorm)) return false;
+    std::copy(xd.begin(), xd.end(), x);
+    return true;
+  };
+  if (direct_mode == 1 && direct()) { last_solve_flag = 4; return 4; }
   bool need_fallback = false;
   int total_it = 0;
   std::vector<double> xbest(n, 0.0);
@@ -263,7 +275,8 @@ int Scene::solve(const double* b, double* x) {
     }
     if (ok) { last_solve_flag = 1; return 1; }
   }
-  // ---- stage 3: dense LU with partial pivoting (small systems only)
+  // ---- stage 3: sparse direct solve of the harness if there is one, else dense LU with partial pivoting (small systems only)
+  if (direct_mode == 2 && direct()) { last_solve_flag = 4; return 4; }
   if (n <= 4500) {
     std::vector<double> A((size_t)n * n, 0.0), y(b, b + n);
     for (int bi = 0; bi < tot_NV; bi++)

@@ -1,0 +1,240 @@
+"""The path bench.py measures -- tsl_step / tsl_adjoint_step with the multifrontal LU ("direct" = 1, the automatic choice for
+cloth grids of >= 1024 cells) -- against the oracle: contact rollouts with gripper drive + the complete reverse sweep on refined
+scenes (state, contact count, Newton count, tape gradients), and single evaluations at the FULL sizes of BASELINE configs 3 and
+4 (candidate flags, constraint list, energy, gradient, operator, one Newton direction), where a complete oracle step takes
+minutes but one evaluation takes a second.
+
+Reference: BaseScene.time_step (BaseScene.py:1327-1370), Grad.transfer_grad (analytic_grad_single.py:217-257),
+compute_residual_and_Hessian (BaseScene.py:976-1040), contact_energy (:487-598), projection_query (geometry.py:165-229)."""
+import os
+
+import numpy as np
+import pytest
+import torch
+
+from helpers import oracle_from_scene, rel_err, sync_oracle_state
+
+pytestmark = pytest.mark.gpu
+
+
+def _ripple(s, o):
+    """sub-micron deterministic ripple on the cloth (both sides): the native poses put vertices EXACTLY on the contact threshold"""
+    c = s.cloths[0]
+    x = s.pos.to_numpy()
+    x[c.offset:c.offset + c.NV, 2] += 2e-6 * np.sin(0.7 * np.arange(c.NV) + 0.3)
+    s.pos.from_numpy(x); s.prev_pos.from_numpy(x)
+    o.pos[:] = x; o.prev_pos[:] = x; o.push_down_all()
+
+
+def _refined(name):
+    if name == "balancing":
+        from thinshelllab_amd.task_scene.Scene_balancing import Scene
+        s = Scene(cloth_size=0.06, cloth_N=48, cloth_M=48)
+        s.init_all()
+    else:
+        from thinshelllab_amd.task_scene.Scene_folding import Scene
+        s = Scene(cloth_size=0.1, cloth_N=60, cloth_M=30)
+        s.cloths[0].Kb[None] = 400.0
+        s.init_all()
+    s.mu_cloth_elastic[None] = 5.0
+    s.prev_pos.copy_from(s.pos)
+    return s
+
+
+@pytest.mark.parametrize("name", ["balancing", "folding"])
+def test_direct_path_rollout_and_adjoint_vs_oracle(oracle, name):
+    """48 x 48 balancing (cloth on ball + 4 pads) / 60 x 30 folding (plastic hinges): 3 gripper-driven steps with contact through the
+    GPU factorisation, then the reverse sweep -- the assertions of test_gpu_scenes.py::test_rollout_and_adjoint on the benchmarked
+    solver path, plus equal Newton counts."""
+    from thinshelllab_amd.engine.analytic_grad_single import Grad
+    from thinshelllab_amd.engine.geometry import projection_query
+    oracle.set_threads(min(os.cpu_count() or 4, 32))
+    s = _refined(name)
+    o = oracle_from_scene(oracle, s, check_init=False)
+    _ripple(s, o)
+    ctx = s._ensure_ctx()
+    ctx.set_param("direct", 1); ctx.set_param("cg_tol", 1e-11); o.set_solver(1e-11)
+    T = 4
+    n_part = s.gripper.n_part
+    g = Grad(s, T, n_part); g.init_mass(s)
+    o.grad_new(T, n_part)
+    g.copy_pos(s, 0); o.grad_copy_pos(0)
+    dpos = np.zeros((n_part, 3)); drot = np.zeros((n_part, 3))
+    if name == "balancing":
+        dpos[:, 2] = [1e-4, -1e-4][:n_part]      # the bench's drive
+    else:
+        dpos[:, 2] = -1e-4; drot[:, 1] = 2e-3
+    nc_seen = 0
+    for f in range(1, T):
+        s.action(f, dpos, drot); o.action(dpos, drot)
+        o.stats(reset=True)
+        st = s.time_step(projection_query, f); o.time_step()
+        g.copy_pos(s, f); o.grad_copy_pos(f)
+        so = o.stats()
+        assert st["factorizations"] == st["solves"] > 0 and st["unconverged"] == 0 and st["fallback"] == 0, st
+        assert st["nc"] == o.nc, (f, st["nc"], o.nc)
+        nc_seen = max(nc_seen, st["nc"])
+        err = np.abs(s.pos.to_numpy() - o.pos).max()
+        assert err < 5e-8, f"{name} step {f}: |dx|max = {err} (newton {st['newton_iters']} / oracle {so['newton']})"
+        assert st["newton_iters"] == so["newton"], (f, st["newton_iters"], so["newton"])
+    assert nc_seen > 0
+    NV = s.tot_NV
+    g.pos_buffer.from_numpy(o.arr("grad.pos_buffer", (T, NV, 3))); g.ref_angle_buffer.from_numpy(o.arr("grad.ref_angle_buffer").reshape(g.ref_angle_buffer.shape))
+    seed = np.random.default_rng(5).normal(size=(NV, 3))
+    g.pos_grad.t[T - 1] = torch.as_tensor(seed, device=s.device); o.arr("grad.pos_grad", (T, NV, 3))[T - 1] = seed
+    if name == "folding":
+        g.get_loss_fold(s, 1.0, -1.0)
+        o.arr("grad.angleref_grad").reshape(g.angleref_grad.shape)[:] = g.angleref_grad.to_numpy()
+    for st_ in range(T - 1, 0, -1):
+        g.transfer_grad(st_, s, projection_query)
+        o.grad_transfer(st_)
+        assert g.last_stats["method"] == 4 and g.last_stats["flag"] == 0, g.last_stats
+    pg_o = o.arr("grad.pos_grad", (T, NV, 3)); pg_g = g.pos_grad.to_numpy()
+    for k in range(T):
+        assert rel_err(pg_g[k], pg_o[k]) < 1e-5, f"pos_grad[{k}]"
+    if name == "folding":
+        assert rel_err(g.angleref_grad.to_numpy().reshape(-1), o.arr("grad.angleref_grad")) < 1e-5
+    gg_o = o.arr("grad.gripper_grad", (T, n_part, 6)); gg_g = g.gripper_grad.to_numpy()[:, :n_part]
+    assert np.abs(gg_o).max() > 0
+    assert rel_err(gg_g, gg_o) < 1e-5
+
+
+def _sorted_constraints(idx, *arrs):
+    key = np.lexsort((idx[:, 0], idx[:, 1], idx[:, 2], idx[:, 3]))
+    return [idx[key]] + [a[key] for a in arrs]
+
+
+def _sparse_rel(Hg, Ho):
+    d = abs(Hg - Ho)
+    return (d.max() if d.nnz else 0.0) / abs(Ho).max()
+
+
+def _single_evaluation_parity(oracle, s, drive, steps, min_nc, newton_direction=False):
+    """drive the GPU scene `steps` steps, then on that state: detection (with the GPU's latched side flags of the previous step
+    handed to the oracle), constraint list, E, grad E, operator for spd True / False against the oracle"""
+    from thinshelllab_amd.engine.geometry import projection_query
+    oracle.set_threads(min(os.cpu_count() or 4, 32))
+    n_part = s.gripper.n_part
+    for f in range(1, steps + 1):
+        s.action(f, *drive(f, n_part))
+        st = s.time_step(projection_query, f)
+        assert st["unconverged"] == 0, (f, st)
+    ctx = s._ctx
+    nb = len(s.body_list)
+    flag0, dir0, _, _ = ctx.proj_export()          # stateful side latch (geometry.py:210-212): state BEFORE the query compared below
+    # exact geometric ties (a frozen cloth vertex straight above an edge of the frozen, regular table mesh: equal distances and
+    # cosines, decided by the last bit of an FMA) are broken by a deterministic micron-scale ripple on every cloth vertex
+    c0 = s.cloths[0]
+    xr = s.pos.to_numpy(); k = np.arange(c0.NV)
+    xr[c0.offset:c0.offset + c0.NV] += 1e-6 * np.stack([np.sin(0.37 * k + 0.1), np.sin(0.53 * k + 0.7), np.sin(0.71 * k + 1.3)], axis=1)
+    s.pos.from_numpy(xr)
+    o = oracle_from_scene(oracle, s, check_init=False)
+    o.arr("proj_flag", (nb, -1))[:] = flag0; o.arr("proj_dir", (nb, -1))[:] = dir0
+    # a small off-equilibrium displacement of the free dofs (the converged state has a gradient of rounding noise)
+    rng = np.random.default_rng(7)
+    x = s.pos.to_numpy()
+    fr = s.frozen.to_numpy().reshape(-1, 3).astype(bool)
+    nc = projection_query(s)
+    o.calc_vn(); o.projection_query(); o.contact_analysis()
+    flag, dr, pidx, pw = ctx.proj_export()
+    fo = o.arr("proj_flag", (nb, -1)); do = o.arr("proj_dir", (nb, -1)); io = o.arr("proj_idx", (nb, -1, 3)); wo = o.arr("proj_w", (nb, -1, 3))
+    assert np.array_equal(flag, fo)
+    assert np.array_equal(dr[fo == 1], do[fo == 1])
+    assert np.array_equal(pidx[fo == 1], io[fo == 1])
+    assert np.abs(pw[fo == 1] - wo[fo == 1]).max() < 1e-9
+    assert nc == o.nc and nc >= min_nc, (nc, o.nc)
+    c = ctx.constraints()
+    gi, gw, gk, gdx0, gT, gn = _sorted_constraints(c["idx"], c["w"], c["k"], c["dx0"], c["T"], c["n"])
+    oi, ow, ok, odx0, oT, on = _sorted_constraints(o.arr("const_idx", (-1, 4))[:nc].copy(), o.arr("const_w", (-1, 3))[:nc].copy(), o.arr("const_k")[:nc].copy(),
+                                                   o.arr("const_dx0", (-1, 3))[:nc].copy(), o.arr("const_T", (-1, 6))[:nc].copy(), o.arr("const_n", (-1, 3))[:nc].copy())
+    assert np.array_equal(gi, oi)
+    assert np.abs(gw - ow).max() < 1e-9 and rel_err(gk, ok) < 1e-9 and np.abs(gdx0 - odx0).max() < 1e-12
+    assert np.abs(gT - oT).max() < 1e-9 and np.abs(gn - on).max() < 1e-9
+    dx = s.cloths[0].dx
+    xp = x + rng.normal(0, 2e-3 * dx, x.shape)
+    xp[fr] = x[fr]
+    s.pos.from_numpy(xp); o.pos[:] = xp; o.push_down_all()
+    o.newton_step_init()
+    Eo = o.compute_energy(); Eg = s.compute_energy()
+    assert abs(Eg - Eo) <= 1e-11 * abs(Eo), (Eg, Eo)
+    oracle.set_spd_mode(1)   # converged eigen-clamp on both sides (test_scene_blocks_* bounds the literal-QR difference on scene blocks)
+    try:
+        for spd in (True, False):
+            o.newton_step_init(); o.compute_energy(); o.compute_residual_and_Hessian(spd)
+            s.compute_residual_and_Hessian(spd=spd)
+            assert rel_err(s.F.to_numpy(), o.arr("F")) < 1e-10
+            Hg = ctx.operator_csr(); Ho = o.H_csr()
+            assert _sparse_rel(Hg, Ho) < 1e-8, spd
+            assert o.stats()["missing"] == 0
+            if spd and newton_direction:
+                # the reference's Newton direction = spsolve(H, F) (sparse_solver.py:85-105): a sparse LU of the ORACLE's operator and
+                # right-hand side against tsl_solve on the GPU's own assembly
+                import scipy.sparse.linalg as spl
+                p_o = spl.splu(Ho.tocsc()).solve(o.arr("F").copy())
+                p_g, stx = ctx.solve(s.F.to_torch().clone())
+                assert stx["flag"] == 0 and stx["method"] == 4, stx
+                assert np.linalg.norm(p_g.cpu().numpy() - p_o) <= 1e-6 * np.linalg.norm(p_o), stx
+    finally:
+        oracle.set_spd_mode(0)
+    s.pos.from_numpy(x)
+
+
+def test_cfg3_single_evaluation_parity(oracle):
+    """BASELINE configs[2] at full size (200 x 100 folding, 40,000 triangles) after 12 driven steps"""
+    from thinshelllab_amd.task_scene.Scene_folding import Scene
+    s = Scene(cloth_size=0.1, cloth_N=200, cloth_M=100)
+    s.cloths[0].Kb[None] = 400.0
+    s.init_all()
+    s.mu_cloth_elastic[None] = 5.0
+    s.prev_pos.copy_from(s.pos)
+
+    def drive(f, n_part):
+        dpos = np.zeros((n_part, 3)); drot = np.zeros((n_part, 3))
+        if f <= 10:
+            dpos[:, 2] = -2e-4
+        else:
+            dpos[:, 0] = 2e-4
+        return dpos, drot
+    _single_evaluation_parity(oracle, s, drive, 12, 100, newton_direction=True)
+
+
+def test_cfg4_single_evaluation_parity(oracle):
+    """BASELINE configs[3] at full size (224 x 224 cloth on ball + 4 pads, 100,352 triangles) after 12 steps of the bench's drive:
+    flags, constraints, E, grad E, operator (projected and not) and one Newton direction"""
+    from thinshelllab_amd.task_scene.Scene_balancing import Scene
+    s = Scene(cloth_size=0.12, cloth_N=224, cloth_M=224)
+    s.init_all()
+    s.mu_cloth_elastic[None] = 5.0
+    s.prev_pos.copy_from(s.pos)
+
+    def drive(f, n_part):
+        dpos = np.zeros((n_part, 3)); drot = np.zeros((n_part, 3)); dpos[:, 2] = [1e-4, -1e-4][:n_part]
+        return dpos, drot
+    _single_evaluation_parity(oracle, s, drive, 12, 100, newton_direction=True)
+
+
+@pytest.mark.parametrize("name", ["folding", "lifting", "balancing"])
+def test_scene_blocks_literal_qr_vs_jacobi_projector(oracle, name):
+    """The SPD projector deviation measured where it matters: the assembled operator of the three native scenes with
+    contact, oracle in its LITERAL mode (Householder + K shifted-QR sweeps, linalg.py:15-148) against the GPU (converged Jacobi
+    eigen-clamp) -- below 1e-8 of |H|."""
+    import test_gpu_scenes as tgs
+    from thinshelllab_amd.engine.geometry import projection_query
+    s, o = tgs._pair(oracle, name)
+    oracle.set_spd_mode(0)
+    rng = np.random.default_rng(2)
+    x = s.pos.to_numpy()
+    xp = x + rng.normal(0, 2e-5, x.shape)
+    fr = s.frozen.to_numpy().reshape(-1, 3).astype(bool)
+    xp[fr] = x[fr]
+    projection_query(s)
+    o.calc_vn(); o.projection_query(); o.contact_analysis()
+    assert o.nc > 0
+    s.pos.from_numpy(xp); o.pos[:] = xp; o.push_down_all()
+    o.newton_step_init(); o.compute_energy(); o.compute_residual_and_Hessian(True)
+    s.compute_residual_and_Hessian(spd=True)
+    Hg = s._ctx.operator_csr().toarray(); Ho = o.H_csr().toarray()
+    worst = np.abs(Hg - Ho).max() / np.abs(Ho).max()
+    print(f"{name}: literal QR projector vs converged Jacobi on the scene operator: max |dH| / |H| = {worst:.3e}")
+    assert worst < 1e-8
+    assert rel_err(s.F.to_numpy(), o.arr("F")) < 1e-10

@@ -292,6 +292,27 @@ def test_solver_matches_spsolve(oracle):
         assert rel_err(x, xs) < 1e-7, (spd, flag)
 
 
+def test_solver_direct_hook_is_the_same_solve(oracle):
+    """set_direct(1) makes scipy's SuperLU the oracle's solver (the reference calls spsolve, sparse_solver.py:85-105): same
+    solution as the iterative stages, and a whole time step lands on the same state"""
+    o = _cloth(oracle, 15, 3, fold=True, Kb=400.0, k_angle=0.5, gravity=(0, 0, 0))
+    rng = np.random.default_rng(0)
+    o.pos[:] += rng.normal(0, 3e-5, o.pos.shape) * (o.frozen.reshape(-1, 3) == 0); o.prev_pos[:] = o.pos; o.push_down_all()
+    o.set_solver(1e-12)
+    x0 = o.pos.copy()
+    for spd in (True, False):
+        o.newton_step_init(); o.compute_energy(); o.compute_residual_and_Hessian(spd)
+        b = rng.normal(size=o.tot_NV * 3)
+        o.set_direct(0); xi, fi = o.solve(b)
+        o.set_direct(1); xd, fd = o.solve(b)
+        assert fi in (0, 1, 2) and fd == 4
+        assert rel_err(xd, xi) < 1e-7, spd
+    o.set_direct(1); o.time_step(); x_direct = o.pos.copy()
+    o.pos[:] = x0; o.prev_pos[:] = x0; o.vel[:] = 0; o.push_down_all(); o.clear_proj()
+    o.set_direct(0); o.time_step()
+    assert np.abs(o.pos - x_direct).max() < 1e-9
+
+
 def test_newton_step_converges_and_decreases_energy(oracle):
     o = _cloth(oracle, 15, 3, fold=True, Kb=400.0, k_angle=0.5, gravity=(0, 0, 0))
     o.set_scalar("plastic", 1)

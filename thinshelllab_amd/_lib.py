@@ -7,7 +7,7 @@ import ctypes as C
 import os
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "lib", "libtsl_hip.so")
+LIB_PATH = os.environ.get("TSL_HIP_LIB") or os.path.join(_HERE, "lib", "libtsl_hip.so")   # TSL_HIP_LIB: A/B builds of the same library (kernel experiments)
 
 
 class TslLibraryError(RuntimeError):

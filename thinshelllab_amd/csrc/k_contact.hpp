@@ -95,14 +95,17 @@ TSL_DEV int lower_bound_dev(const int* __restrict__ a, int n, int key) {
 }
 
 // geometry.project_pair (:165-221).  G lanes (a power of two <= 64) share one query vertex: the candidates of each of the
-// <= 27 cells are dealt round-robin to the lanes, every lane applies the reference's running selection rule (closer by more
-// than 1e-5, or within 1e-5 and larger cosine) to its own subsequence, and the lane results are merged with the same rule
-// taken in scan order.  This equals the sequential scan whenever the near-minimum candidates form a cluster much tighter
-// than the 1e-5 tolerance (shared edges / vertices: the case the rule exists for); the reference's own candidate order is
-// an atomic-append order and not deterministic either.  One lane per query (G = 1 behaviour) left 19 waves on the GPU for
-// the pad-vertices-against-cloth query of the 100k-triangle scene (0.9 ms per launch).
+// <= 27 cells are taken in chunks of G consecutive ones, one per lane, and the reference's running selection rule (closer by more
+// than 1e-5, or within 1e-5 and larger cosine) is applied to the chunk EXACTLY as a sequential scan would: the state (d_min,
+// cos_max) is uniform in the group; a ballot finds the first lane of the chunk whose candidate replaces it, that candidate becomes
+// the state, and the lanes behind it are tested again against the new state -- replacements are rare, so a chunk costs one ballot.
+// (The rule is not transitive: on the refined cloths, where 1e-5 m is 2 % of an edge, per-lane running bests merged at the end
+// picked another triangle than the sequential scan for some vertices -- round 3 parity check at 200 x 100 and 224 x 224.)  The
+// reference's own candidate order inside a cell is an atomic-append order; here and in the oracle it is ascending triangle index.
+// One lane per query (G = 1 behaviour) left 19 waves on the GPU for the pad-vertices-against-cloth query of the 100k-triangle
+// scene (0.9 ms per launch).
 struct ProjBest { double d, cs; int pos; };
-TSL_DEV bool proj_replaces(const ProjBest& cur, const ProjBest& cand) {  // cand comes later in scan order
+TSL_DEV bool proj_replaces(const ProjBest& cur, const ProjBest& cand) {  // cand comes later in scan order (geometry.py:190)
   return cand.d < cur.d - 1e-5 || (cand.d < cur.d + 1e-5 && cand.cs > cur.cs);
 }
 // SELF: geometry_self.project_pair_self (geometry_self.py:166-230) -- the query vertices are the body's own vertices: triangles that
@@ -121,43 +124,56 @@ k_project_pair(GridArgs Gr, int v_start, int v_end, int body_idx, int NV, int nf
   grid_idx3(Gr, xq, q);
   int r0[3], r1[3];
   for (int a = 0; a < 3; a++) { r0[a] = max(q[a] - 1, range[a]); r1[a] = min(q[a] + 1, range[3 + a]) + 1; }
-  ProjBest best{1e6, -1e6, 0x7fffffff};
+  ProjBest cur{1e6, -1e6, 0};
+  int owner = -1;   // lane (inside the group) that holds the current winner's data
   int bc = 0, ba = 0, bb = 0, bc3 = 0;
   d3 pw = d3();
-  int base = 0;
+  const int gbase = (threadIdx.x & 63) & ~(G - 1);
+  const unsigned long long gbits = G == 64 ? ~0ull : ((1ull << G) - 1);
   if (live)
     for (int gi = r0[0]; gi < r1[0]; gi++)
       for (int gj = r0[1]; gj < r1[1]; gj++)
         for (int gk = r0[2]; gk < r1[2]; gk++) {
           const int cell = (gi * Gr.n + gj) * Gr.n + gk;
           const int s0 = lower_bound_dev(skey, nf, cell), s1 = lower_bound_dev(skey, nf, cell + 1);
-          for (int s = s0 + g; s < s1; s += G) {
-            const int f = sval[s];
-            const int a = faces[3 * f], b = faces[3 * f + 1], c3 = faces[3 * f + 2];
-            if (SELF && (i == a || i == b || i == c3)) continue;
-            const d3 v1 = ld3(pos, a), v2 = ld3(pos, b), v3 = ld3(pos, c3);
-            int c; double d; d3 w;
-            pt2tri(xq, v1, v2, v3, c, d, w);
-            if (SELF && c != 0) continue;
-            const d3 vt = v1 * w.x + v2 * w.y + v3 * w.z;
-            const d3 nt = normalized(cross(v2 - v1, v3 - v1));
-            const ProjBest cand{d, dot(xq - vt, nt), base + (s - s0)};
-            if (proj_replaces(best, cand)) { best = cand; bc = c; ba = a; bb = b; bc3 = c3; pw = w; }
+          for (int sb = s0; sb < s1; sb += G) {
+            const int sidx = sb + g;
+            bool valid = sidx < s1;
+            int a = 0, b = 0, c3 = 0, c = 0;
+            double d = 0.0, cs = 0.0;
+            d3 w = d3();
+            if (valid) {
+              const int f = sval[sidx];
+              a = faces[3 * f]; b = faces[3 * f + 1]; c3 = faces[3 * f + 2];
+              if (SELF && (i == a || i == b || i == c3)) valid = false;
+              else {
+                const d3 v1 = ld3(pos, a), v2 = ld3(pos, b), v3 = ld3(pos, c3);
+                pt2tri(xq, v1, v2, v3, c, d, w);
+                if (SELF && c != 0) valid = false;
+                else {
+                  const d3 vt = v1 * w.x + v2 * w.y + v3 * w.z;
+                  const d3 nt = normalized(cross(v2 - v1, v3 - v1));
+                  cs = dot(xq - vt, nt);
+                }
+              }
+            }
+            unsigned long long gm;
+            do {   // sequential rule over the chunk: first replacing candidate, then the ones behind it against the new state
+              const bool rep = valid && proj_replaces(cur, ProjBest{d, cs, 0});
+              gm = (__ballot(rep) >> gbase) & gbits;
+              if (gm) {
+                const int j = __ffsll((long long)gm) - 1;
+                cur.d = __shfl(d, j, G); cur.cs = __shfl(cs, j, G);
+                owner = j;
+                if (g == j) { bc = c; ba = a; bb = b; bc3 = c3; pw = w; }
+                valid = valid && g > j;
+              }
+            } while (gm);
           }
-          base += s1 - s0;
         }
-  // merge the lane results in scan order (all lanes of the group end up with the same winner)
-  ProjBest win = best;
-#pragma unroll
-  for (int m = 1; m < G; m <<= 1) {
-    ProjBest o;
-    o.d = __shfl_xor(win.d, m, G); o.cs = __shfl_xor(win.cs, m, G); o.pos = __shfl_xor(win.pos, m, G);
-    const bool o_later = o.pos > win.pos;
-    if (o_later ? proj_replaces(win, o) : (o.pos != win.pos && !proj_replaces(o, win))) win = o;
-  }
   if (!live) return;
-  const bool none = win.pos == 0x7fffffff;
-  if (none ? (g != 0) : (best.pos != win.pos)) return;
+  const bool none = owner < 0;
+  if (none ? (g != 0) : (g != owner)) return;
   int pflag = 0, pi0 = 0, pi1 = 0, pi2 = 0;
   if (!none) {
     pi0 = ba; pi1 = bb; pi2 = bc3;
@@ -363,7 +379,8 @@ TSL_DEV void spd_clamp9_lds(double* __restrict__ sa, double* __restrict__ sv, in
     for (int k = 0; k < 9; k++) sv[l * 9 + k] = (k == l) ? 1.0 : 0.0;
   }
   __builtin_amdgcn_wave_barrier();
-  if (row) {  // symmetrise (lane l rewrites the upper part of its row and the mirrored entries)
+  if (row && on) {  // symmetrise (lane l rewrites the upper part of its row and the mirrored entries); an un-clamped block stays as it is:
+                    // the kind-1 element block with J clamped is not an exact Hessian and keeps its non-symmetric part
     for (int k = l + 1; k < 9; k++) { const double t = 0.5 * (sa[l * 9 + k] + sa[k * 9 + l]); sa[l * 9 + k] = t; sa[k * 9 + l] = t; }
   }
   __builtin_amdgcn_wave_barrier();
@@ -778,7 +795,9 @@ extern "C" int tsl_contact_detect(tsl_ctx* c, const double* pos, const double* p
   c->nc = 0;
   c->bd_valid = false;
   c->ds.cons_checked = false;   // the factorisation plan compares the new constraint list with the one it was made for
-  if (c->n_body < 2 || c->NF == 0) { if (nc_host) *nc_host = 0; return 0; }
+  bool any_self = false;
+  for (int v : c->self_contact) any_self |= v != 0;
+  if ((c->n_body < 2 && !any_self) || c->NF == 0) { if (nc_host) *nc_host = 0; return 0; }   // a single body can still touch itself (geometry_self.py)
   // calc_vn
   HIP_OK(hipMemsetAsync(c->vn.p, 0, 3 * (size_t)NV * sizeof(double), s));
   hipLaunchKernelGGL(k_vn_accum, dim3(cnblk(c->NF, 256)), dim3(256), 0, s, c->NF, c->faces.p, pos, c->vn.p);

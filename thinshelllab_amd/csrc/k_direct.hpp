@@ -207,6 +207,130 @@ TSL_DEV void ds_invert_tile_wg(double (*T)[DS_T + 1], int* __restrict__ bad, int
   __syncthreads();
 }
 
+// Second form of the tile inversion (round 3): same 4 x 4 block pivots, fewer instructions and a shorter dependent chain per block
+// step (the first form issues 290 instructions per step, of which 53 v_cndmask, 61 f64 multiply-adds of the redundant per-lane 4 x 4
+// Gauss-Jordan with its four dependent reciprocals, 27 accumulator moves and a second matrix-core product).
+//   * The rank-4 update runs on X~ = X with the pivot columns ZEROED against C' = pivot columns with the pivot rows zeroed and the
+//     operand B = Dinv R~ (R~ = pivot rows with the unit block in the pivot columns): every entry outside the pivot rows comes out
+//     right by itself (pivot columns as 0 - C Dinv), the pivot rows are then overwritten with B.  The substitutions are made by
+//     the lanes that WRITE the panels; one conditional move per step is left.  (Folding the pivot rows into the product as well --
+//     C' = D - I there -- cancels catastrophically when |D| >> 1: measured 0.7 instead of 5e-8 on a condition-1e9 tile.)
+//   * A lane needs only row lk of Dinv (its B-operand row).  It reads D with the columns rotated by lk (a per-lane LDS offset) and
+//     forms row 0 of THAT inverse from cofactors: 6 shared 2 x 2 minors, four 3 x 3 minors, one determinant, one reciprocal -- ~45
+//     short-chain instructions instead of ~110 of a four-pivot elimination plus 12 row selects.  On the condition-1e9 tile of
+//     scripts/micro/inv_bench.hip both forms reach |A inv(A) - I| = 5e-8..1e-7.
+//   * Static pivoting keeps its rule where it matters: when the cofactor expansion of the determinant cancels (|det| < 1e-6 sum
+//     |terms|: a block a diagonal-pivot elimination might have to perturb) the lane falls back to the four-pivot elimination with the
+//     per-pivot threshold of the first form (divergent branch, no barrier or matrix instruction inside).  Blocks with a zero
+//     leading entry but a healthy determinant ([0 1; 1 0]) are inverted exactly instead of being perturbed.
+TSL_DEV void ds_invert_tile_wg2(double (*T)[DS_T + 1], int* __restrict__ bad, int cls, int tag, double tol) {
+  __shared__ double rowp[2][DS_PB][DS_T], colp[2][DS_PB][DS_T + 1], dblk[2][DS_PB][DS_PB], red[4], dg0[DS_T];
+  const int lane = threadIdx.x & 63, w = threadIdx.x >> 6, wi = w >> 1, wj = w & 1, lr = lane & 15, lk = lane >> 4;
+  ds_d4 acc;
+  double amax = 0.0;
+#pragma unroll
+  for (int r = 0; r < 4; r++) {
+    acc[r] = T[16 * wi + lk + 4 * r][16 * wj + lr];
+    amax = fmax(amax, fabs(acc[r]));
+    if (wi == wj && lk + 4 * r == lr) dg0[16 * wi + lr] = fabs(acc[r]);
+  }
+  amax = wave_max(amax);
+  if (lane == 0) red[w] = amax;
+  __syncthreads();
+  const double tmax = fmax(fmax(red[0], red[1]), fmax(red[2], red[3]));
+  const double floor0 = fmax(tmax * 1e-20, 1e-300);
+  const double mydg = dg0[lane & 31];
+  unsigned badmask = 0;
+  const int c0 = lk, c1 = (lk + 1) & 3, c2 = (lk + 2) & 3, c3 = (lk + 3) & 3;   // column rotation of this lane
+#pragma unroll
+  for (int s = 0; s < DS_T / DS_PB; s++) {
+    const int buf = s & 1, p0 = DS_PB * s;
+    const int wp = p0 >> 4, rp = (p0 & 15) >> 2, lc = p0 & 15;
+    const bool col_in = wj == wp && lr >= lc && lr < lc + DS_PB;
+    const int mc = (lr - lc) & 3;
+    if (wi == wp) {   // pivot rows (lane row lk, register rp): R~ carries the unit block in the pivot columns, D goes to its own array
+      const double v = acc[rp];
+      rowp[buf][lk][16 * wj + lr] = col_in ? (mc == lk ? 1.0 : 0.0) : v;
+      if (col_in) dblk[buf][lk][mc] = v;
+    }
+    if (col_in) {     // pivot columns, negated, zero in the pivot rows; X~ has zero pivot columns
+#pragma unroll
+      for (int r = 0; r < 4; r++) {
+        colp[buf][mc][16 * wi + lk + 4 * r] = (wi == wp && r == rp) ? 0.0 : -acc[r];
+        acc[r] = 0.0;
+      }
+    }
+    __syncthreads();
+    // rows of D, columns rotated by lk: a = column lk (expansion column), b, c, e the three others
+    double a[4], b[4], c[4], e[4];
+#pragma unroll
+    for (int i = 0; i < 4; i++) { a[i] = dblk[buf][i][c0]; b[i] = dblk[buf][i][c1]; c[i] = dblk[buf][i][c2]; e[i] = dblk[buf][i][c3]; }
+    const double m01 = c[0] * e[1] - c[1] * e[0], m02 = c[0] * e[2] - c[2] * e[0], m03 = c[0] * e[3] - c[3] * e[0];
+    const double m12 = c[1] * e[2] - c[2] * e[1], m13 = c[1] * e[3] - c[3] * e[1], m23 = c[2] * e[3] - c[3] * e[2];
+    const double M0 = b[1] * m23 - b[2] * m13 + b[3] * m12;
+    const double M1 = b[0] * m23 - b[2] * m03 + b[3] * m02;
+    const double M2 = b[0] * m13 - b[1] * m03 + b[3] * m01;
+    const double M3 = b[0] * m12 - b[1] * m02 + b[2] * m01;
+    const double t0 = a[0] * M0, t1 = a[1] * M1, t2 = a[2] * M2, t3 = a[3] * M3;
+    const double det = (t0 - t1) + (t2 - t3);
+    const double dabs = (fabs(t0) + fabs(t1)) + (fabs(t2) + fabs(t3));
+    double drow[DS_PB];
+    if (fabs(det) >= 1e-6 * dabs && dabs < 1e300) {
+      const double idet = ds_rcp(det);
+      drow[0] = M0 * idet; drow[1] = -M1 * idet; drow[2] = M2 * idet; drow[3] = -M3 * idet;
+    } else {
+      // four-pivot elimination on the unrotated block with the per-pivot threshold (first form), then row lk
+      double d[DS_PB][DS_PB];
+#pragma unroll
+      for (int i = 0; i < DS_PB; i++)
+#pragma unroll
+        for (int j = 0; j < DS_PB; j++) d[i][j] = dblk[buf][i][j];
+#pragma unroll
+      for (int p = 0; p < DS_PB; p++) {
+        const double piv0 = d[p][p];
+        const double tiny = fmax(tol * ds_readlane_d(mydg, p0 + p), floor0);
+        const bool small = !(fabs(piv0) >= tiny);
+        const double piv = small ? copysign(tiny, piv0) : piv0;
+        badmask |= small ? (1u << (p0 + p)) : 0u;
+        const double ip = ds_rcp(piv);
+#pragma unroll
+        for (int j = 0; j < DS_PB; j++) d[p][j] = (j == p) ? ip : d[p][j] * ip;
+#pragma unroll
+        for (int i = 0; i < DS_PB; i++) {
+          if (i == p) continue;
+          const double f = d[i][p];
+#pragma unroll
+          for (int j = 0; j < DS_PB; j++) d[i][j] = (j == p) ? -f * ip : fma(-f, d[p][j], d[i][j]);
+        }
+      }
+      const bool k1 = lk == 1, k2 = lk == 2, k3 = lk == 3;
+#pragma unroll
+      for (int j = 0; j < DS_PB; j++) drow[j] = ds_sel4(k1, k2, k3, d[0][j], d[1][j], d[2][j], d[3][j]);
+    }
+    const int col = 16 * wj + lr;
+    const double bop = drow[0] * rowp[buf][0][col] + drow[1] * rowp[buf][1][col] + drow[2] * rowp[buf][2][col] + drow[3] * rowp[buf][3][col];
+    const double aop = colp[buf][lk][16 * wi + lr];
+    acc = __builtin_amdgcn_mfma_f64_16x16x4f64(aop, bop, acc, 0, 0, 0);   // X~ - C' (Dinv R~)
+    if (wi == wp) acc[rp] = bop;                                           // pivot rows = Dinv R~ (Dinv itself in the pivot columns)
+  }
+#pragma unroll
+  for (int r = 0; r < 4; r++) T[16 * wi + lk + 4 * r][16 * wj + lr] = acc[r];
+  if (threadIdx.x == 0 && badmask) {
+    atomicAdd(bad + cls, __popc(badmask));
+    const int slot = atomicAdd(bad + 4, 1);
+    if (slot < DS_BADLOG) { int* L = bad + 8 + 4 * slot; L[0] = tag; L[1] = (int)badmask; L[2] = 0; L[3] = __float_as_int((float)tmax); }
+  }
+  __syncthreads();
+}
+
+// the form the factorisation kernels use (1: four-pivot elimination per block step, 2: cofactor form; A/B builds pass -DDS_INV_FORM=1)
+#ifndef DS_INV_FORM
+#define DS_INV_FORM 1
+#endif
+TSL_DEV void ds_invert_tile(double (*T)[DS_T + 1], int* __restrict__ bad, int cls, int tag, double tol) {
+  if (DS_INV_FORM == 1) ds_invert_tile_wg(T, bad, cls, tag, tol); else ds_invert_tile_wg2(T, bad, cls, tag, tol);
+}
+
 // scratch of a front inside the level scratch (fronts with more than DS_SMALL pivots): pivot-block inverses P[2] (ping-pong) and the
 // side panels of the merged Gauss-Jordan step, row panel R[2] (DS_T x pp) and column panel C[2] (pp x DS_T)
 TSL_DEV double* ds_scr_P(const DsDev& D, const DsFrontDesc& f, int which) { return D.scr + f.scr_off + which * DS_T * DS_T; }
@@ -222,7 +346,7 @@ __global__ void __launch_bounds__(256) k_ds_pivot0(DsDev D, int lv0) {
 #pragma unroll
   for (int q = 0; q < 4; q++) T[ty + 8 * q][tx] = A[(size_t)(ty + 8 * q) * f.ld + tx];
   __syncthreads();
-  ds_invert_tile_wg(T, D.bad, DS_CLS(f), D.level_sn[lv0 + blockIdx.x] << 6, D.piv_tol);
+  ds_invert_tile(T, D.bad, DS_CLS(f), D.level_sn[lv0 + blockIdx.x] << 6, D.piv_tol);
   double* P = ds_scr_P(D, f, 0);
 #pragma unroll
   for (int q = 0; q < 4; q++) P[(ty + 8 * q) * DS_T + tx] = T[ty + 8 * q][tx];
@@ -320,7 +444,7 @@ __global__ void __launch_bounds__(256) k_ds_gj_step(DsDev D, int lv0, int k, int
   }
   if (next_pivot) {
     __syncthreads();
-    if (D.dbg != 1) ds_invert_tile_wg(T2, D.bad, DS_CLS(f), (D.level_sn[lv0 + fz] << 6) | (k + 1), D.piv_tol);
+    if (D.dbg != 1) ds_invert_tile(T2, D.bad, DS_CLS(f), (D.level_sn[lv0 + fz] << 6) | (k + 1), D.piv_tol);
     double* Pn = ds_scr_P(D, f, (k + 1) & 1);
 #pragma unroll
     for (int q = 0; q < 4; q++) Pn[(ty + 8 * q) * DS_T + tx] = T2[ty + 8 * q][tx];
@@ -365,7 +489,7 @@ __global__ void __launch_bounds__(256) k_ds_inv_small(DsDev D, int lv0, int ls) 
 #pragma unroll
     for (int q = 0; q < 4; q++) Tt[ty + 8 * q][tx] = M[(k0 + ty + 8 * q) * ls + k0 + tx];
     __syncthreads();
-    ds_invert_tile_wg(Tt, D.bad, 1, (D.level_sn[lv0 + blockIdx.x] << 6) | k, D.piv_tol);
+    ds_invert_tile(Tt, D.bad, 1, (D.level_sn[lv0 + blockIdx.x] << 6) | k, D.piv_tol);
     // R'_j = P A_Kj in place (a wave owns whole tiles: all its reads of a tile precede its writes)
     for (int j = w; j < nt; j += 4) {
       if (j == k) continue;

@@ -116,6 +116,7 @@ struct DirectSolver {
   int gm_cap = 0;
   int dbg = 0;
   long n_stale = 0;
+  int n_setup_fail = 0;        // set-up failures of the direct path in automatic mode (three disable it)
   DirectPlan plan;
   std::vector<DsGrid> grids;
   std::vector<DsBlock> blocks;

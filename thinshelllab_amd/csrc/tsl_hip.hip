@@ -1082,26 +1082,46 @@ static int solve_perm(tsl_ctx* c, tsl_solve_stats* st) {
       st->iters = s2.iters;   // counted with the solve that follows
     }
     tsl_solve_stats sd = *st;
-    bool stale = false;
-    if (!d.numeric_valid) {
-      TSL_TRY(direct_plan(c));
-      stale = c->in_step && d.lag > 0 && d.have_factor && !d.refactor_next;
-      if (!stale) TSL_TRY(direct_factor(c));
-    }
-    d.refactor_next = false;
-    d.gm_cap = stale ? d.lag : 0;
-    TSL_TRY(gmres(c, &sd, true));
-    d.gm_cap = 0;
-    if (stale) {
-      d.n_stale++;
-      if (sd.flag != 1 || sd.iters > (2 * d.lag) / 3) d.refactor_next = true;   // the next iteration starts from fresh factors
-      if (sd.flag != 1) {
-        const int it0 = sd.iters;
-        TSL_TRY(direct_factor(c));
-        sd = *st;
-        TSL_TRY(gmres(c, &sd, true));
-        sd.iters += it0;
+    // Set-up failures of the direct path (arena or GMRES-basis allocation, an inconsistent plan): with "direct" = 1 they are errors;
+    // in the automatic mode the solve falls through to the iterative hierarchy, which needs none of that memory, and after three
+    // such failures the context stops trying ("direct" = 0).
+    auto direct_try = [&]() -> int {
+      bool stale = false;
+      if (!d.numeric_valid) {
+        TSL_TRY(direct_plan(c));
+        stale = c->in_step && d.lag > 0 && d.have_factor && !d.refactor_next;
+        if (!stale) TSL_TRY(direct_factor(c));
       }
+      d.refactor_next = false;
+      d.gm_cap = stale ? d.lag : 0;
+      const int rc_g = gmres(c, &sd, true);
+      d.gm_cap = 0;
+      if (rc_g) return -1;
+      if (stale) {
+        d.n_stale++;
+        if (sd.flag != 1 || sd.iters > (2 * d.lag) / 3) d.refactor_next = true;   // the next iteration starts from fresh factors
+        if (sd.flag != 1) {
+          const int it0 = sd.iters;
+          TSL_TRY(direct_factor(c));
+          sd = *st;
+          TSL_TRY(gmres(c, &sd, true));
+          sd.iters += it0;
+        }
+      }
+      return 0;
+    };
+    if (direct_try() != 0) {
+      if (d.enable == 1) return -1;
+      (void)hipGetLastError();   // an out-of-memory allocation leaves a sticky-looking but recoverable error code
+      d.numeric_valid = false; d.have_factor = false; d.plan_valid = false;
+      fprintf(stderr, "[tsl] direct solver set-up failed (%s): this solve runs on the iterative hierarchy%s\n", tsl_last_error(),
+              ++d.n_setup_fail >= 3 ? "; direct path disabled for this context" : "");
+      if (d.n_setup_fail >= 3) d.enable = 0;
+      c->ds_suspended = true;
+      const int rc = solve_perm(c, st);
+      c->ds_suspended = false;
+      if (rc == 0 && st->flag == 0) st->flag = 1;   // reported as a fallback
+      return rc;
     }
     if (sd.flag == 1) { *st = sd; st->flag = 0; st->method = 4; return 0; }
     if (c->verbose) {
@@ -1146,7 +1166,11 @@ static int solve_perm(tsl_ctx* c, tsl_solve_stats* st) {
     const int rc = solve_perm(c, &s2);
     c->cg_maxit = maxit_keep;
     c->ds_suspended = false;
-    if (rc == 0 && s2.flag == 3 && !(s2.rel_residual < sd.rel_residual)) {  // keep the better of the two answers, flagged as not converged
+    // keep the better of the two answers, flagged as not converged.  A non-finite residual never wins: a factorisation that produced
+    // Inf / NaN (element entries of 1e15 on a crushed pad) must not overwrite a finite iterate, and two non-finite answers are an error.
+    const bool sd_ok = std::isfinite(sd.rel_residual), s2_ok = rc == 0 && std::isfinite(s2.rel_residual);
+    if (rc == 0 && s2.flag == 3 && !sd_ok && !s2_ok) return tsl_fail("linear solve: factorisation and iterative fallback both ended with a non-finite residual");
+    if (rc == 0 && s2.flag == 3 && sd_ok && (!s2_ok || !(s2.rel_residual < sd.rel_residual))) {
       HIP_OK(hipMemcpyAsync(c->v_x.p, c->v_t4.p, 3 * (size_t)c->NV * sizeof(double), hipMemcpyDeviceToDevice, c->stream));
       *st = sd; st->iters = sd.iters + s2.iters; st->flag = 3; st->method = 4;
       return 0;
