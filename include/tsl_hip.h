@@ -79,7 +79,7 @@ typedef struct {
   /* convergence accounting of the step's linear solves (the reference's spsolve is exact every time, sparse_solver.py:85-105):
    * fallback = solves that needed a second solver and converged there (flag 1); unconverged = solves that ended with flag 3;
    * attained = solves accepted by the attainable-accuracy rule (iterative solvers: true residual stagnating within 100x of cg_tol;
- * direct path: stagnating with a normwise backward error <= 1e-13, what a backward-stable direct solver delivers);
+   * direct path: stagnating with a normwise backward error <= 1e-12, what a backward-stable direct solver delivers);
    * factorizations = numeric factorisations of the direct preconditioner; max_rel_residual over the step's solves */
   int32_t unconverged, attained, factorizations, plans;
   double max_rel_residual, max_backward_error;
@@ -88,7 +88,7 @@ typedef struct {
 typedef struct {
   int32_t iters, restarts, flag; /* flag 0 converged with the primary solver, 1 converged with a fallback solver, 3 NOT converged */
   double rel_residual;           /* true residual |b - Hx| / |b| of the returned solution */
-  int32_t method;                /* solver that produced x: 0 PCG, 1 MINRES, 2 GMRES, 3 BiCGStab, 4 sparse LU + GMRES refinement */
+  int32_t method;                /* solver that produced x: 0 PCG, 1 MINRES, 2 GMRES, 3 BiCGStab, 4 sparse LU + iterative refinement (GMRES where that stalls) */
   int32_t attained;              /* 1: accepted by the attainable-accuracy rule instead of rel_residual <= cg_tol */
   double backward_error;         /* method 4: |b - Hx| / (|H|_inf |x| + |b|) of the returned solution (0 if not evaluated) */
 } tsl_solve_stats;
@@ -209,8 +209,9 @@ int tsl_profile_read_events(tsl_ctx* ctx, double* spmv_ms_hip_events_host); /* s
 int tsl_bench_spmv(tsl_ctx* ctx, int variant, int reps, double* us_per_launch_host);
 
 /* Sparse direct path (multifrontal LU of the operator, the counterpart of the reference's spsolve, sparse_solver.py:85-105).
- * tsl_bench_direct: the launches of one kernel class of ONE factorisation (cls 0 k_ds_update, 1 k_ds_schur, 2 k_ds_panel,
- * 3 k_ds_extend) or of one application (4 k_ds_gemv) on the current plan, replayed `reps` times between one hipEvent pair;
+ * tsl_bench_direct: the launches of one kernel class of ONE factorisation (cls 0 the Gauss-Jordan inversions W = F11^-1:
+ * k_ds_inv_small / k_ds_pivot0 + k_ds_gj_step + k_ds_gj_finish; 1 k_ds_gemm in Schur mode with its extend-add; 2 k_ds_gemm in
+ * G = W F12 mode; 3 unused) or of one application (4 k_ds_gemv) on the current plan, replayed `reps` times between one hipEvent pair;
  * out4 = {us per launch, algorithmic flops per launch, algorithmic bytes per launch, launches per factorisation}.  The factors are
  * invalid afterwards.  tsl_direct_info: {plans, factorisations, applications, perturbed pivots of the last factorisation, host
  * seconds in plan builds, supernodes, levels, batches, flops per factorisation, bytes of fronts}. */

@@ -140,7 +140,8 @@ def _single_evaluation_parity(oracle, s, drive, steps, min_nc, newton_direction=
     fo = o.arr("proj_flag", (nb, -1)); do = o.arr("proj_dir", (nb, -1)); io = o.arr("proj_idx", (nb, -1, 3)); wo = o.arr("proj_w", (nb, -1, 3))
     assert np.array_equal(flag, fo)
     assert np.array_equal(dr[fo == 1], do[fo == 1])
-    assert np.array_equal(pidx[fo == 1], io[fo == 1])
+    mism = ((pidx != io).any(-1) & (fo == 1))
+    assert mism.sum() == 0, f"{int(mism.sum())} of {int((fo == 1).sum())} projected triangles differ (bodies x vertices {np.argwhere(mism)[:5].tolist()})"
     assert np.abs(pw[fo == 1] - wo[fo == 1]).max() < 1e-9
     assert nc == o.nc and nc >= min_nc, (nc, o.nc)
     c = ctx.constraints()

@@ -246,6 +246,20 @@ for s in range(3):
     assert abs(hist[s][0] - r0) < 1e-12 and hist[s][-1] > r0 * 1e-3, (s, hist[s])   # every rank holds the rewards of the whole batch
     assert all(hist[s][k + 1] > hist[s][k] for k in range(5))
 assert best[1] == 0 and best[2] == 5, best                                        # the smallest target converges fastest
+# a rollout that raises on ONE rank (an unconverged adjoint solve) must not stall the gather of the others: NaN for that scene and
+# iteration, no update, everybody continues
+class Flaky(Quad):
+    n = 0
+    def rollout(self):
+        Flaky.n += 1
+        if self.s == 1 and Flaky.n == 2:
+            raise RuntimeError("transfer_grad: linear solve not converged")
+        return super().rollout()
+hist2, _ = run_batch(b, 3, 4, Flaky, out_dir=None, log=lambda *a: None)
+assert all(len(v) == 4 for v in hist2.values())
+assert np.isnan(hist2[1][1]) and np.isfinite([hist2[1][0], hist2[1][2], hist2[1][3]]).all(), hist2[1]
+assert np.isfinite(hist2[0]).all() and np.isfinite(hist2[2]).all()
+assert hist2[1][2] > hist2[1][0]
 b.barrier()
 if b.rank == 0:
     assert np.load(os.path.join(out, "plot_data.npy")).shape == (3, 6)

@@ -179,3 +179,110 @@ def test_static_friction_loss_matches_reference_loops():
                             ref[step - 1, idx[i2], j2] += -dfdp * w1[i2] * c["n"][i][j2] * s.k_contact * g.f_loss_ratio
     assert n_used > 0
     assert np.allclose(g.pos_grad.to_numpy(), ref, rtol=1e-11, atol=1e-16)
+
+
+# ---- the seeds no reference driver calls (analytic_grad_single.py:314-321, 329-371, 384-406, 445-460)
+def _two_sheet_scene(N=9, M=4, n_ball=7):
+    NVc = (N + 1) * (M + 1)
+    c0 = SimpleNamespace(NV=NVc, NF=2 * N * M, offset=0, N=N, M=M)
+    c1 = SimpleNamespace(NV=NVc, NF=2 * N * M, offset=NVc, N=N, M=M)
+    ball = SimpleNamespace(offset=2 * NVc, n_verts=n_ball)
+    return SimpleNamespace(tot_NV=2 * NVc + n_ball, device=torch.device("cpu"), cloth_cnt=2, cloths=[c0, c1], elastics=[ball], dt=5e-3,
+                           cloth_N=N, cloth_M=M, target=0.03)
+
+
+def _grad2(T, seed=0):
+    s = _two_sheet_scene()
+    g = Grad(s, T, 1)
+    g.pos_buffer.from_numpy(np.random.default_rng(seed).normal(size=(T, s.tot_NV, 3)))
+    return s, g
+
+
+def test_get_loss_sep_card_slide_simple_match_reference_loops():
+    s, g = _grad2(6)
+    g.get_loss_sep(s)
+    ref = np.zeros((6, s.tot_NV, 3))
+    for i in range(s.cloths[0].NV):          # :314-321
+        for j in range(6):
+            ref[j, s.cloths[0].offset + i, 0] = 1
+    for i in range(s.cloths[1].NV):
+        for j in range(6):
+            ref[j, s.cloths[1].offset + i, 0] = -1
+    assert np.array_equal(g.pos_grad.to_numpy(), ref)
+    g.pos_grad.t.zero_(); g.get_loss_card(s)
+    ref[:] = 0
+    for i in range(s.cloths[0].NV):          # :384-388
+        for j in range(6):
+            if int(i / (s.cloths[0].M + 1)) == 8:
+                ref[j, s.cloths[0].offset + i, 2] = -1
+    assert np.array_equal(g.pos_grad.to_numpy(), ref) and ref.any()
+    g.pos_grad.t.zero_(); g.get_loss_slide_simple(s)
+    ref[:] = 0
+    for i in range(s.cloths[0].NV):          # :390-393
+        ref[5, s.cloths[0].offset + i, 0] = 1
+    assert np.array_equal(g.pos_grad.to_numpy(), ref)
+
+
+def test_get_loss_deliver_and_side_match_reference_loops():
+    T = 72
+    s, g = _grad2(T, seed=3)
+    g.get_loss_deliver(s)
+    pb = g.pos_buffer.to_numpy(); ref = np.zeros_like(pb)
+    c = s.cloths[0]
+    for i in range(c.NV):                    # :395-406
+        for k in range(3):
+            ref[T - 1, c.offset + i, k] = 2 * (pb[T - 1, c.offset + i, k] - pb[69, c.offset + i, k] - 0.01)
+    assert np.array_equal(g.pos_grad.to_numpy(), ref)
+    g.pos_grad.t.zero_(); g.get_loss_side(s)
+    ref[:] = 0
+    e = s.elastics[0]
+    tt = (s.cloth_N + 1) // 4 * (s.cloth_M + 1) + (s.cloth_M + 1) // 2
+    for i in range(e.n_verts):               # :445-460, serial order
+        for j in range(T - 1):
+            for k in (0, 1):
+                d = 2 * (pb[j + 1, e.offset + i, k] - pb[j + 1, c.offset + tt, k])
+                ref[j + 1, e.offset + i, k] = d
+                ref[j + 1, c.offset + tt, k] = -d
+    assert np.array_equal(g.pos_grad.to_numpy(), ref)
+
+
+def _bounce_reference(pb, T, c, target):
+    """literal restatement of get_loss_bounce (:329-371)"""
+    ref = np.zeros_like(pb)
+    tt = T - 1
+    max_z = -1.0
+    for j in range(40, T):
+        now_z = 0
+        for i in range(c.M + 1):
+            now_z += pb[j, i + c.offset, 2]
+        if now_z > max_z:
+            max_z = now_z; tt = j
+    if tt < T - 1:
+        z_prev = 0.0; z_next = 0.0
+        for i in range(c.M + 1):
+            z_prev += pb[tt - 1, i + c.offset, 2]; z_next += pb[tt + 1, i + c.offset, 2]
+        if z_prev > z_next:
+            for i in range(c.M + 1):
+                ref[tt - 1, c.offset + i, 2] = 2 * (pb[tt - 1, c.offset + i, 2] - target)
+        else:
+            for i in range(c.M + 1):
+                ref[tt + 1, c.offset + i, 2] = 2 * (pb[tt + 1, c.offset + i, 2] - target)
+    for i in range(c.M + 1):
+        ref[tt, c.offset + i, 2] = 2 * (pb[tt, c.offset + i, 2] - target)
+    return ref, tt
+
+
+def test_get_loss_bounce_matches_reference_loop():
+    T = 50
+    for seed, shape in ((0, "interior"), (1, "interior"), (2, "last"), (3, "none")):
+        s, g = _grad2(T, seed=seed)
+        pb = g.pos_buffer.to_numpy()
+        if shape == "last":      # apex on the last tape step: no neighbour seed
+            pb[T - 1, :s.cloths[0].M + 1, 2] = 10.0
+        if shape == "none":      # the first row never rises above -1 after step 40: the seed lands on the last step
+            pb[40:, :s.cloths[0].M + 1, 2] = -5.0
+        g.pos_buffer.from_numpy(pb)
+        tt = g.get_loss_bounce(s)
+        ref, tt_ref = _bounce_reference(pb, T, s.cloths[0], s.target)
+        assert tt == tt_ref and (shape != "last" or tt == T - 1)
+        assert np.allclose(g.pos_grad.to_numpy(), ref, rtol=0, atol=1e-15) and ref.any()

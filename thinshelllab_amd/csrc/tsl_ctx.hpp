@@ -116,6 +116,7 @@ struct DirectSolver {
   int gm_cap = 0;
   int dbg = 0;
   long n_stale = 0;
+  int refine_ir = 1;           // "direct_refine": 1 = classic iterative refinement with the factors (GMRES only where it stalls), 0 = flexible GMRES from the start
   int n_setup_fail = 0;        // set-up failures of the direct path in automatic mode (three disable it)
   DirectPlan plan;
   std::vector<DsGrid> grids;
@@ -217,6 +218,9 @@ struct tsl_ctx {
   DevBuf<float> bd_Binv;
   DevBuf<double> gm_V, gm_h;  // GMRES basis ((m+1) vectors) and projection coefficients
   DevBuf<double> gm_Z;        // preconditioned basis of the flexible variant (direct preconditioner)
+  DevBuf<double> ir_part;     // direct_refine: per-block partial sums + the three results
+  DevBuf<int> ir_ticket;
+  double* h_ir = nullptr;     // pinned host copy of {r.r, x.x, b.b}
   int gmres_m = 300, use_gmres = 1, use_minres = 1, verbose = 0;
   // analytic_grad_system.Grad: pos_grad clamp (1 there, 1000 in analytic_grad_single) and whether angleref_grad is clamped too
   double adj_clamp = 1000.0;

@@ -175,6 +175,51 @@ class Grad:
         k = c.offset + i + sys.cloth_N * (sys.cloth_M + 1)
         self.pos_grad.t[1:, k, 2] = 20 * pb[1:, k, 2]
 
+    # ---- seeds no driver of the reference calls (kept for the surface: analytic_grad_single.py:314-321, 329-371, 384-406, 445-460)
+    def get_loss_sep(self, sys):  # :314-321: pull two sheets apart along x, seeds on every tape step
+        c0, c1 = sys.cloths[0], sys.cloths[1]
+        self.pos_grad.t[:, c0.offset:c0.offset + c0.NV, 0] = 1
+        self.pos_grad.t[:, c1.offset:c1.offset + c1.NV, 0] = -1
+
+    def get_loss_bounce(self, sys):  # :329-371: seed on the first grid row at the apex after step 40 (and on the higher of its neighbours)
+        c = sys.cloths[0]
+        T = self.tot_timestep
+        row = slice(c.offset, c.offset + c.M + 1)
+        zsum = self.pos_buffer.t[:, row, 2].sum(dim=1).cpu().numpy()
+        tt = T - 1
+        max_z = -1.0
+        for j in range(40, T):
+            if zsum[j] > max_z:
+                max_z = zsum[j]; tt = j
+        pb, pg = self.pos_buffer.t, self.pos_grad.t
+        if tt < T - 1:
+            k = tt - 1 if zsum[tt - 1] > zsum[tt + 1] else tt + 1
+            pg[k, row, 2] = 2 * (pb[k, row, 2] - sys.target)
+        pg[tt, row, 2] = 2 * (pb[tt, row, 2] - sys.target)
+        return tt
+
+    def get_loss_card(self, sys):  # :384-388 (the same rows as get_loss_pick)
+        self.get_loss_pick(sys)
+
+    def get_loss_slide_simple(self, sys):  # :390-393
+        c = sys.cloths[0]
+        self.pos_grad.t[self.tot_timestep - 1, c.offset:c.offset + c.NV, 0] = 1
+
+    def get_loss_deliver(self, sys):  # :395-406: final cloth pose 1 cm (every axis) beyond the pose of tape step 69
+        c = sys.cloths[0]
+        j = self.tot_timestep - 1
+        sl = slice(c.offset, c.offset + c.NV)
+        self.pos_grad.t[j, sl] = 2 * (self.pos_buffer.t[j, sl] - self.pos_buffer.t[69, sl] - 0.01)
+
+    def get_loss_side(self, sys):  # :445-460: get_loss_balance towards the vertex a quarter of the way along the cloth
+        e = sys.elastics[0]
+        tt = sys.cloths[0].offset + (sys.cloth_N + 1) // 4 * (sys.cloth_M + 1) + (sys.cloth_M + 1) // 2
+        pb = self.pos_buffer.t
+        sl = slice(e.offset, e.offset + e.n_verts)
+        d = 2 * (pb[1:, sl, 0:2] - pb[1:, tt:tt + 1, 0:2])
+        self.pos_grad.t[1:, sl, 0:2] = d
+        self.pos_grad.t[1:, tt, 0:2] = -d[:, -1, :]
+
     # :492-516
     def accumulate_gripper_grad(self, traj, max_dist):
         g = self.gripper_grad.t

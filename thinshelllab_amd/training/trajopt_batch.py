@@ -40,8 +40,16 @@ def run_batch(batch, n_scenes, iters, make_problem, out_dir=None, log=print):
         t0 = time.time()
         for slot in range(slots):
             s = slot * batch.world + batch.rank
+            ok = False
             if s in problems:
-                reward, g = problems[s].rollout()
+                # a rollout that fails (an unconverged adjoint solve, a constraint overflow) must not take the job down: the other
+                # ranks would wait in the gather below.  The scene reports NaN for this iteration and skips its update.
+                try:
+                    reward, g = problems[s].rollout()
+                    ok = bool(np.isfinite(reward))
+                except Exception as e:  # noqa: BLE001
+                    log(f"rank {batch.rank} scene {s} iter {it}: rollout failed ({e!r}); reported as NaN, no update")
+                    reward, g = float("nan"), torch.zeros(shape, dtype=torch.float64)
             else:
                 reward, g = float("nan"), torch.zeros(shape, dtype=torch.float64)
             rewards, grads = batch.gather_results(reward, g)          # the only exchange of an iteration
@@ -53,7 +61,7 @@ def run_batch(batch, n_scenes, iters, make_problem, out_dir=None, log=print):
                         best = (rewards[r], sr, it)
                         if out_dir is not None and batch.rank == 0:
                             np.save(os.path.join(out_dir, "best_gripper_grad.npy"), grads[r].numpy())
-            if s in problems:
+            if s in problems and ok:
                 problems[s].step(g)
         if batch.rank == 0:
             log(f"iter {it}: rewards {[round(history[s][-1], 6) for s in range(n_scenes)]} best {best} ({time.time() - t0:.2f} s)")
@@ -128,8 +136,13 @@ class SceneProblem:
         else:
             reward = s.compute_reward_all(g)
             g.get_loss_balance(s)
+        g.allow_unconverged = True   # counted instead of raised in the middle of the sweep (run_batch keeps the ranks in lock-step)
+        g.unconverged = 0
         for step in range(T - 1, 0, -1):
             g.transfer_grad(step, s, self.contact)
+        if g.unconverged:
+            print(f"scene rollout: {g.unconverged} adjoint solves of {T - 1} did not converge; the gradient of this iteration is discarded", flush=True)
+            return float("nan"), torch.zeros_like(g.gripper_grad.t)
         if self.limit_grad:
             g.apply_action_limit_grad(self.agent, 0.015)
         return float(reward), g.gripper_grad.t.clone()
