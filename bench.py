@@ -47,6 +47,18 @@ def build_scene(args, rank, grid=None, cloth_size=None):
         s = Scene(cloth_size=args.cloth_size, N=grid, M=grid, Kb=100.0, k_angle=3.14, perturb=1e-4 * (1 + 0.01 * rank), device=dev, newton_cap=50)
         s.init_all()
         return s
+    if args.workload == "cfg3":
+        # SURVEY.md section 8d cfg3 (BASELINE configs[2]): folding topology with a 200 x 100 cloth (40,000 triangles, cloth_size 0.1 m), frozen table +
+        # one tactile pad, plastic hinges; the N = 1 point of the cfg5 batch (8 such scenes over 8 GPUs)
+        from thinshelllab_amd.task_scene.Scene_folding import Scene
+        s = Scene(cloth_size=0.1, cloth_N=grid, cloth_M=grid // 2, device=dev)
+        s.cloths[0].Kb[None] = 400.0      # trajopt_folding.py:50
+        s.init_all()
+        s.mu_cloth_elastic[None] = 5.0    # trajopt_folding.py:66
+        s.prev_pos.copy_from(s.pos)
+        s._bench_gs = 0.0
+        s._bench_rank = rank
+        return s
     # cfg4: balancing topology, cloth N = M = 224 with cloth_size = 0.12 m (dx = 5.4e-4 m) on the ball and the
     # four tactile pads at their native poses.  cfg4-scaled: the same scene enlarged by one similarity factor so that the cloth keeps
     # the native 4 mm spacing (the mesh-dependent stiffness of the reference model makes the literal refinement ~4x more expensive).
@@ -75,7 +87,12 @@ def _drive(n_part, gs, rank, frame=1, idle=0):
     dpos = np.zeros((n_part, 3)); drot = np.zeros((n_part, 3))
     if frame <= idle:
         return dpos, drot
-    if gs == 1.0:
+    if gs == 0.0:    # cfg3: the pad moves -z 2e-4 m per step for ten steps, then +x 2e-4 m per step
+        if frame <= 10:
+            dpos[:, 2] = -2e-4 * a
+        else:
+            dpos[:, 0] = 2e-4 * a
+    elif gs == 1.0:
         dpos[:, 2] = 1e-4 * a * np.where(np.arange(n_part) % 2 == 0, 1.0, -1.0)
     else:
         dpos[:, 2] = 5e-5 * gs * a
@@ -104,7 +121,9 @@ def run_rollout(scene, grad, K, args):
         S["max_res_fwd"] = max(S["max_res_fwd"], st["max_rel_residual"]); S["last_delta"].append(st["last_delta"])
     c = scene.cloths[0]
     grad.pos_grad.t.zero_(); grad.angleref_grad.t.zero_()
-    if contact is not None:
+    if args.workload == "cfg3":
+        grad.get_loss_fold(scene, 1.0, -1.0, rows=scene.fold_rows())   # analytic_grad_single.py:280-294, fold rows scaled with the grid
+    elif contact is not None:
         grad.get_loss_balance(scene)  # analytic_grad_single.py:428-443: ball over the cloth centre, seeds on every tape step
     else:
         grad.pos_grad.t[K, c.offset:c.offset + c.NV, 2] = 1.0  # dL/dx_K: lift the cloth (sum of z)
@@ -142,7 +161,7 @@ def cpu_baseline(args, scene, gpu_stats, K, rank):
     threads = min(ncpu, args.cpu_threads)
     po.set_threads(threads)
     out = {"unit": "element-steps/s", "cores": threads, "kind": "port"}
-    if args.workload != "drape":
+    if args.workload in ("cfg4", "cfg4-scaled"):
         G, Kc = args.cpu_grid, args.cpu_steps
         cs = 0.12 if args.workload == "cfg4" else None
 
@@ -222,7 +241,7 @@ def cpu_baseline(args, scene, gpu_stats, K, rank):
         st = o.stats()
         n_it = gpu_stats["newton"] + K     # every adjoint step = one assembly + one solve
         t_total = 2 * K * t_contact + n_it * t_newton
-        T = 2 * args.grid * args.grid
+        T = scene.cloths[0].NF
         out["bench_size"] = {
             "value": T * K / t_total, "cores": best, "per_newton_iteration_s": t_newton, "contact_detection_s": t_contact,
             "sparse_lu_s": po.direct_seconds[0], "solve_flag": st["flag"], "line_search_evals": st["ls"],
@@ -287,7 +306,7 @@ def roofline(ctx, scene, elapsed, K, stats, args):
                          "launches; compare the rocprofv3 kernel-trace averages under profiles/)",
                "plan": {k: info[k] for k in ("supernodes", "levels", "batches", "flops_per_factorization", "front_bytes")}})
     # bytes_model(measured counts) / wall / 8e12 with the per-triangle figures of the assembled-matrix algorithm (fp64)
-    T = 2 * args.grid * args.grid
+    T = scene.cloths[0].NF
     B_cg, B_asm, B_E = 686.0, 600.0, 128.0
     n_asm = stats["newton"] + K
     bytes_model = T * (n_asm * B_asm + (stats["it_fwd"] + stats["it_adj"]) * B_cg + (stats["newton"] + stats["ls"]) * B_E + K * 150.0)
@@ -306,9 +325,10 @@ def main():
     ap.add_argument("--steps", type=int, default=10)
     ap.add_argument("--warmup", type=int, default=3)
     ap.add_argument("--idle", type=int, default=0, help="cfg4: leading steps with the zero trajectory (SURVEY section 8d: 10 of T = 50); default 0, every step active")
-    ap.add_argument("--workload", choices=["cfg4", "cfg4-scaled", "drape"], default="cfg4",
+    ap.add_argument("--workload", choices=["cfg4", "cfg4-scaled", "cfg3", "drape"], default="cfg4",
                     help="cfg4: cloth on ball + 4 tactile pads with contact, cloth_size 0.12 m (the configuration the metric is quoted on); "
-                         "cfg4-scaled: same scene enlarged so that the cloth keeps its native 4 mm spacing; drape: contact-free pinned cloth")
+                         "cfg4-scaled: same scene enlarged so that the cloth keeps its native 4 mm spacing; cfg3: folding scene with a 200 x 100 cloth "
+                         "(40,000 triangles; --grid sets N, M = N / 2): one scene of the cfg5 batch; drape: contact-free pinned cloth")
     ap.add_argument("--grid", type=int, default=224, help="cloth grid N = M (224 -> 100,352 triangles)")
     ap.add_argument("--cloth-size", type=float, default=0.1 / 15 * 224, help="edge length of the square cloth in m (default keeps the reference dx = 0.1/15)")
     ap.add_argument("--cg-tol", type=float, default=1e-10)
@@ -318,6 +338,8 @@ def main():
     ap.add_argument("--cpu-steps", type=int, default=2)
     ap.add_argument("--cpu-threads", type=int, default=16)
     args = ap.parse_args()
+    if args.workload == "cfg3" and args.grid == 224:
+        args.grid = 200
 
     if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
         # one rank per GPU of this node over RCCL: re-execute under torch.distributed.run (the driver's own launcher sets WORLD_SIZE)
@@ -362,7 +384,7 @@ def main():
     info1 = ctx.direct_info()
     stats["factorizations_total"] = info1["factorizations"] - info0["factorizations"]
 
-    T = 2 * args.grid * args.grid
+    T = scene.cloths[0].NF
     value = T * K * world / elapsed
     n_solves_fwd = max(stats["newton"], 1)
     out = {
@@ -374,6 +396,9 @@ def main():
                                 f"{0.12 * args.grid / 224:.3f} m, dx {0.12 / 224:.2e} m) on the ball + 4 tactile pads at their native poses, paired grippers driven "
                                 f"+-1e-4 m in z every step" + (f" after {args.idle} idle steps" if args.idle else "") + ", loss get_loss_balance; "
                                 if args.workload == "cfg4" else
+                                f"cfg3 (SURVEY.md section 8d): Scene_folding topology with a {args.grid}x{args.grid // 2} cloth ({T} triangles, cloth_size 0.1 m), frozen table + one "
+                                f"tactile pad driven -z 2e-4 m per step for ten steps then +x, plastic hinges, loss get_loss_fold(1, -1); "
+                                if args.workload == "cfg3" else
                                 f"cfg4-scaled: Scene_balancing (cloth on ball + 4 tactile pads, paired grippers driven every step) with a {args.grid}x{args.grid} cloth "
                                 f"({T} triangles) and the whole scene enlarged x{args.grid * 0.004 / 0.06:.2f} so that the cloth keeps its native 4 mm spacing; "
                                 if args.workload == "cfg4-scaled" else

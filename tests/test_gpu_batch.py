@@ -38,3 +38,27 @@ def test_bench_under_launcher_reports_world():
     # a mismatch between --gpus and the launcher's world size is an error, not a silently different run
     r2 = _launch([os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "1", "--warmup", "0", "--grid", "48", "--no-cpu-baseline"], 29645)
     assert r2.returncode != 0
+
+
+def test_trajopt_batch_cfg5_at_stated_size_one_rank(tmp_path):
+    """BASELINE configs[4] at the size SURVEY section 8d states -- 8 scenes of the cfg3 class (folding, 200 x 100 cloth, 40,000 triangles
+    each, trajectory seeds default_rng(1000 + scene)) -- on the one GPU the test box has: the 8 scenes run round-robin on rank 0,
+    one optimisation iteration of 10 tape steps each (forward rollout, loss seed, reverse sweep, RCCL gather, Adam)."""
+    r = _launch(["-m", "thinshelllab_amd.training.trajopt_batch", "--env", "folding", "--scenes", "8", "--iter", "1", "--tot_step", "10", "--cloth_N", "200",
+                 "--out", str(tmp_path)], 29647, timeout=1500)
+    assert r.returncode == 0, r.stderr[-3000:]
+    hist = np.load(tmp_path / "plot_data.npy")
+    assert hist.shape == (8, 1) and np.isfinite(hist).all(), hist      # a scene with an unconverged adjoint solve would report NaN
+    trajs = [np.load(tmp_path / f"traj_scene{s}.npy") for s in range(8)]
+    assert all(t.shape == (10, 1, 6) for t in trajs)
+    assert min(np.abs(trajs[a] - trajs[b]).max() for a in range(8) for b in range(a)) > 0   # eight different trajectories
+    assert np.abs(np.load(tmp_path / "best_gripper_grad.npy")).max() > 0
+
+
+def test_bench_cfg3_workload_line():
+    """bench.py --workload cfg3: the N = 1 point of the cfg5 curve (one 200 x 100 folding scene per GPU)"""
+    r = _launch([os.path.join(ROOT, "bench.py"), "--gpus", "1", "--workload", "cfg3", "--steps", "3", "--warmup", "1", "--no-cpu-baseline"], 29649)
+    assert r.returncode == 0, r.stderr[-3000:]
+    d = json.loads([ln for ln in r.stdout.splitlines() if ln.startswith("{")][-1])
+    assert d["config"]["triangles"] == 40000 and d["value"] > 0 and d["config"]["solves_unconverged"] == 0
+    assert d["config"]["workload"].startswith("cfg3")

@@ -140,11 +140,22 @@ def _single_evaluation_parity(oracle, s, drive, steps, min_nc, newton_direction=
     fo = o.arr("proj_flag", (nb, -1)); do = o.arr("proj_dir", (nb, -1)); io = o.arr("proj_idx", (nb, -1, 3)); wo = o.arr("proj_w", (nb, -1, 3))
     assert np.array_equal(flag, fo)
     assert np.array_equal(dr[fo == 1], do[fo == 1])
+    # A projected triangle may differ only in an exact geometric tie that no perturbation of the query vertex breaks: the closest
+    # point lies on an edge or corner shared by two COPLANAR triangles (a cloth vertex beside the border of the flat table top): same
+    # point, same distance, same cosine, decided by the last bit.  Those entries must describe the same closest point and must not be
+    # active constraints (then nothing downstream depends on the choice).
     mism = ((pidx != io).any(-1) & (fo == 1))
-    assert mism.sum() == 0, f"{int(mism.sum())} of {int((fo == 1).sum())} projected triangles differ (bodies x vertices {np.argwhere(mism)[:5].tolist()})"
-    assert np.abs(pw[fo == 1] - wo[fo == 1]).max() < 1e-9
+    xs = s.pos.to_numpy()
+    tied = np.argwhere(mism)
+    assert len(tied) <= 5, f"{len(tied)} of {int((fo == 1).sum())} projected triangles differ (bodies x vertices {tied[:5].tolist()})"
+    for b_, v_ in tied:
+        cp_g = (pw[b_, v_][:, None] * xs[pidx[b_, v_]]).sum(0); cp_o = (wo[b_, v_][:, None] * xs[io[b_, v_]]).sum(0)
+        assert np.abs(cp_g - cp_o).max() < 1e-12, (b_, v_, cp_g, cp_o)
+    same = (fo == 1) & ~mism
+    assert np.abs(pw[same] - wo[same]).max() < 1e-9
     assert nc == o.nc and nc >= min_nc, (nc, o.nc)
     c = ctx.constraints()
+    assert not np.isin(c["idx"][:, 3], tied[:, 1]).any() if len(tied) else True
     gi, gw, gk, gdx0, gT, gn = _sorted_constraints(c["idx"], c["w"], c["k"], c["dx0"], c["T"], c["n"])
     oi, ow, ok, odx0, oT, on = _sorted_constraints(o.arr("const_idx", (-1, 4))[:nc].copy(), o.arr("const_w", (-1, 3))[:nc].copy(), o.arr("const_k")[:nc].copy(),
                                                    o.arr("const_dx0", (-1, 3))[:nc].copy(), o.arr("const_T", (-1, 6))[:nc].copy(), o.arr("const_n", (-1, 3))[:nc].copy())

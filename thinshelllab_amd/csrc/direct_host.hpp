@@ -332,10 +332,24 @@ static int direct_bench(tsl_ctx* c, int cls, int reps, double* out) {
   };
   if (d.ev0 == nullptr) { HIP_OK(hipEventCreate(&d.ev0)); HIP_OK(hipEventCreate(&d.ev1)); }
   issue(true);  // warm-up and accounting
-  HIP_OK(hipEventRecord(d.ev0, s));
-  for (int r = 0; r < reps; r++) issue(false);
-  HIP_OK(hipEventRecord(d.ev1, s));
-  HIP_OK(hipEventSynchronize(d.ev1));
+  if (d.dbg == 4) {   // timing experiment: the same launches captured into a hipGraph and replayed (gap between dependent kernel nodes against stream launches)
+    hipGraph_t g = nullptr; hipGraphExec_t ge = nullptr;
+    HIP_OK(hipStreamBeginCapture(s, hipStreamCaptureModeThreadLocal));
+    issue(false);
+    HIP_OK(hipStreamEndCapture(s, &g));
+    HIP_OK(hipGraphInstantiate(&ge, g, nullptr, nullptr, 0));
+    HIP_OK(hipGraphLaunch(ge, s));
+    HIP_OK(hipEventRecord(d.ev0, s));
+    for (int r = 0; r < reps; r++) HIP_OK(hipGraphLaunch(ge, s));
+    HIP_OK(hipEventRecord(d.ev1, s));
+    HIP_OK(hipEventSynchronize(d.ev1));
+    (void)hipGraphExecDestroy(ge); (void)hipGraphDestroy(g);
+  } else {
+    HIP_OK(hipEventRecord(d.ev0, s));
+    for (int r = 0; r < reps; r++) issue(false);
+    HIP_OK(hipEventRecord(d.ev1, s));
+    HIP_OK(hipEventSynchronize(d.ev1));
+  }
   HIP_OK(hipGetLastError());
   float ms = 0;
   HIP_OK(hipEventElapsedTime(&ms, d.ev0, d.ev1));
