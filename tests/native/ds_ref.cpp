@@ -30,6 +30,7 @@ extern "C" int dsref_solve(int NV, const int* row_ptr, const int* col, const dou
   const int S = P.sym.n_sn;
   for (int s = 0; s < S; s++) { const DsFrontDesc& f = P.fr[s]; for (int i = f.p; i < f.pp; i++) A[f.off + (long long)i * f.ld + i] = 1.0; }
   double min_piv = 1e300;
+  long n_viol = 0, n_store = 0, n_add = 0;
   for (int l = 0; l < P.n_levels; l++)
     for (int q = P.level_ptr[l]; q < P.level_ptr[l + 1]; q++) {
       const int s = P.level_sn[q];
@@ -61,11 +62,20 @@ extern "C" int dsref_solve(int NV, const int* row_ptr, const int* col, const dou
       if (f.parent >= 0) {
         const DsFrontDesc& pf = P.fr[f.parent];
         double* PF = A.data() + pf.off;
+        // the extend-add with the semantics of the kernel's epilogue: entries marked single-writer are STORED (a wrong mark loses a
+        // contribution and the solve below goes wrong); a non-zero value underneath such an entry is counted as a violation
         for (int iv = 0; iv < f.nv_bnd; iv++)
-          for (int jv = 0; jv < f.nv_bnd; jv++)
+          for (int jv = 0; jv < f.nv_bnd; jv++) {
+            const int ri = P.rel[f.rel_off + iv], rj = P.rel[f.rel_off + jv];
+            const int pi = ri & DS_REL_MASK, pj = rj & DS_REL_MASK;
+            const bool store = pi >= pf.pp && pj >= pf.pp && ((ri | rj) & DS_REL_EXCL);
             for (int r = 0; r < 3; r++)
-              for (int c = 0; c < 3; c++)
-                PF[(size_t)(P.rel[f.rel_off + iv] + r) * pf.ld + P.rel[f.rel_off + jv] + c] += F[(size_t)(f.pp + 3 * iv + r) * ld + f.pp + 3 * jv + c];
+              for (int c = 0; c < 3; c++) {
+                double& dst = PF[(size_t)(pi + r) * pf.ld + pj + c];
+                const double v = F[(size_t)(f.pp + 3 * iv + r) * ld + f.pp + 3 * jv + c];
+                if (store) { if (dst != 0.0) n_viol++; dst = v; n_store++; } else { dst += v; n_add++; }
+              }
+          }
       }
     }
   // solve
@@ -99,7 +109,7 @@ extern "C" int dsref_solve(int NV, const int* row_ptr, const int* col, const dou
         x[3 * (size_t)vt[i / 3] + i % 3] = acc;
       }
     }
-  if (stats) { stats[0] = S; stats[1] = P.n_levels; stats[2] = (double)P.arena; stats[3] = P.flops; stats[4] = min_piv; }
+  if (stats) { stats[0] = S; stats[1] = P.n_levels; stats[2] = (double)P.arena; stats[3] = P.flops; stats[4] = min_piv; stats[5] = (double)n_viol; stats[6] = (double)n_store; stats[7] = (double)n_add; }
   return 0;
 }
 
@@ -123,6 +133,16 @@ extern "C" int dsref_plan_stats(int NV, const int* row_ptr, const int* col, int 
     steps += b.max_pp / DS_T;
     if (verbose) printf("level %2d: %5d fronts  max pp %4d  max ld %4d  max bp %4d\n", b.level, b.count, b.max_pp, b.max_ld, b.max_bp);
   }
+  double n_store = 0, n_add = 0;   // Schur-complement entries that reach their parent by a plain store / by an atomic add
+  for (const DsFrontDesc& f : P.fr) {
+    if (f.parent < 0) continue;
+    const DsFrontDesc& pf = P.fr[f.parent];
+    long ex = 0, bnd = 0;
+    for (int iv = 0; iv < f.nv_bnd; iv++) { const int r = P.rel[f.rel_off + iv]; if ((r & DS_REL_MASK) >= pf.pp) { bnd++; if (r & DS_REL_EXCL) ex++; } }
+    const double st = 9.0 * ((double)bnd * bnd - (double)(bnd - ex) * (bnd - ex));
+    n_store += st; n_add += 9.0 * (double)f.nv_bnd * f.nv_bnd - st;
+  }
+  out[7] = n_store / std::max(n_store + n_add, 1.0);
   out[0] = P.sym.n_sn; out[1] = P.n_levels; out[2] = (double)P.batches.size(); out[3] = steps; out[4] = P.flops; out[5] = (double)P.arena * 8; out[6] = solve_bytes;
   return 0;
 }

@@ -119,3 +119,6 @@ def test_multifrontal_plan_matches_sparse_lu(dsref, N, M, n_body, n_cons, leaf, 
     assert stats[1] >= 2  # a real tree
     assert np.linalg.norm(x - xr) <= 1e-8 * np.linalg.norm(xr), (np.linalg.norm(x - xr) / np.linalg.norm(xr), stats)
     assert np.linalg.norm(A @ x - b) <= 1e-9 * np.linalg.norm(b)
+    # extend-add entries marked single-writer (plain stores in the kernel's epilogue): nothing underneath, and they are the majority
+    assert stats[5] == 0 and stats[6] > 0, stats
+    print(f"extend-add: {stats[6]:.0f} stored, {stats[7]:.0f} added ({100 * stats[6] / (stats[6] + stats[7]):.0f} % without an atomic)")

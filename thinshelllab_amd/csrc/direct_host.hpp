@@ -2,6 +2,7 @@
 //   direct_factor(c)       plan (if the constraint set changed) + numeric factorisation of the current operator (vals + c_H)
 //   direct_apply(c, r, z)  z = (LU)^-1 r on permuted solver vectors
 #pragma once
+#include <array>
 #include <chrono>
 
 #include "k_direct.hpp"
@@ -66,9 +67,22 @@ static int direct_static(tsl_ctx* c) {
   if (d.bad.alloc(8 + 4 * DS_BADLOG)) return -1;
   HIP_OK(hipFuncSetAttribute((const void*)k_ds_inv_small, hipFuncAttributeMaxDynamicSharedMemorySize, (int)ds_small_lds(DS_SMALL)));
   d.plan.sym.build_partition(NV, c->h_rows, d.grids, d.blocks, d.leaf);
+  d.cache.clear();   // parked plans belong to the previous partition
   d.static_ready = true;
   d.plan_valid = false;
   return 0;
+}
+
+static uint64_t ds_cons_key(const std::vector<int>& cons) {   // FNV-1a over the constraint vertex list
+  uint64_t h = 1469598103934665603ull;
+  for (int v : cons) { h ^= (uint64_t)(uint32_t)v; h *= 1099511628211ull; }
+  return h ^ (uint64_t)cons.size();
+}
+// active plan <-> cache slot (host plan, constraint list, every device array that belongs to a plan)
+static void ds_swap_slot(DirectSolver& d, DsPlanSlot& sl) {
+  std::swap(d.plan, sl.plan); d.h_cons.swap(sl.h_cons); d.h_cset.swap(sl.h_cset);
+  d.level_sn.swap(sl.level_sn); d.rel.swap(sl.rel); d.vtx.swap(sl.vtx); d.blk_ld.swap(sl.blk_ld); d.con_ld.swap(sl.con_ld);
+  d.wl_front.swap(sl.wl_front); d.wl_row.swap(sl.wl_row); d.blk_dst.swap(sl.blk_dst); d.con_dst.swap(sl.con_dst); d.fr.swap(sl.fr);
 }
 
 // plan for the current constraint set (rebuilt only when the set differs from the one the plan was made for)
@@ -84,6 +98,52 @@ static int direct_plan(tsl_ctx* c) {
   }
   d.cons_checked = true;
   if (d.plan_valid && cons == d.h_cons) return 0;
+  // the plan depends on the constraint SET (tree, fronts, maps of the static blocks); the order in which the engine appended the
+  // constraints (atomic append: different between the forward detection of a step and the adjoint's re-detection) only enters the
+  // map of the contact blocks
+  std::vector<std::array<int, 4>> canon((size_t)c->nc);
+  for (int e = 0; e < c->nc; e++) canon[e] = {cons[4 * e], cons[4 * e + 1], cons[4 * e + 2], cons[4 * e + 3]};
+  std::sort(canon.begin(), canon.end());
+  std::vector<int> cset((size_t)c->nc * 4);
+  for (int e = 0; e < c->nc; e++) for (int k = 0; k < 4; k++) cset[4 * e + k] = canon[e][k];
+  auto same_set_new_order = [&]() -> int {   // active plan is for this set: contact map for the current order
+    if (cons != d.h_cons) {
+      HIP_OK(hipStreamSynchronize(s));
+      if (d.plan.build_con(cons.data(), c->nc)) return tsl_fail("direct solver: constraint vertex outside its front");
+      TSL_TRY(ds_upload_grow(d.con_dst, d.plan.con_dst, s)); TSL_TRY(ds_upload_grow(d.con_ld, d.plan.con_ld, s));
+      HIP_OK(hipStreamSynchronize(s));
+      d.h_cons = cons;
+    }
+    d.numeric_valid = false; d.have_factor = false;
+    return 0;
+  };
+  if (d.plan_valid && cset == d.h_cset) return same_set_new_order();
+  if (d.cache_cap > 0) {
+    const uint64_t key = ds_cons_key(cset);
+    HIP_OK(hipStreamSynchronize(s));   // the active plan's arrays may still be in use by the previous solve
+    for (auto& sl : d.cache)
+      if (sl->used && sl->key == key && sl->h_cset == cset) {   // a constraint set seen before: its plan comes back, the active one takes the slot
+        ds_swap_slot(d, *sl);
+        sl->used = d.plan_valid; sl->key = ds_cons_key(sl->h_cset); sl->stamp = ++d.cache_clock;
+        d.plan_valid = true;
+        d.n_plan_hits++;
+        if (c->verbose >= 2) fprintf(stderr, "[tsl] direct plan: cached plan reused (nc %d, %d supernodes)\n", c->nc, d.plan.sym.n_sn);
+        return same_set_new_order();
+      }
+    if (d.plan_valid) {   // park the active plan before building the new one in its place
+      DsPlanSlot* dst = nullptr;
+      for (auto& sl : d.cache) if (!sl->used) { dst = sl.get(); break; }
+      if (!dst && (int)d.cache.size() < d.cache_cap) {
+        d.cache.emplace_back(new DsPlanSlot());
+        dst = d.cache.back().get();
+        dst->plan.sym.copy_partition(d.plan.sym); dst->plan.tpos = d.plan.tpos; dst->plan.threads = d.plan.threads;   // the static part a build starts from
+      }
+      if (!dst) { for (auto& sl : d.cache) if (!dst || sl->stamp < dst->stamp) dst = sl.get(); }
+      ds_swap_slot(d, *dst);
+      dst->used = true; dst->key = ds_cons_key(dst->h_cset); dst->stamp = ++d.cache_clock;
+      d.plan_valid = false;
+    }
+  }
   const auto t0 = std::chrono::steady_clock::now();
   const int rc = d.plan.build(c->h_rows, d.row_ptr, cons.data(), c->nc);
   const auto t_build = std::chrono::steady_clock::now();
@@ -104,7 +164,7 @@ static int direct_plan(tsl_ctx* c) {
   const size_t n3 = 3 * (size_t)c->NV;
   if (d.w.n < n3) { if (d.w.alloc(n3)) return -1; }
   HIP_OK(hipStreamSynchronize(s));  // host vectors of this function go out of scope
-  d.h_cons.swap(cons);
+  d.h_cons.swap(cons); d.h_cset.swap(cset);
   d.plan_valid = true;
   d.numeric_valid = false;
   d.have_factor = false;

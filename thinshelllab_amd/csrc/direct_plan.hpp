@@ -12,6 +12,11 @@
 #include "direct_sym.hpp"
 
 #define DS_T 32  // tile edge of the dense kernels; p and b are padded to multiples of it
+// rel[] entries: local dof in the parent's front; bit 30 marks a boundary vertex that NO sibling front has in its boundary and that
+// lies in the parent's boundary part -- an entry of the Schur complement whose row or column vertex carries the mark (and whose other
+// vertex is in the parent's boundary part too) has a single writer and no assembled value underneath: a plain store, no atomic
+#define DS_REL_EXCL (1 << 30)
+#define DS_REL_MASK (DS_REL_EXCL - 1)
 
 struct DsFrontDesc {
   long long off;             // first element of the front in the arena (doubles)
@@ -123,6 +128,7 @@ struct DirectPlan {
       { std::vector<int> fill(cptr.begin(), cptr.end() - 1); for (int s = 0; s < S; s++) if (fr[s].parent >= 0) clist[fill[fr[s].parent]++] = s; }
       const int nt = 1;   // 0.3 ms on one thread (MI355X host); starting threads costs more than they save here
       if ((int)locs.size() < nt) locs.resize(nt);
+      std::vector<std::vector<int>> cnts(nt);
       std::atomic<int> bad{0};
       ds_parallel_for(S, nt, 16, [&](int t, int p) {
         if (cptr[p] == cptr[p + 1]) return;
@@ -132,10 +138,17 @@ struct DirectPlan {
         const int* fv = &vtx[f.vtx_off];
         for (int i = 0; i < f.nv_own; i++) lc[fv[i]] = 3 * i;
         for (int i = 0; i < f.nv_bnd; i++) lc[fv[f.nv_own + i]] = f.pp + 3 * i;
+        std::vector<int>& cnt = cnts[t];   // how many children have the parent's local vertex in their boundary
+        cnt.assign(f.nv_own + f.nv_bnd, 0);
+        auto slot = [&](int l) { return l < f.pp ? l / 3 : f.nv_own + (l - f.pp) / 3; };
         for (int q = cptr[p]; q < cptr[p + 1]; q++) {
           const DsFrontDesc& ch = fr[clist[q]];
           const int* cv = &vtx[ch.vtx_off + ch.nv_own];
-          for (int i = 0; i < ch.nv_bnd; i++) { const int l = lc[cv[i]]; if (l < 0) bad = 1; rel[ch.rel_off + i] = l; }   // the boundary of a child is contained in the front of its parent
+          for (int i = 0; i < ch.nv_bnd; i++) { const int l = lc[cv[i]]; if (l < 0) { bad = 1; continue; } rel[ch.rel_off + i] = l; cnt[slot(l)]++; }   // the boundary of a child is contained in the front of its parent
+        }
+        for (int q = cptr[p]; q < cptr[p + 1]; q++) {
+          const DsFrontDesc& ch = fr[clist[q]];
+          for (int i = 0; i < ch.nv_bnd; i++) { int& l = rel[ch.rel_off + i]; if (l >= f.pp && cnt[slot(l)] == 1) l |= DS_REL_EXCL; }
         }
         for (int i = 0; i < f.nv_own + f.nv_bnd; i++) lc[fv[i]] = -1;
       });
@@ -246,6 +259,12 @@ struct DirectPlan {
       if (bad || written != row_ptr[NV]) return -2;
     }
     lap(3);
+    return build_con(cons, n_cons);
+  }
+
+  // destination of the 16 vertex-pair sub-blocks of every contact block, in the ORDER of `cons` (the engine appends constraints in
+  // no fixed order: a plan found again for the same constraint SET only needs this map redone)
+  int build_con(const int* cons, int n_cons) {
     con_dst.assign((size_t)n_cons * 16, -1); con_ld.assign((size_t)n_cons * 16, 0);
     for (int e = 0; e < n_cons; e++)
       for (int a = 0; a < 4; a++)

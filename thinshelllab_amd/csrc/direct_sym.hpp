@@ -45,6 +45,12 @@ struct DirectSym {
   std::vector<int> parent, level;
   int n_levels = 0;
 
+  // the static part (build_partition) of another instance: what build_tree starts from
+  void copy_partition(const DirectSym& o) {
+    NV = o.NV; c_order = o.c_order; c_ptr = o.c_ptr; c_lo = o.c_lo; c_grid = o.c_grid; c_pos = o.c_pos; c_sn = o.c_sn;
+    blocks = o.blocks; body_of = o.body_of; b_sn = o.b_sn; loose = o.loose; merge_sep = o.merge_sep; merge_k = o.merge_k;
+  }
+
   int own(int s) const { return sn_ptr[s + 1] - sn_ptr[s]; }
 
   // position of vertex v inside the front of supernode s in vertices (own vertices first, then the boundary); -1 if absent

@@ -208,7 +208,7 @@ __global__ void k_cloth_quirk(ClothArgs A, int n_cloth, const double* __restrict
 template <bool CLAMP_ALL>
 __global__ void __launch_bounds__(128)
 k_cloth_hess_face(ClothArgs A, const int* __restrict__ blk, const double* __restrict__ pos, const double* __restrict__ ref_angle,
-                  const double* __restrict__ Q, int spd, double* __restrict__ vals) {
+                  const double* __restrict__ Q, int spd, double* __restrict__ vals, double* __restrict__ rec) {
   const int t = blockIdx.x * blockDim.x + threadIdx.x;
   if (t >= A.n_cface) return;
   const int f = A.f_order[t];
@@ -359,6 +359,19 @@ k_cloth_hess_face(ClothArgs A, const int* __restrict__ blk, const double* __rest
   }
 
   if (CLAMP_ALL) spd_clamp<9>(L);
+  if (rec) {   // gather assembly (k_cloth_gather): the 9 x 9 block as a record of nine contiguous 3 x 3 vertex blocks, addressed by the
+               // processing index t (what the gather lists refer to): a lane fills its own 648 bytes, a gather reads 72 of them in a row
+    double* R = rec + (size_t)t * 81;
+#pragma unroll
+    for (int l = 0; l < 3; l++)
+#pragma unroll
+      for (int m = 0; m < 3; m++)
+#pragma unroll
+        for (int j = 0; j < 3; j++)
+#pragma unroll
+          for (int k = 0; k < 3; k++) R[(l * 3 + m) * 9 + j * 3 + k] = L[(l * 3 + j) * 9 + m * 3 + k];
+    return;
+  }
   // ---- flush the 3x3 grid of blocks
 #pragma unroll
   for (int l = 0; l < 3; l++)
@@ -373,7 +386,7 @@ k_cloth_hess_face(ClothArgs A, const int* __restrict__ blk, const double* __rest
 }
 
 // One lane per hinge: Gauss-Newton block d2theta * grad grad^T (compute_Hessian_bending :616-637)
-__global__ void k_cloth_hess_hinge(ClothArgs A, const int* __restrict__ blk, const double* __restrict__ pos, double* __restrict__ vals) {
+__global__ void k_cloth_hess_hinge(ClothArgs A, const int* __restrict__ blk, const double* __restrict__ pos, double* __restrict__ vals, double* __restrict__ rec) {
   const int h = blockIdx.x * blockDim.x + threadIdx.x;
   if (h >= A.n_hinge) return;
   const int f1 = A.hg_info[8 * h], l = A.hg_info[8 * h + 1], f2 = A.hg_info[8 * h + 2], p4 = A.hg_info[8 * h + 3], p21 = A.hg_info[8 * h + 4];
@@ -385,6 +398,13 @@ __global__ void k_cloth_hess_hinge(ClothArgs A, const int* __restrict__ blk, con
   d3 g[4];
   hinge_grad(g1, g2, l, p4, p21, g);
   const double d2 = 2.0 * c.Kb * c.dx * c.dx * (1.0 / 3.0);
+  if (rec) {   // gather assembly: the four vertex gradients and the scale, entry-major; block (j, k) = d2 g_j g_k^T is formed by k_cloth_gather
+    double* R = rec + (size_t)h * 16;   // 128-byte record: g_0 .. g_3, d2
+#pragma unroll
+    for (int j = 0; j < 4; j++) { R[3 * j] = g[j].x; R[3 * j + 1] = g[j].y; R[3 * j + 2] = g[j].z; }
+    R[12] = d2;
+    return;
+  }
 #pragma unroll
   for (int j = 0; j < 4; j++)
 #pragma unroll
@@ -394,6 +414,42 @@ __global__ void k_cloth_hess_hinge(ClothArgs A, const int* __restrict__ blk, con
 #pragma unroll
       for (int e = 0; e < 9; e++) atomicAdd(&vals[(size_t)base + 64 * e], d2 * B.m[e]);
     }
+}
+
+// Gather assembly of the cloth Hessian (round 3): one lane per 3 x 3 matrix block that some face or hinge contributes to.  The
+// element kernels above leave records (faces: their 9 x 9 block as nine 3 x 3 blocks; hinges: four vertex gradients + scale) and this kernel sums, for
+// its block, the contributions of the incident elements from a list built once per context (ent[ptr[b] .. ptr[b + 1]): bit 31
+// hinge / face, bits 4..30 element, bits 0..3 local vertex pair) and adds the sum to the matrix with ONE plain read-modify-write
+// per entry -- the scatter versions issue 144 (hinge) + 81 (face) f64 atomics per element, 30 M per assembly at 100k triangles,
+// which bound both kernels (0.27 ms of an assembly's 0.45).  Blocks are sorted by their address in the SELL-64 value array: the
+// lanes of a wave write consecutive lanes of one slice.  Fixed summation order: the assembled cloth blocks are the same bits every run.
+__global__ void __launch_bounds__(256) k_cloth_gather(int n_blk, const int* __restrict__ base, const int* __restrict__ ptr, const unsigned* __restrict__ ent, int n_hinge, int n_cface,
+                                                      const double* __restrict__ hrec, const double* __restrict__ frec, double* __restrict__ vals) {
+  const int b = blockIdx.x * blockDim.x + threadIdx.x;
+  if (b >= n_blk) return;
+  double acc[9] = {0, 0, 0, 0, 0, 0, 0, 0, 0};
+  for (int q = ptr[b]; q < ptr[b + 1]; q++) {
+    const unsigned e = ent[q];
+    const int el = (int)((e >> 4) & 0x7ffffff), pr = (int)(e & 15);
+    if (e >> 31) {
+      const int j = pr >> 2, k = pr & 3;
+      const double* R = hrec + (size_t)el * 16;
+      const double d2 = R[12];
+      const double gj[3] = {R[3 * j], R[3 * j + 1], R[3 * j + 2]};
+      const double gk[3] = {R[3 * k], R[3 * k + 1], R[3 * k + 2]};
+#pragma unroll
+      for (int r = 0; r < 3; r++)
+#pragma unroll
+        for (int c = 0; c < 3; c++) acc[3 * r + c] += d2 * (gj[r] * gk[c]);
+    } else {
+      const double* R = frec + (size_t)el * 81 + pr * 9;   // el: the face's processing index, pr = 3 l + m
+#pragma unroll
+      for (int q2 = 0; q2 < 9; q2++) acc[q2] += R[q2];
+    }
+  }
+  const size_t a0 = (size_t)base[b];
+#pragma unroll
+  for (int e = 0; e < 9; e++) vals[a0 + 64 * e] += acc[e];
 }
 
 // Cloth.update_ref_angle (:176-185), one lane per hinge

@@ -629,6 +629,7 @@ __global__ void __launch_bounds__(256, WPC) k_ds_gemm(DsDev D, int lv0) {
       pb1[q] = cols_hi ? Bm[(size_t)(k0 + r) * ldb + J0 + 32 + tx] : 0.0;
     }
   };
+  if (D.dbg == 6) { Am -= (size_t)I0 * ld; Bm -= J0; }   // timing experiments only: every workgroup streams the SAME operand tiles (cache-resident) ...
   gload(0);
   for (int k0 = 0; k0 < K; k0 += DS_SK) {
 #pragma unroll
@@ -636,7 +637,7 @@ __global__ void __launch_bounds__(256, WPC) k_ds_gemm(DsDev D, int lv0) {
 #pragma unroll
     for (int q = 0; q < 4; q++) { Bs[(ty + 8 * q) * SB + tx] = pb0[q]; Bs[(ty + 8 * q) * SB + tx + 32] = pb1[q]; }
     __syncthreads();
-    if (k0 + DS_SK < K) gload(k0 + DS_SK);
+    if (k0 + DS_SK < K && D.dbg != 7) gload(k0 + DS_SK);   // ... (7) or none after the first slab: LDS + matrix cores + barriers alone
 #pragma unroll
     for (int kk = 0; kk < DS_SK / 4; kk++) {
       const double a0 = As[(32 * wi + lr) * SA + 4 * kk + lk], a1 = As[(32 * wi + 16 + lr) * SA + 4 * kk + lk];
@@ -671,7 +672,9 @@ __global__ void __launch_bounds__(256, WPC) k_ds_gemm(DsDev D, int lv0) {
   for (int b = 0; b < 2; b++) {
     const int col = J0 + 32 * wj + 16 * b + lr;
     if (col >= f.b) continue;
-    const int pj = rel[col / 3] + col % 3;
+    const int rj = rel[col / 3];
+    const int pj = (rj & DS_REL_MASK) + col % 3;
+    const bool bj = pj >= pf.pp, ej = (rj & DS_REL_EXCL) != 0;   // column vertex in the parent's boundary part / seen by this child only
 #pragma unroll
     for (int a = 0; a < 2; a++)
 #pragma unroll
@@ -679,9 +682,17 @@ __global__ void __launch_bounds__(256, WPC) k_ds_gemm(DsDev D, int lv0) {
         const int row = I0 + 32 * wi + 16 * a + lk + 4 * r;
         if (row >= f.b) continue;
         const double v = f22[a][b][r] - acc[a][b][r];
-        if (D.dbg == 2) { if (v != 0.0) PA[(size_t)(rel[row / 3] + row % 3) * pf.ld + pj] += v; }   // timing experiment only (racy)
-        else if (D.dbg == 3) { if (v == 1e300) PA[0] = v; }                                              // no extend-add at all
-        else if (v != 0.0) atomicAdd(&PA[(size_t)(rel[row / 3] + row % 3) * pf.ld + pj], v);
+        const int ri = rel[row / 3];
+        const int pi = (ri & DS_REL_MASK) + row % 3;
+        double* dst = &PA[(size_t)pi * pf.ld + pj];
+        if (D.dbg == 2) { if (v != 0.0) *dst += v; }            // timing experiment only (racy)
+        else if (D.dbg == 3) { if (v == 1e300) PA[0] = v; }     // no extend-add at all
+        else if (v != 0.0) {
+          // single writer and nothing assembled underneath (both vertices in the parent's boundary part, one of them in no sibling's
+          // boundary): a plain store into the zeroed arena; everything else adds atomically (siblings overlap on the separators)
+          if (D.dbg != 5 && bj && pi >= pf.pp && (ej || (ri & DS_REL_EXCL))) *dst = v;
+          else atomicAdd(dst, v);
+        }
       }
   }
 }

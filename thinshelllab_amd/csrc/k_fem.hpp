@@ -186,7 +186,7 @@ TSL_DEV m3 tet_dH(const ElasticDev& e, const m3& F, const m3& Fi, const m3& FiT,
 // Element Hessians: kind 0 = 9x9 over vertices 0..2 with optional SPD projection, vertex 3 = minus row/col sums
 // (model_elastic_tactile.py:88-124); kind 1 = direct 12x12 (model_elastic_offset.py:101-167, no projection).
 __global__ void __launch_bounds__(64)
-k_tet_hess(TetArgs A, const int* __restrict__ blk, const double* __restrict__ pos, int spd, double* __restrict__ vals) {
+k_tet_hess(TetArgs A, const int* __restrict__ blk, const double* __restrict__ pos, int spd, double* __restrict__ vals, double* __restrict__ Vws, int warm) {
   const int t = blockIdx.x * blockDim.x + threadIdx.x;
   if (t >= A.n_tet) return;
   int v[4]; m3 B;
@@ -212,7 +212,10 @@ k_tet_hess(TetArgs A, const int* __restrict__ blk, const double* __restrict__ po
 #pragma unroll
         for (int j = 0; j < 3; j++) He[(n * 3 + dim) * 9 + i * 3 + j] = dH.m[j * 3 + i];
     }
-  if ((e.kind == 0 && spd) || spd == 2) spd_clamp<9>(He);  // spd 2: preconditioner-only assembly, every element block projected
+  if ((e.kind == 0 && spd) || spd == 2) {   // spd 2: preconditioner-only assembly, every element block projected
+    if (Vws) spd_clamp_warm<9>(He, Vws + t, (size_t)A.n_tet, warm != 0);   // eigenvector basis of the element's previous assembly as the start
+    else spd_clamp<9>(He);
+  }
   if (e.kind != 0) {
     // model_elastic_offset.py:151-167 scatters row = (vertex j, comp r), column = (n, dim): the transpose of the
     // tactile convention (identical whenever the block is symmetric, i.e. J > 0.01)

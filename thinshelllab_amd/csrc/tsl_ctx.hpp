@@ -1,6 +1,7 @@
 // Context of libtsl_hip.so: device-resident topology, the SELL-64 block matrix, solver scratch.
 // Host-side only (no kernels here).
 #pragma once
+#include <memory>
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 
@@ -52,6 +53,10 @@ struct DevBuf {
     return 0;
   }
   void release() { if (p) { (void)hipFree(p); p = nullptr; } n = 0; }
+  void swap(DevBuf& o) { std::swap(p, o.p); std::swap(n, o.n); }
+  DevBuf() = default;
+  DevBuf(const DevBuf&) = delete;
+  DevBuf& operator=(const DevBuf&) = delete;
   ~DevBuf() { release(); }
 };
 
@@ -91,6 +96,19 @@ struct MgCloth {
 
 // sparse direct preconditioner (direct_sym.hpp / direct_plan.hpp / k_direct.hpp): multifrontal LU of the assembled operator
 #define DS_NSIDE 2
+// a plan parked for a constraint set seen earlier: the reverse sweep revisits the sets of the forward rollout step by step
+// (analytic_grad_single.py:217-257 re-detects the contacts of every tape step), so its plans are found here instead of being
+// rebuilt (3-4 ms of host work each on cfg4)
+struct DsPlanSlot {
+  DirectPlan plan;
+  std::vector<int> h_cons, h_cset;   // constraint vertices in the engine's order (contact map) / as a sorted set (what the plan depends on)
+  uint64_t key = 0;
+  long stamp = 0;
+  bool used = false;
+  DevBuf<int> level_sn, rel, vtx, blk_ld, con_ld, wl_front, wl_row;
+  DevBuf<long long> blk_dst, con_dst;
+  DevBuf<DsFrontDesc> fr;
+};
 struct DirectSolver {
   int enable = -1;          // -1 auto (cloth grids of >= 1024 cells: the iterative hierarchy is probed first, the factorisation takes over when it fails), 0 off, 1 always
   bool hard = false;        // auto mode: the last probe of the iterative hierarchy failed
@@ -118,11 +136,15 @@ struct DirectSolver {
   long n_stale = 0;
   int refine_ir = 1;           // "direct_refine": 1 = classic iterative refinement with the factors (GMRES only where it stalls), 0 = flexible GMRES from the start
   int n_setup_fail = 0;        // set-up failures of the direct path in automatic mode (three disable it)
+  std::vector<std::unique_ptr<DsPlanSlot>> cache;   // plans of earlier constraint sets ("direct_plan_cache" slots, least recently used evicted)
+  int cache_cap = 64;
+  long cache_clock = 0, n_plan_hits = 0;
   DirectPlan plan;
   std::vector<DsGrid> grids;
   std::vector<DsBlock> blocks;
   std::vector<int> row_ptr;   // CSR numbering of the static block pattern (rows of h_rows)
-  std::vector<int> h_cons;    // constraint vertices the current plan was built for
+  std::vector<int> h_cons;    // constraint vertices the current plan's contact map was built for (engine order)
+  std::vector<int> h_cset;    // the same constraints as a sorted set: what tree, fronts and static maps depend on
   bool plan_valid = false;
   DevBuf<int> csr2sell, level_sn, rel, vtx, blk_ld, con_ld, bad, wl_front, wl_row;
   DevBuf<long long> blk_dst, con_dst;
@@ -218,6 +240,13 @@ struct tsl_ctx {
   DevBuf<float> bd_Binv;
   DevBuf<double> gm_V, gm_h;  // GMRES basis ((m+1) vectors) and projection coefficients
   DevBuf<double> gm_Z;        // preconditioned basis of the flexible variant (direct preconditioner)
+  DevBuf<unsigned> cg_ent;
+  DevBuf<int> cg_base, cg_ptr;           // gather assembly of the cloth Hessian: block addresses (ascending), list offsets, packed (element, vertex pair)
+  DevBuf<double> cg_hrec, cg_frec;       // per-hinge (13) and per-face (81) records, entry-major
+  int n_cgblk = 0, cloth_gather = 0;   // "cloth_gather" = 1: gather assembly of the cloth Hessian (deterministic; measured no faster than the class-ordered atomics: 268 against 270 us)
+  DevBuf<double> tet_V;       // eigenvector bases of the clamped element blocks of the last assembly (81 x n_tet, entry-major): warm start of the next one
+  long tet_V_count = 0;
+  int tet_warm = 1;
   DevBuf<double> ir_part;     // direct_refine: per-block partial sums + the three results
   DevBuf<int> ir_ticket;
   double* h_ir = nullptr;     // pinned host copy of {r.r, x.x, b.b}

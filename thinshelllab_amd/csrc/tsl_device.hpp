@@ -146,6 +146,78 @@ TSL_DEV void spd_clamp(double* A) {
     }
 }
 
+// The same eigen-clamp started from the eigenvector basis of the PREVIOUS assembly of the same element (Vg: D x D doubles with
+// element stride `vs`, i.e. entry e of this lane at Vg[e * vs]): A' = V^T A V is nearly diagonal when the element moved little (the
+// Newton iterations of a time step), so the cyclic Jacobi converges in 1-2 sweeps instead of 6-8 (k_tet_hess: one lane per element,
+// the longest kernel of an assembly).  Same convergence test, same reconstruction, i.e. the same clamped matrix to rounding; the new
+// basis V R is stored for the next call.  `warm` false (first assembly, periodic refresh against the slow loss of orthogonality of an
+// accumulated rotation product, non-finite stored basis) starts from the identity like spd_clamp.
+template <int D>
+TSL_DEV void spd_clamp_warm(double* A, double* __restrict__ Vg, size_t vs, bool warm) {
+  double V[D * D];
+  for (int i = 0; i < D; i++)
+    for (int j = i + 1; j < D; j++) { double s = 0.5 * (A[i * D + j] + A[j * D + i]); A[i * D + j] = s; A[j * D + i] = s; }
+  if (warm) {
+    bool ok = true;
+#pragma unroll
+    for (int e = 0; e < D * D; e++) { V[e] = Vg[e * vs]; ok = ok && (fabs(V[e]) <= 1.5); }
+    warm = ok;
+  }
+  if (warm) {   // A <- V^T A V
+    double T[D * D];
+    for (int i = 0; i < D; i++)
+      for (int j = 0; j < D; j++) { double s = 0; for (int k = 0; k < D; k++) s += A[i * D + k] * V[k * D + j]; T[i * D + j] = s; }
+    for (int i = 0; i < D; i++)
+      for (int j = i; j < D; j++) { double s = 0; for (int k = 0; k < D; k++) s += V[k * D + i] * T[k * D + j]; A[i * D + j] = s; A[j * D + i] = s; }
+  } else {
+#pragma unroll
+    for (int i = 0; i < D; i++)
+#pragma unroll
+      for (int j = 0; j < D; j++) V[i * D + j] = (i == j) ? 1.0 : 0.0;
+  }
+  for (int sweep = 0; sweep < 30; sweep++) {
+    double off = 0, diag = 0;
+    for (int i = 0; i < D; i++) {
+      diag += A[i * D + i] * A[i * D + i];
+      for (int j = i + 1; j < D; j++) off += A[i * D + j] * A[i * D + j];
+    }
+    if (off <= 1e-32 * (diag + off)) break;
+    for (int p = 0; p < D - 1; p++)
+      for (int q = p + 1; q < D; q++) {
+        double apq = A[p * D + q];
+        if (apq == 0.0) continue;
+        double theta = (A[q * D + q] - A[p * D + p]) / (2.0 * apq);
+        double t = (theta >= 0 ? 1.0 : -1.0) / (fabs(theta) + sqrt(theta * theta + 1.0));
+        double c = 1.0 / sqrt(t * t + 1.0), s = t * c;
+        for (int k = 0; k < D; k++) {
+          double akp = A[k * D + p], akq = A[k * D + q];
+          A[k * D + p] = c * akp - s * akq;
+          A[k * D + q] = s * akp + c * akq;
+        }
+        for (int k = 0; k < D; k++) {
+          double apk = A[p * D + k], aqk = A[q * D + k];
+          A[p * D + k] = c * apk - s * aqk;
+          A[q * D + k] = s * apk + c * aqk;
+        }
+        for (int k = 0; k < D; k++) {
+          double vkp = V[k * D + p], vkq = V[k * D + q];
+          V[k * D + p] = c * vkp - s * vkq;
+          V[k * D + q] = s * vkp + c * vkq;
+        }
+      }
+  }
+#pragma unroll
+  for (int e = 0; e < D * D; e++) Vg[e * vs] = V[e];
+  double lam[D];
+  for (int e = 0; e < D; e++) lam[e] = A[e * D + e] > 0 ? A[e * D + e] : 0.0;
+  for (int i = 0; i < D; i++)
+    for (int j = 0; j < D; j++) {
+      double s = 0;
+      for (int e = 0; e < D; e++) s += lam[e] * V[i * D + e] * V[j * D + e];
+      A[i * D + j] = s;
+    }
+}
+
 // 2x2 symmetric PSD projection (engine/linalg.py:5-12, closed form of the ti.svd based rule)
 TSL_DEV void spd_clamp2(double& a, double& b, double& d) {
   double tr = a + d, df = a - d;

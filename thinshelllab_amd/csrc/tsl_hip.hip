@@ -260,7 +260,6 @@ extern "C" int tsl_ctx_create(const tsl_scene_desc* d, tsl_ctx** out) {
     for (int j = 0; j < 4; j++)
       for (int k = 0; k < 4; k++) tetblk[(size_t)t * 16 + j * 4 + k] = P.lookup(tv[4 * t + j], tv[4 * t + k]);
   for (int v = 0; v < NV; v++) dblk[v] = P.lookup(v, v);
-
 #define UP(buf, vec) do { if (c->buf.upload(vec)) { delete c; return -1; } } while (0)
   UP(d_cloth, c->h_cloth); UP(cf_f2v, f2v); UP(cf_cf, cf); UP(cf_cp, cp); UP(cf_cloth, cid); UP(cf_V, V); UP(cf_li, li);
   std::vector<int> forder(c->n_cface);
@@ -276,7 +275,31 @@ extern "C" int tsl_ctx_create(const tsl_scene_desc* d, tsl_ctx** out) {
     std::stable_sort(forder.begin(), forder.end(), [&](int x, int y) { return key[x] != key[y] ? key[x] < key[y] : f2v[3 * x] < f2v[3 * y]; });
   }
   UP(cf_order, forder);
+  // gather assembly of the cloth Hessian (k_cloth_gather): per matrix block the list of (element, local vertex pair) that add to it
+  std::vector<int> cg_base, cg_ptr;
+  std::vector<unsigned> cg_ent;
+  {
+    std::vector<std::pair<int, unsigned>> tup;
+    tup.reserve((size_t)c->n_cface * 9 + (size_t)c->n_hinge * 16);
+    std::vector<int> fpos(c->n_cface);   // face -> its processing index (the face kernel writes its record there)
+    for (int t = 0; t < c->n_cface; t++) fpos[forder[t]] = t;
+    for (int f = 0; f < c->n_cface; f++)
+      for (int e = 0; e < 9; e++) tup.emplace_back(cfblk[(size_t)f * 9 + e], ((unsigned)fpos[f] << 4) | (unsigned)e);
+    for (int h = 0; h < c->n_hinge; h++)
+      for (int e = 0; e < 16; e++) tup.emplace_back(hgblk[(size_t)h * 16 + e], 0x80000000u | ((unsigned)h << 4) | (unsigned)e);
+    std::sort(tup.begin(), tup.end());
+    cg_ent.reserve(tup.size());
+    for (size_t i = 0; i < tup.size(); i++) {
+      if (i == 0 || tup[i].first != tup[i - 1].first) { cg_base.push_back(tup[i].first); cg_ptr.push_back((int)i); }
+      cg_ent.push_back(tup[i].second);
+    }
+    cg_ptr.push_back((int)tup.size());
+    c->n_cgblk = (int)cg_base.size();
+    if (c->n_cface >= (1 << 27) || c->n_hinge >= (1 << 27)) { delete c; return tsl_fail("cloth too large for the packed gather lists"); }
+  }
+
   UP(cf_blk, cfblk); UP(hg_info, hinfo); UP(hg_v, hv); UP(hg_blk, hgblk);
+  if (c->n_cgblk > 0) { UP(cg_base, cg_base); UP(cg_ptr, cg_ptr); UP(cg_ent, cg_ent); }
   UP(d_el, c->h_el); UP(tet_v, tv); UP(tet_el, tel); UP(tet_blk, tetblk); UP(tet_B, tB); UP(tet_W, tW);
   UP(diag_blk, dblk); UP(rowpos, P.rowpos); UP(perm, P.perm); UP(slice_off, P.slice_off); UP(slice_len, P.slice_len); UP(colidx, P.colidx);
   UP(diag_perm, P.diag_perm);
@@ -288,6 +311,7 @@ extern "C" int tsl_ctx_create(const tsl_scene_desc* d, tsl_ctx** out) {
 #undef UP
   int rc = 0;
   rc |= c->norm_dir.alloc((size_t)std::max(c->n_cface, 1) * 3);
+  if (c->n_cgblk > 0) { rc |= c->cg_hrec.alloc((size_t)std::max(c->n_hinge, 1) * 16); rc |= c->cg_frec.alloc((size_t)c->n_cface * 81); }
   rc |= c->quirk.alloc((size_t)std::max(d->n_cloth, 1) * 90);
   rc |= c->vals.alloc((size_t)P.n_slots * 9); rc |= c->vals_full.alloc((size_t)P.n_slots * 9);
   rc |= c->Dinv.alloc((size_t)NV * 9);
@@ -374,6 +398,9 @@ extern "C" int tsl_set_param(tsl_ctx* c, const char* key, double v) {
   else if (k == "direct") { c->ds.enable = (int)v; c->ds.numeric_valid = false; c->ds.hard = false; }
   else if (k == "direct_lag") c->ds.lag = (int)v;
   else if (k == "direct_refine") c->ds.refine_ir = (int)v;
+  else if (k == "direct_plan_cache") { c->ds.cache_cap = std::max(0, (int)v); c->ds.cache.clear(); }
+  else if (k == "tet_warm") c->tet_warm = (int)v;
+  else if (k == "cloth_gather") c->cloth_gather = (int)v;
   else if (k == "ds_dbg") c->ds.dbg = (int)v;
   else if (k == "direct_fallback_cap") c->ds.fallback_cap = (int)v;
   else if (k == "ds_bench_batch") c->ds.bench_batch = (int)v;
@@ -381,7 +408,7 @@ extern "C" int tsl_set_param(tsl_ctx* c, const char* key, double v) {
   else if (k == "direct_par_batches") c->ds.par_batches = (int)v;
   else if (k == "direct_gemm_wpc") c->ds.gemm_wpc = (int)v;
   else if (k == "direct_merge_sep") { c->ds.plan.sym.merge_sep = (int)v; c->ds.static_ready = false; c->ds.plan_valid = false; c->ds.numeric_valid = false; }
-  else if (k == "direct_merge_k") { c->ds.plan.sym.merge_k = v != 0; c->ds.plan_valid = false; c->ds.numeric_valid = false; }
+  else if (k == "direct_merge_k") { c->ds.plan.sym.merge_k = v != 0; c->ds.plan_valid = false; c->ds.numeric_valid = false; c->ds.cache.clear(); }
   else if (k == "direct_piv_tol") { c->ds.piv_tol = v; c->ds.numeric_valid = false; }
   else if (k == "direct_probe_cap") c->ds.probe_cap = std::max(1, (int)v);
   else if (k == "direct_probe_every") c->ds.probe_every = std::max(1, (int)v);
@@ -538,23 +565,43 @@ static int assemble(tsl_ctx* c, const double* pos, const double* prev, const dou
   if (c->n_tet) {
     if (grad) hipLaunchKernelGGL(k_tet_grad, dim3(nblk(c->n_tet, 256)), dim3(256), 0, stt, TA, pos, grad);
     if (c->tet_coop) hipLaunchKernelGGL(k_tet_hess_coop, dim3(nblk((long)c->n_tet * 16, 256)), dim3(256), 0, stt, TA, c->tet_blk.p, pos, spd, c->vals_full.p);
-    else hipLaunchKernelGGL(k_tet_hess, dim3(nblk(c->n_tet, 64)), dim3(64), 0, stt, TA, c->tet_blk.p, pos, spd, c->vals_full.p);
+    else {
+      // eigen-clamp of the element blocks warm-started from the previous assembly's eigenvectors ("tet_warm", on by default);
+      // every 16th clamped assembly starts from the identity again (orthogonality of the accumulated rotations)
+      double* vws = nullptr;
+      int warm = 0;
+      if (c->tet_warm && spd != 0) {
+        if (c->tet_V.n < (size_t)81 * c->n_tet) { if (c->tet_V.alloc((size_t)81 * c->n_tet)) return tsl_fail("out of device memory (tet eigenvectors)"); c->tet_V_count = 0; }
+        vws = c->tet_V.p;
+        warm = (c->tet_V_count++ % 16) != 0;
+      }
+      hipLaunchKernelGGL(k_tet_hess, dim3(nblk(c->n_tet, 64)), dim3(64), 0, stt, TA, c->tet_blk.p, pos, spd, c->vals_full.p, vws, warm);
+    }
   }
   TSL_TRY(contact_assemble(c, pos, spd, grad, st));
+  // the cloth gradient kernels (0.11 ms) ride behind the contact kernels on the side stream: the cloth Hessian kernels on the engine
+  // stream are the longest chain of an assembly once the element blocks are warm-started
+  hipStream_t sg = fork ? st : s;
+  if (grad) {
+    if (c->n_cface) hipLaunchKernelGGL(k_cloth_grad_face, dim3(nblk(c->n_cface, 256)), dim3(256), 0, sg, CA, pos, grad);
+    if (c->n_hinge) hipLaunchKernelGGL(k_cloth_grad_hinge, dim3(nblk(c->n_hinge, 256)), dim3(256), 0, sg, CA, pos, ref, grad);
+  }
   if (fork) HIP_OK(hipEventRecord(c->ev_join, c->side));
   if (fork_t) HIP_OK(hipEventRecord(c->ev_join2, c->side2));
-  if (grad) {
-    if (c->n_cface) hipLaunchKernelGGL(k_cloth_grad_face, dim3(nblk(c->n_cface, 256)), dim3(256), 0, s, CA, pos, grad);
-    if (c->n_hinge) hipLaunchKernelGGL(k_cloth_grad_hinge, dim3(nblk(c->n_hinge, 256)), dim3(256), 0, s, CA, pos, ref, grad);
-  }
   hipLaunchKernelGGL(k_vert_hess, dim3(nblk(NV, 256)), dim3(256), 0, s, VA, c->diag_blk.p, c->vals_full.p);
+  const bool gather = c->cloth_gather && c->n_cgblk > 0 && c->n_cface > 0;
   if (c->n_cface) {
     const int nq = (int)c->h_cloth.size() * 9;
     hipLaunchKernelGGL(k_cloth_quirk, dim3(nblk(nq, 64)), dim3(64), 0, s, CA, (int)c->h_cloth.size(), pos, ref, c->quirk.p);
-    if (spd == 2) hipLaunchKernelGGL((k_cloth_hess_face<true>), dim3(nblk(c->n_cface, 128)), dim3(128), 0, s, CA, c->cf_blk.p, pos, ref, c->quirk.p, spd, c->vals_full.p);
-    else hipLaunchKernelGGL((k_cloth_hess_face<false>), dim3(nblk(c->n_cface, 128)), dim3(128), 0, s, CA, c->cf_blk.p, pos, ref, c->quirk.p, spd, c->vals_full.p);
+    double* frec = gather ? c->cg_frec.p : (double*)nullptr;
+    if (spd == 2) hipLaunchKernelGGL((k_cloth_hess_face<true>), dim3(nblk(c->n_cface, 128)), dim3(128), 0, s, CA, c->cf_blk.p, pos, ref, c->quirk.p, spd, c->vals_full.p, frec);
+    else hipLaunchKernelGGL((k_cloth_hess_face<false>), dim3(nblk(c->n_cface, 128)), dim3(128), 0, s, CA, c->cf_blk.p, pos, ref, c->quirk.p, spd, c->vals_full.p, frec);
   }
-  if (c->n_hinge) hipLaunchKernelGGL(k_cloth_hess_hinge, dim3(nblk(c->n_hinge, 256)), dim3(256), 0, s, CA, c->hg_blk.p, pos, c->vals_full.p);
+  if (c->n_hinge) hipLaunchKernelGGL(k_cloth_hess_hinge, dim3(nblk(c->n_hinge, 256)), dim3(256), 0, s, CA, c->hg_blk.p, pos, c->vals_full.p, gather ? c->cg_hrec.p : (double*)nullptr);
+  // element records -> matrix blocks, one lane per block, no atomics (the element blocks of the FEM bodies and the mass diagonal touch other
+  // entries or were added before: k_vert_hess above runs on this stream)
+  if (gather) hipLaunchKernelGGL(k_cloth_gather, dim3(nblk(c->n_cgblk, 256)), dim3(256), 0, s, c->n_cgblk, c->cg_base.p, c->cg_ptr.p, (const unsigned*)c->cg_ent.p, c->n_hinge, c->n_cface,
+                                 (const double*)c->cg_hrec.p, (const double*)c->cg_frec.p, c->vals_full.p);
   if (fork) HIP_OK(hipStreamWaitEvent(s, c->ev_join, 0));
   if (fork_t) HIP_OK(hipStreamWaitEvent(s, c->ev_join2, 0));
   if (grad) hipLaunchKernelGGL(k_mask_vec, dim3(gsz(3 * (size_t)NV)), dim3(256), 0, s, 3 * (size_t)NV, c->frozen.p, grad);
