@@ -285,12 +285,18 @@ def roofline(ctx, scene, elapsed, K, stats, args):
     else:
         ach = v["bytes_per_launch"] / (v["us_per_launch"] * 1e-6) / 1e9
         rf = {"bound": "hbm", "achieved": ach, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": ach / HBM_PEAK_GBS, "traffic": None}
-    try:  # HBM bytes per launch from the committed rocprofv3 --pmc passes (scripts/gpu_profile.sh), if present for this kernel
+    # HBM bytes per launch: NOT measured by this run -- the figure of the latest committed rocprofv3 --pmc passes for this kernel
+    # (scripts/gpu_profile.sh + install_profiles.py), labelled with the profile set and the commit it was taken on
+    rf["traffic_source"] = None
+    try:
         key = {0: "k_ds_gj_step", 1: "k_ds_gemm1", 2: "k_ds_gemm0", 4: "k_ds_gemv"}[dom]
-        path = os.path.join(ROOT, "profiles", f"r02_{args.workload.replace('-', '_')}_pmc_{key}.json")
+        path = os.path.join(ROOT, "profiles", f"latest_{args.workload.replace('-', '_')}_pmc_{key}.json")
         if os.path.exists(path) and args.grid == 224:
             with open(path) as fh:
-                rf["traffic"] = json.load(fh)["traffic_bytes_per_launch"]
+                j = json.load(fh)
+            rf["traffic"] = j["traffic_bytes_per_launch"]
+            rf["traffic_source"] = (f"committed rocprofv3 --pmc passes (FETCH_SIZE x2 + WRITE_SIZE, separate passes) of profile set {j.get('tag', '?')} taken on commit "
+                                    f"{j.get('commit', '?')}: a constant read from profiles/, not a measurement of this run")
     except (OSError, KeyError, ValueError):
         pass
     tot = sum(share.values())

@@ -9,6 +9,13 @@ src = os.path.join(root, "gpurun_out", "prof") + os.sep
 dst = os.path.join(root, "profiles") + os.sep
 
 
+import subprocess
+try:
+    COMMIT = subprocess.check_output(["git", "-C", root, "rev-parse", "--short", "HEAD"], text=True).strip()
+except Exception:
+    COMMIT = "unknown"
+
+
 def last_json_line(path):
     return [l for l in open(path) if l.startswith('{"metric"')][-1]
 
@@ -31,11 +38,11 @@ for kn in ("k_ds_gemm1", "k_ds_gemm0", "k_ds_gj_step", "k_ds_gemv"):
     open(dst + f"{TAG}_{WL}_pmc_{kn}.txt", "w").write(f + "\n" + w + "\n")
     fm = float(re.search(r"mean=([0-9.]+)", f).group(1)); wm = float(re.search(r"mean=([0-9.]+)", w).group(1))
     traffic = int(round((2 * fm + wm) * 1024))
-    json.dump({"kernel": kn, "workload": WL.replace("_", "-"), "counters": {"FETCH_SIZE_KB_mean_per_dispatch": fm, "WRITE_SIZE_KB_mean_per_dispatch": wm},
+    json.dump({"kernel": kn, "workload": WL.replace("_", "-"), "tag": TAG, "commit": COMMIT, "counters": {"FETCH_SIZE_KB_mean_per_dispatch": fm, "WRITE_SIZE_KB_mean_per_dispatch": wm},
                "correction": "FETCH_SIZE x2 on gfx950 (MI355X_MICROARCH.md, HBM section); WRITE_SIZE as reported; separate --pmc passes, no tracing",
                "traffic_bytes_per_launch": traffic}, open(dst + f"{TAG}_{WL}_pmc_{kn}.json", "w"), indent=1)
-    # the name bench.py looks for (latest counters of the round)
-    shutil.copy(dst + f"{TAG}_{WL}_pmc_{kn}.json", dst + f"r02_{WL}_pmc_{kn}.json")
+    # the name bench.py looks for (latest counters; the JSON carries the profile set and the commit)
+    shutil.copy(dst + f"{TAG}_{WL}_pmc_{kn}.json", dst + f"latest_{WL}_pmc_{kn}.json")
     print(kn, "HBM traffic per launch:", traffic, "B (FETCH_SIZE", fm, "KB x2, WRITE_SIZE", wm, "KB)")
 rows = list(csv.DictReader(open(dst + f"{TAG}_{WL}_kernel_stats.csv")))
 tot = sum(float(r["TotalDurationNs"]) for r in rows)

@@ -42,6 +42,21 @@ def test_direct_solve_matches_sparse_lu(N, M, leaf):
     assert st2["method"] == 0 and rel_err(x2.cpu().numpy(), xs) < 1e-7
 
 
+def test_direct_deferred_schur_tiles_agree():
+    """"direct_overlap" = 1: the Schur tiles outside the parents' pivot blocks on a side stream from a capped grid (an experiment kept
+    behind its flag): the same factorisation"""
+    import scipy.sparse.linalg as spl
+    s = _drape(96, 64, 5e-5, seed=3)
+    ctx = s._ensure_ctx()
+    ctx.set_param("direct", 1); ctx.set_param("direct_leaf", 16); ctx.set_param("direct_overlap", 1); ctx.set_param("direct_overlap_cap", 64)
+    s.compute_residual_and_Hessian(spd=True)
+    b = s.F.to_torch().clone()
+    x, st = ctx.solve(b)
+    xs = spl.splu(ctx.operator_csr().tocsc()).solve(b.cpu().numpy())
+    assert st["flag"] == 0 and st["method"] == 4 and st["iters"] <= 3, st
+    assert rel_err(x.cpu().numpy(), xs) < 1e-9
+
+
 @pytest.mark.parametrize("wpc", [3, 4])
 def test_direct_gemm_occupancy_variants_agree(wpc):
     """k_ds_gemm is compiled for three (F22 tile prefetched) and four (fetched in the epilogue) workgroups per CU

@@ -21,11 +21,17 @@ static inline bool ds_use_small(const DsBatch& b) {
 
 // G = W F12 (mode 0) / S = F22 - F21 G added into the parents (mode 1) of a batch.  A 128 x 128-tile variant (64 accumulator
 // registers per lane, one wave per SIMD) was 2.5x slower than these 64 x 64 tiles, which reach 25-49 TFLOP/s per level on cfg4.
-static void ds_launch_gemm(hipStream_t s, const DsDev& D, const DsBatch& b, int mode, int wpc) {
+// part: 0 all tiles, 1 / 2 the urgent / deferred tiles of the Schur mode (k_ds_gemm); cap > 0: at most `cap` workgroups walk the tiles
+static void ds_launch_gemm(hipStream_t s, const DsDev& D, const DsBatch& b, int mode, int wpc, int part = 0, int cap = 0) {
   const int rows = mode == 0 ? b.max_pp : b.max_bp, cols = b.max_bp;
   const dim3 grid((cols + 63) / 64, (rows + 63) / 64, b.count);
-  if (mode == 0) { if (wpc >= 4) hipLaunchKernelGGL((k_ds_gemm<0, 4>), grid, dim3(256), 0, s, D, b.first); else hipLaunchKernelGGL((k_ds_gemm<0, 3>), grid, dim3(256), 0, s, D, b.first); }
-  else { if (wpc >= 4) hipLaunchKernelGGL((k_ds_gemm<1, 4>), grid, dim3(256), 0, s, D, b.first); else hipLaunchKernelGGL((k_ds_gemm<1, 3>), grid, dim3(256), 0, s, D, b.first); }
+  const long tiles = (long)grid.x * grid.y * grid.z;
+  if (cap > 0 && mode == 1 && tiles > cap) {
+    hipLaunchKernelGGL((k_ds_gemm_capped<1, 4>), dim3(cap), dim3(256), 0, s, D, b.first, (int)grid.x, (int)grid.y, (int)grid.z, part);
+    return;
+  }
+  if (mode == 0) { if (wpc >= 4) hipLaunchKernelGGL((k_ds_gemm<0, 4>), grid, dim3(256), 0, s, D, b.first, 0); else hipLaunchKernelGGL((k_ds_gemm<0, 3>), grid, dim3(256), 0, s, D, b.first, 0); }
+  else { if (wpc >= 4) hipLaunchKernelGGL((k_ds_gemm<1, 4>), grid, dim3(256), 0, s, D, b.first, part); else hipLaunchKernelGGL((k_ds_gemm<1, 3>), grid, dim3(256), 0, s, D, b.first, part); }
 }
 
 static bool direct_enabled(tsl_ctx* c) {
@@ -217,7 +223,16 @@ static int direct_factor(tsl_ctx* c, int stop_sn = -1, const char* dump_path = n
   hipLaunchKernelGGL(k_ds_assemble_blocks, dim3(ds_nblk(nnzb * 9, 256)), dim3(256), 0, s, nnzb, d.csr2sell.p, c->vals.p, d.blk_dst.p, d.blk_ld.p, d.arena.p);
   if (c->nc > 0) hipLaunchKernelGGL(k_ds_assemble_contacts, dim3(ds_nblk((long)c->nc * 144, 256)), dim3(256), 0, s, c->nc, c->c_H.p, d.con_dst.p, d.con_ld.p, d.arena.p);
   hipLaunchKernelGGL(k_ds_pad_diag, dim3(P.sym.n_sn), dim3(64), 0, s, P.sym.n_sn, d.fr.p, d.arena.p);
-  auto run_batch = [&](const DsBatch& b, hipStream_t bs) {
+  // "direct_overlap": the deferred part of a level's Schur complements overlaps with the block steps of the next level (which are
+  // latency-bound: a handful of fronts, one dependent launch per 32 pivots)
+  if (d.overlap && d.gstream == nullptr) {
+    HIP_OK(hipStreamCreateWithFlags(&d.gstream, hipStreamNonBlocking));
+    for (int k = 0; k < 8; k++) HIP_OK(hipEventCreateWithFlags(&d.ev_g[k], hipEventDisableTiming));
+    HIP_OK(hipEventCreateWithFlags(&d.ev_def, hipEventDisableTiming));
+  }
+  bool def_pending = false;   // deferred launches of the previous level not yet joined
+  int nrec = 0;
+  auto run_batch = [&](const DsBatch& b, hipStream_t bs, bool defer) {
     const int lv0 = b.first, nf = b.count;
     const int tp = b.max_pp / DS_T, tb = b.max_bp / DS_T;
     if (ds_use_small(b)) hipLaunchKernelGGL(k_ds_inv_small, dim3(nf), dim3(256), ds_small_lds(b.max_pp), bs, D, lv0, b.max_pp + 1);
@@ -226,9 +241,19 @@ static int direct_factor(tsl_ctx* c, int stop_sn = -1, const char* dump_path = n
       for (int k = 0; k < tp; k++) { const int na = P.act_n[b.act_off + k]; hipLaunchKernelGGL(k_ds_gj_step, dim3(na + na * tp * tp), dim3(256), 0, bs, D, lv0, k, tp, na); }   // fronts are sorted by pp: the active ones are a prefix
       hipLaunchKernelGGL(k_ds_gj_finish, dim3(tp, nf), dim3(256), 0, bs, D, lv0);
     }
+    if (def_pending) (void)hipStreamWaitEvent(bs, d.ev_def, 0);   // F12 / F21 / F22 of this level's fronts are complete once the previous level's deferred tiles are in
     if (tb > 0) {
       ds_launch_gemm(bs, D, b, 0, d.gemm_wpc);
-      ds_launch_gemm(bs, D, b, 1, d.gemm_wpc);   // + extend-add into the parents
+      if (!defer) ds_launch_gemm(bs, D, b, 1, d.gemm_wpc);   // + extend-add into the parents
+      else {
+        // Only the tiles of S that land in the parents' PIVOT blocks are in front of the next level's Gauss-Jordan chain; the rest
+        // (what the parents' own GEMMs need) runs on the deferred stream from a capped grid next to that chain.
+        (void)hipEventRecord(d.ev_g[nrec], bs);
+        (void)hipStreamWaitEvent(d.gstream, d.ev_g[nrec], 0);
+        nrec++;
+        ds_launch_gemm(bs, D, b, 1, d.gemm_wpc, 1);
+        ds_launch_gemm(d.gstream, D, b, 1, d.gemm_wpc, 2, d.overlap_cap);
+      }
     }
   };
   // The fronts of a level are independent: where a level was split into batches (by pivot-block size) the batches run on parallel
@@ -264,13 +289,25 @@ static int direct_factor(tsl_ctx* c, int stop_sn = -1, const char* dump_path = n
       HIP_OK(hipEventRecord(d.ev_ffork, s));
       for (int k = 0; k < nside; k++) HIP_OK(hipStreamWaitEvent(d.fstream[k], d.ev_ffork, 0));
     }
+    // defer this level's Schur tiles when the NEXT level is a short list of fronts on the block-step path (its chain is what the
+    // deferred tiles hide behind; the LDS kernel of small pivot blocks needs a whole CU's LDS and would wait for the capped grid)
+    bool defer = false;
+    if (d.overlap && stop_sn < 0 && be < P.batches.size()) {
+      size_t bn = be; int nfn = 0; bool small = false;
+      while (bn < P.batches.size() && P.batches[bn].level == P.batches[be].level) { nfn += P.batches[bn].count; small |= ds_use_small(P.batches[bn]); bn++; }
+      defer = nfn <= d.overlap_max_fronts && !small && (be - bi) <= 8;
+    }
+    nrec = 0;
     for (size_t q = bi; q < be; q++) {
       const int k = (int)(q - bi);   // batch 0 of the level (the largest pivot blocks: the longest chain of block steps) stays on the engine stream
-      run_batch(P.batches[q], (nside > 0 && k > 0) ? d.fstream[(k - 1) % nside] : s);
+      run_batch(P.batches[q], (nside > 0 && k > 0) ? d.fstream[(k - 1) % nside] : s, defer);
     }
     for (int k = 0; k < nside; k++) { HIP_OK(hipEventRecord(d.ev_fjoin[k], d.fstream[k])); HIP_OK(hipStreamWaitEvent(s, d.ev_fjoin[k], 0)); }
+    def_pending = defer;
+    if (defer) HIP_OK(hipEventRecord(d.ev_def, d.gstream));
     bi = be;
   }
+  if (def_pending) HIP_OK(hipStreamWaitEvent(s, d.ev_def, 0));
   d.anorm_valid = false;   // |H|_inf is formed when a refinement first asks for a backward error (direct_anorm): most solves never do
   if (stop_sn >= 0 || c->verbose >= 2) HIP_OK(hipStreamSynchronize(s));
   HIP_OK(hipGetLastError());

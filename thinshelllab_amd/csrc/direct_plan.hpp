@@ -27,6 +27,7 @@ struct DsFrontDesc {
   int vtx_off;               // vtx[vtx_off + iv]: vertex id of local vertex iv (own vertices, then boundary vertices)
   int nv_own, nv_bnd;
   int scr_off;               // offset of this front's scratch inside the per-level scratch (doubles)
+  int bu;                    // boundary dofs that are OWN dofs of the parent front (they come first: the boundary is sorted by elimination position)
 };
 
 // fronts of one tree level with pivot blocks of similar size: one set of launches (level_sn[first .. first + count), sorted by pp descending)
@@ -148,7 +149,9 @@ struct DirectPlan {
         }
         for (int q = cptr[p]; q < cptr[p + 1]; q++) {
           const DsFrontDesc& ch = fr[clist[q]];
-          for (int i = 0; i < ch.nv_bnd; i++) { int& l = rel[ch.rel_off + i]; if (l >= f.pp && cnt[slot(l)] == 1) l |= DS_REL_EXCL; }
+          int nu = 0;
+          for (int i = 0; i < ch.nv_bnd; i++) { int& l = rel[ch.rel_off + i]; if (l < f.pp) { if (nu != i) bad = 1; nu++; } else if (cnt[slot(l)] == 1) l |= DS_REL_EXCL; }
+          fr[clist[q]].bu = 3 * nu;
         }
         for (int i = 0; i < f.nv_own + f.nv_bnd; i++) lc[fv[i]] = -1;
       });

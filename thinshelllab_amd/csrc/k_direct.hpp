@@ -574,16 +574,20 @@ __global__ void __launch_bounds__(256) k_ds_inv_small(DsDev D, int lv0, int ls) 
 // workgroups per CU: 2-4 % slower on every level), an XCD-aware workgroup -> tile map (each XCD a contiguous tile range: no change
 // on the levels above the leaves, the leaf batch 77 instead of 49 us) -- the launches are bound neither by the LDS nor by the L2.
 #define DS_SK 32
+// part (Schur mode): 0 every tile; 1 only the tiles that reach the PARENT'S PIVOT BLOCK (rows and columns below f.bu: the boundary
+// of a front is sorted by elimination position, the parent's own dofs come first) -- what the parent's Gauss-Jordan chain waits
+// for; 2 the rest, which only the parent's GEMMs need.
 template <int mode, int WPC>
-__global__ void __launch_bounds__(256, WPC) k_ds_gemm(DsDev D, int lv0) {
+TSL_DEV void ds_gemm_tile(const DsDev& D, int lv0, int bx, int by, int bz, int part) {
   constexpr int SA = DS_SK + 1, SB = 64 + 1;
   constexpr bool PF = WPC <= 3;
   __shared__ double As[64 * SA];
   __shared__ double Bs[DS_SK * SB];
-  const DsFrontDesc f = D.fr[D.level_sn[lv0 + blockIdx.z]];
+  const DsFrontDesc f = D.fr[D.level_sn[lv0 + bz]];
   const int Mr = mode == 0 ? f.pp : f.bp, Nc = f.bp, K = f.pp;
-  const int I0 = blockIdx.y * 64, J0 = blockIdx.x * 64;
+  const int I0 = by * 64, J0 = bx * 64;
   if (I0 >= Mr || J0 >= Nc) return;
+  if (mode == 1 && part != 0) { const bool urgent = I0 < f.bu && J0 < f.bu; if (urgent != (part == 1)) return; }
   double* F = D.A + f.off;
   double* G = D.G + f.goff;
   const int ld = f.ld, pp = f.pp;
@@ -694,6 +698,23 @@ __global__ void __launch_bounds__(256, WPC) k_ds_gemm(DsDev D, int lv0) {
           else atomicAdd(dst, v);
         }
       }
+  }
+}
+
+template <int mode, int WPC>
+__global__ void __launch_bounds__(256, WPC) k_ds_gemm(DsDev D, int lv0, int part) {
+  ds_gemm_tile<mode, WPC>(D, lv0, blockIdx.x, blockIdx.y, blockIdx.z, part);
+}
+// The same tiles from a CAPPED grid: gridDim.x workgroups walk the (gx, gy, gz) tile space.  Launched with fewer workgroups than
+// the chip holds, it leaves room on every CU for the dependent block-step launches of the next level's Gauss-Jordan chain, which
+// run next to it on the engine stream (direct_factor: the deferred part of a level's Schur complements).
+template <int mode, int WPC>
+__global__ void __launch_bounds__(256, WPC) k_ds_gemm_capped(DsDev D, int lv0, int gx, int gy, int gz, int part) {
+  const int T = gx * gy * gz;
+  for (int t = blockIdx.x; t < T; t += gridDim.x) {
+    const int bx = t % gx, q = t / gx;
+    ds_gemm_tile<mode, WPC>(D, lv0, bx, q % gy, q / gy, part);
+    __syncthreads();   // the next tile overwrites the LDS slabs
   }
 }
 

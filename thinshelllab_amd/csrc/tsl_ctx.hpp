@@ -121,6 +121,13 @@ struct DirectSolver {
   hipStream_t fstream[2] = {nullptr, nullptr};   // batches of one level run next to each other (direct_factor)
   hipEvent_t ev_ffork = nullptr, ev_fjoin[2] = {nullptr, nullptr};
   int par_batches = 1;      // "direct_par_batches"
+  hipStream_t gstream = nullptr;   // deferred Schur tiles (direct_factor, "direct_overlap")
+  hipEvent_t ev_g[8] = {}, ev_def = nullptr;
+  // "direct_overlap" (off), "direct_overlap_cap" (workgroups of the capped grid), "direct_overlap_fronts".  Measured on cfg4 (round 3, kernel trace +
+  // four A/B runs of the driver's command): the deferred tiles run 1.8x slower from the capped grid and the block steps next to them 1.3-1.6x
+  // slower (219 instead of 134 us for the 8 steps of 16 fronts): every level takes as long as before, 309-311 against 305-306 ms per step --
+  // the block steps are not idle time that other work can fill, their 1024 workgroups keep the memory system busy
+  int overlap = 0, overlap_cap = 512, overlap_max_fronts = 160;
   int gemm_wpc = 4;         // "direct_gemm_wpc": workgroups per CU the GEMM kernels are compiled for (3: F22 tile prefetched, 4: fetched in the epilogue)
   bool cons_checked = false; // the constraint list has not changed since direct_plan last looked (reset by tsl_contact_detect)
   double* h_anorm = nullptr; // pinned: |H|_inf of the last factorisation (valid after the next stream synchronisation)

@@ -357,6 +357,7 @@ extern "C" void tsl_ctx_destroy(tsl_ctx* c) {
   if (c->ds.ev_ffork) (void)hipEventDestroy(c->ds.ev_ffork);
   if (c->ds.h_anorm) (void)hipHostFree(c->ds.h_anorm);
   if (c->h_ir) (void)hipHostFree(c->h_ir);
+  if (c->ds.gstream) { (void)hipStreamSynchronize(c->ds.gstream); for (int k = 0; k < 8; k++) (void)hipEventDestroy(c->ds.ev_g[k]); (void)hipEventDestroy(c->ds.ev_def); (void)hipStreamDestroy(c->ds.gstream); }
   if (c->ds.zstream) { (void)hipStreamSynchronize(c->ds.zstream); (void)hipEventDestroy(c->ds.ev_zfork); (void)hipEventDestroy(c->ds.ev_zero); (void)hipStreamDestroy(c->ds.zstream); }
   if (c->ev_fork) (void)hipEventDestroy(c->ev_fork);
   if (c->ev_join) (void)hipEventDestroy(c->ev_join);
@@ -398,6 +399,9 @@ extern "C" int tsl_set_param(tsl_ctx* c, const char* key, double v) {
   else if (k == "direct") { c->ds.enable = (int)v; c->ds.numeric_valid = false; c->ds.hard = false; }
   else if (k == "direct_lag") c->ds.lag = (int)v;
   else if (k == "direct_refine") c->ds.refine_ir = (int)v;
+  else if (k == "direct_overlap") c->ds.overlap = (int)v;
+  else if (k == "direct_overlap_cap") c->ds.overlap_cap = std::max(0, (int)v);
+  else if (k == "direct_overlap_fronts") c->ds.overlap_max_fronts = (int)v;
   else if (k == "direct_plan_cache") { c->ds.cache_cap = std::max(0, (int)v); c->ds.cache.clear(); }
   else if (k == "tet_warm") c->tet_warm = (int)v;
   else if (k == "cloth_gather") c->cloth_gather = (int)v;
