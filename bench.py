@@ -244,7 +244,8 @@ def cpu_baseline(args, scene, gpu_stats, K, rank):
         T = scene.cloths[0].NF
         out["bench_size"] = {
             "value": T * K / t_total, "cores": best, "per_newton_iteration_s": t_newton, "contact_detection_s": t_contact,
-            "sparse_lu_s": po.direct_seconds[0], "solve_flag": st["flag"], "line_search_evals": st["ls"],
+            "sparse_lu_s": po.direct_seconds[0], "sparse_lu_rel_residual": (po.direct_residuals[-1] if po.direct_residuals else None),
+            "solve_flag": st["flag"], "line_search_evals": st["ls"],
             "assembly_s_by_threads": {str(k): v for k, v in sweep.items()},
             "what": f"measured per iteration, scaled: ONE complete Newton iteration of the oracle on the bench scene and state (energy + assembly on {best} OpenMP threads of "
                     f"{ncpu} host cpus, best of the thread sweep: {sweep[best]:.3f} s; the linear solve by scipy's SuperLU like the reference's spsolve, single-threaded: "

@@ -55,6 +55,7 @@ def lib():
 # SuperLU on the oracle's own assembled block-CSR matrix
 _DIRECT_CB = C.CFUNCTYPE(C.c_int, C.c_int, C.POINTER(C.c_int), C.POINTER(C.c_int), C.POINTER(C.c_double), C.POINTER(C.c_double), C.POINTER(C.c_double))
 direct_seconds = [0.0, 0]   # [time spent in SuperLU, calls] (bench.py's cpu_baseline reports it)
+direct_residuals = []        # relative residuals |b - Hx| / |b| of the last SuperLU solves
 
 
 def _direct_solve(nb, row_ptr, col, vals, b, x):
@@ -74,6 +75,8 @@ def _direct_solve(nb, row_ptr, col, vals, b, x):
             return 1
         np.ctypeslib.as_array(x, shape=(3 * nb,))[:] = xx
         direct_seconds[0] += time.time() - t0; direct_seconds[1] += 1
+        direct_residuals.append(float(np.linalg.norm(bb - A @ xx) / max(np.linalg.norm(bb), 1e-300)))   # what a pivoted sparse LU attains on this system
+        del direct_residuals[:-64]
         return 0
     except Exception:   # noqa: BLE001 -- a Python exception must not unwind through the C frame
         return 2

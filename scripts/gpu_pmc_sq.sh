@@ -3,7 +3,7 @@
 # the block-step kernel go (MFMA busy, waiting, issue stalls, LDS conflicts).  usage (GPU box): bash scripts/gpu_pmc_sq.sh <tag>
 cd $GRAFT_REPO_ROOT
 export TMPDIR=/tmp
-TAG=${1:-r02f}
+TAG=${1:-r03}
 mkdir -p gpurun_out/prof
 for KRN in "k_ds_gemm<1" "k_ds_gemm<0" "k_ds_gj_step"; do
   KN=$(echo $KRN | tr -d '<>')

@@ -5,7 +5,7 @@
 #   combined with tracing), 3. the bench lines with cpu_baseline (default command and the driver's command).
 cd $GRAFT_REPO_ROOT
 export TMPDIR=/tmp
-TAG=${1:-r02}
+TAG=${1:-r03}
 WL=${WORKLOAD:-cfg4}
 ARGS=${BENCH_ARGS:---steps 20 --warmup 5 --no-cpu-baseline}
 PMC_ARGS=${PMC_ARGS:---steps 3 --warmup 1 --no-cpu-baseline}

@@ -2,7 +2,7 @@
 headline numbers.  usage (repo root, after `gpurun -- 'bash scripts/gpu_profile.sh r02a'`):  python scripts/install_profiles.py r02a [workload]"""
 import csv, json, os, re, shutil, sys
 
-TAG = sys.argv[1] if len(sys.argv) > 1 else "r02a"
+TAG = sys.argv[1] if len(sys.argv) > 1 else "r03a"
 WL = (sys.argv[2] if len(sys.argv) > 2 else "cfg4").replace("-", "_")
 root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 src = os.path.join(root, "gpurun_out", "prof") + os.sep
