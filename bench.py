@@ -411,7 +411,7 @@ def main():
                                 if args.workload == "cfg4-scaled" else
                                 f"drape: {args.grid}x{args.grid} square cloth ({T} triangles, dx={args.cloth_size / args.grid:.3e} m), one pinned row, no contact; ") +
                                "per step: implicit-Euler Newton time step (contact detection, friction; per Newton iteration one multifrontal LU of the "
-                               "operator + GMRES refinement to cg_tol) + adjoint transfer_grad; one independent scene per GPU",
+                               "operator + iterative refinement to cg_tol) + adjoint transfer_grad; one independent scene per GPU",
                    "triangles": T, "tot_NV": scene.tot_NV, "cg_tol": args.cg_tol, "active_contacts_per_step": stats["nc"] / K,
                    "newton_iters_per_step": stats["newton"] / K, "line_search_evals_per_step": stats["ls"] / K,
                    "newton_last_delta_per_step": [float(f"{d:.3g}") for d in stats["last_delta"]],

@@ -119,6 +119,12 @@ int tsl_set_stream(tsl_ctx* ctx, void* hip_stream);
  * "direct_gemm_wpc" (4 / 3: workgroups per CU the factorisation GEMMs are compiled for; 3 prefetches the F22 tile, default 4),
  * "direct_par_batches" (1: batches of one elimination level on parallel streams), "direct_merge_k" (1: constrained body vertices share the
  * supernode of their separator), "direct_merge_sep" (separators of at most this many vertices join the enclosing separator's supernode; 16, 0 = off),
+ * "direct_refine" (1: plain iterative refinement with the factors, GMRES only where it stalls; 0: flexible GMRES from the start),
+ * "direct_plan_cache" (plans of earlier constraint sets kept, default 64; the reverse sweep finds the forward rollout's plans there),
+ * "direct_overlap" / "direct_overlap_cap" / "direct_overlap_fronts" (0: Schur tiles outside the parents' pivot blocks on a side stream from a capped
+ * grid next to the next level's block steps -- an experiment, measured without gain), "tet_warm" (1: the eigen-clamp of the element blocks starts
+ * from the eigenvectors of the element's previous assembly), "cloth_gather" (0; 1: cloth Hessian gathered per matrix block from element records
+ * instead of scattered atomics: deterministic, measured no faster),
  * "tet_coop" (1: 16 lanes per tetrahedron in the element Hessians), "ds_dbg" / "ds_bench_batch" (timing experiments of tsl_bench_direct),
  * "mg_fuse_restrict" (first sweep + residual + restriction of a stencil level in one launch), "mg_st_f32" (single-precision stencil
  * operators), "mg_fr_rows", "pcg_body_fold" (dense-body first sweep inside the PCG update launch), "asm_overlap" (contact blocks on a
