@@ -198,7 +198,8 @@ static int direct_prezero(tsl_ctx* c) {
   HIP_OK(hipEventRecord(d.ev_zfork, c->stream));
   HIP_OK(hipStreamWaitEvent(d.zstream, d.ev_zfork, 0));
   d.prezero_n = (size_t)d.plan.arena;
-  HIP_OK(hipMemsetAsync(d.arena.p, 0, d.prezero_n * sizeof(double), d.zstream));
+  if (d.two_arenas) hipLaunchKernelGGL(k_ds_clear, dim3(std::max(1, d.clear_wgs)), dim3(256), 0, d.zstream, d.arena.p, d.prezero_n);   // next to the following iteration, which uses the other arena
+  else HIP_OK(hipMemsetAsync(d.arena.p, 0, d.prezero_n * sizeof(double), d.zstream));
   HIP_OK(hipEventRecord(d.ev_zero, d.zstream));
   d.prezero_pending = true;
   d.numeric_valid = false; d.have_factor = false;
@@ -212,12 +213,30 @@ static int direct_factor(tsl_ctx* c, int stop_sn = -1, const char* dump_path = n
   TSL_TRY(direct_plan(c));
   if (d.numeric_valid) return 0;
   const DirectPlan& P = d.plan;
+  if (d.two_arenas && d.prezero && d.prezero_pending && stop_sn < 0) {
+    // Two arenas: the one released by the last solve is being cleared in the background; this factorisation takes the OTHER one, which
+    // was cleared during the previous iteration.  First use (or a plan that outgrew it): allocate it and clear it inline once.
+    if (d.arena_b.n < (size_t)P.arena) {
+      if (d.b_pending) { HIP_OK(hipEventSynchronize(d.ev_zero_b)); d.b_pending = false; }
+      if (d.arena_b.alloc(std::max(d.arena.n, (size_t)P.arena + (size_t)P.arena / 8))) return tsl_fail("direct solver: out of device memory (second front arena)");
+    }
+    if (d.ev_zero_b == nullptr) HIP_OK(hipEventCreateWithFlags(&d.ev_zero_b, hipEventDisableTiming));
+    if (!d.b_pending) {
+      HIP_OK(hipMemsetAsync(d.arena_b.p, 0, (size_t)P.arena * sizeof(double), s));
+      HIP_OK(hipEventRecord(d.ev_zero_b, s));
+      d.b_pending = true; d.b_n = (size_t)P.arena;
+    }
+    d.arena.swap(d.arena_b);
+    std::swap(d.ev_zero, d.ev_zero_b); std::swap(d.prezero_n, d.b_n);
+    // both are pending now: the new current one (clean, or its clear long done) and the released one (being cleared)
+  }
   const DsDev D = ds_dev(c);
   if (d.prezero_pending) {   // cleared on the side stream since the last solve (direct_prezero)
     HIP_OK(hipStreamWaitEvent(s, d.ev_zero, 0));
     d.prezero_pending = false;
     if (d.prezero_n < (size_t)P.arena) HIP_OK(hipMemsetAsync(d.arena.p + d.prezero_n, 0, ((size_t)P.arena - d.prezero_n) * sizeof(double), s));   // a new, larger plan
   } else HIP_OK(hipMemsetAsync(d.arena.p, 0, (size_t)P.arena * sizeof(double), s));
+  // (two arenas: arena_b -- the one released by the last solve -- stays marked b_pending with its event until it is taken again)
   HIP_OK(hipMemsetAsync(d.bad.p, 0, 8 * sizeof(int), s));
   const long nnzb = d.row_ptr[c->NV];
   hipLaunchKernelGGL(k_ds_assemble_blocks, dim3(ds_nblk(nnzb * 9, 256)), dim3(256), 0, s, nnzb, d.csr2sell.p, c->vals.p, d.blk_dst.p, d.blk_ld.p, d.arena.p);

@@ -50,6 +50,16 @@ __global__ void k_ds_rownorm(int NV, const int* __restrict__ slice_off, const in
   if ((threadIdx.x & 63) == 0) atomicMax((unsigned long long*)out, (unsigned long long)__double_as_longlong(m));
 }
 
+// Background clear of the idle front arena (direct_prezero with two arenas): a small grid (gridDim.x workgroups, 16-byte stores) that
+// takes a millisecond instead of the 0.22 ms of a full-width memset, so that it runs NEXT to the engine stream's kernels instead of
+// in front of them (a memset fills every CU: measured serialised with whatever follows on the other streams).
+__global__ void __launch_bounds__(256) k_ds_clear(double* __restrict__ p, size_t n) {
+  double2* q = (double2*)p;
+  const size_t n2 = n >> 1;
+  for (size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x; i < n2; i += (size_t)gridDim.x * blockDim.x) q[i] = double2{0.0, 0.0};
+  if ((n & 1) && blockIdx.x == 0 && threadIdx.x == 0) p[n - 1] = 0.0;
+}
+
 // ---- assembly -------------------------------------------------------------------------------------------------------------
 // static pattern: block q of the CSR numbering lives at vals[csr2sell[q] + 64 e] (SELL-64, element e of the 3 x 3 block)
 __global__ void k_ds_assemble_blocks(long nnzb, const int* __restrict__ csr2sell, const double* __restrict__ vals, const long long* __restrict__ blk_dst,

@@ -118,6 +118,15 @@ struct DirectSolver {
   bool prezero_pending = false;
   size_t prezero_n = 0;
   int prezero = 1;          // "direct_prezero"
+  // "direct_two_arenas" (off): factorisations alternate between two front arenas; the one just released is cleared by a throttled
+  // kernel ("direct_clear_wgs" workgroups) during the NEXT Newton iteration while that iteration factorises into the other one.
+  // Measured (round 3, driver's command): 305.9 / 311.3 ms per step with two arenas and 64 workgroups, 305.6 with 128, 321.2 with 32,
+  // against 304.0 with the single arena -- the 1.6 GB of writes cost the same memory time next to the other kernels as in front of them
+  DevBuf<double> arena_b;
+  bool b_pending = false;   // arena_b is clean or being cleared (ev_zero_b)
+  size_t b_n = 0;
+  hipEvent_t ev_zero_b = nullptr;
+  int two_arenas = 0, clear_wgs = 64;
   hipStream_t fstream[2] = {nullptr, nullptr};   // batches of one level run next to each other (direct_factor)
   hipEvent_t ev_ffork = nullptr, ev_fjoin[2] = {nullptr, nullptr};
   int par_batches = 1;      // "direct_par_batches"

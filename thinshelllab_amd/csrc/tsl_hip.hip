@@ -358,6 +358,7 @@ extern "C" void tsl_ctx_destroy(tsl_ctx* c) {
   if (c->ds.h_anorm) (void)hipHostFree(c->ds.h_anorm);
   if (c->h_ir) (void)hipHostFree(c->h_ir);
   if (c->ds.gstream) { (void)hipStreamSynchronize(c->ds.gstream); for (int k = 0; k < 8; k++) (void)hipEventDestroy(c->ds.ev_g[k]); (void)hipEventDestroy(c->ds.ev_def); (void)hipStreamDestroy(c->ds.gstream); }
+  if (c->ds.ev_zero_b) (void)hipEventDestroy(c->ds.ev_zero_b);
   if (c->ds.zstream) { (void)hipStreamSynchronize(c->ds.zstream); (void)hipEventDestroy(c->ds.ev_zfork); (void)hipEventDestroy(c->ds.ev_zero); (void)hipStreamDestroy(c->ds.zstream); }
   if (c->ev_fork) (void)hipEventDestroy(c->ev_fork);
   if (c->ev_join) (void)hipEventDestroy(c->ev_join);
@@ -409,6 +410,8 @@ extern "C" int tsl_set_param(tsl_ctx* c, const char* key, double v) {
   else if (k == "direct_fallback_cap") c->ds.fallback_cap = (int)v;
   else if (k == "ds_bench_batch") c->ds.bench_batch = (int)v;
   else if (k == "direct_prezero") c->ds.prezero = (int)v;
+  else if (k == "direct_two_arenas") c->ds.two_arenas = (int)v;
+  else if (k == "direct_clear_wgs") c->ds.clear_wgs = std::max(1, (int)v);
   else if (k == "direct_par_batches") c->ds.par_batches = (int)v;
   else if (k == "direct_gemm_wpc") c->ds.gemm_wpc = (int)v;
   else if (k == "direct_merge_sep") { c->ds.plan.sym.merge_sep = (int)v; c->ds.static_ready = false; c->ds.plan_valid = false; c->ds.numeric_valid = false; }
