@@ -12,7 +12,7 @@ dpos = np.zeros((n_part, 3)); drot = np.zeros((n_part, 3)); dpos[:, 2] = [1e-4, 
 for f in range(1, 4):
     s.action(f, dpos, drot); st = s.time_step(projection_query, f)
 ctx = s._ctx
-for dbg, name in ((0, "stream launches"), (4, "hipGraph replays"), (1, "stream launches, no pivot-tile inversion")):
+for dbg, name in ((0, "stream launches"), (4, "hipGraph replays"), (1, "stream launches, no pivot-tile inversion"), (9, "update tiles without their own read / write (half the tile traffic)")):
     ctx.set_param("ds_dbg", dbg)
     out = {k: ctx.bench_direct(k, 10) for k in (0, 1, 2, 4)}
     print(name, {k: (round(v["us_per_launch"], 2), v["launches"]) for k, v in out.items()}, flush=True)

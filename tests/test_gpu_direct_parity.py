@@ -109,18 +109,71 @@ def _sparse_rel(Hg, Ho):
     return (d.max() if d.nnz else 0.0) / abs(Ho).max()
 
 
-def _single_evaluation_parity(oracle, s, drive, steps, min_nc, newton_direction=False):
-    """drive the GPU scene `steps` steps, then on that state: detection (with the GPU's latched side flags of the previous step
-    handed to the oracle), constraint list, E, grad E, operator for spd True / False against the oracle"""
+def _one_adjoint_step_parity(oracle, o, s, g, T, fold):
+    """ONE reverse step (Grad.transfer_grad, analytic_grad_single.py:217-257) of the last tape step at the full size: the oracle gets
+    the GPU's tape, gripper frames and latched side flags, re-detects the contacts, assembles the un-projected Hessian, solves with a
+    sparse direct solver like the reference (scipy's SuperLU, ~10 s at 100k triangles) and back-propagates; compared: pos_grad and
+    angleref_grad of the previous tape step, tmp_z_frozen, gripper_grad."""
+    from thinshelllab_amd.engine.geometry import projection_query
+    ctx = s._ctx
+    nb = len(s.body_list)
+    NV = s.tot_NV
+    n_part = s.gripper.n_part
+    flag0, dir0, _, _ = ctx.proj_export()
+    sync_oracle_state(o, s)
+    o.set_solver(1e-11); o.set_direct(1)
+    s._ensure_ctx().set_param("cg_tol", 1e-11)
+    o.arr("proj_flag", (nb, -1))[:] = flag0; o.arr("proj_dir", (nb, -1))[:] = dir0
+    o.grad_new(T, n_part)
+    o.arr("grad.pos_buffer", (T, NV, 3))[:] = g.pos_buffer.to_numpy()
+    o.arr("grad.ref_angle_buffer").reshape(g.ref_angle_buffer.shape)[:] = g.ref_angle_buffer.to_numpy()
+    o.arr("grad.gripper_pos_buffer", (T, -1, 3))[:, :n_part] = g.gripper_pos_buffer.to_numpy()[:, :n_part]
+    o.arr("grad.gripper_rot_buffer", (T, -1, 4))[:, :n_part] = g.gripper_rot_buffer.to_numpy()[:, :n_part]
+    seed = np.random.default_rng(11).normal(size=(NV, 3))
+    g.pos_grad.t.zero_(); g.angleref_grad.t.zero_()
+    g.pos_grad.t[T - 1] = torch.as_tensor(seed, device=s.device)
+    if fold:
+        g.get_loss_fold(s, 1.0, -1.0, rows=s.fold_rows())
+    o.arr("grad.pos_grad", (T, NV, 3))[T - 1] = seed
+    o.arr("grad.angleref_grad").reshape(g.angleref_grad.shape)[:] = g.angleref_grad.to_numpy()
+    g.transfer_grad(T - 1, s, projection_query)
+    ls = g.last_stats
+    assert ls["flag"] == 0 and ls["method"] == 4, ls
+    o.grad_transfer(T - 1)
+    assert o.stats()["flag"] == 4
+    pg_o = o.arr("grad.pos_grad", (T, NV, 3)); pg_g = g.pos_grad.to_numpy()
+    assert np.abs(pg_o[T - 2]).max() > 0
+    assert rel_err(pg_g[T - 2], pg_o[T - 2]) < 1e-5, rel_err(pg_g[T - 2], pg_o[T - 2])
+    if fold:
+        ag_o = o.arr("grad.angleref_grad").reshape(g.angleref_grad.shape); ag_g = g.angleref_grad.to_numpy()
+        assert np.abs(ag_o[T - 2]).max() > 0 and rel_err(ag_g[T - 2], ag_o[T - 2]) < 1e-5
+    assert rel_err(s.tmp_z_frozen.to_numpy(), o.arr("tmp_z_frozen")) < 1e-5
+    gg_o = o.arr("grad.gripper_grad", (T, n_part, 6)); gg_g = g.gripper_grad.to_numpy()[:, :n_part]
+    assert np.abs(gg_o[T - 1]).max() > 0 and rel_err(gg_g[T - 1], gg_o[T - 1]) < 1e-5
+    # the reverse step leaves the scene at the tape state of step T - 1 (copy_pos_and_refangle): the evaluations below start there
+    s._ensure_ctx().set_param("cg_tol", 1e-10)
+
+
+def _single_evaluation_parity(oracle, s, drive, steps, min_nc, newton_direction=False, fold=False):
+    """drive the GPU scene `steps` steps, then on that state: one reverse step, and detection (with the GPU's latched side flags of the
+    previous step handed to the oracle), constraint list, E, grad E, operator for spd True / False against the oracle"""
+    from thinshelllab_amd.engine.analytic_grad_single import Grad
     from thinshelllab_amd.engine.geometry import projection_query
     oracle.set_threads(min(os.cpu_count() or 4, 32))
     n_part = s.gripper.n_part
+    T = steps + 1
+    g = Grad(s, T, n_part); g.init_mass(s)
+    g.copy_pos(s, 0)
+    o_adj = oracle_from_scene(oracle, s, check_init=False)   # mirrored at t = 0: the gripper's local frame is taken from the initial poses on both sides
     for f in range(1, steps + 1):
         s.action(f, *drive(f, n_part))
         st = s.time_step(projection_query, f)
+        g.copy_pos(s, f)
         assert st["unconverged"] == 0, (f, st)
     ctx = s._ctx
     nb = len(s.body_list)
+    _one_adjoint_step_parity(oracle, o_adj, s, g, T, fold)
+    del o_adj
     flag0, dir0, _, _ = ctx.proj_export()          # stateful side latch (geometry.py:210-212): state BEFORE the query compared below
     # exact geometric ties (a frozen cloth vertex straight above an edge of the frozen, regular table mesh: equal distances and
     # cosines, decided by the last bit of an FMA) are broken by a deterministic micron-scale ripple on every cloth vertex
@@ -212,7 +265,7 @@ def test_cfg3_single_evaluation_parity(oracle):
         else:
             dpos[:, 0] = 2e-4
         return dpos, drot
-    _single_evaluation_parity(oracle, s, drive, 12, 100, newton_direction=True)
+    _single_evaluation_parity(oracle, s, drive, 12, 100, newton_direction=True, fold=True)
 
 
 def test_cfg4_single_evaluation_parity(oracle):

@@ -416,7 +416,7 @@ __global__ void __launch_bounds__(256) k_ds_gj_step(DsDev D, int lv0, int k, int
   }
   // the tile's own entries (quadrant layout of the matrix-core result) are requested before the products
   ds_d4 old = {0.0, 0.0, 0.0, 0.0};
-  if (bi != k && bj != k) {
+  if (bi != k && bj != k && D.dbg != 9) {   // ("ds_dbg" 9, timing experiment: the update tiles neither read nor write their own entries)
 #pragma unroll
     for (int r = 0; r < 4; r++) old[r] = ds_tile_elem(A, ld, Rs, Cs, pp, kp, bi, bj, 16 * wi + lk + 4 * r, 16 * wj + lr);
   }
@@ -449,7 +449,7 @@ __global__ void __launch_bounds__(256) k_ds_gj_step(DsDev D, int lv0, int k, int
   for (int r = 0; r < 4; r++) {
     const int row = 16 * wi + lk + 4 * r, col = 16 * wj + lr;
     const double v = old[r] - acc[r];
-    A[(size_t)(bi * DS_T + row) * ld + bj * DS_T + col] = v;
+    if (D.dbg != 9 || next_pivot) A[(size_t)(bi * DS_T + row) * ld + bj * DS_T + col] = v;
     if (next_pivot) T2[row][col] = v;
   }
   if (next_pivot) {
