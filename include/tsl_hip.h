@@ -114,7 +114,7 @@ int tsl_set_stream(tsl_ctx* ctx, void* hip_stream);
  * "direct_leaf" (vertices per nested-dissection leaf, default 64), "direct_lag" (Newton iterations of a time step reuse earlier factors while the
  * refinement converges within this many iterations; 0 = refactorise for every solve), "direct_fallback_cap" (a refined factorisation
  * that stalls within 1e-3 of the right-hand side is returned flagged not converged; above that the hierarchy gets this many iterations),
- * "direct_piv_tol" (static pivoting: pivots below this fraction of their entry diagonal are perturbed to it, default 1e-8),
+ * "direct_piv_tol" (static pivoting: pivots below this fraction of their entry diagonal are perturbed to it, default 1e-11),
  * "direct_prezero" (1: the front arena of the next factorisation is cleared on a side stream after each solve of a time step),
  * "direct_gemm_wpc" (4 / 3: workgroups per CU the factorisation GEMMs are compiled for; 3 prefetches the F22 tile, default 4),
  * "direct_par_batches" (1: batches of one elimination level on parallel streams), "direct_merge_k" (1: constrained body vertices share the

@@ -5,7 +5,7 @@
 N=${1:-8}
 mkdir -p gpurun_out/flake
 for r in $(seq 1 $N); do
-  TSL_PARAMS=verbose=1 python bench.py --steps 20 --warmup 5 --no-cpu-baseline > gpurun_out/flake/run_$r.json 2> gpurun_out/flake/run_$r.err
+  TSL_PARAMS=verbose=1 python bench.py --steps 20 --warmup 5 --no-cpu-baseline $FLAKE_ARGS > gpurun_out/flake/run_$r.json 2> gpurun_out/flake/run_$r.err
   grep -E "did not converge|perturbed|fallback|unconverged" gpurun_out/flake/run_$r.err | head -20 > gpurun_out/flake/run_$r.msgs
   python - <<PY
 import json
