@@ -713,32 +713,44 @@ __global__ void k_dot_free(size_t i0, size_t i1, const double* __restrict__ a, c
   s = wave_sum(s);
   if ((threadIdx.x & 63) == 0 && s != 0.0) atomicAdd(out, scale * s);
 }
-// Iterative refinement of the factorised solve (tsl_hip.hip: direct_refine): r = b - w (w = H x), optionally x += z first, and
-// out[0..2] = {r.r, x.x, b.b} in ONE launch with a fixed summation order (per-block partials, the last block to finish adds them
-// up: no f64 atomics, the same bits every run).  part: 3 x gridDim doubles, ticket: one int, zero on entry and left zero.
+// Iterative refinement of the factorised solve (tsl_hip.hip: direct_refine): r = b - w (w = H x) and
+// out[0..3] = {r.r, x.x, b.b, max |x_i|} in ONE launch with a fixed summation order (per-block partials, the last block to finish
+// adds them up: no f64 atomics, the same bits every run).  part: 4 x gridDim doubles, ticket: one int, zero on entry and left zero.
+// max |x_i| is the Newton loop's |p|max (calc_p_norm, BaseScene.py:1096-1103): the stop rule reads it from the same host record.
 __global__ void __launch_bounds__(256) k_ir_resid(size_t n, const double* __restrict__ b, const double* __restrict__ w, const double* __restrict__ x, double* __restrict__ r,
                                                   double* __restrict__ part, int* __restrict__ ticket, double* __restrict__ out) {
   __shared__ double sm[8];
   __shared__ int last;
-  double rr = 0, xx = 0, bb = 0;
+  double rr = 0, xx = 0, bb = 0, xm = 0;
   for (size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x) {
     const double bi = b[i], ri = bi - w[i], xi = x[i];
     r[i] = ri;
-    rr += ri * ri; xx += xi * xi; bb += bi * bi;
+    rr += ri * ri; xx += xi * xi; bb += bi * bi; xm = fmax(xm, fabs(xi));
   }
   rr = block_sum(rr, sm); xx = block_sum(xx, sm); bb = block_sum(bb, sm);
+  xm = wave_max(xm);
+  if ((threadIdx.x & 63) == 0) sm[threadIdx.x >> 6] = xm;
+  __syncthreads();
   if (threadIdx.x == 0) {
-    part[3 * blockIdx.x] = rr; part[3 * blockIdx.x + 1] = xx; part[3 * blockIdx.x + 2] = bb;
+    xm = fmax(fmax(sm[0], sm[1]), fmax(sm[2], sm[3]));
+    part[4 * blockIdx.x] = rr; part[4 * blockIdx.x + 1] = xx; part[4 * blockIdx.x + 2] = bb; part[4 * blockIdx.x + 3] = xm;
     __threadfence();
     last = atomicAdd(ticket, 1) == (int)gridDim.x - 1;
   }
   __syncthreads();
   if (!last) return;
   __threadfence();
-  double a0 = 0, a1 = 0, a2 = 0;
-  for (int k = threadIdx.x; k < (int)gridDim.x; k += blockDim.x) { a0 += __builtin_nontemporal_load(&part[3 * k]); a1 += __builtin_nontemporal_load(&part[3 * k + 1]); a2 += __builtin_nontemporal_load(&part[3 * k + 2]); }
+  double a0 = 0, a1 = 0, a2 = 0, a3 = 0;
+  for (int k = threadIdx.x; k < (int)gridDim.x; k += blockDim.x) {
+    a0 += __builtin_nontemporal_load(&part[4 * k]); a1 += __builtin_nontemporal_load(&part[4 * k + 1]); a2 += __builtin_nontemporal_load(&part[4 * k + 2]);
+    a3 = fmax(a3, __builtin_nontemporal_load(&part[4 * k + 3]));
+  }
   a0 = block_sum(a0, sm); a1 = block_sum(a1, sm); a2 = block_sum(a2, sm);
-  if (threadIdx.x == 0) { out[0] = a0; out[1] = a1; out[2] = a2; *ticket = 0; }
+  a3 = wave_max(a3);
+  __syncthreads();
+  if ((threadIdx.x & 63) == 0) sm[threadIdx.x >> 6] = a3;
+  __syncthreads();
+  if (threadIdx.x == 0) { out[0] = a0; out[1] = a1; out[2] = a2; out[3] = fmax(fmax(sm[0], sm[1]), fmax(sm[2], sm[3])); *ticket = 0; }
 }
 // y = a*x + b*y (b == 0 ignores old y)
 __global__ void k_axpby(size_t n, double a, const double* __restrict__ x, double b, double* __restrict__ y) {

@@ -270,7 +270,9 @@ struct tsl_ctx {
   int tet_warm = 1;
   DevBuf<double> ir_part;     // direct_refine: per-block partial sums + the three results
   DevBuf<int> ir_ticket;
-  double* h_ir = nullptr;     // pinned host copy of {r.r, x.x, b.b}
+  double* h_ir = nullptr;     // pinned host copy of {r.r, x.x, b.b, max |x_i|}
+  double last_xmax = 0;       // max |x_i| of the solution direct_refine returned (the Newton loop's |p|max)
+  bool last_xmax_valid = false;
   int gmres_m = 300, use_gmres = 1, use_minres = 1, verbose = 0;
   // analytic_grad_system.Grad: pos_grad clamp (1 there, 1000 in analytic_grad_single) and whether angleref_grad is clamped too
   double adj_clamp = 1000.0;

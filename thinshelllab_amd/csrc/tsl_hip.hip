@@ -1114,6 +1114,7 @@ static int solve_perm(tsl_ctx* c, tsl_solve_stats* st) {
   const size_t n3 = 3 * (size_t)NV;
   const int gb = nblk(NV, 256);
   st->iters = 0; st->restarts = 0; st->flag = 0; st->rel_residual = 0; st->method = 0; st->attained = 0; st->backward_error = 0;
+  c->last_xmax_valid = false;
   if (direct_enabled(c) && !c->ds_suspended) {
     // primary path on refined cloths: multifrontal LU of the operator (like the reference's spsolve) + GMRES refinement
     // against the operator product; the iterative hierarchy below only runs if that fails.
@@ -1154,7 +1155,7 @@ static int solve_perm(tsl_ctx* c, tsl_solve_stats* st) {
       int rc_g = 0;
       if (!stale && d.refine_ir) {   // plain refinement first; systems it does not settle go through the flexible GMRES from scratch
         rc_g = direct_refine(c, &sd);
-        if (rc_g == 0 && sd.flag != 1) { const int it0 = sd.iters; sd = *st; rc_g = gmres(c, &sd, true); sd.iters += it0; }
+        if (rc_g == 0 && sd.flag != 1) { const int it0 = sd.iters; sd = *st; c->last_xmax_valid = false; rc_g = gmres(c, &sd, true); sd.iters += it0; }
       } else rc_g = gmres(c, &sd, true);
       d.gm_cap = 0;
       if (rc_g) return -1;
@@ -1693,11 +1694,11 @@ static int direct_refine(tsl_ctx* c, tsl_solve_stats* st) {
   hipStream_t s = c->stream;
   const size_t n3 = 3 * (size_t)c->NV;
   const int gv = std::min(gsz(n3), 240);
-  if (c->ir_part.n < (size_t)3 * 240 + 4 && c->ir_part.alloc(3 * 240 + 4)) return -1;
+  if (c->ir_part.n < (size_t)4 * 240 + 4 && c->ir_part.alloc(4 * 240 + 4)) return -1;
   if (c->ir_ticket.n < 1) { if (c->ir_ticket.alloc(1)) return -1; HIP_OK(hipMemsetAsync(c->ir_ticket.p, 0, sizeof(int), s)); }
   if (c->h_ir == nullptr) HIP_OK(hipHostMalloc((void**)&c->h_ir, 4 * sizeof(double)));
   double *x = c->v_x.p, *r = c->v_r.p, *w = c->v_Ap.p, *z = c->v_z.p;
-  double* out = c->ir_part.p + 3 * 240;
+  double* out = c->ir_part.p + 4 * 240;
   st->flag = 3;
   double rr_prev = 1e300;
   for (int it = 0; it < 4; it++) {
@@ -1708,9 +1709,10 @@ static int direct_refine(tsl_ctx* c, tsl_solve_stats* st) {
     }
     launch_spmv(c, c->vals.p, x, w, -1, 0);
     hipLaunchKernelGGL(k_ir_resid, dim3(gv), dim3(256), 0, s, n3, (const double*)c->v_b.p, (const double*)w, (const double*)x, r, c->ir_part.p, c->ir_ticket.p, out);
-    HIP_OK(hipMemcpyAsync(c->h_ir, out, 3 * sizeof(double), hipMemcpyDeviceToHost, s));
+    HIP_OK(hipMemcpyAsync(c->h_ir, out, 4 * sizeof(double), hipMemcpyDeviceToHost, s));
     HIP_OK(hipStreamSynchronize(s));
     const double rr = c->h_ir[0], xx = c->h_ir[1], bb = c->h_ir[2];
+    c->last_xmax = c->h_ir[3]; c->last_xmax_valid = true;   // max |x_i| of the iterate this residual belongs to
     st->iters++;
     if (!(bb > 0)) { st->flag = 1; st->rel_residual = 0; return 0; }   // zero right-hand side: x = 0
     st->rel_residual = sqrt(rr / bb);
@@ -1987,10 +1989,14 @@ extern "C" int tsl_step(tsl_ctx* c, double* pos, double* prev, double* vel, doub
     t_energy += secs(t0, t1); t_asm += secs(t1, t2); t_solve += secs(t2, t3);
     st.cg_iters += ss.iters; st.solves++; st.restarts += ss.restarts; st.fallback += (ss.flag == 1); st.unconverged += (ss.flag == 3); st.attained += ss.attained;
     st.max_rel_residual = std::max(st.max_rel_residual, ss.rel_residual); st.max_backward_error = std::max(st.max_backward_error, ss.backward_error);
-    // p_norm = max |p|  (calc_p_norm :1096-1103)
-    HIP_OK(hipMemsetAsync(&SC(c)->pmax, 0, sizeof(double), s));
-    hipLaunchKernelGGL(k_absmax, dim3(gsz(n3)), dim3(256), 0, s, n3, c->pdir.p, &SC(c)->pmax);
-    HIP_OK(hipMemcpyAsync(&HSC(c)->pmax, &SC(c)->pmax, sizeof(double), hipMemcpyDeviceToHost, s));
+    // p_norm = max |p|  (calc_p_norm :1096-1103): the refinement of the factorised solve delivers it with its last residual; other solvers: one reduction
+    const bool have_pmax = ss.method == 4 && ss.flag == 0 && c->last_xmax_valid;
+    if (have_pmax) HSC(c)->pmax = c->last_xmax;
+    else {
+      HIP_OK(hipMemsetAsync(&SC(c)->pmax, 0, sizeof(double), s));
+      hipLaunchKernelGGL(k_absmax, dim3(gsz(n3)), dim3(256), 0, s, n3, c->pdir.p, &SC(c)->pmax);
+      HIP_OK(hipMemcpyAsync(&HSC(c)->pmax, &SC(c)->pmax, sizeof(double), hipMemcpyDeviceToHost, s));
+    }
     HIP_OK(hipMemcpyAsync(c->x1.p, pos, n3 * sizeof(double), hipMemcpyDeviceToDevice, s));
     double alpha = 1.0, E = 0;
     while (alpha > 1e-8) {
