@@ -15,7 +15,7 @@ __global__ void __launch_bounds__(256) k_bench(const double* __restrict__ in, do
     for (int q = 0; q < 4; q++) T[ty + 8 * q][tx] = in[(ty + 8 * q) * DS_T + tx];
     __syncthreads();
     t0 = wall_clock64();
-    if (V == 1) ds_invert_tile_wg(T, bad, 1, 0, 1e-8); else ds_invert_tile_wg2(T, bad, 1, 0, 1e-8);
+    if (V == 1) ds_invert_tile_wg(&T[0][0], DS_T + 1, bad, 1, 0, 1e-8); else ds_invert_tile_wg2(&T[0][0], DS_T + 1, bad, 1, 0, 1e-8);
     acc += wall_clock64() - t0;
   }
   for (int q = 0; q < 4; q++) out[(ty + 8 * q) * DS_T + tx] = T[ty + 8 * q][tx];

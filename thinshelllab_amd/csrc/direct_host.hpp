@@ -10,13 +10,16 @@
 
 static inline int ds_nblk(long n, int b) { return (int)((n + b - 1) / b); }
 
-static inline size_t ds_small_lds(int max_pp) { return ((size_t)max_pp * (max_pp + 1) + (size_t)DS_T * (DS_T + 1)) * sizeof(double); }
-// a batch goes to the LDS kernel (all block steps in one launch, one workgroup per front) when its fronts fit the chip in one round;
-// a larger batch has enough tile parallelism for the block-step kernel (measured: 1024 fronts of 96 pivots 322 us against ~100)
+static inline size_t ds_small_lds(int max_pp) { return (size_t)max_pp * (max_pp + 1) * sizeof(double); }   // the block alone: the pivot tile is inverted in place
+// a batch goes to the LDS kernel (all block steps in one launch, one workgroup per front) when its fronts fit the chip in
+// `ds_small_rounds` rounds (workgroups per CU by LDS: 4.5 KB of static arrays of the tile inversion on top of the block -- two at 96
+// pivots, one at 128); a larger batch has enough tile parallelism for the block-step kernel (round 2: 1024 fronts of 96 pivots 322 us
+// at one workgroup per CU against ~190 us tile-parallel)
+static int ds_small_rounds = 2;   // "direct_small_rounds": 847 leaf fronts of 96 pivots 139.5 us in two rounds of the LDS kernel against 204 us on the block-step path (5 launches)
 static inline bool ds_use_small(const DsBatch& b) {
   if (b.max_pp > DS_SMALL) return false;
-  const size_t per_cu = std::min<size_t>(8, (160 * 1024) / (ds_small_lds(b.max_pp) + 1024));
-  return (size_t)b.count <= 256 * std::max<size_t>(per_cu, 1);
+  const size_t per_cu = std::min<size_t>(8, (160 * 1024) / (ds_small_lds(b.max_pp) + 5 * 1024));
+  return (size_t)b.count <= 256 * std::max<size_t>(per_cu, 1) * (size_t)ds_small_rounds;
 }
 
 // G = W F12 (mode 0) / S = F22 - F21 G added into the parents (mode 1) of a batch.  A 128 x 128-tile variant (64 accumulator

@@ -28,6 +28,7 @@ struct DsFrontDesc {
   int nv_own, nv_bnd;
   int scr_off;               // offset of this front's scratch inside the per-level scratch (doubles)
   int bu;                    // boundary dofs that are OWN dofs of the parent front (they come first: the boundary is sorted by elimination position)
+  int nchild;                // child fronts: F22 of a front without children holds nothing (entries between two boundary vertices live in earlier fronts)
 };
 
 // fronts of one tree level with pivot blocks of similar size: one set of launches (level_sn[first .. first + count), sorted by pp descending)
@@ -124,7 +125,7 @@ struct DirectPlan {
       for (int s = 0; s < S; s++) { fr[s].rel_off = total; total += fr[s].nv_bnd; }
       rel.assign(total, -1);
       std::vector<int> cptr(S + 1, 0), clist(S);
-      for (int s = 0; s < S; s++) if (fr[s].parent >= 0) cptr[fr[s].parent + 1]++;
+      for (int s = 0; s < S; s++) if (fr[s].parent >= 0) { cptr[fr[s].parent + 1]++; fr[fr[s].parent].nchild++; }
       for (int s = 0; s < S; s++) cptr[s + 1] += cptr[s];
       { std::vector<int> fill(cptr.begin(), cptr.end() - 1); for (int s = 0; s < S; s++) if (fr[s].parent >= 0) clist[fill[fr[s].parent]++] = s; }
       const int nt = 1;   // 0.3 ms on one thread (MI355X host); starting threads costs more than they save here

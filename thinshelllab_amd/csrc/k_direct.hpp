@@ -122,14 +122,14 @@ TSL_DEV double ds_readlane_d(double v, int l) {
   const int lo = __builtin_amdgcn_readlane(__double2loint(v), l), hi = __builtin_amdgcn_readlane(__double2hiint(v), l);
   return __hiloint2double(hi, lo);
 }
-TSL_DEV void ds_invert_tile_wg(double (*T)[DS_T + 1], int* __restrict__ bad, int cls, int tag, double tol) {
+TSL_DEV void ds_invert_tile_wg(double* __restrict__ T, int ldt, int* __restrict__ bad, int cls, int tag, double tol) {   // T[row * ldt + col]
   __shared__ double rowp[2][DS_PB][DS_T], colp[2][DS_PB][DS_T + 1], red[4], dg0[DS_T];
   const int lane = threadIdx.x & 63, w = threadIdx.x >> 6, wi = w >> 1, wj = w & 1, lr = lane & 15, lk = lane >> 4;
   ds_d4 acc;
   double amax = 0.0;
 #pragma unroll
   for (int r = 0; r < 4; r++) {
-    acc[r] = T[16 * wi + lk + 4 * r][16 * wj + lr];
+    acc[r] = T[(16 * wi + lk + 4 * r) * ldt + 16 * wj + lr];
     amax = fmax(amax, fabs(acc[r]));
     if (wi == wj && lk + 4 * r == lr) dg0[16 * wi + lr] = fabs(acc[r]);   // the diagonal on entry: the scale a pivot is measured against
   }
@@ -208,7 +208,7 @@ TSL_DEV void ds_invert_tile_wg(double (*T)[DS_T + 1], int* __restrict__ bad, int
     }
   }
 #pragma unroll
-  for (int r = 0; r < 4; r++) T[16 * wi + lk + 4 * r][16 * wj + lr] = acc[r];
+  for (int r = 0; r < 4; r++) T[(16 * wi + lk + 4 * r) * ldt + 16 * wj + lr] = acc[r];
   if (threadIdx.x == 0 && badmask) {
     atomicAdd(bad + cls, __popc(badmask));
     const int slot = atomicAdd(bad + 4, 1);   // log of the first perturbed tiles (verbose >= 2)
@@ -233,14 +233,14 @@ TSL_DEV void ds_invert_tile_wg(double (*T)[DS_T + 1], int* __restrict__ bad, int
 //     |terms|: a block a diagonal-pivot elimination might have to perturb) the lane falls back to the four-pivot elimination with the
 //     per-pivot threshold of the first form (divergent branch, no barrier or matrix instruction inside).  Blocks with a zero
 //     leading entry but a healthy determinant ([0 1; 1 0]) are inverted exactly instead of being perturbed.
-TSL_DEV void ds_invert_tile_wg2(double (*T)[DS_T + 1], int* __restrict__ bad, int cls, int tag, double tol) {
+TSL_DEV void ds_invert_tile_wg2(double* __restrict__ T, int ldt, int* __restrict__ bad, int cls, int tag, double tol) {
   __shared__ double rowp[2][DS_PB][DS_T], colp[2][DS_PB][DS_T + 1], dblk[2][DS_PB][DS_PB], red[4], dg0[DS_T];
   const int lane = threadIdx.x & 63, w = threadIdx.x >> 6, wi = w >> 1, wj = w & 1, lr = lane & 15, lk = lane >> 4;
   ds_d4 acc;
   double amax = 0.0;
 #pragma unroll
   for (int r = 0; r < 4; r++) {
-    acc[r] = T[16 * wi + lk + 4 * r][16 * wj + lr];
+    acc[r] = T[(16 * wi + lk + 4 * r) * ldt + 16 * wj + lr];
     amax = fmax(amax, fabs(acc[r]));
     if (wi == wj && lk + 4 * r == lr) dg0[16 * wi + lr] = fabs(acc[r]);
   }
@@ -324,7 +324,7 @@ TSL_DEV void ds_invert_tile_wg2(double (*T)[DS_T + 1], int* __restrict__ bad, in
     if (wi == wp) acc[rp] = bop;                                           // pivot rows = Dinv R~ (Dinv itself in the pivot columns)
   }
 #pragma unroll
-  for (int r = 0; r < 4; r++) T[16 * wi + lk + 4 * r][16 * wj + lr] = acc[r];
+  for (int r = 0; r < 4; r++) T[(16 * wi + lk + 4 * r) * ldt + 16 * wj + lr] = acc[r];
   if (threadIdx.x == 0 && badmask) {
     atomicAdd(bad + cls, __popc(badmask));
     const int slot = atomicAdd(bad + 4, 1);
@@ -337,8 +337,8 @@ TSL_DEV void ds_invert_tile_wg2(double (*T)[DS_T + 1], int* __restrict__ bad, in
 #ifndef DS_INV_FORM
 #define DS_INV_FORM 1
 #endif
-TSL_DEV void ds_invert_tile(double (*T)[DS_T + 1], int* __restrict__ bad, int cls, int tag, double tol) {
-  if (DS_INV_FORM == 1) ds_invert_tile_wg(T, bad, cls, tag, tol); else ds_invert_tile_wg2(T, bad, cls, tag, tol);
+TSL_DEV void ds_invert_tile(double* __restrict__ T, int ldt, int* __restrict__ bad, int cls, int tag, double tol) {
+  if (DS_INV_FORM == 1) ds_invert_tile_wg(T, ldt, bad, cls, tag, tol); else ds_invert_tile_wg2(T, ldt, bad, cls, tag, tol);
 }
 
 // scratch of a front inside the level scratch (fronts with more than DS_SMALL pivots): pivot-block inverses P[2] (ping-pong) and the
@@ -356,7 +356,7 @@ __global__ void __launch_bounds__(256) k_ds_pivot0(DsDev D, int lv0) {
 #pragma unroll
   for (int q = 0; q < 4; q++) T[ty + 8 * q][tx] = A[(size_t)(ty + 8 * q) * f.ld + tx];
   __syncthreads();
-  ds_invert_tile(T, D.bad, DS_CLS(f), D.level_sn[lv0 + blockIdx.x] << 6, D.piv_tol);
+  ds_invert_tile(&T[0][0], DS_T + 1, D.bad, DS_CLS(f), D.level_sn[lv0 + blockIdx.x] << 6, D.piv_tol);
   double* P = ds_scr_P(D, f, 0);
 #pragma unroll
   for (int q = 0; q < 4; q++) P[(ty + 8 * q) * DS_T + tx] = T[ty + 8 * q][tx];
@@ -454,7 +454,7 @@ __global__ void __launch_bounds__(256) k_ds_gj_step(DsDev D, int lv0, int k, int
   }
   if (next_pivot) {
     __syncthreads();
-    if (D.dbg != 1) ds_invert_tile(T2, D.bad, DS_CLS(f), (D.level_sn[lv0 + fz] << 6) | (k + 1), D.piv_tol);
+    if (D.dbg != 1) ds_invert_tile(&T2[0][0], DS_T + 1, D.bad, DS_CLS(f), (D.level_sn[lv0 + fz] << 6) | (k + 1), D.piv_tol);
     double* Pn = ds_scr_P(D, f, (k + 1) & 1);
 #pragma unroll
     for (int q = 0; q < 4; q++) Pn[(ty + 8 * q) * DS_T + tx] = T2[ty + 8 * q][tx];
@@ -479,13 +479,13 @@ __global__ void __launch_bounds__(256) k_ds_gj_finish(DsDev D, int lv0) {
 }
 
 // W = F11^-1 of a front with at most DS_SMALL pivots by ONE workgroup with the block in LDS (row stride ls = batch maximum + 1):
-// the same blocked Gauss-Jordan, all block steps inside the launch -- wave 0 inverts the pivot block, every wave owns row chunks of
-// the rank-T update on the matrix cores (its column-panel fragment lives in registers while the chunk is rewritten).
+// the same blocked Gauss-Jordan, all block steps inside the launch -- the workgroup inverts the pivot tile where it lies, every wave
+// owns row chunks of the rank-T update on the matrix cores (its column-panel fragment lives in registers while the chunk is rewritten).
 #define DS_SMALL 128
 __global__ void __launch_bounds__(256) k_ds_inv_small(DsDev D, int lv0, int ls) {
   extern __shared__ double ds_sm[];
-  double* M = ds_sm;
-  double (*Tt)[DS_T + 1] = (double (*)[DS_T + 1])(ds_sm + (size_t)(ls - 1) * ls);
+  double* M = ds_sm;   // the block, row stride ls; the pivot tile of a step is inverted IN PLACE (no copy: at 96 pivots the block alone is 74.5 KB and
+                       // two workgroups share a CU only without a separate tile buffer)
   const DsFrontDesc f = D.fr[D.level_sn[lv0 + blockIdx.x]];
   const int pp = f.pp, nt = pp / DS_T;
   double* A = D.A + f.off;
@@ -496,10 +496,8 @@ __global__ void __launch_bounds__(256) k_ds_inv_small(DsDev D, int lv0, int ls) 
   __syncthreads();
   for (int k = 0; k < nt; k++) {
     const int k0 = k * DS_T;
-#pragma unroll
-    for (int q = 0; q < 4; q++) Tt[ty + 8 * q][tx] = M[(k0 + ty + 8 * q) * ls + k0 + tx];
-    __syncthreads();
-    ds_invert_tile(Tt, D.bad, 1, (D.level_sn[lv0 + blockIdx.x] << 6) | k, D.piv_tol);
+    double* Tt = M + k0 * ls + k0;   // P after the call
+    ds_invert_tile(Tt, ls, D.bad, 1, (D.level_sn[lv0 + blockIdx.x] << 6) | k, D.piv_tol);
     // R'_j = P A_Kj in place (a wave owns whole tiles: all its reads of a tile precede its writes)
     for (int j = w; j < nt; j += 4) {
       if (j == k) continue;
@@ -511,7 +509,7 @@ __global__ void __launch_bounds__(256) k_ds_inv_small(DsDev D, int lv0, int ls) 
         for (int b = 0; b < 2; b++) acc[a][b] = ds_d4{0.0, 0.0, 0.0, 0.0};
 #pragma unroll
       for (int kk = 0; kk < DS_T / 4; kk++) {
-        const double a0 = Tt[lr][4 * kk + lk], a1 = Tt[16 + lr][4 * kk + lk];
+        const double a0 = Tt[lr * ls + 4 * kk + lk], a1 = Tt[(16 + lr) * ls + 4 * kk + lk];
         const double b0 = M[(k0 + 4 * kk + lk) * ls + j0 + lr], b1 = M[(k0 + 4 * kk + lk) * ls + j0 + 16 + lr];
         acc[0][0] = __builtin_amdgcn_mfma_f64_16x16x4f64(a0, b0, acc[0][0], 0, 0, 0);
         acc[0][1] = __builtin_amdgcn_mfma_f64_16x16x4f64(a0, b1, acc[0][1], 0, 0, 0);
@@ -545,9 +543,8 @@ __global__ void __launch_bounds__(256) k_ds_inv_small(DsDev D, int lv0, int ls) 
 #pragma unroll
             for (int r = 0; r < 4; r++) acc[a][b][r] = (j == k) ? 0.0 : M[(i0 + 16 * a + lk + 4 * r) * ls + j0 + 16 * b + lr];
 #pragma unroll
-        for (int kk = 0; kk < DS_T / 4; kk++) {
-          const double b0 = (j == k) ? Tt[4 * kk + lk][lr] : M[(k0 + 4 * kk + lk) * ls + j0 + lr];
-          const double b1 = (j == k) ? Tt[4 * kk + lk][16 + lr] : M[(k0 + 4 * kk + lk) * ls + j0 + 16 + lr];
+        for (int kk = 0; kk < DS_T / 4; kk++) {   // row K of M holds R'_j for j != k and P itself at j == k
+          const double b0 = M[(k0 + 4 * kk + lk) * ls + j0 + lr], b1 = M[(k0 + 4 * kk + lk) * ls + j0 + 16 + lr];
           acc[0][0] = __builtin_amdgcn_mfma_f64_16x16x4f64(c0[kk], b0, acc[0][0], 0, 0, 0);
           acc[0][1] = __builtin_amdgcn_mfma_f64_16x16x4f64(c0[kk], b1, acc[0][1], 0, 0, 0);
           acc[1][0] = __builtin_amdgcn_mfma_f64_16x16x4f64(c1[kk], b0, acc[1][0], 0, 0, 0);
@@ -561,9 +558,6 @@ __global__ void __launch_bounds__(256) k_ds_inv_small(DsDev D, int lv0, int ls) 
             for (int r = 0; r < 4; r++) M[(i0 + 16 * a + lk + 4 * r) * ls + j0 + 16 * b + lr] = acc[a][b][r];
       }
     }
-    __syncthreads();
-#pragma unroll
-    for (int q = 0; q < 4; q++) M[(k0 + ty + 8 * q) * ls + k0 + tx] = Tt[ty + 8 * q][tx];
     __syncthreads();
   }
   for (int i = ty; i < pp; i += 8)
@@ -624,7 +618,7 @@ TSL_DEV void ds_gemm_tile(const DsDev& D, int lv0, int bx, int by, int bz, int p
 #pragma unroll
         for (int r = 0; r < 4; r++) {
           const int row = I0 + 32 * wi + 16 * a + lk + 4 * r, col = J0 + 32 * wj + 16 * b + lr;
-          f22[a][b][r] = (row < f.b && col < f.b) ? F[(size_t)(pp + row) * ld + pp + col] : 0.0;
+          f22[a][b][r] = (f.nchild > 0 && row < f.b && col < f.b) ? F[(size_t)(pp + row) * ld + pp + col] : 0.0;   // a leaf's F22 is zero: not read
         }
   };
   if (mode == 1 && PF) load_f22();

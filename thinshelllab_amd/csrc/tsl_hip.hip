@@ -400,6 +400,7 @@ extern "C" int tsl_set_param(tsl_ctx* c, const char* key, double v) {
   else if (k == "direct") { c->ds.enable = (int)v; c->ds.numeric_valid = false; c->ds.hard = false; }
   else if (k == "direct_lag") c->ds.lag = (int)v;
   else if (k == "direct_refine") c->ds.refine_ir = (int)v;
+  else if (k == "direct_small_rounds") { ds_small_rounds = std::max(1, (int)v); c->ds.plan_valid = false; c->ds.numeric_valid = false; c->ds.cache.clear(); }
   else if (k == "direct_overlap") c->ds.overlap = (int)v;
   else if (k == "direct_overlap_cap") c->ds.overlap_cap = std::max(0, (int)v);
   else if (k == "direct_overlap_fronts") c->ds.overlap_max_fronts = (int)v;
