@@ -215,9 +215,9 @@ int tsl_profile_read_events(tsl_ctx* ctx, double* spmv_ms_hip_events_host); /* s
 int tsl_bench_spmv(tsl_ctx* ctx, int variant, int reps, double* us_per_launch_host);
 
 /* Sparse direct path (multifrontal LU of the operator, the counterpart of the reference's spsolve, sparse_solver.py:85-105).
- * tsl_bench_direct: the launches of one kernel class of ONE factorisation (cls 0 the Gauss-Jordan inversions W = F11^-1:
- * k_ds_inv_small / k_ds_pivot0 + k_ds_gj_step + k_ds_gj_finish; 1 k_ds_gemm in Schur mode with its extend-add; 2 k_ds_gemm in
- * G = W F12 mode; 3 unused) or of one application (4 k_ds_gemv) on the current plan, replayed `reps` times between one hipEvent pair;
+ * tsl_bench_direct: the launches of one kernel class of ONE factorisation (cls 0 the Gauss-Jordan inversions W = F11^-1 on the block-step
+ * path: k_ds_pivot0 + k_ds_gj_step + k_ds_gj_finish; 1 k_ds_gemm in Schur mode with its extend-add; 2 k_ds_gemm in G = W F12 mode;
+ * 3 the inversions in the LDS kernel k_ds_inv_small) or of one application (4 k_ds_gemv) on the current plan, replayed `reps` times between one hipEvent pair;
  * out4 = {us per launch, algorithmic flops per launch, algorithmic bytes per launch, launches per factorisation}.  The factors are
  * invalid afterwards.  tsl_direct_info: {plans, factorisations, applications, perturbed pivots of the last factorisation, host
  * seconds in plan builds, supernodes, levels, batches, flops per factorisation, bytes of fronts}. */

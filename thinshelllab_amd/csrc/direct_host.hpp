@@ -380,8 +380,9 @@ static int direct_apply(tsl_ctx* c, const double* r, double* z) {
 
 // Timing of one kernel class of the factorisation / solve for bench.py's roofline object: the launches of that class of ONE
 // factorisation (or one application), exactly as direct_factor / direct_apply issue them on the current plan, replayed `reps` times
-// back to back between one hipEvent pair on the engine stream.  cls: 0 the Gauss-Jordan inversions W = F11^-1 (k_ds_inv_small /
-// k_ds_pivot0 + k_ds_gj_step + k_ds_gj_finish), 1 k_ds_gemm mode 1 (Schur complements + extend-add), 2 k_ds_gemm mode 0 (G = W F12), 3 unused,
+// back to back between one hipEvent pair on the engine stream.  cls: 0 the Gauss-Jordan inversions W = F11^-1 on the block-step path
+// (k_ds_pivot0 + k_ds_gj_step + k_ds_gj_finish), 1 k_ds_gemm mode 1 (Schur complements + extend-add), 2 k_ds_gemm mode 0 (G = W F12), 3 the inversions of
+// the batches in the LDS kernel (k_ds_inv_small: leaf levels and small fronts, one launch per batch),
 // 4 k_ds_gemv (all sweeps of one application).  The replays overwrite the factors (marked invalid afterwards).
 // out: {us per launch, algorithmic flops per launch, algorithmic bytes per launch, launches per factorisation / application}
 static int direct_bench(tsl_ctx* c, int cls, int reps, double* out) {
@@ -422,8 +423,9 @@ static int direct_bench(tsl_ctx* c, int cls, int reps, double* out) {
       if (d.bench_batch >= 0 && bi != d.bench_batch) continue;   // "ds_bench_batch": one batch only (scripts/exp_batches.py)
       const int lv0 = b.first, nf = b.count;
       const int tp = b.max_pp / DS_T, tb = b.max_bp / DS_T;
-      if (cls == 0) {   // W = F11^-1: the LDS kernel or pivot0 + block steps + finish
-        if (ds_use_small(b)) { hipLaunchKernelGGL(k_ds_inv_small, dim3(nf), dim3(256), ds_small_lds(b.max_pp), s, D, lv0, b.max_pp + 1); if (count) launches++; }
+      if (cls == 0 || cls == 3) {   // W = F11^-1: cls 0 the batches on the block-step path (pivot0 + block steps + finish), cls 3 the batches in the LDS kernel
+        if (ds_use_small(b) != (cls == 3)) continue;
+        if (cls == 3) { hipLaunchKernelGGL(k_ds_inv_small, dim3(nf), dim3(256), ds_small_lds(b.max_pp), s, D, lv0, b.max_pp + 1); if (count) launches++; }
         else {
           hipLaunchKernelGGL(k_ds_pivot0, dim3(nf), dim3(256), 0, s, D, lv0);
           for (int k = 0; k < tp; k++) { const int na = P.act_n[b.act_off + k]; hipLaunchKernelGGL(k_ds_gj_step, dim3(na + na * tp * tp), dim3(256), 0, s, D, lv0, k, tp, na); }
