@@ -695,3 +695,25 @@ def test_state_and_mesh_export_formats(oracle, tmp_path):
     v = np.array([[float(x) for x in ln.split()] for ln in lines[h + 1:h + 1 + c.NV]])
     f = np.array([[int(x) for x in ln.split()] for ln in lines[h + 1 + c.NV:h + 1 + c.NV + c.NF]])
     assert np.array_equal(v, c.pos.to_numpy()) and np.array_equal(f[:, 1:], c.f2v.to_numpy()) and (f[:, 0] == 3).all()
+
+
+def test_warm_started_element_eigen_clamp_is_the_same_projection():
+    """"tet_warm" (default): the Jacobi eigen-clamp of every tactile element block starts from the eigenvectors of the element's
+    previous assembly.  Over a sequence of states (the Newton iterations of a step) the assembled operator must be the one the
+    cold-started clamp gives, to rounding."""
+    s = _scene("balancing")
+    rng = np.random.default_rng(3)
+    x0 = s.pos.to_numpy()
+    fr = s.frozen.to_numpy().reshape(-1, 3).astype(bool)
+    ctx = s._ensure_ctx()
+    for it in range(5):
+        x = x0 + rng.normal(0, 3e-5 * (it + 1), x0.shape)
+        x[fr] = x0[fr]
+        s.pos.from_numpy(x)
+        ctx.set_param("tet_warm", 1)
+        s.compute_Hessian(spd=True)
+        Hw = ctx.matrix_csr().toarray()
+        ctx.set_param("tet_warm", 0)
+        s.compute_Hessian(spd=True)
+        Hc = ctx.matrix_csr().toarray()
+        assert np.abs(Hw - Hc).max() <= 1e-11 * np.abs(Hc).max(), it

@@ -157,11 +157,12 @@ TSL_DEV void spd_clamp_warm(double* A, double* __restrict__ Vg, size_t vs, bool 
   double V[D * D];
   for (int i = 0; i < D; i++)
     for (int j = i + 1; j < D; j++) { double s = 0.5 * (A[i * D + j] + A[j * D + i]); A[i * D + j] = s; A[j * D + i] = s; }
-  if (warm) {
-    bool ok = true;
+  if (warm) {   // the stored basis must look like one: finite entries and squared Frobenius norm D (a slot never written -- an element
+                // that was not clamped before -- or one poisoned by a non-finite block starts from the identity)
+    double ss = 0.0;
 #pragma unroll
-    for (int e = 0; e < D * D; e++) { V[e] = Vg[e * vs]; ok = ok && (fabs(V[e]) <= 1.5); }
-    warm = ok;
+    for (int e = 0; e < D * D; e++) { V[e] = Vg[e * vs]; ss += V[e] * V[e]; }
+    warm = fabs(ss - (double)D) <= 1e-6 * D;
   }
   if (warm) {   // A <- V^T A V
     double T[D * D];

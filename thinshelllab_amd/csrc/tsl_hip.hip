@@ -579,7 +579,11 @@ static int assemble(tsl_ctx* c, const double* pos, const double* prev, const dou
       double* vws = nullptr;
       int warm = 0;
       if (c->tet_warm && spd != 0) {
-        if (c->tet_V.n < (size_t)81 * c->n_tet) { if (c->tet_V.alloc((size_t)81 * c->n_tet)) return tsl_fail("out of device memory (tet eigenvectors)"); c->tet_V_count = 0; }
+        if (c->tet_V.n < (size_t)81 * c->n_tet) {
+          if (c->tet_V.alloc((size_t)81 * c->n_tet)) return tsl_fail("out of device memory (tet eigenvectors)");
+          HIP_OK(hipMemsetAsync(c->tet_V.p, 0, c->tet_V.n * sizeof(double), stt));   // "no basis yet" for every element (spd_clamp_warm checks the norm)
+          c->tet_V_count = 0;
+        }
         vws = c->tet_V.p;
         warm = (c->tet_V_count++ % 16) != 0;
       }
