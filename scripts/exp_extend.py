@@ -19,7 +19,7 @@ for rep in range(2):
         print(name, round(r["us_per_launch"] * r["launches"], 1), "us per factorisation", flush=True)
 ctx.set_param("ds_dbg", 0)
 # product alone (G = W F12 launches: no extend-add): real operands / every workgroup on the same operand tiles / no global loads after the first slab
-for dbg, name in ((0, "G product"), (6, "G product, cache-resident operands"), (7, "G product, no global loads in the K loop")):
+for dbg, name in ((0, "G product"), (6, "G product, cache-resident operands"), (7, "G product, no global loads in the K loop"), (10, "G product, no global loads and no barriers in the K loop"), (11, "G product, no loads, no barriers, no LDS refill: LDS reads + matrix cores only")):
     ctx.set_param("ds_dbg", dbg)
     r = ctx.bench_direct(2, 10)
     t = r["us_per_launch"] * r["launches"]

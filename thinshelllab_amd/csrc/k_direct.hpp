@@ -640,12 +640,14 @@ TSL_DEV void ds_gemm_tile(const DsDev& D, int lv0, int bx, int by, int bz, int p
   if (D.dbg == 6) { Am -= (size_t)I0 * ld; Bm -= J0; }   // timing experiments only: every workgroup streams the SAME operand tiles (cache-resident) ...
   gload(0);
   for (int k0 = 0; k0 < K; k0 += DS_SK) {
+    if (D.dbg < 11 || k0 == 0) {   // ("ds_dbg" 10 / 11, timing experiments: no barriers / no LDS refill either inside the K loop)
 #pragma unroll
-    for (int q = 0; q < 8; q++) As[(ty + 8 * q) * SA + tx] = pa[q];
+      for (int q = 0; q < 8; q++) As[(ty + 8 * q) * SA + tx] = pa[q];
 #pragma unroll
-    for (int q = 0; q < 4; q++) { Bs[(ty + 8 * q) * SB + tx] = pb0[q]; Bs[(ty + 8 * q) * SB + tx + 32] = pb1[q]; }
-    __syncthreads();
-    if (k0 + DS_SK < K && D.dbg != 7) gload(k0 + DS_SK);   // ... (7) or none after the first slab: LDS + matrix cores + barriers alone
+      for (int q = 0; q < 4; q++) { Bs[(ty + 8 * q) * SB + tx] = pb0[q]; Bs[(ty + 8 * q) * SB + tx + 32] = pb1[q]; }
+    }
+    if (D.dbg < 10 || k0 == 0) __syncthreads();
+    if (k0 + DS_SK < K && D.dbg != 7 && D.dbg < 10) gload(k0 + DS_SK);   // ... (7) or none after the first slab: LDS + matrix cores + barriers alone
 #pragma unroll
     for (int kk = 0; kk < DS_SK / 4; kk++) {
       const double a0 = As[(32 * wi + lr) * SA + 4 * kk + lk], a1 = As[(32 * wi + 16 + lr) * SA + 4 * kk + lk];
@@ -655,7 +657,7 @@ TSL_DEV void ds_gemm_tile(const DsDev& D, int lv0, int bx, int by, int bz, int p
       acc[1][0] = __builtin_amdgcn_mfma_f64_16x16x4f64(a1, b0, acc[1][0], 0, 0, 0);
       acc[1][1] = __builtin_amdgcn_mfma_f64_16x16x4f64(a1, b1, acc[1][1], 0, 0, 0);
     }
-    __syncthreads();
+    if (D.dbg < 10) __syncthreads();
   }
   if (mode == 0) {
 #pragma unroll
