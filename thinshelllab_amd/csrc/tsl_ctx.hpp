@@ -144,8 +144,9 @@ struct DirectSolver {
   // static pivoting: pivots below piv_tol x their own scale are perturbed to that bound ("direct_piv_tol").  1e-11 since round 3: a pivot
   // that lost eleven digits to cancellation against its entry diagonal (a contact stiffness of 1e14 on a nearly collapsed pad triangle over
   // a true pivot of 1e4) still carries five -- enough for a factorisation that is refined --, while 1e-8 replaced such pivots by 1e6 and
-  // sent the refinement into its fallback: driver's command 3 of 18 runs with flagged solves at 1e-8, 0 of 16 at 1e-11; the T = 50 rollout
-  // 1 of 2 (26 flagged solves) at 1e-8, 2 of 3 at 1e-10, 1 of 7 (7 solves) at 1e-11, 0 of 3 at 1e-12, 30 flagged solves at 1e-13 (garbage pivots pass)
+  // sent the refinement into its fallback: driver's command 3 of 18 runs with flagged solves at 1e-8, 0 of 16 at 1e-11; 30 flagged solves in a
+  // T = 50 run at 1e-13 (garbage pivots pass).  (The T = 50 rollout reaches collapsed pad triangles -- entries of 1e17..1e22 -- in a third of its
+  // runs at any threshold: 5 of 15 at 1e-11, 3 of 11 at 1e-12.)
   double piv_tol = 1e-11;
   int fallback_cap = 1000;  // iteration cap of the hierarchy when the factorisation broke down ("direct_fallback_cap")
   int leaf = 64;            // vertices per leaf of the nested dissection (cfg4 sweep: 32 -> 452, 48 -> 420, 56 / 64 -> 407, 80 -> 538 ms per step)
