@@ -127,6 +127,7 @@ struct DirectSolver {
   size_t b_n = 0;
   hipEvent_t ev_zero_b = nullptr;
   int two_arenas = 0, clear_wgs = 64;
+  int clear_chunks = 1;     // "direct_clear_chunks": pieces of the side-stream clear of the front arena (direct_prezero); measured 16 / 8 pieces: 307-311 ms per step against 306-307 with one
   hipStream_t fstream[2] = {nullptr, nullptr};   // batches of one level run next to each other (direct_factor)
   hipEvent_t ev_ffork = nullptr, ev_fjoin[2] = {nullptr, nullptr};
   int par_batches = 1;      // "direct_par_batches"
