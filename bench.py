@@ -35,8 +35,8 @@ if ROOT not in sys.path:
 
 HBM_PEAK_GBS = 8000.0     # /opt/skills/guides/MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
 F64_MFMA_PEAK_TF = 78.6   # v_mfma_f64_16x16x4_f64: half the f32 MFMA rate the guide lists (157.3 TF) = the f64 vector rate (AMD MI355X datasheet: 78.6 TF)
-F64_MFMA_SUSTAINED_TF = 47.6   # what the instruction delivers from registers alone on this part, four waves per SIMD (scripts/micro/mfma_peak.hip,
-                               # profiles/r03_mfma_f64_sustained_peak.txt: 33.4 / 45.0 / 47.6 TFLOP/s at 1 / 2 / 4 workgroups per CU = a clock of ~1.45 GHz under this load)
+F64_MFMA_SUSTAINED_TF = 65.0   # what a GEMM K loop (LDS operand reads + v_mfma_f64_16x16x4_f64, 2 x 2 tiles per wave) sustains on this part: scripts/micro/mfma_lds.hip,
+                               # profiles/r03_mfma_f64_sustained_peak.txt (65 TFLOP/s with the reads inside the loop, 67-72 with the operands in registers)
 
 GS_CFG4 = 224 * 0.004 / 0.06  # similarity factor that keeps the native 4 mm cloth spacing of Scene_balancing at 224x224
 
@@ -316,8 +316,8 @@ def roofline(ctx, scene, elapsed, K, stats, args):
                          "launches; compare the rocprofv3 kernel-trace averages under profiles/)",
                "plan": {k: info[k] for k in ("supernodes", "levels", "batches", "flops_per_factorization", "front_bytes")},
                "mfma_f64_sustained_TFLOPs": {"value": F64_MFMA_SUSTAINED_TF,
-                                             "source": "committed micro-benchmark scripts/micro/mfma_peak.hip (profiles/r03_mfma_f64_sustained_peak.txt): v_mfma_f64_16x16x4_f64 from registers "
-                                                       "alone, four waves per SIMD; a constant, not measured by this run.  The GEMM classes against it: "
+                                             "source": "committed micro-benchmark scripts/micro/mfma_lds.hip (profiles/r03_mfma_f64_sustained_peak.txt): the K loop of a GEMM tile alone, LDS operand reads + "
+                                                       "v_mfma_f64_16x16x4_f64; a constant, not measured by this run.  The GEMM classes against it: "
                                                        + ", ".join(f"{names[k].split(' ')[0]} {cls[k]['flops_per_launch'] / max(cls[k]['us_per_launch'], 1e-9) / 1e6 / F64_MFMA_SUSTAINED_TF:.2f}" for k in (1, 2))}})
     # bytes_model(measured counts) / wall / 8e12 with the per-triangle figures of the assembled-matrix algorithm (fp64)
     T = scene.cloths[0].NF

@@ -25,3 +25,9 @@ for dbg, name in ((0, "G product"), (6, "G product, cache-resident operands"), (
     t = r["us_per_launch"] * r["launches"]
     print(name, round(t, 1), "us per factorisation,", round(r["flops_per_launch"] * r["launches"] / t * 1e-6, 1), "TFLOP/s", flush=True)
 ctx.set_param("ds_dbg", 0)
+# persistent variant: at most `cap` workgroups walk the tiles (does desynchronising the workgroups of a CU raise the matrix-core utilisation?)
+for cap in (0, 1024, 2048, 768):
+    ctx.set_param("direct_gemm_persist", cap)
+    r1 = ctx.bench_direct(1, 10); r2 = ctx.bench_direct(2, 10)
+    print("gemm_persist", cap, "Schur", round(r1["us_per_launch"] * r1["launches"], 1), "us  G", round(r2["us_per_launch"] * r2["launches"], 1), "us", flush=True)
+ctx.set_param("direct_gemm_persist", 0)

@@ -29,8 +29,9 @@ static void ds_launch_gemm(hipStream_t s, const DsDev& D, const DsBatch& b, int 
   const int rows = mode == 0 ? b.max_pp : b.max_bp, cols = b.max_bp;
   const dim3 grid((cols + 63) / 64, (rows + 63) / 64, b.count);
   const long tiles = (long)grid.x * grid.y * grid.z;
-  if (cap > 0 && mode == 1 && tiles > cap) {
-    hipLaunchKernelGGL((k_ds_gemm_capped<1, 4>), dim3(cap), dim3(256), 0, s, D, b.first, (int)grid.x, (int)grid.y, (int)grid.z, part);
+  if (cap > 0 && tiles > cap) {
+    if (mode == 1) hipLaunchKernelGGL((k_ds_gemm_capped<1, 4>), dim3(cap), dim3(256), 0, s, D, b.first, (int)grid.x, (int)grid.y, (int)grid.z, part);
+    else hipLaunchKernelGGL((k_ds_gemm_capped<0, 4>), dim3(cap), dim3(256), 0, s, D, b.first, (int)grid.x, (int)grid.y, (int)grid.z, 0);
     return;
   }
   if (mode == 0) { if (wpc >= 4) hipLaunchKernelGGL((k_ds_gemm<0, 4>), grid, dim3(256), 0, s, D, b.first, 0); else hipLaunchKernelGGL((k_ds_gemm<0, 3>), grid, dim3(256), 0, s, D, b.first, 0); }
@@ -270,8 +271,8 @@ static int direct_factor(tsl_ctx* c, int stop_sn = -1, const char* dump_path = n
     }
     if (def_pending) (void)hipStreamWaitEvent(bs, d.ev_def, 0);   // F12 / F21 / F22 of this level's fronts are complete once the previous level's deferred tiles are in
     if (tb > 0) {
-      ds_launch_gemm(bs, D, b, 0, d.gemm_wpc);
-      if (!defer) ds_launch_gemm(bs, D, b, 1, d.gemm_wpc);   // + extend-add into the parents
+      ds_launch_gemm(bs, D, b, 0, d.gemm_wpc, 0, d.gemm_persist);
+      if (!defer) ds_launch_gemm(bs, D, b, 1, d.gemm_wpc, 0, d.gemm_persist);   // + extend-add into the parents
       else {
         // Only the tiles of S that land in the parents' PIVOT blocks are in front of the next level's Gauss-Jordan chain; the rest
         // (what the parents' own GEMMs need) runs on the deferred stream from a capped grid next to that chain.
@@ -443,7 +444,7 @@ static int direct_bench(tsl_ctx* c, int cls, int reps, double* out) {
           bytes += 16.0 * (double)f.pp * f.pp * (ds_use_small(b) ? 1.0 : f.pp / (double)DS_T);   // the block read and written once per launch that touches it
         }
       } else if (tb > 0) {
-        if (cls == 1 || cls == 2) ds_launch_gemm(s, D, b, cls == 2 ? 0 : 1, d.gemm_wpc);
+        if (cls == 1 || cls == 2) ds_launch_gemm(s, D, b, cls == 2 ? 0 : 1, d.gemm_wpc, 0, d.gemm_persist);
         else continue;
         if (count) {
           launches++;

@@ -138,6 +138,7 @@ struct DirectSolver {
   // slower (219 instead of 134 us for the 8 steps of 16 fronts): every level takes as long as before, 309-311 against 305-306 ms per step --
   // the block steps are not idle time that other work can fill, their 1024 workgroups keep the memory system busy
   int overlap = 0, overlap_cap = 512, overlap_max_fronts = 160;
+  int gemm_persist = 0;     // "direct_gemm_persist": > 0 = the GEMM launches use at most this many workgroups, each walking several tiles (experiment)
   int gemm_wpc = 4;         // "direct_gemm_wpc": workgroups per CU the GEMM kernels are compiled for (3: F22 tile prefetched, 4: fetched in the epilogue)
   bool cons_checked = false; // the constraint list has not changed since direct_plan last looked (reset by tsl_contact_detect)
   double* h_anorm = nullptr; // pinned: |H|_inf of the last factorisation (valid after the next stream synchronisation)
