@@ -38,6 +38,44 @@ static void ds_launch_gemm(hipStream_t s, const DsDev& D, const DsBatch& b, int 
   else { if (wpc >= 4) hipLaunchKernelGGL((k_ds_gemm<1, 4>), grid, dim3(256), 0, s, D, b.first, part); else hipLaunchKernelGGL((k_ds_gemm<1, 3>), grid, dim3(256), 0, s, D, b.first, part); }
 }
 
+
+// "direct_flow": the block steps of a batch as ONE persistent dataflow launch (k_ds_gj_flow) -- for a batch that is alone on its level
+// (no second persistent grid next to it), of at most DS_FLOW_MAXF fronts, whose tiles are all resident at once.  Fills the launch
+// arguments and grows the exchange buffers; false = the batch stays on the launch-per-block-step path.
+static int ds_flow_prepare(DirectSolver& d, const DirectPlan& P, const DsBatch& b, bool alone, DsFlowArgs& a) {   // -> workgroups per CU of the instantiation to launch (4 / 5), 0 = not on this path
+  if (!d.flow || !alone || ds_use_small(b) || b.count > DS_FLOW_MAXF) return 0;
+  if (d.flow_cap[0] == 0) {
+    int occ4 = 0, occ5 = 0, dev = 0;
+    hipDeviceProp_t prop;
+    if (hipGetDevice(&dev) != hipSuccess || hipGetDeviceProperties(&prop, dev) != hipSuccess ||
+        hipOccupancyMaxActiveBlocksPerMultiprocessor(&occ4, (const void*)k_ds_gj_flow<4>, 256, 0) != hipSuccess ||
+        hipOccupancyMaxActiveBlocksPerMultiprocessor(&occ5, (const void*)k_ds_gj_flow<5>, 256, 0) != hipSuccess) { d.flow_cap[0] = d.flow_cap[1] = -1; return 0; }
+    d.flow_cap[0] = std::max(1, occ4 * prop.multiProcessorCount);
+    d.flow_cap[1] = std::max(1, occ5 * prop.multiProcessorCount);
+    if (getenv("TSL_FLOW_DEBUG")) fprintf(stderr, "[tsl] k_ds_gj_flow: %d / %d workgroups per CU x %d CUs resident\n", occ4, occ5, prop.multiProcessorCount);
+  }
+  long tiles = 0, x = 0, fl = 0;
+  for (int z = 0; z < b.count; z++) {
+    const long nt = P.fr[P.level_sn[b.first + z]].pp / DS_T;
+    a.tile0[z] = (int)tiles; a.xoff[z] = x; a.foff[z] = (int)fl;
+    tiles += nt * nt; x += (nt + 2 * nt * nt) * (DS_T * DS_T); fl += 32 * nt + 2 * nt * nt;
+  }
+  a.tile0[b.count] = (int)tiles; a.nf = b.count;
+  if (tiles > d.flow_cap[1] || tiles < 4) return 0;
+  if (d.flow_x.n < (size_t)x) { if (d.flow_x.alloc((size_t)x)) return 0; }
+  if (d.flow_f.n < (size_t)fl) {   // flags start below every epoch
+    if (d.flow_f.alloc((size_t)fl + 1024)) return 0;
+    if (hipMemset(d.flow_f.p, 0, d.flow_f.n * sizeof(int)) != hipSuccess) return 0;
+    d.flow_epoch = 0;
+  }
+  a.epoch = ++d.flow_epoch;
+  return tiles <= d.flow_cap[0] ? 4 : 5;   // the fifth workgroup per CU costs 15 spilled registers: only for a root beyond 1024 tiles
+}
+static void ds_flow_launch(hipStream_t s, const DsDev& D, int lv0, const DsFlowArgs& fa, int wpc, DirectSolver& d) {
+  if (wpc == 4) hipLaunchKernelGGL(k_ds_gj_flow<4>, dim3(fa.tile0[fa.nf]), dim3(256), 0, s, D, lv0, fa, d.flow_x.p, d.flow_f.p);
+  else hipLaunchKernelGGL(k_ds_gj_flow<5>, dim3(fa.tile0[fa.nf]), dim3(256), 0, s, D, lv0, fa, d.flow_x.p, d.flow_f.p);
+}
+
 static bool direct_enabled(tsl_ctx* c) {
   DirectSolver& d = c->ds;
   if (d.enable == 0) return false;
@@ -260,10 +298,12 @@ static int direct_factor(tsl_ctx* c, int stop_sn = -1, const char* dump_path = n
   }
   bool def_pending = false;   // deferred launches of the previous level not yet joined
   int nrec = 0;
-  auto run_batch = [&](const DsBatch& b, hipStream_t bs, bool defer) {
+  auto run_batch = [&](const DsBatch& b, hipStream_t bs, bool defer, bool alone) {
     const int lv0 = b.first, nf = b.count;
     const int tp = b.max_pp / DS_T, tb = b.max_bp / DS_T;
+    DsFlowArgs fa;
     if (ds_use_small(b)) hipLaunchKernelGGL(k_ds_inv_small, dim3(nf), dim3(256), ds_small_lds(b.max_pp), bs, D, lv0, b.max_pp + 1);
+    else if (const int wpc = ds_flow_prepare(d, P, b, alone, fa)) { ds_flow_launch(bs, D, lv0, fa, wpc, d); d.n_flow++; }
     else {
       hipLaunchKernelGGL(k_ds_pivot0, dim3(nf), dim3(256), 0, bs, D, lv0);
       for (int k = 0; k < tp; k++) { const int na = P.act_n[b.act_off + k]; hipLaunchKernelGGL(k_ds_gj_step, dim3(na + na * tp * tp), dim3(256), 0, bs, D, lv0, k, tp, na); }   // fronts are sorted by pp: the active ones are a prefix
@@ -328,7 +368,7 @@ static int direct_factor(tsl_ctx* c, int stop_sn = -1, const char* dump_path = n
     nrec = 0;
     for (size_t q = bi; q < be; q++) {
       const int k = (int)(q - bi);   // batch 0 of the level (the largest pivot blocks: the longest chain of block steps) stays on the engine stream
-      run_batch(P.batches[q], (nside > 0 && k > 0) ? d.fstream[(k - 1) % nside] : s, defer);
+      run_batch(P.batches[q], (nside > 0 && k > 0) ? d.fstream[(k - 1) % nside] : s, defer, be - bi == 1 && !defer);
     }
     for (int k = 0; k < nside; k++) { HIP_OK(hipEventRecord(d.ev_fjoin[k], d.fstream[k])); HIP_OK(hipStreamWaitEvent(s, d.ev_fjoin[k], 0)); }
     def_pending = defer;
@@ -389,7 +429,7 @@ static int direct_apply(tsl_ctx* c, const double* r, double* z) {
 // back to back between one hipEvent pair on the engine stream.  cls: 0 the Gauss-Jordan inversions W = F11^-1 on the block-step path
 // (k_ds_pivot0 + k_ds_gj_step + k_ds_gj_finish), 1 k_ds_gemm mode 1 (Schur complements + extend-add), 2 k_ds_gemm mode 0 (G = W F12), 3 the inversions of
 // the batches in the LDS kernel (k_ds_inv_small: leaf levels and small fronts, one launch per batch),
-// 4 k_ds_gemv (all sweeps of one application).  The replays overwrite the factors (marked invalid afterwards).
+// 4 k_ds_gemv (all sweeps of one application), 5 the inversions of the batches in the dataflow kernel (k_ds_gj_flow: one persistent launch per batch).  The replays overwrite the factors (marked invalid afterwards).
 // out: {us per launch, algorithmic flops per launch, algorithmic bytes per launch, launches per factorisation / application}
 static int direct_bench(tsl_ctx* c, int cls, int reps, double* out) {
   DirectSolver& d = c->ds;
@@ -429,9 +469,15 @@ static int direct_bench(tsl_ctx* c, int cls, int reps, double* out) {
       if (d.bench_batch >= 0 && bi != d.bench_batch) continue;   // "ds_bench_batch": one batch only (scripts/exp_batches.py)
       const int lv0 = b.first, nf = b.count;
       const int tp = b.max_pp / DS_T, tb = b.max_bp / DS_T;
-      if (cls == 0 || cls == 3) {   // W = F11^-1: cls 0 the batches on the block-step path (pivot0 + block steps + finish), cls 3 the batches in the LDS kernel
+      if (cls == 0 || cls == 3 || cls == 5) {   // W = F11^-1: cls 0 the batches on the block-step path (pivot0 + block steps + finish), cls 3 the batches in the LDS kernel, cls 5 those in the dataflow kernel
         if (ds_use_small(b) != (cls == 3)) continue;
-        if (cls == 3) { hipLaunchKernelGGL(k_ds_inv_small, dim3(nf), dim3(256), ds_small_lds(b.max_pp), s, D, lv0, b.max_pp + 1); if (count) launches++; }
+        bool alone = true;
+        for (size_t q = 0; q < P.batches.size(); q++) alone &= ((int)q == bi || P.batches[q].level != b.level);
+        DsFlowArgs fa;
+        const int flow = cls != 3 ? ds_flow_prepare(d, P, b, alone, fa) : 0;
+        if ((flow != 0) != (cls == 5) && cls != 3) continue;
+        if (cls == 5) { ds_flow_launch(s, D, lv0, fa, flow, d); if (count) launches++; }
+        else if (cls == 3) { hipLaunchKernelGGL(k_ds_inv_small, dim3(nf), dim3(256), ds_small_lds(b.max_pp), s, D, lv0, b.max_pp + 1); if (count) launches++; }
         else {
           hipLaunchKernelGGL(k_ds_pivot0, dim3(nf), dim3(256), 0, s, D, lv0);
           for (int k = 0; k < tp; k++) { const int na = P.act_n[b.act_off + k]; hipLaunchKernelGGL(k_ds_gj_step, dim3(na + na * tp * tp), dim3(256), 0, s, D, lv0, k, tp, na); }
@@ -441,7 +487,7 @@ static int direct_bench(tsl_ctx* c, int cls, int reps, double* out) {
         if (count) for (int i = 0; i < nf; i++) {
           const DsFrontDesc& f = P.fr[P.level_sn[lv0 + i]];
           flops += 2.0 * (double)f.pp * f.pp * f.pp;
-          bytes += 16.0 * (double)f.pp * f.pp * (ds_use_small(b) ? 1.0 : f.pp / (double)DS_T);   // the block read and written once per launch that touches it
+          bytes += 16.0 * (double)f.pp * f.pp * (cls != 0 ? 1.0 : f.pp / (double)DS_T);   // the block read and written once per launch that touches it
         }
       } else if (tb > 0) {
         if (cls == 1 || cls == 2) ds_launch_gemm(s, D, b, cls == 2 ? 0 : 1, d.gemm_wpc, 0, d.gemm_persist);

@@ -478,6 +478,164 @@ __global__ void __launch_bounds__(256) k_ds_gj_finish(DsDev D, int lv0) {
   }
 }
 
+// ---- dataflow form of the same block Gauss-Jordan: ONE persistent launch per batch ("direct_flow") --------------------------------
+// On the upper levels of the tree (1 - 16 fronts) a block step is a dependent launch of ~13.4 us of which the arithmetic is a fraction.
+// Here every workgroup KEEPS its 32 x 32 tile in registers (matrix-core result layout) over all block steps of its front and the steps
+// are ordered by point-to-point flags instead of kernel boundaries (`scripts/micro/flag_chain.hip`: a hop -- publish an 8 KB tile,
+// raise a flag, see it from another workgroup, fetch the tile -- is 2.0 us for 4 to 1024 workgroups):
+//   * what another workgroup needs of a tile is PUBLISHED into an exchange slot with agent-scope (write-through) stores, the publisher
+//     waits for their completion and then raises the slot's flag to this launch's epoch; readers poll the flag and fetch the slot with
+//     agent-scope loads (no L2 invalidation: an acquire fence per workgroup and step costs 30 ns x the number of workgroups per hop);
+//   * tile (i, j) publishes twice at most: when step i is next (it lies in the row panel of that step) and when step j is next (column
+//     panel); the owner of the next pivot tile inverts it and publishes the inverse P[k + 1] -- the critical path of a step is
+//     fetch P[k] -> two 32^3 products -> inversion -> publication, the panel tiles it needs were published an inversion earlier;
+//   * nobody but the owner reads the front itself, so the result goes back in place at the end.
+// The launch must be resident as a whole (the host checks tiles <= CUs x occupancy and runs it only for a batch alone on its level);
+// a flag that does not come within DS_FLOW_SPINS polls raises bad[DS_FLOW_ABORT] and lets every workgroup run out (the host reports it).
+#define DS_FLOW_MAXF 16
+#define DS_FLOW_ABORT 5
+#define DS_FLOW_SPINS (1 << 22)
+struct DsFlowArgs {
+  int nf, epoch;
+  int tile0[DS_FLOW_MAXF + 1];     // first workgroup of front z of the batch
+  int foff[DS_FLOW_MAXF];          // first flag of front z: nt pivot flags (one per 128 B), nt^2 row-panel flags, nt^2 column-panel flags
+  long long xoff[DS_FLOW_MAXF];    // first exchange slot of front z (doubles): nt pivot inverses, nt^2 row-panel slots, nt^2 column-panel slots
+};
+TSL_DEV void ds_flow_poll(const int* flag, int epoch, int* abort_w, int* s_dead) {
+  int spins = 0;
+  while (__hip_atomic_load(flag, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < epoch) {
+    if (++spins >= DS_FLOW_SPINS) { __hip_atomic_store(abort_w, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); *s_dead = 1; return; }
+    if ((spins & 1023) == 0 && __hip_atomic_load(abort_w, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0) { *s_dead = 1; return; }
+  }
+}
+TSL_DEV void ds_flow_fetch(double (*T)[DS_T + 1], const double* __restrict__ slot, int tx, int ty) {
+#pragma unroll
+  for (int q = 0; q < 4; q++) T[ty + 8 * q][tx] = __hip_atomic_load(slot + (ty + 8 * q) * DS_T + tx, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+// the stores of every wave are complete (write-through, waited for) before thread 0 raises the flag
+// (a workgroup-scope release fence alone emits no wait on gfx950: the flag overtook the tiles -- 11 instead of 2 refinement iterations on cfg4)
+#ifndef DS_FLOW_FENCE
+#define DS_FLOW_FENCE 0
+#endif
+TSL_DEV void ds_flow_raise(int* flag, int epoch) {
+  if (DS_FLOW_FENCE == 1) __threadfence();
+  else { __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup"); __builtin_amdgcn_s_waitcnt(0); }   // vmcnt(0): the write-through stores of this wave are acknowledged
+  __syncthreads();
+  if (threadIdx.x == 0) __hip_atomic_store(flag, epoch, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+template <int WPC>
+__global__ void __launch_bounds__(256, WPC) k_ds_gj_flow(DsDev D, int lv0, DsFlowArgs a, double* __restrict__ X, int* __restrict__ Fl) {
+  __shared__ double Ps[DS_T][DS_T + 1];
+  __shared__ double T1[DS_T][DS_T + 1];
+  __shared__ double T2[DS_T][DS_T + 1];
+  __shared__ int s_dead;
+  const int L = blockIdx.x;
+  int z = 0;
+  while (z + 1 < a.nf && L >= a.tile0[z + 1]) z++;
+  const int sn = D.level_sn[lv0 + z];
+  const DsFrontDesc f = D.fr[sn];
+  const int nt = f.pp / DS_T, t = L - a.tile0[z], bi = t / nt, bj = t - bi * nt;
+  const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;
+  const int lane = threadIdx.x & 63, w = threadIdx.x >> 6, wi = w >> 1, wj = w & 1, lr = lane & 15, lk = lane >> 4;
+  const int epoch = a.epoch, cls = DS_CLS(f);
+  double* A = D.A + f.off + (size_t)(bi * DS_T) * f.ld + bj * DS_T;
+  double* Xp = X + a.xoff[z];
+  int* Fp = Fl + a.foff[z];
+  int* abort_w = D.bad + DS_FLOW_ABORT;
+#define DS_FLOW_PSLOT(k) (Xp + (size_t)(k) * (DS_T * DS_T))
+#define DS_FLOW_RSLOT(i, j) (Xp + (size_t)(nt + (i) * nt + (j)) * (DS_T * DS_T))
+#define DS_FLOW_CSLOT(i, j) (Xp + (size_t)(nt + nt * nt + (i) * nt + (j)) * (DS_T * DS_T))
+#define DS_FLOW_PFLAG(k) (Fp + 32 * (k))
+#define DS_FLOW_RFLAG(i, j) (Fp + 32 * nt + (i) * nt + (j))
+#define DS_FLOW_CFLAG(i, j) (Fp + 32 * nt + nt * nt + (i) * nt + (j))
+  if (threadIdx.x == 0) s_dead = 0;
+  ds_d4 own;
+#pragma unroll
+  for (int r = 0; r < 4; r++) own[r] = A[(size_t)(16 * wi + lk + 4 * r) * f.ld + 16 * wj + lr];
+  // publication of the tile held in registers
+  auto publish = [&](double* slot, int* flag) {
+#pragma unroll
+    for (int r = 0; r < 4; r++) __hip_atomic_store(slot + (16 * wi + lk + 4 * r) * DS_T + 16 * wj + lr, own[r], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    ds_flow_raise(flag, epoch);
+  };
+  // the tile becomes its own inverse (pivot tile of step k): through T2, published as P[k]
+  auto invert_publish = [&](int k) {
+    __syncthreads();   // every wave is done with T2
+#pragma unroll
+    for (int r = 0; r < 4; r++) T2[16 * wi + lk + 4 * r][16 * wj + lr] = own[r];
+    __syncthreads();
+    ds_invert_tile(&T2[0][0], DS_T + 1, D.bad, cls, (sn << 6) | k, D.piv_tol);
+    __syncthreads();
+    double* slot = DS_FLOW_PSLOT(k);
+#pragma unroll
+    for (int q = 0; q < 4; q++) __hip_atomic_store(slot + (ty + 8 * q) * DS_T + tx, T2[ty + 8 * q][tx], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+#pragma unroll
+    for (int r = 0; r < 4; r++) own[r] = T2[16 * wi + lk + 4 * r][16 * wj + lr];
+    ds_flow_raise(DS_FLOW_PFLAG(k), epoch);
+  };
+  __syncthreads();
+  if (bi == 0 && bj == 0) invert_publish(0);
+  else if (bi == 0) publish(DS_FLOW_RSLOT(0, bj), DS_FLOW_RFLAG(0, bj));
+  else if (bj == 0) publish(DS_FLOW_CSLOT(bi, 0), DS_FLOW_CFLAG(bi, 0));
+  for (int k = 0; k < nt; k++) {
+    if (!(bi == k && bj == k)) {   // (the pivot tile of step k holds P[k] already)
+      const bool general = bi != k && bj != k;
+      if (general) {   // the panel tiles first: they were published an inversion before P[k]
+        if (threadIdx.x == 64) ds_flow_poll(DS_FLOW_RFLAG(k, bj), epoch, abort_w, &s_dead);
+        if (threadIdx.x == 128) ds_flow_poll(DS_FLOW_CFLAG(bi, k), epoch, abort_w, &s_dead);
+        __syncthreads();
+        ds_flow_fetch(T1, DS_FLOW_RSLOT(k, bj), tx, ty);
+        ds_flow_fetch(T2, DS_FLOW_CSLOT(bi, k), tx, ty);
+      }
+      if (threadIdx.x == 0) ds_flow_poll(DS_FLOW_PFLAG(k), epoch, abort_w, &s_dead);
+      __syncthreads();
+      ds_flow_fetch(Ps, DS_FLOW_PSLOT(k), tx, ty);
+      if (bi == k) {
+#pragma unroll
+        for (int r = 0; r < 4; r++) T1[16 * wi + lk + 4 * r][16 * wj + lr] = own[r];
+      } else if (bj == k) {
+#pragma unroll
+        for (int r = 0; r < 4; r++) T2[16 * wi + lk + 4 * r][16 * wj + lr] = own[r];
+      }
+      __syncthreads();
+      if (s_dead) break;
+      ds_d4 acc = {0.0, 0.0, 0.0, 0.0};
+      if (bj == k) {   // A_iK = -A_iK P
+#pragma unroll
+        for (int kk = 0; kk < DS_T / 4; kk++) acc = __builtin_amdgcn_mfma_f64_16x16x4f64(T2[16 * wi + lr][4 * kk + lk], Ps[4 * kk + lk][16 * wj + lr], acc, 0, 0, 0);
+        own = -acc;
+      } else {         // R'_j = P A_Kj
+#pragma unroll
+        for (int kk = 0; kk < DS_T / 4; kk++) acc = __builtin_amdgcn_mfma_f64_16x16x4f64(Ps[16 * wi + lr][4 * kk + lk], T1[4 * kk + lk][16 * wj + lr], acc, 0, 0, 0);
+        if (bi == k) own = acc;
+        else {         // A_ij -= A_iK R'_j
+          __syncthreads();   // every quadrant has read T1
+#pragma unroll
+          for (int r = 0; r < 4; r++) T1[16 * wi + lk + 4 * r][16 * wj + lr] = acc[r];
+          __syncthreads();
+          acc = ds_d4{0.0, 0.0, 0.0, 0.0};
+#pragma unroll
+          for (int kk = 0; kk < DS_T / 4; kk++) acc = __builtin_amdgcn_mfma_f64_16x16x4f64(T2[16 * wi + lr][4 * kk + lk], T1[4 * kk + lk][16 * wj + lr], acc, 0, 0, 0);
+          own -= acc;
+        }
+      }
+    }
+    if (k + 1 < nt) {
+      if (bi == k + 1 && bj == k + 1) invert_publish(k + 1);
+      else if (bi == k + 1) publish(DS_FLOW_RSLOT(bi, bj), DS_FLOW_RFLAG(bi, bj));
+      else if (bj == k + 1) publish(DS_FLOW_CSLOT(bi, bj), DS_FLOW_CFLAG(bi, bj));
+    }
+  }
+#pragma unroll
+  for (int r = 0; r < 4; r++) A[(size_t)(16 * wi + lk + 4 * r) * f.ld + 16 * wj + lr] = own[r];
+#undef DS_FLOW_PSLOT
+#undef DS_FLOW_RSLOT
+#undef DS_FLOW_CSLOT
+#undef DS_FLOW_PFLAG
+#undef DS_FLOW_RFLAG
+#undef DS_FLOW_CFLAG
+}
+
 // W = F11^-1 of a front with at most DS_SMALL pivots by ONE workgroup with the block in LDS (row stride ls = batch maximum + 1):
 // the same blocked Gauss-Jordan, all block steps inside the launch -- the workgroup inverts the pivot tile where it lies, every wave
 // owns row chunks of the rank-T update on the matrix cores (its column-panel fragment lives in registers while the chunk is rewritten).

@@ -138,6 +138,11 @@ struct DirectSolver {
   // slower (219 instead of 134 us for the 8 steps of 16 fronts): every level takes as long as before, 309-311 against 305-306 ms per step --
   // the block steps are not idle time that other work can fill, their 1024 workgroups keep the memory system busy
   int overlap = 0, overlap_cap = 512, overlap_max_fronts = 160;
+  // "direct_flow": block steps of a batch alone on its level as one persistent dataflow launch (k_ds_gj_flow)
+  int flow = 1, flow_cap[2] = {0, 0}, flow_epoch = 0;   // flow_cap: resident workgroups of the 4 / 5-per-CU instantiations
+  long n_flow = 0;
+  DevBuf<double> flow_x;    // exchange slots (pivot inverses, row / column panel tiles)
+  DevBuf<int> flow_f;       // their flags (epoch of the launch that published the slot)
   int gemm_persist = 0;     // "direct_gemm_persist": > 0 = the GEMM launches use at most this many workgroups, each walking several tiles (experiment)
   int gemm_wpc = 4;         // "direct_gemm_wpc": workgroups per CU the GEMM kernels are compiled for (3: F22 tile prefetched, 4: fetched in the epilogue)
   bool cons_checked = false; // the constraint list has not changed since direct_plan last looked (reset by tsl_contact_detect)

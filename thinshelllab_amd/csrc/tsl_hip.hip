@@ -413,6 +413,7 @@ extern "C" int tsl_set_param(tsl_ctx* c, const char* key, double v) {
   else if (k == "direct_prezero") c->ds.prezero = (int)v;
   else if (k == "direct_two_arenas") c->ds.two_arenas = (int)v;
   else if (k == "direct_gemm_persist") c->ds.gemm_persist = std::max(0, (int)v);
+  else if (k == "direct_flow") c->ds.flow = (int)v != 0;
   else if (k == "direct_clear_chunks") c->ds.clear_chunks = std::max(1, (int)v);
   else if (k == "direct_clear_wgs") c->ds.clear_wgs = std::max(1, (int)v);
   else if (k == "direct_par_batches") c->ds.par_batches = (int)v;
@@ -1166,6 +1167,17 @@ static int solve_perm(tsl_ctx* c, tsl_solve_stats* st) {
       } else rc_g = gmres(c, &sd, true);
       d.gm_cap = 0;
       if (rc_g) return -1;
+      if (sd.flag != 1 && d.flow && d.n_flow > 0) {   // a dataflow launch that lost a flag leaves garbage factors: say so, go back to the launch-per-block-step path
+        int ab = 0;
+        HIP_OK(hipMemcpy(&ab, d.bad.p + DS_FLOW_ABORT, sizeof(int), hipMemcpyDeviceToHost));
+        if (ab) {
+          fprintf(stderr, "[tsl] k_ds_gj_flow: a workgroup waited in vain for a flag (launch not resident as a whole?): \"direct_flow\" disabled for this context, refactorising\n");
+          d.flow = 0;
+          TSL_TRY(direct_factor(c));
+          sd = *st; c->last_xmax_valid = false;
+          TSL_TRY(gmres(c, &sd, true));
+        }
+      }
       if (stale) {
         d.n_stale++;
         if (sd.flag != 1 || sd.iters > (2 * d.lag) / 3) d.refactor_next = true;   // the next iteration starts from fresh factors
