@@ -267,6 +267,7 @@ def roofline(ctx, scene, elapsed, K, stats, args):
     """dominant kernel class of the sparse direct solve, measured live with HIP events (tsl_bench_direct), + section 8d's whole-step model"""
     names = {0: "k_ds_gj_step (+ k_ds_pivot0 / k_ds_gj_finish: blocked Gauss-Jordan inversion W = F11^-1 of every front of a batch, one launch per 32 pivots, f64 MFMA tiles)",
              3: "k_ds_inv_small (the same inversion of the leaf levels and small fronts: all block steps inside one launch, the pivot block in LDS)",
+             5: "k_ds_gj_flow (the same inversion of the batches of the upper tree levels as ONE persistent launch per batch: a workgroup keeps its 32 x 32 tile in registers over all block steps, steps ordered by point-to-point flags; bytes = the pivot blocks read and written once)",
              1: "k_ds_gemm[schur] (Schur complement S = F22 - F21 G of every front of a batch, K = pp GEMM on v_mfma_f64_16x16x4_f64, added into the parent fronts by the epilogue)",
              2: "k_ds_gemm[g] (G = W F12 of every front of a batch: K = pp GEMM on v_mfma_f64_16x16x4_f64)",
              4: "k_ds_gemv (level sweeps of one application of the factors: W, F21 upwards, G downwards)"}
@@ -293,7 +294,7 @@ def roofline(ctx, scene, elapsed, K, stats, args):
     # (scripts/gpu_profile.sh + install_profiles.py), labelled with the profile set and the commit it was taken on
     rf["traffic_source"] = None
     try:
-        key = {0: "k_ds_gj_step", 1: "k_ds_gemm1", 2: "k_ds_gemm0", 3: "k_ds_inv_small", 4: "k_ds_gemv"}[dom]
+        key = {0: "k_ds_gj_step", 1: "k_ds_gemm1", 2: "k_ds_gemm0", 3: "k_ds_inv_small", 4: "k_ds_gemv", 5: "k_ds_gj_flow"}[dom]
         path = os.path.join(ROOT, "profiles", f"latest_{args.workload.replace('-', '_')}_pmc_{key}.json")
         if os.path.exists(path) and args.grid == 224:
             with open(path) as fh:

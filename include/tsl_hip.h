@@ -121,6 +121,9 @@ int tsl_set_stream(tsl_ctx* ctx, void* hip_stream);
  * supernode of their separator), "direct_merge_sep" (separators of at most this many vertices join the enclosing separator's supernode; 16, 0 = off),
  * "direct_refine" (1: plain iterative refinement with the factors, GMRES only where it stalls; 0: flexible GMRES from the start),
  * "direct_plan_cache" (plans of earlier constraint sets kept, default 64; the reverse sweep finds the forward rollout's plans there),
+ * "direct_flow" (1: the block steps of a batch that is alone on its tree level, of at most 64 fronts and small enough to be resident as a
+ * whole, run as ONE persistent dataflow launch -- k_ds_gj_flow: every workgroup keeps its tile in registers, steps ordered by
+ * point-to-point flags; 3: also the batches the LDS kernel would take; 0: one launch per 32 pivots everywhere),
  * "direct_overlap" / "direct_overlap_cap" / "direct_overlap_fronts" (0: Schur tiles outside the parents' pivot blocks on a side stream from a capped
  * grid next to the next level's block steps -- an experiment, measured without gain), "tet_warm" (1: the eigen-clamp of the element blocks starts
  * from the eigenvectors of the element's previous assembly), "cloth_gather" (0; 1: cloth Hessian gathered per matrix block from element records
@@ -217,7 +220,8 @@ int tsl_bench_spmv(tsl_ctx* ctx, int variant, int reps, double* us_per_launch_ho
 /* Sparse direct path (multifrontal LU of the operator, the counterpart of the reference's spsolve, sparse_solver.py:85-105).
  * tsl_bench_direct: the launches of one kernel class of ONE factorisation (cls 0 the Gauss-Jordan inversions W = F11^-1 on the block-step
  * path: k_ds_pivot0 + k_ds_gj_step + k_ds_gj_finish; 1 k_ds_gemm in Schur mode with its extend-add; 2 k_ds_gemm in G = W F12 mode;
- * 3 the inversions in the LDS kernel k_ds_inv_small) or of one application (4 k_ds_gemv) on the current plan, replayed `reps` times between one hipEvent pair;
+ * 3 the inversions in the LDS kernel k_ds_inv_small; 5 the inversions in the persistent dataflow kernel k_ds_gj_flow) or of one application
+ * (4 k_ds_gemv) on the current plan, replayed `reps` times between one hipEvent pair;
  * out4 = {us per launch, algorithmic flops per launch, algorithmic bytes per launch, launches per factorisation}.  The factors are
  * invalid afterwards.  tsl_direct_info: {plans, factorisations, applications, perturbed pivots of the last factorisation, host
  * seconds in plan builds, supernodes, levels, batches, flops per factorisation, bytes of fronts}. */

@@ -25,21 +25,26 @@ for flow in (0, 1):
     print("flow", flow, {k: ss[k] for k in ("iters", "rel_residual", "flag", "method") if k in ss}, flush=True)
 print("max |x1 - x0| / max |x0| =", float((xs[1] - xs[0]).abs().max() / xs[0].abs().max()), flush=True)
 nb = int(ctx.direct_info()["batches"])
-tot = {0: 0.0, 1: 0.0}
+tot = {0: 0.0, 1: 0.0, 3: 0.0}
+def t_of(r): return r["us_per_launch"] * r["launches"]
 for bt in range(nb):
     ctx.set_param("ds_bench_batch", bt)
     ctx.set_param("direct_flow", 0)
-    r0 = ctx.bench_direct(0, 10)
-    ctx.set_param("direct_flow", 1)
-    r5 = ctx.bench_direct(5, 10); r0b = ctx.bench_direct(0, 10)
-    t0 = r0["us_per_launch"] * r0["launches"]; t5 = r5["us_per_launch"] * r5["launches"]; t0b = r0b["us_per_launch"] * r0b["launches"]
-    if r0["launches"] == 0: continue
-    tot[0] += t0; tot[1] += t5 + t0b
-    print(f"batch {bt:2d}: launch per block step {t0:7.1f} us ({r0['launches']:3d} launches)   dataflow {t5:7.1f} us ({r5['launches']} launch)" + (f" + {t0b:7.1f} us still on block steps" if r0b["launches"] else ""), flush=True)
-print("block-step class per factorisation:", tot)
+    r0 = ctx.bench_direct(0, 10); r3 = ctx.bench_direct(3, 10)
+    base = t_of(r0) + t_of(r3)
+    line = f"batch {bt:2d}: " + (f"launch per block step {t_of(r0):7.1f} us ({r0['launches']:3d} launches)" if r0["launches"] else f"LDS kernel            {t_of(r3):7.1f} us (  1 launch  )")
+    for flow in (1, 3):
+        ctx.set_param("direct_flow", flow)
+        r5 = ctx.bench_direct(5, 10)
+        t = t_of(r5) if r5["launches"] else base
+        tot[flow] += t
+        line += f"   direct_flow {flow}: " + (f"dataflow {t_of(r5):7.1f} us" if r5["launches"] else "unchanged        ")
+    tot[0] += base
+    print(line, flush=True)
+print("inversions per factorisation, us:", tot)
 ctx.set_param("ds_bench_batch", -1)
 # whole time steps with either
-for flow in (0, 1, 0, 1):
+for flow in (0, 1, 3, 0, 1, 3):
     ctx.set_param("direct_flow", flow)
     torch.cuda.synchronize(); t0 = time.time()
     for f in range(steps + 1, steps + 4):

@@ -243,7 +243,7 @@ class TslContext:
         return dict(ms_per_launch=ms.value, launches=n.value, bytes_per_launch=b.value, ms_per_launch_events=ev.value)
 
     def bench_direct(self, cls, reps=20):
-        """kernel class of the sparse direct path replayed back to back (0 Gauss-Jordan inversions on the block-step path, 1 Schur GEMM + extend-add, 2 G = W F12 GEMM, 3 inversions in the LDS kernel, 4 gemv sweeps of one application)"""
+        """kernel class of the sparse direct path replayed back to back (0 Gauss-Jordan inversions on the block-step path, 1 Schur GEMM + extend-add, 2 G = W F12 GEMM, 3 inversions in the LDS kernel, 4 gemv sweeps of one application, 5 inversions in the persistent dataflow kernel)"""
         out = (C.c_double * 4)()
         check(self.L.tsl_bench_direct(self.h, int(cls), int(reps), out), "tsl_bench_direct")
         return dict(us_per_launch=out[0], flops_per_launch=out[1], bytes_per_launch=out[2], launches=int(out[3]))

@@ -43,7 +43,8 @@ static void ds_launch_gemm(hipStream_t s, const DsDev& D, const DsBatch& b, int 
 // (no second persistent grid next to it), of at most DS_FLOW_MAXF fronts, whose tiles are all resident at once.  Fills the launch
 // arguments and grows the exchange buffers; false = the batch stays on the launch-per-block-step path.
 static int ds_flow_prepare(DirectSolver& d, const DirectPlan& P, const DsBatch& b, bool alone, DsFlowArgs& a) {   // -> workgroups per CU of the instantiation to launch (4 / 5), 0 = not on this path
-  if (!d.flow || !alone || ds_use_small(b) || b.count > DS_FLOW_MAXF) return 0;
+  if (!d.flow || !alone || b.count > DS_FLOW_MAXF || b.max_pp < 2 * DS_T) return 0;
+  if (ds_use_small(b) && !(d.flow & 2)) return 0;   // bit 1: also the batches the LDS kernel would take (64 / 32 fronts of <= 128 pivots on levels 3 and 4 of cfg4)
   if (d.flow_cap[0] == 0) {
     int occ4 = 0, occ5 = 0, dev = 0;
     hipDeviceProp_t prop;
@@ -302,8 +303,8 @@ static int direct_factor(tsl_ctx* c, int stop_sn = -1, const char* dump_path = n
     const int lv0 = b.first, nf = b.count;
     const int tp = b.max_pp / DS_T, tb = b.max_bp / DS_T;
     DsFlowArgs fa;
-    if (ds_use_small(b)) hipLaunchKernelGGL(k_ds_inv_small, dim3(nf), dim3(256), ds_small_lds(b.max_pp), bs, D, lv0, b.max_pp + 1);
-    else if (const int wpc = ds_flow_prepare(d, P, b, alone, fa)) { ds_flow_launch(bs, D, lv0, fa, wpc, d); d.n_flow++; }
+    if (const int wpc = ds_flow_prepare(d, P, b, alone, fa)) { ds_flow_launch(bs, D, lv0, fa, wpc, d); d.n_flow++; }
+    else if (ds_use_small(b)) hipLaunchKernelGGL(k_ds_inv_small, dim3(nf), dim3(256), ds_small_lds(b.max_pp), bs, D, lv0, b.max_pp + 1);
     else {
       hipLaunchKernelGGL(k_ds_pivot0, dim3(nf), dim3(256), 0, bs, D, lv0);
       for (int k = 0; k < tp; k++) { const int na = P.act_n[b.act_off + k]; hipLaunchKernelGGL(k_ds_gj_step, dim3(na + na * tp * tp), dim3(256), 0, bs, D, lv0, k, tp, na); }   // fronts are sorted by pp: the active ones are a prefix
@@ -470,12 +471,12 @@ static int direct_bench(tsl_ctx* c, int cls, int reps, double* out) {
       const int lv0 = b.first, nf = b.count;
       const int tp = b.max_pp / DS_T, tb = b.max_bp / DS_T;
       if (cls == 0 || cls == 3 || cls == 5) {   // W = F11^-1: cls 0 the batches on the block-step path (pivot0 + block steps + finish), cls 3 the batches in the LDS kernel, cls 5 those in the dataflow kernel
-        if (ds_use_small(b) != (cls == 3)) continue;
         bool alone = true;
         for (size_t q = 0; q < P.batches.size(); q++) alone &= ((int)q == bi || P.batches[q].level != b.level);
         DsFlowArgs fa;
-        const int flow = cls != 3 ? ds_flow_prepare(d, P, b, alone, fa) : 0;
-        if ((flow != 0) != (cls == 5) && cls != 3) continue;
+        const int flow = ds_flow_prepare(d, P, b, alone, fa);
+        const int mine = flow ? 5 : (ds_use_small(b) ? 3 : 0);   // the class direct_factor runs this batch in
+        if (mine != cls) continue;
         if (cls == 5) { ds_flow_launch(s, D, lv0, fa, flow, d); if (count) launches++; }
         else if (cls == 3) { hipLaunchKernelGGL(k_ds_inv_small, dim3(nf), dim3(256), ds_small_lds(b.max_pp), s, D, lv0, b.max_pp + 1); if (count) launches++; }
         else {

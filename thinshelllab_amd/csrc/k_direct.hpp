@@ -492,7 +492,7 @@ __global__ void __launch_bounds__(256) k_ds_gj_finish(DsDev D, int lv0) {
 //   * nobody but the owner reads the front itself, so the result goes back in place at the end.
 // The launch must be resident as a whole (the host checks tiles <= CUs x occupancy and runs it only for a batch alone on its level);
 // a flag that does not come within DS_FLOW_SPINS polls raises bad[DS_FLOW_ABORT] and lets every workgroup run out (the host reports it).
-#define DS_FLOW_MAXF 16
+#define DS_FLOW_MAXF 64
 #define DS_FLOW_ABORT 5
 #define DS_FLOW_SPINS (1 << 22)
 struct DsFlowArgs {
@@ -531,7 +531,7 @@ __global__ void __launch_bounds__(256, WPC) k_ds_gj_flow(DsDev D, int lv0, DsFlo
   __shared__ int s_dead;
   const int L = blockIdx.x;
   int z = 0;
-  while (z + 1 < a.nf && L >= a.tile0[z + 1]) z++;
+  for (int step = DS_FLOW_MAXF / 2; step > 0; step >>= 1) { const int q = z + step; if (q < a.nf && L >= a.tile0[q]) z = q; }   // last front with tile0 <= L
   const int sn = D.level_sn[lv0 + z];
   const DsFrontDesc f = D.fr[sn];
   const int nt = f.pp / DS_T, t = L - a.tile0[z], bi = t / nt, bj = t - bi * nt;

@@ -413,7 +413,7 @@ extern "C" int tsl_set_param(tsl_ctx* c, const char* key, double v) {
   else if (k == "direct_prezero") c->ds.prezero = (int)v;
   else if (k == "direct_two_arenas") c->ds.two_arenas = (int)v;
   else if (k == "direct_gemm_persist") c->ds.gemm_persist = std::max(0, (int)v);
-  else if (k == "direct_flow") c->ds.flow = (int)v != 0;
+  else if (k == "direct_flow") c->ds.flow = std::max(0, (int)v);
   else if (k == "direct_clear_chunks") c->ds.clear_chunks = std::max(1, (int)v);
   else if (k == "direct_clear_wgs") c->ds.clear_wgs = std::max(1, (int)v);
   else if (k == "direct_par_batches") c->ds.par_batches = (int)v;
