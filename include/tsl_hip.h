@@ -124,6 +124,7 @@ int tsl_set_stream(tsl_ctx* ctx, void* hip_stream);
  * "direct_flow" (1: the block steps of a batch that is alone on its tree level, of at most 64 fronts and small enough to be resident as a
  * whole, run as ONE persistent dataflow launch -- k_ds_gj_flow: every workgroup keeps its tile in registers, steps ordered by
  * point-to-point flags; 3: also the batches the LDS kernel would take; 0: one launch per 32 pivots everywhere),
+ * "direct_sweep_flow" (0; L0 > 0: the sweeps of one application for the tree levels >= L0 as one launch with chained phases -- an experiment, measured slower),
  * "direct_overlap" / "direct_overlap_cap" / "direct_overlap_fronts" (0: Schur tiles outside the parents' pivot blocks on a side stream from a capped
  * grid next to the next level's block steps -- an experiment, measured without gain), "tet_warm" (1: the eigen-clamp of the element blocks starts
  * from the eigenvectors of the element's previous assembly), "cloth_gather" (0; 1: cloth Hessian gathered per matrix block from element records

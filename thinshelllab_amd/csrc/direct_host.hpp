@@ -412,12 +412,47 @@ static int direct_apply(tsl_ctx* c, const double* r, double* z) {
   const DsDev D = ds_dev(c);
   const size_t n3 = 3 * (size_t)c->NV;
   HIP_OK(hipMemcpyAsync(d.w.p, r, n3 * sizeof(double), hipMemcpyDeviceToDevice, s));
-  for (int l = 0; l < P.n_levels; l++) {
+  // "direct_sweep_flow" = L0 > 0: the sweeps of the levels >= L0 (latency-bound: 1 - 132 fronts each) are ONE launch (k_ds_sweep_flow)
+  const int L0 = (d.sweep_flow > 0 && d.sweep_flow < P.n_levels - 1 && 3 * (P.n_levels - d.sweep_flow) <= DS_SWEEP_MAXP) ? d.sweep_flow : P.n_levels;
+  for (int l = 0; l < L0; l++) {
     const int o0 = P.wl_own_ptr[l], b0 = P.wl_bnd_ptr[l], o1 = P.wl_own_ptr[l + 1];
     hipLaunchKernelGGL(k_ds_gemv, dim3(b0 - o0), dim3(256), 0, s, D, d.wl_front.p, d.wl_row.p, o0, 0, (const double*)d.w.p, z);
     if (o1 > b0) hipLaunchKernelGGL(k_ds_gemv, dim3(o1 - b0), dim3(256), 0, s, D, d.wl_front.p, d.wl_row.p, b0, 1, (const double*)z, d.w.p);
   }
-  for (int l = P.n_levels - 2; l >= 0; l--) {   // the top level has no boundary
+  if (L0 < P.n_levels) {
+    DirectPlan& Pm = d.plan;
+    if (Pm.sweep_cache_L0 != L0) {   // phase table of this plan: {np, start[np + 1], wl0[np], mode[np], nfront[np]}
+      std::vector<int> st{0}, w0, md, nf;
+      auto phase = [&](int a0, int a1, int mode) {
+        int fronts = 0;
+        for (int e = a0; e < a1; e++) fronts += P.wl_row[e] == 0;
+        w0.push_back(a0); md.push_back(mode); nf.push_back(fronts); st.push_back(st.back() + (a1 - a0));
+      };
+      for (int l = L0; l < P.n_levels; l++) {
+        const int o0 = P.wl_own_ptr[l], b0 = P.wl_bnd_ptr[l], o1 = P.wl_own_ptr[l + 1];
+        phase(o0, b0, 0);
+        if (o1 > b0) phase(b0, o1, 1);
+      }
+      for (int l = P.n_levels - 2; l >= L0; l--) phase(P.wl_own_ptr[l], P.wl_bnd_ptr[l], 2);
+      Pm.sweep_cache.clear();
+      Pm.sweep_cache.push_back((int)w0.size());
+      for (const std::vector<int>* v : {&st, &w0, &md, &nf}) Pm.sweep_cache.insert(Pm.sweep_cache.end(), v->begin(), v->end());
+      Pm.sweep_cache_L0 = L0;
+    }
+    DsSweepArgs a;
+    const int* q = Pm.sweep_cache.data();
+    a.np = *q++;
+    for (int i = 0; i <= a.np; i++) a.start[i] = *q++;
+    for (int i = 0; i < a.np; i++) a.wl0[i] = *q++;
+    for (int i = 0; i < a.np; i++) a.mode[i] = *q++;
+    for (int i = 0; i < a.np; i++) a.nfront[i] = *q++;
+    const size_t ncnt = (size_t)a.np * P.sym.n_sn + 32 * (size_t)a.np;
+    if (d.sweep_cnt.n < ncnt) { if (d.sweep_cnt.alloc(ncnt + ncnt / 4)) return -1; }
+    HIP_OK(hipMemsetAsync(d.sweep_cnt.p, 0, ncnt * sizeof(int), s));
+    hipLaunchKernelGGL(k_ds_sweep_flow, dim3(a.start[a.np]), dim3(256), 0, s, D, d.wl_front.p, d.wl_row.p, a, d.sweep_cnt.p + 32 * (size_t)a.np, d.sweep_cnt.p, P.sym.n_sn, d.w.p, z);
+    d.n_sweep_flow++;
+  }
+  for (int l = std::min(P.n_levels - 2, L0 - 1); l >= 0; l--) {   // the top level has no boundary
     const int o0 = P.wl_own_ptr[l], b0 = P.wl_bnd_ptr[l];
     hipLaunchKernelGGL(k_ds_gemv, dim3(b0 - o0), dim3(256), 0, s, D, d.wl_front.p, d.wl_row.p, o0, 2, (const double*)z, z);
   }
@@ -449,19 +484,15 @@ static int direct_bench(tsl_ctx* c, int cls, int reps, double* out) {
   double flops = 0, bytes = 0;
   long launches = 0;
   auto issue = [&](bool count) {
-    if (cls == 4) {
-      for (int l = 0; l < P.n_levels; l++) {
-        const int o0 = P.wl_own_ptr[l], b0 = P.wl_bnd_ptr[l], o1 = P.wl_own_ptr[l + 1];
-        hipLaunchKernelGGL(k_ds_gemv, dim3(b0 - o0), dim3(256), 0, s, D, d.wl_front.p, d.wl_row.p, o0, 0, (const double*)d.w.p, c->v_t4.p);
-        if (o1 > b0) hipLaunchKernelGGL(k_ds_gemv, dim3(o1 - b0), dim3(256), 0, s, D, d.wl_front.p, d.wl_row.p, b0, 1, (const double*)c->v_t4.p, d.w.p);
-        if (count) launches += 1 + (o1 > b0);
+    if (cls == 4) {   // one application as direct_apply issues it (the right-hand side copy included)
+      (void)direct_apply(c, c->v_b.p, c->v_t4.p);
+      d.n_apply--;
+      if (count) {
+        const int L0 = (d.sweep_flow > 0 && d.sweep_flow < P.n_levels - 1 && 3 * (P.n_levels - d.sweep_flow) <= DS_SWEEP_MAXP) ? d.sweep_flow : P.n_levels;
+        for (int l = 0; l < L0; l++) launches += 1 + (P.wl_own_ptr[l + 1] > P.wl_bnd_ptr[l]) + (l < P.n_levels - 1);
+        if (L0 < P.n_levels) launches++;
+        for (const DsFrontDesc& f : P.fr) { bytes += 8.0 * ((double)f.p * f.p + 2.0 * (double)f.p * f.b); flops += 2.0 * ((double)f.p * f.p + 2.0 * (double)f.p * f.b); }
       }
-      for (int l = P.n_levels - 2; l >= 0; l--) {
-        const int o0 = P.wl_own_ptr[l], b0 = P.wl_bnd_ptr[l];
-        hipLaunchKernelGGL(k_ds_gemv, dim3(b0 - o0), dim3(256), 0, s, D, d.wl_front.p, d.wl_row.p, o0, 2, (const double*)c->v_t4.p, c->v_t4.p);
-        if (count) launches++;
-      }
-      if (count) for (const DsFrontDesc& f : P.fr) { bytes += 8.0 * ((double)f.p * f.p + 2.0 * (double)f.p * f.b); flops += 2.0 * ((double)f.p * f.p + 2.0 * (double)f.p * f.b); }
       return;
     }
     int bi = -1;

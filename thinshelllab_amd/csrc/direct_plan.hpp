@@ -69,6 +69,7 @@ struct DirectPlan {
   std::vector<DsBatch> batches;                  // in level order
   std::vector<int> act_n, act_ld;
   // solve work lists: (front, first row) of every 16-row chunk of the own rows / boundary rows, level after level
+  std::vector<int> sweep_cache; int sweep_cache_L0 = -1;   // phase table of the one-launch sweeps of levels >= sweep_cache_L0 (filled by direct_apply, dropped by build)
   std::vector<int> wl_front, wl_row, wl_own_ptr, wl_bnd_ptr;   // own chunks of level l: [wl_own_ptr[l], wl_bnd_ptr[l]); boundary chunks: [wl_bnd_ptr[l], wl_own_ptr[l + 1])
   int n_levels = 0;
   long long arena = 0;      // doubles
@@ -171,6 +172,7 @@ struct DirectPlan {
     level_ptr.assign(L + 1, 0); level_sn.clear();
     batches.clear(); act_n.clear(); act_ld.clear();
     wl_front.clear(); wl_row.clear(); wl_own_ptr.assign(L + 1, 0); wl_bnd_ptr.assign(L, 0);
+    sweep_cache_L0 = -1;
     scratch = 0;
     // a new batch starts where the pivot block falls below a quarter of the batch's largest (empty workgroups of the smaller
     // fronts are cheap, an extra batch costs its block steps in sequence); on a level with hundreds of fronts a batch of 32 or

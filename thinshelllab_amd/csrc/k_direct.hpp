@@ -891,11 +891,13 @@ __global__ void __launch_bounds__(256, WPC) k_ds_gemm_capped(DsDev D, int lv0, i
 //   mode 1 (up, F21):  w[bnd i] -= sum_j F21[i, j] t[own j]          (atomic: sibling fronts share boundary vertices)
 //   mode 2 (down, G):  x[own i]  = t[own i] - sum_j G[i, j] x[bnd j]  (x and t may alias)
 #define DS_VCHUNK 2048
-__global__ void __launch_bounds__(256) k_ds_gemv(DsDev D, const int* __restrict__ wl_front, const int* __restrict__ wl_row, int wl0, int mode, const double* vin, double* vout) {
-  __shared__ double xs[DS_VCHUNK];
-  const DsFrontDesc f = D.fr[wl_front[wl0 + blockIdx.x]];
+// one chunk of 16 rows of one front in one mode of the level sweeps: 0  z_own = W w_own;  1  w_bnd -= F21 z_own (atomic: several fronts
+// share a boundary dof);  2  z_own -= G z_bnd.  FLOW: the vectors are exchanged between workgroups of ONE launch (k_ds_sweep_flow):
+// agent-scope loads and write-through stores instead of cached ones.
+template <bool FLOW>
+TSL_DEV void ds_gemv_chunk(const DsDev& D, int sn, int r0, int mode, const double* vin, double* vout, double* xs) {
+  const DsFrontDesc f = D.fr[sn];
   const int nrows = mode == 1 ? f.b : f.p, ncols = mode == 2 ? f.b : f.p;
-  const int r0 = wl_row[wl0 + blockIdx.x];
   const int* vt = D.vtx + f.vtx_off;
   const int in_v0 = mode == 2 ? f.nv_own : 0, out_v0 = mode == 1 ? f.nv_own : 0;
   const double* M = mode == 2 ? D.G + f.goff : D.A + f.off + (mode == 1 ? (size_t)f.pp * f.ld : 0);
@@ -912,7 +914,11 @@ __global__ void __launch_bounds__(256) k_ds_gemv(DsDev D, const int* __restrict_
   for (int c0 = 0; c0 < ncols; c0 += DS_VCHUNK) {
     const int cn = min(DS_VCHUNK, ncols - c0);
     __syncthreads();
-    for (int j = threadIdx.x; j < cn; j += 256) { const int jj = c0 + j; xs[j] = vin[3 * (size_t)vt[in_v0 + jj / 3] + jj % 3]; }
+    for (int j = threadIdx.x; j < cn; j += 256) {
+      const int jj = c0 + j;
+      const double* src = &vin[3 * (size_t)vt[in_v0 + jj / 3] + jj % 3];
+      xs[j] = FLOW ? __hip_atomic_load(src, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : *src;
+    }
     __syncthreads();
 #pragma unroll 4
     for (int j = lane; j < cn; j += 64) {
@@ -926,9 +932,57 @@ __global__ void __launch_bounds__(256) k_ds_gemv(DsDev D, const int* __restrict_
     const double a = wave_sum(acc[q]);
     if (lane == 0 && i < nrows) {
       const size_t o = 3 * (size_t)vt[out_v0 + i / 3] + i % 3;
-      if (mode == 0) vout[o] = a;
-      else if (mode == 1) atomicAdd(&vout[o], -a);
-      else vout[o] = vout[o] - a;
+      if (mode == 1) atomicAdd(&vout[o], -a);
+      else if (!FLOW) vout[o] = mode == 0 ? a : vout[o] - a;
+      else {
+        const double v = mode == 0 ? a : __hip_atomic_load(&vout[o], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) - a;
+        __hip_atomic_store(&vout[o], v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      }
     }
+  }
+}
+__global__ void __launch_bounds__(256) k_ds_gemv(DsDev D, const int* __restrict__ wl_front, const int* __restrict__ wl_row, int wl0, int mode, const double* vin, double* vout) {
+  __shared__ double xs[DS_VCHUNK];
+  ds_gemv_chunk<false>(D, wl_front[wl0 + blockIdx.x], wl_row[wl0 + blockIdx.x], mode, vin, vout, xs);
+}
+
+// The sweeps of the upper tree levels ("direct_sweep_flow" = first level) as ONE launch: the chunks of every phase -- level l upwards
+// in modes 0 and 1, then downwards in mode 2 -- in dependency order in one grid; a workgroup waits until the phase before its own is
+// complete.  Workgroups are dispatched in index order, so whatever a workgroup waits for is resident or done (no residency
+// condition, unlike k_ds_gj_flow).  Completion: the workgroup's stores and atomics are acknowledged (vmcnt(0)), then it takes a ticket
+// of its front's counter; the last of a front raises the phase counter (two levels: no counter sees more than ~130 arrivals).
+// The launches these phases replace take 7-15 us each with 1 - 132 fronts per level.
+#define DS_SWEEP_MAXP 40
+#define DS_SWEEP_ABORT 6
+struct DsSweepArgs {
+  int np;
+  int start[DS_SWEEP_MAXP + 1];   // first workgroup of phase p
+  int wl0[DS_SWEEP_MAXP];         // its first work-list entry
+  int mode[DS_SWEEP_MAXP];
+  int nfront[DS_SWEEP_MAXP];      // fronts with chunks in the phase (arrivals at the phase counter)
+};
+__global__ void __launch_bounds__(256) k_ds_sweep_flow(DsDev D, const int* __restrict__ wl_front, const int* __restrict__ wl_row, DsSweepArgs a, int* __restrict__ fcnt,
+                                                       int* __restrict__ pcnt, int n_sn, double* w, double* z) {
+  __shared__ double xs[DS_VCHUNK];
+  __shared__ int s_dead;
+  const int L = blockIdx.x;
+  int p = 0;
+  for (int step = 32; step > 0; step >>= 1) { const int q = p + step; if (q < a.np && L >= a.start[q]) p = q; }
+  const int mode = a.mode[p], e = a.wl0[p] + (L - a.start[p]);
+  const int sn = wl_front[e], r0 = wl_row[e];
+  if (threadIdx.x == 0) {
+    s_dead = 0;
+    if (p > 0) ds_flow_poll(pcnt + 32 * (p - 1), a.nfront[p - 1], D.bad + DS_SWEEP_ABORT, &s_dead);
+  }
+  __syncthreads();
+  if (!s_dead) ds_gemv_chunk<true>(D, sn, r0, mode, mode == 0 ? w : z, mode == 1 ? w : z, xs);
+  __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+  __builtin_amdgcn_s_waitcnt(0);
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    const DsFrontDesc f = D.fr[sn];
+    const int nwg = ((mode == 1 ? f.b : f.p) + 15) / 16;
+    const int ticket = __hip_atomic_fetch_add(fcnt + (size_t)p * n_sn + sn, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    if (ticket == nwg - 1) __hip_atomic_fetch_add(pcnt + 32 * p, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
   }
 }

@@ -143,6 +143,13 @@ struct DirectSolver {
   long n_flow = 0;
   DevBuf<double> flow_x;    // exchange slots (pivot inverses, row / column panel tiles)
   DevBuf<int> flow_f;       // their flags (epoch of the launch that published the slot)
+  // "direct_sweep_flow" = L0 > 0 (experiment, off): the sweeps of the tree levels >= L0 inside ONE launch (k_ds_sweep_flow), phases chained by
+  // ticket counters.  Measured on cfg4 (scripts/exp_sweep.py): one application 404 us in 28 launches against 572 / 511 / 478 / 454 / 427 us
+  // with L0 = 1 .. 5, same answer -- a phase hop (stores acknowledged, ticket with return, phase counter, poll, uncached vector loads)
+  // costs more than the 7-14 us launches of the upper levels, unlike the Gauss-Jordan chain where the tile stays in registers
+  int sweep_flow = 0;
+  long n_sweep_flow = 0;
+  DevBuf<int> sweep_cnt;    // its phase counters (one per 128 B) and per-front tickets, cleared per application
   int gemm_persist = 0;     // "direct_gemm_persist": > 0 = the GEMM launches use at most this many workgroups, each walking several tiles (experiment)
   int gemm_wpc = 4;         // "direct_gemm_wpc": workgroups per CU the GEMM kernels are compiled for (3: F22 tile prefetched, 4: fetched in the epilogue)
   bool cons_checked = false; // the constraint list has not changed since direct_plan last looked (reset by tsl_contact_detect)

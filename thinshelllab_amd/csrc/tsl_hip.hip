@@ -414,6 +414,7 @@ extern "C" int tsl_set_param(tsl_ctx* c, const char* key, double v) {
   else if (k == "direct_two_arenas") c->ds.two_arenas = (int)v;
   else if (k == "direct_gemm_persist") c->ds.gemm_persist = std::max(0, (int)v);
   else if (k == "direct_flow") c->ds.flow = std::max(0, (int)v);
+  else if (k == "direct_sweep_flow") c->ds.sweep_flow = std::max(0, (int)v);
   else if (k == "direct_clear_chunks") c->ds.clear_chunks = std::max(1, (int)v);
   else if (k == "direct_clear_wgs") c->ds.clear_wgs = std::max(1, (int)v);
   else if (k == "direct_par_batches") c->ds.par_batches = (int)v;
@@ -1167,6 +1168,17 @@ static int solve_perm(tsl_ctx* c, tsl_solve_stats* st) {
       } else rc_g = gmres(c, &sd, true);
       d.gm_cap = 0;
       if (rc_g) return -1;
+      if (sd.flag != 1 && d.sweep_flow && d.n_sweep_flow > 0) {
+        int ab = 0;
+        HIP_OK(hipMemcpy(&ab, d.bad.p + DS_SWEEP_ABORT, sizeof(int), hipMemcpyDeviceToHost));
+        if (ab) {
+          fprintf(stderr, "[tsl] k_ds_sweep_flow: a workgroup waited in vain for the phase before it: \"direct_sweep_flow\" disabled for this context, solving again\n");
+          d.sweep_flow = 0;
+          TSL_TRY(direct_factor(c));
+          sd = *st; c->last_xmax_valid = false;
+          TSL_TRY(gmres(c, &sd, true));
+        }
+      }
       if (sd.flag != 1 && d.flow && d.n_flow > 0) {   // a dataflow launch that lost a flag leaves garbage factors: say so, go back to the launch-per-block-step path
         int ab = 0;
         HIP_OK(hipMemcpy(&ab, d.bad.p + DS_FLOW_ABORT, sizeof(int), hipMemcpyDeviceToHost));
