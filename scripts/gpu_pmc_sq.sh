@@ -5,7 +5,7 @@ cd $GRAFT_REPO_ROOT
 export TMPDIR=/tmp
 TAG=${1:-r03}
 mkdir -p gpurun_out/prof
-for KRN in "k_ds_gemm<1" "k_ds_gemm<0" "k_ds_gj_step"; do
+for KRN in "k_ds_gemm<1" "k_ds_gemm<0" "k_ds_gj_step" "k_ds_gj_flow"; do
   KN=$(echo $KRN | tr -d '<>')
   rocprofv3 --pmc SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_VALU_MFMA_BUSY_CYCLES SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE \
     --kernel-include-regex "$KRN" --output-format csv -d gpurun_out/prof -o ${TAG}_sq_${KN} -- python bench.py --steps 3 --warmup 1 --no-cpu-baseline > gpurun_out/prof/${TAG}_sq_stdout.log 2>&1
