@@ -121,9 +121,9 @@ int tsl_set_stream(tsl_ctx* ctx, void* hip_stream);
  * supernode of their separator), "direct_merge_sep" (separators of at most this many vertices join the enclosing separator's supernode; 16, 0 = off),
  * "direct_refine" (1: plain iterative refinement with the factors, GMRES only where it stalls; 0: flexible GMRES from the start),
  * "direct_plan_cache" (plans of earlier constraint sets kept, default 64; the reverse sweep finds the forward rollout's plans there),
- * "direct_flow" (1: the block steps of a batch that is alone on its tree level, of at most 64 fronts and small enough to be resident as a
+ * "direct_flow" (3; bit 0: the block steps of a batch that is alone on its tree level, of at most 64 fronts and small enough to be resident as a
  * whole, run as ONE persistent dataflow launch -- k_ds_gj_flow: every workgroup keeps its tile in registers, steps ordered by
- * point-to-point flags; 3: also the batches the LDS kernel would take; 0: one launch per 32 pivots everywhere),
+ * point-to-point flags; bit 1: also the batches the LDS kernel would take; 0: one launch per 32 pivots everywhere),
  * "direct_sweep_flow" (0; L0 > 0: the sweeps of one application for the tree levels >= L0 as one launch with chained phases -- an experiment, measured slower),
  * "direct_overlap" / "direct_overlap_cap" / "direct_overlap_fronts" (0: Schur tiles outside the parents' pivot blocks on a side stream from a capped
  * grid next to the next level's block steps -- an experiment, measured without gain), "tet_warm" (1: the eigen-clamp of the element blocks starts

@@ -57,6 +57,50 @@ def test_direct_deferred_schur_tiles_agree():
     assert rel_err(x.cpu().numpy(), xs) < 1e-9
 
 
+def test_direct_dataflow_chains_agree_with_block_step_launches():
+    """"direct_flow": the Gauss-Jordan chains of the batches that are alone on their tree level as ONE persistent launch each
+    (k_ds_gj_flow: tiles in registers, block steps ordered by point-to-point flags) -- the same factors as one launch per 32 pivots,
+    on a plan whose upper levels have several fronts per batch (160 x 96 drape, leaves of 16 vertices), against scipy's LU; the
+    class replay must show that the dataflow path is the one that ran"""
+    import scipy.sparse.linalg as spl
+    s = _drape(160, 96, 5e-5, seed=5)
+    ctx = s._ensure_ctx()
+    ctx.set_param("direct", 1); ctx.set_param("direct_leaf", 16)
+    s.compute_residual_and_Hessian(spd=True)
+    b = s.F.to_torch().clone()
+    xs = spl.splu(ctx.operator_csr().tocsc()).solve(b.cpu().numpy())
+    sols = {}
+    for flow in (0, 1, 3):
+        ctx.set_param("direct_flow", flow)
+        s.compute_residual_and_Hessian(spd=True)      # fresh factors on the selected path
+        for rep in range(3):                          # the flags carry the launch epoch: repeated factorisations reuse every slot
+            x, st = ctx.solve(b.clone())
+            assert st["flag"] == 0 and st["method"] == 4 and st["iters"] <= 3, (flow, st)
+            assert rel_err(x.cpu().numpy(), xs) < 1e-9
+            s.compute_residual_and_Hessian(spd=True)
+        sols[flow] = x.cpu().numpy()
+        launches = ctx.bench_direct(5, 2)["launches"]
+        x, st = ctx.solve(b.clone())                  # (the replays invalidate the factors)
+        assert (launches > 0) == (flow > 0), (flow, launches)
+    assert rel_err(sols[1], sols[0]) < 1e-10 and rel_err(sols[3], sols[0]) < 1e-10
+
+
+def test_direct_one_launch_sweeps_agree():
+    """"direct_sweep_flow" (an experiment kept behind its flag, measured slower): the level sweeps of the upper levels inside one
+    launch with chained phases give the same solution"""
+    s = _drape(96, 64, 5e-5, seed=4)
+    ctx = s._ensure_ctx()
+    ctx.set_param("direct", 1); ctx.set_param("direct_leaf", 16)
+    s.compute_residual_and_Hessian(spd=True)
+    b = s.F.to_torch().clone()
+    x0, st0 = ctx.solve(b.clone())
+    for L0 in (1, 3):
+        ctx.set_param("direct_sweep_flow", L0)
+        x, st = ctx.solve(b.clone())
+        assert st["flag"] == 0 and st["iters"] == st0["iters"], (L0, st, st0)
+        assert rel_err(x.cpu().numpy(), x0.cpu().numpy()) < 1e-10
+
+
 @pytest.mark.parametrize("wpc", [3, 4])
 def test_direct_gemm_occupancy_variants_agree(wpc):
     """k_ds_gemm is compiled for three (F22 tile prefetched) and four (fetched in the epilogue) workgroups per CU

@@ -42,7 +42,7 @@ static void ds_launch_gemm(hipStream_t s, const DsDev& D, const DsBatch& b, int 
 // "direct_flow": the block steps of a batch as ONE persistent dataflow launch (k_ds_gj_flow) -- for a batch that is alone on its level
 // (no second persistent grid next to it), of at most DS_FLOW_MAXF fronts, whose tiles are all resident at once.  Fills the launch
 // arguments and grows the exchange buffers; false = the batch stays on the launch-per-block-step path.
-static int ds_flow_prepare(DirectSolver& d, const DirectPlan& P, const DsBatch& b, bool alone, DsFlowArgs& a) {   // -> workgroups per CU of the instantiation to launch (4 / 5), 0 = not on this path
+static int ds_flow_prepare(DirectSolver& d, const DirectPlan& P, const DsBatch& b, bool alone, DsFlowArgs& a, hipStream_t s) {   // -> workgroups per CU of the instantiation to launch (4 / 5), 0 = not on this path
   if (!d.flow || !alone || b.count > DS_FLOW_MAXF || b.max_pp < 2 * DS_T) return 0;
   if (ds_use_small(b) && !(d.flow & 2)) return 0;   // bit 1: also the batches the LDS kernel would take (64 / 32 fronts of <= 128 pivots on levels 3 and 4 of cfg4)
   if (d.flow_cap[0] == 0) {
@@ -66,8 +66,9 @@ static int ds_flow_prepare(DirectSolver& d, const DirectPlan& P, const DsBatch& 
   if (d.flow_x.n < (size_t)x) { if (d.flow_x.alloc((size_t)x)) return 0; }
   if (d.flow_f.n < (size_t)fl) {   // flags start below every epoch
     if (d.flow_f.alloc((size_t)fl + 1024)) return 0;
-    if (hipMemset(d.flow_f.p, 0, d.flow_f.n * sizeof(int)) != hipSuccess) return 0;
-    d.flow_epoch = 0;
+    // on the stream of the launch: a hipMemset on the null stream is not ordered against a non-blocking stream (seen once: the
+    // first launch of a fresh context started before the clear had run and lost its flags)
+    if (hipMemsetAsync(d.flow_f.p, 0, d.flow_f.n * sizeof(int), s) != hipSuccess) return 0;   // (the epoch keeps counting: zero is below every epoch)
   }
   a.epoch = ++d.flow_epoch;
   return tiles <= d.flow_cap[0] ? 4 : 5;   // the fifth workgroup per CU costs 15 spilled registers: only for a root beyond 1024 tiles
@@ -303,7 +304,7 @@ static int direct_factor(tsl_ctx* c, int stop_sn = -1, const char* dump_path = n
     const int lv0 = b.first, nf = b.count;
     const int tp = b.max_pp / DS_T, tb = b.max_bp / DS_T;
     DsFlowArgs fa;
-    if (const int wpc = ds_flow_prepare(d, P, b, alone, fa)) { ds_flow_launch(bs, D, lv0, fa, wpc, d); d.n_flow++; }
+    if (const int wpc = ds_flow_prepare(d, P, b, alone, fa, bs)) { ds_flow_launch(bs, D, lv0, fa, wpc, d); d.n_flow++; }
     else if (ds_use_small(b)) hipLaunchKernelGGL(k_ds_inv_small, dim3(nf), dim3(256), ds_small_lds(b.max_pp), bs, D, lv0, b.max_pp + 1);
     else {
       hipLaunchKernelGGL(k_ds_pivot0, dim3(nf), dim3(256), 0, bs, D, lv0);
@@ -505,7 +506,7 @@ static int direct_bench(tsl_ctx* c, int cls, int reps, double* out) {
         bool alone = true;
         for (size_t q = 0; q < P.batches.size(); q++) alone &= ((int)q == bi || P.batches[q].level != b.level);
         DsFlowArgs fa;
-        const int flow = ds_flow_prepare(d, P, b, alone, fa);
+        const int flow = ds_flow_prepare(d, P, b, alone, fa, s);
         const int mine = flow ? 5 : (ds_use_small(b) ? 3 : 0);   // the class direct_factor runs this batch in
         if (mine != cls) continue;
         if (cls == 5) { ds_flow_launch(s, D, lv0, fa, flow, d); if (count) launches++; }

@@ -501,9 +501,12 @@ struct DsFlowArgs {
   int foff[DS_FLOW_MAXF];          // first flag of front z: nt pivot flags (one per 128 B), nt^2 row-panel flags, nt^2 column-panel flags
   long long xoff[DS_FLOW_MAXF];    // first exchange slot of front z (doubles): nt pivot inverses, nt^2 row-panel slots, nt^2 column-panel slots
 };
+template <bool EXACT = false>   // EXACT: a flag is raised once per launch to the launch's epoch (a stale or foreign value never passes); otherwise a counter reaching its target
 TSL_DEV void ds_flow_poll(const int* flag, int epoch, int* abort_w, int* s_dead) {
   int spins = 0;
-  while (__hip_atomic_load(flag, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < epoch) {
+  for (;;) {
+    const int v = __hip_atomic_load(flag, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    if (EXACT ? v == epoch : v >= epoch) break;
     if (++spins >= DS_FLOW_SPINS) { __hip_atomic_store(abort_w, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); *s_dead = 1; return; }
     if ((spins & 1023) == 0 && __hip_atomic_load(abort_w, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0) { *s_dead = 1; return; }
   }
@@ -581,13 +584,13 @@ __global__ void __launch_bounds__(256, WPC) k_ds_gj_flow(DsDev D, int lv0, DsFlo
     if (!(bi == k && bj == k)) {   // (the pivot tile of step k holds P[k] already)
       const bool general = bi != k && bj != k;
       if (general) {   // the panel tiles first: they were published an inversion before P[k]
-        if (threadIdx.x == 64) ds_flow_poll(DS_FLOW_RFLAG(k, bj), epoch, abort_w, &s_dead);
-        if (threadIdx.x == 128) ds_flow_poll(DS_FLOW_CFLAG(bi, k), epoch, abort_w, &s_dead);
+        if (threadIdx.x == 64) ds_flow_poll<true>(DS_FLOW_RFLAG(k, bj), epoch, abort_w, &s_dead);
+        if (threadIdx.x == 128) ds_flow_poll<true>(DS_FLOW_CFLAG(bi, k), epoch, abort_w, &s_dead);
         __syncthreads();
         ds_flow_fetch(T1, DS_FLOW_RSLOT(k, bj), tx, ty);
         ds_flow_fetch(T2, DS_FLOW_CSLOT(bi, k), tx, ty);
       }
-      if (threadIdx.x == 0) ds_flow_poll(DS_FLOW_PFLAG(k), epoch, abort_w, &s_dead);
+      if (threadIdx.x == 0) ds_flow_poll<true>(DS_FLOW_PFLAG(k), epoch, abort_w, &s_dead);
       __syncthreads();
       ds_flow_fetch(Ps, DS_FLOW_PSLOT(k), tx, ty);
       if (bi == k) {

@@ -139,7 +139,7 @@ struct DirectSolver {
   // the block steps are not idle time that other work can fill, their 1024 workgroups keep the memory system busy
   int overlap = 0, overlap_cap = 512, overlap_max_fronts = 160;
   // "direct_flow": block steps of a batch alone on its level as one persistent dataflow launch (k_ds_gj_flow)
-  int flow = 1, flow_cap[2] = {0, 0}, flow_epoch = 0;   // flow_cap: resident workgroups of the 4 / 5-per-CU instantiations
+  int flow = 3, flow_cap[2] = {0, 0}, flow_epoch = 0;   // flow_cap: resident workgroups of the 4 / 5-per-CU instantiations
   long n_flow = 0;
   DevBuf<double> flow_x;    // exchange slots (pivot inverses, row / column panel tiles)
   DevBuf<int> flow_f;       // their flags (epoch of the launch that published the slot)

@@ -724,7 +724,7 @@ static int body_dense_setup(tsl_ctx* c) {
   TSL_TRY(c->bd_rows.upload(rows)); TSL_TRY(c->bd_body_of.upload(body_of)); TSL_TRY(c->bd_local_of.upload(local_of));
   if (c->bd_bad.alloc(TSL_MAX_DENSE_BODIES) | c->bd_W.alloc(c->bd_w_total) | c->bd_Binv.alloc(c->bd_w_total) | c->bd_scr.alloc(4 * (size_t)c->bd_scr_n) | c->bd_rb.alloc(2 * (size_t)c->bd_scr_n)) return -1;
   A.rows = c->bd_rows.p; A.body_of = c->bd_body_of.p; A.local_of = c->bd_local_of.p;
-  HIP_OK(hipMemset(c->bd_Binv.p, 0, c->bd_w_total * sizeof(float)));  // the row padding must stay finite (it multiplies zeros)
+  HIP_OK(hipMemsetAsync(c->bd_Binv.p, 0, c->bd_w_total * sizeof(float), c->stream));  // the row padding must stay finite (it multiplies zeros)
   return 0;
 }
 
