@@ -482,7 +482,7 @@ __global__ void __launch_bounds__(256) k_ds_gj_finish(DsDev D, int lv0) {
 // On the upper levels of the tree (1 - 16 fronts) a block step is a dependent launch of ~13.4 us of which the arithmetic is a fraction.
 // Here every workgroup KEEPS its 32 x 32 tile in registers (matrix-core result layout) over all block steps of its front and the steps
 // are ordered by point-to-point flags instead of kernel boundaries (`scripts/micro/flag_chain.hip`: a hop -- publish an 8 KB tile,
-// raise a flag, see it from another workgroup, fetch the tile -- is 2.0 us for 4 to 1024 workgroups):
+// raise a flag, see it from another workgroup, fetch the tile -- is 2.1-2.5 us for 4 to 1024 workgroups):
 //   * what another workgroup needs of a tile is PUBLISHED into an exchange slot with agent-scope (write-through) stores, the publisher
 //     waits for their completion and then raises the slot's flag to this launch's epoch; readers poll the flag and fetch the slot with
 //     agent-scope loads (no L2 invalidation: an acquire fence per workgroup and step costs 30 ns x the number of workgroups per hop);
