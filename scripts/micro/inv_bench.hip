@@ -15,7 +15,7 @@ __global__ void __launch_bounds__(256) k_bench(const double* __restrict__ in, do
     for (int q = 0; q < 4; q++) T[ty + 8 * q][tx] = in[(ty + 8 * q) * DS_T + tx];
     __syncthreads();
     t0 = wall_clock64();
-    if (V == 1) ds_invert_tile_wg(&T[0][0], DS_T + 1, bad, 1, 0, 1e-8); else ds_invert_tile_wg2(&T[0][0], DS_T + 1, bad, 1, 0, 1e-8);
+    if (V == 1) ds_invert_tile_wg(&T[0][0], DS_T + 1, bad, 1, 0, 1e-8); else if (V == 2) ds_invert_tile_wg2(&T[0][0], DS_T + 1, bad, 1, 0, 1e-8); else ds_invert_tile_wg4(&T[0][0], DS_T + 1, bad, 1, 0, 1e-8);
     acc += wall_clock64() - t0;
   }
   for (int q = 0; q < 4; q++) out[(ty + 8 * q) * DS_T + tx] = T[ty + 8 * q][tx];
@@ -45,21 +45,21 @@ int main() {
     if (cs == 2) for (int i = 0; i < DS_T; i += 2) { h[i * DS_T + i] = 0.0; h[(i + 1) * DS_T + i + 1] = 0.0; h[i * DS_T + i + 1] = 30.0; h[(i + 1) * DS_T + i] = 30.0; }
     if (cs == 3) for (int i = 0; i < 4; i++) for (int j = 0; j < 4; j++) h[i * DS_T + j] = 1.0;
     hipMemcpy(din, h.data(), nn * 8, hipMemcpyHostToDevice);
-    for (int V = 1; V <= 2; V++) {
+    for (int V = 1; V <= 3; V++) {
       hipMemset(bad, 0, 32);
       for (int blocks : {1, 256}) {
         for (int reps : {1, 101}) {
-          auto L = [&]() { if (V == 1) hipLaunchKernelGGL(k_bench<1>, dim3(blocks), dim3(256), 0, 0, din, dout, reps, bad, cyc); else hipLaunchKernelGGL(k_bench<2>, dim3(blocks), dim3(256), 0, 0, din, dout, reps, bad, cyc); };
+          auto L = [&]() { if (V == 1) hipLaunchKernelGGL(k_bench<1>, dim3(blocks), dim3(256), 0, 0, din, dout, reps, bad, cyc); else if (V == 2) hipLaunchKernelGGL(k_bench<2>, dim3(blocks), dim3(256), 0, 0, din, dout, reps, bad, cyc); else hipLaunchKernelGGL(k_bench<3>, dim3(blocks), dim3(256), 0, 0, din, dout, reps, bad, cyc); };
           L(); hipDeviceSynchronize();
           hipEventRecord(e0); L(); hipEventRecord(e1); hipEventSynchronize(e1);
           float ms; hipEventElapsedTime(&ms, e0, e1);
           long long c; hipMemcpy(&c, cyc, 8, hipMemcpyDeviceToHost);
-          if (cs == 0) printf("form %d blocks %4d reps %3d: kernel %.2f us (%.2f us per inversion), wall_clock64 per inversion %.0f ticks (100 MHz)\n", V, blocks, reps, ms * 1e3, ms * 1e3 / reps, (double)c / reps);
+          if (cs == 0) printf("form %d blocks %4d reps %3d: kernel %.2f us (%.2f us per inversion), wall_clock64 per inversion %.0f ticks (100 MHz)\n", V == 3 ? 4 : V, blocks, reps, ms * 1e3, ms * 1e3 / reps, (double)c / reps);
         }
       }
       std::vector<double> o(nn); int hb[8];
       hipMemcpy(o.data(), dout, nn * 8, hipMemcpyDeviceToHost); hipMemcpy(hb, bad, 32, hipMemcpyDeviceToHost);
-      printf("case %d form %d: max |A inv(A) - I| = %.2e, perturbed pivots counted %d\n", cs, V, check(h, o), hb[1]);
+      printf("case %d form %d: max |A inv(A) - I| = %.2e, perturbed pivots counted %d\n", cs, V == 3 ? 4 : V, check(h, o), hb[1]);
     }
   }
   return 0;

@@ -333,13 +333,179 @@ TSL_DEV void ds_invert_tile_wg2(double* __restrict__ T, int ldt, int* __restrict
   __syncthreads();
 }
 
-// the form the factorisation kernels use (1: four-pivot elimination per block step, 2: cofactor form; A/B builds pass -DDS_INV_FORM=1)
-#ifndef DS_INV_FORM
-#define DS_INV_FORM 1
-#endif
-TSL_DEV void ds_invert_tile(double* __restrict__ T, int ldt, int* __restrict__ bad, int cls, int tag, double tol) {
-  if (DS_INV_FORM == 1) ds_invert_tile_wg(T, ldt, bad, cls, tag, tol); else ds_invert_tile_wg2(T, ldt, bad, cls, tag, tol);
+// Fourth form (round 3, for the dataflow chains, where the tile inversion IS the critical path of a block step): wave-specialised.
+// A block step of forms 1 / 2 is one dependent chain that every wave walks in lock step -- panels to LDS, barrier, pivot block back,
+// 4 x 4 inverse, B operand, matrix-core update, back to LDS: ~1500 cycles.  Here the chain is cut in two that run on different SIMDs
+// between the same pair of barriers:
+//   * waves 0 / 1 (workers) own the upper / lower 16 rows of the tile (two accumulator quadrants each); in step s they read row lk of
+//     Dinv(s) from LDS, form the B operands, update, and write the panels of step s+1 (pivot rows, pivot columns, and the 4 x 4 corner
+//     X[n, n] at the NEXT pivot position);
+//   * wave 2 (scout) forms the pivot block of step s+1 from the panels of step s by a 16x16x4 product of its own -- A operand the
+//     4 x 4 corner of the column panel, B operand Dinv(s) R at the next pivot columns, C operand X[n, n] --, passes it round its lanes
+//     through a private LDS patch, computes Dinv(s+1) (cofactor form, row lk per lane; static-pivot fall-back as in form 2) and leaves
+//     it in LDS for the workers; wave 3 only keeps the barriers.
+// The tile enters and leaves through T in LDS, so the distribution over waves is private to this function.
+TSL_DEV void ds_invert_tile_wg4(double* __restrict__ T, int ldt, int* __restrict__ bad, int cls, int tag, double tol) {
+  __shared__ double rowp[2][DS_PB][DS_T], colp[2][DS_PB][DS_T + 1], dnext[2][DS_PB][DS_PB], dinv[2][DS_PB][DS_PB], dloc[DS_PB][DS_PB], red[2], dg0[DS_T];
+  const int lane = threadIdx.x & 63, w = threadIdx.x >> 6, lr = lane & 15, lk = lane >> 4;
+  const bool worker = w < 2, scout = w == 2;
+  ds_d4 acc[2];
+  if (worker) {
+    double amax = 0.0;
+#pragma unroll
+    for (int q = 0; q < 2; q++)
+#pragma unroll
+      for (int r = 0; r < 4; r++) {
+        acc[q][r] = T[(16 * w + lk + 4 * r) * ldt + 16 * q + lr];
+        amax = fmax(amax, fabs(acc[q][r]));
+        if (q == w && lk + 4 * r == lr) dg0[16 * w + lr] = fabs(acc[q][r]);   // the diagonal on entry: the scale a pivot is measured against
+      }
+    amax = wave_max(amax);
+    if (lane == 0) red[w] = amax;
+    if (w == 0 && lr < DS_PB) dnext[1][lk][lr] = acc[0][0];   // the first pivot block (rows lk, columns lr < 4, register 0) where step "-1" would have left it
+  }
+  __syncthreads();
+  const double tmax = fmax(red[0], red[1]);
+  const double floor0 = fmax(tmax * 1e-20, 1e-300);
+  const double mydg = dg0[lane & 31];
+  unsigned badmask = 0;
+  const int c0 = lk, c1 = (lk + 1) & 3, c2 = (lk + 2) & 3, c3 = (lk + 3) & 3;   // column rotation of this lane
+  // row lk of the inverse of the 4 x 4 block D (pivot rows p0..p0+3) -> drow
+  auto inv_row = [&](const double (*D)[DS_PB], int p0, double* drow) {
+    double a[4], b[4], c[4], e[4];
+#pragma unroll
+    for (int i = 0; i < 4; i++) { a[i] = D[i][c0]; b[i] = D[i][c1]; c[i] = D[i][c2]; e[i] = D[i][c3]; }
+    const double m01 = c[0] * e[1] - c[1] * e[0], m02 = c[0] * e[2] - c[2] * e[0], m03 = c[0] * e[3] - c[3] * e[0];
+    const double m12 = c[1] * e[2] - c[2] * e[1], m13 = c[1] * e[3] - c[3] * e[1], m23 = c[2] * e[3] - c[3] * e[2];
+    const double M0 = b[1] * m23 - b[2] * m13 + b[3] * m12;
+    const double M1 = b[0] * m23 - b[2] * m03 + b[3] * m02;
+    const double M2 = b[0] * m13 - b[1] * m03 + b[3] * m01;
+    const double M3 = b[0] * m12 - b[1] * m02 + b[2] * m01;
+    const double t0 = a[0] * M0, t1 = a[1] * M1, t2 = a[2] * M2, t3 = a[3] * M3;
+    const double det = (t0 - t1) + (t2 - t3);
+    const double dabs = (fabs(t0) + fabs(t1)) + (fabs(t2) + fabs(t3));
+    if (fabs(det) >= 1e-6 * dabs && dabs < 1e300) {
+      const double idet = ds_rcp(det);
+      drow[0] = M0 * idet; drow[1] = -M1 * idet; drow[2] = M2 * idet; drow[3] = -M3 * idet;
+    } else {   // four-pivot elimination on the unrotated block with the per-pivot threshold (first form), then row lk
+      double d[DS_PB][DS_PB];
+#pragma unroll
+      for (int i = 0; i < DS_PB; i++)
+#pragma unroll
+        for (int j = 0; j < DS_PB; j++) d[i][j] = D[i][j];
+#pragma unroll
+      for (int p = 0; p < DS_PB; p++) {
+        const double piv0 = d[p][p];
+        const double tiny = fmax(tol * ds_readlane_d(mydg, p0 + p), floor0);
+        const bool small = !(fabs(piv0) >= tiny);
+        const double piv = small ? copysign(tiny, piv0) : piv0;
+        badmask |= small ? (1u << (p0 + p)) : 0u;
+        const double ip = ds_rcp(piv);
+#pragma unroll
+        for (int j = 0; j < DS_PB; j++) d[p][j] = (j == p) ? ip : d[p][j] * ip;
+#pragma unroll
+        for (int i = 0; i < DS_PB; i++) {
+          if (i == p) continue;
+          const double f = d[i][p];
+#pragma unroll
+          for (int j = 0; j < DS_PB; j++) d[i][j] = (j == p) ? -f * ip : fma(-f, d[p][j], d[i][j]);
+        }
+      }
+      const bool k1 = lk == 1, k2 = lk == 2, k3 = lk == 3;
+#pragma unroll
+      for (int j = 0; j < DS_PB; j++) drow[j] = ds_sel4(k1, k2, k3, d[0][j], d[1][j], d[2][j], d[3][j]);
+    }
+  };
+  // panels of step s from the workers' accumulators (before the barrier that opens step s)
+  auto write_panels = [&](int s) {
+    const int buf = s & 1, p0 = DS_PB * s, wp = p0 >> 4, rp = (p0 & 15) >> 2, lc = p0 & 15;
+    const int n0 = p0 + DS_PB, wn = n0 >> 4, rn = (n0 & 15) >> 2, ln = n0 & 15;
+    if (s + 1 < DS_T / DS_PB && w == wn && lr >= ln && lr < ln + DS_PB) dnext[buf][lk][lr - ln] = acc[wn][rn];   // X[n, n] before step s
+    const bool col_in = lr >= lc && lr < lc + DS_PB;   // (of column half wp)
+    const int mc = (lr - lc) & 3;
+    if (w == wp) {   // pivot rows: R~ carries the unit block in the pivot columns
+#pragma unroll
+      for (int q = 0; q < 2; q++) rowp[buf][lk][16 * q + lr] = (q == wp && col_in) ? (mc == lk ? 1.0 : 0.0) : acc[q][rp];
+    }
+    if (col_in) {    // pivot columns, negated, zero in the pivot rows; X~ has zero pivot columns
+#pragma unroll
+      for (int r = 0; r < 4; r++) {
+        colp[buf][mc][16 * w + lk + 4 * r] = (w == wp && r == rp) ? 0.0 : -acc[wp][r];
+        acc[wp][r] = 0.0;
+      }
+    }
+  };
+  double drow[DS_PB] = {0.0, 0.0, 0.0, 0.0};
+  if (worker) write_panels(0);
+  if (scout) {
+    inv_row(dnext[1], 0, drow);
+    if (lr == 0) {
+#pragma unroll
+      for (int j = 0; j < DS_PB; j++) dinv[0][lk][j] = drow[j];
+    }
+  }
+  __syncthreads();
+#pragma unroll
+  for (int s = 0; s < DS_T / DS_PB; s++) {
+    const int buf = s & 1, p0 = DS_PB * s, wp = p0 >> 4, rp = (p0 & 15) >> 2;
+    const bool has_next = s + 1 < DS_T / DS_PB;
+    if (worker) {
+      double dr[DS_PB];
+#pragma unroll
+      for (int j = 0; j < DS_PB; j++) dr[j] = dinv[buf][lk][j];
+      const double aop = colp[buf][lk][16 * w + lr];
+#pragma unroll
+      for (int q = 0; q < 2; q++) {
+        const int col = 16 * q + lr;
+        const double bop = dr[0] * rowp[buf][0][col] + dr[1] * rowp[buf][1][col] + dr[2] * rowp[buf][2][col] + dr[3] * rowp[buf][3][col];
+        acc[q] = __builtin_amdgcn_mfma_f64_16x16x4f64(aop, bop, acc[q], 0, 0, 0);   // X~ - C' (Dinv R~)
+        if (w == wp) acc[q][rp] = bop;                                                // pivot rows = Dinv R~ (Dinv itself in the pivot columns)
+      }
+      if (has_next) write_panels(s + 1);
+    } else if (scout && has_next) {
+      const int n0 = p0 + DS_PB, cn = n0 + (lr & 3);
+      const double bn = drow[0] * rowp[buf][0][cn] + drow[1] * rowp[buf][1][cn] + drow[2] * rowp[buf][2][cn] + drow[3] * rowp[buf][3][cn];
+      const double an = lr < DS_PB ? colp[buf][lk][n0 + lr] : 0.0;
+      const ds_d4 cin = {lr < DS_PB ? dnext[buf][lk][lr & 3] : 0.0, 0.0, 0.0, 0.0};
+      const ds_d4 dn = __builtin_amdgcn_mfma_f64_16x16x4f64(an, bn, cin, 0, 0, 0);    // D(s+1) = X[n, n] - C[n, :] (Dinv(s) R[:, n]) in lanes (lk, lr < 4), register 0
+      if (lr < DS_PB) dloc[lk][lr] = dn[0];
+      __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+      __builtin_amdgcn_wave_barrier();
+      __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+      inv_row(dloc, n0, drow);
+      if (lr == 0) {
+#pragma unroll
+        for (int j = 0; j < DS_PB; j++) dinv[buf ^ 1][lk][j] = drow[j];
+      }
+    }
+    __syncthreads();
+  }
+  if (worker) {
+#pragma unroll
+    for (int q = 0; q < 2; q++)
+#pragma unroll
+      for (int r = 0; r < 4; r++) T[(16 * w + lk + 4 * r) * ldt + 16 * q + lr] = acc[q][r];
+  }
+  if (scout && lane == 0 && badmask) {
+    atomicAdd(bad + cls, __popc(badmask));
+    const int slot = atomicAdd(bad + 4, 1);
+    if (slot < DS_BADLOG) { int* L = bad + 8 + 4 * slot; L[0] = tag; L[1] = (int)badmask; L[2] = 0; L[3] = __float_as_int((float)tmax); }
+  }
+  __syncthreads();
 }
+
+// the form the factorisation kernels use (1: four-pivot elimination per block step, 2: cofactor form, 4: wave-specialised; A/B builds pass
+// -DDS_INV_FORM=n).  scripts/micro/inv_bench.hip: 5.58 / 4.88 / 4.29 us per tile, same accuracy (the cofactor forms do not perturb blocks
+// like [0 1; 1 0]).  Form 4 since the dataflow chains put the inversion on the critical path of every block step; the five-workgroups-per-CU
+// instantiation of k_ds_gj_flow keeps form 1 (form 4 spills 88 registers at 96: 587 against 354 us for the 1056-pivot root).
+#ifndef DS_INV_FORM
+#define DS_INV_FORM 4
+#endif
+template <int FORM>
+TSL_DEV void ds_invert_tile_f(double* __restrict__ T, int ldt, int* __restrict__ bad, int cls, int tag, double tol) {
+  if (FORM == 1) ds_invert_tile_wg(T, ldt, bad, cls, tag, tol); else if (FORM == 2) ds_invert_tile_wg2(T, ldt, bad, cls, tag, tol); else ds_invert_tile_wg4(T, ldt, bad, cls, tag, tol);
+}
+TSL_DEV void ds_invert_tile(double* __restrict__ T, int ldt, int* __restrict__ bad, int cls, int tag, double tol) { ds_invert_tile_f<DS_INV_FORM>(T, ldt, bad, cls, tag, tol); }
 
 // scratch of a front inside the level scratch (fronts with more than DS_SMALL pivots): pivot-block inverses P[2] (ping-pong) and the
 // side panels of the merged Gauss-Jordan step, row panel R[2] (DS_T x pp) and column panel C[2] (pp x DS_T)
@@ -567,7 +733,7 @@ __global__ void __launch_bounds__(256, WPC) k_ds_gj_flow(DsDev D, int lv0, DsFlo
 #pragma unroll
     for (int r = 0; r < 4; r++) T2[16 * wi + lk + 4 * r][16 * wj + lr] = own[r];
     __syncthreads();
-    ds_invert_tile(&T2[0][0], DS_T + 1, D.bad, cls, (sn << 6) | k, D.piv_tol);
+    ds_invert_tile_f<(WPC >= 5 ? 1 : DS_INV_FORM)>(&T2[0][0], DS_T + 1, D.bad, cls, (sn << 6) | k, D.piv_tol);
     __syncthreads();
     double* slot = DS_FLOW_PSLOT(k);
 #pragma unroll
