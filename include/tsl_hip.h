@@ -116,7 +116,8 @@ int tsl_set_stream(tsl_ctx* ctx, void* hip_stream);
  * that stalls within 1e-3 of the right-hand side is returned flagged not converged; above that the hierarchy gets this many iterations),
  * "direct_piv_tol" (static pivoting: pivots below this fraction of their entry diagonal are perturbed to it, default 1e-11),
  * "direct_prezero" (1: the front arena of the next factorisation is cleared on a side stream after each solve of a time step),
- * "direct_gemm_wpc" (4 / 3: workgroups per CU the factorisation GEMMs are compiled for; 3 prefetches the F22 tile, default 4),
+ * "direct_gemm_wpc" (4 / 3 / 2: workgroups per CU the factorisation GEMMs are compiled for; 3 prefetches the F22 tile, 2 double-buffers the LDS slabs
+ * -- one barrier per slab, measured slower --, default 4),
  * "direct_par_batches" (1: batches of one elimination level on parallel streams), "direct_merge_k" (1: constrained body vertices share the
  * supernode of their separator), "direct_merge_sep" (separators of at most this many vertices join the enclosing separator's supernode; 16, 0 = off),
  * "direct_refine" (1: plain iterative refinement with the factors, GMRES only where it stalls; 0: flexible GMRES from the start),

@@ -101,7 +101,7 @@ def test_direct_one_launch_sweeps_agree():
         assert rel_err(x.cpu().numpy(), x0.cpu().numpy()) < 1e-10
 
 
-@pytest.mark.parametrize("wpc", [3, 4])
+@pytest.mark.parametrize("wpc", [2, 3, 4])
 def test_direct_gemm_occupancy_variants_agree(wpc):
     """k_ds_gemm is compiled for three (F22 tile prefetched) and four (fetched in the epilogue) workgroups per CU
     ("direct_gemm_wpc"); both factorise a grid with several levels of Schur complements to the same answer as scipy's LU"""

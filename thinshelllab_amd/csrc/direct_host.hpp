@@ -34,8 +34,15 @@ static void ds_launch_gemm(hipStream_t s, const DsDev& D, const DsBatch& b, int 
     else hipLaunchKernelGGL((k_ds_gemm_capped<0, 4>), dim3(cap), dim3(256), 0, s, D, b.first, (int)grid.x, (int)grid.y, (int)grid.z, 0);
     return;
   }
-  if (mode == 0) { if (wpc >= 4) hipLaunchKernelGGL((k_ds_gemm<0, 4>), grid, dim3(256), 0, s, D, b.first, 0); else hipLaunchKernelGGL((k_ds_gemm<0, 3>), grid, dim3(256), 0, s, D, b.first, 0); }
-  else { if (wpc >= 4) hipLaunchKernelGGL((k_ds_gemm<1, 4>), grid, dim3(256), 0, s, D, b.first, part); else hipLaunchKernelGGL((k_ds_gemm<1, 3>), grid, dim3(256), 0, s, D, b.first, part); }
+  if (mode == 0) {
+    if (wpc >= 4) hipLaunchKernelGGL((k_ds_gemm<0, 4>), grid, dim3(256), 0, s, D, b.first, 0);
+    else if (wpc == 3) hipLaunchKernelGGL((k_ds_gemm<0, 3>), grid, dim3(256), 0, s, D, b.first, 0);
+    else hipLaunchKernelGGL((k_ds_gemm<0, 2>), grid, dim3(256), 0, s, D, b.first, 0);
+  } else {
+    if (wpc >= 4) hipLaunchKernelGGL((k_ds_gemm<1, 4>), grid, dim3(256), 0, s, D, b.first, part);
+    else if (wpc == 3) hipLaunchKernelGGL((k_ds_gemm<1, 3>), grid, dim3(256), 0, s, D, b.first, part);
+    else hipLaunchKernelGGL((k_ds_gemm<1, 2>), grid, dim3(256), 0, s, D, b.first, part);
+  }
 }
 
 

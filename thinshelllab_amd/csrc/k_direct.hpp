@@ -911,9 +911,10 @@ __global__ void __launch_bounds__(256) k_ds_inv_small(DsDev D, int lv0, int ls) 
 template <int mode, int WPC>
 TSL_DEV void ds_gemm_tile(const DsDev& D, int lv0, int bx, int by, int bz, int part) {
   constexpr int SA = DS_SK + 1, SB = 64 + 1;
-  constexpr bool PF = WPC <= 3;
-  __shared__ double As[64 * SA];
-  __shared__ double Bs[DS_SK * SB];
+  constexpr bool PF = WPC == 3;
+  constexpr int NB = WPC == 2 ? 2 : 1;   // WPC 2 ("direct_gemm_wpc" 2): two LDS slab buffers, ONE barrier per slab, two workgroups per CU
+  __shared__ double As[NB * 64 * SA];
+  __shared__ double Bs[NB * DS_SK * SB];
   const DsFrontDesc f = D.fr[D.level_sn[lv0 + bz]];
   const int Mr = mode == 0 ? f.pp : f.bp, Nc = f.bp, K = f.pp;
   const int I0 = by * 64, J0 = bx * 64;
@@ -966,6 +967,32 @@ TSL_DEV void ds_gemm_tile(const DsDev& D, int lv0, int bx, int by, int bz, int p
   };
   if (D.dbg == 6) { Am -= (size_t)I0 * ld; Bm -= J0; }   // timing experiments only: every workgroup streams the SAME operand tiles (cache-resident) ...
   gload(0);
+  if (NB == 2) {
+    auto fill = [&](int b) {
+      double* Ab = As + b * 64 * SA; double* Bb = Bs + b * DS_SK * SB;
+#pragma unroll
+      for (int q = 0; q < 8; q++) Ab[(ty + 8 * q) * SA + tx] = pa[q];
+#pragma unroll
+      for (int q = 0; q < 4; q++) { Bb[(ty + 8 * q) * SB + tx] = pb0[q]; Bb[(ty + 8 * q) * SB + tx + 32] = pb1[q]; }
+    };
+    fill(0);
+    __syncthreads();
+    for (int k0 = 0, cur = 0; k0 < K; k0 += DS_SK, cur ^= 1) {
+      const bool more = k0 + DS_SK < K;
+      if (more) gload(k0 + DS_SK);
+      const double* Ab = As + cur * 64 * SA; const double* Bb = Bs + cur * DS_SK * SB;
+#pragma unroll
+      for (int kk = 0; kk < DS_SK / 4; kk++) {
+        const double a0 = Ab[(32 * wi + lr) * SA + 4 * kk + lk], a1 = Ab[(32 * wi + 16 + lr) * SA + 4 * kk + lk];
+        const double b0 = Bb[(4 * kk + lk) * SB + 32 * wj + lr], b1 = Bb[(4 * kk + lk) * SB + 32 * wj + 16 + lr];
+        acc[0][0] = __builtin_amdgcn_mfma_f64_16x16x4f64(a0, b0, acc[0][0], 0, 0, 0);
+        acc[0][1] = __builtin_amdgcn_mfma_f64_16x16x4f64(a0, b1, acc[0][1], 0, 0, 0);
+        acc[1][0] = __builtin_amdgcn_mfma_f64_16x16x4f64(a1, b0, acc[1][0], 0, 0, 0);
+        acc[1][1] = __builtin_amdgcn_mfma_f64_16x16x4f64(a1, b1, acc[1][1], 0, 0, 0);
+      }
+      if (more) { fill(cur ^ 1); __syncthreads(); }   // the other buffer was last read before the barrier of the previous slab
+    }
+  } else
   for (int k0 = 0; k0 < K; k0 += DS_SK) {
     if (D.dbg < 11 || k0 == 0) {   // ("ds_dbg" 10 / 11, timing experiments: no barriers / no LDS refill either inside the K loop)
 #pragma unroll
