@@ -304,6 +304,14 @@ def roofline(ctx, scene, elapsed, K, stats, args):
                                     f"{j.get('commit', '?')}: a constant read from profiles/, not a measurement of this run")
     except (OSError, KeyError, ValueError):
         pass
+    # the GEMM classes against BOTH roofs: the Schur launches spend most of their time in the epilogue (F22 tile in, scattered read-modify-write of
+    # the parent front out: scripts/exp_gemm_dbg.py), i.e. on HBM traffic, not on the matrix cores
+    if dom in (1, 2):
+        rf["hbm_side"] = {"algorithmic_GBs": v["bytes_per_launch"] / (v["us_per_launch"] * 1e-6) / 1e9,
+                          "algorithmic_frac_of_peak": v["bytes_per_launch"] / (v["us_per_launch"] * 1e-6) / 1e9 / HBM_PEAK_GBS,
+                          "counted_GBs": (rf["traffic"] / (v["us_per_launch"] * 1e-6) / 1e9) if rf["traffic"] else None,
+                          "counted_frac_of_peak": (rf["traffic"] / (v["us_per_launch"] * 1e-6) / 1e9 / HBM_PEAK_GBS) if rf["traffic"] else None,
+                          "note": "same launches priced against the 8 TB/s HBM roof: algorithmic bytes from the plan, counted bytes from the committed --pmc passes (traffic_source)"}
     tot = sum(share.values())
     rf.update({"kernel": names[dom], "flops_per_launch": v["flops_per_launch"], "bytes_per_launch": v["bytes_per_launch"], "avg_launch_us": v["us_per_launch"],
                "launches_per_factorization": v["launches"], "share_of_direct_solve_time": share[dom] / tot,

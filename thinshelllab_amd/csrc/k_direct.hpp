@@ -993,7 +993,7 @@ TSL_DEV void ds_gemm_tile(const DsDev& D, int lv0, int bx, int by, int bz, int p
       if (more) { fill(cur ^ 1); __syncthreads(); }   // the other buffer was last read before the barrier of the previous slab
     }
   } else
-  for (int k0 = 0; k0 < K; k0 += DS_SK) {
+  for (int k0 = 0; k0 < (D.dbg == 12 ? DS_SK : K); k0 += DS_SK) {   // ("ds_dbg" 12, timing experiment: one slab only -- prologue + epilogue)
     if (D.dbg < 11 || k0 == 0) {   // ("ds_dbg" 10 / 11, timing experiments: no barriers / no LDS refill either inside the K loop)
 #pragma unroll
       for (int q = 0; q < 8; q++) As[(ty + 8 * q) * SA + tx] = pa[q];
