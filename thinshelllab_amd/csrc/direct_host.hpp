@@ -242,6 +242,7 @@ static int direct_prezero(tsl_ctx* c) {
   DirectSolver& d = c->ds;
   if (!d.prezero || d.lag > 0 || !d.plan_valid || d.arena.n == 0 || d.prezero_pending) return 0;   // ("direct_lag" keeps factors across iterations)
   if (d.zstream == nullptr) {
+    for (int k = 0; k < d.zstream_skip; k++) { hipStream_t dummy; HIP_OK(hipStreamCreateWithFlags(&dummy, hipStreamNonBlocking)); }   // ("direct_zstream_skip": experiment on the stream -> hardware queue map)
     HIP_OK(hipStreamCreateWithFlags(&d.zstream, hipStreamNonBlocking));   // (a lowest-priority stream made the step 3 % slower: the next factorisation waits for the clear)
     HIP_OK(hipEventCreateWithFlags(&d.ev_zfork, hipEventDisableTiming));
     HIP_OK(hipEventCreateWithFlags(&d.ev_zero, hipEventDisableTiming));
@@ -249,7 +250,7 @@ static int direct_prezero(tsl_ctx* c) {
   HIP_OK(hipEventRecord(d.ev_zfork, c->stream));
   HIP_OK(hipStreamWaitEvent(d.zstream, d.ev_zfork, 0));
   d.prezero_n = (size_t)d.plan.arena;
-  if (d.two_arenas) hipLaunchKernelGGL(k_ds_clear, dim3(std::max(1, d.clear_wgs)), dim3(256), 0, d.zstream, d.arena.p, d.prezero_n);   // next to the following iteration, which uses the other arena
+  if (d.two_arenas || d.clear_kernel) hipLaunchKernelGGL(k_ds_clear, dim3(std::max(1, d.clear_wgs)), dim3(256), 0, d.zstream, d.arena.p, d.prezero_n);   // (two arenas: next to the following iteration, which uses the other arena)
   else {
     // optionally in `clear_chunks` pieces so that the small kernels of the line search and of the next assembly are dispatched between them
     // instead of behind ONE launch that fills every CU for 0.22 ms (measured without gain: one piece is the default)

@@ -414,6 +414,8 @@ extern "C" int tsl_set_param(tsl_ctx* c, const char* key, double v) {
   else if (k == "direct_two_arenas") c->ds.two_arenas = (int)v;
   else if (k == "direct_gemm_persist") c->ds.gemm_persist = std::max(0, (int)v);
   else if (k == "direct_flow") c->ds.flow = std::max(0, (int)v);
+  else if (k == "direct_clear_kernel") c->ds.clear_kernel = (int)v != 0;
+  else if (k == "direct_zstream_skip") c->ds.zstream_skip = std::max(0, (int)v);
   else if (k == "direct_sweep_flow") c->ds.sweep_flow = std::max(0, (int)v);
   else if (k == "direct_clear_chunks") c->ds.clear_chunks = std::max(1, (int)v);
   else if (k == "direct_clear_wgs") c->ds.clear_wgs = std::max(1, (int)v);
