@@ -1,5 +1,5 @@
 """Probe (not part of the product): per-batch time of the G = W F12 launches with parts of the K loop removed ("ds_dbg": 0 full, 6 every workgroup streams the
-same operand tiles, 7 no global loads after the first slab, 10 no barriers either, 11 no LDS refill either, 12 no K loop at all: prologue + epilogue)."""
+same operand tiles, 7 no global loads after the first slab, 10 no barriers either, 11 no LDS refill either, 12 one slab only: prologue + epilogue, 13 F22 not read, 3 no extend-add)."""
 import sys, os
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import numpy as np, torch
@@ -18,7 +18,7 @@ for cls, name in ((2, "G"), (1, "schur")):
     for b in range(nb):
         ctx.set_param("ds_bench_batch", b)
         line = f"{name} batch {b:2d}:"
-        for dbg in (0, 6, 7, 10, 11, 12):
+        for dbg in (0, 6, 7, 10, 11, 12, 13, 3):
             ctx.set_param("ds_dbg", dbg)
             r = ctx.bench_direct(cls, 10)
             t = r["us_per_launch"] * r["launches"]

@@ -946,7 +946,7 @@ TSL_DEV void ds_gemm_tile(const DsDev& D, int lv0, int bx, int by, int bz, int p
 #pragma unroll
         for (int r = 0; r < 4; r++) {
           const int row = I0 + 32 * wi + 16 * a + lk + 4 * r, col = J0 + 32 * wj + 16 * b + lr;
-          f22[a][b][r] = (f.nchild > 0 && row < f.b && col < f.b) ? F[(size_t)(pp + row) * ld + pp + col] : 0.0;   // a leaf's F22 is zero: not read
+          f22[a][b][r] = (f.nchild > 0 && row < f.b && col < f.b && D.dbg != 13) ? F[(size_t)(pp + row) * ld + pp + col] : 0.0;   // a leaf's F22 is zero: not read ("ds_dbg" 13, timing experiment: no front's is)
         }
   };
   if (mode == 1 && PF) load_f22();
