@@ -101,6 +101,23 @@ def test_direct_one_launch_sweeps_agree():
         assert rel_err(x.cpu().numpy(), x0.cpu().numpy()) < 1e-10
 
 
+def test_direct_small_tile_g_kernel_agrees():
+    """"direct_g32_below": G = W F12 in 32 x 32 tiles (k_ds_gemm_g32, the upper tree levels by default) against 64 x 64 tiles everywhere"""
+    s = _drape(96, 64, 5e-5, seed=6)
+    ctx = s._ensure_ctx()
+    ctx.set_param("direct", 1); ctx.set_param("direct_leaf", 16)
+    s.compute_residual_and_Hessian(spd=True)
+    b = s.F.to_torch().clone()
+    sols = []
+    for g32 in (0, 1 << 30):
+        ctx.set_param("direct_g32_below", g32)
+        s.compute_residual_and_Hessian(spd=True)
+        x, st = ctx.solve(b.clone())
+        assert st["flag"] == 0 and st["method"] == 4 and st["iters"] <= 3, (g32, st)
+        sols.append(x.cpu().numpy())
+    assert rel_err(sols[1], sols[0]) < 1e-10
+
+
 @pytest.mark.parametrize("wpc", [2, 3, 4])
 def test_direct_gemm_occupancy_variants_agree(wpc):
     """k_ds_gemm is compiled for three (F22 tile prefetched) and four (fetched in the epilogue) workgroups per CU

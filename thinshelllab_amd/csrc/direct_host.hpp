@@ -25,13 +25,17 @@ static inline bool ds_use_small(const DsBatch& b) {
 // G = W F12 (mode 0) / S = F22 - F21 G added into the parents (mode 1) of a batch.  A 128 x 128-tile variant (64 accumulator
 // registers per lane, one wave per SIMD) was 2.5x slower than these 64 x 64 tiles, which reach 25-49 TFLOP/s per level on cfg4.
 // part: 0 all tiles, 1 / 2 the urgent / deferred tiles of the Schur mode (k_ds_gemm); cap > 0: at most `cap` workgroups walk the tiles
-static void ds_launch_gemm(hipStream_t s, const DsDev& D, const DsBatch& b, int mode, int wpc, int part = 0, int cap = 0) {
+static void ds_launch_gemm(hipStream_t s, const DsDev& D, const DsBatch& b, int mode, int wpc, int part = 0, int cap = 0, int ds_g32_below = 0) {
   const int rows = mode == 0 ? b.max_pp : b.max_bp, cols = b.max_bp;
   const dim3 grid((cols + 63) / 64, (rows + 63) / 64, b.count);
   const long tiles = (long)grid.x * grid.y * grid.z;
   if (cap > 0 && tiles > cap) {
     if (mode == 1) hipLaunchKernelGGL((k_ds_gemm_capped<1, 4>), dim3(cap), dim3(256), 0, s, D, b.first, (int)grid.x, (int)grid.y, (int)grid.z, part);
     else hipLaunchKernelGGL((k_ds_gemm_capped<0, 4>), dim3(cap), dim3(256), 0, s, D, b.first, (int)grid.x, (int)grid.y, (int)grid.z, 0);
+    return;
+  }
+  if (mode == 0 && ds_g32_below > 0 && tiles < ds_g32_below) {   // "direct_g32_below": few 64 x 64 tiles (upper levels) -> 32 x 32 tiles, four times the workgroups
+    hipLaunchKernelGGL(k_ds_gemm_g32, dim3((cols + 31) / 32, (rows + 31) / 32, b.count), dim3(256), 0, s, D, b.first);
     return;
   }
   if (mode == 0) {
@@ -321,7 +325,7 @@ static int direct_factor(tsl_ctx* c, int stop_sn = -1, const char* dump_path = n
     }
     if (def_pending) (void)hipStreamWaitEvent(bs, d.ev_def, 0);   // F12 / F21 / F22 of this level's fronts are complete once the previous level's deferred tiles are in
     if (tb > 0) {
-      ds_launch_gemm(bs, D, b, 0, d.gemm_wpc, 0, d.gemm_persist);
+      ds_launch_gemm(bs, D, b, 0, d.gemm_wpc, 0, d.gemm_persist, d.g32_below);
       if (!defer) ds_launch_gemm(bs, D, b, 1, d.gemm_wpc, 0, d.gemm_persist);   // + extend-add into the parents
       else {
         // Only the tiles of S that land in the parents' PIVOT blocks are in front of the next level's Gauss-Jordan chain; the rest
@@ -531,7 +535,7 @@ static int direct_bench(tsl_ctx* c, int cls, int reps, double* out) {
           bytes += 16.0 * (double)f.pp * f.pp * (cls != 0 ? 1.0 : f.pp / (double)DS_T);   // the block read and written once per launch that touches it
         }
       } else if (tb > 0) {
-        if (cls == 1 || cls == 2) ds_launch_gemm(s, D, b, cls == 2 ? 0 : 1, d.gemm_wpc, 0, d.gemm_persist);
+        if (cls == 1 || cls == 2) ds_launch_gemm(s, D, b, cls == 2 ? 0 : 1, d.gemm_wpc, 0, d.gemm_persist, d.g32_below);
         else continue;
         if (count) {
           launches++;

@@ -1063,6 +1063,50 @@ TSL_DEV void ds_gemm_tile(const DsDev& D, int lv0, int bx, int by, int bz, int p
   }
 }
 
+// G = W F12 with 32 x 32 output tiles (one 16 x 16 matrix-core tile per wave), for the batches of the upper levels: there the 64 x 64
+// tiles of k_ds_gemm are 320 - 670 workgroups -- one to three per CU --, and with so few the global loads of the next slab (prefetched ONE
+// slab = 0.5 us ahead, against ~2 us of latency) are what a slab waits for: the K loop runs at 26-42 instead of 63 TFLOP/s
+// (scripts/exp_gemm_dbg.py).  Four times the workgroups, a quarter of the registers: the latency hides behind occupancy again.
+__global__ void __launch_bounds__(256) k_ds_gemm_g32(DsDev D, int lv0) {
+  constexpr int SA = DS_SK + 1, SB = 32 + 1;
+  __shared__ double As[32 * SA];
+  __shared__ double Bs[DS_SK * SB];
+  const DsFrontDesc f = D.fr[D.level_sn[lv0 + blockIdx.z]];
+  const int Mr = f.pp, Nc = f.bp, K = f.pp;
+  const int I0 = blockIdx.y * 32, J0 = blockIdx.x * 32;
+  if (I0 >= Mr || J0 >= Nc) return;
+  const double* F = D.A + f.off;
+  double* G = D.G + f.goff;
+  const int ld = f.ld;
+  const double* Am = F;             // W rows, row stride ld
+  const double* Bm = F + f.pp;      // F12, row stride ld
+  const int lane = threadIdx.x & 63, w = threadIdx.x >> 6, wi = w >> 1, wj = w & 1, lr = lane & 15, lk = lane >> 4;
+  const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;   // 32 x 8
+  ds_d4 acc = {0.0, 0.0, 0.0, 0.0};
+  double pa[4], pb[4];
+  auto gload = [&](int k0) {
+#pragma unroll
+    for (int q = 0; q < 4; q++) {
+      const int r = ty + 8 * q;
+      pa[q] = Am[(size_t)(I0 + r) * ld + k0 + tx];
+      pb[q] = Bm[(size_t)(k0 + r) * ld + J0 + tx];
+    }
+  };
+  gload(0);
+  for (int k0 = 0; k0 < K; k0 += DS_SK) {
+#pragma unroll
+    for (int q = 0; q < 4; q++) { As[(ty + 8 * q) * SA + tx] = pa[q]; Bs[(ty + 8 * q) * SB + tx] = pb[q]; }
+    __syncthreads();
+    if (k0 + DS_SK < K) gload(k0 + DS_SK);
+#pragma unroll
+    for (int kk = 0; kk < DS_SK / 4; kk++)
+      acc = __builtin_amdgcn_mfma_f64_16x16x4f64(As[(16 * wi + lr) * SA + 4 * kk + lk], Bs[(4 * kk + lk) * SB + 16 * wj + lr], acc, 0, 0, 0);
+    __syncthreads();
+  }
+#pragma unroll
+  for (int r = 0; r < 4; r++) G[(size_t)(I0 + 16 * wi + lk + 4 * r) * f.bp + J0 + 16 * wj + lr] = acc[r];
+}
+
 template <int mode, int WPC>
 __global__ void __launch_bounds__(256, WPC) k_ds_gemm(DsDev D, int lv0, int part) {
   ds_gemm_tile<mode, WPC>(D, lv0, blockIdx.x, blockIdx.y, blockIdx.z, part);
