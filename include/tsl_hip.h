@@ -127,6 +127,8 @@ int tsl_set_stream(tsl_ctx* ctx, void* hip_stream);
  * point-to-point flags; bit 1: also the batches the LDS kernel would take; 0: one launch per 32 pivots everywhere),
  * "direct_g32_below" (1100: G = W F12 of a batch with fewer 64 x 64 tiles than this uses 32 x 32 tiles -- the upper levels, where the large tiles leave
  * one to three workgroups per CU; 0 = never),
+ * "direct_gemv_wide_below" (300: a sweep launch of fewer 16-row chunks than this -- the upper levels -- runs four workgroups per chunk, 4 rows each, the waves
+ * a quarter of the columns each; 0 = never),
  * "direct_sweep_flow" (0; L0 > 0: the sweeps of one application for the tree levels >= L0 as one launch with chained phases -- an experiment, measured slower),
  * "direct_overlap" / "direct_overlap_cap" / "direct_overlap_fronts" (0: Schur tiles outside the parents' pivot blocks on a side stream from a capped
  * grid next to the next level's block steps -- an experiment, measured without gain), "tet_warm" (1: the eigen-clamp of the element blocks starts

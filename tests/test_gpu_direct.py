@@ -101,6 +101,23 @@ def test_direct_one_launch_sweeps_agree():
         assert rel_err(x.cpu().numpy(), x0.cpu().numpy()) < 1e-10
 
 
+def test_direct_wide_sweep_kernel_agrees():
+    """"direct_gemv_wide_below": the sweep launches of the upper levels with four narrow workgroups per chunk (k_ds_gemv_wide) against the
+    16-row kernel everywhere and against the narrow kernel everywhere"""
+    s = _drape(96, 64, 5e-5, seed=7)
+    ctx = s._ensure_ctx()
+    ctx.set_param("direct", 1); ctx.set_param("direct_leaf", 16)
+    s.compute_residual_and_Hessian(spd=True)
+    b = s.F.to_torch().clone()
+    sols = []
+    for below in (0, 300, 1 << 30):
+        ctx.set_param("direct_gemv_wide_below", below)
+        x, st = ctx.solve(b.clone())
+        assert st["flag"] == 0 and st["method"] == 4 and st["iters"] <= 3, (below, st)
+        sols.append(x.cpu().numpy())
+    assert rel_err(sols[1], sols[0]) < 1e-10 and rel_err(sols[2], sols[0]) < 1e-10
+
+
 def test_direct_small_tile_g_kernel_agrees():
     """"direct_g32_below": G = W F12 in 32 x 32 tiles (k_ds_gemm_g32, the upper tree levels by default) against 64 x 64 tiles everywhere"""
     s = _drape(96, 64, 5e-5, seed=6)

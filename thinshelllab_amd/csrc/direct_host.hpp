@@ -418,6 +418,12 @@ static int direct_anorm(tsl_ctx* c) {
 }
 
 // z = (LU)^-1 r, permuted solver vectors (r is not modified; z may not alias r)
+// one launch of the level sweeps: chunks wl[o .. o + n) in `mode`; few chunks (upper levels) -> four narrow workgroups per chunk
+static void ds_launch_gemv(hipStream_t s, const DsDev& D, DirectSolver& d, int o, int n, int mode, const double* vin, double* vout) {
+  if (n <= 0) return;
+  if (d.gemv_wide_below > 0 && n < d.gemv_wide_below) hipLaunchKernelGGL(k_ds_gemv_wide, dim3(4 * n), dim3(256), 0, s, D, d.wl_front.p, d.wl_row.p, o, mode, vin, vout);
+  else hipLaunchKernelGGL(k_ds_gemv, dim3(n), dim3(256), 0, s, D, d.wl_front.p, d.wl_row.p, o, mode, vin, vout);
+}
 static int direct_apply(tsl_ctx* c, const double* r, double* z) {
   DirectSolver& d = c->ds;
   hipStream_t s = c->stream;
@@ -429,8 +435,8 @@ static int direct_apply(tsl_ctx* c, const double* r, double* z) {
   const int L0 = (d.sweep_flow > 0 && d.sweep_flow < P.n_levels - 1 && 3 * (P.n_levels - d.sweep_flow) <= DS_SWEEP_MAXP) ? d.sweep_flow : P.n_levels;
   for (int l = 0; l < L0; l++) {
     const int o0 = P.wl_own_ptr[l], b0 = P.wl_bnd_ptr[l], o1 = P.wl_own_ptr[l + 1];
-    hipLaunchKernelGGL(k_ds_gemv, dim3(b0 - o0), dim3(256), 0, s, D, d.wl_front.p, d.wl_row.p, o0, 0, (const double*)d.w.p, z);
-    if (o1 > b0) hipLaunchKernelGGL(k_ds_gemv, dim3(o1 - b0), dim3(256), 0, s, D, d.wl_front.p, d.wl_row.p, b0, 1, (const double*)z, d.w.p);
+    ds_launch_gemv(s, D, d, o0, b0 - o0, 0, (const double*)d.w.p, z);
+    ds_launch_gemv(s, D, d, b0, o1 - b0, 1, (const double*)z, d.w.p);
   }
   if (L0 < P.n_levels) {
     DirectPlan& Pm = d.plan;
@@ -467,7 +473,7 @@ static int direct_apply(tsl_ctx* c, const double* r, double* z) {
   }
   for (int l = std::min(P.n_levels - 2, L0 - 1); l >= 0; l--) {   // the top level has no boundary
     const int o0 = P.wl_own_ptr[l], b0 = P.wl_bnd_ptr[l];
-    hipLaunchKernelGGL(k_ds_gemv, dim3(b0 - o0), dim3(256), 0, s, D, d.wl_front.p, d.wl_row.p, o0, 2, (const double*)z, z);
+    ds_launch_gemv(s, D, d, o0, b0 - o0, 2, (const double*)z, z);
   }
   d.n_apply++;
   return 0;

@@ -1186,6 +1186,53 @@ __global__ void __launch_bounds__(256) k_ds_gemv(DsDev D, const int* __restrict_
   ds_gemv_chunk<false>(D, wl_front[wl0 + blockIdx.x], wl_row[wl0 + blockIdx.x], mode, vin, vout, xs);
 }
 
+// The same chunk for the launches of the upper levels, which have 66 - 600 workgroups of 16 rows: FOUR workgroups per chunk, each
+// with 4 rows, its four waves a quarter of the columns each (partial sums joined through LDS) -- a quarter of the serial column loop
+// per wave, four times the workgroups on a chip the launch did not fill ("direct_gemv_wide_below").
+__global__ void __launch_bounds__(256) k_ds_gemv_wide(DsDev D, const int* __restrict__ wl_front, const int* __restrict__ wl_row, int wl0, int mode, const double* vin, double* vout) {
+  __shared__ double xs[DS_VCHUNK];
+  __shared__ double part[4][4];
+  const int e = wl0 + (blockIdx.x >> 2);
+  const DsFrontDesc f = D.fr[wl_front[e]];
+  const int nrows = mode == 1 ? f.b : f.p, ncols = mode == 2 ? f.b : f.p;
+  const int r0 = wl_row[e] + 4 * (blockIdx.x & 3);
+  if (r0 >= nrows) return;
+  const int* vt = D.vtx + f.vtx_off;
+  const int in_v0 = mode == 2 ? f.nv_own : 0, out_v0 = mode == 1 ? f.nv_own : 0;
+  const double* M = mode == 2 ? D.G + f.goff : D.A + f.off + (mode == 1 ? (size_t)f.pp * f.ld : 0);
+  const int rs = mode == 2 ? f.bp : f.ld;
+  const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+  double acc[4] = {0.0, 0.0, 0.0, 0.0};
+  const double* row0 = M + (size_t)min(r0, nrows - 1) * rs;
+  const double* row1 = M + (size_t)min(r0 + 1, nrows - 1) * rs;
+  const double* row2 = M + (size_t)min(r0 + 2, nrows - 1) * rs;
+  const double* row3 = M + (size_t)min(r0 + 3, nrows - 1) * rs;
+  for (int c0 = 0; c0 < ncols; c0 += DS_VCHUNK) {
+    const int cn = min(DS_VCHUNK, ncols - c0);
+    __syncthreads();
+    for (int j = threadIdx.x; j < cn; j += 256) { const int jj = c0 + j; xs[j] = vin[3 * (size_t)vt[in_v0 + jj / 3] + jj % 3]; }
+    __syncthreads();
+#pragma unroll 4
+    for (int j = threadIdx.x; j < cn; j += 256) {
+      const double xv = xs[j];
+      acc[0] += row0[c0 + j] * xv; acc[1] += row1[c0 + j] * xv; acc[2] += row2[c0 + j] * xv; acc[3] += row3[c0 + j] * xv;
+    }
+  }
+#pragma unroll
+  for (int q = 0; q < 4; q++) { const double a = wave_sum(acc[q]); if (lane == 0) part[w][q] = a; }
+  __syncthreads();
+  if (threadIdx.x < 4) {
+    const int q = threadIdx.x, i = r0 + q;
+    if (i < nrows) {
+      const double a = (part[0][q] + part[1][q]) + (part[2][q] + part[3][q]);
+      const size_t o = 3 * (size_t)vt[out_v0 + i / 3] + i % 3;
+      if (mode == 0) vout[o] = a;
+      else if (mode == 1) atomicAdd(&vout[o], -a);
+      else vout[o] = vout[o] - a;
+    }
+  }
+}
+
 // The sweeps of the upper tree levels ("direct_sweep_flow" = first level) as ONE launch: the chunks of every phase -- level l upwards
 // in modes 0 and 1, then downwards in mode 2 -- in dependency order in one grid; a workgroup waits until the phase before its own is
 // complete.  Workgroups are dispatched in index order, so whatever a workgroup waits for is resident or done (no residency

@@ -414,6 +414,7 @@ extern "C" int tsl_set_param(tsl_ctx* c, const char* key, double v) {
   else if (k == "direct_two_arenas") c->ds.two_arenas = (int)v;
   else if (k == "direct_gemm_persist") c->ds.gemm_persist = std::max(0, (int)v);
   else if (k == "direct_flow") c->ds.flow = std::max(0, (int)v);
+  else if (k == "direct_gemv_wide_below") c->ds.gemv_wide_below = std::max(0, (int)v);
   else if (k == "direct_g32_below") c->ds.g32_below = std::max(0, (int)v);
   else if (k == "direct_clear_kernel") c->ds.clear_kernel = (int)v != 0;
   else if (k == "direct_zstream_skip") c->ds.zstream_skip = std::max(0, (int)v);
