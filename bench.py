@@ -268,7 +268,8 @@ def roofline(ctx, scene, elapsed, K, stats, args):
     names = {0: "k_ds_gj_step (+ k_ds_pivot0 / k_ds_gj_finish: blocked Gauss-Jordan inversion W = F11^-1 of every front of a batch, one launch per 32 pivots, f64 MFMA tiles)",
              3: "k_ds_inv_small (the same inversion of the leaf levels and small fronts: all block steps inside one launch, the pivot block in LDS)",
              5: "k_ds_gj_flow (the same inversion of the batches of the upper tree levels as ONE persistent launch per batch: a workgroup keeps its 32 x 32 tile in registers over all block steps, steps ordered by point-to-point flags; bytes = the pivot blocks read and written once)",
-             1: "k_ds_gemm[schur] (Schur complement S = F22 - F21 G of every front of a batch, K = pp GEMM on v_mfma_f64_16x16x4_f64, added into the parent fronts by the epilogue)",
+             1: "k_ds_gemm[schur] (Schur complement S = sum_children ext(S_child) - F21 G of every front of a batch: K = pp GEMM on v_mfma_f64_16x16x4_f64, the children's stored S gathered in the epilogue, S stored once -- no atomics, no cleared F22)",
+             6: "k_ds_extend_panels (the panels F11 / F12 / F21 of every front of a level take their share of the children's Schur complements: the other half of the gather-form extend-add)",
              2: "k_ds_gemm[g] (G = W F12 of every front of a batch: K = pp GEMM on v_mfma_f64_16x16x4_f64)",
              4: "k_ds_gemv (level sweeps of one application of the factors: W, F21 upwards, G downwards)"}
     cls = {}
@@ -294,7 +295,7 @@ def roofline(ctx, scene, elapsed, K, stats, args):
     # (scripts/gpu_profile.sh + install_profiles.py), labelled with the profile set and the commit it was taken on
     rf["traffic_source"] = None
     try:
-        key = {0: "k_ds_gj_step", 1: "k_ds_gemm1", 2: "k_ds_gemm0", 3: "k_ds_inv_small", 4: "k_ds_gemv", 5: "k_ds_gj_flow"}[dom]
+        key = {0: "k_ds_gj_step", 1: "k_ds_gemm1", 2: "k_ds_gemm0", 3: "k_ds_inv_small", 4: "k_ds_gemv", 5: "k_ds_gj_flow", 6: "k_ds_extend_panels"}[dom]
         path = os.path.join(ROOT, "profiles", f"latest_{args.workload.replace('-', '_')}_pmc_{key}.json")
         if os.path.exists(path) and args.grid == 224:
             with open(path) as fh:
@@ -304,8 +305,7 @@ def roofline(ctx, scene, elapsed, K, stats, args):
                                     f"{j.get('commit', '?')}: a constant read from profiles/, not a measurement of this run")
     except (OSError, KeyError, ValueError):
         pass
-    # the GEMM classes against BOTH roofs: the Schur launches spend most of their time in the epilogue (F22 tile in, scattered read-modify-write of
-    # the parent front out: scripts/exp_gemm_dbg.py), i.e. on HBM traffic, not on the matrix cores
+    # the GEMM classes against BOTH roofs (the Schur launches gather the children's Schur complements and store their own in the epilogue)
     if dom in (1, 2):
         rf["hbm_side"] = {"algorithmic_GBs": v["bytes_per_launch"] / (v["us_per_launch"] * 1e-6) / 1e9,
                           "algorithmic_frac_of_peak": v["bytes_per_launch"] / (v["us_per_launch"] * 1e-6) / 1e9 / HBM_PEAK_GBS,
@@ -442,6 +442,7 @@ def main():
     }
     rf, step = roofline(ctx, scene, elapsed, K, stats, args)
     if rf is not None:
+        rf["whole_step"] = step   # SURVEY section 8d's bytes model and the factorisation-flops figure of the WHOLE step, inside the object the driver keeps
         out["roofline"] = rf
         out["roofline_step"] = step
     if rank == 0:

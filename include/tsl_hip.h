@@ -225,14 +225,19 @@ int tsl_bench_spmv(tsl_ctx* ctx, int variant, int reps, double* us_per_launch_ho
 
 /* Sparse direct path (multifrontal LU of the operator, the counterpart of the reference's spsolve, sparse_solver.py:85-105).
  * tsl_bench_direct: the launches of one kernel class of ONE factorisation (cls 0 the Gauss-Jordan inversions W = F11^-1 on the block-step
- * path: k_ds_pivot0 + k_ds_gj_step + k_ds_gj_finish; 1 k_ds_gemm in Schur mode with its extend-add; 2 k_ds_gemm in G = W F12 mode;
- * 3 the inversions in the LDS kernel k_ds_inv_small; 5 the inversions in the persistent dataflow kernel k_ds_gj_flow) or of one application
- * (4 k_ds_gemv) on the current plan, replayed `reps` times between one hipEvent pair;
+ * path: k_ds_pivot0 + k_ds_gj_step + k_ds_gj_finish; 1 k_ds_gemm in Schur mode: product, gather of the children's Schur complements,
+ * store; 2 k_ds_gemm in G = W F12 mode; 3 the inversions in the LDS kernel k_ds_inv_small; 5 the inversions in the persistent dataflow
+ * kernel k_ds_gj_flow; 6 k_ds_extend_panels, the panels' share of the extend-add) or of one application (4 k_ds_gemv) on the current
+ * plan, replayed `reps` times between one hipEvent pair;
  * out4 = {us per launch, algorithmic flops per launch, algorithmic bytes per launch, launches per factorisation}.  The factors are
  * invalid afterwards.  tsl_direct_info: {plans, factorisations, applications, perturbed pivots of the last factorisation, host
- * seconds in plan builds, supernodes, levels, batches, flops per factorisation, bytes of fronts}. */
+ * seconds in plan builds, supernodes, levels, batches, flops per factorisation, bytes of fronts (panels + Schur complements)}.
+ * tsl_direct_counters: the first n of {dataflow launches, dataflow launches that lost a flag (redone on the block-step path), plan-cache
+ * hits, bytes of the panel arena (cleared per factorisation), of the Schur arena, of the G arena, Schur-complement entries stored per
+ * factorisation, plans parked in the cache}. */
 int tsl_bench_direct(tsl_ctx* ctx, int cls, int reps, double* out4_host);
 int tsl_direct_info(tsl_ctx* ctx, double* out10_host);
+int tsl_direct_counters(tsl_ctx* ctx, double* out_host, int32_t n);
 
 #ifdef __cplusplus
 }

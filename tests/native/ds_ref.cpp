@@ -18,33 +18,64 @@ extern "C" int dsref_solve(int NV, const int* row_ptr, const int* col, const dou
   P.sym.build_partition(NV, adj, G, B, leaf);
   const int rc = P.build(adj, rp, cons, n_cons);
   if (rc) return rc;
-  std::vector<double> A((size_t)P.arena, 0.0);
-  for (int q = 0; q < row_ptr[NV]; q++)
-    for (int r = 0; r < 3; r++)
-      for (int c = 0; c < 3; c++) A[P.blk_dst[q] + (long long)r * P.blk_ld[q] + c] += vals[(size_t)q * 9 + 3 * r + c];
-  for (int e = 0; e < n_cons; e++)
-    for (int a = 0; a < 4; a++)
-      for (int b = 0; b < 4; b++)
-        for (int r = 0; r < 3; r++)
-          for (int c = 0; c < 3; c++) A[P.con_dst[(size_t)e * 16 + 4 * a + b] + (long long)r * P.con_ld[(size_t)e * 16 + 4 * a + b] + c] += conH[(size_t)e * 144 + (3 * a + r) * 12 + 3 * b + c];
+  // Panel arena (top rows + F21 of every front) and Schur arena, as the GPU path treats them: only the panels of the LEAF level (the
+  // head of the panel arena) are cleared; everything else starts as NaN -- the panels of a higher level must be WRITTEN by the gather
+  // of the children's Schur complements before the level's matrix entries are added, and every Schur entry the gather reads must
+  // have been stored by the child before.
+  std::vector<double> A((size_t)P.arena, std::nan("")), SA((size_t)P.sarena, std::nan(""));
+  std::fill(A.begin(), A.begin() + P.arena_leaf, 0.0);
   const int S = P.sym.n_sn;
-  for (int s = 0; s < S; s++) { const DsFrontDesc& f = P.fr[s]; for (int i = f.p; i < f.pp; i++) A[f.off + (long long)i * f.ld + i] = 1.0; }
   double min_piv = 1e300;
-  long n_viol = 0, n_store = 0, n_add = 0;
-  for (int l = 0; l < P.n_levels; l++)
+  long n_gather = 0, n_level_viol = 0;
+  // sum over the children (fixed order) of the entries of their Schur complements that land on (i, j) of front f, local dofs
+  auto gather = [&](const DsFrontDesc& f, int i, int j) {
+    double v = 0.0;
+    for (int q = f.ch_off; q < f.ch_off + f.nchild; q++) {
+      const DsChildRec& c = P.ch_rec[q];
+      const int ci = P.pmap[c.pmap_off + i], cj = P.pmap[c.pmap_off + j];
+      if (ci >= 0 && cj >= 0) { v += SA[c.soff + (long long)ci * c.bp + cj]; n_gather++; }
+    }
+    return v;
+  };
+  for (int l = 0; l < P.n_levels; l++) {
+    // start of the level: panels written from the children (k_ds_extend_panels; level 0 was cleared), then the level's matrix entries,
+    // contact blocks and the identity on the padding of the pivot blocks (k_ds_assemble_level)
+    for (int q = P.level_ptr[l]; q < P.level_ptr[l + 1]; q++) {
+      const DsFrontDesc& f = P.fr[P.level_sn[q]];
+      if (l == 0) { if (f.off21 + (long long)f.bp * f.pp > P.arena_leaf) n_level_viol++; continue; }
+      if (f.off < P.arena_leaf) n_level_viol++;
+      for (int i = 0; i < f.pp; i++) for (int j = 0; j < f.ld; j++) A[f.off + (size_t)i * f.ld + j] = gather(f, i, j);
+      for (int i = 0; i < f.bp; i++) for (int j = 0; j < f.pp; j++) A[f.off21 + (size_t)i * f.pp + j] = gather(f, f.pp + i, j);
+    }
+    for (int i = P.blk_lptr[l]; i < P.blk_lptr[l + 1]; i++) {
+      const int q = P.blk_q[i];
+      for (int r = 0; r < 3; r++)
+        for (int c = 0; c < 3; c++) A[P.blk_dst[q] + (long long)r * P.blk_ld[q] + c] += vals[(size_t)q * 9 + 3 * r + c];
+    }
+    for (int e = 0; e < n_cons; e++)
+      for (int a = 0; a < 4; a++)
+        for (int b = 0; b < 4; b++) {
+          if (P.con_lvl[(size_t)e * 16 + 4 * a + b] != l) continue;
+          for (int r = 0; r < 3; r++)
+            for (int c = 0; c < 3; c++) A[P.con_dst[(size_t)e * 16 + 4 * a + b] + (long long)r * P.con_ld[(size_t)e * 16 + 4 * a + b] + c] += conH[(size_t)e * 144 + (3 * a + r) * 12 + 3 * b + c];
+        }
+    for (int q = P.level_ptr[l]; q < P.level_ptr[l + 1]; q++) { const DsFrontDesc& f = P.fr[P.level_sn[q]]; for (int i = f.p; i < f.pp; i++) A[f.off + (long long)i * f.ld + i] = 1.0; }
     for (int q = P.level_ptr[l]; q < P.level_ptr[l + 1]; q++) {
       const int s = P.level_sn[q];
       const DsFrontDesc& f = P.fr[s];
-      double* F = A.data() + f.off;
-      const int ld = f.ld;
+      for (int c = f.ch_off; c < f.ch_off + f.nchild; c++) if (P.sym.level[P.ch_rec[c].sn] >= l) n_level_viol++;
+      double* F = A.data() + f.off;     // top rows, stride ld
+      double* F21 = A.data() + f.off21; // stride pp
+      double* Sf = SA.data() + f.soff;  // stride bp
+      const int ld = f.ld, pp = f.pp;
       // in-place Gauss-Jordan on rows 0..pp of [F11 | F12]
-      for (int k = 0; k < f.pp; k++) {
+      for (int k = 0; k < pp; k++) {
         const double piv = F[(size_t)k * ld + k];
         min_piv = std::min(min_piv, std::fabs(piv));
         const double ip = 1.0 / piv;
         for (int j = 0; j < ld; j++) F[(size_t)k * ld + j] *= ip;
         F[(size_t)k * ld + k] = ip;
-        for (int i = 0; i < f.pp; i++) {
+        for (int i = 0; i < pp; i++) {
           if (i == k) continue;
           const double c = F[(size_t)i * ld + k];
           if (c == 0.0) continue;
@@ -52,32 +83,15 @@ extern "C" int dsref_solve(int NV, const int* row_ptr, const int* col, const dou
           for (int j = 0; j < ld; j++) F[(size_t)i * ld + j] -= c * F[(size_t)k * ld + j];
         }
       }
-      // S = F22 - F21 G
-      for (int i = f.pp; i < f.pp + f.b; i++)
-        for (int k = 0; k < f.p; k++) {
-          const double c = F[(size_t)i * ld + k];
-          if (c == 0.0) continue;
-          for (int j = f.pp; j < f.pp + f.b; j++) F[(size_t)i * ld + j] -= c * F[(size_t)k * ld + j];
+      // S = sum_children ext(S_child) - F21 G, stored (the Schur GEMM's epilogue)
+      for (int i = 0; i < f.b; i++)
+        for (int j = 0; j < f.b; j++) {
+          double acc = 0.0;
+          for (int k = 0; k < f.p; k++) acc += F21[(size_t)i * pp + k] * F[(size_t)k * ld + pp + j];
+          Sf[(size_t)i * f.bp + j] = gather(f, pp + i, pp + j) - acc;
         }
-      if (f.parent >= 0) {
-        const DsFrontDesc& pf = P.fr[f.parent];
-        double* PF = A.data() + pf.off;
-        // the extend-add with the semantics of the kernel's epilogue: entries marked single-writer are STORED (a wrong mark loses a
-        // contribution and the solve below goes wrong); a non-zero value underneath such an entry is counted as a violation
-        for (int iv = 0; iv < f.nv_bnd; iv++)
-          for (int jv = 0; jv < f.nv_bnd; jv++) {
-            const int ri = P.rel[f.rel_off + iv], rj = P.rel[f.rel_off + jv];
-            const int pi = ri & DS_REL_MASK, pj = rj & DS_REL_MASK;
-            const bool store = pi >= pf.pp && pj >= pf.pp && ((ri | rj) & DS_REL_EXCL);
-            for (int r = 0; r < 3; r++)
-              for (int c = 0; c < 3; c++) {
-                double& dst = PF[(size_t)(pi + r) * pf.ld + pj + c];
-                const double v = F[(size_t)(f.pp + 3 * iv + r) * ld + f.pp + 3 * jv + c];
-                if (store) { if (dst != 0.0) n_viol++; dst = v; n_store++; } else { dst += v; n_add++; }
-              }
-          }
-      }
     }
+  }
   // solve
   std::vector<double> w(rhs, rhs + 3 * (size_t)NV), t(3 * (size_t)NV, 0.0);
   for (int l = 0; l < P.n_levels; l++)
@@ -93,7 +107,7 @@ extern "C" int dsref_solve(int NV, const int* row_ptr, const int* col, const dou
       }
       for (int i = 0; i < f.b; i++) {
         double acc = 0;
-        for (int j = 0; j < f.p; j++) acc += F[(size_t)(f.pp + i) * f.ld + j] * t[3 * (size_t)vt[j / 3] + j % 3];
+        for (int j = 0; j < f.p; j++) acc += A[f.off21 + (size_t)i * f.pp + j] * t[3 * (size_t)vt[j / 3] + j % 3];
         w[3 * (size_t)vt[f.nv_own + i / 3] + i % 3] -= acc;
       }
     }
@@ -109,7 +123,7 @@ extern "C" int dsref_solve(int NV, const int* row_ptr, const int* col, const dou
         x[3 * (size_t)vt[i / 3] + i % 3] = acc;
       }
     }
-  if (stats) { stats[0] = S; stats[1] = P.n_levels; stats[2] = (double)P.arena; stats[3] = P.flops; stats[4] = min_piv; stats[5] = (double)n_viol; stats[6] = (double)n_store; stats[7] = (double)n_add; }
+  if (stats) { stats[0] = S; stats[1] = P.n_levels; stats[2] = (double)P.arena; stats[3] = P.flops; stats[4] = min_piv; stats[5] = (double)n_level_viol; stats[6] = (double)n_gather; stats[7] = (double)P.sarena; }
   return 0;
 }
 
@@ -133,16 +147,9 @@ extern "C" int dsref_plan_stats(int NV, const int* row_ptr, const int* col, int 
     steps += b.max_pp / DS_T;
     if (verbose) printf("level %2d: %5d fronts  max pp %4d  max ld %4d  max bp %4d\n", b.level, b.count, b.max_pp, b.max_ld, b.max_bp);
   }
-  double n_store = 0, n_add = 0;   // Schur-complement entries that reach their parent by a plain store / by an atomic add
-  for (const DsFrontDesc& f : P.fr) {
-    if (f.parent < 0) continue;
-    const DsFrontDesc& pf = P.fr[f.parent];
-    long ex = 0, bnd = 0;
-    for (int iv = 0; iv < f.nv_bnd; iv++) { const int r = P.rel[f.rel_off + iv]; if ((r & DS_REL_MASK) >= pf.pp) { bnd++; if (r & DS_REL_EXCL) ex++; } }
-    const double st = 9.0 * ((double)bnd * bnd - (double)(bnd - ex) * (bnd - ex));
-    n_store += st; n_add += 9.0 * (double)f.nv_bnd * f.nv_bnd - st;
-  }
-  out[7] = n_store / std::max(n_store + n_add, 1.0);
+  double n_ent = 0;   // Schur-complement entries stored per factorisation
+  for (const DsFrontDesc& f : P.fr) n_ent += (double)f.b * f.b;
+  out[7] = n_ent;
   out[0] = P.sym.n_sn; out[1] = P.n_levels; out[2] = (double)P.batches.size(); out[3] = steps; out[4] = P.flops; out[5] = (double)P.arena * 8; out[6] = solve_bytes;
   return 0;
 }

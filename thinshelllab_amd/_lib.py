@@ -75,7 +75,7 @@ EXPORTS = [
     "tsl_set_ext_force", "tsl_set_gravity", "tsl_energy", "tsl_assemble", "tsl_solve", "tsl_step", "tsl_contact_detect",
     "tsl_contact_reset", "tsl_update_ref_angle", "tsl_adjoint_step", "tsl_param_grad", "tsl_friction_grad", "tsl_elastic_force", "tsl_matrix_nnzb", "tsl_matrix_export",
     "tsl_constraints_export", "tsl_contact_blocks_export", "tsl_proj_export", "tsl_proj_import", "tsl_set_border", "tsl_spd_project", "tsl_profile_reset", "tsl_profile_read", "tsl_profile_read_events",
-    "tsl_bench_spmv", "tsl_bench_direct", "tsl_direct_info",
+    "tsl_bench_spmv", "tsl_bench_direct", "tsl_direct_info", "tsl_direct_counters",
 ]
 
 _lib = None
@@ -130,6 +130,7 @@ def load():
     L.tsl_bench_spmv.argtypes = [C.c_void_p, C.c_int, C.c_int, C.POINTER(C.c_double)]
     L.tsl_bench_direct.argtypes = [C.c_void_p, C.c_int, C.c_int, C.POINTER(C.c_double)]
     L.tsl_direct_info.argtypes = [C.c_void_p, C.POINTER(C.c_double)]
+    L.tsl_direct_counters.argtypes = [C.c_void_p, C.POINTER(C.c_double), C.c_int32]
     L.tsl_param_grad.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.POINTER(C.c_double)]
     L.tsl_friction_grad.argtypes = [C.c_void_p, C.c_void_p, C.POINTER(C.c_double)]
     L.tsl_elastic_force.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p]

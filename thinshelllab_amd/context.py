@@ -254,6 +254,12 @@ class TslContext:
         keys = ("plans", "factorizations", "applications", "perturbed_pivots", "plan_seconds", "supernodes", "levels", "batches", "flops_per_factorization", "front_bytes")
         return dict(zip(keys, [float(v) for v in out]))
 
+    def direct_counters(self):
+        out = (C.c_double * 8)()
+        check(self.L.tsl_direct_counters(self.h, out, 8), "tsl_direct_counters")
+        keys = ("flow_launches", "flow_aborts", "plan_cache_hits", "panel_bytes", "schur_bytes", "g_bytes", "schur_entries", "plans_parked")
+        return dict(zip(keys, [float(v) for v in out]))
+
     def bench_spmv(self, variant=20, reps=500):
         """microseconds per launch of `reps` back-to-back operator launches between one hipEvent pair (20 = k_pcg_spmv)"""
         us = C.c_double(0)

@@ -4,6 +4,7 @@
 #pragma once
 #include <array>
 #include <chrono>
+#include <mutex>
 
 #include "k_direct.hpp"
 #include "tsl_ctx.hpp"
@@ -22,31 +23,39 @@ static inline bool ds_use_small(const DsBatch& b) {
   return (size_t)b.count <= 256 * std::max<size_t>(per_cu, 1) * (size_t)ds_small_rounds;
 }
 
-// G = W F12 (mode 0) / S = F22 - F21 G added into the parents (mode 1) of a batch.  A 128 x 128-tile variant (64 accumulator
-// registers per lane, one wave per SIMD) was 2.5x slower than these 64 x 64 tiles, which reach 25-49 TFLOP/s per level on cfg4.
-// part: 0 all tiles, 1 / 2 the urgent / deferred tiles of the Schur mode (k_ds_gemm); cap > 0: at most `cap` workgroups walk the tiles
-static void ds_launch_gemm(hipStream_t s, const DsDev& D, const DsBatch& b, int mode, int wpc, int part = 0, int cap = 0, int ds_g32_below = 0) {
+// G = W F12 (mode 0) / S = sum_children ext(S_child) - F21 G, stored (mode 1) of a batch: 64 x 64 output tiles; "direct_g32_below": G of a
+// batch with few 64 x 64 tiles (upper levels) in 32 x 32 tiles, four times the workgroups
+static void ds_launch_gemm(hipStream_t s, const DsDev& D, const DsBatch& b, int mode, int wpc, int ds_g32_below = 0) {
   const int rows = mode == 0 ? b.max_pp : b.max_bp, cols = b.max_bp;
   const dim3 grid((cols + 63) / 64, (rows + 63) / 64, b.count);
   const long tiles = (long)grid.x * grid.y * grid.z;
-  if (cap > 0 && tiles > cap) {
-    if (mode == 1) hipLaunchKernelGGL((k_ds_gemm_capped<1, 4>), dim3(cap), dim3(256), 0, s, D, b.first, (int)grid.x, (int)grid.y, (int)grid.z, part);
-    else hipLaunchKernelGGL((k_ds_gemm_capped<0, 4>), dim3(cap), dim3(256), 0, s, D, b.first, (int)grid.x, (int)grid.y, (int)grid.z, 0);
-    return;
-  }
-  if (mode == 0 && ds_g32_below > 0 && tiles < ds_g32_below) {   // "direct_g32_below": few 64 x 64 tiles (upper levels) -> 32 x 32 tiles, four times the workgroups
+  if (mode == 0 && ds_g32_below > 0 && tiles < ds_g32_below) {
     hipLaunchKernelGGL(k_ds_gemm_g32, dim3((cols + 31) / 32, (rows + 31) / 32, b.count), dim3(256), 0, s, D, b.first);
     return;
   }
   if (mode == 0) {
-    if (wpc >= 4) hipLaunchKernelGGL((k_ds_gemm<0, 4>), grid, dim3(256), 0, s, D, b.first, 0);
-    else if (wpc == 3) hipLaunchKernelGGL((k_ds_gemm<0, 3>), grid, dim3(256), 0, s, D, b.first, 0);
-    else hipLaunchKernelGGL((k_ds_gemm<0, 2>), grid, dim3(256), 0, s, D, b.first, 0);
+    if (wpc >= 4) hipLaunchKernelGGL((k_ds_gemm<0, 4>), grid, dim3(256), 0, s, D, b.first);
+    else hipLaunchKernelGGL((k_ds_gemm<0, 2>), grid, dim3(256), 0, s, D, b.first);
   } else {
-    if (wpc >= 4) hipLaunchKernelGGL((k_ds_gemm<1, 4>), grid, dim3(256), 0, s, D, b.first, part);
-    else if (wpc == 3) hipLaunchKernelGGL((k_ds_gemm<1, 3>), grid, dim3(256), 0, s, D, b.first, part);
-    else hipLaunchKernelGGL((k_ds_gemm<1, 2>), grid, dim3(256), 0, s, D, b.first, part);
+    if (wpc >= 4) hipLaunchKernelGGL((k_ds_gemm<1, 4>), grid, dim3(256), 0, s, D, b.first);
+    else hipLaunchKernelGGL((k_ds_gemm<1, 2>), grid, dim3(256), 0, s, D, b.first);
   }
+}
+// the panels of the fronts level_sn[lv0 .. lv0 + nf) (one level, or one batch of it) are written from their children's Schur complements
+static void ds_launch_extend(hipStream_t s, const DsDev& D, int lv0, int nf, int max_ld) {
+  const int ncc = (max_ld + 64 * DS_XU - 1) / (64 * DS_XU);
+  hipLaunchKernelGGL(k_ds_extend_panels, dim3(((max_ld + DS_XROWS - 1) / DS_XROWS) * ncc, nf), dim3(256), 0, s, D, lv0, ncc);
+}
+// start of level l: its panels are written (level 0: cleared before, see direct_prezero), then its matrix entries are added
+static void ds_launch_level_start(tsl_ctx* c, hipStream_t s, const DsDev& D, int l) {
+  DirectSolver& d = c->ds;
+  const DirectPlan& P = d.plan;
+  const int lv0 = P.level_ptr[l], nf = P.level_ptr[l + 1] - lv0;
+  if (l > 0) ds_launch_extend(s, D, lv0, nf, P.level_maxld[l]);
+  const int nb = P.blk_lptr[l + 1] - P.blk_lptr[l];
+  const long nt = (long)nb * 9 + (long)c->nc * 144 + (long)nf * DS_T;
+  hipLaunchKernelGGL(k_ds_assemble_level, dim3(ds_nblk(nt, 256)), dim3(256), 0, s, P.blk_lptr[l], nb, d.blk_q.p, d.csr2sell.p, c->vals.p, d.blk_dst.p, d.blk_ld.p, c->nc, l, c->c_H.p,
+                     d.con_dst.p, d.con_ld.p, d.con_lvl.p, lv0, nf, d.frl.p, d.arena.p);
 }
 
 
@@ -55,6 +64,8 @@ static void ds_launch_gemm(hipStream_t s, const DsDev& D, const DsBatch& b, int 
 // arguments and grows the exchange buffers; false = the batch stays on the launch-per-block-step path.
 static int ds_flow_prepare(DirectSolver& d, const DirectPlan& P, const DsBatch& b, bool alone, DsFlowArgs& a, hipStream_t s) {   // -> workgroups per CU of the instantiation to launch (4 / 5), 0 = not on this path
   if (!d.flow || !alone || b.count > DS_FLOW_MAXF || b.max_pp < 2 * DS_T) return 0;
+  { hipStreamCaptureStatus cs = hipStreamCaptureStatusNone;   // a captured launch would be replayed with ONE epoch: flags of the previous replay would pass
+    if (hipStreamIsCapturing(s, &cs) != hipSuccess || cs != hipStreamCaptureStatusNone) return 0; }
   if (ds_use_small(b) && !(d.flow & 2)) return 0;   // bit 1: also the batches the LDS kernel would take (64 / 32 fronts of <= 128 pivots on levels 3 and 4 of cfg4)
   if (d.flow_cap[0] == 0) {
     int occ4 = 0, occ5 = 0, dev = 0;
@@ -84,9 +95,24 @@ static int ds_flow_prepare(DirectSolver& d, const DirectPlan& P, const DsBatch& 
   a.epoch = ++d.flow_epoch;
   return tiles <= d.flow_cap[0] ? 4 : 5;   // the fifth workgroup per CU costs 15 spilled registers: only for a root beyond 1024 tiles
 }
+// The launch must be resident as a whole (its workgroups wait for each other's flags).  Inside ONE context the host guarantees that by
+// running it alone on its level; between the contexts of one process (several scenes per GPU) the launches are chained through a
+// process-wide event, so that two persistent grids never share the chip -- each could hold part of the CUs and wait for workgroups of
+// its own that are not resident.  Other PROCESSES on the same device are not covered: there a launch that cannot become resident runs
+// into DS_FLOW_SPINS, raises bad[DS_FLOW_ABORT], and the solve falls back to the launch-per-block-step path (solve_perm).
+struct DsFlowChain { std::mutex mu; hipEvent_t ev[16] = {}; bool recorded[16] = {}; };
+static DsFlowChain g_flow_chain;
 static void ds_flow_launch(hipStream_t s, const DsDev& D, int lv0, const DsFlowArgs& fa, int wpc, DirectSolver& d) {
+  int dev = 0;
+  (void)hipGetDevice(&dev);
+  dev &= 15;
+  std::lock_guard<std::mutex> lk(g_flow_chain.mu);
+  if (g_flow_chain.ev[dev] == nullptr) (void)hipEventCreateWithFlags(&g_flow_chain.ev[dev], hipEventDisableTiming);
+  if (g_flow_chain.recorded[dev]) (void)hipStreamWaitEvent(s, g_flow_chain.ev[dev], 0);
   if (wpc == 4) hipLaunchKernelGGL(k_ds_gj_flow<4>, dim3(fa.tile0[fa.nf]), dim3(256), 0, s, D, lv0, fa, d.flow_x.p, d.flow_f.p);
   else hipLaunchKernelGGL(k_ds_gj_flow<5>, dim3(fa.tile0[fa.nf]), dim3(256), 0, s, D, lv0, fa, d.flow_x.p, d.flow_f.p);
+  (void)hipEventRecord(g_flow_chain.ev[dev], s);
+  g_flow_chain.recorded[dev] = true;
 }
 
 static bool direct_enabled(tsl_ctx* c) {
@@ -100,7 +126,7 @@ static bool direct_enabled(tsl_ctx* c) {
 static DsDev ds_dev(tsl_ctx* c) {
   DirectSolver& d = c->ds;
   DsDev D;
-  D.fr = d.fr.p; D.level_sn = d.level_sn.p; D.A = d.arena.p; D.G = d.garena.p; D.scr = d.scr.p; D.rel = d.rel.p; D.vtx = d.vtx.p; D.bad = d.bad.p; D.dbg = d.dbg; D.piv_tol = d.piv_tol;
+  D.fr = d.fr.p; D.frl = d.frl.p; D.level_sn = d.level_sn.p; D.A = d.arena.p; D.S = d.sarena.p; D.G = d.garena.p; D.scr = d.scr.p; D.ch = d.ch_rec.p; D.pmap = d.pmap.p; D.vtx = d.vtx.p; D.bad = d.bad.p; D.dbg = d.dbg; D.piv_tol = d.piv_tol;
   return D;
 }
 
@@ -142,8 +168,8 @@ static uint64_t ds_cons_key(const std::vector<int>& cons) {   // FNV-1a over the
 // active plan <-> cache slot (host plan, constraint list, every device array that belongs to a plan)
 static void ds_swap_slot(DirectSolver& d, DsPlanSlot& sl) {
   std::swap(d.plan, sl.plan); d.h_cons.swap(sl.h_cons); d.h_cset.swap(sl.h_cset);
-  d.level_sn.swap(sl.level_sn); d.rel.swap(sl.rel); d.vtx.swap(sl.vtx); d.blk_ld.swap(sl.blk_ld); d.con_ld.swap(sl.con_ld);
-  d.wl_front.swap(sl.wl_front); d.wl_row.swap(sl.wl_row); d.blk_dst.swap(sl.blk_dst); d.con_dst.swap(sl.con_dst); d.fr.swap(sl.fr);
+  d.level_sn.swap(sl.level_sn); d.pmap.swap(sl.pmap); d.ch_rec.swap(sl.ch_rec); d.vtx.swap(sl.vtx); d.blk_ld.swap(sl.blk_ld); d.con_ld.swap(sl.con_ld);
+  d.wl_front.swap(sl.wl_front); d.wl_row.swap(sl.wl_row); d.blk_dst.swap(sl.blk_dst); d.con_dst.swap(sl.con_dst); d.fr.swap(sl.fr); d.frl.swap(sl.frl); d.blk_q.swap(sl.blk_q); d.con_lvl.swap(sl.con_lvl);
 }
 
 // plan for the current constraint set (rebuilt only when the set differs from the one the plan was made for)
@@ -171,7 +197,7 @@ static int direct_plan(tsl_ctx* c) {
     if (cons != d.h_cons) {
       HIP_OK(hipStreamSynchronize(s));
       if (d.plan.build_con(cons.data(), c->nc)) return tsl_fail("direct solver: constraint vertex outside its front");
-      TSL_TRY(ds_upload_grow(d.con_dst, d.plan.con_dst, s)); TSL_TRY(ds_upload_grow(d.con_ld, d.plan.con_ld, s));
+      TSL_TRY(ds_upload_grow(d.con_dst, d.plan.con_dst, s)); TSL_TRY(ds_upload_grow(d.con_ld, d.plan.con_ld, s)); TSL_TRY(ds_upload_grow(d.con_lvl, d.plan.con_lvl, s));
       HIP_OK(hipStreamSynchronize(s));
       d.h_cons = cons;
     }
@@ -214,12 +240,17 @@ static int direct_plan(tsl_ctx* c) {
   std::vector<int> vtxp(P.vtx.size());
   for (size_t i = 0; i < vtxp.size(); i++) vtxp[i] = c->h_rowpos[P.vtx[i]];
   HIP_OK(hipStreamSynchronize(s));  // the previous plan's arrays may still be in use
-  TSL_TRY(ds_upload_grow(d.fr, P.fr, s)); TSL_TRY(ds_upload_grow(d.level_sn, P.level_sn, s)); TSL_TRY(ds_upload_grow(d.rel, P.rel, s));
+  TSL_TRY(ds_upload_grow(d.fr, P.fr, s)); TSL_TRY(ds_upload_grow(d.level_sn, P.level_sn, s)); TSL_TRY(ds_upload_grow(d.pmap, P.pmap, s)); TSL_TRY(ds_upload_grow(d.ch_rec, P.ch_rec, s));
   TSL_TRY(ds_upload_grow(d.vtx, vtxp, s)); TSL_TRY(ds_upload_grow(d.blk_dst, P.blk_dst, s)); TSL_TRY(ds_upload_grow(d.blk_ld, P.blk_ld, s));
-  TSL_TRY(ds_upload_grow(d.con_dst, P.con_dst, s)); TSL_TRY(ds_upload_grow(d.con_ld, P.con_ld, s));
+  TSL_TRY(ds_upload_grow(d.con_dst, P.con_dst, s)); TSL_TRY(ds_upload_grow(d.con_ld, P.con_ld, s)); TSL_TRY(ds_upload_grow(d.con_lvl, P.con_lvl, s));
+  TSL_TRY(ds_upload_grow(d.blk_q, P.blk_q, s));
+  std::vector<DsFrontDesc> frl(P.level_sn.size());
+  for (size_t i = 0; i < frl.size(); i++) frl[i] = P.fr[P.level_sn[i]];
+  TSL_TRY(ds_upload_grow(d.frl, frl, s));
   TSL_TRY(ds_upload_grow(d.wl_front, P.wl_front, s)); TSL_TRY(ds_upload_grow(d.wl_row, P.wl_row, s));
   if (d.prezero_pending && d.arena.n < (size_t)P.arena) { HIP_OK(hipEventSynchronize(d.ev_zero)); d.prezero_pending = false; }   // the clear runs on the buffer about to be replaced
-  if (d.arena.n < (size_t)P.arena) { if (d.arena.alloc((size_t)P.arena + (size_t)P.arena / 8)) return tsl_fail("direct solver: out of device memory (%.2f GB of fronts)", P.arena * 8e-9); }
+  if (d.arena.n < (size_t)P.arena) { if (d.arena.alloc((size_t)P.arena + (size_t)P.arena / 8)) return tsl_fail("direct solver: out of device memory (%.2f GB of front panels)", P.arena * 8e-9); }
+  if (d.sarena.n < (size_t)P.sarena) { if (d.sarena.alloc((size_t)P.sarena + (size_t)P.sarena / 8 + 16)) return tsl_fail("direct solver: out of device memory (%.2f GB of Schur complements)", P.sarena * 8e-9); }
   if (d.garena.n < (size_t)P.garena) { if (d.garena.alloc((size_t)P.garena + (size_t)P.garena / 8 + 16)) return tsl_fail("direct solver: out of device memory (G arena)"); }
   if (d.scr.n < (size_t)P.scratch) { if (d.scr.alloc((size_t)P.scratch + (size_t)P.scratch / 8)) return -1; }
   const size_t n3 = 3 * (size_t)c->NV;
@@ -232,35 +263,29 @@ static int direct_plan(tsl_ctx* c) {
   d.n_plans++;
   d.t_plan += std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
   if (c->verbose >= 2)
-    fprintf(stderr, "[tsl] direct plan: %d supernodes, %d levels, %zu batches, %.2f GB of fronts, %.1f GFLOP per factorisation, nc %d; host %.2f ms (tree + maps %.2f)\n", P.sym.n_sn, P.n_levels, P.batches.size(), P.arena * 8e-9,
+    fprintf(stderr, "[tsl] direct plan: %d supernodes, %d levels, %zu batches, %.2f + %.2f GB of panels + Schur complements, %.1f GFLOP per factorisation, nc %d; host %.2f ms (tree + maps %.2f)\n", P.sym.n_sn, P.n_levels, P.batches.size(), P.arena * 8e-9, P.sarena * 8e-9,
             P.flops * 1e-9, c->nc, 1e3 * std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count(), 1e3 * std::chrono::duration<double>(t_build - t0).count());
   if (c->verbose >= 3)
     for (const DsBatch& b : P.batches) fprintf(stderr, "[tsl]   level %2d: %5d fronts, pivots <= %4d, boundary <= %4d%s\n", b.level, b.count, b.max_pp, b.max_bp, ds_use_small(b) ? " (LDS kernel)" : "");
   return 0;
 }
 
-// Inside a time step the factors die with the solve of their Newton iteration: the 1.8 GB clear of the front arena for the next
-// factorisation (0.44 ms at HBM speed) starts on a side stream as soon as that solve is done and runs next to the line search, the
-// energy evaluations and the next assembly.  The factors are marked invalid here.
+// Inside a time step the factors die with the solve of their Newton iteration: the clear of the LEAF level's panels for the next
+// factorisation (the contiguous head of the panel arena, ~0.3 GB on cfg4; the panels of every other level are written by the gather of
+// their children's Schur complements, the Schur arena is never cleared) starts on a side stream as soon as that solve is done and runs
+// next to the line search, the energy evaluations and the next assembly.  The factors are marked invalid here.
 static int direct_prezero(tsl_ctx* c) {
   DirectSolver& d = c->ds;
   if (!d.prezero || d.lag > 0 || !d.plan_valid || d.arena.n == 0 || d.prezero_pending) return 0;   // ("direct_lag" keeps factors across iterations)
   if (d.zstream == nullptr) {
-    for (int k = 0; k < d.zstream_skip; k++) { hipStream_t dummy; HIP_OK(hipStreamCreateWithFlags(&dummy, hipStreamNonBlocking)); }   // ("direct_zstream_skip": experiment on the stream -> hardware queue map)
     HIP_OK(hipStreamCreateWithFlags(&d.zstream, hipStreamNonBlocking));   // (a lowest-priority stream made the step 3 % slower: the next factorisation waits for the clear)
     HIP_OK(hipEventCreateWithFlags(&d.ev_zfork, hipEventDisableTiming));
     HIP_OK(hipEventCreateWithFlags(&d.ev_zero, hipEventDisableTiming));
   }
   HIP_OK(hipEventRecord(d.ev_zfork, c->stream));
   HIP_OK(hipStreamWaitEvent(d.zstream, d.ev_zfork, 0));
-  d.prezero_n = (size_t)d.plan.arena;
-  if (d.two_arenas || d.clear_kernel) hipLaunchKernelGGL(k_ds_clear, dim3(std::max(1, d.clear_wgs)), dim3(256), 0, d.zstream, d.arena.p, d.prezero_n);   // (two arenas: next to the following iteration, which uses the other arena)
-  else {
-    // optionally in `clear_chunks` pieces so that the small kernels of the line search and of the next assembly are dispatched between them
-    // instead of behind ONE launch that fills every CU for 0.22 ms (measured without gain: one piece is the default)
-    const size_t nch = (size_t)std::max(1, d.clear_chunks), per = (d.prezero_n + nch - 1) / nch;
-    for (size_t o = 0; o < d.prezero_n; o += per) HIP_OK(hipMemsetAsync(d.arena.p + o, 0, std::min(per, d.prezero_n - o) * sizeof(double), d.zstream));
-  }
+  d.prezero_n = (size_t)d.plan.arena_leaf;
+  HIP_OK(hipMemsetAsync(d.arena.p, 0, d.prezero_n * sizeof(double), d.zstream));
   HIP_OK(hipEventRecord(d.ev_zero, d.zstream));
   d.prezero_pending = true;
   d.numeric_valid = false; d.have_factor = false;
@@ -274,45 +299,14 @@ static int direct_factor(tsl_ctx* c, int stop_sn = -1, const char* dump_path = n
   TSL_TRY(direct_plan(c));
   if (d.numeric_valid) return 0;
   const DirectPlan& P = d.plan;
-  if (d.two_arenas && d.prezero && d.prezero_pending && stop_sn < 0) {
-    // Two arenas: the one released by the last solve is being cleared in the background; this factorisation takes the OTHER one, which
-    // was cleared during the previous iteration.  First use (or a plan that outgrew it): allocate it and clear it inline once.
-    if (d.arena_b.n < (size_t)P.arena) {
-      if (d.b_pending) { HIP_OK(hipEventSynchronize(d.ev_zero_b)); d.b_pending = false; }
-      if (d.arena_b.alloc(std::max(d.arena.n, (size_t)P.arena + (size_t)P.arena / 8))) return tsl_fail("direct solver: out of device memory (second front arena)");
-    }
-    if (d.ev_zero_b == nullptr) HIP_OK(hipEventCreateWithFlags(&d.ev_zero_b, hipEventDisableTiming));
-    if (!d.b_pending) {
-      HIP_OK(hipMemsetAsync(d.arena_b.p, 0, (size_t)P.arena * sizeof(double), s));
-      HIP_OK(hipEventRecord(d.ev_zero_b, s));
-      d.b_pending = true; d.b_n = (size_t)P.arena;
-    }
-    d.arena.swap(d.arena_b);
-    std::swap(d.ev_zero, d.ev_zero_b); std::swap(d.prezero_n, d.b_n);
-    // both are pending now: the new current one (clean, or its clear long done) and the released one (being cleared)
-  }
   const DsDev D = ds_dev(c);
   if (d.prezero_pending) {   // cleared on the side stream since the last solve (direct_prezero)
     HIP_OK(hipStreamWaitEvent(s, d.ev_zero, 0));
     d.prezero_pending = false;
-    if (d.prezero_n < (size_t)P.arena) HIP_OK(hipMemsetAsync(d.arena.p + d.prezero_n, 0, ((size_t)P.arena - d.prezero_n) * sizeof(double), s));   // a new, larger plan
-  } else HIP_OK(hipMemsetAsync(d.arena.p, 0, (size_t)P.arena * sizeof(double), s));
-  // (two arenas: arena_b -- the one released by the last solve -- stays marked b_pending with its event until it is taken again)
+    if (d.prezero_n < (size_t)P.arena_leaf) HIP_OK(hipMemsetAsync(d.arena.p + d.prezero_n, 0, ((size_t)P.arena_leaf - d.prezero_n) * sizeof(double), s));   // a new plan with more leaf panels
+  } else HIP_OK(hipMemsetAsync(d.arena.p, 0, (size_t)P.arena_leaf * sizeof(double), s));
   HIP_OK(hipMemsetAsync(d.bad.p, 0, 8 * sizeof(int), s));
-  const long nnzb = d.row_ptr[c->NV];
-  hipLaunchKernelGGL(k_ds_assemble_blocks, dim3(ds_nblk(nnzb * 9, 256)), dim3(256), 0, s, nnzb, d.csr2sell.p, c->vals.p, d.blk_dst.p, d.blk_ld.p, d.arena.p);
-  if (c->nc > 0) hipLaunchKernelGGL(k_ds_assemble_contacts, dim3(ds_nblk((long)c->nc * 144, 256)), dim3(256), 0, s, c->nc, c->c_H.p, d.con_dst.p, d.con_ld.p, d.arena.p);
-  hipLaunchKernelGGL(k_ds_pad_diag, dim3(P.sym.n_sn), dim3(64), 0, s, P.sym.n_sn, d.fr.p, d.arena.p);
-  // "direct_overlap": the deferred part of a level's Schur complements overlaps with the block steps of the next level (which are
-  // latency-bound: a handful of fronts, one dependent launch per 32 pivots)
-  if (d.overlap && d.gstream == nullptr) {
-    HIP_OK(hipStreamCreateWithFlags(&d.gstream, hipStreamNonBlocking));
-    for (int k = 0; k < 8; k++) HIP_OK(hipEventCreateWithFlags(&d.ev_g[k], hipEventDisableTiming));
-    HIP_OK(hipEventCreateWithFlags(&d.ev_def, hipEventDisableTiming));
-  }
-  bool def_pending = false;   // deferred launches of the previous level not yet joined
-  int nrec = 0;
-  auto run_batch = [&](const DsBatch& b, hipStream_t bs, bool defer, bool alone) {
+  auto run_batch = [&](const DsBatch& b, hipStream_t bs, bool alone) {
     const int lv0 = b.first, nf = b.count;
     const int tp = b.max_pp / DS_T, tb = b.max_bp / DS_T;
     DsFlowArgs fa;
@@ -323,45 +317,34 @@ static int direct_factor(tsl_ctx* c, int stop_sn = -1, const char* dump_path = n
       for (int k = 0; k < tp; k++) { const int na = P.act_n[b.act_off + k]; hipLaunchKernelGGL(k_ds_gj_step, dim3(na + na * tp * tp), dim3(256), 0, bs, D, lv0, k, tp, na); }   // fronts are sorted by pp: the active ones are a prefix
       hipLaunchKernelGGL(k_ds_gj_finish, dim3(tp, nf), dim3(256), 0, bs, D, lv0);
     }
-    if (def_pending) (void)hipStreamWaitEvent(bs, d.ev_def, 0);   // F12 / F21 / F22 of this level's fronts are complete once the previous level's deferred tiles are in
     if (tb > 0) {
-      ds_launch_gemm(bs, D, b, 0, d.gemm_wpc, 0, d.gemm_persist, d.g32_below);
-      if (!defer) ds_launch_gemm(bs, D, b, 1, d.gemm_wpc, 0, d.gemm_persist);   // + extend-add into the parents
-      else {
-        // Only the tiles of S that land in the parents' PIVOT blocks are in front of the next level's Gauss-Jordan chain; the rest
-        // (what the parents' own GEMMs need) runs on the deferred stream from a capped grid next to that chain.
-        (void)hipEventRecord(d.ev_g[nrec], bs);
-        (void)hipStreamWaitEvent(d.gstream, d.ev_g[nrec], 0);
-        nrec++;
-        ds_launch_gemm(bs, D, b, 1, d.gemm_wpc, 1);
-        ds_launch_gemm(d.gstream, D, b, 1, d.gemm_wpc, 2, d.overlap_cap);
-      }
+      ds_launch_gemm(bs, D, b, 0, d.gemm_wpc, d.g32_below);
+      ds_launch_gemm(bs, D, b, 1, d.gemm_wpc);
     }
   };
   // The fronts of a level are independent: where a level was split into batches (by pivot-block size) the batches run on parallel
   // streams -- the latency-bound one (a few fronts in the LDS kernel, or the block steps of a handful of larger fronts) next to the
-  // throughput-bound one (a thousand leaves); the extend-add into the parents is atomic anyway.
+  // throughput-bound one (a thousand leaves).
   for (size_t bi = 0; bi < P.batches.size();) {
     size_t be = bi;
     while (be < P.batches.size() && P.batches[be].level == P.batches[bi].level) be++;
-    if (stop_sn >= 0) {   // diagnostic: the assembled front stop_sn (children added, not yet factorised) -> file
-      bool here = false;
-      for (int q = P.batches[bi].first; q < P.batches[be - 1].first + P.batches[be - 1].count; q++) here |= P.level_sn[q] == stop_sn;
-      if (here) {
-        const DsFrontDesc& f = P.fr[stop_sn];
-        std::vector<double> h((size_t)f.pp * f.ld);
-        HIP_OK(hipStreamSynchronize(s));
-        HIP_OK(hipMemcpy(h.data(), d.arena.p + f.off, h.size() * sizeof(double), hipMemcpyDeviceToHost));
-        if (FILE* fp = fopen(dump_path, "wb")) {
-          const int hdr[8] = {f.p, f.pp, f.b, f.bp, f.ld, f.nv_own, f.nv_bnd, 0};
-          fwrite(hdr, sizeof(int), 8, fp);
-          fwrite(&P.vtx[f.vtx_off], sizeof(int), (size_t)f.nv_own + f.nv_bnd, fp);
-          fwrite(h.data(), sizeof(double), h.size(), fp);
-          fclose(fp);
-        }
-        d.numeric_valid = false; d.have_factor = false;
-        return 0;
+    bool stop_here = false;
+    if (stop_sn >= 0) for (int q = P.batches[bi].first; q < P.batches[be - 1].first + P.batches[be - 1].count; q++) stop_here |= P.level_sn[q] == stop_sn;
+    ds_launch_level_start(c, s, D, P.batches[bi].level);   // (the children's Schur complements of every lower level are stored)
+    if (stop_here) {   // diagnostic: the top rows of the assembled front stop_sn (children added, not yet factorised) -> file
+      const DsFrontDesc& f = P.fr[stop_sn];
+      std::vector<double> h((size_t)f.pp * f.ld);
+      HIP_OK(hipStreamSynchronize(s));
+      HIP_OK(hipMemcpy(h.data(), d.arena.p + f.off, h.size() * sizeof(double), hipMemcpyDeviceToHost));
+      if (FILE* fp = fopen(dump_path, "wb")) {
+        const int hdr[8] = {f.p, f.pp, f.b, f.bp, f.ld, f.nv_own, f.nv_bnd, 0};
+        fwrite(hdr, sizeof(int), 8, fp);
+        fwrite(&P.vtx[f.vtx_off], sizeof(int), (size_t)f.nv_own + f.nv_bnd, fp);
+        fwrite(h.data(), sizeof(double), h.size(), fp);
+        fclose(fp);
       }
+      d.numeric_valid = false; d.have_factor = false;
+      return 0;
     }
     const int nside = d.par_batches ? (int)std::min<size_t>(be - bi - 1, DS_NSIDE) : 0;
     if (nside > 0) {
@@ -371,25 +354,13 @@ static int direct_factor(tsl_ctx* c, int stop_sn = -1, const char* dump_path = n
       HIP_OK(hipEventRecord(d.ev_ffork, s));
       for (int k = 0; k < nside; k++) HIP_OK(hipStreamWaitEvent(d.fstream[k], d.ev_ffork, 0));
     }
-    // defer this level's Schur tiles when the NEXT level is a short list of fronts on the block-step path (its chain is what the
-    // deferred tiles hide behind; the LDS kernel of small pivot blocks needs a whole CU's LDS and would wait for the capped grid)
-    bool defer = false;
-    if (d.overlap && stop_sn < 0 && be < P.batches.size()) {
-      size_t bn = be; int nfn = 0; bool small = false;
-      while (bn < P.batches.size() && P.batches[bn].level == P.batches[be].level) { nfn += P.batches[bn].count; small |= ds_use_small(P.batches[bn]); bn++; }
-      defer = nfn <= d.overlap_max_fronts && !small && (be - bi) <= 8;
-    }
-    nrec = 0;
     for (size_t q = bi; q < be; q++) {
       const int k = (int)(q - bi);   // batch 0 of the level (the largest pivot blocks: the longest chain of block steps) stays on the engine stream
-      run_batch(P.batches[q], (nside > 0 && k > 0) ? d.fstream[(k - 1) % nside] : s, defer, be - bi == 1 && !defer);
+      run_batch(P.batches[q], (nside > 0 && k > 0) ? d.fstream[(k - 1) % nside] : s, be - bi == 1);
     }
     for (int k = 0; k < nside; k++) { HIP_OK(hipEventRecord(d.ev_fjoin[k], d.fstream[k])); HIP_OK(hipStreamWaitEvent(s, d.ev_fjoin[k], 0)); }
-    def_pending = defer;
-    if (defer) HIP_OK(hipEventRecord(d.ev_def, d.gstream));
     bi = be;
   }
-  if (def_pending) HIP_OK(hipStreamWaitEvent(s, d.ev_def, 0));
   d.anorm_valid = false;   // |H|_inf is formed when a refinement first asks for a backward error (direct_anorm): most solves never do
   if (stop_sn >= 0 || c->verbose >= 2) HIP_OK(hipStreamSynchronize(s));
   HIP_OK(hipGetLastError());
@@ -431,47 +402,12 @@ static int direct_apply(tsl_ctx* c, const double* r, double* z) {
   const DsDev D = ds_dev(c);
   const size_t n3 = 3 * (size_t)c->NV;
   HIP_OK(hipMemcpyAsync(d.w.p, r, n3 * sizeof(double), hipMemcpyDeviceToDevice, s));
-  // "direct_sweep_flow" = L0 > 0: the sweeps of the levels >= L0 (latency-bound: 1 - 132 fronts each) are ONE launch (k_ds_sweep_flow)
-  const int L0 = (d.sweep_flow > 0 && d.sweep_flow < P.n_levels - 1 && 3 * (P.n_levels - d.sweep_flow) <= DS_SWEEP_MAXP) ? d.sweep_flow : P.n_levels;
-  for (int l = 0; l < L0; l++) {
+  for (int l = 0; l < P.n_levels; l++) {
     const int o0 = P.wl_own_ptr[l], b0 = P.wl_bnd_ptr[l], o1 = P.wl_own_ptr[l + 1];
     ds_launch_gemv(s, D, d, o0, b0 - o0, 0, (const double*)d.w.p, z);
     ds_launch_gemv(s, D, d, b0, o1 - b0, 1, (const double*)z, d.w.p);
   }
-  if (L0 < P.n_levels) {
-    DirectPlan& Pm = d.plan;
-    if (Pm.sweep_cache_L0 != L0) {   // phase table of this plan: {np, start[np + 1], wl0[np], mode[np], nfront[np]}
-      std::vector<int> st{0}, w0, md, nf;
-      auto phase = [&](int a0, int a1, int mode) {
-        int fronts = 0;
-        for (int e = a0; e < a1; e++) fronts += P.wl_row[e] == 0;
-        w0.push_back(a0); md.push_back(mode); nf.push_back(fronts); st.push_back(st.back() + (a1 - a0));
-      };
-      for (int l = L0; l < P.n_levels; l++) {
-        const int o0 = P.wl_own_ptr[l], b0 = P.wl_bnd_ptr[l], o1 = P.wl_own_ptr[l + 1];
-        phase(o0, b0, 0);
-        if (o1 > b0) phase(b0, o1, 1);
-      }
-      for (int l = P.n_levels - 2; l >= L0; l--) phase(P.wl_own_ptr[l], P.wl_bnd_ptr[l], 2);
-      Pm.sweep_cache.clear();
-      Pm.sweep_cache.push_back((int)w0.size());
-      for (const std::vector<int>* v : {&st, &w0, &md, &nf}) Pm.sweep_cache.insert(Pm.sweep_cache.end(), v->begin(), v->end());
-      Pm.sweep_cache_L0 = L0;
-    }
-    DsSweepArgs a;
-    const int* q = Pm.sweep_cache.data();
-    a.np = *q++;
-    for (int i = 0; i <= a.np; i++) a.start[i] = *q++;
-    for (int i = 0; i < a.np; i++) a.wl0[i] = *q++;
-    for (int i = 0; i < a.np; i++) a.mode[i] = *q++;
-    for (int i = 0; i < a.np; i++) a.nfront[i] = *q++;
-    const size_t ncnt = (size_t)a.np * P.sym.n_sn + 32 * (size_t)a.np;
-    if (d.sweep_cnt.n < ncnt) { if (d.sweep_cnt.alloc(ncnt + ncnt / 4)) return -1; }
-    HIP_OK(hipMemsetAsync(d.sweep_cnt.p, 0, ncnt * sizeof(int), s));
-    hipLaunchKernelGGL(k_ds_sweep_flow, dim3(a.start[a.np]), dim3(256), 0, s, D, d.wl_front.p, d.wl_row.p, a, d.sweep_cnt.p + 32 * (size_t)a.np, d.sweep_cnt.p, P.sym.n_sn, d.w.p, z);
-    d.n_sweep_flow++;
-  }
-  for (int l = std::min(P.n_levels - 2, L0 - 1); l >= 0; l--) {   // the top level has no boundary
+  for (int l = P.n_levels - 2; l >= 0; l--) {   // the top level has no boundary
     const int o0 = P.wl_own_ptr[l], b0 = P.wl_bnd_ptr[l];
     ds_launch_gemv(s, D, d, o0, b0 - o0, 2, (const double*)z, z);
   }
@@ -482,9 +418,10 @@ static int direct_apply(tsl_ctx* c, const double* r, double* z) {
 // Timing of one kernel class of the factorisation / solve for bench.py's roofline object: the launches of that class of ONE
 // factorisation (or one application), exactly as direct_factor / direct_apply issue them on the current plan, replayed `reps` times
 // back to back between one hipEvent pair on the engine stream.  cls: 0 the Gauss-Jordan inversions W = F11^-1 on the block-step path
-// (k_ds_pivot0 + k_ds_gj_step + k_ds_gj_finish), 1 k_ds_gemm mode 1 (Schur complements + extend-add), 2 k_ds_gemm mode 0 (G = W F12), 3 the inversions of
-// the batches in the LDS kernel (k_ds_inv_small: leaf levels and small fronts, one launch per batch),
-// 4 k_ds_gemv (all sweeps of one application), 5 the inversions of the batches in the dataflow kernel (k_ds_gj_flow: one persistent launch per batch).  The replays overwrite the factors (marked invalid afterwards).
+// (k_ds_pivot0 + k_ds_gj_step + k_ds_gj_finish), 1 k_ds_gemm mode 1 (Schur complements: product + gather of the children + store),
+// 2 G = W F12, 3 the inversions of the batches in the LDS kernel (k_ds_inv_small), 4 k_ds_gemv (all sweeps of one application),
+// 5 the inversions of the batches in the dataflow kernel (k_ds_gj_flow), 6 k_ds_extend_panels (the panels' share of the extend-add).
+// The replays overwrite the factors (marked invalid afterwards).
 // out: {us per launch, algorithmic flops per launch, algorithmic bytes per launch, launches per factorisation / application}
 static int direct_bench(tsl_ctx* c, int cls, int reps, double* out) {
   DirectSolver& d = c->ds;
@@ -492,24 +429,31 @@ static int direct_bench(tsl_ctx* c, int cls, int reps, double* out) {
   if (!d.plan_valid || d.arena.n == 0) return tsl_fail("tsl_bench_direct: no factorisation yet");
   if (d.prezero_pending) { HIP_OK(hipStreamWaitEvent(s, d.ev_zero, 0)); d.prezero_pending = false; }
   const DirectPlan& P = d.plan;
-  // Inside a time step the arena is cleared right after every solve: replays on zero fronts would time the Schur launches WITHOUT
-  // their extend-add (the epilogue skips exact zeros; measured: 0.87 instead of 1.4 ms per factorisation) and the sweeps on
-  // zero factors.  Fronts and G get a finite non-zero pattern (bytes 0x3F = 4.8e-4) unless real factors are in place.
+  // Inside a time step the panel arena is cleared right after every solve: panels, Schur complements and G get a finite non-zero
+  // pattern (bytes 0x3F = 4.8e-4) unless real factors are in place.
   if (!d.have_factor) {
     HIP_OK(hipMemsetAsync(d.arena.p, 0x3F, (size_t)P.arena * sizeof(double), s));
+    HIP_OK(hipMemsetAsync(d.sarena.p, 0x3F, (size_t)P.sarena * sizeof(double), s));
     HIP_OK(hipMemsetAsync(d.garena.p, 0x3F, (size_t)P.garena * sizeof(double), s));
   }
   const DsDev D = ds_dev(c);
   double flops = 0, bytes = 0;
   long launches = 0;
+  // entries of the children's Schur complements that land in the boundary part (-> S) / in the panels of front f
+  auto child_entries = [&](const DsFrontDesc& f, double& to_s, double& to_panels) {
+    to_s = 0; to_panels = 0;
+    for (int q = f.ch_off; q < f.ch_off + f.nchild; q++) {
+      const DsChildRec& cr = P.ch_rec[q];
+      const double nb = cr.nb, b = cr.b;
+      to_s += nb * nb; to_panels += b * b - nb * nb;
+    }
+  };
   auto issue = [&](bool count) {
     if (cls == 4) {   // one application as direct_apply issues it (the right-hand side copy included)
       (void)direct_apply(c, c->v_b.p, c->v_t4.p);
       d.n_apply--;
       if (count) {
-        const int L0 = (d.sweep_flow > 0 && d.sweep_flow < P.n_levels - 1 && 3 * (P.n_levels - d.sweep_flow) <= DS_SWEEP_MAXP) ? d.sweep_flow : P.n_levels;
-        for (int l = 0; l < L0; l++) launches += 1 + (P.wl_own_ptr[l + 1] > P.wl_bnd_ptr[l]) + (l < P.n_levels - 1);
-        if (L0 < P.n_levels) launches++;
+        for (int l = 0; l < P.n_levels; l++) launches += 1 + (P.wl_own_ptr[l + 1] > P.wl_bnd_ptr[l]) + (l < P.n_levels - 1);
         for (const DsFrontDesc& f : P.fr) { bytes += 8.0 * ((double)f.p * f.p + 2.0 * (double)f.p * f.b); flops += 2.0 * ((double)f.p * f.p + 2.0 * (double)f.p * f.b); }
       }
       return;
@@ -517,10 +461,22 @@ static int direct_bench(tsl_ctx* c, int cls, int reps, double* out) {
     int bi = -1;
     for (const DsBatch& b : P.batches) {
       bi++;
-      if (d.bench_batch >= 0 && bi != d.bench_batch) continue;   // "ds_bench_batch": one batch only (scripts/exp_batches.py)
+      if (d.bench_batch >= 0 && bi != d.bench_batch) continue;   // "ds_bench_batch": one batch only
       const int lv0 = b.first, nf = b.count;
       const int tp = b.max_pp / DS_T, tb = b.max_bp / DS_T;
-      if (cls == 0 || cls == 3 || cls == 5) {   // W = F11^-1: cls 0 the batches on the block-step path (pivot0 + block steps + finish), cls 3 the batches in the LDS kernel, cls 5 those in the dataflow kernel
+      if (cls == 6) {
+        if (b.level == 0) continue;
+        ds_launch_extend(s, D, b.first, b.count, b.max_pp + b.max_bp);
+        if (count) {
+          launches++;
+          for (int i = 0; i < nf; i++) {
+            const DsFrontDesc& f = P.fr[P.level_sn[lv0 + i]];
+            double to_s, to_p;
+            child_entries(f, to_s, to_p);
+            bytes += 8.0 * (to_p + (double)f.pp * f.ld + (double)f.bp * f.pp); flops += to_p;   // the children's entries read, every panel entry written once
+          }
+        }
+      } else if (cls == 0 || cls == 3 || cls == 5) {   // W = F11^-1: cls 0 the batches on the block-step path (pivot0 + block steps + finish), cls 3 the batches in the LDS kernel, cls 5 those in the dataflow kernel
         bool alone = true;
         for (size_t q = 0; q < P.batches.size(); q++) alone &= ((int)q == bi || P.batches[q].level != b.level);
         DsFlowArgs fa;
@@ -541,14 +497,17 @@ static int direct_bench(tsl_ctx* c, int cls, int reps, double* out) {
           bytes += 16.0 * (double)f.pp * f.pp * (cls != 0 ? 1.0 : f.pp / (double)DS_T);   // the block read and written once per launch that touches it
         }
       } else if (tb > 0) {
-        if (cls == 1 || cls == 2) ds_launch_gemm(s, D, b, cls == 2 ? 0 : 1, d.gemm_wpc, 0, d.gemm_persist, d.g32_below);
+        if (cls == 1 || cls == 2) ds_launch_gemm(s, D, b, cls == 2 ? 0 : 1, d.gemm_wpc, d.g32_below);
         else continue;
         if (count) {
           launches++;
           for (int i = 0; i < nf; i++) {
             const DsFrontDesc& f = P.fr[P.level_sn[lv0 + i]];
-            if (cls == 1) { flops += 2.0 * (double)f.bp * f.bp * f.pp; bytes += 8.0 * (2.0 * (double)f.bp * f.pp + (double)f.bp * f.bp + 2.0 * (double)f.b * f.b); }  // F21, G, F22 read, parent entries read + written
-            else if (cls == 2) { flops += 2.0 * (double)f.pp * f.pp * f.bp; bytes += 8.0 * ((double)f.pp * f.pp + 2.0 * (double)f.pp * f.bp); }
+            if (cls == 1) {   // F21 and G read, S stored, the children's entries that land in the boundary part read
+              double to_s, to_p;
+              child_entries(f, to_s, to_p);
+              flops += 2.0 * (double)f.bp * f.bp * f.pp; bytes += 8.0 * (2.0 * (double)f.bp * f.pp + (double)f.b * f.b + to_s);
+            } else { flops += 2.0 * (double)f.pp * f.pp * f.bp; bytes += 8.0 * ((double)f.pp * f.pp + 2.0 * (double)f.pp * f.bp); }
           }
         }
       }
@@ -556,24 +515,10 @@ static int direct_bench(tsl_ctx* c, int cls, int reps, double* out) {
   };
   if (d.ev0 == nullptr) { HIP_OK(hipEventCreate(&d.ev0)); HIP_OK(hipEventCreate(&d.ev1)); }
   issue(true);  // warm-up and accounting
-  if (d.dbg == 4) {   // timing experiment: the same launches captured into a hipGraph and replayed (gap between dependent kernel nodes against stream launches)
-    hipGraph_t g = nullptr; hipGraphExec_t ge = nullptr;
-    HIP_OK(hipStreamBeginCapture(s, hipStreamCaptureModeThreadLocal));
-    issue(false);
-    HIP_OK(hipStreamEndCapture(s, &g));
-    HIP_OK(hipGraphInstantiate(&ge, g, nullptr, nullptr, 0));
-    HIP_OK(hipGraphLaunch(ge, s));
-    HIP_OK(hipEventRecord(d.ev0, s));
-    for (int r = 0; r < reps; r++) HIP_OK(hipGraphLaunch(ge, s));
-    HIP_OK(hipEventRecord(d.ev1, s));
-    HIP_OK(hipEventSynchronize(d.ev1));
-    (void)hipGraphExecDestroy(ge); (void)hipGraphDestroy(g);
-  } else {
-    HIP_OK(hipEventRecord(d.ev0, s));
-    for (int r = 0; r < reps; r++) issue(false);
-    HIP_OK(hipEventRecord(d.ev1, s));
-    HIP_OK(hipEventSynchronize(d.ev1));
-  }
+  HIP_OK(hipEventRecord(d.ev0, s));
+  for (int r = 0; r < reps; r++) issue(false);
+  HIP_OK(hipEventRecord(d.ev1, s));
+  HIP_OK(hipEventSynchronize(d.ev1));
   HIP_OK(hipGetLastError());
   float ms = 0;
   HIP_OK(hipEventElapsedTime(&ms, d.ev0, d.ev1));

@@ -1,10 +1,17 @@
 // Front layout and index maps of the multifrontal factorisation (host only, no HIP): turns the symbolic result of direct_sym.hpp
 // into the arrays the kernels of k_direct.hpp consume.  Recomputed whenever the contact constraint set changes.
 //
-// Front of supernode s (row-major, leading dimension ld = pp + bp, all multiples of DS_T):
-//      [ F11 (pp x pp) | F12 (pp x bp) ]      own dofs 0..p-1 (padding p..pp-1 carries an identity diagonal)
-//      [ F21 (bp x pp) | F22 (bp x bp) ]      boundary dofs pp..pp+b-1 (padding is zero)
-// after the factorisation:  [ W = F11^-1 | G = W F12 ] / [ F21 | S = F22 - F21 G ];  S is added into the parent's front.
+// Front of supernode s (p own dofs padded to pp, b boundary dofs padded to bp, all multiples of DS_T; ld = pp + bp):
+//      [ F11 (pp x pp) | F12 (pp x bp) ]      "top rows", row stride ld, in the panel arena at `off` (padding p..pp-1: identity diagonal)
+//      [ F21 (bp x pp) ]                      row stride pp, in the panel arena at `off21` = off + pp ld (padding rows are zero)
+//      [ S   (bp x bp) ]                      row stride bp, in the Schur arena at `soff`
+// F22 is never materialised: no matrix entry lies between two boundary vertices (a block lives in the front of the earlier-eliminated
+// of its two vertices), F22 is the sum of the children's Schur complements only.  After the factorisation:
+//      [ W = F11^-1 | G = W F12 (G arena) ] / [ F21 ] / [ S = sum_children ext(S_child) - F21 G ].
+// The extend-add is a GATHER on the parent's side (round 4): a child STORES its S (one writer, coalesced); the parent's panels
+// (F11, F12, F21) and its own Schur complement read the children's S through `pmap` -- for every child a table over the parent's local
+// dofs that gives the child's boundary dof or -1 -- in the fixed child order of `ch_list`.  No atomics, no cleared F22, every sum has
+// a fixed order (bit-reproducible factors).
 #pragma once
 #include <atomic>
 #include <chrono>
@@ -12,23 +19,27 @@
 #include "direct_sym.hpp"
 
 #define DS_T 32  // tile edge of the dense kernels; p and b are padded to multiples of it
-// rel[] entries: local dof in the parent's front; bit 30 marks a boundary vertex that NO sibling front has in its boundary and that
-// lies in the parent's boundary part -- an entry of the Schur complement whose row or column vertex carries the mark (and whose other
-// vertex is in the parent's boundary part too) has a single writer and no assembled value underneath: a plain store, no atomic
-#define DS_REL_EXCL (1 << 30)
-#define DS_REL_MASK (DS_REL_EXCL - 1)
 
 struct DsFrontDesc {
-  long long off;             // first element of the front in the arena (doubles)
+  long long off;             // top rows [F11 | F12] in the panel arena (doubles)
+  long long off21;           // F21 (bp x pp, row stride pp) in the panel arena
+  long long soff;            // S (bp x bp, row stride bp) in the Schur arena
   long long goff;            // first element of G = W F12 (pp x bp, row stride bp) in the G arena
-  int p, pp, b, bp, ld;      // own dofs, padded; boundary dofs, padded; leading dimension
+  int p, pp, b, bp, ld;      // own dofs, padded; boundary dofs, padded; pp + bp
   int parent;                // supernode of the parent front, -1 at a root
-  int rel_off;               // rel[rel_off + iv]: local dof index (in the parent front) of the first dof of boundary vertex iv
+  int pmap_off;              // pmap[pmap_off + d], d a local dof of the PARENT (0 .. parent ld): this front's boundary dof that lands there, or -1
   int vtx_off;               // vtx[vtx_off + iv]: vertex id of local vertex iv (own vertices, then boundary vertices)
   int nv_own, nv_bnd;
   int scr_off;               // offset of this front's scratch inside the per-level scratch (doubles)
-  int bu;                    // boundary dofs that are OWN dofs of the parent front (they come first: the boundary is sorted by elimination position)
-  int nchild;                // child fronts: F22 of a front without children holds nothing (entries between two boundary vertices live in earlier fronts)
+  int ch_off, nchild;        // child fronts: ch_rec[ch_off .. ch_off + nchild), ascending supernode id (the summation order of the gather)
+};
+// what the gather kernels need of a child, in the parent's child order
+struct DsChildRec {
+  long long soff;            // the child's S
+  int bp, b;                 // its row stride and size
+  int pmap_off;              // its table over the parent's dofs
+  int sn;
+  int nb, pad_;              // boundary dofs that land in the parent's BOUNDARY part (the others are own dofs of the parent)
 };
 
 // fronts of one tree level with pivot blocks of similar size: one set of launches (level_sn[first .. first + count), sorted by pp descending)
@@ -60,11 +71,16 @@ static void ds_parallel_for(int n, int nt, int chunk, F body) {
 struct DirectPlan {
   DirectSym sym;
   std::vector<DsFrontDesc> fr;
-  std::vector<int> rel, vtx;
-  std::vector<long long> blk_dst;  // per block of the static pattern (CSR order of `adj`): top-left element in the arena
+  std::vector<int> pmap, vtx;
+  std::vector<DsChildRec> ch_rec;
+  std::vector<long long> blk_dst;  // per block of the static pattern (CSR order of `adj`): top-left element in the panel arena
   std::vector<int> blk_ld;
+  std::vector<int> blk_q, blk_lptr;   // the same blocks level by level: blk_q[blk_lptr[l] .. blk_lptr[l + 1]) land in fronts of level l
   std::vector<long long> con_dst;  // per constraint x 16 (vertex pair a, b)
-  std::vector<int> con_ld;
+  std::vector<int> con_ld, con_lvl;   // row stride and tree level of the destination
+  std::vector<int> level_maxld;
+  long long arena_leaf = 0;        // extent of the leaf level's panels at the head of the panel arena (doubles)
+  std::vector<std::vector<int>> lists;   // scratch of the level-by-level block list (per host thread and level)
   std::vector<int> level_ptr, level_sn;          // fronts per level (level 0 = leaves)
   std::vector<DsBatch> batches;                  // in level order
   std::vector<int> act_n, act_ld;
@@ -72,7 +88,8 @@ struct DirectPlan {
   std::vector<int> sweep_cache; int sweep_cache_L0 = -1;   // phase table of the one-launch sweeps of levels >= sweep_cache_L0 (filled by direct_apply, dropped by build)
   std::vector<int> wl_front, wl_row, wl_own_ptr, wl_bnd_ptr;   // own chunks of level l: [wl_own_ptr[l], wl_bnd_ptr[l]); boundary chunks: [wl_bnd_ptr[l], wl_own_ptr[l + 1])
   int n_levels = 0;
-  long long arena = 0;      // doubles
+  long long arena = 0;      // panel arena (top rows + F21 of every front), doubles; the fronts of level 0 come first
+  long long sarena = 0;     // Schur arena, doubles
   long long garena = 0;     // doubles
   long long scratch = 0;    // doubles, max over the levels
   double phase_ms[6] = {0, 0, 0, 0, 0, 0};   // host time of the last build: tree, descriptors + parent maps, levels / batches / work lists, static block map, contact map
@@ -91,6 +108,13 @@ struct DirectPlan {
     const int no = sym.own(s);
     return l < no ? 3 * l : fr[s].pp + 3 * (l - no);
   }
+  // panel-arena address and row stride of the entry (lr, lc) of front f, local dofs; -1 inside F22 (no matrix entry lives there)
+  static long long panel_addr(const DsFrontDesc& f, int lr, int lc, int* ld_out) {
+    if (lr < f.pp) { *ld_out = f.ld; return f.off + (long long)lr * f.ld + lc; }
+    if (lc >= f.pp) { *ld_out = 0; return -1; }
+    *ld_out = f.pp;
+    return f.off21 + (long long)(lr - f.pp) * f.pp + lc;
+  }
 
   // adj: sorted adjacency (with or without self); row_ptr: CSR offsets of adj (blocks are numbered row by row);
   // cons: n_cons x 4 vertex ids of the contact constraints
@@ -101,17 +125,13 @@ struct DirectPlan {
     lap(0);
     const int S = sym.n_sn;
     fr.assign(S, DsFrontDesc{});
-    rel.clear(); vtx.clear();
-    arena = 0; garena = 0; flops = 0;
+    pmap.clear(); vtx.clear(); ch_rec.clear();
+    arena = 0; sarena = 0; garena = 0; flops = 0;
     for (int s = 0; s < S; s++) {
       DsFrontDesc& f = fr[s];
       f.nv_own = sym.own(s); f.nv_bnd = (int)sym.bnd[s].size();
       f.p = 3 * f.nv_own; f.b = 3 * f.nv_bnd;
       f.pp = pad(f.p); f.bp = pad(f.b); f.ld = f.pp + f.bp;
-      f.off = arena;
-      arena += (long long)f.ld * f.ld;
-      f.goff = garena;
-      garena += (long long)f.pp * f.bp;
       f.parent = sym.parent[s];
       f.vtx_off = (int)vtx.size();
       for (int q = sym.sn_ptr[s]; q < sym.sn_ptr[s + 1]; q++) vtx.push_back(sym.order[q]);
@@ -119,44 +139,60 @@ struct DirectPlan {
       const double p = f.pp, b = f.bp;
       flops += 2.0 * p * p * p + 2.0 * p * p * b + 2.0 * p * b * b;
     }
-    // child boundary -> local dof in the parent's front: per parent, its front is scattered into a vertex table once and every
-    // child reads its boundary from it
+    // arena addresses level by level (the panels of the leaf level are one contiguous range at the start of the panel arena)
     {
-      int total = 0;
-      for (int s = 0; s < S; s++) { fr[s].rel_off = total; total += fr[s].nv_bnd; }
-      rel.assign(total, -1);
-      std::vector<int> cptr(S + 1, 0), clist(S);
+      std::vector<int> cnt(sym.n_levels + 1, 0), ord(S);
+      for (int s = 0; s < S; s++) cnt[sym.level[s] + 1]++;
+      for (int l = 0; l < sym.n_levels; l++) cnt[l + 1] += cnt[l];
+      for (int s = 0; s < S; s++) ord[cnt[sym.level[s]]++] = s;
+      for (int s : ord) {
+        DsFrontDesc& f = fr[s];
+        f.off = arena; f.off21 = arena + (long long)f.pp * f.ld;
+        arena += (long long)f.pp * f.ld + (long long)f.bp * f.pp;
+        f.soff = sarena; sarena += (long long)f.bp * f.bp;
+        f.goff = garena; garena += (long long)f.pp * f.bp;
+      }
+    }
+    // children of every front in ascending supernode order, and for every child its table over the PARENT's local dofs: the
+    // child's boundary dof that lands there, or -1 (the boundary of a child is contained in the front of its parent).  The parent's
+    // front is scattered into a vertex table once and every child reads its boundary from it.
+    {
+      std::vector<int> cptr(S + 1, 0);
       for (int s = 0; s < S; s++) if (fr[s].parent >= 0) { cptr[fr[s].parent + 1]++; fr[fr[s].parent].nchild++; }
       for (int s = 0; s < S; s++) cptr[s + 1] += cptr[s];
-      { std::vector<int> fill(cptr.begin(), cptr.end() - 1); for (int s = 0; s < S; s++) if (fr[s].parent >= 0) clist[fill[fr[s].parent]++] = s; }
-      const int nt = 1;   // 0.3 ms on one thread (MI355X host); starting threads costs more than they save here
-      if ((int)locs.size() < nt) locs.resize(nt);
-      std::vector<std::vector<int>> cnts(nt);
-      std::atomic<int> bad{0};
-      ds_parallel_for(S, nt, 16, [&](int t, int p) {
-        if (cptr[p] == cptr[p + 1]) return;
-        std::vector<int>& lc = locs[t];
-        if ((int)lc.size() != sym.NV) lc.assign(sym.NV, -1);
+      ch_rec.assign(cptr[S], DsChildRec{});
+      long long total = 0;
+      { std::vector<int> fill(cptr.begin(), cptr.end() - 1);
+        for (int s = 0; s < S; s++) { fr[s].ch_off = cptr[s]; if (fr[s].parent >= 0) { fr[s].pmap_off = (int)total; total += fr[fr[s].parent].ld; ch_rec[fill[fr[s].parent]++].sn = s; } } }
+      if (total > 0x7fffffffLL) return -1;
+      pmap.assign((size_t)total, -1);
+      if (locs.empty()) locs.resize(1);
+      std::vector<int>& lc = locs[0];
+      if ((int)lc.size() != sym.NV) lc.assign(sym.NV, -1);
+      bool bad = false;
+      for (int p = 0; p < S; p++) {   // 0.3 ms on one thread (MI355X host); starting threads costs more than they save here
+        if (cptr[p] == cptr[p + 1]) continue;
         const DsFrontDesc& f = fr[p];
         const int* fv = &vtx[f.vtx_off];
         for (int i = 0; i < f.nv_own; i++) lc[fv[i]] = 3 * i;
         for (int i = 0; i < f.nv_bnd; i++) lc[fv[f.nv_own + i]] = f.pp + 3 * i;
-        std::vector<int>& cnt = cnts[t];   // how many children have the parent's local vertex in their boundary
-        cnt.assign(f.nv_own + f.nv_bnd, 0);
-        auto slot = [&](int l) { return l < f.pp ? l / 3 : f.nv_own + (l - f.pp) / 3; };
         for (int q = cptr[p]; q < cptr[p + 1]; q++) {
-          const DsFrontDesc& ch = fr[clist[q]];
+          DsChildRec& cr = ch_rec[q];
+          const DsFrontDesc& ch = fr[cr.sn];
+          cr.soff = ch.soff; cr.bp = ch.bp; cr.b = ch.b; cr.pmap_off = ch.pmap_off;
           const int* cv = &vtx[ch.vtx_off + ch.nv_own];
-          for (int i = 0; i < ch.nv_bnd; i++) { const int l = lc[cv[i]]; if (l < 0) { bad = 1; continue; } rel[ch.rel_off + i] = l; cnt[slot(l)]++; }   // the boundary of a child is contained in the front of its parent
-        }
-        for (int q = cptr[p]; q < cptr[p + 1]; q++) {
-          const DsFrontDesc& ch = fr[clist[q]];
-          int nu = 0;
-          for (int i = 0; i < ch.nv_bnd; i++) { int& l = rel[ch.rel_off + i]; if (l < f.pp) { if (nu != i) bad = 1; nu++; } else if (cnt[slot(l)] == 1) l |= DS_REL_EXCL; }
-          fr[clist[q]].bu = 3 * nu;
+          int* pm = &pmap[ch.pmap_off];
+          int prev = -1;
+          for (int i = 0; i < ch.nv_bnd; i++) {
+            const int l = lc[cv[i]];
+            if (l < 0 || l <= prev) { bad = true; continue; }   // (the boundary is sorted by elimination position: the table is monotone)
+            prev = l;
+            pm[l] = 3 * i; pm[l + 1] = 3 * i + 1; pm[l + 2] = 3 * i + 2;
+            if (l >= f.pp) cr.nb += 3;
+          }
         }
         for (int i = 0; i < f.nv_own + f.nv_bnd; i++) lc[fv[i]] = -1;
-      });
+      }
       if (bad) return -1;
       for (int s = 0; s < S; s++) if (fr[s].parent < 0 && fr[s].nv_bnd > 0) return -1;
     }
@@ -232,11 +268,16 @@ struct DirectPlan {
     {
       const int nt = n_threads();
       if ((int)locs.size() < nt) locs.resize(nt);
+      // the blocks are also listed LEVEL BY LEVEL (blk_q): the panels of a level are written by the gather of the children's Schur
+      // complements when the level starts (a store, nothing is cleared), its matrix entries are added right after
+      if ((int)lists.size() < nt * L) lists.resize((size_t)nt * L);
+      for (auto& v : lists) v.clear();
       std::atomic<int> bad{0};
       std::atomic<long long> written{0};
       ds_parallel_for(S, nt, 16, [&](int t, int s) {
         std::vector<int>& loc = locs[t];
         if ((int)loc.size() != NV) loc.assign(NV, -1);
+        std::vector<int>& mine = lists[(size_t)t * L + alap[s]];
         const DsFrontDesc& f = fr[s];
         const int no = f.nv_own;
         long long nw = 0;
@@ -252,10 +293,10 @@ struct DirectPlan {
             const int lc = loc[c];
             if (lc < 0) { bad = 1; continue; }
             const int q = row_ptr[r] + k;
-            blk_dst[q] = f.off + (long long)(3 * i) * f.ld + lc; blk_ld[q] = f.ld; nw++;
-            if (sym.sn_of[c] > s) {
+            blk_dst[q] = f.off + (long long)(3 * i) * f.ld + lc; blk_ld[q] = f.ld; nw++; mine.push_back(q);
+            if (sym.sn_of[c] > s) {   // the mirrored block (c, r) lies in F21 (c is a boundary vertex of this front)
               const int qt = tpos[q];
-              if (qt >= 0) { blk_dst[qt] = f.off + (long long)lc * f.ld + 3 * i; blk_ld[qt] = f.ld; nw++; }
+              if (qt >= 0) { blk_dst[qt] = f.off21 + (long long)(lc - f.pp) * f.pp + 3 * i; blk_ld[qt] = f.pp; nw++; mine.push_back(qt); }
             }
           }
         }
@@ -263,7 +304,18 @@ struct DirectPlan {
         written += nw;
       });
       if (bad || written != row_ptr[NV]) return -2;
+      blk_q.resize(row_ptr[NV]); blk_lptr.assign(L + 1, 0);
+      size_t o = 0;
+      for (int l = 0; l < L; l++) {
+        for (int t = 0; t < nt; t++) { const std::vector<int>& v = lists[(size_t)t * L + l]; std::copy(v.begin(), v.end(), blk_q.begin() + o); o += v.size(); }
+        blk_lptr[l + 1] = (int)o;
+      }
     }
+    // panels of the leaf level: the contiguous head of the panel arena (the only part that is cleared)
+    arena_leaf = 0;
+    for (int q = level_ptr[0]; q < level_ptr[1]; q++) { const DsFrontDesc& f = fr[level_sn[q]]; arena_leaf = std::max(arena_leaf, f.off21 + (long long)f.bp * f.pp); }
+    level_maxld.assign(L, 0);
+    for (int l = 0; l < L; l++) for (int q = level_ptr[l]; q < level_ptr[l + 1]; q++) level_maxld[l] = std::max(level_maxld[l], fr[level_sn[q]].ld);
     lap(3);
     return build_con(cons, n_cons);
   }
@@ -271,7 +323,7 @@ struct DirectPlan {
   // destination of the 16 vertex-pair sub-blocks of every contact block, in the ORDER of `cons` (the engine appends constraints in
   // no fixed order: a plan found again for the same constraint SET only needs this map redone)
   int build_con(const int* cons, int n_cons) {
-    con_dst.assign((size_t)n_cons * 16, -1); con_ld.assign((size_t)n_cons * 16, 0);
+    con_dst.assign((size_t)n_cons * 16, -1); con_ld.assign((size_t)n_cons * 16, 0); con_lvl.assign((size_t)n_cons * 16, 0);
     for (int e = 0; e < n_cons; e++)
       for (int a = 0; a < 4; a++)
         for (int b = 0; b < 4; b++) {
@@ -279,8 +331,12 @@ struct DirectPlan {
           const int s = std::min(sym.sn_of[va], sym.sn_of[vb]);
           const int lr = local_dof(s, va), lc = local_dof(s, vb);
           if (lr < 0 || lc < 0) return -3;
-          con_dst[(size_t)e * 16 + a * 4 + b] = fr[s].off + (long long)lr * fr[s].ld + lc;
-          con_ld[(size_t)e * 16 + a * 4 + b] = fr[s].ld;
+          int ldq = 0;
+          const long long dst = panel_addr(fr[s], lr, lc, &ldq);   // one of the two vertices is an own vertex of front s
+          if (dst < 0) return -3;
+          con_dst[(size_t)e * 16 + a * 4 + b] = dst;
+          con_ld[(size_t)e * 16 + a * 4 + b] = ldq;
+          con_lvl[(size_t)e * 16 + a * 4 + b] = sym.level[s];
         }
     return 0;
   }

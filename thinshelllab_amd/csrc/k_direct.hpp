@@ -8,8 +8,10 @@
 //     the step kernel).  No pivoting: measured on the cfg4 operators (forward and un-projected adjoint) a nested-dissection LU with
 //     diagonal pivots reaches a 1e-10 relative residual.
 //   * G = W F12 and S = F22 - F21 G: K = pp GEMMs on the f64 matrix cores (v_mfma_f64_16x16x4_f64), the bulk of the flops.
-//   * S is never stored: the GEMM's epilogue adds it into the parent front through the child's boundary -> parent index map
-//     (extend-add, f64 atomics: siblings overlap).
+//   * extend-add as a GATHER on the parent's side (round 4): the Schur GEMM's epilogue forms S = sum_children ext(S_child) - F21 G
+//     -- reading the children's stored S through their tables over this front's dofs -- and STORES it; the parent's panels take
+//     their share in k_ds_extend_panels before the parent is factorised.  One writer per entry, fixed child order: no atomics, no
+//     cleared F22, bit-reproducible factors.
 // A solve is three matrix-vector passes per level (W, F21 upwards; G downwards), no triangular recurrences.
 #pragma once
 #include "direct_plan.hpp"
@@ -18,12 +20,15 @@
 typedef double ds_d4 __attribute__((ext_vector_type(4)));
 
 struct DsDev {                 // device views shared by the kernels
-  const DsFrontDesc* fr;
+  const DsFrontDesc* fr;       // by supernode id
+  const DsFrontDesc* frl;      // the same descriptors in level order: frl[i] = fr[level_sn[i]] (one load instead of two dependent ones)
   const int* level_sn;         // front ids, level after level
-  double* A;                   // front arena
+  double* A;                   // panel arena: top rows [F11 | F12] (row stride ld) and F21 (row stride pp) of every front
+  double* S;                   // Schur arena: S of every front (bp x bp, row stride bp)
   double* G;                   // G = W F12 of every front (pp x bp, row stride bp)
   double* scr;                 // per-level scratch (pivot-block inverses, row panel, column panel per front)
-  const int* rel;
+  const DsChildRec* ch;        // children of every front (DsFrontDesc.ch_off / nchild), ascending supernode id
+  const int* pmap;             // per child: table over the parent's local dofs -> the child's boundary dof, or -1
   const int* vtx;              // local vertex -> PERMUTED vertex position (rows of the solver vectors)
   int* bad;                    // [1..3]: perturbed pivots of the last factorisation by front size class, [4] + [8..]: log of the first ones
   double piv_tol;              // a pivot below piv_tol x its own scale is replaced by that bound
@@ -50,45 +55,42 @@ __global__ void k_ds_rownorm(int NV, const int* __restrict__ slice_off, const in
   if ((threadIdx.x & 63) == 0) atomicMax((unsigned long long*)out, (unsigned long long)__double_as_longlong(m));
 }
 
-// Background clear of the idle front arena (direct_prezero with two arenas): a small grid (gridDim.x workgroups, 16-byte stores) that
-// takes a millisecond instead of the 0.22 ms of a full-width memset, so that it runs NEXT to the engine stream's kernels instead of
-// in front of them (a memset fills every CU: measured serialised with whatever follows on the other streams).
-__global__ void __launch_bounds__(256) k_ds_clear(double* __restrict__ p, size_t n) {
-  double2* q = (double2*)p;
-  const size_t n2 = n >> 1;
-  for (size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x; i < n2; i += (size_t)gridDim.x * blockDim.x) q[i] = double2{0.0, 0.0};
-  if ((n & 1) && blockIdx.x == 0 && threadIdx.x == 0) p[n - 1] = 0.0;
-}
-
 // ---- assembly -------------------------------------------------------------------------------------------------------------
-// static pattern: block q of the CSR numbering lives at vals[csr2sell[q] + 64 e] (SELL-64, element e of the 3 x 3 block)
-__global__ void k_ds_assemble_blocks(long nnzb, const int* __restrict__ csr2sell, const double* __restrict__ vals, const long long* __restrict__ blk_dst,
-                                     const int* __restrict__ blk_ld, double* __restrict__ A) {
-  const long t = (long)blockIdx.x * blockDim.x + threadIdx.x;
-  if (t >= nnzb * 9) return;
-  const long q = t / 9;
-  const int e = (int)(t % 9);
-  const long long d = blk_dst[q];
-  if (d < 0) return;
-  A[d + (long long)(e / 3) * blk_ld[q] + e % 3] = vals[(size_t)csr2sell[q] + 64 * e];
-}
-// contact blocks: 16 vertex-pair sub-blocks per constraint (several constraints may share a vertex pair: atomics)
-__global__ void k_ds_assemble_contacts(int nc, const double* __restrict__ H, const long long* __restrict__ con_dst, const int* __restrict__ con_ld, double* __restrict__ A) {
-  const long t = (long)blockIdx.x * blockDim.x + threadIdx.x;
-  if (t >= (long)nc * 144) return;
-  const int c = (int)(t / 144), e = (int)(t % 144), r = e / 12, cc = e % 12;
-  const double v = H[t];
-  if (v == 0.0) return;
-  const int sub = (r / 3) * 4 + cc / 3;
-  const long long d = con_dst[(size_t)c * 16 + sub];
-  atomicAdd(&A[d + (long long)(r % 3) * con_ld[(size_t)c * 16 + sub] + cc % 3], v);
-}
-// identity on the padding of the pivot block
-__global__ void k_ds_pad_diag(int n_sn, const DsFrontDesc* __restrict__ fr, double* __restrict__ A) {
-  const int s = blockIdx.x;
-  if (s >= n_sn) return;
-  const DsFrontDesc f = fr[s];
-  for (int i = f.p + threadIdx.x; i < f.pp; i += blockDim.x) A[f.off + (long long)i * f.ld + i] = 1.0;
+// The matrix entries of ONE tree level go into the panels of its fronts when the level starts: the panels were just written -- cleared
+// (leaf level: the contiguous head of the panel arena) or stored by the gather of the children's Schur complements (k_ds_extend_panels)
+// --, so nothing above the leaves is ever cleared.  One launch per level, three thread ranges:
+//   * static pattern: block q = blk_q[i] of the CSR numbering lives at vals[csr2sell[q] + 64 e] (SELL-64, element e of the 3 x 3 block);
+//     every block has ONE destination: a plain add;
+//   * contact blocks: 16 vertex-pair sub-blocks per constraint, those whose destination front is on this level (several constraints
+//     may share a vertex pair: atomics);
+//   * identity on the padding of the pivot blocks.
+__global__ void k_ds_assemble_level(int i0, int nblk, const int* __restrict__ blk_q, const int* __restrict__ csr2sell, const double* __restrict__ vals,
+                                    const long long* __restrict__ blk_dst, const int* __restrict__ blk_ld, int nc, int level, const double* __restrict__ H,
+                                    const long long* __restrict__ con_dst, const int* __restrict__ con_ld, const int* __restrict__ con_lvl, int lv0, int nf,
+                                    const DsFrontDesc* __restrict__ frl, double* __restrict__ A) {
+  long t = (long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (t < (long)nblk * 9) {
+    const int q = blk_q[i0 + t / 9];
+    const int e = (int)(t % 9);
+    atomicAdd(&A[blk_dst[q] + (long long)(e / 3) * blk_ld[q] + e % 3], vals[(size_t)csr2sell[q] + 64 * e]);   // (atomic: a contact sub-block of this launch may target the same entry)
+    return;
+  }
+  t -= (long)nblk * 9;
+  if (t < (long)nc * 144) {
+    const int c = (int)(t / 144), e = (int)(t % 144), r = e / 12, cc = e % 12;
+    const int sub = (r / 3) * 4 + cc / 3;
+    if (con_lvl[(size_t)c * 16 + sub] != level) return;
+    const double v = H[t];
+    if (v == 0.0) return;
+    atomicAdd(&A[con_dst[(size_t)c * 16 + sub] + (long long)(r % 3) * con_ld[(size_t)c * 16 + sub] + cc % 3], v);
+    return;
+  }
+  t -= (long)nc * 144;
+  if (t < (long)nf * DS_T) {
+    const DsFrontDesc f = frl[lv0 + t / DS_T];
+    const int i = f.p + (int)(t % DS_T);
+    if (i < f.pp) A[f.off + (long long)i * f.ld + i] = 1.0;
+  }
 }
 
 // ---- blocked Gauss-Jordan on the top block rows ---------------------------------------------------------------------------
@@ -516,7 +518,7 @@ TSL_DEV double* ds_scr_C(const DsDev& D, const DsFrontDesc& f, int which) { retu
 // inverse of the first pivot block of every front of the batch -> P[0]
 __global__ void __launch_bounds__(256) k_ds_pivot0(DsDev D, int lv0) {
   __shared__ double T[DS_T][DS_T + 1];
-  const DsFrontDesc f = D.fr[D.level_sn[lv0 + blockIdx.x]];
+  const DsFrontDesc f = D.frl[lv0 + blockIdx.x];
   const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;
   const double* A = D.A + f.off;
 #pragma unroll
@@ -551,7 +553,7 @@ __global__ void __launch_bounds__(256) k_ds_gj_step(DsDev D, int lv0, int k, int
   const int L = blockIdx.x;
   int fz = L, bi = k + 1, bj = k + 1;
   if (L >= nf) { const int q = L - nf, t2 = tp * tp; fz = q / t2; const int t = q - fz * t2; bi = t / tp; bj = t - bi * tp; }
-  const DsFrontDesc f = D.fr[D.level_sn[lv0 + fz]];
+  const DsFrontDesc f = D.frl[lv0 + fz];
   const int pp = f.pp, k0 = k * DS_T;
   if (k0 >= pp) return;
   const bool has_next = k0 + DS_T < pp;
@@ -628,7 +630,7 @@ __global__ void __launch_bounds__(256) k_ds_gj_step(DsDev D, int lv0, int k, int
 }
 // side panels of the last block step back into the front: workgroup (b, front) copies row-panel chunk b and column-panel chunk b
 __global__ void __launch_bounds__(256) k_ds_gj_finish(DsDev D, int lv0) {
-  const DsFrontDesc f = D.fr[D.level_sn[lv0 + blockIdx.y]];
+  const DsFrontDesc f = D.frl[lv0 + blockIdx.y];
   const int pp = f.pp, b0 = blockIdx.x * DS_T;
   if (b0 >= pp) return;
   const int kl = pp / DS_T - 1;
@@ -702,7 +704,7 @@ __global__ void __launch_bounds__(256, WPC) k_ds_gj_flow(DsDev D, int lv0, DsFlo
   int z = 0;
   for (int step = DS_FLOW_MAXF / 2; step > 0; step >>= 1) { const int q = z + step; if (q < a.nf && L >= a.tile0[q]) z = q; }   // last front with tile0 <= L
   const int sn = D.level_sn[lv0 + z];
-  const DsFrontDesc f = D.fr[sn];
+  const DsFrontDesc f = D.frl[lv0 + z];
   const int nt = f.pp / DS_T, t = L - a.tile0[z], bi = t / nt, bj = t - bi * nt;
   const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;
   const int lane = threadIdx.x & 63, w = threadIdx.x >> 6, wi = w >> 1, wj = w & 1, lr = lane & 15, lk = lane >> 4;
@@ -813,7 +815,7 @@ __global__ void __launch_bounds__(256) k_ds_inv_small(DsDev D, int lv0, int ls) 
   extern __shared__ double ds_sm[];
   double* M = ds_sm;   // the block, row stride ls; the pivot tile of a step is inverted IN PLACE (no copy: at 96 pivots the block alone is 74.5 KB and
                        // two workgroups share a CU only without a separate tile buffer)
-  const DsFrontDesc f = D.fr[D.level_sn[lv0 + blockIdx.x]];
+  const DsFrontDesc f = D.frl[lv0 + blockIdx.x];
   const int pp = f.pp, nt = pp / DS_T;
   double* A = D.A + f.off;
   const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;
@@ -892,39 +894,35 @@ __global__ void __launch_bounds__(256) k_ds_inv_small(DsDev D, int lv0, int ls) 
 }
 
 // ---- the two GEMMs of a front on the f64 matrix cores -------------------------------------------------------------------------
-//   mode 0:  G = W F12            (pp x bp, K = pp)  into the G arena (row stride bp)
-//   mode 1:  S = F22 - F21 G      (bp x bp, K = pp)  in place
+//   mode 0:  G = W F12                               (pp x bp, K = pp)  into the G arena (row stride bp)
+//   mode 1:  S = sum_children ext(S_child) - F21 G   (bp x bp, K = pp)  into the Schur arena (row stride bp)
 // one 64 x 64 output tile per workgroup (four waves, each a 32 x 32 quadrant = 2 x 2 MFMA tiles), K in slabs of 32 through LDS.
 // LDS strides 33 / 65 doubles: the compiler fetches the operands with ds_read2_b64 (two doubles of one lane per instruction), which
 // is served in groups of 16 consecutive lanes against 32 four-byte banks: the 16 rows lr of the A operand must fall on 16 different
 // bank pairs, i.e. row stride == 1 (mod 16) doubles; the B operand's 16 lanes are contiguous.  (Strides 34 / 80, conflict-free
 // under the ds_read_b64 rule -- 32 lanes against 64 banks --, measured 25 % SQ_LDS_BANK_CONFLICT of SQ_LDS_IDX_ACTIVE.)
-// WPC = workgroups per CU the register allocation aims at (one wave of each per SIMD): 3 with the F22 tile of the Schur mode
-// prefetched before the product, 4 with that tile fetched in the epilogue ("direct_gemm_wpc").
-// Measured and dropped (round 2, cfg4 plan, per-batch replays): K slabs of 64 (half the barriers and load round trips, two
-// workgroups per CU: 2-4 % slower on every level), an XCD-aware workgroup -> tile map (each XCD a contiguous tile range: no change
-// on the levels above the leaves, the leaf batch 77 instead of 49 us) -- the launches are bound neither by the LDS nor by the L2.
+// WPC = workgroups per CU the register allocation aims at (one wave of each per SIMD): 4 by default ("direct_gemm_wpc"; 2 = two LDS
+// slab buffers with one barrier per slab, measured slower: what four workgroups hide is each other's prologues and epilogues).
+// Measured and dropped (round 2 / 3, cfg4 plan, per-batch replays; profiles/README.md): K slabs of 64, an XCD-aware workgroup -> tile
+// map, a capped persistent grid walking the tiles, skipping the products of quadrants outside the front, 128 x 128 tiles.
 #define DS_SK 32
-// part (Schur mode): 0 every tile; 1 only the tiles that reach the PARENT'S PIVOT BLOCK (rows and columns below f.bu: the boundary
-// of a front is sorted by elimination position, the parent's own dofs come first) -- what the parent's Gauss-Jordan chain waits
-// for; 2 the rest, which only the parent's GEMMs need.
+#define DS_GMC 8   // children of a front whose tables the Schur epilogue keeps in LDS per pass
 template <int mode, int WPC>
-TSL_DEV void ds_gemm_tile(const DsDev& D, int lv0, int bx, int by, int bz, int part) {
+TSL_DEV void ds_gemm_tile(const DsDev& D, int lv0, int bx, int by, int bz) {
   constexpr int SA = DS_SK + 1, SB = 64 + 1;
-  constexpr bool PF = WPC == 3;
-  constexpr int NB = WPC == 2 ? 2 : 1;   // WPC 2 ("direct_gemm_wpc" 2): two LDS slab buffers, ONE barrier per slab, two workgroups per CU
+  constexpr int NB = WPC == 2 ? 2 : 1;
   __shared__ double As[NB * 64 * SA];
   __shared__ double Bs[NB * DS_SK * SB];
-  const DsFrontDesc f = D.fr[D.level_sn[lv0 + bz]];
+  const DsFrontDesc f = D.frl[lv0 + bz];
   const int Mr = mode == 0 ? f.pp : f.bp, Nc = f.bp, K = f.pp;
   const int I0 = by * 64, J0 = bx * 64;
   if (I0 >= Mr || J0 >= Nc) return;
-  if (mode == 1 && part != 0) { const bool urgent = I0 < f.bu && J0 < f.bu; if (urgent != (part == 1)) return; }
-  double* F = D.A + f.off;
+  const double* F = D.A + f.off;
   double* G = D.G + f.goff;
   const int ld = f.ld, pp = f.pp;
-  const double* Am = mode == 0 ? F : F + (size_t)pp * ld;          // W rows / F21 rows, row stride ld
-  const double* Bm = mode == 0 ? F + pp : G;                          // F12 (row stride ld) / G (row stride bp)
+  const double* Am = mode == 0 ? F : D.A + f.off21;   // W rows (row stride ld) / F21 rows (row stride pp)
+  const int lda = mode == 0 ? ld : pp;
+  const double* Bm = mode == 0 ? F + pp : G;           // F12 (row stride ld) / G (row stride bp)
   const int ldb = mode == 0 ? ld : f.bp;
   const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
   const int wi = w >> 1, wj = w & 1;
@@ -936,27 +934,13 @@ TSL_DEV void ds_gemm_tile(const DsDev& D, int lv0, int bx, int by, int bz, int p
 #pragma unroll
     for (int b = 0; b < 2; b++) acc[a][b] = ds_d4{0.0, 0.0, 0.0, 0.0};
   const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;  // 32 x 8
-  // Schur mode: the F22 entries of this workgroup's tile are fetched before the product (their latency hides behind it)
-  double f22[2][2][4];
-  auto load_f22 = [&]() {
-#pragma unroll
-    for (int a = 0; a < 2; a++)
-#pragma unroll
-      for (int b = 0; b < 2; b++)
-#pragma unroll
-        for (int r = 0; r < 4; r++) {
-          const int row = I0 + 32 * wi + 16 * a + lk + 4 * r, col = J0 + 32 * wj + 16 * b + lr;
-          f22[a][b][r] = (f.nchild > 0 && row < f.b && col < f.b && D.dbg != 13) ? F[(size_t)(pp + row) * ld + pp + col] : 0.0;   // a leaf's F22 is zero: not read ("ds_dbg" 13, timing experiment: no front's is)
-        }
-  };
-  if (mode == 1 && PF) load_f22();
   // K loop, software-pipelined: the global loads of slab k + 1 are in flight (registers) while the matrix cores work on slab k in LDS
   double pa[8], pb0[4], pb1[4];
   auto gload = [&](int k0) {
 #pragma unroll
     for (int q = 0; q < 8; q++) {
       const int r = ty + 8 * q;
-      pa[q] = (r < 32 || rows_hi) ? Am[(size_t)(I0 + r) * ld + k0 + tx] : 0.0;
+      pa[q] = (r < 32 || rows_hi) ? Am[(size_t)(I0 + r) * lda + k0 + tx] : 0.0;
     }
 #pragma unroll
     for (int q = 0; q < 4; q++) {
@@ -965,8 +949,23 @@ TSL_DEV void ds_gemm_tile(const DsDev& D, int lv0, int bx, int by, int bz, int p
       pb1[q] = cols_hi ? Bm[(size_t)(k0 + r) * ldb + J0 + 32 + tx] : 0.0;
     }
   };
-  if (D.dbg == 6) { Am -= (size_t)I0 * ld; Bm -= J0; }   // timing experiments only: every workgroup streams the SAME operand tiles (cache-resident) ...
   gload(0);
+  // Schur mode: the rows / columns of this tile in the tables of the first DS_GMC children are requested now and parked in registers over
+  // the K loop (thread t: child t >> 7 and t >> 7 + 2 ..., table entry t & 127: 64 rows, then 64 columns); they go to LDS for the epilogue
+  constexpr int GMC = DS_GMC;
+  __shared__ int s_map[mode == 1 ? GMC : 1][128];
+  __shared__ long long s_soff[mode == 1 ? GMC : 1];
+  __shared__ int s_cbp[mode == 1 ? GMC : 1];
+  int pre[GMC / 2];
+  auto map_load = [&](int q) {   // this thread's entry of child q's table (q < nchild)
+    const int k = threadIdx.x & 127;
+    const int idx = k < 64 ? I0 + k : J0 + k - 64;
+    return idx < f.bp ? D.pmap[D.ch[f.ch_off + q].pmap_off + pp + idx] : -1;
+  };
+  if (mode == 1) {
+#pragma unroll
+    for (int h = 0; h < GMC / 2; h++) { const int q = 2 * h + (threadIdx.x >> 7); pre[h] = q < f.nchild ? map_load(q) : -1; }
+  }
   if (NB == 2) {
     auto fill = [&](int b) {
       double* Ab = As + b * 64 * SA; double* Bb = Bs + b * DS_SK * SB;
@@ -994,16 +993,12 @@ TSL_DEV void ds_gemm_tile(const DsDev& D, int lv0, int bx, int by, int bz, int p
     }
   } else
   for (int k0 = 0; k0 < (D.dbg == 12 ? DS_SK : K); k0 += DS_SK) {   // ("ds_dbg" 12, timing experiment: one slab only -- prologue + epilogue)
-    if (D.dbg < 11 || k0 == 0) {   // ("ds_dbg" 10 / 11, timing experiments: no barriers / no LDS refill either inside the K loop)
 #pragma unroll
-      for (int q = 0; q < 8; q++) As[(ty + 8 * q) * SA + tx] = pa[q];
+    for (int q = 0; q < 8; q++) As[(ty + 8 * q) * SA + tx] = pa[q];
 #pragma unroll
-      for (int q = 0; q < 4; q++) { Bs[(ty + 8 * q) * SB + tx] = pb0[q]; Bs[(ty + 8 * q) * SB + tx + 32] = pb1[q]; }
-    }
-    if (D.dbg < 10 || k0 == 0) __syncthreads();
-    if (k0 + DS_SK < K && D.dbg != 7 && D.dbg < 10) gload(k0 + DS_SK);   // ... (7) or none after the first slab: LDS + matrix cores + barriers alone
-    // (a wave whose 32 x 32 quadrant lies outside the front -- sizes are multiples of 32, tiles 64 wide -- multiplies zeros: skipping its
-    // products behind a wave-uniform branch was measured 2.5 % SLOWER on the Schur class, the branch disturbs the schedule of the loop)
+    for (int q = 0; q < 4; q++) { Bs[(ty + 8 * q) * SB + tx] = pb0[q]; Bs[(ty + 8 * q) * SB + tx + 32] = pb1[q]; }
+    __syncthreads();
+    if (k0 + DS_SK < K) gload(k0 + DS_SK);
 #pragma unroll
     for (int kk = 0; kk < DS_SK / 4; kk++) {
       const double a0 = As[(32 * wi + lr) * SA + 4 * kk + lk], a1 = As[(32 * wi + 16 + lr) * SA + 4 * kk + lk];
@@ -1013,7 +1008,7 @@ TSL_DEV void ds_gemm_tile(const DsDev& D, int lv0, int bx, int by, int bz, int p
       acc[1][0] = __builtin_amdgcn_mfma_f64_16x16x4f64(a1, b0, acc[1][0], 0, 0, 0);
       acc[1][1] = __builtin_amdgcn_mfma_f64_16x16x4f64(a1, b1, acc[1][1], 0, 0, 0);
     }
-    if (D.dbg < 10) __syncthreads();
+    __syncthreads();
   }
   if (mode == 0) {
 #pragma unroll
@@ -1027,39 +1022,105 @@ TSL_DEV void ds_gemm_tile(const DsDev& D, int lv0, int bx, int by, int bz, int p
         }
     return;
   }
-  // Schur complement: S is needed by nobody but the parent front, so the entries go straight into it through the child's
-  // boundary -> parent index map (extend-add; f64 atomics: sibling fronts overlap) instead of being stored and re-read
+  // Schur complement: S = F22 - F21 G with F22 = the children's Schur complements extended to this front, gathered here (F22 is never
+  // materialised) child after child in the fixed order of the plan; S is stored once, coalesced, for the parent to gather in turn.
   if (f.parent < 0) return;
-  if (!PF) load_f22();
-  const DsFrontDesc pf = D.fr[f.parent];
-  double* PA = D.A + pf.off;
-  const int* rel = D.rel + f.rel_off;
+  double s22[2][2][4];
 #pragma unroll
-  for (int b = 0; b < 2; b++) {
-    const int col = J0 + 32 * wj + 16 * b + lr;
-    if (col >= f.b) continue;
-    const int rj = rel[col / 3];
-    const int pj = (rj & DS_REL_MASK) + col % 3;
-    const bool bj = pj >= pf.pp, ej = (rj & DS_REL_EXCL) != 0;   // column vertex in the parent's boundary part / seen by this child only
+  for (int a = 0; a < 2; a++)
 #pragma unroll
-    for (int a = 0; a < 2; a++)
+    for (int b = 0; b < 2; b++)
 #pragma unroll
-      for (int r = 0; r < 4; r++) {
-        const int row = I0 + 32 * wi + 16 * a + lk + 4 * r;
-        if (row >= f.b) continue;
-        const double v = f22[a][b][r] - acc[a][b][r];
-        const int ri = rel[row / 3];
-        const int pi = (ri & DS_REL_MASK) + row % 3;
-        double* dst = &PA[(size_t)pi * pf.ld + pj];
-        if (D.dbg == 2) { if (v != 0.0) *dst += v; }            // timing experiment only (racy)
-        else if (D.dbg == 3) { if (v == 1e300) PA[0] = v; }     // no extend-add at all
-        else if (v != 0.0) {
-          // single writer and nothing assembled underneath (both vertices in the parent's boundary part, one of them in no sibling's
-          // boundary): a plain store into the zeroed arena; everything else adds atomically (siblings overlap on the separators)
-          if (D.dbg != 5 && bj && pi >= pf.pp && (ej || (ri & DS_REL_EXCL))) *dst = v;
-          else atomicAdd(dst, v);
+      for (int r = 0; r < 4; r++) s22[a][b][r] = 0.0;
+  const int row0 = I0 + 32 * wi + lk, col0 = J0 + 32 * wj + lr;   // + 16 a + 4 r / + 16 b
+  for (int q0 = 0; q0 < f.nchild; q0 += GMC) {
+    const int nq = min(GMC, f.nchild - q0);
+    if (q0 > 0) __syncthreads();   // (more than DS_GMC children: further passes load their tables here)
+#pragma unroll
+    for (int h = 0; h < GMC / 2; h++) {
+      const int q = 2 * h + (threadIdx.x >> 7);
+      if (q < nq) s_map[q][threadIdx.x & 127] = q0 == 0 ? pre[h] : map_load(q0 + q);
+    }
+    if ((int)threadIdx.x < nq) { const DsChildRec c = D.ch[f.ch_off + q0 + threadIdx.x]; s_soff[threadIdx.x] = c.soff; s_cbp[threadIdx.x] = c.bp; }
+    __syncthreads();
+    if (D.dbg == 13) continue;   // ("ds_dbg" 13, timing experiment: no gather)
+    for (int q = 0; q < nq; q++) {   // ascending child order: the fixed summation order
+      const double* Sc = D.S + s_soff[q];
+      const int cbp = s_cbp[q];
+      const int cj0 = s_map[q][64 + 32 * wj + lr], cj1 = s_map[q][64 + 32 * wj + 16 + lr];
+#pragma unroll
+      for (int a = 0; a < 2; a++)
+#pragma unroll
+        for (int r = 0; r < 4; r++) {
+          const int ci = s_map[q][32 * wi + 16 * a + lk + 4 * r];
+          if (ci < 0) continue;
+          const double* Srow = Sc + (size_t)ci * cbp;
+          if (cj0 >= 0) s22[a][0][r] += Srow[cj0];
+          if (cj1 >= 0) s22[a][1][r] += Srow[cj1];
         }
+    }
+  }
+  double* Sf = D.S + f.soff;
+#pragma unroll
+  for (int a = 0; a < 2; a++)
+#pragma unroll
+    for (int r = 0; r < 4; r++) {
+      const int row = row0 + 16 * a + 4 * r;
+      if (row >= f.b) continue;
+#pragma unroll
+      for (int b = 0; b < 2; b++) {
+        const int col = col0 + 16 * b;
+        if (col < f.b) Sf[(size_t)row * f.bp + col] = s22[a][b][r] - acc[a][b][r];
       }
+    }
+}
+
+// The panels of the fronts of a level (F11, F12, F21) are WRITTEN here when the level starts: entry (i, j) = sum over the children, in
+// the plan's fixed order, of S_child[pmap_child[i]][pmap_child[j]] -- the part of the extend-add that lands on the panels --, zero where
+// no child reaches; the level's matrix entries are added right after (k_ds_assemble_level).  Every entry has one writer and is written
+// once: no atomics, no cleared memory, a fixed summation order.  Work item of a wave: one row x DS_XU chunks of 64 columns; lane q looks
+// the row up in child q's table, a ballot gives the children that reach the row (usually one or two), then DS_XU independent table
+// and S loads per lane and child are in flight.  Row r < pp is a top row (columns 0 .. ld), row r >= pp a row of F21 (columns 0 .. pp).
+#define DS_XROWS 8
+#define DS_XU 4
+#define DS_XMAXC 64   // children per pass of the table look-up (fronts with more take several passes)
+__global__ void __launch_bounds__(256) k_ds_extend_panels(DsDev D, int lv0, int ncc) {   // ncc: column chunks (of 64 DS_XU) of the widest front
+  const DsFrontDesc f = D.frl[lv0 + blockIdx.y];
+  const int rb = blockIdx.x / ncc, cc = blockIdx.x - rb * ncc;
+  const int r0 = rb * DS_XROWS, j0 = cc * (64 * DS_XU);
+  if (r0 >= f.ld || j0 >= f.ld) return;
+  const int lane = threadIdx.x & 63, w = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  const DsChildRec* ch = D.ch + f.ch_off;
+  for (int rr = w; rr < DS_XROWS; rr += 4) {
+    const int r = r0 + rr;
+    if (r >= f.ld) break;
+    const bool top = r < f.pp;
+    double* row = top ? D.A + f.off + (size_t)r * f.ld : D.A + f.off21 + (size_t)(r - f.pp) * f.pp;
+    const int ncol = top ? f.ld : f.pp;
+    if (j0 >= ncol) continue;
+    double v[DS_XU];
+#pragma unroll
+    for (int u = 0; u < DS_XU; u++) v[u] = 0.0;
+    for (int q0 = 0; q0 < f.nchild; q0 += DS_XMAXC) {
+      const int nq = min(DS_XMAXC, f.nchild - q0);
+      int my_ci = -1, my_off = 0, my_bp = 0;
+      long long my_soff = 0;
+      if (lane < nq) { const DsChildRec c = ch[q0 + lane]; my_off = c.pmap_off; my_bp = c.bp; my_soff = c.soff; my_ci = D.pmap[c.pmap_off + r]; }
+      for (unsigned long long m = __ballot(my_ci >= 0); m != 0; m &= m - 1) {   // ascending child order: the fixed summation order
+        const int q = __builtin_ctzll(m);
+        const int ci = __builtin_amdgcn_readlane(my_ci, q), off = __builtin_amdgcn_readlane(my_off, q), cbp = __builtin_amdgcn_readlane(my_bp, q);
+        const long long so = ((long long)__builtin_amdgcn_readlane((int)(my_soff >> 32), q) << 32) | (unsigned)__builtin_amdgcn_readlane((int)my_soff, q);
+        const int* pm = D.pmap + off;
+        const double* Srow = D.S + so + (size_t)ci * cbp;
+        int cj[DS_XU];
+#pragma unroll
+        for (int u = 0; u < DS_XU; u++) { const int j = j0 + 64 * u + lane; cj[u] = j < ncol ? pm[j] : -1; }
+#pragma unroll
+        for (int u = 0; u < DS_XU; u++) if (cj[u] >= 0) v[u] += Srow[cj[u]];
+      }
+    }
+#pragma unroll
+    for (int u = 0; u < DS_XU; u++) { const int j = j0 + 64 * u + lane; if (j < ncol) row[j] = v[u]; }
   }
 }
 
@@ -1071,7 +1132,7 @@ __global__ void __launch_bounds__(256) k_ds_gemm_g32(DsDev D, int lv0) {
   constexpr int SA = DS_SK + 1, SB = 32 + 1;
   __shared__ double As[32 * SA];
   __shared__ double Bs[DS_SK * SB];
-  const DsFrontDesc f = D.fr[D.level_sn[lv0 + blockIdx.z]];
+  const DsFrontDesc f = D.frl[lv0 + blockIdx.z];
   const int Mr = f.pp, Nc = f.bp, K = f.pp;
   const int I0 = blockIdx.y * 32, J0 = blockIdx.x * 32;
   if (I0 >= Mr || J0 >= Nc) return;
@@ -1108,20 +1169,8 @@ __global__ void __launch_bounds__(256) k_ds_gemm_g32(DsDev D, int lv0) {
 }
 
 template <int mode, int WPC>
-__global__ void __launch_bounds__(256, WPC) k_ds_gemm(DsDev D, int lv0, int part) {
-  ds_gemm_tile<mode, WPC>(D, lv0, blockIdx.x, blockIdx.y, blockIdx.z, part);
-}
-// The same tiles from a CAPPED grid: gridDim.x workgroups walk the (gx, gy, gz) tile space.  Launched with fewer workgroups than
-// the chip holds, it leaves room on every CU for the dependent block-step launches of the next level's Gauss-Jordan chain, which
-// run next to it on the engine stream (direct_factor: the deferred part of a level's Schur complements).
-template <int mode, int WPC>
-__global__ void __launch_bounds__(256, WPC) k_ds_gemm_capped(DsDev D, int lv0, int gx, int gy, int gz, int part) {
-  const int T = gx * gy * gz;
-  for (int t = blockIdx.x; t < T; t += gridDim.x) {
-    const int bx = t % gx, q = t / gx;
-    ds_gemm_tile<mode, WPC>(D, lv0, bx, q % gy, q / gy, part);
-    __syncthreads();   // the next tile overwrites the LDS slabs
-  }
+__global__ void __launch_bounds__(256, WPC) k_ds_gemm(DsDev D, int lv0) {
+  ds_gemm_tile<mode, WPC>(D, lv0, blockIdx.x, blockIdx.y, blockIdx.z);
 }
 
 // ---- solve ----------------------------------------------------------------------------------------------------------------
@@ -1132,16 +1181,16 @@ __global__ void __launch_bounds__(256, WPC) k_ds_gemm_capped(DsDev D, int lv0, i
 //   mode 2 (down, G):  x[own i]  = t[own i] - sum_j G[i, j] x[bnd j]  (x and t may alias)
 #define DS_VCHUNK 2048
 // one chunk of 16 rows of one front in one mode of the level sweeps: 0  z_own = W w_own;  1  w_bnd -= F21 z_own (atomic: several fronts
-// share a boundary dof);  2  z_own -= G z_bnd.  FLOW: the vectors are exchanged between workgroups of ONE launch (k_ds_sweep_flow):
-// agent-scope loads and write-through stores instead of cached ones.
+// share a boundary dof);  2  z_own -= G z_bnd.  (FLOW: agent-scope loads and write-through stores -- the form a one-launch sweep with
+// chained phases needs; measured slower than the 28 launches it replaces, profiles/README.md -- not instantiated.)
 template <bool FLOW>
 TSL_DEV void ds_gemv_chunk(const DsDev& D, int sn, int r0, int mode, const double* vin, double* vout, double* xs) {
   const DsFrontDesc f = D.fr[sn];
   const int nrows = mode == 1 ? f.b : f.p, ncols = mode == 2 ? f.b : f.p;
   const int* vt = D.vtx + f.vtx_off;
   const int in_v0 = mode == 2 ? f.nv_own : 0, out_v0 = mode == 1 ? f.nv_own : 0;
-  const double* M = mode == 2 ? D.G + f.goff : D.A + f.off + (mode == 1 ? (size_t)f.pp * f.ld : 0);
-  const int rs = mode == 2 ? f.bp : f.ld;
+  const double* M = mode == 2 ? D.G + f.goff : D.A + (mode == 1 ? f.off21 : f.off);
+  const int rs = mode == 2 ? f.bp : (mode == 1 ? f.pp : f.ld);
   const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
   double acc[4] = {0.0, 0.0, 0.0, 0.0};
   // the four rows of a wave advance together and the column loop is unrolled: 16 independent loads in flight per wave (one row at
@@ -1199,8 +1248,8 @@ __global__ void __launch_bounds__(256) k_ds_gemv_wide(DsDev D, const int* __rest
   if (r0 >= nrows) return;
   const int* vt = D.vtx + f.vtx_off;
   const int in_v0 = mode == 2 ? f.nv_own : 0, out_v0 = mode == 1 ? f.nv_own : 0;
-  const double* M = mode == 2 ? D.G + f.goff : D.A + f.off + (mode == 1 ? (size_t)f.pp * f.ld : 0);
-  const int rs = mode == 2 ? f.bp : f.ld;
+  const double* M = mode == 2 ? D.G + f.goff : D.A + (mode == 1 ? f.off21 : f.off);
+  const int rs = mode == 2 ? f.bp : (mode == 1 ? f.pp : f.ld);
   const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
   double acc[4] = {0.0, 0.0, 0.0, 0.0};
   const double* row0 = M + (size_t)min(r0, nrows - 1) * rs;
@@ -1230,46 +1279,5 @@ __global__ void __launch_bounds__(256) k_ds_gemv_wide(DsDev D, const int* __rest
       else if (mode == 1) atomicAdd(&vout[o], -a);
       else vout[o] = vout[o] - a;
     }
-  }
-}
-
-// The sweeps of the upper tree levels ("direct_sweep_flow" = first level) as ONE launch: the chunks of every phase -- level l upwards
-// in modes 0 and 1, then downwards in mode 2 -- in dependency order in one grid; a workgroup waits until the phase before its own is
-// complete.  Workgroups are dispatched in index order, so whatever a workgroup waits for is resident or done (no residency
-// condition, unlike k_ds_gj_flow).  Completion: the workgroup's stores and atomics are acknowledged (vmcnt(0)), then it takes a ticket
-// of its front's counter; the last of a front raises the phase counter (two levels: no counter sees more than ~130 arrivals).
-// The launches these phases replace take 7-15 us each with 1 - 132 fronts per level.
-#define DS_SWEEP_MAXP 40
-#define DS_SWEEP_ABORT 6
-struct DsSweepArgs {
-  int np;
-  int start[DS_SWEEP_MAXP + 1];   // first workgroup of phase p
-  int wl0[DS_SWEEP_MAXP];         // its first work-list entry
-  int mode[DS_SWEEP_MAXP];
-  int nfront[DS_SWEEP_MAXP];      // fronts with chunks in the phase (arrivals at the phase counter)
-};
-__global__ void __launch_bounds__(256) k_ds_sweep_flow(DsDev D, const int* __restrict__ wl_front, const int* __restrict__ wl_row, DsSweepArgs a, int* __restrict__ fcnt,
-                                                       int* __restrict__ pcnt, int n_sn, double* w, double* z) {
-  __shared__ double xs[DS_VCHUNK];
-  __shared__ int s_dead;
-  const int L = blockIdx.x;
-  int p = 0;
-  for (int step = 32; step > 0; step >>= 1) { const int q = p + step; if (q < a.np && L >= a.start[q]) p = q; }
-  const int mode = a.mode[p], e = a.wl0[p] + (L - a.start[p]);
-  const int sn = wl_front[e], r0 = wl_row[e];
-  if (threadIdx.x == 0) {
-    s_dead = 0;
-    if (p > 0) ds_flow_poll(pcnt + 32 * (p - 1), a.nfront[p - 1], D.bad + DS_SWEEP_ABORT, &s_dead);
-  }
-  __syncthreads();
-  if (!s_dead) ds_gemv_chunk<true>(D, sn, r0, mode, mode == 0 ? w : z, mode == 1 ? w : z, xs);
-  __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
-  __builtin_amdgcn_s_waitcnt(0);
-  __syncthreads();
-  if (threadIdx.x == 0) {
-    const DsFrontDesc f = D.fr[sn];
-    const int nwg = ((mode == 1 ? f.b : f.p) + 15) / 16;
-    const int ticket = __hip_atomic_fetch_add(fcnt + (size_t)p * n_sn + sn, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    if (ticket == nwg - 1) __hip_atomic_fetch_add(pcnt + 32 * p, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
   }
 }

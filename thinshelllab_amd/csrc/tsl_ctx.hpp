@@ -105,9 +105,10 @@ struct DsPlanSlot {
   uint64_t key = 0;
   long stamp = 0;
   bool used = false;
-  DevBuf<int> level_sn, rel, vtx, blk_ld, con_ld, wl_front, wl_row;
+  DevBuf<int> level_sn, pmap, vtx, blk_ld, con_ld, wl_front, wl_row, blk_q, con_lvl;
   DevBuf<long long> blk_dst, con_dst;
-  DevBuf<DsFrontDesc> fr;
+  DevBuf<DsFrontDesc> fr, frl;
+  DevBuf<DsChildRec> ch_rec;
 };
 struct DirectSolver {
   int enable = -1;          // -1 auto (cloth grids of >= 1024 cells: the iterative hierarchy is probed first, the factorisation takes over when it fails), 0 off, 1 always
@@ -118,45 +119,19 @@ struct DirectSolver {
   bool prezero_pending = false;
   size_t prezero_n = 0;
   int prezero = 1;          // "direct_prezero"
-  // "direct_two_arenas" (off): factorisations alternate between two front arenas; the one just released is cleared by a throttled
-  // kernel ("direct_clear_wgs" workgroups) during the NEXT Newton iteration while that iteration factorises into the other one.
-  // Measured (round 3, driver's command): 305.9 / 311.3 ms per step with two arenas and 64 workgroups, 305.6 with 128, 321.2 with 32,
-  // against 304.0 with the single arena -- the 1.6 GB of writes cost the same memory time next to the other kernels as in front of them
-  DevBuf<double> arena_b;
-  bool b_pending = false;   // arena_b is clean or being cleared (ev_zero_b)
-  size_t b_n = 0;
-  hipEvent_t ev_zero_b = nullptr;
-  int two_arenas = 0, clear_wgs = 64;
-  int clear_chunks = 1;     // "direct_clear_chunks": pieces of the side-stream clear of the front arena (direct_prezero); measured 16 / 8 pieces: 307-311 ms per step against 306-307 with one
   hipStream_t fstream[2] = {nullptr, nullptr};   // batches of one level run next to each other (direct_factor)
   hipEvent_t ev_ffork = nullptr, ev_fjoin[2] = {nullptr, nullptr};
   int par_batches = 1;      // "direct_par_batches"
-  hipStream_t gstream = nullptr;   // deferred Schur tiles (direct_factor, "direct_overlap")
-  hipEvent_t ev_g[8] = {}, ev_def = nullptr;
-  // "direct_overlap" (off), "direct_overlap_cap" (workgroups of the capped grid), "direct_overlap_fronts".  Measured on cfg4 (round 3, kernel trace +
-  // four A/B runs of the driver's command): the deferred tiles run 1.8x slower from the capped grid and the block steps next to them 1.3-1.6x
-  // slower (219 instead of 134 us for the 8 steps of 16 fronts): every level takes as long as before, 309-311 against 305-306 ms per step --
-  // the block steps are not idle time that other work can fill, their 1024 workgroups keep the memory system busy
-  int overlap = 0, overlap_cap = 512, overlap_max_fronts = 160;
   // "direct_flow": block steps of a batch alone on its level as one persistent dataflow launch (k_ds_gj_flow)
   int flow = 3, flow_cap[2] = {0, 0}, flow_epoch = 0;   // flow_cap: resident workgroups of the 4 / 5-per-CU instantiations
-  long n_flow = 0;
+  long n_flow = 0, n_flow_abort = 0;   // dataflow launches / launches that lost a flag (the solve then refactorises on the block-step path)
   DevBuf<double> flow_x;    // exchange slots (pivot inverses, row / column panel tiles)
   DevBuf<int> flow_f;       // their flags (epoch of the launch that published the slot)
-  // "direct_sweep_flow" = L0 > 0 (experiment, off): the sweeps of the tree levels >= L0 inside ONE launch (k_ds_sweep_flow), phases chained by
-  // ticket counters.  Measured on cfg4 (scripts/exp_sweep.py): one application 404 us in 28 launches against 572 / 511 / 478 / 454 / 427 us
-  // with L0 = 1 .. 5, same answer -- a phase hop (stores acknowledged, ticket with return, phase counter, poll, uncached vector loads)
-  // costs more than the 7-14 us launches of the upper levels, unlike the Gauss-Jordan chain where the tile stays in registers
-  int sweep_flow = 0;
-  long n_sweep_flow = 0;
-  DevBuf<int> sweep_cnt;    // its phase counters (one per 128 B) and per-front tickets, cleared per application
-  int clear_kernel = 0, zstream_skip = 0;   // experiments on the exposed arena clear: own kernel instead of hipMemsetAsync; dummy streams created before the clear's stream
   int gemv_wide_below = 300;   // "direct_gemv_wide_below": a sweep launch of fewer 16-row chunks than this runs four narrow workgroups per chunk (k_ds_gemv_wide; 0 = never).
                                // cfg4, one application: 404 us without, 385 / 380 / 387 / 388 / 409 / 523 us at 150 / 300 / 600 / 1200 / 2400 / always (scripts/exp_gemv_wide.py)
   int g32_below = 1100;     // "direct_g32_below": G = W F12 of a batch with fewer 64 x 64 tiles than this runs in the 32 x 32-tile kernel (k_ds_gemm_g32; 0 = never).
                             // cfg4: 52 -> 34, 67 -> 52, 37 -> 32 us on the three top levels with boundaries; the batches of 1150+ tiles lose (31 -> 33 us)
-  int gemm_persist = 0;     // "direct_gemm_persist": > 0 = the GEMM launches use at most this many workgroups, each walking several tiles (experiment)
-  int gemm_wpc = 4;         // "direct_gemm_wpc": workgroups per CU the GEMM kernels are compiled for (3: F22 tile prefetched, 4: fetched in the epilogue)
+  int gemm_wpc = 4;         // "direct_gemm_wpc": workgroups per CU the GEMM kernels are compiled for (4; 2 = two LDS slab buffers, one barrier per slab: measured slower)
   bool cons_checked = false; // the constraint list has not changed since direct_plan last looked (reset by tsl_contact_detect)
   double* h_anorm = nullptr; // pinned: |H|_inf of the last factorisation (valid after the next stream synchronisation)
   int bench_batch = -1;     // tsl_bench_direct: restrict the replay to one batch (-1: all)
@@ -187,10 +162,11 @@ struct DirectSolver {
   std::vector<int> h_cons;    // constraint vertices the current plan's contact map was built for (engine order)
   std::vector<int> h_cset;    // the same constraints as a sorted set: what tree, fronts and static maps depend on
   bool plan_valid = false;
-  DevBuf<int> csr2sell, level_sn, rel, vtx, blk_ld, con_ld, bad, wl_front, wl_row;
+  DevBuf<int> csr2sell, level_sn, pmap, vtx, blk_ld, con_ld, bad, wl_front, wl_row, blk_q, con_lvl;
   DevBuf<long long> blk_dst, con_dst;
-  DevBuf<DsFrontDesc> fr;
-  DevBuf<double> arena, garena, scr, w;
+  DevBuf<DsFrontDesc> fr, frl;   // front descriptors by supernode id / in level order
+  DevBuf<DsChildRec> ch_rec;
+  DevBuf<double> arena, sarena, garena, scr, w;   // panel arena (cleared per factorisation), Schur arena (never cleared), G arena
   long n_plans = 0, n_factor = 0, n_apply = 0, n_perturbed = 0;
   double t_plan = 0;          // host seconds spent in plan builds
   double anorm = 0;           // infinity norm of the factorised operator's static part (backward-error yardstick)

@@ -357,8 +357,6 @@ extern "C" void tsl_ctx_destroy(tsl_ctx* c) {
   if (c->ds.ev_ffork) (void)hipEventDestroy(c->ds.ev_ffork);
   if (c->ds.h_anorm) (void)hipHostFree(c->ds.h_anorm);
   if (c->h_ir) (void)hipHostFree(c->h_ir);
-  if (c->ds.gstream) { (void)hipStreamSynchronize(c->ds.gstream); for (int k = 0; k < 8; k++) (void)hipEventDestroy(c->ds.ev_g[k]); (void)hipEventDestroy(c->ds.ev_def); (void)hipStreamDestroy(c->ds.gstream); }
-  if (c->ds.ev_zero_b) (void)hipEventDestroy(c->ds.ev_zero_b);
   if (c->ds.zstream) { (void)hipStreamSynchronize(c->ds.zstream); (void)hipEventDestroy(c->ds.ev_zfork); (void)hipEventDestroy(c->ds.ev_zero); (void)hipStreamDestroy(c->ds.zstream); }
   if (c->ev_fork) (void)hipEventDestroy(c->ev_fork);
   if (c->ev_join) (void)hipEventDestroy(c->ev_join);
@@ -401,9 +399,6 @@ extern "C" int tsl_set_param(tsl_ctx* c, const char* key, double v) {
   else if (k == "direct_lag") c->ds.lag = (int)v;
   else if (k == "direct_refine") c->ds.refine_ir = (int)v;
   else if (k == "direct_small_rounds") { ds_small_rounds = std::max(1, (int)v); c->ds.plan_valid = false; c->ds.numeric_valid = false; c->ds.cache.clear(); }
-  else if (k == "direct_overlap") c->ds.overlap = (int)v;
-  else if (k == "direct_overlap_cap") c->ds.overlap_cap = std::max(0, (int)v);
-  else if (k == "direct_overlap_fronts") c->ds.overlap_max_fronts = (int)v;
   else if (k == "direct_plan_cache") { c->ds.cache_cap = std::max(0, (int)v); c->ds.cache.clear(); }
   else if (k == "tet_warm") c->tet_warm = (int)v;
   else if (k == "cloth_gather") c->cloth_gather = (int)v;
@@ -411,16 +406,9 @@ extern "C" int tsl_set_param(tsl_ctx* c, const char* key, double v) {
   else if (k == "direct_fallback_cap") c->ds.fallback_cap = (int)v;
   else if (k == "ds_bench_batch") c->ds.bench_batch = (int)v;
   else if (k == "direct_prezero") c->ds.prezero = (int)v;
-  else if (k == "direct_two_arenas") c->ds.two_arenas = (int)v;
-  else if (k == "direct_gemm_persist") c->ds.gemm_persist = std::max(0, (int)v);
   else if (k == "direct_flow") c->ds.flow = std::max(0, (int)v);
   else if (k == "direct_gemv_wide_below") c->ds.gemv_wide_below = std::max(0, (int)v);
   else if (k == "direct_g32_below") c->ds.g32_below = std::max(0, (int)v);
-  else if (k == "direct_clear_kernel") c->ds.clear_kernel = (int)v != 0;
-  else if (k == "direct_zstream_skip") c->ds.zstream_skip = std::max(0, (int)v);
-  else if (k == "direct_sweep_flow") c->ds.sweep_flow = std::max(0, (int)v);
-  else if (k == "direct_clear_chunks") c->ds.clear_chunks = std::max(1, (int)v);
-  else if (k == "direct_clear_wgs") c->ds.clear_wgs = std::max(1, (int)v);
   else if (k == "direct_par_batches") c->ds.par_batches = (int)v;
   else if (k == "direct_gemm_wpc") c->ds.gemm_wpc = (int)v;
   else if (k == "direct_merge_sep") { c->ds.plan.sym.merge_sep = (int)v; c->ds.static_ready = false; c->ds.plan_valid = false; c->ds.numeric_valid = false; }
@@ -1172,26 +1160,20 @@ static int solve_perm(tsl_ctx* c, tsl_solve_stats* st) {
       } else rc_g = gmres(c, &sd, true);
       d.gm_cap = 0;
       if (rc_g) return -1;
-      if (sd.flag != 1 && d.sweep_flow && d.n_sweep_flow > 0) {
-        int ab = 0;
-        HIP_OK(hipMemcpy(&ab, d.bad.p + DS_SWEEP_ABORT, sizeof(int), hipMemcpyDeviceToHost));
-        if (ab) {
-          fprintf(stderr, "[tsl] k_ds_sweep_flow: a workgroup waited in vain for the phase before it: \"direct_sweep_flow\" disabled for this context, solving again\n");
-          d.sweep_flow = 0;
-          TSL_TRY(direct_factor(c));
-          sd = *st; c->last_xmax_valid = false;
-          TSL_TRY(gmres(c, &sd, true));
-        }
-      }
-      if (sd.flag != 1 && d.flow && d.n_flow > 0) {   // a dataflow launch that lost a flag leaves garbage factors: say so, go back to the launch-per-block-step path
+      if ((sd.flag != 1 || d.dbg == 21) && d.flow && d.n_flow > 0) {   // a dataflow launch that lost a flag leaves garbage factors: say so, go back to the launch-per-block-step path
         int ab = 0;
         HIP_OK(hipMemcpy(&ab, d.bad.p + DS_FLOW_ABORT, sizeof(int), hipMemcpyDeviceToHost));
-        if (ab) {
+        if (ab || d.dbg == 21) {   // ("ds_dbg" 21: tests force this branch)
           fprintf(stderr, "[tsl] k_ds_gj_flow: a workgroup waited in vain for a flag (launch not resident as a whole?): \"direct_flow\" disabled for this context, refactorising\n");
-          d.flow = 0;
+          d.flow = 0; d.n_flow_abort++;
+          d.numeric_valid = false; d.have_factor = false;   // the factors in place are garbage: direct_factor must not return early
+          if (d.prezero_pending) { HIP_OK(hipStreamWaitEvent(c->stream, d.ev_zero, 0)); d.prezero_pending = false; }
           TSL_TRY(direct_factor(c));
           sd = *st; c->last_xmax_valid = false;
-          TSL_TRY(gmres(c, &sd, true));
+          if (d.refine_ir) {
+            TSL_TRY(direct_refine(c, &sd));
+            if (sd.flag != 1) { const int it0 = sd.iters; sd = *st; c->last_xmax_valid = false; TSL_TRY(gmres(c, &sd, true)); sd.iters += it0; }
+          } else TSL_TRY(gmres(c, &sd, true));
         }
       }
       if (stale) {
@@ -2230,7 +2212,21 @@ extern "C" int tsl_direct_info(tsl_ctx* c, double* out10) {
   if (d.bad.p) HIP_OK(hipMemcpy(bad, d.bad.p, sizeof(bad), hipMemcpyDeviceToHost));
   out10[0] = (double)d.n_plans; out10[1] = (double)d.n_factor; out10[2] = (double)d.n_apply; out10[3] = bad[1] + bad[2] + bad[3]; out10[4] = d.t_plan;
   out10[5] = d.plan_valid ? d.plan.sym.n_sn : 0; out10[6] = d.plan_valid ? d.plan.n_levels : 0; out10[7] = d.plan_valid ? (double)d.plan.batches.size() : 0;
-  out10[8] = d.plan_valid ? d.plan.flops : 0; out10[9] = d.plan_valid ? 8.0 * (double)d.plan.arena : 0;
+  out10[8] = d.plan_valid ? d.plan.flops : 0; out10[9] = d.plan_valid ? 8.0 * (double)(d.plan.arena + d.plan.sarena) : 0;
+  return 0;
+}
+// further counters of the direct path, the first n of: {dataflow launches (k_ds_gj_flow), dataflow launches that lost a flag and were redone
+// on the block-step path, plans found in the plan cache, bytes of the panel arena (cleared per factorisation), bytes of the Schur arena,
+// bytes of the G arena, entries of Schur complements stored per factorisation, plans parked in the cache}
+extern "C" int tsl_direct_counters(tsl_ctx* c, double* out, int32_t n) {
+  const DirectSolver& d = c->ds;
+  double e = 0;
+  if (d.plan_valid) for (const DsFrontDesc& f : d.plan.fr) e += (double)f.b * f.b;
+  size_t parked = 0;
+  for (const auto& sl : d.cache) parked += sl->used ? 1 : 0;
+  const double v[8] = {(double)d.n_flow, (double)d.n_flow_abort, (double)d.n_plan_hits, d.plan_valid ? 8.0 * (double)d.plan.arena : 0.0, d.plan_valid ? 8.0 * (double)d.plan.sarena : 0.0,
+                       d.plan_valid ? 8.0 * (double)d.plan.garena : 0.0, e, (double)parked};
+  for (int i = 0; i < std::min<int>(n, 8); i++) out[i] = v[i];
   return 0;
 }
 
