@@ -49,3 +49,17 @@ for dbg, what in ((13, "schur without the gather of the children"), (12, "schur,
     r = ctx.bench_direct(1, 10)
     print(f"{what}: {r['us_per_launch'] * r['launches']:8.1f} us")
 ctx.set_param("ds_dbg", 0)
+if "--s32" in sys.argv:
+    for thr in (0, 1100, 3000, 8000, 1 << 30):
+        ctx.set_param("direct_s32_below", thr)
+        line = f"s32_below {thr}: "
+        tot = 0
+        for b in range(nb):
+            ctx.set_param("ds_bench_batch", b)
+            r = ctx.bench_direct(1, 10)
+            t = r["us_per_launch"] * r["launches"]; tot += t
+            line += f"{t:6.1f} "
+        ctx.set_param("ds_bench_batch", -1)
+        r = ctx.bench_direct(1, 10)
+        print(line, f"| sum {tot:7.1f} | all together {r['us_per_launch'] * r['launches']:7.1f} us")
+    ctx.set_param("direct_s32_below", 0)

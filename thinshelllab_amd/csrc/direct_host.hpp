@@ -29,8 +29,9 @@ static void ds_launch_gemm(hipStream_t s, const DsDev& D, const DsBatch& b, int 
   const int rows = mode == 0 ? b.max_pp : b.max_bp, cols = b.max_bp;
   const dim3 grid((cols + 63) / 64, (rows + 63) / 64, b.count);
   const long tiles = (long)grid.x * grid.y * grid.z;
-  if (mode == 0 && ds_g32_below > 0 && tiles < ds_g32_below) {
-    hipLaunchKernelGGL(k_ds_gemm_g32, dim3((cols + 31) / 32, (rows + 31) / 32, b.count), dim3(256), 0, s, D, b.first);
+  if (ds_g32_below > 0 && tiles < ds_g32_below) {
+    if (mode == 0) hipLaunchKernelGGL(k_ds_gemm_g32, dim3((cols + 31) / 32, (rows + 31) / 32, b.count), dim3(256), 0, s, D, b.first);
+    else hipLaunchKernelGGL(k_ds_gemm_s32, dim3((cols + 31) / 32, (rows + 31) / 32, b.count), dim3(256), 0, s, D, b.first);
     return;
   }
   if (mode == 0) {
@@ -43,8 +44,8 @@ static void ds_launch_gemm(hipStream_t s, const DsDev& D, const DsBatch& b, int 
 }
 // the panels of the fronts level_sn[lv0 .. lv0 + nf) (one level, or one batch of it) are written from their children's Schur complements
 static void ds_launch_extend(hipStream_t s, const DsDev& D, int lv0, int nf, int max_ld) {
-  const int ncc = (max_ld + 64 * DS_XU - 1) / (64 * DS_XU);
-  hipLaunchKernelGGL(k_ds_extend_panels, dim3(((max_ld + DS_XROWS - 1) / DS_XROWS) * ncc, nf), dim3(256), 0, s, D, lv0, ncc);
+  const int nsp = (max_ld + DS_XSPAN - 1) / DS_XSPAN;
+  hipLaunchKernelGGL(k_ds_extend_panels, dim3(((max_ld / 3 + 2 + 3) / 4) * nsp, nf), dim3(256), 0, s, D, lv0, nsp);   // items: local vertices (<= ld / 3) + 2 for the padding rows, four per workgroup
 }
 // start of level l: its panels are written (level 0: cleared before, see direct_prezero), then its matrix entries are added
 static void ds_launch_level_start(tsl_ctx* c, hipStream_t s, const DsDev& D, int l) {
@@ -319,7 +320,7 @@ static int direct_factor(tsl_ctx* c, int stop_sn = -1, const char* dump_path = n
     }
     if (tb > 0) {
       ds_launch_gemm(bs, D, b, 0, d.gemm_wpc, d.g32_below);
-      ds_launch_gemm(bs, D, b, 1, d.gemm_wpc);
+      ds_launch_gemm(bs, D, b, 1, d.gemm_wpc, d.s32_below);
     }
   };
   // The fronts of a level are independent: where a level was split into batches (by pivot-block size) the batches run on parallel
@@ -497,7 +498,7 @@ static int direct_bench(tsl_ctx* c, int cls, int reps, double* out) {
           bytes += 16.0 * (double)f.pp * f.pp * (cls != 0 ? 1.0 : f.pp / (double)DS_T);   // the block read and written once per launch that touches it
         }
       } else if (tb > 0) {
-        if (cls == 1 || cls == 2) ds_launch_gemm(s, D, b, cls == 2 ? 0 : 1, d.gemm_wpc, d.g32_below);
+        if (cls == 1 || cls == 2) ds_launch_gemm(s, D, b, cls == 2 ? 0 : 1, d.gemm_wpc, cls == 2 ? d.g32_below : d.s32_below);
         else continue;
         if (count) {
           launches++;

@@ -1078,49 +1078,86 @@ TSL_DEV void ds_gemm_tile(const DsDev& D, int lv0, int bx, int by, int bz) {
 // The panels of the fronts of a level (F11, F12, F21) are WRITTEN here when the level starts: entry (i, j) = sum over the children, in
 // the plan's fixed order, of S_child[pmap_child[i]][pmap_child[j]] -- the part of the extend-add that lands on the panels --, zero where
 // no child reaches; the level's matrix entries are added right after (k_ds_assemble_level).  Every entry has one writer and is written
-// once: no atomics, no cleared memory, a fixed summation order.  Work item of a wave: one row x DS_XU chunks of 64 columns; lane q looks
-// the row up in child q's table, a ballot gives the children that reach the row (usually one or two), then DS_XU independent table
-// and S loads per lane and child are in flight.  Row r < pp is a top row (columns 0 .. ld), row r >= pp a row of F21 (columns 0 .. pp).
-#define DS_XROWS 8
+// once: no atomics, no cleared memory, a fixed summation order.
+// Work item of a wave: the THREE rows of one local vertex of the front (own vertex: top rows 3 v .., columns 0 .. ld; boundary vertex:
+// rows of F21, columns 0 .. pp) x a span of DS_XSPAN columns.  Lane q looks the vertex up in child q's table (the three dofs of a vertex
+// are consecutive in every table), a ballot gives the children that reach it (usually one or two), then per child and pass
+// DS_XU table loads and 3 DS_XU loads of S per lane are in flight.  The last two items of a front zero its padding rows.
 #define DS_XU 4
-#define DS_XMAXC 64   // children per pass of the table look-up (fronts with more take several passes)
-__global__ void __launch_bounds__(256) k_ds_extend_panels(DsDev D, int lv0, int ncc) {   // ncc: column chunks (of 64 DS_XU) of the widest front
+#define DS_XSPAN 1024  // columns per work item (DS_XSPAN / (64 DS_XU) passes: the vertex look-up is paid once per span)
+#define DS_XMAXC 64    // children whose look-up fits one ballot (fronts with more take the general loop)
+__global__ void __launch_bounds__(256) k_ds_extend_panels(DsDev D, int lv0, int nsp) {   // nsp: column spans of the widest front
   const DsFrontDesc f = D.frl[lv0 + blockIdx.y];
-  const int rb = blockIdx.x / ncc, cc = blockIdx.x - rb * ncc;
-  const int r0 = rb * DS_XROWS, j0 = cc * (64 * DS_XU);
-  if (r0 >= f.ld || j0 >= f.ld) return;
+  const int ib = blockIdx.x / nsp, sp = blockIdx.x - ib * nsp;
   const int lane = threadIdx.x & 63, w = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  const int g = 4 * ib + w, ng = f.nv_own + f.nv_bnd, c0 = sp * DS_XSPAN;
+  if (g >= ng + 2) return;
+  if (g >= ng) {   // padding rows: p .. pp of the top rows (the identity comes with k_ds_assemble_level) / b .. bp of F21
+    const bool top = g == ng;
+    const int nrow = top ? f.pp - f.p : f.bp - f.b, ncol = top ? f.ld : f.pp;
+    double* base = top ? D.A + f.off + (size_t)f.p * f.ld : D.A + f.off21 + (size_t)f.b * f.pp;
+    const int c1 = min(ncol, c0 + DS_XSPAN);
+    for (int i = 0; i < nrow; i++)
+      for (int j = c0 + lane; j < c1; j += 64) base[(size_t)i * ncol + j] = 0.0;
+    return;
+  }
+  const bool top = g < f.nv_own;
+  const int r = top ? 3 * g : f.pp + 3 * (g - f.nv_own);            // first of the three local dofs of the vertex
+  const int ncol = top ? f.ld : f.pp;
+  if (c0 >= ncol) return;
+  double* row = top ? D.A + f.off + (size_t)r * f.ld : D.A + f.off21 + (size_t)(r - f.pp) * f.pp;
+  const int c1 = min(ncol, c0 + DS_XSPAN);
   const DsChildRec* ch = D.ch + f.ch_off;
-  for (int rr = w; rr < DS_XROWS; rr += 4) {
-    const int r = r0 + rr;
-    if (r >= f.ld) break;
-    const bool top = r < f.pp;
-    double* row = top ? D.A + f.off + (size_t)r * f.ld : D.A + f.off21 + (size_t)(r - f.pp) * f.pp;
-    const int ncol = top ? f.ld : f.pp;
-    if (j0 >= ncol) continue;
-    double v[DS_XU];
+  if (f.nchild <= DS_XMAXC) {   // (every front of the plans seen so far)
+    int my_ci = -1, my_off = 0, my_bp = 0;
+    long long my_soff = 0;
+    if (lane < f.nchild) { const DsChildRec c = ch[lane]; my_off = c.pmap_off; my_bp = c.bp; my_soff = c.soff; my_ci = D.pmap[c.pmap_off + r]; }
+    const unsigned long long mask = __ballot(my_ci >= 0);
+    for (int j0 = c0; j0 < c1; j0 += 64 * DS_XU) {
+      double v[3][DS_XU];
 #pragma unroll
-    for (int u = 0; u < DS_XU; u++) v[u] = 0.0;
-    for (int q0 = 0; q0 < f.nchild; q0 += DS_XMAXC) {
-      const int nq = min(DS_XMAXC, f.nchild - q0);
-      int my_ci = -1, my_off = 0, my_bp = 0;
-      long long my_soff = 0;
-      if (lane < nq) { const DsChildRec c = ch[q0 + lane]; my_off = c.pmap_off; my_bp = c.bp; my_soff = c.soff; my_ci = D.pmap[c.pmap_off + r]; }
-      for (unsigned long long m = __ballot(my_ci >= 0); m != 0; m &= m - 1) {   // ascending child order: the fixed summation order
+      for (int k = 0; k < 3; k++)
+#pragma unroll
+        for (int u = 0; u < DS_XU; u++) v[k][u] = 0.0;
+      for (unsigned long long m = mask; m != 0; m &= m - 1) {   // ascending child order: the fixed summation order
         const int q = __builtin_ctzll(m);
         const int ci = __builtin_amdgcn_readlane(my_ci, q), off = __builtin_amdgcn_readlane(my_off, q), cbp = __builtin_amdgcn_readlane(my_bp, q);
         const long long so = ((long long)__builtin_amdgcn_readlane((int)(my_soff >> 32), q) << 32) | (unsigned)__builtin_amdgcn_readlane((int)my_soff, q);
         const int* pm = D.pmap + off;
-        const double* Srow = D.S + so + (size_t)ci * cbp;
+        const double* S0 = D.S + so + (size_t)ci * cbp;
         int cj[DS_XU];
 #pragma unroll
-        for (int u = 0; u < DS_XU; u++) { const int j = j0 + 64 * u + lane; cj[u] = j < ncol ? pm[j] : -1; }
+        for (int u = 0; u < DS_XU; u++) { const int j = j0 + 64 * u + lane; cj[u] = j < c1 ? pm[j] : -1; }
 #pragma unroll
-        for (int u = 0; u < DS_XU; u++) if (cj[u] >= 0) v[u] += Srow[cj[u]];
+        for (int u = 0; u < DS_XU; u++)
+          if (cj[u] >= 0) {
+#pragma unroll
+            for (int k = 0; k < 3; k++) v[k][u] += S0[(size_t)k * cbp + cj[u]];
+          }
+      }
+#pragma unroll
+      for (int u = 0; u < DS_XU; u++) {
+        const int j = j0 + 64 * u + lane;
+        if (j < c1) {
+#pragma unroll
+          for (int k = 0; k < 3; k++) row[(size_t)k * ncol + j] = v[k][u];
+        }
+      }
+    }
+    return;
+  }
+  for (int j = c0 + lane; j < c1; j += 64) {   // general form: any number of children, one column per lane and pass
+    double v[3] = {0.0, 0.0, 0.0};
+    for (int q = 0; q < f.nchild; q++) {
+      const int* pm = D.pmap + ch[q].pmap_off;
+      const int ci = pm[r], cj = pm[j];
+      if (ci >= 0 && cj >= 0) {
+#pragma unroll
+        for (int k = 0; k < 3; k++) v[k] += D.S[ch[q].soff + (size_t)(ci + k) * ch[q].bp + cj];
       }
     }
 #pragma unroll
-    for (int u = 0; u < DS_XU; u++) { const int j = j0 + 64 * u + lane; if (j < ncol) row[j] = v[u]; }
+    for (int k = 0; k < 3; k++) row[(size_t)k * ncol + j] = v[k];
   }
 }
 
@@ -1166,6 +1203,85 @@ __global__ void __launch_bounds__(256) k_ds_gemm_g32(DsDev D, int lv0) {
   }
 #pragma unroll
   for (int r = 0; r < 4; r++) G[(size_t)(I0 + 16 * wi + lk + 4 * r) * f.bp + J0 + 16 * wj + lr] = acc[r];
+}
+
+// The Schur complement in the same 32 x 32 tiles ("direct_s32_below"): per workgroup a quarter of the epilogue (4 gathered entries per lane
+// and child instead of 16) and a quarter of the registers, so that eight and more workgroups per CU hide each other's descriptor ->
+// first slab -> ... -> table -> S-load -> store chains, which is what the 64 x 64-tile launches spend more than half their time in at
+// K = 96 .. 544.  The tables of the tile's 32 rows and 32 columns in the first DS_GMC children are requested before the K loop.
+__global__ void __launch_bounds__(256) k_ds_gemm_s32(DsDev D, int lv0) {
+  constexpr int SA = DS_SK + 1, SB = 32 + 1, GMC = DS_GMC;
+  __shared__ double As[32 * SA];
+  __shared__ double Bs[DS_SK * SB];
+  __shared__ int s_map[GMC][64];
+  __shared__ long long s_soff[GMC];
+  __shared__ int s_cbp[GMC];
+  const DsFrontDesc f = D.frl[lv0 + blockIdx.z];
+  const int Mr = f.bp, Nc = f.bp, K = f.pp;
+  const int I0 = blockIdx.y * 32, J0 = blockIdx.x * 32;
+  if (I0 >= Mr || J0 >= Nc || f.parent < 0) return;
+  const double* Am = D.A + f.off21;   // F21 rows, row stride pp
+  const double* Bm = D.G + f.goff;    // G, row stride bp
+  const int lda = f.pp, ldb = f.bp;
+  const int lane = threadIdx.x & 63, w = threadIdx.x >> 6, wi = w >> 1, wj = w & 1, lr = lane & 15, lk = lane >> 4;
+  const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;   // 32 x 8
+  ds_d4 acc = {0.0, 0.0, 0.0, 0.0};
+  double pa[4], pb[4];
+  auto gload = [&](int k0) {
+#pragma unroll
+    for (int q = 0; q < 4; q++) {
+      const int r = ty + 8 * q;
+      pa[q] = Am[(size_t)(I0 + r) * lda + k0 + tx];
+      pb[q] = Bm[(size_t)(k0 + r) * ldb + J0 + tx];
+    }
+  };
+  gload(0);
+  auto map_load = [&](int q) {   // this thread's entry of child q's table: 32 rows, then 32 columns
+    const int k = threadIdx.x & 63;
+    return D.pmap[D.ch[f.ch_off + q].pmap_off + f.pp + (k < 32 ? I0 + k : J0 + k - 32)];
+  };
+  int pre[GMC / 4];
+#pragma unroll
+  for (int h = 0; h < GMC / 4; h++) { const int q = 4 * h + w; pre[h] = q < f.nchild ? map_load(q) : -1; }
+  for (int k0 = 0; k0 < K; k0 += DS_SK) {
+#pragma unroll
+    for (int q = 0; q < 4; q++) { As[(ty + 8 * q) * SA + tx] = pa[q]; Bs[(ty + 8 * q) * SB + tx] = pb[q]; }
+    __syncthreads();
+    if (k0 + DS_SK < K) gload(k0 + DS_SK);
+#pragma unroll
+    for (int kk = 0; kk < DS_SK / 4; kk++)
+      acc = __builtin_amdgcn_mfma_f64_16x16x4f64(As[(16 * wi + lr) * SA + 4 * kk + lk], Bs[(4 * kk + lk) * SB + 16 * wj + lr], acc, 0, 0, 0);
+    __syncthreads();
+  }
+  double s22[4] = {0.0, 0.0, 0.0, 0.0};
+  for (int q0 = 0; q0 < f.nchild; q0 += GMC) {
+    const int nq = min(GMC, f.nchild - q0);
+    if (q0 > 0) __syncthreads();
+#pragma unroll
+    for (int h = 0; h < GMC / 4; h++) {
+      const int q = 4 * h + w;
+      if (q < nq) s_map[q][threadIdx.x & 63] = q0 == 0 ? pre[h] : map_load(q0 + q);
+    }
+    if ((int)threadIdx.x < nq) { const DsChildRec c = D.ch[f.ch_off + q0 + threadIdx.x]; s_soff[threadIdx.x] = c.soff; s_cbp[threadIdx.x] = c.bp; }
+    __syncthreads();
+    for (int q = 0; q < nq; q++) {   // ascending child order: the fixed summation order
+      const int cj = s_map[q][32 + 16 * wj + lr];
+      if (cj < 0) continue;
+      const double* Sc = D.S + s_soff[q] + cj;
+      const int cbp = s_cbp[q];
+#pragma unroll
+      for (int r = 0; r < 4; r++) {
+        const int ci = s_map[q][16 * wi + lk + 4 * r];
+        if (ci >= 0) s22[r] += Sc[(size_t)ci * cbp];
+      }
+    }
+  }
+  double* Sf = D.S + f.soff;
+  const int col = J0 + 16 * wj + lr;
+  if (col < f.b) {
+#pragma unroll
+    for (int r = 0; r < 4; r++) { const int row = I0 + 16 * wi + lk + 4 * r; if (row < f.b) Sf[(size_t)row * f.bp + col] = s22[r] - acc[r]; }
+  }
 }
 
 template <int mode, int WPC>

@@ -131,6 +131,7 @@ struct DirectSolver {
                                // cfg4, one application: 404 us without, 385 / 380 / 387 / 388 / 409 / 523 us at 150 / 300 / 600 / 1200 / 2400 / always (scripts/exp_gemv_wide.py)
   int g32_below = 1100;     // "direct_g32_below": G = W F12 of a batch with fewer 64 x 64 tiles than this runs in the 32 x 32-tile kernel (k_ds_gemm_g32; 0 = never).
                             // cfg4: 52 -> 34, 67 -> 52, 37 -> 32 us on the three top levels with boundaries; the batches of 1150+ tiles lose (31 -> 33 us)
+  int s32_below = 0;        // "direct_s32_below": the same for the Schur complements (k_ds_gemm_s32)
   int gemm_wpc = 4;         // "direct_gemm_wpc": workgroups per CU the GEMM kernels are compiled for (4; 2 = two LDS slab buffers, one barrier per slab: measured slower)
   bool cons_checked = false; // the constraint list has not changed since direct_plan last looked (reset by tsl_contact_detect)
   double* h_anorm = nullptr; // pinned: |H|_inf of the last factorisation (valid after the next stream synchronisation)

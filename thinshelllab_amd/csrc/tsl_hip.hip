@@ -409,6 +409,7 @@ extern "C" int tsl_set_param(tsl_ctx* c, const char* key, double v) {
   else if (k == "direct_flow") c->ds.flow = std::max(0, (int)v);
   else if (k == "direct_gemv_wide_below") c->ds.gemv_wide_below = std::max(0, (int)v);
   else if (k == "direct_g32_below") c->ds.g32_below = std::max(0, (int)v);
+  else if (k == "direct_s32_below") c->ds.s32_below = std::max(0, (int)v);
   else if (k == "direct_par_batches") c->ds.par_batches = (int)v;
   else if (k == "direct_gemm_wpc") c->ds.gemm_wpc = (int)v;
   else if (k == "direct_merge_sep") { c->ds.plan.sym.merge_sep = (int)v; c->ds.static_ready = false; c->ds.plan_valid = false; c->ds.numeric_valid = false; }
