@@ -47,6 +47,10 @@ def lib():
         L.tslo_newton_step.restype = C.c_double
         L.tslo_set_scalar.argtypes = [C.c_void_p, C.c_char_p, C.c_double]
         L.tslo_set_direct.argtypes = [C.c_void_p, _DIRECT_CB, C.c_int]
+        L.tslo_grad_loss.restype = C.c_int
+        L.tslo_grad_loss.argtypes = [C.c_void_p, C.c_char_p, C.c_double, C.c_double, C.POINTER(C.c_int), C.POINTER(C.c_double)]
+        L.tslo_reward.restype = C.c_double
+        L.tslo_reward.argtypes = [C.c_void_p, C.c_char_p, C.c_double, C.c_double, C.POINTER(C.c_int), C.POINTER(C.c_double)]
         _lib = L
     return _lib
 
@@ -330,6 +334,26 @@ class OracleScene:
         if self.stats()["flag"] == 3:   # PCG, BiCGStab and (n <= 4500) dense LU all failed: nothing to compare against
             raise RuntimeError(f"oracle: the adjoint solve of step {step} did not converge")
 
+    def grad_loss(self, name, a0=0.0, a1=0.0, rows=(6, 8, 7, 9), target=None):
+        """Grad.get_loss_<name> of the reference (analytic_grad_single.py:259-471; name "" = get_loss) on the oracle's own tape;
+        a0 / a1: curve7 / curve8 (fold) or sys.target (bounce); rows: hinge rows of the folding seeds; target: NV x 3 (push)"""
+        r = np.ascontiguousarray(rows, dtype=np.int32).ravel()
+        t = None if target is None else np.ascontiguousarray(target, dtype=np.float64)
+        rc = self.L.tslo_grad_loss(self.h, name.encode(), float(a0), float(a1), _ip(r), None if t is None else _dp(t))
+        if rc < 0:
+            raise ValueError(f"oracle: no loss seed named {name!r}")
+        return rc
+
+    def reward(self, name, a0=0.0, a1=0.0, rows=(6, 8, 7, 9), target=None):
+        """compute_reward* of the reference's task scenes ("folding", "folding.8", "lifting", "balancing", "balancing.all", ...) from the
+        oracle's per-body state (and tape, where the kernel reads pos_buffer)"""
+        r = np.ascontiguousarray(rows, dtype=np.int32).ravel()
+        t = None if target is None else np.ascontiguousarray(target, dtype=np.float64)
+        v = float(self.L.tslo_reward(self.h, name.encode(), float(a0), float(a1), _ip(r), None if t is None else _dp(t)))
+        if v != v:
+            raise ValueError(f"oracle: no reward named {name!r}")
+        return v
+
     def grad_system(self, system_mode=True, count_kb=True, count_mu_lam=False, count_friction=False):
         """switch the reverse step to analytic_grad_system.Grad semantics (pos_grad clamp +-1, parameter gradients)"""
         self.L.tslo_grad_system(self.h, int(system_mode), int(count_kb), int(count_mu_lam), int(count_friction))
@@ -355,6 +379,12 @@ class OracleScene:
 
 def set_threads(n):
     lib().tslo_set_threads(int(n))
+
+
+def set_sign_mode(m):
+    """1: the reference's literal sign test `norm_dir[i2] . e < 0` (model_fold_offset.py:116,135,144); 0 (default): values within
+    1e-10 |e| of zero count as zero, the exact-arithmetic value on the wrongly-tabled slots"""
+    lib().tslo_set_sign_mode(int(m))
 
 
 def set_spd_mode(m):

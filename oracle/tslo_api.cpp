@@ -8,6 +8,11 @@
 #include "tslo_engine.h"
 
 using namespace tslo;
+namespace tslo {
+int grad_get_loss(Grad& g, Scene& sys, const char* name, double a0, double a1, const int* rows, const double* target);   // tslo_loss.cpp
+double scene_reward(Scene& sys, const Grad* g, const char* name, double a0, double a1, const int* rows, const double* target);
+int& sign_mode();   // tslo_cloth.cpp
+}
 
 struct Handle {
   Scene sys;
@@ -225,6 +230,7 @@ void tslo_stats(void* h, long* out, int reset) {
 }
 
 void tslo_set_spd_mode(int m) { spd_mode() = m; }
+void tslo_set_sign_mode(int m) { sign_mode() = m; }   // 1: literal `n2 . e < 0` of model_fold_offset.py:116,135,144; 0: |n2 . e| <= 1e-10 |e| counts as zero
 
 // SPD projections for unit tests
 int tslo_spd_project(double* A, int n, int K) {
@@ -378,5 +384,9 @@ double tslo_double(void* h, const char* name) {
   }
   return 0.0 / 0.0;
 }
+
+// loss seeds (analytic_grad_single.py:259-471) and rewards (task_scene/Scene_*.py compute_reward*), tslo_loss.cpp
+int tslo_grad_loss(void* h, const char* name, double a0, double a1, const int* rows, const double* target) { return grad_get_loss(G(h), S(h), name, a0, a1, rows, target); }
+double tslo_reward(void* h, const char* name, double a0, double a1, const int* rows, const double* target) { return scene_reward(S(h), &G(h), name, a0, a1, rows, target); }
 
 }  // extern "C"

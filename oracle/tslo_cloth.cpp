@@ -13,7 +13,9 @@ namespace tslo {
 // plane of face i2, so the dot product is 0 in exact arithmetic and its floating-point sign is rounding noise
 // (it decides judge_angle -> sign of mat_M and c_i of those slots).  The restatement evaluates the test as in
 // exact arithmetic: values within 1e-10 |e| of zero count as zero (not negative).  Documented in DESIGN.md.
-static inline bool sign_test_negative(const V3& n2, const V3& e) { return dot(n2, e) < -1e-10 * norm(e); }
+// sign_mode() = 1 switches to the LITERAL test `< 0` of the reference (tslo_set_sign_mode; tests measure what the tolerance changes).
+int& sign_mode() { static int m = 0; return m; }
+static inline bool sign_test_negative(const V3& n2, const V3& e) { return sign_mode() == 1 ? dot(n2, e) < 0 : dot(n2, e) < -1e-10 * norm(e); }
 
 // model_fold_offset.py:11-33
 void Cloth::construct(int N_, double dt_, double Len, double rho_, int offset_, bool is_square, int M_) {

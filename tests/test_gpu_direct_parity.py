@@ -12,7 +12,7 @@ import numpy as np
 import pytest
 import torch
 
-from helpers import oracle_from_scene, rel_err, sync_oracle_state
+from helpers import seeds_agree, oracle_from_scene, rel_err, sync_oracle_state
 
 pytestmark = pytest.mark.gpu
 
@@ -50,7 +50,7 @@ def test_direct_path_rollout_and_adjoint_vs_oracle(oracle, name):
     from thinshelllab_amd.engine.geometry import projection_query
     oracle.set_threads(min(os.cpu_count() or 4, 32))
     s = _refined(name)
-    o = oracle_from_scene(oracle, s, check_init=False)
+    o = oracle_from_scene(oracle, s, check_init=True)
     _ripple(s, o)
     ctx = s._ensure_ctx()
     ctx.set_param("direct", 1); ctx.set_param("cg_tol", 1e-11); o.set_solver(1e-11)
@@ -80,11 +80,17 @@ def test_direct_path_rollout_and_adjoint_vs_oracle(oracle, name):
     assert nc_seen > 0
     NV = s.tot_NV
     g.pos_buffer.from_numpy(o.arr("grad.pos_buffer", (T, NV, 3))); g.ref_angle_buffer.from_numpy(o.arr("grad.ref_angle_buffer").reshape(g.ref_angle_buffer.shape))
+    # a dense random dL/dx_T as input data on both sides, then every side writes ITS OWN loss seed of the scene's task on top
     seed = np.random.default_rng(5).normal(size=(NV, 3))
     g.pos_grad.t[T - 1] = torch.as_tensor(seed, device=s.device); o.arr("grad.pos_grad", (T, NV, 3))[T - 1] = seed
     if name == "folding":
-        g.get_loss_fold(s, 1.0, -1.0)
-        o.arr("grad.angleref_grad").reshape(g.angleref_grad.shape)[:] = g.angleref_grad.to_numpy()
+        g.get_loss_fold(s, 1.0, -1.0); o.grad_loss("fold", 1.0, -1.0)
+        assert abs(s.compute_reward(1.0, -1.0) - o.reward("folding", 1.0, -1.0)) < 1e-9
+    else:
+        g.get_loss_balance(s); o.grad_loss("balance")
+        r_o = o.reward("balancing.all")
+        assert abs(s.compute_reward_all(g) - r_o) < 1e-12 * abs(r_o) and r_o < 0
+    seeds_agree(g, o, T, NV)
     for st_ in range(T - 1, 0, -1):
         g.transfer_grad(st_, s, projection_query)
         o.grad_transfer(st_)
@@ -129,13 +135,15 @@ def _one_adjoint_step_parity(oracle, o, s, g, T, fold):
     o.arr("grad.ref_angle_buffer").reshape(g.ref_angle_buffer.shape)[:] = g.ref_angle_buffer.to_numpy()
     o.arr("grad.gripper_pos_buffer", (T, -1, 3))[:, :n_part] = g.gripper_pos_buffer.to_numpy()[:, :n_part]
     o.arr("grad.gripper_rot_buffer", (T, -1, 4))[:, :n_part] = g.gripper_rot_buffer.to_numpy()[:, :n_part]
-    seed = np.random.default_rng(11).normal(size=(NV, 3))
+    seed = np.random.default_rng(11).normal(size=(NV, 3))   # dense random dL/dx_T (input data on both sides) under each side's own loss seed
     g.pos_grad.t.zero_(); g.angleref_grad.t.zero_()
     g.pos_grad.t[T - 1] = torch.as_tensor(seed, device=s.device)
-    if fold:
-        g.get_loss_fold(s, 1.0, -1.0, rows=s.fold_rows())
     o.arr("grad.pos_grad", (T, NV, 3))[T - 1] = seed
-    o.arr("grad.angleref_grad").reshape(g.angleref_grad.shape)[:] = g.angleref_grad.to_numpy()
+    if fold:
+        g.get_loss_fold(s, 1.0, -1.0, rows=s.fold_rows()); o.grad_loss("fold", 1.0, -1.0, rows=np.array(s.fold_rows()).ravel())
+    else:
+        g.get_loss_balance(s); o.grad_loss("balance")
+    seeds_agree(g, o, T, NV)
     g.transfer_grad(T - 1, s, projection_query)
     ls = g.last_stats
     assert ls["flag"] == 0 and ls["method"] == 4, ls
@@ -164,7 +172,7 @@ def _single_evaluation_parity(oracle, s, drive, steps, min_nc, newton_direction=
     T = steps + 1
     g = Grad(s, T, n_part); g.init_mass(s)
     g.copy_pos(s, 0)
-    o_adj = oracle_from_scene(oracle, s, check_init=False)   # mirrored at t = 0: the gripper's local frame is taken from the initial poses on both sides
+    o_adj = oracle_from_scene(oracle, s, check_init=True)   # mirrored at t = 0: the gripper's local frame is taken from the initial poses on both sides
     for f in range(1, steps + 1):
         s.action(f, *drive(f, n_part))
         st = s.time_step(projection_query, f)
