@@ -138,6 +138,70 @@ def run_rollout(scene, grad, K, args):
     return S
 
 
+def multi_scene(args, rank, S, K, W, single_value):
+    """--scenes-per-gpu S: S independent scenes of the bench workload on ONE GPU -- S engine contexts on S streams, driven by S host
+    threads (the engine calls release the GIL) -- through the same warm-up + K fwd+adjoint steps each.  One scene leaves most of the
+    chip idle between its dependent launches (roofline.whole_step); this is what a trajectory-optimisation batch larger than the
+    GPU count does with it (BASELINE configs[4]: more scenes than GPUs).  Reported NEXT to the single-scene headline, never instead."""
+    import threading
+    import torch
+    from thinshelllab_amd.engine.analytic_grad_single import Grad
+    scenes, grads = [], []
+    # (with several contexts alive on the device the engine keeps its persistent dataflow launches off by itself: direct_host.hpp)
+    for k in range(S):
+        sc = build_scene(args, rank * S + k)   # (own drive amplitude per scene, like the ranks)
+        ctx = sc._ensure_ctx()
+        ctx.set_param("cg_tol", args.cg_tol)
+        for kv in args.param:
+            key, v = kv.split("=")
+            ctx.set_param(key, float(v))
+        n_part = sc.gripper.n_part if args.workload != "drape" else 0
+        g = Grad(sc, max(K, W) + 1, n_part); g.init_mass(sc)
+        scenes.append(sc); grads.append(g)
+    stats = [None] * S; errs = []
+    start = threading.Barrier(S + 1); warm = threading.Barrier(S + 1)
+
+    def work(k):
+        try:
+            torch.cuda.set_device(scenes[k].device)
+            if W > 0:
+                run_rollout(scenes[k], grads[k], W, args)
+            warm.wait(); start.wait()
+            stats[k] = run_rollout(scenes[k], grads[k], K, args)
+        except Exception as e:   # noqa: BLE001 -- reported below
+            errs.append(repr(e))
+            for b in (warm, start):
+                b.abort()
+    th = [threading.Thread(target=work, args=(k,)) for k in range(S)]
+    for t in th:
+        t.start()
+    try:
+        warm.wait()
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        start.wait()
+    except threading.BrokenBarrierError:
+        pass
+    for t in th:
+        t.join()
+    torch.cuda.synchronize()
+    elapsed = time.perf_counter() - t0
+    if errs:
+        return {"scenes_per_gpu": S, "value": None, "error": errs[0]}
+    T = scenes[0].cloths[0].NF
+    val = T * K * S / elapsed
+    cnt = [sc._ensure_ctx().direct_counters() for sc in scenes]
+    return {"scenes_per_gpu": S, "value": val, "unit": "element-steps/s on this GPU, all scenes together", "seconds": elapsed,
+            "ms_per_step_per_scene": elapsed / K * 1e3, "speedup_vs_single_scene": val / single_value if single_value else None,
+            "solves_unconverged": sum(st["fwd_unconverged"] + st["adj_unconverged"] for st in stats),
+            "newton_iters_per_step": [st["newton"] / K for st in stats],
+            "dataflow_launches_lost": sum(int(c["flow_aborts"]) for c in cnt),
+            "hw_queues": os.environ.get("GPU_MAX_HW_QUEUES", "default (4)"),
+            "note": "S engine contexts on S streams of one process, one host thread each, measured in a child process with GPU_MAX_HW_QUEUES=16 (the contexts' ~6 streams each "
+                    "would otherwise share four hardware queues and serialise); the persistent dataflow launches (k_ds_gj_flow, ~8 % of a single scene's step) are off while "
+                    "several contexts share the device: they need every workgroup slot of the chip for themselves"}
+
+
 def _ripple(x, c):
     """deterministic sub-micron ripple on the cloth rows: the native poses put cloth vertices EXACTLY on the contact threshold, where
     the activation test is decided by round-off (tests/test_gpu_scenes.py::_pair does the same on both sides)"""
@@ -357,6 +421,10 @@ def main():
     ap.add_argument("--cg-tol", type=float, default=1e-10)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--param", action="append", default=[], metavar="KEY=VALUE", help="extra tsl_set_param settings (solver experiments)")
+    ap.add_argument("--scenes-per-gpu", type=int, default=0, help="after the single-scene measurement: the same workload as S independent scenes on this GPU (S contexts, S streams, "
+                                                                     "S host threads), reported as multi_scene next to the headline value")
+    ap.add_argument("--multi-only", type=int, default=0, help=argparse.SUPPRESS)      # child process of --scenes-per-gpu
+    ap.add_argument("--single-value", type=float, default=0.0, help=argparse.SUPPRESS)
     ap.add_argument("--cpu-grid", type=int, default=71, help="cloth grid of the complete oracle steps of cpu_baseline")
     ap.add_argument("--cpu-steps", type=int, default=2)
     ap.add_argument("--cpu-threads", type=int, default=16)
@@ -364,6 +432,10 @@ def main():
     if args.workload == "cfg3" and args.grid == 224:
         args.grid = 200
 
+    if args.multi_only > 1:
+        import torch  # noqa: F401
+        print(json.dumps(multi_scene(args, 0, args.multi_only, args.steps, args.warmup, args.single_value)), flush=True)
+        return
     if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
         # one rank per GPU of this node over RCCL: re-execute under torch.distributed.run (the driver's own launcher sets WORLD_SIZE)
         port = 29500 + os.getpid() % 2000
@@ -445,6 +517,17 @@ def main():
         rf["whole_step"] = step   # SURVEY section 8d's bytes model and the factorisation-flops figure of the WHOLE step, inside the object the driver keeps
         out["roofline"] = rf
         out["roofline_step"] = step
+    if args.scenes_per_gpu > 1 and rank == 0 and world == 1:
+        # the multi-scene leg runs in a child process of its own (more hardware queues: an environment variable the HIP runtime reads at start-up)
+        try:
+            env = dict(os.environ, GPU_MAX_HW_QUEUES=os.environ.get("TSL_MULTI_HW_QUEUES", "16"))
+            cmd = [sys.executable, os.path.abspath(__file__), "--multi-only", str(args.scenes_per_gpu), "--single-value", repr(value / world), "--steps", str(K), "--warmup", str(W),
+                   "--workload", args.workload, "--grid", str(args.grid), "--idle", str(args.idle), "--cg-tol", repr(args.cg_tol)] + [x for kv in args.param for x in ("--param", kv)]
+            r = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=1800)
+            line = [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
+            out["multi_scene"] = json.loads(line[-1]) if line else {"scenes_per_gpu": args.scenes_per_gpu, "value": None, "error": (r.stderr or "no output")[-400:]}
+        except Exception as e:   # noqa: BLE001 -- never fail the headline on the extra measurement
+            out["multi_scene"] = {"scenes_per_gpu": args.scenes_per_gpu, "value": None, "error": repr(e)}
     if rank == 0:
         if world == 1 and not args.no_cpu_baseline:
             try:

@@ -263,3 +263,52 @@ def test_elastic_parameters_reach_the_engine_after_context_creation():
     s._ctx.set_param("cloth0.Kb", 123.0)     # index parsed up to the dot
     with pytest.raises(Exception):
         s._ctx.set_param("cloth10.Kb", 1.0)
+
+
+def test_two_contexts_share_the_device_without_dataflow_launches():
+    """Several scenes per GPU (bench.py --scenes-per-gpu): the persistent dataflow launches need every workgroup slot of the chip, so the
+    engine keeps them off while another context of the process is factorising on the device too -- both contexts
+    solve concurrently from two host threads on the launch-per-block-step path, and the path comes back when the second context is gone."""
+    import gc
+    import threading
+    import time
+    gc.collect(); time.sleep(2.1)   # (contexts of earlier tests of this process count as neighbours for two seconds after their last factorisation)
+    import scipy.sparse.linalg as spl
+    s1 = _drape(160, 96, 5e-5, seed=11)
+    c1 = s1._ensure_ctx()
+    c1.set_param("direct", 1); c1.set_param("direct_leaf", 16)
+    s1.compute_residual_and_Hessian(spd=True)
+    b1 = s1.F.to_torch().clone()
+    x, st = c1.solve(b1.clone())
+    n0 = c1.direct_counters()["flow_launches"]
+    assert n0 > 0 and st["flag"] == 0
+    xs1 = spl.splu(c1.operator_csr().tocsc()).solve(b1.cpu().numpy())
+    s2 = _drape(96, 64, 5e-5, seed=12)
+    c2 = s2._ensure_ctx()
+    c2.set_param("direct", 1); c2.set_param("direct_leaf", 16)
+    s2.compute_residual_and_Hessian(spd=True)
+    b2 = s2.F.to_torch().clone()
+    xs2 = spl.splu(c2.operator_csr().tocsc()).solve(b2.cpu().numpy())
+    c2.solve(b2.clone())                     # the neighbour's first factorisation (it sees context 1 active: no dataflow launch)
+    out = {}
+
+    def work(name, s, c, b, xs):
+        errs = []
+        for _ in range(4):
+            s.compute_residual_and_Hessian(spd=True)      # fresh factors every time
+            x, st = c.solve(b.clone())
+            errs.append((st["flag"], rel_err(x.cpu().numpy(), xs)))
+        out[name] = errs
+    th = [threading.Thread(target=work, args=("a", s1, c1, b1, xs1)), threading.Thread(target=work, args=("b", s2, c2, b2, xs2))]
+    for t in th:
+        t.start()
+    for t in th:
+        t.join()
+    assert all(f == 0 and e < 1e-9 for f, e in out["a"] + out["b"]), out
+    assert c1.direct_counters()["flow_launches"] == n0 and c2.direct_counters()["flow_launches"] == 0
+    assert c1.direct_counters()["flow_aborts"] == 0
+    del c2, s2, th
+    gc.collect(); time.sleep(2.1)   # (gone, or at least silent for two seconds)
+    s1.compute_residual_and_Hessian(spd=True)
+    x, st = c1.solve(b1.clone())
+    assert st["flag"] == 0 and c1.direct_counters()["flow_launches"] > n0

@@ -4,10 +4,32 @@
 #pragma once
 #include <array>
 #include <chrono>
-#include <mutex>
 
 #include "k_direct.hpp"
 #include "tsl_ctx.hpp"
+
+// Registry of the contexts of this process that factorise: (context, device, time of its last factorisation).  A context whose neighbour on
+// the same device factorised within the last two seconds keeps its persistent dataflow launches off (direct_factor / ds_flow_prepare);
+// stale contexts -- scene objects nobody steps any more -- do not count.
+#include <mutex>
+struct DsActivity { std::mutex mu; struct E { const void* ctx; int dev; long long ns; }; std::vector<E> e; };
+static DsActivity g_ds_activity;
+static bool ds_mark_active(const void* ctx, int dev) {   // -> is another context active on `dev`?
+  const long long now = std::chrono::duration_cast<std::chrono::nanoseconds>(std::chrono::steady_clock::now().time_since_epoch()).count();
+  std::lock_guard<std::mutex> lk(g_ds_activity.mu);
+  bool mine = false, other = false;
+  for (auto& x : g_ds_activity.e) {
+    if (x.ctx == ctx) { x.ns = now; x.dev = dev; mine = true; }
+    else if (x.dev == dev && now - x.ns < 2000000000LL) other = true;
+  }
+  if (!mine) g_ds_activity.e.push_back({ctx, dev, now});
+  return other;
+}
+static void ds_forget(const void* ctx) {
+  std::lock_guard<std::mutex> lk(g_ds_activity.mu);
+  auto& v = g_ds_activity.e;
+  v.erase(std::remove_if(v.begin(), v.end(), [&](const DsActivity::E& x) { return x.ctx == ctx; }), v.end());
+}
 
 static inline int ds_nblk(long n, int b) { return (int)((n + b - 1) / b); }
 
@@ -65,6 +87,7 @@ static void ds_launch_level_start(tsl_ctx* c, hipStream_t s, const DsDev& D, int
 // arguments and grows the exchange buffers; false = the batch stays on the launch-per-block-step path.
 static int ds_flow_prepare(DirectSolver& d, const DirectPlan& P, const DsBatch& b, bool alone, DsFlowArgs& a, hipStream_t s) {   // -> workgroups per CU of the instantiation to launch (4 / 5), 0 = not on this path
   if (!d.flow || !alone || b.count > DS_FLOW_MAXF || b.max_pp < 2 * DS_T) return 0;
+  if (d.shared_device) return 0;   // another context of this process is working on the device (direct_factor)
   { hipStreamCaptureStatus cs = hipStreamCaptureStatusNone;   // a captured launch would be replayed with ONE epoch: flags of the previous replay would pass
     if (hipStreamIsCapturing(s, &cs) != hipSuccess || cs != hipStreamCaptureStatusNone) return 0; }
   if (ds_use_small(b) && !(d.flow & 2)) return 0;   // bit 1: also the batches the LDS kernel would take (64 / 32 fronts of <= 128 pivots on levels 3 and 4 of cfg4)
@@ -97,23 +120,14 @@ static int ds_flow_prepare(DirectSolver& d, const DirectPlan& P, const DsBatch& 
   return tiles <= d.flow_cap[0] ? 4 : 5;   // the fifth workgroup per CU costs 15 spilled registers: only for a root beyond 1024 tiles
 }
 // The launch must be resident as a whole (its workgroups wait for each other's flags).  Inside ONE context the host guarantees that by
-// running it alone on its level; between the contexts of one process (several scenes per GPU) the launches are chained through a
-// process-wide event, so that two persistent grids never share the chip -- each could hold part of the CUs and wait for workgroups of
-// its own that are not resident.  Other PROCESSES on the same device are not covered: there a launch that cannot become resident runs
-// into DS_FLOW_SPINS, raises bad[DS_FLOW_ABORT], and the solve falls back to the launch-per-block-step path (solve_perm).
-struct DsFlowChain { std::mutex mu; hipEvent_t ev[16] = {}; bool recorded[16] = {}; };
-static DsFlowChain g_flow_chain;
+// running it alone on its level; while ANOTHER context of this process is factorising on the device too (several scenes per GPU) the path
+// is off (direct_factor / ds_flow_prepare: the other context's launches keep workgroup slots occupied for as long as it has work, measured round 4: both
+// contexts of a two-scene run lost a flag within their first steps, and chaining the persistent launches through an event did not
+// prevent it).  Other PROCESSES on the same device are not visible from here: there a launch that cannot become resident runs into
+// DS_FLOW_SPINS, raises bad[DS_FLOW_ABORT], and the solve refactorises on the launch-per-block-step path (solve_perm).
 static void ds_flow_launch(hipStream_t s, const DsDev& D, int lv0, const DsFlowArgs& fa, int wpc, DirectSolver& d) {
-  int dev = 0;
-  (void)hipGetDevice(&dev);
-  dev &= 15;
-  std::lock_guard<std::mutex> lk(g_flow_chain.mu);
-  if (g_flow_chain.ev[dev] == nullptr) (void)hipEventCreateWithFlags(&g_flow_chain.ev[dev], hipEventDisableTiming);
-  if (g_flow_chain.recorded[dev]) (void)hipStreamWaitEvent(s, g_flow_chain.ev[dev], 0);
   if (wpc == 4) hipLaunchKernelGGL(k_ds_gj_flow<4>, dim3(fa.tile0[fa.nf]), dim3(256), 0, s, D, lv0, fa, d.flow_x.p, d.flow_f.p);
   else hipLaunchKernelGGL(k_ds_gj_flow<5>, dim3(fa.tile0[fa.nf]), dim3(256), 0, s, D, lv0, fa, d.flow_x.p, d.flow_f.p);
-  (void)hipEventRecord(g_flow_chain.ev[dev], s);
-  g_flow_chain.recorded[dev] = true;
 }
 
 static bool direct_enabled(tsl_ctx* c) {
@@ -127,7 +141,7 @@ static bool direct_enabled(tsl_ctx* c) {
 static DsDev ds_dev(tsl_ctx* c) {
   DirectSolver& d = c->ds;
   DsDev D;
-  D.fr = d.fr.p; D.frl = d.frl.p; D.level_sn = d.level_sn.p; D.A = d.arena.p; D.S = d.sarena.p; D.G = d.garena.p; D.scr = d.scr.p; D.ch = d.ch_rec.p; D.pmap = d.pmap.p; D.vtx = d.vtx.p; D.bad = d.bad.p; D.dbg = d.dbg; D.piv_tol = d.piv_tol;
+  D.fr = d.fr.p; D.frl = d.frl.p; D.level_sn = d.level_sn.p; D.A = d.arena.p; D.S = d.sarena.p; D.Y = d.w.p; D.G = d.garena.p; D.scr = d.scr.p; D.ch = d.ch_rec.p; D.pmap = d.pmap.p; D.vtx = d.vtx.p; D.bad = d.bad.p; D.dbg = d.dbg; D.piv_tol = d.piv_tol;
   return D;
 }
 
@@ -171,6 +185,29 @@ static void ds_swap_slot(DirectSolver& d, DsPlanSlot& sl) {
   std::swap(d.plan, sl.plan); d.h_cons.swap(sl.h_cons); d.h_cset.swap(sl.h_cset);
   d.level_sn.swap(sl.level_sn); d.pmap.swap(sl.pmap); d.ch_rec.swap(sl.ch_rec); d.vtx.swap(sl.vtx); d.blk_ld.swap(sl.blk_ld); d.con_ld.swap(sl.con_ld);
   d.wl_front.swap(sl.wl_front); d.wl_row.swap(sl.wl_row); d.blk_dst.swap(sl.blk_dst); d.con_dst.swap(sl.con_dst); d.fr.swap(sl.fr); d.frl.swap(sl.frl); d.blk_q.swap(sl.blk_q); d.con_lvl.swap(sl.con_lvl);
+}
+
+// device + host bytes a parked plan holds (index maps, descriptors, host tree)
+static size_t ds_slot_bytes(const DsPlanSlot& sl) {
+  const DirectPlan& P = sl.plan;
+  size_t b = 4 * (sl.level_sn.n + sl.pmap.n + sl.vtx.n + sl.blk_ld.n + sl.con_ld.n + sl.wl_front.n + sl.wl_row.n + sl.blk_q.n + sl.con_lvl.n) + 8 * (sl.blk_dst.n + sl.con_dst.n) +
+             sizeof(DsFrontDesc) * (sl.fr.n + sl.frl.n) + sizeof(DsChildRec) * sl.ch_rec.n;
+  b += 4 * (P.pmap.size() + P.vtx.size() + P.blk_ld.size() + P.blk_q.size() + P.wl_front.size() + P.wl_row.size() + P.level_sn.size()) + 8 * P.blk_dst.size() + sizeof(DsFrontDesc) * P.fr.size();
+  return b;
+}
+// the cache is bounded by slots ("direct_plan_cache") AND by bytes ("direct_plan_cache_mb"): least recently used plans are dropped, their
+// device arrays released (a plan is ~25 MB on cfg4; a long tape would otherwise pin 64 of them per context)
+static void ds_cache_trim(DirectSolver& d) {
+  for (;;) {
+    size_t total = 0;
+    DsPlanSlot* lru = nullptr;
+    for (auto& sl : d.cache) if (sl->used) { total += ds_slot_bytes(*sl); if (!lru || sl->stamp < lru->stamp) lru = sl.get(); }
+    if (!lru || total <= (size_t)d.cache_mb << 20) return;
+    lru->used = false;
+    lru->level_sn.release(); lru->pmap.release(); lru->vtx.release(); lru->blk_ld.release(); lru->con_ld.release(); lru->wl_front.release(); lru->wl_row.release();
+    lru->blk_q.release(); lru->con_lvl.release(); lru->blk_dst.release(); lru->con_dst.release(); lru->fr.release(); lru->frl.release(); lru->ch_rec.release();
+    d.n_plan_evicted++;
+  }
 }
 
 // plan for the current constraint set (rebuilt only when the set differs from the one the plan was made for)
@@ -230,6 +267,7 @@ static int direct_plan(tsl_ctx* c) {
       ds_swap_slot(d, *dst);
       dst->used = true; dst->key = ds_cons_key(dst->h_cset); dst->stamp = ++d.cache_clock;
       d.plan_valid = false;
+      ds_cache_trim(d);
     }
   }
   const auto t0 = std::chrono::steady_clock::now();
@@ -254,8 +292,7 @@ static int direct_plan(tsl_ctx* c) {
   if (d.sarena.n < (size_t)P.sarena) { if (d.sarena.alloc((size_t)P.sarena + (size_t)P.sarena / 8 + 16)) return tsl_fail("direct solver: out of device memory (%.2f GB of Schur complements)", P.sarena * 8e-9); }
   if (d.garena.n < (size_t)P.garena) { if (d.garena.alloc((size_t)P.garena + (size_t)P.garena / 8 + 16)) return tsl_fail("direct solver: out of device memory (G arena)"); }
   if (d.scr.n < (size_t)P.scratch) { if (d.scr.alloc((size_t)P.scratch + (size_t)P.scratch / 8)) return -1; }
-  const size_t n3 = 3 * (size_t)c->NV;
-  if (d.w.n < n3) { if (d.w.alloc(n3)) return -1; }
+  if (d.w.n < (size_t)P.ylen) { if (d.w.alloc((size_t)P.ylen + (size_t)P.ylen / 4 + 16)) return -1; }
   HIP_OK(hipStreamSynchronize(s));  // host vectors of this function go out of scope
   d.h_cons.swap(cons); d.h_cset.swap(cset);
   d.plan_valid = true;
@@ -293,12 +330,27 @@ static int direct_prezero(tsl_ctx* c) {
   return 0;
 }
 
+// z = (LU)^-1 r, permuted solver vectors (r is not modified; z may not alias r)
+// one launch of the level sweeps: chunks wl[o .. o + n) in `mode`; few chunks (upper levels) -> four narrow workgroups per chunk
+static void ds_launch_gemv(hipStream_t s, const DsDev& D, DirectSolver& d, int o, int n, int mode, const double* vin, double* vout) {
+  if (n <= 0) return;
+  if (d.gemv_wide_below > 0 && n < d.gemv_wide_below) hipLaunchKernelGGL(k_ds_gemv_wide, dim3(4 * n), dim3(256), 0, s, D, d.wl_front.p, d.wl_row.p, o, mode, vin, vout);
+  else hipLaunchKernelGGL(k_ds_gemv, dim3(n), dim3(256), 0, s, D, d.wl_front.p, d.wl_row.p, o, mode, vin, vout);
+}
+// upward sweep of level l: t = W (r - children) on the own dofs, then y_f on the boundary dofs
+static void ds_sweep_up_level(hipStream_t s, const DsDev& D, DirectSolver& d, int l, const double* r, double* z) {
+  const DirectPlan& P = d.plan;
+  const int o0 = P.wl_own_ptr[l], b0 = P.wl_bnd_ptr[l], o1 = P.wl_own_ptr[l + 1];
+  ds_launch_gemv(s, D, d, o0, b0 - o0, 0, r, z);
+  ds_launch_gemv(s, D, d, b0, o1 - b0, 1, (const double*)z, nullptr);
+}
 // numeric factorisation of the operator of the last assemble (c->vals + masked contact blocks c->c_H)
 static int direct_factor(tsl_ctx* c, int stop_sn = -1, const char* dump_path = nullptr) {
   DirectSolver& d = c->ds;
   hipStream_t s = c->stream;
   TSL_TRY(direct_plan(c));
   if (d.numeric_valid) return 0;
+  d.shared_device = ds_mark_active(c, d.device);   // is a neighbour context at work on this device?
   const DirectPlan& P = d.plan;
   const DsDev D = ds_dev(c);
   if (d.prezero_pending) {   // cleared on the side stream since the last solve (direct_prezero)
@@ -389,25 +441,15 @@ static int direct_anorm(tsl_ctx* c) {
   return 0;
 }
 
-// z = (LU)^-1 r, permuted solver vectors (r is not modified; z may not alias r)
-// one launch of the level sweeps: chunks wl[o .. o + n) in `mode`; few chunks (upper levels) -> four narrow workgroups per chunk
-static void ds_launch_gemv(hipStream_t s, const DsDev& D, DirectSolver& d, int o, int n, int mode, const double* vin, double* vout) {
-  if (n <= 0) return;
-  if (d.gemv_wide_below > 0 && n < d.gemv_wide_below) hipLaunchKernelGGL(k_ds_gemv_wide, dim3(4 * n), dim3(256), 0, s, D, d.wl_front.p, d.wl_row.p, o, mode, vin, vout);
-  else hipLaunchKernelGGL(k_ds_gemv, dim3(n), dim3(256), 0, s, D, d.wl_front.p, d.wl_row.p, o, mode, vin, vout);
-}
+// z = (LU)^-1 r (permuted solver vectors; r is not modified, z may not alias r).  Measured and dropped (round 4): the upward half of the
+// first application on a side stream next to the factorisation of the levels above ("eager" right-hand side) -- 268-271 ms per step with
+// the lower 3 / 5 levels overlapped, 288 ms with every level, against 269 without: the sweeps slow the block-step chains down by what they take.
 static int direct_apply(tsl_ctx* c, const double* r, double* z) {
   DirectSolver& d = c->ds;
   hipStream_t s = c->stream;
   const DirectPlan& P = d.plan;
   const DsDev D = ds_dev(c);
-  const size_t n3 = 3 * (size_t)c->NV;
-  HIP_OK(hipMemcpyAsync(d.w.p, r, n3 * sizeof(double), hipMemcpyDeviceToDevice, s));
-  for (int l = 0; l < P.n_levels; l++) {
-    const int o0 = P.wl_own_ptr[l], b0 = P.wl_bnd_ptr[l], o1 = P.wl_own_ptr[l + 1];
-    ds_launch_gemv(s, D, d, o0, b0 - o0, 0, (const double*)d.w.p, z);
-    ds_launch_gemv(s, D, d, b0, o1 - b0, 1, (const double*)z, d.w.p);
-  }
+  for (int l = 0; l < P.n_levels; l++) ds_sweep_up_level(s, D, d, l, r, z);
   for (int l = P.n_levels - 2; l >= 0; l--) {   // the top level has no boundary
     const int o0 = P.wl_own_ptr[l], b0 = P.wl_bnd_ptr[l];
     ds_launch_gemv(s, D, d, o0, b0 - o0, 2, (const double*)z, z);

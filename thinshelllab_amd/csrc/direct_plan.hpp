@@ -31,6 +31,8 @@ struct DsFrontDesc {
   int vtx_off;               // vtx[vtx_off + iv]: vertex id of local vertex iv (own vertices, then boundary vertices)
   int nv_own, nv_bnd;
   int scr_off;               // offset of this front's scratch inside the per-level scratch (doubles)
+  int yoff;                  // y_f (the boundary update of the upward solve sweep, b entries) in the Y buffer
+  int cpm[4], cy[4];         // pmap_off / yoff of the first four children, inline: the sweeps' gather then needs no look-up of the child records
   int ch_off, nchild;        // child fronts: ch_rec[ch_off .. ch_off + nchild), ascending supernode id (the summation order of the gather)
 };
 // what the gather kernels need of a child, in the parent's child order
@@ -39,7 +41,8 @@ struct DsChildRec {
   int bp, b;                 // its row stride and size
   int pmap_off;              // its table over the parent's dofs
   int sn;
-  int nb, pad_;              // boundary dofs that land in the parent's BOUNDARY part (the others are own dofs of the parent)
+  int nb;                    // boundary dofs that land in the parent's BOUNDARY part (the others are own dofs of the parent)
+  int yoff;                  // the child's y_f in the Y buffer
 };
 
 // fronts of one tree level with pivot blocks of similar size: one set of launches (level_sn[first .. first + count), sorted by pp descending)
@@ -91,6 +94,7 @@ struct DirectPlan {
   long long arena = 0;      // panel arena (top rows + F21 of every front), doubles; the fronts of level 0 come first
   long long sarena = 0;     // Schur arena, doubles
   long long garena = 0;     // doubles
+  long long ylen = 0;       // doubles: boundary updates of the solve's upward sweep, bp per front
   long long scratch = 0;    // doubles, max over the levels
   double phase_ms[6] = {0, 0, 0, 0, 0, 0};   // host time of the last build: tree, descriptors + parent maps, levels / batches / work lists, static block map, contact map
   std::vector<int> tpos;                 // static: index of the mirrored block of every pattern block
@@ -126,7 +130,7 @@ struct DirectPlan {
     const int S = sym.n_sn;
     fr.assign(S, DsFrontDesc{});
     pmap.clear(); vtx.clear(); ch_rec.clear();
-    arena = 0; sarena = 0; garena = 0; flops = 0;
+    arena = 0; sarena = 0; garena = 0; flops = 0; ylen = 0;
     for (int s = 0; s < S; s++) {
       DsFrontDesc& f = fr[s];
       f.nv_own = sym.own(s); f.nv_bnd = (int)sym.bnd[s].size();
@@ -151,6 +155,7 @@ struct DirectPlan {
         arena += (long long)f.pp * f.ld + (long long)f.bp * f.pp;
         f.soff = sarena; sarena += (long long)f.bp * f.bp;
         f.goff = garena; garena += (long long)f.pp * f.bp;
+        f.yoff = (int)ylen; ylen += f.bp;
       }
     }
     // children of every front in ascending supernode order, and for every child its table over the PARENT's local dofs: the
@@ -179,7 +184,8 @@ struct DirectPlan {
         for (int q = cptr[p]; q < cptr[p + 1]; q++) {
           DsChildRec& cr = ch_rec[q];
           const DsFrontDesc& ch = fr[cr.sn];
-          cr.soff = ch.soff; cr.bp = ch.bp; cr.b = ch.b; cr.pmap_off = ch.pmap_off;
+          cr.soff = ch.soff; cr.bp = ch.bp; cr.b = ch.b; cr.pmap_off = ch.pmap_off; cr.yoff = ch.yoff;
+          if (q - cptr[p] < 4) { fr[p].cpm[q - cptr[p]] = ch.pmap_off; fr[p].cy[q - cptr[p]] = ch.yoff; }
           const int* cv = &vtx[ch.vtx_off + ch.nv_own];
           int* pm = &pmap[ch.pmap_off];
           int prev = -1;

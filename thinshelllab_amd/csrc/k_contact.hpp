@@ -7,7 +7,6 @@
 // needs.  Contact couplings change every step, so they are NOT merged into the static SELL matrix: each
 // constraint keeps its dense 12x12 block in HBM and the PCG operator adds  sum_c P_c^T H_c P_c x  by atomics.
 #pragma once
-#include <hipcub/hipcub.hpp>
 
 #include "k_solver.hpp"
 #include "tsl_ctx.hpp"
@@ -46,21 +45,102 @@ TSL_DEV void grid_idx3(const GridArgs& G, const d3& x, int o[3]) {
   o[1] = (int)floor(fmin(fmax(x.y, -G.bound), G.bound) / G.h) + G.n / 2;
   o[2] = (int)floor(fmin(fmax(x.z, -G.bound), G.bound) / G.h) + G.n / 2;
 }
-// geometry.p2g first pass (:108-113): cell of every triangle centroid + active box
+// ---- broad phase: the reference's p2g is a counting sort of the triangle centroids into a dense 132^3 grid (geometry.py:96-163).  The
+// refined scenes scale the cell with the mesh (up to 10^9 cells), so the counting sort runs over HASH BUCKETS of the cell id instead
+// (table of >= 2 nf buckets): count per bucket, exclusive scan, scatter, and a rank pass that orders every bucket by (cell, triangle)
+// -- the candidates of a cell are then contiguous inside their bucket in ascending triangle index, the order the sequential selection
+// rule of project_pair is applied in (in the reference it is an atomic-append order).  All hand-written: k_grid_keys,
+// k_scan_local / _top / _add, k_bucket_scatter, k_bucket_rank.
+TSL_DEV int grid_bucket(int cell, int hshift) { return (int)(((unsigned)cell * 2654435761u) >> hshift); }
+// geometry.p2g first pass (:108-113): cell of every triangle centroid + active box + bucket histogram
 __global__ void k_grid_keys(GridArgs G, int f_start, int nf, const int* __restrict__ faces, const double* __restrict__ pos, int* __restrict__ key,
-                            int* __restrict__ val, int* __restrict__ range) {
+                            int* __restrict__ range, int hshift, int* __restrict__ cnt) {
   const int t = blockIdx.x * blockDim.x + threadIdx.x;
   if (t >= nf) return;
   const int f = f_start + t;
   const d3 mid = (ld3(pos, faces[3 * f]) + ld3(pos, faces[3 * f + 1]) + ld3(pos, faces[3 * f + 2])) / 3.0;
   int id[3];
   grid_idx3(G, mid, id);
-  key[t] = (id[0] * G.n + id[1]) * G.n + id[2];
-  val[t] = f;
+  const int cell = (id[0] * G.n + id[1]) * G.n + id[2];
+  key[t] = cell;
+  atomicAdd(&cnt[grid_bucket(cell, hshift)], 1);
   for (int a = 0; a < 3; a++) { atomicMin(&range[a], id[a]); atomicMax(&range[3 + a], id[a]); }
 }
 __global__ void k_grid_range_init(int* range, int n) {
   if (threadIdx.x < 3) range[threadIdx.x] = n; else if (threadIdx.x < 6) range[threadIdx.x] = 0;
+}
+// exclusive prefix sum of n ints in three launches: 1024 elements per workgroup (4 per thread), the workgroup totals scanned by one
+// workgroup, the offsets added back
+#define SCAN_TILE 1024
+TSL_DEV int wg_exclusive_scan256(int v, int* total) {   // 256 threads; returns the exclusive prefix of v, *total = sum (valid in every thread)
+  __shared__ int s_w[4];
+  const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+  int incl = v;
+#pragma unroll
+  for (int o = 1; o < 64; o <<= 1) { const int u = __shfl_up(incl, o, 64); if (lane >= o) incl += u; }
+  if (lane == 63) s_w[w] = incl;
+  __syncthreads();
+  int base = 0;
+  for (int k = 0; k < w; k++) base += s_w[k];
+  *total = s_w[0] + s_w[1] + s_w[2] + s_w[3];
+  __syncthreads();
+  return base + incl - v;
+}
+__global__ void __launch_bounds__(256) k_scan_local(int n, const int* __restrict__ in, int* __restrict__ out, int* __restrict__ bsum) {
+  const int i0 = blockIdx.x * SCAN_TILE + 4 * threadIdx.x;
+  int v[4];
+#pragma unroll
+  for (int k = 0; k < 4; k++) v[k] = i0 + k < n ? in[i0 + k] : 0;
+  int tot;
+  int ex = wg_exclusive_scan256(v[0] + v[1] + v[2] + v[3], &tot);
+#pragma unroll
+  for (int k = 0; k < 4; k++) { if (i0 + k < n) out[i0 + k] = ex; ex += v[k]; }
+  if (threadIdx.x == 0) bsum[blockIdx.x] = tot;
+}
+__global__ void __launch_bounds__(256) k_scan_top(int nb, int* __restrict__ bsum) {   // in place, nb workgroup totals (any count: chunks of 256)
+  int carry = 0;
+  for (int c0 = 0; c0 < nb; c0 += 256) {
+    const int i = c0 + threadIdx.x;
+    const int v = i < nb ? bsum[i] : 0;
+    int tot;
+    const int ex = wg_exclusive_scan256(v, &tot);
+    if (i < nb) bsum[i] = carry + ex;
+    carry += tot;
+  }
+}
+__global__ void __launch_bounds__(256) k_scan_add(int n, int* __restrict__ out, const int* __restrict__ bsum) {
+  const int i0 = blockIdx.x * SCAN_TILE + 4 * threadIdx.x;
+  const int b = bsum[blockIdx.x];
+#pragma unroll
+  for (int k = 0; k < 4; k++) if (i0 + k < n) out[i0 + k] += b;
+}
+static void scan_exclusive(hipStream_t s, int n, const int* in, int* out, int* bsum) {   // bsum: (n + SCAN_TILE - 1) / SCAN_TILE ints of scratch
+  const int nb = (n + SCAN_TILE - 1) / SCAN_TILE;
+  hipLaunchKernelGGL(k_scan_local, dim3(nb), dim3(256), 0, s, n, in, out, bsum);
+  if (nb > 1) {
+    hipLaunchKernelGGL(k_scan_top, dim3(1), dim3(256), 0, s, nb, bsum);
+    hipLaunchKernelGGL(k_scan_add, dim3(nb), dim3(256), 0, s, n, out, (const int*)bsum);
+  }
+}
+// members of every bucket in arrival order (atomic cursor) ...
+__global__ void k_bucket_scatter(int nf, const int* __restrict__ key, int hshift, const int* __restrict__ ptr, int* __restrict__ cur, int* __restrict__ tmp) {
+  const int t = blockIdx.x * blockDim.x + threadIdx.x;
+  if (t >= nf) return;
+  const int b = grid_bucket(key[t], hshift);
+  tmp[ptr[b] + atomicAdd(&cur[b], 1)] = t;
+}
+// ... then every member finds its rank by (cell, triangle) among the members of its bucket (a handful): the result does not depend on the
+// arrival order
+__global__ void k_bucket_rank(int nf, int f_start, const int* __restrict__ key, int hshift, const int* __restrict__ ptr, const int* __restrict__ tmp,
+                              int* __restrict__ skey, int* __restrict__ sval) {
+  const int t = blockIdx.x * blockDim.x + threadIdx.x;
+  if (t >= nf) return;
+  const int k = key[t], b = grid_bucket(k, hshift);
+  const int s0 = ptr[b], s1 = ptr[b + 1];
+  int rank = 0;
+  for (int e = s0; e < s1; e++) { const int u = tmp[e]; const int ku = key[u]; rank += (ku < k || (ku == k && u < t)) ? 1 : 0; }
+  skey[s0 + rank] = k;
+  sval[s0 + rank] = f_start + t;
 }
 
 // geometry.pt2tri (:23-87)
@@ -88,12 +168,6 @@ TSL_DEV void pt2tri(const d3& x, const d3& p1, const d3& p2, const d3& p3, int& 
   }
 }
 
-TSL_DEV int lower_bound_dev(const int* __restrict__ a, int n, int key) {
-  int lo = 0, hi = n;
-  while (lo < hi) { const int mid = (lo + hi) >> 1; if (a[mid] < key) lo = mid + 1; else hi = mid; }
-  return lo;
-}
-
 // geometry.project_pair (:165-221).  G lanes (a power of two <= 64) share one query vertex: the candidates of each of the
 // <= 27 cells are taken in chunks of G consecutive ones, one per lane, and the reference's running selection rule (closer by more
 // than 1e-5, or within 1e-5 and larger cosine) is applied to the chunk EXACTLY as a sequential scan would: the state (d_min,
@@ -112,7 +186,7 @@ TSL_DEV bool proj_replaces(const ProjBest& cur, const ProjBest& cand) {  // cand
 // contain the vertex are skipped, only projections INSIDE a triangle (c == 0) are candidates, the flag is "a candidate exists"
 template <int G, bool SELF>
 __global__ void __launch_bounds__(256)
-k_project_pair(GridArgs Gr, int v_start, int v_end, int body_idx, int NV, int nf, const int* __restrict__ skey, const int* __restrict__ sval,
+k_project_pair(GridArgs Gr, int v_start, int v_end, int body_idx, int NV, int hshift, const int* __restrict__ bptr, const int* __restrict__ skey, const int* __restrict__ sval,
                const int* __restrict__ range, const int* __restrict__ faces, const double* __restrict__ pos, const double* __restrict__ vn,
                const int* __restrict__ border, int* __restrict__ proj_flag, int* __restrict__ proj_dir, int* __restrict__ proj_idx,
                double* __restrict__ proj_w) {
@@ -135,10 +209,11 @@ k_project_pair(GridArgs Gr, int v_start, int v_end, int body_idx, int NV, int nf
       for (int gj = r0[1]; gj < r1[1]; gj++)
         for (int gk = r0[2]; gk < r1[2]; gk++) {
           const int cell = (gi * Gr.n + gj) * Gr.n + gk;
-          const int s0 = lower_bound_dev(skey, nf, cell), s1 = lower_bound_dev(skey, nf, cell + 1);
+          const int bk = grid_bucket(cell, hshift);
+          const int s0 = bptr[bk], s1 = bptr[bk + 1];   // the cell's triangles lie in its hash bucket, contiguous, in ascending triangle index
           for (int sb = s0; sb < s1; sb += G) {
             const int sidx = sb + g;
-            bool valid = sidx < s1;
+            bool valid = sidx < s1 && skey[sidx] == cell;
             int a = 0, b = 0, c3 = 0, c = 0;
             double d = 0.0, cs = 0.0;
             d3 w = d3();
@@ -771,10 +846,12 @@ static int contact_alloc(tsl_ctx* c, const tsl_scene_desc* d) {
   int mbf = 1;
   for (auto& b : c->h_bodies) mbf = std::max(mbf, b.f_end - b.f_start);
   c->max_body_faces = mbf;
+  int ts = 64;
+  while (ts < 2 * mbf) ts <<= 1;   // hash buckets of the broad phase: a power of two >= 2 x the largest triangle set
+  c->grid_buckets_max = ts;
   rc |= c->grid_key.alloc(mbf); rc |= c->grid_val.alloc(mbf); rc |= c->grid_key2.alloc(mbf); rc |= c->grid_val2.alloc(mbf); rc |= c->grid_range.alloc(8);
-  size_t tmp_bytes = 0;
-  hipcub::DeviceRadixSort::SortPairs(nullptr, tmp_bytes, c->grid_key.p, c->grid_key2.p, c->grid_val.p, c->grid_val2.p, mbf);
-  rc |= c->sort_tmp.alloc(tmp_bytes + 256);
+  rc |= c->grid_cnt.alloc((size_t)ts + 1); rc |= c->grid_ptr.alloc((size_t)ts + 1); rc |= c->grid_cur.alloc((size_t)ts + 1);
+  rc |= c->scan_tmp.alloc((size_t)std::max(ts, NV + 1) / SCAN_TILE + 2);
   // border_flag (BaseScene.py:82): all zero unless imported
   rc |= c->border.alloc(NV);
   if (rc) return -1;
@@ -806,17 +883,24 @@ extern "C" int tsl_contact_detect(tsl_ctx* c, const double* pos, const double* p
     const tsl_body& body = c->h_bodies[b];
     const int nf = body.f_end - body.f_start;
     if (nf <= 0) continue;
+    int ts = 64, lg = 6;
+    while (ts < 2 * nf) { ts <<= 1; lg++; }
+    const int hshift = 32 - lg;
     hipLaunchKernelGGL(k_grid_range_init, dim3(1), dim3(64), 0, s, c->grid_range.p, G.n);
-    hipLaunchKernelGGL(k_grid_keys, dim3(cnblk(nf, 256)), dim3(256), 0, s, G, body.f_start, nf, c->faces.p, pos, c->grid_key.p, c->grid_val.p, c->grid_range.p);
-    size_t tmp_bytes = c->sort_tmp.n;
-    HIP_OK(hipcub::DeviceRadixSort::SortPairs(c->sort_tmp.p, tmp_bytes, c->grid_key.p, c->grid_key2.p, c->grid_val.p, c->grid_val2.p, nf, 0, 32, s));
+    HIP_OK(hipMemsetAsync(c->grid_cnt.p, 0, ((size_t)ts + 1) * sizeof(int), s));
+    HIP_OK(hipMemsetAsync(c->grid_cur.p, 0, (size_t)ts * sizeof(int), s));
+    hipLaunchKernelGGL(k_grid_keys, dim3(cnblk(nf, 256)), dim3(256), 0, s, G, body.f_start, nf, c->faces.p, pos, c->grid_key.p, c->grid_range.p, hshift, c->grid_cnt.p);
+    scan_exclusive(s, ts + 1, c->grid_cnt.p, c->grid_ptr.p, c->scan_tmp.p);
+    hipLaunchKernelGGL(k_bucket_scatter, dim3(cnblk(nf, 256)), dim3(256), 0, s, nf, (const int*)c->grid_key.p, hshift, (const int*)c->grid_ptr.p, c->grid_cur.p, c->grid_val.p);
+    hipLaunchKernelGGL(k_bucket_rank, dim3(cnblk(nf, 256)), dim3(256), 0, s, nf, body.f_start, (const int*)c->grid_key.p, hshift, (const int*)c->grid_ptr.p, (const int*)c->grid_val.p,
+                       c->grid_key2.p, c->grid_val2.p);
     for (int b2 = 0; b2 < c->n_body; b2++) {
       if (b2 == b) continue;
       const tsl_body& q = c->h_bodies[b2];
       const int nq = q.v_end - q.v_start;
       if (nq <= 0) continue;
 #define TSL_PROJ_LAUNCH(GW, SF)                                                                                                                                      \
-  hipLaunchKernelGGL((k_project_pair<GW, SF>), dim3(cnblk((long)nq * GW, 256)), dim3(256), 0, s, G, q.v_start, q.v_end, b, NV, nf, c->grid_key2.p, c->grid_val2.p, \
+  hipLaunchKernelGGL((k_project_pair<GW, SF>), dim3(cnblk((long)nq * GW, 256)), dim3(256), 0, s, G, q.v_start, q.v_end, b, NV, hshift, (const int*)c->grid_ptr.p, c->grid_key2.p, c->grid_val2.p, \
                      c->grid_range.p, c->faces.p, pos, c->vn.p, c->border.p, c->proj_flag.p, c->proj_dir.p, c->proj_idx.p, c->proj_w.p)
       // lanes per query vertex by the size of the triangle set it scans (many triangles per cell on refined cloths)
       if (nf >= 8192) TSL_PROJ_LAUNCH(64, false);
@@ -860,15 +944,12 @@ extern "C" int tsl_contact_detect(tsl_ctx* c, const double* pos, const double* p
   if (c->nc > 0) {
     const int n1 = NV + 1;
     if (c->cr_ptr.n == 0) {
-      size_t tb = 0;
-      (void)hipcub::DeviceScan::ExclusiveSum(nullptr, tb, (int*)nullptr, (int*)nullptr, n1, s);
-      if (c->cr_ptr.alloc(n1) | c->cr_cnt.alloc(n1) | c->cr_fill.alloc(n1) | c->cr_ent.alloc(4 * (size_t)c->max_n_constraints) | c->cr_rows.alloc(4 * (size_t)c->max_n_constraints) | c->cr_tmp.alloc(tb + 16)) return -1;
+      if (c->cr_ptr.alloc(n1) | c->cr_cnt.alloc(n1) | c->cr_fill.alloc(n1) | c->cr_ent.alloc(4 * (size_t)c->max_n_constraints) | c->cr_rows.alloc(4 * (size_t)c->max_n_constraints)) return -1;
     }
     HIP_OK(hipMemsetAsync(c->cr_cnt.p, 0, n1 * sizeof(int), s));
     HIP_OK(hipMemsetAsync(c->cr_fill.p, 0, n1 * sizeof(int), s));
     hipLaunchKernelGGL(k_cr_count, dim3(cnblk(4 * (long)c->nc, 256)), dim3(256), 0, s, c->nc, c->c_idx.p, c->rowpos.p, c->cr_cnt.p);
-    size_t tb = c->cr_tmp.n;
-    HIP_OK(hipcub::DeviceScan::ExclusiveSum(c->cr_tmp.p, tb, c->cr_cnt.p, c->cr_ptr.p, n1, s));
+    scan_exclusive(s, n1, c->cr_cnt.p, c->cr_ptr.p, c->scan_tmp.p);
     hipLaunchKernelGGL(k_cr_fill, dim3(cnblk(4 * (long)c->nc, 256)), dim3(256), 0, s, c->nc, c->c_idx.p, c->rowpos.p, c->cr_ptr.p, c->cr_fill.p, c->cr_ent.p, c->cr_rows.p);
     HIP_OK(hipGetLastError());
   }

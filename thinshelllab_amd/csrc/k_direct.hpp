@@ -27,6 +27,7 @@ struct DsDev {                 // device views shared by the kernels
   double* S;                   // Schur arena: S of every front (bp x bp, row stride bp)
   double* G;                   // G = W F12 of every front (pp x bp, row stride bp)
   double* scr;                 // per-level scratch (pivot-block inverses, row panel, column panel per front)
+  double* Y;                   // boundary updates of the upward sweep: y_f at DsFrontDesc.yoff (b entries per front)
   const DsChildRec* ch;        // children of every front (DsFrontDesc.ch_off / nchild), ascending supernode id
   const int* pmap;             // per child: table over the parent's local dofs -> the child's boundary dof, or -1
   const int* vtx;              // local vertex -> PERMUTED vertex position (rows of the solver vectors)
@@ -231,10 +232,11 @@ TSL_DEV void ds_invert_tile_wg(double* __restrict__ T, int ldt, int* __restrict_
 //     forms row 0 of THAT inverse from cofactors: 6 shared 2 x 2 minors, four 3 x 3 minors, one determinant, one reciprocal -- ~45
 //     short-chain instructions instead of ~110 of a four-pivot elimination plus 12 row selects.  On the condition-1e9 tile of
 //     scripts/micro/inv_bench.hip both forms reach |A inv(A) - I| = 5e-8..1e-7.
-//   * Static pivoting keeps its rule where it matters: when the cofactor expansion of the determinant cancels (|det| < 1e-6 sum
-//     |terms|: a block a diagonal-pivot elimination might have to perturb) the lane falls back to the four-pivot elimination with the
-//     per-pivot threshold of the first form (divergent branch, no barrier or matrix instruction inside).  Blocks with a zero
-//     leading entry but a healthy determinant ([0 1; 1 0]) are inverted exactly instead of being perturbed.
+//   * Static pivoting keeps its rule: when the cofactor expansion of the determinant cancels (|det| < 1e-6 sum |terms|) OR an entry
+//     of the inverse exceeds 1 / (tol x the entry diagonal of its row) -- a pivot that lost its digits before it reached this block --
+//     the wave falls back to the four-pivot elimination with the per-pivot threshold of the first form (uniform branch, no barrier or
+//     matrix instruction inside).  Blocks with a zero leading entry but a healthy determinant ([0 1; 1 0]) are inverted exactly
+//     instead of being perturbed.
 TSL_DEV void ds_invert_tile_wg2(double* __restrict__ T, int ldt, int* __restrict__ bad, int cls, int tag, double tol) {
   __shared__ double rowp[2][DS_PB][DS_T], colp[2][DS_PB][DS_T + 1], dblk[2][DS_PB][DS_PB], red[4], dg0[DS_T];
   const int lane = threadIdx.x & 63, w = threadIdx.x >> 6, wi = w >> 1, wj = w & 1, lr = lane & 15, lk = lane >> 4;
@@ -287,10 +289,13 @@ TSL_DEV void ds_invert_tile_wg2(double* __restrict__ T, int ldt, int* __restrict
     const double det = (t0 - t1) + (t2 - t3);
     const double dabs = (fabs(t0) + fabs(t1)) + (fabs(t2) + fabs(t3));
     double drow[DS_PB];
-    if (fabs(det) >= 1e-6 * dabs && dabs < 1e300) {
-      const double idet = ds_rcp(det);
-      drow[0] = M0 * idet; drow[1] = -M1 * idet; drow[2] = M2 * idet; drow[3] = -M3 * idet;
-    } else {
+    const double idet = ds_rcp(det);
+    drow[0] = M0 * idet; drow[1] = -M1 * idet; drow[2] = M2 * idet; drow[3] = -M3 * idet;
+    // static-pivot rule on the cofactor path: the determinant must not cancel, and no entry of the lane's row of the inverse may exceed
+    // 1 / (tol x the entry diagonal of that row) -- for a diagonal block exactly "pivot >= tol x its own scale"; a block like
+    // diag(1e-20, 1, 1, 1) shows no cancellation and would be inverted as it is.  Every lane of the wave takes the same path.
+    const bool ok = fabs(det) >= 1e-6 * dabs && dabs < 1e300 && fmax(fmax(fabs(drow[0]), fabs(drow[1])), fmax(fabs(drow[2]), fabs(drow[3]))) * (tol * dg0[p0 + lk]) <= 1.0;
+    if (__builtin_amdgcn_ballot_w64(!ok) != 0) {
       // four-pivot elimination on the unrotated block with the per-pivot threshold (first form), then row lk
       double d[DS_PB][DS_PB];
 #pragma unroll
@@ -386,10 +391,12 @@ TSL_DEV void ds_invert_tile_wg4(double* __restrict__ T, int ldt, int* __restrict
     const double t0 = a[0] * M0, t1 = a[1] * M1, t2 = a[2] * M2, t3 = a[3] * M3;
     const double det = (t0 - t1) + (t2 - t3);
     const double dabs = (fabs(t0) + fabs(t1)) + (fabs(t2) + fabs(t3));
-    if (fabs(det) >= 1e-6 * dabs && dabs < 1e300) {
-      const double idet = ds_rcp(det);
-      drow[0] = M0 * idet; drow[1] = -M1 * idet; drow[2] = M2 * idet; drow[3] = -M3 * idet;
-    } else {   // four-pivot elimination on the unrotated block with the per-pivot threshold (first form), then row lk
+    const double idet = ds_rcp(det);
+    drow[0] = M0 * idet; drow[1] = -M1 * idet; drow[2] = M2 * idet; drow[3] = -M3 * idet;
+    // static-pivot rule on the cofactor path (see form 2): no cancellation in the determinant AND no entry of the lane's row of the inverse
+    // above 1 / (tol x the entry diagonal of that row); the whole wave takes the same path
+    const bool ok = fabs(det) >= 1e-6 * dabs && dabs < 1e300 && fmax(fmax(fabs(drow[0]), fabs(drow[1])), fmax(fabs(drow[2]), fabs(drow[3]))) * (tol * dg0[p0 + lk]) <= 1.0;
+    if (__builtin_amdgcn_ballot_w64(!ok) != 0) {   // four-pivot elimination on the unrotated block with the per-pivot threshold (first form), then row lk
       double d[DS_PB][DS_PB];
 #pragma unroll
       for (int i = 0; i < DS_PB; i++)
@@ -1291,20 +1298,48 @@ __global__ void __launch_bounds__(256, WPC) k_ds_gemm(DsDev D, int lv0) {
 
 // ---- solve ----------------------------------------------------------------------------------------------------------------
 // One matrix-vector pass over the fronts of a level; a workgroup owns 16 rows of one front (4 per wave), the input vector of the
-// front is staged in LDS in chunks.
-//   mode 0 (up, W):    t[own i]  = sum_j W[i, j] w[own j]
-//   mode 1 (up, F21):  w[bnd i] -= sum_j F21[i, j] t[own j]          (atomic: sibling fronts share boundary vertices)
+// front is staged in LDS in chunks.  The upward sweep carries the boundary updates from child to parent like the factorisation carries the
+// Schur complements: every front STORES y_f (b entries: what its subtree subtracts from the right-hand side on its boundary dofs) and its
+// parent gathers it through the same child tables (pmap) in the plan's fixed child order -- no atomics, the right-hand side is not
+// modified (no copy), a fixed summation order:
+//   mode 0 (up, W):    t[own i]  = sum_j W[i, j] (r[own j] - sum_children y_c[pmap_c[j]])
+//   mode 1 (up, F21):  y_f[i]    = sum_children y_c[pmap_c[pp + i]] + sum_j F21[i, j] t[own j]
 //   mode 2 (down, G):  x[own i]  = t[own i] - sum_j G[i, j] x[bnd j]  (x and t may alias)
 #define DS_VCHUNK 2048
-// one chunk of 16 rows of one front in one mode of the level sweeps: 0  z_own = W w_own;  1  w_bnd -= F21 z_own (atomic: several fronts
-// share a boundary dof);  2  z_own -= G z_bnd.  (FLOW: agent-scope loads and write-through stores -- the form a one-launch sweep with
-// chained phases needs; measured slower than the 28 launches it replaces, profiles/README.md -- not instantiated.)
-template <bool FLOW>
-TSL_DEV void ds_gemv_chunk(const DsDev& D, int sn, int r0, int mode, const double* vin, double* vout, double* xs) {
-  const DsFrontDesc f = D.fr[sn];
+// what the children's subtrees subtract on local dof d (own: d < p, boundary: pp + i) of front f.  The table and y offsets of the first
+// four children sit in the front's descriptor: four independent table loads, then four independent loads of y -- two round trips, the
+// depth of the vertex-id -> vector gather they run next to
+TSL_DEV double ds_child_sum(const DsDev& D, const DsFrontDesc& f, int d) {
+  int ci[4];
+#pragma unroll
+  for (int q = 0; q < 4; q++) ci[q] = q < f.nchild ? D.pmap[f.cpm[q] + d] : -1;
+  double y[4];
+#pragma unroll
+  for (int q = 0; q < 4; q++) y[q] = ci[q] >= 0 ? D.Y[f.cy[q] + ci[q]] : 0.0;
+  double a = ((y[0] + y[1]) + y[2]) + y[3];   // (ascending child order)
+  for (int q = 4; q < f.nchild; q++) {
+    const DsChildRec c = D.ch[f.ch_off + q];
+    const int cq = D.pmap[c.pmap_off + d];
+    if (cq >= 0) a += D.Y[c.yoff + cq];
+  }
+  return a;
+}
+TSL_DEV void ds_gemv_stage(const DsDev& D, const DsFrontDesc& f, int mode, const int* vt, int in_v0, const double* vin, int c0, int cn, double* xs) {
+  __syncthreads();
+  for (int j = threadIdx.x; j < cn; j += 256) {
+    const int jj = c0 + j;
+    const double sub = (mode == 0 && f.nchild > 0) ? ds_child_sum(D, f, jj) : 0.0;
+    xs[j] = vin[3 * (size_t)vt[in_v0 + jj / 3] + jj % 3] - sub;
+  }
+  __syncthreads();
+}
+__global__ void __launch_bounds__(256) k_ds_gemv(DsDev D, const int* __restrict__ wl_front, const int* __restrict__ wl_row, int wl0, int mode, const double* vin, double* vout) {
+  __shared__ double xs[DS_VCHUNK];
+  const DsFrontDesc f = D.fr[wl_front[wl0 + blockIdx.x]];
+  const int r0 = wl_row[wl0 + blockIdx.x];
   const int nrows = mode == 1 ? f.b : f.p, ncols = mode == 2 ? f.b : f.p;
   const int* vt = D.vtx + f.vtx_off;
-  const int in_v0 = mode == 2 ? f.nv_own : 0, out_v0 = mode == 1 ? f.nv_own : 0;
+  const int in_v0 = mode == 2 ? f.nv_own : 0;
   const double* M = mode == 2 ? D.G + f.goff : D.A + (mode == 1 ? f.off21 : f.off);
   const int rs = mode == 2 ? f.bp : (mode == 1 ? f.pp : f.ld);
   const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
@@ -1318,13 +1353,7 @@ TSL_DEV void ds_gemv_chunk(const DsDev& D, int sn, int r0, int mode, const doubl
   const double* row3 = M + (size_t)min(ib + 3, nrows - 1) * rs;
   for (int c0 = 0; c0 < ncols; c0 += DS_VCHUNK) {
     const int cn = min(DS_VCHUNK, ncols - c0);
-    __syncthreads();
-    for (int j = threadIdx.x; j < cn; j += 256) {
-      const int jj = c0 + j;
-      const double* src = &vin[3 * (size_t)vt[in_v0 + jj / 3] + jj % 3];
-      xs[j] = FLOW ? __hip_atomic_load(src, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : *src;
-    }
-    __syncthreads();
+    ds_gemv_stage(D, f, mode, vt, in_v0, vin, c0, cn, xs);
 #pragma unroll 4
     for (int j = lane; j < cn; j += 64) {
       const double xv = xs[j];
@@ -1336,19 +1365,13 @@ TSL_DEV void ds_gemv_chunk(const DsDev& D, int sn, int r0, int mode, const doubl
     const int i = r0 + 4 * w + q;
     const double a = wave_sum(acc[q]);
     if (lane == 0 && i < nrows) {
-      const size_t o = 3 * (size_t)vt[out_v0 + i / 3] + i % 3;
-      if (mode == 1) atomicAdd(&vout[o], -a);
-      else if (!FLOW) vout[o] = mode == 0 ? a : vout[o] - a;
+      if (mode == 1) D.Y[f.yoff + i] = (f.nchild > 0 ? ds_child_sum(D, f, f.pp + i) : 0.0) + a;
       else {
-        const double v = mode == 0 ? a : __hip_atomic_load(&vout[o], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) - a;
-        __hip_atomic_store(&vout[o], v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        const size_t o = 3 * (size_t)vt[i / 3] + i % 3;
+        vout[o] = mode == 0 ? a : vout[o] - a;
       }
     }
   }
-}
-__global__ void __launch_bounds__(256) k_ds_gemv(DsDev D, const int* __restrict__ wl_front, const int* __restrict__ wl_row, int wl0, int mode, const double* vin, double* vout) {
-  __shared__ double xs[DS_VCHUNK];
-  ds_gemv_chunk<false>(D, wl_front[wl0 + blockIdx.x], wl_row[wl0 + blockIdx.x], mode, vin, vout, xs);
 }
 
 // The same chunk for the launches of the upper levels, which have 66 - 600 workgroups of 16 rows: FOUR workgroups per chunk, each
@@ -1363,7 +1386,7 @@ __global__ void __launch_bounds__(256) k_ds_gemv_wide(DsDev D, const int* __rest
   const int r0 = wl_row[e] + 4 * (blockIdx.x & 3);
   if (r0 >= nrows) return;
   const int* vt = D.vtx + f.vtx_off;
-  const int in_v0 = mode == 2 ? f.nv_own : 0, out_v0 = mode == 1 ? f.nv_own : 0;
+  const int in_v0 = mode == 2 ? f.nv_own : 0;
   const double* M = mode == 2 ? D.G + f.goff : D.A + (mode == 1 ? f.off21 : f.off);
   const int rs = mode == 2 ? f.bp : (mode == 1 ? f.pp : f.ld);
   const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
@@ -1374,9 +1397,7 @@ __global__ void __launch_bounds__(256) k_ds_gemv_wide(DsDev D, const int* __rest
   const double* row3 = M + (size_t)min(r0 + 3, nrows - 1) * rs;
   for (int c0 = 0; c0 < ncols; c0 += DS_VCHUNK) {
     const int cn = min(DS_VCHUNK, ncols - c0);
-    __syncthreads();
-    for (int j = threadIdx.x; j < cn; j += 256) { const int jj = c0 + j; xs[j] = vin[3 * (size_t)vt[in_v0 + jj / 3] + jj % 3]; }
-    __syncthreads();
+    ds_gemv_stage(D, f, mode, vt, in_v0, vin, c0, cn, xs);
 #pragma unroll 4
     for (int j = threadIdx.x; j < cn; j += 256) {
       const double xv = xs[j];
@@ -1390,10 +1411,11 @@ __global__ void __launch_bounds__(256) k_ds_gemv_wide(DsDev D, const int* __rest
     const int q = threadIdx.x, i = r0 + q;
     if (i < nrows) {
       const double a = (part[0][q] + part[1][q]) + (part[2][q] + part[3][q]);
-      const size_t o = 3 * (size_t)vt[out_v0 + i / 3] + i % 3;
-      if (mode == 0) vout[o] = a;
-      else if (mode == 1) atomicAdd(&vout[o], -a);
-      else vout[o] = vout[o] - a;
+      if (mode == 1) D.Y[f.yoff + i] = (f.nchild > 0 ? ds_child_sum(D, f, f.pp + i) : 0.0) + a;
+      else {
+        const size_t o = 3 * (size_t)vt[i / 3] + i % 3;
+        vout[o] = mode == 0 ? a : vout[o] - a;
+      }
     }
   }
 }

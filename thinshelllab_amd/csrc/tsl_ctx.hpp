@@ -123,6 +123,8 @@ struct DirectSolver {
   hipEvent_t ev_ffork = nullptr, ev_fjoin[2] = {nullptr, nullptr};
   int par_batches = 1;      // "direct_par_batches"
   // "direct_flow": block steps of a batch alone on its level as one persistent dataflow launch (k_ds_gj_flow)
+  int device = 0;          // HIP device of the context (tsl_ctx_create)
+  bool shared_device = false;   // another context of this process factorised on the device within the last two seconds (direct_factor)
   int flow = 3, flow_cap[2] = {0, 0}, flow_epoch = 0;   // flow_cap: resident workgroups of the 4 / 5-per-CU instantiations
   long n_flow = 0, n_flow_abort = 0;   // dataflow launches / launches that lost a flag (the solve then refactorises on the block-step path)
   DevBuf<double> flow_x;    // exchange slots (pivot inverses, row / column panel tiles)
@@ -154,8 +156,8 @@ struct DirectSolver {
   int refine_ir = 1;           // "direct_refine": 1 = classic iterative refinement with the factors (GMRES only where it stalls), 0 = flexible GMRES from the start
   int n_setup_fail = 0;        // set-up failures of the direct path in automatic mode (three disable it)
   std::vector<std::unique_ptr<DsPlanSlot>> cache;   // plans of earlier constraint sets ("direct_plan_cache" slots, least recently used evicted)
-  int cache_cap = 64;
-  long cache_clock = 0, n_plan_hits = 0;
+  int cache_cap = 64, cache_mb = 1024;   // slots / MB of parked plans ("direct_plan_cache", "direct_plan_cache_mb")
+  long cache_clock = 0, n_plan_hits = 0, n_plan_evicted = 0;
   DirectPlan plan;
   std::vector<DsGrid> grids;
   std::vector<DsBlock> blocks;
@@ -313,14 +315,14 @@ struct tsl_ctx {
   DevBuf<double> c_w, c_n, c_dx0, c_k, c_mu, c_T;     // 3,3,3,1,1,6
   DevBuf<int> cr_ptr, cr_cnt, cr_fill, cr_ent;        // row -> (constraint, slot) CSR of the step's constraints (ContactRows)
   DevBuf<int4> cr_rows;
-  DevBuf<unsigned char> cr_tmp;
   DevBuf<int> c_kind;                                 // friction parameter of the constraint's pair (0 fixed, 1 / 2 live)
   DevBuf<double> c_H;                                 // max_nc x 144 (12x12, masked) for the matrix-free product
   DevBuf<double> c_Hfull;                             // unmasked copy (adjoint)
   DevBuf<double> c_diag;                              // NV x 9 (permuted): masked contact contribution to the diagonal blocks
   DevBuf<double> c_G;                                 // max_nc x 12 scratch
   DevBuf<int> grid_key, grid_val, grid_key2, grid_val2, grid_range;  // per target body: cell id / face id (sorted), active range (6 ints)
-  DevBuf<unsigned char> sort_tmp;
+  DevBuf<int> grid_cnt, grid_ptr, grid_cur, scan_tmp;   // hash buckets of the broad phase (histogram, offsets, cursors) and the scratch of the scan
+  int grid_buckets_max = 0;
   int max_body_faces = 0;
 
   // ---- multigrid preconditioner

@@ -311,7 +311,7 @@ extern "C" int tsl_ctx_create(const tsl_scene_desc* d, tsl_ctx** out) {
 #undef UP
   int rc = 0;
   rc |= c->norm_dir.alloc((size_t)std::max(c->n_cface, 1) * 3);
-  if (c->n_cgblk > 0) { rc |= c->cg_hrec.alloc((size_t)std::max(c->n_hinge, 1) * 16); rc |= c->cg_frec.alloc((size_t)c->n_cface * 81); }
+  // (the element records of the gather assembly -- 81 doubles per face, 65 MB at 100k triangles -- are allocated when "cloth_gather" first runs)
   rc |= c->quirk.alloc((size_t)std::max(d->n_cloth, 1) * 90);
   rc |= c->vals.alloc((size_t)P.n_slots * 9); rc |= c->vals_full.alloc((size_t)P.n_slots * 9);
   rc |= c->Dinv.alloc((size_t)NV * 9);
@@ -339,12 +339,14 @@ extern "C" int tsl_ctx_create(const tsl_scene_desc* d, tsl_ctx** out) {
   if (mg_build(c, d)) { delete c; return -1; }
   if (body_dense_setup(c)) { delete c; return -1; }
   (void)hipDeviceSynchronize();
+  (void)hipGetDevice(&c->ds.device);
   *out = c;
   return 0;
 }
 
 extern "C" void tsl_ctx_destroy(tsl_ctx* c) {
   if (!c) return;
+  ds_forget(c);
   (void)hipDeviceSynchronize();
   if (c->h_scal) (void)hipHostFree(c->h_scal);
   if (c->h_scal2) (void)hipHostFree(c->h_scal2);
@@ -400,6 +402,7 @@ extern "C" int tsl_set_param(tsl_ctx* c, const char* key, double v) {
   else if (k == "direct_refine") c->ds.refine_ir = (int)v;
   else if (k == "direct_small_rounds") { ds_small_rounds = std::max(1, (int)v); c->ds.plan_valid = false; c->ds.numeric_valid = false; c->ds.cache.clear(); }
   else if (k == "direct_plan_cache") { c->ds.cache_cap = std::max(0, (int)v); c->ds.cache.clear(); }
+  else if (k == "direct_plan_cache_mb") c->ds.cache_mb = std::max(1, (int)v);
   else if (k == "tet_warm") c->tet_warm = (int)v;
   else if (k == "cloth_gather") c->cloth_gather = (int)v;
   else if (k == "ds_dbg") c->ds.dbg = (int)v;
