@@ -5,7 +5,7 @@
 #   combined with tracing), 3. the bench lines with cpu_baseline (default command and the driver's command).
 cd $GRAFT_REPO_ROOT
 export TMPDIR=/tmp
-TAG=${1:-r03}
+TAG=${1:-r04}
 WL=${WORKLOAD:-cfg4}
 ARGS=${BENCH_ARGS:---steps 20 --warmup 5 --no-cpu-baseline}
 PMC_ARGS=${PMC_ARGS:---steps 3 --warmup 1 --no-cpu-baseline}
@@ -13,7 +13,7 @@ mkdir -p gpurun_out/prof
 rocprofv3 --kernel-trace --stats --output-format csv -d gpurun_out/prof -o ${TAG}_bench -- python bench.py --workload $WL $ARGS > gpurun_out/prof/${TAG}_bench_stdout.log 2>&1
 tail -1 gpurun_out/prof/${TAG}_bench_stdout.log | cut -c1-300
 rm -f gpurun_out/prof/*kernel_trace.csv
-for KRN in "k_ds_gemm<1" "k_ds_gemm<0" "k_ds_gj_step" "k_ds_gj_flow" "k_ds_gemv"; do   # regex prefixes: the GEMM templates carry a second parameter
+for KRN in "k_ds_gemm<1" "k_ds_extend_panels" "k_ds_gemm<0" "k_ds_gj_flow" "k_ds_gemv"; do   # regex prefixes: the GEMM templates carry a second parameter
   KN=$(echo $KRN | tr -d '<>')
   for CNT in FETCH_SIZE WRITE_SIZE; do
     rocprofv3 --pmc $CNT --kernel-include-regex "$KRN" --output-format csv -d gpurun_out/prof -o ${TAG}_pmc_${KN}_$CNT -- python bench.py --workload $WL $PMC_ARGS > gpurun_out/prof/${TAG}_pmc_stdout.log 2>&1

@@ -29,7 +29,7 @@ for s, d in ((f"{TAG}_full_default.json", f"{TAG}_{WL}_bench_default.json"), (f"
         j = json.loads(line); c = j["config"]; r = j["roofline"]
         print(d, round(j["value"]), "el-steps/s", round(j["ms_per_step"], 1), "ms/step; unconverged", c["solves_unconverged"], "fallbacks", c["solver_fallbacks"],
               "| roofline", r["kernel"].split(" ")[0], r["bound"], round(r["achieved"], 1), r["unit"], "frac", round(r["frac"], 3), "| cpu", (j.get("cpu_baseline") or {}).get("value"))
-for kn in ("k_ds_gemm1", "k_ds_gemm0", "k_ds_gj_step", "k_ds_gj_flow", "k_ds_gemv"):
+for kn in ("k_ds_gemm1", "k_ds_extend_panels", "k_ds_gemm0", "k_ds_gj_step", "k_ds_gj_flow", "k_ds_gemv"):
     try:
         f = open(src + f"{TAG}_pmc_{kn}_FETCH_SIZE_summary.txt").read().strip()
         w = open(src + f"{TAG}_pmc_{kn}_WRITE_SIZE_summary.txt").read().strip()

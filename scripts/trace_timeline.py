@@ -1,11 +1,11 @@
 """Reads a rocprofv3 kernel-trace CSV and prints the kernel sequence of one Newton iteration late in the run with durations and
-gaps, plus busy / idle totals per kernel name over the window between two consecutive k_ds_assemble_blocks launches.
+gaps, plus busy / idle totals per kernel name over the window between the starts of two consecutive factorisations.
 usage: trace_timeline.py <kernel_trace.csv> [which]"""
 import csv, sys, collections
 rows = list(csv.DictReader(open(sys.argv[1])))
 which = int(sys.argv[2]) if len(sys.argv) > 2 else -20
 rows.sort(key=lambda r: int(r["Start_Timestamp"]))
-marks = [i for i, r in enumerate(rows) if r["Kernel_Name"].startswith("k_ds_assemble_blocks")]
+marks = [i for i, r in enumerate(rows) if r["Kernel_Name"].startswith("k_ds_assemble_level") and not rows[i - 1]["Kernel_Name"].startswith("k_ds_")]   # first launch of a factorisation
 a, b = marks[which], marks[which + 1]
 t0 = int(rows[a]["Start_Timestamp"])
 busy = collections.defaultdict(float); cnt = collections.Counter()
