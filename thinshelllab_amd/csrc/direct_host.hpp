@@ -76,9 +76,11 @@ static void ds_launch_level_start(tsl_ctx* c, hipStream_t s, const DsDev& D, int
   const int lv0 = P.level_ptr[l], nf = P.level_ptr[l + 1] - lv0;
   if (l > 0) ds_launch_extend(s, D, lv0, nf, P.level_maxld[l]);
   const int nb = P.blk_lptr[l + 1] - P.blk_lptr[l];
-  const long nt = (long)nb * 9 + (long)c->nc * 144 + (long)nf * DS_T;
-  hipLaunchKernelGGL(k_ds_assemble_level, dim3(ds_nblk(nt, 256)), dim3(256), 0, s, P.blk_lptr[l], nb, d.blk_q.p, d.csr2sell.p, c->vals.p, d.blk_dst.p, d.blk_ld.p, c->nc, l, c->c_H.p,
-                     d.con_dst.p, d.con_ld.p, d.con_lvl.p, lv0, nf, d.frl.p, d.arena.p);
+  const long nt = (long)nb * 9 + (long)nf * DS_T;
+  hipLaunchKernelGGL(k_ds_assemble_level, dim3(ds_nblk(nt, 256)), dim3(256), 0, s, P.blk_lptr[l], nb, d.blk_q.p, d.csr2sell.p, c->vals.p, d.blk_dst.p, d.blk_ld.p, lv0, nf, d.frl.p, d.arena.p);
+  const int ng = c->nc > 0 ? P.cgr_lptr[l + 1] - P.cgr_lptr[l] : 0;
+  if (ng > 0) hipLaunchKernelGGL(k_ds_assemble_contacts_level, dim3(ds_nblk((long)ng * 64, 256)), dim3(256), 0, s, P.cgr_lptr[l], ng, (const int*)d.cgr_ptr.p, (const int*)d.cgr_ent.p,
+                                 (const long long*)d.cgr_dst.p, (const int*)d.cgr_ld.p, (const double*)c->c_H.p, d.arena.p);
 }
 
 
@@ -153,6 +155,14 @@ static int ds_upload_grow(DevBuf<T>& buf, const std::vector<T>& h, hipStream_t s
   return 0;
 }
 
+// contact maps of the active plan (redone whenever the constraint ORDER changes: build_con)
+static int ds_upload_con(DirectSolver& d, hipStream_t s) {
+  const DirectPlan& P = d.plan;
+  TSL_TRY(ds_upload_grow(d.cgr_ptr, P.cgr_ptr, s)); TSL_TRY(ds_upload_grow(d.cgr_ent, P.cgr_ent, s)); TSL_TRY(ds_upload_grow(d.cgr_ld, P.cgr_ld, s));
+  TSL_TRY(ds_upload_grow(d.cgr_dst, P.cgr_dst, s));
+  return 0;
+}
+
 // once per context: CSR numbering of the static pattern, its SELL addresses, the nested-dissection partition
 static int direct_static(tsl_ctx* c) {
   DirectSolver& d = c->ds;
@@ -183,14 +193,14 @@ static uint64_t ds_cons_key(const std::vector<int>& cons) {   // FNV-1a over the
 // active plan <-> cache slot (host plan, constraint list, every device array that belongs to a plan)
 static void ds_swap_slot(DirectSolver& d, DsPlanSlot& sl) {
   std::swap(d.plan, sl.plan); d.h_cons.swap(sl.h_cons); d.h_cset.swap(sl.h_cset);
-  d.level_sn.swap(sl.level_sn); d.pmap.swap(sl.pmap); d.ch_rec.swap(sl.ch_rec); d.vtx.swap(sl.vtx); d.blk_ld.swap(sl.blk_ld); d.con_ld.swap(sl.con_ld);
-  d.wl_front.swap(sl.wl_front); d.wl_row.swap(sl.wl_row); d.blk_dst.swap(sl.blk_dst); d.con_dst.swap(sl.con_dst); d.fr.swap(sl.fr); d.frl.swap(sl.frl); d.blk_q.swap(sl.blk_q); d.con_lvl.swap(sl.con_lvl);
+  d.level_sn.swap(sl.level_sn); d.pmap.swap(sl.pmap); d.ch_rec.swap(sl.ch_rec); d.vtx.swap(sl.vtx); d.blk_ld.swap(sl.blk_ld); 
+  d.wl_front.swap(sl.wl_front); d.wl_row.swap(sl.wl_row); d.blk_dst.swap(sl.blk_dst); d.fr.swap(sl.fr); d.frl.swap(sl.frl); d.blk_q.swap(sl.blk_q); d.cgr_ptr.swap(sl.cgr_ptr); d.cgr_ent.swap(sl.cgr_ent); d.cgr_ld.swap(sl.cgr_ld); d.cgr_dst.swap(sl.cgr_dst);
 }
 
 // device + host bytes a parked plan holds (index maps, descriptors, host tree)
 static size_t ds_slot_bytes(const DsPlanSlot& sl) {
   const DirectPlan& P = sl.plan;
-  size_t b = 4 * (sl.level_sn.n + sl.pmap.n + sl.vtx.n + sl.blk_ld.n + sl.con_ld.n + sl.wl_front.n + sl.wl_row.n + sl.blk_q.n + sl.con_lvl.n) + 8 * (sl.blk_dst.n + sl.con_dst.n) +
+  size_t b = 4 * (sl.level_sn.n + sl.pmap.n + sl.vtx.n + sl.blk_ld.n + sl.cgr_ptr.n + sl.cgr_ent.n + sl.cgr_ld.n + sl.wl_front.n + sl.wl_row.n + sl.blk_q.n) + 8 * (sl.blk_dst.n + sl.cgr_dst.n) +
              sizeof(DsFrontDesc) * (sl.fr.n + sl.frl.n) + sizeof(DsChildRec) * sl.ch_rec.n;
   b += 4 * (P.pmap.size() + P.vtx.size() + P.blk_ld.size() + P.blk_q.size() + P.wl_front.size() + P.wl_row.size() + P.level_sn.size()) + 8 * P.blk_dst.size() + sizeof(DsFrontDesc) * P.fr.size();
   return b;
@@ -204,8 +214,8 @@ static void ds_cache_trim(DirectSolver& d) {
     for (auto& sl : d.cache) if (sl->used) { total += ds_slot_bytes(*sl); if (!lru || sl->stamp < lru->stamp) lru = sl.get(); }
     if (!lru || total <= (size_t)d.cache_mb << 20) return;
     lru->used = false;
-    lru->level_sn.release(); lru->pmap.release(); lru->vtx.release(); lru->blk_ld.release(); lru->con_ld.release(); lru->wl_front.release(); lru->wl_row.release();
-    lru->blk_q.release(); lru->con_lvl.release(); lru->blk_dst.release(); lru->con_dst.release(); lru->fr.release(); lru->frl.release(); lru->ch_rec.release();
+    lru->level_sn.release(); lru->pmap.release(); lru->vtx.release(); lru->blk_ld.release(); lru->cgr_ptr.release(); lru->cgr_ent.release(); lru->cgr_ld.release(); lru->cgr_dst.release(); lru->wl_front.release(); lru->wl_row.release();
+    lru->blk_q.release(); lru->blk_dst.release(); lru->fr.release(); lru->frl.release(); lru->ch_rec.release();
     d.n_plan_evicted++;
   }
 }
@@ -235,7 +245,7 @@ static int direct_plan(tsl_ctx* c) {
     if (cons != d.h_cons) {
       HIP_OK(hipStreamSynchronize(s));
       if (d.plan.build_con(cons.data(), c->nc)) return tsl_fail("direct solver: constraint vertex outside its front");
-      TSL_TRY(ds_upload_grow(d.con_dst, d.plan.con_dst, s)); TSL_TRY(ds_upload_grow(d.con_ld, d.plan.con_ld, s)); TSL_TRY(ds_upload_grow(d.con_lvl, d.plan.con_lvl, s));
+      TSL_TRY(ds_upload_con(d, s));
       HIP_OK(hipStreamSynchronize(s));
       d.h_cons = cons;
     }
@@ -281,7 +291,7 @@ static int direct_plan(tsl_ctx* c) {
   HIP_OK(hipStreamSynchronize(s));  // the previous plan's arrays may still be in use
   TSL_TRY(ds_upload_grow(d.fr, P.fr, s)); TSL_TRY(ds_upload_grow(d.level_sn, P.level_sn, s)); TSL_TRY(ds_upload_grow(d.pmap, P.pmap, s)); TSL_TRY(ds_upload_grow(d.ch_rec, P.ch_rec, s));
   TSL_TRY(ds_upload_grow(d.vtx, vtxp, s)); TSL_TRY(ds_upload_grow(d.blk_dst, P.blk_dst, s)); TSL_TRY(ds_upload_grow(d.blk_ld, P.blk_ld, s));
-  TSL_TRY(ds_upload_grow(d.con_dst, P.con_dst, s)); TSL_TRY(ds_upload_grow(d.con_ld, P.con_ld, s)); TSL_TRY(ds_upload_grow(d.con_lvl, P.con_lvl, s));
+  TSL_TRY(ds_upload_con(d, s));
   TSL_TRY(ds_upload_grow(d.blk_q, P.blk_q, s));
   std::vector<DsFrontDesc> frl(P.level_sn.size());
   for (size_t i = 0; i < frl.size(); i++) frl[i] = P.fr[P.level_sn[i]];

@@ -81,6 +81,11 @@ struct DirectPlan {
   std::vector<int> blk_q, blk_lptr;   // the same blocks level by level: blk_q[blk_lptr[l] .. blk_lptr[l + 1]) land in fronts of level l
   std::vector<long long> con_dst;  // per constraint x 16 (vertex pair a, b)
   std::vector<int> con_ld, con_lvl;   // row stride and tree level of the destination
+  // the same sub-blocks grouped by DESTINATION, level by level (groups cgr_lptr[l] .. cgr_lptr[l + 1] land on level l): group g adds the
+  // sub-blocks cgr_ent[cgr_ptr[g] .. cgr_ptr[g + 1]) (16 c + sub, ascending) to the 3 x 3 block at cgr_dst[g] -- one writer per entry, a
+  // fixed order (several constraints share vertex pairs)
+  std::vector<int> cgr_lptr, cgr_ptr, cgr_ent, cgr_ld;
+  std::vector<long long> cgr_dst;
   std::vector<int> level_maxld;
   long long arena_leaf = 0;        // extent of the leaf level's panels at the head of the panel arena (doubles)
   std::vector<std::vector<int>> lists;   // scratch of the level-by-level block list (per host thread and level)
@@ -344,6 +349,26 @@ struct DirectPlan {
           con_ld[(size_t)e * 16 + a * 4 + b] = ldq;
           con_lvl[(size_t)e * 16 + a * 4 + b] = sym.level[s];
         }
+    {
+      const size_t n = (size_t)n_cons * 16;
+      std::vector<int> ord(n);
+      for (size_t i = 0; i < n; i++) ord[i] = (int)i;
+      std::sort(ord.begin(), ord.end(), [&](int x, int y) {
+        if (con_lvl[x] != con_lvl[y]) return con_lvl[x] < con_lvl[y];
+        if (con_dst[x] != con_dst[y]) return con_dst[x] < con_dst[y];
+        return x < y;
+      });
+      cgr_lptr.assign(n_levels + 1, 0); cgr_ptr.clear(); cgr_ent.assign(ord.begin(), ord.end()); cgr_ld.clear(); cgr_dst.clear();
+      for (size_t i = 0; i < n; i++) {
+        const int x = ord[i];
+        if (i == 0 || con_dst[x] != con_dst[ord[i - 1]] || con_lvl[x] != con_lvl[ord[i - 1]]) {
+          cgr_ptr.push_back((int)i); cgr_dst.push_back(con_dst[x]); cgr_ld.push_back(con_ld[x]);
+          cgr_lptr[con_lvl[x] + 1]++;
+        }
+      }
+      cgr_ptr.push_back((int)n);
+      for (int l = 0; l < n_levels; l++) cgr_lptr[l + 1] += cgr_lptr[l];
+    }
     return 0;
   }
 };

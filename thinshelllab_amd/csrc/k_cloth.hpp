@@ -91,6 +91,10 @@ struct ClothArgs {
   const int *hg_info, *hg_v;
   const double* norm_dir;
   const int* f_order;   // processing order of the faces in the kernels that scatter with atomics: faces of one stencil class in a row (coalesced)
+  // deterministic assembly: element gradients go to a staging array of 3-vectors (face f, slot l: 3 f + l; hinge h, slot j: gs_hinge + 4 h + j)
+  // that k_vertex_gather sums per vertex in a fixed order; null: f64 atomics into the gradient
+  double* gstage;
+  int gs_hinge;
 };
 
 // hinge energy (Cloth.compute_bending_energy :108-120)
@@ -134,6 +138,11 @@ __global__ void k_cloth_grad_face(ClothArgs A, const double* __restrict__ pos, d
     const d3 ga = 0.5 * cross(nh, P[(l + 2) % 3] - P[(l + 1) % 3]);
     g[l] = g[l] + da * ga;
   }
+  if (A.gstage) {
+#pragma unroll
+    for (int l = 0; l < 3; l++) st3(A.gstage, 3 * f + l, g[l]);
+    return;
+  }
 #pragma unroll
   for (int l = 0; l < 3; l++) atomic_add3(F, v[l], g[l]);
 }
@@ -151,6 +160,11 @@ __global__ void k_cloth_grad_hinge(ClothArgs A, const double* __restrict__ pos, 
   hinge_grad(g1, g2, l, p4, p21, g);
   const double theta = dihedral(g1.n, g2.n, P1[(l + 1) % 2] - P1[l]);
   const double dth = 2.0 * c.Kb * (theta - ref_angle[3 * f1 + l]) * c.dx * c.dx * (1.0 / 3.0);
+  if (A.gstage) {
+#pragma unroll
+    for (int j = 0; j < 4; j++) st3(A.gstage, A.gs_hinge + 4 * h + j, dth * g[j]);
+    return;
+  }
   atomic_add3(F, v1[l], dth * g[0]);
   atomic_add3(F, v1[(l + 1) % 3], dth * g[1]);
   atomic_add3(F, v1[(l + 2) % 3], dth * g[2]);
@@ -424,14 +438,18 @@ __global__ void k_cloth_hess_hinge(ClothArgs A, const int* __restrict__ blk, con
 // which bound both kernels (0.27 ms of an assembly's 0.45).  Blocks are sorted by their address in the SELL-64 value array: the
 // lanes of a wave write consecutive lanes of one slice.  Fixed summation order: the assembled cloth blocks are the same bits every run.
 __global__ void __launch_bounds__(256) k_cloth_gather(int n_blk, const int* __restrict__ base, const int* __restrict__ ptr, const unsigned* __restrict__ ent, int n_hinge, int n_cface,
-                                                      const double* __restrict__ hrec, const double* __restrict__ frec, double* __restrict__ vals) {
+                                                      const double* __restrict__ hrec, const double* __restrict__ frec, const double* __restrict__ trec, double* __restrict__ vals) {
   const int b = blockIdx.x * blockDim.x + threadIdx.x;
   if (b >= n_blk) return;
   double acc[9] = {0, 0, 0, 0, 0, 0, 0, 0, 0};
   for (int q = ptr[b]; q < ptr[b + 1]; q++) {
     const unsigned e = ent[q];
     const int el = (int)((e >> 4) & 0x7ffffff), pr = (int)(e & 15);
-    if (e >> 31) {
+    if ((e >> 30) == 1) {   // tetrahedron: its 16 vertex-pair blocks as stored by k_tet_hess (144 doubles per element)
+      const double* R = trec + (size_t)(el & 0x3ffffff) * 144 + pr * 9;
+#pragma unroll
+      for (int q2 = 0; q2 < 9; q2++) acc[q2] += R[q2];
+    } else if (e >> 31) {
       const int j = pr >> 2, k = pr & 3;
       const double* R = hrec + (size_t)el * 16;
       const double d2 = R[12];

@@ -32,6 +32,19 @@ __global__ void k_vn_accum(int NF, const int* __restrict__ faces, const double* 
   const d3 n = cross(v2 - v1, v3 - v1);
   atomic_add3(vn, a, n); atomic_add3(vn, b, n); atomic_add3(vn, c, n);
 }
+// the same sum per vertex over its incident surface triangles (static vertex -> triangle lists, ascending triangle index): no atomics,
+// a fixed order (the projection query's side flag proj_dir is the sign of a dot product with these normals)
+__global__ void k_vn_gather(int NV, const int* __restrict__ ptr, const int* __restrict__ lst, const int* __restrict__ faces, const double* __restrict__ pos, double* __restrict__ vn) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= NV) return;
+  d3 a = d3();
+  for (int e = ptr[i]; e < ptr[i + 1]; e++) {
+    const int f = lst[e];
+    const d3 v1 = ld3(pos, faces[3 * f]), v2 = ld3(pos, faces[3 * f + 1]), v3 = ld3(pos, faces[3 * f + 2]);
+    a = a + cross(v2 - v1, v3 - v1);
+  }
+  st3(vn, i, a);
+}
 __global__ void k_vn_normalize(int NV, double* __restrict__ vn) {
   const int i = blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= NV) return;
@@ -274,11 +287,15 @@ __global__ void k_contact_pair(int b_idx, int v_start, int v_end, double mu, int
                                const double* __restrict__ pos, const double* __restrict__ prev, const int* __restrict__ proj_flag, const int* __restrict__ proj_dir,
                                const int* __restrict__ proj_idx, const double* __restrict__ proj_w, int* nc, int* __restrict__ c_idx, double* __restrict__ c_w,
                                double* __restrict__ c_k, double* __restrict__ c_mu, double* __restrict__ c_dx0, double* __restrict__ c_T, double* __restrict__ c_n, int kind,
-                               int* __restrict__ c_kind) {
+                               int* __restrict__ c_kind, int phase, int qoff, int* __restrict__ qflag, const int* __restrict__ qscan) {
+  // Two phases per detection so that the constraint LIST has a fixed order -- pair after pair in the scene's call order, query vertices
+  // ascending (the reference appends with an atomic counter: any order): phase 0 writes the activity flag of every query vertex,
+  // an exclusive scan over all pairs gives the slots, phase 1 writes the constraints there.
   const int i = v_start + blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= v_end) return;
+  const int qi = qoff + (i - v_start);
   const size_t bi = (size_t)b_idx * NV + i;
-  if (!proj_flag[bi]) return;
+  if (!proj_flag[bi]) { if (phase == 0) qflag[qi] = 0; return; }
   int i0 = proj_idx[3 * bi], i1 = proj_idx[3 * bi + 1], i2 = proj_idx[3 * bi + 2];
   double w0 = proj_w[3 * bi], w1 = proj_w[3 * bi + 1], w2 = proj_w[3 * bi + 2];
   const d3 x_c = ld3(pos, i0) * w0 + ld3(pos, i1) * w1 + ld3(pos, i2) * w2;
@@ -290,8 +307,9 @@ __global__ void k_contact_pair(int b_idx, int v_start, int v_end, double mu, int
     const double tw = w1; w1 = w2; w2 = tw;
   }
   const double gap = dot(ld3(pos, i) - x_c, n_c);
+  if (phase == 0) { qflag[qi] = gap < eps_contact ? 1 : 0; return; }
   if (gap < eps_contact) {
-    const int c = atomicAdd(nc, 1);
+    const int c = qscan[qi];
     if (c >= max_nc) return;
     const double cforce = k_contact * (gap - eps_contact);
     c_idx[4 * c] = i0; c_idx[4 * c + 1] = i1; c_idx[4 * c + 2] = i2; c_idx[4 * c + 3] = i;
@@ -310,7 +328,7 @@ __global__ void k_contact_pair(int b_idx, int v_start, int v_end, double mu, int
 
 // ------------------------------------------------------------------------------------------------ energy
 // BaseScene.contact_energy(diff=False) (:490-543 normal, :548-595 friction)
-__global__ void k_contact_energy(int nc, ContactArgs A, const double* __restrict__ pos, double* e_out) {
+__global__ void k_contact_energy(int nc, ContactArgs A, const double* __restrict__ pos, double* e_out, double* __restrict__ e_part) {
   const int i = blockIdx.x * blockDim.x + threadIdx.x;
   double e = 0;
   if (i < nc) {
@@ -328,7 +346,8 @@ __global__ void k_contact_energy(int nc, ContactArgs A, const double* __restrict
     e += A.k[i] * fr_f0(sqrt(u0 * u0 + u1 * u1), A.eps_vh);
   }
   e = wave_sum(e);
-  if ((threadIdx.x & 63) == 0 && e != 0.0) atomicAdd(e_out, e);
+  if (e_part) { if ((threadIdx.x & 63) == 0) e_part[blockIdx.x] = e; }   // (one wave per workgroup: a partial per workgroup, summed in order by k_energy_final)
+  else if ((threadIdx.x & 63) == 0 && e != 0.0) atomicAdd(e_out, e);
 }
 
 // ------------------------------------------------------------------------------------------------ gradient + blocks
@@ -337,7 +356,7 @@ __global__ void k_contact_energy(int nc, ContactArgs A, const double* __restrict
 // (contact_diff.py carries the same quantities as expanded SymPy output).  Friction part BaseScene.py:548-593.
 // Output: gradient (12) into grad (atomics), dense 12x12 into Hfull[c] (vertex order idx0..idx3).
 __global__ void __launch_bounds__(64)
-k_contact_assemble(int nc, ContactArgs A, const double* __restrict__ pos, int spd, double* __restrict__ grad, double* __restrict__ Hfull) {
+k_contact_assemble(int nc, ContactArgs A, const double* __restrict__ pos, int spd, double* __restrict__ grad, double* __restrict__ Hfull, double* __restrict__ cg) {
   const int ci = blockIdx.x * blockDim.x + threadIdx.x;
   if (ci >= nc) return;
   int id[4];
@@ -429,7 +448,8 @@ k_contact_assemble(int nc, ContactArgs A, const double* __restrict__ pos, int sp
           for (int j2 = 0; j2 < 3; j2++) Hc[(i1 * 3 + j1) * 12 + i2 * 3 + j2] += w1[i1] * w1[i2] * h1[j1 * 3 + j2];
       }
   }
-  if (grad)
+  if (cg) { for (int k = 0; k < 12; k++) cg[12 * (size_t)ci + k] = gv[k]; }   // deterministic assembly: k_vertex_gather sums the rows' entries in a fixed order
+  else if (grad)
     for (int k = 0; k < 4; k++) atomic_add3(grad, id[k], d3(gv[3 * k], gv[3 * k + 1], gv[3 * k + 2]));
   double* out = Hfull + 144 * (size_t)ci;
   for (int k = 0; k < 144; k++) out[k] = Hc[k];
@@ -515,7 +535,7 @@ TSL_DEV void spd_clamp9_lds(double* __restrict__ sa, double* __restrict__ sv, in
 }
 
 __global__ void __launch_bounds__(256)
-k_contact_assemble_coop(int nc, ContactArgs A, const double* __restrict__ pos, int spd, double* __restrict__ grad, double* __restrict__ Hfull) {
+k_contact_assemble_coop(int nc, ContactArgs A, const double* __restrict__ pos, int spd, double* __restrict__ grad, double* __restrict__ Hfull, double* __restrict__ cg) {
   const int l = threadIdx.x & 15;
   int ci = (int)((blockIdx.x * (size_t)blockDim.x + threadIdx.x) >> 4);
   const bool valid = ci < nc;
@@ -632,7 +652,8 @@ k_contact_assemble_coop(int nc, ContactArgs A, const double* __restrict__ pos, i
   }
   if (!valid || l >= 12) return;
   const int rowi = l < 9 ? 3 + l : l - 9;
-  if (grad) atomicAdd(&grad[3 * (size_t)id[rowi / 3] + rowi % 3], gout);
+  if (cg) cg[12 * (size_t)ci + rowi] = gout;
+  else if (grad) atomicAdd(&grad[3 * (size_t)id[rowi / 3] + rowi % 3], gout);
   double* dst = Hfull + 144 * (size_t)ci + 12 * rowi;
 #pragma unroll
   for (int k = 0; k < 12; k++) dst[k] = out[k];
@@ -650,7 +671,32 @@ __global__ void k_contact_mask(int nc, const int* __restrict__ idx, const int* _
   const int vr = idx[4 * ci + r / 3], vc = idx[4 * ci + c / 3];
   const double v = (frozen[3 * vr + r % 3] || frozen[3 * vc + c % 3]) ? 0.0 : Hfull[t];
   Hm[t] = v;
-  if (r / 3 == c / 3 && v != 0.0) atomicAdd(&cdiag[9 * (size_t)rowpos[vr] + 3 * (r % 3) + (c % 3)], v);
+  if (cdiag && r / 3 == c / 3 && v != 0.0) atomicAdd(&cdiag[9 * (size_t)rowpos[vr] + 3 * (r % 3) + (c % 3)], v);
+}
+// the same diagonal blocks without atomics: one thread per (permuted) row sums the diagonal 3 x 3 sub-blocks of the row's entries in
+// their stored order (ascending constraint, slot); every row is written (zero without entries): no clear needed
+__global__ void __launch_bounds__(256) k_contact_diag(int NV, const int* __restrict__ ptr, const int* __restrict__ ent, const double* __restrict__ Hm, double* __restrict__ cdiag) {
+  // one WAVE per row: lanes over the row's entries (l, l + 64, ...), joined by the fixed tree of wave_sum
+  const int p = (int)((blockIdx.x * (size_t)blockDim.x + threadIdx.x) >> 6), lane = threadIdx.x & 63;
+  if (p >= NV) return;
+  const int r0 = ptr[p], r1 = ptr[p + 1];
+  double a[9] = {0, 0, 0, 0, 0, 0, 0, 0, 0};
+  for (int e = r0 + lane; e < r1; e += 64) {
+    const int q = ent[e];
+    const double* H = Hm + 144 * (size_t)(q >> 2) + 39 * (q & 3);   // element (3 a, 3 a) of the 12 x 12 block
+#pragma unroll
+    for (int r = 0; r < 3; r++)
+#pragma unroll
+      for (int c = 0; c < 3; c++) a[3 * r + c] += H[12 * r + c];
+  }
+  if (r1 > r0) {
+#pragma unroll
+    for (int k = 0; k < 9; k++) a[k] = wave_sum(a[k]);
+  }
+  if (lane == 0) {
+#pragma unroll
+    for (int k = 0; k < 9; k++) cdiag[9 * (size_t)p + k] = a[k];
+  }
 }
 
 // y += sum_c P_c^T H_c P_c x  (permuted vectors).  16 lanes per constraint (12 active, one per block row), 64 constraints
@@ -682,16 +728,26 @@ __global__ void k_cr_count(int nc, const int* __restrict__ idx, const int* __res
   if (q >= 4 * nc) return;
   atomicAdd(&cnt[rowpos[idx[q]]], 1);
 }
-__global__ void k_cr_fill(int nc, const int* __restrict__ idx, const int* __restrict__ rowpos, const int* __restrict__ ptr, int* __restrict__ fill, int* __restrict__ ent,
+// entries of every row in arrival order (atomic cursor) ...
+__global__ void k_cr_fill(int nc, const int* __restrict__ idx, const int* __restrict__ rowpos, const int* __restrict__ ptr, int* __restrict__ fill, int* __restrict__ tmp) {
+  const int q = blockIdx.x * blockDim.x + threadIdx.x;
+  if (q >= 4 * nc) return;
+  const int p = rowpos[idx[q]];
+  tmp[ptr[p] + atomicAdd(&fill[p], 1)] = q;
+}
+// ... then in ascending (constraint, slot) order: the sums over a row's entries (products, diagonal blocks, gradients) have a fixed order
+__global__ void k_cr_rank(int nc, const int* __restrict__ idx, const int* __restrict__ rowpos, const int* __restrict__ ptr, const int* __restrict__ tmp, int* __restrict__ ent,
                           int4* __restrict__ rows) {
   const int q = blockIdx.x * blockDim.x + threadIdx.x;
   if (q >= 4 * nc) return;
   const int c4 = q & ~3;
   const int4 r = make_int4(rowpos[idx[c4]], rowpos[idx[c4 + 1]], rowpos[idx[c4 + 2]], rowpos[idx[c4 + 3]]);
   const int p = (q & 3) == 0 ? r.x : (q & 3) == 1 ? r.y : (q & 3) == 2 ? r.z : r.w;
-  const int e = ptr[p] + atomicAdd(&fill[p], 1);
-  ent[e] = q;  // (constraint << 2) | slot
-  rows[e] = r;
+  const int s0 = ptr[p], s1 = ptr[p + 1];
+  int rank = 0;
+  for (int e = s0; e < s1; e++) rank += tmp[e] < q ? 1 : 0;
+  ent[s0 + rank] = q;  // (constraint << 2) | slot
+  rows[s0 + rank] = r;
 }
 
 // dot(x, H_c x) added to pAp[slot] (slot < 0: product only)
@@ -729,7 +785,7 @@ __global__ void k_contact_zfrozen(int nc, const int* __restrict__ idx, const int
 }
 
 // BaseScene.contact_energy_backprop (:682-730): friction-lag adjoint into pos_grad[step-1] (pg points at that slice)
-__global__ void k_contact_backprop(int nc, ContactArgs A, const double* __restrict__ pos, const double* __restrict__ z, double* __restrict__ pg) {
+__global__ void k_contact_backprop(int nc, ContactArgs A, const double* __restrict__ pos, const double* __restrict__ z, double* __restrict__ pg, double* __restrict__ cg) {
   const int ci = blockIdx.x * blockDim.x + threadIdx.x;
   if (ci >= nc) return;
   int id[4];
@@ -772,6 +828,7 @@ __global__ void k_contact_backprop(int nc, ContactArgs A, const double* __restri
         for (int j1 = 0; j1 < 3; j1++)
           for (int j2 = 0; j2 < 3; j2++) acc[3 * i2 + j2] += zv[3 * i1 + j1] * w1[i1] * w1[i2] * h1[j1 * 3 + j2];
   }
+  if (cg) { for (int k = 0; k < 12; k++) cg[12 * (size_t)ci + k] = acc[k]; return; }   // deterministic: summed per vertex by k_vertex_gather
   for (int k = 0; k < 4; k++) atomic_add3(pg, id[k], d3(acc[3 * k], acc[3 * k + 1], acc[3 * k + 2]));
 }
 
@@ -836,6 +893,14 @@ static int contact_alloc(tsl_ctx* c, const tsl_scene_desc* d) {
   if (d->tot_NF > 0 && d->faces_host) faces.assign(d->faces_host, d->faces_host + 3 * (size_t)d->tot_NF);
   rc |= c->faces.upload(faces);
   rc |= c->vn.alloc(3 * (size_t)NV);
+  {   // vertex -> incident surface triangles (k_vn_gather)
+    std::vector<int> ptr(NV + 1, 0), lst(faces.size());
+    for (int v : faces) ptr[v + 1]++;
+    for (int v = 0; v < NV; v++) ptr[v + 1] += ptr[v];
+    std::vector<int> cur(ptr.begin(), ptr.end() - 1);
+    for (size_t f = 0; f < faces.size() / 3; f++) for (int k = 0; k < 3; k++) lst[cur[faces[3 * f + k]]++] = (int)f;
+    if (!faces.empty()) { rc |= c->vnf_ptr.upload(ptr); rc |= c->vnf_lst.upload(lst); }
+  }
   const size_t nb = (size_t)std::max(c->n_body, 1);
   rc |= c->proj_flag.alloc(nb * NV); rc |= c->proj_dir.alloc(nb * NV); rc |= c->proj_idx.alloc(nb * NV * 3); rc |= c->proj_w.alloc(nb * NV * 3);
   rc |= c->nc_dev.alloc(1);
@@ -873,8 +938,11 @@ extern "C" int tsl_contact_detect(tsl_ctx* c, const double* pos, const double* p
   for (int v : c->self_contact) any_self |= v != 0;
   if ((c->n_body < 2 && !any_self) || c->NF == 0) { if (nc_host) *nc_host = 0; return 0; }   // a single body can still touch itself (geometry_self.py)
   // calc_vn
-  HIP_OK(hipMemsetAsync(c->vn.p, 0, 3 * (size_t)NV * sizeof(double), s));
-  hipLaunchKernelGGL(k_vn_accum, dim3(cnblk(c->NF, 256)), dim3(256), 0, s, c->NF, c->faces.p, pos, c->vn.p);
+  if (c->deterministic && c->vnf_ptr.n > 0) hipLaunchKernelGGL(k_vn_gather, dim3(cnblk(NV, 256)), dim3(256), 0, s, NV, (const int*)c->vnf_ptr.p, (const int*)c->vnf_lst.p, c->faces.p, pos, c->vn.p);
+  else {
+    HIP_OK(hipMemsetAsync(c->vn.p, 0, 3 * (size_t)NV * sizeof(double), s));
+    hipLaunchKernelGGL(k_vn_accum, dim3(cnblk(c->NF, 256)), dim3(256), 0, s, c->NF, c->faces.p, pos, c->vn.p);
+  }
   hipLaunchKernelGGL(k_vn_normalize, dim3(cnblk(NV, 256)), dim3(256), 0, s, NV, c->vn.p);
   // projection_query
   GridArgs G;
@@ -918,24 +986,33 @@ extern "C" int tsl_contact_detect(tsl_ctx* c, const double* pos, const double* p
     }
 #undef TSL_PROJ_LAUNCH
   }
-  // contact_analysis
-  HIP_OK(hipMemsetAsync(c->nc_dev.p, 0, sizeof(int), s));
-  for (const auto& pr : c->h_pairs) {
-    const int nq = pr.v_end - pr.v_start;
-    if (nq <= 0) continue;
-    // parameter-driven pairs may carry a factor in mu (Scene_card.py:122-126: mu_cloth_elastic * 10 for the upper cards)
-    const double live = pr.mu_is_param == 2 ? c->mu_cloth_cloth : c->mu_cloth_elastic;  // Scene_sliding.py:80 has a second live parameter
-    const double mu = pr.mu_is_param ? live * (pr.mu > 0 ? pr.mu : 1.0) : pr.mu;
-    hipLaunchKernelGGL(k_contact_pair, dim3(cnblk(nq, 128)), dim3(128), 0, s, pr.b_idx, pr.v_start, pr.v_end, mu, NV, c->max_n_constraints, c->k_contact, c->eps_contact, pos,
-                       prev, c->proj_flag.p, c->proj_dir.p, c->proj_idx.p, c->proj_w.p, c->nc_dev.p, c->c_idx.p, c->c_w.p, c->c_k.p, c->c_mu.p, c->c_dx0.p, c->c_T.p, c->c_n.p, pr.mu_is_param,
-                       c->c_kind.p);
+  // contact_analysis: flags of every pair's query vertices, one exclusive scan, then the constraints at their slots (fixed list order)
+  long Q = 0;
+  for (const auto& pr : c->h_pairs) Q += std::max(0, pr.v_end - pr.v_start);
+  if (c->cq_flag.n < (size_t)Q + 1) { if (c->cq_flag.alloc((size_t)Q + 1) | c->cq_scan.alloc((size_t)Q + 1)) return -1; }
+  if (c->scan_tmp.n < (size_t)(Q + 1) / SCAN_TILE + 2) { if (c->scan_tmp.alloc((size_t)std::max<long>(std::max<long>(c->grid_buckets_max, NV + 1), Q + 1) / SCAN_TILE + 2)) return -1; }
+  HIP_OK(hipMemsetAsync(c->cq_flag.p + Q, 0, sizeof(int), s));
+  for (int phase = 0; phase < 2; phase++) {
+    long qoff = 0;
+    for (const auto& pr : c->h_pairs) {
+      const int nq = pr.v_end - pr.v_start;
+      if (nq <= 0) continue;
+      // parameter-driven pairs may carry a factor in mu (Scene_card.py:122-126: mu_cloth_elastic * 10 for the upper cards)
+      const double live = pr.mu_is_param == 2 ? c->mu_cloth_cloth : c->mu_cloth_elastic;  // Scene_sliding.py:80 has a second live parameter
+      const double mu = pr.mu_is_param ? live * (pr.mu > 0 ? pr.mu : 1.0) : pr.mu;
+      hipLaunchKernelGGL(k_contact_pair, dim3(cnblk(nq, 128)), dim3(128), 0, s, pr.b_idx, pr.v_start, pr.v_end, mu, NV, c->max_n_constraints, c->k_contact, c->eps_contact, pos,
+                         prev, c->proj_flag.p, c->proj_dir.p, c->proj_idx.p, c->proj_w.p, c->nc_dev.p, c->c_idx.p, c->c_w.p, c->c_k.p, c->c_mu.p, c->c_dx0.p, c->c_T.p, c->c_n.p, pr.mu_is_param,
+                         c->c_kind.p, phase, (int)qoff, c->cq_flag.p, (const int*)c->cq_scan.p);
+      qoff += nq;
+    }
+    if (phase == 0 && Q > 0) scan_exclusive(s, (int)Q + 1, c->cq_flag.p, c->cq_scan.p, c->scan_tmp.p);
   }
   int nc = 0;
-  HIP_OK(hipMemcpyAsync(&nc, c->nc_dev.p, sizeof(int), hipMemcpyDeviceToHost, s));
+  if (Q > 0) HIP_OK(hipMemcpyAsync(&nc, c->cq_scan.p + Q, sizeof(int), hipMemcpyDeviceToHost, s));
   HIP_OK(hipStreamSynchronize(s));
   HIP_OK(hipGetLastError());
   if (nc > c->max_n_constraints) {
-    // the surplus constraints were dropped in atomic-append order: which ones survive is not deterministic, so this is an error
+    // more constraints than the scene's cap (the reference would drop the surplus in atomic-append order): an error
     c->nc = 0;
     return tsl_fail("contact detection: %d active constraints exceed max_n_constraints = %d (raise the scene's max_n_constraints)", nc, c->max_n_constraints);
   }
@@ -944,13 +1021,14 @@ extern "C" int tsl_contact_detect(tsl_ctx* c, const double* pos, const double* p
   if (c->nc > 0) {
     const int n1 = NV + 1;
     if (c->cr_ptr.n == 0) {
-      if (c->cr_ptr.alloc(n1) | c->cr_cnt.alloc(n1) | c->cr_fill.alloc(n1) | c->cr_ent.alloc(4 * (size_t)c->max_n_constraints) | c->cr_rows.alloc(4 * (size_t)c->max_n_constraints)) return -1;
+      if (c->cr_ptr.alloc(n1) | c->cr_cnt.alloc(n1) | c->cr_fill.alloc(n1) | c->cr_ent.alloc(4 * (size_t)c->max_n_constraints) | c->cr_rows.alloc(4 * (size_t)c->max_n_constraints) | c->cr_tmp.alloc(4 * (size_t)c->max_n_constraints)) return -1;
     }
     HIP_OK(hipMemsetAsync(c->cr_cnt.p, 0, n1 * sizeof(int), s));
     HIP_OK(hipMemsetAsync(c->cr_fill.p, 0, n1 * sizeof(int), s));
     hipLaunchKernelGGL(k_cr_count, dim3(cnblk(4 * (long)c->nc, 256)), dim3(256), 0, s, c->nc, c->c_idx.p, c->rowpos.p, c->cr_cnt.p);
     scan_exclusive(s, n1, c->cr_cnt.p, c->cr_ptr.p, c->scan_tmp.p);
-    hipLaunchKernelGGL(k_cr_fill, dim3(cnblk(4 * (long)c->nc, 256)), dim3(256), 0, s, c->nc, c->c_idx.p, c->rowpos.p, c->cr_ptr.p, c->cr_fill.p, c->cr_ent.p, c->cr_rows.p);
+    hipLaunchKernelGGL(k_cr_fill, dim3(cnblk(4 * (long)c->nc, 256)), dim3(256), 0, s, c->nc, c->c_idx.p, c->rowpos.p, (const int*)c->cr_ptr.p, c->cr_fill.p, c->cr_tmp.p);
+    hipLaunchKernelGGL(k_cr_rank, dim3(cnblk(4 * (long)c->nc, 256)), dim3(256), 0, s, c->nc, c->c_idx.p, c->rowpos.p, (const int*)c->cr_ptr.p, (const int*)c->cr_tmp.p, c->cr_ent.p, c->cr_rows.p);
     HIP_OK(hipGetLastError());
   }
   return 0;
@@ -961,10 +1039,18 @@ static int contact_assemble(tsl_ctx* c, const double* pos, int spd, double* grad
   ContactArgs A;
   A.idx = c->c_idx.p; A.w = c->c_w.p; A.n = c->c_n.p; A.dx0 = c->c_dx0.p; A.k = c->c_k.p; A.mu = c->c_mu.p; A.T = c->c_T.p;
   A.k_contact = c->k_contact; A.eps_contact = c->eps_contact; A.eps_vh = c->eps_v * c->dt;
-  if (c->contact_coop) hipLaunchKernelGGL(k_contact_assemble_coop, dim3(cnblk((long)c->nc * 16, 256)), dim3(256), 0, s, c->nc, A, pos, spd, grad, c->c_Hfull.p);
-  else hipLaunchKernelGGL(k_contact_assemble, dim3(cnblk(c->nc, 64)), dim3(64), 0, s, c->nc, A, pos, spd, grad, c->c_Hfull.p);
-  HIP_OK(hipMemsetAsync(c->c_diag.p, 0, c->c_diag.n * sizeof(double), s));
-  hipLaunchKernelGGL(k_contact_mask, dim3(cnblk((long)c->nc * 144, 256)), dim3(256), 0, s, c->nc, c->c_idx.p, c->frozen.p, c->rowpos.p, c->c_Hfull.p, c->c_H.p, c->c_diag.p);
+  const bool want_cg = c->deterministic && grad;   // deterministic: per-constraint gradients, summed per vertex by k_vertex_gather
+  if (want_cg && c->c_G.n < 12 * (size_t)c->max_n_constraints) { if (c->c_G.alloc(12 * (size_t)c->max_n_constraints)) return -1; }
+  double* cg = want_cg ? c->c_G.p : (double*)nullptr;
+  if (c->contact_coop) hipLaunchKernelGGL(k_contact_assemble_coop, dim3(cnblk((long)c->nc * 16, 256)), dim3(256), 0, s, c->nc, A, pos, spd, grad, c->c_Hfull.p, cg);
+  else hipLaunchKernelGGL(k_contact_assemble, dim3(cnblk(c->nc, 64)), dim3(64), 0, s, c->nc, A, pos, spd, grad, c->c_Hfull.p, cg);
+  if (c->deterministic) {
+    hipLaunchKernelGGL(k_contact_mask, dim3(cnblk((long)c->nc * 144, 256)), dim3(256), 0, s, c->nc, c->c_idx.p, c->frozen.p, c->rowpos.p, c->c_Hfull.p, c->c_H.p, (double*)nullptr);
+    hipLaunchKernelGGL(k_contact_diag, dim3(cnblk((long)c->NV * 64, 256)), dim3(256), 0, s, c->NV, (const int*)c->cr_ptr.p, (const int*)c->cr_ent.p, (const double*)c->c_H.p, c->c_diag.p);
+  } else {
+    HIP_OK(hipMemsetAsync(c->c_diag.p, 0, c->c_diag.n * sizeof(double), s));
+    hipLaunchKernelGGL(k_contact_mask, dim3(cnblk((long)c->nc * 144, 256)), dim3(256), 0, s, c->nc, c->c_idx.p, c->frozen.p, c->rowpos.p, c->c_Hfull.p, c->c_H.p, c->c_diag.p);
+  }
   return 0;
 }
 

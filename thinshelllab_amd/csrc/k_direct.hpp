@@ -62,35 +62,52 @@ __global__ void k_ds_rownorm(int NV, const int* __restrict__ slice_off, const in
 // --, so nothing above the leaves is ever cleared.  One launch per level, three thread ranges:
 //   * static pattern: block q = blk_q[i] of the CSR numbering lives at vals[csr2sell[q] + 64 e] (SELL-64, element e of the 3 x 3 block);
 //     every block has ONE destination: a plain add;
-//   * contact blocks: 16 vertex-pair sub-blocks per constraint, those whose destination front is on this level (several constraints
-//     may share a vertex pair: atomics);
-//   * identity on the padding of the pivot blocks.
+//   * identity on the padding of the pivot blocks;
+//   * contact blocks (their own launch behind it, only on levels that have any): 16 vertex-pair sub-blocks per constraint, grouped by
+//     destination on the host.
 __global__ void k_ds_assemble_level(int i0, int nblk, const int* __restrict__ blk_q, const int* __restrict__ csr2sell, const double* __restrict__ vals,
-                                    const long long* __restrict__ blk_dst, const int* __restrict__ blk_ld, int nc, int level, const double* __restrict__ H,
-                                    const long long* __restrict__ con_dst, const int* __restrict__ con_ld, const int* __restrict__ con_lvl, int lv0, int nf,
-                                    const DsFrontDesc* __restrict__ frl, double* __restrict__ A) {
+                                    const long long* __restrict__ blk_dst, const int* __restrict__ blk_ld, int lv0, int nf, const DsFrontDesc* __restrict__ frl, double* __restrict__ A) {
   long t = (long)blockIdx.x * blockDim.x + threadIdx.x;
   if (t < (long)nblk * 9) {
     const int q = blk_q[i0 + t / 9];
     const int e = (int)(t % 9);
-    atomicAdd(&A[blk_dst[q] + (long long)(e / 3) * blk_ld[q] + e % 3], vals[(size_t)csr2sell[q] + 64 * e]);   // (atomic: a contact sub-block of this launch may target the same entry)
+    A[blk_dst[q] + (long long)(e / 3) * blk_ld[q] + e % 3] += vals[(size_t)csr2sell[q] + 64 * e];   // one writer per entry
     return;
   }
   t -= (long)nblk * 9;
-  if (t < (long)nc * 144) {
-    const int c = (int)(t / 144), e = (int)(t % 144), r = e / 12, cc = e % 12;
-    const int sub = (r / 3) * 4 + cc / 3;
-    if (con_lvl[(size_t)c * 16 + sub] != level) return;
-    const double v = H[t];
-    if (v == 0.0) return;
-    atomicAdd(&A[con_dst[(size_t)c * 16 + sub] + (long long)(r % 3) * con_ld[(size_t)c * 16 + sub] + cc % 3], v);
-    return;
-  }
-  t -= (long)nc * 144;
   if (t < (long)nf * DS_T) {
     const DsFrontDesc f = frl[lv0 + t / DS_T];
     const int i = f.p + (int)(t % DS_T);
     if (i < f.pp) A[f.off + (long long)i * f.ld + i] = 1.0;
+  }
+}
+// contact sub-blocks of one level, behind k_ds_assemble_level on the same stream: one thread per entry of a destination GROUP sums the
+// group's sub-blocks (ascending constraint, slot) and adds the sum -- one writer per entry, a fixed order, no atomics
+__global__ void __launch_bounds__(256) k_ds_assemble_contacts_level(int g0, int ng, const int* __restrict__ gptr, const int* __restrict__ gent, const long long* __restrict__ gdst,
+                                                                    const int* __restrict__ gld, const double* __restrict__ H, double* __restrict__ A) {
+  // one WAVE per destination group: lanes over the group's members (l, l + 64, ...: a pair of table vertices under a folded cloth is shared
+  // by hundreds of constraints), the nine entries joined by the fixed tree of wave_sum, lane 0 adds them
+  const int gi = (int)((blockIdx.x * (size_t)blockDim.x + threadIdx.x) >> 6), lane = threadIdx.x & 63;
+  if (gi >= ng) return;
+  const int g = g0 + gi;
+  double v[9] = {0, 0, 0, 0, 0, 0, 0, 0, 0};
+  for (int k = gptr[g] + lane; k < gptr[g + 1]; k += 64) {
+    const int x = gent[k], c = x >> 4, sub = x & 15;
+    const double* Hb = H + (size_t)c * 144 + (3 * (sub >> 2)) * 12 + 3 * (sub & 3);
+#pragma unroll
+    for (int r = 0; r < 3; r++)
+#pragma unroll
+      for (int cc = 0; cc < 3; cc++) v[3 * r + cc] += Hb[12 * r + cc];
+  }
+#pragma unroll
+  for (int e = 0; e < 9; e++) v[e] = wave_sum(v[e]);
+  if (lane == 0) {
+    double* dst = A + gdst[g];
+    const int ld = gld[g];
+#pragma unroll
+    for (int r = 0; r < 3; r++)
+#pragma unroll
+      for (int cc = 0; cc < 3; cc++) dst[(long long)r * ld + cc] += v[3 * r + cc];
   }
 }
 

@@ -26,7 +26,7 @@ __global__ void k_vert_grad(VertArgs A, const double* __restrict__ pos, const do
   const double m = A.mass[i];
   const d3 X = ld3(pos, i) - ld3(prev, i) - ld3(vel, i) * A.dt;
   const d3 g = -m * ld3(A.grav, i) - ld3(A.fext, i) + X * (m / (A.dt * A.dt));
-  atomic_add3(F, i, g);
+  st3(F, i, g);   // (the first contribution: the gradient array holds nothing else yet)
 }
 
 // mass diagonal m/dt^2 on every dof, frozen or not (H.H.add without frozen test, model_fold_offset.py:468-470,
@@ -46,6 +46,7 @@ struct TetArgs {
   const ElasticDev* el;
   const int *tv, *tel;
   const double *B, *W;
+  double* gstage;   // deterministic assembly: element gradients of tet t at gstage[3 (4 t + j)] (null: atomics)
 };
 
 TSL_DEV m3 tet_F(const TetArgs& A, int t, const double* __restrict__ pos, int v[4], m3& B) {
@@ -110,10 +111,10 @@ __global__ void k_tet_grad(TetArgs A, const double* __restrict__ pos, double* __
 #pragma unroll
   for (int i = 0; i < 3; i++) {
     const d3 gi = d3(W * Hm.m[i], W * Hm.m[3 + i], W * Hm.m[6 + i]);  // +W*col = -(force) = dE/dx_i
-    atomic_add3(Fg, v[i], gi);
+    if (A.gstage) st3(A.gstage, 4 * t + i, gi); else atomic_add3(Fg, v[i], gi);
     f3 = f3 - gi;
   }
-  atomic_add3(Fg, v[3], f3);
+  if (A.gstage) st3(A.gstage, 4 * t + 3, f3); else atomic_add3(Fg, v[3], f3);
 }
 
 // F_f = -(elastic gradient) + m g + f_ext on the vertices of the FEM bodies (Elastic.get_force, model_elastic_tactile.py:144-164 /
@@ -186,7 +187,7 @@ TSL_DEV m3 tet_dH(const ElasticDev& e, const m3& F, const m3& Fi, const m3& FiT,
 // Element Hessians: kind 0 = 9x9 over vertices 0..2 with optional SPD projection, vertex 3 = minus row/col sums
 // (model_elastic_tactile.py:88-124); kind 1 = direct 12x12 (model_elastic_offset.py:101-167, no projection).
 __global__ void __launch_bounds__(64)
-k_tet_hess(TetArgs A, const int* __restrict__ blk, const double* __restrict__ pos, int spd, double* __restrict__ vals, double* __restrict__ Vws, int warm) {
+k_tet_hess(TetArgs A, const int* __restrict__ blk, const double* __restrict__ pos, int spd, double* __restrict__ vals, double* __restrict__ Vws, int warm, double* __restrict__ rec) {
   const int t = blockIdx.x * blockDim.x + threadIdx.x;
   if (t >= A.n_tet) return;
   int v[4]; m3 B;
@@ -233,7 +234,8 @@ k_tet_hess(TetArgs A, const int* __restrict__ blk, const double* __restrict__ po
           else if (a < 3) { for (int bb = 0; bb < 3; bb++) s -= He[(a * 3 + j) * 9 + bb * 3 + j2]; }
           else if (b < 3) { for (int aa = 0; aa < 3; aa++) s -= He[(aa * 3 + j) * 9 + b * 3 + j2]; }
           else { for (int aa = 0; aa < 3; aa++) for (int bb = 0; bb < 3; bb++) s += He[(aa * 3 + j) * 9 + bb * 3 + j2]; }
-          atomicAdd(&vals[(size_t)base + 64 * (3 * j + j2)], s);
+          if (rec) rec[(size_t)t * 144 + (a * 4 + b) * 9 + 3 * j + j2] = s;   // gather assembly: k_cloth_gather adds the block
+          else atomicAdd(&vals[(size_t)base + 64 * (3 * j + j2)], s);
         }
     }
 }

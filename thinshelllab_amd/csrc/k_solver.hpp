@@ -79,35 +79,47 @@ struct ContactRows {
   const int* ent;      // (constraint << 2) | slot, grouped by row
   const int4* rows;    // permuted rows of the entry's four constraint vertices
   const double* H;     // masked 12x12 blocks
+  int nv;              // rows
 };
 // adds sum_b H_c[a][b] x[row_c[b]] of entries [e0, e1) (the rows [row0, row0 + 64) of the slice) into acc[k][row - row0] (k = 0..2),
 // optionally the same product with a second vector into acc[3 + k]; called by all threads of the workgroup, acc zeroed and
 // synchronised by the caller.  e0 / e1 are fetched at kernel entry so that slices without contacts pay one barrier only.
 template <int NVEC>
 TSL_DEV void contact_slice_add(const ContactRows& C, int e0, int e1, int row0, const double* __restrict__ x, const double* __restrict__ x2, double (*acc)[64]) {
-  for (int e = e0 + (int)threadIdx.x; e < e1; e += (int)blockDim.x) {
-    const int q = C.ent[e];
-    const int4 r4 = C.rows[e];
-    const int c = q >> 2, a = q & 3;
-    const double* H = C.H + 144 * (size_t)c + 36 * a;
-    const int pb[4] = {r4.x, r4.y, r4.z, r4.w};
-    const int l = pb[a] - row0;
+  // One WAVE per row of the slice (the workgroup's waves take the 64 rows in turn): lane l takes the row's entries l, l + 64, ... in their
+  // stored order (ascending constraint, slot), the lanes' partial sums are joined by the fixed shuffle tree of wave_sum -- a fixed
+  // summation order, no atomics, and a row with hundreds of entries (a table vertex under a folded cloth) is not walked by one thread.
+  // (Round 3 summed a row's contributions with LDS atomics in arrival order.)
+  (void)e0; (void)e1;
+  const int lane = threadIdx.x & 63, nw = blockDim.x >> 6;
+  for (int l = threadIdx.x >> 6; l < 64; l += nw) {
+    const bool in = row0 + l < C.nv;   // (the last slice is partial)
+    const int r0 = in ? C.ptr[row0 + l] : 0, r1 = in ? C.ptr[row0 + l + 1] : 0;
+    if (r1 <= r0) { if (lane == 0) { acc[0][l] = 0.0; acc[1][l] = 0.0; acc[2][l] = 0.0; if (NVEC == 2) { acc[3][l] = 0.0; acc[4][l] = 0.0; acc[5][l] = 0.0; } } continue; }
     double y0 = 0, y1 = 0, y2 = 0, q0 = 0, q1 = 0, q2 = 0;
+    for (int e = r0 + lane; e < r1; e += 64) {
+      const int q = C.ent[e];
+      const int4 r4 = C.rows[e];
+      const int c = q >> 2, a = q & 3;
+      const double* H = C.H + 144 * (size_t)c + 36 * a;
+      const int pb[4] = {r4.x, r4.y, r4.z, r4.w};
 #pragma unroll
-    for (int b = 0; b < 4; b++) {
-      const d3 xb = ld3(x, pb[b]);
-      y0 += H[3 * b] * xb.x + H[3 * b + 1] * xb.y + H[3 * b + 2] * xb.z;
-      y1 += H[12 + 3 * b] * xb.x + H[12 + 3 * b + 1] * xb.y + H[12 + 3 * b + 2] * xb.z;
-      y2 += H[24 + 3 * b] * xb.x + H[24 + 3 * b + 1] * xb.y + H[24 + 3 * b + 2] * xb.z;
-      if (NVEC == 2) {
-        const d3 wb = ld3(x2, pb[b]);
-        q0 += H[3 * b] * wb.x + H[3 * b + 1] * wb.y + H[3 * b + 2] * wb.z;
-        q1 += H[12 + 3 * b] * wb.x + H[12 + 3 * b + 1] * wb.y + H[12 + 3 * b + 2] * wb.z;
-        q2 += H[24 + 3 * b] * wb.x + H[24 + 3 * b + 1] * wb.y + H[24 + 3 * b + 2] * wb.z;
+      for (int b = 0; b < 4; b++) {
+        const d3 xb = ld3(x, pb[b]);
+        y0 += H[3 * b] * xb.x + H[3 * b + 1] * xb.y + H[3 * b + 2] * xb.z;
+        y1 += H[12 + 3 * b] * xb.x + H[12 + 3 * b + 1] * xb.y + H[12 + 3 * b + 2] * xb.z;
+        y2 += H[24 + 3 * b] * xb.x + H[24 + 3 * b + 1] * xb.y + H[24 + 3 * b + 2] * xb.z;
+        if (NVEC == 2) {
+          const d3 wb = ld3(x2, pb[b]);
+          q0 += H[3 * b] * wb.x + H[3 * b + 1] * wb.y + H[3 * b + 2] * wb.z;
+          q1 += H[12 + 3 * b] * wb.x + H[12 + 3 * b + 1] * wb.y + H[12 + 3 * b + 2] * wb.z;
+          q2 += H[24 + 3 * b] * wb.x + H[24 + 3 * b + 1] * wb.y + H[24 + 3 * b + 2] * wb.z;
+        }
       }
     }
-    atomicAdd(&acc[0][l], y0); atomicAdd(&acc[1][l], y1); atomicAdd(&acc[2][l], y2);
-    if (NVEC == 2) { atomicAdd(&acc[3][l], q0); atomicAdd(&acc[4][l], q1); atomicAdd(&acc[5][l], q2); }
+    y0 = wave_sum(y0); y1 = wave_sum(y1); y2 = wave_sum(y2);
+    if (NVEC == 2) { q0 = wave_sum(q0); q1 = wave_sum(q1); q2 = wave_sum(q2); }
+    if (lane == 0) { acc[0][l] = y0; acc[1][l] = y1; acc[2][l] = y2; if (NVEC == 2) { acc[3][l] = q0; acc[4][l] = q1; acc[5][l] = q2; } }
   }
 }
 
@@ -609,12 +621,35 @@ __global__ void k_cg_p(int NV, const double* __restrict__ z, double* __restrict_
 }
 
 // generic helpers ------------------------------------------------------------------------------
-// sum of a*b over n doubles into *out
-__global__ void k_dot(size_t n, const double* __restrict__ a, const double* __restrict__ b, double* out) {
+// sum of a*b over n doubles ADDED to *out.  part / ticket (deterministic mode): every workgroup leaves its partial (waves in order), the
+// last one to arrive adds the partials in workgroup order and makes the one addition to *out -- a fixed summation order; null: one f64
+// atomic per wave
+TSL_DEV void dot_finish(double s, double* out, double* __restrict__ part, int* __restrict__ ticket) {
+  __shared__ double sw[4];
+  __shared__ int s_last;
+  s = wave_sum(s);
+  if (!part) { if ((threadIdx.x & 63) == 0) atomicAdd(out, s); return; }
+  if ((threadIdx.x & 63) == 0) sw[threadIdx.x >> 6] = s;
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    part[blockIdx.x] = ((sw[0] + sw[1]) + sw[2]) + sw[3];
+    __threadfence();
+    s_last = atomicAdd(ticket, 1) == (int)gridDim.x - 1;
+  }
+  __syncthreads();
+  if (!s_last) return;
+  __threadfence();
+  if (threadIdx.x == 0) {
+    double t = 0.0;
+    for (unsigned i = 0; i < gridDim.x; i++) t += __hip_atomic_load(&part[i], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    *out += t;
+    *ticket = 0;
+  }
+}
+__global__ void __launch_bounds__(256) k_dot(size_t n, const double* __restrict__ a, const double* __restrict__ b, double* out, double* __restrict__ part, int* __restrict__ ticket) {
   double s = 0;
   for (size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x) s += a[i] * b[i];
-  s = wave_sum(s);
-  if ((threadIdx.x & 63) == 0) atomicAdd(out, s);
+  dot_finish(s, out, part, ticket);
 }
 // max |a_i| into *out (non-negative doubles compare like their bit patterns)
 __global__ void k_absmax(size_t n, const double* __restrict__ a, double* out) {
@@ -690,12 +725,12 @@ __global__ void k_mr_wx(size_t n, const double* __restrict__ z, const double* __
 __global__ void k_mr_seal(MrScal* sc) { if (sc->flag == 3) sc->flag = 2; }
 
 // out[j] += V_j . w for j < k (V: k vectors of stride ld); grid (chunks, k)
-__global__ void __launch_bounds__(256) k_multi_dot(size_t n, const double* __restrict__ V, size_t ld, const double* __restrict__ w, double* __restrict__ out) {
+__global__ void __launch_bounds__(256) k_multi_dot(size_t n, const double* __restrict__ V, size_t ld, const double* __restrict__ w, double* __restrict__ out, double* __restrict__ part,
+                                                   int* __restrict__ ticket) {
   const double* v = V + (size_t)blockIdx.y * ld;
   double s = 0;
   for (size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x) s += v[i] * w[i];
-  s = wave_sum(s);
-  if ((threadIdx.x & 63) == 0) atomicAdd(&out[blockIdx.y], s);
+  dot_finish(s, &out[blockIdx.y], part ? part + (size_t)blockIdx.y * gridDim.x : (double*)nullptr, ticket ? ticket + blockIdx.y : (int*)nullptr);
 }
 // w += sign * sum_j h[j] V_j  (h on the device: no host round trip between the projection and the update)
 __global__ void __launch_bounds__(256) k_multi_axpy(size_t n, const double* __restrict__ V, size_t ld, int k, const double* __restrict__ h, double sign, double* __restrict__ w) {

@@ -105,8 +105,8 @@ struct DsPlanSlot {
   uint64_t key = 0;
   long stamp = 0;
   bool used = false;
-  DevBuf<int> level_sn, pmap, vtx, blk_ld, con_ld, wl_front, wl_row, blk_q, con_lvl;
-  DevBuf<long long> blk_dst, con_dst;
+  DevBuf<int> level_sn, pmap, vtx, blk_ld, wl_front, wl_row, blk_q, cgr_ptr, cgr_ent, cgr_ld;
+  DevBuf<long long> blk_dst, cgr_dst;
   DevBuf<DsFrontDesc> fr, frl;
   DevBuf<DsChildRec> ch_rec;
 };
@@ -165,8 +165,8 @@ struct DirectSolver {
   std::vector<int> h_cons;    // constraint vertices the current plan's contact map was built for (engine order)
   std::vector<int> h_cset;    // the same constraints as a sorted set: what tree, fronts and static maps depend on
   bool plan_valid = false;
-  DevBuf<int> csr2sell, level_sn, pmap, vtx, blk_ld, con_ld, bad, wl_front, wl_row, blk_q, con_lvl;
-  DevBuf<long long> blk_dst, con_dst;
+  DevBuf<int> csr2sell, level_sn, pmap, vtx, blk_ld, bad, wl_front, wl_row, blk_q, cgr_ptr, cgr_ent, cgr_ld;
+  DevBuf<long long> blk_dst, cgr_dst;
   DevBuf<DsFrontDesc> fr, frl;   // front descriptors by supernode id / in level order
   DevBuf<DsChildRec> ch_rec;
   DevBuf<double> arena, sarena, garena, scr, w;   // panel arena (cleared per factorisation), Schur arena (never cleared), G arena
@@ -263,6 +263,16 @@ struct tsl_ctx {
   DevBuf<unsigned> cg_ent;
   DevBuf<int> cg_base, cg_ptr;           // gather assembly of the cloth Hessian: block addresses (ascending), list offsets, packed (element, vertex pair)
   DevBuf<double> cg_hrec, cg_frec;       // per-hinge (13) and per-face (81) records, entry-major
+  // "deterministic" = 1 (default): every sum of the step and of the adjoint has a fixed order -- element gradients, energies and the Hessian blocks of
+  // cloth AND tets go through staging records and gathers, contact lists are ordered, contact sums walk them in order: two runs give the same bits.
+  // 0: the f64-atomic scatter kernels of rounds 1-3 (kept for A/B timing).
+  int deterministic = 1;
+  DevBuf<int> trans;                     // slot of a matrix block -> address of its transposed block
+  DevBuf<int> vg_ptr, vg_idx;            // vertex -> staging slots of its incident faces / hinges / tets (k_vertex_gather)
+  DevBuf<double> vg_stage, cg_trec;      // staged element gradients (3-vectors); per-tet 12 x 12 records (144)
+  int vg_ns = 0, vg_hinge0 = 0, vg_tet0 = 0;
+  DevBuf<double> dot_part; DevBuf<int> dot_ticket;   // scratch of the deterministic dot products
+  DevBuf<double> e_part;                 // per-workgroup partial energies
   int n_cgblk = 0, cloth_gather = 0;   // "cloth_gather" = 1: gather assembly of the cloth Hessian (deterministic; measured no faster than the class-ordered atomics: 268 against 270 us)
   DevBuf<double> tet_V;       // eigenvector bases of the clamped element blocks of the last assembly (81 x n_tet, entry-major): warm start of the next one
   long tet_V_count = 0;
@@ -315,12 +325,15 @@ struct tsl_ctx {
   DevBuf<double> c_w, c_n, c_dx0, c_k, c_mu, c_T;     // 3,3,3,1,1,6
   DevBuf<int> cr_ptr, cr_cnt, cr_fill, cr_ent;        // row -> (constraint, slot) CSR of the step's constraints (ContactRows)
   DevBuf<int4> cr_rows;
+  DevBuf<int> cr_tmp;
   DevBuf<int> c_kind;                                 // friction parameter of the constraint's pair (0 fixed, 1 / 2 live)
   DevBuf<double> c_H;                                 // max_nc x 144 (12x12, masked) for the matrix-free product
   DevBuf<double> c_Hfull;                             // unmasked copy (adjoint)
   DevBuf<double> c_diag;                              // NV x 9 (permuted): masked contact contribution to the diagonal blocks
   DevBuf<double> c_G;                                 // max_nc x 12 scratch
   DevBuf<int> grid_key, grid_val, grid_key2, grid_val2, grid_range;  // per target body: cell id / face id (sorted), active range (6 ints)
+  DevBuf<int> vnf_ptr, vnf_lst;   // vertex -> incident surface triangles (deterministic vertex normals)
+  DevBuf<int> cq_flag, cq_scan;   // activity flag / constraint slot of every query vertex of every contact pair (fixed constraint order)
   DevBuf<int> grid_cnt, grid_ptr, grid_cur, scan_tmp;   // hash buckets of the broad phase (histogram, offsets, cursors) and the scratch of the scan
   int grid_buckets_max = 0;
   int max_body_faces = 0;

@@ -38,6 +38,8 @@ int tsl_fail(const char* fmt, ...) {
 #ifndef TSL_NT
 #define TSL_NT false
 #endif
+// partial sums + tickets of the deterministic dot products (k_dot / k_multi_dot; allocated at context creation, ticket rows start at zero)
+#define DOT_SCRATCH(c) ((c)->deterministic ? (c)->dot_part.p : (double*)nullptr), ((c)->deterministic ? (c)->dot_ticket.p : (int*)nullptr)
 #define DOT_BLOCKS 120  // one f64 atomic per wave into a single address: more blocks only add contention (30 us at 600 blocks)
 static inline int nblk(long n, int b) { return (int)((n + b - 1) / b); }
 static inline int gsz(size_t n) { size_t b = (n + 255) / 256; return (int)std::min<size_t>(std::max<size_t>(b, 1), 4096); }
@@ -109,6 +111,7 @@ static ClothArgs cloth_args(tsl_ctx* c) {
   A.n_cface = c->n_cface; A.n_hinge = c->n_hinge; A.cloth = c->d_cloth.p;
   A.f2v = c->cf_f2v.p; A.cf = c->cf_cf.p; A.cp = c->cf_cp.p; A.cid = c->cf_cloth.p;
   A.V = c->cf_V.p; A.li = c->cf_li.p; A.hg_info = c->hg_info.p; A.hg_v = c->hg_v.p; A.norm_dir = c->norm_dir.p; A.f_order = c->cf_order.p;
+  A.gstage = nullptr; A.gs_hinge = c->vg_hinge0;
   return A;
 }
 static VertArgs vert_args(tsl_ctx* c) {
@@ -118,7 +121,7 @@ static VertArgs vert_args(tsl_ctx* c) {
 }
 static TetArgs tet_args(tsl_ctx* c) {
   TetArgs A;
-  A.n_tet = c->n_tet; A.el = c->d_el.p; A.tv = c->tet_v.p; A.tel = c->tet_el.p; A.B = c->tet_B.p; A.W = c->tet_W.p;
+  A.n_tet = c->n_tet; A.el = c->d_el.p; A.tv = c->tet_v.p; A.tel = c->tet_el.p; A.B = c->tet_B.p; A.W = c->tet_W.p; A.gstage = nullptr;
   return A;
 }
 static ContactArgs contact_args(tsl_ctx* c) {
@@ -287,6 +290,8 @@ extern "C" int tsl_ctx_create(const tsl_scene_desc* d, tsl_ctx** out) {
       for (int e = 0; e < 9; e++) tup.emplace_back(cfblk[(size_t)f * 9 + e], ((unsigned)fpos[f] << 4) | (unsigned)e);
     for (int h = 0; h < c->n_hinge; h++)
       for (int e = 0; e < 16; e++) tup.emplace_back(hgblk[(size_t)h * 16 + e], 0x80000000u | ((unsigned)h << 4) | (unsigned)e);
+    for (int t = 0; t < c->n_tet; t++)   // the element blocks of the FEM bodies take the same road (bit 30)
+      for (int e = 0; e < 16; e++) tup.emplace_back(tetblk[(size_t)t * 16 + e], 0x40000000u | ((unsigned)t << 4) | (unsigned)e);
     std::sort(tup.begin(), tup.end());
     cg_ent.reserve(tup.size());
     for (size_t i = 0; i < tup.size(); i++) {
@@ -295,11 +300,34 @@ extern "C" int tsl_ctx_create(const tsl_scene_desc* d, tsl_ctx** out) {
     }
     cg_ptr.push_back((int)tup.size());
     c->n_cgblk = (int)cg_base.size();
-    if (c->n_cface >= (1 << 27) || c->n_hinge >= (1 << 27)) { delete c; return tsl_fail("cloth too large for the packed gather lists"); }
+    if (c->n_cface >= (1 << 26) || c->n_hinge >= (1 << 26) || c->n_tet >= (1 << 26)) { delete c; return tsl_fail("mesh too large for the packed gather lists"); }
+  }
+  // vertex -> staging slots of the element gradients (k_vertex_gather): faces (3 f + l), hinges (+ 4 h + j), tets (+ 4 t + j), ascending
+  std::vector<int> vg_ptr(NV + 1, 0), vg_idx;
+  {
+    c->vg_hinge0 = 3 * c->n_cface; c->vg_tet0 = c->vg_hinge0 + 4 * c->n_hinge; c->vg_ns = c->vg_tet0 + 4 * c->n_tet;
+    for (int v : f2v) vg_ptr[v + 1]++;
+    for (int v : hv) vg_ptr[v + 1]++;
+    for (int v : tv) vg_ptr[v + 1]++;
+    for (int v = 0; v < NV; v++) vg_ptr[v + 1] += vg_ptr[v];
+    vg_idx.resize(vg_ptr[NV]);
+    std::vector<int> cur(vg_ptr.begin(), vg_ptr.end() - 1);
+    for (size_t i = 0; i < f2v.size(); i++) vg_idx[cur[f2v[i]]++] = (int)i;
+    for (size_t i = 0; i < hv.size(); i++) vg_idx[cur[hv[i]]++] = c->vg_hinge0 + (int)i;
+    for (size_t i = 0; i < tv.size(); i++) vg_idx[cur[tv[i]]++] = c->vg_tet0 + (int)i;
   }
 
   UP(cf_blk, cfblk); UP(hg_info, hinfo); UP(hg_v, hv); UP(hg_blk, hgblk);
   if (c->n_cgblk > 0) { UP(cg_base, cg_base); UP(cg_ptr, cg_ptr); UP(cg_ent, cg_ent); }
+  UP(vg_ptr, vg_ptr); if (!vg_idx.empty()) UP(vg_idx, vg_idx);
+  {   // slot of block (r, c) -> address of the transposed block (c, r) (k_zfrozen_gather); -1 on the padding of a slice
+    std::vector<int> trans((size_t)P.n_slots, -1);
+    for (int v = 0; v < NV; v++) {
+      const int pr = P.rowpos[v], sl = pr >> 6, lane = pr & 63;
+      for (int k = 0; k < (int)P.rows[v].size(); k++) trans[(size_t)P.slice_off[sl] + 64 * (size_t)k + lane] = P.lookup(P.rows[v][k], v);
+    }
+    UP(trans, trans);
+  }
   UP(d_el, c->h_el); UP(tet_v, tv); UP(tet_el, tel); UP(tet_blk, tetblk); UP(tet_B, tB); UP(tet_W, tW);
   UP(diag_blk, dblk); UP(rowpos, P.rowpos); UP(perm, P.perm); UP(slice_off, P.slice_off); UP(slice_len, P.slice_len); UP(colidx, P.colidx);
   UP(diag_perm, P.diag_perm);
@@ -313,6 +341,8 @@ extern "C" int tsl_ctx_create(const tsl_scene_desc* d, tsl_ctx** out) {
   rc |= c->norm_dir.alloc((size_t)std::max(c->n_cface, 1) * 3);
   // (the element records of the gather assembly -- 81 doubles per face, 65 MB at 100k triangles -- are allocated when "cloth_gather" first runs)
   rc |= c->quirk.alloc((size_t)std::max(d->n_cloth, 1) * 90);
+  rc |= c->dot_part.alloc(64 * 512); rc |= c->dot_ticket.alloc(512);
+  if (!rc) (void)hipMemset(c->dot_ticket.p, 0, 512 * sizeof(int));
   rc |= c->vals.alloc((size_t)P.n_slots * 9); rc |= c->vals_full.alloc((size_t)P.n_slots * 9);
   rc |= c->Dinv.alloc((size_t)NV * 9);
   const size_t n3 = (size_t)NV * 3;
@@ -410,6 +440,7 @@ extern "C" int tsl_set_param(tsl_ctx* c, const char* key, double v) {
   else if (k == "ds_bench_batch") c->ds.bench_batch = (int)v;
   else if (k == "direct_prezero") c->ds.prezero = (int)v;
   else if (k == "direct_flow") c->ds.flow = std::max(0, (int)v);
+  else if (k == "deterministic") c->deterministic = (int)v != 0;
   else if (k == "direct_gemv_wide_below") c->ds.gemv_wide_below = std::max(0, (int)v);
   else if (k == "direct_g32_below") c->ds.g32_below = std::max(0, (int)v);
   else if (k == "direct_s32_below") c->ds.s32_below = std::max(0, (int)v);
@@ -505,7 +536,7 @@ extern "C" int tsl_set_gravity(tsl_ctx* c, const double* g) {
 
 // ------------------------------------------------------------------------------------------------
 __global__ void k_energy(VertArgs VA, ClothArgs CA, TetArgs TA, const double* __restrict__ pos, const double* __restrict__ prev,
-                         const double* __restrict__ vel, const double* __restrict__ ref_angle, double* e_out) {
+                         const double* __restrict__ vel, const double* __restrict__ ref_angle, double* e_out, double* __restrict__ e_part) {
   const int t = blockIdx.x * blockDim.x + threadIdx.x;
   double e = 0;
   if (t < VA.NV) e += vert_energy(VA, t, pos, prev, vel);
@@ -518,7 +549,24 @@ __global__ void k_energy(VertArgs VA, ClothArgs CA, TetArgs TA, const double* __
   if (t < CA.n_hinge) e += hinge_energy(CA, t, pos, ref_angle);
   if (t < TA.n_tet) e += tet_energy(TA, t, pos);
   e = wave_sum(e);
+  if (e_part) {   // deterministic: the four waves of the workgroup in order, one partial per workgroup; k_energy_final adds the partials in order
+    __shared__ double sw[4];
+    if ((threadIdx.x & 63) == 0) sw[threadIdx.x >> 6] = e;
+    __syncthreads();
+    if (threadIdx.x == 0) e_part[blockIdx.x] = ((sw[0] + sw[1]) + sw[2]) + sw[3];
+    return;
+  }
   if ((threadIdx.x & 63) == 0) atomicAdd(e_out, e);
+}
+// sum of n partial energies in a fixed order (one workgroup: strided per-thread sums, then a fixed tree)
+__global__ void __launch_bounds__(256) k_energy_final(int n, const double* __restrict__ part, double* __restrict__ e_out) {
+  __shared__ double sh[256];
+  double a = 0.0;
+  for (int i = threadIdx.x; i < n; i += 256) a += part[i];
+  sh[threadIdx.x] = a;
+  __syncthreads();
+  for (int o = 128; o > 0; o >>= 1) { if ((int)threadIdx.x < o) sh[threadIdx.x] += sh[threadIdx.x + o]; __syncthreads(); }
+  if (threadIdx.x == 0) *e_out = sh[0];
 }
 
 static CgScal* SC(tsl_ctx* c) { return (CgScal*)c->scal.p; }
@@ -526,11 +574,19 @@ static CgScal* HSC(tsl_ctx* c) { return (CgScal*)c->h_scal; }
 
 static int energy_async(tsl_ctx* c, const double* pos, const double* prev, const double* vel, const double* ref) {
   hipStream_t s = c->stream;
-  HIP_OK(hipMemsetAsync(&SC(c)->energy, 0, sizeof(double), s));
   if (c->n_cface) hipLaunchKernelGGL(k_cloth_normals, dim3(nblk(c->n_cface, 256)), dim3(256), 0, s, c->n_cface, pos, c->cf_f2v.p, c->norm_dir.p);
   const int nmax = std::max(std::max(c->NV, c->n_cface), std::max(c->n_hinge, c->n_tet));
-  hipLaunchKernelGGL(k_energy, dim3(nblk(nmax, 256)), dim3(256), 0, s, vert_args(c), cloth_args(c), tet_args(c), pos, prev, vel, ref, &SC(c)->energy);
-  if (c->nc > 0) hipLaunchKernelGGL(k_contact_energy, dim3(nblk(c->nc, 64)), dim3(64), 0, s, c->nc, contact_args(c), pos, &SC(c)->energy);
+  if (c->deterministic) {   // partials per workgroup, added in a fixed order (the line search decides on E < E0)
+    const int nb1 = nblk(nmax, 256), nb2 = c->nc > 0 ? nblk(c->nc, 64) : 0;
+    if (c->e_part.n < (size_t)nb1 + (size_t)nblk(c->max_n_constraints, 64)) { if (c->e_part.alloc((size_t)nb1 + (size_t)nblk(c->max_n_constraints, 64))) return -1; }
+    hipLaunchKernelGGL(k_energy, dim3(nb1), dim3(256), 0, s, vert_args(c), cloth_args(c), tet_args(c), pos, prev, vel, ref, (double*)nullptr, c->e_part.p);
+    if (nb2 > 0) hipLaunchKernelGGL(k_contact_energy, dim3(nb2), dim3(64), 0, s, c->nc, contact_args(c), pos, (double*)nullptr, c->e_part.p + nb1);
+    hipLaunchKernelGGL(k_energy_final, dim3(1), dim3(256), 0, s, nb1 + nb2, (const double*)c->e_part.p, &SC(c)->energy);
+    return 0;
+  }
+  HIP_OK(hipMemsetAsync(&SC(c)->energy, 0, sizeof(double), s));
+  hipLaunchKernelGGL(k_energy, dim3(nblk(nmax, 256)), dim3(256), 0, s, vert_args(c), cloth_args(c), tet_args(c), pos, prev, vel, ref, &SC(c)->energy, (double*)nullptr);
+  if (c->nc > 0) hipLaunchKernelGGL(k_contact_energy, dim3(nblk(c->nc, 64)), dim3(64), 0, s, c->nc, contact_args(c), pos, &SC(c)->energy, (double*)nullptr);
   return 0;
 }
 static int energy_sync(tsl_ctx* c, const double* pos, const double* prev, const double* vel, const double* ref, double* E) {
@@ -546,6 +602,34 @@ extern "C" int tsl_energy(tsl_ctx* c, const double* pos, const double* prev, con
   return energy_sync(c, pos, prev, vel, ref, E);
 }
 
+// Deterministic gradient: F[v] (holding the vertex term) += the staged gradients of the faces, hinges and tets at v (static lists, ascending
+// slot) + the rows of the contact constraints at v (the step's row lists, ascending constraint and slot), in this order
+__global__ void k_vertex_gather(int NV, const int* __restrict__ vg_ptr, const int* __restrict__ vg_idx, const double* __restrict__ stage, int lo, int hi, double* __restrict__ F) {
+  const int v = blockIdx.x * blockDim.x + threadIdx.x;
+  if (v >= NV) return;
+  d3 a = ld3(F, v);
+  for (int e = vg_ptr[v]; e < vg_ptr[v + 1]; e++) { const int i = vg_idx[e]; if (i >= lo && i < hi) a = a + ld3(stage, i); }   // staging slots in [lo, hi) only
+  st3(F, v, a);
+}
+// ... and the contact part: one WAVE per vertex, lanes over the entries of its row (l, l + 64, ...: a table vertex under a folded cloth has
+// hundreds), joined by the fixed tree of wave_sum; cg: per-constraint 12-vectors
+__global__ void __launch_bounds__(256) k_contact_row_gather(int NV, const int* __restrict__ rowpos, const int* __restrict__ cr_ptr, const int* __restrict__ cr_ent,
+                                                            const double* __restrict__ cg, double* __restrict__ F) {
+  const int v = (int)((blockIdx.x * (size_t)blockDim.x + threadIdx.x) >> 6), lane = threadIdx.x & 63;
+  if (v >= NV) return;
+  const int p = rowpos[v];
+  const int r0 = cr_ptr[p], r1 = cr_ptr[p + 1];
+  if (r1 <= r0) return;
+  double a0 = 0, a1 = 0, a2 = 0;
+  for (int e = r0 + lane; e < r1; e += 64) {
+    const int q = cr_ent[e];
+    const double* g = cg + 12 * (size_t)(q >> 2) + 3 * (q & 3);
+    a0 += g[0]; a1 += g[1]; a2 += g[2];
+  }
+  a0 = wave_sum(a0); a1 = wave_sum(a1); a2 = wave_sum(a2);
+  if (lane == 0) st3(F, v, ld3(F, v) + d3(a0, a1, a2));
+}
+
 static int assemble(tsl_ctx* c, const double* pos, const double* prev, const double* vel, const double* ref, int spd, double* grad) {
   hipStream_t s = c->stream;
   const int NV = c->NV;
@@ -553,9 +637,15 @@ static int assemble(tsl_ctx* c, const double* pos, const double* prev, const dou
   c->ds.numeric_valid = false; c->ds.anorm_valid = false;
   HIP_OK(hipMemsetAsync(c->vals_full.p, 0, c->vals_full.n * sizeof(double), s));
   if (c->n_cface) hipLaunchKernelGGL(k_cloth_normals, dim3(nblk(c->n_cface, 256)), dim3(256), 0, s, c->n_cface, pos, c->cf_f2v.p, c->norm_dir.p);
-  const ClothArgs CA = cloth_args(c);
+  ClothArgs CA = cloth_args(c);
   const VertArgs VA = vert_args(c);
-  const TetArgs TA = tet_args(c);
+  TetArgs TA = tet_args(c);
+  const bool det = c->deterministic != 0;
+  if (det) {   // element gradients into staging slots, element blocks into records: summed by k_vertex_gather / k_cloth_gather in a fixed order
+    if (c->vg_stage.n < 3 * (size_t)std::max(c->vg_ns, 1)) { if (c->vg_stage.alloc(3 * (size_t)std::max(c->vg_ns, 1))) return tsl_fail("out of device memory (gradient staging)"); }
+    if (c->n_tet > 0 && c->cg_trec.n < 144 * (size_t)c->n_tet) { if (c->cg_trec.alloc(144 * (size_t)c->n_tet)) return tsl_fail("out of device memory (element records)"); }
+    CA.gstage = c->vg_stage.p; TA.gstage = c->vg_stage.p + 3 * (size_t)c->vg_tet0;
+  }
   if (grad) HIP_OK(hipMemsetAsync(grad, 0, 3 * (size_t)NV * sizeof(double), s));
   // contact: gradient into grad (atomics), per-constraint 12x12 into c_Hfull, masked copy + diagonal into c_H / cdiag.  The contact
   // launches (0.15 + 0.11 ms at 200 constraints) and the tet kernels (0.23 ms) go to a second stream next to the cloth kernels
@@ -572,7 +662,7 @@ static int assemble(tsl_ctx* c, const double* pos, const double* prev, const dou
   }
   if (c->n_tet) {
     if (grad) hipLaunchKernelGGL(k_tet_grad, dim3(nblk(c->n_tet, 256)), dim3(256), 0, stt, TA, pos, grad);
-    if (c->tet_coop) hipLaunchKernelGGL(k_tet_hess_coop, dim3(nblk((long)c->n_tet * 16, 256)), dim3(256), 0, stt, TA, c->tet_blk.p, pos, spd, c->vals_full.p);
+    if (c->tet_coop && !det) hipLaunchKernelGGL(k_tet_hess_coop, dim3(nblk((long)c->n_tet * 16, 256)), dim3(256), 0, stt, TA, c->tet_blk.p, pos, spd, c->vals_full.p);
     else {
       // eigen-clamp of the element blocks warm-started from the previous assembly's eigenvectors ("tet_warm", on by default);
       // every 16th clamped assembly starts from the identity again (orthogonality of the accumulated rotations)
@@ -587,7 +677,7 @@ static int assemble(tsl_ctx* c, const double* pos, const double* prev, const dou
         vws = c->tet_V.p;
         warm = (c->tet_V_count++ % 16) != 0;
       }
-      hipLaunchKernelGGL(k_tet_hess, dim3(nblk(c->n_tet, 64)), dim3(64), 0, stt, TA, c->tet_blk.p, pos, spd, c->vals_full.p, vws, warm);
+      hipLaunchKernelGGL(k_tet_hess, dim3(nblk(c->n_tet, 64)), dim3(64), 0, stt, TA, c->tet_blk.p, pos, spd, c->vals_full.p, vws, warm, det ? c->cg_trec.p : (double*)nullptr);
     }
   }
   TSL_TRY(contact_assemble(c, pos, spd, grad, st));
@@ -601,7 +691,10 @@ static int assemble(tsl_ctx* c, const double* pos, const double* prev, const dou
   if (fork) HIP_OK(hipEventRecord(c->ev_join, c->side));
   if (fork_t) HIP_OK(hipEventRecord(c->ev_join2, c->side2));
   hipLaunchKernelGGL(k_vert_hess, dim3(nblk(NV, 256)), dim3(256), 0, s, VA, c->diag_blk.p, c->vals_full.p);
-  const bool gather = c->cloth_gather && c->n_cgblk > 0 && c->n_cface > 0;
+  const bool gather = (c->cloth_gather || det) && c->n_cgblk > 0;
+  if (gather && c->n_cface > 0 && c->cg_frec.n == 0) {   // element records of the gather assembly, on first use
+    if (c->cg_hrec.alloc((size_t)std::max(c->n_hinge, 1) * 16) | c->cg_frec.alloc((size_t)c->n_cface * 81)) return tsl_fail("out of device memory (cloth element records)");
+  }
   if (c->n_cface) {
     const int nq = (int)c->h_cloth.size() * 9;
     hipLaunchKernelGGL(k_cloth_quirk, dim3(nblk(nq, 64)), dim3(64), 0, s, CA, (int)c->h_cloth.size(), pos, ref, c->quirk.p);
@@ -612,10 +705,16 @@ static int assemble(tsl_ctx* c, const double* pos, const double* prev, const dou
   if (c->n_hinge) hipLaunchKernelGGL(k_cloth_hess_hinge, dim3(nblk(c->n_hinge, 256)), dim3(256), 0, s, CA, c->hg_blk.p, pos, c->vals_full.p, gather ? c->cg_hrec.p : (double*)nullptr);
   // element records -> matrix blocks, one lane per block, no atomics (the element blocks of the FEM bodies and the mass diagonal touch other
   // entries or were added before: k_vert_hess above runs on this stream)
-  if (gather) hipLaunchKernelGGL(k_cloth_gather, dim3(nblk(c->n_cgblk, 256)), dim3(256), 0, s, c->n_cgblk, c->cg_base.p, c->cg_ptr.p, (const unsigned*)c->cg_ent.p, c->n_hinge, c->n_cface,
-                                 (const double*)c->cg_hrec.p, (const double*)c->cg_frec.p, c->vals_full.p);
   if (fork) HIP_OK(hipStreamWaitEvent(s, c->ev_join, 0));
   if (fork_t) HIP_OK(hipStreamWaitEvent(s, c->ev_join2, 0));
+  // (after the join: the tet records come from the element stream)
+  if (gather) hipLaunchKernelGGL(k_cloth_gather, dim3(nblk(c->n_cgblk, 256)), dim3(256), 0, s, c->n_cgblk, c->cg_base.p, c->cg_ptr.p, (const unsigned*)c->cg_ent.p, c->n_hinge, c->n_cface,
+                                 (const double*)c->cg_hrec.p, (const double*)c->cg_frec.p, (const double*)c->cg_trec.p, c->vals_full.p);
+  if (det && grad) {
+    hipLaunchKernelGGL(k_vertex_gather, dim3(nblk(NV, 256)), dim3(256), 0, s, NV, (const int*)c->vg_ptr.p, (const int*)c->vg_idx.p, (const double*)c->vg_stage.p, 0, c->vg_ns, grad);
+    if (c->nc > 0) hipLaunchKernelGGL(k_contact_row_gather, dim3(nblk((long)NV * 64, 256)), dim3(256), 0, s, NV, (const int*)c->rowpos.p, (const int*)c->cr_ptr.p, (const int*)c->cr_ent.p,
+                                      (const double*)c->c_G.p, grad);
+  }
   if (grad) hipLaunchKernelGGL(k_mask_vec, dim3(gsz(3 * (size_t)NV)), dim3(256), 0, s, 3 * (size_t)NV, c->frozen.p, grad);
   hipLaunchKernelGGL(k_mask_matrix, dim3(c->n_slices), dim3(256), 0, s, c->n_slices, c->slice_off.p, c->slice_len.p, c->colidx.p, c->fzmask.p, c->mdt2.p,
                      c->vals_full.p, c->vals.p, NV);
@@ -642,7 +741,7 @@ extern "C" int tsl_assemble(tsl_ctx* c, const double* pos, const double* prev, c
 static ContactRows contact_rows(tsl_ctx* c, const double* blocks) {
   ContactRows R;
   R.ptr = c->nc > 0 ? c->cr_ptr.p : (const int*)nullptr;
-  R.ent = c->cr_ent.p; R.rows = c->cr_rows.p; R.H = blocks;
+  R.ent = c->cr_ent.p; R.rows = c->cr_rows.p; R.H = blocks; R.nv = c->NV;
   return R;
 }
 
@@ -1131,7 +1230,9 @@ static int solve_perm(tsl_ctx* c, tsl_solve_stats* st) {
     // iterations per solve (46 ms per step) against one 6 ms factorisation per solve (86 ms per step).  A solve first probes the
     // hierarchy with a cap of `probe_cap` iterations (the cost of one factorisation); the first failure marks the scene hard and
     // the following `probe_every` time steps go straight to the factorisation.
-    if (d.enable < 0 && !d.hard) {
+    // Scenes with FEM bodies or active contacts skip the probe (round 4): it never succeeded on them (cfg3 / cfg4: 60 wasted iterations every
+    // 16 steps), and the hierarchy's f64-atomic reductions are the one part of the step that is not bit-reproducible.
+    if (d.enable < 0 && !d.hard && c->n_tet == 0 && c->nc == 0) {
       c->ds_suspended = true; c->ds_probe = true;
       const int maxit_keep = c->cg_maxit;
       c->cg_maxit = std::min(c->cg_maxit, d.probe_cap);
@@ -1268,7 +1369,7 @@ static int solve_perm(tsl_ctx* c, tsl_solve_stats* st) {
   const bool warm = c->warm_start && c->in_step && c->warm_valid;
   if (!warm) HIP_OK(hipMemsetAsync(c->v_x.p, 0, n3 * sizeof(double), s));
   HIP_OK(hipMemsetAsync(c->scal.p, 0, sizeof(SolverScalars), s));
-  hipLaunchKernelGGL(k_dot, dim3(DOT_BLOCKS), dim3(256), 0, s, n3, c->v_b.p, c->v_b.p, &SC(c)->bb);
+  hipLaunchKernelGGL(k_dot, dim3(DOT_BLOCKS), dim3(256), 0, s, n3, c->v_b.p, c->v_b.p, &SC(c)->bb, DOT_SCRATCH(c));
   TSL_TRY(read_scal(c));
   const double bb = HSC(c)->bb;
   if (!(bb > 0)) return 0;  // zero rhs -> x = 0
@@ -1432,7 +1533,7 @@ static void launch_minres_iteration(tsl_ctx* c, const MrBufs& B, int j) {
   else {
     hipLaunchKernelGGL(k_precond, dim3(nblk(c->NV, 256)), dim3(256), 0, s, c->NV, c->Dinv.p, v_next, z_next);
     if (bd) body_apply(c, 0, v_next, nullptr, z_next, nullptr, nullptr);
-    hipLaunchKernelGGL(k_dot, dim3(DOT_BLOCKS), dim3(256), 0, s, n3, z_next, v_next, &sc->g2n);
+    hipLaunchKernelGGL(k_dot, dim3(DOT_BLOCKS), dim3(256), 0, s, n3, z_next, v_next, &sc->g2n, DOT_SCRATCH(c));
   }
   hipLaunchKernelGGL(k_mr_scal, dim3(1), dim3(256), 0, s, sc, mg ? c->part_rz.p : (const double*)nullptr, nblk(c->NV, 256) + (bd ? c->bd_wg : 0));
   hipLaunchKernelGGL(k_mr_wx, dim3(gv), dim3(256), 0, s, n3, z_cur, w_prev, w_cur, w_next, B.x, sc);
@@ -1483,8 +1584,8 @@ static int minres(tsl_ctx* c, tsl_solve_stats* st) {
   MrScal* h = (MrScal*)c->h_scal;
   auto dot2 = [&](const double* a1, const double* b1, const double* a2, const double* b2, double* o1, double* o2) -> int {
     HIP_OK(hipMemsetAsync(&d->delta, 0, 2 * sizeof(double), s));
-    hipLaunchKernelGGL(k_dot, dim3(DOT_BLOCKS), dim3(256), 0, s, n3, a1, b1, &d->delta);
-    if (a2) hipLaunchKernelGGL(k_dot, dim3(DOT_BLOCKS), dim3(256), 0, s, n3, a2, b2, &d->g2n);
+    hipLaunchKernelGGL(k_dot, dim3(DOT_BLOCKS), dim3(256), 0, s, n3, a1, b1, &d->delta, DOT_SCRATCH(c));
+    if (a2) hipLaunchKernelGGL(k_dot, dim3(DOT_BLOCKS), dim3(256), 0, s, n3, a2, b2, &d->g2n, DOT_SCRATCH(c));
     HIP_OK(hipMemcpyAsync(&h->delta, &d->delta, 2 * sizeof(double), hipMemcpyDeviceToHost, s));
     HIP_OK(hipStreamSynchronize(s));
     *o1 = h->delta;
@@ -1594,7 +1695,7 @@ static int gmres(tsl_ctx* c, tsl_solve_stats* st, bool direct) {
   };
   auto norm2 = [&](const double* a, double* out) -> int {
     HIP_OK(hipMemsetAsync(dh + on, 0, sizeof(double), s));
-    hipLaunchKernelGGL(k_dot, dim3(DOT_BLOCKS), dim3(256), 0, s, n3, a, a, dh + on);
+    hipLaunchKernelGGL(k_dot, dim3(DOT_BLOCKS), dim3(256), 0, s, n3, a, a, dh + on, DOT_SCRATCH(c));
     HIP_OK(hipMemcpyAsync(out, dh + on, sizeof(double), hipMemcpyDeviceToHost, s));
     HIP_OK(hipStreamSynchronize(s));
     return 0;
@@ -1621,11 +1722,11 @@ static int gmres(tsl_ctx* c, tsl_solve_stats* st, bool direct) {
       precond(V + (size_t)j * n3, z);
       launch_spmv(c, c->vals.p, z, w, -1, 0);
       HIP_OK(hipMemsetAsync(dh, 0, (size_t)(on + 1) * sizeof(double), s));
-      hipLaunchKernelGGL(k_multi_dot, dim3(64, j + 1), dim3(256), 0, s, n3, V, n3, w, dh);
+      hipLaunchKernelGGL(k_multi_dot, dim3(64, j + 1), dim3(256), 0, s, n3, V, n3, w, dh, DOT_SCRATCH(c));
       hipLaunchKernelGGL(k_multi_axpy, dim3(gv), dim3(256), 0, s, n3, V, n3, j + 1, dh, -1.0, w);
-      hipLaunchKernelGGL(k_multi_dot, dim3(64, j + 1), dim3(256), 0, s, n3, V, n3, w, dh + o2);
+      hipLaunchKernelGGL(k_multi_dot, dim3(64, j + 1), dim3(256), 0, s, n3, V, n3, w, dh + o2, DOT_SCRATCH(c));
       hipLaunchKernelGGL(k_multi_axpy, dim3(gv), dim3(256), 0, s, n3, V, n3, j + 1, dh + o2, -1.0, w);
-      hipLaunchKernelGGL(k_dot, dim3(DOT_BLOCKS), dim3(256), 0, s, n3, w, w, dh + on);
+      hipLaunchKernelGGL(k_dot, dim3(DOT_BLOCKS), dim3(256), 0, s, n3, w, w, dh + on, DOT_SCRATCH(c));
       TSL_TRY(read_h(on + 1));
       total++; st->iters++;
       if (direct && c->ds.gm_cap > 0 && total > c->ds.gm_cap) return 0;  // stale factors: give up, the caller refactorises (flag stays 3)
@@ -1673,8 +1774,8 @@ static int gmres(tsl_ctx* c, tsl_solve_stats* st, bool direct) {
     double rr, xx = 0.0;
     {
       HIP_OK(hipMemsetAsync(dh + on, 0, 2 * sizeof(double), s));
-      hipLaunchKernelGGL(k_dot, dim3(DOT_BLOCKS), dim3(256), 0, s, n3, (const double*)r, (const double*)r, dh + on);
-      if (direct) hipLaunchKernelGGL(k_dot, dim3(DOT_BLOCKS), dim3(256), 0, s, n3, (const double*)x, (const double*)x, dh + on + 1);
+      hipLaunchKernelGGL(k_dot, dim3(DOT_BLOCKS), dim3(256), 0, s, n3, (const double*)r, (const double*)r, dh + on, DOT_SCRATCH(c));
+      if (direct) hipLaunchKernelGGL(k_dot, dim3(DOT_BLOCKS), dim3(256), 0, s, n3, (const double*)x, (const double*)x, dh + on + 1, DOT_SCRATCH(c));
       double two[2];
       HIP_OK(hipMemcpyAsync(two, dh + on, 2 * sizeof(double), hipMemcpyDeviceToHost, s));
       HIP_OK(hipStreamSynchronize(s));
@@ -1767,8 +1868,8 @@ static int bicgstab(tsl_ctx* c, tsl_solve_stats* st) {
   CgScal* h = HSC(c);
   auto dots = [&](const double* a1, const double* b1, const double* a2, const double* b2, double* o1, double* o2) -> int {
     HIP_OK(hipMemsetAsync(&d->aux[0], 0, 2 * sizeof(double), s));
-    hipLaunchKernelGGL(k_dot, dim3(DOT_BLOCKS), dim3(256), 0, s, n3, a1, b1, &d->aux[0]);
-    if (a2) hipLaunchKernelGGL(k_dot, dim3(DOT_BLOCKS), dim3(256), 0, s, n3, a2, b2, &d->aux[1]);
+    hipLaunchKernelGGL(k_dot, dim3(DOT_BLOCKS), dim3(256), 0, s, n3, a1, b1, &d->aux[0], DOT_SCRATCH(c));
+    if (a2) hipLaunchKernelGGL(k_dot, dim3(DOT_BLOCKS), dim3(256), 0, s, n3, a2, b2, &d->aux[1], DOT_SCRATCH(c));
     HIP_OK(hipMemcpyAsync(&h->aux[0], &d->aux[0], 2 * sizeof(double), hipMemcpyDeviceToHost, s));
     HIP_OK(hipStreamSynchronize(s));
     *o1 = h->aux[0];
@@ -2266,6 +2367,11 @@ __global__ void k_adj_a2ax(ClothArgs A, const double* __restrict__ pos, const do
   const double a = ag_s[3 * f1 + l];
   ag_prev[3 * f1 + l] += a;
   const double sgn = (fabs(theta - ref[3 * f1 + l]) > c.k_angle) ? a : a * 0.1;
+  if (A.gstage) {   // deterministic: staged, summed per vertex by k_vertex_gather
+#pragma unroll
+    for (int j = 0; j < 4; j++) st3(A.gstage, A.gs_hinge + 4 * h + j, sgn * g[j]);
+    return;
+  }
   atomic_add3(pg_s, v1[l], sgn * g[0]);
   atomic_add3(pg_s, v1[(l + 1) % 3], sgn * g[1]);
   atomic_add3(pg_s, v1[(l + 2) % 3], sgn * g[2]);
@@ -2316,6 +2422,64 @@ __global__ void k_zfrozen_matrix(int NV, int n_slices, const int* __restrict__ s
   }
 }
 
+// The same sums without atomics: one thread per (permuted) row c with a frozen dof walks ITS blocks (c, p); the block that carries the
+// contribution is the transposed one, (p, c), found through a static table (trans[slot of (c, p)] = address of block (p, c); the
+// pattern is symmetric, the values are not: factor-2 quirk of the area term); fixed order, plain store of the row's three sums
+__global__ void k_zfrozen_gather(int NV, const int* __restrict__ slice_off, const int* __restrict__ slice_len, const int* __restrict__ colidx, const int* __restrict__ trans,
+                                 const unsigned char* __restrict__ fz, const double* __restrict__ vals, const double* __restrict__ zp, double* __restrict__ out) {
+  const int c = blockIdx.x * blockDim.x + threadIdx.x;
+  if (c >= NV) return;
+  const unsigned cm = fz[c];
+  double acc[3] = {0.0, 0.0, 0.0};
+  if (cm) {
+    const int slice = c >> 6, lane = c & 63, off = slice_off[slice], len = slice_len[slice];
+    for (int k = 0; k < len; k++) {
+      const int sl = off + 64 * k + lane;
+      const int p = colidx[sl];
+      const int tb = trans[sl];
+      if (tb < 0) continue;   // padding of the slice
+      const unsigned rm = fz[p];
+      if (rm == 7u) continue;
+      const d3 zi = ld3(zp, p);
+      const double zr[3] = {zi.x, zi.y, zi.z};
+      for (int cc = 0; cc < 3; cc++) {
+        if (!((cm >> cc) & 1u)) continue;
+        double s = 0;
+        for (int r = 0; r < 3; r++) if (!((rm >> r) & 1u)) s += vals[(size_t)tb + 64 * (3 * r + cc)] * zr[r];
+        acc[cc] -= s;
+      }
+    }
+  }
+  out[3 * (size_t)c] = acc[0]; out[3 * (size_t)c + 1] = acc[1]; out[3 * (size_t)c + 2] = acc[2];
+}
+// contact part of tmp_z_frozen per vertex (original order) through the row lists of the step's constraints, fixed order
+__global__ void __launch_bounds__(256) k_contact_zfrozen_gather(int NV, const int* __restrict__ rowpos, const int* __restrict__ cr_ptr, const int* __restrict__ cr_ent,
+                                                                const int* __restrict__ idx, const int* __restrict__ frozen, const double* __restrict__ Hfull,
+                                                                const double* __restrict__ z, double* __restrict__ out) {
+  const int v = (int)((blockIdx.x * (size_t)blockDim.x + threadIdx.x) >> 6), lane = threadIdx.x & 63;   // one wave per vertex, lanes over the row's entries
+  if (v >= NV) return;
+  const int fz[3] = {frozen[3 * v], frozen[3 * v + 1], frozen[3 * v + 2]};
+  if (!(fz[0] | fz[1] | fz[2])) return;
+  const int p = rowpos[v];
+  const int r0 = cr_ptr[p], r1 = cr_ptr[p + 1];
+  if (r1 <= r0) return;
+  double acc[3] = {0.0, 0.0, 0.0};
+  for (int e = r0 + lane; e < r1; e += 64) {
+    const int q = cr_ent[e], ci = q >> 2, a = q & 3;
+    const double* H = Hfull + 144 * (size_t)ci;
+    for (int cc = 0; cc < 3; cc++) {
+      if (!fz[cc]) continue;
+      double s = 0;
+      for (int k = 0; k < 4; k++) {
+        const int u = idx[4 * ci + k];
+        for (int j = 0; j < 3; j++) if (!frozen[3 * u + j]) s += H[(3 * k + j) * 12 + 3 * a + cc] * z[3 * (size_t)u + j];
+      }
+      acc[cc] -= s;
+    }
+  }
+  for (int cc = 0; cc < 3; cc++) { const double t = wave_sum(acc[cc]); if (lane == 0 && fz[cc]) out[3 * (size_t)v + cc] += t; }
+}
+
 // x_hat_grad = z m / dt^2 ; pos_grad[s-1] += (1+d) x_hat_grad, pos_grad[s-2] -= d x_hat_grad on free dofs
 // (Grad.get_grad / get_prev_grad / get_prev_prev_grad, analytic_grad_single.py:81-106)
 __global__ void k_adj_prev(int NV, const double* __restrict__ z, const double* __restrict__ mass, const int* __restrict__ frozen, double dt, double d,
@@ -2353,14 +2517,21 @@ extern "C" int tsl_adjoint_step(tsl_ctx* c, int step, int T, const double* pos_b
   int nc = 0;
   if (c->contact_enable) TSL_TRY(tsl_contact_detect(c, x_prev, x_prev, &nc));
   else { c->nc = 0; c->ds.cons_checked = false; }
-  const ClothArgs CA = cloth_args(c);
+  ClothArgs CA = cloth_args(c);
+  const bool det = c->deterministic != 0;
+  if (det && c->vg_stage.n < 3 * (size_t)std::max(c->vg_ns, 1)) { if (c->vg_stage.alloc(3 * (size_t)std::max(c->vg_ns, 1))) return tsl_fail("out of device memory (gradient staging)"); }
   // pos = x_s, ref_angle = ref_{s-1}: init_folding + ref_angle_backprop_a2ax
-  if (c->n_hinge) hipLaunchKernelGGL(k_adj_a2ax, dim3(nblk(c->n_hinge, 256)), dim3(256), 0, s, CA, x_s, ref_prev, ag_s, ag_prev, pg_s);
+  if (c->n_hinge) {
+    if (det) CA.gstage = c->vg_stage.p;
+    hipLaunchKernelGGL(k_adj_a2ax, dim3(nblk(c->n_hinge, 256)), dim3(256), 0, s, CA, x_s, ref_prev, ag_s, ag_prev, pg_s);
+    if (det) hipLaunchKernelGGL(k_vertex_gather, dim3(nblk(NV, 256)), dim3(256), 0, s, NV, (const int*)c->vg_ptr.p, (const int*)c->vg_idx.p, (const double*)c->vg_stage.p, c->vg_hinge0, c->vg_tet0, pg_s);
+    CA.gstage = nullptr;
+  }
   // preconditioner from the SPD-projected Hessian of the same state (block Jacobi + multigrid hierarchy): the operator
   // below is the un-projected H, which may be indefinite, and smoothers / coarse operators built from it are not safe
   const bool have_mg = !c->mg.empty() && c->mg_enable != 0;
   // the direct path factorises the un-projected operator itself; its auto mode may still probe the hierarchy first (not marked hard)
-  const bool spd_pc = c->adj_spd_pc && (have_mg || body_active(c)) && !(direct_enabled(c) && (c->ds.enable == 1 || c->ds.hard));
+  const bool spd_pc = c->adj_spd_pc && (have_mg || body_active(c)) && !(direct_enabled(c) && (c->ds.enable == 1 || c->ds.hard || c->n_tet > 0 || c->nc > 0));   // (no probe of the hierarchy: see solve_perm)
   c->bd_valid = false;
   c->mg_omega_valid = false; c->mg_cinv_valid = false;
   if (spd_pc) {
@@ -2387,13 +2558,28 @@ extern "C" int tsl_adjoint_step(tsl_ctx* c, int step, int T, const double* pos_b
   if (st->method == 4) TSL_TRY(direct_prezero(c));   // the next adjoint step assembles another operator
   if (c->verbose) fprintf(stderr, "[tsl] adjoint step %d: nc %d solver flag %d iters %d restarts %d rel_residual %.2e\n", step, c->nc, st->flag, st->iters, st->restarts, st->rel_residual);
   // tmp_z_frozen (second compute_Hessian pass with counting_z_frozen)
-  HIP_OK(hipMemsetAsync(c->v_t4.p, 0, n3 * sizeof(double), s));
-  hipLaunchKernelGGL(k_zfrozen_matrix, dim3(c->n_slices), dim3(256), 0, s, NV, c->n_slices, c->slice_off.p, c->slice_len.p, c->colidx.p, c->fzmask.p, c->vals_full.p, c->v_x.p,
-                     c->v_t4.p);
+  if (det) hipLaunchKernelGGL(k_zfrozen_gather, dim3(nblk(NV, 256)), dim3(256), 0, s, NV, c->slice_off.p, c->slice_len.p, c->colidx.p, (const int*)c->trans.p, c->fzmask.p, c->vals_full.p,
+                              c->v_x.p, c->v_t4.p);
+  else {
+    HIP_OK(hipMemsetAsync(c->v_t4.p, 0, n3 * sizeof(double), s));
+    hipLaunchKernelGGL(k_zfrozen_matrix, dim3(c->n_slices), dim3(256), 0, s, NV, c->n_slices, c->slice_off.p, c->slice_len.p, c->colidx.p, c->fzmask.p, c->vals_full.p, c->v_x.p,
+                       c->v_t4.p);
+  }
   hipLaunchKernelGGL(k_scatter_perm, dim3(nblk(NV, 256)), dim3(256), 0, s, NV, c->perm.p, c->v_t4.p, tmp_z_frozen);
-  if (c->nc > 0) hipLaunchKernelGGL(k_contact_zfrozen, dim3(nblk(c->nc, 64)), dim3(64), 0, s, c->nc, c->c_idx.p, c->frozen.p, c->c_Hfull.p, c->pdir.p, tmp_z_frozen);
+  if (c->nc > 0) {
+    if (det) hipLaunchKernelGGL(k_contact_zfrozen_gather, dim3(nblk((long)NV * 64, 256)), dim3(256), 0, s, NV, (const int*)c->rowpos.p, (const int*)c->cr_ptr.p, (const int*)c->cr_ent.p, c->c_idx.p,
+                                c->frozen.p, c->c_Hfull.p, c->pdir.p, tmp_z_frozen);
+    else hipLaunchKernelGGL(k_contact_zfrozen, dim3(nblk(c->nc, 64)), dim3(64), 0, s, c->nc, c->c_idx.p, c->frozen.p, c->c_Hfull.p, c->pdir.p, tmp_z_frozen);
+  }
   // contact_energy_backprop(step-1) ; ref_angle_backprop_x2a
-  if (c->nc > 0) hipLaunchKernelGGL(k_contact_backprop, dim3(nblk(c->nc, 64)), dim3(64), 0, s, c->nc, contact_args(c), x_s, c->pdir.p, pg_prev);
+  if (c->nc > 0) {
+    if (det) {
+      if (c->c_G.n < 12 * (size_t)c->max_n_constraints) { if (c->c_G.alloc(12 * (size_t)c->max_n_constraints)) return -1; }
+      hipLaunchKernelGGL(k_contact_backprop, dim3(nblk(c->nc, 64)), dim3(64), 0, s, c->nc, contact_args(c), x_s, c->pdir.p, pg_prev, c->c_G.p);
+      hipLaunchKernelGGL(k_contact_row_gather, dim3(nblk((long)NV * 64, 256)), dim3(256), 0, s, NV, (const int*)c->rowpos.p, (const int*)c->cr_ptr.p, (const int*)c->cr_ent.p,
+                         (const double*)c->c_G.p, pg_prev);
+    } else hipLaunchKernelGGL(k_contact_backprop, dim3(nblk(c->nc, 64)), dim3(64), 0, s, c->nc, contact_args(c), x_s, c->pdir.p, pg_prev, (double*)nullptr);
+  }
   if (c->n_hinge) hipLaunchKernelGGL(k_adj_x2a, dim3(nblk(c->n_hinge, 256)), dim3(256), 0, s, CA, x_s, c->pdir.p, ag_prev);
   // get_prev_grad / get_prev_prev_grad
   hipLaunchKernelGGL(k_adj_prev, dim3(gsz(n3)), dim3(256), 0, s, NV, c->pdir.p, c->mass.p, c->frozen.p, c->dt, adj_damping, pg_prev, pg_prev2);
