@@ -7,6 +7,11 @@ import pytest
 import torch
 
 pytestmark = pytest.mark.gpu
+# The T = 50 rollout is bit-reproducible since round 4 (deterministic assembly, tests/test_gpu_determinism.py): it ends with NO flagged
+# solve (0 of 2456 forward, 0 of 50 adjoint).  Round 3 had widened these bounds to 20 to absorb run-to-run chaos; they
+# are back to a small margin for code changes that move the rollout, not for noise.
+FLAGGED_STEPS_MAX = 2
+ADJ_FLAGGED_MAX = 2
 
 
 def _free_mask(s):
@@ -171,8 +176,7 @@ def test_cfg4_balancing_224_T50_rollout():
         solves += st["newton_iters"]; flagged += st["unconverged"]
         if f <= 10:   # the idle phase settles below the reference's stop rule after the first steps
             assert st["unconverged"] == 0, (f, st)
-    # (fifteen runs of this rollout in round 3: ten without a flagged solve, five with 7-40 of ~2,550 -- bounded generously, the point is that they are reported)
-    assert flagged_steps <= 20 and flagged <= 0.05 * solves, (flagged_steps, flagged, solves)
+    assert flagged_steps <= FLAGGED_STEPS_MAX and flagged <= 0.05 * solves, (flagged_steps, flagged, solves)
     g.get_loss_balance(s)
     adj_flagged = 0
     for st_ in range(T - 1, 0, -1):
@@ -183,7 +187,8 @@ def test_cfg4_balancing_224_T50_rollout():
             adj_flagged += 1
         else:
             assert ls["rel_residual"] < 1e-8 or (ls["attained"] == 1 and ls["backward_error"] < 1e-12), (st_, ls)
-    assert adj_flagged <= 20, adj_flagged
+    print(f"T = 50 rollout: {flagged_steps} flagged steps, {flagged} of {solves} forward solves flagged, {adj_flagged} adjoint solves flagged")
+    assert adj_flagged <= ADJ_FLAGGED_MAX, adj_flagged
     assert np.isfinite(g.pos_grad.to_numpy()).all() and np.isfinite(g.gripper_grad.to_numpy()).all()
 
 
