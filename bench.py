@@ -17,7 +17,7 @@ The JSON line also carries
   roofline      -- the kernel class of the sparse direct solve that takes the most time per Newton iteration (named in the object):
                    algorithmic flops (or bytes) per launch / average launch duration between one HIP-event pair around back-to-back
                    replays of that class's launches on the run's last plan, against the f64 matrix-core peak (or 8 TB/s);
-  roofline_step -- SURVEY.md section 8d's whole-step figures from the measured counts;
+                   roofline.whole_step = SURVEY.md section 8d's whole-step figures from the measured counts;
   cpu_baseline  -- the fp64 CPU restatement (oracle/, "port": the reference itself needs taichi + cupy/CUDA and cannot run) timed on
                    this box's host cores: complete fwd+adjoint steps of the same scene with a coarser cloth next to the GPU on that
                    scene, and the cfg4-size extrapolation of a bounded sample (labelled as such).
@@ -516,7 +516,6 @@ def main():
     if rf is not None:
         rf["whole_step"] = step   # SURVEY section 8d's bytes model and the factorisation-flops figure of the WHOLE step, inside the object the driver keeps
         out["roofline"] = rf
-        out["roofline_step"] = step
     if args.scenes_per_gpu > 1 and rank == 0 and world == 1:
         # the multi-scene leg runs in a child process of its own (more hardware queues: an environment variable the HIP runtime reads at start-up)
         try:

@@ -77,7 +77,8 @@ static void ds_launch_level_start(tsl_ctx* c, hipStream_t s, const DsDev& D, int
   if (l > 0) ds_launch_extend(s, D, lv0, nf, P.level_maxld[l]);
   const int nb = P.blk_lptr[l + 1] - P.blk_lptr[l];
   const long nt = (long)nb * 9 + (long)nf * DS_T;
-  hipLaunchKernelGGL(k_ds_assemble_level, dim3(ds_nblk(nt, 256)), dim3(256), 0, s, P.blk_lptr[l], nb, d.blk_q.p, d.csr2sell.p, c->vals.p, d.blk_dst.p, d.blk_ld.p, lv0, nf, d.frl.p, d.arena.p);
+  hipLaunchKernelGGL(k_ds_assemble_level, dim3(ds_nblk(nt, 256)), dim3(256), 0, s, P.blk_lptr[l], nb, (const int*)d.blk_q.p, (const double*)c->vals.p, (const long long*)d.blk_dst.p,
+                     (const int*)d.blk_ld.p, lv0, nf, d.frl.p, d.arena.p);
   const int ng = c->nc > 0 ? P.cgr_lptr[l + 1] - P.cgr_lptr[l] : 0;
   if (ng > 0) hipLaunchKernelGGL(k_ds_assemble_contacts_level, dim3(ds_nblk((long)ng * 64, 256)), dim3(256), 0, s, P.cgr_lptr[l], ng, (const int*)d.cgr_ptr.p, (const int*)d.cgr_ent.p,
                                  (const long long*)d.cgr_dst.p, (const int*)d.cgr_ld.p, (const double*)c->c_H.p, d.arena.p);
@@ -175,7 +176,7 @@ static int direct_static(tsl_ctx* c) {
     const int p = c->h_rowpos[v], s = p >> 6, lane = p & 63;
     for (int k = 0; k < (int)c->h_rows[v].size(); k++) c2s[d.row_ptr[v] + k] = (int)(((long)c->h_slice_off[s] + 64L * k) * 9 + lane);
   }
-  if (d.csr2sell.upload(c2s)) return -1;
+  d.h_c2s = c2s;   // (SELL address of every CSR block: the plan uploads bake it into their level-ordered lists)
   if (d.bad.alloc(8 + 4 * DS_BADLOG)) return -1;
   HIP_OK(hipFuncSetAttribute((const void*)k_ds_inv_small, hipFuncAttributeMaxDynamicSharedMemorySize, (int)ds_small_lds(DS_SMALL)));
   d.plan.sym.build_partition(NV, c->h_rows, d.grids, d.blocks, d.leaf);
@@ -290,9 +291,17 @@ static int direct_plan(tsl_ctx* c) {
   for (size_t i = 0; i < vtxp.size(); i++) vtxp[i] = c->h_rowpos[P.vtx[i]];
   HIP_OK(hipStreamSynchronize(s));  // the previous plan's arrays may still be in use
   TSL_TRY(ds_upload_grow(d.fr, P.fr, s)); TSL_TRY(ds_upload_grow(d.level_sn, P.level_sn, s)); TSL_TRY(ds_upload_grow(d.pmap, P.pmap, s)); TSL_TRY(ds_upload_grow(d.ch_rec, P.ch_rec, s));
-  TSL_TRY(ds_upload_grow(d.vtx, vtxp, s)); TSL_TRY(ds_upload_grow(d.blk_dst, P.blk_dst, s)); TSL_TRY(ds_upload_grow(d.blk_ld, P.blk_ld, s));
+  TSL_TRY(ds_upload_grow(d.vtx, vtxp, s));
+  // the static blocks in the plan's level order: SELL source address, destination, row stride (the device arrays blk_q / blk_dst / blk_ld)
+  const size_t nbk = P.blk_q.size();
+  std::vector<int> src_l(nbk), ld_l(nbk);
+  std::vector<long long> dst_l(nbk);
+  ds_parallel_for((int)((nbk + 4095) / 4096), P.n_threads(), 1, [&](int, int ch) {
+    for (size_t i = (size_t)ch * 4096; i < std::min(nbk, (size_t)(ch + 1) * 4096); i++) { const int q = P.blk_q[i]; src_l[i] = d.h_c2s[q]; dst_l[i] = P.blk_dst[q]; ld_l[i] = P.blk_ld[q]; }
+  });
+  TSL_TRY(ds_upload_grow(d.blk_dst, dst_l, s)); TSL_TRY(ds_upload_grow(d.blk_ld, ld_l, s));
   TSL_TRY(ds_upload_con(d, s));
-  TSL_TRY(ds_upload_grow(d.blk_q, P.blk_q, s));
+  TSL_TRY(ds_upload_grow(d.blk_q, src_l, s));
   std::vector<DsFrontDesc> frl(P.level_sn.size());
   for (size_t i = 0; i < frl.size(); i++) frl[i] = P.fr[P.level_sn[i]];
   TSL_TRY(ds_upload_grow(d.frl, frl, s));

@@ -60,18 +60,18 @@ __global__ void k_ds_rownorm(int NV, const int* __restrict__ slice_off, const in
 // The matrix entries of ONE tree level go into the panels of its fronts when the level starts: the panels were just written -- cleared
 // (leaf level: the contiguous head of the panel arena) or stored by the gather of the children's Schur complements (k_ds_extend_panels)
 // --, so nothing above the leaves is ever cleared.  One launch per level, three thread ranges:
-//   * static pattern: block q = blk_q[i] of the CSR numbering lives at vals[csr2sell[q] + 64 e] (SELL-64, element e of the 3 x 3 block);
+//   * static pattern: block i of the level-ordered list lives at vals[src[i] + 64 e] (SELL-64, element e of the 3 x 3 block);
 //     every block has ONE destination: a plain add;
 //   * identity on the padding of the pivot blocks;
 //   * contact blocks (their own launch behind it, only on levels that have any): 16 vertex-pair sub-blocks per constraint, grouped by
 //     destination on the host.
-__global__ void k_ds_assemble_level(int i0, int nblk, const int* __restrict__ blk_q, const int* __restrict__ csr2sell, const double* __restrict__ vals,
-                                    const long long* __restrict__ blk_dst, const int* __restrict__ blk_ld, int lv0, int nf, const DsFrontDesc* __restrict__ frl, double* __restrict__ A) {
+__global__ void k_ds_assemble_level(int i0, int nblk, const int* __restrict__ src, const double* __restrict__ vals, const long long* __restrict__ dst, const int* __restrict__ dld,
+                                    int lv0, int nf, const DsFrontDesc* __restrict__ frl, double* __restrict__ A) {
   long t = (long)blockIdx.x * blockDim.x + threadIdx.x;
-  if (t < (long)nblk * 9) {
-    const int q = blk_q[i0 + t / 9];
+  if (t < (long)nblk * 9) {   // (src / dst / dld: the level-ordered block list of the plan, three independent loads per entry)
+    const long i = i0 + t / 9;
     const int e = (int)(t % 9);
-    A[blk_dst[q] + (long long)(e / 3) * blk_ld[q] + e % 3] += vals[(size_t)csr2sell[q] + 64 * e];   // one writer per entry
+    A[dst[i] + (long long)(e / 3) * dld[i] + e % 3] += vals[(size_t)src[i] + 64 * e];   // one writer per entry
     return;
   }
   t -= (long)nblk * 9;

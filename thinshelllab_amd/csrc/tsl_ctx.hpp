@@ -162,10 +162,11 @@ struct DirectSolver {
   std::vector<DsGrid> grids;
   std::vector<DsBlock> blocks;
   std::vector<int> row_ptr;   // CSR numbering of the static block pattern (rows of h_rows)
+  std::vector<int> h_c2s;     // SELL address of every CSR block
   std::vector<int> h_cons;    // constraint vertices the current plan's contact map was built for (engine order)
   std::vector<int> h_cset;    // the same constraints as a sorted set: what tree, fronts and static maps depend on
   bool plan_valid = false;
-  DevBuf<int> csr2sell, level_sn, pmap, vtx, blk_ld, bad, wl_front, wl_row, blk_q, cgr_ptr, cgr_ent, cgr_ld;
+  DevBuf<int> level_sn, pmap, vtx, blk_ld, bad, wl_front, wl_row, blk_q, cgr_ptr, cgr_ent, cgr_ld;
   DevBuf<long long> blk_dst, cgr_dst;
   DevBuf<DsFrontDesc> fr, frl;   // front descriptors by supernode id / in level order
   DevBuf<DsChildRec> ch_rec;
@@ -273,7 +274,7 @@ struct tsl_ctx {
   int vg_ns = 0, vg_hinge0 = 0, vg_tet0 = 0;
   DevBuf<double> dot_part; DevBuf<int> dot_ticket;   // scratch of the deterministic dot products
   DevBuf<double> e_part;                 // per-workgroup partial energies
-  int n_cgblk = 0, cloth_gather = 0;   // "cloth_gather" = 1: gather assembly of the cloth Hessian (deterministic; measured no faster than the class-ordered atomics: 268 against 270 us)
+  int n_cgblk = 0, n_cgblk_cloth = 0, cloth_gather = 0;   // gather lists: blocks of the cloth first, blocks of the FEM bodies behind them   // "cloth_gather" = 1: gather assembly of the cloth Hessian (deterministic; measured no faster than the class-ordered atomics: 268 against 270 us)
   DevBuf<double> tet_V;       // eigenvector bases of the clamped element blocks of the last assembly (81 x n_tet, entry-major): warm start of the next one
   long tet_V_count = 0;
   int tet_warm = 1;

@@ -292,10 +292,19 @@ extern "C" int tsl_ctx_create(const tsl_scene_desc* d, tsl_ctx** out) {
       for (int e = 0; e < 16; e++) tup.emplace_back(hgblk[(size_t)h * 16 + e], 0x80000000u | ((unsigned)h << 4) | (unsigned)e);
     for (int t = 0; t < c->n_tet; t++)   // the element blocks of the FEM bodies take the same road (bit 30)
       for (int e = 0; e < 16; e++) tup.emplace_back(tetblk[(size_t)t * 16 + e], 0x40000000u | ((unsigned)t << 4) | (unsigned)e);
-    std::sort(tup.begin(), tup.end());
+    // blocks of the cloth first, blocks of the FEM bodies behind them (a block belongs to one kind: the two gathers run on different streams)
+    auto is_tet = [](unsigned e) { return (e >> 30) == 1u; };
+    std::sort(tup.begin(), tup.end(), [&](const std::pair<int, unsigned>& x, const std::pair<int, unsigned>& y) {
+      if (is_tet(x.second) != is_tet(y.second)) return is_tet(y.second);
+      return x < y;
+    });
     cg_ent.reserve(tup.size());
+    c->n_cgblk_cloth = 0;
     for (size_t i = 0; i < tup.size(); i++) {
-      if (i == 0 || tup[i].first != tup[i - 1].first) { cg_base.push_back(tup[i].first); cg_ptr.push_back((int)i); }
+      if (i == 0 || tup[i].first != tup[i - 1].first || is_tet(tup[i].second) != is_tet(tup[i - 1].second)) {
+        cg_base.push_back(tup[i].first); cg_ptr.push_back((int)i);
+        if (!is_tet(tup[i].second)) c->n_cgblk_cloth++;
+      }
       cg_ent.push_back(tup[i].second);
     }
     cg_ptr.push_back((int)tup.size());
@@ -630,11 +639,10 @@ __global__ void __launch_bounds__(256) k_contact_row_gather(int NV, const int* _
   if (lane == 0) st3(F, v, ld3(F, v) + d3(a0, a1, a2));
 }
 
-static int assemble(tsl_ctx* c, const double* pos, const double* prev, const double* vel, const double* ref, int spd, double* grad) {
+// GPU work of one assembly (no host state, no allocation: assemble() below prepares both, so that the launches can be captured into a graph)
+static int assemble_enqueue(tsl_ctx* c, const double* pos, const double* prev, const double* vel, const double* ref, int spd, double* grad, int tet_warm_flag) {
   hipStream_t s = c->stream;
   const int NV = c->NV;
-  c->st_pos = pos; c->st_prev = prev; c->st_vel = vel; c->st_ref = ref;  // for forward_spd_pc (valid while tsl_step runs)
-  c->ds.numeric_valid = false; c->ds.anorm_valid = false;
   HIP_OK(hipMemsetAsync(c->vals_full.p, 0, c->vals_full.n * sizeof(double), s));
   if (c->n_cface) hipLaunchKernelGGL(k_cloth_normals, dim3(nblk(c->n_cface, 256)), dim3(256), 0, s, c->n_cface, pos, c->cf_f2v.p, c->norm_dir.p);
   ClothArgs CA = cloth_args(c);
@@ -642,8 +650,6 @@ static int assemble(tsl_ctx* c, const double* pos, const double* prev, const dou
   TetArgs TA = tet_args(c);
   const bool det = c->deterministic != 0;
   if (det) {   // element gradients into staging slots, element blocks into records: summed by k_vertex_gather / k_cloth_gather in a fixed order
-    if (c->vg_stage.n < 3 * (size_t)std::max(c->vg_ns, 1)) { if (c->vg_stage.alloc(3 * (size_t)std::max(c->vg_ns, 1))) return tsl_fail("out of device memory (gradient staging)"); }
-    if (c->n_tet > 0 && c->cg_trec.n < 144 * (size_t)c->n_tet) { if (c->cg_trec.alloc(144 * (size_t)c->n_tet)) return tsl_fail("out of device memory (element records)"); }
     CA.gstage = c->vg_stage.p; TA.gstage = c->vg_stage.p + 3 * (size_t)c->vg_tet0;
   }
   if (grad) HIP_OK(hipMemsetAsync(grad, 0, 3 * (size_t)NV * sizeof(double), s));
@@ -652,6 +658,7 @@ static int assemble(tsl_ctx* c, const double* pos, const double* prev, const dou
   // (face 0.15 ms + hinge 0.28 ms): they share nothing but the zeroed gradient / matrix, which both sides only add to.
   const bool fork = c->asm_overlap && (c->nc > 0 || c->n_tet > 0);
   if (grad) hipLaunchKernelGGL(k_vert_grad, dim3(nblk(NV, 256)), dim3(256), 0, s, VA, pos, prev, vel, grad);   // before the fork: it may store, the others add
+  hipLaunchKernelGGL(k_vert_hess, dim3(nblk(NV, 256)), dim3(256), 0, s, VA, c->diag_blk.p, c->vals_full.p);      // (the mass diagonal: the first contribution to its blocks)
   hipStream_t st = fork ? c->side : s;   // stream of the contact kernels
   const bool fork_t = fork && c->n_tet > 0 && c->nc > 0;   // the element kernels of the FEM bodies on a stream of their own (0.4 ms: one lane per element, latency-bound)
   hipStream_t stt = fork_t ? c->side2 : st;
@@ -666,35 +673,27 @@ static int assemble(tsl_ctx* c, const double* pos, const double* prev, const dou
     else {
       // eigen-clamp of the element blocks warm-started from the previous assembly's eigenvectors ("tet_warm", on by default);
       // every 16th clamped assembly starts from the identity again (orthogonality of the accumulated rotations)
-      double* vws = nullptr;
-      int warm = 0;
-      if (c->tet_warm && spd != 0) {
-        if (c->tet_V.n < (size_t)81 * c->n_tet) {
-          if (c->tet_V.alloc((size_t)81 * c->n_tet)) return tsl_fail("out of device memory (tet eigenvectors)");
-          HIP_OK(hipMemsetAsync(c->tet_V.p, 0, c->tet_V.n * sizeof(double), stt));   // "no basis yet" for every element (spd_clamp_warm checks the norm)
-          c->tet_V_count = 0;
-        }
-        vws = c->tet_V.p;
-        warm = (c->tet_V_count++ % 16) != 0;
-      }
+      double* vws = (c->tet_warm && spd != 0) ? c->tet_V.p : (double*)nullptr;   // (allocated and counted by assemble())
+      const int warm = vws ? tet_warm_flag : 0;
       hipLaunchKernelGGL(k_tet_hess, dim3(nblk(c->n_tet, 64)), dim3(64), 0, stt, TA, c->tet_blk.p, pos, spd, c->vals_full.p, vws, warm, det ? c->cg_trec.p : (double*)nullptr);
+      // the element records of the bodies -> their matrix blocks, on the element stream (the blocks of the bodies and of the cloth are disjoint)
+      const int nt_blk = c->n_cgblk - c->n_cgblk_cloth;
+      if (det && nt_blk > 0)
+        hipLaunchKernelGGL(k_cloth_gather, dim3(nblk(nt_blk, 256)), dim3(256), 0, stt, nt_blk, c->cg_base.p + c->n_cgblk_cloth, c->cg_ptr.p + c->n_cgblk_cloth, (const unsigned*)c->cg_ent.p,
+                           c->n_hinge, c->n_cface, (const double*)c->cg_hrec.p, (const double*)c->cg_frec.p, (const double*)c->cg_trec.p, c->vals_full.p);
     }
   }
   TSL_TRY(contact_assemble(c, pos, spd, grad, st));
-  // the cloth gradient kernels (0.11 ms) ride behind the contact kernels on the side stream: the cloth Hessian kernels on the engine
-  // stream are the longest chain of an assembly once the element blocks are warm-started
-  hipStream_t sg = fork ? st : s;
+  // the cloth gradient kernels ride behind the element kernels of the bodies (deterministic assembly: the contact chain -- blocks, mask,
+  // diagonal -- is the longest of the three streams; round 3 had them behind the contact kernels)
+  hipStream_t sg = det ? stt : (fork ? st : s);
   if (grad) {
     if (c->n_cface) hipLaunchKernelGGL(k_cloth_grad_face, dim3(nblk(c->n_cface, 256)), dim3(256), 0, sg, CA, pos, grad);
     if (c->n_hinge) hipLaunchKernelGGL(k_cloth_grad_hinge, dim3(nblk(c->n_hinge, 256)), dim3(256), 0, sg, CA, pos, ref, grad);
   }
   if (fork) HIP_OK(hipEventRecord(c->ev_join, c->side));
   if (fork_t) HIP_OK(hipEventRecord(c->ev_join2, c->side2));
-  hipLaunchKernelGGL(k_vert_hess, dim3(nblk(NV, 256)), dim3(256), 0, s, VA, c->diag_blk.p, c->vals_full.p);
   const bool gather = (c->cloth_gather || det) && c->n_cgblk > 0;
-  if (gather && c->n_cface > 0 && c->cg_frec.n == 0) {   // element records of the gather assembly, on first use
-    if (c->cg_hrec.alloc((size_t)std::max(c->n_hinge, 1) * 16) | c->cg_frec.alloc((size_t)c->n_cface * 81)) return tsl_fail("out of device memory (cloth element records)");
-  }
   if (c->n_cface) {
     const int nq = (int)c->h_cloth.size() * 9;
     hipLaunchKernelGGL(k_cloth_quirk, dim3(nblk(nq, 64)), dim3(64), 0, s, CA, (int)c->h_cloth.size(), pos, ref, c->quirk.p);
@@ -703,13 +702,13 @@ static int assemble(tsl_ctx* c, const double* pos, const double* prev, const dou
     else hipLaunchKernelGGL((k_cloth_hess_face<false>), dim3(nblk(c->n_cface, 128)), dim3(128), 0, s, CA, c->cf_blk.p, pos, ref, c->quirk.p, spd, c->vals_full.p, frec);
   }
   if (c->n_hinge) hipLaunchKernelGGL(k_cloth_hess_hinge, dim3(nblk(c->n_hinge, 256)), dim3(256), 0, s, CA, c->hg_blk.p, pos, c->vals_full.p, gather ? c->cg_hrec.p : (double*)nullptr);
-  // element records -> matrix blocks, one lane per block, no atomics (the element blocks of the FEM bodies and the mass diagonal touch other
-  // entries or were added before: k_vert_hess above runs on this stream)
+  // element records of the cloth -> its matrix blocks, one lane per block, no atomics, next to the other two streams (the mass diagonal was
+  // added before the fork)
+  if (gather && c->n_cgblk_cloth > 0)
+    hipLaunchKernelGGL(k_cloth_gather, dim3(nblk(c->n_cgblk_cloth, 256)), dim3(256), 0, s, c->n_cgblk_cloth, c->cg_base.p, c->cg_ptr.p, (const unsigned*)c->cg_ent.p, c->n_hinge, c->n_cface,
+                       (const double*)c->cg_hrec.p, (const double*)c->cg_frec.p, (const double*)c->cg_trec.p, c->vals_full.p);
   if (fork) HIP_OK(hipStreamWaitEvent(s, c->ev_join, 0));
   if (fork_t) HIP_OK(hipStreamWaitEvent(s, c->ev_join2, 0));
-  // (after the join: the tet records come from the element stream)
-  if (gather) hipLaunchKernelGGL(k_cloth_gather, dim3(nblk(c->n_cgblk, 256)), dim3(256), 0, s, c->n_cgblk, c->cg_base.p, c->cg_ptr.p, (const unsigned*)c->cg_ent.p, c->n_hinge, c->n_cface,
-                                 (const double*)c->cg_hrec.p, (const double*)c->cg_frec.p, (const double*)c->cg_trec.p, c->vals_full.p);
   if (det && grad) {
     hipLaunchKernelGGL(k_vertex_gather, dim3(nblk(NV, 256)), dim3(256), 0, s, NV, (const int*)c->vg_ptr.p, (const int*)c->vg_idx.p, (const double*)c->vg_stage.p, 0, c->vg_ns, grad);
     if (c->nc > 0) hipLaunchKernelGGL(k_contact_row_gather, dim3(nblk((long)NV * 64, 256)), dim3(256), 0, s, NV, (const int*)c->rowpos.p, (const int*)c->cr_ptr.p, (const int*)c->cr_ent.p,
@@ -721,11 +720,42 @@ static int assemble(tsl_ctx* c, const double* pos, const double* prev, const dou
   if (!c->pc_frozen) {
     hipLaunchKernelGGL(k_block_jacobi, dim3(nblk(NV, 256)), dim3(256), 0, s, NV, c->diag_perm.p, c->vals.p, c->nc > 0 ? c->c_diag.p : (const double*)nullptr, c->Dinv.p);
     if (body_active(c) && c->bd_valid) body_zero_dinv(c);  // those rows are served by the (lagged) dense inverse
-    c->mg_ops_valid = false;
-    c->pc_separate = false;
   }
   HIP_OK(hipGetLastError());
   return 0;
+}
+
+// One assembly: host state and lazy allocations, then the ~45 launches on three streams.  Measured and dropped (round 4): the launches as ONE
+// hipGraph launch keyed by the arguments (the 50 Newton iterations of a step call with the same ones) -- right after the host has read the
+// line search's energy the GPU has nothing queued and the assembly's kernels are shorter than the host needs to issue them (a kernel
+// trace shows the engine stream idle for 120 us in front of the first cloth kernel), but the replay of the three-stream graph is slower
+// than the launches: 269.2 against 263.4 ms per step on the driver's command.
+static int assemble(tsl_ctx* c, const double* pos, const double* prev, const double* vel, const double* ref, int spd, double* grad) {
+  hipStream_t s = c->stream;
+  const bool det = c->deterministic != 0;
+  // ---- allocations the launches rely on
+  if (det) {
+    if (c->vg_stage.n < 3 * (size_t)std::max(c->vg_ns, 1)) { if (c->vg_stage.alloc(3 * (size_t)std::max(c->vg_ns, 1))) return tsl_fail("out of device memory (gradient staging)"); }
+    if (c->n_tet > 0 && c->cg_trec.n < 144 * (size_t)c->n_tet) { if (c->cg_trec.alloc(144 * (size_t)c->n_tet)) return tsl_fail("out of device memory (element records)"); }
+    if (grad && c->nc > 0 && c->c_G.n < 12 * (size_t)c->max_n_constraints) { if (c->c_G.alloc(12 * (size_t)c->max_n_constraints)) return -1; }
+  }
+  if ((c->cloth_gather || det) && c->n_cgblk > 0 && c->n_cface > 0 && c->cg_frec.n == 0) {
+    if (c->cg_hrec.alloc((size_t)std::max(c->n_hinge, 1) * 16) | c->cg_frec.alloc((size_t)c->n_cface * 81)) return tsl_fail("out of device memory (cloth element records)");
+  }
+  int warm = 0;
+  if (c->n_tet > 0 && c->tet_warm && spd != 0 && !(c->tet_coop && !det)) {
+    if (c->tet_V.n < (size_t)81 * c->n_tet) {
+      if (c->tet_V.alloc((size_t)81 * c->n_tet)) return tsl_fail("out of device memory (tet eigenvectors)");
+      HIP_OK(hipMemsetAsync(c->tet_V.p, 0, c->tet_V.n * sizeof(double), s));   // "no basis yet" for every element (spd_clamp_warm checks the norm)
+      c->tet_V_count = 0;
+    }
+    warm = (c->tet_V_count++ % 16) != 0;   // every 16th clamped assembly starts from the identity again
+  }
+  // ---- host state
+  c->st_pos = pos; c->st_prev = prev; c->st_vel = vel; c->st_ref = ref;  // for forward_spd_pc (valid while tsl_step runs)
+  c->ds.numeric_valid = false; c->ds.anorm_valid = false;
+  if (!c->pc_frozen) { c->mg_ops_valid = false; c->pc_separate = false; }
+  return assemble_enqueue(c, pos, prev, vel, ref, spd, grad, warm);
 }
 
 extern "C" int tsl_assemble(tsl_ctx* c, const double* pos, const double* prev, const double* vel, const double* ref, int spd, double* grad) {
