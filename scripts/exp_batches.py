@@ -33,13 +33,15 @@ for b in range(nb):
         tf = r["flops_per_launch"] * r["launches"] / max(t, 1e-9) * 1e-6
         line += f"  {name} {t:8.1f} us ({r['launches']:3d} launches, {tf:5.1f} TF/s)"
         if cls == 1:
-            ctx.set_param("ds_dbg", 3)
-            r3 = ctx.bench_direct(cls, 10)
-            ctx.set_param("ds_dbg", 0)
-            line += f" [without extend-add {r3['us_per_launch'] * r3['launches']:7.1f} us]"
+            line += f" {r['bytes_per_launch'] * r['launches'] / max(t, 1e-9) * 1e-3:6.0f} GB/s"
+            for dbg, what in ((13, "no gather"), (12, "one K slab")):
+                ctx.set_param("ds_dbg", dbg)
+                r3 = ctx.bench_direct(cls, 10)
+                ctx.set_param("ds_dbg", 0)
+                line += f" [{what} {r3['us_per_launch'] * r3['launches']:7.1f} us]"
     print(line, flush=True)
 ctx.set_param("ds_bench_batch", -1)
-for dbg in (0, 2, 3):
+for dbg in (0, 12, 13, 0):
     ctx.set_param("ds_dbg", dbg)
     r = ctx.bench_direct(1, 10)
     print("schur total, ds_dbg", dbg, r["us_per_launch"] * r["launches"], "us")

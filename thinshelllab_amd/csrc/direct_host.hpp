@@ -47,6 +47,7 @@ static inline bool ds_use_small(const DsBatch& b) {
 
 // G = W F12 (mode 0) / S = sum_children ext(S_child) - F21 G, stored (mode 1) of a batch: 64 x 64 output tiles; "direct_g32_below": G of a
 // batch with few 64 x 64 tiles (upper levels) in 32 x 32 tiles, four times the workgroups
+static int ds_xcd_map = 64;   // "direct_xcd": batches of at least this many fronts launch their GEMM tiles with the XCD-aware map (k_ds_gemm_x: a front per XCD); 0: never
 static void ds_launch_gemm(hipStream_t s, const DsDev& D, const DsBatch& b, int mode, int wpc, int ds_g32_below = 0) {
   const int rows = mode == 0 ? b.max_pp : b.max_bp, cols = b.max_bp;
   const dim3 grid((cols + 63) / 64, (rows + 63) / 64, b.count);
@@ -54,6 +55,13 @@ static void ds_launch_gemm(hipStream_t s, const DsDev& D, const DsBatch& b, int 
   if (ds_g32_below > 0 && tiles < ds_g32_below) {
     if (mode == 0) hipLaunchKernelGGL(k_ds_gemm_g32, dim3((cols + 31) / 32, (rows + 31) / 32, b.count), dim3(256), 0, s, D, b.first);
     else hipLaunchKernelGGL(k_ds_gemm_s32, dim3((cols + 31) / 32, (rows + 31) / 32, b.count), dim3(256), 0, s, D, b.first);
+    return;
+  }
+  if (ds_xcd_map > 0 && wpc >= 4 && b.count >= ds_xcd_map) {
+    const int gx = grid.x, gy = grid.y, nf = b.count;
+    const long ng = ((long)nf + 7) / 8 * 8 * gx * gy;
+    if (mode == 0) hipLaunchKernelGGL((k_ds_gemm_x<0, 4>), dim3((unsigned)ng), dim3(256), 0, s, D, b.first, gx, gy, nf);
+    else hipLaunchKernelGGL((k_ds_gemm_x<1, 4>), dim3((unsigned)ng), dim3(256), 0, s, D, b.first, gx, gy, nf);
     return;
   }
   if (mode == 0) {
@@ -322,6 +330,7 @@ static int direct_plan(tsl_ctx* c) {
   if (c->verbose >= 2)
     fprintf(stderr, "[tsl] direct plan: %d supernodes, %d levels, %zu batches, %.2f + %.2f GB of panels + Schur complements, %.1f GFLOP per factorisation, nc %d; host %.2f ms (tree + maps %.2f)\n", P.sym.n_sn, P.n_levels, P.batches.size(), P.arena * 8e-9, P.sarena * 8e-9,
             P.flops * 1e-9, c->nc, 1e3 * std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count(), 1e3 * std::chrono::duration<double>(t_build - t0).count());
+  if (c->verbose >= 2) fprintf(stderr, "[tsl]   plan phases (ms): tree %.2f, descriptors + parent maps %.2f, levels %.2f, static block map %.2f, contact map %.2f\n", P.phase_ms[0], P.phase_ms[1], P.phase_ms[2], P.phase_ms[3], P.phase_ms[4]);
   if (c->verbose >= 3)
     for (const DsBatch& b : P.batches) fprintf(stderr, "[tsl]   level %2d: %5d fronts, pivots <= %4d, boundary <= %4d%s\n", b.level, b.count, b.max_pp, b.max_bp, ds_use_small(b) ? " (LDS kernel)" : "");
   return 0;

@@ -328,7 +328,9 @@ struct DirectPlan {
     level_maxld.assign(L, 0);
     for (int l = 0; l < L; l++) for (int q = level_ptr[l]; q < level_ptr[l + 1]; q++) level_maxld[l] = std::max(level_maxld[l], fr[level_sn[q]].ld);
     lap(3);
-    return build_con(cons, n_cons);
+    const int rc = build_con(cons, n_cons);
+    lap(4);
+    return rc;
   }
 
   // destination of the 16 vertex-pair sub-blocks of every contact block, in the ORDER of `cons` (the engine appends constraints in

@@ -928,7 +928,9 @@ __global__ void __launch_bounds__(256) k_ds_inv_small(DsDev D, int lv0, int ls) 
 // WPC = workgroups per CU the register allocation aims at (one wave of each per SIMD): 4 by default ("direct_gemm_wpc"; 2 = two LDS
 // slab buffers with one barrier per slab, measured slower: what four workgroups hide is each other's prologues and epilogues).
 // Measured and dropped (round 2 / 3, cfg4 plan, per-batch replays; profiles/README.md): K slabs of 64, an XCD-aware workgroup -> tile
-// map, a capped persistent grid walking the tiles, skipping the products of quadrants outside the front, 128 x 128 tiles.
+// map (round 4: kept for the batches of many fronts, k_ds_gemm_x below), a capped persistent grid walking the tiles, skipping the products of
+// quadrants outside the front, 128 x 128 tiles; round 4: wave priorities (s_setprio) that differ between the workgroups sharing a CU, to
+// stagger their K loops and epilogues -- no change (976-1004 us for the Schur launches of a factorisation under four priority patterns).
 #define DS_SK 32
 #define DS_GMC 8   // children of a front whose tables the Schur epilogue keeps in LDS per pass
 template <int mode, int WPC>
@@ -1311,6 +1313,23 @@ __global__ void __launch_bounds__(256) k_ds_gemm_s32(DsDev D, int lv0) {
 template <int mode, int WPC>
 __global__ void __launch_bounds__(256, WPC) k_ds_gemm(DsDev D, int lv0) {
   ds_gemm_tile<mode, WPC>(D, lv0, blockIdx.x, blockIdx.y, blockIdx.z);
+}
+
+// The same tiles launched as a one-dimensional grid with an XCD-aware map ("direct_xcd", batches of at least that many fronts; default 64):
+// the hardware hands consecutive workgroups to the eight XCDs in turn, each with an L2 of its own, so with blockIdx = (tile column, tile
+// row, front) the tiles of one front -- which share its F21 / G (or W / F12) panels -- are spread over all eight L2s and every panel is
+// fetched from memory up to eight times.  Here workgroup L is taken as the (L / 8)-th of XCD L % 8 and a whole front belongs to one XCD;
+// fronts are dealt to the XCDs in turn (they are sorted by size: every XCD gets every eighth).  Affinity only -- nothing depends on where
+// a workgroup runs.  Measured on cfg4 (scripts/pmc_gemm.sh, exp_batches.py): FETCH_SIZE of the batches it applies to falls 3x (Schur) and
+// 2.3x (G) at equal time (+-3 %).  Batches of 2 .. 32 unequal fronts lose time under any such map -- a front per XCD is unbalanced, every
+// front split 2 x 4 over the XCDs (an equal share of every front each) is 10-35 % slower than dealing single tiles -- and keep blockIdx order.
+template <int mode, int WPC>
+__global__ void __launch_bounds__(256, WPC) k_ds_gemm_x(DsDev D, int lv0, int gx, int gy, int nf) {
+  const unsigned L = blockIdx.x, xcd = L & 7, k = L >> 3;
+  const unsigned tpf = (unsigned)gx * gy;
+  const unsigned bz = (k / tpf) * 8 + xcd, t = k % tpf;
+  if (bz >= (unsigned)nf) return;
+  ds_gemm_tile<mode, WPC>(D, lv0, t % gx, t / gx, bz);
 }
 
 // ---- solve ----------------------------------------------------------------------------------------------------------------
