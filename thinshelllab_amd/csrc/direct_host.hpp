@@ -33,7 +33,6 @@ static void ds_forget(const void* ctx) {
 
 static inline int ds_nblk(long n, int b) { return (int)((n + b - 1) / b); }
 
-static inline size_t ds_small_lds(int max_pp) { return (size_t)max_pp * (max_pp + 1) * sizeof(double); }   // the block alone: the pivot tile is inverted in place
 // a batch goes to the LDS kernel (all block steps in one launch, one workgroup per front) when its fronts fit the chip in
 // `ds_small_rounds` rounds (workgroups per CU by LDS: 4.5 KB of static arrays of the tile inversion on top of the block -- two at 96
 // pivots, one at 128); a larger batch has enough tile parallelism for the block-step kernel (round 2: 1024 fronts of 96 pivots 322 us
@@ -41,8 +40,7 @@ static inline size_t ds_small_lds(int max_pp) { return (size_t)max_pp * (max_pp 
 static int ds_small_rounds = 2;   // "direct_small_rounds": 847 leaf fronts of 96 pivots 139.5 us in two rounds of the LDS kernel against 204 us on the block-step path (5 launches)
 static inline bool ds_use_small(const DsBatch& b) {
   if (b.max_pp > DS_SMALL) return false;
-  const size_t per_cu = std::min<size_t>(8, (160 * 1024) / (ds_small_lds(b.max_pp) + 5 * 1024));
-  return (size_t)b.count <= 256 * std::max<size_t>(per_cu, 1) * (size_t)ds_small_rounds;
+  return (size_t)b.count <= (size_t)256 * ds_small_per_cu(b.max_pp) * (size_t)ds_small_rounds;
 }
 
 // G = W F12 (mode 0) / S = sum_children ext(S_child) - F21 G, stored (mode 1) of a batch: 64 x 64 output tiles; "direct_g32_below": G of a
@@ -93,25 +91,32 @@ static void ds_launch_level_start(tsl_ctx* c, hipStream_t s, const DsDev& D, int
 }
 
 
-// "direct_flow": the block steps of a batch as ONE persistent dataflow launch (k_ds_gj_flow) -- for a batch that is alone on its level
-// (no second persistent grid next to it), of at most DS_FLOW_MAXF fronts, whose tiles are all resident at once.  Fills the launch
+// "direct_flow": the block steps of a batch as ONE persistent dataflow launch (k_ds_gj_flow) -- for ONE batch of a level (no second
+// persistent grid next to it; ordinary launches of sibling batches end by themselves), of at most DS_FLOW_MAXF fronts, whose tiles are all resident at once.  Fills the launch
 // arguments and grows the exchange buffers; false = the batch stays on the launch-per-block-step path.
-static int ds_flow_prepare(DirectSolver& d, const DirectPlan& P, const DsBatch& b, bool alone, DsFlowArgs& a, hipStream_t s) {   // -> workgroups per CU of the instantiation to launch (4 / 5), 0 = not on this path
-  if (!d.flow || !alone || b.count > DS_FLOW_MAXF || b.max_pp < 2 * DS_T) return 0;
-  if (d.shared_device) return 0;   // another context of this process is working on the device (direct_factor)
+// could this batch take the dataflow path (no side effects: direct_bench asks for the earlier batches of a level)?
+static bool ds_flow_eligible(DirectSolver& d, const DirectPlan& P, const DsBatch& b, hipStream_t s) {
+  if (!d.flow || b.count > DS_FLOW_MAXF || b.max_pp < 2 * DS_T) return false;
+  if (d.shared_device) return false;   // another context of this process is working on the device (direct_factor)
   { hipStreamCaptureStatus cs = hipStreamCaptureStatusNone;   // a captured launch would be replayed with ONE epoch: flags of the previous replay would pass
-    if (hipStreamIsCapturing(s, &cs) != hipSuccess || cs != hipStreamCaptureStatusNone) return 0; }
-  if (ds_use_small(b) && !(d.flow & 2)) return 0;   // bit 1: also the batches the LDS kernel would take (64 / 32 fronts of <= 128 pivots on levels 3 and 4 of cfg4)
+    if (hipStreamIsCapturing(s, &cs) != hipSuccess || cs != hipStreamCaptureStatusNone) return false; }
+  if (ds_use_small(b) && !(d.flow & 2)) return false;   // bit 1: also the batches the LDS kernel would take (64 / 32 fronts of <= 128 pivots on levels 3 and 4 of cfg4)
   if (d.flow_cap[0] == 0) {
     int occ4 = 0, occ5 = 0, dev = 0;
     hipDeviceProp_t prop;
     if (hipGetDevice(&dev) != hipSuccess || hipGetDeviceProperties(&prop, dev) != hipSuccess ||
         hipOccupancyMaxActiveBlocksPerMultiprocessor(&occ4, (const void*)k_ds_gj_flow<4>, 256, 0) != hipSuccess ||
-        hipOccupancyMaxActiveBlocksPerMultiprocessor(&occ5, (const void*)k_ds_gj_flow<5>, 256, 0) != hipSuccess) { d.flow_cap[0] = d.flow_cap[1] = -1; return 0; }
+        hipOccupancyMaxActiveBlocksPerMultiprocessor(&occ5, (const void*)k_ds_gj_flow<5>, 256, 0) != hipSuccess) { d.flow_cap[0] = d.flow_cap[1] = -1; return false; }
     d.flow_cap[0] = std::max(1, occ4 * prop.multiProcessorCount);
     d.flow_cap[1] = std::max(1, occ5 * prop.multiProcessorCount);
     if (getenv("TSL_FLOW_DEBUG")) fprintf(stderr, "[tsl] k_ds_gj_flow: %d / %d workgroups per CU x %d CUs resident\n", occ4, occ5, prop.multiProcessorCount);
   }
+  long tiles = 0;
+  for (int z = 0; z < b.count; z++) { const long nt = P.fr[P.level_sn[b.first + z]].pp / DS_T; tiles += nt * nt; }
+  return tiles <= d.flow_cap[1] && tiles >= 4;
+}
+static int ds_flow_prepare(DirectSolver& d, const DirectPlan& P, const DsBatch& b, bool flow_free, DsFlowArgs& a, hipStream_t s) {   // -> workgroups per CU of the instantiation to launch (4 / 5), 0 = not on this path
+  if (!flow_free || !ds_flow_eligible(d, P, b, s)) return 0;
   long tiles = 0, x = 0, fl = 0;
   for (int z = 0; z < b.count; z++) {
     const long nt = P.fr[P.level_sn[b.first + z]].pp / DS_T;
@@ -280,7 +285,7 @@ static int direct_plan(tsl_ctx* c) {
       if (!dst && (int)d.cache.size() < d.cache_cap) {
         d.cache.emplace_back(new DsPlanSlot());
         dst = d.cache.back().get();
-        dst->plan.sym.copy_partition(d.plan.sym); dst->plan.tpos = d.plan.tpos; dst->plan.threads = d.plan.threads;   // the static part a build starts from
+        dst->plan.sym.copy_partition(d.plan.sym); dst->plan.tpos = d.plan.tpos; dst->plan.threads = d.plan.threads; dst->plan.n_cu = d.plan.n_cu; dst->plan.split_small = d.plan.split_small; dst->plan.split_rem = d.plan.split_rem;   // the static part a build starts from
       }
       if (!dst) { for (auto& sl : d.cache) if (!dst || sl->stamp < dst->stamp) dst = sl.get(); }
       ds_swap_slot(d, *dst);
@@ -332,7 +337,14 @@ static int direct_plan(tsl_ctx* c) {
             P.flops * 1e-9, c->nc, 1e3 * std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count(), 1e3 * std::chrono::duration<double>(t_build - t0).count());
   if (c->verbose >= 2) fprintf(stderr, "[tsl]   plan phases (ms): tree %.2f, descriptors + parent maps %.2f, levels %.2f, static block map %.2f, contact map %.2f\n", P.phase_ms[0], P.phase_ms[1], P.phase_ms[2], P.phase_ms[3], P.phase_ms[4]);
   if (c->verbose >= 3)
-    for (const DsBatch& b : P.batches) fprintf(stderr, "[tsl]   level %2d: %5d fronts, pivots <= %4d, boundary <= %4d%s\n", b.level, b.count, b.max_pp, b.max_bp, ds_use_small(b) ? " (LDS kernel)" : "");
+    for (const DsBatch& b : P.batches) {
+      fprintf(stderr, "[tsl]   level %2d: %5d fronts, pivots <= %4d, boundary <= %4d%s; fronts by padded pivot count:", b.level, b.count, b.max_pp, b.max_bp, ds_use_small(b) ? " (LDS kernel)" : "");
+      for (int q = 0, run = 0; q < b.count; q++) {   // (sorted by pp, descending)
+        run++;
+        if (q + 1 == b.count || P.fr[P.level_sn[b.first + q + 1]].pp != P.fr[P.level_sn[b.first + q]].pp) { fprintf(stderr, " %d x %d", run, P.fr[P.level_sn[b.first + q]].pp); run = 0; }
+      }
+      fprintf(stderr, "\n");
+    }
   return 0;
 }
 
@@ -387,11 +399,12 @@ static int direct_factor(tsl_ctx* c, int stop_sn = -1, const char* dump_path = n
     if (d.prezero_n < (size_t)P.arena_leaf) HIP_OK(hipMemsetAsync(d.arena.p + d.prezero_n, 0, ((size_t)P.arena_leaf - d.prezero_n) * sizeof(double), s));   // a new plan with more leaf panels
   } else HIP_OK(hipMemsetAsync(d.arena.p, 0, (size_t)P.arena_leaf * sizeof(double), s));
   HIP_OK(hipMemsetAsync(d.bad.p, 0, 8 * sizeof(int), s));
-  auto run_batch = [&](const DsBatch& b, hipStream_t bs, bool alone) {
+  // (a persistent dataflow launch runs next to ordinary launches of sibling batches -- those end by themselves --, never next to a second one)
+  auto run_batch = [&](const DsBatch& b, hipStream_t bs, bool& flow_free) {
     const int lv0 = b.first, nf = b.count;
     const int tp = b.max_pp / DS_T, tb = b.max_bp / DS_T;
     DsFlowArgs fa;
-    if (const int wpc = ds_flow_prepare(d, P, b, alone, fa, bs)) { ds_flow_launch(bs, D, lv0, fa, wpc, d); d.n_flow++; }
+    if (const int wpc = ds_flow_prepare(d, P, b, flow_free, fa, bs)) { ds_flow_launch(bs, D, lv0, fa, wpc, d); d.n_flow++; flow_free = false; }
     else if (ds_use_small(b)) hipLaunchKernelGGL(k_ds_inv_small, dim3(nf), dim3(256), ds_small_lds(b.max_pp), bs, D, lv0, b.max_pp + 1);
     else {
       hipLaunchKernelGGL(k_ds_pivot0, dim3(nf), dim3(256), 0, bs, D, lv0);
@@ -435,9 +448,10 @@ static int direct_factor(tsl_ctx* c, int stop_sn = -1, const char* dump_path = n
       HIP_OK(hipEventRecord(d.ev_ffork, s));
       for (int k = 0; k < nside; k++) HIP_OK(hipStreamWaitEvent(d.fstream[k], d.ev_ffork, 0));
     }
+    bool flow_free = true;
     for (size_t q = bi; q < be; q++) {
       const int k = (int)(q - bi);   // batch 0 of the level (the largest pivot blocks: the longest chain of block steps) stays on the engine stream
-      run_batch(P.batches[q], (nside > 0 && k > 0) ? d.fstream[(k - 1) % nside] : s, be - bi == 1);
+      run_batch(P.batches[q], (nside > 0 && k > 0) ? d.fstream[(k - 1) % nside] : s, flow_free);
     }
     for (int k = 0; k < nside; k++) { HIP_OK(hipEventRecord(d.ev_fjoin[k], d.fstream[k])); HIP_OK(hipStreamWaitEvent(s, d.ev_fjoin[k], 0)); }
     bi = be;
@@ -548,10 +562,10 @@ static int direct_bench(tsl_ctx* c, int cls, int reps, double* out) {
           }
         }
       } else if (cls == 0 || cls == 3 || cls == 5) {   // W = F11^-1: cls 0 the batches on the block-step path (pivot0 + block steps + finish), cls 3 the batches in the LDS kernel, cls 5 those in the dataflow kernel
-        bool alone = true;
-        for (size_t q = 0; q < P.batches.size(); q++) alone &= ((int)q == bi || P.batches[q].level != b.level);
+        bool flow_free = true;   // (one dataflow launch per level: the first batch of the level that can take it)
+        for (int q = 0; q < bi; q++) if (P.batches[q].level == b.level && ds_flow_eligible(d, P, P.batches[q], s)) flow_free = false;
         DsFlowArgs fa;
-        const int flow = ds_flow_prepare(d, P, b, alone, fa, s);
+        const int flow = ds_flow_prepare(d, P, b, flow_free, fa, s);
         const int mine = flow ? 5 : (ds_use_small(b) ? 3 : 0);   // the class direct_factor runs this batch in
         if (mine != cls) continue;
         if (cls == 5) { ds_flow_launch(s, D, lv0, fa, flow, d); if (count) launches++; }

@@ -19,6 +19,10 @@
 #include "direct_sym.hpp"
 
 #define DS_T 32  // tile edge of the dense kernels; p and b are padded to multiples of it
+#define DS_SMALL 128   // fronts of at most this many (padded) pivots can be inverted by ONE workgroup with the pivot block in LDS (k_ds_inv_small)
+// workgroups of k_ds_inv_small a CU holds: the block (row stride max_pp + 1) + 4.5 KB of static arrays, 160 KB of LDS -- two at 96 pivots, one at 128
+static inline size_t ds_small_lds(int max_pp) { return (size_t)max_pp * (max_pp + 1) * sizeof(double); }   // the block alone: the pivot tile is inverted in place
+static inline int ds_small_per_cu(int max_pp) { return (int)std::max<size_t>(1, std::min<size_t>(8, (160 * 1024) / (ds_small_lds(max_pp) + 5 * 1024))); }
 
 struct DsFrontDesc {
   long long off;             // top rows [F11 | F12] in the panel arena (doubles)
@@ -105,6 +109,8 @@ struct DirectPlan {
   std::vector<int> tpos;                 // static: index of the mirrored block of every pattern block
   std::vector<std::vector<int>> locs;    // per host thread: vertex -> local dof of the front being scattered (-1 outside)
   int threads = 0;                       // host threads of the map construction (0: min(8, hardware))
+  int n_cu = 256;                        // compute units of the device (rounds of the LDS kernel)
+  bool split_small = true, split_rem = true;   // batch rules of round 4 ("direct_split": bit 0 / bit 1)
   int n_threads() const { return threads > 0 ? threads : (int)std::max(1u, std::min(8u, std::thread::hardware_concurrency())); }
   double flops = 0;
 
@@ -231,7 +237,10 @@ struct DirectPlan {
       for (size_t i = 0; i < fl.size(); i++) {
         const int s = fl[i];
         DsFrontDesc& f = fr[s];
-        if (i == 0 || 4 * f.pp <= batches.back().max_pp || (fl.size() > 256 && batches.back().count >= 32 && f.pp < fr[fl[i - 1]].pp)) {
+        // (round 4) ... and where fronts that fit the LDS kernel, of at most half the batch's largest pivot block, follow fronts that do not
+        // (cfg4 level 2: 2 x 224, 2 x 192 and 128 x 64 pivots -- the 128 small ones went through the seven block steps of the four large ones)
+        if (i == 0 || 4 * f.pp <= batches.back().max_pp || (fl.size() > 256 && batches.back().count >= 32 && f.pp < fr[fl[i - 1]].pp) ||
+            (split_small && batches.back().max_pp > DS_SMALL && f.pp <= DS_SMALL && 2 * f.pp <= batches.back().max_pp)) {
           DsBatch b{};
           b.first = (int)level_sn.size(); b.count = 0; b.level = l;
           batches.push_back(b);
@@ -243,6 +252,24 @@ struct DirectPlan {
         f.scr_off = (int)scr;
         scr += 2LL * DS_T * DS_T + 4LL * DS_T * f.pp;  // pivot-block inverses, row and column side panels (ping-pong each)
       }
+      // (round 4) a batch of the LDS kernel that needs one more round of the chip for a few fronts hands them to a batch of their own, which
+      // takes another path next to it (cfg4 level 1: 261 fronts of 128 pivots, one workgroup per CU -- 256 in the first round, 5 in a second
+      // one that took as long)
+      if (split_rem)
+        for (size_t q = 0; q < batches.size(); q++) {
+          DsBatch& b = batches[q];
+          if (b.level != l || b.max_pp > DS_SMALL) continue;
+          const int cap = n_cu * ds_small_per_cu(b.max_pp), rem = b.count % cap;
+          if (b.count <= cap || rem == 0 || rem > cap / 8) continue;
+          DsBatch r{};
+          r.first = b.first + b.count - rem; r.count = rem; r.level = l;
+          b.count -= rem;
+          for (int z = 0; z < r.count; z++) { const DsFrontDesc& f = fr[level_sn[r.first + z]]; r.max_pp = std::max(r.max_pp, f.pp); r.max_ld = std::max(r.max_ld, f.ld); r.max_bp = std::max(r.max_bp, f.bp); }
+          b.max_ld = 0; b.max_bp = 0;
+          for (int z = 0; z < b.count; z++) { const DsFrontDesc& f = fr[level_sn[b.first + z]]; b.max_ld = std::max(b.max_ld, f.ld); b.max_bp = std::max(b.max_bp, f.bp); }
+          batches.insert(batches.begin() + q + 1, r);
+          q++;
+        }
       level_ptr[l + 1] = (int)level_sn.size();
       scratch = std::max(scratch, scr);
       wl_own_ptr[l] = (int)wl_front.size();

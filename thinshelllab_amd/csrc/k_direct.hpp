@@ -834,7 +834,6 @@ __global__ void __launch_bounds__(256, WPC) k_ds_gj_flow(DsDev D, int lv0, DsFlo
 // W = F11^-1 of a front with at most DS_SMALL pivots by ONE workgroup with the block in LDS (row stride ls = batch maximum + 1):
 // the same blocked Gauss-Jordan, all block steps inside the launch -- the workgroup inverts the pivot tile where it lies, every wave
 // owns row chunks of the rank-T update on the matrix cores (its column-panel fragment lives in registers while the chunk is rewritten).
-#define DS_SMALL 128
 __global__ void __launch_bounds__(256) k_ds_inv_small(DsDev D, int lv0, int ls) {
   extern __shared__ double ds_sm[];
   double* M = ds_sm;   // the block, row stride ls; the pivot tile of a step is inverted IN PLACE (no copy: at 96 pivots the block alone is 74.5 KB and

@@ -456,6 +456,7 @@ extern "C" int tsl_set_param(tsl_ctx* c, const char* key, double v) {
   else if (k == "direct_par_batches") c->ds.par_batches = (int)v;
   else if (k == "direct_gemm_wpc") c->ds.gemm_wpc = (int)v;
   else if (k == "direct_xcd") ds_xcd_map = (int)v;
+  else if (k == "direct_split") { c->ds.plan.split_small = ((int)v & 1) != 0; c->ds.plan.split_rem = ((int)v & 2) != 0; c->ds.plan_valid = false; c->ds.numeric_valid = false; c->ds.cache.clear(); }
   else if (k == "direct_merge_sep") { c->ds.plan.sym.merge_sep = (int)v; c->ds.static_ready = false; c->ds.plan_valid = false; c->ds.numeric_valid = false; }
   else if (k == "direct_merge_k") { c->ds.plan.sym.merge_k = v != 0; c->ds.plan_valid = false; c->ds.numeric_valid = false; c->ds.cache.clear(); }
   else if (k == "direct_piv_tol") { c->ds.piv_tol = v; c->ds.numeric_valid = false; }
