@@ -300,7 +300,8 @@ struct tsl_ctx {
   SolverScalars* h_scal2 = nullptr; // pinned, two records: read-back slots of the PCG chunks in flight
   hipEvent_t rb_event[2] = {nullptr, nullptr};
   hipStream_t side = 0;                         // second stream: contact blocks of an assembly run next to the cloth / tet kernels
-  hipEvent_t ev_fork = nullptr, ev_join = nullptr, ev_join2 = nullptr;
+  int asm_early = 1;   // "asm_early": issue order of the deterministic assembly with bodies / contacts (assemble_enqueue_early); 0: the order of the other modes
+  hipEvent_t ev_fork = nullptr, ev_fork0 = nullptr, ev_g2 = nullptr, ev_join = nullptr, ev_join2 = nullptr;
   hipStream_t side2 = 0;                        // third stream: the tet kernels next to the contact kernels (side) and the cloth kernels
   int asm_overlap = 1;
   int contact_coop = 1;  // 16 lanes per constraint in the contact block assembly (0: one lane per constraint)

@@ -366,7 +366,7 @@ extern "C" int tsl_ctx_create(const tsl_scene_desc* d, tsl_ctx** out) {
   for (int i = 0; i < 2; i++)
     if (hipEventCreateWithFlags(&c->rb_event[i], hipEventDisableTiming) != hipSuccess) { delete c; return tsl_fail("hipEventCreate failed"); }
   if (hipStreamCreateWithFlags(&c->side, hipStreamNonBlocking) != hipSuccess || hipStreamCreateWithFlags(&c->side2, hipStreamNonBlocking) != hipSuccess ||
-      hipEventCreateWithFlags(&c->ev_join2, hipEventDisableTiming) != hipSuccess || hipEventCreateWithFlags(&c->ev_fork, hipEventDisableTiming) != hipSuccess ||
+      hipEventCreateWithFlags(&c->ev_join2, hipEventDisableTiming) != hipSuccess || hipEventCreateWithFlags(&c->ev_fork, hipEventDisableTiming) != hipSuccess || hipEventCreateWithFlags(&c->ev_fork0, hipEventDisableTiming) != hipSuccess || hipEventCreateWithFlags(&c->ev_g2, hipEventDisableTiming) != hipSuccess ||
       hipEventCreateWithFlags(&c->ev_join, hipEventDisableTiming) != hipSuccess) { delete c; return tsl_fail("side stream / event creation failed"); }
   c->vals.zero(); c->vals_full.zero(); c->scal.zero(); c->part_rz.zero(); c->part_rr.zero();
 
@@ -400,6 +400,8 @@ extern "C" void tsl_ctx_destroy(tsl_ctx* c) {
   if (c->h_ir) (void)hipHostFree(c->h_ir);
   if (c->ds.zstream) { (void)hipStreamSynchronize(c->ds.zstream); (void)hipEventDestroy(c->ds.ev_zfork); (void)hipEventDestroy(c->ds.ev_zero); (void)hipStreamDestroy(c->ds.zstream); }
   if (c->ev_fork) (void)hipEventDestroy(c->ev_fork);
+  if (c->ev_fork0) (void)hipEventDestroy(c->ev_fork0);
+  if (c->ev_g2) (void)hipEventDestroy(c->ev_g2);
   if (c->ev_join) (void)hipEventDestroy(c->ev_join);
   if (c->side) (void)hipStreamDestroy(c->side);
   if (c->ev_join2) (void)hipEventDestroy(c->ev_join2);
@@ -456,6 +458,7 @@ extern "C" int tsl_set_param(tsl_ctx* c, const char* key, double v) {
   else if (k == "direct_par_batches") c->ds.par_batches = (int)v;
   else if (k == "direct_gemm_wpc") c->ds.gemm_wpc = (int)v;
   else if (k == "direct_xcd") ds_xcd_map = (int)v;
+  else if (k == "asm_early") c->asm_early = (int)v;
   else if (k == "direct_split") { c->ds.plan.split_small = ((int)v & 1) != 0; c->ds.plan.split_rem = ((int)v & 2) != 0; c->ds.plan_valid = false; c->ds.numeric_valid = false; c->ds.cache.clear(); }
   else if (k == "direct_merge_sep") { c->ds.plan.sym.merge_sep = (int)v; c->ds.static_ready = false; c->ds.plan_valid = false; c->ds.numeric_valid = false; }
   else if (k == "direct_merge_k") { c->ds.plan.sym.merge_k = v != 0; c->ds.plan_valid = false; c->ds.numeric_valid = false; c->ds.cache.clear(); }
@@ -642,15 +645,18 @@ __global__ void __launch_bounds__(256) k_contact_row_gather(int NV, const int* _
 }
 
 // GPU work of one assembly (no host state, no allocation: assemble() below prepares both, so that the launches can be captured into a graph)
+static int assemble_enqueue_early(tsl_ctx* c, const double* pos, const double* prev, const double* vel, const double* ref, int spd, double* grad, int tet_warm_flag);
 static int assemble_enqueue(tsl_ctx* c, const double* pos, const double* prev, const double* vel, const double* ref, int spd, double* grad, int tet_warm_flag) {
   hipStream_t s = c->stream;
   const int NV = c->NV;
+  const bool det = c->deterministic != 0;
+  const bool fork = c->asm_overlap && (c->nc > 0 || c->n_tet > 0);
+  if (det && fork && c->asm_early) return assemble_enqueue_early(c, pos, prev, vel, ref, spd, grad, tet_warm_flag);
   HIP_OK(hipMemsetAsync(c->vals_full.p, 0, c->vals_full.n * sizeof(double), s));
   if (c->n_cface) hipLaunchKernelGGL(k_cloth_normals, dim3(nblk(c->n_cface, 256)), dim3(256), 0, s, c->n_cface, pos, c->cf_f2v.p, c->norm_dir.p);
   ClothArgs CA = cloth_args(c);
   const VertArgs VA = vert_args(c);
   TetArgs TA = tet_args(c);
-  const bool det = c->deterministic != 0;
   if (det) {   // element gradients into staging slots, element blocks into records: summed by k_vertex_gather / k_cloth_gather in a fixed order
     CA.gstage = c->vg_stage.p; TA.gstage = c->vg_stage.p + 3 * (size_t)c->vg_tet0;
   }
@@ -658,7 +664,6 @@ static int assemble_enqueue(tsl_ctx* c, const double* pos, const double* prev, c
   // contact: gradient into grad (atomics), per-constraint 12x12 into c_Hfull, masked copy + diagonal into c_H / cdiag.  The contact
   // launches (0.15 + 0.11 ms at 200 constraints) and the tet kernels (0.23 ms) go to a second stream next to the cloth kernels
   // (face 0.15 ms + hinge 0.28 ms): they share nothing but the zeroed gradient / matrix, which both sides only add to.
-  const bool fork = c->asm_overlap && (c->nc > 0 || c->n_tet > 0);
   if (grad) hipLaunchKernelGGL(k_vert_grad, dim3(nblk(NV, 256)), dim3(256), 0, s, VA, pos, prev, vel, grad);   // before the fork: it may store, the others add
   hipLaunchKernelGGL(k_vert_hess, dim3(nblk(NV, 256)), dim3(256), 0, s, VA, c->diag_blk.p, c->vals_full.p);      // (the mass diagonal: the first contribution to its blocks)
   hipStream_t st = fork ? c->side : s;   // stream of the contact kernels
@@ -678,7 +683,6 @@ static int assemble_enqueue(tsl_ctx* c, const double* pos, const double* prev, c
       double* vws = (c->tet_warm && spd != 0) ? c->tet_V.p : (double*)nullptr;   // (allocated and counted by assemble())
       const int warm = vws ? tet_warm_flag : 0;
       hipLaunchKernelGGL(k_tet_hess, dim3(nblk(c->n_tet, 64)), dim3(64), 0, stt, TA, c->tet_blk.p, pos, spd, c->vals_full.p, vws, warm, det ? c->cg_trec.p : (double*)nullptr);
-      // the element records of the bodies -> their matrix blocks, on the element stream (the blocks of the bodies and of the cloth are disjoint)
       const int nt_blk = c->n_cgblk - c->n_cgblk_cloth;
       if (det && nt_blk > 0)
         hipLaunchKernelGGL(k_cloth_gather, dim3(nblk(nt_blk, 256)), dim3(256), 0, stt, nt_blk, c->cg_base.p + c->n_cgblk_cloth, c->cg_ptr.p + c->n_cgblk_cloth, (const unsigned*)c->cg_ent.p,
@@ -686,8 +690,6 @@ static int assemble_enqueue(tsl_ctx* c, const double* pos, const double* prev, c
     }
   }
   TSL_TRY(contact_assemble(c, pos, spd, grad, st));
-  // the cloth gradient kernels ride behind the element kernels of the bodies (deterministic assembly: the contact chain -- blocks, mask,
-  // diagonal -- is the longest of the three streams; round 3 had them behind the contact kernels)
   hipStream_t sg = det ? stt : (fork ? st : s);
   if (grad) {
     if (c->n_cface) hipLaunchKernelGGL(k_cloth_grad_face, dim3(nblk(c->n_cface, 256)), dim3(256), 0, sg, CA, pos, grad);
@@ -704,8 +706,6 @@ static int assemble_enqueue(tsl_ctx* c, const double* pos, const double* prev, c
     else hipLaunchKernelGGL((k_cloth_hess_face<false>), dim3(nblk(c->n_cface, 128)), dim3(128), 0, s, CA, c->cf_blk.p, pos, ref, c->quirk.p, spd, c->vals_full.p, frec);
   }
   if (c->n_hinge) hipLaunchKernelGGL(k_cloth_hess_hinge, dim3(nblk(c->n_hinge, 256)), dim3(256), 0, s, CA, c->hg_blk.p, pos, c->vals_full.p, gather ? c->cg_hrec.p : (double*)nullptr);
-  // element records of the cloth -> its matrix blocks, one lane per block, no atomics, next to the other two streams (the mass diagonal was
-  // added before the fork)
   if (gather && c->n_cgblk_cloth > 0)
     hipLaunchKernelGGL(k_cloth_gather, dim3(nblk(c->n_cgblk_cloth, 256)), dim3(256), 0, s, c->n_cgblk_cloth, c->cg_base.p, c->cg_ptr.p, (const unsigned*)c->cg_ent.p, c->n_hinge, c->n_cface,
                        (const double*)c->cg_hrec.p, (const double*)c->cg_frec.p, (const double*)c->cg_trec.p, c->vals_full.p);
@@ -719,6 +719,91 @@ static int assemble_enqueue(tsl_ctx* c, const double* pos, const double* prev, c
   if (grad) hipLaunchKernelGGL(k_mask_vec, dim3(gsz(3 * (size_t)NV)), dim3(256), 0, s, 3 * (size_t)NV, c->frozen.p, grad);
   hipLaunchKernelGGL(k_mask_matrix, dim3(c->n_slices), dim3(256), 0, s, c->n_slices, c->slice_off.p, c->slice_len.p, c->colidx.p, c->fzmask.p, c->mdt2.p,
                      c->vals_full.p, c->vals.p, NV);
+  if (!c->pc_frozen) {
+    hipLaunchKernelGGL(k_block_jacobi, dim3(nblk(NV, 256)), dim3(256), 0, s, NV, c->diag_perm.p, c->vals.p, c->nc > 0 ? c->c_diag.p : (const double*)nullptr, c->Dinv.p);
+    if (body_active(c) && c->bd_valid) body_zero_dinv(c);  // those rows are served by the (lagged) dense inverse
+  }
+  HIP_OK(hipGetLastError());
+  return 0;
+}
+
+// The deterministic assembly with bodies or contacts (the default of every scene but a bare cloth): the element, hinge and contact kernels only
+// STORE (staging slots of the gradient, element records of the matrix), so the three streams depend on each other in few places, and the
+// HOST paces an assembly -- it starts right after the line search's energy was read back, every queue empty, and issues ~35 launches of
+// 5-120 us at 6-8 us each.  Issue order = priority order: the long kernel of every chain first, then the short ones.
+//   element stream:  tet gradients, tet blocks (110 us) | after the mass diagonal: body blocks gathered, hinge blocks (records), face gradients
+//   engine stream:   clear, normals, vertex terms, quirk, face blocks (90 us) | after the hinge records: cloth blocks gathered, mask, block-Jacobi
+//   contact stream:  contact blocks (120 us), mask, diagonal | hinge gradients | after the other gradients: vertex gather, contact rows, mask
+// (round 4 traces, cfg4: the engine stream's first cloth kernel started 200 us after the assembly's first launch and its chain -- face blocks,
+// hinge blocks, gather, then the gradient tail and the matrix tail one after the other -- ended 580 us after the energy read-back; now ~440.)
+static int assemble_enqueue_early(tsl_ctx* c, const double* pos, const double* prev, const double* vel, const double* ref, int spd, double* grad, int tet_warm_flag) {
+  hipStream_t s = c->stream, st = c->side;
+  const bool fork_t = c->n_tet > 0 && c->nc > 0;
+  hipStream_t stt = fork_t ? c->side2 : st;
+  const int NV = c->NV;
+  ClothArgs CA = cloth_args(c);
+  const VertArgs VA = vert_args(c);
+  TetArgs TA = tet_args(c);
+  CA.gstage = c->vg_stage.p; TA.gstage = c->vg_stage.p + 3 * (size_t)c->vg_tet0;
+  const bool gather = c->n_cgblk > 0;
+  HIP_OK(hipEventRecord(c->ev_fork0, s));   // (whatever the caller queued on the engine stream before -- positions -- comes first)
+  HIP_OK(hipStreamWaitEvent(st, c->ev_fork0, 0));
+  if (fork_t) HIP_OK(hipStreamWaitEvent(stt, c->ev_fork0, 0));
+  TSL_TRY(contact_assemble(c, pos, spd, grad, st));   // (the longest chain: blocks 120-160 us, mask, diagonal, hinge gradients, gradient tail)
+  if (c->n_tet) {
+    if (grad) hipLaunchKernelGGL(k_tet_grad, dim3(nblk(c->n_tet, 256)), dim3(256), 0, stt, TA, pos, grad);
+    // eigen-clamp of the element blocks warm-started from the previous assembly's eigenvectors ("tet_warm", on by default);
+    // every 16th clamped assembly starts from the identity again (orthogonality of the accumulated rotations)
+    double* vws = (c->tet_warm && spd != 0) ? c->tet_V.p : (double*)nullptr;   // (allocated and counted by assemble())
+    hipLaunchKernelGGL(k_tet_hess, dim3(nblk(c->n_tet, 64)), dim3(64), 0, stt, TA, c->tet_blk.p, pos, spd, c->vals_full.p, vws, vws ? tet_warm_flag : 0, c->cg_trec.p);
+  }
+  HIP_OK(hipMemsetAsync(c->vals_full.p, 0, c->vals_full.n * sizeof(double), s));
+  if (c->n_cface) hipLaunchKernelGGL(k_cloth_normals, dim3(nblk(c->n_cface, 256)), dim3(256), 0, s, c->n_cface, pos, c->cf_f2v.p, c->norm_dir.p);
+  if (grad) {
+    HIP_OK(hipMemsetAsync(grad, 0, 3 * (size_t)NV * sizeof(double), s));
+    hipLaunchKernelGGL(k_vert_grad, dim3(nblk(NV, 256)), dim3(256), 0, s, VA, pos, prev, vel, grad);
+  }
+  hipLaunchKernelGGL(k_vert_hess, dim3(nblk(NV, 256)), dim3(256), 0, s, VA, c->diag_blk.p, c->vals_full.p);   // (the mass diagonal: the first contribution to its blocks)
+  HIP_OK(hipEventRecord(c->ev_fork, s));   // normals, vertex gradient and mass diagonal are in place
+  if (c->n_cface) {
+    const int nq = (int)c->h_cloth.size() * 9;
+    hipLaunchKernelGGL(k_cloth_quirk, dim3(nblk(nq, 64)), dim3(64), 0, s, CA, (int)c->h_cloth.size(), pos, ref, c->quirk.p);
+    double* frec = gather ? c->cg_frec.p : (double*)nullptr;
+    if (spd == 2) hipLaunchKernelGGL((k_cloth_hess_face<true>), dim3(nblk(c->n_cface, 128)), dim3(128), 0, s, CA, c->cf_blk.p, pos, ref, c->quirk.p, spd, c->vals_full.p, frec);
+    else hipLaunchKernelGGL((k_cloth_hess_face<false>), dim3(nblk(c->n_cface, 128)), dim3(128), 0, s, CA, c->cf_blk.p, pos, ref, c->quirk.p, spd, c->vals_full.p, frec);
+  }
+  // element stream, second part (behind the mass diagonal and the normals)
+  HIP_OK(hipStreamWaitEvent(stt, c->ev_fork, 0));
+  const int nt_blk = c->n_cgblk - c->n_cgblk_cloth;
+  if (c->n_tet && nt_blk > 0)   // the element records of the bodies -> their matrix blocks (the blocks of the bodies and of the cloth are disjoint)
+    hipLaunchKernelGGL(k_cloth_gather, dim3(nblk(nt_blk, 256)), dim3(256), 0, stt, nt_blk, c->cg_base.p + c->n_cgblk_cloth, c->cg_ptr.p + c->n_cgblk_cloth, (const unsigned*)c->cg_ent.p,
+                       c->n_hinge, c->n_cface, (const double*)c->cg_hrec.p, (const double*)c->cg_frec.p, (const double*)c->cg_trec.p, c->vals_full.p);
+  if (c->n_hinge) hipLaunchKernelGGL(k_cloth_hess_hinge, dim3(nblk(c->n_hinge, 256)), dim3(256), 0, stt, CA, c->hg_blk.p, pos, c->vals_full.p, gather ? c->cg_hrec.p : (double*)nullptr);
+  HIP_OK(hipEventRecord(c->ev_join2, stt));   // body blocks and hinge records
+  if (grad && c->n_cface) hipLaunchKernelGGL(k_cloth_grad_face, dim3(nblk(c->n_cface, 256)), dim3(256), 0, stt, CA, pos, grad);
+  if (grad) HIP_OK(hipEventRecord(c->ev_g2, stt));   // tet and face gradients staged
+  // contact stream, second part
+  if (grad) {
+    if (fork_t) HIP_OK(hipStreamWaitEvent(st, c->ev_fork, 0));
+    if (c->n_hinge) hipLaunchKernelGGL(k_cloth_grad_hinge, dim3(nblk(c->n_hinge, 256)), dim3(256), 0, st, CA, pos, ref, grad);
+  }
+  // engine stream: cloth blocks, then the matrix tail
+  HIP_OK(hipStreamWaitEvent(s, c->ev_join2, 0));
+  if (gather && c->n_cgblk_cloth > 0)
+    hipLaunchKernelGGL(k_cloth_gather, dim3(nblk(c->n_cgblk_cloth, 256)), dim3(256), 0, s, c->n_cgblk_cloth, c->cg_base.p, c->cg_ptr.p, (const unsigned*)c->cg_ent.p, c->n_hinge, c->n_cface,
+                       (const double*)c->cg_hrec.p, (const double*)c->cg_frec.p, (const double*)c->cg_trec.p, c->vals_full.p);
+  hipLaunchKernelGGL(k_mask_matrix, dim3(c->n_slices), dim3(256), 0, s, c->n_slices, c->slice_off.p, c->slice_len.p, c->colidx.p, c->fzmask.p, c->mdt2.p,
+                     c->vals_full.p, c->vals.p, NV);
+  // contact stream: the gradient tail
+  if (grad) {
+    if (fork_t) HIP_OK(hipStreamWaitEvent(st, c->ev_g2, 0));
+    hipLaunchKernelGGL(k_vertex_gather, dim3(nblk(NV, 256)), dim3(256), 0, st, NV, (const int*)c->vg_ptr.p, (const int*)c->vg_idx.p, (const double*)c->vg_stage.p, 0, c->vg_ns, grad);
+    if (c->nc > 0) hipLaunchKernelGGL(k_contact_row_gather, dim3(nblk((long)NV * 64, 256)), dim3(256), 0, st, NV, (const int*)c->rowpos.p, (const int*)c->cr_ptr.p, (const int*)c->cr_ent.p,
+                                      (const double*)c->c_G.p, grad);
+    hipLaunchKernelGGL(k_mask_vec, dim3(gsz(3 * (size_t)NV)), dim3(256), 0, st, 3 * (size_t)NV, c->frozen.p, grad);
+  }
+  HIP_OK(hipEventRecord(c->ev_join, st));
+  HIP_OK(hipStreamWaitEvent(s, c->ev_join, 0));   // (contact diagonal for the block-Jacobi inverse, the gradient for whatever follows)
   if (!c->pc_frozen) {
     hipLaunchKernelGGL(k_block_jacobi, dim3(nblk(NV, 256)), dim3(256), 0, s, NV, c->diag_perm.p, c->vals.p, c->nc > 0 ? c->c_diag.p : (const double*)nullptr, c->Dinv.p);
     if (body_active(c) && c->bd_valid) body_zero_dinv(c);  // those rows are served by the (lagged) dense inverse
