@@ -13,8 +13,8 @@ mkdir -p gpurun_out/prof
 rocprofv3 --kernel-trace --stats --output-format csv -d gpurun_out/prof -o ${TAG}_bench -- python bench.py --workload $WL $ARGS > gpurun_out/prof/${TAG}_bench_stdout.log 2>&1
 tail -1 gpurun_out/prof/${TAG}_bench_stdout.log | cut -c1-300
 rm -f gpurun_out/prof/*kernel_trace.csv
-for KRN in "k_ds_gemm<1" "k_ds_extend_panels" "k_ds_gemm<0" "k_ds_gj_flow" "k_ds_gemv"; do   # regex prefixes: the GEMM templates carry a second parameter
-  KN=$(echo $KRN | tr -d '<>')
+for PAIR in "k_ds_gemm1=k_ds_gemm(_x)?<1" "k_ds_extend_panels=k_ds_extend_panels" "k_ds_gemm0=k_ds_gemm(_x)?<0" "k_ds_gj_flow=k_ds_gj_flow" "k_ds_gemv=k_ds_gemv"; do   # name=regex: the Schur / G GEMMs run as k_ds_gemm<mode, 4> and k_ds_gemm_x<mode, 4>
+  KN=${PAIR%%=*}; KRN=${PAIR#*=}
   for CNT in FETCH_SIZE WRITE_SIZE; do
     rocprofv3 --pmc $CNT --kernel-include-regex "$KRN" --output-format csv -d gpurun_out/prof -o ${TAG}_pmc_${KN}_$CNT -- python bench.py --workload $WL $PMC_ARGS > gpurun_out/prof/${TAG}_pmc_stdout.log 2>&1
     python - <<PY
