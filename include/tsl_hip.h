@@ -122,18 +122,24 @@ int tsl_set_stream(tsl_ctx* ctx, void* hip_stream);
  * supernode of their separator), "direct_merge_sep" (separators of at most this many vertices join the enclosing separator's supernode; 16, 0 = off),
  * "direct_refine" (1: plain iterative refinement with the factors, GMRES only where it stalls; 0: flexible GMRES from the start),
  * "direct_plan_cache" (plans of earlier constraint sets kept, default 64; the reverse sweep finds the forward rollout's plans there),
- * "direct_flow" (3; bit 0: the block steps of a batch that is alone on its tree level, of at most 64 fronts and small enough to be resident as a
+ * "direct_flow" (3; bit 0: the block steps of ONE batch per tree level, of at most 64 fronts and small enough to be resident as a
  * whole, run as ONE persistent dataflow launch -- k_ds_gj_flow: every workgroup keeps its tile in registers, steps ordered by
  * point-to-point flags; bit 1: also the batches the LDS kernel would take; 0: one launch per 32 pivots everywhere),
  * "direct_g32_below" (1100: G = W F12 of a batch with fewer 64 x 64 tiles than this uses 32 x 32 tiles -- the upper levels, where the large tiles leave
  * one to three workgroups per CU; 0 = never),
  * "direct_gemv_wide_below" (300: a sweep launch of fewer 16-row chunks than this -- the upper levels -- runs four workgroups per chunk, 4 rows each, the waves
  * a quarter of the columns each; 0 = never),
- * "direct_sweep_flow" (0; L0 > 0: the sweeps of one application for the tree levels >= L0 as one launch with chained phases -- an experiment, measured slower),
- * "direct_overlap" / "direct_overlap_cap" / "direct_overlap_fronts" (0: Schur tiles outside the parents' pivot blocks on a side stream from a capped
- * grid next to the next level's block steps -- an experiment, measured without gain), "tet_warm" (1: the eigen-clamp of the element blocks starts
- * from the eigenvectors of the element's previous assembly), "cloth_gather" (0; 1: cloth Hessian gathered per matrix block from element records
- * instead of scattered atomics: deterministic, measured no faster),
+ * "direct_s32_below" (0: the same for the Schur complements -- measured slower on the leaf levels), "direct_small_rounds" (2: rounds of the chip a batch may
+ * take in the LDS kernel k_ds_inv_small), "direct_plan_cache_mb" (1024: bound of the parked plans in MB),
+ * "direct_xcd" (64: batches of at least this many fronts launch their GEMM tiles with the XCD-aware map k_ds_gemm_x -- a front per XCD; 0 = never),
+ * "direct_split" (3; bit 0: fronts that fit the LDS kernel leave a batch of much larger ones, bit 1: a few fronts that would cost the LDS kernel one
+ * more round of the chip get a batch of their own),
+ * "deterministic" (1: element gradients / blocks and contact rows go to staging slots and records and are summed by gather kernels in a fixed
+ * order, constraint lists are compacted by scan, energies and dot products joined from per-workgroup partials -- no f64 atomics on the step and
+ * adjoint path, two runs give the same bits; 0: scattered atomics), "asm_early" (1: launches of the deterministic assembly issued in priority
+ * order, the long kernel of each of the three streams first), "tet_warm" (1: the eigen-clamp of the element blocks starts
+ * from the eigenvectors of the element's previous assembly), "cloth_gather" (0; with "deterministic" 0: cloth Hessian gathered per matrix block from
+ * element records instead of scattered atomics),
  * "tet_coop" (1: 16 lanes per tetrahedron in the element Hessians), "ds_dbg" / "ds_bench_batch" (timing experiments of tsl_bench_direct),
  * "mg_fuse_restrict" (first sweep + residual + restriction of a stencil level in one launch), "mg_st_f32" (single-precision stencil
  * operators), "mg_fr_rows", "pcg_body_fold" (dense-body first sweep inside the PCG update launch), "asm_overlap" (contact blocks on a
