@@ -161,19 +161,40 @@ static DsDev ds_dev(tsl_ctx* c) {
   return D;
 }
 
+// Pinned staging arena of the plan uploads: the maps of a plan (~14 MB on cfg4, of which 11 MB the level-ordered block lists) go through it
+// as true asynchronous copies.  ds_pin_reset only after the stream was synchronised (the arena is reused); ds_pin_take returns null when
+// the arena has no room (the copy then goes the pageable way).
+static void ds_pin_reset(DirectSolver& d, size_t need) {
+  if (d.pin_cap < need) {
+    if (d.pin) (void)hipHostFree(d.pin);
+    d.pin = nullptr; d.pin_cap = 0;
+    void* p = nullptr;
+    if (hipHostMalloc(&p, need + need / 4) == hipSuccess) { d.pin = (char*)p; d.pin_cap = need + need / 4; }
+    else (void)hipGetLastError();
+  }
+  d.pin_off = 0;
+}
+static void* ds_pin_take(DirectSolver& d, size_t bytes) {
+  const size_t o = (d.pin_off + 255) & ~(size_t)255;
+  if (!d.pin || o + bytes > d.pin_cap) return nullptr;
+  d.pin_off = o + bytes;
+  return d.pin + o;
+}
 template <class T>
-static int ds_upload_grow(DevBuf<T>& buf, const std::vector<T>& h, hipStream_t s) {
+static int ds_upload_grow(DevBuf<T>& buf, const std::vector<T>& h, hipStream_t s, DirectSolver* d = nullptr) {
   if (buf.n < h.size()) { if (buf.alloc(h.size() + h.size() / 4 + 16)) return -1; }
   if (h.empty()) return 0;
-  HIP_OK(hipMemcpyAsync(buf.p, h.data(), h.size() * sizeof(T), hipMemcpyHostToDevice, s));
+  const void* src = h.data();
+  if (d) if (void* st = ds_pin_take(*d, h.size() * sizeof(T))) { memcpy(st, h.data(), h.size() * sizeof(T)); src = st; }
+  HIP_OK(hipMemcpyAsync(buf.p, src, h.size() * sizeof(T), hipMemcpyHostToDevice, s));
   return 0;
 }
 
 // contact maps of the active plan (redone whenever the constraint ORDER changes: build_con)
 static int ds_upload_con(DirectSolver& d, hipStream_t s) {
   const DirectPlan& P = d.plan;
-  TSL_TRY(ds_upload_grow(d.cgr_ptr, P.cgr_ptr, s)); TSL_TRY(ds_upload_grow(d.cgr_ent, P.cgr_ent, s)); TSL_TRY(ds_upload_grow(d.cgr_ld, P.cgr_ld, s));
-  TSL_TRY(ds_upload_grow(d.cgr_dst, P.cgr_dst, s));
+  TSL_TRY(ds_upload_grow(d.cgr_ptr, P.cgr_ptr, s, &d)); TSL_TRY(ds_upload_grow(d.cgr_ent, P.cgr_ent, s, &d)); TSL_TRY(ds_upload_grow(d.cgr_ld, P.cgr_ld, s, &d));
+  TSL_TRY(ds_upload_grow(d.cgr_dst, P.cgr_dst, s, &d));
   return 0;
 }
 
@@ -207,6 +228,10 @@ static uint64_t ds_cons_key(const std::vector<int>& cons) {   // FNV-1a over the
 // active plan <-> cache slot (host plan, constraint list, every device array that belongs to a plan)
 static void ds_swap_slot(DirectSolver& d, DsPlanSlot& sl) {
   std::swap(d.plan, sl.plan); d.h_cons.swap(sl.h_cons); d.h_cset.swap(sl.h_cset);
+  // the build's scratch stays with the ACTIVE plan (host block maps, child tables, per-thread lists, the static mirror table: 15 MB that only
+  // the build and the upload right after it read -- a parked plan does not carry them, a new build does not allocate and fault them in again)
+  d.plan.blk_dst.swap(sl.plan.blk_dst); d.plan.blk_ld.swap(sl.plan.blk_ld); d.plan.blk_q.swap(sl.plan.blk_q); d.plan.pmap.swap(sl.plan.pmap);
+  d.plan.lists.swap(sl.plan.lists); d.plan.locs.swap(sl.plan.locs); d.plan.tpos.swap(sl.plan.tpos);
   d.level_sn.swap(sl.level_sn); d.pmap.swap(sl.pmap); d.ch_rec.swap(sl.ch_rec); d.vtx.swap(sl.vtx); d.blk_ld.swap(sl.blk_ld); 
   d.wl_front.swap(sl.wl_front); d.wl_row.swap(sl.wl_row); d.blk_dst.swap(sl.blk_dst); d.fr.swap(sl.fr); d.frl.swap(sl.frl); d.blk_q.swap(sl.blk_q); d.cgr_ptr.swap(sl.cgr_ptr); d.cgr_ent.swap(sl.cgr_ent); d.cgr_ld.swap(sl.cgr_ld); d.cgr_dst.swap(sl.cgr_dst);
 }
@@ -259,6 +284,7 @@ static int direct_plan(tsl_ctx* c) {
     if (cons != d.h_cons) {
       HIP_OK(hipStreamSynchronize(s));
       if (d.plan.build_con(cons.data(), c->nc)) return tsl_fail("direct solver: constraint vertex outside its front");
+      ds_pin_reset(d, 20 * (d.plan.cgr_ent.size() + d.plan.cgr_ptr.size()) + 4096);
       TSL_TRY(ds_upload_con(d, s));
       HIP_OK(hipStreamSynchronize(s));
       d.h_cons = cons;
@@ -285,7 +311,7 @@ static int direct_plan(tsl_ctx* c) {
       if (!dst && (int)d.cache.size() < d.cache_cap) {
         d.cache.emplace_back(new DsPlanSlot());
         dst = d.cache.back().get();
-        dst->plan.sym.copy_partition(d.plan.sym); dst->plan.tpos = d.plan.tpos; dst->plan.threads = d.plan.threads; dst->plan.n_cu = d.plan.n_cu; dst->plan.split_small = d.plan.split_small; dst->plan.split_rem = d.plan.split_rem;   // the static part a build starts from
+        dst->plan.sym.copy_partition(d.plan.sym); dst->plan.threads = d.plan.threads; dst->plan.n_cu = d.plan.n_cu; dst->plan.split_small = d.plan.split_small; dst->plan.split_rem = d.plan.split_rem;   // the static part a build starts from
       }
       if (!dst) { for (auto& sl : d.cache) if (!dst || sl->stamp < dst->stamp) dst = sl.get(); }
       ds_swap_slot(d, *dst);
@@ -302,23 +328,37 @@ static int direct_plan(tsl_ctx* c) {
   // local vertex -> permuted row of the solver vectors
   std::vector<int> vtxp(P.vtx.size());
   for (size_t i = 0; i < vtxp.size(); i++) vtxp[i] = c->h_rowpos[P.vtx[i]];
-  HIP_OK(hipStreamSynchronize(s));  // the previous plan's arrays may still be in use
-  TSL_TRY(ds_upload_grow(d.fr, P.fr, s)); TSL_TRY(ds_upload_grow(d.level_sn, P.level_sn, s)); TSL_TRY(ds_upload_grow(d.pmap, P.pmap, s)); TSL_TRY(ds_upload_grow(d.ch_rec, P.ch_rec, s));
-  TSL_TRY(ds_upload_grow(d.vtx, vtxp, s));
-  // the static blocks in the plan's level order: SELL source address, destination, row stride (the device arrays blk_q / blk_dst / blk_ld)
+  HIP_OK(hipStreamSynchronize(s));  // the previous plan's arrays may still be in use (and the staging arena of the previous upload)
   const size_t nbk = P.blk_q.size();
-  std::vector<int> src_l(nbk), ld_l(nbk);
-  std::vector<long long> dst_l(nbk);
-  ds_parallel_for((int)((nbk + 4095) / 4096), P.n_threads(), 1, [&](int, int ch) {
-    for (size_t i = (size_t)ch * 4096; i < std::min(nbk, (size_t)(ch + 1) * 4096); i++) { const int q = P.blk_q[i]; src_l[i] = d.h_c2s[q]; dst_l[i] = P.blk_dst[q]; ld_l[i] = P.blk_ld[q]; }
-  });
-  TSL_TRY(ds_upload_grow(d.blk_dst, dst_l, s)); TSL_TRY(ds_upload_grow(d.blk_ld, ld_l, s));
+  ds_pin_reset(d, 16 * nbk + 2 * sizeof(DsFrontDesc) * P.fr.size() + sizeof(DsChildRec) * P.ch_rec.size() +
+                      4 * (P.level_sn.size() + P.pmap.size() + vtxp.size() + P.wl_front.size() + P.wl_row.size()) + 20 * (P.cgr_ent.size() + P.cgr_ptr.size()) + 64 * 256);
+  TSL_TRY(ds_upload_grow(d.fr, P.fr, s, &d)); TSL_TRY(ds_upload_grow(d.level_sn, P.level_sn, s, &d)); TSL_TRY(ds_upload_grow(d.pmap, P.pmap, s, &d)); TSL_TRY(ds_upload_grow(d.ch_rec, P.ch_rec, s, &d));
+  TSL_TRY(ds_upload_grow(d.vtx, vtxp, s, &d));
+  // the static blocks in the plan's level order: SELL source address, destination, row stride (the device arrays blk_q / blk_dst / blk_ld),
+  // written straight into the staging arena
+  {
+    std::vector<int> src_v, ld_v;
+    std::vector<long long> dst_v;
+    int* src_l = (int*)ds_pin_take(d, 4 * nbk); int* ld_l = (int*)ds_pin_take(d, 4 * nbk); long long* dst_l = (long long*)ds_pin_take(d, 8 * nbk);
+    if (!src_l || !ld_l || !dst_l) { src_v.resize(nbk); ld_v.resize(nbk); dst_v.resize(nbk); src_l = src_v.data(); ld_l = ld_v.data(); dst_l = dst_v.data(); }
+    ds_parallel_for((int)((nbk + 4095) / 4096), P.n_threads(), 1, [&](int, int ch) {
+      for (size_t i = (size_t)ch * 4096; i < std::min(nbk, (size_t)(ch + 1) * 4096); i++) { const int q = P.blk_q[i]; src_l[i] = d.h_c2s[q]; dst_l[i] = P.blk_dst[q]; ld_l[i] = P.blk_ld[q]; }
+    });
+    if (d.blk_dst.n < nbk) { if (d.blk_dst.alloc(nbk + nbk / 4 + 16)) return -1; }
+    if (d.blk_ld.n < nbk) { if (d.blk_ld.alloc(nbk + nbk / 4 + 16)) return -1; }
+    if (d.blk_q.n < nbk) { if (d.blk_q.alloc(nbk + nbk / 4 + 16)) return -1; }
+    if (nbk > 0) {
+      HIP_OK(hipMemcpyAsync(d.blk_dst.p, dst_l, 8 * nbk, hipMemcpyHostToDevice, s));
+      HIP_OK(hipMemcpyAsync(d.blk_ld.p, ld_l, 4 * nbk, hipMemcpyHostToDevice, s));
+      HIP_OK(hipMemcpyAsync(d.blk_q.p, src_l, 4 * nbk, hipMemcpyHostToDevice, s));
+      if (!src_v.empty()) HIP_OK(hipStreamSynchronize(s));   // (pageable fallback: the vectors end here)
+    }
+  }
   TSL_TRY(ds_upload_con(d, s));
-  TSL_TRY(ds_upload_grow(d.blk_q, src_l, s));
   std::vector<DsFrontDesc> frl(P.level_sn.size());
   for (size_t i = 0; i < frl.size(); i++) frl[i] = P.fr[P.level_sn[i]];
-  TSL_TRY(ds_upload_grow(d.frl, frl, s));
-  TSL_TRY(ds_upload_grow(d.wl_front, P.wl_front, s)); TSL_TRY(ds_upload_grow(d.wl_row, P.wl_row, s));
+  TSL_TRY(ds_upload_grow(d.frl, frl, s, &d));
+  TSL_TRY(ds_upload_grow(d.wl_front, P.wl_front, s, &d)); TSL_TRY(ds_upload_grow(d.wl_row, P.wl_row, s, &d));
   if (d.prezero_pending && d.arena.n < (size_t)P.arena) { HIP_OK(hipEventSynchronize(d.ev_zero)); d.prezero_pending = false; }   // the clear runs on the buffer about to be replaced
   if (d.arena.n < (size_t)P.arena) { if (d.arena.alloc((size_t)P.arena + (size_t)P.arena / 8)) return tsl_fail("direct solver: out of device memory (%.2f GB of front panels)", P.arena * 8e-9); }
   if (d.sarena.n < (size_t)P.sarena) { if (d.sarena.alloc((size_t)P.sarena + (size_t)P.sarena / 8 + 16)) return tsl_fail("direct solver: out of device memory (%.2f GB of Schur complements)", P.sarena * 8e-9); }

@@ -111,6 +111,7 @@ struct DsPlanSlot {
   DevBuf<DsChildRec> ch_rec;
 };
 struct DirectSolver {
+  char* pin = nullptr; size_t pin_cap = 0, pin_off = 0;   // pinned staging arena of the plan uploads (pageable copies are staged by the runtime at ~6 GB/s, synchronously)
   int enable = -1;          // -1 auto (cloth grids of >= 1024 cells: the iterative hierarchy is probed first, the factorisation takes over when it fails), 0 off, 1 always
   bool hard = false;        // auto mode: the last probe of the iterative hierarchy failed
   int hard_steps = 0, probe_cap = 60, probe_every = 16;

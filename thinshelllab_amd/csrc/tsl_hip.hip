@@ -397,6 +397,7 @@ extern "C" void tsl_ctx_destroy(tsl_ctx* c) {
   for (int k = 0; k < DS_NSIDE; k++) if (c->ds.fstream[k]) { (void)hipStreamSynchronize(c->ds.fstream[k]); (void)hipEventDestroy(c->ds.ev_fjoin[k]); (void)hipStreamDestroy(c->ds.fstream[k]); }
   if (c->ds.ev_ffork) (void)hipEventDestroy(c->ds.ev_ffork);
   if (c->ds.h_anorm) (void)hipHostFree(c->ds.h_anorm);
+  if (c->ds.pin) (void)hipHostFree(c->ds.pin);
   if (c->h_ir) (void)hipHostFree(c->h_ir);
   if (c->ds.zstream) { (void)hipStreamSynchronize(c->ds.zstream); (void)hipEventDestroy(c->ds.ev_zfork); (void)hipEventDestroy(c->ds.ev_zero); (void)hipStreamDestroy(c->ds.zstream); }
   if (c->ev_fork) (void)hipEventDestroy(c->ev_fork);
