@@ -131,7 +131,7 @@ struct DirectSolver {
   DevBuf<double> flow_x;    // exchange slots (pivot inverses, row / column panel tiles)
   DevBuf<int> flow_f;       // their flags (epoch of the launch that published the slot)
   int gemv_wide_below = 300;   // "direct_gemv_wide_below": a sweep launch of fewer 16-row chunks than this runs four narrow workgroups per chunk (k_ds_gemv_wide; 0 = never).
-                               // cfg4, one application: 404 us without, 385 / 380 / 387 / 388 / 409 / 523 us at 150 / 300 / 600 / 1200 / 2400 / always (scripts/exp_gemv_wide.py)
+                               // cfg4, one application: 404 us without, 385 / 380 / 387 / 388 / 409 / 523 us at 150 / 300 / 600 / 1200 / 2400 / always (scripts/archive_r02_r03/exp_gemv_wide.py)
   int g32_below = 1100;     // "direct_g32_below": G = W F12 of a batch with fewer 64 x 64 tiles than this runs in the 32 x 32-tile kernel (k_ds_gemm_g32; 0 = never).
                             // cfg4: 52 -> 34, 67 -> 52, 37 -> 32 us on the three top levels with boundaries; the batches of 1150+ tiles lose (31 -> 33 us)
   int s32_below = 0;        // "direct_s32_below": the same for the Schur complements (k_ds_gemm_s32)
