@@ -76,6 +76,53 @@ def test_two_runs_give_the_same_bits(name):
         assert np.array_equal(a[k], b[k]), f"{name}: {k} differs between two runs (max |d| = {np.abs(a[k] - b[k]).max():.3e})"
 
 
+def _sysid_sweep(name):
+    """system identification (analytic_grad_system.Grad): 3 driven steps, reverse sweep with the parameter gradients"""
+    import gc
+    import time
+    gc.collect(); time.sleep(2.2)
+    from thinshelllab_amd.engine.analytic_grad_system import Grad
+    from thinshelllab_amd.engine.geometry import projection_query
+    if name == "balancing":
+        from thinshelllab_amd.task_scene.Scene_balancing import Scene
+        s = Scene(cloth_size=0.06, cloth_N=48, cloth_M=48)
+    else:
+        from thinshelllab_amd.task_scene.Scene_folding import Scene
+        s = Scene(cloth_size=0.1, cloth_N=60, cloth_M=30)
+    s.init_all(); s.mu_cloth_elastic[None] = 5.0; s.prev_pos.copy_from(s.pos)
+    s._ensure_ctx().set_param("direct", 1)
+    T, n_part = 4, s.gripper.n_part
+    g = Grad(s, T, n_part); g.init_mass(s)
+    g.count_mu_lam_grad = True
+    g.copy_pos(s, 0)
+    dpos = np.zeros((n_part, 3)); drot = np.zeros((n_part, 3))
+    dpos[:, 2] = -1e-4 if name != "balancing" else 5e-5
+    drot[:, 1] = 2e-3
+    for f in range(1, T):
+        s.action(f, dpos, drot)
+        s.time_step(projection_query, f)
+        g.copy_pos(s, f)
+    g.get_loss_slide(s)
+    for k in range(T - 1, 0, -1):
+        g.transfer_grad(k, s, projection_query)
+    force = s.gather_force() if hasattr(s, "gather_force") else None
+    out = dict(pos_grad=g.pos_grad.to_numpy().copy(), params=np.array([g.grad_kb.value, g.grad_mu.value, g.grad_lam.value]))
+    if force is not None:
+        out["force"] = np.asarray(force, dtype=np.float64).copy()
+    del g, s
+    gc.collect()
+    return out
+
+
+@pytest.mark.parametrize("name", ["balancing", "folding"])
+def test_system_identification_sweep_gives_the_same_bits(name):
+    """tsl_param_grad / tsl_elastic_force: staged element contributions + ticketed dot products (no f64 atomics) -- two runs, the same bits"""
+    a = _sysid_sweep(name); b = _sysid_sweep(name)
+    assert np.abs(a["params"][:2]).min() > 0
+    for k in a:
+        assert np.array_equal(a[k], b[k]), f"{name}: {k} differs between two runs: {a[k] if a[k].size < 8 else ''} {b[k] if b[k].size < 8 else ''}"
+
+
 def test_cfg4_steps_are_reproducible_at_full_size():
     a = rollout("balancing", 4, grid=224)
     b = rollout("balancing", 4, grid=224)

@@ -835,8 +835,9 @@ __global__ void k_contact_backprop(int nc, ContactArgs A, const double* __restri
 // Scene_sliding.contact_energy_backprop_friction (Scene_sliding.py:139-176): d(loss)/d(mu_cloth_cloth) contribution of the
 // constraints whose pair uses that parameter (the reference loops over the first nc1 constraints = the cloth-cloth pairs):
 // sum over the free dofs of z * w1 * g1 / mu_cloth_cloth, g1 = T^T (k f1(r) u), w1 = (w0, w1, w2, -1).
+// (part / ticket: one partial per workgroup = wave, joined in workgroup order by the last one to finish; null: one atomic per wave)
 __global__ void k_contact_friction_grad(int nc, ContactArgs A, const int* __restrict__ kind, const int* __restrict__ frozen, const double* __restrict__ pos,
-                                        const double* __restrict__ z, double mu_cc, double* out) {
+                                        const double* __restrict__ z, double mu_cc, double* out, double* __restrict__ part, int* __restrict__ ticket) {
   const int ci = blockIdx.x * blockDim.x + threadIdx.x;
   double s = 0;
   if (ci < nc && kind[ci] == 2) {
@@ -859,6 +860,20 @@ __global__ void k_contact_friction_grad(int nc, ContactArgs A, const int* __rest
       }
   }
   s = wave_sum(s);
+  if (part) {
+    if (threadIdx.x == 0) {
+      part[blockIdx.x] = s;
+      __threadfence();
+      if (atomicAdd(ticket, 1) == (int)gridDim.x - 1) {
+        __threadfence();
+        double t = 0.0;
+        for (unsigned i = 0; i < gridDim.x; i++) t += __hip_atomic_load(&part[i], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        *out += t;
+        *ticket = 0;
+      }
+    }
+    return;
+  }
   if ((threadIdx.x & 63) == 0 && s != 0.0) atomicAdd(out, s);
 }
 

@@ -129,7 +129,9 @@ __global__ void k_elastic_force_finish(VertArgs A, int v0, int v1, double* __res
 // d(force)/d(mu): model_elastic_tactile.py:329-347 (P1 / mu = F - J F^-T) and model_elastic_offset.py:415-431 (P1 / mu = F - F^-T).
 // Tactile contributions go to d_tact (cleared by the caller on every call), box / ball contributions to d_accum, which the
 // reference never clears (it zeroes F_f instead), so it keeps growing over the calls.
-__global__ void k_tet_deri_mu(TetArgs A, const double* __restrict__ pos, double* __restrict__ d_tact, double* __restrict__ d_accum) {
+// stA / stB (deterministic): the four vertex contributions of tet t go to slots 4 t + j of stA (tactile material) or stB (the others), zeros to
+// the other array; k_vertex_gather sums them per vertex in a fixed order
+__global__ void k_tet_deri_mu(TetArgs A, const double* __restrict__ pos, double* __restrict__ d_tact, double* __restrict__ d_accum, double* __restrict__ stA, double* __restrict__ stB) {
   const int t = blockIdx.x * blockDim.x + threadIdx.x;
   if (t >= A.n_tet) return;
   int v[4]; m3 B;
@@ -142,14 +144,18 @@ __global__ void k_tet_deri_mu(TetArgs A, const double* __restrict__ pos, double*
   const m3 Hm = m3_mul(P, m3_T(B));
   const double W = A.W[t];
   double* out = (e.kind == 0) ? d_tact : d_accum;
+  double* sto = (e.kind == 0) ? stA : stB;
+  double* stz = (e.kind == 0) ? stB : stA;
   d3 f3 = d3();
 #pragma unroll
   for (int i = 0; i < 3; i++) {
     const d3 fi = d3(-W * Hm.m[i], -W * Hm.m[3 + i], -W * Hm.m[6 + i]);
-    atomic_add3(out, v[i], fi);
+    if (sto) { st3(sto, 4 * t + i, fi); st3(stz, 4 * t + i, d3()); }
+    else atomic_add3(out, v[i], fi);
     f3 = f3 - fi;
   }
-  atomic_add3(out, v[3], f3);
+  if (sto) { st3(sto, 4 * t + 3, f3); st3(stz, 4 * t + 3, d3()); }
+  else atomic_add3(out, v[3], f3);
 }
 
 // dP(dF) for the two materials (energy Hessian direction), returns dE-Hessian column block dH = W * dP * B^T

@@ -741,10 +741,13 @@ __global__ void __launch_bounds__(256) k_multi_axpy(size_t n, const double* __re
   }
 }
 // out += sum over free dofs of scale * a_i * b_i for i in [i0, i1)  (parameter gradients of the system-identification adjoint)
-__global__ void k_dot_free(size_t i0, size_t i1, const double* __restrict__ a, const double* __restrict__ b, const int* __restrict__ frozen, double scale, double* out) {
+// (part / ticket: per-block partials joined in a fixed order by the last block, like k_dot; null: one atomic per wave)
+__global__ void __launch_bounds__(256) k_dot_free(size_t i0, size_t i1, const double* __restrict__ a, const double* __restrict__ b, const int* __restrict__ frozen, double scale, double* out,
+                                                  double* __restrict__ part, int* __restrict__ ticket) {
   double s = 0;
   for (size_t i = i0 + blockIdx.x * (size_t)blockDim.x + threadIdx.x; i < i1; i += (size_t)gridDim.x * blockDim.x)
     if (!frozen[i]) s += a[i] * b[i];
+  if (part) { dot_finish(scale * s, out, part, ticket); return; }
   s = wave_sum(s);
   if ((threadIdx.x & 63) == 0 && s != 0.0) atomicAdd(out, scale * s);
 }

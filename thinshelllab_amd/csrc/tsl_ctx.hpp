@@ -273,6 +273,7 @@ struct tsl_ctx {
   DevBuf<int> vg_ptr, vg_idx;            // vertex -> staging slots of its incident faces / hinges / tets (k_vertex_gather)
   DevBuf<double> vg_stage, cg_trec;      // staged element gradients (3-vectors); per-tet 12 x 12 records (144)
   int vg_ns = 0, vg_hinge0 = 0, vg_tet0 = 0;
+  DevBuf<double> vg_stage2;   // second staging array of the tet slots (tsl_param_grad: the two materials accumulate into different vectors)
   DevBuf<double> dot_part; DevBuf<int> dot_ticket;   // scratch of the deterministic dot products
   DevBuf<double> e_part;                 // per-workgroup partial energies
   int n_cgblk = 0, n_cgblk_cloth = 0, cloth_gather = 0;   // gather lists: blocks of the cloth first, blocks of the FEM bodies behind them   // "cloth_gather" = 1: gather assembly of the cloth Hessian (deterministic; measured no faster than the class-ordered atomics: 268 against 270 us)

@@ -2097,7 +2097,12 @@ extern "C" int tsl_elastic_force(tsl_ctx* c, const double* pos, double* force) {
   const size_t n3 = 3 * (size_t)c->NV;
   HIP_OK(hipMemsetAsync(force, 0, n3 * sizeof(double), s));
   if (c->n_tet) {
-    hipLaunchKernelGGL(k_tet_grad, dim3(nblk(c->n_tet, 256)), dim3(256), 0, s, tet_args(c), pos, force);
+    TetArgs TA = tet_args(c);
+    const bool det = c->deterministic != 0;   // element gradients staged and summed per vertex in a fixed order (as in the assembly)
+    if (det && c->vg_stage.n < 3 * (size_t)std::max(c->vg_ns, 1)) { if (c->vg_stage.alloc(3 * (size_t)std::max(c->vg_ns, 1))) return tsl_fail("out of device memory (gradient staging)"); }
+    if (det) TA.gstage = c->vg_stage.p + 3 * (size_t)c->vg_tet0;
+    hipLaunchKernelGGL(k_tet_grad, dim3(nblk(c->n_tet, 256)), dim3(256), 0, s, TA, pos, force);
+    if (det) hipLaunchKernelGGL(k_vertex_gather, dim3(nblk(c->NV, 256)), dim3(256), 0, s, c->NV, (const int*)c->vg_ptr.p, (const int*)c->vg_idx.p, (const double*)c->vg_stage.p, c->vg_tet0, c->vg_ns, force);
     for (const ElasticDev& e : c->h_el)
       hipLaunchKernelGGL(k_elastic_force_finish, dim3(nblk(e.n_verts, 256)), dim3(256), 0, s, vert_args(c), e.v_offset, e.v_offset + e.n_verts, force);
   }
@@ -2116,7 +2121,8 @@ extern "C" int tsl_friction_grad(tsl_ctx* c, const double* pos, double* out_host
   double* acc = &SC(c)->aux[0];
   HIP_OK(hipMemsetAsync(acc, 0, sizeof(double), s));
   if (c->nc > 0)
-    hipLaunchKernelGGL(k_contact_friction_grad, dim3(nblk(c->nc, 64)), dim3(64), 0, s, c->nc, contact_args(c), c->c_kind.p, c->frozen.p, pos, c->pdir.p, c->mu_cloth_cloth, acc);
+    hipLaunchKernelGGL(k_contact_friction_grad, dim3(nblk(c->nc, 64)), dim3(64), 0, s, c->nc, contact_args(c), c->c_kind.p, c->frozen.p, pos, c->pdir.p, c->mu_cloth_cloth, acc,
+                       (c->deterministic && nblk(c->nc, 64) <= 64 * 512) ? c->dot_part.p : (double*)nullptr, c->deterministic ? c->dot_ticket.p : (int*)nullptr);
   HIP_OK(hipMemcpyAsync(out_host, acc, sizeof(double), hipMemcpyDeviceToHost, s));
   HIP_OK(hipStreamSynchronize(s));
   return 0;
@@ -2135,21 +2141,38 @@ extern "C" int tsl_param_grad(tsl_ctx* c, const double* pos, const double* ref, 
   double* tmp = c->v_t4.p;
   double* acc = &SC(c)->aux[0];
   HIP_OK(hipMemsetAsync(acc, 0, 2 * sizeof(double), s));
+  // deterministic (default): hinge / tet contributions staged per element and summed per vertex in a fixed order, the dot products joined
+  // from per-block partials -- two runs of a system-identification sweep give the same bits
+  const bool det = c->deterministic != 0;
+  if (det && c->vg_stage.n < 3 * (size_t)std::max(c->vg_ns, 1)) { if (c->vg_stage.alloc(3 * (size_t)std::max(c->vg_ns, 1))) return tsl_fail("out of device memory (gradient staging)"); }
   // d_kb = -(bending gradient) / Kb per cloth
   if (c->n_hinge) {
     HIP_OK(hipMemsetAsync(tmp, 0, n3 * sizeof(double), s));
     hipLaunchKernelGGL(k_cloth_normals, dim3(nblk(c->n_cface, 256)), dim3(256), 0, s, c->n_cface, pos, c->cf_f2v.p, c->norm_dir.p);
-    hipLaunchKernelGGL(k_cloth_grad_hinge, dim3(nblk(c->n_hinge, 256)), dim3(256), 0, s, cloth_args(c), pos, ref, tmp);
+    ClothArgs CA = cloth_args(c);
+    if (det) CA.gstage = c->vg_stage.p;
+    hipLaunchKernelGGL(k_cloth_grad_hinge, dim3(nblk(c->n_hinge, 256)), dim3(256), 0, s, CA, pos, ref, tmp);
+    if (det) hipLaunchKernelGGL(k_vertex_gather, dim3(nblk(NV, 256)), dim3(256), 0, s, NV, (const int*)c->vg_ptr.p, (const int*)c->vg_idx.p, (const double*)c->vg_stage.p, c->vg_hinge0, c->vg_tet0, tmp);
     for (const ClothDev& cd : c->h_cloth)
-      hipLaunchKernelGGL(k_dot_free, dim3(DOT_BLOCKS), dim3(256), 0, s, 3 * (size_t)cd.v_offset, 3 * (size_t)(cd.v_offset + cd.NV), c->pdir.p, tmp, c->frozen.p, -1.0 / cd.Kb, acc);
+      hipLaunchKernelGGL(k_dot_free, dim3(DOT_BLOCKS), dim3(256), 0, s, 3 * (size_t)cd.v_offset, 3 * (size_t)(cd.v_offset + cd.NV), c->pdir.p, tmp, c->frozen.p, -1.0 / cd.Kb, acc, DOT_SCRATCH(c));
   }
   // d_mu
   if (c->n_tet) {
     if (c->dmu_accum.n == 0) { TSL_TRY(c->dmu_accum.alloc(n3)); HIP_OK(hipMemsetAsync(c->dmu_accum.p, 0, n3 * sizeof(double), s)); }
     HIP_OK(hipMemsetAsync(tmp, 0, n3 * sizeof(double), s));
-    hipLaunchKernelGGL(k_tet_deri_mu, dim3(nblk(c->n_tet, 64)), dim3(64), 0, s, tet_args(c), pos, tmp, c->dmu_accum.p);
-    hipLaunchKernelGGL(k_dot_free, dim3(DOT_BLOCKS), dim3(256), 0, s, (size_t)0, n3, c->pdir.p, tmp, c->frozen.p, 1.0, acc + 1);
-    hipLaunchKernelGGL(k_dot_free, dim3(DOT_BLOCKS), dim3(256), 0, s, (size_t)0, n3, c->pdir.p, c->dmu_accum.p, c->frozen.p, 1.0, acc + 1);
+    double *stA = nullptr, *stB = nullptr;
+    if (det) {
+      if (c->vg_stage2.n < 12 * (size_t)c->n_tet) { if (c->vg_stage2.alloc(12 * (size_t)c->n_tet)) return tsl_fail("out of device memory (gradient staging)"); }
+      stA = c->vg_stage.p + 3 * (size_t)c->vg_tet0; stB = c->vg_stage2.p;
+    }
+    hipLaunchKernelGGL(k_tet_deri_mu, dim3(nblk(c->n_tet, 64)), dim3(64), 0, s, tet_args(c), pos, tmp, c->dmu_accum.p, stA, stB);
+    if (det) {   // (the second gather reads the same slot numbers from a staging array that holds the tet slots only)
+      hipLaunchKernelGGL(k_vertex_gather, dim3(nblk(NV, 256)), dim3(256), 0, s, NV, (const int*)c->vg_ptr.p, (const int*)c->vg_idx.p, (const double*)c->vg_stage.p, c->vg_tet0, c->vg_ns, tmp);
+      hipLaunchKernelGGL(k_vertex_gather, dim3(nblk(NV, 256)), dim3(256), 0, s, NV, (const int*)c->vg_ptr.p, (const int*)c->vg_idx.p, (const double*)c->vg_stage2.p - 3 * (size_t)c->vg_tet0, c->vg_tet0, c->vg_ns,
+                         c->dmu_accum.p);
+    }
+    hipLaunchKernelGGL(k_dot_free, dim3(DOT_BLOCKS), dim3(256), 0, s, (size_t)0, n3, c->pdir.p, tmp, c->frozen.p, 1.0, acc + 1, DOT_SCRATCH(c));
+    hipLaunchKernelGGL(k_dot_free, dim3(DOT_BLOCKS), dim3(256), 0, s, (size_t)0, n3, c->pdir.p, c->dmu_accum.p, c->frozen.p, 1.0, acc + 1, DOT_SCRATCH(c));
   }
   double h[2];
   HIP_OK(hipMemcpyAsync(h, acc, 2 * sizeof(double), hipMemcpyDeviceToHost, s));
