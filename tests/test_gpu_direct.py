@@ -281,7 +281,7 @@ def test_two_contexts_share_the_device_without_dataflow_launches():
     b1 = s1.F.to_torch().clone()
     x, st = c1.solve(b1.clone())
     n0 = c1.direct_counters()["flow_launches"]
-    assert n0 > 0 and st["flag"] == 0
+    assert n0 > 0 and st["flag"] == 0, (n0, st, c1.direct_counters())
     xs1 = spl.splu(c1.operator_csr().tocsc()).solve(b1.cpu().numpy())
     s2 = _drape(96, 64, 5e-5, seed=12)
     c2 = s2._ensure_ctx()
@@ -292,14 +292,18 @@ def test_two_contexts_share_the_device_without_dataflow_launches():
     c2.solve(b2.clone())                     # the neighbour's first factorisation (it sees context 1 active: no dataflow launch)
     out = {}
 
-    a_done = threading.Event()
+    a_done, b_running = threading.Event(), threading.Event()
 
     def work(name, s, c, b, xs):
         errs = []
+        if name == "a":
+            b_running.wait(30.0)    # context 1 starts once the neighbour is factorising (a cold box takes its time to get a thread going)
         while len(errs) < 4 or (name == "b" and not a_done.is_set() and len(errs) < 400):   # the neighbour keeps factorising for as long as context 1 works
             s.compute_residual_and_Hessian(spd=True)      # fresh factors every time
             x, st = c.solve(b.clone())
             errs.append((st["flag"], rel_err(x.cpu().numpy(), xs)))
+            if name == "b":
+                b_running.set()
         if name == "a":
             a_done.set()
         out[name] = errs
@@ -309,10 +313,11 @@ def test_two_contexts_share_the_device_without_dataflow_launches():
     for t in th:
         t.join()
     assert all(f == 0 and e < 1e-9 for f, e in out["a"] + out["b"]), out
-    assert c1.direct_counters()["flow_launches"] == n0 and c2.direct_counters()["flow_launches"] == 0
-    assert c1.direct_counters()["flow_aborts"] == 0
+    k1, k2 = c1.direct_counters(), c2.direct_counters()
+    assert k1["flow_aborts"] == 0 and k2["flow_aborts"] == 0, (k1, k2)
+    assert k1["flow_launches"] == n0 and k2["flow_launches"] == 0, (n0, k1, k2, len(out["a"]), len(out["b"]))
     del c2, s2, th
     gc.collect(); time.sleep(2.1)   # (gone, or at least silent for two seconds)
     s1.compute_residual_and_Hessian(spd=True)
     x, st = c1.solve(b1.clone())
-    assert st["flag"] == 0 and c1.direct_counters()["flow_launches"] > n0
+    assert st["flag"] == 0 and c1.direct_counters()["flow_launches"] > n0, (st, n0, c1.direct_counters())
