@@ -289,7 +289,10 @@ def test_two_contexts_share_the_device_without_dataflow_launches():
     s2.compute_residual_and_Hessian(spd=True)
     b2 = s2.F.to_torch().clone()
     xs2 = spl.splu(c2.operator_csr().tocsc()).solve(b2.cpu().numpy())
-    c2.solve(b2.clone())                     # the neighbour's first factorisation (it sees context 1 active: no dataflow launch)
+    c2.solve(b2.clone())                     # the neighbour's first factorisation (alone on the device if setting it up took more than two seconds)
+    s1.compute_residual_and_Hessian(spd=True)
+    c1.solve(b1.clone())                     # context 1 is active from here on: the concurrent phase starts within milliseconds
+    n0, m0 = c1.direct_counters()["flow_launches"], c2.direct_counters()["flow_launches"]
     out = {}
 
     a_done, b_running = threading.Event(), threading.Event()
@@ -315,7 +318,7 @@ def test_two_contexts_share_the_device_without_dataflow_launches():
     assert all(f == 0 and e < 1e-9 for f, e in out["a"] + out["b"]), out
     k1, k2 = c1.direct_counters(), c2.direct_counters()
     assert k1["flow_aborts"] == 0 and k2["flow_aborts"] == 0, (k1, k2)
-    assert k1["flow_launches"] == n0 and k2["flow_launches"] == 0, (n0, k1, k2, len(out["a"]), len(out["b"]))
+    assert k1["flow_launches"] == n0 and k2["flow_launches"] == m0, (n0, m0, k1, k2, len(out["a"]), len(out["b"]))   # none during the concurrent phase
     del c2, s2, th
     gc.collect(); time.sleep(2.1)   # (gone, or at least silent for two seconds)
     s1.compute_residual_and_Hessian(spd=True)
