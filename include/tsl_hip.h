@@ -240,7 +240,8 @@ int tsl_bench_spmv(tsl_ctx* ctx, int variant, int reps, double* us_per_launch_ho
  * seconds in plan builds, supernodes, levels, batches, flops per factorisation, bytes of fronts (panels + Schur complements)}.
  * tsl_direct_counters: the first n of {dataflow launches, dataflow launches that lost a flag (redone on the block-step path), plan-cache
  * hits, bytes of the panel arena (cleared per factorisation), of the Schur arena, of the G arena, Schur-complement entries stored per
- * factorisation, plans parked in the cache}. */
+ * factorisation, plans parked in the cache, first passes of refined solves whose normwise backward error |b - Hx| / (|H|_inf |x| + |b|)
+ * was evaluated, first passes accepted on it ("direct_berr", default 1e-12), largest backward error / forward residual so accepted}. */
 int tsl_bench_direct(tsl_ctx* ctx, int cls, int reps, double* out4_host);
 int tsl_direct_info(tsl_ctx* ctx, double* out10_host);
 int tsl_direct_counters(tsl_ctx* ctx, double* out_host, int32_t n);

@@ -1,0 +1,10 @@
+#!/bin/bash
+# gpurun with retries while no box / slot is free (exit code 3): scripts/gr.sh <timeout-seconds> '<command>'
+T=$1; shift
+for i in $(seq 1 30); do
+  /usr/local/graft/bin/gpurun --timeout $T -- "$@"
+  rc=$?
+  if [ $rc -ne 3 ]; then exit $rc; fi
+  sleep 90
+done
+exit 3

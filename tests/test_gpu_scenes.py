@@ -621,25 +621,30 @@ def test_cmaes_parameter_driver(tmp_path, monkeypatch):
 
 def test_reference_state_projection_query_on_gpu():
     """REFERENCE OUTPUT through the C ABI: the reference's saved balancing state (tests/golden/balance_state, written by
-    Scene_balancing.save_all of the reference engine) with the flags its projection_query left (geometry.py:96-229).  The HIP broad /
-    narrow phase on the saved positions reproduces the flags of the five FEM bodies exactly and proj_dir on every vertex flagged in
-    both; on the cloth body a handful of entries differ (the flags belong to the start of the reference's last step, the positions
-    to its end) -- the same entries as in the CPU restatement (tests/test_oracle_pinning.py)."""
+    Scene_balancing.save_all of the reference engine) with the flags its projection_query left (geometry.py:96-229) at the START of its
+    last step.  The HIP broad / narrow phase on the start-of-step positions (x - v dt, exact with damping = 1) reproduces the flags of
+    the five FEM bodies exactly, proj_dir on every vertex flagged in both, and the cloth-as-target row up to the one cell-boundary triangle
+    of tests/test_oracle_pinning.py (ten pad vertices, candidate [109, 108, 116] whose centroid lies 8.9 um from a cell face), asserted as that."""
+    import torch
+    from helpers import assert_cloth_target_mismatches_are_the_cell_boundary_triangle
     from thinshelllab_amd.task_scene.Scene_balancing import Scene
     from thinshelllab_amd.engine.geometry import projection_query
     g = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "balance_state")
     s = Scene(cloth_size=0.06)
     s.init_all()
     s.load_state(os.path.join(g, "state"))
+    s.pos.t.copy_(s.pos.t - s.vel.t * s.dt)
     s.prev_pos.copy_from(s.pos)
+    x = s.pos.to_numpy().copy()
     ctx = s._ensure_ctx()
     ctx.contact_reset()
     projection_query(s)
-    flag, dr, _, _ = ctx.proj_export()
+    flag, dr, pidx, _ = ctx.proj_export()
     F = np.load(os.path.join(g, "proj_flag.npy")); D = np.load(os.path.join(g, "proj_dir.npy"))
     assert flag.shape == F.shape == (6, 1332)
     assert np.array_equal(flag[1:], F[1:]) and flag[1:].sum(1).tolist() == [14, 151, 159, 153, 155]
-    assert (flag[0] != F[0]).sum() <= 20
+    mm = assert_cloth_target_mismatches_are_the_cell_boundary_triangle(flag[0], F[0], pidx[0], x)
+    assert len(mm) == 10
     both = (flag == 1) & (F == 1)
     assert both.sum() >= 1600 and np.array_equal(dr[both], D[both])
     # load_all restores the reference's latched flags for a continued rollout

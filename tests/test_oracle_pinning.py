@@ -390,23 +390,27 @@ def test_reference_state_pins_pad_placement_and_gripper_frames():
 
 def test_reference_state_pins_projection_query(oracle):
     """REFERENCE OUTPUT: proj_flag / proj_dir of data/balance_state were produced by the reference's projection_query
-    (geometry.py:96-229) during its last time step.  The restated query on the saved positions reproduces the flags of the five
-    FEM bodies exactly (14 / 151 / 159 / 153 / 155 vertices) and the side flag proj_dir on every vertex flagged in both.  On the
-    cloth body 16 of 1332 entries differ: the reference saved the state AFTER the step whose start the flags belong to, so vertices
-    at the edge of the 3 x 3 x 3 cell neighbourhood have moved across it."""
-    import torch
+    (geometry.py:96-229) at the START of its last time step; the saved positions are those at its END, the saved velocities give the
+    start exactly (x - v dt, damping = 1).  The restated query there reproduces the flags of the five FEM bodies exactly (14 / 151 / 159 /
+    153 / 155 vertices), proj_dir on every vertex flagged in both, and the cloth-as-target row up to ONE cell-boundary triangle: ten pad
+    vertices whose candidate is the cloth triangle [109, 108, 116] (centroid 8.9 um above the z = 0 cell face) are flagged here and not in the
+    reference -- asserted as exactly that.  (On the end-of-step positions 16 entries differ: six more vertices crossed their neighbourhood
+    during the step.)"""
     from oracle.mirror import oracle_from_scene
     s = _balancing_host_scene()
     o = oracle_from_scene(oracle, s, check_init=True)
     g = os.path.join(GOLD, "balance_state")
-    pos = torch.load(os.path.join(g, "state"), weights_only=False)["pos"].numpy()
-    o.pos[:] = pos; o.prev_pos[:] = pos; o.push_down_all()
+    from helpers import start_of_step_positions, assert_cloth_target_mismatches_are_the_cell_boundary_triangle
+    x = start_of_step_positions(g, s.dt)
+    o.pos[:] = x; o.prev_pos[:] = x; o.push_down_all()
     o.calc_vn(); o.projection_query()
     flag = o.arr("proj_flag").reshape(-1, s.tot_NV); dr = o.arr("proj_dir").reshape(-1, s.tot_NV)
+    pidx = o.arr("proj_idx").reshape(6, s.tot_NV, 3)
     F = np.load(os.path.join(g, "proj_flag.npy")); D = np.load(os.path.join(g, "proj_dir.npy"))
     assert flag.shape == F.shape == (6, 1332)
     assert flag[1:].sum(1).tolist() == [14, 151, 159, 153, 155] and np.array_equal(flag[1:], F[1:])
-    assert (flag[0] != F[0]).sum() <= 20 and abs(int(flag[0].sum()) - 998) <= 10
+    mm = assert_cloth_target_mismatches_are_the_cell_boundary_triangle(flag[0], F[0], pidx[0], x)
+    assert len(mm) == 10 and int(flag[0].sum()) == 998 + 10
     both = (flag == 1) & (F == 1)
     assert both.sum() >= 1600 and np.array_equal(dr[both], D[both])
 

@@ -154,6 +154,11 @@ struct DirectSolver {
   int gm_cap = 0;
   int dbg = 0;
   long n_stale = 0;
+  // "direct_berr": the first pass of a refined solve is accepted when its normwise backward error |b - Hx| / (|H|_inf |x| + |b|) is at most this
+  // (0: forward-residual rule only) and its forward residual at most "direct_berr_rel_cap" x cg_tol (direct_refine)
+  double berr_tol = 1e-12, berr_rel_cap = 50.0;
+  long berr_seen = 0, berr_accepted = 0;
+  double berr_max = 0, berr_rel_max = 0;   // largest backward error / forward residual accepted under the rule
   int refine_ir = 1;           // "direct_refine": 1 = classic iterative refinement with the factors (GMRES only where it stalls), 0 = flexible GMRES from the start
   int n_setup_fail = 0;        // set-up failures of the direct path in automatic mode (three disable it)
   std::vector<std::unique_ptr<DsPlanSlot>> cache;   // plans of earlier constraint sets ("direct_plan_cache" slots, least recently used evicted)
@@ -175,7 +180,8 @@ struct DirectSolver {
   long n_plans = 0, n_factor = 0, n_apply = 0, n_perturbed = 0;
   double t_plan = 0;          // host seconds spent in plan builds
   double anorm = 0;           // infinity norm of the factorised operator's static part (backward-error yardstick)
-  bool anorm_valid = false;   // anorm belongs to the operator of the last factorisation
+  bool anorm_valid = false;   // anorm belongs to an operator at most 64 factorisations old
+  int anorm_age = 0;
   DevBuf<double> anorm_dev;
   hipEvent_t ev0 = nullptr, ev1 = nullptr;
 };
