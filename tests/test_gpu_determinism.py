@@ -13,13 +13,10 @@ pytestmark = pytest.mark.gpu
 GOLD = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
 
 
-def rollout(name, T, grid=None, direct=1):
-    """one fresh scene, T - 1 driven steps, the reverse sweep.  Which kernels factorise depends on the neighbourhood: while another
-    context of the process factorised on the device within the last two seconds the persistent dataflow launches are off
-    (direct_host.hpp) and the block-step kernels round differently -- so the scene starts in a quiet process."""
+def rollout(name, T, grid=None, direct=1, params=()):
+    """one fresh scene, T - 1 driven steps, the reverse sweep.  Which kernels invert the pivot blocks depends on the neighbourhood (the
+    dataflow token of the device, direct_host.hpp) -- and no longer matters: every path gives the same bits (tests/test_gpu_direct.py)."""
     import gc
-    import time
-    gc.collect(); time.sleep(2.2)
     from thinshelllab_amd.engine.analytic_grad_single import Grad
     from thinshelllab_amd.engine.geometry import projection_query
     if name == "balancing":
@@ -35,6 +32,8 @@ def rollout(name, T, grid=None, direct=1):
     s.prev_pos.copy_from(s.pos)
     ctx = s._ensure_ctx()
     ctx.set_param("direct", direct)
+    for key, v in params:
+        ctx.set_param(key, v)
     n_part = s.gripper.n_part
     g = Grad(s, T, n_part); g.init_mass(s)
     g.copy_pos(s, 0)
@@ -57,7 +56,7 @@ def rollout(name, T, grid=None, direct=1):
         g.transfer_grad(k, s, projection_query)
     out = dict(pos_buffer=g.pos_buffer.to_numpy().copy(), pos_grad=g.pos_grad.to_numpy().copy(), gripper_grad=g.gripper_grad.to_numpy().copy(),
                angleref_grad=g.angleref_grad.to_numpy().copy(), stats=np.array(stats, dtype=np.float64))
-    out["flow_launches"] = np.array([ctx.direct_counters()["flow_launches"]])
+    rollout.last_flow_launches = ctx.direct_counters()["flow_launches"]
     del g, s, ctx
     gc.collect()
     return out
@@ -79,8 +78,7 @@ def test_two_runs_give_the_same_bits(name):
 def _sysid_sweep(name):
     """system identification (analytic_grad_system.Grad): 3 driven steps, reverse sweep with the parameter gradients"""
     import gc
-    import time
-    gc.collect(); time.sleep(2.2)
+    gc.collect()
     from thinshelllab_amd.engine.analytic_grad_system import Grad
     from thinshelllab_amd.engine.geometry import projection_query
     if name == "balancing":
@@ -121,6 +119,20 @@ def test_system_identification_sweep_gives_the_same_bits(name):
     assert np.abs(a["params"][:2]).min() > 0
     for k in a:
         assert np.array_equal(a[k], b[k]), f"{name}: {k} differs between two runs: {a[k] if a[k].size < 8 else ''} {b[k] if b[k].size < 8 else ''}"
+
+
+def test_rollout_bits_do_not_depend_on_the_inversion_path():
+    """the same rollout with the pivot blocks inverted by the persistent dataflow launches (default, if this process holds the device's
+    token), by one launch per block step ("direct_flow" 0), and without the LDS kernel either: the same bits in tape and gradients (round 5:
+    every path forms the same products in the same order)"""
+    a = rollout("balancing", 4, grid=96)
+    fl = rollout.last_flow_launches
+    b = rollout("balancing", 4, grid=96, params=(("direct_flow", 0),))
+    assert rollout.last_flow_launches == 0
+    c = rollout("balancing", 4, grid=96, params=(("direct_flow", 0), ("direct_small_rounds", 1)))
+    assert fl > 0, "the default rollout did not run a dataflow launch (token held by a context that is still alive?)"
+    for k in a:
+        assert np.array_equal(a[k], b[k]) and np.array_equal(a[k], c[k]), f"{k}: max |d| = {np.abs(a[k] - b[k]).max():.3e} / {np.abs(a[k] - c[k]).max():.3e}"
 
 
 def test_cfg4_steps_are_reproducible_at_full_size():

@@ -8,27 +8,39 @@
 #include "k_direct.hpp"
 #include "tsl_ctx.hpp"
 
-// Registry of the contexts of this process that factorise: (context, device, time of its last factorisation).  A context whose neighbour on
-// the same device factorised within the last two seconds keeps its persistent dataflow launches off (direct_factor / ds_flow_prepare);
-// stale contexts -- scene objects nobody steps any more -- do not count.
-#include <mutex>
-struct DsActivity { std::mutex mu; struct E { const void* ctx; int dev; long long ns; }; std::vector<E> e; };
-static DsActivity g_ds_activity;
-static bool ds_mark_active(const void* ctx, int dev) {   // -> is another context active on `dev`?
-  const long long now = std::chrono::duration_cast<std::chrono::nanoseconds>(std::chrono::steady_clock::now().time_since_epoch()).count();
-  std::lock_guard<std::mutex> lk(g_ds_activity.mu);
-  bool mine = false, other = false;
-  for (auto& x : g_ds_activity.e) {
-    if (x.ctx == ctx) { x.ns = now; x.dev = dev; mine = true; }
-    else if (x.dev == dev && now - x.ns < 2000000000LL) other = true;
+// The dataflow token of a device: an advisory lock (flock on /dev/shm/tsl_flow_<PCI bus id>; a lock belongs to an open file description, so it
+// excludes other contexts of this process and other processes alike).  The persistent launch k_ds_gj_flow needs every one of its workgroups
+// resident; two such grids on one device -- two contexts of a process, two ranks on one GPU -- can each fit and together not, and then both
+// wait for flags that never come.  So a context launches the kernel only while it holds the token; it asks for it at its first eligible
+// factorisation and keeps it until it is destroyed, a context that was refused asks again every 256 factorisations (the holder may be gone)
+// and runs the same block steps as one launch each meanwhile.  Every inversion path produces the same bits (k_direct.hpp), so which
+// context holds the token changes times, not answers.
+#include <fcntl.h>
+#include <sys/file.h>
+#include <sys/stat.h>
+#include <unistd.h>
+static void ds_flow_token_acquire(DirectSolver& d) {
+  char bus[64] = "dev";
+  if (hipDeviceGetPCIBusId(bus, sizeof(bus), d.device) != hipSuccess) { (void)hipGetLastError(); snprintf(bus, sizeof(bus), "dev%d", d.device); }
+  for (char* q = bus; *q; q++) if (*q == ':' || *q == '/') *q = '_';
+  d.flow_token = -1; d.flow_token_asked = d.n_factor;
+  for (const char* dir : {"/dev/shm", "/tmp"}) {
+    const std::string path = std::string(dir) + "/tsl_flow_" + bus;
+    const int fd = open(path.c_str(), O_CREAT | O_RDWR | O_CLOEXEC, 0666);
+    if (fd < 0) continue;
+    (void)fchmod(fd, 0666);   // (another user's process must be able to open it)
+    if (flock(fd, LOCK_EX | LOCK_NB) == 0) { d.flow_token = 1; d.flow_token_fd = fd; }
+    else close(fd);
+    return;   // (the first directory that can hold the file decides: every process looks there first)
   }
-  if (!mine) g_ds_activity.e.push_back({ctx, dev, now});
-  return other;
 }
-static void ds_forget(const void* ctx) {
-  std::lock_guard<std::mutex> lk(g_ds_activity.mu);
-  auto& v = g_ds_activity.e;
-  v.erase(std::remove_if(v.begin(), v.end(), [&](const DsActivity::E& x) { return x.ctx == ctx; }), v.end());
+static void ds_flow_token_release(DirectSolver& d) {
+  if (d.flow_token_fd >= 0) { (void)flock(d.flow_token_fd, LOCK_UN); close(d.flow_token_fd); }
+  d.flow_token_fd = -1; d.flow_token = 0;
+}
+static bool ds_flow_token_held(DirectSolver& d) {
+  if (d.flow_token == 0 || (d.flow_token < 0 && d.n_factor - d.flow_token_asked >= 256)) ds_flow_token_acquire(d);
+  return d.flow_token > 0;
 }
 
 static inline int ds_nblk(long n, int b) { return (int)((n + b - 1) / b); }
@@ -37,16 +49,16 @@ static inline int ds_nblk(long n, int b) { return (int)((n + b - 1) / b); }
 // `ds_small_rounds` rounds (workgroups per CU by LDS: 4.5 KB of static arrays of the tile inversion on top of the block -- two at 96
 // pivots, one at 128); a larger batch has enough tile parallelism for the block-step kernel (round 2: 1024 fronts of 96 pivots 322 us
 // at one workgroup per CU against ~190 us tile-parallel)
-static int ds_small_rounds = 2;   // "direct_small_rounds": 847 leaf fronts of 96 pivots 139.5 us in two rounds of the LDS kernel against 204 us on the block-step path (5 launches)
-static inline bool ds_use_small(const DsBatch& b) {
+// ("direct_small_rounds", default 2: 847 leaf fronts of 96 pivots 139.5 us in two rounds of the LDS kernel against 204 us on the block-step path, 5 launches)
+static inline bool ds_use_small(const DirectSolver& d, const DsBatch& b) {
   if (b.max_pp > DS_SMALL) return false;
-  return (size_t)b.count <= (size_t)256 * ds_small_per_cu(b.max_pp) * (size_t)ds_small_rounds;
+  return (size_t)b.count <= (size_t)d.plan.n_cu * ds_small_per_cu(b.max_pp) * (size_t)d.small_rounds;
 }
 
 // G = W F12 (mode 0) / S = sum_children ext(S_child) - F21 G, stored (mode 1) of a batch: 64 x 64 output tiles; "direct_g32_below": G of a
 // batch with few 64 x 64 tiles (upper levels) in 32 x 32 tiles, four times the workgroups
-static int ds_xcd_map = 64;   // "direct_xcd": batches of at least this many fronts launch their GEMM tiles with the XCD-aware map (k_ds_gemm_x: a front per XCD); 0: never
-static void ds_launch_gemm(hipStream_t s, const DsDev& D, const DsBatch& b, int mode, int wpc, int ds_g32_below = 0) {
+// "direct_xcd" (DirectSolver::xcd_map): batches of at least this many fronts launch their GEMM tiles with the XCD-aware map (k_ds_gemm_x: a front per XCD); 0: never
+static void ds_launch_gemm(hipStream_t s, const DsDev& D, const DsBatch& b, int mode, int wpc, int ds_xcd_map, int ds_g32_below = 0) {
   const int rows = mode == 0 ? b.max_pp : b.max_bp, cols = b.max_bp;
   const dim3 grid((cols + 63) / 64, (rows + 63) / 64, b.count);
   const long tiles = (long)grid.x * grid.y * grid.z;
@@ -95,55 +107,54 @@ static void ds_launch_level_start(tsl_ctx* c, hipStream_t s, const DsDev& D, int
 // persistent grid next to it; ordinary launches of sibling batches end by themselves), of at most DS_FLOW_MAXF fronts, whose tiles are all resident at once.  Fills the launch
 // arguments and grows the exchange buffers; false = the batch stays on the launch-per-block-step path.
 // could this batch take the dataflow path (no side effects: direct_bench asks for the earlier batches of a level)?
+static long ds_flow_wgs(const DirectPlan& P, const DsBatch& b) {   // workgroups of the batch's dataflow launch: a super-tile of DS_FLOW_B x DS_FLOW_B tiles each
+  long n = 0;
+  for (int z = 0; z < b.count; z++) { const long ns = (P.fr[P.level_sn[b.first + z]].pp / DS_T + DS_FLOW_B - 1) / DS_FLOW_B; n += ns * ns; }
+  return n;
+}
 static bool ds_flow_eligible(DirectSolver& d, const DirectPlan& P, const DsBatch& b, hipStream_t s) {
   if (!d.flow || b.count > DS_FLOW_MAXF || b.max_pp < 2 * DS_T) return false;
-  if (d.shared_device) return false;   // another context of this process is working on the device (direct_factor)
   { hipStreamCaptureStatus cs = hipStreamCaptureStatusNone;   // a captured launch would be replayed with ONE epoch: flags of the previous replay would pass
     if (hipStreamIsCapturing(s, &cs) != hipSuccess || cs != hipStreamCaptureStatusNone) return false; }
-  if (ds_use_small(b) && !(d.flow & 2)) return false;   // bit 1: also the batches the LDS kernel would take (64 / 32 fronts of <= 128 pivots on levels 3 and 4 of cfg4)
-  if (d.flow_cap[0] == 0) {
-    int occ4 = 0, occ5 = 0, dev = 0;
+  if (!ds_flow_token_held(d)) return false;   // another context / process launches the persistent kernel on this device
+  if (ds_use_small(d, b) && !(d.flow & 2)) return false;   // bit 1: also the batches the LDS kernel would take (64 / 32 fronts of <= 128 pivots on levels 3 and 4 of cfg4)
+  if (d.flow_cap == 0) {
+    int occ = 0, dev = 0;
     hipDeviceProp_t prop;
     if (hipGetDevice(&dev) != hipSuccess || hipGetDeviceProperties(&prop, dev) != hipSuccess ||
-        hipOccupancyMaxActiveBlocksPerMultiprocessor(&occ4, (const void*)k_ds_gj_flow<4>, 256, 0) != hipSuccess ||
-        hipOccupancyMaxActiveBlocksPerMultiprocessor(&occ5, (const void*)k_ds_gj_flow<5>, 256, 0) != hipSuccess) { d.flow_cap[0] = d.flow_cap[1] = -1; return false; }
-    d.flow_cap[0] = std::max(1, occ4 * prop.multiProcessorCount);
-    d.flow_cap[1] = std::max(1, occ5 * prop.multiProcessorCount);
-    if (getenv("TSL_FLOW_DEBUG")) fprintf(stderr, "[tsl] k_ds_gj_flow: %d / %d workgroups per CU x %d CUs resident\n", occ4, occ5, prop.multiProcessorCount);
+        hipOccupancyMaxActiveBlocksPerMultiprocessor(&occ, (const void*)k_ds_gj_flow<DS_FLOW_B>, 256, 0) != hipSuccess) { d.flow_cap = -1; return false; }
+    d.flow_cap = std::max(1, occ * prop.multiProcessorCount);
+    if (getenv("TSL_FLOW_DEBUG")) fprintf(stderr, "[tsl] k_ds_gj_flow: %d workgroups per CU x %d CUs resident\n", occ, prop.multiProcessorCount);
   }
-  long tiles = 0;
-  for (int z = 0; z < b.count; z++) { const long nt = P.fr[P.level_sn[b.first + z]].pp / DS_T; tiles += nt * nt; }
-  return tiles <= d.flow_cap[1] && tiles >= 4;
+  return ds_flow_wgs(P, b) <= d.flow_cap;
 }
-static int ds_flow_prepare(DirectSolver& d, const DirectPlan& P, const DsBatch& b, bool flow_free, DsFlowArgs& a, hipStream_t s) {   // -> workgroups per CU of the instantiation to launch (4 / 5), 0 = not on this path
-  if (!flow_free || !ds_flow_eligible(d, P, b, s)) return 0;
-  long tiles = 0, x = 0, fl = 0;
+static bool ds_flow_prepare(DirectSolver& d, const DirectPlan& P, const DsBatch& b, bool flow_free, DsFlowArgs& a, hipStream_t s) {   // false = not on this path
+  if (!flow_free || !ds_flow_eligible(d, P, b, s)) return false;
+  long wgs = 0, x = 0, fl = 0;
   for (int z = 0; z < b.count; z++) {
-    const long nt = P.fr[P.level_sn[b.first + z]].pp / DS_T;
-    a.tile0[z] = (int)tiles; a.xoff[z] = x; a.foff[z] = (int)fl;
-    tiles += nt * nt; x += (nt + 2 * nt * nt) * (DS_T * DS_T); fl += 32 * nt + 2 * nt * nt;
+    const long nt = P.fr[P.level_sn[b.first + z]].pp / DS_T, ns = (nt + DS_FLOW_B - 1) / DS_FLOW_B;
+    a.tile0[z] = (int)wgs; a.xoff[z] = x; a.foff[z] = (int)fl;
+    wgs += ns * ns; x += (nt + 2 * nt * nt) * (DS_T * DS_T); fl += 32 * nt + 2 * nt * nt;
   }
-  a.tile0[b.count] = (int)tiles; a.nf = b.count;
-  if (tiles > d.flow_cap[1] || tiles < 4) return 0;
-  if (d.flow_x.n < (size_t)x) { if (d.flow_x.alloc((size_t)x)) return 0; }
+  a.tile0[b.count] = (int)wgs; a.nf = b.count;
+  if (d.flow_x.n < (size_t)x) { if (d.flow_x.alloc((size_t)x)) return false; }
   if (d.flow_f.n < (size_t)fl) {   // flags start below every epoch
-    if (d.flow_f.alloc((size_t)fl + 1024)) return 0;
+    if (d.flow_f.alloc((size_t)fl + 1024)) return false;
     // on the stream of the launch: a hipMemset on the null stream is not ordered against a non-blocking stream (seen once: the
     // first launch of a fresh context started before the clear had run and lost its flags)
-    if (hipMemsetAsync(d.flow_f.p, 0, d.flow_f.n * sizeof(int), s) != hipSuccess) return 0;   // (the epoch keeps counting: zero is below every epoch)
+    if (hipMemsetAsync(d.flow_f.p, 0, d.flow_f.n * sizeof(int), s) != hipSuccess) return false;   // (the epoch keeps counting: zero is below every epoch)
   }
   a.epoch = ++d.flow_epoch;
-  return tiles <= d.flow_cap[0] ? 4 : 5;   // the fifth workgroup per CU costs 15 spilled registers: only for a root beyond 1024 tiles
+  return true;
 }
 // The launch must be resident as a whole (its workgroups wait for each other's flags).  Inside ONE context the host guarantees that by
-// running it alone on its level; while ANOTHER context of this process is factorising on the device too (several scenes per GPU) the path
-// is off (direct_factor / ds_flow_prepare: the other context's launches keep workgroup slots occupied for as long as it has work, measured round 4: both
-// contexts of a two-scene run lost a flag within their first steps, and chaining the persistent launches through an event did not
-// prevent it).  Other PROCESSES on the same device are not visible from here: there a launch that cannot become resident runs into
-// DS_FLOW_SPINS, raises bad[DS_FLOW_ABORT], and the solve refactorises on the launch-per-block-step path (solve_perm).
-static void ds_flow_launch(hipStream_t s, const DsDev& D, int lv0, const DsFlowArgs& fa, int wpc, DirectSolver& d) {
-  if (wpc == 4) hipLaunchKernelGGL(k_ds_gj_flow<4>, dim3(fa.tile0[fa.nf]), dim3(256), 0, s, D, lv0, fa, d.flow_x.p, d.flow_f.p);
-  else hipLaunchKernelGGL(k_ds_gj_flow<5>, dim3(fa.tile0[fa.nf]), dim3(256), 0, s, D, lv0, fa, d.flow_x.p, d.flow_f.p);
+// running one such launch per level.  ACROSS contexts and processes the device's dataflow token does (ds_flow_token_*, tsl_ctx_create): the
+// context that holds it is the only one on the device that launches this kernel, for as long as it lives; every other context runs the same
+// block steps as one launch each (k_ds_gj_step) and gets the same bits.  A launch that still cannot become resident (a foreign process that
+// does not take part in the protocol) runs into DS_FLOW_SPINS, raises bad[DS_FLOW_ABORT], and the solve refactorises on the
+// launch-per-block-step path (solve_perm).
+static void ds_flow_launch(hipStream_t s, const DsDev& D, int lv0, const DsFlowArgs& fa, DirectSolver& d) {
+  hipLaunchKernelGGL(k_ds_gj_flow<DS_FLOW_B>, dim3(fa.tile0[fa.nf]), dim3(256), 0, s, D, lv0, fa, d.flow_x.p, d.flow_f.p);
 }
 
 static bool direct_enabled(tsl_ctx* c) {
@@ -158,6 +169,7 @@ static DsDev ds_dev(tsl_ctx* c) {
   DirectSolver& d = c->ds;
   DsDev D;
   D.fr = d.fr.p; D.frl = d.frl.p; D.level_sn = d.level_sn.p; D.A = d.arena.p; D.S = d.sarena.p; D.Y = d.w.p; D.G = d.garena.p; D.scr = d.scr.p; D.ch = d.ch_rec.p; D.pmap = d.pmap.p; D.vtx = d.vtx.p; D.bad = d.bad.p; D.dbg = d.dbg; D.piv_tol = d.piv_tol;
+  D.tlog = (d.dbg == 30 && d.tlog.n >= 1024) ? d.tlog.p : nullptr;
   return D;
 }
 
@@ -213,6 +225,8 @@ static int direct_static(tsl_ctx* c) {
   d.h_c2s = c2s;   // (SELL address of every CSR block: the plan uploads bake it into their level-ordered lists)
   if (d.bad.alloc(8 + 4 * DS_BADLOG)) return -1;
   HIP_OK(hipFuncSetAttribute((const void*)k_ds_inv_small, hipFuncAttributeMaxDynamicSharedMemorySize, (int)ds_small_lds(DS_SMALL)));
+  { hipDeviceProp_t prop;   // compute units of THIS device: rounds of the LDS kernel, remainder rule of the batches (was a constant 256)
+    if (hipGetDeviceProperties(&prop, d.device) == hipSuccess && prop.multiProcessorCount > 0) d.plan.n_cu = prop.multiProcessorCount; else (void)hipGetLastError(); }
   d.plan.sym.build_partition(NV, c->h_rows, d.grids, d.blocks, d.leaf);
   d.cache.clear();   // parked plans belong to the previous partition
   d.static_ready = true;
@@ -378,7 +392,7 @@ static int direct_plan(tsl_ctx* c) {
   if (c->verbose >= 2) fprintf(stderr, "[tsl]   plan phases (ms): tree %.2f, descriptors + parent maps %.2f, levels %.2f, static block map %.2f, contact map %.2f\n", P.phase_ms[0], P.phase_ms[1], P.phase_ms[2], P.phase_ms[3], P.phase_ms[4]);
   if (c->verbose >= 3)
     for (const DsBatch& b : P.batches) {
-      fprintf(stderr, "[tsl]   level %2d: %5d fronts, pivots <= %4d, boundary <= %4d%s; fronts by padded pivot count:", b.level, b.count, b.max_pp, b.max_bp, ds_use_small(b) ? " (LDS kernel)" : "");
+      fprintf(stderr, "[tsl]   level %2d: %5d fronts, pivots <= %4d, boundary <= %4d%s; fronts by padded pivot count:", b.level, b.count, b.max_pp, b.max_bp, ds_use_small(d, b) ? " (LDS kernel)" : "");
       for (int q = 0, run = 0; q < b.count; q++) {   // (sorted by pp, descending)
         run++;
         if (q + 1 == b.count || P.fr[P.level_sn[b.first + q + 1]].pp != P.fr[P.level_sn[b.first + q]].pp) { fprintf(stderr, " %d x %d", run, P.fr[P.level_sn[b.first + q]].pp); run = 0; }
@@ -430,7 +444,6 @@ static int direct_factor(tsl_ctx* c, int stop_sn = -1, const char* dump_path = n
   hipStream_t s = c->stream;
   TSL_TRY(direct_plan(c));
   if (d.numeric_valid) return 0;
-  d.shared_device = ds_mark_active(c, d.device);   // is a neighbour context at work on this device?
   const DirectPlan& P = d.plan;
   const DsDev D = ds_dev(c);
   if (d.prezero_pending) {   // cleared on the side stream since the last solve (direct_prezero)
@@ -444,16 +457,16 @@ static int direct_factor(tsl_ctx* c, int stop_sn = -1, const char* dump_path = n
     const int lv0 = b.first, nf = b.count;
     const int tp = b.max_pp / DS_T, tb = b.max_bp / DS_T;
     DsFlowArgs fa;
-    if (const int wpc = ds_flow_prepare(d, P, b, flow_free, fa, bs)) { ds_flow_launch(bs, D, lv0, fa, wpc, d); d.n_flow++; flow_free = false; }
-    else if (ds_use_small(b)) hipLaunchKernelGGL(k_ds_inv_small, dim3(nf), dim3(256), ds_small_lds(b.max_pp), bs, D, lv0, b.max_pp + 1);
+    if (ds_flow_prepare(d, P, b, flow_free, fa, bs)) { ds_flow_launch(bs, D, lv0, fa, d); d.n_flow++; flow_free = false; }
+    else if (ds_use_small(d, b)) hipLaunchKernelGGL(k_ds_inv_small, dim3(nf), dim3(256), ds_small_lds(b.max_pp), bs, D, lv0, b.max_pp + 1);
     else {
       hipLaunchKernelGGL(k_ds_pivot0, dim3(nf), dim3(256), 0, bs, D, lv0);
       for (int k = 0; k < tp; k++) { const int na = P.act_n[b.act_off + k]; hipLaunchKernelGGL(k_ds_gj_step, dim3(na + na * tp * tp), dim3(256), 0, bs, D, lv0, k, tp, na); }   // fronts are sorted by pp: the active ones are a prefix
       hipLaunchKernelGGL(k_ds_gj_finish, dim3(tp, nf), dim3(256), 0, bs, D, lv0);
     }
     if (tb > 0) {
-      ds_launch_gemm(bs, D, b, 0, d.gemm_wpc, d.g32_below);
-      ds_launch_gemm(bs, D, b, 1, d.gemm_wpc, d.s32_below);
+      ds_launch_gemm(bs, D, b, 0, d.gemm_wpc, d.xcd_map, d.g32_below);
+      ds_launch_gemm(bs, D, b, 1, d.gemm_wpc, d.xcd_map, d.s32_below);
     }
   };
   // The fronts of a level are independent: where a level was split into batches (by pivot-block size) the batches run on parallel
@@ -501,6 +514,25 @@ static int direct_factor(tsl_ctx* c, int stop_sn = -1, const char* dump_path = n
   // few per cent between them, the quantity it is compared with spans five decades
   if (++d.anorm_age >= 64) d.anorm_valid = false;
   if (stop_sn >= 0 || c->verbose >= 2) HIP_OK(hipStreamSynchronize(s));
+  if (d.dbg == 30) {   // diagnostic: when did the pivots of the LAST dataflow launch's first front get published, when did two far workgroups finish each step
+    if (d.tlog.n < 1024) { if (d.tlog.alloc(1024)) return -1; HIP_OK(hipMemset(d.tlog.p, 0, 1024 * sizeof(unsigned long long))); HIP_OK(hipMemset(d.tlog.p + 194, 0xff, sizeof(unsigned long long))); }
+    else {
+      unsigned long long h[1024];
+      HIP_OK(hipStreamSynchronize(s));
+      HIP_OK(hipMemcpy(h, d.tlog.p, sizeof(h), hipMemcpyDeviceToHost));
+      int khz = 100000;
+      (void)hipDeviceGetAttribute(&khz, hipDeviceAttributeWallClockRate, d.device);
+      auto us = [&](unsigned long long t) { return t ? (double)(long long)(t - h[192]) * 1e3 / khz : -1.0; };
+      fprintf(stderr, "[tsl] dataflow chain of the last launch (us since its start): pivot published | step finished by the last workgroup | by the first of the last super-row; first workgroup started at %.2f, last ended at %.2f\n", us(h[194]), us(h[193]));
+      for (int k = 0; k < 64 && (h[k] || h[64 + k]); k++) {
+        fprintf(stderr, "[tsl]   %2d  %8.2f (+%5.2f)   %8.2f   %8.2f   | owner of the pivot, relative to the publication of the previous one: flags seen, operands in LDS, R' done, tile updated, inverted:", k, us(h[k]), k ? us(h[k]) - us(h[k - 1]) : 0.0, us(h[64 + k]), us(h[128 + k]));
+        for (int i = 0; i < 5; i++) fprintf(stderr, " %6.2f", h[256 + 8 * k + i] && k ? us(h[256 + 8 * k + i]) - us(h[k - 1]) : 0.0);
+        fprintf(stderr, "\n");
+      }
+      HIP_OK(hipMemset(d.tlog.p, 0, 1024 * sizeof(unsigned long long)));
+      HIP_OK(hipMemset(d.tlog.p + 194, 0xff, sizeof(unsigned long long)));
+    }
+  }
   HIP_OK(hipGetLastError());
   d.numeric_valid = true;
   d.have_factor = true;
@@ -608,10 +640,10 @@ static int direct_bench(tsl_ctx* c, int cls, int reps, double* out) {
         bool flow_free = true;   // (one dataflow launch per level: the first batch of the level that can take it)
         for (int q = 0; q < bi; q++) if (P.batches[q].level == b.level && ds_flow_eligible(d, P, P.batches[q], s)) flow_free = false;
         DsFlowArgs fa;
-        const int flow = ds_flow_prepare(d, P, b, flow_free, fa, s);
-        const int mine = flow ? 5 : (ds_use_small(b) ? 3 : 0);   // the class direct_factor runs this batch in
+        const bool flow = ds_flow_prepare(d, P, b, flow_free, fa, s);
+        const int mine = flow ? 5 : (ds_use_small(d, b) ? 3 : 0);   // the class direct_factor runs this batch in
         if (mine != cls) continue;
-        if (cls == 5) { ds_flow_launch(s, D, lv0, fa, flow, d); if (count) launches++; }
+        if (cls == 5) { ds_flow_launch(s, D, lv0, fa, d); if (count) launches++; }
         else if (cls == 3) { hipLaunchKernelGGL(k_ds_inv_small, dim3(nf), dim3(256), ds_small_lds(b.max_pp), s, D, lv0, b.max_pp + 1); if (count) launches++; }
         else {
           hipLaunchKernelGGL(k_ds_pivot0, dim3(nf), dim3(256), 0, s, D, lv0);
@@ -625,7 +657,7 @@ static int direct_bench(tsl_ctx* c, int cls, int reps, double* out) {
           bytes += 16.0 * (double)f.pp * f.pp * (cls != 0 ? 1.0 : f.pp / (double)DS_T);   // the block read and written once per launch that touches it
         }
       } else if (tb > 0) {
-        if (cls == 1 || cls == 2) ds_launch_gemm(s, D, b, cls == 2 ? 0 : 1, d.gemm_wpc, cls == 2 ? d.g32_below : d.s32_below);
+        if (cls == 1 || cls == 2) ds_launch_gemm(s, D, b, cls == 2 ? 0 : 1, d.gemm_wpc, d.xcd_map, cls == 2 ? d.g32_below : d.s32_below);
         else continue;
         if (count) {
           launches++;

@@ -34,6 +34,7 @@ struct DsDev {                 // device views shared by the kernels
   int* bad;                    // [1..3]: perturbed pivots of the last factorisation by front size class, [4] + [8..]: log of the first ones
   double piv_tol;              // a pivot below piv_tol x its own scale is replaced by that bound
   int dbg;                     // timing experiments only ("ds_dbg"): 1 = the block-step kernel skips the pivot-tile inversion
+  unsigned long long* tlog;    // "ds_dbg" 30: device-clock stamps of the dataflow launch's first front (pivot publications [0, 64), steps finished by two far workgroups [64, 192), start [192]); else null
 };
 
 // infinity norm of the SELL-64 matrix (largest absolute row sum), the yardstick of the solve's backward error; out must be zeroed
@@ -522,8 +523,9 @@ TSL_DEV void ds_invert_tile_wg4(double* __restrict__ T, int ldt, int* __restrict
 
 // the form the factorisation kernels use (1: four-pivot elimination per block step, 2: cofactor form, 4: wave-specialised; A/B builds pass
 // -DDS_INV_FORM=n).  scripts/micro/inv_bench.hip: 5.58 / 4.88 / 4.29 us per tile, same accuracy (the cofactor forms do not perturb blocks
-// like [0 1; 1 0]).  Form 4 since the dataflow chains put the inversion on the critical path of every block step; the five-workgroups-per-CU
-// instantiation of k_ds_gj_flow keeps form 1 (form 4 spills 88 registers at 96: 587 against 354 us for the 1056-pivot root).
+// like [0 1; 1 0]).  Form 4 since the dataflow chains put the inversion on the critical path of every block step.  EVERY path of the
+// factorisation (k_ds_pivot0 / k_ds_gj_step, k_ds_gj_flow, k_ds_inv_small) inverts its pivot tiles with this one form and forms the same
+// products in the same order: the factors do not depend on which kernel a batch ran in (tests/test_gpu_direct.py asserts equal bits).
 #ifndef DS_INV_FORM
 #define DS_INV_FORM 4
 #endif
@@ -672,33 +674,41 @@ __global__ void __launch_bounds__(256) k_ds_gj_finish(DsDev D, int lv0) {
 
 // ---- dataflow form of the same block Gauss-Jordan: ONE persistent launch per batch ("direct_flow") --------------------------------
 // On the upper levels of the tree (1 - 16 fronts) a block step is a dependent launch of ~13.4 us of which the arithmetic is a fraction.
-// Here every workgroup KEEPS its 32 x 32 tile in registers (matrix-core result layout) over all block steps of its front and the steps
-// are ordered by point-to-point flags instead of kernel boundaries (`scripts/micro/flag_chain.hip`: a hop -- publish an 8 KB tile,
-// raise a flag, see it from another workgroup, fetch the tile -- is 2.1-2.5 us for 4 to 1024 workgroups):
+// Here the tiles stay in registers (matrix-core result layout) over all block steps of their front and the steps are ordered by
+// point-to-point flags instead of kernel boundaries (`scripts/micro/flag_chain.hip`: a hop -- publish an 8 KB tile, raise a flag, see it
+// from another workgroup, fetch the tile -- is 2.1-2.5 us for 4 to 1024 workgroups):
 //   * what another workgroup needs of a tile is PUBLISHED into an exchange slot with agent-scope (write-through) stores, the publisher
 //     waits for their completion and then raises the slot's flag to this launch's epoch; readers poll the flag and fetch the slot with
 //     agent-scope loads (no L2 invalidation: an acquire fence per workgroup and step costs 30 ns x the number of workgroups per hop);
 //   * tile (i, j) publishes twice at most: when step i is next (it lies in the row panel of that step) and when step j is next (column
-//     panel); the owner of the next pivot tile inverts it and publishes the inverse P[k + 1] -- the critical path of a step is
-//     fetch P[k] -> two 32^3 products -> inversion -> publication, the panel tiles it needs were published an inversion earlier;
+//     panel); the owner of the next pivot tile inverts it and publishes the inverse P[k + 1];
 //   * nobody but the owner reads the front itself, so the result goes back in place at the end.
-// The launch must be resident as a whole (the host checks tiles <= CUs x occupancy and runs it only for a batch alone on its level);
+// Round 5: a workgroup owns a SUPER-TILE of B x B tiles (B = 2: 64 x 64 entries).  The pivots still advance 32 at a time -- the arithmetic
+// per entry is that of k_ds_gj_step, product for product, so both paths give the SAME BITS --, but the pivot tiles of B consecutive steps
+// lie in one workgroup: the chain  fetch P[k] -> two 32^3 products -> inversion -> publication  of the one-tile-per-workgroup form (8-11 us
+// per step of which 4.3 us the inversion) pays its hop once per B steps, the steps in between go  P[k] (LDS) -> two products -> inversion.
+// The owner of the next pivot updates THAT tile first, inverts it, and only then touches its other tiles; a published inverse is flagged
+// at once where the chain leaves the workgroup, together with the panel tiles where it stays.  A quarter of the workgroups (289 instead
+// of 1089 for the 1056-pivot root of cfg4: two per CU, no spilled fifth one), 1.5 instead of 2 products per tile and step (R'_j = P A_Kj
+// is shared by the B tiles of a column).
+// The launch must be resident as a whole (the host checks workgroups <= CUs x occupancy and runs it only for a batch alone on its level);
 // a flag that does not come within DS_FLOW_SPINS polls raises bad[DS_FLOW_ABORT] and lets every workgroup run out (the host reports it).
 #define DS_FLOW_MAXF 64
 #define DS_FLOW_ABORT 5
 #define DS_FLOW_SPINS (1 << 22)
+#define DS_FLOW_B 2
 struct DsFlowArgs {
   int nf, epoch;
-  int tile0[DS_FLOW_MAXF + 1];     // first workgroup of front z of the batch
+  int tile0[DS_FLOW_MAXF + 1];     // first workgroup of front z of the batch (a front of nt x nt tiles has ceil(nt / B)^2 workgroups)
   int foff[DS_FLOW_MAXF];          // first flag of front z: nt pivot flags (one per 128 B), nt^2 row-panel flags, nt^2 column-panel flags
   long long xoff[DS_FLOW_MAXF];    // first exchange slot of front z (doubles): nt pivot inverses, nt^2 row-panel slots, nt^2 column-panel slots
 };
-template <bool EXACT = false>   // EXACT: a flag is raised once per launch to the launch's epoch (a stale or foreign value never passes); otherwise a counter reaching its target
+// a flag is raised once per launch to the launch's epoch (a stale or foreign value never passes)
 TSL_DEV void ds_flow_poll(const int* flag, int epoch, int* abort_w, int* s_dead) {
   int spins = 0;
   for (;;) {
     const int v = __hip_atomic_load(flag, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    if (EXACT ? v == epoch : v >= epoch) break;
+    if (v == epoch) break;
     if (++spins >= DS_FLOW_SPINS) { __hip_atomic_store(abort_w, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); *s_dead = 1; return; }
     if ((spins & 1023) == 0 && __hip_atomic_load(abort_w, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0) { *s_dead = 1; return; }
   }
@@ -707,33 +717,36 @@ TSL_DEV void ds_flow_fetch(double (*T)[DS_T + 1], const double* __restrict__ slo
 #pragma unroll
   for (int q = 0; q < 4; q++) T[ty + 8 * q][tx] = __hip_atomic_load(slot + (ty + 8 * q) * DS_T + tx, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 }
-// the stores of every wave are complete (write-through, waited for) before thread 0 raises the flag
+// the stores of every wave are complete (write-through, waited for) before a flag is raised
 // (a workgroup-scope release fence alone emits no wait on gfx950: the flag overtook the tiles -- 11 instead of 2 refinement iterations on cfg4)
-#ifndef DS_FLOW_FENCE
-#define DS_FLOW_FENCE 0
-#endif
-TSL_DEV void ds_flow_raise(int* flag, int epoch) {
-  if (DS_FLOW_FENCE == 1) __threadfence();
-  else { __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup"); __builtin_amdgcn_s_waitcnt(0); }   // vmcnt(0): the write-through stores of this wave are acknowledged
+TSL_DEV void ds_flow_commit() {
+  __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+  __builtin_amdgcn_s_waitcnt(0);   // vmcnt(0): the write-through stores of this wave are acknowledged
   __syncthreads();
-  if (threadIdx.x == 0) __hip_atomic_store(flag, epoch, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 }
-template <int WPC>
-__global__ void __launch_bounds__(256, WPC) k_ds_gj_flow(DsDev D, int lv0, DsFlowArgs a, double* __restrict__ X, int* __restrict__ Fl) {
-  __shared__ double Ps[DS_T][DS_T + 1];
-  __shared__ double T1[DS_T][DS_T + 1];
-  __shared__ double T2[DS_T][DS_T + 1];
+TSL_DEV void ds_flow_raise(int* flag, int epoch) { __hip_atomic_store(flag, epoch, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+// one quadrant of the 32 x 32 x 32 product Am Bm (LDS tiles, row stride DS_T + 1): the operand order of k_ds_gj_step
+TSL_DEV ds_d4 ds_prod32(const double (*Am)[DS_T + 1], const double (*Bm)[DS_T + 1], int wi, int wj, int lr, int lk) {
+  ds_d4 acc = {0.0, 0.0, 0.0, 0.0};
+#pragma unroll
+  for (int kk = 0; kk < DS_T / 4; kk++) acc = __builtin_amdgcn_mfma_f64_16x16x4f64(Am[16 * wi + lr][4 * kk + lk], Bm[4 * kk + lk][16 * wj + lr], acc, 0, 0, 0);
+  return acc;
+}
+template <int B>
+__global__ void __launch_bounds__(256, 2) k_ds_gj_flow(DsDev D, int lv0, DsFlowArgs a, double* __restrict__ X, int* __restrict__ Fl) {
+  __shared__ double Pb[2][DS_T][DS_T + 1];   // P[k] of the current step / the inverse being formed for the next one
+  __shared__ double Rs[B][DS_T][DS_T + 1];   // per owned column: A[K, j] as it was before the step, then R'_j = P A[K, j]
+  __shared__ double Cs[B][DS_T][DS_T + 1];   // per owned row: A[i, K] as it was before the step
   __shared__ int s_dead;
   const int L = blockIdx.x;
   int z = 0;
   for (int step = DS_FLOW_MAXF / 2; step > 0; step >>= 1) { const int q = z + step; if (q < a.nf && L >= a.tile0[q]) z = q; }   // last front with tile0 <= L
   const int sn = D.level_sn[lv0 + z];
   const DsFrontDesc f = D.frl[lv0 + z];
-  const int nt = f.pp / DS_T, t = L - a.tile0[z], bi = t / nt, bj = t - bi * nt;
+  const int nt = f.pp / DS_T, ns = (nt + B - 1) / B, t = L - a.tile0[z], I = t / ns, J = t - I * ns;
   const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;
   const int lane = threadIdx.x & 63, w = threadIdx.x >> 6, wi = w >> 1, wj = w & 1, lr = lane & 15, lk = lane >> 4;
   const int epoch = a.epoch, cls = DS_CLS(f);
-  double* A = D.A + f.off + (size_t)(bi * DS_T) * f.ld + bj * DS_T;
   double* Xp = X + a.xoff[z];
   int* Fp = Fl + a.foff[z];
   int* abort_w = D.bad + DS_FLOW_ABORT;
@@ -744,85 +757,219 @@ __global__ void __launch_bounds__(256, WPC) k_ds_gj_flow(DsDev D, int lv0, DsFlo
 #define DS_FLOW_RFLAG(i, j) (Fp + 32 * nt + (i) * nt + (j))
 #define DS_FLOW_CFLAG(i, j) (Fp + 32 * nt + nt * nt + (i) * nt + (j))
   if (threadIdx.x == 0) s_dead = 0;
-  ds_d4 own;
+  const bool tl = D.tlog != nullptr && z == 0 && threadIdx.x == 0;
+  if (tl && t == 0) D.tlog[192] = wall_clock64();
+  if (D.tlog != nullptr && threadIdx.x == 0) atomicMin(&D.tlog[194], wall_clock64());   // first workgroup of the launch to start
+  bool va[B], vb[B];   // rows / columns of the super-tile inside the front
 #pragma unroll
-  for (int r = 0; r < 4; r++) own[r] = A[(size_t)(16 * wi + lk + 4 * r) * f.ld + 16 * wj + lr];
-  // publication of the tile held in registers
-  auto publish = [&](double* slot, int* flag) {
+  for (int q = 0; q < B; q++) { va[q] = B * I + q < nt; vb[q] = B * J + q < nt; }
+  ds_d4 own[B][B];
+  const int qr = 16 * wi + lk, qc = 16 * wj + lr;   // this lane's quadrant entries: rows qr + 4 r, column qc
 #pragma unroll
-    for (int r = 0; r < 4; r++) __hip_atomic_store(slot + (16 * wi + lk + 4 * r) * DS_T + 16 * wj + lr, own[r], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    ds_flow_raise(flag, epoch);
+  for (int x = 0; x < B; x++)
+#pragma unroll
+    for (int y = 0; y < B; y++) {
+      const double* At = D.A + f.off + (size_t)((B * I + x) * DS_T) * f.ld + (B * J + y) * DS_T;
+#pragma unroll
+      for (int r = 0; r < 4; r++) own[x][y][r] = (va[x] && vb[y]) ? At[(size_t)(qr + 4 * r) * f.ld + qc] : 0.0;
+    }
+  auto to_slot = [&](double* slot, const ds_d4& v) {
+#pragma unroll
+    for (int r = 0; r < 4; r++) __hip_atomic_store(slot + (qr + 4 * r) * DS_T + qc, v[r], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
   };
-  // the tile becomes its own inverse (pivot tile of step k): through T2, published as P[k]
-  auto invert_publish = [&](int k) {
-    __syncthreads();   // every wave is done with T2
+  auto to_lds = [&](double (*T)[DS_T + 1], const ds_d4& v) {
 #pragma unroll
-    for (int r = 0; r < 4; r++) T2[16 * wi + lk + 4 * r][16 * wj + lr] = own[r];
-    __syncthreads();
-    ds_invert_tile_f<(WPC >= 5 ? 1 : DS_INV_FORM)>(&T2[0][0], DS_T + 1, D.bad, cls, (sn << 6) | k, D.piv_tol);
-    __syncthreads();
-    double* slot = DS_FLOW_PSLOT(k);
-#pragma unroll
-    for (int q = 0; q < 4; q++) __hip_atomic_store(slot + (ty + 8 * q) * DS_T + tx, T2[ty + 8 * q][tx], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-#pragma unroll
-    for (int r = 0; r < 4; r++) own[r] = T2[16 * wi + lk + 4 * r][16 * wj + lr];
-    ds_flow_raise(DS_FLOW_PFLAG(k), epoch);
+    for (int r = 0; r < 4; r++) T[qr + 4 * r][qc] = v[r];
   };
   __syncthreads();
-  if (bi == 0 && bj == 0) invert_publish(0);
-  else if (bi == 0) publish(DS_FLOW_RSLOT(0, bj), DS_FLOW_RFLAG(0, bj));
-  else if (bj == 0) publish(DS_FLOW_CSLOT(bi, 0), DS_FLOW_CFLAG(bi, 0));
-  for (int k = 0; k < nt; k++) {
-    if (!(bi == k && bj == k)) {   // (the pivot tile of step k holds P[k] already)
-      const bool general = bi != k && bj != k;
-      if (general) {   // the panel tiles first: they were published an inversion before P[k]
-        if (threadIdx.x == 64) ds_flow_poll<true>(DS_FLOW_RFLAG(k, bj), epoch, abort_w, &s_dead);
-        if (threadIdx.x == 128) ds_flow_poll<true>(DS_FLOW_CFLAG(bi, k), epoch, abort_w, &s_dead);
-        __syncthreads();
-        ds_flow_fetch(T1, DS_FLOW_RSLOT(k, bj), tx, ty);
-        ds_flow_fetch(T2, DS_FLOW_CSLOT(bi, k), tx, ty);
-      }
-      if (threadIdx.x == 0) ds_flow_poll<true>(DS_FLOW_PFLAG(k), epoch, abort_w, &s_dead);
-      __syncthreads();
-      ds_flow_fetch(Ps, DS_FLOW_PSLOT(k), tx, ty);
-      if (bi == k) {
+  // k = -1 is the prologue (nothing to update, pivot 0 "is next"); step k >= 0 eliminates the pivots [32 k, 32 k + 32)
+  for (int k = -1; k < nt; k++) {
+    const int K = k >= 0 ? k / B : -1, ka = k - B * K;
+    const bool rowK = k >= 0 && I == K, colK = k >= 0 && J == K;
+    const int kn = k + 1, Kn = kn / B, an = kn - B * Kn;
+    const bool more = kn < nt;
+    const bool rowN = more && I == Kn, colN = more && J == Kn, pivn = rowN && colN;
+    double (*Ps)[DS_T + 1] = Pb[k & 1];
+    double (*Pn)[DS_T + 1] = Pb[kn & 1];
+    if (k >= 0) {
+      // ---- operands of the step.  Every workgroup of the front passes here once per step, so the memory round trips of this block ARE the
+      // step rate of the launch: every flag is polled first (one thread per wave; where the chain has just changed workgroups the panel tiles
+      // and P[k] arrive within a microsecond of each other), then ALL tiles -- up to 2 B panel tiles and P[k] -- are requested together, parked
+      // in registers and written to LDS: ONE round trip.  (Tile by tile -- load, wait, store to LDS, next tile -- the five fetches of a step
+      // were five dependent round trips: 1.07 instead of 0.97 ms per factorisation for the chains of cfg4; panels and P[k] in two trips: 10.3 us
+      // per hop step of the root against 7.1 us for a step that stays in its workgroup.)
+      bool need_r[B], need_c[B];   // tiles of the pivot row / column that live in another workgroup
 #pragma unroll
-        for (int r = 0; r < 4; r++) T1[16 * wi + lk + 4 * r][16 * wj + lr] = own[r];
-      } else if (bj == k) {
+      for (int q = 0; q < B; q++) { need_r[q] = vb[q] && !rowK && !(colK && q == ka); need_c[q] = va[q] && !colK && !(rowK && q == ka); }
+      const bool fetch_p = !(rowK && colK);   // (the pivot's owner left P[k] in Ps when it inverted the tile)
 #pragma unroll
-        for (int r = 0; r < 4; r++) T2[16 * wi + lk + 4 * r][16 * wj + lr] = own[r];
+      for (int y = 0; y < B; y++) if (need_r[y] && (int)threadIdx.x == 64 * (y & 3)) ds_flow_poll(DS_FLOW_RFLAG(k, B * J + y), epoch, abort_w, &s_dead);
+#pragma unroll
+      for (int x = 0; x < B; x++) if (need_c[x] && (int)threadIdx.x == 64 * ((B + x) & 3)) ds_flow_poll(DS_FLOW_CFLAG(B * I + x, k), epoch, abort_w, &s_dead);
+      if (fetch_p && threadIdx.x == 32) ds_flow_poll(DS_FLOW_PFLAG(k), epoch, abort_w, &s_dead);
+      __syncthreads();   // (also: every wave is done with Rs / Cs / Pn of the previous step)
+      if (tl && pivn && kn < 64) D.tlog[256 + 8 * kn] = wall_clock64();
+      double pr[B][4], pc[B][4], pp[4];
+#pragma unroll
+      for (int y = 0; y < B; y++) if (need_r[y]) {
+        const double* slot = DS_FLOW_RSLOT(k, B * J + y);
+#pragma unroll
+        for (int q = 0; q < 4; q++) pr[y][q] = __hip_atomic_load(slot + (ty + 8 * q) * DS_T + tx, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      }
+#pragma unroll
+      for (int x = 0; x < B; x++) if (need_c[x]) {
+        const double* slot = DS_FLOW_CSLOT(B * I + x, k);
+#pragma unroll
+        for (int q = 0; q < 4; q++) pc[x][q] = __hip_atomic_load(slot + (ty + 8 * q) * DS_T + tx, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      }
+      if (fetch_p) {
+        const double* slot = DS_FLOW_PSLOT(k);
+#pragma unroll
+        for (int q = 0; q < 4; q++) pp[q] = __hip_atomic_load(slot + (ty + 8 * q) * DS_T + tx, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      }
+      // local panel tiles (this workgroup lies in the pivot's super-row / super-column): registers -> LDS
+#pragma unroll
+      for (int y = 0; y < B; y++) if (vb[y] && rowK && !(colK && y == ka)) {
+#pragma unroll
+        for (int x = 0; x < B; x++) if (x == ka) to_lds(Rs[y], own[x][y]);
+      }
+#pragma unroll
+      for (int x = 0; x < B; x++) if (va[x] && colK && !(rowK && x == ka)) {
+#pragma unroll
+        for (int y = 0; y < B; y++) if (y == ka) to_lds(Cs[x], own[x][y]);
+      }
+#pragma unroll
+      for (int y = 0; y < B; y++) if (need_r[y]) {
+#pragma unroll
+        for (int q = 0; q < 4; q++) Rs[y][ty + 8 * q][tx] = pr[y][q];
+      }
+#pragma unroll
+      for (int x = 0; x < B; x++) if (need_c[x]) {
+#pragma unroll
+        for (int q = 0; q < 4; q++) Cs[x][ty + 8 * q][tx] = pc[x][q];
+      }
+      if (fetch_p) {
+#pragma unroll
+        for (int q = 0; q < 4; q++) Ps[ty + 8 * q][tx] = pp[q];
       }
       __syncthreads();
+      if (tl && pivn && kn < 64) D.tlog[256 + 8 * kn + 1] = wall_clock64();
       if (s_dead) break;
-      ds_d4 acc = {0.0, 0.0, 0.0, 0.0};
-      if (bj == k) {   // A_iK = -A_iK P
+      // ---- R'_j = P A[K, j] for the owned columns (the pivot row's tiles ARE R'_j afterwards).  Only the products a tile needs are formed: a
+      // 32^3 product is 8 v_mfma_f64_16x16x4_f64 per wave at 64 cycles each -- 0.2 us at the matrix cores' rate, 0.5 us with its LDS operand
+      // reads and barriers -- and every one in front of the inversion is on the chain (all B + B x B products of a step unconditionally, as one
+      // straight line of matrix instructions: 2.2 instead of 1.2 us per step of the root's pivot owner).
+      ds_d4 rp[B];
 #pragma unroll
-        for (int kk = 0; kk < DS_T / 4; kk++) acc = __builtin_amdgcn_mfma_f64_16x16x4f64(T2[16 * wi + lr][4 * kk + lk], Ps[4 * kk + lk][16 * wj + lr], acc, 0, 0, 0);
-        own = -acc;
-      } else {         // R'_j = P A_Kj
+      for (int y = 0; y < B; y++) if (vb[y] && !(colK && y == ka)) rp[y] = ds_prod32(Ps, Rs[y], wi, wj, lr, lk);
+      __syncthreads();   // every quadrant has read Rs
 #pragma unroll
-        for (int kk = 0; kk < DS_T / 4; kk++) acc = __builtin_amdgcn_mfma_f64_16x16x4f64(Ps[16 * wi + lr][4 * kk + lk], T1[4 * kk + lk][16 * wj + lr], acc, 0, 0, 0);
-        if (bi == k) own = acc;
-        else {         // A_ij -= A_iK R'_j
-          __syncthreads();   // every quadrant has read T1
+      for (int y = 0; y < B; y++) {
+        if (!vb[y] || (colK && y == ka)) continue;
+        to_lds(Rs[y], rp[y]);
+        if (rowK) {
 #pragma unroll
-          for (int r = 0; r < 4; r++) T1[16 * wi + lk + 4 * r][16 * wj + lr] = acc[r];
-          __syncthreads();
-          acc = ds_d4{0.0, 0.0, 0.0, 0.0};
-#pragma unroll
-          for (int kk = 0; kk < DS_T / 4; kk++) acc = __builtin_amdgcn_mfma_f64_16x16x4f64(T2[16 * wi + lr][4 * kk + lk], T1[4 * kk + lk][16 * wj + lr], acc, 0, 0, 0);
-          own -= acc;
+          for (int x = 0; x < B; x++) if (x == ka) own[x][y] = rp[y];
         }
       }
+      __syncthreads();
     }
-    if (k + 1 < nt) {
-      if (bi == k + 1 && bj == k + 1) invert_publish(k + 1);
-      else if (bi == k + 1) publish(DS_FLOW_RSLOT(bi, bj), DS_FLOW_RFLAG(bi, bj));
-      else if (bj == k + 1) publish(DS_FLOW_CSLOT(bi, bj), DS_FLOW_CFLAG(bi, bj));
+    // A[i, j] -= A[i, K] R'_j,  A[i, K] = -A[i, K] P   (i outside the pivot rows), in up to three passes: 0 the next pivot tile, 1 the other
+    // tiles of the next pivot's row and column (published as its panels), 2 the rest
+    auto update = [&](int pass_lo, int pass_hi) {
+#pragma unroll
+      for (int x = 0; x < B; x++) {
+        if (!va[x] || (rowK && x == ka)) continue;
+#pragma unroll
+        for (int y = 0; y < B; y++) {
+          if (!vb[y]) continue;
+          const int pass = (pivn && x == an && y == an) ? 0 : (((rowN && x == an) || (colN && y == an)) ? 1 : 2);
+          if (pass < pass_lo || pass > pass_hi) continue;
+          if (colK && y == ka) own[x][y] = -ds_prod32(Cs[x], Ps, wi, wj, lr, lk);
+          else own[x][y] -= ds_prod32(Cs[x], Rs[y], wi, wj, lr, lk);
+        }
+      }
+    };
+    // tiles of the next step's pivot row (read by the other super-rows) and pivot column -> their exchange slots (stores only)
+    auto store_panels = [&]() {
+      if (rowN) {
+#pragma unroll
+        for (int y = 0; y < B; y++) {
+          if (!vb[y] || (colN && y == an)) continue;
+#pragma unroll
+          for (int x = 0; x < B; x++) if (x == an) to_slot(DS_FLOW_RSLOT(kn, B * J + y), own[x][y]);
+        }
+      }
+      if (colN) {
+#pragma unroll
+        for (int x = 0; x < B; x++) {
+          if (!va[x] || (rowN && x == an)) continue;
+#pragma unroll
+          for (int y = 0; y < B; y++) if (y == an) to_slot(DS_FLOW_CSLOT(B * I + x, kn), own[x][y]);
+        }
+      }
+    };
+    auto raise_panels = [&]() {   // (after ds_flow_commit)
+      const int tq = threadIdx.x;
+      if (rowN && tq >= 1 && tq <= B) { const int y = tq - 1; if (B * J + y < nt && !(colN && y == an)) ds_flow_raise(DS_FLOW_RFLAG(kn, B * J + y), epoch); }
+      if (colN && tq >= 1 + B && tq <= 2 * B) { const int x = tq - 1 - B; if (B * I + x < nt && !(rowN && x == an)) ds_flow_raise(DS_FLOW_CFLAG(B * I + x, kn), epoch); }
+    };
+    const bool pub = ns > 1 && (rowN || colN);
+    if (pivn) {
+      // The owner of the next pivot updates THAT tile first, inverts it in Pn and publishes it as P[k + 1].  Where the chain LEAVES this
+      // workgroup (the pivot after it lies in the next super-tile) the inverse is flagged at once: the next owner waits for nothing else of
+      // this workgroup; its other tiles and their panel publications follow.  Where the chain STAYS, the workgroups of this super-row and
+      // super-column -- who feed the owner after that -- need P[k + 1] AND this workgroup's panel tiles: those are updated and sent off in
+      // front of the inversion (their stores complete behind it) and one completion wait flags everything.
+      const bool leaves = an == B - 1 || kn + 1 >= nt;
+      if (k >= 0) update(0, leaves ? 0 : 1);
+      if (pub && !leaves) store_panels();
+#pragma unroll
+      for (int x = 0; x < B; x++)
+#pragma unroll
+        for (int y = 0; y < B; y++) if (x == an && y == an) to_lds(Pn, own[x][y]);
+      __syncthreads();
+      if (tl && kn < 64) D.tlog[256 + 8 * kn + 3] = wall_clock64();
+      ds_invert_tile(&Pn[0][0], DS_T + 1, D.bad, cls, (sn << 6) | kn, D.piv_tol);   // (ends with a barrier)
+      if (tl && kn < 64) D.tlog[256 + 8 * kn + 4] = wall_clock64();
+      if (ns > 1) {
+        double* slot = DS_FLOW_PSLOT(kn);
+#pragma unroll
+        for (int q = 0; q < 4; q++) __hip_atomic_store(slot + (ty + 8 * q) * DS_T + tx, Pn[ty + 8 * q][tx], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      }
+#pragma unroll
+      for (int x = 0; x < B; x++)
+#pragma unroll
+        for (int y = 0; y < B; y++) if (x == an && y == an) {
+#pragma unroll
+          for (int r = 0; r < 4; r++) own[x][y][r] = Pn[qr + 4 * r][qc];
+        }
+      if (ns > 1) {
+        ds_flow_commit();
+        if (threadIdx.x == 0) { ds_flow_raise(DS_FLOW_PFLAG(kn), epoch); if (tl && kn < 64) D.tlog[kn] = wall_clock64(); }
+        if (!leaves) raise_panels();
+      }
+      if (k >= 0) update(leaves ? 1 : 2, 2);
+      if (pub && leaves) { store_panels(); ds_flow_commit(); raise_panels(); }
+    } else {
+      if (k >= 0) update(1, 1);
+      if (pub) store_panels();
+      if (k >= 0) update(2, 2);
+      if (pub) { ds_flow_commit(); raise_panels(); }
     }
+    if (tl && k >= 0 && k < 64 && I == ns - 1 && (J == ns - 1 || J == 0)) D.tlog[(J == 0 ? 128 : 64) + k] = wall_clock64();
+    if (!more) break;
   }
 #pragma unroll
-  for (int r = 0; r < 4; r++) A[(size_t)(16 * wi + lk + 4 * r) * f.ld + 16 * wj + lr] = own[r];
+  for (int x = 0; x < B; x++)
+#pragma unroll
+    for (int y = 0; y < B; y++) {
+      if (!(va[x] && vb[y])) continue;
+      double* At = D.A + f.off + (size_t)((B * I + x) * DS_T) * f.ld + (B * J + y) * DS_T;
+#pragma unroll
+      for (int r = 0; r < 4; r++) At[(size_t)(qr + 4 * r) * f.ld + qc] = own[x][y][r];
+    }
+  if (D.tlog != nullptr && threadIdx.x == 0) atomicMax(&D.tlog[193], wall_clock64());   // last workgroup of the launch to end
 #undef DS_FLOW_PSLOT
 #undef DS_FLOW_RSLOT
 #undef DS_FLOW_CSLOT
@@ -883,17 +1030,17 @@ __global__ void __launch_bounds__(256) k_ds_inv_small(DsDev D, int lv0, int ls) 
       const int i0 = i * DS_T;
       double c0[DS_T / 4], c1[DS_T / 4];
 #pragma unroll
-      for (int kk = 0; kk < DS_T / 4; kk++) { c0[kk] = -M[(i0 + lr) * ls + k0 + 4 * kk + lk]; c1[kk] = -M[(i0 + 16 + lr) * ls + k0 + 4 * kk + lk]; }
+      for (int kk = 0; kk < DS_T / 4; kk++) { c0[kk] = M[(i0 + lr) * ls + k0 + 4 * kk + lk]; c1[kk] = M[(i0 + 16 + lr) * ls + k0 + 4 * kk + lk]; }
       __builtin_amdgcn_wave_barrier();
       for (int j = 0; j < nt; j++) {
         const int j0 = j * DS_T;
+        // the product is formed from zero and subtracted afterwards -- A_ij - (A_iK R'_j), -(A_iK P) -- like k_ds_gj_step / k_ds_gj_flow form it:
+        // the three inversion paths give the same bits (accumulating onto the old entry rounds differently)
         ds_d4 acc[2][2];
 #pragma unroll
         for (int a = 0; a < 2; a++)
 #pragma unroll
-          for (int b = 0; b < 2; b++)
-#pragma unroll
-            for (int r = 0; r < 4; r++) acc[a][b][r] = (j == k) ? 0.0 : M[(i0 + 16 * a + lk + 4 * r) * ls + j0 + 16 * b + lr];
+          for (int b = 0; b < 2; b++) acc[a][b] = ds_d4{0.0, 0.0, 0.0, 0.0};
 #pragma unroll
         for (int kk = 0; kk < DS_T / 4; kk++) {   // row K of M holds R'_j for j != k and P itself at j == k
           const double b0 = M[(k0 + 4 * kk + lk) * ls + j0 + lr], b1 = M[(k0 + 4 * kk + lk) * ls + j0 + 16 + lr];
@@ -907,7 +1054,10 @@ __global__ void __launch_bounds__(256) k_ds_inv_small(DsDev D, int lv0, int ls) 
 #pragma unroll
           for (int b = 0; b < 2; b++)
 #pragma unroll
-            for (int r = 0; r < 4; r++) M[(i0 + 16 * a + lk + 4 * r) * ls + j0 + 16 * b + lr] = acc[a][b][r];
+            for (int r = 0; r < 4; r++) {
+              double* m = &M[(i0 + 16 * a + lk + 4 * r) * ls + j0 + 16 * b + lr];
+              *m = (j == k) ? -acc[a][b][r] : *m - acc[a][b][r];
+            }
       }
     }
     __syncthreads();

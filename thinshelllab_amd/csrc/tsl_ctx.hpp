@@ -125,11 +125,15 @@ struct DirectSolver {
   int par_batches = 1;      // "direct_par_batches"
   // "direct_flow": block steps of a batch alone on its level as one persistent dataflow launch (k_ds_gj_flow)
   int device = 0;          // HIP device of the context (tsl_ctx_create)
-  bool shared_device = false;   // another context of this process factorised on the device within the last two seconds (direct_factor)
-  int flow = 3, flow_cap[2] = {0, 0}, flow_epoch = 0;   // flow_cap: resident workgroups of the 4 / 5-per-CU instantiations
+  int flow = 3, flow_cap = 0, flow_epoch = 0;   // flow_cap: workgroups of k_ds_gj_flow the device holds at once
+  int flow_token = 0, flow_token_fd = -1;       // the device's dataflow token (direct_host.hpp): 0 not asked yet, 1 held, -1 refused
+  long flow_token_asked = 0;                    // n_factor at the last request
+  int small_rounds = 2;     // "direct_small_rounds": rounds of the chip a batch may take in the LDS kernel
+  int xcd_map = 64;         // "direct_xcd": batches of at least this many fronts launch their GEMM tiles with the XCD-aware map; 0: never
   long n_flow = 0, n_flow_abort = 0;   // dataflow launches / launches that lost a flag (the solve then refactorises on the block-step path)
   DevBuf<double> flow_x;    // exchange slots (pivot inverses, row / column panel tiles)
   DevBuf<int> flow_f;       // their flags (epoch of the launch that published the slot)
+  DevBuf<unsigned long long> tlog;   // "ds_dbg" 30: device-clock stamps of a dataflow launch (diagnostic)
   int gemv_wide_below = 300;   // "direct_gemv_wide_below": a sweep launch of fewer 16-row chunks than this runs four narrow workgroups per chunk (k_ds_gemv_wide; 0 = never).
                                // cfg4, one application: 404 us without, 385 / 380 / 387 / 388 / 409 / 523 us at 150 / 300 / 600 / 1200 / 2400 / always (scripts/archive_r02_r03/exp_gemv_wide.py)
   int g32_below = 1100;     // "direct_g32_below": G = W F12 of a batch with fewer 64 x 64 tiles than this runs in the 32 x 32-tile kernel (k_ds_gemm_g32; 0 = never).

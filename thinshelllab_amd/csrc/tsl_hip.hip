@@ -385,8 +385,8 @@ extern "C" int tsl_ctx_create(const tsl_scene_desc* d, tsl_ctx** out) {
 
 extern "C" void tsl_ctx_destroy(tsl_ctx* c) {
   if (!c) return;
-  ds_forget(c);
   (void)hipDeviceSynchronize();
+  ds_flow_token_release(c->ds);   // (after the last launch of the context has ended)
   if (c->h_scal) (void)hipHostFree(c->h_scal);
   if (c->h_scal2) (void)hipHostFree(c->h_scal2);
   for (int i = 0; i < 2; i++) if (c->rb_event[i]) (void)hipEventDestroy(c->rb_event[i]);
@@ -444,7 +444,7 @@ extern "C" int tsl_set_param(tsl_ctx* c, const char* key, double v) {
   else if (k == "direct_refine") c->ds.refine_ir = (int)v;
   else if (k == "direct_berr") c->ds.berr_tol = v;
   else if (k == "direct_berr_rel_cap") c->ds.berr_rel_cap = v;
-  else if (k == "direct_small_rounds") { ds_small_rounds = std::max(1, (int)v); c->ds.plan_valid = false; c->ds.numeric_valid = false; c->ds.cache.clear(); }
+  else if (k == "direct_small_rounds") { c->ds.small_rounds = std::max(1, (int)v); c->ds.plan_valid = false; c->ds.numeric_valid = false; c->ds.cache.clear(); }
   else if (k == "direct_plan_cache") { c->ds.cache_cap = std::max(0, (int)v); c->ds.cache.clear(); }
   else if (k == "direct_plan_cache_mb") c->ds.cache_mb = std::max(1, (int)v);
   else if (k == "tet_warm") c->tet_warm = (int)v;
@@ -460,7 +460,7 @@ extern "C" int tsl_set_param(tsl_ctx* c, const char* key, double v) {
   else if (k == "direct_s32_below") c->ds.s32_below = std::max(0, (int)v);
   else if (k == "direct_par_batches") c->ds.par_batches = (int)v;
   else if (k == "direct_gemm_wpc") c->ds.gemm_wpc = (int)v;
-  else if (k == "direct_xcd") ds_xcd_map = (int)v;
+  else if (k == "direct_xcd") c->ds.xcd_map = (int)v;
   else if (k == "asm_early") c->asm_early = (int)v;
   else if (k == "direct_split") { c->ds.plan.split_small = ((int)v & 1) != 0; c->ds.plan.split_rem = ((int)v & 2) != 0; c->ds.plan_valid = false; c->ds.numeric_valid = false; c->ds.cache.clear(); }
   else if (k == "direct_merge_sep") { c->ds.plan.sym.merge_sep = (int)v; c->ds.static_ready = false; c->ds.plan_valid = false; c->ds.numeric_valid = false; }
