@@ -138,68 +138,89 @@ def run_rollout(scene, grad, K, args):
     return S
 
 
+def run_group_rollout(scenes, grads, group, K, args):
+    """run_rollout for the members of a scene group: the K forward steps of ALL members in lock step (SceneGroup.time_step: one merged
+    factorisation and first application per Newton iteration), then every member's loss seed and reverse sweep on its own path"""
+    from thinshelllab_amd.engine.geometry import projection_query as contact
+    stats = [dict(newton=0, it_fwd=0, ls=0, it_adj=0, nc=0, fwd_fallback=0, fwd_unconverged=0, fwd_attained=0, factorizations=0, plans=0, max_res_fwd=0.0,
+                  adj_fallback=0, adj_unconverged=0, adj_attained=0, max_res_adj=0.0, max_be_adj=0.0, last_delta=[], methods={}) for _ in scenes]
+    for sc, g in zip(scenes, grads):
+        g.allow_unconverged = True
+        g.copy_pos(sc, 0)
+    for f in range(1, K + 1):
+        for sc in scenes:
+            sc._bench_frame = getattr(sc, "_bench_frame", 0) + 1
+            sc.action(f, *_drive(sc.gripper.n_part, sc._bench_gs, sc._bench_rank, sc._bench_frame, args.idle))
+        sts = group.time_step(contact, f)
+        for sc, g, st, S in zip(scenes, grads, sts, stats):
+            g.copy_pos(sc, f)
+            S["newton"] += st["newton_iters"]; S["it_fwd"] += st["cg_iters"]; S["ls"] += st["ls_evals"]; S["nc"] += st.get("nc", 0)
+            S["fwd_fallback"] += st["fallback"]; S["fwd_unconverged"] += st["unconverged"]; S["fwd_attained"] += st["attained"]
+            S["factorizations"] += st["factorizations"]; S["plans"] += st["plans"]
+            S["max_res_fwd"] = max(S["max_res_fwd"], st["max_rel_residual"]); S["last_delta"].append(st["last_delta"])
+    for sc, g, S in zip(scenes, grads, stats):
+        g.pos_grad.t.zero_(); g.angleref_grad.t.zero_()
+        if args.workload == "cfg3":
+            g.get_loss_fold(sc, 1.0, -1.0, rows=sc.fold_rows())
+        else:
+            g.get_loss_balance(sc)
+        for k in range(K, 0, -1):
+            g.transfer_grad(k, sc, contact)
+            ls = g.last_stats
+            S["it_adj"] += ls["iters"]; S["adj_fallback"] += int(ls["flag"] == 1); S["adj_unconverged"] += int(ls["flag"] == 3); S["adj_attained"] += ls["attained"]
+            S["max_res_adj"] = max(S["max_res_adj"], ls["rel_residual"]); S["max_be_adj"] = max(S["max_be_adj"], ls["backward_error"])
+    return stats
+
+
 def multi_scene(args, rank, S, K, W, single_value):
-    """--scenes-per-gpu S: S independent scenes of the bench workload on ONE GPU -- S engine contexts on S streams, driven by S host
-    threads (the engine calls release the GIL) -- through the same warm-up + K fwd+adjoint steps each.  One scene leaves most of the
-    chip idle between its dependent launches (roofline.whole_step); this is what a trajectory-optimisation batch larger than the
-    GPU count does with it (BASELINE configs[4]: more scenes than GPUs).  Reported NEXT to the single-scene headline, never instead."""
-    import threading
+    """--scenes-per-gpu S: S independent scenes of the bench workload on ONE GPU as a scene group (thinshelllab_amd/scene_group.py,
+    csrc/direct_group.hpp): one host thread steps them in lock step, the sparse direct solves of all members are ONE factorisation and ONE
+    first application of the merged plan per Newton iteration, everything else runs per member on its own streams.  Each member's tape is
+    bit-identical to its single-scene run (tests/test_gpu_group.py).  One scene leaves most of the chip idle during the latency-bound
+    parts of its factorisation (roofline.whole_step); this is what a trajectory-optimisation batch larger than the GPU count does with it
+    (BASELINE configs[4]).  Reported NEXT to the single-scene headline, never instead."""
     import torch
     from thinshelllab_amd.engine.analytic_grad_single import Grad
+    from thinshelllab_amd.scene_group import SceneGroup
+    if args.workload == "drape":
+        return {"scenes_per_gpu": S, "value": None, "error": "scene groups need the sparse direct solve (contact workloads)"}
     scenes, grads = [], []
-    # (with several contexts alive on the device the engine keeps its persistent dataflow launches off by itself: direct_host.hpp)
     for k in range(S):
         sc = build_scene(args, rank * S + k)   # (own drive amplitude per scene, like the ranks)
         ctx = sc._ensure_ctx()
         ctx.set_param("cg_tol", args.cg_tol)
+        ctx.set_param("direct", 1)
         for kv in args.param:
             key, v = kv.split("=")
             ctx.set_param(key, float(v))
-        n_part = sc.gripper.n_part if args.workload != "drape" else 0
-        g = Grad(sc, max(K, W) + 1, n_part); g.init_mass(sc)
+        g = Grad(sc, max(K, W) + 1, sc.gripper.n_part); g.init_mass(sc)
         scenes.append(sc); grads.append(g)
-    stats = [None] * S; errs = []
-    start = threading.Barrier(S + 1); warm = threading.Barrier(S + 1)
-
-    def work(k):
-        try:
-            torch.cuda.set_device(scenes[k].device)
-            if W > 0:
-                run_rollout(scenes[k], grads[k], W, args)
-            warm.wait(); start.wait()
-            stats[k] = run_rollout(scenes[k], grads[k], K, args)
-        except Exception as e:   # noqa: BLE001 -- reported below
-            errs.append(repr(e))
-            for b in (warm, start):
-                b.abort()
-    th = [threading.Thread(target=work, args=(k,)) for k in range(S)]
-    for t in th:
-        t.start()
     try:
-        warm.wait()
+        group = SceneGroup(scenes)
+        if W > 0:
+            run_group_rollout(scenes, grads, group, W, args)
         torch.cuda.synchronize()
         t0 = time.perf_counter()
-        start.wait()
-    except threading.BrokenBarrierError:
-        pass
-    for t in th:
-        t.join()
-    torch.cuda.synchronize()
-    elapsed = time.perf_counter() - t0
-    if errs:
-        return {"scenes_per_gpu": S, "value": None, "error": errs[0]}
+        stats = run_group_rollout(scenes, grads, group, K, args)
+        torch.cuda.synchronize()
+        elapsed = time.perf_counter() - t0
+        info = group.info()
+    except Exception as e:   # noqa: BLE001 -- reported in the line
+        return {"scenes_per_gpu": S, "value": None, "error": repr(e)}
     T = scenes[0].cloths[0].NF
     val = T * K * S / elapsed
     cnt = [sc._ensure_ctx().direct_counters() for sc in scenes]
-    return {"scenes_per_gpu": S, "value": val, "unit": "element-steps/s on this GPU, all scenes together", "seconds": elapsed,
-            "ms_per_step_per_scene": elapsed / K * 1e3, "speedup_vs_single_scene": val / single_value if single_value else None,
-            "solves_unconverged": sum(st["fwd_unconverged"] + st["adj_unconverged"] for st in stats),
-            "newton_iters_per_step": [st["newton"] / K for st in stats],
-            "dataflow_launches_lost": sum(int(c["flow_aborts"]) for c in cnt),
-            "hw_queues": os.environ.get("GPU_MAX_HW_QUEUES", "default (4)"),
-            "note": "S engine contexts on S streams of one process, one host thread each, measured in a child process with GPU_MAX_HW_QUEUES=16 (the contexts' ~6 streams each "
-                    "would otherwise share four hardware queues and serialise); the persistent dataflow launches (k_ds_gj_flow, ~8 % of a single scene's step) are off while "
-                    "several contexts share the device: they need every workgroup slot of the chip for themselves"}
+    out = {"scenes_per_gpu": S, "value": val, "unit": "element-steps/s on this GPU, all scenes together", "seconds": elapsed,
+           "ms_per_step_per_scene": elapsed / (K * S) * 1e3, "ms_per_lock_step": elapsed / K * 1e3, "speedup_vs_single_scene": val / single_value if single_value else None,
+           "solves_unconverged": sum(st["fwd_unconverged"] + st["adj_unconverged"] for st in stats),
+           "newton_iters_per_step": [st["newton"] / K for st in stats],
+           "applications_per_fwd_solve": [st["it_fwd"] / max(st["newton"], 1) for st in stats],
+           "dataflow_launches_lost": sum(int(c["flow_aborts"]) for c in cnt),
+           "group": info,
+           "note": "S scenes as ONE scene group on one host thread: forward steps in lock step (merged factorisation + first application per Newton iteration), "
+                   "loss seeds and reverse sweeps per member; every member's tape equals its single-scene run bit for bit (tests/test_gpu_group.py)"}
+    group.close()
+    return out
 
 
 def _ripple(x, c):
@@ -421,8 +442,8 @@ def main():
     ap.add_argument("--cg-tol", type=float, default=1e-10)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--param", action="append", default=[], metavar="KEY=VALUE", help="extra tsl_set_param settings (solver experiments)")
-    ap.add_argument("--scenes-per-gpu", type=int, default=0, help="after the single-scene measurement: the same workload as S independent scenes on this GPU (S contexts, S streams, "
-                                                                     "S host threads), reported as multi_scene next to the headline value")
+    ap.add_argument("--scenes-per-gpu", type=int, default=0, help="after the single-scene measurement: the same workload as S independent scenes on this GPU stepped in lock step as one scene group "
+                                                                     "(merged factorisations), reported as multi_scene next to the headline value")
     ap.add_argument("--multi-only", type=int, default=0, help=argparse.SUPPRESS)      # child process of --scenes-per-gpu
     ap.add_argument("--single-value", type=float, default=0.0, help=argparse.SUPPRESS)
     ap.add_argument("--cpu-grid", type=int, default=71, help="cloth grid of the complete oracle steps of cpu_baseline")
@@ -519,6 +540,7 @@ def main():
     if args.scenes_per_gpu > 1 and rank == 0 and world == 1:
         # the multi-scene leg runs in a child process of its own (more hardware queues: an environment variable the HIP runtime reads at start-up)
         try:
+            ctx.set_param("direct_flow_token", 0)   # the child's scene group takes the device's dataflow token while this process waits
             env = dict(os.environ, GPU_MAX_HW_QUEUES=os.environ.get("TSL_MULTI_HW_QUEUES", "16"))
             cmd = [sys.executable, os.path.abspath(__file__), "--multi-only", str(args.scenes_per_gpu), "--single-value", repr(value / world), "--steps", str(K), "--warmup", str(W),
                    "--workload", args.workload, "--grid", str(args.grid), "--idle", str(args.idle), "--cg-tol", repr(args.cg_tol)] + [x for kv in args.param for x in ("--param", kv)]

@@ -246,6 +246,22 @@ int tsl_bench_direct(tsl_ctx* ctx, int cls, int reps, double* out4_host);
 int tsl_direct_info(tsl_ctx* ctx, double* out10_host);
 int tsl_direct_counters(tsl_ctx* ctx, double* out_host, int32_t n);
 
+/* ---- scene groups: several scenes of ONE device whose sparse direct solves share their launches --------------------------------------------
+ * The reference's trajectory-optimisation drivers roll out independent copies of one scene (training/trajopt_*.py, one rollout per candidate
+ * trajectory); a single 100k-triangle scene leaves most of the chip idle during the latency-bound parts of its factorisation.  A group takes the
+ * members' matrices, solution / right-hand side vectors and fronts into memory of its own, merges their plans, and tsl_group_step advances all
+ * members by one time step in lock step: per member exactly tsl_step's kernels and decisions (BaseScene.time_step, BaseScene.py:1327-1370),
+ * the factorisation and the first application of the factors as ONE set of launches for all.  A member's result is bit-identical to the one
+ * tsl_step gives for it alone.  Members stay ordinary contexts: every other entry point (tsl_adjoint_step, tsl_solve, ...) works on them as before.
+ *   tsl_group_create: ctxs[n] contexts of one device that use the sparse direct solve and belong to no group; destroying a member destroys the group.
+ *   tsl_group_step:   pos / prev / vel / ref_angle[n] device pointers (as tsl_step), stats[n] host records (null: none).
+ *   tsl_group_info:   {plan merges, arena re-layouts, host seconds in merges, bytes of the group's arenas, merged factorisations, merged applications}. */
+typedef struct tsl_group tsl_group;
+int tsl_group_create(tsl_ctx* const* ctxs, int32_t n, tsl_group** out);
+void tsl_group_destroy(tsl_group* g);
+int tsl_group_step(tsl_group* g, double* const* pos, double* const* prev_pos, double* const* vel, double* const* ref_angle, tsl_step_stats* stats_host);
+int tsl_group_info(tsl_group* g, double* out6_host);
+
 #ifdef __cplusplus
 }
 #endif

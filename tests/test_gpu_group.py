@@ -1,0 +1,118 @@
+"""Scene groups (tsl_group_*, thinshelllab_amd/scene_group.py): several scenes of one GPU stepped in lock step, the sparse direct solves of all
+members as ONE factorisation and ONE first application of the merged plan.  The statement under test: a member's rollout -- tape, solver
+statistics, gradients of the reverse sweep that follows -- is BIT-IDENTICAL to the rollout of the same scene stepped alone
+(training/trajopt_*.py of the reference rolls out independent copies of one scene; nothing may couple them)."""
+import gc
+
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+
+def _make(name, grid, amp):
+    if name == "balancing":
+        from thinshelllab_amd.task_scene.Scene_balancing import Scene
+        s = Scene(cloth_size=0.12 * grid / 224 if grid > 100 else 0.06, cloth_N=grid, cloth_M=grid)
+    else:
+        from thinshelllab_amd.task_scene.Scene_folding import Scene
+        s = Scene(cloth_size=0.1, cloth_N=grid, cloth_M=grid // 2)
+    s.init_all()
+    s.mu_cloth_elastic[None] = 5.0
+    s.prev_pos.copy_from(s.pos)
+    s._ensure_ctx().set_param("direct", 1)
+    s._test_name, s._test_amp = name, amp
+    return s
+
+
+def _drive(s, f):
+    n_part = s.gripper.n_part
+    dpos = np.zeros((n_part, 3)); drot = np.zeros((n_part, 3))
+    if s._test_name == "balancing":
+        dpos[:, 2] = np.array([1e-4, -1e-4][:n_part]) * s._test_amp
+    else:
+        dpos[:, 2] = -2e-4 * s._test_amp
+    s.action(f, dpos, drot)
+
+
+def _rollout(specs, T, grouped):
+    """the scenes of `specs` for T - 1 driven steps and the reverse sweep, stepped together (grouped) or one after the other"""
+    from thinshelllab_amd.engine.analytic_grad_single import Grad
+    from thinshelllab_amd.engine.geometry import projection_query
+    from thinshelllab_amd.scene_group import SceneGroup
+    scenes = [_make(*sp) for sp in specs]
+    grads = []
+    for s in scenes:
+        g = Grad(s, T, s.gripper.n_part); g.init_mass(s); g.copy_pos(s, 0)
+        grads.append(g)
+    stats = [[] for _ in scenes]
+    info = None
+    if grouped:
+        G = SceneGroup(scenes)
+        for f in range(1, T):
+            for s in scenes:
+                _drive(s, f)
+            sts = G.time_step(projection_query, f)
+            for i, (s, g) in enumerate(zip(scenes, grads)):
+                g.copy_pos(s, f)
+                stats[i].append(sts[i])
+        info = G.info()
+    else:
+        for i, (s, g) in enumerate(zip(scenes, grads)):
+            for f in range(1, T):
+                _drive(s, f)
+                stats[i].append(s.time_step(projection_query, f))
+                g.copy_pos(s, f)
+    out = []
+    for i, (s, g) in enumerate(zip(scenes, grads)):   # the reverse sweep runs on the member's own path in both cases
+        if s._test_name == "balancing":
+            g.get_loss_balance(s)
+        else:
+            g.get_loss_fold(s, 1.0, -1.0, rows=s.fold_rows())
+        for k in range(T - 1, 0, -1):
+            g.transfer_grad(k, s, projection_query)
+        keys = ("nc", "newton_iters", "ls_evals", "cg_iters", "unconverged", "energy", "last_delta", "last_alpha", "max_rel_residual")
+        out.append(dict(pos_buffer=g.pos_buffer.to_numpy().copy(), pos_grad=g.pos_grad.to_numpy().copy(), gripper_grad=g.gripper_grad.to_numpy().copy(),
+                        stats=np.array([[st[k] for k in keys] for st in stats[i]], dtype=np.float64)))
+    if grouped:
+        G.close()
+    del scenes, grads
+    gc.collect()
+    return out, info
+
+
+@pytest.mark.parametrize("specs", [
+    [("balancing", 48, 1.0), ("balancing", 48, 1.3)],                                   # one topology, two trajectories
+    [("balancing", 48, 1.0), ("folding", 60, 1.0), ("balancing", 64, 0.7)],             # different topologies, tree depths and contact sets
+])
+def test_group_members_match_their_single_scene_rollouts_bit_for_bit(specs):
+    T = 4
+    single, _ = _rollout(specs, T, grouped=False)
+    group, info = _rollout(specs, T, grouped=True)
+    assert info["merged_factorizations"] > 0 and info["merged_applications"] == info["merged_factorizations"], info
+    for i, (a, b) in enumerate(zip(single, group)):
+        assert a["stats"][:, 0].max() > 0, "no contact in the rollout"
+        for k in a:
+            assert np.array_equal(a[k], b[k]), f"scene {i} {specs[i]}: {k} differs (max |d| = {np.abs(a[k] - b[k]).max():.3e})"
+
+
+def test_group_of_one_and_regrouping():
+    """a group of a single scene is that scene; members can be regrouped after a group is closed (their buffers come back)"""
+    from thinshelllab_amd.engine.geometry import projection_query
+    from thinshelllab_amd.scene_group import SceneGroup
+    a, b = _make("balancing", 48, 1.0), _make("balancing", 48, 1.0)
+    G = SceneGroup([a])
+    for f in range(1, 3):
+        _drive(a, f); _drive(b, f)
+        G.time_step(projection_query, f)
+        b.time_step(projection_query, f)
+    assert np.array_equal(a.pos.to_numpy(), b.pos.to_numpy())
+    G.close()
+    G2 = SceneGroup([a, b])
+    for f in range(3, 5):
+        _drive(a, f); _drive(b, f)
+        sts = G2.time_step(projection_query, f)
+    assert np.array_equal(a.pos.to_numpy(), b.pos.to_numpy()) and sts[0]["newton_iters"] == sts[1]["newton_iters"]
+    G2.close()
+    _drive(a, 5); a.time_step(projection_query, 5)     # ... and step alone again
+    assert np.isfinite(a.pos.to_numpy()).all()

@@ -82,6 +82,9 @@ class TslContext:
 
     def close(self):
         if getattr(self, "h", None) is not None and self.h:
+            g = getattr(self, "_group", None)
+            if g is not None:   # member of a scene group: the group goes first (the members get buffers of their own again)
+                g.close()
             self.L.tsl_ctx_destroy(self.h)
             self.h = None
 

@@ -39,6 +39,7 @@ static void ds_flow_token_release(DirectSolver& d) {
   d.flow_token_fd = -1; d.flow_token = 0;
 }
 static bool ds_flow_token_held(DirectSolver& d) {
+  if (d.token_lender) return ds_flow_token_held(*d.token_lender);   // member of a scene group: the group's token (its host thread runs group and members one after the other)
   if (d.flow_token == 0 || (d.flow_token < 0 && d.n_factor - d.flow_token_asked >= 256)) ds_flow_token_acquire(d);
   return d.flow_token > 0;
 }
@@ -274,8 +275,10 @@ static void ds_cache_trim(DirectSolver& d) {
 }
 
 // plan for the current constraint set (rebuilt only when the set differs from the one the plan was made for)
+static int group_ensure_arenas(tsl_ctx* c);   // direct_group.hpp
 static int direct_plan(tsl_ctx* c) {
   DirectSolver& d = c->ds;
+  if (d.merged) return 0;   // the merged plan of a scene group is managed by the group
   hipStream_t s = c->stream;
   TSL_TRY(direct_static(c));
   if (d.plan_valid && d.cons_checked) return 0;   // every Newton iteration of a step factorises on the step's constraint set
@@ -302,6 +305,7 @@ static int direct_plan(tsl_ctx* c) {
       TSL_TRY(ds_upload_con(d, s));
       HIP_OK(hipStreamSynchronize(s));
       d.h_cons = cons;
+      d.plan_gen++;
     }
     d.numeric_valid = false; d.have_factor = false;
     return 0;
@@ -315,7 +319,8 @@ static int direct_plan(tsl_ctx* c) {
         ds_swap_slot(d, *sl);
         sl->used = d.plan_valid; sl->key = ds_cons_key(sl->h_cset); sl->stamp = ++d.cache_clock;
         d.plan_valid = true;
-        d.n_plan_hits++;
+        d.n_plan_hits++; d.plan_gen++;
+        if (c->group) TSL_TRY(group_ensure_arenas(c));
         if (c->verbose >= 2) fprintf(stderr, "[tsl] direct plan: cached plan reused (nc %d, %d supernodes)\n", c->nc, d.plan.sym.n_sn);
         return same_set_new_order();
       }
@@ -373,18 +378,21 @@ static int direct_plan(tsl_ctx* c) {
   for (size_t i = 0; i < frl.size(); i++) frl[i] = P.fr[P.level_sn[i]];
   TSL_TRY(ds_upload_grow(d.frl, frl, s, &d));
   TSL_TRY(ds_upload_grow(d.wl_front, P.wl_front, s, &d)); TSL_TRY(ds_upload_grow(d.wl_row, P.wl_row, s, &d));
-  if (d.prezero_pending && d.arena.n < (size_t)P.arena) { HIP_OK(hipEventSynchronize(d.ev_zero)); d.prezero_pending = false; }   // the clear runs on the buffer about to be replaced
-  if (d.arena.n < (size_t)P.arena) { if (d.arena.alloc((size_t)P.arena + (size_t)P.arena / 8)) return tsl_fail("direct solver: out of device memory (%.2f GB of front panels)", P.arena * 8e-9); }
-  if (d.sarena.n < (size_t)P.sarena) { if (d.sarena.alloc((size_t)P.sarena + (size_t)P.sarena / 8 + 16)) return tsl_fail("direct solver: out of device memory (%.2f GB of Schur complements)", P.sarena * 8e-9); }
-  if (d.garena.n < (size_t)P.garena) { if (d.garena.alloc((size_t)P.garena + (size_t)P.garena / 8 + 16)) return tsl_fail("direct solver: out of device memory (G arena)"); }
+  if (c->group) TSL_TRY(group_ensure_arenas(c));   // panels, Schur complements, G and the sweeps' boundary vector live in the group's memory
+  else {
+    if (d.prezero_pending && d.arena.n < (size_t)P.arena) { HIP_OK(hipEventSynchronize(d.ev_zero)); d.prezero_pending = false; }   // the clear runs on the buffer about to be replaced
+    if (d.arena.n < (size_t)P.arena) { if (d.arena.alloc((size_t)P.arena + (size_t)P.arena / 8)) return tsl_fail("direct solver: out of device memory (%.2f GB of front panels)", P.arena * 8e-9); }
+    if (d.sarena.n < (size_t)P.sarena) { if (d.sarena.alloc((size_t)P.sarena + (size_t)P.sarena / 8 + 16)) return tsl_fail("direct solver: out of device memory (%.2f GB of Schur complements)", P.sarena * 8e-9); }
+    if (d.garena.n < (size_t)P.garena) { if (d.garena.alloc((size_t)P.garena + (size_t)P.garena / 8 + 16)) return tsl_fail("direct solver: out of device memory (G arena)"); }
+    if (d.w.n < (size_t)P.ylen) { if (d.w.alloc((size_t)P.ylen + (size_t)P.ylen / 4 + 16)) return -1; }
+  }
   if (d.scr.n < (size_t)P.scratch) { if (d.scr.alloc((size_t)P.scratch + (size_t)P.scratch / 8)) return -1; }
-  if (d.w.n < (size_t)P.ylen) { if (d.w.alloc((size_t)P.ylen + (size_t)P.ylen / 4 + 16)) return -1; }
   HIP_OK(hipStreamSynchronize(s));  // host vectors of this function go out of scope
   d.h_cons.swap(cons); d.h_cset.swap(cset);
   d.plan_valid = true;
   d.numeric_valid = false;
   d.have_factor = false;
-  d.n_plans++;
+  d.n_plans++; d.plan_gen++;
   d.t_plan += std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
   if (c->verbose >= 2)
     fprintf(stderr, "[tsl] direct plan: %d supernodes, %d levels, %zu batches, %.2f + %.2f GB of panels + Schur complements, %.1f GFLOP per factorisation, nc %d; host %.2f ms (tree + maps %.2f)\n", P.sym.n_sn, P.n_levels, P.batches.size(), P.arena * 8e-9, P.sarena * 8e-9,
@@ -417,7 +425,8 @@ static int direct_prezero(tsl_ctx* c) {
   HIP_OK(hipEventRecord(d.ev_zfork, c->stream));
   HIP_OK(hipStreamWaitEvent(d.zstream, d.ev_zfork, 0));
   d.prezero_n = (size_t)d.plan.arena_leaf;
-  HIP_OK(hipMemsetAsync(d.arena.p, 0, d.prezero_n * sizeof(double), d.zstream));
+  if (d.plan.leaf_ranges.empty()) HIP_OK(hipMemsetAsync(d.arena.p, 0, d.prezero_n * sizeof(double), d.zstream));
+  else for (const auto& r : d.plan.leaf_ranges) HIP_OK(hipMemsetAsync(d.arena.p + r.first, 0, (size_t)r.second * sizeof(double), d.zstream));   // (merged plan: every member's leaf panels)
   HIP_OK(hipEventRecord(d.ev_zero, d.zstream));
   d.prezero_pending = true;
   d.numeric_valid = false; d.have_factor = false;
@@ -426,8 +435,14 @@ static int direct_prezero(tsl_ctx* c) {
 
 // z = (LU)^-1 r, permuted solver vectors (r is not modified; z may not alias r)
 // one launch of the level sweeps: chunks wl[o .. o + n) in `mode`; few chunks (upper levels) -> four narrow workgroups per chunk
-static void ds_launch_gemv(hipStream_t s, const DsDev& D, DirectSolver& d, int o, int n, int mode, const double* vin, double* vout) {
+static void ds_launch_gemv(hipStream_t s, const DsDev& D, DirectSolver& d, int o, int n, int mode, const double* vin, double* vout, int wide_from = -1) {
   if (n <= 0) return;
+  if (wide_from >= 0) {   // merged plan of a scene group: chunks [o, wide_from) in the plain kernel, [wide_from, o + n) in the wide one (every member keeps the kernel of its own launch)
+    const int n0 = wide_from - o, n1 = o + n - wide_from;
+    if (n0 > 0) hipLaunchKernelGGL(k_ds_gemv, dim3(n0), dim3(256), 0, s, D, d.wl_front.p, d.wl_row.p, o, mode, vin, vout);
+    if (n1 > 0) hipLaunchKernelGGL(k_ds_gemv_wide, dim3(4 * n1), dim3(256), 0, s, D, d.wl_front.p, d.wl_row.p, wide_from, mode, vin, vout);
+    return;
+  }
   if (d.gemv_wide_below > 0 && n < d.gemv_wide_below) hipLaunchKernelGGL(k_ds_gemv_wide, dim3(4 * n), dim3(256), 0, s, D, d.wl_front.p, d.wl_row.p, o, mode, vin, vout);
   else hipLaunchKernelGGL(k_ds_gemv, dim3(n), dim3(256), 0, s, D, d.wl_front.p, d.wl_row.p, o, mode, vin, vout);
 }
@@ -435,8 +450,8 @@ static void ds_launch_gemv(hipStream_t s, const DsDev& D, DirectSolver& d, int o
 static void ds_sweep_up_level(hipStream_t s, const DsDev& D, DirectSolver& d, int l, const double* r, double* z) {
   const DirectPlan& P = d.plan;
   const int o0 = P.wl_own_ptr[l], b0 = P.wl_bnd_ptr[l], o1 = P.wl_own_ptr[l + 1];
-  ds_launch_gemv(s, D, d, o0, b0 - o0, 0, r, z);
-  ds_launch_gemv(s, D, d, b0, o1 - b0, 1, (const double*)z, nullptr);
+  ds_launch_gemv(s, D, d, o0, b0 - o0, 0, r, z, P.wl_own_wide.empty() ? -1 : P.wl_own_wide[l]);
+  ds_launch_gemv(s, D, d, b0, o1 - b0, 1, (const double*)z, nullptr, P.wl_bnd_wide.empty() ? -1 : P.wl_bnd_wide[l]);
 }
 // numeric factorisation of the operator of the last assemble (c->vals + masked contact blocks c->c_H)
 static int direct_factor(tsl_ctx* c, int stop_sn = -1, const char* dump_path = nullptr) {
@@ -449,8 +464,9 @@ static int direct_factor(tsl_ctx* c, int stop_sn = -1, const char* dump_path = n
   if (d.prezero_pending) {   // cleared on the side stream since the last solve (direct_prezero)
     HIP_OK(hipStreamWaitEvent(s, d.ev_zero, 0));
     d.prezero_pending = false;
-    if (d.prezero_n < (size_t)P.arena_leaf) HIP_OK(hipMemsetAsync(d.arena.p + d.prezero_n, 0, ((size_t)P.arena_leaf - d.prezero_n) * sizeof(double), s));   // a new plan with more leaf panels
-  } else HIP_OK(hipMemsetAsync(d.arena.p, 0, (size_t)P.arena_leaf * sizeof(double), s));
+    if (P.leaf_ranges.empty() && d.prezero_n < (size_t)P.arena_leaf) HIP_OK(hipMemsetAsync(d.arena.p + d.prezero_n, 0, ((size_t)P.arena_leaf - d.prezero_n) * sizeof(double), s));   // a new plan with more leaf panels
+  } else if (P.leaf_ranges.empty()) HIP_OK(hipMemsetAsync(d.arena.p, 0, (size_t)P.arena_leaf * sizeof(double), s));
+  else for (const auto& r : P.leaf_ranges) HIP_OK(hipMemsetAsync(d.arena.p + r.first, 0, (size_t)r.second * sizeof(double), s));
   HIP_OK(hipMemsetAsync(d.bad.p, 0, 8 * sizeof(int), s));
   // (a persistent dataflow launch runs next to ordinary launches of sibling batches -- those end by themselves --, never next to a second one)
   auto run_batch = [&](const DsBatch& b, hipStream_t bs, bool& flow_free) {
@@ -569,7 +585,7 @@ static int direct_apply(tsl_ctx* c, const double* r, double* z) {
   for (int l = 0; l < P.n_levels; l++) ds_sweep_up_level(s, D, d, l, r, z);
   for (int l = P.n_levels - 2; l >= 0; l--) {   // the top level has no boundary
     const int o0 = P.wl_own_ptr[l], b0 = P.wl_bnd_ptr[l];
-    ds_launch_gemv(s, D, d, o0, b0 - o0, 2, (const double*)z, z);
+    ds_launch_gemv(s, D, d, o0, b0 - o0, 2, (const double*)z, z, P.wl_own_wide.empty() ? -1 : P.wl_own_wide[l]);
   }
   d.n_apply++;
   return 0;

@@ -92,6 +92,10 @@ struct DirectPlan {
   std::vector<long long> cgr_dst;
   std::vector<int> level_maxld;
   long long arena_leaf = 0;        // extent of the leaf level's panels at the head of the panel arena (doubles)
+  std::vector<std::pair<long long, long long>> leaf_ranges;   // merged plan of a scene group: (offset, extent) of every member's leaf panels; empty: [0, arena_leaf)
+  // merged plan: first chunk of the WIDE part of the own / boundary chunk lists of every level (chunks of members whose own launch would be
+  // k_ds_gemv_wide come last: the two sweep kernels round differently, every member keeps the kernel of its single-scene run); empty: the rule of ds_launch_gemv
+  std::vector<int> wl_own_wide, wl_bnd_wide;
   std::vector<std::vector<int>> lists;   // scratch of the level-by-level block list (per host thread and level)
   std::vector<int> level_ptr, level_sn;          // fronts per level (level 0 = leaves)
   std::vector<DsBatch> batches;                  // in level order
@@ -129,6 +133,78 @@ struct DirectPlan {
     if (lc >= f.pp) { *ld_out = 0; return -1; }
     *ld_out = f.pp;
     return f.off21 + (long long)(lr - f.pp) * f.pp + lc;
+  }
+
+  // fronts of every level (by_level[l]: ids into `fr`) -> level_sn / level_ptr, the batches of every level, the active-front tables of the
+  // block steps, the per-level scratch offsets of the fronts, the work lists of the solve sweeps.  Used by build() for one scene and by
+  // merge() for the fronts of several scenes that share the launches of a level (direct_group.hpp).
+  void build_levels(std::vector<std::vector<int>>& by_level) {
+    const int L = (int)by_level.size();
+    n_levels = L;
+    level_ptr.assign(L + 1, 0); level_sn.clear();
+    batches.clear(); act_n.clear(); act_ld.clear();
+    wl_front.clear(); wl_row.clear(); wl_own_ptr.assign(L + 1, 0); wl_bnd_ptr.assign(L, 0);
+    sweep_cache_L0 = -1;
+    scratch = 0;
+    // a new batch starts where the pivot block falls below a quarter of the batch's largest (empty workgroups of the smaller
+    // fronts are cheap, an extra batch costs its block steps in sequence); on a level with hundreds of fronts a batch of 32 or
+    // more also ends where the pivot block shrinks at all (a handful of larger fronts must not size the grid of a thousand leaves)
+    for (int l = 0; l < L; l++) {
+      std::vector<int>& fl = by_level[l];
+      std::stable_sort(fl.begin(), fl.end(), [&](int a, int b) { return fr[a].pp > fr[b].pp; });
+      long long scr = 0;
+      for (size_t i = 0; i < fl.size(); i++) {
+        const int s = fl[i];
+        DsFrontDesc& f = fr[s];
+        // (round 4) ... and where fronts that fit the LDS kernel, of at most half the batch's largest pivot block, follow fronts that do not
+        // (cfg4 level 2: 2 x 224, 2 x 192 and 128 x 64 pivots -- the 128 small ones went through the seven block steps of the four large ones)
+        if (i == 0 || 4 * f.pp <= batches.back().max_pp || (fl.size() > 256 && batches.back().count >= 32 && f.pp < fr[fl[i - 1]].pp) ||
+            (split_small && batches.back().max_pp > DS_SMALL && f.pp <= DS_SMALL && 2 * f.pp <= batches.back().max_pp)) {
+          DsBatch b{};
+          b.first = (int)level_sn.size(); b.count = 0; b.level = l;
+          batches.push_back(b);
+        }
+        DsBatch& b = batches.back();
+        b.count++;
+        b.max_pp = std::max(b.max_pp, f.pp); b.max_ld = std::max(b.max_ld, f.ld); b.max_bp = std::max(b.max_bp, f.bp);
+        level_sn.push_back(s);
+        f.scr_off = (int)scr;
+        scr += 2LL * DS_T * DS_T + 4LL * DS_T * f.pp;  // pivot-block inverses, row and column side panels (ping-pong each)
+      }
+      // (round 4) a batch of the LDS kernel that needs one more round of the chip for a few fronts hands them to a batch of their own, which
+      // takes another path next to it (cfg4 level 1: 261 fronts of 128 pivots, one workgroup per CU -- 256 in the first round, 5 in a second
+      // one that took as long)
+      if (split_rem)
+        for (size_t q = 0; q < batches.size(); q++) {
+          DsBatch& b = batches[q];
+          if (b.level != l || b.max_pp > DS_SMALL) continue;
+          const int cap = n_cu * ds_small_per_cu(b.max_pp), rem = b.count % cap;
+          if (b.count <= cap || rem == 0 || rem > cap / 8) continue;
+          DsBatch r{};
+          r.first = b.first + b.count - rem; r.count = rem; r.level = l;
+          b.count -= rem;
+          for (int z = 0; z < r.count; z++) { const DsFrontDesc& f = fr[level_sn[r.first + z]]; r.max_pp = std::max(r.max_pp, f.pp); r.max_ld = std::max(r.max_ld, f.ld); r.max_bp = std::max(r.max_bp, f.bp); }
+          b.max_ld = 0; b.max_bp = 0;
+          for (int z = 0; z < b.count; z++) { const DsFrontDesc& f = fr[level_sn[b.first + z]]; b.max_ld = std::max(b.max_ld, f.ld); b.max_bp = std::max(b.max_bp, f.bp); }
+          batches.insert(batches.begin() + q + 1, r);
+          q++;
+        }
+      level_ptr[l + 1] = (int)level_sn.size();
+      scratch = std::max(scratch, scr);
+      wl_own_ptr[l] = (int)wl_front.size();
+      for (int s : fl) for (int r = 0; r < fr[s].p; r += 16) { wl_front.push_back(s); wl_row.push_back(r); }
+      wl_bnd_ptr[l] = (int)wl_front.size();
+      for (int s : fl) for (int r = 0; r < fr[s].b; r += 16) { wl_front.push_back(s); wl_row.push_back(r); }
+    }
+    wl_own_ptr[L] = (int)wl_front.size();
+    for (DsBatch& b : batches) {
+      b.act_off = (int)act_n.size();
+      for (int k = 0; k * DS_T < b.max_pp; k++) {
+        int n = 0, mld = 0;
+        while (n < b.count && fr[level_sn[b.first + n]].pp > k * DS_T) { mld = std::max(mld, fr[level_sn[b.first + n]].ld); n++; }
+        act_n.push_back(n); act_ld.push_back(mld);
+      }
+    }
   }
 
   // adj: sorted adjacency (with or without self); row_ptr: CSR offsets of adj (blocks are numbered row by row);
@@ -217,75 +293,13 @@ struct DirectPlan {
     // levels: as soon as possible (a front sits one level above its deepest child): the small fronts of the FEM bodies' own
     // dissection trees and of shallow subtrees then share the batches of the ~10^3 cloth leaves instead of adding batches of their
     // own next to the few large fronts near the root, where every batch costs its block steps in sequence
+    {
+      std::vector<std::vector<int>> by_level(sym.n_levels);
+      for (int s = 0; s < S; s++) by_level[sym.level[s]].push_back(s);
+      build_levels(by_level);
+    }
     const int L = sym.n_levels;
-    n_levels = L;
     const std::vector<int>& alap = sym.level;
-    std::vector<std::vector<int>> by_level(L);
-    for (int s = 0; s < S; s++) by_level[alap[s]].push_back(s);
-    level_ptr.assign(L + 1, 0); level_sn.clear();
-    batches.clear(); act_n.clear(); act_ld.clear();
-    wl_front.clear(); wl_row.clear(); wl_own_ptr.assign(L + 1, 0); wl_bnd_ptr.assign(L, 0);
-    sweep_cache_L0 = -1;
-    scratch = 0;
-    // a new batch starts where the pivot block falls below a quarter of the batch's largest (empty workgroups of the smaller
-    // fronts are cheap, an extra batch costs its block steps in sequence); on a level with hundreds of fronts a batch of 32 or
-    // more also ends where the pivot block shrinks at all (a handful of larger fronts must not size the grid of a thousand leaves)
-    for (int l = 0; l < L; l++) {
-      std::vector<int>& fl = by_level[l];
-      std::stable_sort(fl.begin(), fl.end(), [&](int a, int b) { return fr[a].pp > fr[b].pp; });
-      long long scr = 0;
-      for (size_t i = 0; i < fl.size(); i++) {
-        const int s = fl[i];
-        DsFrontDesc& f = fr[s];
-        // (round 4) ... and where fronts that fit the LDS kernel, of at most half the batch's largest pivot block, follow fronts that do not
-        // (cfg4 level 2: 2 x 224, 2 x 192 and 128 x 64 pivots -- the 128 small ones went through the seven block steps of the four large ones)
-        if (i == 0 || 4 * f.pp <= batches.back().max_pp || (fl.size() > 256 && batches.back().count >= 32 && f.pp < fr[fl[i - 1]].pp) ||
-            (split_small && batches.back().max_pp > DS_SMALL && f.pp <= DS_SMALL && 2 * f.pp <= batches.back().max_pp)) {
-          DsBatch b{};
-          b.first = (int)level_sn.size(); b.count = 0; b.level = l;
-          batches.push_back(b);
-        }
-        DsBatch& b = batches.back();
-        b.count++;
-        b.max_pp = std::max(b.max_pp, f.pp); b.max_ld = std::max(b.max_ld, f.ld); b.max_bp = std::max(b.max_bp, f.bp);
-        level_sn.push_back(s);
-        f.scr_off = (int)scr;
-        scr += 2LL * DS_T * DS_T + 4LL * DS_T * f.pp;  // pivot-block inverses, row and column side panels (ping-pong each)
-      }
-      // (round 4) a batch of the LDS kernel that needs one more round of the chip for a few fronts hands them to a batch of their own, which
-      // takes another path next to it (cfg4 level 1: 261 fronts of 128 pivots, one workgroup per CU -- 256 in the first round, 5 in a second
-      // one that took as long)
-      if (split_rem)
-        for (size_t q = 0; q < batches.size(); q++) {
-          DsBatch& b = batches[q];
-          if (b.level != l || b.max_pp > DS_SMALL) continue;
-          const int cap = n_cu * ds_small_per_cu(b.max_pp), rem = b.count % cap;
-          if (b.count <= cap || rem == 0 || rem > cap / 8) continue;
-          DsBatch r{};
-          r.first = b.first + b.count - rem; r.count = rem; r.level = l;
-          b.count -= rem;
-          for (int z = 0; z < r.count; z++) { const DsFrontDesc& f = fr[level_sn[r.first + z]]; r.max_pp = std::max(r.max_pp, f.pp); r.max_ld = std::max(r.max_ld, f.ld); r.max_bp = std::max(r.max_bp, f.bp); }
-          b.max_ld = 0; b.max_bp = 0;
-          for (int z = 0; z < b.count; z++) { const DsFrontDesc& f = fr[level_sn[b.first + z]]; b.max_ld = std::max(b.max_ld, f.ld); b.max_bp = std::max(b.max_bp, f.bp); }
-          batches.insert(batches.begin() + q + 1, r);
-          q++;
-        }
-      level_ptr[l + 1] = (int)level_sn.size();
-      scratch = std::max(scratch, scr);
-      wl_own_ptr[l] = (int)wl_front.size();
-      for (int s : fl) for (int r = 0; r < fr[s].p; r += 16) { wl_front.push_back(s); wl_row.push_back(r); }
-      wl_bnd_ptr[l] = (int)wl_front.size();
-      for (int s : fl) for (int r = 0; r < fr[s].b; r += 16) { wl_front.push_back(s); wl_row.push_back(r); }
-    }
-    wl_own_ptr[L] = (int)wl_front.size();
-    for (DsBatch& b : batches) {
-      b.act_off = (int)act_n.size();
-      for (int k = 0; k * DS_T < b.max_pp; k++) {
-        int n = 0, mld = 0;
-        while (n < b.count && fr[level_sn[b.first + n]].pp > k * DS_T) { mld = std::max(mld, fr[level_sn[b.first + n]].ld); n++; }
-        act_n.push_back(n); act_ld.push_back(mld);
-      }
-    }
     lap(2);
     // static blocks: block (r, c) of the pattern lives in the front of the earlier-eliminated of its two vertices.  One pass over
     // the supernodes with a scattered vertex -> local index table (own vertices and boundary of the current front) and the static

@@ -31,7 +31,9 @@ template <class T>
 struct DevBuf {
   T* p = nullptr;
   size_t n = 0;
+  bool owned = true;   // false: a VIEW into memory of a scene group (direct_group.hpp): never freed or re-allocated here
   int alloc(size_t count) {
+    if (!owned) return tsl_fail("internal: allocation of %zu B requested for a buffer that is a view into a scene group's memory", count * sizeof(T));
     release();
     n = count;
     if (count == 0) return 0;
@@ -52,8 +54,9 @@ struct DevBuf {
     if (e != hipSuccess) return tsl_fail("hipMemset failed: %s", hipGetErrorString(e));
     return 0;
   }
-  void release() { if (p) { (void)hipFree(p); p = nullptr; } n = 0; }
-  void swap(DevBuf& o) { std::swap(p, o.p); std::swap(n, o.n); }
+  void release() { if (p && owned) (void)hipFree(p); p = nullptr; n = 0; owned = true; }
+  void view(T* q, size_t count) { release(); p = q; n = count; owned = false; }
+  void swap(DevBuf& o) { std::swap(p, o.p); std::swap(n, o.n); std::swap(owned, o.owned); }
   DevBuf() = default;
   DevBuf(const DevBuf&) = delete;
   DevBuf& operator=(const DevBuf&) = delete;
@@ -182,6 +185,9 @@ struct DirectSolver {
   DevBuf<DsChildRec> ch_rec;
   DevBuf<double> arena, sarena, garena, scr, w;   // panel arena (cleared per factorisation), Schur arena (never cleared), G arena
   long n_plans = 0, n_factor = 0, n_apply = 0, n_perturbed = 0;
+  long plan_gen = 0;          // counts every change of the device arrays of the active plan (new plan, cached plan swapped in, contact map redone): a scene group re-merges on it
+  bool merged = false;        // the solver of a scene group's pseudo-context: its plan is the merge of the members' plans (direct_group.hpp), direct_plan does nothing
+  DirectSolver* token_lender = nullptr;   // member of a scene group: the group's solver, whose dataflow token the member may use (the host runs them in lock step)
   double t_plan = 0;          // host seconds spent in plan builds
   double anorm = 0;           // infinity norm of the factorised operator's static part (backward-error yardstick)
   bool anorm_valid = false;   // anorm belongs to an operator at most 64 factorisations old
@@ -190,7 +196,9 @@ struct DirectSolver {
   hipEvent_t ev0 = nullptr, ev1 = nullptr;
 };
 
+struct tsl_group;
 struct tsl_ctx {
+  tsl_group* group = nullptr;   // set while the context is a member of a scene group (its matrix, right-hand side / solution vectors and fronts are views into the group's memory)
   hipStream_t stream = 0;       // internal non-blocking work stream (graph capture needs a real stream)
   hipStream_t user_stream = 0;  // caller's stream (tsl_set_stream); ordered with `stream` through events at every entry point
   hipEvent_t ev_in = nullptr, ev_out = nullptr;

@@ -5,6 +5,7 @@
 // There is no CPU fallback in this library: without a HIP device every entry point fails.
 #include <stdarg.h>
 #include <chrono>
+#include <mutex>
 
 #include <array>
 #include <map>
@@ -29,6 +30,7 @@ int tsl_fail(const char* fmt, ...) {
 
 #define TSL_TRY(x) do { if ((x) != 0) return -1; } while (0)
 #include "direct_host.hpp"
+#include "direct_group.hpp"
 
 #ifndef PCG_WPS
 #define PCG_WPS 4
@@ -383,8 +385,10 @@ extern "C" int tsl_ctx_create(const tsl_scene_desc* d, tsl_ctx** out) {
   return 0;
 }
 
+static void group_unregister_and_destroy(tsl_group* G);
 extern "C" void tsl_ctx_destroy(tsl_ctx* c) {
   if (!c) return;
+  if (c->group) group_unregister_and_destroy(c->group);   // (a member that goes takes the group with it: the others get buffers of their own again)
   (void)hipDeviceSynchronize();
   ds_flow_token_release(c->ds);   // (after the last launch of the context has ended)
   if (c->h_scal) (void)hipHostFree(c->h_scal);
@@ -454,6 +458,7 @@ extern "C" int tsl_set_param(tsl_ctx* c, const char* key, double v) {
   else if (k == "ds_bench_batch") c->ds.bench_batch = (int)v;
   else if (k == "direct_prezero") c->ds.prezero = (int)v;
   else if (k == "direct_flow") c->ds.flow = std::max(0, (int)v);
+  else if (k == "direct_flow_token") { if (v == 0) ds_flow_token_release(c->ds); }   // 0: hand the device's dataflow token back (asked for again at the next eligible factorisation)
   else if (k == "deterministic") c->deterministic = (int)v != 0;
   else if (k == "direct_gemv_wide_below") c->ds.gemv_wide_below = std::max(0, (int)v);
   else if (k == "direct_g32_below") c->ds.g32_below = std::max(0, (int)v);
@@ -902,7 +907,7 @@ static int read_scal(tsl_ctx* c) {
 
 static int bicgstab(tsl_ctx* c, tsl_solve_stats* st);
 static int gmres(tsl_ctx* c, tsl_solve_stats* st, bool direct = false);
-static int direct_refine(tsl_ctx* c, tsl_solve_stats* st);
+static int direct_refine(tsl_ctx* c, tsl_solve_stats* st, bool first_applied = false);
 static int minres(tsl_ctx* c, tsl_solve_stats* st);
 
 // ------------------------------------------------------------------------------------------------ dense body blocks (k_body.hpp)
@@ -1932,7 +1937,8 @@ static int gmres(tsl_ctx* c, tsl_solve_stats* st, bool direct) {
 // step; the flexible GMRES above spends 2 products, ~12 vector launches and 3-4 synchronisations on a one-iteration solve and is
 // kept for the systems refinement does not contract on (flag stays 3: the caller runs it from scratch).  Same acceptance rules:
 // |b - Hx| <= cg_tol |b|, or -- when a step no longer halves the residual -- a normwise backward error below 1e-12 ("attained").
-static int direct_refine(tsl_ctx* c, tsl_solve_stats* st) {
+// first_applied: x = M^-1 b is in place already (scene group: the merged application of the factors of every member, tsl_group_step)
+static int direct_refine(tsl_ctx* c, tsl_solve_stats* st, bool first_applied) {
   hipStream_t s = c->stream;
   const size_t n3 = 3 * (size_t)c->NV;
   const int gv = std::min(gsz(n3), 240);
@@ -1945,7 +1951,7 @@ static int direct_refine(tsl_ctx* c, tsl_solve_stats* st) {
   st->flag = 3;
   double rr_prev = 1e300;
   for (int it = 0; it < 4; it++) {
-    if (it == 0) TSL_TRY(direct_apply(c, c->v_b.p, x));
+    if (it == 0) { if (!first_applied) TSL_TRY(direct_apply(c, c->v_b.p, x)); }
     else {
       TSL_TRY(direct_apply(c, r, z));
       hipLaunchKernelGGL(k_axpby, dim3(gsz(n3)), dim3(256), 0, s, n3, 1.0, (const double*)z, 1.0, x);
@@ -2308,6 +2314,223 @@ extern "C" int tsl_step(tsl_ctx* c, double* pos, double* prev, double* vel, doub
   HIP_OK(hipGetLastError());
   if (st.solves > 0) c->last_step_iters_per_solve = (double)st.cg_iters / st.solves;
   if (stats) *stats = st;
+  return 0;
+}
+
+// ------------------------------------------------------------------------------------------------
+// Scene group (direct_group.hpp): S scenes of one GPU stepped in LOCK STEP by one host thread.  Every phase of a Newton iteration is issued
+// for all members before any of them is waited for -- energies, assemblies (each on the member's own three streams), the line-search trials --
+// and the sparse direct solves of all members are ONE factorisation and ONE application of the merged plan on the group's stream.  Per member
+// the sequence of kernels, their arguments and every decision (refinement stop rule, line-search halving, Newton stop rule, BaseScene.py:1327-1370)
+// are those of tsl_step, so a member's tape is bit-identical to its single-scene run.  A member whose merged first pass is not accepted goes
+// through its own solve path (its plan addresses the same factors; if they were cleared meanwhile it refactorises by itself).
+static std::mutex g_group_mu;
+static std::vector<tsl_group*> g_groups;
+static void group_unregister_and_destroy(tsl_group* G) {
+  { std::lock_guard<std::mutex> lk(g_group_mu);
+    auto it = std::find(g_groups.begin(), g_groups.end(), G);
+    if (it == g_groups.end()) return;
+    g_groups.erase(it); }
+  group_destroy(G);
+}
+extern "C" int tsl_group_create(tsl_ctx* const* ctxs, int32_t n, tsl_group** out) {
+  for (int i = 0; i < n; i++) if (!direct_enabled(ctxs[i])) return tsl_fail("tsl_group_create: scene %d does not use the sparse direct solve (\"direct\" = 1 or a cloth grid of >= 1024 cells)", i);
+  TSL_TRY(group_create(ctxs, n, out));
+  std::lock_guard<std::mutex> lk(g_group_mu);
+  g_groups.push_back(*out);
+  return 0;
+}
+extern "C" void tsl_group_destroy(tsl_group* G) { if (G) group_unregister_and_destroy(G); }
+// {merges of the members' plans, re-layouts of the group's arenas, host seconds in merges, bytes of the group's arenas, factorisations and applications of the merged plan}
+extern "C" int tsl_group_info(tsl_group* G, double* out6) {
+  out6[0] = (double)G->n_merge; out6[1] = (double)G->n_relayout; out6[2] = G->t_merge; out6[3] = 8.0 * (double)(G->arena.n + G->sarena.n + G->garena.n + G->w.n);
+  out6[4] = (double)G->g->ds.n_factor; out6[5] = (double)G->g->ds.n_apply;
+  return 0;
+}
+
+extern "C" int tsl_group_step(tsl_group* G, double* const* pos_a, double* const* prev_a, double* const* vel_a, double* const* ref_a, tsl_step_stats* stats) {
+  const int n = (int)G->m.size();
+  tsl_ctx* g = G->g;
+  std::vector<std::unique_ptr<Scope>> scopes;
+  for (int i = 0; i < n; i++) scopes.emplace_back(new Scope(G->m[i]));
+  struct InStep { tsl_group* G; ~InStep() { for (tsl_ctx* c : G->m) { c->in_step = false; c->st_pos = nullptr; } } } guard{G};
+  std::vector<tsl_step_stats> st(n);
+  std::vector<long> fact0(n), plans0(n);
+  std::vector<int> iter(n, 0), active(n, 1);
+  std::vector<double> delta(n, 1e5), E0(n, 0.0), E_last(n, 0.0), alpha(n, 1.0);
+  for (int i = 0; i < n; i++) {
+    tsl_ctx* c = G->m[i];
+    memset(&st[i], 0, sizeof(tsl_step_stats));
+    if (!direct_enabled(c)) return tsl_fail("tsl_group_step: scene %d does not use the sparse direct solve", i);
+    fact0[i] = c->ds.n_factor; plans0[i] = c->ds.n_plans;
+    c->in_step = true; c->warm_valid = false; c->mg_omega_valid = false; c->mg_cinv_valid = false; c->bd_valid = false; c->tm_loop = 0;
+    const size_t n3 = 3 * (size_t)c->NV;
+    HIP_OK(hipMemcpyAsync(prev_a[i], pos_a[i], n3 * sizeof(double), hipMemcpyDeviceToDevice, c->stream));   // timestep_init: prev_pos <- pos
+  }
+  for (int i = 0; i < n; i++) {   // calc_vn + projection_query + contact_analysis
+    tsl_ctx* c = G->m[i];
+    int nc = 0;
+    if (c->contact_enable) TSL_TRY(tsl_contact_detect(c, pos_a[i], prev_a[i], &nc));
+    else { c->nc = 0; c->ds.cons_checked = false; }
+    st[i].nc = nc;
+  }
+  const long gfact0 = g->ds.n_factor;
+  g->verbose = G->m[0]->verbose;
+  // verbose: host wall time per phase (every phase ends in a synchronisation of all streams when timed)
+  const bool timed = g->verbose >= 1;
+  double tph[6] = {0, 0, 0, 0, 0, 0};
+  auto tick = std::chrono::steady_clock::now();
+  auto lap = [&](int k) { if (!timed) return; for (tsl_ctx* c : G->m) (void)hipStreamSynchronize(c->stream); (void)hipStreamSynchronize(g->stream);
+                          const auto nw = std::chrono::steady_clock::now(); tph[k] += std::chrono::duration<double>(nw - tick).count(); tick = nw; };
+  for (;;) {
+    std::vector<int> act;
+    for (int i = 0; i < n; i++) if (active[i] && iter[i] < G->m[i]->newton_cap) act.push_back(i);
+    if (act.empty()) break;
+    // ---- energy at the top of the iteration (evaluated anew only in the first one), assembly, right-hand side
+    for (int i : act) { iter[i]++; if (iter[i] == 1) { tsl_ctx* c = G->m[i]; TSL_TRY(energy_async(c, pos_a[i], prev_a[i], vel_a[i], ref_a[i])); HIP_OK(hipMemcpyAsync(&HSC(c)->energy, &SC(c)->energy, sizeof(double), hipMemcpyDeviceToHost, c->stream)); } }
+    for (int i : act) { tsl_ctx* c = G->m[i]; if (iter[i] == 1) { HIP_OK(hipStreamSynchronize(c->stream)); E0[i] = HSC(c)->energy; } else E0[i] = E_last[i]; }
+    for (int i : act) { tsl_ctx* c = G->m[i]; TSL_TRY(assemble(c, pos_a[i], prev_a[i], vel_a[i], ref_a[i], 1, c->F.p)); }
+    for (int i : act) { tsl_ctx* c = G->m[i]; hipLaunchKernelGGL(k_gather_perm, dim3(nblk(c->NV, 256)), dim3(256), 0, c->stream, c->NV, c->perm.p, (const double*)c->F.p, c->v_b.p); }
+    lap(0);
+    // ---- plans: every member's own (rebuilt when its constraint set changed: once per time step), then the merge
+    for (int i = 0; i < n; i++) TSL_TRY(direct_plan(G->m[i]));
+    bool stale = !G->merged_valid;
+    for (int i = 0; i < n; i++) stale |= G->seen_gen[i] != G->m[i]->ds.plan_gen;
+    if (stale) {
+      for (int i = 0; i < n; i++) HIP_OK(hipStreamSynchronize(G->m[i]->stream));
+      TSL_TRY(group_merge(G));
+    }
+    lap(1);
+    // ---- ONE factorisation and ONE application for all members
+    for (int i = 0; i < n; i++) { HIP_OK(hipEventRecord(G->ev_m[i], G->m[i]->stream)); HIP_OK(hipStreamWaitEvent(g->stream, G->ev_m[i], 0)); }
+    g->ds.numeric_valid = false;
+    TSL_TRY(direct_factor(g));
+    lap(2);
+    TSL_TRY(direct_apply(g, G->vb.p, G->vx.p));
+    HIP_OK(hipEventRecord(G->ev_g, g->stream));
+    lap(3);
+    TSL_TRY(direct_prezero(g));   // the leaf panels of the next factorisation are cleared next to the residuals and the line search
+    for (int i = 0; i < n; i++) {
+      tsl_ctx* c = G->m[i];
+      HIP_OK(hipStreamWaitEvent(c->stream, G->ev_g, 0));
+      c->ds.numeric_valid = false; c->ds.have_factor = false;   // (the member's own path refactorises if it is needed: the panels are being cleared)
+    }
+    // ---- per member: residual of the merged first pass and the stop rule of direct_refine
+    std::vector<tsl_solve_stats> ss(n);
+    for (int i : act) {
+      tsl_ctx* c = G->m[i];
+      const size_t n3 = 3 * (size_t)c->NV;
+      const int gv = std::min(gsz(n3), 240);
+      if (c->ir_part.n < (size_t)4 * 240 + 8 && c->ir_part.alloc(4 * 240 + 8)) return -1;
+      if (c->ir_ticket.n < 2) { if (c->ir_ticket.alloc(2)) return -1; HIP_OK(hipMemsetAsync(c->ir_ticket.p, 0, 2 * sizeof(int), c->stream)); }
+      if (c->h_ir == nullptr) HIP_OK(hipHostMalloc((void**)&c->h_ir, 8 * sizeof(double)));
+      double* out = c->ir_part.p + 4 * 240;
+      launch_spmv(c, c->vals.p, c->v_x.p, c->v_Ap.p, -1, 0);
+      hipLaunchKernelGGL(k_ir_resid, dim3(gv), dim3(256), 0, c->stream, n3, (const double*)c->v_b.p, (const double*)c->v_Ap.p, (const double*)c->v_x.p, c->v_r.p, c->ir_part.p, c->ir_ticket.p, out);
+      HIP_OK(hipMemcpyAsync(c->h_ir, out, 4 * sizeof(double), hipMemcpyDeviceToHost, c->stream));
+    }
+    for (int i : act) {
+      tsl_ctx* c = G->m[i];
+      DirectSolver& d = c->ds;
+      HIP_OK(hipStreamSynchronize(c->stream));
+      tsl_solve_stats& s1 = ss[i];
+      memset(&s1, 0, sizeof(s1));
+      const double rr = c->h_ir[0], xx = c->h_ir[1], bb = c->h_ir[2];
+      c->last_xmax = c->h_ir[3]; c->last_xmax_valid = true;
+      s1.iters = 1; s1.method = 4;
+      bool ok = false;
+      if (!(bb > 0)) ok = true;
+      else {
+        s1.rel_residual = sqrt(rr / bb);
+        if (std::isfinite(rr)) {
+          if (rr <= c->cg_tol * c->cg_tol * bb) ok = true;
+          else if (d.berr_tol > 0 && rr <= d.berr_rel_cap * d.berr_rel_cap * c->cg_tol * c->cg_tol * bb) {   // (the rule of direct_refine's first pass)
+            TSL_TRY(direct_anorm(c));
+            const double be = sqrt(rr) / (d.anorm * sqrt(xx) + sqrt(bb));
+            d.berr_seen++;
+            if (be <= d.berr_tol) { ok = true; s1.backward_error = be; d.berr_accepted++; d.berr_max = std::max(d.berr_max, be); d.berr_rel_max = std::max(d.berr_rel_max, s1.rel_residual); }
+          }
+        }
+      }
+      if (!ok) {   // the member's own path from scratch (refactorisation, refinement, GMRES, the hierarchy): rare
+        HIP_OK(hipStreamWaitEvent(c->stream, g->ds.ev_zero ? g->ds.ev_zero : G->ev_g, 0));   // (its leaf panels are being cleared by the group)
+        if (g->ds.prezero_pending) {   // ... and will be written by the member's own factorisation: the next merged factorisation clears every member's leaf panels itself, behind the pending clear
+          HIP_OK(hipStreamWaitEvent(g->stream, g->ds.ev_zero, 0));
+          g->ds.prezero_pending = false;
+        }
+        TSL_TRY(solve_perm(c, &s1));
+        if (c->verbose) fprintf(stderr, "[tsl] scene group: member %d left the merged solve (rel_residual of the merged pass %.2e): own path, flag %d after %d applications\n", i, sqrt(rr / std::max(bb, 1e-300)), s1.flag, s1.iters);
+      }
+      tsl_step_stats& t = st[i];
+      t.cg_iters += s1.iters; t.solves++; t.restarts += s1.restarts; t.fallback += (s1.flag == 1); t.unconverged += (s1.flag == 3); t.attained += s1.attained;
+      t.max_rel_residual = std::max(t.max_rel_residual, s1.rel_residual); t.max_backward_error = std::max(t.max_backward_error, s1.backward_error);
+    }
+    lap(4);
+    // ---- direction, line search: all trials of a round are issued, then read
+    for (int i : act) {
+      tsl_ctx* c = G->m[i];
+      const size_t n3 = 3 * (size_t)c->NV;
+      hipStream_t s = c->stream;
+      hipLaunchKernelGGL(k_scatter_perm, dim3(nblk(c->NV, 256)), dim3(256), 0, s, c->NV, c->perm.p, (const double*)c->v_x.p, c->pdir.p);
+      const bool have_pmax = ss[i].method == 4 && ss[i].flag == 0 && c->last_xmax_valid;
+      if (have_pmax) HSC(c)->pmax = c->last_xmax;
+      else {
+        HIP_OK(hipMemsetAsync(&SC(c)->pmax, 0, sizeof(double), s));
+        hipLaunchKernelGGL(k_absmax, dim3(gsz(n3)), dim3(256), 0, s, n3, c->pdir.p, &SC(c)->pmax);
+        HIP_OK(hipMemcpyAsync(&HSC(c)->pmax, &SC(c)->pmax, sizeof(double), hipMemcpyDeviceToHost, s));
+      }
+      HIP_OK(hipMemcpyAsync(c->x1.p, pos_a[i], n3 * sizeof(double), hipMemcpyDeviceToDevice, s));
+      alpha[i] = 1.0;
+    }
+    std::vector<int> pend = act;
+    std::vector<double> E(n, 0.0);
+    while (!pend.empty()) {
+      for (int i : pend) {
+        tsl_ctx* c = G->m[i];
+        const size_t n3 = 3 * (size_t)c->NV;
+        hipLaunchKernelGGL(k_linesearch, dim3(gsz(n3)), dim3(256), 0, c->stream, n3, c->x1.p, c->pdir.p, alpha[i], pos_a[i]);
+        TSL_TRY(energy_async(c, pos_a[i], prev_a[i], vel_a[i], ref_a[i]));
+        HIP_OK(hipMemcpyAsync(&HSC(c)->energy, &SC(c)->energy, sizeof(double), hipMemcpyDeviceToHost, c->stream));
+      }
+      std::vector<int> again;
+      for (int i : pend) {
+        tsl_ctx* c = G->m[i];
+        HIP_OK(hipStreamSynchronize(c->stream));
+        E[i] = HSC(c)->energy;
+        st[i].ls_evals++;
+        if (E[i] < E0[i]) continue;
+        alpha[i] /= 2;
+        if (alpha[i] > 1e-8) again.push_back(i);
+      }
+      pend.swap(again);
+    }
+    for (int i : act) {
+      tsl_ctx* c = G->m[i];
+      delta[i] = HSC(c)->pmax / c->dt;
+      st[i].last_alpha = alpha[i]; st[i].energy = E[i]; E_last[i] = E[i];
+      if (c->verbose >= 4) fprintf(stderr, "[tsl]   scene %d newton %2d: E0 %.12e  E - E0 %+.3e  alpha %.3g  |p|max %.3e  delta %.3e  (solve: %d its, rel_residual %.1e)\n", i, iter[i], E0[i], E[i] - E0[i], alpha[i],
+                                   HSC(c)->pmax, delta[i], ss[i].iters, ss[i].rel_residual);
+      if (delta[i] < 1e-7) active[i] = 0;
+    }
+    lap(5);
+  }
+  if (timed) fprintf(stderr, "[tsl] group step of %d scenes: energy + assembly %.3f s, plans + merge %.3f s, factorisation %.3f s, application %.3f s, residuals %.3f s, line search %.3f s\n", n, tph[0], tph[1], tph[2], tph[3], tph[4], tph[5]);
+  for (int i = 0; i < n; i++) {
+    tsl_ctx* c = G->m[i];
+    const size_t n3 = 3 * (size_t)c->NV;
+    st[i].newton_iters = iter[i]; st[i].last_delta = delta[i];
+    st[i].factorizations = (int)(c->ds.n_factor - fact0[i]) + (i == 0 ? (int)(g->ds.n_factor - gfact0) : 0); st[i].plans = (int)(c->ds.n_plans - plans0[i]);
+    hipLaunchKernelGGL(k_update_vel, dim3(gsz(n3)), dim3(256), 0, c->stream, n3, pos_a[i], prev_a[i], c->damping / c->dt, vel_a[i]);
+    if (c->plastic) TSL_TRY(tsl_update_ref_angle(c, pos_a[i], ref_a[i]));
+  }
+  for (int i = 0; i < n; i++) {
+    tsl_ctx* c = G->m[i];
+    HIP_OK(hipStreamSynchronize(c->stream));
+    if (st[i].solves > 0) c->last_step_iters_per_solve = (double)st[i].cg_iters / st[i].solves;
+    if (stats) stats[i] = st[i];
+  }
+  HIP_OK(hipStreamSynchronize(g->stream));
+  HIP_OK(hipGetLastError());
   return 0;
 }
 
