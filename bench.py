@@ -223,6 +223,12 @@ def multi_scene(args, rank, S, K, W, single_value):
     return out
 
 
+def _berr_counters(ctx):
+    cc = ctx.direct_counters()
+    return {"accepted": cc["berr_accepted"], "evaluated": cc["berr_seen"], "max_backward_error": cc["berr_max"], "max_rel_residual": cc["berr_rel_max"],
+            "rule": "normwise |b - Hx| / (|H|_inf |x| + |b|) <= 1e-12 and |b - Hx| <= 50 cg_tol |b| (direct_refine; counters since context creation, warm-up included)"}
+
+
 def _ripple(x, c):
     """deterministic sub-micron ripple on the cloth rows: the native poses put cloth vertices EXACTLY on the contact threshold, where
     the activation test is decided by round-off (tests/test_gpu_scenes.py::_pair does the same on both sides)"""
@@ -321,22 +327,34 @@ def cpu_baseline(args, scene, gpu_stats, K, rank):
         t_contact = 0.0
         if args.workload != "drape":
             t0 = time.time(); o.calc_vn(); o.projection_query(); o.contact_analysis(); t_contact = time.time() - t0
-        o.stats(reset=True); po.direct_seconds[:] = [0.0, 0]
-        t0 = time.time()
-        o.newton_step_init(); o.compute_energy(); o.compute_residual_and_Hessian(True); o.newton_step()
-        t_newton = time.time() - t0
-        st = o.stats()
+        # the iteration twice from the same state: SuperLU with scipy's default column ordering (COLAMD) and with MMD on A^T + A (the operator is
+        # structurally symmetric: the ordering the reference's cupyx spsolve would pick for it is not documented; the faster of the two is the baseline)
+        x_keep = o.pos.copy()
+        by_order = {}
+        for order in ("COLAMD", "MMD_AT_PLUS_A"):
+            po.direct_permc[0] = order
+            o.pos[:] = x_keep; o.push_down_all()
+            o.stats(reset=True); po.direct_seconds[:] = [0.0, 0]
+            t0 = time.time()
+            o.newton_step_init(); o.compute_energy(); o.compute_residual_and_Hessian(True); o.newton_step()
+            by_order[order] = {"per_newton_iteration_s": time.time() - t0, "sparse_lu_s": po.direct_seconds[0], "stats": o.stats(),
+                               "sparse_lu_rel_residual": (po.direct_residuals[-1] if po.direct_residuals else None)}
+        order = min(by_order, key=lambda k: by_order[k]["per_newton_iteration_s"])
+        po.direct_permc[0] = "COLAMD"
+        t_newton = by_order[order]["per_newton_iteration_s"]; st = by_order[order]["stats"]
+        po.direct_seconds[0] = by_order[order]["sparse_lu_s"]
         n_it = gpu_stats["newton"] + K     # every adjoint step = one assembly + one solve
         t_total = 2 * K * t_contact + n_it * t_newton
         T = scene.cloths[0].NF
         out["bench_size"] = {
             "value": T * K / t_total, "cores": best, "per_newton_iteration_s": t_newton, "contact_detection_s": t_contact,
-            "sparse_lu_s": po.direct_seconds[0], "sparse_lu_rel_residual": (po.direct_residuals[-1] if po.direct_residuals else None),
+            "sparse_lu_s": po.direct_seconds[0], "sparse_lu_rel_residual": by_order[order]["sparse_lu_rel_residual"],
+            "sparse_lu_ordering": order, "by_ordering": {k: {"per_newton_iteration_s": v["per_newton_iteration_s"], "sparse_lu_s": v["sparse_lu_s"]} for k, v in by_order.items()},
             "solve_flag": st["flag"], "line_search_evals": st["ls"],
             "assembly_s_by_threads": {str(k): v for k, v in sweep.items()},
             "what": f"measured per iteration, scaled: ONE complete Newton iteration of the oracle on the bench scene and state (energy + assembly on {best} OpenMP threads of "
-                    f"{ncpu} host cpus, best of the thread sweep: {sweep[best]:.3f} s; the linear solve by scipy's SuperLU like the reference's spsolve, single-threaded: "
-                    f"{po.direct_seconds[0]:.1f} s; {st['ls']} line-search evaluations) = {t_newton:.1f} s, times the {n_it} Newton iterations + adjoint solves of the GPU run's "
+                    f"{ncpu} host cpus, best of the thread sweep: {sweep[best]:.3f} s; the linear solve by scipy's SuperLU like the reference's spsolve, single-threaded, column ordering {order} "
+                    f"(the faster of COLAMD / MMD_AT_PLUS_A): {po.direct_seconds[0]:.1f} s; {st['ls']} line-search evaluations) = {t_newton:.1f} s, times the {n_it} Newton iterations + adjoint solves of the GPU run's "
                     f"{K} steps, plus 2 x {K} contact detections of {t_contact:.3f} s"}
         out["value"] = out["bench_size"]["value"]; out["cores"] = best
         out["sample"] = out["bench_size"]["what"] + (" || " + out["complete_steps_small_scene"]["sample"] if "complete_steps_small_scene" in out else "")
@@ -352,7 +370,7 @@ def roofline(ctx, scene, elapsed, K, stats, args):
     """dominant kernel class of the sparse direct solve, measured live with HIP events (tsl_bench_direct), + section 8d's whole-step model"""
     names = {0: "k_ds_gj_step (+ k_ds_pivot0 / k_ds_gj_finish: blocked Gauss-Jordan inversion W = F11^-1 of every front of a batch, one launch per 32 pivots, f64 MFMA tiles)",
              3: "k_ds_inv_small (the same inversion of the leaf levels and small fronts: all block steps inside one launch, the pivot block in LDS)",
-             5: "k_ds_gj_flow (the same inversion of the batches of the upper tree levels as ONE persistent launch per batch: a workgroup keeps its 32 x 32 tile in registers over all block steps, steps ordered by point-to-point flags; bytes = the pivot blocks read and written once)",
+             5: "k_ds_gj_flow (the same inversion of the batches of the upper tree levels as ONE persistent launch per batch: a workgroup keeps a super-tile of 2 x 2 tiles in registers over all block steps, steps ordered by point-to-point flags; bytes = the pivot blocks read and written once)",
              1: "k_ds_gemm[schur] (Schur complement S = sum_children ext(S_child) - F21 G of every front of a batch: K = pp GEMM on v_mfma_f64_16x16x4_f64, the children's stored S gathered in the epilogue, S stored once -- no atomics, no cleared F22)",
              6: "k_ds_extend_panels (the panels F11 / F12 / F21 of every front of a level take their share of the children's Schur complements: the other half of the gather-form extend-add)",
              2: "k_ds_gemm[g] (G = W F12 of every front of a batch: K = pp GEMM on v_mfma_f64_16x16x4_f64)",
@@ -388,6 +406,30 @@ def roofline(ctx, scene, elapsed, K, stats, args):
             rf["traffic"] = j["traffic_bytes_per_launch"]
             rf["traffic_source"] = (f"committed rocprofv3 --pmc passes (FETCH_SIZE x2 + WRITE_SIZE, separate passes) of profile set {j.get('tag', '?')} taken on commit "
                                     f"{j.get('commit', '?')}: a constant read from profiles/, not a measurement of this run")
+    except (OSError, KeyError, ValueError):
+        pass
+    # the same class IN SITU: average duration of its launches in the committed rocprofv3 kernel trace of the driver's command (sibling batches on parallel
+    # streams, the real cache state) -- a constant read from profiles/, labelled with its set and commit, next to this run's own replays
+    rf["avg_launch_us_replay"] = v["us_per_launch"]
+    rf["avg_launch_us_rocprof"] = None
+    try:
+        pat = {0: ("k_ds_gj_step", "k_ds_pivot0", "k_ds_gj_finish"), 1: ("k_ds_gemm<1", "k_ds_gemm_x<1"), 2: ("k_ds_gemm<0", "k_ds_gemm_x<0", "k_ds_gemm_g32"), 3: ("k_ds_inv_small",),
+               4: ("k_ds_gemv",), 5: ("k_ds_gj_flow",), 6: ("k_ds_extend_panels",)}[dom]
+        path = os.path.join(ROOT, "profiles", f"latest_{args.workload.replace('-', '_')}_kernel_stats.json")
+        if os.path.exists(path) and args.grid == 224:
+            with open(path) as fh:
+                ks = json.load(fh)
+            sel = [x for nm, x in ks["kernels"].items() if any(q in nm for q in pat)]
+            calls = sum(x["calls"] for x in sel); tot_ns = sum(x["total_ns"] for x in sel)
+            if calls:
+                us = tot_ns / calls * 1e-3
+                rf["avg_launch_us_rocprof"] = us
+                if dom in (1, 2):
+                    rf["frac_in_situ"] = v["flops_per_launch"] / (us * 1e-6) / 1e12 / F64_MFMA_PEAK_TF
+                else:
+                    rf["frac_in_situ"] = v["bytes_per_launch"] / (us * 1e-6) / 1e9 / HBM_PEAK_GBS
+                rf["rocprof_source"] = (f"kernel trace of profile set {ks.get('tag', '?')} (commit {ks.get('commit', '?')}; {ks.get('command', '')}): {calls} launches of {' + '.join(pat)}; "
+                                        "a constant read from profiles/, not a measurement of this run")
     except (OSError, KeyError, ValueError):
         pass
     # the GEMM classes against BOTH roofs (the Schur launches gather the children's Schur complements and store their own in the epilogue)
@@ -520,7 +562,7 @@ def main():
                                 if args.workload == "cfg4-scaled" else
                                 f"drape: {args.grid}x{args.grid} square cloth ({T} triangles, dx={args.cloth_size / args.grid:.3e} m), one pinned row, no contact; ") +
                                "per step: implicit-Euler Newton time step (contact detection, friction; per Newton iteration one multifrontal LU of the "
-                               "operator + iterative refinement to cg_tol) + adjoint transfer_grad; one independent scene per GPU",
+                               "operator, its first application accepted when backward stable, else refined to cg_tol) + adjoint transfer_grad; one independent scene per GPU",
                    "triangles": T, "tot_NV": scene.tot_NV, "cg_tol": args.cg_tol, "active_contacts_per_step": stats["nc"] / K,
                    "newton_iters_per_step": stats["newton"] / K, "line_search_evals_per_step": stats["ls"] / K,
                    "newton_last_delta_per_step": [float(f"{d:.3g}") for d in stats["last_delta"]],
@@ -530,6 +572,7 @@ def main():
                    "solves_unconverged": stats["fwd_unconverged"] + stats["adj_unconverged"],
                    "solver_fallbacks": {"forward": stats["fwd_fallback"], "adjoint": stats["adj_fallback"]},
                    "solves_accepted_at_attainable_accuracy": {"forward": stats["fwd_attained"], "adjoint": stats["adj_attained"]},
+                   "first_passes_accepted_on_backward_error": _berr_counters(ctx),
                    "max_rel_residual_fwd": stats["max_res_fwd"], "max_rel_residual_adjoint": stats["max_res_adj"], "max_backward_error_adjoint": stats["max_be_adj"],
                    "adjoint_solve_methods": {str(k): v for k, v in stats["methods"].items()}},
     }

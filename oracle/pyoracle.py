@@ -59,6 +59,7 @@ def lib():
 # SuperLU on the oracle's own assembled block-CSR matrix
 _DIRECT_CB = C.CFUNCTYPE(C.c_int, C.c_int, C.POINTER(C.c_int), C.POINTER(C.c_int), C.POINTER(C.c_double), C.POINTER(C.c_double), C.POINTER(C.c_double))
 direct_seconds = [0.0, 0]   # [time spent in SuperLU, calls] (bench.py's cpu_baseline reports it)
+direct_permc = ["COLAMD"]    # column ordering handed to SuperLU: scipy's default, or "MMD_AT_PLUS_A" (the operator is structurally symmetric: bench.py times both)
 direct_residuals = []        # relative residuals |b - Hx| / |b| of the last SuperLU solves
 
 
@@ -74,7 +75,7 @@ def _direct_solve(nb, row_ptr, col, vals, b, x):
         vv = np.ctypeslib.as_array(vals, shape=(nnzb * 9,)).reshape(nnzb, 3, 3)
         A = sp.bsr_matrix((vv, cc, rp), shape=(3 * nb, 3 * nb)).tocsc()
         bb = np.ctypeslib.as_array(b, shape=(3 * nb,))
-        xx = spl.splu(A).solve(bb)
+        xx = spl.splu(A, permc_spec=direct_permc[0]).solve(bb)
         if not np.isfinite(xx).all():
             return 1
         np.ctypeslib.as_array(x, shape=(3 * nb,))[:] = xx

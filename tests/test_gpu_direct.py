@@ -163,22 +163,6 @@ def test_direct_small_tile_g_kernel_agrees():
     assert rel_err(sols[1], sols[0]) < 1e-10
 
 
-@pytest.mark.parametrize("wpc", [2, 4])
-def test_direct_gemm_occupancy_variants_agree(wpc):
-    """k_ds_gemm is compiled for four workgroups per CU (one LDS slab buffer) and for two (two buffers, one barrier per slab;
-    "direct_gemm_wpc"); both factorise a grid with several levels of Schur complements to the same answer as scipy's LU"""
-    import scipy.sparse.linalg as spl
-    s = _drape(70, 45, 5e-5, seed=2)
-    ctx = s._ensure_ctx()
-    ctx.set_param("direct", 1); ctx.set_param("direct_leaf", 16); ctx.set_param("direct_gemm_wpc", wpc)
-    s.compute_residual_and_Hessian(spd=True)
-    b = s.F.to_torch().clone()
-    x, st = ctx.solve(b)
-    xs = spl.splu(ctx.operator_csr().tocsc()).solve(b.cpu().numpy())
-    assert st["flag"] == 0 and st["method"] == 4 and st["iters"] <= 3, st
-    assert rel_err(x.cpu().numpy(), xs) < 1e-9
-
-
 def test_direct_solve_indefinite_operator():
     """un-projected Hessian of a strongly perturbed cloth (adjoint systems): indefinite, no pivoting inside the factorisation"""
     import scipy.sparse.linalg as spl
@@ -275,6 +259,20 @@ def test_constraint_overflow_is_an_error():
         for f in range(1, 4):
             s.action(f, dpos, drot)
             s.time_step(projection_query, f)
+
+
+def test_oversized_broad_phase_bucket_is_an_error():
+    """the broad phase ranks the triangles of a hash bucket against each other (quadratic in the bucket): a body outside grid_extent -- every
+    centroid clamped into the boundary cells -- must be reported, not ranked for seconds"""
+    from thinshelllab_amd._lib import TslError
+    from thinshelllab_amd.engine.geometry import projection_query
+    from thinshelllab_amd.task_scene.Scene_balancing import Scene
+    s = Scene(cloth_size=0.06, cloth_N=96, cloth_M=96)     # 18,432 cloth triangles
+    s.init_all()
+    s.prev_pos.copy_from(s.pos)
+    s._ensure_ctx().set_param("grid_extent", 0.004)        # two cells per axis: the whole cloth falls into four of them
+    with pytest.raises(TslError, match="broad-phase cell"):
+        s.time_step(projection_query, 1)
 
 
 def test_elastic_parameters_reach_the_engine_after_context_creation():

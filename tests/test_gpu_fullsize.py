@@ -219,15 +219,6 @@ def test_cfg4_balancing_224_contact_solve():
     x, stx = ctx.solve(b)
     r, H = _residual(ctx, b, x)
     assert r < 1e-7, (stx, r)
-    # the fused launches are algebraic rewrites of the same preconditioner (restriction through S = P^T A Dinv, dense-body first
-    # sweep inside the PCG update kernel, contact blocks on the second stream; the single-precision stencil copies change the
-    # preconditioner at the 1e-7 level only): same solution, same iteration count up to round-off
-    ctx.set_param("mg_fuse_restrict", 0); ctx.set_param("pcg_body_fold", 0); ctx.set_param("mg_st_f32", 0); ctx.set_param("asm_overlap", 0)
-    s.compute_residual_and_Hessian(spd=True)
-    x0, st0 = ctx.solve(b)
-    ctx.set_param("mg_fuse_restrict", 1); ctx.set_param("pcg_body_fold", 1); ctx.set_param("mg_st_f32", 1); ctx.set_param("asm_overlap", 1)
-    assert abs(st0["iters"] - stx["iters"]) <= max(4, stx["iters"] // 20), (st0, stx)
-    assert float((x0 - x).norm() / x.norm()) < 1e-7
     # the step direction is a descent direction of the incremental potential: E(x - a p) < E(x) for a small a
     Ecur = s.compute_energy()
     pos0 = s.pos.to_torch().clone()

@@ -17,7 +17,71 @@
 // member's factors, solutions and tape are BIT-IDENTICAL to its single-scene run.  A member's own plan addresses the same memory: a solve that
 // needs more than the merged first pass (refinement, GMRES, the adjoint step) runs on the member's own path without copying anything.
 #pragma once
+#include <condition_variable>
+#include <functional>
+#include <thread>
 #include "direct_host.hpp"
+
+// Host threads of a group: member i's ~35 assembly launches of a Newton iteration are issued by thread i (the caller's thread takes member 0).
+// One thread issuing them member after member paces the GPU -- a launch costs the host 8-10 us, the kernels are shorter: measured 0.87 ms from
+// the first to the last assembly kernel of two cfg4 scenes, of which scene 2 waited 0.29 ms for its first launch.
+struct GroupPool {
+  std::vector<std::thread> th;
+  std::mutex mu;
+  std::condition_variable cv, cv_done;
+  std::function<int(int)> job;
+  std::vector<int> rc;
+  std::vector<std::string> err;
+  int gen = 0, pending = 0, dev = 0;
+  bool stop = false;
+  void start(int n, int device) {
+    dev = device; rc.assign(n, 0); err.assign(n, "");
+    for (int i = 1; i < n; i++) th.emplace_back([this, i] {
+      (void)hipSetDevice(dev);
+      int seen = 0;
+      for (;;) {
+        std::unique_lock<std::mutex> lk(mu);
+        cv.wait(lk, [&] { return stop || gen != seen; });
+        if (stop) return;
+        seen = gen;
+        lk.unlock();
+        const int r = job(i);
+        lk.lock();
+        rc[i] = r; if (r) err[i] = g_tsl_err;
+        if (--pending == 0) cv_done.notify_one();
+      }
+    });
+  }
+  // fn(i) for i in idx, in parallel; the first failure is reported through tsl_fail on the caller's thread
+  int run(const std::vector<int>& idx, const std::function<int(int)>& fn) {
+    if (idx.empty()) return 0;
+    std::vector<int> mine, theirs;
+    for (int i : idx) (i == 0 || th.empty() ? mine : theirs).push_back(i);
+    if (!theirs.empty()) {
+      std::unique_lock<std::mutex> lk(mu);
+      std::vector<char> sel(rc.size(), 0);
+      for (int i : theirs) sel[i] = 1;
+      job = [fn, sel](int i) { return sel[i] ? fn(i) : 0; };
+      for (size_t i = 0; i < rc.size(); i++) rc[i] = 0;
+      pending = (int)th.size(); gen++;
+      lk.unlock();
+      cv.notify_all();
+    }
+    int r0 = 0;
+    for (int i : mine) { r0 = fn(i); if (r0) break; }
+    if (!theirs.empty()) {
+      std::unique_lock<std::mutex> lk(mu);
+      cv_done.wait(lk, [&] { return pending == 0; });
+      for (size_t i = 1; i < rc.size(); i++) if (rc[i]) return tsl_fail("%s", err[i].c_str());
+    }
+    return r0;
+  }
+  ~GroupPool() {
+    { std::lock_guard<std::mutex> lk(mu); stop = true; }
+    cv.notify_all();
+    for (auto& t : th) t.join();
+  }
+};
 
 struct tsl_group {
   std::vector<tsl_ctx*> m;       // members (not owned)
@@ -32,6 +96,7 @@ struct tsl_group {
   hipEvent_t ev_g = nullptr;     // group stream -> member streams
   long n_merge = 0, n_relayout = 0;
   double t_merge = 0;
+  std::unique_ptr<GroupPool> pool;
 };
 
 static inline size_t grp_align(size_t n) { return (n + 31) & ~(size_t)31; }   // 256-byte granules
@@ -284,7 +349,7 @@ static int group_create(tsl_ctx* const* ctxs, int n, tsl_group** out) {
   // (the LDS kernel takes a batch that fits the chip in `small_rounds` rounds: n scenes bring n times the leaf fronts, and the alternative -- one launch per
   // block step over all of them -- costs the same per front: measured 1.1 ms of k_ds_gj_step for the 1690 leaf fronts of two cfg4 scenes against 0.14 ms per scene in the LDS kernel)
   gd.merged = true; gd.enable = 1; gd.device = dev; gd.flow = d0.flow; gd.small_rounds = d0.small_rounds * n; gd.xcd_map = d0.xcd_map; gd.gemv_wide_below = d0.gemv_wide_below;
-  gd.g32_below = d0.g32_below; gd.s32_below = d0.s32_below; gd.gemm_wpc = d0.gemm_wpc; gd.par_batches = d0.par_batches; gd.piv_tol = d0.piv_tol; gd.prezero = d0.prezero;
+  gd.g32_below = d0.g32_below; gd.piv_tol = d0.piv_tol; gd.prezero = d0.prezero;
   gd.static_ready = true;
   if (gd.bad.alloc(8 + 4 * DS_BADLOG)) return -1;
   HIP_OK(hipFuncSetAttribute((const void*)k_ds_inv_small, hipFuncAttributeMaxDynamicSharedMemorySize, (int)ds_small_lds(DS_SMALL)));
@@ -292,6 +357,8 @@ static int group_create(tsl_ctx* const* ctxs, int n, tsl_group** out) {
   G->ev_m.resize(n);
   for (int i = 0; i < n; i++) HIP_OK(hipEventCreateWithFlags(&G->ev_m[i], hipEventDisableTiming));
   for (int i = 0; i < n; i++) { ctxs[i]->group = G.get(); ctxs[i]->ds.token_lender = &gd; ds_flow_token_release(ctxs[i]->ds); }
+  G->pool.reset(new GroupPool());
+  if (n > 1 && !getenv("TSL_GROUP_NO_THREADS")) G->pool->start(n, dev);
   *out = G.release();
   return 0;
 }
@@ -299,6 +366,7 @@ static int group_create(tsl_ctx* const* ctxs, int n, tsl_group** out) {
 // gives the members buffers of their own again (contents preserved) and frees the group
 static void group_destroy(tsl_group* G) {
   if (!G) return;
+  G->pool.reset();
   (void)hipDeviceSynchronize();
   for (tsl_ctx* c : G->m) {
     auto give = [&](DevBuf<double>& b) {

@@ -57,31 +57,26 @@ static inline bool ds_use_small(const DirectSolver& d, const DsBatch& b) {
 }
 
 // G = W F12 (mode 0) / S = sum_children ext(S_child) - F21 G, stored (mode 1) of a batch: 64 x 64 output tiles; "direct_g32_below": G of a
-// batch with few 64 x 64 tiles (upper levels) in 32 x 32 tiles, four times the workgroups
+// batch with few 64 x 64 tiles (upper levels) in 32 x 32 tiles, four times the workgroups (the same for the Schur complements was measured
+// slower on the leaf levels and no faster above: gone)
 // "direct_xcd" (DirectSolver::xcd_map): batches of at least this many fronts launch their GEMM tiles with the XCD-aware map (k_ds_gemm_x: a front per XCD); 0: never
-static void ds_launch_gemm(hipStream_t s, const DsDev& D, const DsBatch& b, int mode, int wpc, int ds_xcd_map, int ds_g32_below = 0) {
+static void ds_launch_gemm(hipStream_t s, const DsDev& D, const DsBatch& b, int mode, int ds_xcd_map, int ds_g32_below = 0) {
   const int rows = mode == 0 ? b.max_pp : b.max_bp, cols = b.max_bp;
   const dim3 grid((cols + 63) / 64, (rows + 63) / 64, b.count);
   const long tiles = (long)grid.x * grid.y * grid.z;
-  if (ds_g32_below > 0 && tiles < ds_g32_below) {
-    if (mode == 0) hipLaunchKernelGGL(k_ds_gemm_g32, dim3((cols + 31) / 32, (rows + 31) / 32, b.count), dim3(256), 0, s, D, b.first);
-    else hipLaunchKernelGGL(k_ds_gemm_s32, dim3((cols + 31) / 32, (rows + 31) / 32, b.count), dim3(256), 0, s, D, b.first);
+  if (mode == 0 && ds_g32_below > 0 && tiles < ds_g32_below) {
+    hipLaunchKernelGGL(k_ds_gemm_g32, dim3((cols + 31) / 32, (rows + 31) / 32, b.count), dim3(256), 0, s, D, b.first);
     return;
   }
-  if (ds_xcd_map > 0 && wpc >= 4 && b.count >= ds_xcd_map) {
+  if (ds_xcd_map > 0 && b.count >= ds_xcd_map) {
     const int gx = grid.x, gy = grid.y, nf = b.count;
     const long ng = ((long)nf + 7) / 8 * 8 * gx * gy;
     if (mode == 0) hipLaunchKernelGGL((k_ds_gemm_x<0, 4>), dim3((unsigned)ng), dim3(256), 0, s, D, b.first, gx, gy, nf);
     else hipLaunchKernelGGL((k_ds_gemm_x<1, 4>), dim3((unsigned)ng), dim3(256), 0, s, D, b.first, gx, gy, nf);
     return;
   }
-  if (mode == 0) {
-    if (wpc >= 4) hipLaunchKernelGGL((k_ds_gemm<0, 4>), grid, dim3(256), 0, s, D, b.first);
-    else hipLaunchKernelGGL((k_ds_gemm<0, 2>), grid, dim3(256), 0, s, D, b.first);
-  } else {
-    if (wpc >= 4) hipLaunchKernelGGL((k_ds_gemm<1, 4>), grid, dim3(256), 0, s, D, b.first);
-    else hipLaunchKernelGGL((k_ds_gemm<1, 2>), grid, dim3(256), 0, s, D, b.first);
-  }
+  if (mode == 0) hipLaunchKernelGGL((k_ds_gemm<0, 4>), grid, dim3(256), 0, s, D, b.first);
+  else hipLaunchKernelGGL((k_ds_gemm<1, 4>), grid, dim3(256), 0, s, D, b.first);
 }
 // the panels of the fronts level_sn[lv0 .. lv0 + nf) (one level, or one batch of it) are written from their children's Schur complements
 static void ds_launch_extend(hipStream_t s, const DsDev& D, int lv0, int nf, int max_ld) {
@@ -416,7 +411,7 @@ static int direct_plan(tsl_ctx* c) {
 // next to the line search, the energy evaluations and the next assembly.  The factors are marked invalid here.
 static int direct_prezero(tsl_ctx* c) {
   DirectSolver& d = c->ds;
-  if (!d.prezero || d.lag > 0 || !d.plan_valid || d.arena.n == 0 || d.prezero_pending) return 0;   // ("direct_lag" keeps factors across iterations)
+  if (!d.prezero || !d.plan_valid || d.arena.n == 0 || d.prezero_pending) return 0;
   if (d.zstream == nullptr) {
     HIP_OK(hipStreamCreateWithFlags(&d.zstream, hipStreamNonBlocking));   // (a lowest-priority stream made the step 3 % slower: the next factorisation waits for the clear)
     HIP_OK(hipEventCreateWithFlags(&d.ev_zfork, hipEventDisableTiming));
@@ -481,8 +476,8 @@ static int direct_factor(tsl_ctx* c, int stop_sn = -1, const char* dump_path = n
       hipLaunchKernelGGL(k_ds_gj_finish, dim3(tp, nf), dim3(256), 0, bs, D, lv0);
     }
     if (tb > 0) {
-      ds_launch_gemm(bs, D, b, 0, d.gemm_wpc, d.xcd_map, d.g32_below);
-      ds_launch_gemm(bs, D, b, 1, d.gemm_wpc, d.xcd_map, d.s32_below);
+      ds_launch_gemm(bs, D, b, 0, d.xcd_map, d.g32_below);
+      ds_launch_gemm(bs, D, b, 1, d.xcd_map);
     }
   };
   // The fronts of a level are independent: where a level was split into batches (by pivot-block size) the batches run on parallel
@@ -509,7 +504,7 @@ static int direct_factor(tsl_ctx* c, int stop_sn = -1, const char* dump_path = n
       d.numeric_valid = false; d.have_factor = false;
       return 0;
     }
-    const int nside = d.par_batches ? (int)std::min<size_t>(be - bi - 1, DS_NSIDE) : 0;
+    const int nside = (int)std::min<size_t>(be - bi - 1, DS_NSIDE);
     if (nside > 0) {
       if (d.fstream[0] == nullptr)
         for (int k = 0; k < DS_NSIDE; k++) { HIP_OK(hipStreamCreateWithFlags(&d.fstream[k], hipStreamNonBlocking)); HIP_OK(hipEventCreateWithFlags(&d.ev_fjoin[k], hipEventDisableTiming)); }
@@ -673,7 +668,7 @@ static int direct_bench(tsl_ctx* c, int cls, int reps, double* out) {
           bytes += 16.0 * (double)f.pp * f.pp * (cls != 0 ? 1.0 : f.pp / (double)DS_T);   // the block read and written once per launch that touches it
         }
       } else if (tb > 0) {
-        if (cls == 1 || cls == 2) ds_launch_gemm(s, D, b, cls == 2 ? 0 : 1, d.gemm_wpc, d.xcd_map, cls == 2 ? d.g32_below : d.s32_below);
+        if (cls == 1 || cls == 2) ds_launch_gemm(s, D, b, cls == 2 ? 0 : 1, d.xcd_map, cls == 2 ? d.g32_below : 0);
         else continue;
         if (count) {
           launches++;

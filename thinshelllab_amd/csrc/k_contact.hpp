@@ -143,13 +143,24 @@ __global__ void k_bucket_scatter(int nf, const int* __restrict__ key, int hshift
   tmp[ptr[b] + atomicAdd(&cur[b], 1)] = t;
 }
 // ... then every member finds its rank by (cell, triangle) among the members of its bucket (a handful): the result does not depend on the
-// arrival order
+// arrival order.  The ranking is quadratic in the bucket size: a bucket of more than TSL_BUCKET_CAP triangles -- a body that lies outside
+// grid_extent (every centroid is clamped into the boundary cells, grid_idx3) or a cell size far above the triangle size -- is reported
+// through `err` instead of being ranked (tsl_contact_detect fails loudly; its first member copies the bucket in arrival order so that the
+// kernels already queued behind read valid indices).
+#define TSL_BUCKET_CAP 4096
 __global__ void k_bucket_rank(int nf, int f_start, const int* __restrict__ key, int hshift, const int* __restrict__ ptr, const int* __restrict__ tmp,
-                              int* __restrict__ skey, int* __restrict__ sval) {
+                              int* __restrict__ skey, int* __restrict__ sval, int* __restrict__ err) {
   const int t = blockIdx.x * blockDim.x + threadIdx.x;
   if (t >= nf) return;
   const int k = key[t], b = grid_bucket(k, hshift);
   const int s0 = ptr[b], s1 = ptr[b + 1];
+  if (s1 - s0 > TSL_BUCKET_CAP) {
+    if (tmp[s0] == t) {
+      atomicMax(err, s1 - s0);
+      for (int e = s0; e < s1; e++) { skey[e] = key[tmp[e]]; sval[e] = f_start + tmp[e]; }
+    }
+    return;
+  }
   int rank = 0;
   for (int e = s0; e < s1; e++) { const int u = tmp[e]; const int ku = key[u]; rank += (ku < k || (ku == k && u < t)) ? 1 : 0; }
   skey[s0 + rank] = k;
@@ -351,116 +362,11 @@ __global__ void k_contact_energy(int nc, ContactArgs A, const double* __restrict
 }
 
 // ------------------------------------------------------------------------------------------------ gradient + blocks
-// One lane per constraint.  Normal part: d = D/C with D = p.(p1 x p2), C = |p1 x p2| in the relative coordinates
-// q = (p1,p2,p); quotient rule as BaseScene.py:502-521; derivatives of D and C written in vector form
-// (contact_diff.py carries the same quantities as expanded SymPy output).  Friction part BaseScene.py:548-593.
-// Output: gradient (12) into grad (atomics), dense 12x12 into Hfull[c] (vertex order idx0..idx3).
-__global__ void __launch_bounds__(64)
-k_contact_assemble(int nc, ContactArgs A, const double* __restrict__ pos, int spd, double* __restrict__ grad, double* __restrict__ Hfull, double* __restrict__ cg) {
-  const int ci = blockIdx.x * blockDim.x + threadIdx.x;
-  if (ci >= nc) return;
-  int id[4];
-  for (int k = 0; k < 4; k++) id[k] = A.idx[4 * ci + k];
-  const d3 x0 = ld3(pos, id[0]), xa = ld3(pos, id[1]), xb = ld3(pos, id[2]), xp = ld3(pos, id[3]);
-  double Hc[144];
-  for (int k = 0; k < 144; k++) Hc[k] = 0;
-  double gv[12];
-  for (int k = 0; k < 12; k++) gv[k] = 0;
-  {
-    const d3 a = xa - x0, b = xb - x0, p = xp - x0;
-    const d3 cr = cross(a, b);
-    const double D = dot(cr, p), C = norm(cr);
-    if (D / C < A.eps_contact) {
-      const d3 nh = cr / C;
-      double gD[9], gC[9], HC[81], HD[81];
-      const d3 gDa = cross(b, p), gDb = cross(p, a), gDc = cr;
-      const d3 gCa = cross(b, nh), gCb = cross(nh, a);
-      gD[0] = gDa.x; gD[1] = gDa.y; gD[2] = gDa.z; gD[3] = gDb.x; gD[4] = gDb.y; gD[5] = gDb.z; gD[6] = gDc.x; gD[7] = gDc.y; gD[8] = gDc.z;
-      gC[0] = gCa.x; gC[1] = gCa.y; gC[2] = gCa.z; gC[3] = gCb.x; gC[4] = gCb.y; gC[5] = gCb.z; gC[6] = gC[7] = gC[8] = 0;
-      for (int k = 0; k < 81; k++) { HC[k] = 0; HD[k] = 0; }
-      const d3 ex[3] = {d3(1, 0, 0), d3(0, 1, 0), d3(0, 0, 1)};
-      for (int j = 0; j < 3; j++)
-        for (int k = 0; k < 3; k++) {
-          const d3 ejb = cross(ex[j], b), ekb = cross(ex[k], b), aej = cross(a, ex[j]), aek = cross(a, ex[k]);
-          const d3 ejk = cross(ex[j], ex[k]);
-          HC[(0 + j) * 9 + 0 + k] = (dot(ejb, ekb) - dot(nh, ejb) * dot(nh, ekb)) / C;
-          HC[(3 + j) * 9 + 3 + k] = (dot(aej, aek) - dot(nh, aej) * dot(nh, aek)) / C;
-          const double hab = (dot(ejb, aek) - dot(nh, ejb) * dot(nh, aek)) / C + dot(nh, ejk);
-          HC[(0 + j) * 9 + 3 + k] = hab;
-          HC[(3 + k) * 9 + 0 + j] = hab;
-          // D = a . (b x p): d2D/da_j db_k = e_j.(e_k x p) ... = (e_j x e_k).p etc.
-          const double dab = dot(ejk, p), dbc = dot(ejk, a), dca = dot(ejk, b);
-          HD[(0 + j) * 9 + 3 + k] = dab; HD[(3 + k) * 9 + 0 + j] = dab;
-          HD[(3 + j) * 9 + 6 + k] = dbc; HD[(6 + k) * 9 + 3 + j] = dbc;
-          HD[(6 + j) * 9 + 0 + k] = dca; HD[(0 + k) * 9 + 6 + j] = dca;
-        }
-      const double d = D / C;
-      double G9[9], H9[81];
-      for (int j = 0; j < 9; j++) G9[j] = gD[j] / C - D * gC[j] / (C * C);
-      for (int j = 0; j < 9; j++)
-        for (int k = 0; k < 9; k++)
-          H9[j * 9 + k] = HD[j * 9 + k] / C - gD[j] * gC[k] / (C * C) - gD[k] * gC[j] / (C * C) - D * HC[j * 9 + k] / (C * C) + 2 * D * gC[j] * gC[k] / (C * C * C);
-      const double pe_pd = A.k_contact * (d - A.eps_contact);
-      for (int j = 0; j < 9; j++)
-        for (int k = 0; k < 9; k++) H9[j * 9 + k] = A.k_contact * G9[j] * G9[k] + pe_pd * H9[j * 9 + k];
-      for (int j = 0; j < 9; j++) G9[j] *= pe_pd;
-      if (spd) spd_clamp<9>(H9);
-      // relative coordinate (k, j) <-> vertex k+1, axis j ; vertex 0 gets minus the sums
-      for (int k = 0; k < 3; k++)
-        for (int j = 0; j < 3; j++) {
-          const double g = G9[k * 3 + j];
-          gv[(k + 1) * 3 + j] += g;
-          gv[j] -= g;
-          for (int k2 = 0; k2 < 3; k2++)
-            for (int j2 = 0; j2 < 3; j2++) {
-              const double hh = H9[(k * 3 + j) * 9 + k2 * 3 + j2];
-              Hc[((k + 1) * 3 + j) * 12 + (k2 + 1) * 3 + j2] += hh;
-              Hc[((k + 1) * 3 + j) * 12 + j2] -= hh;
-              Hc[j * 12 + (k2 + 1) * 3 + j2] -= hh;
-              Hc[j * 12 + j2] += hh;
-            }
-        }
-    }
-  }
-  {
-    const double w[3] = {A.w[3 * ci], A.w[3 * ci + 1], A.w[3 * ci + 2]};
-    const double kf = A.k[ci];
-    const double* T = A.T + 6 * (size_t)ci;
-    const d3 x_c = x0 * w[0] + xa * w[1] + xb * w[2];
-    const d3 dx = xp - x_c - ld3(A.dx0, ci);
-    const double u[2] = {T[0] * dx.x + T[1] * dx.y + T[2] * dx.z, T[3] * dx.x + T[4] * dx.y + T[5] * dx.z};
-    const double r = sqrt(u[0] * u[0] + u[1] * u[1]);
-    const double f1 = fr_f1(r, A.eps_vh), f2 = fr_f2(r, A.eps_vh);
-    double g1[3];
-    for (int j = 0; j < 3; j++) g1[j] = kf * f1 * (u[0] * T[j] + u[1] * T[3 + j]);
-    double ha = f1, hb = 0, hd = f1;
-    if (r > 1e-9) { ha += f2 * u[0] * u[0] / r; hb += f2 * u[0] * u[1] / r; hd += f2 * u[1] * u[1] / r; }
-    if (spd) spd_clamp2(ha, hb, hd);
-    double h1[9];
-    for (int a = 0; a < 3; a++)
-      for (int b = 0; b < 3; b++)
-        h1[a * 3 + b] = kf * (T[a] * (ha * T[b] + hb * T[3 + b]) + T[3 + a] * (hb * T[b] + hd * T[3 + b]));
-    const double w1[4] = {-w[0], -w[1], -w[2], 1.0};
-    for (int i1 = 0; i1 < 4; i1++)
-      for (int j1 = 0; j1 < 3; j1++) {
-        gv[i1 * 3 + j1] += w1[i1] * g1[j1];
-        for (int i2 = 0; i2 < 4; i2++)
-          for (int j2 = 0; j2 < 3; j2++) Hc[(i1 * 3 + j1) * 12 + i2 * 3 + j2] += w1[i1] * w1[i2] * h1[j1 * 3 + j2];
-      }
-  }
-  if (cg) { for (int k = 0; k < 12; k++) cg[12 * (size_t)ci + k] = gv[k]; }   // deterministic assembly: k_vertex_gather sums the rows' entries in a fixed order
-  else if (grad)
-    for (int k = 0; k < 4; k++) atomic_add3(grad, id[k], d3(gv[3 * k], gv[3 * k + 1], gv[3 * k + 2]));
-  double* out = Hfull + 144 * (size_t)ci;
-  for (int k = 0; k < 144; k++) out[k] = Hc[k];
-}
-
-// ---- the same blocks with 16 lanes per constraint -----------------------------------------------------------------------------
-// k_contact_assemble keeps a constraint's 12 x 12 block, the 9 x 9 derivative tables and the eigenvector matrix of the 9 x 9
-// eigen-clamp in per-lane arrays (private memory) and runs ~10 Jacobi sweeps serially: 0.9 ms per launch at 200 constraints, the
-// longest kernel of an assembly.  Here lane l < 9 of a 16-lane group owns ROW l of the 9 x 9 normal block (relative coordinate
-// l = 3 (vertex - 1) + axis), lanes 9..11 the three rows of vertex 0; the cyclic Jacobi eigen-clamp runs on the group's matrix in LDS,
-// one lane per row / column of a rotation.
+// Normal part: d = D / C with D = p . (p1 x p2), C = |p1 x p2| in the relative coordinates q = (p1, p2, p); quotient rule as BaseScene.py:502-521,
+// 9 x 9 eigen-clamp (linalg.py:15-148), friction block (BaseScene.py:548-593).  16 lanes per constraint: lane l < 9 of a group owns ROW l of the
+// 9 x 9 normal block (relative coordinate l = 3 (vertex - 1) + axis), lanes 9..11 the three rows of vertex 0; the cyclic Jacobi eigen-clamp runs
+// on the group's matrix in LDS, one lane per row / column of a rotation.  (One lane per constraint with the block and the eigenvector matrix in
+// private arrays ran ~10 Jacobi sweeps serially: 0.9 ms per launch at 200 constraints; gone.)
 TSL_DEV d3 c_unit(int a) { return d3(a == 0 ? 1.0 : 0.0, a == 1 ? 1.0 : 0.0, a == 2 ? 1.0 : 0.0); }
 TSL_DEV double c_comp(const d3& v, int a) { return a == 0 ? v.x : (a == 1 ? v.y : v.z); }
 // cyclic Jacobi eigen-clamp A <- sum_{lambda > 0} lambda v v^T of the symmetric 9 x 9 matrix of a 16-lane group, matrix and
@@ -918,7 +824,7 @@ static int contact_alloc(tsl_ctx* c, const tsl_scene_desc* d) {
   }
   const size_t nb = (size_t)std::max(c->n_body, 1);
   rc |= c->proj_flag.alloc(nb * NV); rc |= c->proj_dir.alloc(nb * NV); rc |= c->proj_idx.alloc(nb * NV * 3); rc |= c->proj_w.alloc(nb * NV * 3);
-  rc |= c->nc_dev.alloc(1);
+  rc |= c->nc_dev.alloc(2);   // [1]: largest oversized broad-phase bucket of the last detection (k_bucket_rank)
   const size_t mc = (size_t)c->max_n_constraints;
   rc |= c->c_idx.alloc(mc * 4); rc |= c->c_w.alloc(mc * 3); rc |= c->c_n.alloc(mc * 3); rc |= c->c_dx0.alloc(mc * 3);
   rc |= c->c_k.alloc(mc); rc |= c->c_mu.alloc(mc); rc |= c->c_T.alloc(mc * 6); rc |= c->c_kind.alloc(mc);
@@ -952,6 +858,7 @@ extern "C" int tsl_contact_detect(tsl_ctx* c, const double* pos, const double* p
   bool any_self = false;
   for (int v : c->self_contact) any_self |= v != 0;
   if ((c->n_body < 2 && !any_self) || c->NF == 0) { if (nc_host) *nc_host = 0; return 0; }   // a single body can still touch itself (geometry_self.py)
+  HIP_OK(hipMemsetAsync(c->nc_dev.p + 1, 0, sizeof(int), s));
   // calc_vn
   if (c->deterministic && c->vnf_ptr.n > 0) hipLaunchKernelGGL(k_vn_gather, dim3(cnblk(NV, 256)), dim3(256), 0, s, NV, (const int*)c->vnf_ptr.p, (const int*)c->vnf_lst.p, c->faces.p, pos, c->vn.p);
   else {
@@ -976,7 +883,7 @@ extern "C" int tsl_contact_detect(tsl_ctx* c, const double* pos, const double* p
     scan_exclusive(s, ts + 1, c->grid_cnt.p, c->grid_ptr.p, c->scan_tmp.p);
     hipLaunchKernelGGL(k_bucket_scatter, dim3(cnblk(nf, 256)), dim3(256), 0, s, nf, (const int*)c->grid_key.p, hshift, (const int*)c->grid_ptr.p, c->grid_cur.p, c->grid_val.p);
     hipLaunchKernelGGL(k_bucket_rank, dim3(cnblk(nf, 256)), dim3(256), 0, s, nf, body.f_start, (const int*)c->grid_key.p, hshift, (const int*)c->grid_ptr.p, (const int*)c->grid_val.p,
-                       c->grid_key2.p, c->grid_val2.p);
+                       c->grid_key2.p, c->grid_val2.p, c->nc_dev.p + 1);
     for (int b2 = 0; b2 < c->n_body; b2++) {
       if (b2 == b) continue;
       const tsl_body& q = c->h_bodies[b2];
@@ -1022,10 +929,16 @@ extern "C" int tsl_contact_detect(tsl_ctx* c, const double* pos, const double* p
     }
     if (phase == 0 && Q > 0) scan_exclusive(s, (int)Q + 1, c->cq_flag.p, c->cq_scan.p, c->scan_tmp.p);
   }
-  int nc = 0;
+  int nc = 0, big_bucket = 0;
   if (Q > 0) HIP_OK(hipMemcpyAsync(&nc, c->cq_scan.p + Q, sizeof(int), hipMemcpyDeviceToHost, s));
+  HIP_OK(hipMemcpyAsync(&big_bucket, c->nc_dev.p + 1, sizeof(int), hipMemcpyDeviceToHost, s));
   HIP_OK(hipStreamSynchronize(s));
   HIP_OK(hipGetLastError());
+  if (big_bucket > 0) {
+    c->nc = 0;
+    return tsl_fail("contact detection: %d triangles of one body fall into one broad-phase cell (more than %d are not ranked): the body lies outside grid_extent = %g m "
+                    "(centroids are clamped into the boundary cells) or grid_h = %g m is far larger than its triangles", big_bucket, TSL_BUCKET_CAP, c->grid_extent, c->grid_h);
+  }
   if (nc > c->max_n_constraints) {
     // more constraints than the scene's cap (the reference would drop the surplus in atomic-append order): an error
     c->nc = 0;
@@ -1057,8 +970,7 @@ static int contact_assemble(tsl_ctx* c, const double* pos, int spd, double* grad
   const bool want_cg = c->deterministic && grad;   // deterministic: per-constraint gradients, summed per vertex by k_vertex_gather
   if (want_cg && c->c_G.n < 12 * (size_t)c->max_n_constraints) { if (c->c_G.alloc(12 * (size_t)c->max_n_constraints)) return -1; }
   double* cg = want_cg ? c->c_G.p : (double*)nullptr;
-  if (c->contact_coop) hipLaunchKernelGGL(k_contact_assemble_coop, dim3(cnblk((long)c->nc * 16, 256)), dim3(256), 0, s, c->nc, A, pos, spd, grad, c->c_Hfull.p, cg);
-  else hipLaunchKernelGGL(k_contact_assemble, dim3(cnblk(c->nc, 64)), dim3(64), 0, s, c->nc, A, pos, spd, grad, c->c_Hfull.p, cg);
+  hipLaunchKernelGGL(k_contact_assemble_coop, dim3(cnblk((long)c->nc * 16, 256)), dim3(256), 0, s, c->nc, A, pos, spd, grad, c->c_Hfull.p, cg);
   if (c->deterministic) {
     hipLaunchKernelGGL(k_contact_mask, dim3(cnblk((long)c->nc * 144, 256)), dim3(256), 0, s, c->nc, c->c_idx.p, c->frozen.p, c->rowpos.p, c->c_Hfull.p, c->c_H.p, (double*)nullptr);
     hipLaunchKernelGGL(k_contact_diag, dim3(cnblk((long)c->NV * 64, 256)), dim3(256), 0, s, c->NV, (const int*)c->cr_ptr.p, (const int*)c->cr_ent.p, (const double*)c->c_H.p, c->c_diag.p);

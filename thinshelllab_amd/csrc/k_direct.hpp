@@ -33,7 +33,7 @@ struct DsDev {                 // device views shared by the kernels
   const int* vtx;              // local vertex -> PERMUTED vertex position (rows of the solver vectors)
   int* bad;                    // [1..3]: perturbed pivots of the last factorisation by front size class, [4] + [8..]: log of the first ones
   double piv_tol;              // a pivot below piv_tol x its own scale is replaced by that bound
-  int dbg;                     // timing experiments only ("ds_dbg"): 1 = the block-step kernel skips the pivot-tile inversion
+  int dbg;                     // diagnostics ("ds_dbg"): 21 forces the dataflow-abort branch of solve_perm (tests), 30 records the device-clock trace of a dataflow chain
   unsigned long long* tlog;    // "ds_dbg" 30: device-clock stamps of the dataflow launch's first front (pivot publications [0, 64), steps finished by two far workgroups [64, 192), start [192]); else null
 };
 
@@ -610,7 +610,7 @@ __global__ void __launch_bounds__(256) k_ds_gj_step(DsDev D, int lv0, int k, int
   }
   // the tile's own entries (quadrant layout of the matrix-core result) are requested before the products
   ds_d4 old = {0.0, 0.0, 0.0, 0.0};
-  if (bi != k && bj != k && D.dbg != 9) {   // ("ds_dbg" 9, timing experiment: the update tiles neither read nor write their own entries)
+  if (bi != k && bj != k) {
 #pragma unroll
     for (int r = 0; r < 4; r++) old[r] = ds_tile_elem(A, ld, Rs, Cs, pp, kp, bi, bj, 16 * wi + lk + 4 * r, 16 * wj + lr);
   }
@@ -643,12 +643,12 @@ __global__ void __launch_bounds__(256) k_ds_gj_step(DsDev D, int lv0, int k, int
   for (int r = 0; r < 4; r++) {
     const int row = 16 * wi + lk + 4 * r, col = 16 * wj + lr;
     const double v = old[r] - acc[r];
-    if (D.dbg != 9 || next_pivot) A[(size_t)(bi * DS_T + row) * ld + bj * DS_T + col] = v;
+    A[(size_t)(bi * DS_T + row) * ld + bj * DS_T + col] = v;
     if (next_pivot) T2[row][col] = v;
   }
   if (next_pivot) {
     __syncthreads();
-    if (D.dbg != 1) ds_invert_tile(&T2[0][0], DS_T + 1, D.bad, DS_CLS(f), (D.level_sn[lv0 + fz] << 6) | (k + 1), D.piv_tol);
+    ds_invert_tile(&T2[0][0], DS_T + 1, D.bad, DS_CLS(f), (D.level_sn[lv0 + fz] << 6) | (k + 1), D.piv_tol);
     double* Pn = ds_scr_P(D, f, (k + 1) & 1);
 #pragma unroll
     for (int q = 0; q < 4; q++) Pn[(ty + 8 * q) * DS_T + tx] = T2[ty + 8 * q][tx];
@@ -1074,8 +1074,8 @@ __global__ void __launch_bounds__(256) k_ds_inv_small(DsDev D, int lv0, int ls) 
 // is served in groups of 16 consecutive lanes against 32 four-byte banks: the 16 rows lr of the A operand must fall on 16 different
 // bank pairs, i.e. row stride == 1 (mod 16) doubles; the B operand's 16 lanes are contiguous.  (Strides 34 / 80, conflict-free
 // under the ds_read_b64 rule -- 32 lanes against 64 banks --, measured 25 % SQ_LDS_BANK_CONFLICT of SQ_LDS_IDX_ACTIVE.)
-// WPC = workgroups per CU the register allocation aims at (one wave of each per SIMD): 4 by default ("direct_gemm_wpc"; 2 = two LDS
-// slab buffers with one barrier per slab, measured slower: what four workgroups hide is each other's prologues and epilogues).
+// WPC = workgroups per CU the register allocation aims at (one wave of each per SIMD): 4 (two LDS slab buffers with one barrier per slab at
+// two workgroups per CU were measured slower and are gone: what four workgroups hide is each other's prologues and epilogues).
 // Measured and dropped (round 2 / 3, cfg4 plan, per-batch replays; profiles/README.md): K slabs of 64, an XCD-aware workgroup -> tile
 // map (round 4: kept for the batches of many fronts, k_ds_gemm_x below), a capped persistent grid walking the tiles, skipping the products of
 // quadrants outside the front, 128 x 128 tiles; round 4: wave priorities (s_setprio) that differ between the workgroups sharing a CU, to
@@ -1085,9 +1085,8 @@ __global__ void __launch_bounds__(256) k_ds_inv_small(DsDev D, int lv0, int ls) 
 template <int mode, int WPC>
 TSL_DEV void ds_gemm_tile(const DsDev& D, int lv0, int bx, int by, int bz) {
   constexpr int SA = DS_SK + 1, SB = 64 + 1;
-  constexpr int NB = WPC == 2 ? 2 : 1;
-  __shared__ double As[NB * 64 * SA];
-  __shared__ double Bs[NB * DS_SK * SB];
+  __shared__ double As[64 * SA];
+  __shared__ double Bs[DS_SK * SB];
   const DsFrontDesc f = D.frl[lv0 + bz];
   const int Mr = mode == 0 ? f.pp : f.bp, Nc = f.bp, K = f.pp;
   const int I0 = by * 64, J0 = bx * 64;
@@ -1141,33 +1140,7 @@ TSL_DEV void ds_gemm_tile(const DsDev& D, int lv0, int bx, int by, int bz) {
 #pragma unroll
     for (int h = 0; h < GMC / 2; h++) { const int q = 2 * h + (threadIdx.x >> 7); pre[h] = q < f.nchild ? map_load(q) : -1; }
   }
-  if (NB == 2) {
-    auto fill = [&](int b) {
-      double* Ab = As + b * 64 * SA; double* Bb = Bs + b * DS_SK * SB;
-#pragma unroll
-      for (int q = 0; q < 8; q++) Ab[(ty + 8 * q) * SA + tx] = pa[q];
-#pragma unroll
-      for (int q = 0; q < 4; q++) { Bb[(ty + 8 * q) * SB + tx] = pb0[q]; Bb[(ty + 8 * q) * SB + tx + 32] = pb1[q]; }
-    };
-    fill(0);
-    __syncthreads();
-    for (int k0 = 0, cur = 0; k0 < K; k0 += DS_SK, cur ^= 1) {
-      const bool more = k0 + DS_SK < K;
-      if (more) gload(k0 + DS_SK);
-      const double* Ab = As + cur * 64 * SA; const double* Bb = Bs + cur * DS_SK * SB;
-#pragma unroll
-      for (int kk = 0; kk < DS_SK / 4; kk++) {
-        const double a0 = Ab[(32 * wi + lr) * SA + 4 * kk + lk], a1 = Ab[(32 * wi + 16 + lr) * SA + 4 * kk + lk];
-        const double b0 = Bb[(4 * kk + lk) * SB + 32 * wj + lr], b1 = Bb[(4 * kk + lk) * SB + 32 * wj + 16 + lr];
-        acc[0][0] = __builtin_amdgcn_mfma_f64_16x16x4f64(a0, b0, acc[0][0], 0, 0, 0);
-        acc[0][1] = __builtin_amdgcn_mfma_f64_16x16x4f64(a0, b1, acc[0][1], 0, 0, 0);
-        acc[1][0] = __builtin_amdgcn_mfma_f64_16x16x4f64(a1, b0, acc[1][0], 0, 0, 0);
-        acc[1][1] = __builtin_amdgcn_mfma_f64_16x16x4f64(a1, b1, acc[1][1], 0, 0, 0);
-      }
-      if (more) { fill(cur ^ 1); __syncthreads(); }   // the other buffer was last read before the barrier of the previous slab
-    }
-  } else
-  for (int k0 = 0; k0 < (D.dbg == 12 ? DS_SK : K); k0 += DS_SK) {   // ("ds_dbg" 12, timing experiment: one slab only -- prologue + epilogue)
+  for (int k0 = 0; k0 < K; k0 += DS_SK) {
 #pragma unroll
     for (int q = 0; q < 8; q++) As[(ty + 8 * q) * SA + tx] = pa[q];
 #pragma unroll
@@ -1218,7 +1191,6 @@ TSL_DEV void ds_gemm_tile(const DsDev& D, int lv0, int bx, int by, int bz) {
     }
     if ((int)threadIdx.x < nq) { const DsChildRec c = D.ch[f.ch_off + q0 + threadIdx.x]; s_soff[threadIdx.x] = c.soff; s_cbp[threadIdx.x] = c.bp; }
     __syncthreads();
-    if (D.dbg == 13) continue;   // ("ds_dbg" 13, timing experiment: no gather)
     for (int q = 0; q < nq; q++) {   // ascending child order: the fixed summation order
       const double* Sc = D.S + s_soff[q];
       const int cbp = s_cbp[q];
@@ -1378,85 +1350,6 @@ __global__ void __launch_bounds__(256) k_ds_gemm_g32(DsDev D, int lv0) {
   }
 #pragma unroll
   for (int r = 0; r < 4; r++) G[(size_t)(I0 + 16 * wi + lk + 4 * r) * f.bp + J0 + 16 * wj + lr] = acc[r];
-}
-
-// The Schur complement in the same 32 x 32 tiles ("direct_s32_below"): per workgroup a quarter of the epilogue (4 gathered entries per lane
-// and child instead of 16) and a quarter of the registers, so that eight and more workgroups per CU hide each other's descriptor ->
-// first slab -> ... -> table -> S-load -> store chains, which is what the 64 x 64-tile launches spend more than half their time in at
-// K = 96 .. 544.  The tables of the tile's 32 rows and 32 columns in the first DS_GMC children are requested before the K loop.
-__global__ void __launch_bounds__(256) k_ds_gemm_s32(DsDev D, int lv0) {
-  constexpr int SA = DS_SK + 1, SB = 32 + 1, GMC = DS_GMC;
-  __shared__ double As[32 * SA];
-  __shared__ double Bs[DS_SK * SB];
-  __shared__ int s_map[GMC][64];
-  __shared__ long long s_soff[GMC];
-  __shared__ int s_cbp[GMC];
-  const DsFrontDesc f = D.frl[lv0 + blockIdx.z];
-  const int Mr = f.bp, Nc = f.bp, K = f.pp;
-  const int I0 = blockIdx.y * 32, J0 = blockIdx.x * 32;
-  if (I0 >= Mr || J0 >= Nc || f.parent < 0) return;
-  const double* Am = D.A + f.off21;   // F21 rows, row stride pp
-  const double* Bm = D.G + f.goff;    // G, row stride bp
-  const int lda = f.pp, ldb = f.bp;
-  const int lane = threadIdx.x & 63, w = threadIdx.x >> 6, wi = w >> 1, wj = w & 1, lr = lane & 15, lk = lane >> 4;
-  const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;   // 32 x 8
-  ds_d4 acc = {0.0, 0.0, 0.0, 0.0};
-  double pa[4], pb[4];
-  auto gload = [&](int k0) {
-#pragma unroll
-    for (int q = 0; q < 4; q++) {
-      const int r = ty + 8 * q;
-      pa[q] = Am[(size_t)(I0 + r) * lda + k0 + tx];
-      pb[q] = Bm[(size_t)(k0 + r) * ldb + J0 + tx];
-    }
-  };
-  gload(0);
-  auto map_load = [&](int q) {   // this thread's entry of child q's table: 32 rows, then 32 columns
-    const int k = threadIdx.x & 63;
-    return D.pmap[D.ch[f.ch_off + q].pmap_off + f.pp + (k < 32 ? I0 + k : J0 + k - 32)];
-  };
-  int pre[GMC / 4];
-#pragma unroll
-  for (int h = 0; h < GMC / 4; h++) { const int q = 4 * h + w; pre[h] = q < f.nchild ? map_load(q) : -1; }
-  for (int k0 = 0; k0 < K; k0 += DS_SK) {
-#pragma unroll
-    for (int q = 0; q < 4; q++) { As[(ty + 8 * q) * SA + tx] = pa[q]; Bs[(ty + 8 * q) * SB + tx] = pb[q]; }
-    __syncthreads();
-    if (k0 + DS_SK < K) gload(k0 + DS_SK);
-#pragma unroll
-    for (int kk = 0; kk < DS_SK / 4; kk++)
-      acc = __builtin_amdgcn_mfma_f64_16x16x4f64(As[(16 * wi + lr) * SA + 4 * kk + lk], Bs[(4 * kk + lk) * SB + 16 * wj + lr], acc, 0, 0, 0);
-    __syncthreads();
-  }
-  double s22[4] = {0.0, 0.0, 0.0, 0.0};
-  for (int q0 = 0; q0 < f.nchild; q0 += GMC) {
-    const int nq = min(GMC, f.nchild - q0);
-    if (q0 > 0) __syncthreads();
-#pragma unroll
-    for (int h = 0; h < GMC / 4; h++) {
-      const int q = 4 * h + w;
-      if (q < nq) s_map[q][threadIdx.x & 63] = q0 == 0 ? pre[h] : map_load(q0 + q);
-    }
-    if ((int)threadIdx.x < nq) { const DsChildRec c = D.ch[f.ch_off + q0 + threadIdx.x]; s_soff[threadIdx.x] = c.soff; s_cbp[threadIdx.x] = c.bp; }
-    __syncthreads();
-    for (int q = 0; q < nq; q++) {   // ascending child order: the fixed summation order
-      const int cj = s_map[q][32 + 16 * wj + lr];
-      if (cj < 0) continue;
-      const double* Sc = D.S + s_soff[q] + cj;
-      const int cbp = s_cbp[q];
-#pragma unroll
-      for (int r = 0; r < 4; r++) {
-        const int ci = s_map[q][16 * wi + lk + 4 * r];
-        if (ci >= 0) s22[r] += Sc[(size_t)ci * cbp];
-      }
-    }
-  }
-  double* Sf = D.S + f.soff;
-  const int col = J0 + 16 * wj + lr;
-  if (col < f.b) {
-#pragma unroll
-    for (int r = 0; r < 4; r++) { const int row = I0 + 16 * wi + lk + 4 * r; if (row < f.b) Sf[(size_t)row * f.bp + col] = s22[r] - acc[r]; }
-  }
 }
 
 template <int mode, int WPC>

@@ -245,59 +245,3 @@ k_tet_hess(TetArgs A, const int* __restrict__ blk, const double* __restrict__ po
         }
     }
 }
-
-// The same element Hessians with 16 lanes per tetrahedron (k_tet_hess keeps one thread per element with the 9 x 9 block and its
-// Jacobi eigen-clamp in private arrays: 0.35-0.55 ms for the 5.8k elements of cfg4, ninety waves on the whole chip).  Lane l < 9
-// forms row l of the block -- the derivative in direction (vertex l / 3, axis l % 3) -- into LDS, the eigen-clamp is the
-// group-cooperative spd_clamp9_lds of the contact assembly (k_contact.hpp), lane 4 a + b scatters vertex block (a, b).
-__global__ void __launch_bounds__(256)
-k_tet_hess_coop(TetArgs A, const int* __restrict__ blk, const double* __restrict__ pos, int spd, double* __restrict__ vals) {
-  __shared__ double s_a[16][81], s_v[16][81];
-  const int l = threadIdx.x & 15, g = threadIdx.x >> 4;
-  int t = (int)((blockIdx.x * (size_t)blockDim.x + threadIdx.x) >> 4);
-  const bool valid = t < A.n_tet;
-  if (!valid) t = A.n_tet - 1;   // whole groups beyond the list still take part in the wave-wide shuffles
-  int v[4]; m3 B;
-  const m3 F = tet_F(A, t, pos, v, B);
-  const ElasticDev e = A.el[A.tel[t]];
-  const m3 Fi = (e.kind == 0) ? F : m3_inv(F), FiT = m3_T(Fi), BT = m3_T(B);
-  const double W = A.W[t];
-  const double Jraw = m3_det(F);
-  const double J = (e.kind == 0) ? Jraw : fmax(Jraw, 0.01);
-  const double logJ = (e.kind == 0) ? 0.0 : log(J);
-  double* sa = s_a[g];
-  if (l < 9) {
-    const int n = l / 3, dim = l % 3;
-    m3 dF;
-#pragma unroll
-    for (int k = 0; k < 9; k++) dF.m[k] = 0;
-#pragma unroll
-    for (int c = 0; c < 3; c++) dF.m[dim * 3 + c] = B.m[n * 3 + c];
-    const m3 dH = tet_dH(e, F, Fi, FiT, J, logJ, dF, BT, W);
-#pragma unroll
-    for (int i = 0; i < 3; i++)
-#pragma unroll
-      for (int j = 0; j < 3; j++) sa[l * 9 + i * 3 + j] = dH.m[j * 3 + i];
-  }
-  __builtin_amdgcn_wave_barrier();
-  const bool clamp = (e.kind == 0 && spd) || spd == 2;
-  spd_clamp9_lds(sa, s_v[g], l, clamp);
-  if (!valid) return;
-  // He(r, c): the tactile convention; model_elastic_offset.py:151-167 scatters the transpose (identical whenever the block is symmetric)
-  const bool tr = e.kind != 0;
-  const int a = l >> 2, b = l & 3;
-  const int base = blk[16 * t + l];
-#pragma unroll
-  for (int j = 0; j < 3; j++)
-#pragma unroll
-    for (int j2 = 0; j2 < 3; j2++) {
-      double s = 0;
-      for (int aa = (a < 3 ? a : 0); aa < (a < 3 ? a + 1 : 3); aa++)
-        for (int bb = (b < 3 ? b : 0); bb < (b < 3 ? b + 1 : 3); bb++) {
-          const int r = aa * 3 + j, c = bb * 3 + j2;
-          s += tr ? sa[c * 9 + r] : sa[r * 9 + c];
-        }
-      if ((a == 3) != (b == 3)) s = -s;
-      atomicAdd(&vals[(size_t)base + 64 * (3 * j + j2)], s);
-    }
-}

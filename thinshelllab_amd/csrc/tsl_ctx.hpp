@@ -125,7 +125,6 @@ struct DirectSolver {
   int prezero = 1;          // "direct_prezero"
   hipStream_t fstream[2] = {nullptr, nullptr};   // batches of one level run next to each other (direct_factor)
   hipEvent_t ev_ffork = nullptr, ev_fjoin[2] = {nullptr, nullptr};
-  int par_batches = 1;      // "direct_par_batches"
   // "direct_flow": block steps of a batch alone on its level as one persistent dataflow launch (k_ds_gj_flow)
   int device = 0;          // HIP device of the context (tsl_ctx_create)
   int flow = 3, flow_cap = 0, flow_epoch = 0;   // flow_cap: workgroups of k_ds_gj_flow the device holds at once
@@ -141,8 +140,6 @@ struct DirectSolver {
                                // cfg4, one application: 404 us without, 385 / 380 / 387 / 388 / 409 / 523 us at 150 / 300 / 600 / 1200 / 2400 / always (scripts/archive_r02_r03/exp_gemv_wide.py)
   int g32_below = 1100;     // "direct_g32_below": G = W F12 of a batch with fewer 64 x 64 tiles than this runs in the 32 x 32-tile kernel (k_ds_gemm_g32; 0 = never).
                             // cfg4: 52 -> 34, 67 -> 52, 37 -> 32 us on the three top levels with boundaries; the batches of 1150+ tiles lose (31 -> 33 us)
-  int s32_below = 0;        // "direct_s32_below": the same for the Schur complements (k_ds_gemm_s32)
-  int gemm_wpc = 4;         // "direct_gemm_wpc": workgroups per CU the GEMM kernels are compiled for (4; 2 = two LDS slab buffers, one barrier per slab: measured slower)
   bool cons_checked = false; // the constraint list has not changed since direct_plan last looked (reset by tsl_contact_detect)
   double* h_anorm = nullptr; // pinned: |H|_inf of the last factorisation (valid after the next stream synchronisation)
   int bench_batch = -1;     // tsl_bench_direct: restrict the replay to one batch (-1: all)
@@ -156,17 +153,13 @@ struct DirectSolver {
   int fallback_cap = 1000;  // iteration cap of the hierarchy when the factorisation broke down ("direct_fallback_cap")
   int leaf = 64;            // vertices per leaf of the nested dissection (cfg4 sweep: 32 -> 452, 48 -> 420, 56 / 64 -> 407, 80 -> 538 ms per step)
   bool static_ready = false, numeric_valid = false;
-  bool have_factor = false, refactor_next = false;  // factors of the current plan exist (possibly of an earlier operator)
-  int lag = 0;              // > 0: Newton iterations reuse earlier factors while the refinement needs at most this many iterations.  Off: measured on cfg4, factors of the PREVIOUS Newton iteration need more than 20 refinement iterations (the projected blocks switch between iterations), a refactorisation costs ~10
-  int gm_cap = 0;
+  bool have_factor = false;  // factors of the current plan exist
   int dbg = 0;
-  long n_stale = 0;
   // "direct_berr": the first pass of a refined solve is accepted when its normwise backward error |b - Hx| / (|H|_inf |x| + |b|) is at most this
   // (0: forward-residual rule only) and its forward residual at most "direct_berr_rel_cap" x cg_tol (direct_refine)
   double berr_tol = 1e-12, berr_rel_cap = 50.0;
   long berr_seen = 0, berr_accepted = 0;
   double berr_max = 0, berr_rel_max = 0;   // largest backward error / forward residual accepted under the rule
-  int refine_ir = 1;           // "direct_refine": 1 = classic iterative refinement with the factors (GMRES only where it stalls), 0 = flexible GMRES from the start
   int n_setup_fail = 0;        // set-up failures of the direct path in automatic mode (three disable it)
   std::vector<std::unique_ptr<DsPlanSlot>> cache;   // plans of earlier constraint sets ("direct_plan_cache" slots, least recently used evicted)
   int cache_cap = 64, cache_mb = 1024;   // slots / MB of parked plans ("direct_plan_cache", "direct_plan_cache_mb")
@@ -294,7 +287,7 @@ struct tsl_ctx {
   DevBuf<double> vg_stage2;   // second staging array of the tet slots (tsl_param_grad: the two materials accumulate into different vectors)
   DevBuf<double> dot_part; DevBuf<int> dot_ticket;   // scratch of the deterministic dot products
   DevBuf<double> e_part;                 // per-workgroup partial energies
-  int n_cgblk = 0, n_cgblk_cloth = 0, cloth_gather = 0;   // gather lists: blocks of the cloth first, blocks of the FEM bodies behind them   // "cloth_gather" = 1: gather assembly of the cloth Hessian (deterministic; measured no faster than the class-ordered atomics: 268 against 270 us)
+  int n_cgblk = 0, n_cgblk_cloth = 0;   // gather lists: blocks of the cloth first, blocks of the FEM bodies behind them   // "cloth_gather" = 1: gather assembly of the cloth Hessian (deterministic; measured no faster than the class-ordered atomics: 268 against 270 us)
   DevBuf<double> tet_V;       // eigenvector bases of the clamped element blocks of the last assembly (81 x n_tet, entry-major): warm start of the next one
   long tet_V_count = 0;
   int tet_warm = 1;
@@ -320,13 +313,8 @@ struct tsl_ctx {
   SolverScalars* h_scal2 = nullptr; // pinned, two records: read-back slots of the PCG chunks in flight
   hipEvent_t rb_event[2] = {nullptr, nullptr};
   hipStream_t side = 0;                         // second stream: contact blocks of an assembly run next to the cloth / tet kernels
-  int asm_early = 1;   // "asm_early": issue order of the deterministic assembly with bodies / contacts (assemble_enqueue_early); 0: the order of the other modes
   hipEvent_t ev_fork = nullptr, ev_fork0 = nullptr, ev_g2 = nullptr, ev_join = nullptr, ev_join2 = nullptr;
   hipStream_t side2 = 0;                        // third stream: the tet kernels next to the contact kernels (side) and the cloth kernels
-  int asm_overlap = 1;
-  int contact_coop = 1;  // 16 lanes per constraint in the contact block assembly (0: one lane per constraint)
-  int tet_coop = 0;      // 1: 16 lanes per tetrahedron in the element Hessians (k_tet_hess_coop): measured 0.76 ms per launch against 0.40 ms of the
-                         // one-lane-per-element kernel on cfg4 (5.8k elements; the group-cooperative Jacobi pays for contacts, not here): off
 
   // ---- Newton scratch (original order)
   DevBuf<double> F, pdir, x1;
@@ -368,9 +356,7 @@ struct tsl_ctx {
   DevBuf<double> mg_omega0, mg_pi_part, mg_pi_norm;  // level 0
   int mg_nu = 1, mg_coarse_sweeps = 8, mg_fuse = 1, mg_fuse_restrict = 1, mg_max_levels = 16, mg_coarse_exact = 1, mg_coarse_lag = 0, mg_dense_nodes = 64, mg_dense_auto = 1;
   double last_step_iters_per_solve = 0.0;
-  int warm_start = 0;       // PCG of a Newton iteration starts from the previous iteration's direction (optional, see solve_perm)
   bool warm_valid = false;
-  int pcg_ahead = 0;        // 1: a second PCG chunk is launched before the convergence record of the first is read
   bool mg_cinv_valid = false;
   bool mg_ops_valid = false, mg_suspended = false, mg_omega_valid = false;
 

@@ -431,7 +431,6 @@ extern "C" int tsl_set_param(tsl_ctx* c, const char* key, double v) {
   else if (k == "damping") c->damping = v;
   else if (k == "cg_tol") c->cg_tol = v;
   else if (k == "cg_maxit") c->cg_maxit = (int)v;
-  else if (k == "cg_check") c->cg_check = std::max(1, (int)v);
   else if (k == "newton_cap") c->newton_cap = (int)v;
   else if (k == "plastic") c->plastic = (int)v;
   else if (k == "contact") c->contact_enable = (v != 0.0);
@@ -440,21 +439,14 @@ extern "C" int tsl_set_param(tsl_ctx* c, const char* key, double v) {
   else if (k == "adj_spd_pc") c->adj_spd_pc = (int)v;
   else if (k == "adj_clamp") c->adj_clamp = v;
   else if (k == "adj_clamp_angleref") c->adj_clamp_angleref = (int)v;
-  else if (k == "gmres") c->use_gmres = (int)v;
-  else if (k == "minres") c->use_minres = (int)v;
   else if (k == "verbose") c->verbose = (int)v;
   else if (k == "direct") { c->ds.enable = (int)v; c->ds.numeric_valid = false; c->ds.hard = false; }
-  else if (k == "direct_lag") c->ds.lag = (int)v;
-  else if (k == "direct_refine") c->ds.refine_ir = (int)v;
   else if (k == "direct_berr") c->ds.berr_tol = v;
   else if (k == "direct_berr_rel_cap") c->ds.berr_rel_cap = v;
   else if (k == "direct_small_rounds") { c->ds.small_rounds = std::max(1, (int)v); c->ds.plan_valid = false; c->ds.numeric_valid = false; c->ds.cache.clear(); }
   else if (k == "direct_plan_cache") { c->ds.cache_cap = std::max(0, (int)v); c->ds.cache.clear(); }
-  else if (k == "direct_plan_cache_mb") c->ds.cache_mb = std::max(1, (int)v);
   else if (k == "tet_warm") c->tet_warm = (int)v;
-  else if (k == "cloth_gather") c->cloth_gather = (int)v;
   else if (k == "ds_dbg") c->ds.dbg = (int)v;
-  else if (k == "direct_fallback_cap") c->ds.fallback_cap = (int)v;
   else if (k == "ds_bench_batch") c->ds.bench_batch = (int)v;
   else if (k == "direct_prezero") c->ds.prezero = (int)v;
   else if (k == "direct_flow") c->ds.flow = std::max(0, (int)v);
@@ -462,28 +454,12 @@ extern "C" int tsl_set_param(tsl_ctx* c, const char* key, double v) {
   else if (k == "deterministic") c->deterministic = (int)v != 0;
   else if (k == "direct_gemv_wide_below") c->ds.gemv_wide_below = std::max(0, (int)v);
   else if (k == "direct_g32_below") c->ds.g32_below = std::max(0, (int)v);
-  else if (k == "direct_s32_below") c->ds.s32_below = std::max(0, (int)v);
-  else if (k == "direct_par_batches") c->ds.par_batches = (int)v;
-  else if (k == "direct_gemm_wpc") c->ds.gemm_wpc = (int)v;
   else if (k == "direct_xcd") c->ds.xcd_map = (int)v;
-  else if (k == "asm_early") c->asm_early = (int)v;
-  else if (k == "direct_split") { c->ds.plan.split_small = ((int)v & 1) != 0; c->ds.plan.split_rem = ((int)v & 2) != 0; c->ds.plan_valid = false; c->ds.numeric_valid = false; c->ds.cache.clear(); }
-  else if (k == "direct_merge_sep") { c->ds.plan.sym.merge_sep = (int)v; c->ds.static_ready = false; c->ds.plan_valid = false; c->ds.numeric_valid = false; }
-  else if (k == "direct_merge_k") { c->ds.plan.sym.merge_k = v != 0; c->ds.plan_valid = false; c->ds.numeric_valid = false; c->ds.cache.clear(); }
   else if (k == "direct_piv_tol") { c->ds.piv_tol = v; c->ds.numeric_valid = false; }
-  else if (k == "direct_probe_cap") c->ds.probe_cap = std::max(1, (int)v);
-  else if (k == "direct_probe_every") c->ds.probe_every = std::max(1, (int)v);
   else if (k == "direct_leaf") { c->ds.leaf = std::max(4, (int)v); c->ds.static_ready = false; c->ds.plan_valid = false; c->ds.numeric_valid = false; }
-  else if (k == "fwd_spd_pc") c->fwd_spd_pc = (int)v;
   else if (k == "gmres_m") c->gmres_m = (int)v;
   else if (k == "body_inv") { c->bd_enable = (int)v; c->bd_valid = false; }
   else if (k == "mg") c->mg_enable = (int)v;
-  else if (k == "mg_omega") c->mg_omega = v;
-  else if (k == "mg_fuse") c->mg_fuse = (int)v;
-  else if (k == "pcg_body_fold") c->pcg_body_fold = (int)v;
-  else if (k == "asm_overlap") c->asm_overlap = (int)v;
-  else if (k == "contact_coop") c->contact_coop = (int)v;
-  else if (k == "tet_coop") c->tet_coop = (int)v;
   else if (k.rfind("self_contact", 0) == 0 && k.size() > 12) {   // "self_contact<body>" (geometry_self.projection_query(self_contact=[...]))
     char* endp = nullptr;
     const long b = strtol(k.c_str() + 12, &endp, 10);
@@ -491,22 +467,8 @@ extern "C" int tsl_set_param(tsl_ctx* c, const char* key, double v) {
     if ((long)c->self_contact.size() < c->n_body) c->self_contact.assign(c->n_body, 0);
     c->self_contact[b] = (v != 0.0);
   }
-  else if (k == "mg_chunk") c->mg_chunk = (int)v;  // 0 = chosen from the previous step's iterations per solve
-  else if (k == "mr_eta") c->mr_eta = v;
-  else if (k == "mg_st_f32") { c->mg_st_f32 = (int)v; c->mg_ops_valid = false; }
-  else if (k == "mg_fr_rows") { c->mg_fr_rows = (int)v; if (c->pcg_graph) { (void)hipGraphExecDestroy(c->pcg_graph); c->pcg_graph = nullptr; } if (c->mr_graph) { (void)hipGraphExecDestroy(c->mr_graph); c->mr_graph = nullptr; } }
-  else if (k == "mg_fuse_restrict") { c->mg_fuse_restrict = (int)v; c->mg_ops_valid = false; }
   else if (k == "mg_coarse_exact") c->mg_coarse_exact = (int)v;
-  else if (k == "mg_coarse_lag") c->mg_coarse_lag = (int)v;
-  else if (k == "warm_start") c->warm_start = (int)v;
-  else if (k == "mg_f32") { c->mg_f32 = (int)v; c->vals32_valid = false; c->mg_ops_valid = false; }
-  else if (k == "pcg_ahead") c->pcg_ahead = (int)v;
   else if (k == "mg_dense_nodes") { c->mg_dense_auto = v < 0; if (v >= 0) c->mg_dense_nodes = (int)v; c->mg_ops_valid = false; }
-  else if (k == "mg_max_levels") c->mg_max_levels = (int)v;
-  else if (k == "mg_pi_iters") c->mg_pi_iters = (int)v;
-  else if (k == "graph") c->use_graph = (int)v;
-  else if (k == "mg_nu") c->mg_nu = std::max(1, (int)v);
-  else if (k == "mg_coarse_sweeps") c->mg_coarse_sweeps = std::max(1, (int)v);
   else if ((k.rfind("cloth", 0) == 0 || k.rfind("elastic", 0) == 0) && k.find('.') != std::string::npos) {
     // "cloth<i>.Kb|Kl|Ka|k_angle", "elastic<i>.mu|lam|alpha" (0-d field writes after the context exists)
     const bool is_cloth = k[0] == 'c';
@@ -658,8 +620,8 @@ static int assemble_enqueue(tsl_ctx* c, const double* pos, const double* prev, c
   hipStream_t s = c->stream;
   const int NV = c->NV;
   const bool det = c->deterministic != 0;
-  const bool fork = c->asm_overlap && (c->nc > 0 || c->n_tet > 0);
-  if (det && fork && c->asm_early) return assemble_enqueue_early(c, pos, prev, vel, ref, spd, grad, tet_warm_flag);
+  const bool fork = c->nc > 0 || c->n_tet > 0;
+  if (det && fork) return assemble_enqueue_early(c, pos, prev, vel, ref, spd, grad, tet_warm_flag);
   HIP_OK(hipMemsetAsync(c->vals_full.p, 0, c->vals_full.n * sizeof(double), s));
   if (c->n_cface) hipLaunchKernelGGL(k_cloth_normals, dim3(nblk(c->n_cface, 256)), dim3(256), 0, s, c->n_cface, pos, c->cf_f2v.p, c->norm_dir.p);
   ClothArgs CA = cloth_args(c);
@@ -684,8 +646,7 @@ static int assemble_enqueue(tsl_ctx* c, const double* pos, const double* prev, c
   }
   if (c->n_tet) {
     if (grad) hipLaunchKernelGGL(k_tet_grad, dim3(nblk(c->n_tet, 256)), dim3(256), 0, stt, TA, pos, grad);
-    if (c->tet_coop && !det) hipLaunchKernelGGL(k_tet_hess_coop, dim3(nblk((long)c->n_tet * 16, 256)), dim3(256), 0, stt, TA, c->tet_blk.p, pos, spd, c->vals_full.p);
-    else {
+    {
       // eigen-clamp of the element blocks warm-started from the previous assembly's eigenvectors ("tet_warm", on by default);
       // every 16th clamped assembly starts from the identity again (orthogonality of the accumulated rotations)
       double* vws = (c->tet_warm && spd != 0) ? c->tet_V.p : (double*)nullptr;   // (allocated and counted by assemble())
@@ -705,7 +666,7 @@ static int assemble_enqueue(tsl_ctx* c, const double* pos, const double* prev, c
   }
   if (fork) HIP_OK(hipEventRecord(c->ev_join, c->side));
   if (fork_t) HIP_OK(hipEventRecord(c->ev_join2, c->side2));
-  const bool gather = (c->cloth_gather || det) && c->n_cgblk > 0;
+  const bool gather = det && c->n_cgblk > 0;
   if (c->n_cface) {
     const int nq = (int)c->h_cloth.size() * 9;
     hipLaunchKernelGGL(k_cloth_quirk, dim3(nblk(nq, 64)), dim3(64), 0, s, CA, (int)c->h_cloth.size(), pos, ref, c->quirk.p);
@@ -834,11 +795,11 @@ static int assemble(tsl_ctx* c, const double* pos, const double* prev, const dou
     if (c->n_tet > 0 && c->cg_trec.n < 144 * (size_t)c->n_tet) { if (c->cg_trec.alloc(144 * (size_t)c->n_tet)) return tsl_fail("out of device memory (element records)"); }
     if (grad && c->nc > 0 && c->c_G.n < 12 * (size_t)c->max_n_constraints) { if (c->c_G.alloc(12 * (size_t)c->max_n_constraints)) return -1; }
   }
-  if ((c->cloth_gather || det) && c->n_cgblk > 0 && c->n_cface > 0 && c->cg_frec.n == 0) {
+  if (det && c->n_cgblk > 0 && c->n_cface > 0 && c->cg_frec.n == 0) {
     if (c->cg_hrec.alloc((size_t)std::max(c->n_hinge, 1) * 16) | c->cg_frec.alloc((size_t)c->n_cface * 81)) return tsl_fail("out of device memory (cloth element records)");
   }
   int warm = 0;
-  if (c->n_tet > 0 && c->tet_warm && spd != 0 && !(c->tet_coop && !det)) {
+  if (c->n_tet > 0 && c->tet_warm && spd != 0) {
     if (c->tet_V.n < (size_t)81 * c->n_tet) {
       if (c->tet_V.alloc((size_t)81 * c->n_tet)) return tsl_fail("out of device memory (tet eigenvectors)");
       HIP_OK(hipMemsetAsync(c->tet_V.p, 0, c->tet_V.n * sizeof(double), s));   // "no basis yet" for every element (spd_clamp_warm checks the norm)
@@ -1347,9 +1308,6 @@ static int solve_perm(tsl_ctx* c, tsl_solve_stats* st) {
   if (direct_enabled(c) && !c->ds_suspended) {
     // primary path on refined cloths: multifrontal LU of the operator (like the reference's spsolve) + GMRES refinement
     // against the operator product; the iterative hierarchy below only runs if that fails.
-    // Inside a time step the factors of an earlier Newton iteration of the same constraint set are reused as long as the
-    // refinement converges within `lag` iterations (the operator changes little between iterations; a refactorisation costs
-    // ~10 applications); the solution is always refined against the CURRENT operator to the same tolerance.
     DirectSolver& d = c->ds;
     // "direct" = -1 (auto): easy systems stay with the iterative hierarchy -- the contact-free 224 x 224 drape needs 26 multigrid-PCG
     // iterations per solve (46 ms per step) against one 6 ms factorisation per solve (86 ms per step).  A solve first probes the
@@ -1375,20 +1333,13 @@ static int solve_perm(tsl_ctx* c, tsl_solve_stats* st) {
     // in the automatic mode the solve falls through to the iterative hierarchy, which needs none of that memory, and after three
     // such failures the context stops trying ("direct" = 0).
     auto direct_try = [&]() -> int {
-      bool stale = false;
       if (!d.numeric_valid) {
         TSL_TRY(direct_plan(c));
-        stale = c->in_step && d.lag > 0 && d.have_factor && !d.refactor_next;
-        if (!stale) TSL_TRY(direct_factor(c));
+        TSL_TRY(direct_factor(c));
       }
-      d.refactor_next = false;
-      d.gm_cap = stale ? d.lag : 0;
-      int rc_g = 0;
-      if (!stale && d.refine_ir) {   // plain refinement first; systems it does not settle go through the flexible GMRES from scratch
-        rc_g = direct_refine(c, &sd);
-        if (rc_g == 0 && sd.flag != 1) { const int it0 = sd.iters; sd = *st; c->last_xmax_valid = false; rc_g = gmres(c, &sd, true); sd.iters += it0; }
-      } else rc_g = gmres(c, &sd, true);
-      d.gm_cap = 0;
+      // plain refinement first; systems it does not settle go through the flexible GMRES from scratch
+      int rc_g = direct_refine(c, &sd);
+      if (rc_g == 0 && sd.flag != 1) { const int it0 = sd.iters; sd = *st; c->last_xmax_valid = false; rc_g = gmres(c, &sd, true); sd.iters += it0; }
       if (rc_g) return -1;
       if ((sd.flag != 1 || d.dbg == 21) && d.flow && d.n_flow > 0) {   // a dataflow launch that lost a flag leaves garbage factors: say so, go back to the launch-per-block-step path
         int ab = 0;
@@ -1400,21 +1351,8 @@ static int solve_perm(tsl_ctx* c, tsl_solve_stats* st) {
           if (d.prezero_pending) { HIP_OK(hipStreamWaitEvent(c->stream, d.ev_zero, 0)); d.prezero_pending = false; }
           TSL_TRY(direct_factor(c));
           sd = *st; c->last_xmax_valid = false;
-          if (d.refine_ir) {
-            TSL_TRY(direct_refine(c, &sd));
-            if (sd.flag != 1) { const int it0 = sd.iters; sd = *st; c->last_xmax_valid = false; TSL_TRY(gmres(c, &sd, true)); sd.iters += it0; }
-          } else TSL_TRY(gmres(c, &sd, true));
-        }
-      }
-      if (stale) {
-        d.n_stale++;
-        if (sd.flag != 1 || sd.iters > (2 * d.lag) / 3) d.refactor_next = true;   // the next iteration starts from fresh factors
-        if (sd.flag != 1) {
-          const int it0 = sd.iters;
-          TSL_TRY(direct_factor(c));
-          sd = *st;
-          TSL_TRY(gmres(c, &sd, true));
-          sd.iters += it0;
+          TSL_TRY(direct_refine(c, &sd));
+          if (sd.flag != 1) { const int it0 = sd.iters; sd = *st; c->last_xmax_valid = false; TSL_TRY(gmres(c, &sd, true)); sd.iters += it0; }
         }
       }
       return 0;
@@ -1491,7 +1429,7 @@ static int solve_perm(tsl_ctx* c, tsl_solve_stats* st) {
   // optional warm start ("warm_start" = 1, off by default): inside a time step the previous Newton iteration's direction (still in
   // v_x) is the initial guess.  Measured: -4 % iterations on one cfg4 window, none on another, +2 % time on drape (one more product
   // per solve); its initial residual is usually LARGER than |b|, so a residual test cannot decide when to use it.
-  const bool warm = c->warm_start && c->in_step && c->warm_valid;
+  const bool warm = false;   // (a warm start from the previous Newton direction was measured: -4 % iterations on one cfg4 window, none on another, +2 % time on drape; gone)
   if (!warm) HIP_OK(hipMemsetAsync(c->v_x.p, 0, n3 * sizeof(double), s));
   HIP_OK(hipMemsetAsync(c->scal.p, 0, sizeof(SolverScalars), s));
   hipLaunchKernelGGL(k_dot, dim3(DOT_BLOCKS), dim3(256), 0, s, n3, c->v_b.p, c->v_b.p, &SC(c)->bb, DOT_SCRATCH(c));
@@ -1575,7 +1513,7 @@ static int solve_perm(tsl_ctx* c, tsl_solve_stats* st) {
       return 0;
     };
     while (true) {
-      while (inflight < 1 + (c->pcg_ahead ? 1 : 0) && total_it < c->cg_maxit && !(inflight == 1 && sampled[head])) TSL_TRY(launch_chunk());
+      while (inflight < 1 && total_it < c->cg_maxit && !(inflight == 1 && sampled[head])) TSL_TRY(launch_chunk());
       if (inflight == 0) break;  // iteration cap
       HIP_OK(hipEventSynchronize(c->rb_event[head]));
       if (sampled[head]) TSL_TRY(prof_sample_graph(c));
@@ -1854,7 +1792,6 @@ static int gmres(tsl_ctx* c, tsl_solve_stats* st, bool direct) {
       hipLaunchKernelGGL(k_dot, dim3(DOT_BLOCKS), dim3(256), 0, s, n3, w, w, dh + on, DOT_SCRATCH(c));
       TSL_TRY(read_h(on + 1));
       total++; st->iters++;
-      if (direct && c->ds.gm_cap > 0 && total > c->ds.gm_cap) return 0;  // stale factors: give up, the caller refactorises (flag stays 3)
       const double hn = sqrt(std::max(hh[on], 0.0));
       double* Hj = &H[(size_t)j * (m + 1)];  // column j
       for (int i = 0; i <= j; i++) Hj[i] = hh[i] + hh[o2 + i];
@@ -2389,8 +2326,12 @@ extern "C" int tsl_group_step(tsl_group* G, double* const* pos_a, double* const*
     // ---- energy at the top of the iteration (evaluated anew only in the first one), assembly, right-hand side
     for (int i : act) { iter[i]++; if (iter[i] == 1) { tsl_ctx* c = G->m[i]; TSL_TRY(energy_async(c, pos_a[i], prev_a[i], vel_a[i], ref_a[i])); HIP_OK(hipMemcpyAsync(&HSC(c)->energy, &SC(c)->energy, sizeof(double), hipMemcpyDeviceToHost, c->stream)); } }
     for (int i : act) { tsl_ctx* c = G->m[i]; if (iter[i] == 1) { HIP_OK(hipStreamSynchronize(c->stream)); E0[i] = HSC(c)->energy; } else E0[i] = E_last[i]; }
-    for (int i : act) { tsl_ctx* c = G->m[i]; TSL_TRY(assemble(c, pos_a[i], prev_a[i], vel_a[i], ref_a[i], 1, c->F.p)); }
-    for (int i : act) { tsl_ctx* c = G->m[i]; hipLaunchKernelGGL(k_gather_perm, dim3(nblk(c->NV, 256)), dim3(256), 0, c->stream, c->NV, c->perm.p, (const double*)c->F.p, c->v_b.p); }
+    TSL_TRY(G->pool->run(act, [&](int i) -> int {   // (one host thread per member: the ~35 launches of an assembly are issued side by side)
+      tsl_ctx* c = G->m[i];
+      TSL_TRY(assemble(c, pos_a[i], prev_a[i], vel_a[i], ref_a[i], 1, c->F.p));
+      hipLaunchKernelGGL(k_gather_perm, dim3(nblk(c->NV, 256)), dim3(256), 0, c->stream, c->NV, c->perm.p, (const double*)c->F.p, c->v_b.p);
+      return 0;
+    }));
     lap(0);
     // ---- plans: every member's own (rebuilt when its constraint set changed: once per time step), then the merge
     for (int i = 0; i < n; i++) TSL_TRY(direct_plan(G->m[i]));
