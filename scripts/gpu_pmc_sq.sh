@@ -3,10 +3,10 @@
 # the block-step kernel go (MFMA busy, waiting, issue stalls, LDS conflicts).  usage (GPU box): bash scripts/gpu_pmc_sq.sh <tag>
 cd $GRAFT_REPO_ROOT
 export TMPDIR=/tmp
-TAG=${1:-r03}
+TAG=${1:-r05}
 mkdir -p gpurun_out/prof
-for KRN in "k_ds_gemm<1" "k_ds_gemm<0" "k_ds_gj_step" "k_ds_gj_flow"; do
-  KN=$(echo $KRN | tr -d '<>')
+for KRN in "k_ds_gemm(_x)?<1" "k_ds_gemm(_x)?<0" "k_ds_gj_step" "k_ds_gj_flow" "k_ds_inv_small"; do
+  KN=$(echo $KRN | tr -d '<>()?' | sed s/_x//)
   rocprofv3 --pmc SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_VALU_MFMA_BUSY_CYCLES SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE \
     --kernel-include-regex "$KRN" --output-format csv -d gpurun_out/prof -o ${TAG}_sq_${KN} -- python bench.py --steps 3 --warmup 1 --no-cpu-baseline > gpurun_out/prof/${TAG}_sq_stdout.log 2>&1
   python - <<PY

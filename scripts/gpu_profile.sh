@@ -5,7 +5,7 @@
 #   combined with tracing), 3. the bench lines with cpu_baseline (default command and the driver's command).
 cd $GRAFT_REPO_ROOT
 export TMPDIR=/tmp
-TAG=${1:-r04}
+TAG=${1:-r05}
 WL=${WORKLOAD:-cfg4}
 ARGS=${BENCH_ARGS:---steps 20 --warmup 5 --no-cpu-baseline}
 PMC_ARGS=${PMC_ARGS:---steps 3 --warmup 1 --no-cpu-baseline}
@@ -33,4 +33,8 @@ PY
 done
 python bench.py --workload $WL > gpurun_out/prof/${TAG}_full_default.json 2> gpurun_out/prof/${TAG}_full_default.err
 python bench.py --workload $WL --steps 20 --warmup 5 > gpurun_out/prof/${TAG}_full_driver.json 2> gpurun_out/prof/${TAG}_full_driver.err
+# scene groups next to the headline (S scenes of this GPU in lock step, merged factorisations): the multi_scene object of the same line
+for S in 2 4; do
+  python bench.py --workload $WL --steps 10 --warmup 3 --no-cpu-baseline --scenes-per-gpu $S > gpurun_out/prof/${TAG}_multi_$S.json 2> gpurun_out/prof/${TAG}_multi_$S.err
+done
 ls gpurun_out/prof

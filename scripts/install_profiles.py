@@ -34,6 +34,15 @@ for s, d in ((f"{TAG}_full_default.json", f"{TAG}_{WL}_bench_default.json"), (f"
         j = json.loads(line); c = j["config"]; r = j["roofline"]
         print(d, round(j["value"]), "el-steps/s", round(j["ms_per_step"], 1), "ms/step; unconverged", c["solves_unconverged"], "fallbacks", c["solver_fallbacks"],
               "| roofline", r["kernel"].split(" ")[0], r["bound"], round(r["achieved"], 1), r["unit"], "frac", round(r["frac"], 3), "| cpu", (j.get("cpu_baseline") or {}).get("value"))
+for S in (2, 4):
+    if os.path.exists(src + f"{TAG}_multi_{S}.json"):
+        try:
+            line = last_json_line(src + f"{TAG}_multi_{S}.json")
+            open(dst + f"{TAG}_{WL}_bench_scenes_per_gpu_{S}.json", "w").write(line)
+            m = json.loads(line).get("multi_scene", {})
+            print(f"scenes per GPU {S}:", m.get("value"), "el-steps/s,", m.get("speedup_vs_single_scene"), "x one scene, unconverged", m.get("solves_unconverged"), m.get("error"))
+        except Exception as e:
+            print("multi", S, "failed:", e)
 for kn in ("k_ds_gemm1", "k_ds_extend_panels", "k_ds_gemm0", "k_ds_gj_step", "k_ds_gj_flow", "k_ds_gemv"):
     try:
         f = open(src + f"{TAG}_pmc_{kn}_FETCH_SIZE_summary.txt").read().strip()
@@ -49,6 +58,9 @@ for kn in ("k_ds_gemm1", "k_ds_extend_panels", "k_ds_gemm0", "k_ds_gj_step", "k_
     # the name bench.py looks for (latest counters; the JSON carries the profile set and the commit)
     shutil.copy(dst + f"{TAG}_{WL}_pmc_{kn}.json", dst + f"latest_{WL}_pmc_{kn}.json")
     print(kn, "HBM traffic per launch:", traffic, "B (FETCH_SIZE", fm, "KB x2, WRITE_SIZE", wm, "KB)")
+for f in os.listdir(src):   # SQ counter summaries of scripts/gpu_pmc_sq.sh
+    if f.startswith(f"{TAG}_sq_") and f.endswith("_summary.txt"):
+        shutil.copy(src + f, dst + f.replace(f"{TAG}_sq_", f"{TAG}_{WL}_sq_").replace("_summary", ""))
 rows = list(csv.DictReader(open(dst + f"{TAG}_{WL}_kernel_stats.csv")))
 tot = sum(float(r["TotalDurationNs"]) for r in rows)
 print("total GPU ms", round(tot / 1e6))
