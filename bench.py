@@ -327,34 +327,26 @@ def cpu_baseline(args, scene, gpu_stats, K, rank):
         t_contact = 0.0
         if args.workload != "drape":
             t0 = time.time(); o.calc_vn(); o.projection_query(); o.contact_analysis(); t_contact = time.time() - t0
-        # the iteration twice from the same state: SuperLU with scipy's default column ordering (COLAMD) and with MMD on A^T + A (the operator is
-        # structurally symmetric: the ordering the reference's cupyx spsolve would pick for it is not documented; the faster of the two is the baseline)
-        x_keep = o.pos.copy()
-        by_order = {}
-        for order in ("COLAMD", "MMD_AT_PLUS_A"):
-            po.direct_permc[0] = order
-            o.pos[:] = x_keep; o.push_down_all()
-            o.stats(reset=True); po.direct_seconds[:] = [0.0, 0]
-            t0 = time.time()
-            o.newton_step_init(); o.compute_energy(); o.compute_residual_and_Hessian(True); o.newton_step()
-            by_order[order] = {"per_newton_iteration_s": time.time() - t0, "sparse_lu_s": po.direct_seconds[0], "stats": o.stats(),
-                               "sparse_lu_rel_residual": (po.direct_residuals[-1] if po.direct_residuals else None)}
-        order = min(by_order, key=lambda k: by_order[k]["per_newton_iteration_s"])
-        po.direct_permc[0] = "COLAMD"
-        t_newton = by_order[order]["per_newton_iteration_s"]; st = by_order[order]["stats"]
-        po.direct_seconds[0] = by_order[order]["sparse_lu_s"]
+        # SuperLU with scipy's default column ordering (COLAMD).  MMD on A^T + A -- the operator is structurally symmetric -- was measured once and is 12x
+        # SLOWER on this operator (590 s against 49 s per iteration in the build container: profiles/r05_cpu_superlu_orderings.txt), so it is not timed here
+        o.stats(reset=True); po.direct_seconds[:] = [0.0, 0]
+        t0 = time.time()
+        o.newton_step_init(); o.compute_energy(); o.compute_residual_and_Hessian(True); o.newton_step()
+        t_newton = time.time() - t0
+        st = o.stats()
+        order = "COLAMD"
         n_it = gpu_stats["newton"] + K     # every adjoint step = one assembly + one solve
         t_total = 2 * K * t_contact + n_it * t_newton
         T = scene.cloths[0].NF
         out["bench_size"] = {
             "value": T * K / t_total, "cores": best, "per_newton_iteration_s": t_newton, "contact_detection_s": t_contact,
-            "sparse_lu_s": po.direct_seconds[0], "sparse_lu_rel_residual": by_order[order]["sparse_lu_rel_residual"],
-            "sparse_lu_ordering": order, "by_ordering": {k: {"per_newton_iteration_s": v["per_newton_iteration_s"], "sparse_lu_s": v["sparse_lu_s"]} for k, v in by_order.items()},
+            "sparse_lu_s": po.direct_seconds[0], "sparse_lu_rel_residual": (po.direct_residuals[-1] if po.direct_residuals else None),
+            "sparse_lu_ordering": "COLAMD (scipy's default; MMD_AT_PLUS_A measured 12x slower on this operator: profiles/r05_cpu_superlu_orderings.txt)",
             "solve_flag": st["flag"], "line_search_evals": st["ls"],
             "assembly_s_by_threads": {str(k): v for k, v in sweep.items()},
             "what": f"measured per iteration, scaled: ONE complete Newton iteration of the oracle on the bench scene and state (energy + assembly on {best} OpenMP threads of "
-                    f"{ncpu} host cpus, best of the thread sweep: {sweep[best]:.3f} s; the linear solve by scipy's SuperLU like the reference's spsolve, single-threaded, column ordering {order} "
-                    f"(the faster of COLAMD / MMD_AT_PLUS_A): {po.direct_seconds[0]:.1f} s; {st['ls']} line-search evaluations) = {t_newton:.1f} s, times the {n_it} Newton iterations + adjoint solves of the GPU run's "
+                    f"{ncpu} host cpus, best of the thread sweep: {sweep[best]:.3f} s; the linear solve by scipy's SuperLU like the reference's spsolve, single-threaded, column ordering {order}: "
+                    f"{po.direct_seconds[0]:.1f} s; {st['ls']} line-search evaluations) = {t_newton:.1f} s, times the {n_it} Newton iterations + adjoint solves of the GPU run's "
                     f"{K} steps, plus 2 x {K} contact detections of {t_contact:.3f} s"}
         out["value"] = out["bench_size"]["value"]; out["cores"] = best
         out["sample"] = out["bench_size"]["what"] + (" || " + out["complete_steps_small_scene"]["sample"] if "complete_steps_small_scene" in out else "")
