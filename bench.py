@@ -573,10 +573,10 @@ def main():
         rf["whole_step"] = step   # SURVEY section 8d's bytes model and the factorisation-flops figure of the WHOLE step, inside the object the driver keeps
         out["roofline"] = rf
     if args.scenes_per_gpu > 1 and rank == 0 and world == 1:
-        # the multi-scene leg runs in a child process of its own (more hardware queues: an environment variable the HIP runtime reads at start-up)
+        # the multi-scene leg runs in a child process of its own (a fresh HIP context: this process keeps its scene, plans and arenas for the baseline leg below)
         try:
             ctx.set_param("direct_flow_token", 0)   # the child's scene group takes the device's dataflow token while this process waits
-            env = dict(os.environ, GPU_MAX_HW_QUEUES=os.environ.get("TSL_MULTI_HW_QUEUES", "16"))
+            env = dict(os.environ)   # (more hardware queues than the runtime's default were measured SLOWER for a group: 461 against 430 ms per lock step at S = 2, 1168 against 855 at S = 4)
             cmd = [sys.executable, os.path.abspath(__file__), "--multi-only", str(args.scenes_per_gpu), "--single-value", repr(value / world), "--steps", str(K), "--warmup", str(W),
                    "--workload", args.workload, "--grid", str(args.grid), "--idle", str(args.idle), "--cg-tol", repr(args.cg_tol)] + [x for kv in args.param for x in ("--param", kv)]
             r = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=1800)

@@ -15,7 +15,7 @@ trace)
   rocprofv3 --kernel-trace --stats --output-format csv -d gpurun_out/prof -o ${TAG}_bench -- python bench.py --workload $WL --steps 20 --warmup 5 --no-cpu-baseline > gpurun_out/prof/${TAG}_bench_stdout.log 2>&1
   tail -1 gpurun_out/prof/${TAG}_bench_stdout.log | cut -c1-300
   F=$(find gpurun_out/prof -name "${TAG}_bench_kernel_trace.csv" | head -1)
-  python scripts/trace_timeline.py $F -20 full > gpurun_out/prof/${TAG}_iteration_timeline.txt 2>&1
+  python scripts/trace_timeline.py $F -200 full > gpurun_out/prof/${TAG}_iteration_timeline.txt 2>&1
   python scripts/trace_gaps.py $F > gpurun_out/prof/${TAG}_gap_table.txt 2>&1
   rm -f $F
   head -14 gpurun_out/prof/${TAG}_iteration_timeline.txt ;;
@@ -52,6 +52,12 @@ import json
 d = json.loads(open('gpurun_out/prof/${TAG}_multi_$S.json').read().strip().splitlines()[-1]); m = d.get('multi_scene', {})
 print('S=$S single', d['value'], d['ms_per_step'], '| group', m.get('value'), m.get('speedup_vs_single_scene'), m.get('solves_unconverged'), m.get('error'))"
   done
+  rocprofv3 --kernel-trace --output-format csv -d gpurun_out/prof -o ${TAG}_tl -- python bench.py --workload $WL --steps 6 --warmup 2 --no-cpu-baseline > /dev/null 2>&1
+  F=$(find gpurun_out/prof -name "${TAG}_tl_kernel_trace.csv" | head -1)
+  python scripts/trace_timeline.py $F -120 full > gpurun_out/prof/${TAG}_iteration_timeline.txt 2>&1
+  python scripts/trace_gaps.py $F > gpurun_out/prof/${TAG}_gap_table.txt 2>&1
+  rm -f $F
+  head -3 gpurun_out/prof/${TAG}_iteration_timeline.txt
   python scripts/probe_flow_chain.py > gpurun_out/prof/${TAG}_root_chain_trace.txt 2>&1
   tail -3 gpurun_out/prof/${TAG}_root_chain_trace.txt | cut -c1-120 ;;
 esac

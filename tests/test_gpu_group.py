@@ -116,3 +116,52 @@ def test_group_of_one_and_regrouping():
     G2.close()
     _drive(a, 5); a.time_step(projection_query, 5)     # ... and step alone again
     assert np.isfinite(a.pos.to_numpy()).all()
+
+
+def test_group_steps_after_a_reverse_sweep_use_cached_plans_correctly():
+    """the reverse sweep revisits the constraint sets of the forward rollout, so the members' plans come back from their plan caches; the next
+    group step merges such plans (round 5: a cached plan came back without its host block lists and the merge produced NaN factors, hidden by the
+    members' own fallback).  Forward, reverse sweep, forward again -- grouped against one after the other, bit for bit, and no member may leave
+    the merged solve more than a few times"""
+    from thinshelllab_amd.engine.analytic_grad_single import Grad
+    from thinshelllab_amd.engine.geometry import projection_query
+    from thinshelllab_amd.scene_group import SceneGroup
+    res = {}
+    for grouped in (False, True):
+        scenes = [_make("balancing", 48, 1.0), _make("balancing", 48, 1.3)]
+        T = 4
+        grads = []
+        for s in scenes:
+            g = Grad(s, T, s.gripper.n_part); g.init_mass(s); g.copy_pos(s, 0); grads.append(g)
+        G = SceneGroup(scenes) if grouped else None
+
+        def forward(f0, f1):
+            for f in range(f0, f1):
+                for s in scenes:
+                    _drive(s, f)
+                if grouped:
+                    G.time_step(projection_query, f)
+                else:
+                    for s in scenes:
+                        s.time_step(projection_query, f)
+                for s, g in zip(scenes, grads):
+                    if f < T:
+                        g.copy_pos(s, f)
+        forward(1, T)
+        end = [s.pos.to_numpy().copy() for s in scenes]
+        for s, g in zip(scenes, grads):
+            g.get_loss_balance(s)
+            for k in range(T - 1, 0, -1):
+                g.transfer_grad(k, s, projection_query)
+        for s, x in zip(scenes, end):      # back to the end of the rollout, then on
+            s.pos.from_numpy(x); s.prev_pos.from_numpy(x)
+        forward(T, T + 2)
+        res[grouped] = [s.pos.to_numpy().copy() for s in scenes] + [g.pos_grad.to_numpy().copy() for g in grads]
+        if grouped:
+            info = G.info()
+            assert info["member_solves_on_own_path"] <= 6, info
+            G.close()
+        del scenes, grads
+        gc.collect()
+    for a, b in zip(res[False], res[True]):
+        assert np.isfinite(a).all() and np.array_equal(a, b), np.abs(a - b).max()

@@ -94,7 +94,7 @@ struct tsl_group {
   bool merged_valid = false;
   std::vector<hipEvent_t> ev_m;  // member stream -> group stream
   hipEvent_t ev_g = nullptr;     // group stream -> member streams
-  long n_merge = 0, n_relayout = 0;
+  long n_merge = 0, n_relayout = 0, n_own_path = 0;
   double t_merge = 0;
   std::unique_ptr<GroupPool> pool;
 };
@@ -356,7 +356,7 @@ static int group_create(tsl_ctx* const* ctxs, int n, tsl_group** out) {
   HIP_OK(hipEventCreateWithFlags(&G->ev_g, hipEventDisableTiming));
   G->ev_m.resize(n);
   for (int i = 0; i < n; i++) HIP_OK(hipEventCreateWithFlags(&G->ev_m[i], hipEventDisableTiming));
-  for (int i = 0; i < n; i++) { ctxs[i]->group = G.get(); ctxs[i]->ds.token_lender = &gd; ds_flow_token_release(ctxs[i]->ds); }
+  for (int i = 0; i < n; i++) { ctxs[i]->group = G.get(); ctxs[i]->ds.token_lender = &gd; ctxs[i]->ds.keep_host_maps = true; ds_flow_token_release(ctxs[i]->ds); }
   G->pool.reset(new GroupPool());
   if (n > 1 && !getenv("TSL_GROUP_NO_THREADS")) G->pool->start(n, dev);
   *out = G.release();
@@ -379,7 +379,7 @@ static void group_destroy(tsl_group* G) {
     d.arena.release(); d.sarena.release(); d.garena.release(); d.w.release();
     d.plan_valid = false; d.numeric_valid = false; d.have_factor = false; d.cons_checked = false; d.prezero_pending = false;
     for (auto& sl : d.cache) sl->used = false;
-    d.token_lender = nullptr;
+    d.token_lender = nullptr; d.keep_host_maps = false;
     c->group = nullptr;
   }
   if (G->g) {

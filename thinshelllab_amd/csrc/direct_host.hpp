@@ -244,7 +244,9 @@ static void ds_swap_slot(DirectSolver& d, DsPlanSlot& sl) {
   std::swap(d.plan, sl.plan); d.h_cons.swap(sl.h_cons); d.h_cset.swap(sl.h_cset);
   // the build's scratch stays with the ACTIVE plan (host block maps, child tables, per-thread lists, the static mirror table: 15 MB that only
   // the build and the upload right after it read -- a parked plan does not carry them, a new build does not allocate and fault them in again)
-  d.plan.blk_dst.swap(sl.plan.blk_dst); d.plan.blk_ld.swap(sl.plan.blk_ld); d.plan.blk_q.swap(sl.plan.blk_q); d.plan.pmap.swap(sl.plan.pmap);
+  // (a member of a scene group keeps the maps WITH their plan: the group's merge reads the block lists and child tables of the active plan on the host --
+  // a plan that came back from the cache without them merged garbage: NaN factors for every member in the one step of a rollout whose constraint set repeated)
+  if (!d.keep_host_maps) { d.plan.blk_dst.swap(sl.plan.blk_dst); d.plan.blk_ld.swap(sl.plan.blk_ld); d.plan.blk_q.swap(sl.plan.blk_q); d.plan.pmap.swap(sl.plan.pmap); }
   d.plan.lists.swap(sl.plan.lists); d.plan.locs.swap(sl.plan.locs); d.plan.tpos.swap(sl.plan.tpos);
   d.level_sn.swap(sl.level_sn); d.pmap.swap(sl.pmap); d.ch_rec.swap(sl.ch_rec); d.vtx.swap(sl.vtx); d.blk_ld.swap(sl.blk_ld); 
   d.wl_front.swap(sl.wl_front); d.wl_row.swap(sl.wl_row); d.blk_dst.swap(sl.blk_dst); d.fr.swap(sl.fr); d.frl.swap(sl.frl); d.blk_q.swap(sl.blk_q); d.cgr_ptr.swap(sl.cgr_ptr); d.cgr_ent.swap(sl.cgr_ent); d.cgr_ld.swap(sl.cgr_ld); d.cgr_dst.swap(sl.cgr_dst);

@@ -179,6 +179,7 @@ struct DirectSolver {
   DevBuf<double> arena, sarena, garena, scr, w;   // panel arena (cleared per factorisation), Schur arena (never cleared), G arena
   long n_plans = 0, n_factor = 0, n_apply = 0, n_perturbed = 0;
   long plan_gen = 0;          // counts every change of the device arrays of the active plan (new plan, cached plan swapped in, contact map redone): a scene group re-merges on it
+  bool keep_host_maps = false;   // member of a scene group: parked plans keep their host block lists / child tables (ds_swap_slot)
   bool merged = false;        // the solver of a scene group's pseudo-context: its plan is the merge of the members' plans (direct_group.hpp), direct_plan does nothing
   DirectSolver* token_lender = nullptr;   // member of a scene group: the group's solver, whose dataflow token the member may use (the host runs them in lock step)
   double t_plan = 0;          // host seconds spent in plan builds

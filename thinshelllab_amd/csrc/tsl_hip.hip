@@ -2278,10 +2278,11 @@ extern "C" int tsl_group_create(tsl_ctx* const* ctxs, int32_t n, tsl_group** out
   return 0;
 }
 extern "C" void tsl_group_destroy(tsl_group* G) { if (G) group_unregister_and_destroy(G); }
-// {merges of the members' plans, re-layouts of the group's arenas, host seconds in merges, bytes of the group's arenas, factorisations and applications of the merged plan}
-extern "C" int tsl_group_info(tsl_group* G, double* out6) {
+// {merges of the members' plans, re-layouts of the group's arenas, host seconds in merges, bytes of the group's arenas, factorisations and applications of the merged plan,
+// solves in which a member went on from the merged first pass on its own path}
+extern "C" int tsl_group_info(tsl_group* G, double* out6) {   // (seven values)
   out6[0] = (double)G->n_merge; out6[1] = (double)G->n_relayout; out6[2] = G->t_merge; out6[3] = 8.0 * (double)(G->arena.n + G->sarena.n + G->garena.n + G->w.n);
-  out6[4] = (double)G->g->ds.n_factor; out6[5] = (double)G->g->ds.n_apply;
+  out6[4] = (double)G->g->ds.n_factor; out6[5] = (double)G->g->ds.n_apply; out6[6] = (double)G->n_own_path;
   return 0;
 }
 
@@ -2350,12 +2351,7 @@ extern "C" int tsl_group_step(tsl_group* G, double* const* pos_a, double* const*
     TSL_TRY(direct_apply(g, G->vb.p, G->vx.p));
     HIP_OK(hipEventRecord(G->ev_g, g->stream));
     lap(3);
-    TSL_TRY(direct_prezero(g));   // the leaf panels of the next factorisation are cleared next to the residuals and the line search
-    for (int i = 0; i < n; i++) {
-      tsl_ctx* c = G->m[i];
-      HIP_OK(hipStreamWaitEvent(c->stream, G->ev_g, 0));
-      c->ds.numeric_valid = false; c->ds.have_factor = false;   // (the member's own path refactorises if it is needed: the panels are being cleared)
-    }
+    for (int i = 0; i < n; i++) HIP_OK(hipStreamWaitEvent(G->m[i]->stream, G->ev_g, 0));
     // ---- per member: residual of the merged first pass and the stop rule of direct_refine
     std::vector<tsl_solve_stats> ss(n);
     for (int i : act) {
@@ -2393,19 +2389,25 @@ extern "C" int tsl_group_step(tsl_group* G, double* const* pos_a, double* const*
           }
         }
       }
-      if (!ok) {   // the member's own path from scratch (refactorisation, refinement, GMRES, the hierarchy): rare
-        HIP_OK(hipStreamWaitEvent(c->stream, g->ds.ev_zero ? g->ds.ev_zero : G->ev_g, 0));   // (its leaf panels are being cleared by the group)
-        if (g->ds.prezero_pending) {   // ... and will be written by the member's own factorisation: the next merged factorisation clears every member's leaf panels itself, behind the pending clear
-          HIP_OK(hipStreamWaitEvent(g->stream, g->ds.ev_zero, 0));
-          g->ds.prezero_pending = false;
-        }
-        TSL_TRY(solve_perm(c, &s1));
-        if (c->verbose) fprintf(stderr, "[tsl] scene group: member %d left the merged solve (rel_residual of the merged pass %.2e): own path, flag %d after %d applications\n", i, sqrt(rr / std::max(bb, 1e-300)), s1.flag, s1.iters);
+      if (!ok) {
+        // The merged factorisation IS the member's factorisation (its own plan addresses the same memory in the same layout): the member goes on
+        // from the merged first pass on its own path -- refinement with its own sweeps, flexible GMRES and the hierarchy behind it (solve_perm) if that
+        // does not settle.  (The group's clear of the leaf panels is issued after these, below.)
+        d.numeric_valid = true; d.have_factor = true;
+        tsl_solve_stats s2;
+        memset(&s2, 0, sizeof(s2));
+        TSL_TRY(direct_refine(c, &s2, true));
+        if (s2.flag == 1) { s1 = s2; s1.flag = 0; s1.method = 4; }
+        else TSL_TRY(solve_perm(c, &s1));
+        G->n_own_path++;
+        if (c->verbose >= 2) fprintf(stderr, "[tsl] scene group: member %d went on from the merged pass (rel_residual %.2e) on its own path: flag %d after %d applications\n", i, sqrt(rr / std::max(bb, 1e-300)), s1.flag, s1.iters);
       }
       tsl_step_stats& t = st[i];
       t.cg_iters += s1.iters; t.solves++; t.restarts += s1.restarts; t.fallback += (s1.flag == 1); t.unconverged += (s1.flag == 3); t.attained += s1.attained;
       t.max_rel_residual = std::max(t.max_rel_residual, s1.rel_residual); t.max_backward_error = std::max(t.max_backward_error, s1.backward_error);
     }
+    for (int i = 0; i < n; i++) { tsl_ctx* c = G->m[i]; c->ds.numeric_valid = false; c->ds.have_factor = false; HIP_OK(hipEventRecord(G->ev_m[i], c->stream)); HIP_OK(hipStreamWaitEvent(g->stream, G->ev_m[i], 0)); }
+    TSL_TRY(direct_prezero(g));   // the factors are dead: the leaf panels of the next factorisation are cleared next to the line search and the next assembly
     lap(4);
     // ---- direction, line search: all trials of a round are issued, then read
     for (int i : act) {

@@ -69,7 +69,7 @@ class SceneGroup:
         return out
 
     def info(self):
-        v = (C.c_double * 6)()
+        v = (C.c_double * 7)()
         check(self.L.tsl_group_info(self.h, v), "tsl_group_info")
-        keys = ("plan_merges", "arena_relayouts", "merge_seconds", "arena_bytes", "merged_factorizations", "merged_applications")
+        keys = ("plan_merges", "arena_relayouts", "merge_seconds", "arena_bytes", "merged_factorizations", "merged_applications", "member_solves_on_own_path")
         return dict(zip(keys, [float(x) for x in v]))
