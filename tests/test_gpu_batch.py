@@ -28,6 +28,23 @@ def test_trajopt_batch_folding_one_rank(tmp_path):
     assert np.load(tmp_path / "best_gripper_grad.npy").shape == (4, 1, 6)
 
 
+def test_trajopt_batch_grouped_scenes_of_a_rank_match_ungrouped(tmp_path):
+    """more scenes than GPUs (BASELINE configs[4] on fewer GPUs): with --group 1 the scenes of a rank step in lock step as ONE scene group
+    (merged sparse factorisations, thinshelllab_amd/scene_group.py); rewards and optimised trajectories of two iterations must equal the
+    round-robin run bit for bit"""
+    outs = []
+    for k, grp in enumerate(("0", "1")):
+        out = tmp_path / f"g{grp}"
+        r = _launch(["-m", "thinshelllab_amd.training.trajopt_batch", "--env", "balancing", "--scenes", "3", "--iter", "2", "--tot_step", "4", "--cloth_N", "48", "--group", grp,
+                     "--out", str(out)], 29651 + 2 * k)
+        assert r.returncode == 0, r.stderr[-3000:]
+        outs.append((np.load(out / "plot_data.npy"), [np.load(out / f"traj_scene{s}.npy") for s in range(3)]))
+    assert outs[0][0].shape == (3, 2) and np.isfinite(outs[0][0]).all()
+    assert np.array_equal(outs[0][0], outs[1][0]), (outs[0][0], outs[1][0])
+    for a, b in zip(outs[0][1], outs[1][1]):
+        assert np.array_equal(a, b)
+
+
 def test_bench_under_launcher_reports_world():
     r = _launch([os.path.join(ROOT, "bench.py"), "--gpus", "1", "--steps", "2", "--warmup", "1", "--grid", "48", "--no-cpu-baseline"], 29643)
     assert r.returncode == 0, r.stderr[-3000:]

@@ -260,6 +260,21 @@ assert all(len(v) == 4 for v in hist2.values())
 assert np.isnan(hist2[1][1]) and np.isfinite([hist2[1][0], hist2[1][2], hist2[1][3]]).all(), hist2[1]
 assert np.isfinite(hist2[0]).all() and np.isfinite(hist2[2]).all()
 assert hist2[1][2] > hist2[1][0]
+# the scenes of a rank rolled out TOGETHER (rollout_many: a scene group on the GPU): rank 0 holds scenes 0 and 2, rank 1 scene 1 -- same history as one
+# after the other; a grouped rollout that raises costs its rank's scenes one iteration, nobody stalls
+calls = []
+def many(ps):
+    calls.append(len(ps))
+    if len(calls) == 2:
+        raise RuntimeError("tsl_group_step failed")
+    return [p.rollout() for p in ps]
+hist3, _ = run_batch(b, 3, 4, Quad, out_dir=None, log=lambda *a: None, rollout_many=many)
+if b.rank == 0:
+    assert calls == [2, 2, 2, 2], calls
+    assert np.isnan(hist3[0][1]) and np.isnan(hist3[2][1]) and np.isfinite(hist3[1]).all(), hist3
+else:
+    assert calls == [], calls      # one scene on this rank: its own rollout
+assert abs(hist3[0][0] - hist[0][0]) < 1e-15 and abs(hist3[1][3] - hist[1][3]) < 1e-15
 b.barrier()
 if b.rank == 0:
     assert np.load(os.path.join(out, "plot_data.npy")).shape == (3, 6)

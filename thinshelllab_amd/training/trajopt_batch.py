@@ -17,12 +17,14 @@ import numpy as np
 import torch
 
 
-def run_batch(batch, n_scenes, iters, make_problem, out_dir=None, log=print):
+def run_batch(batch, n_scenes, iters, make_problem, out_dir=None, log=print, rollout_many=None):
     """Generic driver.  ``make_problem(scene_id)`` returns an object with
          traj: torch tensor (T, n_part, 6), updated in place by ``step(grad)``;
          rollout() -> (reward: float, gripper_grad: tensor (T, n_part, 6))   -- forward rollout + reverse sweep of one scene;
          step(gripper_grad)                                                  -- optimiser update (+ action limits).
     Scene s runs on rank s % world (``batch.scene_ids``); after every iteration all ranks hold the rewards of the whole batch.
+    ``rollout_many(list of problems) -> list of (reward, gripper_grad)``, if given, rolls out ALL scenes of this rank together (a scene group:
+    lock-step forward steps with merged factorisations, ``rollout_scene_group``) instead of one after the other.
     Returns {scene: [reward per iteration]} (identical on every rank) and the best (reward, scene, iteration)."""
     local = batch.scene_ids(n_scenes)
     slots = (n_scenes + batch.world - 1) // batch.world
@@ -38,10 +40,20 @@ def run_batch(batch, n_scenes, iters, make_problem, out_dir=None, log=print):
         shape = tuple(int(v) for v in t.tolist())
     for it in range(iters):
         t0 = time.time()
+        together = None
+        if rollout_many is not None and len(local) > 1:
+            try:
+                together = dict(zip(local, rollout_many([problems[s] for s in local])))
+            except Exception as e:  # noqa: BLE001 -- as below: the other ranks wait in the gathers
+                log(f"rank {batch.rank} iter {it}: grouped rollout failed ({e!r}); its scenes are reported as NaN, no update")
+                together = {s: (float("nan"), torch.zeros(shape, dtype=torch.float64)) for s in local}
         for slot in range(slots):
             s = slot * batch.world + batch.rank
             ok = False
-            if s in problems:
+            if s in problems and together is not None:
+                reward, g = together[s]
+                ok = bool(np.isfinite(reward))
+            elif s in problems:
                 # a rollout that fails (an unconverged adjoint solve, a constraint overflow) must not take the job down: the other
                 # ranks would wait in the gather below.  The scene reports NaN for this iteration and skips its update.
                 try:
@@ -117,16 +129,22 @@ class SceneProblem:
             self.agent.fix_action(0.015)
         self.traj = self.agent.traj.t
 
-    def rollout(self):
-        s, g, T = self.sys, self.grad, self.T
+    def begin(self):
+        s, g = self.sys, self.grad
         s.reset()
         s.mu_cloth_elastic[None] = self.mu
         g.copy_pos(s, 0)
-        for frame in range(1, T):
-            self.agent.get_action(frame)
-            s.action(frame, self.agent.delta_pos, self.agent.delta_rot)
-            s.time_step(self.contact, frame)
-            g.copy_pos(s, frame)
+
+    def pre_step(self, frame):
+        self.agent.get_action(frame)
+        self.sys.action(frame, self.agent.delta_pos, self.agent.delta_rot)
+
+    def post_step(self, frame):
+        self.grad.copy_pos(self.sys, frame)
+
+    def finish(self):
+        """reward, loss seed, reverse sweep (trajopt_folding.py:100-135)"""
+        s, g, T = self.sys, self.grad, self.T
         if self.env == "folding":
             reward = s.compute_reward(1.0, -1.0)
             g.get_loss_fold(s, 1.0, -1.0, rows=s.fold_rows())
@@ -147,11 +165,43 @@ class SceneProblem:
             g.apply_action_limit_grad(self.agent, 0.015)
         return float(reward), g.gripper_grad.t.clone()
 
+    def rollout(self):
+        self.begin()
+        for frame in range(1, self.T):
+            self.pre_step(frame)
+            self.sys.time_step(self.contact, frame)
+            self.post_step(frame)
+        return self.finish()
+
     def step(self, gripper_grad):
         self.adam.step(self.agent.traj, self.grad.gripper_grad)
         if self.fix:
             self.agent.fix_action(0.015)
         self.grad.reset()
+
+
+_GROUPS = {}
+
+
+def rollout_scene_group(problems):
+    """the scenes of one rank rolled out together: every frame's time steps as ONE SceneGroup.time_step (thinshelllab_amd/scene_group.py: lock step,
+    merged factorisations, each scene bit-identical to its own time_step), reward / seed / reverse sweep per scene"""
+    from ..scene_group import SceneGroup
+    key = tuple(id(p) for p in problems)
+    if key not in _GROUPS:
+        for p in problems:
+            p.sys._ensure_ctx().set_param("direct", 1)     # a group shares the sparse direct solves of its members
+        _GROUPS[key] = SceneGroup([p.sys for p in problems])
+    group = _GROUPS[key]
+    for p in problems:
+        p.begin()
+    for frame in range(1, problems[0].T):
+        for p in problems:
+            p.pre_step(frame)
+        group.time_step(problems[0].contact, frame)
+        for p in problems:
+            p.post_step(frame)
+    return [p.finish() for p in problems]
 
 
 def main(argv=None):
@@ -164,6 +214,8 @@ def main(argv=None):
     ap.add_argument("--init_sigma", type=float, default=1e-4)
     ap.add_argument("--cloth_N", type=int, default=0, help="refined cloth grid (0: the task's native grid)")
     ap.add_argument("--out", type=str, default=None)
+    ap.add_argument("--group", type=int, default=0, help="1: the scenes of a rank step in lock step as one scene group (more scenes than GPUs; needs --cloth_N large enough "
+                                                         "for the sparse direct solve or forces it)")
     args = ap.parse_args(argv)
     from ..batch import Batch
     batch = Batch()
@@ -174,7 +226,11 @@ def main(argv=None):
         os.makedirs(out_dir, exist_ok=True)
     batch.barrier()
     history, best = run_batch(batch, n_scenes, args.iter,
-                              lambda s: SceneProblem(args.env, s, args.tot_step, args.lr, dev, args.init_sigma, args.cloth_N or None), out_dir=out_dir)
+                              lambda s: SceneProblem(args.env, s, args.tot_step, args.lr, dev, args.init_sigma, args.cloth_N or None), out_dir=out_dir,
+                              rollout_many=rollout_scene_group if args.group else None)
+    for g in _GROUPS.values():
+        g.close()
+    _GROUPS.clear()
     batch.close()
     return history, best
 
