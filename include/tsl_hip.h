@@ -102,50 +102,34 @@ int tsl_ctx_create(const tsl_scene_desc* desc, tsl_ctx** out);
 void tsl_ctx_destroy(tsl_ctx* ctx);
 int tsl_set_stream(tsl_ctx* ctx, void* hip_stream);
 
-/* 0-d field writes: "cloth<i>.Kb|Kl|Ka|k_angle", "elastic<i>.mu|lam|alpha", "mu_cloth_elastic", "mu_cloth_cloth", "k_contact", "eps_contact", "damping",
- * "newton_cap", "plastic", "contact" (trajopt_folding.py:50,66; Scene_folding.py:30-31), the broad-phase box
- * "grid_h", "grid_extent" (geometry.py:8-19), "self_contact<body>" (0 / 1: the body's vertices are also projected onto its own
- * triangles, geometry_self.project_pair_self, geometry_self.py:166-230), and the solver knobs that have no reference counterpart (the reference
- * calls a direct solver): "cg_tol", "cg_maxit", "cg_check", "mg" (-1 auto / 0 / 1), "mg_nu", "mg_coarse_sweeps",
- * "mg_omega", "mg_pi_iters", "mg_fuse", "mg_max_levels", "mg_coarse_exact" (dense inverse of the last multigrid level),
- * "mg_dense_nodes" (largest level solved exactly; -1 = chosen per time step, default), "mg_coarse_lag", "warm_start", "pcg_ahead", "body_inv"
- * "direct" (-1 auto / 0 / 1: multifrontal LU of the operator as preconditioner; auto = cloth grids of >= 1024 cells, after a probe of
- * the iterative hierarchy capped at "direct_probe_cap" iterations failed -- re-probed every "direct_probe_every" time steps),
- * "direct_leaf" (vertices per nested-dissection leaf, default 64), "direct_lag" (Newton iterations of a time step reuse earlier factors while the
- * refinement converges within this many iterations; 0 = refactorise for every solve), "direct_fallback_cap" (a refined factorisation
- * that stalls within 1e-3 of the right-hand side is returned flagged not converged; above that the hierarchy gets this many iterations),
- * "direct_piv_tol" (static pivoting: pivots below this fraction of their entry diagonal are perturbed to it, default 1e-11),
- * "direct_prezero" (1: the front arena of the next factorisation is cleared on a side stream after each solve of a time step),
- * "direct_gemm_wpc" (4 / 3 / 2: workgroups per CU the factorisation GEMMs are compiled for; 3 prefetches the F22 tile, 2 double-buffers the LDS slabs
- * -- one barrier per slab, measured slower --, default 4),
- * "direct_par_batches" (1: batches of one elimination level on parallel streams), "direct_merge_k" (1: constrained body vertices share the
- * supernode of their separator), "direct_merge_sep" (separators of at most this many vertices join the enclosing separator's supernode; 16, 0 = off),
- * "direct_refine" (1: plain iterative refinement with the factors, GMRES only where it stalls; 0: flexible GMRES from the start),
- * "direct_plan_cache" (plans of earlier constraint sets kept, default 64; the reverse sweep finds the forward rollout's plans there),
- * "direct_flow" (3; bit 0: the block steps of ONE batch per tree level, of at most 64 fronts and small enough to be resident as a
- * whole, run as ONE persistent dataflow launch -- k_ds_gj_flow: every workgroup keeps its tile in registers, steps ordered by
- * point-to-point flags; bit 1: also the batches the LDS kernel would take; 0: one launch per 32 pivots everywhere),
- * "direct_g32_below" (1100: G = W F12 of a batch with fewer 64 x 64 tiles than this uses 32 x 32 tiles -- the upper levels, where the large tiles leave
- * one to three workgroups per CU; 0 = never),
- * "direct_gemv_wide_below" (300: a sweep launch of fewer 16-row chunks than this -- the upper levels -- runs four workgroups per chunk, 4 rows each, the waves
- * a quarter of the columns each; 0 = never),
- * "direct_s32_below" (0: the same for the Schur complements -- measured slower on the leaf levels), "direct_small_rounds" (2: rounds of the chip a batch may
- * take in the LDS kernel k_ds_inv_small), "direct_plan_cache_mb" (1024: bound of the parked plans in MB),
- * "direct_xcd" (64: batches of at least this many fronts launch their GEMM tiles with the XCD-aware map k_ds_gemm_x -- a front per XCD; 0 = never),
- * "direct_split" (3; bit 0: fronts that fit the LDS kernel leave a batch of much larger ones, bit 1: a few fronts that would cost the LDS kernel one
- * more round of the chip get a batch of their own),
- * "deterministic" (1: element gradients / blocks and contact rows go to staging slots and records and are summed by gather kernels in a fixed
- * order, constraint lists are compacted by scan, energies and dot products joined from per-workgroup partials -- no f64 atomics on the step and
- * adjoint path, two runs give the same bits; 0: scattered atomics), "asm_early" (1: launches of the deterministic assembly issued in priority
- * order, the long kernel of each of the three streams first), "tet_warm" (1: the eigen-clamp of the element blocks starts
- * from the eigenvectors of the element's previous assembly), "cloth_gather" (0; with "deterministic" 0: cloth Hessian gathered per matrix block from
- * element records instead of scattered atomics),
- * "tet_coop" (1: 16 lanes per tetrahedron in the element Hessians), "ds_dbg" / "ds_bench_batch" (timing experiments of tsl_bench_direct),
- * "mg_fuse_restrict" (first sweep + residual + restriction of a stencil level in one launch), "mg_st_f32" (single-precision stencil
- * operators), "mg_fr_rows", "pcg_body_fold" (dense-body first sweep inside the PCG update launch), "asm_overlap" (contact blocks on a
- * second stream), "mr_eta" (stop factor of a MINRES recurrence cycle), "mg_chunk" (multigrid-PCG iterations per graph replay; 0 = 8 on long solves, else 4),
- * (-1 auto / 0 / 1), "adj_spd_pc", "fwd_spd_pc", "minres", "gmres", "gmres_m", "graph", "verbose"; "adj_clamp", "adj_clamp_angleref" select the clamping of analytic_grad_single (1000, on) or
- * analytic_grad_system (1, off). */
+/* 0-d field writes of the reference and the engine's own switches (39 keys + three patterns; an unknown key is an error).
+ *  Scene (trajopt_folding.py:50,66; Scene_folding.py:30-31; geometry.py:8-19; geometry_self.py:166-230):
+ *   "cloth<i>.Kb|Kl|Ka|k_angle", "elastic<i>.mu|lam|alpha", "mu_cloth_elastic", "mu_cloth_cloth", "k_contact", "eps_contact", "eps_v", "damping",
+ *   "newton_cap", "plastic", "contact" (0: no detection in tsl_step), "grid_h", "grid_extent" (broad-phase cell and box), "self_contact<body>"
+ *   (0 / 1: the body's vertices are also projected onto its own triangles), "adj_clamp", "adj_clamp_angleref" (the clamping of analytic_grad_single:
+ *   1000, on; of analytic_grad_system: 1, off), "adj_spd_pc" (adjoint solves of the iterative hierarchy preconditioned from the projected assembly).
+ *  Linear solve (no reference counterpart: the reference calls cupyx spsolve):
+ *   "cg_tol" (1e-10), "cg_maxit", "direct" (-1 auto: cloth grids of >= 1024 cells / 0 iterative hierarchy only / 1 always: multifrontal LU on the GPU),
+ *   "direct_leaf" (vertices per nested-dissection leaf, 64), "direct_piv_tol" (static pivoting: pivots below this fraction of their entry diagonal are
+ *   perturbed to it, 1e-11), "direct_berr" (1e-12: a first pass of the factorised solve whose normwise backward error |b - Hx| / (|H|_inf |x| + |b|) is
+ *   at most this is accepted; 0: every solve is refined to cg_tol), "direct_berr_rel_cap" (50: ... and whose forward residual is at most this x cg_tol),
+ *   "direct_flow" (3; bit 0: the block steps of one batch per tree level as ONE persistent dataflow launch, k_ds_gj_flow; bit 1: also the batches the
+ *   LDS kernel would take; 0: one launch per 32 pivots -- the same bits either way), "direct_flow_token" (0: hand the device's dataflow token back),
+ *   "direct_small_rounds" (2: rounds of the chip a batch may take in the LDS kernel k_ds_inv_small), "direct_g32_below" (1100: G = W F12 of a batch
+ *   with fewer 64 x 64 tiles than this uses 32 x 32 tiles), "direct_gemv_wide_below" (300: a sweep launch of fewer 16-row chunks than this runs four
+ *   workgroups per chunk), "direct_xcd" (64: batches of at least this many fronts launch their GEMM tiles with the XCD-aware map), "direct_prezero"
+ *   (1: the leaf panels of the next factorisation are cleared on a side stream after each solve of a time step), "direct_plan_cache" (64: plans of
+ *   earlier constraint sets kept; the reverse sweep finds the forward rollout's plans there),
+ *   "mg" (-1 auto / 0 / 1), "mg_coarse_exact", "mg_dense_nodes" (largest multigrid level solved exactly; -1 = chosen per time step), "body_inv"
+ *   (dense inverses of the small FEM-body blocks), "gmres_m" (GMRES restart length), "tet_warm" (1: the eigen-clamp of the element blocks starts from
+ *   the eigenvectors of the element's previous assembly),
+ *   "deterministic" (1: element gradients / blocks and contact rows go to staging slots and records and are summed by gather kernels in a fixed order,
+ *   constraint lists are compacted by scan, energies and dot products joined from per-workgroup partials -- no f64 atomics on the step and adjoint
+ *   path, two runs give the same bits; 0: the scattered atomics of rounds 1-3).
+ *  Diagnostics: "verbose" (1 phase times per step, 2 plans, 3 batches, 4 Newton iterations, 5 refinement passes), "ds_dbg" (21: force the dataflow-abort
+ *   branch, tests; 30: device-clock trace of a dataflow chain), "ds_bench_batch" (tsl_bench_direct on one batch).
+ * The experiment switches of rounds 1-4 (factor lagging, alternative GEMM / Schur tilings, one-lane contact and 16-lane element assembly, PCG warm
+ * start, ...) are gone with the code they selected; the measurements that retired them are in profiles/README.md and DESIGN.md section 9. */
 int tsl_set_param(tsl_ctx* ctx, const char* key, double value);
 int tsl_set_frozen(tsl_ctx* ctx, const int32_t* frozen_host);          /* BaseScene.set_frozen */
 int tsl_set_ext_force(tsl_ctx* ctx, const double* ext_force_host);      /* BaseScene.ext_force / manipulate_force */

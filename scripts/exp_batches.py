@@ -1,4 +1,5 @@
-"""Probe (not part of the product): per-batch time of the factorisation kernels on the cfg4 plan (tsl_bench_direct with "ds_bench_batch")."""
+"""Probe (not part of the product): per-batch time of the factorisation kernels on the cfg4 plan (tsl_bench_direct with "ds_bench_batch").
+(The timing switches that removed the gather / all but one K slab from the Schur kernel -- profiles/r04c_cfg4_schur_per_batch.txt -- left with round 5's prune.)"""
 import sys, os
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import numpy as np, torch
@@ -34,16 +35,6 @@ for b in range(nb):
         line += f"  {name} {t:8.1f} us ({r['launches']:3d} launches, {tf:5.1f} TF/s)"
         if cls == 1:
             line += f" {r['bytes_per_launch'] * r['launches'] / max(t, 1e-9) * 1e-3:6.0f} GB/s"
-            for dbg, what in ((13, "no gather"), (12, "one K slab")):
-                ctx.set_param("ds_dbg", dbg)
-                r3 = ctx.bench_direct(cls, 10)
-                ctx.set_param("ds_dbg", 0)
-                line += f" [{what} {r3['us_per_launch'] * r3['launches']:7.1f} us]"
     print(line, flush=True)
 ctx.set_param("ds_bench_batch", -1)
-for dbg in (0, 12, 13, 0):
-    ctx.set_param("ds_dbg", dbg)
-    r = ctx.bench_direct(1, 10)
-    print("schur total, ds_dbg", dbg, r["us_per_launch"] * r["launches"], "us")
-ctx.set_param("ds_dbg", 0)
 print("totals us:", tot, "sum", sum(tot.values()))

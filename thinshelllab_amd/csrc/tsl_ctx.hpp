@@ -288,7 +288,7 @@ struct tsl_ctx {
   DevBuf<double> vg_stage2;   // second staging array of the tet slots (tsl_param_grad: the two materials accumulate into different vectors)
   DevBuf<double> dot_part; DevBuf<int> dot_ticket;   // scratch of the deterministic dot products
   DevBuf<double> e_part;                 // per-workgroup partial energies
-  int n_cgblk = 0, n_cgblk_cloth = 0;   // gather lists: blocks of the cloth first, blocks of the FEM bodies behind them   // "cloth_gather" = 1: gather assembly of the cloth Hessian (deterministic; measured no faster than the class-ordered atomics: 268 against 270 us)
+  int n_cgblk = 0, n_cgblk_cloth = 0;   // gather lists: blocks of the cloth first, blocks of the FEM bodies behind them
   DevBuf<double> tet_V;       // eigenvector bases of the clamped element blocks of the last assembly (81 x n_tet, entry-major): warm start of the next one
   long tet_V_count = 0;
   int tet_warm = 1;

@@ -350,7 +350,7 @@ extern "C" int tsl_ctx_create(const tsl_scene_desc* d, tsl_ctx** out) {
 #undef UP
   int rc = 0;
   rc |= c->norm_dir.alloc((size_t)std::max(c->n_cface, 1) * 3);
-  // (the element records of the gather assembly -- 81 doubles per face, 65 MB at 100k triangles -- are allocated when "cloth_gather" first runs)
+  // (the element records of the gather assembly -- 81 doubles per face, 65 MB at 100k triangles -- are allocated at the first deterministic assembly)
   rc |= c->quirk.alloc((size_t)std::max(d->n_cloth, 1) * 90);
   rc |= c->dot_part.alloc(64 * 512); rc |= c->dot_ticket.alloc(512);
   if (!rc) (void)hipMemset(c->dot_ticket.p, 0, 512 * sizeof(int));
@@ -1426,9 +1426,6 @@ static int solve_perm(tsl_ctx* c, tsl_solve_stats* st) {
     st->flag = s2.flag == 0 ? 1 : s2.flag;
     return rc;
   }
-  // optional warm start ("warm_start" = 1, off by default): inside a time step the previous Newton iteration's direction (still in
-  // v_x) is the initial guess.  Measured: -4 % iterations on one cfg4 window, none on another, +2 % time on drape (one more product
-  // per solve); its initial residual is usually LARGER than |b|, so a residual test cannot decide when to use it.
   const bool warm = false;   // (a warm start from the previous Newton direction was measured: -4 % iterations on one cfg4 window, none on another, +2 % time on drape; gone)
   if (!warm) HIP_OK(hipMemsetAsync(c->v_x.p, 0, n3 * sizeof(double), s));
   HIP_OK(hipMemsetAsync(c->scal.p, 0, sizeof(SolverScalars), s));
@@ -1490,9 +1487,8 @@ static int solve_perm(tsl_ctx* c, tsl_solve_stats* st) {
     const bool graph = c->use_graph != 0;
     if (graph) TSL_TRY(pcg_chunk_graph(c, chunk));
     int n_chunks = 0;
-    // "pcg_ahead" = 1 keeps one more chunk in flight behind the one whose convergence record the host waits for; after
-    // convergence that extra chunk runs idle kernels (flag set).  Off by default: measured, the time per iteration does not change
-    // (the gaps are between dependent kernels inside the graph, not host round trips) and the idle chunk costs ~0.2 ms per solve.
+    // (a second chunk kept in flight behind the one whose convergence record the host waits for was measured and dropped: the time per iteration
+    // does not change -- the gaps are between dependent kernels inside the graph, not host round trips -- and the idle chunk cost ~0.2 ms per solve.)
     // A chunk whose device-clock stamps are sampled for the profile gets no successor until read.
     int inflight = 0, head = 0;
     bool sampled[2] = {false, false};
