@@ -281,7 +281,7 @@ static int group_merge(tsl_group* G) {
   if (g->verbose >= 3)
     for (const DsBatch& b : M.batches) {
       fprintf(stderr, "[tsl]   merged level %2d: %5d fronts, pivots <= %4d, boundary <= %4d, dataflow workgroups %ld (cap %d)%s; fronts by padded pivot count:", b.level, b.count, b.max_pp, b.max_bp,
-              ds_flow_wgs(M, b), gd.flow_cap[1], ds_use_small(gd, b) ? " (LDS kernel)" : "");
+              ds_flow_wgs(M, b), gd.flow_cap, ds_use_small(gd, b) ? " (LDS kernel)" : "");
       for (int q = 0, run = 0; q < b.count; q++) {
         run++;
         if (q + 1 == b.count || M.fr[M.level_sn[b.first + q + 1]].pp != M.fr[M.level_sn[b.first + q]].pp) { fprintf(stderr, " %d x %d", run, M.fr[M.level_sn[b.first + q]].pp); run = 0; }

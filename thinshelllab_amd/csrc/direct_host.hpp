@@ -114,17 +114,15 @@ static bool ds_flow_eligible(DirectSolver& d, const DirectPlan& P, const DsBatch
     if (hipStreamIsCapturing(s, &cs) != hipSuccess || cs != hipStreamCaptureStatusNone) return false; }
   if (!ds_flow_token_held(d)) return false;   // another context / process launches the persistent kernel on this device
   if (ds_use_small(d, b) && !(d.flow & 2)) return false;   // bit 1: also the batches the LDS kernel would take (64 / 32 fronts of <= 128 pivots on levels 3 and 4 of cfg4)
-  if (d.flow_cap[0] == 0) {
-    int occ2 = 0, occ3 = 0, dev = 0;
+  if (d.flow_cap == 0) {
+    int occ = 0, dev = 0;
     hipDeviceProp_t prop;
     if (hipGetDevice(&dev) != hipSuccess || hipGetDeviceProperties(&prop, dev) != hipSuccess ||
-        hipOccupancyMaxActiveBlocksPerMultiprocessor(&occ2, (const void*)k_ds_gj_flow<DS_FLOW_B, 2>, 256, 0) != hipSuccess ||
-        hipOccupancyMaxActiveBlocksPerMultiprocessor(&occ3, (const void*)k_ds_gj_flow<DS_FLOW_B, 3>, 256, 0) != hipSuccess) { d.flow_cap[0] = d.flow_cap[1] = -1; return false; }
-    d.flow_cap[0] = std::max(1, occ2 * prop.multiProcessorCount);
-    d.flow_cap[1] = std::max(d.flow_cap[0], occ3 * prop.multiProcessorCount);
-    if (getenv("TSL_FLOW_DEBUG")) fprintf(stderr, "[tsl] k_ds_gj_flow: %d / %d workgroups per CU x %d CUs resident\n", occ2, occ3, prop.multiProcessorCount);
+        hipOccupancyMaxActiveBlocksPerMultiprocessor(&occ, (const void*)k_ds_gj_flow<DS_FLOW_B>, 256, 0) != hipSuccess) { d.flow_cap = -1; return false; }
+    d.flow_cap = std::max(1, occ * prop.multiProcessorCount);
+    if (getenv("TSL_FLOW_DEBUG")) fprintf(stderr, "[tsl] k_ds_gj_flow: %d workgroups per CU x %d CUs resident\n", occ, prop.multiProcessorCount);
   }
-  return ds_flow_wgs(P, b) <= d.flow_cap[1];
+  return ds_flow_wgs(P, b) <= d.flow_cap;
 }
 static bool ds_flow_prepare(DirectSolver& d, const DirectPlan& P, const DsBatch& b, bool flow_free, DsFlowArgs& a, hipStream_t s) {   // false = not on this path
   if (!flow_free || !ds_flow_eligible(d, P, b, s)) return false;
@@ -143,7 +141,6 @@ static bool ds_flow_prepare(DirectSolver& d, const DirectPlan& P, const DsBatch&
     if (hipMemsetAsync(d.flow_f.p, 0, d.flow_f.n * sizeof(int), s) != hipSuccess) return false;   // (the epoch keeps counting: zero is below every epoch)
   }
   a.epoch = ++d.flow_epoch;
-  a.wpc = wgs <= d.flow_cap[0] ? 2 : 3;   // (the instantiation with three workgroups per CU spills 58 registers: only where two do not hold the batch)
   return true;
 }
 // The launch must be resident as a whole (its workgroups wait for each other's flags).  Inside ONE context the host guarantees that by
@@ -153,8 +150,7 @@ static bool ds_flow_prepare(DirectSolver& d, const DirectPlan& P, const DsBatch&
 // does not take part in the protocol) runs into DS_FLOW_SPINS, raises bad[DS_FLOW_ABORT], and the solve refactorises on the
 // launch-per-block-step path (solve_perm).
 static void ds_flow_launch(hipStream_t s, const DsDev& D, int lv0, const DsFlowArgs& fa, DirectSolver& d) {
-  if (fa.wpc == 2) hipLaunchKernelGGL((k_ds_gj_flow<DS_FLOW_B, 2>), dim3(fa.tile0[fa.nf]), dim3(256), 0, s, D, lv0, fa, d.flow_x.p, d.flow_f.p);
-  else hipLaunchKernelGGL((k_ds_gj_flow<DS_FLOW_B, 3>), dim3(fa.tile0[fa.nf]), dim3(256), 0, s, D, lv0, fa, d.flow_x.p, d.flow_f.p);
+  hipLaunchKernelGGL(k_ds_gj_flow<DS_FLOW_B>, dim3(fa.tile0[fa.nf]), dim3(256), 0, s, D, lv0, fa, d.flow_x.p, d.flow_f.p);
 }
 
 static bool direct_enabled(tsl_ctx* c) {

@@ -698,7 +698,7 @@ __global__ void __launch_bounds__(256) k_ds_gj_finish(DsDev D, int lv0) {
 #define DS_FLOW_SPINS (1 << 22)
 #define DS_FLOW_B 2
 struct DsFlowArgs {
-  int nf, epoch, wpc;
+  int nf, epoch;
   int tile0[DS_FLOW_MAXF + 1];     // first workgroup of front z of the batch (a front of nt x nt tiles has ceil(nt / B)^2 workgroups)
   int foff[DS_FLOW_MAXF];          // first flag of front z: nt pivot flags (one per 128 B), nt^2 row-panel flags, nt^2 column-panel flags
   long long xoff[DS_FLOW_MAXF];    // first exchange slot of front z (doubles): nt pivot inverses, nt^2 row-panel slots, nt^2 column-panel slots
@@ -732,10 +732,9 @@ TSL_DEV ds_d4 ds_prod32(const double (*Am)[DS_T + 1], const double (*Bm)[DS_T + 
   for (int kk = 0; kk < DS_T / 4; kk++) acc = __builtin_amdgcn_mfma_f64_16x16x4f64(Am[16 * wi + lr][4 * kk + lk], Bm[4 * kk + lk][16 * wj + lr], acc, 0, 0, 0);
   return acc;
 }
-template <int B, int WPC>   // WPC: workgroups per CU the register allocation aims at -- 2 (191 registers, none spilled) or 3 (168 registers, 58 spilled: only for batches
-                            // that are not resident otherwise, e.g. the two 1056-pivot roots of a scene group of two)
-__global__ void __launch_bounds__(256, WPC) k_ds_gj_flow(DsDev D, int lv0, DsFlowArgs a, double* __restrict__ X, int* __restrict__ Fl) {
-  __shared__ double Ps[DS_T][DS_T + 1];      // P[k] of the current step; the next pivot tile is inverted in place here once the step's updates are done
+template <int B>
+__global__ void __launch_bounds__(256, 2) k_ds_gj_flow(DsDev D, int lv0, DsFlowArgs a, double* __restrict__ X, int* __restrict__ Fl) {
+  __shared__ double Pb[2][DS_T][DS_T + 1];   // P[k] of the current step / the inverse being formed for the next one
   __shared__ double Rs[B][DS_T][DS_T + 1];   // per owned column: A[K, j] as it was before the step, then R'_j = P A[K, j]
   __shared__ double Cs[B][DS_T][DS_T + 1];   // per owned row: A[i, K] as it was before the step
   __shared__ int s_dead;
@@ -790,6 +789,8 @@ __global__ void __launch_bounds__(256, WPC) k_ds_gj_flow(DsDev D, int lv0, DsFlo
     const int kn = k + 1, Kn = kn / B, an = kn - B * Kn;
     const bool more = kn < nt;
     const bool rowN = more && I == Kn, colN = more && J == Kn, pivn = rowN && colN;
+    double (*Ps)[DS_T + 1] = Pb[k & 1];
+    double (*Pn)[DS_T + 1] = Pb[kn & 1];
     if (k >= 0) {
       // ---- operands of the step.  Every workgroup of the front passes here once per step, so the memory round trips of this block ARE the
       // step rate of the launch: every flag is polled first (one thread per wave; where the chain has just changed workgroups the panel tiles
@@ -806,7 +807,7 @@ __global__ void __launch_bounds__(256, WPC) k_ds_gj_flow(DsDev D, int lv0, DsFlo
 #pragma unroll
       for (int x = 0; x < B; x++) if (need_c[x] && (int)threadIdx.x == 64 * ((B + x) & 3)) ds_flow_poll(DS_FLOW_CFLAG(B * I + x, k), epoch, abort_w, &s_dead);
       if (fetch_p && threadIdx.x == 32) ds_flow_poll(DS_FLOW_PFLAG(k), epoch, abort_w, &s_dead);
-      __syncthreads();   // (also: every wave is done with Rs / Cs of the previous step)
+      __syncthreads();   // (also: every wave is done with Rs / Cs / Pn of the previous step)
       if (tl && pivn && kn < 64) D.tlog[256 + 8 * kn] = wall_clock64();
       double pr[B][4], pc[B][4], pp[4];
 #pragma unroll
@@ -873,19 +874,22 @@ __global__ void __launch_bounds__(256, WPC) k_ds_gj_flow(DsDev D, int lv0, DsFlo
       }
       __syncthreads();
     }
-    // A[i, j] -= A[i, K] R'_j,  A[i, K] = -A[i, K] P   (i outside the pivot rows)
-    if (k >= 0) {
+    // A[i, j] -= A[i, K] R'_j,  A[i, K] = -A[i, K] P   (i outside the pivot rows), in up to three passes: 0 the next pivot tile, 1 the other
+    // tiles of the next pivot's row and column (published as its panels), 2 the rest
+    auto update = [&](int pass_lo, int pass_hi) {
 #pragma unroll
       for (int x = 0; x < B; x++) {
         if (!va[x] || (rowK && x == ka)) continue;
 #pragma unroll
         for (int y = 0; y < B; y++) {
           if (!vb[y]) continue;
+          const int pass = (pivn && x == an && y == an) ? 0 : (((rowN && x == an) || (colN && y == an)) ? 1 : 2);
+          if (pass < pass_lo || pass > pass_hi) continue;
           if (colK && y == ka) own[x][y] = -ds_prod32(Cs[x], Ps, wi, wj, lr, lk);
           else own[x][y] -= ds_prod32(Cs[x], Rs[y], wi, wj, lr, lk);
         }
       }
-    }
+    };
     // tiles of the next step's pivot row (read by the other super-rows) and pivot column -> their exchange slots (stores only)
     auto store_panels = [&]() {
       if (rowN) {
@@ -911,38 +915,47 @@ __global__ void __launch_bounds__(256, WPC) k_ds_gj_flow(DsDev D, int lv0, DsFlo
       if (colN && tq >= 1 + B && tq <= 2 * B) { const int x = tq - 1 - B; if (B * I + x < nt && !(rowN && x == an)) ds_flow_raise(DS_FLOW_CFLAG(B * I + x, kn), epoch); }
     };
     const bool pub = ns > 1 && (rowN || colN);
-    if (pub) store_panels();   // (the stores complete behind the inversion / next to the products of the next step's operands)
     if (pivn) {
-      // the owner of the next pivot inverts its tile in Ps (P[k] is not needed any more) and publishes it as P[k + 1]; one completion wait flags the
-      // inverse and the panel tiles.  (Measured on the 1056-pivot root of cfg4: the pivot tile updated and inverted in front of the workgroup's other
-      // tiles, the inverse flagged alone where the chain leaves the workgroup -- 17.4 us per pair of pivots either way; this order needs one P buffer
-      // less, which puts three workgroups on a CU.)
-      __syncthreads();   // every quadrant is done with Ps
+      // The owner of the next pivot updates THAT tile first, inverts it in Pn and publishes it as P[k + 1].  Where the chain LEAVES this
+      // workgroup (the pivot after it lies in the next super-tile) the inverse is flagged at once: the next owner waits for nothing else of
+      // this workgroup; its other tiles and their panel publications follow.  Where the chain STAYS, the workgroups of this super-row and
+      // super-column -- who feed the owner after that -- need P[k + 1] AND this workgroup's panel tiles: those are updated and sent off in
+      // front of the inversion (their stores complete behind it) and one completion wait flags everything.
+      const bool leaves = an == B - 1 || kn + 1 >= nt;
+      if (k >= 0) update(0, leaves ? 0 : 1);
+      if (pub && !leaves) store_panels();
 #pragma unroll
       for (int x = 0; x < B; x++)
 #pragma unroll
-        for (int y = 0; y < B; y++) if (x == an && y == an) to_lds(Ps, own[x][y]);
+        for (int y = 0; y < B; y++) if (x == an && y == an) to_lds(Pn, own[x][y]);
       __syncthreads();
       if (tl && kn < 64) D.tlog[256 + 8 * kn + 3] = wall_clock64();
-      ds_invert_tile(&Ps[0][0], DS_T + 1, D.bad, cls, (sn << 6) | kn, D.piv_tol);   // (ends with a barrier)
+      ds_invert_tile(&Pn[0][0], DS_T + 1, D.bad, cls, (sn << 6) | kn, D.piv_tol);   // (ends with a barrier)
       if (tl && kn < 64) D.tlog[256 + 8 * kn + 4] = wall_clock64();
       if (ns > 1) {
         double* slot = DS_FLOW_PSLOT(kn);
 #pragma unroll
-        for (int q = 0; q < 4; q++) __hip_atomic_store(slot + (ty + 8 * q) * DS_T + tx, Ps[ty + 8 * q][tx], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        for (int q = 0; q < 4; q++) __hip_atomic_store(slot + (ty + 8 * q) * DS_T + tx, Pn[ty + 8 * q][tx], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
       }
 #pragma unroll
       for (int x = 0; x < B; x++)
 #pragma unroll
         for (int y = 0; y < B; y++) if (x == an && y == an) {
 #pragma unroll
-          for (int r = 0; r < 4; r++) own[x][y][r] = Ps[qr + 4 * r][qc];
+          for (int r = 0; r < 4; r++) own[x][y][r] = Pn[qr + 4 * r][qc];
         }
-    }
-    if (pub) {
-      ds_flow_commit();
-      if (pivn && threadIdx.x == 0) { ds_flow_raise(DS_FLOW_PFLAG(kn), epoch); if (tl && kn < 64) D.tlog[kn] = wall_clock64(); }
-      raise_panels();
+      if (ns > 1) {
+        ds_flow_commit();
+        if (threadIdx.x == 0) { ds_flow_raise(DS_FLOW_PFLAG(kn), epoch); if (tl && kn < 64) D.tlog[kn] = wall_clock64(); }
+        if (!leaves) raise_panels();
+      }
+      if (k >= 0) update(leaves ? 1 : 2, 2);
+      if (pub && leaves) { store_panels(); ds_flow_commit(); raise_panels(); }
+    } else {
+      if (k >= 0) update(1, 1);
+      if (pub) store_panels();
+      if (k >= 0) update(2, 2);
+      if (pub) { ds_flow_commit(); raise_panels(); }
     }
     if (tl && k >= 0 && k < 64 && I == ns - 1 && (J == ns - 1 || J == 0)) D.tlog[(J == 0 ? 128 : 64) + k] = wall_clock64();
     if (!more) break;

@@ -127,7 +127,7 @@ struct DirectSolver {
   hipEvent_t ev_ffork = nullptr, ev_fjoin[2] = {nullptr, nullptr};
   // "direct_flow": block steps of a batch alone on its level as one persistent dataflow launch (k_ds_gj_flow)
   int device = 0;          // HIP device of the context (tsl_ctx_create)
-  int flow = 3, flow_cap[2] = {0, 0}, flow_epoch = 0;   // flow_cap: workgroups of k_ds_gj_flow the device holds at once (two / three per CU)
+  int flow = 3, flow_cap = 0, flow_epoch = 0;   // flow_cap: workgroups of k_ds_gj_flow the device holds at once
   int flow_token = 0, flow_token_fd = -1;       // the device's dataflow token (direct_host.hpp): 0 not asked yet, 1 held, -1 refused
   long flow_token_asked = 0;                    // n_factor at the last request
   int small_rounds = 2;     // "direct_small_rounds": rounds of the chip a batch may take in the LDS kernel
