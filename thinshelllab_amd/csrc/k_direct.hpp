@@ -1192,18 +1192,32 @@ TSL_DEV void ds_gemm_tile(const DsDev& D, int lv0, int bx, int by, int bz) {
     if ((int)threadIdx.x < nq) { const DsChildRec c = D.ch[f.ch_off + q0 + threadIdx.x]; s_soff[threadIdx.x] = c.soff; s_cbp[threadIdx.x] = c.bp; }
     __syncthreads();
     for (int q = 0; q < nq; q++) {   // ascending child order: the fixed summation order
+      // The 16 entries of a lane are REQUESTED TOGETHER (entries the child does not reach read its entry (0, 0) and are dropped by a select -- no
+      // arithmetic on them, the sums keep their bits): behind `if (ci >= 0)` every load was a branch of its own and the additions waited for
+      // them one by one -- sixteen dependent round trips per child and tile in the epilogue of every workgroup.
       const double* Sc = D.S + s_soff[q];
       const int cbp = s_cbp[q];
       const int cj0 = s_map[q][64 + 32 * wj + lr], cj1 = s_map[q][64 + 32 * wj + 16 + lr];
+      const int dj0 = max(cj0, 0), dj1 = max(cj1, 0);
+      int ci[2][4];
+      double v0[2][4], v1[2][4];
+#pragma unroll
+      for (int a = 0; a < 2; a++)
+#pragma unroll
+        for (int r = 0; r < 4; r++) ci[a][r] = s_map[q][32 * wi + 16 * a + lk + 4 * r];
 #pragma unroll
       for (int a = 0; a < 2; a++)
 #pragma unroll
         for (int r = 0; r < 4; r++) {
-          const int ci = s_map[q][32 * wi + 16 * a + lk + 4 * r];
-          if (ci < 0) continue;
-          const double* Srow = Sc + (size_t)ci * cbp;
-          if (cj0 >= 0) s22[a][0][r] += Srow[cj0];
-          if (cj1 >= 0) s22[a][1][r] += Srow[cj1];
+          const double* Srow = Sc + (size_t)max(ci[a][r], 0) * cbp;
+          v0[a][r] = Srow[dj0]; v1[a][r] = Srow[dj1];
+        }
+#pragma unroll
+      for (int a = 0; a < 2; a++)
+#pragma unroll
+        for (int r = 0; r < 4; r++) {
+          s22[a][0][r] = (ci[a][r] >= 0 && cj0 >= 0) ? s22[a][0][r] + v0[a][r] : s22[a][0][r];
+          s22[a][1][r] = (ci[a][r] >= 0 && cj1 >= 0) ? s22[a][1][r] + v1[a][r] : s22[a][1][r];
         }
     }
   }
