@@ -140,7 +140,8 @@ def run_rollout(scene, grad, K, args):
 
 def run_group_rollout(scenes, grads, group, K, args):
     """run_rollout for the members of a scene group: the K forward steps of ALL members in lock step (SceneGroup.time_step: one merged
-    factorisation and first application per Newton iteration), then every member's loss seed and reverse sweep on its own path"""
+    factorisation and first application per Newton iteration), then every member's loss seed and the reverse sweep in lock step as well
+    (SceneGroup.transfer_grad: one merged factorisation per adjoint step)"""
     from thinshelllab_amd.engine.geometry import projection_query as contact
     stats = [dict(newton=0, it_fwd=0, ls=0, it_adj=0, nc=0, fwd_fallback=0, fwd_unconverged=0, fwd_attained=0, factorizations=0, plans=0, max_res_fwd=0.0,
                   adj_fallback=0, adj_unconverged=0, adj_attained=0, max_res_adj=0.0, max_be_adj=0.0, last_delta=[], methods={}) for _ in scenes]
@@ -158,14 +159,15 @@ def run_group_rollout(scenes, grads, group, K, args):
             S["fwd_fallback"] += st["fallback"]; S["fwd_unconverged"] += st["unconverged"]; S["fwd_attained"] += st["attained"]
             S["factorizations"] += st["factorizations"]; S["plans"] += st["plans"]
             S["max_res_fwd"] = max(S["max_res_fwd"], st["max_rel_residual"]); S["last_delta"].append(st["last_delta"])
-    for sc, g, S in zip(scenes, grads, stats):
+    for sc, g in zip(scenes, grads):
         g.pos_grad.t.zero_(); g.angleref_grad.t.zero_()
         if args.workload == "cfg3":
             g.get_loss_fold(sc, 1.0, -1.0, rows=sc.fold_rows())
         else:
             g.get_loss_balance(sc)
-        for k in range(K, 0, -1):
-            g.transfer_grad(k, sc, contact)
+    for k in range(K, 0, -1):
+        group.transfer_grad(k, grads, contact)
+        for g, S in zip(grads, stats):
             ls = g.last_stats
             S["it_adj"] += ls["iters"]; S["adj_fallback"] += int(ls["flag"] == 1); S["adj_unconverged"] += int(ls["flag"] == 3); S["adj_attained"] += ls["attained"]
             S["max_res_adj"] = max(S["max_res_adj"], ls["rel_residual"]); S["max_be_adj"] = max(S["max_be_adj"], ls["backward_error"])

@@ -35,8 +35,9 @@ def _drive(s, f):
     s.action(f, dpos, drot)
 
 
-def _rollout(specs, T, grouped):
-    """the scenes of `specs` for T - 1 driven steps and the reverse sweep, stepped together (grouped) or one after the other"""
+def _rollout(specs, T, grouped, group_adjoint=False):
+    """the scenes of `specs` for T - 1 driven steps and the reverse sweep, stepped together (grouped) or one after the other; group_adjoint: the
+    reverse sweep in lock step as well (SceneGroup.transfer_grad), otherwise on every member's own path"""
     from thinshelllab_amd.engine.analytic_grad_single import Grad
     from thinshelllab_amd.engine.geometry import projection_query
     from thinshelllab_amd.scene_group import SceneGroup
@@ -64,16 +65,29 @@ def _rollout(specs, T, grouped):
                 stats[i].append(s.time_step(projection_query, f))
                 g.copy_pos(s, f)
     out = []
-    for i, (s, g) in enumerate(zip(scenes, grads)):   # the reverse sweep runs on the member's own path in both cases
+    adj = [[] for _ in scenes]
+    akeys = ("flag", "iters", "restarts", "rel_residual", "method")
+    for s, g in zip(scenes, grads):
         if s._test_name == "balancing":
             g.get_loss_balance(s)
         else:
             g.get_loss_fold(s, 1.0, -1.0, rows=s.fold_rows())
+    if grouped and group_adjoint:
         for k in range(T - 1, 0, -1):
-            g.transfer_grad(k, s, projection_query)
+            G.transfer_grad(k, grads, projection_query)
+            for i, g in enumerate(grads):
+                adj[i].append([g.last_stats[a] for a in akeys])
+        info = G.info()
+    else:
+        for i, (s, g) in enumerate(zip(scenes, grads)):
+            for k in range(T - 1, 0, -1):
+                g.transfer_grad(k, s, projection_query)
+                adj[i].append([g.last_stats[a] for a in akeys])
+    for i, (s, g) in enumerate(zip(scenes, grads)):
         keys = ("nc", "newton_iters", "ls_evals", "cg_iters", "unconverged", "energy", "last_delta", "last_alpha", "max_rel_residual")
         out.append(dict(pos_buffer=g.pos_buffer.to_numpy().copy(), pos_grad=g.pos_grad.to_numpy().copy(), gripper_grad=g.gripper_grad.to_numpy().copy(),
-                        stats=np.array([[st[k] for k in keys] for st in stats[i]], dtype=np.float64)))
+                        angleref_grad=g.angleref_grad.to_numpy().copy(), end_pos=s.pos.to_numpy().copy(),
+                        stats=np.array([[st[k] for k in keys] for st in stats[i]], dtype=np.float64), adjoint_stats=np.array(adj[i], dtype=np.float64)))
     if grouped:
         G.close()
     del scenes, grads
@@ -85,10 +99,11 @@ def _rollout(specs, T, grouped):
     [("balancing", 48, 1.0), ("balancing", 48, 1.3)],                                   # one topology, two trajectories
     [("balancing", 48, 1.0), ("folding", 60, 1.0), ("balancing", 64, 0.7)],             # different topologies, tree depths and contact sets
 ])
-def test_group_members_match_their_single_scene_rollouts_bit_for_bit(specs):
+@pytest.mark.parametrize("group_adjoint", [False, True])
+def test_group_members_match_their_single_scene_rollouts_bit_for_bit(specs, group_adjoint):
     T = 4
     single, _ = _rollout(specs, T, grouped=False)
-    group, info = _rollout(specs, T, grouped=True)
+    group, info = _rollout(specs, T, grouped=True, group_adjoint=group_adjoint)
     assert info["merged_factorizations"] > 0 and info["merged_applications"] == info["merged_factorizations"], info
     for i, (a, b) in enumerate(zip(single, group)):
         assert a["stats"][:, 0].max() > 0, "no contact in the rollout"

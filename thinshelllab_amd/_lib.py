@@ -76,7 +76,7 @@ EXPORTS = [
     "tsl_contact_reset", "tsl_update_ref_angle", "tsl_adjoint_step", "tsl_param_grad", "tsl_friction_grad", "tsl_elastic_force", "tsl_matrix_nnzb", "tsl_matrix_export",
     "tsl_constraints_export", "tsl_contact_blocks_export", "tsl_proj_export", "tsl_proj_import", "tsl_set_border", "tsl_spd_project", "tsl_profile_reset", "tsl_profile_read", "tsl_profile_read_events",
     "tsl_bench_spmv", "tsl_bench_direct", "tsl_direct_info", "tsl_direct_counters",
-    "tsl_group_create", "tsl_group_destroy", "tsl_group_step", "tsl_group_info",
+    "tsl_group_create", "tsl_group_destroy", "tsl_group_step", "tsl_group_adjoint_step", "tsl_group_info",
 ]
 
 _lib = None
@@ -139,6 +139,7 @@ def load():
     L.tsl_group_destroy.argtypes = [C.c_void_p]
     L.tsl_group_destroy.restype = None
     L.tsl_group_step.argtypes = [C.c_void_p] + [C.POINTER(C.c_void_p)] * 4 + [C.POINTER(StepStats)]
+    L.tsl_group_adjoint_step.argtypes = [C.c_void_p, C.c_int, C.c_int] + [C.POINTER(C.c_void_p)] * 5 + [C.POINTER(C.c_double), C.POINTER(SolveStats)]
     L.tsl_group_info.argtypes = [C.c_void_p, C.POINTER(C.c_double)]
     _lib = L
     return L

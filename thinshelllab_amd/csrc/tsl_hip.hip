@@ -2282,6 +2282,92 @@ extern "C" int tsl_group_info(tsl_group* G, double* out6) {   // (seven values)
   return 0;
 }
 
+// The merged solve of a scene group: v_x <- H^-1 v_b for the members in `act` (permuted order; every member has assembled its operator and gathered
+// its right-hand side on its own stream).  Plans (and the merge when one changed), ONE factorisation and ONE first application for all members,
+// then per member the residual, the stop rule of direct_refine and -- where the first pass does not settle -- the member's own path on the
+// merged factors.  ss[i] = the solve statistics of member i; st (optional) = per-member step statistics to accumulate into.
+static int group_solve(tsl_group* G, const std::vector<int>& act, std::vector<tsl_solve_stats>& ss, tsl_step_stats* st, const std::function<void(int)>& lap) {
+  const int n = (int)G->m.size();
+  tsl_ctx* g = G->g;
+  // ---- plans: every member's own (rebuilt when its constraint set changed: once per time step), then the merge
+  for (int i = 0; i < n; i++) TSL_TRY(direct_plan(G->m[i]));
+  bool stale = !G->merged_valid;
+  for (int i = 0; i < n; i++) stale |= G->seen_gen[i] != G->m[i]->ds.plan_gen;
+  if (stale) {
+    for (int i = 0; i < n; i++) HIP_OK(hipStreamSynchronize(G->m[i]->stream));
+    TSL_TRY(group_merge(G));
+  }
+  lap(1);
+  // ---- ONE factorisation and ONE application for all members
+  for (int i = 0; i < n; i++) { HIP_OK(hipEventRecord(G->ev_m[i], G->m[i]->stream)); HIP_OK(hipStreamWaitEvent(g->stream, G->ev_m[i], 0)); }
+  g->ds.numeric_valid = false;
+  TSL_TRY(direct_factor(g));
+  lap(2);
+  TSL_TRY(direct_apply(g, G->vb.p, G->vx.p));
+  HIP_OK(hipEventRecord(G->ev_g, g->stream));
+  lap(3);
+  for (int i = 0; i < n; i++) HIP_OK(hipStreamWaitEvent(G->m[i]->stream, G->ev_g, 0));
+  // ---- per member: residual of the merged first pass and the stop rule of direct_refine
+  ss.assign(n, tsl_solve_stats{});
+  for (int i : act) {
+    tsl_ctx* c = G->m[i];
+    const size_t n3 = 3 * (size_t)c->NV;
+    const int gv = std::min(gsz(n3), 240);
+    if (c->ir_part.n < (size_t)4 * 240 + 8 && c->ir_part.alloc(4 * 240 + 8)) return -1;
+    if (c->ir_ticket.n < 2) { if (c->ir_ticket.alloc(2)) return -1; HIP_OK(hipMemsetAsync(c->ir_ticket.p, 0, 2 * sizeof(int), c->stream)); }
+    if (c->h_ir == nullptr) HIP_OK(hipHostMalloc((void**)&c->h_ir, 8 * sizeof(double)));
+    double* out = c->ir_part.p + 4 * 240;
+    launch_spmv(c, c->vals.p, c->v_x.p, c->v_Ap.p, -1, 0);
+    hipLaunchKernelGGL(k_ir_resid, dim3(gv), dim3(256), 0, c->stream, n3, (const double*)c->v_b.p, (const double*)c->v_Ap.p, (const double*)c->v_x.p, c->v_r.p, c->ir_part.p, c->ir_ticket.p, out);
+    HIP_OK(hipMemcpyAsync(c->h_ir, out, 4 * sizeof(double), hipMemcpyDeviceToHost, c->stream));
+  }
+  for (int i : act) {
+    tsl_ctx* c = G->m[i];
+    DirectSolver& d = c->ds;
+    HIP_OK(hipStreamSynchronize(c->stream));
+    tsl_solve_stats& s1 = ss[i];
+    memset(&s1, 0, sizeof(s1));
+    const double rr = c->h_ir[0], xx = c->h_ir[1], bb = c->h_ir[2];
+    c->last_xmax = c->h_ir[3]; c->last_xmax_valid = true;
+    s1.iters = 1; s1.method = 4;
+    bool ok = false;
+    if (!(bb > 0)) ok = true;
+    else {
+      s1.rel_residual = sqrt(rr / bb);
+      if (std::isfinite(rr)) {
+        if (rr <= c->cg_tol * c->cg_tol * bb) ok = true;
+        else if (d.berr_tol > 0 && rr <= d.berr_rel_cap * d.berr_rel_cap * c->cg_tol * c->cg_tol * bb) {   // (the rule of direct_refine's first pass)
+          TSL_TRY(direct_anorm(c));
+          const double be = sqrt(rr) / (d.anorm * sqrt(xx) + sqrt(bb));
+          d.berr_seen++;
+          if (be <= d.berr_tol) { ok = true; s1.backward_error = be; d.berr_accepted++; d.berr_max = std::max(d.berr_max, be); d.berr_rel_max = std::max(d.berr_rel_max, s1.rel_residual); }
+        }
+      }
+    }
+    if (!ok) {
+      // The merged factorisation IS the member's factorisation (its own plan addresses the same memory in the same layout): the member goes on
+      // from the merged first pass on its own path -- refinement with its own sweeps, flexible GMRES and the hierarchy behind it (solve_perm) if that
+      // does not settle.  (The group's clear of the leaf panels is issued after these, below.)
+      d.numeric_valid = true; d.have_factor = true;
+      tsl_solve_stats s2;
+      memset(&s2, 0, sizeof(s2));
+      TSL_TRY(direct_refine(c, &s2, true));
+      if (s2.flag == 1) { s1 = s2; s1.flag = 0; s1.method = 4; }
+      else TSL_TRY(solve_perm(c, &s1));
+      G->n_own_path++;
+      if (c->verbose >= 2) fprintf(stderr, "[tsl] scene group: member %d went on from the merged pass (rel_residual %.2e) on its own path: flag %d after %d applications\n", i, sqrt(rr / std::max(bb, 1e-300)), s1.flag, s1.iters);
+    }
+    if (st == nullptr) continue;
+    tsl_step_stats& t = st[i];
+    t.cg_iters += s1.iters; t.solves++; t.restarts += s1.restarts; t.fallback += (s1.flag == 1); t.unconverged += (s1.flag == 3); t.attained += s1.attained;
+    t.max_rel_residual = std::max(t.max_rel_residual, s1.rel_residual); t.max_backward_error = std::max(t.max_backward_error, s1.backward_error);
+  }
+  for (int i = 0; i < n; i++) { tsl_ctx* c = G->m[i]; c->ds.numeric_valid = false; c->ds.have_factor = false; HIP_OK(hipEventRecord(G->ev_m[i], c->stream)); HIP_OK(hipStreamWaitEvent(g->stream, G->ev_m[i], 0)); }
+  TSL_TRY(direct_prezero(g));   // the factors are dead: the leaf panels of the next factorisation are cleared next to the line search and the next assembly
+  lap(4);
+  return 0;
+}
+
 extern "C" int tsl_group_step(tsl_group* G, double* const* pos_a, double* const* prev_a, double* const* vel_a, double* const* ref_a, tsl_step_stats* stats) {
   const int n = (int)G->m.size();
   tsl_ctx* g = G->g;
@@ -2314,7 +2400,7 @@ extern "C" int tsl_group_step(tsl_group* G, double* const* pos_a, double* const*
   const bool timed = g->verbose >= 1;
   double tph[6] = {0, 0, 0, 0, 0, 0};
   auto tick = std::chrono::steady_clock::now();
-  auto lap = [&](int k) { if (!timed) return; for (tsl_ctx* c : G->m) (void)hipStreamSynchronize(c->stream); (void)hipStreamSynchronize(g->stream);
+  const std::function<void(int)> lap = [&](int k) { if (!timed) return; for (tsl_ctx* c : G->m) (void)hipStreamSynchronize(c->stream); (void)hipStreamSynchronize(g->stream);
                           const auto nw = std::chrono::steady_clock::now(); tph[k] += std::chrono::duration<double>(nw - tick).count(); tick = nw; };
   for (;;) {
     std::vector<int> act;
@@ -2330,81 +2416,8 @@ extern "C" int tsl_group_step(tsl_group* G, double* const* pos_a, double* const*
       return 0;
     }));
     lap(0);
-    // ---- plans: every member's own (rebuilt when its constraint set changed: once per time step), then the merge
-    for (int i = 0; i < n; i++) TSL_TRY(direct_plan(G->m[i]));
-    bool stale = !G->merged_valid;
-    for (int i = 0; i < n; i++) stale |= G->seen_gen[i] != G->m[i]->ds.plan_gen;
-    if (stale) {
-      for (int i = 0; i < n; i++) HIP_OK(hipStreamSynchronize(G->m[i]->stream));
-      TSL_TRY(group_merge(G));
-    }
-    lap(1);
-    // ---- ONE factorisation and ONE application for all members
-    for (int i = 0; i < n; i++) { HIP_OK(hipEventRecord(G->ev_m[i], G->m[i]->stream)); HIP_OK(hipStreamWaitEvent(g->stream, G->ev_m[i], 0)); }
-    g->ds.numeric_valid = false;
-    TSL_TRY(direct_factor(g));
-    lap(2);
-    TSL_TRY(direct_apply(g, G->vb.p, G->vx.p));
-    HIP_OK(hipEventRecord(G->ev_g, g->stream));
-    lap(3);
-    for (int i = 0; i < n; i++) HIP_OK(hipStreamWaitEvent(G->m[i]->stream, G->ev_g, 0));
-    // ---- per member: residual of the merged first pass and the stop rule of direct_refine
-    std::vector<tsl_solve_stats> ss(n);
-    for (int i : act) {
-      tsl_ctx* c = G->m[i];
-      const size_t n3 = 3 * (size_t)c->NV;
-      const int gv = std::min(gsz(n3), 240);
-      if (c->ir_part.n < (size_t)4 * 240 + 8 && c->ir_part.alloc(4 * 240 + 8)) return -1;
-      if (c->ir_ticket.n < 2) { if (c->ir_ticket.alloc(2)) return -1; HIP_OK(hipMemsetAsync(c->ir_ticket.p, 0, 2 * sizeof(int), c->stream)); }
-      if (c->h_ir == nullptr) HIP_OK(hipHostMalloc((void**)&c->h_ir, 8 * sizeof(double)));
-      double* out = c->ir_part.p + 4 * 240;
-      launch_spmv(c, c->vals.p, c->v_x.p, c->v_Ap.p, -1, 0);
-      hipLaunchKernelGGL(k_ir_resid, dim3(gv), dim3(256), 0, c->stream, n3, (const double*)c->v_b.p, (const double*)c->v_Ap.p, (const double*)c->v_x.p, c->v_r.p, c->ir_part.p, c->ir_ticket.p, out);
-      HIP_OK(hipMemcpyAsync(c->h_ir, out, 4 * sizeof(double), hipMemcpyDeviceToHost, c->stream));
-    }
-    for (int i : act) {
-      tsl_ctx* c = G->m[i];
-      DirectSolver& d = c->ds;
-      HIP_OK(hipStreamSynchronize(c->stream));
-      tsl_solve_stats& s1 = ss[i];
-      memset(&s1, 0, sizeof(s1));
-      const double rr = c->h_ir[0], xx = c->h_ir[1], bb = c->h_ir[2];
-      c->last_xmax = c->h_ir[3]; c->last_xmax_valid = true;
-      s1.iters = 1; s1.method = 4;
-      bool ok = false;
-      if (!(bb > 0)) ok = true;
-      else {
-        s1.rel_residual = sqrt(rr / bb);
-        if (std::isfinite(rr)) {
-          if (rr <= c->cg_tol * c->cg_tol * bb) ok = true;
-          else if (d.berr_tol > 0 && rr <= d.berr_rel_cap * d.berr_rel_cap * c->cg_tol * c->cg_tol * bb) {   // (the rule of direct_refine's first pass)
-            TSL_TRY(direct_anorm(c));
-            const double be = sqrt(rr) / (d.anorm * sqrt(xx) + sqrt(bb));
-            d.berr_seen++;
-            if (be <= d.berr_tol) { ok = true; s1.backward_error = be; d.berr_accepted++; d.berr_max = std::max(d.berr_max, be); d.berr_rel_max = std::max(d.berr_rel_max, s1.rel_residual); }
-          }
-        }
-      }
-      if (!ok) {
-        // The merged factorisation IS the member's factorisation (its own plan addresses the same memory in the same layout): the member goes on
-        // from the merged first pass on its own path -- refinement with its own sweeps, flexible GMRES and the hierarchy behind it (solve_perm) if that
-        // does not settle.  (The group's clear of the leaf panels is issued after these, below.)
-        d.numeric_valid = true; d.have_factor = true;
-        tsl_solve_stats s2;
-        memset(&s2, 0, sizeof(s2));
-        TSL_TRY(direct_refine(c, &s2, true));
-        if (s2.flag == 1) { s1 = s2; s1.flag = 0; s1.method = 4; }
-        else TSL_TRY(solve_perm(c, &s1));
-        G->n_own_path++;
-        if (c->verbose >= 2) fprintf(stderr, "[tsl] scene group: member %d went on from the merged pass (rel_residual %.2e) on its own path: flag %d after %d applications\n", i, sqrt(rr / std::max(bb, 1e-300)), s1.flag, s1.iters);
-      }
-      tsl_step_stats& t = st[i];
-      t.cg_iters += s1.iters; t.solves++; t.restarts += s1.restarts; t.fallback += (s1.flag == 1); t.unconverged += (s1.flag == 3); t.attained += s1.attained;
-      t.max_rel_residual = std::max(t.max_rel_residual, s1.rel_residual); t.max_backward_error = std::max(t.max_backward_error, s1.backward_error);
-    }
-    for (int i = 0; i < n; i++) { tsl_ctx* c = G->m[i]; c->ds.numeric_valid = false; c->ds.have_factor = false; HIP_OK(hipEventRecord(G->ev_m[i], c->stream)); HIP_OK(hipStreamWaitEvent(g->stream, G->ev_m[i], 0)); }
-    TSL_TRY(direct_prezero(g));   // the factors are dead: the leaf panels of the next factorisation are cleared next to the line search and the next assembly
-    lap(4);
+    std::vector<tsl_solve_stats> ss;
+    TSL_TRY(group_solve(G, act, ss, st.data(), lap));
     // ---- direction, line search: all trials of a round are issued, then read
     for (int i : act) {
       tsl_ctx* c = G->m[i];
@@ -2820,22 +2833,24 @@ __global__ void k_adj_prev(int NV, const double* __restrict__ z, const double* _
   }
 }
 
-// Grad.transfer_grad (analytic_grad_single.py:217-257) without the gripper part (host: gripper.set / gather_grad).
-extern "C" int tsl_adjoint_step(tsl_ctx* c, int step, int T, const double* pos_buffer, double* pos_grad, const double* ref_buffer, double* angleref_grad,
-                                double* tmp_z_frozen, double adj_damping, tsl_solve_stats* st) {
-  Scope scope(c);
-  if (step < 1 || step >= T) return tsl_fail("tsl_adjoint_step: step %d outside [1, %d)", step, T);
+// Grad.transfer_grad (analytic_grad_single.py:217-257) without the gripper part (host: gripper.set / gather_grad), in two halves around the
+// linear solve p = H^-1 pos_grad[s] (tsl_adjoint_step: the scene's own solve; tsl_group_adjoint_step: the merged solve of a scene group).
+struct AdjArgs { int step, T; const double* pos_buffer; double* pos_grad; const double* ref_buffer; double* angleref_grad; double* tmp_z_frozen; double adj_damping; };
+
+// clamp, contacts at x_{s-1}, ref-angle backprop (a2ax), the un-projected Hessian at x_s in c->vals / c->c_H; *rhs = pos_grad[s]
+static int adjoint_pre(tsl_ctx* c, const AdjArgs& a, double** rhs) {
   hipStream_t s = c->stream;
   const int NV = c->NV;
   const size_t n3 = 3 * (size_t)NV, nr = 3 * (size_t)std::max(c->n_cface, 1);
-  double* pg_s = pos_grad + (size_t)step * n3;
-  double* pg_prev = pos_grad + (size_t)(step - 1) * n3;
-  double* pg_prev2 = step > 1 ? pos_grad + (size_t)(step - 2) * n3 : nullptr;
-  const double* x_s = pos_buffer + (size_t)step * n3;
-  const double* x_prev = pos_buffer + (size_t)(step - 1) * n3;
-  double* ag_s = angleref_grad + (size_t)step * nr;
-  double* ag_prev = angleref_grad + (size_t)(step - 1) * nr;
-  const double* ref_prev = ref_buffer + (size_t)(step - 1) * nr;
+  double* pg_s = a.pos_grad + (size_t)a.step * n3;
+  double* pg_prev = a.pos_grad + (size_t)(a.step - 1) * n3;
+  double* pg_prev2 = a.step > 1 ? a.pos_grad + (size_t)(a.step - 2) * n3 : nullptr;
+  const double* x_s = a.pos_buffer + (size_t)a.step * n3;
+  const double* x_prev = a.pos_buffer + (size_t)(a.step - 1) * n3;
+  double* ag_s = a.angleref_grad + (size_t)a.step * nr;
+  double* ag_prev = a.angleref_grad + (size_t)(a.step - 1) * nr;
+  const double* ref_prev = a.ref_buffer + (size_t)(a.step - 1) * nr;
+  (void)pg_prev; (void)pg_prev2; (void)ag_prev;
   // clamp_grad
   hipLaunchKernelGGL(k_clamp, dim3(gsz(n3)), dim3(256), 0, s, n3, pg_s, c->adj_clamp);
   if (c->n_cface && c->adj_clamp_angleref)
@@ -2878,12 +2893,28 @@ extern "C" int tsl_adjoint_step(tsl_ctx* c, int step, int T, const double* pos_b
   c->pc_frozen = false;
   if (rc_asm) return rc_asm;
   if (spd_pc) c->pc_separate = true;
-  // p = H^-1 pos_grad[s]
-  tsl_solve_stats local;
-  if (!st) st = &local;
-  TSL_TRY(solve_orig(c, pg_s, c->pdir.p, st));
-  if (st->method == 4) TSL_TRY(direct_prezero(c));   // the next adjoint step assembles another operator
-  if (c->verbose) fprintf(stderr, "[tsl] adjoint step %d: nc %d solver flag %d iters %d restarts %d rel_residual %.2e\n", step, c->nc, st->flag, st->iters, st->restarts, st->rel_residual);
+  *rhs = pg_s;
+  return 0;
+}
+
+// p = c->pdir (original order), c->v_x (permuted): tmp_z_frozen, contact / ref-angle / inertia backprop into step s-1 and s-2
+static int adjoint_post(tsl_ctx* c, const AdjArgs& a) {
+  hipStream_t s = c->stream;
+  const int NV = c->NV;
+  const size_t n3 = 3 * (size_t)NV, nr = 3 * (size_t)std::max(c->n_cface, 1);
+  double* pg_s = a.pos_grad + (size_t)a.step * n3;
+  double* pg_prev = a.pos_grad + (size_t)(a.step - 1) * n3;
+  double* pg_prev2 = a.step > 1 ? a.pos_grad + (size_t)(a.step - 2) * n3 : nullptr;
+  const double* x_s = a.pos_buffer + (size_t)a.step * n3;
+  const double* x_prev = a.pos_buffer + (size_t)(a.step - 1) * n3;
+  double* ag_s = a.angleref_grad + (size_t)a.step * nr;
+  double* ag_prev = a.angleref_grad + (size_t)(a.step - 1) * nr;
+  const double* ref_prev = a.ref_buffer + (size_t)(a.step - 1) * nr;
+  (void)pg_s; (void)x_prev; (void)ag_s; (void)ref_prev;
+  double* tmp_z_frozen = a.tmp_z_frozen;
+  const double adj_damping = a.adj_damping;
+  ClothArgs CA = cloth_args(c);
+  const bool det = c->deterministic != 0;
   // tmp_z_frozen (second compute_Hessian pass with counting_z_frozen)
   if (det) hipLaunchKernelGGL(k_zfrozen_gather, dim3(nblk(NV, 256)), dim3(256), 0, s, NV, c->slice_off.p, c->slice_len.p, c->colidx.p, (const int*)c->trans.p, c->fzmask.p, c->vals_full.p,
                               c->v_x.p, c->v_t4.p);
@@ -2910,7 +2941,68 @@ extern "C" int tsl_adjoint_step(tsl_ctx* c, int step, int T, const double* pos_b
   if (c->n_hinge) hipLaunchKernelGGL(k_adj_x2a, dim3(nblk(c->n_hinge, 256)), dim3(256), 0, s, CA, x_s, c->pdir.p, ag_prev);
   // get_prev_grad / get_prev_prev_grad
   hipLaunchKernelGGL(k_adj_prev, dim3(gsz(n3)), dim3(256), 0, s, NV, c->pdir.p, c->mass.p, c->frozen.p, c->dt, adj_damping, pg_prev, pg_prev2);
-  HIP_OK(hipStreamSynchronize(s));
+  HIP_OK(hipGetLastError());
+  return 0;
+}
+
+extern "C" int tsl_adjoint_step(tsl_ctx* c, int step, int T, const double* pos_buffer, double* pos_grad, const double* ref_buffer, double* angleref_grad,
+                                double* tmp_z_frozen, double adj_damping, tsl_solve_stats* st) {
+  Scope scope(c);
+  if (step < 1 || step >= T) return tsl_fail("tsl_adjoint_step: step %d outside [1, %d)", step, T);
+  const AdjArgs a{step, T, pos_buffer, pos_grad, ref_buffer, angleref_grad, tmp_z_frozen, adj_damping};
+  double* pg_s = nullptr;
+  TSL_TRY(adjoint_pre(c, a, &pg_s));
+  // p = H^-1 pos_grad[s]
+  tsl_solve_stats local;
+  if (!st) st = &local;
+  TSL_TRY(solve_orig(c, pg_s, c->pdir.p, st));
+  if (st->method == 4) TSL_TRY(direct_prezero(c));   // the next adjoint step assembles another operator
+  if (c->verbose) fprintf(stderr, "[tsl] adjoint step %d: nc %d solver flag %d iters %d restarts %d rel_residual %.2e\n", step, c->nc, st->flag, st->iters, st->restarts, st->rel_residual);
+  TSL_TRY(adjoint_post(c, a));
+  HIP_OK(hipStreamSynchronize(c->stream));
+  HIP_OK(hipGetLastError());
+  return 0;
+}
+
+// Grad.transfer_grad of every scene of a group for the same reverse step: the S adjoint systems H_i p_i = pos_grad_i[s] go through ONE merged
+// factorisation and first application (group_solve), the halves before and after it run per member on its own stream (one host thread each).
+// Same bits per scene as tsl_adjoint_step on a context with the sparse direct solve.  stats: S records (or NULL).
+extern "C" int tsl_group_adjoint_step(tsl_group* G, int step, int T, const double* const* pos_buffer_a, double* const* pos_grad_a, const double* const* ref_buffer_a,
+                                      double* const* angleref_grad_a, double* const* tmp_z_a, const double* adj_damping_a, tsl_solve_stats* stats) {
+  const int n = (int)G->m.size();
+  tsl_ctx* g = G->g;
+  if (step < 1 || step >= T) return tsl_fail("tsl_group_adjoint_step: step %d outside [1, %d)", step, T);
+  std::vector<std::unique_ptr<Scope>> scopes;
+  for (int i = 0; i < n; i++) scopes.emplace_back(new Scope(G->m[i]));
+  std::vector<AdjArgs> aa(n);
+  std::vector<int> act(n);
+  for (int i = 0; i < n; i++) {
+    if (!direct_enabled(G->m[i])) return tsl_fail("tsl_group_adjoint_step: scene %d does not use the sparse direct solve", i);
+    aa[i] = AdjArgs{step, T, pos_buffer_a[i], pos_grad_a[i], ref_buffer_a[i], angleref_grad_a[i], tmp_z_a[i], adj_damping_a[i]};
+    act[i] = i;
+  }
+  g->verbose = G->m[0]->verbose;
+  TSL_TRY(G->pool->run(act, [&](int i) -> int {
+    tsl_ctx* c = G->m[i];
+    double* rhs = nullptr;
+    TSL_TRY(adjoint_pre(c, aa[i], &rhs));
+    hipLaunchKernelGGL(k_gather_perm, dim3(nblk(c->NV, 256)), dim3(256), 0, c->stream, c->NV, c->perm.p, (const double*)rhs, c->v_b.p);
+    return 0;
+  }));
+  std::vector<tsl_solve_stats> ss;
+  TSL_TRY(group_solve(G, act, ss, nullptr, [](int) {}));
+  TSL_TRY(G->pool->run(act, [&](int i) -> int {
+    tsl_ctx* c = G->m[i];
+    hipLaunchKernelGGL(k_scatter_perm, dim3(nblk(c->NV, 256)), dim3(256), 0, c->stream, c->NV, c->perm.p, (const double*)c->v_x.p, c->pdir.p);
+    if (c->verbose) fprintf(stderr, "[tsl] group adjoint step %d, scene %d: nc %d solver flag %d iters %d restarts %d rel_residual %.2e\n", step, i, c->nc, ss[i].flag, ss[i].iters, ss[i].restarts,
+                            ss[i].rel_residual);
+    TSL_TRY(adjoint_post(c, aa[i]));
+    return 0;
+  }));
+  for (int i = 0; i < n; i++) {
+    HIP_OK(hipStreamSynchronize(G->m[i]->stream));
+    if (stats) stats[i] = ss[i];
+  }
   HIP_OK(hipGetLastError());
   return 0;
 }

@@ -10,7 +10,7 @@ bit-identical to what its own ``time_step`` gives.
 import ctypes as C
 
 from . import _lib
-from ._lib import StepStats, check
+from ._lib import SolveStats, StepStats, check
 from .context import _ptr
 
 
@@ -67,6 +67,34 @@ class SceneGroup:
             s.E[None] = d["energy"]
             out.append(d)
         return out
+
+    def transfer_grad(self, step, grads, f_contact):
+        """``Grad.transfer_grad(step, scene, f_contact)`` (analytic_grad_single.py:217-257) of every member for the same reverse step: the members'
+        adjoint systems go through one merged factorisation; ``grads[i]`` is the tape of ``scenes[i]``."""
+        n = len(self.scenes)
+        assert len(grads) == n
+        T = grads[0].tot_timestep
+        cols = [[], [], [], [], []]
+        damp = (C.c_double * n)()
+        for i, (s, g) in enumerate(zip(self.scenes, grads)):
+            assert g.tot_timestep == T, "the members' tapes must have one length"
+            ctx = s._ensure_ctx()
+            ctx.set_param("contact", 0.0 if f_contact is None else 1.0)
+            ctx.refresh_stream()
+            for k, t in enumerate((g.pos_buffer.t, g.pos_grad.t, g.ref_angle_buffer.t, g.angleref_grad.t, s.tmp_z_frozen.t)):
+                cols[k].append(_ptr(t))
+            damp[i] = float(g.damping)
+        arrs = [(C.c_void_p * n)(*col) for col in cols]
+        st = (SolveStats * n)()
+        check(self.L.tsl_group_adjoint_step(self.h, int(step), int(T), *arrs, damp, st), "tsl_group_adjoint_step")
+        for s, g, r in zip(self.scenes, grads, st):
+            g.last_stats = r.as_dict()
+            g.check_solve(step)
+            s.copy_pos_and_refangle(g, step)
+            if g.n_part > 0 and hasattr(s, "gripper"):
+                s.gripper.set(g.gripper_pos_buffer, g.gripper_rot_buffer, step)
+                if step > 0:
+                    g.get_gripper_grad(step, s)
 
     def info(self):
         v = (C.c_double * 7)()

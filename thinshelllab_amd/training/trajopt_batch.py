@@ -142,28 +142,37 @@ class SceneProblem:
     def post_step(self, frame):
         self.grad.copy_pos(self.sys, frame)
 
-    def finish(self):
-        """reward, loss seed, reverse sweep (trajopt_folding.py:100-135)"""
-        s, g, T = self.sys, self.grad, self.T
+    def seed(self):
+        """reward and loss seed at the end of the forward sweep (trajopt_folding.py:100-118)"""
+        s, g = self.sys, self.grad
         if self.env == "folding":
-            reward = s.compute_reward(1.0, -1.0)
+            self.reward = s.compute_reward(1.0, -1.0)
             g.get_loss_fold(s, 1.0, -1.0, rows=s.fold_rows())
         elif self.env == "lifting":
-            reward = s.compute_reward()
+            self.reward = s.compute_reward()
             g.get_loss_lift(s)
         else:
-            reward = s.compute_reward_all(g)
+            self.reward = s.compute_reward_all(g)
             g.get_loss_balance(s)
         g.allow_unconverged = True   # counted instead of raised in the middle of the sweep (run_batch keeps the ranks in lock-step)
         g.unconverged = 0
-        for step in range(T - 1, 0, -1):
-            g.transfer_grad(step, s, self.contact)
+
+    def collect(self):
+        """(reward, gripper gradient) after the reverse sweep (trajopt_folding.py:119-135)"""
+        g, T = self.grad, self.T
         if g.unconverged:
             print(f"scene rollout: {g.unconverged} adjoint solves of {T - 1} did not converge; the gradient of this iteration is discarded", flush=True)
             return float("nan"), torch.zeros_like(g.gripper_grad.t)
         if self.limit_grad:
             g.apply_action_limit_grad(self.agent, 0.015)
-        return float(reward), g.gripper_grad.t.clone()
+        return float(self.reward), g.gripper_grad.t.clone()
+
+    def finish(self):
+        """reward, loss seed, reverse sweep (trajopt_folding.py:100-135)"""
+        self.seed()
+        for step in range(self.T - 1, 0, -1):
+            self.grad.transfer_grad(step, self.sys, self.contact)
+        return self.collect()
 
     def rollout(self):
         self.begin()
@@ -185,7 +194,7 @@ _GROUPS = {}
 
 def rollout_scene_group(problems):
     """the scenes of one rank rolled out together: every frame's time steps as ONE SceneGroup.time_step (thinshelllab_amd/scene_group.py: lock step,
-    merged factorisations, each scene bit-identical to its own time_step), reward / seed / reverse sweep per scene"""
+    merged factorisations, each scene bit-identical to its own time_step), the reverse sweep as SceneGroup.transfer_grad per step, reward / seed per scene"""
     from ..scene_group import SceneGroup
     key = tuple(id(p) for p in problems)
     if key not in _GROUPS:
@@ -201,7 +210,11 @@ def rollout_scene_group(problems):
         group.time_step(problems[0].contact, frame)
         for p in problems:
             p.post_step(frame)
-    return [p.finish() for p in problems]
+    for p in problems:
+        p.seed()
+    for step in range(problems[0].T - 1, 0, -1):   # the reverse sweep in lock step as well: one merged factorisation per adjoint step
+        group.transfer_grad(step, [p.grad for p in problems], problems[0].contact)
+    return [p.collect() for p in problems]
 
 
 def main(argv=None):
