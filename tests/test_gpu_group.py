@@ -180,3 +180,18 @@ def test_group_steps_after_a_reverse_sweep_use_cached_plans_correctly():
         gc.collect()
     for a, b in zip(res[False], res[True]):
         assert np.isfinite(a).all() and np.array_equal(a, b), np.abs(a - b).max()
+
+
+def test_group_at_cfg4_size_bit_for_bit():
+    """BASELINE configs[4]'s scene at its stated size (224 x 224 cloth, 100,352 triangles, ball + four pads) twice with different drives: two driven steps
+    and the reverse sweep as a scene group (forward and reverse in lock step) against one scene after the other -- same tapes, gradients and solver
+    statistics bit for bit; the merged solves went through the dataflow inversions (the group holds the device's token)"""
+    specs = [("balancing", 224, 1.0), ("balancing", 224, 1.3)]
+    T = 3
+    single, _ = _rollout(specs, T, grouped=False)
+    group, info = _rollout(specs, T, grouped=True, group_adjoint=True)
+    assert info["merged_factorizations"] >= 2 * (T - 1) and info["member_solves_on_own_path"] <= 8, info
+    for i, (a, b) in enumerate(zip(single, group)):
+        assert a["stats"][:, 0].max() > 50, "too few contacts for the cfg4 scene"
+        for k in a:
+            assert np.array_equal(a[k], b[k]), f"scene {i}: {k} differs (max |d| = {np.abs(a[k] - b[k]).max():.3e})"

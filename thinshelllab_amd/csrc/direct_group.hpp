@@ -84,6 +84,7 @@ struct GroupPool {
 };
 
 struct tsl_group {
+  std::mutex mu_layout;          // group_ensure_arenas (members build their plans side by side)
   std::vector<tsl_ctx*> m;       // members (not owned)
   tsl_ctx* g = nullptr;          // pseudo-context of the merged solver (owned)
   DevBuf<double> vals, cH, vb, vx, arena, sarena, garena, w;
@@ -105,6 +106,7 @@ static inline size_t grp_align(size_t n) { return (n + 31) & ~(size_t)31; }   //
 // (25 % headroom for the one that grew), the shared buffers grow if they must, all factors are declared invalid
 static int group_ensure_arenas(tsl_ctx* c) {
   tsl_group* G = c->group;
+  std::lock_guard<std::mutex> lk(G->mu_layout);
   int me = -1;
   for (size_t i = 0; i < G->m.size(); i++) if (G->m[i] == c) me = (int)i;
   if (me < 0) return tsl_fail("scene group: context is not a member");
@@ -166,7 +168,10 @@ static int group_merge(tsl_group* G) {
   M.arena = (long long)G->arena.n; M.sarena = (long long)G->sarena.n; M.garena = (long long)G->garena.n; M.ylen = (long long)G->w.n;
   M.flops = 0; M.leaf_ranges.clear(); M.arena_leaf = 0;
   std::vector<std::vector<int>> by_level(L);
-  for (int i = 0; i < n; i++) {
+  std::vector<int> all(n);
+  for (int i = 0; i < n; i++) all[i] = i;
+  // the members' tables copied side by side (one host thread per member: disjoint ranges of the merged tables)
+  TSL_TRY(G->pool->run(all, [&](int i) -> int {
     tsl_ctx* c = G->m[i];
     const DirectPlan& P = c->ds.plan;
     const long long oa = (long long)G->off_a[i], os = (long long)G->off_s[i], og = (long long)G->off_g[i];
@@ -187,10 +192,14 @@ static int group_merge(tsl_group* G) {
       r.soff += os; r.pmap_off += pmap_base[i]; r.sn += sn_base[i]; r.yoff += ow;
       M.ch_rec[ch_base[i] + q] = r;
     }
+    return 0;
+  }));
+  for (int i = 0; i < n; i++) {
+    const DirectPlan& P = G->m[i]->ds.plan;
     for (int l = 0; l < P.n_levels; l++)
       for (int q = P.level_ptr[l]; q < P.level_ptr[l + 1]; q++) by_level[l].push_back(sn_base[i] + P.level_sn[q]);
     M.flops += P.flops;
-    M.leaf_ranges.push_back({oa, P.arena_leaf});
+    M.leaf_ranges.push_back({(long long)G->off_a[i], P.arena_leaf});
     M.arena_leaf += P.arena_leaf;
   }
   M.build_levels(by_level);
@@ -237,6 +246,7 @@ static int group_merge(tsl_group* G) {
   cg_ptr.reserve(ngr + 1); cg_ent.reserve(nge); cg_ld.reserve(ngr); cg_dst.reserve(ngr);
   M.blk_lptr.assign(L + 1, 0); M.cgr_lptr.assign(L + 1, 0);
   {
+    std::vector<size_t> at((size_t)L * n, 0);   // where member i's blocks of level l start in the merged, level-ordered list
     size_t o = 0;
     for (int l = 0; l < L; l++) {
       for (int i = 0; i < n; i++) {
@@ -244,10 +254,10 @@ static int group_merge(tsl_group* G) {
         const DirectPlan& P = c->ds.plan;
         if (l >= P.n_levels) continue;
         if (G->vals_off[i] + c->vals.n > 0x7fffffffULL) return tsl_fail("scene group: matrix values exceed 2^31 doubles");
-        const int vo = (int)G->vals_off[i];
-        const long long oa = (long long)G->off_a[i];
-        for (int k = P.blk_lptr[l]; k < P.blk_lptr[l + 1]; k++) { const int q = P.blk_q[k]; src[o] = c->ds.h_c2s[q] + vo; dst[o] = P.blk_dst[q] + oa; ld[o] = P.blk_ld[q]; o++; }
+        at[(size_t)l * n + i] = o;
+        o += (size_t)(P.blk_lptr[l + 1] - P.blk_lptr[l]);
         if (c->nc > 0 && !P.cgr_lptr.empty()) {
+          const long long oa = (long long)G->off_a[i];
           const int eo = 16 * G->nc_off[i];
           for (int gq = P.cgr_lptr[l]; gq < P.cgr_lptr[l + 1]; gq++) {
             cg_ptr.push_back((int)cg_ent.size());
@@ -260,6 +270,17 @@ static int group_merge(tsl_group* G) {
       M.cgr_lptr[l + 1] = (int)cg_dst.size();
     }
     cg_ptr.push_back((int)cg_ent.size());
+    TSL_TRY(G->pool->run(all, [&](int i) -> int {
+      tsl_ctx* c = G->m[i];
+      const DirectPlan& P = c->ds.plan;
+      const int vo = (int)G->vals_off[i];
+      const long long oa = (long long)G->off_a[i];
+      for (int l = 0; l < P.n_levels; l++) {
+        size_t w = at[(size_t)l * n + i];
+        for (int k = P.blk_lptr[l]; k < P.blk_lptr[l + 1]; k++, w++) { const int q = P.blk_q[k]; src[w] = c->ds.h_c2s[q] + vo; dst[w] = P.blk_dst[q] + oa; ld[w] = P.blk_ld[q]; }
+      }
+      return 0;
+    }));
   }
   // uploads (pinned staging arena of the group's solver)
   std::vector<DsFrontDesc> frl(M.level_sn.size());

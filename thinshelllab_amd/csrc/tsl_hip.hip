@@ -2290,7 +2290,12 @@ static int group_solve(tsl_group* G, const std::vector<int>& act, std::vector<ts
   const int n = (int)G->m.size();
   tsl_ctx* g = G->g;
   // ---- plans: every member's own (rebuilt when its constraint set changed: once per time step), then the merge
-  for (int i = 0; i < n; i++) TSL_TRY(direct_plan(G->m[i]));
+  {
+    std::vector<int> todo;   // (members whose constraint set has not been looked at since the last detection: the first solve of a time step / adjoint step)
+    for (int i = 0; i < n; i++) { tsl_ctx* c = G->m[i]; if (!(c->ds.plan_valid && c->ds.cons_checked)) todo.push_back(i); }
+    if (todo.size() > 1) TSL_TRY(G->pool->run(todo, [&](int i) -> int { return direct_plan(G->m[i]); }));   // side by side: a plan is ~5 ms of host work
+    for (int i = 0; i < n; i++) TSL_TRY(direct_plan(G->m[i]));
+  }
   bool stale = !G->merged_valid;
   for (int i = 0; i < n; i++) stale |= G->seen_gen[i] != G->m[i]->ds.plan_gen;
   if (stale) {
