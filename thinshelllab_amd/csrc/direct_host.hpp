@@ -593,7 +593,8 @@ static int direct_apply(tsl_ctx* c, const double* r, double* z) {
 // back to back between one hipEvent pair on the engine stream.  cls: 0 the Gauss-Jordan inversions W = F11^-1 on the block-step path
 // (k_ds_pivot0 + k_ds_gj_step + k_ds_gj_finish), 1 k_ds_gemm mode 1 (Schur complements: product + gather of the children + store),
 // 2 G = W F12, 3 the inversions of the batches in the LDS kernel (k_ds_inv_small), 4 k_ds_gemv (all sweeps of one application),
-// 5 the inversions of the batches in the dataflow kernel (k_ds_gj_flow), 6 k_ds_extend_panels (the panels' share of the extend-add).
+// 5 the inversions of the batches in the dataflow kernel (k_ds_gj_flow), 6 k_ds_extend_panels (the panels' share of the extend-add),
+// 7 (probe, with "ds_bench_batch" b) the dataflow inversion of batch b next to G + Schur GEMM of batch b - 1 on a side stream (scripts/probe_overlap.py).
 // The replays overwrite the factors (marked invalid afterwards).
 // out: {us per launch, algorithmic flops per launch, algorithmic bytes per launch, launches per factorisation / application}
 static int direct_bench(tsl_ctx* c, int cls, int reps, double* out) {
@@ -629,6 +630,23 @@ static int direct_bench(tsl_ctx* c, int cls, int reps, double* out) {
         for (int l = 0; l < P.n_levels; l++) launches += 1 + (P.wl_own_ptr[l + 1] > P.wl_bnd_ptr[l]) + (l < P.n_levels - 1);
         for (const DsFrontDesc& f : P.fr) { bytes += 8.0 * ((double)f.p * f.p + 2.0 * (double)f.p * f.b); flops += 2.0 * ((double)f.p * f.p + 2.0 * (double)f.p * f.b); }
       }
+      return;
+    }
+    if (cls == 7) {   // probe: the dataflow inversion of batch "ds_bench_batch" on the engine stream NEXT TO G and the Schur GEMM of the batch before it on a side stream
+      const int bq = d.bench_batch;
+      if (bq < 1 || bq >= (int)P.batches.size()) return;
+      const DsBatch& bf = P.batches[bq];
+      const DsBatch& bg = P.batches[bq - 1];
+      DsFlowArgs fa;
+      if (!ds_flow_prepare(d, P, bf, true, fa, s) || bg.max_bp == 0) return;
+      (void)hipEventRecord(d.ev_ffork, s);
+      (void)hipStreamWaitEvent(d.fstream[0], d.ev_ffork, 0);
+      ds_flow_launch(s, D, bf.first, fa, d);
+      ds_launch_gemm(d.fstream[0], D, bg, 0, d.xcd_map, d.g32_below);
+      ds_launch_gemm(d.fstream[0], D, bg, 1, d.xcd_map);
+      (void)hipEventRecord(d.ev_fjoin[0], d.fstream[0]);
+      (void)hipStreamWaitEvent(s, d.ev_fjoin[0], 0);
+      if (count) launches++;
       return;
     }
     int bi = -1;
@@ -687,6 +705,11 @@ static int direct_bench(tsl_ctx* c, int cls, int reps, double* out) {
     }
   };
   if (d.ev0 == nullptr) { HIP_OK(hipEventCreate(&d.ev0)); HIP_OK(hipEventCreate(&d.ev1)); }
+  if (cls == 7) {
+    if (d.fstream[0] == nullptr)
+      for (int k = 0; k < DS_NSIDE; k++) { HIP_OK(hipStreamCreateWithFlags(&d.fstream[k], hipStreamNonBlocking)); HIP_OK(hipEventCreateWithFlags(&d.ev_fjoin[k], hipEventDisableTiming)); }
+    if (d.ev_ffork == nullptr) HIP_OK(hipEventCreateWithFlags(&d.ev_ffork, hipEventDisableTiming));
+  }
   issue(true);  // warm-up and accounting
   HIP_OK(hipEventRecord(d.ev0, s));
   for (int r = 0; r < reps; r++) issue(false);
