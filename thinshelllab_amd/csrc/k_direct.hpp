@@ -990,8 +990,19 @@ __global__ void __launch_bounds__(256) k_ds_inv_small(DsDev D, int lv0, int ls) 
   double* A = D.A + f.off;
   const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;
   const int lane = threadIdx.x & 63, w = threadIdx.x >> 6, lr = lane & 15, lk = lane >> 4;
-  for (int i = ty; i < pp; i += 8)
-    for (int j = tx; j < pp; j += 32) M[i * ls + j] = A[(size_t)i * f.ld + j];
+  // the block comes in with 16 loads of a lane in flight (four rows x four column groups per pass; pp is a multiple of 32, at most 128): one
+  // load per loop iteration and lane made the copy 64 dependent round trips, as long as the inversion itself
+  for (int i = ty; i < pp; i += 32) {
+    double v[4][4];
+#pragma unroll
+    for (int a = 0; a < 4; a++)
+#pragma unroll
+      for (int b = 0; b < 4; b++) v[a][b] = (b < nt) ? A[(size_t)(i + 8 * a) * f.ld + tx + 32 * b] : 0.0;
+#pragma unroll
+    for (int a = 0; a < 4; a++)
+#pragma unroll
+      for (int b = 0; b < 4; b++) if (b < nt) M[(i + 8 * a) * ls + tx + 32 * b] = v[a][b];
+  }
   __syncthreads();
   for (int k = 0; k < nt; k++) {
     const int k0 = k * DS_T;
@@ -1062,8 +1073,12 @@ __global__ void __launch_bounds__(256) k_ds_inv_small(DsDev D, int lv0, int ls) 
     }
     __syncthreads();
   }
-  for (int i = ty; i < pp; i += 8)
-    for (int j = tx; j < pp; j += 32) A[(size_t)i * f.ld + j] = M[i * ls + j];
+  for (int i = ty; i < pp; i += 32) {
+#pragma unroll
+    for (int a = 0; a < 4; a++)
+#pragma unroll
+      for (int b = 0; b < 4; b++) if (b < nt) A[(size_t)(i + 8 * a) * f.ld + tx + 32 * b] = M[(i + 8 * a) * ls + tx + 32 * b];
+  }
 }
 
 // ---- the two GEMMs of a front on the f64 matrix cores -------------------------------------------------------------------------
