@@ -720,7 +720,7 @@ static int assemble_enqueue_early(tsl_ctx* c, const double* pos, const double* p
   if (fork_t) HIP_OK(hipStreamWaitEvent(stt, c->ev_fork0, 0));
   TSL_TRY(contact_assemble(c, pos, spd, grad, st));   // (the longest chain: blocks 120-160 us, mask, diagonal, hinge gradients, gradient tail)
   if (c->n_tet) {
-    if (grad) hipLaunchKernelGGL(k_tet_grad, dim3(nblk(c->n_tet, 256)), dim3(256), 0, stt, TA, pos, grad);
+    if (grad) { hipLaunchKernelGGL(k_tet_grad, dim3(nblk(c->n_tet, 256)), dim3(256), 0, stt, TA, pos, grad); HIP_OK(hipEventRecord(c->ev_g2, stt)); }   // tet gradients staged
     // eigen-clamp of the element blocks warm-started from the previous assembly's eigenvectors ("tet_warm", on by default);
     // every 16th clamped assembly starts from the identity again (orthogonality of the accumulated rotations)
     double* vws = (c->tet_warm && spd != 0) ? c->tet_V.p : (double*)nullptr;   // (allocated and counted by assemble())
@@ -741,31 +741,32 @@ static int assemble_enqueue_early(tsl_ctx* c, const double* pos, const double* p
     if (spd == 2) hipLaunchKernelGGL((k_cloth_hess_face<true>), dim3(nblk(c->n_cface, 128)), dim3(128), 0, s, CA, c->cf_blk.p, pos, ref, c->quirk.p, spd, c->vals_full.p, frec);
     else hipLaunchKernelGGL((k_cloth_hess_face<false>), dim3(nblk(c->n_cface, 128)), dim3(128), 0, s, CA, c->cf_blk.p, pos, ref, c->quirk.p, spd, c->vals_full.p, frec);
   }
-  // element stream, second part (behind the mass diagonal and the normals)
+  // engine stream: the hinge blocks (records) right behind the face blocks -- round 5: they sat on the element stream behind the element blocks of the
+  // bodies (170 us) and held back both tails, the cloth gather and the gradient gather
+  if (c->n_hinge) hipLaunchKernelGGL(k_cloth_hess_hinge, dim3(nblk(c->n_hinge, 256)), dim3(256), 0, s, CA, c->hg_blk.p, pos, c->vals_full.p, gather ? c->cg_hrec.p : (double*)nullptr);
+  // element stream, second part (behind the mass diagonal)
   HIP_OK(hipStreamWaitEvent(stt, c->ev_fork, 0));
   const int nt_blk = c->n_cgblk - c->n_cgblk_cloth;
   if (c->n_tet && nt_blk > 0)   // the element records of the bodies -> their matrix blocks (the blocks of the bodies and of the cloth are disjoint)
     hipLaunchKernelGGL(k_cloth_gather, dim3(nblk(nt_blk, 256)), dim3(256), 0, stt, nt_blk, c->cg_base.p + c->n_cgblk_cloth, c->cg_ptr.p + c->n_cgblk_cloth, (const unsigned*)c->cg_ent.p,
                        c->n_hinge, c->n_cface, (const double*)c->cg_hrec.p, (const double*)c->cg_frec.p, (const double*)c->cg_trec.p, c->vals_full.p);
-  if (c->n_hinge) hipLaunchKernelGGL(k_cloth_hess_hinge, dim3(nblk(c->n_hinge, 256)), dim3(256), 0, stt, CA, c->hg_blk.p, pos, c->vals_full.p, gather ? c->cg_hrec.p : (double*)nullptr);
-  HIP_OK(hipEventRecord(c->ev_join2, stt));   // body blocks and hinge records
-  if (grad && c->n_cface) hipLaunchKernelGGL(k_cloth_grad_face, dim3(nblk(c->n_cface, 256)), dim3(256), 0, stt, CA, pos, grad);
-  if (grad) HIP_OK(hipEventRecord(c->ev_g2, stt));   // tet and face gradients staged
-  // contact stream, second part
+  HIP_OK(hipEventRecord(c->ev_join2, stt));   // body blocks
+  // contact stream, second part: hinge and face gradients (staging slots)
   if (grad) {
     if (fork_t) HIP_OK(hipStreamWaitEvent(st, c->ev_fork, 0));
     if (c->n_hinge) hipLaunchKernelGGL(k_cloth_grad_hinge, dim3(nblk(c->n_hinge, 256)), dim3(256), 0, st, CA, pos, ref, grad);
+    if (c->n_cface) hipLaunchKernelGGL(k_cloth_grad_face, dim3(nblk(c->n_cface, 256)), dim3(256), 0, st, CA, pos, grad);
   }
   // engine stream: cloth blocks, then the matrix tail
-  HIP_OK(hipStreamWaitEvent(s, c->ev_join2, 0));
   if (gather && c->n_cgblk_cloth > 0)
     hipLaunchKernelGGL(k_cloth_gather, dim3(nblk(c->n_cgblk_cloth, 256)), dim3(256), 0, s, c->n_cgblk_cloth, c->cg_base.p, c->cg_ptr.p, (const unsigned*)c->cg_ent.p, c->n_hinge, c->n_cface,
                        (const double*)c->cg_hrec.p, (const double*)c->cg_frec.p, (const double*)c->cg_trec.p, c->vals_full.p);
+  HIP_OK(hipStreamWaitEvent(s, c->ev_join2, 0));
   hipLaunchKernelGGL(k_mask_matrix, dim3(c->n_slices), dim3(256), 0, s, c->n_slices, c->slice_off.p, c->slice_len.p, c->colidx.p, c->fzmask.p, c->mdt2.p,
                      c->vals_full.p, c->vals.p, NV);
   // contact stream: the gradient tail
   if (grad) {
-    if (fork_t) HIP_OK(hipStreamWaitEvent(st, c->ev_g2, 0));
+    if (fork_t && c->n_tet) HIP_OK(hipStreamWaitEvent(st, c->ev_g2, 0));
     hipLaunchKernelGGL(k_vertex_gather, dim3(nblk(NV, 256)), dim3(256), 0, st, NV, (const int*)c->vg_ptr.p, (const int*)c->vg_idx.p, (const double*)c->vg_stage.p, 0, c->vg_ns, grad);
     if (c->nc > 0) hipLaunchKernelGGL(k_contact_row_gather, dim3(nblk((long)NV * 64, 256)), dim3(256), 0, st, NV, (const int*)c->rowpos.p, (const int*)c->cr_ptr.p, (const int*)c->cr_ent.p,
                                       (const double*)c->c_G.p, grad);
