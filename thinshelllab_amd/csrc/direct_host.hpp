@@ -143,6 +143,37 @@ static bool ds_flow_prepare(DirectSolver& d, const DirectPlan& P, const DsBatch&
   a.epoch = ++d.flow_epoch;
   return true;
 }
+// The dataflow launches of batch b (empty: not on this path).  A batch that passes every test but the residency -- more fronts than DS_FLOW_MAXF or
+// more workgroups than the device holds -- is cut into up to DS_FLOW_PIECES consecutive pieces that run ONE AFTER THE OTHER on the batch's stream
+// (round 5, cfg4 level 0: 6 fronts of 160 pivots and 188 of 128 took five launches of k_ds_gj_step at 22-73 us each, every one reading and
+// writing all pivot blocks: 290 us; as two dataflow launches the blocks are read and written once).
+#define DS_FLOW_PIECES 4
+static std::vector<DsBatch> ds_flow_pieces(DirectSolver& d, const DirectPlan& P, const DsBatch& b, bool flow_free, hipStream_t s) {
+  std::vector<DsBatch> out;
+  if (!flow_free) return out;
+  if (ds_flow_eligible(d, P, b, s)) { out.push_back(b); return out; }
+  if (ds_use_small(d, b) || b.count < 2) return out;   // (the LDS kernel takes it / a single front that is too large)
+  DsBatch one = b;
+  one.count = 1;
+  if (!ds_flow_eligible(d, P, one, s) || d.flow_cap <= 0) return out;   // (switch, capture, token, a first front that fits: everything but the size of the batch)
+  int start = 0;
+  while (start < b.count) {
+    DsBatch pc{};
+    pc.first = b.first + start; pc.level = b.level; pc.act_off = b.act_off;
+    long wgs = 0;
+    while (start + pc.count < b.count && pc.count < DS_FLOW_MAXF) {
+      const DsFrontDesc& f = P.fr[P.level_sn[pc.first + pc.count]];
+      const long ns = (f.pp / DS_T + DS_FLOW_B - 1) / DS_FLOW_B;
+      if (pc.count > 0 && wgs + ns * ns > d.flow_cap) break;
+      wgs += ns * ns; pc.count++;
+      pc.max_pp = std::max(pc.max_pp, f.pp); pc.max_bp = std::max(pc.max_bp, f.bp); pc.max_ld = std::max(pc.max_ld, f.ld);
+    }
+    if (pc.max_pp < 2 * DS_T || !ds_flow_eligible(d, P, pc, s) || (int)out.size() == DS_FLOW_PIECES) { out.clear(); return out; }
+    out.push_back(pc);
+    start += pc.count;
+  }
+  return out;
+}
 // The launch must be resident as a whole (its workgroups wait for each other's flags).  Inside ONE context the host guarantees that by
 // running one such launch per level.  ACROSS contexts and processes the device's dataflow token does (ds_flow_token_*, tsl_ctx_create): the
 // context that holds it is the only one on the device that launches this kernel, for as long as it lives; every other context runs the same
@@ -469,8 +500,13 @@ static int direct_factor(tsl_ctx* c, int stop_sn = -1, const char* dump_path = n
   auto run_batch = [&](const DsBatch& b, hipStream_t bs, bool& flow_free) {
     const int lv0 = b.first, nf = b.count;
     const int tp = b.max_pp / DS_T, tb = b.max_bp / DS_T;
-    DsFlowArgs fa;
-    if (ds_flow_prepare(d, P, b, flow_free, fa, bs)) { ds_flow_launch(bs, D, lv0, fa, d); d.n_flow++; flow_free = false; }
+    bool flowed = false;
+    for (const DsBatch& pc : ds_flow_pieces(d, P, b, flow_free, bs)) {
+      DsFlowArgs fa;
+      if (!ds_flow_prepare(d, P, pc, true, fa, bs)) { if (flowed) d.flow = 0; break; }   // (out of memory for the exchange buffers: the whole batch below -- after a piece went out, the switch goes off and the abort path redoes the factorisation)
+      ds_flow_launch(bs, D, pc.first, fa, d); d.n_flow++; flowed = true; flow_free = false;
+    }
+    if (flowed) {}
     else if (ds_use_small(d, b)) hipLaunchKernelGGL(k_ds_inv_small, dim3(nf), dim3(256), ds_small_lds(b.max_pp), bs, D, lv0, b.max_pp + 1);
     else {
       hipLaunchKernelGGL(k_ds_pivot0, dim3(nf), dim3(256), 0, bs, D, lv0);
@@ -669,12 +705,11 @@ static int direct_bench(tsl_ctx* c, int cls, int reps, double* out) {
         }
       } else if (cls == 0 || cls == 3 || cls == 5) {   // W = F11^-1: cls 0 the batches on the block-step path (pivot0 + block steps + finish), cls 3 the batches in the LDS kernel, cls 5 those in the dataflow kernel
         bool flow_free = true;   // (one dataflow launch per level: the first batch of the level that can take it)
-        for (int q = 0; q < bi; q++) if (P.batches[q].level == b.level && ds_flow_eligible(d, P, P.batches[q], s)) flow_free = false;
-        DsFlowArgs fa;
-        const bool flow = ds_flow_prepare(d, P, b, flow_free, fa, s);
-        const int mine = flow ? 5 : (ds_use_small(d, b) ? 3 : 0);   // the class direct_factor runs this batch in
+        for (int q = 0; q < bi; q++) if (P.batches[q].level == b.level && !ds_flow_pieces(d, P, P.batches[q], true, s).empty()) flow_free = false;
+        const std::vector<DsBatch> pieces = ds_flow_pieces(d, P, b, flow_free, s);
+        const int mine = !pieces.empty() ? 5 : (ds_use_small(d, b) ? 3 : 0);   // the class direct_factor runs this batch in
         if (mine != cls) continue;
-        if (cls == 5) { ds_flow_launch(s, D, lv0, fa, d); if (count) launches++; }
+        if (cls == 5) { for (const DsBatch& pc : pieces) { DsFlowArgs fa; if (ds_flow_prepare(d, P, pc, true, fa, s)) { ds_flow_launch(s, D, pc.first, fa, d); if (count) launches++; } } }
         else if (cls == 3) { hipLaunchKernelGGL(k_ds_inv_small, dim3(nf), dim3(256), ds_small_lds(b.max_pp), s, D, lv0, b.max_pp + 1); if (count) launches++; }
         else {
           hipLaunchKernelGGL(k_ds_pivot0, dim3(nf), dim3(256), 0, s, D, lv0);

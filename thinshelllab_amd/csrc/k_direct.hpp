@@ -693,7 +693,7 @@ __global__ void __launch_bounds__(256) k_ds_gj_finish(DsDev D, int lv0) {
 // is shared by the B tiles of a column).
 // The launch must be resident as a whole (the host checks workgroups <= CUs x occupancy and runs it only for a batch alone on its level);
 // a flag that does not come within DS_FLOW_SPINS polls raises bad[DS_FLOW_ABORT] and lets every workgroup run out (the host reports it).
-#define DS_FLOW_MAXF 64
+#define DS_FLOW_MAXF 128
 #define DS_FLOW_ABORT 5
 #define DS_FLOW_SPINS (1 << 22)
 #define DS_FLOW_B 2
