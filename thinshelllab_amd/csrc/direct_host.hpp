@@ -92,7 +92,7 @@ static void ds_launch_level_start(tsl_ctx* c, hipStream_t s, const DsDev& D, int
   const int nb = P.blk_lptr[l + 1] - P.blk_lptr[l];
   const long nt = (long)nb * 9 + (long)nf * DS_T;
   hipLaunchKernelGGL(k_ds_assemble_level, dim3(ds_nblk(nt, 256)), dim3(256), 0, s, P.blk_lptr[l], nb, (const int*)d.blk_q.p, (const double*)c->vals.p, (const long long*)d.blk_dst.p,
-                     (const int*)d.blk_ld.p, lv0, nf, d.frl.p, d.arena.p);
+                     (const int*)d.blk_ld.p, lv0, nf, d.frl.p, d.arena.p, l == 0 ? 1 : 0);
   const int ng = c->nc > 0 ? P.cgr_lptr[l + 1] - P.cgr_lptr[l] : 0;
   if (ng > 0) hipLaunchKernelGGL(k_ds_assemble_contacts_level, dim3(ds_nblk((long)ng * 64, 256)), dim3(256), 0, s, P.cgr_lptr[l], ng, (const int*)d.cgr_ptr.p, (const int*)d.cgr_ent.p,
                                  (const long long*)d.cgr_dst.p, (const int*)d.cgr_ld.p, (const double*)c->c_H.p, d.arena.p);

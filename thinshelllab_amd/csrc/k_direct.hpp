@@ -67,12 +67,15 @@ __global__ void k_ds_rownorm(int NV, const int* __restrict__ slice_off, const in
 //   * contact blocks (their own launch behind it, only on levels that have any): 16 vertex-pair sub-blocks per constraint, grouped by
 //     destination on the host.
 __global__ void k_ds_assemble_level(int i0, int nblk, const int* __restrict__ src, const double* __restrict__ vals, const long long* __restrict__ dst, const int* __restrict__ dld,
-                                    int lv0, int nf, const DsFrontDesc* __restrict__ frl, double* __restrict__ A) {
+                                    int lv0, int nf, const DsFrontDesc* __restrict__ frl, double* __restrict__ A, int cleared) {
   long t = (long)blockIdx.x * blockDim.x + threadIdx.x;
   if (t < (long)nblk * 9) {   // (src / dst / dld: the level-ordered block list of the plan, three independent loads per entry)
     const long i = i0 + t / 9;
     const int e = (int)(t % 9);
-    A[dst[i] + (long long)(e / 3) * dld[i] + e % 3] += vals[(size_t)src[i] + 64 * e];   // one writer per entry
+    double* a = &A[dst[i] + (long long)(e / 3) * dld[i] + e % 3];
+    const double v = vals[(size_t)src[i] + 64 * e];
+    // one writer per entry; the panels of the leaf level were CLEARED, not gathered: 0 + v without reading the zero back (75 of the launch's 240 MB)
+    *a = cleared ? 0.0 + v : *a + v;
     return;
   }
   t -= (long)nblk * 9;
