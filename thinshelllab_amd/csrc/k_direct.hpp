@@ -1038,16 +1038,26 @@ __global__ void __launch_bounds__(256) k_ds_inv_small(DsDev D, int lv0, int ls) 
           for (int r = 0; r < 4; r++) M[(k0 + 16 * a + lk + 4 * r) * ls + j0 + 16 * b + lr] = acc[a][b][r];
     }
     __syncthreads();
-    // A_ij -= A_iK R'_j, A_iK = -A_iK P for the row chunks i != k
-    for (int i = w; i < nt; i += 4) {
-      if (i == k) continue;
-      const int i0 = i * DS_T;
-      double c0[DS_T / 4], c1[DS_T / 4];
+    // A_ij -= A_iK R'_j, A_iK = -A_iK P for the row chunks i != k.  The (nt - 1) nt tiles go round the four waves one by one (a wave per row chunk left
+    // one or two waves idle at three or four chunks and gave the busy ones nt tiles each): every wave first takes the column-panel fragments of ITS
+    // tiles into registers, then -- behind a barrier, tile (i, k) is overwritten by whoever owns it -- forms and stores them.
+    const int nit = (nt - 1) * nt;
+    double c0[3][DS_T / 4], c1[3][DS_T / 4];   // (nt <= 4: at most three tiles per wave)
 #pragma unroll
-      for (int kk = 0; kk < DS_T / 4; kk++) { c0[kk] = M[(i0 + lr) * ls + k0 + 4 * kk + lk]; c1[kk] = M[(i0 + 16 + lr) * ls + k0 + 4 * kk + lk]; }
-      __builtin_amdgcn_wave_barrier();
-      for (int j = 0; j < nt; j++) {
-        const int j0 = j * DS_T;
+    for (int q = 0; q < 3; q++) {
+      const int t = w + 4 * q;
+      if (t < nit) {
+        const int ii = t / nt, i0 = (ii < k ? ii : ii + 1) * DS_T;
+#pragma unroll
+        for (int kk = 0; kk < DS_T / 4; kk++) { c0[q][kk] = M[(i0 + lr) * ls + k0 + 4 * kk + lk]; c1[q][kk] = M[(i0 + 16 + lr) * ls + k0 + 4 * kk + lk]; }
+      }
+    }
+    __syncthreads();
+#pragma unroll
+    for (int q = 0; q < 3; q++) {
+      const int t = w + 4 * q;
+      if (t < nit) {
+        const int ii = t / nt, j = t - ii * nt, i0 = (ii < k ? ii : ii + 1) * DS_T, j0 = j * DS_T;
         // the product is formed from zero and subtracted afterwards -- A_ij - (A_iK R'_j), -(A_iK P) -- like k_ds_gj_step / k_ds_gj_flow form it:
         // the three inversion paths give the same bits (accumulating onto the old entry rounds differently)
         ds_d4 acc[2][2];
@@ -1058,10 +1068,10 @@ __global__ void __launch_bounds__(256) k_ds_inv_small(DsDev D, int lv0, int ls) 
 #pragma unroll
         for (int kk = 0; kk < DS_T / 4; kk++) {   // row K of M holds R'_j for j != k and P itself at j == k
           const double b0 = M[(k0 + 4 * kk + lk) * ls + j0 + lr], b1 = M[(k0 + 4 * kk + lk) * ls + j0 + 16 + lr];
-          acc[0][0] = __builtin_amdgcn_mfma_f64_16x16x4f64(c0[kk], b0, acc[0][0], 0, 0, 0);
-          acc[0][1] = __builtin_amdgcn_mfma_f64_16x16x4f64(c0[kk], b1, acc[0][1], 0, 0, 0);
-          acc[1][0] = __builtin_amdgcn_mfma_f64_16x16x4f64(c1[kk], b0, acc[1][0], 0, 0, 0);
-          acc[1][1] = __builtin_amdgcn_mfma_f64_16x16x4f64(c1[kk], b1, acc[1][1], 0, 0, 0);
+          acc[0][0] = __builtin_amdgcn_mfma_f64_16x16x4f64(c0[q][kk], b0, acc[0][0], 0, 0, 0);
+          acc[0][1] = __builtin_amdgcn_mfma_f64_16x16x4f64(c0[q][kk], b1, acc[0][1], 0, 0, 0);
+          acc[1][0] = __builtin_amdgcn_mfma_f64_16x16x4f64(c1[q][kk], b0, acc[1][0], 0, 0, 0);
+          acc[1][1] = __builtin_amdgcn_mfma_f64_16x16x4f64(c1[q][kk], b1, acc[1][1], 0, 0, 0);
         }
 #pragma unroll
         for (int a = 0; a < 2; a++)
