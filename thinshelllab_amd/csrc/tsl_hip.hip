@@ -700,11 +700,14 @@ static int assemble_enqueue(tsl_ctx* c, const double* pos, const double* prev, c
 // STORE (staging slots of the gradient, element records of the matrix), so the three streams depend on each other in few places, and the
 // HOST paces an assembly -- it starts right after the line search's energy was read back, every queue empty, and issues ~35 launches of
 // 5-120 us at 6-8 us each.  Issue order = priority order: the long kernel of every chain first, then the short ones.
-//   element stream:  tet gradients, tet blocks (110 us) | after the mass diagonal: body blocks gathered, hinge blocks (records), face gradients
-//   engine stream:   clear, normals, vertex terms, quirk, face blocks (90 us) | after the hinge records: cloth blocks gathered, mask, block-Jacobi
-//   contact stream:  contact blocks (120 us), mask, diagonal | hinge gradients | after the other gradients: vertex gather, contact rows, mask
+//   element stream:  tet gradients, tet blocks (110 us) | after the mass diagonal: body blocks gathered
+//   engine stream:   clear, normals, vertex terms, quirk, face blocks (90 us), hinge blocks (records, 30 us), cloth blocks gathered | after the body blocks: mask,
+//                    block-Jacobi
+//   contact stream:  contact blocks (120 us), mask, diagonal | hinge gradients, face gradients | after the tet gradients: vertex gather, contact rows, mask
 // (round 4 traces, cfg4: the engine stream's first cloth kernel started 200 us after the assembly's first launch and its chain -- face blocks,
-// hinge blocks, gather, then the gradient tail and the matrix tail one after the other -- ended 580 us after the energy read-back; now ~440.)
+// hinge blocks, gather, then the gradient tail and the matrix tail one after the other -- ended 580 us after the energy read-back; then ~440.  Round 5: the
+// hinge blocks and the face gradients sat on the element stream behind the bodies' element blocks and held back both gathers: moved, -1.8 % of a step.
+// A fourth stream for the gradient chain and the engine stream's head issued first were measured slower: DESIGN.md 9b.)
 static int assemble_enqueue_early(tsl_ctx* c, const double* pos, const double* prev, const double* vel, const double* ref, int spd, double* grad, int tet_warm_flag) {
   hipStream_t s = c->stream, st = c->side;
   const bool fork_t = c->n_tet > 0 && c->nc > 0;
