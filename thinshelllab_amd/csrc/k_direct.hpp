@@ -1308,21 +1308,48 @@ __global__ void __launch_bounds__(256) k_ds_extend_panels(DsDev D, int lv0, int 
       for (int k = 0; k < 3; k++)
 #pragma unroll
         for (int u = 0; u < DS_XU; u++) v[k][u] = 0.0;
-      for (unsigned long long m = mask; m != 0; m &= m - 1) {   // ascending child order: the fixed summation order
-        const int q = __builtin_ctzll(m);
-        const int ci = __builtin_amdgcn_readlane(my_ci, q), off = __builtin_amdgcn_readlane(my_off, q), cbp = __builtin_amdgcn_readlane(my_bp, q);
+      // ascending child order: the fixed summation order.  The children that reach the vertex are taken TWO at a time (a front of the upper levels has
+      // two): the table look-ups of both, then the entries of both, then the sums in order -- two dependent round trips per pass instead of four
+      auto child = [&](int q, int& ci, const int*& pm, const double*& S0, int& cbp) {
+        ci = __builtin_amdgcn_readlane(my_ci, q);
+        const int off = __builtin_amdgcn_readlane(my_off, q);
+        cbp = __builtin_amdgcn_readlane(my_bp, q);
         const long long so = ((long long)__builtin_amdgcn_readlane((int)(my_soff >> 32), q) << 32) | (unsigned)__builtin_amdgcn_readlane((int)my_soff, q);
-        const int* pm = D.pmap + off;
-        const double* S0 = D.S + so + (size_t)ci * cbp;
-        int cj[DS_XU];
+        pm = D.pmap + off;
+        S0 = D.S + so + (size_t)ci * cbp;
+      };
+      unsigned long long m = mask;
+      while (m != 0) {
+        const int q0 = __builtin_ctzll(m);
+        m &= m - 1;
+        const bool two = m != 0;
+        const int q1 = two ? __builtin_ctzll(m) : q0;
+        if (two) m &= m - 1;
+        int ci0, ci1, cbp0, cbp1;
+        const int *pm0, *pm1;
+        const double *Sa, *Sb;
+        child(q0, ci0, pm0, Sa, cbp0);
+        child(q1, ci1, pm1, Sb, cbp1);
+        int cja[DS_XU], cjb[DS_XU];
 #pragma unroll
-        for (int u = 0; u < DS_XU; u++) { const int j = j0 + 64 * u + lane; cj[u] = j < c1 ? pm[j] : -1; }
+        for (int u = 0; u < DS_XU; u++) { const int j = j0 + 64 * u + lane; cja[u] = j < c1 ? pm0[j] : -1; cjb[u] = (two && j < c1) ? pm1[j] : -1; }
+        double sa[3][DS_XU], sb[3][DS_XU];
 #pragma unroll
-        for (int u = 0; u < DS_XU; u++)
-          if (cj[u] >= 0) {
+        for (int u = 0; u < DS_XU; u++) {
 #pragma unroll
-            for (int k = 0; k < 3; k++) v[k][u] += S0[(size_t)k * cbp + cj[u]];
+          for (int k = 0; k < 3; k++) { sa[k][u] = cja[u] >= 0 ? Sa[(size_t)k * cbp0 + cja[u]] : 0.0; sb[k][u] = cjb[u] >= 0 ? Sb[(size_t)k * cbp1 + cjb[u]] : 0.0; }
+        }
+#pragma unroll
+        for (int u = 0; u < DS_XU; u++) {
+          if (cja[u] >= 0) {
+#pragma unroll
+            for (int k = 0; k < 3; k++) v[k][u] += sa[k][u];
           }
+          if (cjb[u] >= 0) {
+#pragma unroll
+            for (int k = 0; k < 3; k++) v[k][u] += sb[k][u];
+          }
+        }
       }
 #pragma unroll
       for (int u = 0; u < DS_XU; u++) {
