@@ -501,10 +501,16 @@ static int direct_factor(tsl_ctx* c, int stop_sn = -1, const char* dump_path = n
     const int lv0 = b.first, nf = b.count;
     const int tp = b.max_pp / DS_T, tb = b.max_bp / DS_T;
     bool flowed = false;
-    for (const DsBatch& pc : ds_flow_pieces(d, P, b, flow_free, bs)) {
-      DsFlowArgs fa;
-      if (!ds_flow_prepare(d, P, pc, true, fa, bs)) { if (flowed) d.flow = 0; break; }   // (out of memory for the exchange buffers: the whole batch below -- after a piece went out, the switch goes off and the abort path redoes the factorisation)
-      ds_flow_launch(bs, D, pc.first, fa, d); d.n_flow++; flowed = true; flow_free = false;
+    {
+      const std::vector<DsBatch> pieces = ds_flow_pieces(d, P, b, flow_free, bs);
+      std::vector<DsFlowArgs> fas(pieces.size());
+      bool ready = !pieces.empty();
+      for (size_t i = 0; ready && i < pieces.size(); i++) ready = ds_flow_prepare(d, P, pieces[i], true, fas[i], bs);   // (every piece's buffers before any piece goes out:
+                                                                                                                           // a batch is inverted on ONE path)
+      if (ready) {
+        for (size_t i = 0; i < pieces.size(); i++) { ds_flow_launch(bs, D, pieces[i].first, fas[i], d); d.n_flow++; }
+        flowed = true; flow_free = false;
+      }
     }
     if (flowed) {}
     else if (ds_use_small(d, b)) hipLaunchKernelGGL(k_ds_inv_small, dim3(nf), dim3(256), ds_small_lds(b.max_pp), bs, D, lv0, b.max_pp + 1);
