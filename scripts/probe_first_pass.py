@@ -25,6 +25,10 @@ x1, st1 = ctx.solve(b.clone())
 ctx.set_param("cg_tol", 1e-10)
 bn = b.cpu().numpy(); r = bn - H @ x1.cpu().numpy()
 print("first pass: rel residual", np.linalg.norm(r) / np.linalg.norm(bn), st1)
+try:
+    print("tiles through the guarded form in that factorisation:", ctx.direct_counters().get("tiles_guarded"), " perturbed pivots:", ctx.direct_info()["perturbed_pivots"])
+except Exception as e:
+    print(e)
 rv = (r.reshape(-1, 3) ** 2).sum(1)
 c = s.cloths[0]
 g = rv[c.offset:c.offset + c.NV].reshape(N + 1, N + 1)

@@ -258,10 +258,10 @@ class TslContext:
         return dict(zip(keys, [float(v) for v in out]))
 
     def direct_counters(self):
-        out = (C.c_double * 12)()
-        check(self.L.tsl_direct_counters(self.h, out, 12), "tsl_direct_counters")
+        out = (C.c_double * 13)()
+        check(self.L.tsl_direct_counters(self.h, out, 13), "tsl_direct_counters")
         keys = ("flow_launches", "flow_aborts", "plan_cache_hits", "panel_bytes", "schur_bytes", "g_bytes", "schur_entries", "plans_parked",
-                "berr_seen", "berr_accepted", "berr_max", "berr_rel_max")
+                "berr_seen", "berr_accepted", "berr_max", "berr_rel_max", "tiles_guarded")
         return dict(zip(keys, [float(v) for v in out]))
 
     def bench_spmv(self, variant=20, reps=500):

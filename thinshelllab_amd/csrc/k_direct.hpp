@@ -116,19 +116,24 @@ __global__ void __launch_bounds__(256) k_ds_assemble_contacts_level(int g0, int 
 }
 
 // ---- blocked Gauss-Jordan on the top block rows ---------------------------------------------------------------------------
-// In-place Gauss-Jordan inversion of one DS_T x DS_T tile in LDS by the whole 256-thread workgroup with 4 x 4 BLOCK pivots on the
-// matrix cores: wave (wi, wj) keeps its 16 x 16 quadrant in the accumulator layout of v_mfma_f64_16x16x4_f64 (lane l, register r
-// = element (16 wi + (l >> 4) + 4 r, 16 wj + (l & 15))), so that the rank-4 update of a block step is ONE matrix instruction per
-// wave; per step the four pivot rows and columns go through double-buffered LDS panels (one barrier per step) and every lane inverts
-// the 4 x 4 pivot block itself.  Eight dependent steps instead of 32 scalar pivots: the tile inversion sits on the critical path
-// of every block step of the factorisation (measured inside a kernel: 10.7 us for the scalar-pivot version -- one LDS round
-// trip, one reciprocal and a chain of selects per pivot -- and for a 4 x 4-block version on the vector units alike).
-// Static pivoting: a scalar pivot that fell below tol (DsDev.piv_tol, 1e-8) x its own scale -- the diagonal entry the tile came in
-// with -- is replaced by that bound and counted in bad[cls]; the refinement outside absorbs the perturbation.  (NOT measured against
-// the largest entry of the tile: contact blocks on degenerate triangles put 1e13 next to the m/dt^2 = 0.3 of a frozen dof, both exact.)  All 256 threads must call
-// it; the tile is complete in LDS on return (the function ends with a barrier).
+// In-place Gauss-Jordan inversion of one DS_T x DS_T tile in LDS by the 256-thread workgroup with 4 x 4 BLOCK pivots on the matrix cores:
+// eight dependent block steps instead of 32 scalar pivots.  The tile inversion sits on the critical path of every block step of the
+// factorisation (it is half of a step of the dataflow chains), so its form was chosen with device-clock measurements inside a kernel
+// (scripts/micro/inv_bench.hip, scripts/micro/lat_probe.hip; history in DESIGN 9c):
+//   form 1  every wave a quadrant, every lane eliminates the 4 x 4 pivot block itself, two matrix-core products per step        5.6 us
+//   form 2  the same with a per-lane cofactor inverse and one product per step                                                  4.9 us
+//   form 4  wave-specialised: two workers own 16 rows each, a scout forms the next pivot block and its inverse one step ahead   4.4 us
+//   form 5  ONE wave, whole tile in registers, no barrier: a v_mfma_f64 blocks its wave for 32 cycles and nothing of the same
+//           wave overlaps with it -- six products + ~70 vector instructions per step in one instruction stream                 3.7 us
+//   form 6  form 4 with the scout's 4 x 4 inverse spread over the lanes and no branch inside the steps (below)                  3.3 us
+// Forms 6 (ds_invert_tile) and 4 (ds_invert_tile_guarded, the path of tiles that fail the static-pivot rule) are kept.
+// Static pivoting: a scalar pivot that fell below tol (DsDev.piv_tol) x its own scale -- the diagonal entry the tile came in with -- is
+// replaced by that bound and counted in bad[cls]; the refinement outside absorbs the perturbation.  (NOT measured against the largest entry
+// of the tile: contact blocks on degenerate triangles put 1e13 next to the m/dt^2 = 0.3 of a frozen dof, both exact.)  All 256 threads must
+// call it; the tile is complete in LDS on return (the function ends with a barrier).
 #define DS_PB 4
 #define DS_BADLOG 64
+#define DS_REDO 6   // bad[DS_REDO]: tiles of the last factorisation that went through the guarded form
 #define DS_CLS(f) ((f).pp > 512 ? 3 : ((f).pp > 128 ? 2 : 1))
 TSL_DEV double ds_rcp(double x) {
   double r = __builtin_amdgcn_rcp(x);   // hardware estimate (~2^-27 relative) + one Newton step: 2^-53 without the IEEE division sequence
@@ -146,235 +151,46 @@ TSL_DEV double ds_readlane_d(double v, int l) {
   const int lo = __builtin_amdgcn_readlane(__double2loint(v), l), hi = __builtin_amdgcn_readlane(__double2hiint(v), l);
   return __hiloint2double(hi, lo);
 }
-TSL_DEV void ds_invert_tile_wg(double* __restrict__ T, int ldt, int* __restrict__ bad, int cls, int tag, double tol) {   // T[row * ldt + col]
-  __shared__ double rowp[2][DS_PB][DS_T], colp[2][DS_PB][DS_T + 1], red[4], dg0[DS_T];
-  const int lane = threadIdx.x & 63, w = threadIdx.x >> 6, wi = w >> 1, wj = w & 1, lr = lane & 15, lk = lane >> 4;
-  ds_d4 acc;
-  double amax = 0.0;
-#pragma unroll
-  for (int r = 0; r < 4; r++) {
-    acc[r] = T[(16 * wi + lk + 4 * r) * ldt + 16 * wj + lr];
-    amax = fmax(amax, fabs(acc[r]));
-    if (wi == wj && lk + 4 * r == lr) dg0[16 * wi + lr] = fabs(acc[r]);   // the diagonal on entry: the scale a pivot is measured against
-  }
-  amax = wave_max(amax);
-  if (lane == 0) red[w] = amax;
-  __syncthreads();
-  const double tmax = fmax(fmax(red[0], red[1]), fmax(red[2], red[3]));
-  const double floor0 = fmax(tmax * 1e-20, 1e-300);
-  const double mydg = dg0[lane & 31];   // lane l keeps entry diagonal l: the pivot loop fetches its four with v_readlane (no LDS traffic, two registers)
-  unsigned badmask = 0;   // perturbed pivots of the tile
-#pragma unroll
-  for (int s = 0; s < DS_T / DS_PB; s++) {
-    const int buf = s & 1, p0 = DS_PB * s;
-    const int wp = p0 >> 4;             // quadrant row / column that holds the pivots
-    const int rp = (p0 & 15) >> 2;      // their accumulator register (rows) ...
-    const int lc = p0 & 15;             // ... and first lane column (columns)
-    // pivot rows: local row (p0 & 15) + j sits in lanes lk == j, register rp
-    if (wi == wp) rowp[buf][lk][16 * wj + lr] = acc[rp];
-    if (wj == wp && lr >= lc && lr < lc + DS_PB) {
-#pragma unroll
-      for (int r = 0; r < 4; r++) colp[buf][lr - lc][16 * wi + lk + 4 * r] = acc[r];
-    }
-    __syncthreads();
-    // inverse of the 4 x 4 pivot block (every lane, registers).  Everything below is written without data-dependent control
-    // flow: the compiler turned conditional loads / updates into hundreds of exec-mask branches (4 x slower than this form).
-    double d[DS_PB][DS_PB];
-#pragma unroll
-    for (int i = 0; i < DS_PB; i++)
-#pragma unroll
-      for (int j = 0; j < DS_PB; j++) d[i][j] = rowp[buf][i][p0 + j];
-    double thr[DS_PB];
-#pragma unroll
-    for (int p = 0; p < DS_PB; p++) thr[p] = fmax(tol * ds_readlane_d(mydg, p0 + p), floor0);
-#pragma unroll
-    for (int p = 0; p < DS_PB; p++) {
-      const double piv0 = d[p][p];
-      const double tiny = thr[p];
-      const bool small = !(fabs(piv0) >= tiny);
-      const double piv = small ? copysign(tiny, piv0) : piv0;
-      badmask |= small ? (1u << (p0 + p)) : 0u;
-      const double ip = ds_rcp(piv);
-#pragma unroll
-      for (int j = 0; j < DS_PB; j++) d[p][j] = (j == p) ? ip : d[p][j] * ip;
-#pragma unroll
-      for (int i = 0; i < DS_PB; i++) {
-        if (i == p) continue;
-        const double f = d[i][p];
-#pragma unroll
-        for (int j = 0; j < DS_PB; j++) d[i][j] = (j == p) ? -f * ip : fma(-f, d[p][j], d[i][j]);
-      }
-    }
-    // row lk of Dinv (lk = the lane's k index of the matrix-core operands), then (Dinv R)[lk][column of this lane]
-    const bool k1 = lk == 1, k2 = lk == 2, k3 = lk == 3;
-    double drow[DS_PB];
-#pragma unroll
-    for (int j = 0; j < DS_PB; j++) drow[j] = ds_sel4(k1, k2, k3, d[0][j], d[1][j], d[2][j], d[3][j]);
-    double bop = drow[0] * rowp[buf][0][16 * wj + lr] + drow[1] * rowp[buf][1][16 * wj + lr] + drow[2] * rowp[buf][2][16 * wj + lr] + drow[3] * rowp[buf][3][16 * wj + lr];
-    asm volatile("" : "+v"(bop));   // keep the product out of the lane-dependent selects below (the compiler otherwise sinks it into exec-mask branches)
-    const double aop = -colp[buf][lk][16 * wi + lr];
-    const ds_d4 upd = __builtin_amdgcn_mfma_f64_16x16x4f64(aop, bop, acc, 0, 0, 0);   // acc - C (Dinv R)
-    // fix-ups: pivot rows become Dinv R (Dinv inside the pivot columns), pivot columns become -C Dinv.  The latter is a second
-    // matrix-core product with the operand Dinv[lk][mc] in the four pivot-column lanes and zero elsewhere (one instruction instead of
-    // 16 multiply-adds, 16 LDS reads and a column select of Dinv per lane: the block steps are bound by their instruction stream)
-    const bool col_in = wj == wp && lr >= lc && lr < lc + DS_PB;
-    const int mc = (lr - lc) & 3;   // pivot column index of this lane (meaningful if col_in)
-    const bool m1 = mc == 1, m2 = mc == 2, m3 = mc == 3;
-    const double dsel = ds_sel4(m1, m2, m3, drow[0], drow[1], drow[2], drow[3]);   // Dinv[lk][mc]
-    const double bop2 = col_in ? dsel : 0.0;
-    const ds_d4 pc = __builtin_amdgcn_mfma_f64_16x16x4f64(aop, bop2, ds_d4{0.0, 0.0, 0.0, 0.0}, 0, 0, 0);   // -C Dinv in the pivot columns
-#pragma unroll
-    for (int r = 0; r < 4; r++) {
-      const bool row_in = wi == wp && r == rp;   // local row lk + 4 r with r == rp: pivot row j = lk
-      const double v_row = col_in ? dsel : bop;
-      const double v_else = col_in ? pc[r] : upd[r];
-      acc[r] = row_in ? v_row : v_else;
-    }
-  }
-#pragma unroll
-  for (int r = 0; r < 4; r++) T[(16 * wi + lk + 4 * r) * ldt + 16 * wj + lr] = acc[r];
-  if (threadIdx.x == 0 && badmask) {
-    atomicAdd(bad + cls, __popc(badmask));
-    const int slot = atomicAdd(bad + 4, 1);   // log of the first perturbed tiles (verbose >= 2)
-    if (slot < DS_BADLOG) { int* L = bad + 8 + 4 * slot; L[0] = tag; L[1] = (int)badmask; L[2] = 0; L[3] = __float_as_int((float)tmax); }
-  }
-  __syncthreads();
+template <int CTRL>
+TSL_DEV double ds_dpp(double v) {   // v of another lane of the same row of 16 lanes (DPP control CTRL), both halves
+  const int lo = __builtin_amdgcn_update_dpp(0, __double2loint(v), CTRL, 0xF, 0xF, true);
+  const int hi = __builtin_amdgcn_update_dpp(0, __double2hiint(v), CTRL, 0xF, 0xF, true);
+  return __hiloint2double(hi, lo);
 }
-
-// Second form of the tile inversion (round 3): same 4 x 4 block pivots, fewer instructions and a shorter dependent chain per block
-// step (the first form issues 290 instructions per step, of which 53 v_cndmask, 61 f64 multiply-adds of the redundant per-lane 4 x 4
-// Gauss-Jordan with its four dependent reciprocals, 27 accumulator moves and a second matrix-core product).
-//   * The rank-4 update runs on X~ = X with the pivot columns ZEROED against C' = pivot columns with the pivot rows zeroed and the
-//     operand B = Dinv R~ (R~ = pivot rows with the unit block in the pivot columns): every entry outside the pivot rows comes out
-//     right by itself (pivot columns as 0 - C Dinv), the pivot rows are then overwritten with B.  The substitutions are made by
-//     the lanes that WRITE the panels; one conditional move per step is left.  (Folding the pivot rows into the product as well --
-//     C' = D - I there -- cancels catastrophically when |D| >> 1: measured 0.7 instead of 5e-8 on a condition-1e9 tile.)
-//   * A lane needs only row lk of Dinv (its B-operand row).  It reads D with the columns rotated by lk (a per-lane LDS offset) and
-//     forms row 0 of THAT inverse from cofactors: 6 shared 2 x 2 minors, four 3 x 3 minors, one determinant, one reciprocal -- ~45
-//     short-chain instructions instead of ~110 of a four-pivot elimination plus 12 row selects.  On the condition-1e9 tile of
-//     scripts/micro/inv_bench.hip both forms reach |A inv(A) - I| = 5e-8..1e-7.
-//   * Static pivoting keeps its rule: when the cofactor expansion of the determinant cancels (|det| < 1e-6 sum |terms|) OR an entry
-//     of the inverse exceeds 1 / (tol x the entry diagonal of its row) -- a pivot that lost its digits before it reached this block --
-//     the wave falls back to the four-pivot elimination with the per-pivot threshold of the first form (uniform branch, no barrier or
-//     matrix instruction inside).  Blocks with a zero leading entry but a healthy determinant ([0 1; 1 0]) are inverted exactly
-//     instead of being perturbed.
-TSL_DEV void ds_invert_tile_wg2(double* __restrict__ T, int ldt, int* __restrict__ bad, int cls, int tag, double tol) {
-  __shared__ double rowp[2][DS_PB][DS_T], colp[2][DS_PB][DS_T + 1], dblk[2][DS_PB][DS_PB], red[4], dg0[DS_T];
-  const int lane = threadIdx.x & 63, w = threadIdx.x >> 6, wi = w >> 1, wj = w & 1, lr = lane & 15, lk = lane >> 4;
-  ds_d4 acc;
-  double amax = 0.0;
-#pragma unroll
-  for (int r = 0; r < 4; r++) {
-    acc[r] = T[(16 * wi + lk + 4 * r) * ldt + 16 * wj + lr];
-    amax = fmax(amax, fabs(acc[r]));
-    if (wi == wj && lk + 4 * r == lr) dg0[16 * wi + lr] = fabs(acc[r]);
-  }
-  amax = wave_max(amax);
-  if (lane == 0) red[w] = amax;
-  __syncthreads();
-  const double tmax = fmax(fmax(red[0], red[1]), fmax(red[2], red[3]));
-  const double floor0 = fmax(tmax * 1e-20, 1e-300);
-  const double mydg = dg0[lane & 31];
-  unsigned badmask = 0;
-  const int c0 = lk, c1 = (lk + 1) & 3, c2 = (lk + 2) & 3, c3 = (lk + 3) & 3;   // column rotation of this lane
-#pragma unroll
-  for (int s = 0; s < DS_T / DS_PB; s++) {
-    const int buf = s & 1, p0 = DS_PB * s;
-    const int wp = p0 >> 4, rp = (p0 & 15) >> 2, lc = p0 & 15;
-    const bool col_in = wj == wp && lr >= lc && lr < lc + DS_PB;
-    const int mc = (lr - lc) & 3;
-    if (wi == wp) {   // pivot rows (lane row lk, register rp): R~ carries the unit block in the pivot columns, D goes to its own array
-      const double v = acc[rp];
-      rowp[buf][lk][16 * wj + lr] = col_in ? (mc == lk ? 1.0 : 0.0) : v;
-      if (col_in) dblk[buf][lk][mc] = v;
-    }
-    if (col_in) {     // pivot columns, negated, zero in the pivot rows; X~ has zero pivot columns
-#pragma unroll
-      for (int r = 0; r < 4; r++) {
-        colp[buf][mc][16 * wi + lk + 4 * r] = (wi == wp && r == rp) ? 0.0 : -acc[r];
-        acc[r] = 0.0;
-      }
-    }
-    __syncthreads();
-    // rows of D, columns rotated by lk: a = column lk (expansion column), b, c, e the three others
-    double a[4], b[4], c[4], e[4];
-#pragma unroll
-    for (int i = 0; i < 4; i++) { a[i] = dblk[buf][i][c0]; b[i] = dblk[buf][i][c1]; c[i] = dblk[buf][i][c2]; e[i] = dblk[buf][i][c3]; }
-    const double m01 = c[0] * e[1] - c[1] * e[0], m02 = c[0] * e[2] - c[2] * e[0], m03 = c[0] * e[3] - c[3] * e[0];
-    const double m12 = c[1] * e[2] - c[2] * e[1], m13 = c[1] * e[3] - c[3] * e[1], m23 = c[2] * e[3] - c[3] * e[2];
-    const double M0 = b[1] * m23 - b[2] * m13 + b[3] * m12;
-    const double M1 = b[0] * m23 - b[2] * m03 + b[3] * m02;
-    const double M2 = b[0] * m13 - b[1] * m03 + b[3] * m01;
-    const double M3 = b[0] * m12 - b[1] * m02 + b[2] * m01;
-    const double t0 = a[0] * M0, t1 = a[1] * M1, t2 = a[2] * M2, t3 = a[3] * M3;
-    const double det = (t0 - t1) + (t2 - t3);
-    const double dabs = (fabs(t0) + fabs(t1)) + (fabs(t2) + fabs(t3));
-    double drow[DS_PB];
-    const double idet = ds_rcp(det);
-    drow[0] = M0 * idet; drow[1] = -M1 * idet; drow[2] = M2 * idet; drow[3] = -M3 * idet;
-    // static-pivot rule on the cofactor path: the determinant must not cancel, and no entry of the lane's row of the inverse may exceed
-    // 1 / (tol x the entry diagonal of that row) -- for a diagonal block exactly "pivot >= tol x its own scale"; a block like
-    // diag(1e-20, 1, 1, 1) shows no cancellation and would be inverted as it is.  Every lane of the wave takes the same path.
-    const bool ok = fabs(det) >= 1e-6 * dabs && dabs < 1e300 && fmax(fmax(fabs(drow[0]), fabs(drow[1])), fmax(fabs(drow[2]), fabs(drow[3]))) * (tol * dg0[p0 + lk]) <= 1.0;
-    if (__builtin_amdgcn_ballot_w64(!ok) != 0) {
-      // four-pivot elimination on the unrotated block with the per-pivot threshold (first form), then row lk
-      double d[DS_PB][DS_PB];
-#pragma unroll
-      for (int i = 0; i < DS_PB; i++)
-#pragma unroll
-        for (int j = 0; j < DS_PB; j++) d[i][j] = dblk[buf][i][j];
-#pragma unroll
-      for (int p = 0; p < DS_PB; p++) {
-        const double piv0 = d[p][p];
-        const double tiny = fmax(tol * ds_readlane_d(mydg, p0 + p), floor0);
-        const bool small = !(fabs(piv0) >= tiny);
-        const double piv = small ? copysign(tiny, piv0) : piv0;
-        badmask |= small ? (1u << (p0 + p)) : 0u;
-        const double ip = ds_rcp(piv);
-#pragma unroll
-        for (int j = 0; j < DS_PB; j++) d[p][j] = (j == p) ? ip : d[p][j] * ip;
-#pragma unroll
-        for (int i = 0; i < DS_PB; i++) {
-          if (i == p) continue;
-          const double f = d[i][p];
-#pragma unroll
-          for (int j = 0; j < DS_PB; j++) d[i][j] = (j == p) ? -f * ip : fma(-f, d[p][j], d[i][j]);
-        }
-      }
-      const bool k1 = lk == 1, k2 = lk == 2, k3 = lk == 3;
-#pragma unroll
-      for (int j = 0; j < DS_PB; j++) drow[j] = ds_sel4(k1, k2, k3, d[0][j], d[1][j], d[2][j], d[3][j]);
-    }
-    const int col = 16 * wj + lr;
-    const double bop = drow[0] * rowp[buf][0][col] + drow[1] * rowp[buf][1][col] + drow[2] * rowp[buf][2][col] + drow[3] * rowp[buf][3][col];
-    const double aop = colp[buf][lk][16 * wi + lr];
-    acc = __builtin_amdgcn_mfma_f64_16x16x4f64(aop, bop, acc, 0, 0, 0);   // X~ - C' (Dinv R~)
-    if (wi == wp) acc[rp] = bop;                                           // pivot rows = Dinv R~ (Dinv itself in the pivot columns)
-  }
-#pragma unroll
-  for (int r = 0; r < 4; r++) T[(16 * wi + lk + 4 * r) * ldt + 16 * wj + lr] = acc[r];
-  if (threadIdx.x == 0 && badmask) {
-    atomicAdd(bad + cls, __popc(badmask));
-    const int slot = atomicAdd(bad + 4, 1);
-    if (slot < DS_BADLOG) { int* L = bad + 8 + 4 * slot; L[0] = tag; L[1] = (int)badmask; L[2] = 0; L[3] = __float_as_int((float)tmax); }
-  }
-  __syncthreads();
+TSL_DEV double ds_quad_sum(double v) {   // sum over the four lanes of a quad, the same bits in all four
+  v += ds_dpp<0xB1>(v);   // quad_perm [1, 0, 3, 2]
+  v += ds_dpp<0x4E>(v);   // quad_perm [2, 3, 0, 1]
+  return v;
 }
+// LDS of one tile inversion (5.4 KB; both forms use the one copy: k_ds_inv_small keeps two workgroups with a 96-pivot block on a CU only
+// while the static arrays stay below 7.4 KB)
+struct DsInvLds {
+  double rowp[2][DS_PB][DS_T], colp[2][DS_PB][DS_T + 1];   // pivot rows R~ / pivot columns -C' of a step, double-buffered
+  double dnext[2][DS_PB][DS_PB], dinv[2][DS_PB][DS_PB];    // X[n, n] at the next pivot position; the inverse the workers apply
+  double dd[DS_PB][2 * DS_PB];                              // the scout's next pivot block, its columns stored twice (entry (a, b) = D[a][b & 3]: a lane reads them rotated)
+  double red[2], dg0[DS_T];
+  int redo;
+};
 
-// Fourth form (round 3, for the dataflow chains, where the tile inversion IS the critical path of a block step): wave-specialised.
-// A block step of forms 1 / 2 is one dependent chain that every wave walks in lock step -- panels to LDS, barrier, pivot block back,
-// 4 x 4 inverse, B operand, matrix-core update, back to LDS: ~1500 cycles.  Here the chain is cut in two that run on different SIMDs
-// between the same pair of barriers:
-//   * waves 0 / 1 (workers) own the upper / lower 16 rows of the tile (two accumulator quadrants each); in step s they read row lk of
-//     Dinv(s) from LDS, form the B operands, update, and write the panels of step s+1 (pivot rows, pivot columns, and the 4 x 4 corner
-//     X[n, n] at the NEXT pivot position);
+// Form 4 (round 3): wave-specialised.  A block step of the lock-step forms is one dependent chain that every wave walks -- panels to LDS,
+// barrier, pivot block back, 4 x 4 inverse, B operand, matrix-core update, back to LDS.  Here the chain is cut in two that run on different
+// SIMDs between the same pair of barriers:
+//   * waves 0 / 1 (workers) own the upper / lower 16 rows of the tile (two accumulator quadrants each, lane l, register r = element
+//     (16 w + (l >> 4) + 4 r, 16 q + (l & 15)): the accumulator layout of v_mfma_f64_16x16x4_f64); in step s they read row lk of Dinv(s) from
+//     LDS, form the B operands, update, and write the panels of step s+1 (pivot rows R~ with the unit block in the pivot columns, pivot
+//     columns -C' with the pivot rows zeroed -- every entry outside the pivot rows then comes out of X~ - C' (Dinv R~) by itself, the pivot
+//     rows are overwritten with Dinv R~ --, and the 4 x 4 corner X[n, n] at the NEXT pivot position);
 //   * wave 2 (scout) forms the pivot block of step s+1 from the panels of step s by a 16x16x4 product of its own -- A operand the
 //     4 x 4 corner of the column panel, B operand Dinv(s) R at the next pivot columns, C operand X[n, n] --, passes it round its lanes
-//     through a private LDS patch, computes Dinv(s+1) (cofactor form, row lk per lane; static-pivot fall-back as in form 2) and leaves
-//     it in LDS for the workers; wave 3 only keeps the barriers.
-// The tile enters and leaves through T in LDS, so the distribution over waves is private to this function.
-TSL_DEV void ds_invert_tile_wg4(double* __restrict__ T, int ldt, int* __restrict__ bad, int cls, int tag, double tol) {
-  __shared__ double rowp[2][DS_PB][DS_T], colp[2][DS_PB][DS_T + 1], dnext[2][DS_PB][DS_PB], dinv[2][DS_PB][DS_PB], dloc[DS_PB][DS_PB], red[2], dg0[DS_T];
+//     through a private LDS patch, computes Dinv(s+1) (cofactor form: a lane reads D with the columns rotated by lk and forms row 0 of THAT
+//     inverse -- 6 shared 2 x 2 minors, four 3 x 3 minors, one determinant, one reciprocal) and leaves it in LDS for the workers; wave 3
+//     only keeps the barriers.
+// Static-pivot rule on the cofactor path: when the expansion of the determinant cancels (|det| < 1e-6 sum |terms|) OR an entry of the inverse
+// exceeds 1 / (tol x the entry diagonal of its row) -- a pivot that lost its digits before it reached this block -- the scout falls back to a
+// four-pivot elimination with per-pivot thresholds (uniform branch).  Blocks with a zero leading entry but a healthy determinant
+// ([0 1; 1 0]) are inverted exactly instead of being perturbed.
+TSL_DEV void ds_invert_tile_guarded(DsInvLds& L, double* __restrict__ T, int ldt, int* __restrict__ bad, int cls, int tag, double tol) {
+  auto& rowp = L.rowp; auto& colp = L.colp; auto& dnext = L.dnext; auto& dinv = L.dinv; auto& dloc = L.dd; auto& red = L.red; auto& dg0 = L.dg0;
   const int lane = threadIdx.x & 63, w = threadIdx.x >> 6, lr = lane & 15, lk = lane >> 4;
   const bool worker = w < 2, scout = w == 2;
   ds_d4 acc[2];
@@ -399,7 +215,7 @@ TSL_DEV void ds_invert_tile_wg4(double* __restrict__ T, int ldt, int* __restrict
   unsigned badmask = 0;
   const int c0 = lk, c1 = (lk + 1) & 3, c2 = (lk + 2) & 3, c3 = (lk + 3) & 3;   // column rotation of this lane
   // row lk of the inverse of the 4 x 4 block D (pivot rows p0..p0+3) -> drow
-  auto inv_row = [&](const double (*D)[DS_PB], int p0, double* drow) {
+  auto inv_row = [&](auto D, int p0, double* drow) {
     double a[4], b[4], c[4], e[4];
 #pragma unroll
     for (int i = 0; i < 4; i++) { a[i] = D[i][c0]; b[i] = D[i][c1]; c[i] = D[i][c2]; e[i] = D[i][c3]; }
@@ -524,19 +340,146 @@ TSL_DEV void ds_invert_tile_wg4(double* __restrict__ T, int ldt, int* __restrict
   __syncthreads();
 }
 
-// the form the factorisation kernels use (1: four-pivot elimination per block step, 2: cofactor form, 4: wave-specialised; A/B builds pass
-// -DDS_INV_FORM=n).  scripts/micro/inv_bench.hip: 5.58 / 4.88 / 4.29 us per tile, same accuracy (the cofactor forms do not perturb blocks
-// like [0 1; 1 0]).  Form 4 since the dataflow chains put the inversion on the critical path of every block step.  EVERY path of the
-// factorisation (k_ds_pivot0 / k_ds_gj_step, k_ds_gj_flow, k_ds_inv_small) inverts its pivot tiles with this one form and forms the same
-// products in the same order: the factors do not depend on which kernel a batch ran in (tests/test_gpu_direct.py asserts equal bits).
-#ifndef DS_INV_FORM
-#define DS_INV_FORM 4
-#endif
-template <int FORM>
-TSL_DEV void ds_invert_tile_f(double* __restrict__ T, int ldt, int* __restrict__ bad, int cls, int tag, double tol) {
-  if (FORM == 1) ds_invert_tile_wg(T, ldt, bad, cls, tag, tol); else if (FORM == 2) ds_invert_tile_wg2(T, ldt, bad, cls, tag, tol); else ds_invert_tile_wg4(T, ldt, bad, cls, tag, tol);
+
+// Form 6 (round 6): form 4's wave specialisation with
+//   * the scout's 4 x 4 inverse spread over the lanes: lane (lk, lr) forms ONE entry (row lk, column lr & 3) -- a 3 x 3 minor of the block as it
+//     lies in LDS with its columns stored twice (the lane reads them rotated by lk), the determinant by the expansion along column lk summed over
+//     the quad with two DPP steps -- instead of a whole row per lane from ~55 dependent f64 instructions (a v_fma_f64 issues every 5.3 cycles,
+//     dependent or not: scripts/micro/lat_probe.hip);
+//   * NO branch inside the eight steps: the static-pivot rule (no term of the expansion above 2.5e5 |det|, no entry of the inverse above
+//     1 / (tol x the entry diagonal of its row); NaN fails both) is evaluated lane by lane and and-ed up over the steps (a compare + ballot + branch
+//     costs ~120 cycles per step, lat_probe); a tile that fails it anywhere is inverted AGAIN from its untouched LDS image by form 4, whose
+//     fall-back path perturbs and counts the pivots.  Which tiles take that way depends on their entries only: all three factorisation paths
+//     still give the same bits;
+//   * the tile maximum (needed by the fall-back path only) is not formed here at all (six ds_bpermute rounds in front of the first step).
+// EVERY path of the factorisation (k_ds_pivot0 / k_ds_gj_step, k_ds_gj_flow, k_ds_inv_small) inverts its pivot tiles with this one routine and
+// forms the same products in the same order: the factors do not depend on which kernel a batch ran in (tests/test_gpu_direct.py asserts equal bits).
+TSL_DEV void ds_invert_tile(double* __restrict__ T, int ldt, int* __restrict__ bad, int cls, int tag, double tol) {
+  __shared__ DsInvLds L;
+  auto& rowp = L.rowp; auto& colp = L.colp; auto& dnext = L.dnext; auto& dinv = L.dinv; auto& dd = L.dd; auto& dg0 = L.dg0;
+  const int lane = threadIdx.x & 63, w = threadIdx.x >> 6, lr = lane & 15, lk = lane >> 4;
+  const bool worker = w < 2, scout = w == 2;
+  const int mj = lr & 3;
+  ds_d4 acc[2];
+  if (worker) {
+#pragma unroll
+    for (int q = 0; q < 2; q++)
+#pragma unroll
+      for (int r = 0; r < 4; r++) {
+        acc[q][r] = T[(16 * w + lk + 4 * r) * ldt + 16 * q + lr];
+        if (q == w && lk + 4 * r == lr) dg0[16 * w + lr] = fabs(acc[q][r]);   // the diagonal on entry: the scale a pivot is measured against
+      }
+    if (w == 0 && lr < DS_PB) {   // the first pivot block (rows lk, columns lr < 4, register 0), columns stored twice for the scout's rotated reads
+      const double v = acc[0][0];
+      dd[lk][lr] = v; dd[lk][lr + DS_PB] = v;
+    }
+  }
+  const double sgn = (mj & 1) ? -1.0 : 1.0;
+  const double *q0 = &dd[mj == 0 ? 1 : 0][lk], *q1 = &dd[mj <= 1 ? 2 : 1][lk], *q2 = &dd[mj <= 2 ? 3 : 2][lk];   // the three rows other than mj, columns from lk on
+  bool okall = true;
+  // entry (lk, mj) of the inverse of the 4 x 4 block in dd (scout)
+  auto inv_entry = [&](int p0) -> double {
+    // row lk of the inverse = row 0 of the inverse of D with its columns rotated by lk (a = column lk, then b, c, e); the lane's entry mj is
+    // (-1)^mj minor(row mj deleted; columns b, c, e) / det with the three remaining rows r0 < r1 < r2 in natural order, the minor expanded along
+    // column b over 2 x 2 minors of columns (c, e) -- the expressions form 4 evaluates per lane; det = the expansion along a, summed over the quad
+    const double a_ = dd[mj][lk];
+    const double b0 = q0[1], c0 = q0[2], e0 = q0[3], b1 = q1[1], c1 = q1[2], e1 = q1[3], b2 = q2[1], c2 = q2[2], e2 = q2[3];
+    const double tdg = tol * dg0[p0 + lk];
+    const double m12 = c1 * e2 - c2 * e1, m02 = c0 * e2 - c2 * e0, m01 = c0 * e1 - c1 * e0;
+    const double M = b0 * m12 - b1 * m02 + b2 * m01;
+    double t = (sgn * a_) * M;
+    // the term must be ROUNDED before the quad sum.  Contracted into it -- fma(sgn a, M, the neighbour's term), what the compiler makes of
+    // `t + dpp(t)` -- the four lanes of a quad get four different determinants, and a row of the inverse whose entries are divided by different
+    // determinants leaves eps (|t| / |det|)^2 instead of eps |t| / |det| in Dinv D - I: measured 1e-5 against 9e-8 relative residual of the
+    // first application of the factors on the cfg4 operator, 1.6 instead of 1.0 applications per solve
+    asm volatile("" : "+v"(t));
+    const double det = ds_quad_sum(t);
+    const double idet = ds_rcp(det);
+    const double e = (M * sgn) * idet;
+    okall &= (fabs(det) >= 4e-6 * fabs(t)) & (fabs(e) * tdg <= 1.0);
+    return e;
+  };
+  // panels of step s from the workers' accumulators (before the barrier that opens step s)
+  auto write_panels = [&](int s) {
+    const int buf = s & 1, p0 = DS_PB * s, wp = p0 >> 4, rp = (p0 & 15) >> 2, lc = p0 & 15;
+    const int n0 = p0 + DS_PB, wn = n0 >> 4, rn = (n0 & 15) >> 2, ln = n0 & 15;
+    if (s + 1 < DS_T / DS_PB && w == wn && lr >= ln && lr < ln + DS_PB) dnext[buf][lk][lr - ln] = acc[wn][rn];   // X[n, n] before step s
+    const bool col_in = lr >= lc && lr < lc + DS_PB;   // (of column half wp)
+    if (w == wp) {   // pivot rows: R~ carries the unit block in the pivot columns
+#pragma unroll
+      for (int q = 0; q < 2; q++) rowp[buf][lk][16 * q + lr] = (q == wp && col_in) ? (mj == lk ? 1.0 : 0.0) : acc[q][rp];
+    }
+    if (col_in) {    // pivot columns, negated, zero in the pivot rows; X~ has zero pivot columns
+#pragma unroll
+      for (int r = 0; r < 4; r++) {
+        colp[buf][mj][16 * w + lk + 4 * r] = (w == wp && r == rp) ? 0.0 : -acc[wp][r];
+        acc[wp][r] = 0.0;
+      }
+    }
+  };
+  double e = 0.0;   // the scout's entry (lk, mj) of the current inverse
+  if (worker) write_panels(0);
+  __syncthreads();
+  if (scout) {
+    e = inv_entry(0);
+    if (lr < DS_PB) dinv[0][lk][lr] = e;
+  }
+  __syncthreads();
+#pragma unroll
+  for (int s = 0; s < DS_T / DS_PB; s++) {
+    const int buf = s & 1, p0 = DS_PB * s, wp = p0 >> 4, rp = (p0 & 15) >> 2;
+    const bool has_next = s + 1 < DS_T / DS_PB;
+    if (worker) {
+      double dr[DS_PB];
+#pragma unroll
+      for (int j = 0; j < DS_PB; j++) dr[j] = dinv[buf][lk][j];
+      const double aop = colp[buf][lk][16 * w + lr];
+      double bop[2];
+#pragma unroll
+      for (int q = 0; q < 2; q++) {
+        const int col = 16 * q + lr;
+        bop[q] = dr[0] * rowp[buf][0][col] + dr[1] * rowp[buf][1][col] + dr[2] * rowp[buf][2][col] + dr[3] * rowp[buf][3][col];
+      }
+#pragma unroll
+      for (int q = 0; q < 2; q++) acc[q] = __builtin_amdgcn_mfma_f64_16x16x4f64(aop, bop[q], acc[q], 0, 0, 0);   // X~ - C' (Dinv R~)
+      if (w == wp) {                                                                                            // pivot rows = Dinv R~ (Dinv itself in the pivot columns)
+#pragma unroll
+        for (int q = 0; q < 2; q++) acc[q][rp] = bop[q];
+      }
+      if (has_next) write_panels(s + 1);
+    } else if (scout) {
+      if (has_next) {
+        const int n0 = p0 + DS_PB, cn = n0 + mj;
+        const double bn = ds_dpp<0x00>(e) * rowp[buf][0][cn] + ds_dpp<0x55>(e) * rowp[buf][1][cn] + ds_dpp<0xAA>(e) * rowp[buf][2][cn] + ds_dpp<0xFF>(e) * rowp[buf][3][cn];
+        const double an = lr < DS_PB ? colp[buf][lk][n0 + lr] : 0.0;
+        const ds_d4 cin = {lr < DS_PB ? dnext[buf][lk][mj] : 0.0, 0.0, 0.0, 0.0};
+        const ds_d4 dn = __builtin_amdgcn_mfma_f64_16x16x4f64(an, bn, cin, 0, 0, 0);    // D(s+1) = X[n, n] - C[n, :] (Dinv(s) R[:, n]) in lanes (lk, lr < 4), register 0
+        if (lr < DS_PB) { const double v = dn[0]; dd[lk][lr] = v; dd[lk][lr + DS_PB] = v; }
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+        e = inv_entry(n0);
+        if (lr < DS_PB) dinv[buf ^ 1][lk][lr] = e;
+      } else {
+        L.redo = __builtin_amdgcn_ballot_w64(!okall) != 0 ? 1 : 0;   // any lane, any step (every lane writes the same value)
+      }
+    }
+    __syncthreads();
+  }
+  if (L.redo) {   // (uniform) a step met a pivot block the cofactor path must not invert: the whole tile again, from T, with the guarded form
+    if (threadIdx.x == 0) atomicAdd(bad + DS_REDO, 1);
+    __syncthreads();
+    ds_invert_tile_guarded(L, T, ldt, bad, cls, tag, tol);
+    return;
+  }
+  if (worker) {
+#pragma unroll
+    for (int q = 0; q < 2; q++)
+#pragma unroll
+      for (int r = 0; r < 4; r++) T[(16 * w + lk + 4 * r) * ldt + 16 * q + lr] = acc[q][r];
+  }
+  __syncthreads();
 }
-TSL_DEV void ds_invert_tile(double* __restrict__ T, int ldt, int* __restrict__ bad, int cls, int tag, double tol) { ds_invert_tile_f<DS_INV_FORM>(T, ldt, bad, cls, tag, tol); }
 
 // scratch of a front inside the level scratch (fronts with more than DS_SMALL pivots): pivot-block inverses P[2] (ping-pong) and the
 // side panels of the merged Gauss-Jordan step, row panel R[2] (DS_T x pp) and column panel C[2] (pp x DS_T)

@@ -2671,16 +2671,18 @@ extern "C" int tsl_direct_info(tsl_ctx* c, double* out10) {
 // on the block-step path, plans found in the plan cache, bytes of the panel arena (cleared per factorisation), bytes of the Schur arena,
 // bytes of the G arena, entries of Schur complements stored per factorisation, plans parked in the cache, first passes of refined solves whose
 // componentwise backward error was looked at, first passes accepted on it ("direct_berr"), the largest backward error and the largest forward
-// residual so accepted}
+// residual so accepted, pivot tiles of the LAST factorisation that failed the static-pivot rule of the cofactor path and were inverted by the guarded form}
 extern "C" int tsl_direct_counters(tsl_ctx* c, double* out, int32_t n) {
   const DirectSolver& d = c->ds;
   double e = 0;
   if (d.plan_valid) for (const DsFrontDesc& f : d.plan.fr) e += (double)f.b * f.b;
   size_t parked = 0;
   for (const auto& sl : d.cache) parked += sl->used ? 1 : 0;
-  const double v[12] = {(double)d.n_flow, (double)d.n_flow_abort, (double)d.n_plan_hits, d.plan_valid ? 8.0 * (double)d.plan.arena : 0.0, d.plan_valid ? 8.0 * (double)d.plan.sarena : 0.0,
-                        d.plan_valid ? 8.0 * (double)d.plan.garena : 0.0, e, (double)parked, (double)d.berr_seen, (double)d.berr_accepted, d.berr_max, d.berr_rel_max};
-  for (int i = 0; i < std::min<int>(n, 12); i++) out[i] = v[i];
+  int redo = 0;
+  if (n > 12 && d.bad.p) { HIP_OK(hipStreamSynchronize(c->stream)); HIP_OK(hipMemcpy(&redo, d.bad.p + DS_REDO, sizeof(int), hipMemcpyDeviceToHost)); }
+  const double v[13] = {(double)d.n_flow, (double)d.n_flow_abort, (double)d.n_plan_hits, d.plan_valid ? 8.0 * (double)d.plan.arena : 0.0, d.plan_valid ? 8.0 * (double)d.plan.sarena : 0.0,
+                        d.plan_valid ? 8.0 * (double)d.plan.garena : 0.0, e, (double)parked, (double)d.berr_seen, (double)d.berr_accepted, d.berr_max, d.berr_rel_max, (double)redo};
+  for (int i = 0; i < std::min<int>(n, 13); i++) out[i] = v[i];
   return 0;
 }
 
