@@ -4,7 +4,7 @@ An ORACLE rollout at the full sizes of BASELINE configs[2] / configs[3] -- the C
 (BaseScene.time_step, BaseScene.py:1327-1370; Grad.transfer_grad, analytic_grad_single.py:217-257; the linear solves by scipy's
 SuperLU as the reference calls spsolve, sparse_solver.py:85-105), from the deterministic initial state of the product scene's HOST
 initialisation (built on device "cpu": no kernel runs) + the sub-micron ripple of the parity tests:
-    cfg4  Scene_balancing 224 x 224 (100,352 triangles), bench drive (+-1e-4 m on the paired grippers): 1 step + its reverse step, loss get_loss_balance
+    cfg4  Scene_balancing 224 x 224 (100,352 triangles), bench drive (+-1e-4 m on the paired grippers): 2 steps + the reverse step of the last, loss get_loss_balance
     cfg3  Scene_folding 200 x 100 (40,000 triangles), pad -2e-4 m in z per step: 2 steps + the reverse step of the last, loss get_loss_fold
 tests/test_gpu_fullsize_oracle.py steps the HIP engine from the same state and compares.  Kept small: a strided sample of the cloth
 vertices + every body vertex, SHA-256 digests of the oracle's full arrays (fixture integrity), Newton / contact / line-search counts
@@ -43,7 +43,7 @@ def build(which, device="cpu"):
             dpos = np.zeros((n_part, 3)); drot = np.zeros((n_part, 3))
             dpos[:, 2] = 1e-4 * np.where(np.arange(n_part) % 2 == 0, 1.0, -1.0)   # bench.py _drive, rank 0
             return dpos, drot
-        steps = 1
+        steps = int(os.environ.get("TSL_GOLDEN_STEPS", "2"))   # step 1 meets one contact and converges in 7 Newton iterations; step 2 has ~76 contacts and sits at the cap of 50
     else:
         from thinshelllab_amd.task_scene.Scene_folding import Scene
         s = Scene(cloth_size=0.1, cloth_N=200 // shrink, cloth_M=100 // shrink, device=device)
