@@ -354,6 +354,23 @@ def cpu_baseline(args, scene, gpu_stats, K, rank):
         out["sample"] = out["bench_size"]["what"] + (" || " + out["complete_steps_small_scene"]["sample"] if "complete_steps_small_scene" in out else "")
     except Exception as e:  # keep (a)
         out["bench_size"] = {"value": None, "what": f"failed: {e!r}"}
+    # complete oracle steps AT BENCH SIZE exist too, as a constant: the fixture generator of tests/test_gpu_fullsize_oracle.py stepped the oracle on the bench scene in the
+    # BUILD CONTAINER (8 cpus; a complete step at the Newton cap takes ~30 min there, too long for this leg) and recorded its wall times
+    try:
+        fx = os.path.join(ROOT, "tests", "golden", "oracle_cfg4.npz")
+        if args.workload == "cfg4" and args.grid == 224 and os.path.exists(fx):
+            G = np.load(fx)
+            secs, stf = G["seconds"], G["stats"]
+            t_all = float(secs[:, 0].sum() + G["adjoint_seconds"][0])
+            out["complete_steps_bench_size_build_container"] = {
+                "value": float(G["triangles"]) * len(secs) / t_all, "unit": "element-steps/s", "cores": int(G["threads"]),
+                "seconds_per_step": [float(x) for x in secs[:, 0]], "superlu_seconds_per_step": [float(x) for x in secs[:, 1]], "newton_per_step": [int(x) for x in stf[:, 1]],
+                "contacts_per_step": [int(x) for x in stf[:, 0]], "reverse_step_seconds": float(G["adjoint_seconds"][0]),
+                "what": f"MEASURED complete oracle steps at bench size ({len(secs)} forward steps from the initial state + the reverse step of the last), timed in the build container by "
+                        "tests/golden/gen_oracle_fullsize.py when it wrote the parity fixture: a constant read from tests/golden/oracle_cfg4.npz, NOT timed on this box; the HIP engine "
+                        "reproduces that rollout in tests/test_gpu_fullsize_oracle.py"}
+    except Exception as e:   # noqa: BLE001
+        out["complete_steps_bench_size_build_container"] = {"value": None, "what": f"failed: {e!r}"}
     if "parity" in out and not out["parity"]["ok"]:
         out["value"] = None
         out["sample"] = "PARITY FAILED (oracle vs HIP engine on the rollout timed for this baseline): " + json.dumps(out["parity"]) + " || " + out.get("sample", "")
@@ -493,7 +510,55 @@ def roofline(ctx, scene, elapsed, K, stats, args):
                     "each (the reference's own algorithm: a direct sparse solve per Newton iteration), so the model's iteration term is nearly empty and the "
                     "factorisation flops are the whole-step yardstick instead",
             "factorization_flops": flops_fact, "factorization_TFLOPs_over_wall": flops_fact / elapsed / 1e12, "frac_of_f64_mfma_peak": flops_fact / elapsed / 1e12 / F64_MFMA_PEAK_TF}
+    # FLAT keys (a driver that drops nested objects still keeps these): the north_star's whole-step yardsticks and the runner-up class; `frac` is the IN-SITU
+    # figure where the committed kernel trace gives one (what the launches take inside the driver's command), the replay figure of this run stays beside it
+    rf["frac_replay"] = rf["frac"]; rf["achieved_replay"] = rf["achieved"]
+    if rf.get("frac_in_situ") is not None:
+        rf["frac"] = rf["frac_in_situ"]; rf["achieved"] = rf["frac_in_situ"] * rf["peak"]
+        rf["frac_is"] = "in situ: algorithmic flops (bytes) per launch / average launch duration of the committed rocprofv3 kernel trace (rocprof_source); frac_replay = this run's HIP-event replays"
+    else:
+        rf["frac_is"] = "replay: this run's HIP-event pair around back-to-back replays (no committed kernel trace for this workload)"
+    rf["hbm_frac_whole_step"] = step["frac_of_hbm_peak"]
+    rf["mfma_frac_whole_step"] = step["frac_of_f64_mfma_peak"]
+    rf["factorization_TFLOPs_over_wall"] = step["factorization_TFLOPs_over_wall"]
+    if "runner_up" in rf:
+        ru = rf["runner_up"]
+        rf["runner_up_kernel"] = ru["kernel"].split(" ")[0]
+        rf["runner_up_frac_replay"] = ru["frac"]
+        rf["runner_up_frac_in_situ"] = ru.get("frac_in_situ")
+        alg = ru["bytes_per_launch"]
+        rf["runner_up_traffic_ratio"] = (ru["traffic"] / alg) if ru.get("traffic") and alg else None
+    alg = rf["bytes_per_launch"]
+    rf["traffic_ratio"] = (rf["traffic"] / alg) if rf.get("traffic") and alg else None
     return rf, step
+
+
+def timed_region(batch, run, sync=None):
+    """The timed region of the contract: barrier + device synchronisation on BOTH sides of `run()` (K steps of this rank's rollout), wall seconds = the MAX over
+    the ranks.  Returns (what run returned, seconds).  Rank logic only -- tests/test_host_logic.py drives it with two gloo ranks and a stand-in rollout."""
+    sync = sync or (lambda: None)
+    batch.barrier()
+    sync()
+    t0 = time.perf_counter()
+    res = run()
+    sync()
+    batch.barrier()
+    elapsed = time.perf_counter() - t0
+    return res, batch.max_over_ranks(elapsed)
+
+
+def headline(T, K, W, world, elapsed):
+    """the contract's keys: value = units of ALL ranks (T triangles x K steps x world) / the max-over-ranks seconds; weak scaling (one scene per GPU)"""
+    return {"metric": "element-steps/s (fwd+adjoint), 100k-tri cloth; 1/2/4/8-GPU scaling",
+            "value": T * K * world / elapsed, "unit": "element-steps/s", "n_gpus": world, "steps": K, "warmup": W,
+            "ms_per_step": elapsed / K * 1e3, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+            "dtype": "f64", "data": "synthetic"}
+
+
+def emit(out, rank):
+    """rank 0 prints the ONE JSON line"""
+    if rank == 0:
+        print(json.dumps(out), flush=True)
 
 
 def main():
@@ -558,25 +623,15 @@ def main():
         run_rollout(scene, grad, W, args)
 
     info0 = ctx.direct_info()
-    batch.barrier()
-    torch.cuda.synchronize()
-    t0 = time.perf_counter()
-    stats = run_rollout(scene, grad, K, args)
-    torch.cuda.synchronize()
-    batch.barrier()
-    elapsed = time.perf_counter() - t0
-    elapsed = batch.max_over_ranks(elapsed)
+    stats, elapsed = timed_region(batch, lambda: run_rollout(scene, grad, K, args), torch.cuda.synchronize)
     info1 = ctx.direct_info()
     stats["factorizations_total"] = info1["factorizations"] - info0["factorizations"]
 
     T = scene.cloths[0].NF
-    value = T * K * world / elapsed
     n_solves_fwd = max(stats["newton"], 1)
-    out = {
-        "metric": "element-steps/s (fwd+adjoint), 100k-tri cloth; 1/2/4/8-GPU scaling",
-        "value": value, "unit": "element-steps/s", "n_gpus": world, "steps": K, "warmup": W,
-        "ms_per_step": elapsed / K * 1e3, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
-        "dtype": "f64", "data": "synthetic",
+    out = headline(T, K, W, world, elapsed)
+    value = out["value"]
+    out.update({
         "config": {"workload": (f"cfg4 (SURVEY.md section 8d): Scene_balancing topology, {args.grid}x{args.grid} cloth ({T} triangles, cloth_size "
                                 f"{0.12 * args.grid / 224:.3f} m, dx {0.12 / 224:.2e} m) on the ball + 4 tactile pads at their native poses, paired grippers driven "
                                 f"+-1e-4 m in z every step" + (f" after {args.idle} idle steps" if args.idle else "") + ", loss get_loss_balance; "
@@ -602,7 +657,7 @@ def main():
                    "first_passes_accepted_on_backward_error": _berr_counters(ctx),
                    "max_rel_residual_fwd": stats["max_res_fwd"], "max_rel_residual_adjoint": stats["max_res_adj"], "max_backward_error_adjoint": stats["max_be_adj"],
                    "adjoint_solve_methods": {str(k): v for k, v in stats["methods"].items()}},
-    }
+    })
     rf, step = roofline(ctx, scene, elapsed, K, stats, args)
     if rf is not None:
         rf["whole_step"] = step   # SURVEY section 8d's bytes model and the factorisation-flops figure of the WHOLE step, inside the object the driver keeps
@@ -619,13 +674,12 @@ def main():
             out["multi_scene"] = json.loads(line[-1]) if line else {"scenes_per_gpu": args.scenes_per_gpu, "value": None, "error": (r.stderr or "no output")[-400:]}
         except Exception as e:   # noqa: BLE001 -- never fail the headline on the extra measurement
             out["multi_scene"] = {"scenes_per_gpu": args.scenes_per_gpu, "value": None, "error": repr(e)}
-    if rank == 0:
-        if world == 1 and not args.no_cpu_baseline:
-            try:
-                out["cpu_baseline"] = cpu_baseline(args, scene, stats, K, rank)
-            except Exception as e:  # the oracle is optional test infrastructure; never fail the GPU number on it
-                out["cpu_baseline"] = {"value": None, "unit": "element-steps/s", "cores": os.cpu_count(), "kind": "port", "sample": f"failed: {e!r}"}
-        print(json.dumps(out), flush=True)
+    if rank == 0 and world == 1 and not args.no_cpu_baseline:
+        try:
+            out["cpu_baseline"] = cpu_baseline(args, scene, stats, K, rank)
+        except Exception as e:  # the oracle is optional test infrastructure; never fail the GPU number on it
+            out["cpu_baseline"] = {"value": None, "unit": "element-steps/s", "cores": os.cpu_count(), "kind": "port", "sample": f"failed: {e!r}"}
+    emit(out, rank)
     batch.close()
 
 

@@ -242,14 +242,15 @@ int tsl_direct_counters(tsl_ctx* ctx, double* out_host, int32_t n);
  *   tsl_group_adjoint_step: Grad.transfer_grad (analytic_grad_single.py:217-257) of every member for the same reverse step -- the arguments of
  *                     tsl_adjoint_step as arrays of n, the n adjoint systems through one merged factorisation; same bits per member; stats[n] or null.
  *   tsl_group_info:   {plan merges, arena re-layouts, host seconds in merges, bytes of the group's arenas, merged factorisations, merged applications,
- *                     solves in which a member went on from the merged first pass on its own path (refinement, GMRES)}; seven values. */
+ *                     solves in which a member went on from the merged first pass on its own path (refinement, GMRES), dataflow launches of the merged
+ *                     factorisations, merged factorisations redone on the block-step path after such a launch lost a flag}; nine values. */
 typedef struct tsl_group tsl_group;
 int tsl_group_create(tsl_ctx* const* ctxs, int32_t n, tsl_group** out);
 void tsl_group_destroy(tsl_group* g);
 int tsl_group_step(tsl_group* g, double* const* pos, double* const* prev_pos, double* const* vel, double* const* ref_angle, tsl_step_stats* stats_host);
 int tsl_group_adjoint_step(tsl_group* g, int step, int T, const double* const* pos_buffer, double* const* pos_grad, const double* const* ref_buffer,
                            double* const* angleref_grad, double* const* tmp_z_frozen, const double* adj_damping_host, tsl_solve_stats* stats_host);
-int tsl_group_info(tsl_group* g, double* out7_host);
+int tsl_group_info(tsl_group* g, double* out9_host);
 
 #ifdef __cplusplus
 }

@@ -195,3 +195,33 @@ def test_group_at_cfg4_size_bit_for_bit():
         assert a["stats"][:, 0].max() > 50, "too few contacts for the cfg4 scene"
         for k in a:
             assert np.array_equal(a[k], b[k]), f"scene {i}: {k} differs (max |d| = {np.abs(a[k] - b[k]).max():.3e})"
+
+
+def test_group_dataflow_abort_refactorises_the_merged_plan():
+    """a dataflow launch of the MERGED factorisation that loses a flag leaves garbage factors for every member, and the members' own abort
+    branch looks at counters the merged launch never touched.  "ds_dbg" 21 (read from member 0 at every merged solve) forces the group's abort branch:
+    the merged factorisation must run once more on the launch-per-block-step path, the step must still equal the single-scene step bit for bit, and the
+    group must stay off the dataflow path afterwards"""
+    from thinshelllab_amd.engine.geometry import projection_query
+    from thinshelllab_amd.scene_group import SceneGroup
+    a, b, ref = _make("balancing", 96, 1.0), _make("balancing", 96, 1.3), _make("balancing", 96, 1.0)
+    G = SceneGroup([a, b])
+    _drive(a, 1); _drive(b, 1); _drive(ref, 1)
+    G.time_step(projection_query, 1)
+    ref.time_step(projection_query, 1)
+    i0 = G.info()
+    assert i0["merged_flow_launches"] > 0 and i0["merged_flow_aborts"] == 0, i0
+    assert np.array_equal(a.pos.to_numpy(), ref.pos.to_numpy())
+    a._ensure_ctx().set_param("ds_dbg", 21)
+    _drive(a, 2); _drive(b, 2); _drive(ref, 2)
+    sts = G.time_step(projection_query, 2)
+    a._ensure_ctx().set_param("ds_dbg", 0)
+    ref.time_step(projection_query, 2)
+    i1 = G.info()
+    assert i1["merged_flow_aborts"] == 1, i1
+    assert sts[0]["unconverged"] == 0 and sts[1]["unconverged"] == 0
+    assert np.array_equal(a.pos.to_numpy(), ref.pos.to_numpy()), np.abs(a.pos.to_numpy() - ref.pos.to_numpy()).max()
+    _drive(a, 3); _drive(b, 3)
+    G.time_step(projection_query, 3)
+    assert G.info()["merged_flow_launches"] == i1["merged_flow_launches"]     # the group stays on the block-step path
+    G.close()

@@ -347,3 +347,55 @@ def test_rl_env_box_fallback():
     b = Box(low=-0.001, high=0.001, shape=(12,), dtype=np.float32)
     a = b.sample(np.random.default_rng(0)) if not hasattr(b, "np_random") else b.sample()
     assert a.shape == (12,) and b.contains(a)
+
+
+_BENCH_WORKER = r'''
+import json, os, sys, time
+sys.path.insert(0, sys.argv[1])
+import torch
+import bench
+from thinshelllab_amd.batch import Batch
+
+b = Batch(backend="gloo", device=torch.device("cpu"))
+T, K, W = 1000, 4, 1
+calls = []
+def rollout():                      # stand-in for run_rollout: rank 1 is the slow one
+    calls.append(1)
+    time.sleep(0.20 if b.rank == 1 else 0.05)
+    return {"newton": 7 + b.rank}
+t_wall0 = time.perf_counter()
+stats, elapsed = bench.timed_region(b, rollout)
+t_wall = time.perf_counter() - t_wall0
+assert calls == [1] and stats["newton"] == 7 + b.rank
+assert 0.20 <= elapsed <= t_wall + 1e-3, (elapsed, t_wall)          # the MAX over the ranks: the fast rank reports the slow rank's time too
+out = bench.headline(T, K, W, b.world, elapsed)
+assert out["n_gpus"] == 2 and out["steps"] == K and out["warmup"] == W and out["scaling"] == "weak" and out["higher_is_better"] is True
+assert abs(out["value"] - T * K * 2 / elapsed) < 1e-9 * out["value"] and abs(out["ms_per_step"] - elapsed / K * 1e3) < 1e-9
+assert out["metric"] == json.load(open(os.path.join(sys.argv[1], "BASELINE.json")))["metric"]
+e_all = b.sum_over_ranks(elapsed)
+assert abs(e_all - 2 * elapsed) < 1e-12                              # every rank holds the same elapsed
+bench.emit(out, b.rank)
+b.close()
+'''
+
+
+def test_bench_rank_logic_world_size_2_gloo(tmp_path):
+    """bench.py's own rank logic (timed_region / headline / emit) with a stand-in rollout on two gloo ranks: value = T K world / max-over-ranks seconds,
+    n_gpus = world, and ONLY rank 0 prints the JSON line -- so that the first 8-GPU run is a measurement, not a debugging session"""
+    script = tmp_path / "worker.py"
+    script.write_text(_BENCH_WORKER)
+    env = dict(os.environ, MASTER_ADDR="127.0.0.1", MASTER_PORT="29617")
+    procs = []
+    for r in range(2):
+        e = dict(env, RANK=str(r), WORLD_SIZE="2", LOCAL_RANK=str(r))
+        procs.append(subprocess.Popen([sys.executable, str(script), ROOT], env=e, stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True))
+    outs = []
+    for p in procs:
+        o, err = p.communicate(timeout=240)
+        assert p.returncode == 0, err[-2000:]
+        outs.append(o)
+    lines0 = [ln for ln in outs[0].splitlines() if ln.startswith("{")]
+    assert len(lines0) == 1 and not [ln for ln in outs[1].splitlines() if ln.startswith("{")]
+    import json
+    d = json.loads(lines0[0])
+    assert d["n_gpus"] == 2 and d["value"] > 0 and d["unit"] == "element-steps/s"

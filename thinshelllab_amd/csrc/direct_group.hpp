@@ -93,11 +93,13 @@ struct tsl_group {
   std::vector<size_t> cap_a, cap_s, cap_g, cap_w, off_a, off_s, off_g, off_w;   // capacity and base of every member inside the arenas (doubles)
   std::vector<long> seen_gen;    // plan_gen of every member at the last merge
   bool merged_valid = false;
+  bool flow_lost = false;        // a dataflow launch of the merged factorisation lost a flag once: the group stays on the launch-per-block-step path
   std::vector<hipEvent_t> ev_m;  // member stream -> group stream
   hipEvent_t ev_g = nullptr;     // group stream -> member streams
   long n_merge = 0, n_relayout = 0, n_own_path = 0;
   double t_merge = 0;
   std::unique_ptr<GroupPool> pool;
+  ~tsl_group();                  // frees the pseudo-context, its streams and the events (defined behind group_destroy)
 };
 
 static inline size_t grp_align(size_t n) { return (n + 31) & ~(size_t)31; }   // 256-byte granules
@@ -341,24 +343,8 @@ static int group_create(tsl_ctx* const* ctxs, int n, tsl_group** out) {
   }
   TSL_TRY(G->vals.alloc(tv + 32)); TSL_TRY(G->cH.alloc(th + 144)); TSL_TRY(G->vb.alloc(tx + 32)); TSL_TRY(G->vx.alloc(tx + 32));
   HIP_OK(hipMemset(G->vals.p, 0, G->vals.n * sizeof(double)));
-  for (int i = 0; i < n; i++) {
-    tsl_ctx* c = ctxs[i];
-    auto take = [&](DevBuf<double>& b, double* dstp, size_t cnt) -> int {
-      if (b.n && b.p) HIP_OK(hipMemcpy(dstp, b.p, std::min(b.n, cnt) * sizeof(double), hipMemcpyDeviceToDevice));
-      b.view(dstp, cnt);
-      return 0;
-    };
-    const size_t nvals = c->vals.n, nch = c->c_H.n;
-    TSL_TRY(take(c->vals, G->vals.p + G->vals_off[i], nvals)); TSL_TRY(take(c->c_H, G->cH.p + G->cH_off[i], nch));
-    TSL_TRY(take(c->v_b, G->vb.p + G->vec_off[i], 3 * (size_t)c->NV)); TSL_TRY(take(c->v_x, G->vx.p + G->vec_off[i], 3 * (size_t)c->NV));
-    // the arenas follow at the member's next plan (group_ensure_arenas); what it holds now is dropped
-    DirectSolver& d = c->ds;
-    if (d.prezero_pending) { HIP_OK(hipEventSynchronize(d.ev_zero)); d.prezero_pending = false; }
-    d.arena.release(); d.sarena.release(); d.garena.release(); d.w.release();
-    d.arena.view(nullptr, 0); d.sarena.view(nullptr, 0); d.garena.view(nullptr, 0); d.w.view(nullptr, 0);
-    d.plan_valid = false; d.numeric_valid = false; d.have_factor = false; d.cons_checked = false;
-    for (auto& sl : d.cache) sl->used = false;   // (parked plans were sized against the old arenas: rebuilt on demand)
-  }
+  // Everything that can fail comes BEFORE a member's buffer is touched (a failure behind the hand-over left the members with views into freed
+  // memory): the pseudo-context, its stream, counters and events -- owned by G, whose destructor frees them -- and the copies of the members' contents.
   // pseudo-context: only what direct_factor / direct_apply / ds_dev read
   tsl_ctx* g = new tsl_ctx();
   G->g = g;
@@ -369,14 +355,39 @@ static int group_create(tsl_ctx* const* ctxs, int n, tsl_group** out) {
   const DirectSolver& d0 = ctxs[0]->ds;
   // (the LDS kernel takes a batch that fits the chip in `small_rounds` rounds: n scenes bring n times the leaf fronts, and the alternative -- one launch per
   // block step over all of them -- costs the same per front: measured 1.1 ms of k_ds_gj_step for the 1690 leaf fronts of two cfg4 scenes against 0.14 ms per scene in the LDS kernel)
+  // (the tuning parameters are read from the members again at every merged solve: group_solve)
   gd.merged = true; gd.enable = 1; gd.device = dev; gd.flow = d0.flow; gd.small_rounds = d0.small_rounds * n; gd.xcd_map = d0.xcd_map; gd.gemv_wide_below = d0.gemv_wide_below;
   gd.g32_below = d0.g32_below; gd.piv_tol = d0.piv_tol; gd.prezero = d0.prezero;
   gd.static_ready = true;
   if (gd.bad.alloc(8 + 4 * DS_BADLOG)) return -1;
   HIP_OK(hipFuncSetAttribute((const void*)k_ds_inv_small, hipFuncAttributeMaxDynamicSharedMemorySize, (int)ds_small_lds(DS_SMALL)));
   HIP_OK(hipEventCreateWithFlags(&G->ev_g, hipEventDisableTiming));
-  G->ev_m.resize(n);
+  G->ev_m.assign(n, nullptr);
   for (int i = 0; i < n; i++) HIP_OK(hipEventCreateWithFlags(&G->ev_m[i], hipEventDisableTiming));
+  for (int i = 0; i < n; i++) {   // copies (the members keep their buffers until every copy has succeeded)
+    tsl_ctx* c = ctxs[i];
+    auto copy = [&](const DevBuf<double>& b, double* dstp, size_t cnt) -> int {
+      if (b.n && b.p) HIP_OK(hipMemcpy(dstp, b.p, std::min(b.n, cnt) * sizeof(double), hipMemcpyDeviceToDevice));
+      return 0;
+    };
+    TSL_TRY(copy(c->vals, G->vals.p + G->vals_off[i], c->vals.n)); TSL_TRY(copy(c->c_H, G->cH.p + G->cH_off[i], c->c_H.n));
+    TSL_TRY(copy(c->v_b, G->vb.p + G->vec_off[i], 3 * (size_t)c->NV)); TSL_TRY(copy(c->v_x, G->vx.p + G->vec_off[i], 3 * (size_t)c->NV));
+    DirectSolver& d = c->ds;
+    if (d.prezero_pending) { HIP_OK(hipEventSynchronize(d.ev_zero)); d.prezero_pending = false; }
+  }
+  HIP_OK(hipDeviceSynchronize());
+  for (int i = 0; i < n; i++) {   // hand-over: nothing below can fail
+    tsl_ctx* c = ctxs[i];
+    const size_t nvals = c->vals.n, nch = c->c_H.n;
+    c->vals.view(G->vals.p + G->vals_off[i], nvals); c->c_H.view(G->cH.p + G->cH_off[i], nch);
+    c->v_b.view(G->vb.p + G->vec_off[i], 3 * (size_t)c->NV); c->v_x.view(G->vx.p + G->vec_off[i], 3 * (size_t)c->NV);
+    // the arenas follow at the member's next plan (group_ensure_arenas); what it holds now is dropped
+    DirectSolver& d = c->ds;
+    d.arena.release(); d.sarena.release(); d.garena.release(); d.w.release();
+    d.arena.view(nullptr, 0); d.sarena.view(nullptr, 0); d.garena.view(nullptr, 0); d.w.view(nullptr, 0);
+    d.plan_valid = false; d.numeric_valid = false; d.have_factor = false; d.cons_checked = false;
+    for (auto& sl : d.cache) sl->used = false;   // (parked plans were sized against the old arenas: rebuilt on demand)
+  }
   for (int i = 0; i < n; i++) { ctxs[i]->group = G.get(); ctxs[i]->ds.token_lender = &gd; ctxs[i]->ds.keep_host_maps = true; ds_flow_token_release(ctxs[i]->ds); }
   G->pool.reset(new GroupPool());
   if (n > 1 && !getenv("TSL_GROUP_NO_THREADS")) G->pool->start(n, dev);
@@ -394,6 +405,7 @@ static void group_destroy(tsl_group* G) {
       const double* src = b.p; const size_t cnt = b.n;
       b.view(nullptr, 0); b.release();
       if (cnt && b.alloc(cnt) == 0) (void)hipMemcpy(b.p, src, cnt * sizeof(double), hipMemcpyDeviceToDevice);
+      else if (cnt) fprintf(stderr, "[tsl] scene group: out of device memory while a member took back a buffer of %zu doubles: the member is left with an EMPTY buffer (its next call fails loudly)\n", cnt);
     };
     give(c->vals); give(c->c_H); give(c->v_b); give(c->v_x);
     DirectSolver& d = c->ds;
@@ -403,16 +415,21 @@ static void group_destroy(tsl_group* G) {
     d.token_lender = nullptr; d.keep_host_maps = false;
     c->group = nullptr;
   }
-  if (G->g) {
-    ds_flow_token_release(G->g->ds);
-    DirectSolver& gd = G->g->ds;
+  delete G;
+}
+
+tsl_group::~tsl_group() {
+  pool.reset();
+  if (g) {
+    ds_flow_token_release(g->ds);
+    DirectSolver& gd = g->ds;
     if (gd.zstream) (void)hipStreamDestroy(gd.zstream);
     for (int k = 0; k < DS_NSIDE; k++) if (gd.fstream[k]) (void)hipStreamDestroy(gd.fstream[k]);
     if (gd.pin) (void)hipHostFree(gd.pin);
-    if (G->g->stream) (void)hipStreamDestroy(G->g->stream);
-    delete G->g;
+    if (g->stream) (void)hipStreamDestroy(g->stream);
+    delete g;
+    g = nullptr;
   }
-  for (hipEvent_t e : G->ev_m) if (e) (void)hipEventDestroy(e);
-  if (G->ev_g) (void)hipEventDestroy(G->ev_g);
-  delete G;
+  for (hipEvent_t e : ev_m) if (e) (void)hipEventDestroy(e);
+  if (ev_g) (void)hipEventDestroy(ev_g);
 }

@@ -15,6 +15,7 @@
 // factorisation and keeps it until it is destroyed, a context that was refused asks again every 256 factorisations (the holder may be gone)
 // and runs the same block steps as one launch each meanwhile.  Every inversion path produces the same bits (k_direct.hpp), so which
 // context holds the token changes times, not answers.
+#include <cerrno>
 #include <fcntl.h>
 #include <sys/file.h>
 #include <sys/stat.h>
@@ -26,8 +27,16 @@ static void ds_flow_token_acquire(DirectSolver& d) {
   d.flow_token = -1; d.flow_token_asked = d.n_factor;
   for (const char* dir : {"/dev/shm", "/tmp"}) {
     const std::string path = std::string(dir) + "/tsl_flow_" + bus;
-    const int fd = open(path.c_str(), O_CREAT | O_RDWR | O_CLOEXEC, 0666);
-    if (fd < 0) continue;
+    // an existing file first, WITHOUT O_CREAT: with fs.protected_regular set, O_CREAT on another user's file in a sticky directory fails with EACCES although the
+    // file can be opened; only a missing DIRECTORY (ENOENT / ENOTDIR from the create) sends the process to the next directory -- any other failure is a refusal,
+    // or two processes would hold "the" token in two directories
+    int fd = open(path.c_str(), O_RDWR | O_CLOEXEC);
+    if (fd < 0 && errno == ENOENT) {
+      fd = open(path.c_str(), O_CREAT | O_RDWR | O_CLOEXEC, 0666);
+      if (fd < 0 && (errno == ENOENT || errno == ENOTDIR)) continue;   // no such directory on this box
+      if (fd < 0 && errno == EEXIST) fd = open(path.c_str(), O_RDWR | O_CLOEXEC);
+    } else if (fd < 0 && errno == ENOTDIR) continue;
+    if (fd < 0) return;   // refused (EACCES, EPERM, ...): this context stays on the launch-per-block-step path and asks again later
     (void)fchmod(fd, 0666);   // (another user's process must be able to open it)
     if (flock(fd, LOCK_EX | LOCK_NB) == 0) { d.flow_token = 1; d.flow_token_fd = fd; }
     else close(fd);

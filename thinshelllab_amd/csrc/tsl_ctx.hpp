@@ -186,6 +186,7 @@ struct DirectSolver {
   double anorm = 0;           // infinity norm of the factorised operator's static part (backward-error yardstick)
   bool anorm_valid = false;   // anorm belongs to an operator at most 64 factorisations old
   int anorm_age = 0;
+  int anorm_spd = -1;         // projection mode of the assembly the norm belongs to (the adjoint's un-projected operator gets its own)
   DevBuf<double> anorm_dev;
   hipEvent_t ev0 = nullptr, ev1 = nullptr;
 };
@@ -305,6 +306,7 @@ struct tsl_ctx {
   // preconditioner built from a different (SPD-projected) assembly than the operator: adjoint solves (un-projected H)
   DevBuf<double> vals_pc, c_H_pc;
   bool pc_separate = false, pc_frozen = false, in_step = false;
+  bool dinv_valid = false;    // Dinv holds the block-Jacobi inverse of the operator in place (an assembly for the direct path does not form it)
   const double *st_pos = nullptr, *st_prev = nullptr, *st_vel = nullptr, *st_ref = nullptr;  // state of the last assemble
   int fwd_spd_pc = 1;
   int adj_spd_pc = 1;

@@ -105,6 +105,8 @@ static int mg_build(tsl_ctx* c, const tsl_scene_desc* d);
 static int body_dense_setup(tsl_ctx* c);
 static bool body_active(tsl_ctx* c);
 static void body_zero_dinv(tsl_ctx* c);
+static bool direct_takes_solve(tsl_ctx* c);
+static int block_jacobi_refresh(tsl_ctx* c);
 extern "C" const char* tsl_version(void) { return "tsl-hip 0.1 gfx950 fp64"; }
 extern "C" const char* tsl_last_error(void) { return g_tsl_err.c_str(); }
 
@@ -422,6 +424,7 @@ extern "C" int tsl_set_param(tsl_ctx* c, const char* key, double v) {
   Scope scope(c);
   (void)hipStreamSynchronize(c->stream);
   c->mg_omega_valid = false; c->mg_cinv_valid = false;
+  c->ds.anorm_valid = false;   // any key may change the scale of the operator (materials, contact stiffness): |H|_inf is formed again when a refinement asks for it
   std::string k(key);
   if (k == "mu_cloth_elastic") c->mu_cloth_elastic = v;
   else if (k == "mu_cloth_cloth") c->mu_cloth_cloth = v;
@@ -689,8 +692,10 @@ static int assemble_enqueue(tsl_ctx* c, const double* pos, const double* prev, c
   hipLaunchKernelGGL(k_mask_matrix, dim3(c->n_slices), dim3(256), 0, s, c->n_slices, c->slice_off.p, c->slice_len.p, c->colidx.p, c->fzmask.p, c->mdt2.p,
                      c->vals_full.p, c->vals.p, NV);
   if (!c->pc_frozen) {
-    hipLaunchKernelGGL(k_block_jacobi, dim3(nblk(NV, 256)), dim3(256), 0, s, NV, c->diag_perm.p, c->vals.p, c->nc > 0 ? c->c_diag.p : (const double*)nullptr, c->Dinv.p);
-    if (body_active(c) && c->bd_valid) body_zero_dinv(c);  // those rows are served by the (lagged) dense inverse
+    // the block-Jacobi inverse belongs to the iterative hierarchy: a solve that goes to the factorisation never reads it (9 us + one dependent launch per
+    // Newton iteration of the direct path); solve_perm forms it when the hierarchy runs after all (block_jacobi_ensure)
+    if (direct_takes_solve(c)) c->dinv_valid = false;
+    else TSL_TRY(block_jacobi_refresh(c));
   }
   HIP_OK(hipGetLastError());
   return 0;
@@ -778,8 +783,10 @@ static int assemble_enqueue_early(tsl_ctx* c, const double* pos, const double* p
   HIP_OK(hipEventRecord(c->ev_join, st));
   HIP_OK(hipStreamWaitEvent(s, c->ev_join, 0));   // (contact diagonal for the block-Jacobi inverse, the gradient for whatever follows)
   if (!c->pc_frozen) {
-    hipLaunchKernelGGL(k_block_jacobi, dim3(nblk(NV, 256)), dim3(256), 0, s, NV, c->diag_perm.p, c->vals.p, c->nc > 0 ? c->c_diag.p : (const double*)nullptr, c->Dinv.p);
-    if (body_active(c) && c->bd_valid) body_zero_dinv(c);  // those rows are served by the (lagged) dense inverse
+    // the block-Jacobi inverse belongs to the iterative hierarchy: a solve that goes to the factorisation never reads it (9 us + one dependent launch per
+    // Newton iteration of the direct path); solve_perm forms it when the hierarchy runs after all (block_jacobi_ensure)
+    if (direct_takes_solve(c)) c->dinv_valid = false;
+    else TSL_TRY(block_jacobi_refresh(c));
   }
   HIP_OK(hipGetLastError());
   return 0;
@@ -813,7 +820,8 @@ static int assemble(tsl_ctx* c, const double* pos, const double* prev, const dou
   }
   // ---- host state
   c->st_pos = pos; c->st_prev = prev; c->st_vel = vel; c->st_ref = ref;  // for forward_spd_pc (valid while tsl_step runs)
-  c->ds.numeric_valid = false;   // (|H|_inf, the yardstick of the backward errors, ages with the factorisations: direct_factor)
+  c->ds.numeric_valid = false;   // (|H|_inf, the yardstick of the backward errors, ages with the factorisations: direct_factor / group_solve)
+  if (spd != c->ds.anorm_spd) { c->ds.anorm_valid = false; c->ds.anorm_spd = spd; }   // the un-projected adjoint operator does not borrow the forward operator's norm (and back)
   if (!c->pc_frozen) { c->mg_ops_valid = false; c->pc_separate = false; }
   return assemble_enqueue(c, pos, prev, vel, ref, spd, grad, warm);
 }
@@ -873,6 +881,19 @@ static int read_scal(tsl_ctx* c) {
 static int bicgstab(tsl_ctx* c, tsl_solve_stats* st);
 static int gmres(tsl_ctx* c, tsl_solve_stats* st, bool direct = false);
 static int direct_refine(tsl_ctx* c, tsl_solve_stats* st, bool first_applied = false);
+// does the next linear solve of this context go straight to the factorisation (solve_perm's rule, the probe of the automatic mode included)?
+static bool direct_takes_solve(tsl_ctx* c) {
+  const DirectSolver& d = c->ds;
+  return direct_enabled(c) && !c->ds_suspended && !(d.enable < 0 && !d.hard && c->n_tet == 0 && c->nc == 0);
+}
+static int block_jacobi_refresh(tsl_ctx* c) {
+  hipLaunchKernelGGL(k_block_jacobi, dim3(nblk(c->NV, 256)), dim3(256), 0, c->stream, c->NV, c->diag_perm.p, c->vals.p, c->nc > 0 ? c->c_diag.p : (const double*)nullptr, c->Dinv.p);
+  if (body_active(c) && c->bd_valid) body_zero_dinv(c);  // those rows are served by the (lagged) dense inverse
+  c->dinv_valid = true;
+  return 0;
+}
+static int block_jacobi_ensure(tsl_ctx* c) { return c->dinv_valid ? 0 : block_jacobi_refresh(c); }
+
 static int minres(tsl_ctx* c, tsl_solve_stats* st);
 
 // ------------------------------------------------------------------------------------------------ dense body blocks (k_body.hpp)
@@ -1430,6 +1451,7 @@ static int solve_perm(tsl_ctx* c, tsl_solve_stats* st) {
     st->flag = s2.flag == 0 ? 1 : s2.flag;
     return rc;
   }
+  TSL_TRY(block_jacobi_ensure(c));   // (skipped by an assembly that expected the factorisation to take this solve)
   const bool warm = false;   // (a warm start from the previous Newton direction was measured: -4 % iterations on one cfg4 window, none on another, +2 % time on drape; gone)
   if (!warm) HIP_OK(hipMemsetAsync(c->v_x.p, 0, n3 * sizeof(double), s));
   HIP_OK(hipMemsetAsync(c->scal.p, 0, sizeof(SolverScalars), s));
@@ -2279,10 +2301,12 @@ extern "C" int tsl_group_create(tsl_ctx* const* ctxs, int32_t n, tsl_group** out
 }
 extern "C" void tsl_group_destroy(tsl_group* G) { if (G) group_unregister_and_destroy(G); }
 // {merges of the members' plans, re-layouts of the group's arenas, host seconds in merges, bytes of the group's arenas, factorisations and applications of the merged plan,
-// solves in which a member went on from the merged first pass on its own path}
-extern "C" int tsl_group_info(tsl_group* G, double* out6) {   // (seven values)
-  out6[0] = (double)G->n_merge; out6[1] = (double)G->n_relayout; out6[2] = G->t_merge; out6[3] = 8.0 * (double)(G->arena.n + G->sarena.n + G->garena.n + G->w.n);
-  out6[4] = (double)G->g->ds.n_factor; out6[5] = (double)G->g->ds.n_apply; out6[6] = (double)G->n_own_path;
+// solves in which a member went on from the merged first pass on its own path, dataflow launches of the merged factorisations, merged factorisations redone on the
+// block-step path after such a launch lost a flag}
+extern "C" int tsl_group_info(tsl_group* G, double* out9) {   // (nine values)
+  out9[0] = (double)G->n_merge; out9[1] = (double)G->n_relayout; out9[2] = G->t_merge; out9[3] = 8.0 * (double)(G->arena.n + G->sarena.n + G->garena.n + G->w.n);
+  out9[4] = (double)G->g->ds.n_factor; out9[5] = (double)G->g->ds.n_apply; out9[6] = (double)G->n_own_path;
+  out9[7] = (double)G->g->ds.n_flow; out9[8] = (double)G->g->ds.n_flow_abort;
   return 0;
 }
 
@@ -2307,52 +2331,101 @@ static int group_solve(tsl_group* G, const std::vector<int>& act, std::vector<ts
     TSL_TRY(group_merge(G));
   }
   lap(1);
-  // ---- ONE factorisation and ONE application for all members
-  for (int i = 0; i < n; i++) { HIP_OK(hipEventRecord(G->ev_m[i], G->m[i]->stream)); HIP_OK(hipStreamWaitEvent(g->stream, G->ev_m[i], 0)); }
-  g->ds.numeric_valid = false;
-  TSL_TRY(direct_factor(g));
-  lap(2);
-  TSL_TRY(direct_apply(g, G->vb.p, G->vx.p));
-  HIP_OK(hipEventRecord(G->ev_g, g->stream));
-  lap(3);
-  for (int i = 0; i < n; i++) HIP_OK(hipStreamWaitEvent(G->m[i]->stream, G->ev_g, 0));
-  // ---- per member: residual of the merged first pass and the stop rule of direct_refine
+  // ---- the merged solver takes its tuning from the members at every solve (a tsl_set_param on a member after the group was formed must not be lost: a stale
+  // piv_tol changes the factors, and with them the promise that a member's tape equals its single-scene run); members that disagree are an error
+  {
+    DirectSolver& gd = g->ds;
+    const DirectSolver& d0 = G->m[0]->ds;
+    for (int i = 1; i < n; i++) {
+      const DirectSolver& di = G->m[i]->ds;
+      if (di.piv_tol != d0.piv_tol || di.flow != d0.flow || di.g32_below != d0.g32_below || di.gemv_wide_below != d0.gemv_wide_below || di.small_rounds != d0.small_rounds ||
+          di.xcd_map != d0.xcd_map || di.prezero != d0.prezero)
+        return tsl_fail("scene group: members 0 and %d differ in a parameter of the factorisation (direct_piv_tol / _flow / _g32_below / _gemv_wide_below / _small_rounds / _xcd / _prezero)", i);
+    }
+    if (gd.piv_tol != d0.piv_tol) gd.piv_tol = d0.piv_tol;
+    gd.flow = G->flow_lost ? 0 : d0.flow; gd.g32_below = d0.g32_below; gd.gemv_wide_below = d0.gemv_wide_below; gd.small_rounds = d0.small_rounds * n; gd.xcd_map = d0.xcd_map;
+    gd.prezero = d0.prezero; gd.dbg = d0.dbg;
+  }
+  // ---- ONE factorisation and ONE application for all members, the verdict on the first pass per member (direct_refine's rule).  A dataflow launch of the MERGED
+  // factorisation that lost a flag leaves garbage factors for every member (solve_perm's abort branch looks at the member's own counters, which the merged launch never
+  // touched): before any member is sent down its own path the merged launch's abort word is read, and on an abort the merged factorisation runs once more on the
+  // launch-per-block-step path
   ss.assign(n, tsl_solve_stats{});
-  for (int i : act) {
-    tsl_ctx* c = G->m[i];
-    const size_t n3 = 3 * (size_t)c->NV;
-    const int gv = std::min(gsz(n3), 240);
-    if (c->ir_part.n < (size_t)4 * 240 + 8 && c->ir_part.alloc(4 * 240 + 8)) return -1;
-    if (c->ir_ticket.n < 2) { if (c->ir_ticket.alloc(2)) return -1; HIP_OK(hipMemsetAsync(c->ir_ticket.p, 0, 2 * sizeof(int), c->stream)); }
-    if (c->h_ir == nullptr) HIP_OK(hipHostMalloc((void**)&c->h_ir, 8 * sizeof(double)));
-    double* out = c->ir_part.p + 4 * 240;
-    launch_spmv(c, c->vals.p, c->v_x.p, c->v_Ap.p, -1, 0);
-    hipLaunchKernelGGL(k_ir_resid, dim3(gv), dim3(256), 0, c->stream, n3, (const double*)c->v_b.p, (const double*)c->v_Ap.p, (const double*)c->v_x.p, c->v_r.p, c->ir_part.p, c->ir_ticket.p, out);
-    HIP_OK(hipMemcpyAsync(c->h_ir, out, 4 * sizeof(double), hipMemcpyDeviceToHost, c->stream));
+  std::vector<char> okv(n, 1);
+  std::vector<double> rr0(n, 0.0), bb0(n, 0.0);
+  for (int attempt = 0; attempt < 2; attempt++) {
+    DirectSolver& gd = g->ds;
+    for (int i = 0; i < n; i++) { HIP_OK(hipEventRecord(G->ev_m[i], G->m[i]->stream)); HIP_OK(hipStreamWaitEvent(g->stream, G->ev_m[i], 0)); }
+    gd.numeric_valid = false;
+    if (attempt > 0) {
+      gd.have_factor = false;   // the factors in place are garbage: direct_factor must not return early
+      if (gd.prezero_pending) { HIP_OK(hipStreamWaitEvent(g->stream, gd.ev_zero, 0)); gd.prezero_pending = false; }
+    }
+    TSL_TRY(direct_factor(g));
+    if (attempt == 0) for (int i = 0; i < n; i++) { DirectSolver& d = G->m[i]->ds; if (++d.anorm_age >= 64) d.anorm_valid = false; }   // (the members never call direct_factor: |H|_inf ages here)
+    lap(2);
+    TSL_TRY(direct_apply(g, G->vb.p, G->vx.p));
+    HIP_OK(hipEventRecord(G->ev_g, g->stream));
+    lap(3);
+    for (int i = 0; i < n; i++) HIP_OK(hipStreamWaitEvent(G->m[i]->stream, G->ev_g, 0));
+    for (int i : act) {
+      tsl_ctx* c = G->m[i];
+      const size_t n3 = 3 * (size_t)c->NV;
+      const int gv = std::min(gsz(n3), 240);
+      if (c->ir_part.n < (size_t)4 * 240 + 8 && c->ir_part.alloc(4 * 240 + 8)) return -1;
+      if (c->ir_ticket.n < 2) { if (c->ir_ticket.alloc(2)) return -1; HIP_OK(hipMemsetAsync(c->ir_ticket.p, 0, 2 * sizeof(int), c->stream)); }
+      if (c->h_ir == nullptr) HIP_OK(hipHostMalloc((void**)&c->h_ir, 8 * sizeof(double)));
+      double* out = c->ir_part.p + 4 * 240;
+      launch_spmv(c, c->vals.p, c->v_x.p, c->v_Ap.p, -1, 0);
+      hipLaunchKernelGGL(k_ir_resid, dim3(gv), dim3(256), 0, c->stream, n3, (const double*)c->v_b.p, (const double*)c->v_Ap.p, (const double*)c->v_x.p, c->v_r.p, c->ir_part.p, c->ir_ticket.p, out);
+      HIP_OK(hipMemcpyAsync(c->h_ir, out, 4 * sizeof(double), hipMemcpyDeviceToHost, c->stream));
+    }
+    bool any_bad = false;
+    for (int i : act) {
+      tsl_ctx* c = G->m[i];
+      DirectSolver& d = c->ds;
+      HIP_OK(hipStreamSynchronize(c->stream));
+      tsl_solve_stats& s1 = ss[i];
+      memset(&s1, 0, sizeof(s1));
+      const double rr = c->h_ir[0], xx = c->h_ir[1], bb = c->h_ir[2];
+      rr0[i] = rr; bb0[i] = bb;
+      c->last_xmax = c->h_ir[3]; c->last_xmax_valid = true;
+      s1.iters = 1; s1.method = 4;
+      bool ok = false;
+      if (!(bb > 0)) ok = true;
+      else {
+        s1.rel_residual = sqrt(rr / bb);
+        if (std::isfinite(rr)) {
+          if (rr <= c->cg_tol * c->cg_tol * bb) ok = true;
+          else if (d.berr_tol > 0 && rr <= d.berr_rel_cap * d.berr_rel_cap * c->cg_tol * c->cg_tol * bb) {   // (the rule of direct_refine's first pass)
+            TSL_TRY(direct_anorm(c));
+            const double be = sqrt(rr) / (d.anorm * sqrt(xx) + sqrt(bb));
+            d.berr_seen++;
+            if (be <= d.berr_tol) { ok = true; s1.backward_error = be; d.berr_accepted++; d.berr_max = std::max(d.berr_max, be); d.berr_rel_max = std::max(d.berr_rel_max, s1.rel_residual); }
+          }
+        }
+      }
+      okv[i] = ok ? 1 : 0;
+      any_bad |= !ok;
+    }
+    if (attempt == 0 && (any_bad || gd.dbg == 21) && gd.flow && gd.n_flow > 0) {
+      int ab = 0;
+      HIP_OK(hipStreamSynchronize(g->stream));
+      HIP_OK(hipMemcpy(&ab, gd.bad.p + DS_FLOW_ABORT, sizeof(int), hipMemcpyDeviceToHost));
+      if (ab || gd.dbg == 21) {   // ("ds_dbg" 21: tests force this branch)
+        fprintf(stderr, "[tsl] scene group: k_ds_gj_flow of the merged factorisation waited in vain for a flag: \"direct_flow\" disabled for the group, refactorising\n");
+        gd.flow = 0; gd.n_flow_abort++; G->flow_lost = true;
+        continue;
+      }
+    }
+    break;
   }
   for (int i : act) {
     tsl_ctx* c = G->m[i];
     DirectSolver& d = c->ds;
-    HIP_OK(hipStreamSynchronize(c->stream));
     tsl_solve_stats& s1 = ss[i];
-    memset(&s1, 0, sizeof(s1));
-    const double rr = c->h_ir[0], xx = c->h_ir[1], bb = c->h_ir[2];
-    c->last_xmax = c->h_ir[3]; c->last_xmax_valid = true;
-    s1.iters = 1; s1.method = 4;
-    bool ok = false;
-    if (!(bb > 0)) ok = true;
-    else {
-      s1.rel_residual = sqrt(rr / bb);
-      if (std::isfinite(rr)) {
-        if (rr <= c->cg_tol * c->cg_tol * bb) ok = true;
-        else if (d.berr_tol > 0 && rr <= d.berr_rel_cap * d.berr_rel_cap * c->cg_tol * c->cg_tol * bb) {   // (the rule of direct_refine's first pass)
-          TSL_TRY(direct_anorm(c));
-          const double be = sqrt(rr) / (d.anorm * sqrt(xx) + sqrt(bb));
-          d.berr_seen++;
-          if (be <= d.berr_tol) { ok = true; s1.backward_error = be; d.berr_accepted++; d.berr_max = std::max(d.berr_max, be); d.berr_rel_max = std::max(d.berr_rel_max, s1.rel_residual); }
-        }
-      }
-    }
+    const double rr = rr0[i], bb = bb0[i];
+    const bool ok = okv[i] != 0;
     if (!ok) {
       // The merged factorisation IS the member's factorisation (its own plan addresses the same memory in the same layout): the member goes on
       // from the merged first pass on its own path -- refinement with its own sweeps, flexible GMRES and the hierarchy behind it (solve_perm) if that

@@ -97,7 +97,8 @@ class SceneGroup:
                     g.get_gripper_grad(step, s)
 
     def info(self):
-        v = (C.c_double * 7)()
+        v = (C.c_double * 9)()
         check(self.L.tsl_group_info(self.h, v), "tsl_group_info")
-        keys = ("plan_merges", "arena_relayouts", "merge_seconds", "arena_bytes", "merged_factorizations", "merged_applications", "member_solves_on_own_path")
+        keys = ("plan_merges", "arena_relayouts", "merge_seconds", "arena_bytes", "merged_factorizations", "merged_applications", "member_solves_on_own_path",
+                "merged_flow_launches", "merged_flow_aborts")
         return dict(zip(keys, [float(x) for x in v]))
