@@ -364,82 +364,12 @@ __global__ void k_contact_energy(int nc, ContactArgs A, const double* __restrict
 // ------------------------------------------------------------------------------------------------ gradient + blocks
 // Normal part: d = D / C with D = p . (p1 x p2), C = |p1 x p2| in the relative coordinates q = (p1, p2, p); quotient rule as BaseScene.py:502-521,
 // 9 x 9 eigen-clamp (linalg.py:15-148), friction block (BaseScene.py:548-593).  16 lanes per constraint: lane l < 9 of a group owns ROW l of the
-// 9 x 9 normal block (relative coordinate l = 3 (vertex - 1) + axis), lanes 9..11 the three rows of vertex 0; the cyclic Jacobi eigen-clamp runs
-// on the group's matrix in LDS, one lane per row / column of a rotation.  (One lane per constraint with the block and the eigenvector matrix in
-// private arrays ran ~10 Jacobi sweeps serially: 0.9 ms per launch at 200 constraints; gone.)
+// 9 x 9 normal block (relative coordinate l = 3 (vertex - 1) + axis), lanes 9..11 the three rows of vertex 0; the Jacobi eigen-clamp runs on the
+// group's matrix in LDS with the parallel rotation order of spd_clamp9_par (tsl_device.hpp).  (One lane per constraint with the block and the
+// eigenvector matrix in private arrays ran ~10 Jacobi sweeps serially: 0.9 ms per launch at 200 constraints; the cyclic order with one rotation at
+// a time and 16 lanes in lock step: 125-185 us; gone.)
 TSL_DEV d3 c_unit(int a) { return d3(a == 0 ? 1.0 : 0.0, a == 1 ? 1.0 : 0.0, a == 2 ? 1.0 : 0.0); }
 TSL_DEV double c_comp(const d3& v, int a) { return a == 0 ? v.x : (a == 1 ? v.y : v.z); }
-// cyclic Jacobi eigen-clamp A <- sum_{lambda > 0} lambda v v^T of the symmetric 9 x 9 matrix of a 16-lane group, matrix and
-// eigenvectors in LDS (sa, sv: 81 doubles each), lane k < 9 works on row k / column k; same rotation order, threshold and sweep
-// limit as spd_clamp<9>.  The four groups of a wave run in lockstep (a wave's LDS operations complete in order), `on` is uniform
-// within the group.  A version with the rows in registers and lane shuffles needed 256 + 125 registers and 1.4 ms per launch.
-TSL_DEV void spd_clamp9_lds(double* __restrict__ sa, double* __restrict__ sv, int l, bool on) {
-  const bool row = l < 9;
-  if (row) {
-#pragma unroll
-    for (int k = 0; k < 9; k++) sv[l * 9 + k] = (k == l) ? 1.0 : 0.0;
-  }
-  __builtin_amdgcn_wave_barrier();
-  if (row && on) {  // symmetrise (lane l rewrites the upper part of its row and the mirrored entries); an un-clamped block stays as it is:
-                    // the kind-1 element block with J clamped is not an exact Hessian and keeps its non-symmetric part
-    for (int k = l + 1; k < 9; k++) { const double t = 0.5 * (sa[l * 9 + k] + sa[k * 9 + l]); sa[l * 9 + k] = t; sa[k * 9 + l] = t; }
-  }
-  __builtin_amdgcn_wave_barrier();
-  bool done = !on;
-  for (int sweep = 0; sweep < 30; sweep++) {
-    double off = 0.0, diag = 0.0;
-    if (row) {
-      for (int k = 0; k < 9; k++) { const double v = sa[l * 9 + k]; if (k == l) diag = v * v; else off += v * v; }
-    }
-#pragma unroll
-    for (int o = 8; o > 0; o >>= 1) { off += __shfl_xor(off, o, 16); diag += __shfl_xor(diag, o, 16); }
-    if (0.5 * off <= 1e-32 * (diag + 0.5 * off)) done = true;
-    if (!__any(!done)) break;
-    for (int p = 0; p < 8; p++)
-      for (int q = p + 1; q < 9; q++) {
-        const double apq = sa[p * 9 + q], app = sa[p * 9 + p], aqq = sa[q * 9 + q];
-        double c = 1.0, s = 0.0;
-        if (apq != 0.0 && !done) {
-          const double theta = (aqq - app) / (2.0 * apq);
-          const double t = (theta >= 0 ? 1.0 : -1.0) / (fabs(theta) + sqrt(theta * theta + 1.0));
-          c = 1.0 / sqrt(t * t + 1.0); s = t * c;
-        }
-        __builtin_amdgcn_wave_barrier();
-        if (row) {  // columns p, q of row l (matrix and eigenvectors)
-          const double akp = sa[l * 9 + p], akq = sa[l * 9 + q];
-          sa[l * 9 + p] = c * akp - s * akq; sa[l * 9 + q] = s * akp + c * akq;
-          const double vkp = sv[l * 9 + p], vkq = sv[l * 9 + q];
-          sv[l * 9 + p] = c * vkp - s * vkq; sv[l * 9 + q] = s * vkp + c * vkq;
-        }
-        __builtin_amdgcn_wave_barrier();
-        if (row) {  // rows p, q, column l
-          const double apk = sa[p * 9 + l], aqk = sa[q * 9 + l];
-          sa[p * 9 + l] = c * apk - s * aqk; sa[q * 9 + l] = s * apk + c * aqk;
-        }
-        __builtin_amdgcn_wave_barrier();
-      }
-  }
-  // A = sum_e max(lambda_e, 0) v_e v_e^T, row l
-  double outr[9];
-  if (row) {
-#pragma unroll
-    for (int j = 0; j < 9; j++) outr[j] = 0.0;
-    for (int e = 0; e < 9; e++) {
-      const double d = sa[e * 9 + e];
-      const double lam = d > 0.0 ? d : 0.0;
-      const double vl = lam * sv[l * 9 + e];
-#pragma unroll
-      for (int j = 0; j < 9; j++) outr[j] += vl * sv[j * 9 + e];
-    }
-  }
-  __builtin_amdgcn_wave_barrier();
-  if (row && on) {
-#pragma unroll
-    for (int j = 0; j < 9; j++) sa[l * 9 + j] = outr[j];
-  }
-  __builtin_amdgcn_wave_barrier();
-}
-
 __global__ void __launch_bounds__(256)
 k_contact_assemble_coop(int nc, ContactArgs A, const double* __restrict__ pos, int spd, double* __restrict__ grad, double* __restrict__ Hfull, double* __restrict__ cg) {
   const int l = threadIdx.x & 15;
@@ -497,7 +427,7 @@ k_contact_assemble_coop(int nc, ContactArgs A, const double* __restrict__ pos, i
 #pragma unroll
       for (int k = 0; k < 9; k++) sA[g][l * 9 + k] = h[k];
     }
-    spd_clamp9_lds(sA[g], sV[g], l, active);
+    spd_clamp9_cold(sA[g], sV[g], l, active);   // (tsl_device.hpp: nine rounds of four simultaneous rotations per sweep)
     if (l < 9) {
 #pragma unroll
       for (int k = 0; k < 9; k++) h[k] = sA[g][l * 9 + k];
@@ -962,6 +892,11 @@ extern "C" int tsl_contact_detect(tsl_ctx* c, const double* pos, const double* p
   return 0;
 }
 
+static bool direct_takes_solve(tsl_ctx* c);
+static void contact_diag_refresh(tsl_ctx* c, hipStream_t s) {
+  hipLaunchKernelGGL(k_contact_diag, dim3(cnblk((long)c->NV * 64, 256)), dim3(256), 0, s, c->NV, (const int*)c->cr_ptr.p, (const int*)c->cr_ent.p, (const double*)c->c_H.p, c->c_diag.p);
+  c->cdiag_valid = true;
+}
 static int contact_assemble(tsl_ctx* c, const double* pos, int spd, double* grad, hipStream_t s) {
   if (c->nc <= 0) return 0;
   ContactArgs A;
@@ -973,8 +908,12 @@ static int contact_assemble(tsl_ctx* c, const double* pos, int spd, double* grad
   hipLaunchKernelGGL(k_contact_assemble_coop, dim3(cnblk((long)c->nc * 16, 256)), dim3(256), 0, s, c->nc, A, pos, spd, grad, c->c_Hfull.p, cg);
   if (c->deterministic) {
     hipLaunchKernelGGL(k_contact_mask, dim3(cnblk((long)c->nc * 144, 256)), dim3(256), 0, s, c->nc, c->c_idx.p, c->frozen.p, c->rowpos.p, c->c_Hfull.p, c->c_H.p, (double*)nullptr);
-    hipLaunchKernelGGL(k_contact_diag, dim3(cnblk((long)c->NV * 64, 256)), dim3(256), 0, s, c->NV, (const int*)c->cr_ptr.p, (const int*)c->cr_ent.p, (const double*)c->c_H.p, c->c_diag.p);
+    // the diagonal 3 x 3 blocks of the contact terms feed the block-Jacobi inverse and the hierarchy's Galerkin diagonal only: a solve that goes to the
+    // factorisation never reads them (45 us on the longest chain of an assembly); block_jacobi_refresh forms them when the hierarchy runs after all
+    if (direct_takes_solve(c)) c->cdiag_valid = false;
+    else { contact_diag_refresh(c, s); }
   } else {
+    c->cdiag_valid = true;
     HIP_OK(hipMemsetAsync(c->c_diag.p, 0, c->c_diag.n * sizeof(double), s));
     hipLaunchKernelGGL(k_contact_mask, dim3(cnblk((long)c->nc * 144, 256)), dim3(256), 0, s, c->nc, c->c_idx.p, c->frozen.p, c->rowpos.p, c->c_Hfull.p, c->c_H.p, c->c_diag.p);
   }

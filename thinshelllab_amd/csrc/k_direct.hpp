@@ -1144,13 +1144,15 @@ TSL_DEV void ds_gemm_tile(const DsDev& D, int lv0, int bx, int by, int bz) {
   // Schur complement: S = F22 - F21 G with F22 = the children's Schur complements extended to this front, gathered here (F22 is never
   // materialised) child after child in the fixed order of the plan; S is stored once, coalesced, for the parent to gather in turn.
   if (f.parent < 0) return;
+  // (the sums start from -F21 G and take the children in the plan's order: one set of 16 registers instead of two -- the accumulators next to the
+  // children's sums and 16 gathered entries in flight spilled 12 registers at four workgroups per CU)
   double s22[2][2][4];
 #pragma unroll
   for (int a = 0; a < 2; a++)
 #pragma unroll
     for (int b = 0; b < 2; b++)
 #pragma unroll
-      for (int r = 0; r < 4; r++) s22[a][b][r] = 0.0;
+      for (int r = 0; r < 4; r++) s22[a][b][r] = -acc[a][b][r];
   const int row0 = I0 + 32 * wi + lk, col0 = J0 + 32 * wj + lr;   // + 16 a + 4 r / + 16 b
   for (int q0 = 0; q0 < f.nchild; q0 += GMC) {
     const int nq = min(GMC, f.nchild - q0);
@@ -1202,7 +1204,7 @@ TSL_DEV void ds_gemm_tile(const DsDev& D, int lv0, int bx, int by, int bz) {
 #pragma unroll
       for (int b = 0; b < 2; b++) {
         const int col = col0 + 16 * b;
-        if (col < f.b) Sf[(size_t)row * f.bp + col] = s22[a][b][r] - acc[a][b][r];
+        if (col < f.b) Sf[(size_t)row * f.bp + col] = s22[a][b][r];
       }
     }
 }

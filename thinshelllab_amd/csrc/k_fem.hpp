@@ -190,6 +190,106 @@ TSL_DEV m3 tet_dH(const ElasticDev& e, const m3& F, const m3& Fi, const m3& FiT,
   return r;
 }
 
+// Element Hessians, cooperative form (round 6): 16 lanes per tetrahedron, the 9 x 9 block in LDS.  Lane c < 9 forms ROW c = (vertex n, axis dim) of the
+// block (one directional derivative tet_dH each instead of nine per lane), the eigen-clamp is spd_clamp9_par (tsl_device.hpp: nine rounds of four simultaneous
+// Jacobi rotations per sweep) started from the eigenvector basis of the element's previous assembly (Vws, as spd_clamp_warm<9>: A' = V^T A V is nearly diagonal
+// when the element moved little; `warm` false or a stored basis that does not look like one starts from the identity), and lane b of the group writes block
+// (b / 4, b % 4) of the element record that k_cloth_gather sums into the matrix.  One lane per element with the block and the basis in private arrays
+// (k_tet_hess below: 512 registers, 1414 spilled, 130-170 us for the 5.8k elements of cfg4 -- the longest kernel of an assembly) is kept for the callers
+// that scatter with atomics.  kind 0 = 9 x 9 over vertices 0..2 with optional SPD projection, vertex 3 = minus row / column sums
+// (model_elastic_tactile.py:88-124); kind 1 = direct 12 x 12 (model_elastic_offset.py:101-167, no projection).
+__global__ void __launch_bounds__(256)
+k_tet_hess_coop(TetArgs A, const double* __restrict__ pos, int spd, double* __restrict__ Vws, int warm, double* __restrict__ rec) {
+  __shared__ double sA[16][81], sV[16][81], sT[16][81];
+  const int l = threadIdx.x & 15, g = threadIdx.x >> 4;
+  int t = blockIdx.x * 16 + g;
+  const bool valid = t < A.n_tet;
+  if (!valid) t = A.n_tet - 1;   // whole groups beyond the list still take part in the wave-wide votes
+  int v[4]; m3 B;
+  const m3 F = tet_F(A, t, pos, v, B);
+  const ElasticDev e = A.el[A.tel[t]];
+  const m3 Fi = (e.kind == 0) ? F : m3_inv(F), FiT = m3_T(Fi), BT = m3_T(B);   // the tactile material works from cofactors (tet_dH)
+  const double W = A.W[t];
+  const double Jraw = m3_det(F);
+  const double J = (e.kind == 0) ? Jraw : fmax(Jraw, 0.01);
+  const double logJ = (e.kind == 0) ? 0.0 : log(J);
+  double* sa = sA[g]; double* sv = sV[g]; double* st = sT[g];
+  if (l < 9) {   // He[(n * 3 + dim) * 9 + (i * 3 + j)] = d(grad of vertex i, comp j) / d(x_n, dim), n, i in 0..2: row l = (n, dim)
+    const int n = l / 3, dim = l % 3;
+    m3 dF;  // dD @ B with dD[dim][n] = 1  -> row dim of dF = row n of B
+#pragma unroll
+    for (int k = 0; k < 9; k++) dF.m[k] = 0;
+#pragma unroll
+    for (int c = 0; c < 3; c++) {
+      const double bnc = n == 0 ? B.m[c] : (n == 1 ? B.m[3 + c] : B.m[6 + c]);
+      dF.m[c] = dim == 0 ? bnc : 0.0; dF.m[3 + c] = dim == 1 ? bnc : 0.0; dF.m[6 + c] = dim == 2 ? bnc : 0.0;
+    }
+    const m3 dH = tet_dH(e, F, Fi, FiT, J, logJ, dF, BT, W);
+#pragma unroll
+    for (int i = 0; i < 3; i++)
+#pragma unroll
+      for (int j = 0; j < 3; j++) sa[l * 9 + i * 3 + j] = dH.m[j * 3 + i];
+  }
+  spd_grp_sync();
+  const bool clamp = (e.kind == 0 && spd) || spd == 2;   // spd 2: preconditioner-only assembly, every element block projected
+  if (__any(clamp)) {
+    // symmetrise (spd_clamp_warm does so before the basis change)
+    if (l < 9 && clamp) {
+      for (int k = l + 1; k < 9; k++) { const double s2 = 0.5 * (sa[l * 9 + k] + sa[k * 9 + l]); sa[l * 9 + k] = s2; sa[k * 9 + l] = s2; }
+    }
+    bool w_ok = false;
+    if (Vws != nullptr && warm != 0) {   // the stored basis must look like one: finite entries and squared Frobenius norm 9
+      double ss = 0.0;
+      for (int q = l; q < 81; q += 16) { const double x = Vws[(size_t)q * A.n_tet + t]; sv[q] = x; ss += x * x; }
+#pragma unroll
+      for (int o = 8; o > 0; o >>= 1) ss += __shfl_xor(ss, o, 16);
+      w_ok = fabs(ss - 9.0) <= 9e-6;
+    }
+    spd_grp_sync();
+    if (w_ok) {   // A <- V^T A V
+      if (l < 9) {
+#pragma unroll
+        for (int j = 0; j < 9; j++) { double s2 = 0; for (int k = 0; k < 9; k++) s2 += sa[l * 9 + k] * sv[k * 9 + j]; st[l * 9 + j] = s2; }
+      }
+      spd_grp_sync();
+      double ar[9];
+      if (l < 9) {
+#pragma unroll
+        for (int j = 0; j < 9; j++) { double s2 = 0; for (int k = 0; k < 9; k++) s2 += sv[k * 9 + l] * st[k * 9 + j]; ar[j] = s2; }
+      }
+      spd_grp_sync();
+      if (l < 9 && clamp) {   // (upper part of row l and its mirror, as the serial routine: the product is symmetric up to rounding)
+#pragma unroll
+        for (int j = 0; j < 9; j++) if (j >= l) { sa[l * 9 + j] = ar[j]; sa[j * 9 + l] = ar[j]; }
+      }
+    } else if (l < 9) {
+#pragma unroll
+      for (int k = 0; k < 9; k++) sv[l * 9 + k] = (k == l) ? 1.0 : 0.0;
+    }
+    spd_grp_sync();
+    spd_clamp9_par(sa, sv, l, clamp);
+    if (Vws != nullptr && valid && clamp) for (int q = l; q < 81; q += 16) Vws[(size_t)q * A.n_tet + t] = sv[q];   // the new basis for the next call
+  }
+  if (!valid) return;
+  // element record: 16 blocks of 9; block (a, b) element (j, j2): a, b < 3: He[(a * 3 + j) * 9 + b * 3 + j2]; vertex 3 gets minus sums.  model_elastic_offset.py:151-167
+  // scatters row = (vertex j, comp r), column = (n, dim): the transpose of the tactile convention (identical whenever the block is symmetric, i.e. J > 0.01)
+  const bool tr = e.kind != 0;
+  auto He = [&](int x, int y) { return tr ? sa[y * 9 + x] : sa[x * 9 + y]; };
+  const int a = l >> 2, b = l & 3;
+  double* R = rec + (size_t)t * 144 + l * 9;
+#pragma unroll
+  for (int j = 0; j < 3; j++)
+#pragma unroll
+    for (int j2 = 0; j2 < 3; j2++) {
+      double s2 = 0;
+      if (a < 3 && b < 3) s2 = He(a * 3 + j, b * 3 + j2);
+      else if (a < 3) { for (int bb = 0; bb < 3; bb++) s2 -= He(a * 3 + j, bb * 3 + j2); }
+      else if (b < 3) { for (int aa = 0; aa < 3; aa++) s2 -= He(aa * 3 + j, b * 3 + j2); }
+      else { for (int aa = 0; aa < 3; aa++) for (int bb = 0; bb < 3; bb++) s2 += He(aa * 3 + j, bb * 3 + j2); }
+      R[3 * j + j2] = s2;
+    }
+}
+
 // Element Hessians: kind 0 = 9x9 over vertices 0..2 with optional SPD projection, vertex 3 = minus row/col sums
 // (model_elastic_tactile.py:88-124); kind 1 = direct 12x12 (model_elastic_offset.py:101-167, no projection).
 __global__ void __launch_bounds__(64)

@@ -306,6 +306,7 @@ struct tsl_ctx {
   // preconditioner built from a different (SPD-projected) assembly than the operator: adjoint solves (un-projected H)
   DevBuf<double> vals_pc, c_H_pc;
   bool pc_separate = false, pc_frozen = false, in_step = false;
+  bool cdiag_valid = false;   // c_diag holds the diagonal blocks of the contact terms in place (an assembly for the direct path does not form them)
   bool dinv_valid = false;    // Dinv holds the block-Jacobi inverse of the operator in place (an assembly for the direct path does not form it)
   const double *st_pos = nullptr, *st_prev = nullptr, *st_vel = nullptr, *st_ref = nullptr;  // state of the last assemble
   int fwd_spd_pc = 1;
@@ -316,7 +317,7 @@ struct tsl_ctx {
   SolverScalars* h_scal2 = nullptr; // pinned, two records: read-back slots of the PCG chunks in flight
   hipEvent_t rb_event[2] = {nullptr, nullptr};
   hipStream_t side = 0;                         // second stream: contact blocks of an assembly run next to the cloth / tet kernels
-  hipEvent_t ev_fork = nullptr, ev_fork0 = nullptr, ev_g2 = nullptr, ev_join = nullptr, ev_join2 = nullptr;
+  hipEvent_t ev_fork = nullptr, ev_fork0 = nullptr, ev_g2 = nullptr, ev_join = nullptr, ev_join2 = nullptr, ev_hh = nullptr, ev_gf = nullptr;
   hipStream_t side2 = 0;                        // third stream: the tet kernels next to the contact kernels (side) and the cloth kernels
 
   // ---- Newton scratch (original order)

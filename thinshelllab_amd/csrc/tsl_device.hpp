@@ -219,6 +219,115 @@ TSL_DEV void spd_clamp_warm(double* A, double* __restrict__ Vg, size_t vs, bool 
     }
 }
 
+// ---- cooperative 9 x 9 eigen-clamp (round 6): 16 lanes per matrix, matrix and eigenvector accumulator in LDS, PARALLEL rotation order -------------------
+// The cyclic Jacobi of spd_clamp<9> walks 36 rotations per sweep one after the other; one lane per matrix keeps 2 x 81 doubles in private arrays with dynamic
+// indices (scratch memory: k_tet_hess 1414 spilled registers, 130-170 us for 5.8k elements), 16 lanes per matrix in lock step pay three LDS round trips per
+// rotation (k_contact_assemble_coop: 125-185 us for ~100 constraints).  Rotations of DISJOINT index pairs commute, so a sweep is nine rounds of four
+// simultaneous rotations (round r pairs lane l with (r - l) mod 9; the lane with 2 l = r mod 9 sits out): lane l < 9 applies its pair's rotation to column l
+// (matrix and eigenvectors), then to row l.  Same rotation formula, same convergence test (off^2 <= 1e-32 |A|^2), same sweep limit and the same reconstruction
+// A <- sum_{lambda > 0} lambda v v^T as spd_clamp<9>: the clamped matrix agrees with the serial order to rounding (the eigen-decomposition is unique up to it).
+// sa: the symmetric matrix (row-major 9 x 9), sv: the accumulator V (identity, or the warm-start basis with sa = V^T A V); the four groups of a wave run in lock
+// step (LDS operations of a wave complete in order); `on` is uniform within a group; on return sa holds the clamped matrix (groups with `on`), sv the basis.
+TSL_DEV void spd_grp_sync() {
+  __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+  __builtin_amdgcn_wave_barrier();
+  __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+}
+TSL_DEV void spd_clamp9_par(double* __restrict__ sa, double* __restrict__ sv, int l, bool on) {
+  const bool row = l < 9;
+  bool done = !on;
+  double rel_prev = 1.0;
+  for (int sweep = 0; sweep < 30; sweep++) {
+    double off = 0.0, diag = 0.0;
+    if (row) {
+#pragma unroll
+      for (int k = 0; k < 9; k++) { const double v = sa[l * 9 + k]; if (k == l) diag = v * v; else off += v * v; }
+    }
+#pragma unroll
+    for (int o = 8; o > 0; o >>= 1) { off += __shfl_xor(off, o, 16); diag += __shfl_xor(diag, o, 16); }
+    // converged: off^2 <= 1e-32 |A|^2 as in spd_clamp<9> -- or the sweep before did not halve off^2 any more below 1e-24 |A|^2: the quadratic convergence of the
+    // Jacobi iteration ends on a floor of rounding noise (eigenvalues of 1e3 next to 1e-6 in a contact block: 3e-33 for the cyclic order, 1.4e-32 for this one --
+    // the serial routine's bound sits between the two and this order ran its 30 sweeps on two blocks in three)
+    const double rel = 0.5 * off / (diag + 0.5 * off);
+    if (0.5 * off <= 1e-32 * (diag + 0.5 * off) || (rel <= 1e-24 && rel >= 0.5 * rel_prev)) done = true;
+    rel_prev = rel;
+    if (!__any(!done)) break;
+    for (int r = 0; r < 9; r++) {
+      int m = r - l; if (m < 0) m += 9;
+      const bool act = row && m != l && !done;     // (lanes 9..15, the lane that sits out, groups that have converged: no rotation)
+      const int mm = act ? m : 0, ll = row ? l : 0;
+      const int p = min(ll, mm), q = max(ll, mm);
+      const bool isp = ll < mm;
+      double c = 1.0, s = 0.0;
+      if (act) {
+        const double apq = sa[p * 9 + q], app = sa[p * 9 + p], aqq = sa[q * 9 + q];
+        if (apq != 0.0) {
+          const double theta = (aqq - app) / (2.0 * apq);
+          const double t = (theta >= 0 ? 1.0 : -1.0) / (fabs(theta) + sqrt(theta * theta + 1.0));
+          c = 1.0 / sqrt(t * t + 1.0); s = t * c;
+        }
+      }
+      // column l <- rotation of columns (p, q): new[p] = c old[p] - s old[q], new[q] = s old[p] + c old[q]; the same for the eigenvectors
+      const double ss = isp ? -s : s;
+      double ao[9], vo[9];
+      if (act) {
+#pragma unroll
+        for (int i = 0; i < 9; i++) { ao[i] = c * sa[i * 9 + ll] + ss * sa[i * 9 + mm]; vo[i] = c * sv[i * 9 + ll] + ss * sv[i * 9 + mm]; }
+      }
+      spd_grp_sync();
+      if (act) {
+#pragma unroll
+        for (int i = 0; i < 9; i++) { sa[i * 9 + ll] = ao[i]; sv[i * 9 + ll] = vo[i]; }
+      }
+      spd_grp_sync();
+      // row l <- the same rotation of rows (p, q)
+      if (act) {
+#pragma unroll
+        for (int j = 0; j < 9; j++) ao[j] = c * sa[ll * 9 + j] + ss * sa[mm * 9 + j];
+      }
+      spd_grp_sync();
+      if (act) {
+#pragma unroll
+        for (int j = 0; j < 9; j++) sa[ll * 9 + j] = ao[j];
+      }
+      spd_grp_sync();
+    }
+  }
+  // A = sum_e max(lambda_e, 0) v_e v_e^T, row l
+  double outr[9];
+  if (row) {
+#pragma unroll
+    for (int j = 0; j < 9; j++) outr[j] = 0.0;
+    for (int e = 0; e < 9; e++) {
+      const double d = sa[e * 9 + e];
+      const double lam = d > 0.0 ? d : 0.0;
+      const double vl = lam * sv[l * 9 + e];
+#pragma unroll
+      for (int j = 0; j < 9; j++) outr[j] += vl * sv[j * 9 + e];
+    }
+  }
+  spd_grp_sync();
+  if (row && on) {
+#pragma unroll
+    for (int j = 0; j < 9; j++) sa[l * 9 + j] = outr[j];
+  }
+  spd_grp_sync();
+}
+
+// the same from a cold start: V = identity, A symmetrised (inputs are symmetric up to rounding; a block that is not clamped keeps its non-symmetric part)
+TSL_DEV void spd_clamp9_cold(double* __restrict__ sa, double* __restrict__ sv, int l, bool on) {
+  if (l < 9) {
+#pragma unroll
+    for (int k = 0; k < 9; k++) sv[l * 9 + k] = (k == l) ? 1.0 : 0.0;
+  }
+  spd_grp_sync();
+  if (l < 9 && on) {
+    for (int k = l + 1; k < 9; k++) { const double t = 0.5 * (sa[l * 9 + k] + sa[k * 9 + l]); sa[l * 9 + k] = t; sa[k * 9 + l] = t; }
+  }
+  spd_grp_sync();
+  spd_clamp9_par(sa, sv, l, on);
+}
+
 // 2x2 symmetric PSD projection (engine/linalg.py:5-12, closed form of the ti.svd based rule)
 TSL_DEV void spd_clamp2(double& a, double& b, double& d) {
   double tr = a + d, df = a - d;

@@ -370,7 +370,7 @@ extern "C" int tsl_ctx_create(const tsl_scene_desc* d, tsl_ctx** out) {
   for (int i = 0; i < 2; i++)
     if (hipEventCreateWithFlags(&c->rb_event[i], hipEventDisableTiming) != hipSuccess) { delete c; return tsl_fail("hipEventCreate failed"); }
   if (hipStreamCreateWithFlags(&c->side, hipStreamNonBlocking) != hipSuccess || hipStreamCreateWithFlags(&c->side2, hipStreamNonBlocking) != hipSuccess ||
-      hipEventCreateWithFlags(&c->ev_join2, hipEventDisableTiming) != hipSuccess || hipEventCreateWithFlags(&c->ev_fork, hipEventDisableTiming) != hipSuccess || hipEventCreateWithFlags(&c->ev_fork0, hipEventDisableTiming) != hipSuccess || hipEventCreateWithFlags(&c->ev_g2, hipEventDisableTiming) != hipSuccess ||
+      hipEventCreateWithFlags(&c->ev_join2, hipEventDisableTiming) != hipSuccess || hipEventCreateWithFlags(&c->ev_fork, hipEventDisableTiming) != hipSuccess || hipEventCreateWithFlags(&c->ev_fork0, hipEventDisableTiming) != hipSuccess || hipEventCreateWithFlags(&c->ev_g2, hipEventDisableTiming) != hipSuccess || hipEventCreateWithFlags(&c->ev_hh, hipEventDisableTiming) != hipSuccess || hipEventCreateWithFlags(&c->ev_gf, hipEventDisableTiming) != hipSuccess ||
       hipEventCreateWithFlags(&c->ev_join, hipEventDisableTiming) != hipSuccess) { delete c; return tsl_fail("side stream / event creation failed"); }
   c->vals.zero(); c->vals_full.zero(); c->scal.zero(); c->part_rz.zero(); c->part_rr.zero();
 
@@ -409,6 +409,8 @@ extern "C" void tsl_ctx_destroy(tsl_ctx* c) {
   if (c->ev_fork) (void)hipEventDestroy(c->ev_fork);
   if (c->ev_fork0) (void)hipEventDestroy(c->ev_fork0);
   if (c->ev_g2) (void)hipEventDestroy(c->ev_g2);
+  if (c->ev_hh) (void)hipEventDestroy(c->ev_hh);
+  if (c->ev_gf) (void)hipEventDestroy(c->ev_gf);
   if (c->ev_join) (void)hipEventDestroy(c->ev_join);
   if (c->side) (void)hipStreamDestroy(c->side);
   if (c->ev_join2) (void)hipEventDestroy(c->ev_join2);
@@ -654,10 +656,11 @@ static int assemble_enqueue(tsl_ctx* c, const double* pos, const double* prev, c
       // every 16th clamped assembly starts from the identity again (orthogonality of the accumulated rotations)
       double* vws = (c->tet_warm && spd != 0) ? c->tet_V.p : (double*)nullptr;   // (allocated and counted by assemble())
       const int warm = vws ? tet_warm_flag : 0;
-      hipLaunchKernelGGL(k_tet_hess, dim3(nblk(c->n_tet, 64)), dim3(64), 0, stt, TA, c->tet_blk.p, pos, spd, c->vals_full.p, vws, warm, det ? c->cg_trec.p : (double*)nullptr);
+      if (det) hipLaunchKernelGGL(k_tet_hess_coop, dim3(nblk(c->n_tet, 16)), dim3(256), 0, stt, TA, pos, spd, vws, warm, c->cg_trec.p);
+      else hipLaunchKernelGGL(k_tet_hess, dim3(nblk(c->n_tet, 64)), dim3(64), 0, stt, TA, c->tet_blk.p, pos, spd, c->vals_full.p, vws, warm, (double*)nullptr);
       const int nt_blk = c->n_cgblk - c->n_cgblk_cloth;
       if (det && nt_blk > 0)
-        hipLaunchKernelGGL(k_cloth_gather, dim3(nblk(nt_blk, 256)), dim3(256), 0, stt, nt_blk, c->cg_base.p + c->n_cgblk_cloth, c->cg_ptr.p + c->n_cgblk_cloth, (const unsigned*)c->cg_ent.p,
+        hipLaunchKernelGGL(k_cloth_gather, dim3(nblk(9L * nt_blk, 256)), dim3(256), 0, stt, nt_blk, c->cg_base.p + c->n_cgblk_cloth, c->cg_ptr.p + c->n_cgblk_cloth, (const unsigned*)c->cg_ent.p,
                            c->n_hinge, c->n_cface, (const double*)c->cg_hrec.p, (const double*)c->cg_frec.p, (const double*)c->cg_trec.p, c->vals_full.p);
     }
   }
@@ -679,7 +682,7 @@ static int assemble_enqueue(tsl_ctx* c, const double* pos, const double* prev, c
   }
   if (c->n_hinge) hipLaunchKernelGGL(k_cloth_hess_hinge, dim3(nblk(c->n_hinge, 256)), dim3(256), 0, s, CA, c->hg_blk.p, pos, c->vals_full.p, gather ? c->cg_hrec.p : (double*)nullptr);
   if (gather && c->n_cgblk_cloth > 0)
-    hipLaunchKernelGGL(k_cloth_gather, dim3(nblk(c->n_cgblk_cloth, 256)), dim3(256), 0, s, c->n_cgblk_cloth, c->cg_base.p, c->cg_ptr.p, (const unsigned*)c->cg_ent.p, c->n_hinge, c->n_cface,
+    hipLaunchKernelGGL(k_cloth_gather, dim3(nblk(9L * c->n_cgblk_cloth, 256)), dim3(256), 0, s, c->n_cgblk_cloth, c->cg_base.p, c->cg_ptr.p, (const unsigned*)c->cg_ent.p, c->n_hinge, c->n_cface,
                        (const double*)c->cg_hrec.p, (const double*)c->cg_frec.p, (const double*)c->cg_trec.p, c->vals_full.p);
   if (fork) HIP_OK(hipStreamWaitEvent(s, c->ev_join, 0));
   if (fork_t) HIP_OK(hipStreamWaitEvent(s, c->ev_join2, 0));
@@ -732,7 +735,7 @@ static int assemble_enqueue_early(tsl_ctx* c, const double* pos, const double* p
     // eigen-clamp of the element blocks warm-started from the previous assembly's eigenvectors ("tet_warm", on by default);
     // every 16th clamped assembly starts from the identity again (orthogonality of the accumulated rotations)
     double* vws = (c->tet_warm && spd != 0) ? c->tet_V.p : (double*)nullptr;   // (allocated and counted by assemble())
-    hipLaunchKernelGGL(k_tet_hess, dim3(nblk(c->n_tet, 64)), dim3(64), 0, stt, TA, c->tet_blk.p, pos, spd, c->vals_full.p, vws, vws ? tet_warm_flag : 0, c->cg_trec.p);
+    hipLaunchKernelGGL(k_tet_hess_coop, dim3(nblk(c->n_tet, 16)), dim3(256), 0, stt, TA, pos, spd, vws, vws ? tet_warm_flag : 0, c->cg_trec.p);
   }
   HIP_OK(hipMemsetAsync(c->vals_full.p, 0, c->vals_full.n * sizeof(double), s));
   if (c->n_cface) hipLaunchKernelGGL(k_cloth_normals, dim3(nblk(c->n_cface, 256)), dim3(256), 0, s, c->n_cface, pos, c->cf_f2v.p, c->norm_dir.p);
@@ -749,25 +752,34 @@ static int assemble_enqueue_early(tsl_ctx* c, const double* pos, const double* p
     if (spd == 2) hipLaunchKernelGGL((k_cloth_hess_face<true>), dim3(nblk(c->n_cface, 128)), dim3(128), 0, s, CA, c->cf_blk.p, pos, ref, c->quirk.p, spd, c->vals_full.p, frec);
     else hipLaunchKernelGGL((k_cloth_hess_face<false>), dim3(nblk(c->n_cface, 128)), dim3(128), 0, s, CA, c->cf_blk.p, pos, ref, c->quirk.p, spd, c->vals_full.p, frec);
   }
-  // engine stream: the hinge blocks (records) right behind the face blocks -- round 5: they sat on the element stream behind the element blocks of the
-  // bodies (170 us) and held back both tails, the cloth gather and the gradient gather
-  if (c->n_hinge) hipLaunchKernelGGL(k_cloth_hess_hinge, dim3(nblk(c->n_hinge, 256)), dim3(256), 0, s, CA, c->hg_blk.p, pos, c->vals_full.p, gather ? c->cg_hrec.p : (double*)nullptr);
-  // element stream, second part (behind the mass diagonal)
+  // element stream, second part (behind the normals and the mass diagonal).  Round 6: the element blocks of the bodies take 55 us since they are formed by 16 lanes
+  // per element (k_tet_hess_coop; 170 before), so the hinge blocks (records, 45-60 us) run HERE, next to the face blocks on the engine stream, and the face
+  // gradients behind the body blocks: the engine stream's chain is face blocks -> cloth gather -> mask, the contact stream's contact blocks -> hinge gradients ->
+  // gradient tail.  (Round 5 had moved them the other way, when this stream was busy with the bodies for 170 us.)
   HIP_OK(hipStreamWaitEvent(stt, c->ev_fork, 0));
+  const bool hh_side = fork_t && gather;
+  if (c->n_hinge) {
+    hipLaunchKernelGGL(k_cloth_hess_hinge, dim3(nblk(c->n_hinge, 256)), dim3(256), 0, hh_side ? stt : s, CA, c->hg_blk.p, pos, c->vals_full.p, gather ? c->cg_hrec.p : (double*)nullptr);
+    if (hh_side) HIP_OK(hipEventRecord(c->ev_hh, stt));
+  }
   const int nt_blk = c->n_cgblk - c->n_cgblk_cloth;
   if (c->n_tet && nt_blk > 0)   // the element records of the bodies -> their matrix blocks (the blocks of the bodies and of the cloth are disjoint)
-    hipLaunchKernelGGL(k_cloth_gather, dim3(nblk(nt_blk, 256)), dim3(256), 0, stt, nt_blk, c->cg_base.p + c->n_cgblk_cloth, c->cg_ptr.p + c->n_cgblk_cloth, (const unsigned*)c->cg_ent.p,
+    hipLaunchKernelGGL(k_cloth_gather, dim3(nblk(9L * nt_blk, 256)), dim3(256), 0, stt, nt_blk, c->cg_base.p + c->n_cgblk_cloth, c->cg_ptr.p + c->n_cgblk_cloth, (const unsigned*)c->cg_ent.p,
                        c->n_hinge, c->n_cface, (const double*)c->cg_hrec.p, (const double*)c->cg_frec.p, (const double*)c->cg_trec.p, c->vals_full.p);
   HIP_OK(hipEventRecord(c->ev_join2, stt));   // body blocks
-  // contact stream, second part: hinge and face gradients (staging slots)
+  // contact stream, second part: hinge gradients (staging slots); the face gradients behind the body blocks on the element stream
   if (grad) {
     if (fork_t) HIP_OK(hipStreamWaitEvent(st, c->ev_fork, 0));
     if (c->n_hinge) hipLaunchKernelGGL(k_cloth_grad_hinge, dim3(nblk(c->n_hinge, 256)), dim3(256), 0, st, CA, pos, ref, grad);
-    if (c->n_cface) hipLaunchKernelGGL(k_cloth_grad_face, dim3(nblk(c->n_cface, 256)), dim3(256), 0, st, CA, pos, grad);
+    if (c->n_cface) {
+      hipLaunchKernelGGL(k_cloth_grad_face, dim3(nblk(c->n_cface, 256)), dim3(256), 0, hh_side ? stt : st, CA, pos, grad);
+      if (hh_side) HIP_OK(hipEventRecord(c->ev_gf, stt));
+    }
   }
-  // engine stream: cloth blocks, then the matrix tail
+  // engine stream: cloth blocks (behind the hinge records), then the matrix tail
+  if (hh_side && c->n_hinge) HIP_OK(hipStreamWaitEvent(s, c->ev_hh, 0));
   if (gather && c->n_cgblk_cloth > 0)
-    hipLaunchKernelGGL(k_cloth_gather, dim3(nblk(c->n_cgblk_cloth, 256)), dim3(256), 0, s, c->n_cgblk_cloth, c->cg_base.p, c->cg_ptr.p, (const unsigned*)c->cg_ent.p, c->n_hinge, c->n_cface,
+    hipLaunchKernelGGL(k_cloth_gather, dim3(nblk(9L * c->n_cgblk_cloth, 256)), dim3(256), 0, s, c->n_cgblk_cloth, c->cg_base.p, c->cg_ptr.p, (const unsigned*)c->cg_ent.p, c->n_hinge, c->n_cface,
                        (const double*)c->cg_hrec.p, (const double*)c->cg_frec.p, (const double*)c->cg_trec.p, c->vals_full.p);
   HIP_OK(hipStreamWaitEvent(s, c->ev_join2, 0));
   hipLaunchKernelGGL(k_mask_matrix, dim3(c->n_slices), dim3(256), 0, s, c->n_slices, c->slice_off.p, c->slice_len.p, c->colidx.p, c->fzmask.p, c->mdt2.p,
@@ -775,6 +787,7 @@ static int assemble_enqueue_early(tsl_ctx* c, const double* pos, const double* p
   // contact stream: the gradient tail
   if (grad) {
     if (fork_t && c->n_tet) HIP_OK(hipStreamWaitEvent(st, c->ev_g2, 0));
+    if (hh_side && c->n_cface) HIP_OK(hipStreamWaitEvent(st, c->ev_gf, 0));
     hipLaunchKernelGGL(k_vertex_gather, dim3(nblk(NV, 256)), dim3(256), 0, st, NV, (const int*)c->vg_ptr.p, (const int*)c->vg_idx.p, (const double*)c->vg_stage.p, 0, c->vg_ns, grad);
     if (c->nc > 0) hipLaunchKernelGGL(k_contact_row_gather, dim3(nblk((long)NV * 64, 256)), dim3(256), 0, st, NV, (const int*)c->rowpos.p, (const int*)c->cr_ptr.p, (const int*)c->cr_ent.p,
                                       (const double*)c->c_G.p, grad);
@@ -887,6 +900,7 @@ static bool direct_takes_solve(tsl_ctx* c) {
   return direct_enabled(c) && !c->ds_suspended && !(d.enable < 0 && !d.hard && c->n_tet == 0 && c->nc == 0);
 }
 static int block_jacobi_refresh(tsl_ctx* c) {
+  if (c->nc > 0 && c->deterministic && !c->cdiag_valid) contact_diag_refresh(c, c->stream);   // (skipped by an assembly that expected the factorisation to take the solve)
   hipLaunchKernelGGL(k_block_jacobi, dim3(nblk(c->NV, 256)), dim3(256), 0, c->stream, c->NV, c->diag_perm.p, c->vals.p, c->nc > 0 ? c->c_diag.p : (const double*)nullptr, c->Dinv.p);
   if (body_active(c) && c->bd_valid) body_zero_dinv(c);  // those rows are served by the (lagged) dense inverse
   c->dinv_valid = true;
