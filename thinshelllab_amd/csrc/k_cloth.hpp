@@ -45,12 +45,19 @@ TSL_DEV double dihedral(const d3& n1, const d3& n2, const d3& e) {
 }
 
 // Cloth.compute_bending_grad (:379-402): d(theta)/dx for the 4 hinge vertices
+// slot l of a three-entry array by selects: an index computed at run time makes the array an alloca, which the compiler parks in LDS (288 bytes per lane:
+// 72 KB per workgroup, two workgroups per CU for the hinge kernels -- k_cloth_grad_hinge 129 us for 150k hinges next to the other assembly kernels)
+TSL_DEV double pick3(const double a[3], int i) { return i == 0 ? a[0] : (i == 1 ? a[1] : a[2]); }
+TSL_DEV d3 pick3(const d3 a[3], int i) {   // (component by component: a select between structs becomes a select between their ADDRESSES)
+  return d3(i == 0 ? a[0].x : (i == 1 ? a[1].x : a[2].x), i == 0 ? a[0].y : (i == 1 ? a[1].y : a[2].y), i == 0 ? a[0].z : (i == 1 ? a[1].z : a[2].z));
+}
+TSL_DEV int pick3(const int a[3], int i) { return i == 0 ? a[0] : (i == 1 ? a[1] : a[2]); }
 TSL_DEV void hinge_grad(const FaceGeom& g1, const FaceGeom& g2, int l, int p4, int p21, d3 g[4]) {
   const int p11 = (l + 1) % 3, p12 = (l + 2) % 3, p22 = 3 - p21 - p4;
-  g[0] = (-1.0 / g1.h[l]) * g1.n;
-  g[3] = (-1.0 / g2.h[p4]) * g2.n;
-  g[1] = (g1.ca[p12] / g1.h[p11]) * g1.n + (g2.ca[p22] / g2.h[p21]) * g2.n;
-  g[2] = (g1.ca[p11] / g1.h[p12]) * g1.n + (g2.ca[p21] / g2.h[p22]) * g2.n;
+  g[0] = (-1.0 / pick3(g1.h, l)) * g1.n;
+  g[3] = (-1.0 / pick3(g2.h, p4)) * g2.n;
+  g[1] = (pick3(g1.ca, p12) / pick3(g1.h, p11)) * g1.n + (pick3(g2.ca, p22) / pick3(g2.h, p21)) * g2.n;
+  g[2] = (pick3(g1.ca, p11) / pick3(g1.h, p12)) * g1.n + (pick3(g2.ca, p21) / pick3(g2.h, p22)) * g2.n;
 }
 
 TSL_DEV void load_face(const double* __restrict__ pos, const int* __restrict__ f2v, int F, int v[3], d3 P[3]) {
@@ -147,7 +154,7 @@ __global__ void k_cloth_grad_face(ClothArgs A, const double* __restrict__ pos, d
   for (int l = 0; l < 3; l++) atomic_add3(F, v[l], g[l]);
 }
 
-__global__ void k_cloth_grad_hinge(ClothArgs A, const double* __restrict__ pos, const double* __restrict__ ref_angle, double* __restrict__ F) {
+__global__ void __launch_bounds__(256) k_cloth_grad_hinge(ClothArgs A, const double* __restrict__ pos, const double* __restrict__ ref_angle, double* __restrict__ F) {
   const int h = blockIdx.x * blockDim.x + threadIdx.x;
   if (h >= A.n_hinge) return;
   const int f1 = A.hg_info[8 * h], l = A.hg_info[8 * h + 1], f2 = A.hg_info[8 * h + 2], p4 = A.hg_info[8 * h + 3], p21 = A.hg_info[8 * h + 4];
@@ -158,17 +165,17 @@ __global__ void k_cloth_grad_hinge(ClothArgs A, const double* __restrict__ pos, 
   const FaceGeom g1 = face_geom(P1), g2 = face_geom(P2);
   d3 g[4];
   hinge_grad(g1, g2, l, p4, p21, g);
-  const double theta = dihedral(g1.n, g2.n, P1[(l + 1) % 2] - P1[l]);
+  const double theta = dihedral(g1.n, g2.n, pick3(P1, (l + 1) % 2) - pick3(P1, l));
   const double dth = 2.0 * c.Kb * (theta - ref_angle[3 * f1 + l]) * c.dx * c.dx * (1.0 / 3.0);
   if (A.gstage) {
 #pragma unroll
     for (int j = 0; j < 4; j++) st3(A.gstage, A.gs_hinge + 4 * h + j, dth * g[j]);
     return;
   }
-  atomic_add3(F, v1[l], dth * g[0]);
-  atomic_add3(F, v1[(l + 1) % 3], dth * g[1]);
-  atomic_add3(F, v1[(l + 2) % 3], dth * g[2]);
-  atomic_add3(F, v2[p4], dth * g[3]);
+  atomic_add3(F, pick3(v1, l), dth * g[0]);
+  atomic_add3(F, pick3(v1, (l + 1) % 3), dth * g[1]);
+  atomic_add3(F, pick3(v1, (l + 2) % 3), dth * g[2]);
+  atomic_add3(F, pick3(v2, p4), dth * g[3]);
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -400,7 +407,7 @@ k_cloth_hess_face(ClothArgs A, const int* __restrict__ blk, const double* __rest
 }
 
 // One lane per hinge: Gauss-Newton block d2theta * grad grad^T (compute_Hessian_bending :616-637)
-__global__ void k_cloth_hess_hinge(ClothArgs A, const int* __restrict__ blk, const double* __restrict__ pos, double* __restrict__ vals, double* __restrict__ rec) {
+__global__ void __launch_bounds__(256) k_cloth_hess_hinge(ClothArgs A, const int* __restrict__ blk, const double* __restrict__ pos, double* __restrict__ vals, double* __restrict__ rec) {
   const int h = blockIdx.x * blockDim.x + threadIdx.x;
   if (h >= A.n_hinge) return;
   const int f1 = A.hg_info[8 * h], l = A.hg_info[8 * h + 1], f2 = A.hg_info[8 * h + 2], p4 = A.hg_info[8 * h + 3], p21 = A.hg_info[8 * h + 4];

@@ -2789,7 +2789,7 @@ __global__ void k_clamp(size_t n, double* __restrict__ v, double lim) {
 
 // Cloth.ref_angle_backprop_a2ax (model_fold_offset.py:1179-1206), one lane per hinge.
 // ag_s / ag_prev: angleref_grad[s], angleref_grad[s-1]; pg_s: pos_grad[s]; ref = ref_angle_{s-1}; pos = x_s
-__global__ void k_adj_a2ax(ClothArgs A, const double* __restrict__ pos, const double* __restrict__ ref, const double* __restrict__ ag_s, double* __restrict__ ag_prev,
+__global__ void __launch_bounds__(256) k_adj_a2ax(ClothArgs A, const double* __restrict__ pos, const double* __restrict__ ref, const double* __restrict__ ag_s, double* __restrict__ ag_prev,
                            double* __restrict__ pg_s) {
   const int h = blockIdx.x * blockDim.x + threadIdx.x;
   if (h >= A.n_hinge) return;
@@ -2801,7 +2801,7 @@ __global__ void k_adj_a2ax(ClothArgs A, const double* __restrict__ pos, const do
   const FaceGeom g1 = face_geom(P1), g2 = face_geom(P2);
   d3 g[4];
   hinge_grad(g1, g2, l, p4, p21, g);
-  const double theta = dihedral(g1.n, g2.n, P1[(l + 1) % 2] - P1[l]);
+  const double theta = dihedral(g1.n, g2.n, pick3(P1, (l + 1) % 2) - pick3(P1, l));
   const double a = ag_s[3 * f1 + l];
   ag_prev[3 * f1 + l] += a;
   const double sgn = (fabs(theta - ref[3 * f1 + l]) > c.k_angle) ? a : a * 0.1;
@@ -2810,14 +2810,14 @@ __global__ void k_adj_a2ax(ClothArgs A, const double* __restrict__ pos, const do
     for (int j = 0; j < 4; j++) st3(A.gstage, A.gs_hinge + 4 * h + j, sgn * g[j]);
     return;
   }
-  atomic_add3(pg_s, v1[l], sgn * g[0]);
-  atomic_add3(pg_s, v1[(l + 1) % 3], sgn * g[1]);
-  atomic_add3(pg_s, v1[(l + 2) % 3], sgn * g[2]);
-  atomic_add3(pg_s, v2[p4], sgn * g[3]);
+  atomic_add3(pg_s, pick3(v1, l), sgn * g[0]);
+  atomic_add3(pg_s, pick3(v1, (l + 1) % 3), sgn * g[1]);
+  atomic_add3(pg_s, pick3(v1, (l + 2) % 3), sgn * g[2]);
+  atomic_add3(pg_s, pick3(v2, p4), sgn * g[3]);
 }
 
 // Cloth.ref_angle_backprop_x2a (model_fold_offset.py:1154-1168): angleref_grad[s-1] += -z . (d_ref * grad theta)
-__global__ void k_adj_x2a(ClothArgs A, const double* __restrict__ pos, const double* __restrict__ z, double* __restrict__ ag_prev) {
+__global__ void __launch_bounds__(256) k_adj_x2a(ClothArgs A, const double* __restrict__ pos, const double* __restrict__ z, double* __restrict__ ag_prev) {
   const int h = blockIdx.x * blockDim.x + threadIdx.x;
   if (h >= A.n_hinge) return;
   const int f1 = A.hg_info[8 * h], l = A.hg_info[8 * h + 1], f2 = A.hg_info[8 * h + 2], p4 = A.hg_info[8 * h + 3], p21 = A.hg_info[8 * h + 4];
@@ -2829,7 +2829,7 @@ __global__ void k_adj_x2a(ClothArgs A, const double* __restrict__ pos, const dou
   d3 g[4];
   hinge_grad(g1, g2, l, p4, p21, g);
   const double d_ref = -2.0 * c.Kb * c.dx * c.dx * (1.0 / 3.0);
-  const double s = dot(ld3(z, v1[l]), g[0]) + dot(ld3(z, v1[(l + 1) % 3]), g[1]) + dot(ld3(z, v1[(l + 2) % 3]), g[2]) + dot(ld3(z, v2[p4]), g[3]);
+  const double s = dot(ld3(z, pick3(v1, l)), g[0]) + dot(ld3(z, pick3(v1, (l + 1) % 3)), g[1]) + dot(ld3(z, pick3(v1, (l + 2) % 3)), g[2]) + dot(ld3(z, pick3(v2, p4)), g[3]);
   ag_prev[3 * f1 + l] += -s * d_ref;
 }
 
