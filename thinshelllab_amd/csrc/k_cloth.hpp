@@ -444,29 +444,41 @@ __global__ void __launch_bounds__(256) k_cloth_hess_hinge(ClothArgs A, const int
 // per entry -- the scatter versions issue 144 (hinge) + 81 (face) f64 atomics per element, 30 M per assembly at 100k triangles,
 // which bound both kernels (0.27 ms of an assembly's 0.45).  Blocks are sorted by their address in the SELL-64 value array: the
 // lanes of a wave write consecutive lanes of one slice.  Fixed summation order: the assembled cloth blocks are the same bits every run.
+#define CG_BPW 28   // blocks per workgroup of k_cloth_gather (28 x 9 = 252 of 256 threads)
 __global__ void __launch_bounds__(256) k_cloth_gather(int n_blk, const int* __restrict__ base, const int* __restrict__ ptr, const unsigned* __restrict__ ent, int n_hinge, int n_cface,
                                                       const double* __restrict__ hrec, const double* __restrict__ frec, const double* __restrict__ trec, double* __restrict__ vals) {
-  // Round 6: one lane per ENTRY of a block (nine lanes per block, entry index fastest).  One lane per block walked its list with one 72-byte record in
-  // flight at a time -- 84 MB of records at 0.8 TB/s, 120 us for the cloth and 80 us for the 40k blocks of the bodies --; nine lanes per block read a record
-  // as one contiguous run and keep nine times the loads in flight.  Every entry is still summed by ONE lane in the order of the list: the same bits.
-  const long t = (long)blockIdx.x * blockDim.x + threadIdx.x;
-  if (t >= (long)n_blk * 9) return;
-  const int b = (int)(t / 9), e9 = (int)(t - 9L * b), r = e9 / 3, c = e9 - 3 * r;
-  double acc = 0.0;
-  for (int q = ptr[b]; q < ptr[b + 1]; q++) {
-    const unsigned e = ent[q];
-    const int el = (int)((e >> 4) & 0x7ffffff), pr = (int)(e & 15);
-    if ((e >> 30) == 1) {   // tetrahedron: its 16 vertex-pair blocks as stored by k_tet_hess_coop (144 doubles per element)
-      acc += trec[(size_t)(el & 0x3ffffff) * 144 + pr * 9 + e9];
-    } else if (e >> 31) {   // hinge: block (j, k) = d2 g_j g_k^T from the four vertex gradients and the scale
-      const int j = pr >> 2, k = pr & 3;
-      const double* R = hrec + (size_t)el * 16;
-      acc += R[12] * (R[3 * j + r] * R[3 * k + c]);
-    } else {
-      acc += frec[(size_t)el * 81 + pr * 9 + e9];   // el: the face's processing index, pr = 3 l + m
+  // Round 6: a workgroup takes 28 consecutive blocks.  SUMS: one lane per ENTRY of a block (nine lanes per block, entry index fastest: a record is read as one
+  // contiguous run of 72 bytes, nine times the loads in flight of the one-lane-per-block form that walked its list with one record at a time -- 84 MB of records
+  // at 0.8 TB/s).  STORES: through LDS, block index fastest -- the blocks are sorted by their address in the SELL-64 value array, so for one entry index the
+  // lanes write consecutive lanes of a slice (the nine entries of a block lie 512 bytes apart: written by the nine lanes of the block, every read-modify-write
+  // was a 64-byte sector of its own).  Every entry is still summed by ONE lane in the order of the list: the same bits.
+  __shared__ double tile[9][CG_BPW + 1];
+  const int b0 = blockIdx.x * CG_BPW, t = threadIdx.x;
+  if (t < 9 * CG_BPW) {
+    const int bl = t / 9, e9 = t - 9 * bl, b = b0 + bl, r = e9 / 3, c = e9 - 3 * r;
+    double acc = 0.0;
+    if (b < n_blk) {
+      for (int q = ptr[b]; q < ptr[b + 1]; q++) {
+        const unsigned e = ent[q];
+        const int el = (int)((e >> 4) & 0x7ffffff), pr = (int)(e & 15);
+        if ((e >> 30) == 1) {   // tetrahedron: its 16 vertex-pair blocks as stored by k_tet_hess_coop (144 doubles per element)
+          acc += trec[(size_t)(el & 0x3ffffff) * 144 + pr * 9 + e9];
+        } else if (e >> 31) {   // hinge: block (j, k) = d2 g_j g_k^T from the four vertex gradients and the scale
+          const int j = pr >> 2, k = pr & 3;
+          const double* R = hrec + (size_t)el * 16;
+          acc += R[12] * (R[3 * j + r] * R[3 * k + c]);
+        } else {
+          acc += frec[(size_t)el * 81 + pr * 9 + e9];   // el: the face's processing index, pr = 3 l + m
+        }
+      }
     }
+    tile[e9][bl] = acc;
   }
-  vals[(size_t)base[b] + 64 * e9] += acc;
+  __syncthreads();
+  if (t < 9 * CG_BPW) {
+    const int e9 = t / CG_BPW, bl = t - CG_BPW * e9, b = b0 + bl;
+    if (b < n_blk) vals[(size_t)base[b] + 64 * e9] += tile[e9][bl];
+  }
 }
 
 // Cloth.update_ref_angle (:176-185), one lane per hinge

@@ -660,7 +660,7 @@ static int assemble_enqueue(tsl_ctx* c, const double* pos, const double* prev, c
       else hipLaunchKernelGGL(k_tet_hess, dim3(nblk(c->n_tet, 64)), dim3(64), 0, stt, TA, c->tet_blk.p, pos, spd, c->vals_full.p, vws, warm, (double*)nullptr);
       const int nt_blk = c->n_cgblk - c->n_cgblk_cloth;
       if (det && nt_blk > 0)
-        hipLaunchKernelGGL(k_cloth_gather, dim3(nblk(9L * nt_blk, 256)), dim3(256), 0, stt, nt_blk, c->cg_base.p + c->n_cgblk_cloth, c->cg_ptr.p + c->n_cgblk_cloth, (const unsigned*)c->cg_ent.p,
+        hipLaunchKernelGGL(k_cloth_gather, dim3(nblk(nt_blk, CG_BPW)), dim3(256), 0, stt, nt_blk, c->cg_base.p + c->n_cgblk_cloth, c->cg_ptr.p + c->n_cgblk_cloth, (const unsigned*)c->cg_ent.p,
                            c->n_hinge, c->n_cface, (const double*)c->cg_hrec.p, (const double*)c->cg_frec.p, (const double*)c->cg_trec.p, c->vals_full.p);
     }
   }
@@ -682,7 +682,7 @@ static int assemble_enqueue(tsl_ctx* c, const double* pos, const double* prev, c
   }
   if (c->n_hinge) hipLaunchKernelGGL(k_cloth_hess_hinge, dim3(nblk(c->n_hinge, 256)), dim3(256), 0, s, CA, c->hg_blk.p, pos, c->vals_full.p, gather ? c->cg_hrec.p : (double*)nullptr);
   if (gather && c->n_cgblk_cloth > 0)
-    hipLaunchKernelGGL(k_cloth_gather, dim3(nblk(9L * c->n_cgblk_cloth, 256)), dim3(256), 0, s, c->n_cgblk_cloth, c->cg_base.p, c->cg_ptr.p, (const unsigned*)c->cg_ent.p, c->n_hinge, c->n_cface,
+    hipLaunchKernelGGL(k_cloth_gather, dim3(nblk(c->n_cgblk_cloth, CG_BPW)), dim3(256), 0, s, c->n_cgblk_cloth, c->cg_base.p, c->cg_ptr.p, (const unsigned*)c->cg_ent.p, c->n_hinge, c->n_cface,
                        (const double*)c->cg_hrec.p, (const double*)c->cg_frec.p, (const double*)c->cg_trec.p, c->vals_full.p);
   if (fork) HIP_OK(hipStreamWaitEvent(s, c->ev_join, 0));
   if (fork_t) HIP_OK(hipStreamWaitEvent(s, c->ev_join2, 0));
@@ -725,11 +725,17 @@ static int assemble_enqueue_early(tsl_ctx* c, const double* pos, const double* p
   const VertArgs VA = vert_args(c);
   TetArgs TA = tet_args(c);
   CA.gstage = c->vg_stage.p; TA.gstage = c->vg_stage.p + 3 * (size_t)c->vg_tet0;
-  const bool gather = c->n_cgblk > 0;
   HIP_OK(hipEventRecord(c->ev_fork0, s));   // (whatever the caller queued on the engine stream before -- positions -- comes first)
   HIP_OK(hipStreamWaitEvent(st, c->ev_fork0, 0));
   if (fork_t) HIP_OK(hipStreamWaitEvent(stt, c->ev_fork0, 0));
   TSL_TRY(contact_assemble(c, pos, spd, grad, st));   // (the longest chain: blocks 120-160 us, mask, diagonal, hinge gradients, gradient tail)
+  const bool gather = c->n_cgblk > 0;
+  const bool hh_side = fork_t && gather;
+  // element stream: the hinge blocks first (records: they read positions only), so that the cloth gather on the engine stream can start when the face blocks end
+  if (hh_side && c->n_hinge) {
+    hipLaunchKernelGGL(k_cloth_hess_hinge, dim3(nblk(c->n_hinge, 256)), dim3(256), 0, stt, CA, c->hg_blk.p, pos, c->vals_full.p, c->cg_hrec.p);
+    HIP_OK(hipEventRecord(c->ev_hh, stt));
+  }
   if (c->n_tet) {
     if (grad) { hipLaunchKernelGGL(k_tet_grad, dim3(nblk(c->n_tet, 256)), dim3(256), 0, stt, TA, pos, grad); HIP_OK(hipEventRecord(c->ev_g2, stt)); }   // tet gradients staged
     // eigen-clamp of the element blocks warm-started from the previous assembly's eigenvectors ("tet_warm", on by default);
@@ -757,14 +763,10 @@ static int assemble_enqueue_early(tsl_ctx* c, const double* pos, const double* p
   // gradients behind the body blocks: the engine stream's chain is face blocks -> cloth gather -> mask, the contact stream's contact blocks -> hinge gradients ->
   // gradient tail.  (Round 5 had moved them the other way, when this stream was busy with the bodies for 170 us.)
   HIP_OK(hipStreamWaitEvent(stt, c->ev_fork, 0));
-  const bool hh_side = fork_t && gather;
-  if (c->n_hinge) {
-    hipLaunchKernelGGL(k_cloth_hess_hinge, dim3(nblk(c->n_hinge, 256)), dim3(256), 0, hh_side ? stt : s, CA, c->hg_blk.p, pos, c->vals_full.p, gather ? c->cg_hrec.p : (double*)nullptr);
-    if (hh_side) HIP_OK(hipEventRecord(c->ev_hh, stt));
-  }
+  if (c->n_hinge && !hh_side) hipLaunchKernelGGL(k_cloth_hess_hinge, dim3(nblk(c->n_hinge, 256)), dim3(256), 0, s, CA, c->hg_blk.p, pos, c->vals_full.p, gather ? c->cg_hrec.p : (double*)nullptr);
   const int nt_blk = c->n_cgblk - c->n_cgblk_cloth;
   if (c->n_tet && nt_blk > 0)   // the element records of the bodies -> their matrix blocks (the blocks of the bodies and of the cloth are disjoint)
-    hipLaunchKernelGGL(k_cloth_gather, dim3(nblk(9L * nt_blk, 256)), dim3(256), 0, stt, nt_blk, c->cg_base.p + c->n_cgblk_cloth, c->cg_ptr.p + c->n_cgblk_cloth, (const unsigned*)c->cg_ent.p,
+    hipLaunchKernelGGL(k_cloth_gather, dim3(nblk(nt_blk, CG_BPW)), dim3(256), 0, stt, nt_blk, c->cg_base.p + c->n_cgblk_cloth, c->cg_ptr.p + c->n_cgblk_cloth, (const unsigned*)c->cg_ent.p,
                        c->n_hinge, c->n_cface, (const double*)c->cg_hrec.p, (const double*)c->cg_frec.p, (const double*)c->cg_trec.p, c->vals_full.p);
   HIP_OK(hipEventRecord(c->ev_join2, stt));   // body blocks
   // contact stream, second part: hinge gradients (staging slots); the face gradients behind the body blocks on the element stream
@@ -779,7 +781,7 @@ static int assemble_enqueue_early(tsl_ctx* c, const double* pos, const double* p
   // engine stream: cloth blocks (behind the hinge records), then the matrix tail
   if (hh_side && c->n_hinge) HIP_OK(hipStreamWaitEvent(s, c->ev_hh, 0));
   if (gather && c->n_cgblk_cloth > 0)
-    hipLaunchKernelGGL(k_cloth_gather, dim3(nblk(9L * c->n_cgblk_cloth, 256)), dim3(256), 0, s, c->n_cgblk_cloth, c->cg_base.p, c->cg_ptr.p, (const unsigned*)c->cg_ent.p, c->n_hinge, c->n_cface,
+    hipLaunchKernelGGL(k_cloth_gather, dim3(nblk(c->n_cgblk_cloth, CG_BPW)), dim3(256), 0, s, c->n_cgblk_cloth, c->cg_base.p, c->cg_ptr.p, (const unsigned*)c->cg_ent.p, c->n_hinge, c->n_cface,
                        (const double*)c->cg_hrec.p, (const double*)c->cg_frec.p, (const double*)c->cg_trec.p, c->vals_full.p);
   HIP_OK(hipStreamWaitEvent(s, c->ev_join2, 0));
   hipLaunchKernelGGL(k_mask_matrix, dim3(c->n_slices), dim3(256), 0, s, c->n_slices, c->slice_off.p, c->slice_len.p, c->colidx.p, c->fzmask.p, c->mdt2.p,
