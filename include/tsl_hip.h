@@ -112,20 +112,19 @@ int tsl_set_stream(tsl_ctx* ctx, void* hip_stream);
  *   "cg_tol" (1e-10), "cg_maxit", "direct" (-1 auto: cloth grids of >= 1024 cells / 0 iterative hierarchy only / 1 always: multifrontal LU on the GPU),
  *   "direct_leaf" (vertices per nested-dissection leaf, 64), "direct_piv_tol" (static pivoting: pivots below this fraction of their entry diagonal are
  *   perturbed to it, 1e-11), "direct_berr" (1e-12: a first pass of the factorised solve whose normwise backward error |b - Hx| / (|H|_inf |x| + |b|) is
- *   at most this is accepted; 0: every solve is refined to cg_tol), "direct_berr_rel_cap" (50: ... and whose forward residual is at most this x cg_tol),
+ *   at most this is accepted; 0: every solve is refined to cg_tol), and whose forward residual is at most 50 x cg_tol (fixed),
  *   "direct_flow" (3; bit 0: the block steps of one batch per tree level as ONE persistent dataflow launch, k_ds_gj_flow; bit 1: also the batches the
  *   LDS kernel would take; 0: one launch per 32 pivots -- the same bits either way), "direct_flow_token" (0: hand the device's dataflow token back),
  *   "direct_small_rounds" (2: rounds of the chip a batch may take in the LDS kernel k_ds_inv_small), "direct_g32_below" (1100: G = W F12 of a batch
  *   with fewer 64 x 64 tiles than this uses 32 x 32 tiles), "direct_gemv_wide_below" (300: a sweep launch of fewer 16-row chunks than this runs four
- *   workgroups per chunk), "direct_xcd" (64: batches of at least this many fronts launch their GEMM tiles with the XCD-aware map), "direct_prezero"
- *   (1: the leaf panels of the next factorisation are cleared on a side stream after each solve of a time step), "direct_plan_cache" (64: plans of
- *   earlier constraint sets kept; the reverse sweep finds the forward rollout's plans there),
+ *   workgroups per chunk).  (Fixed since round 6: batches of >= 64 fronts launch their GEMM tiles with the XCD-aware map, the leaf panels of the next
+ *   factorisation are cleared on a side stream after each solve of a time step, 64 plans of earlier constraint sets are kept.)
  *   "mg" (-1 auto / 0 / 1), "mg_coarse_exact", "mg_dense_nodes" (largest multigrid level solved exactly; -1 = chosen per time step), "body_inv"
  *   (dense inverses of the small FEM-body blocks), "gmres_m" (GMRES restart length), "tet_warm" (1: the eigen-clamp of the element blocks starts from
- *   the eigenvectors of the element's previous assembly),
- *   "deterministic" (1: element gradients / blocks and contact rows go to staging slots and records and are summed by gather kernels in a fixed order,
- *   constraint lists are compacted by scan, energies and dot products joined from per-workgroup partials -- no f64 atomics on the step and adjoint
- *   path, two runs give the same bits; 0: the scattered atomics of rounds 1-3).
+ *   the eigenvectors of the element's previous assembly).
+ *   (Element gradients / blocks and contact rows go to staging slots and records and are summed by gather kernels in a fixed order, constraint lists are
+ *   compacted by scan, energies and dot products joined from per-workgroup partials: no f64 atomics on the step and adjoint path, two runs give the same
+ *   bits.  There is no switch: the scattered-atomics assembly of rounds 1-3 and its "deterministic" key are gone.)
  *  Diagnostics: "verbose" (1 phase times per step, 2 plans, 3 batches, 4 Newton iterations, 5 refinement passes), "ds_dbg" (21: force the dataflow-abort
  *   branch, tests; 30: device-clock trace of a dataflow chain), "ds_bench_batch" (tsl_bench_direct on one batch).
  * The experiment switches of rounds 1-4 (factor lagging, alternative GEMM / Schur tilings, one-lane contact and 16-lane element assembly, PCG warm

@@ -43,13 +43,10 @@ def test_tables_match_oracle(oracle, N, M):
     assert np.array_equal(c.counter_point.to_numpy(), o.arr("cloth0.counter_point", (-1, 3)))
 
 
-@pytest.mark.parametrize("det", [1, 0])
 @pytest.mark.parametrize("N,M", [(15, 3), (12, 12)])
-def test_energy_gradient_hessian(oracle, N, M, det):
-    """det = 1 (default): element gradients and Hessian blocks through staging records and gathers in a fixed order (k_vertex_gather,
-    k_cloth_gather); 0: the f64-atomic scatter of rounds 1-3"""
+def test_energy_gradient_hessian(oracle, N, M):
+    """element gradients and Hessian blocks through staging records and gathers in a fixed order (k_vertex_gather, k_cloth_gather)"""
     sys, o = _pair(oracle, N, M)
-    sys._ensure_ctx().set_param("deterministic", det)
     o.newton_step_init()
     E_o = o.compute_energy()
     E_g = sys.compute_energy()

@@ -1,12 +1,12 @@
-// Thin-shell (cloth) kernels for gfx950.  What each kernel computes is the sum the reference
-// accumulates with Taichi atomics; how it is organised is native to this engine:
-//   * faces / hinges / vertices are independent work items (one lane each, 64-wide waves, no divergence
-//     inside a work-item class), positions are gathered straight from the global node array (L2 resident:
-//     24 B per node), per-element results are scattered with hardware f64 atomics into the gradient and
-//     into pre-resolved SELL-64 block slots of the system matrix (no (i,j) search on the device).
-//   * closed forms are derived independently of the reference's expanded expressions (vector calculus for
-//     the triangle-area Hessian, explicit quirk terms where the reference deviates) -- the parity tests
-//     compare them with the literal CPU restatement in oracle/.
+// Thin-shell (cloth) kernels for gfx950.  What each kernel computes is the sum the reference accumulates with Taichi atomics; how it is organised
+// is native to this engine:
+//   * faces / hinges are independent work items (one lane each, 64-wide waves, no divergence inside a work-item class), positions are gathered
+//     straight from the global node array (L2 resident: 24 B per node);
+//   * NO atomics: element gradients go to staging slots (three-vectors per element and slot) that k_vertex_gather sums per vertex, element blocks
+//     to records (faces: their 9 x 9 block, hinges: four vertex gradients and a scale) that k_cloth_gather sums per 3 x 3 block of the SELL-64
+//     matrix -- every sum in a fixed order, the assembled gradient and matrix are the same bits in every run;
+//   * closed forms are derived independently of the reference's expanded expressions (vector calculus for the triangle-area Hessian, explicit
+//     quirk terms where the reference deviates) -- the parity tests compare them with the literal CPU restatement in oracle/.
 // Reference: /root/reference/code/engine/model_fold_offset.py (line numbers at each kernel).
 #pragma once
 #include "tsl_ctx.hpp"
@@ -97,9 +97,9 @@ struct ClothArgs {
   const double *V, *li;
   const int *hg_info, *hg_v;
   const double* norm_dir;
-  const int* f_order;   // processing order of the faces in the kernels that scatter with atomics: faces of one stencil class in a row (coalesced)
-  // deterministic assembly: element gradients go to a staging array of 3-vectors (face f, slot l: 3 f + l; hinge h, slot j: gs_hinge + 4 h + j)
-  // that k_vertex_gather sums per vertex in a fixed order; null: f64 atomics into the gradient
+  const int* f_order;   // processing order of the faces: faces of one stencil class in a row (coalesced record writes)
+  // element gradients go to a staging array of 3-vectors (face f, slot l: 3 f + l; hinge h, slot j: gs_hinge + 4 h + j) that k_vertex_gather sums per
+  // vertex in a fixed order
   double* gstage;
   int gs_hinge;
 };
@@ -116,7 +116,7 @@ TSL_DEV double hinge_energy(const ClothArgs& A, int h, const double* __restrict_
 
 // ---------------------------------------------------------------------------------------------
 // gradient: per face (edges + area, Cloth.compute_residual :653-677), per hinge (:679-687)
-__global__ void k_cloth_grad_face(ClothArgs A, const double* __restrict__ pos, double* __restrict__ F) {
+__global__ void k_cloth_grad_face(ClothArgs A, const double* __restrict__ pos) {
   const int t = blockIdx.x * blockDim.x + threadIdx.x;
   if (t >= A.n_cface) return;
   const int f = A.f_order[t];
@@ -145,16 +145,11 @@ __global__ void k_cloth_grad_face(ClothArgs A, const double* __restrict__ pos, d
     const d3 ga = 0.5 * cross(nh, P[(l + 2) % 3] - P[(l + 1) % 3]);
     g[l] = g[l] + da * ga;
   }
-  if (A.gstage) {
 #pragma unroll
-    for (int l = 0; l < 3; l++) st3(A.gstage, 3 * f + l, g[l]);
-    return;
-  }
-#pragma unroll
-  for (int l = 0; l < 3; l++) atomic_add3(F, v[l], g[l]);
+  for (int l = 0; l < 3; l++) st3(A.gstage, 3 * f + l, g[l]);
 }
 
-__global__ void __launch_bounds__(256) k_cloth_grad_hinge(ClothArgs A, const double* __restrict__ pos, const double* __restrict__ ref_angle, double* __restrict__ F) {
+__global__ void __launch_bounds__(256) k_cloth_grad_hinge(ClothArgs A, const double* __restrict__ pos, const double* __restrict__ ref_angle) {
   const int h = blockIdx.x * blockDim.x + threadIdx.x;
   if (h >= A.n_hinge) return;
   const int f1 = A.hg_info[8 * h], l = A.hg_info[8 * h + 1], f2 = A.hg_info[8 * h + 2], p4 = A.hg_info[8 * h + 3], p21 = A.hg_info[8 * h + 4];
@@ -167,24 +162,13 @@ __global__ void __launch_bounds__(256) k_cloth_grad_hinge(ClothArgs A, const dou
   hinge_grad(g1, g2, l, p4, p21, g);
   const double theta = dihedral(g1.n, g2.n, pick3(P1, (l + 1) % 2) - pick3(P1, l));
   const double dth = 2.0 * c.Kb * (theta - ref_angle[3 * f1 + l]) * c.dx * c.dx * (1.0 / 3.0);
-  if (A.gstage) {
 #pragma unroll
-    for (int j = 0; j < 4; j++) st3(A.gstage, A.gs_hinge + 4 * h + j, dth * g[j]);
-    return;
-  }
-  atomic_add3(F, pick3(v1, l), dth * g[0]);
-  atomic_add3(F, pick3(v1, (l + 1) % 3), dth * g[1]);
-  atomic_add3(F, pick3(v1, (l + 2) % 3), dth * g[2]);
-  atomic_add3(F, pick3(v2, p4), dth * g[3]);
+  for (int j = 0; j < 4; j++) st3(A.gstage, A.gs_hinge + 4 * h + j, dth * g[j]);
 }
 
 // ---------------------------------------------------------------------------------------------
-// Hessian.  Block slots: blk[..] is the address of element (0,0) of a 3x3 block inside the SELL-64 value
-// array, element (r,c) lives at +64*(3r+c).
-TSL_DEV void add_block(double* __restrict__ vals, int base, const double* B9) {
-#pragma unroll
-  for (int e = 0; e < 9; e++) atomicAdd(&vals[(size_t)base + 64 * e], B9[e]);
-}
+// Hessian: the element kernels leave RECORDS, k_cloth_gather below sums them into the 3 x 3 blocks of the SELL-64 value array (element (r, c) of a block
+// lives at +64 (3 r + c) from its base).
 
 // Quirk constants: compute_Hessian_bending (:597, :606) reads c_i[l][.] and mat_N[l*3+.] with l the VERTEX SLOT,
 // i.e. the bending data of faces 0,1,2 of the cloth, for every face.  One tiny launch evaluates prepare_bending
@@ -228,8 +212,7 @@ __global__ void k_cloth_quirk(ClothArgs A, int n_cloth, const double* __restrict
 // build an SPD preconditioner when the reference's partially projected Hessian turns out indefinite.
 template <bool CLAMP_ALL>
 __global__ void __launch_bounds__(128)
-k_cloth_hess_face(ClothArgs A, const int* __restrict__ blk, const double* __restrict__ pos, const double* __restrict__ ref_angle,
-                  const double* __restrict__ Q, int spd, double* __restrict__ vals, double* __restrict__ rec) {
+k_cloth_hess_face(ClothArgs A, const double* __restrict__ pos, const double* __restrict__ ref_angle, const double* __restrict__ Q, int spd, double* __restrict__ rec) {
   const int t = blockIdx.x * blockDim.x + threadIdx.x;
   if (t >= A.n_cface) return;
   const int f = A.f_order[t];
@@ -380,34 +363,21 @@ k_cloth_hess_face(ClothArgs A, const int* __restrict__ blk, const double* __rest
   }
 
   if (CLAMP_ALL) spd_clamp<9>(L);
-  if (rec) {   // gather assembly (k_cloth_gather): the 9 x 9 block as a record of nine contiguous 3 x 3 vertex blocks, addressed by the
-               // processing index t (what the gather lists refer to): a lane fills its own 648 bytes, a gather reads 72 of them in a row
-    double* R = rec + (size_t)t * 81;
-#pragma unroll
-    for (int l = 0; l < 3; l++)
-#pragma unroll
-      for (int m = 0; m < 3; m++)
-#pragma unroll
-        for (int j = 0; j < 3; j++)
-#pragma unroll
-          for (int k = 0; k < 3; k++) R[(l * 3 + m) * 9 + j * 3 + k] = L[(l * 3 + j) * 9 + m * 3 + k];
-    return;
-  }
-  // ---- flush the 3x3 grid of blocks
+  // the 9 x 9 block as a record of nine contiguous 3 x 3 vertex blocks for k_cloth_gather, addressed by the processing index t (what the gather lists
+  // refer to): a lane fills its own 648 bytes, a gather reads 72 of them in a row
+  double* R = rec + (size_t)t * 81;
 #pragma unroll
   for (int l = 0; l < 3; l++)
 #pragma unroll
-    for (int m = 0; m < 3; m++) {
-      const int base = blk[9 * f + l * 3 + m];
+    for (int m = 0; m < 3; m++)
 #pragma unroll
       for (int j = 0; j < 3; j++)
 #pragma unroll
-        for (int k = 0; k < 3; k++) atomicAdd(&vals[(size_t)base + 64 * (3 * j + k)], L[(l * 3 + j) * 9 + m * 3 + k]);
-    }
+        for (int k = 0; k < 3; k++) R[(l * 3 + m) * 9 + j * 3 + k] = L[(l * 3 + j) * 9 + m * 3 + k];
 }
 
 // One lane per hinge: Gauss-Newton block d2theta * grad grad^T (compute_Hessian_bending :616-637)
-__global__ void __launch_bounds__(256) k_cloth_hess_hinge(ClothArgs A, const int* __restrict__ blk, const double* __restrict__ pos, double* __restrict__ vals, double* __restrict__ rec) {
+__global__ void __launch_bounds__(256) k_cloth_hess_hinge(ClothArgs A, const double* __restrict__ pos, double* __restrict__ rec) {
   const int h = blockIdx.x * blockDim.x + threadIdx.x;
   if (h >= A.n_hinge) return;
   const int f1 = A.hg_info[8 * h], l = A.hg_info[8 * h + 1], f2 = A.hg_info[8 * h + 2], p4 = A.hg_info[8 * h + 3], p21 = A.hg_info[8 * h + 4];
@@ -419,29 +389,18 @@ __global__ void __launch_bounds__(256) k_cloth_hess_hinge(ClothArgs A, const int
   d3 g[4];
   hinge_grad(g1, g2, l, p4, p21, g);
   const double d2 = 2.0 * c.Kb * c.dx * c.dx * (1.0 / 3.0);
-  if (rec) {   // gather assembly: the four vertex gradients and the scale, entry-major; block (j, k) = d2 g_j g_k^T is formed by k_cloth_gather
-    double* R = rec + (size_t)h * 16;   // 128-byte record: g_0 .. g_3, d2
+  // the record k_cloth_gather forms the blocks from: the four vertex gradients and the scale (128 bytes); block (j, k) = d2 g_j g_k^T
+  double* R = rec + (size_t)h * 16;
 #pragma unroll
-    for (int j = 0; j < 4; j++) { R[3 * j] = g[j].x; R[3 * j + 1] = g[j].y; R[3 * j + 2] = g[j].z; }
-    R[12] = d2;
-    return;
-  }
-#pragma unroll
-  for (int j = 0; j < 4; j++)
-#pragma unroll
-    for (int k = 0; k < 4; k++) {
-      const m3 B = m3_outer(g[j], g[k]);
-      const int base = blk[16 * h + j * 4 + k];
-#pragma unroll
-      for (int e = 0; e < 9; e++) atomicAdd(&vals[(size_t)base + 64 * e], d2 * B.m[e]);
-    }
+  for (int j = 0; j < 4; j++) { R[3 * j] = g[j].x; R[3 * j + 1] = g[j].y; R[3 * j + 2] = g[j].z; }
+  R[12] = d2;
 }
 
 // Gather assembly of the cloth Hessian (round 3): one lane per 3 x 3 matrix block that some face or hinge contributes to.  The
 // element kernels above leave records (faces: their 9 x 9 block as nine 3 x 3 blocks; hinges: four vertex gradients + scale) and this kernel sums, for
 // its block, the contributions of the incident elements from a list built once per context (ent[ptr[b] .. ptr[b + 1]): bit 31
 // hinge / face, bits 4..30 element, bits 0..3 local vertex pair) and adds the sum to the matrix with ONE plain read-modify-write
-// per entry -- the scatter versions issue 144 (hinge) + 81 (face) f64 atomics per element, 30 M per assembly at 100k triangles,
+// per entry -- the scatter versions of rounds 1-2 issued 144 (hinge) + 81 (face) f64 atomics per element, 30 M per assembly at 100k triangles,
 // which bound both kernels (0.27 ms of an assembly's 0.45).  Blocks are sorted by their address in the SELL-64 value array: the
 // lanes of a wave write consecutive lanes of one slice.  Fixed summation order: the assembled cloth blocks are the same bits every run.
 #define CG_BPW 28   // blocks per workgroup of k_cloth_gather (28 x 9 = 252 of 256 threads)

@@ -24,16 +24,8 @@ TSL_DEV double fr_f1(double x, double eh) { return (x > eh) ? 1.0 / x : (-x / (e
 TSL_DEV double fr_f2(double x, double eh) { return (x > eh) ? -1.0 / (x * x) : -1.0 / (eh * eh); }
 
 // ------------------------------------------------------------------------------------------------ vertex normals
-__global__ void k_vn_accum(int NF, const int* __restrict__ faces, const double* __restrict__ pos, double* __restrict__ vn) {
-  const int f = blockIdx.x * blockDim.x + threadIdx.x;
-  if (f >= NF) return;
-  const int a = faces[3 * f], b = faces[3 * f + 1], c = faces[3 * f + 2];
-  const d3 v1 = ld3(pos, a), v2 = ld3(pos, b), v3 = ld3(pos, c);
-  const d3 n = cross(v2 - v1, v3 - v1);
-  atomic_add3(vn, a, n); atomic_add3(vn, b, n); atomic_add3(vn, c, n);
-}
-// the same sum per vertex over its incident surface triangles (static vertex -> triangle lists, ascending triangle index): no atomics,
-// a fixed order (the projection query's side flag proj_dir is the sign of a dot product with these normals)
+// area-weighted normal per vertex (BaseScene.calc_vn): the sum over its incident surface triangles from static vertex -> triangle lists in
+// ascending triangle order: no atomics, a fixed order (the projection query's side flag proj_dir is the sign of a dot product with these normals)
 __global__ void k_vn_gather(int NV, const int* __restrict__ ptr, const int* __restrict__ lst, const int* __restrict__ faces, const double* __restrict__ pos, double* __restrict__ vn) {
   const int i = blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= NV) return;
@@ -339,7 +331,7 @@ __global__ void k_contact_pair(int b_idx, int v_start, int v_end, double mu, int
 
 // ------------------------------------------------------------------------------------------------ energy
 // BaseScene.contact_energy(diff=False) (:490-543 normal, :548-595 friction)
-__global__ void k_contact_energy(int nc, ContactArgs A, const double* __restrict__ pos, double* e_out, double* __restrict__ e_part) {
+__global__ void k_contact_energy(int nc, ContactArgs A, const double* __restrict__ pos, double* __restrict__ e_part) {
   const int i = blockIdx.x * blockDim.x + threadIdx.x;
   double e = 0;
   if (i < nc) {
@@ -357,8 +349,7 @@ __global__ void k_contact_energy(int nc, ContactArgs A, const double* __restrict
     e += A.k[i] * fr_f0(sqrt(u0 * u0 + u1 * u1), A.eps_vh);
   }
   e = wave_sum(e);
-  if (e_part) { if ((threadIdx.x & 63) == 0) e_part[blockIdx.x] = e; }   // (one wave per workgroup: a partial per workgroup, summed in order by k_energy_final)
-  else if ((threadIdx.x & 63) == 0 && e != 0.0) atomicAdd(e_out, e);
+  if ((threadIdx.x & 63) == 0) e_part[blockIdx.x] = e;   // (one wave per workgroup: a partial per workgroup, summed in order by k_energy_final)
 }
 
 // ------------------------------------------------------------------------------------------------ gradient + blocks
@@ -371,7 +362,7 @@ __global__ void k_contact_energy(int nc, ContactArgs A, const double* __restrict
 TSL_DEV d3 c_unit(int a) { return d3(a == 0 ? 1.0 : 0.0, a == 1 ? 1.0 : 0.0, a == 2 ? 1.0 : 0.0); }
 TSL_DEV double c_comp(const d3& v, int a) { return a == 0 ? v.x : (a == 1 ? v.y : v.z); }
 __global__ void __launch_bounds__(256)
-k_contact_assemble_coop(int nc, ContactArgs A, const double* __restrict__ pos, int spd, double* __restrict__ grad, double* __restrict__ Hfull, double* __restrict__ cg) {
+k_contact_assemble_coop(int nc, ContactArgs A, const double* __restrict__ pos, int spd, double* __restrict__ Hfull, double* __restrict__ cg) {
   const int l = threadIdx.x & 15;
   int ci = (int)((blockIdx.x * (size_t)blockDim.x + threadIdx.x) >> 4);
   const bool valid = ci < nc;
@@ -488,28 +479,24 @@ k_contact_assemble_coop(int nc, ContactArgs A, const double* __restrict__ pos, i
   }
   if (!valid || l >= 12) return;
   const int rowi = l < 9 ? 3 + l : l - 9;
-  if (cg) cg[12 * (size_t)ci + rowi] = gout;
-  else if (grad) atomicAdd(&grad[3 * (size_t)id[rowi / 3] + rowi % 3], gout);
+  if (cg) cg[12 * (size_t)ci + rowi] = gout;   // (per-constraint gradients, summed per vertex by k_contact_row_gather)
   double* dst = Hfull + 144 * (size_t)ci + 12 * rowi;
 #pragma unroll
   for (int k = 0; k < 12; k++) dst[k] = out[k];
 }
 
-// masked copy of the per-constraint blocks (add_H frozen rule, BaseScene.py:399-405) + their diagonal 3x3 blocks
-// accumulated for the block-Jacobi preconditioner
+// masked copy of the per-constraint blocks (add_H frozen rule, BaseScene.py:399-405)
 // One thread per ENTRY (nc x 144): the one-thread-per-constraint version walked 144 dependent global accesses per lane and took
 // 96 us at 135 constraints on the contact stream of an assembly.
-__global__ void k_contact_mask(int nc, const int* __restrict__ idx, const int* __restrict__ frozen, const int* __restrict__ rowpos, const double* __restrict__ Hfull,
-                               double* __restrict__ Hm, double* __restrict__ cdiag) {
+__global__ void k_contact_mask(int nc, const int* __restrict__ idx, const int* __restrict__ frozen, const double* __restrict__ Hfull, double* __restrict__ Hm) {
   const long t = (long)blockIdx.x * blockDim.x + threadIdx.x;
   if (t >= (long)nc * 144) return;
   const int ci = (int)(t / 144), e = (int)(t % 144), r = e / 12, c = e % 12;
   const int vr = idx[4 * ci + r / 3], vc = idx[4 * ci + c / 3];
   const double v = (frozen[3 * vr + r % 3] || frozen[3 * vc + c % 3]) ? 0.0 : Hfull[t];
   Hm[t] = v;
-  if (cdiag && r / 3 == c / 3 && v != 0.0) atomicAdd(&cdiag[9 * (size_t)rowpos[vr] + 3 * (r % 3) + (c % 3)], v);
 }
-// the same diagonal blocks without atomics: one thread per (permuted) row sums the diagonal 3 x 3 sub-blocks of the row's entries in
+// their diagonal 3 x 3 blocks for the block-Jacobi preconditioner: one thread per (permuted) row sums the diagonal 3 x 3 sub-blocks of the row's entries in
 // their stored order (ascending constraint, slot); every row is written (zero without entries): no clear needed
 __global__ void __launch_bounds__(256) k_contact_diag(int NV, const int* __restrict__ ptr, const int* __restrict__ ent, const double* __restrict__ Hm, double* __restrict__ cdiag) {
   // one WAVE per row: lanes over the row's entries (l, l + 64, ...), joined by the fixed tree of wave_sum
@@ -599,29 +586,9 @@ k_contact_matvec(int nc, const int* __restrict__ idx, const int* __restrict__ ro
 }
 
 
-// tmp_z_frozen[j] -= H_ij z_i for i free, j frozen (second compute_Hessian pass of transfer_grad,
-// BaseScene.py:403-405 / analytic_grad_single.py:239-243), contact part; z, out in ORIGINAL order
-__global__ void k_contact_zfrozen(int nc, const int* __restrict__ idx, const int* __restrict__ frozen, const double* __restrict__ Hfull, const double* __restrict__ z,
-                                  double* __restrict__ out) {
-  const int ci = blockIdx.x * blockDim.x + threadIdx.x;
-  if (ci >= nc) return;
-  int id[4], fr[12];
-  double zv[12];
-  for (int k = 0; k < 4; k++) {
-    id[k] = idx[4 * ci + k];
-    for (int j = 0; j < 3; j++) { fr[3 * k + j] = frozen[3 * id[k] + j]; zv[3 * k + j] = z[3 * (size_t)id[k] + j]; }
-  }
-  const double* H = Hfull + 144 * (size_t)ci;
-  for (int c = 0; c < 12; c++) {
-    if (!fr[c]) continue;
-    double s = 0;
-    for (int r = 0; r < 12; r++) if (!fr[r]) s += H[r * 12 + c] * zv[r];
-    if (s != 0.0) atomicAdd(&out[3 * (size_t)id[c / 3] + (c % 3)], -s);
-  }
-}
 
 // BaseScene.contact_energy_backprop (:682-730): friction-lag adjoint into pos_grad[step-1] (pg points at that slice)
-__global__ void k_contact_backprop(int nc, ContactArgs A, const double* __restrict__ pos, const double* __restrict__ z, double* __restrict__ pg, double* __restrict__ cg) {
+__global__ void k_contact_backprop(int nc, ContactArgs A, const double* __restrict__ pos, const double* __restrict__ z, double* __restrict__ cg) {
   const int ci = blockIdx.x * blockDim.x + threadIdx.x;
   if (ci >= nc) return;
   int id[4];
@@ -664,8 +631,7 @@ __global__ void k_contact_backprop(int nc, ContactArgs A, const double* __restri
         for (int j1 = 0; j1 < 3; j1++)
           for (int j2 = 0; j2 < 3; j2++) acc[3 * i2 + j2] += zv[3 * i1 + j1] * w1[i1] * w1[i2] * h1[j1 * 3 + j2];
   }
-  if (cg) { for (int k = 0; k < 12; k++) cg[12 * (size_t)ci + k] = acc[k]; return; }   // deterministic: summed per vertex by k_vertex_gather
-  for (int k = 0; k < 4; k++) atomic_add3(pg, id[k], d3(acc[3 * k], acc[3 * k + 1], acc[3 * k + 2]));
+  for (int k = 0; k < 12; k++) cg[12 * (size_t)ci + k] = acc[k];   // summed per vertex by k_contact_row_gather
 }
 
 // Scene_sliding.contact_energy_backprop_friction (Scene_sliding.py:139-176): d(loss)/d(mu_cloth_cloth) contribution of the
@@ -790,11 +756,7 @@ extern "C" int tsl_contact_detect(tsl_ctx* c, const double* pos, const double* p
   if ((c->n_body < 2 && !any_self) || c->NF == 0) { if (nc_host) *nc_host = 0; return 0; }   // a single body can still touch itself (geometry_self.py)
   HIP_OK(hipMemsetAsync(c->nc_dev.p + 1, 0, sizeof(int), s));
   // calc_vn
-  if (c->deterministic && c->vnf_ptr.n > 0) hipLaunchKernelGGL(k_vn_gather, dim3(cnblk(NV, 256)), dim3(256), 0, s, NV, (const int*)c->vnf_ptr.p, (const int*)c->vnf_lst.p, c->faces.p, pos, c->vn.p);
-  else {
-    HIP_OK(hipMemsetAsync(c->vn.p, 0, 3 * (size_t)NV * sizeof(double), s));
-    hipLaunchKernelGGL(k_vn_accum, dim3(cnblk(c->NF, 256)), dim3(256), 0, s, c->NF, c->faces.p, pos, c->vn.p);
-  }
+  hipLaunchKernelGGL(k_vn_gather, dim3(cnblk(NV, 256)), dim3(256), 0, s, NV, (const int*)c->vnf_ptr.p, (const int*)c->vnf_lst.p, c->faces.p, pos, c->vn.p);
   hipLaunchKernelGGL(k_vn_normalize, dim3(cnblk(NV, 256)), dim3(256), 0, s, NV, c->vn.p);
   // projection_query
   GridArgs G;
@@ -902,21 +864,14 @@ static int contact_assemble(tsl_ctx* c, const double* pos, int spd, double* grad
   ContactArgs A;
   A.idx = c->c_idx.p; A.w = c->c_w.p; A.n = c->c_n.p; A.dx0 = c->c_dx0.p; A.k = c->c_k.p; A.mu = c->c_mu.p; A.T = c->c_T.p;
   A.k_contact = c->k_contact; A.eps_contact = c->eps_contact; A.eps_vh = c->eps_v * c->dt;
-  const bool want_cg = c->deterministic && grad;   // deterministic: per-constraint gradients, summed per vertex by k_vertex_gather
-  if (want_cg && c->c_G.n < 12 * (size_t)c->max_n_constraints) { if (c->c_G.alloc(12 * (size_t)c->max_n_constraints)) return -1; }
-  double* cg = want_cg ? c->c_G.p : (double*)nullptr;
-  hipLaunchKernelGGL(k_contact_assemble_coop, dim3(cnblk((long)c->nc * 16, 256)), dim3(256), 0, s, c->nc, A, pos, spd, grad, c->c_Hfull.p, cg);
-  if (c->deterministic) {
-    hipLaunchKernelGGL(k_contact_mask, dim3(cnblk((long)c->nc * 144, 256)), dim3(256), 0, s, c->nc, c->c_idx.p, c->frozen.p, c->rowpos.p, c->c_Hfull.p, c->c_H.p, (double*)nullptr);
-    // the diagonal 3 x 3 blocks of the contact terms feed the block-Jacobi inverse and the hierarchy's Galerkin diagonal only: a solve that goes to the
-    // factorisation never reads them (45 us on the longest chain of an assembly); block_jacobi_refresh forms them when the hierarchy runs after all
-    if (direct_takes_solve(c)) c->cdiag_valid = false;
-    else { contact_diag_refresh(c, s); }
-  } else {
-    c->cdiag_valid = true;
-    HIP_OK(hipMemsetAsync(c->c_diag.p, 0, c->c_diag.n * sizeof(double), s));
-    hipLaunchKernelGGL(k_contact_mask, dim3(cnblk((long)c->nc * 144, 256)), dim3(256), 0, s, c->nc, c->c_idx.p, c->frozen.p, c->rowpos.p, c->c_Hfull.p, c->c_H.p, c->c_diag.p);
-  }
+  if (grad && c->c_G.n < 12 * (size_t)c->max_n_constraints) { if (c->c_G.alloc(12 * (size_t)c->max_n_constraints)) return -1; }
+  double* cg = grad ? c->c_G.p : (double*)nullptr;   // per-constraint gradients, summed per vertex by k_contact_row_gather
+  hipLaunchKernelGGL(k_contact_assemble_coop, dim3(cnblk((long)c->nc * 16, 256)), dim3(256), 0, s, c->nc, A, pos, spd, c->c_Hfull.p, cg);
+  hipLaunchKernelGGL(k_contact_mask, dim3(cnblk((long)c->nc * 144, 256)), dim3(256), 0, s, c->nc, c->c_idx.p, c->frozen.p, c->c_Hfull.p, c->c_H.p);
+  // the diagonal 3 x 3 blocks of the contact terms feed the block-Jacobi inverse and the hierarchy's Galerkin diagonal only: a solve that goes to the
+  // factorisation never reads them (45 us on the longest chain of an assembly); block_jacobi_refresh forms them when the hierarchy runs after all
+  if (direct_takes_solve(c)) c->cdiag_valid = false;
+  else contact_diag_refresh(c, s);
   return 0;
 }
 

@@ -36,9 +36,9 @@ __global__ void k_vert_hess(VertArgs A, const int* __restrict__ diag_blk, double
   if (i >= A.NV) return;
   const double d = A.mass[i] / (A.dt * A.dt);
   const int base = diag_blk[i];
-  atomicAdd(&vals[(size_t)base + 64 * 0], d);
-  atomicAdd(&vals[(size_t)base + 64 * 4], d);
-  atomicAdd(&vals[(size_t)base + 64 * 8], d);
+  vals[(size_t)base + 64 * 0] += d;   // (one writer per diagonal block, behind the clear and in front of the gathers on the same stream)
+  vals[(size_t)base + 64 * 4] += d;
+  vals[(size_t)base + 64 * 8] += d;
 }
 
 struct TetArgs {
@@ -46,7 +46,7 @@ struct TetArgs {
   const ElasticDev* el;
   const int *tv, *tel;
   const double *B, *W;
-  double* gstage;   // deterministic assembly: element gradients of tet t at gstage[3 (4 t + j)] (null: atomics)
+  double* gstage;   // element gradients of tet t go to gstage[3 (4 t + j)], summed per vertex by k_vertex_gather
 };
 
 TSL_DEV m3 tet_F(const TetArgs& A, int t, const double* __restrict__ pos, int v[4], m3& B) {
@@ -83,7 +83,7 @@ TSL_DEV double tet_energy(const TetArgs& A, int t, const double* __restrict__ po
 }
 
 // forces: model_elastic_tactile.py:144-154 / model_elastic_offset.py:188-198 ; residual contribution is -force
-__global__ void k_tet_grad(TetArgs A, const double* __restrict__ pos, double* __restrict__ Fg) {
+__global__ void k_tet_grad(TetArgs A, const double* __restrict__ pos) {
   const int t = blockIdx.x * blockDim.x + threadIdx.x;
   if (t >= A.n_tet) return;
   int v[4]; m3 B;
@@ -111,10 +111,10 @@ __global__ void k_tet_grad(TetArgs A, const double* __restrict__ pos, double* __
 #pragma unroll
   for (int i = 0; i < 3; i++) {
     const d3 gi = d3(W * Hm.m[i], W * Hm.m[3 + i], W * Hm.m[6 + i]);  // +W*col = -(force) = dE/dx_i
-    if (A.gstage) st3(A.gstage, 4 * t + i, gi); else atomic_add3(Fg, v[i], gi);
+    st3(A.gstage, 4 * t + i, gi);
     f3 = f3 - gi;
   }
-  if (A.gstage) st3(A.gstage, 4 * t + 3, f3); else atomic_add3(Fg, v[3], f3);
+  st3(A.gstage, 4 * t + 3, f3);
 }
 
 // F_f = -(elastic gradient) + m g + f_ext on the vertices of the FEM bodies (Elastic.get_force, model_elastic_tactile.py:144-164 /
@@ -129,9 +129,9 @@ __global__ void k_elastic_force_finish(VertArgs A, int v0, int v1, double* __res
 // d(force)/d(mu): model_elastic_tactile.py:329-347 (P1 / mu = F - J F^-T) and model_elastic_offset.py:415-431 (P1 / mu = F - F^-T).
 // Tactile contributions go to d_tact (cleared by the caller on every call), box / ball contributions to d_accum, which the
 // reference never clears (it zeroes F_f instead), so it keeps growing over the calls.
-// stA / stB (deterministic): the four vertex contributions of tet t go to slots 4 t + j of stA (tactile material) or stB (the others), zeros to
-// the other array; k_vertex_gather sums them per vertex in a fixed order
-__global__ void k_tet_deri_mu(TetArgs A, const double* __restrict__ pos, double* __restrict__ d_tact, double* __restrict__ d_accum, double* __restrict__ stA, double* __restrict__ stB) {
+// stA / stB: the four vertex contributions of tet t go to slots 4 t + j of stA (tactile material) or stB (the others), zeros to the other array;
+// k_vertex_gather sums them per vertex in a fixed order (into d_tact / d_accum)
+__global__ void k_tet_deri_mu(TetArgs A, const double* __restrict__ pos, double* __restrict__ stA, double* __restrict__ stB) {
   const int t = blockIdx.x * blockDim.x + threadIdx.x;
   if (t >= A.n_tet) return;
   int v[4]; m3 B;
@@ -143,19 +143,16 @@ __global__ void k_tet_deri_mu(TetArgs A, const double* __restrict__ pos, double*
   for (int k = 0; k < 9; k++) P.m[k] = F.m[k] - JFiT.m[k];
   const m3 Hm = m3_mul(P, m3_T(B));
   const double W = A.W[t];
-  double* out = (e.kind == 0) ? d_tact : d_accum;
   double* sto = (e.kind == 0) ? stA : stB;
   double* stz = (e.kind == 0) ? stB : stA;
   d3 f3 = d3();
 #pragma unroll
   for (int i = 0; i < 3; i++) {
     const d3 fi = d3(-W * Hm.m[i], -W * Hm.m[3 + i], -W * Hm.m[6 + i]);
-    if (sto) { st3(sto, 4 * t + i, fi); st3(stz, 4 * t + i, d3()); }
-    else atomic_add3(out, v[i], fi);
+    st3(sto, 4 * t + i, fi); st3(stz, 4 * t + i, d3());
     f3 = f3 - fi;
   }
-  if (sto) { st3(sto, 4 * t + 3, f3); st3(stz, 4 * t + 3, d3()); }
-  else atomic_add3(out, v[3], f3);
+  st3(sto, 4 * t + 3, f3); st3(stz, 4 * t + 3, d3());
 }
 
 // dP(dF) for the two materials (energy Hessian direction), returns dE-Hessian column block dH = W * dP * B^T
@@ -194,9 +191,8 @@ TSL_DEV m3 tet_dH(const ElasticDev& e, const m3& F, const m3& Fi, const m3& FiT,
 // block (one directional derivative tet_dH each instead of nine per lane), the eigen-clamp is spd_clamp9_par (tsl_device.hpp: nine rounds of four simultaneous
 // Jacobi rotations per sweep) started from the eigenvector basis of the element's previous assembly (Vws, as spd_clamp_warm<9>: A' = V^T A V is nearly diagonal
 // when the element moved little; `warm` false or a stored basis that does not look like one starts from the identity), and lane b of the group writes block
-// (b / 4, b % 4) of the element record that k_cloth_gather sums into the matrix.  One lane per element with the block and the basis in private arrays
-// (k_tet_hess below: 512 registers, 1414 spilled, 130-170 us for the 5.8k elements of cfg4 -- the longest kernel of an assembly) is kept for the callers
-// that scatter with atomics.  kind 0 = 9 x 9 over vertices 0..2 with optional SPD projection, vertex 3 = minus row / column sums
+// (b / 4, b % 4) of the element record that k_cloth_gather sums into the matrix.  (Rounds 1-5: one lane per element with the block and the basis in
+// private arrays -- 512 registers, 1414 spilled, 130-170 us for the 5.8k elements of cfg4, the longest kernel of an assembly.)  kind 0 = 9 x 9 over vertices 0..2 with optional SPD projection, vertex 3 = minus row / column sums
 // (model_elastic_tactile.py:88-124); kind 1 = direct 12 x 12 (model_elastic_offset.py:101-167, no projection).
 __global__ void __launch_bounds__(256)
 k_tet_hess_coop(TetArgs A, const double* __restrict__ pos, int spd, double* __restrict__ Vws, int warm, double* __restrict__ rec) {
@@ -290,58 +286,3 @@ k_tet_hess_coop(TetArgs A, const double* __restrict__ pos, int spd, double* __re
     }
 }
 
-// Element Hessians: kind 0 = 9x9 over vertices 0..2 with optional SPD projection, vertex 3 = minus row/col sums
-// (model_elastic_tactile.py:88-124); kind 1 = direct 12x12 (model_elastic_offset.py:101-167, no projection).
-__global__ void __launch_bounds__(64)
-k_tet_hess(TetArgs A, const int* __restrict__ blk, const double* __restrict__ pos, int spd, double* __restrict__ vals, double* __restrict__ Vws, int warm, double* __restrict__ rec) {
-  const int t = blockIdx.x * blockDim.x + threadIdx.x;
-  if (t >= A.n_tet) return;
-  int v[4]; m3 B;
-  const m3 F = tet_F(A, t, pos, v, B);
-  const ElasticDev e = A.el[A.tel[t]];
-  const m3 Fi = (e.kind == 0) ? F : m3_inv(F), FiT = m3_T(Fi), BT = m3_T(B);   // the tactile material works from cofactors (tet_dH)
-  const double W = A.W[t];
-  const double Jraw = m3_det(F);
-  const double J = (e.kind == 0) ? Jraw : fmax(Jraw, 0.01);
-  const double logJ = (e.kind == 0) ? 0.0 : log(J);
-  // He[(n*3+dim)*9 + (i*3+j)] = d(grad of vertex i, comp j)/d(x_n,dim), n,i in 0..2
-  double He[81];
-  for (int n = 0; n < 3; n++)
-    for (int dim = 0; dim < 3; dim++) {
-      m3 dF;  // dD @ B with dD[dim][n] = 1  -> row dim of dF = row n of B
-#pragma unroll
-      for (int k = 0; k < 9; k++) dF.m[k] = 0;
-#pragma unroll
-      for (int c = 0; c < 3; c++) dF.m[dim * 3 + c] = B.m[n * 3 + c];
-      const m3 dH = tet_dH(e, F, Fi, FiT, J, logJ, dF, BT, W);
-#pragma unroll
-      for (int i = 0; i < 3; i++)
-#pragma unroll
-        for (int j = 0; j < 3; j++) He[(n * 3 + dim) * 9 + i * 3 + j] = dH.m[j * 3 + i];
-    }
-  if ((e.kind == 0 && spd) || spd == 2) {   // spd 2: preconditioner-only assembly, every element block projected
-    if (Vws) spd_clamp_warm<9>(He, Vws + t, (size_t)A.n_tet, warm != 0);   // eigenvector basis of the element's previous assembly as the start
-    else spd_clamp<9>(He);
-  }
-  if (e.kind != 0) {
-    // model_elastic_offset.py:151-167 scatters row = (vertex j, comp r), column = (n, dim): the transpose of the
-    // tactile convention (identical whenever the block is symmetric, i.e. J > 0.01)
-    for (int a = 0; a < 9; a++)
-      for (int b = a + 1; b < 9; b++) { const double tmp = He[a * 9 + b]; He[a * 9 + b] = He[b * 9 + a]; He[b * 9 + a] = tmp; }
-  }
-  // scatter: 16 blocks; block (a,b) element (j,j2): a,b<3: He[(a*3+j)*9 + b*3+j2]; vertex 3 gets minus sums
-  for (int a = 0; a < 4; a++)
-    for (int b = 0; b < 4; b++) {
-      const int base = blk[16 * t + a * 4 + b];
-      for (int j = 0; j < 3; j++)
-        for (int j2 = 0; j2 < 3; j2++) {
-          double s = 0;
-          if (a < 3 && b < 3) s = He[(a * 3 + j) * 9 + b * 3 + j2];
-          else if (a < 3) { for (int bb = 0; bb < 3; bb++) s -= He[(a * 3 + j) * 9 + bb * 3 + j2]; }
-          else if (b < 3) { for (int aa = 0; aa < 3; aa++) s -= He[(aa * 3 + j) * 9 + b * 3 + j2]; }
-          else { for (int aa = 0; aa < 3; aa++) for (int bb = 0; bb < 3; bb++) s += He[(aa * 3 + j) * 9 + bb * 3 + j2]; }
-          if (rec) rec[(size_t)t * 144 + (a * 4 + b) * 9 + 3 * j + j2] = s;   // gather assembly: k_cloth_gather adds the block
-          else atomicAdd(&vals[(size_t)base + 64 * (3 * j + j2)], s);
-        }
-    }
-}

@@ -278,16 +278,15 @@ struct tsl_ctx {
   DevBuf<unsigned> cg_ent;
   DevBuf<int> cg_base, cg_ptr;           // gather assembly of the cloth Hessian: block addresses (ascending), list offsets, packed (element, vertex pair)
   DevBuf<double> cg_hrec, cg_frec;       // per-hinge (13) and per-face (81) records, entry-major
-  // "deterministic" = 1 (default): every sum of the step and of the adjoint has a fixed order -- element gradients, energies and the Hessian blocks of
-  // cloth AND tets go through staging records and gathers, contact lists are ordered, contact sums walk them in order: two runs give the same bits.
-  // 0: the f64-atomic scatter kernels of rounds 1-3 (kept for A/B timing).
-  int deterministic = 1;
+  // Every sum of the step and of the adjoint has a fixed order -- element gradients, energies and the Hessian blocks of cloth AND tets go through staging
+  // records and gathers, contact lists are ordered, contact sums walk them in order: two runs give the same bits.  (The f64-atomic scatter kernels of
+  // rounds 1-3 and their "deterministic" = 0 switch left in round 6.)
   DevBuf<int> trans;                     // slot of a matrix block -> address of its transposed block
   DevBuf<int> vg_ptr, vg_idx;            // vertex -> staging slots of its incident faces / hinges / tets (k_vertex_gather)
   DevBuf<double> vg_stage, cg_trec;      // staged element gradients (3-vectors); per-tet 12 x 12 records (144)
   int vg_ns = 0, vg_hinge0 = 0, vg_tet0 = 0;
   DevBuf<double> vg_stage2;   // second staging array of the tet slots (tsl_param_grad: the two materials accumulate into different vectors)
-  DevBuf<double> dot_part; DevBuf<int> dot_ticket;   // scratch of the deterministic dot products
+  DevBuf<double> dot_part; DevBuf<int> dot_ticket;   // scratch of the dot products (per-workgroup partials joined in a fixed order)
   DevBuf<double> e_part;                 // per-workgroup partial energies
   int n_cgblk = 0, n_cgblk_cloth = 0;   // gather lists: blocks of the cloth first, blocks of the FEM bodies behind them
   DevBuf<double> tet_V;       // eigenvector bases of the clamped element blocks of the last assembly (81 x n_tet, entry-major): warm start of the next one
@@ -346,7 +345,7 @@ struct tsl_ctx {
   DevBuf<double> c_diag;                              // NV x 9 (permuted): masked contact contribution to the diagonal blocks
   DevBuf<double> c_G;                                 // max_nc x 12 scratch
   DevBuf<int> grid_key, grid_val, grid_key2, grid_val2, grid_range;  // per target body: cell id / face id (sorted), active range (6 ints)
-  DevBuf<int> vnf_ptr, vnf_lst;   // vertex -> incident surface triangles (deterministic vertex normals)
+  DevBuf<int> vnf_ptr, vnf_lst;   // vertex -> incident surface triangles (vertex normals summed in a fixed order)
   DevBuf<int> cq_flag, cq_scan;   // activity flag / constraint slot of every query vertex of every contact pair (fixed constraint order)
   DevBuf<int> grid_cnt, grid_ptr, grid_cur, scan_tmp;   // hash buckets of the broad phase (histogram, offsets, cursors) and the scratch of the scan
   int grid_buckets_max = 0;

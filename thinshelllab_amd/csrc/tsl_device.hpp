@@ -26,11 +26,6 @@ TSL_HD d3 normalized(const d3& a) { return a / norm(a); }
 
 TSL_DEV d3 ld3(const double* __restrict__ p, int i) { return d3(p[3 * (size_t)i], p[3 * (size_t)i + 1], p[3 * (size_t)i + 2]); }
 TSL_DEV void st3(double* p, int i, const d3& v) { p[3 * (size_t)i] = v.x; p[3 * (size_t)i + 1] = v.y; p[3 * (size_t)i + 2] = v.z; }
-TSL_DEV void atomic_add3(double* p, int i, const d3& v) {
-  atomicAdd(&p[3 * (size_t)i], v.x);
-  atomicAdd(&p[3 * (size_t)i + 1], v.y);
-  atomicAdd(&p[3 * (size_t)i + 2], v.z);
-}
 
 // row-major 3x3
 struct m3 {

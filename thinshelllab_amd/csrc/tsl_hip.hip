@@ -41,7 +41,7 @@ int tsl_fail(const char* fmt, ...) {
 #define TSL_NT false
 #endif
 // partial sums + tickets of the deterministic dot products (k_dot / k_multi_dot; allocated at context creation, ticket rows start at zero)
-#define DOT_SCRATCH(c) ((c)->deterministic ? (c)->dot_part.p : (double*)nullptr), ((c)->deterministic ? (c)->dot_ticket.p : (int*)nullptr)
+#define DOT_SCRATCH(c) (c)->dot_part.p, (c)->dot_ticket.p
 #define DOT_BLOCKS 120  // one f64 atomic per wave into a single address: more blocks only add contention (30 us at 600 blocks)
 static inline int nblk(long n, int b) { return (int)((n + b - 1) / b); }
 static inline int gsz(size_t n) { size_t b = (n + 255) / 256; return (int)std::min<size_t>(std::max<size_t>(b, 1), 4096); }
@@ -447,19 +447,14 @@ extern "C" int tsl_set_param(tsl_ctx* c, const char* key, double v) {
   else if (k == "verbose") c->verbose = (int)v;
   else if (k == "direct") { c->ds.enable = (int)v; c->ds.numeric_valid = false; c->ds.hard = false; }
   else if (k == "direct_berr") c->ds.berr_tol = v;
-  else if (k == "direct_berr_rel_cap") c->ds.berr_rel_cap = v;
   else if (k == "direct_small_rounds") { c->ds.small_rounds = std::max(1, (int)v); c->ds.plan_valid = false; c->ds.numeric_valid = false; c->ds.cache.clear(); }
-  else if (k == "direct_plan_cache") { c->ds.cache_cap = std::max(0, (int)v); c->ds.cache.clear(); }
   else if (k == "tet_warm") c->tet_warm = (int)v;
   else if (k == "ds_dbg") c->ds.dbg = (int)v;
   else if (k == "ds_bench_batch") c->ds.bench_batch = (int)v;
-  else if (k == "direct_prezero") c->ds.prezero = (int)v;
   else if (k == "direct_flow") c->ds.flow = std::max(0, (int)v);
   else if (k == "direct_flow_token") { if (v == 0) ds_flow_token_release(c->ds); }   // 0: hand the device's dataflow token back (asked for again at the next eligible factorisation)
-  else if (k == "deterministic") c->deterministic = (int)v != 0;
   else if (k == "direct_gemv_wide_below") c->ds.gemv_wide_below = std::max(0, (int)v);
   else if (k == "direct_g32_below") c->ds.g32_below = std::max(0, (int)v);
-  else if (k == "direct_xcd") c->ds.xcd_map = (int)v;
   else if (k == "direct_piv_tol") { c->ds.piv_tol = v; c->ds.numeric_valid = false; }
   else if (k == "direct_leaf") { c->ds.leaf = std::max(4, (int)v); c->ds.static_ready = false; c->ds.plan_valid = false; c->ds.numeric_valid = false; }
   else if (k == "gmres_m") c->gmres_m = (int)v;
@@ -525,7 +520,7 @@ extern "C" int tsl_set_gravity(tsl_ctx* c, const double* g) {
 
 // ------------------------------------------------------------------------------------------------
 __global__ void k_energy(VertArgs VA, ClothArgs CA, TetArgs TA, const double* __restrict__ pos, const double* __restrict__ prev,
-                         const double* __restrict__ vel, const double* __restrict__ ref_angle, double* e_out, double* __restrict__ e_part) {
+                         const double* __restrict__ vel, const double* __restrict__ ref_angle, double* __restrict__ e_part) {
   const int t = blockIdx.x * blockDim.x + threadIdx.x;
   double e = 0;
   if (t < VA.NV) e += vert_energy(VA, t, pos, prev, vel);
@@ -538,14 +533,11 @@ __global__ void k_energy(VertArgs VA, ClothArgs CA, TetArgs TA, const double* __
   if (t < CA.n_hinge) e += hinge_energy(CA, t, pos, ref_angle);
   if (t < TA.n_tet) e += tet_energy(TA, t, pos);
   e = wave_sum(e);
-  if (e_part) {   // deterministic: the four waves of the workgroup in order, one partial per workgroup; k_energy_final adds the partials in order
-    __shared__ double sw[4];
-    if ((threadIdx.x & 63) == 0) sw[threadIdx.x >> 6] = e;
-    __syncthreads();
-    if (threadIdx.x == 0) e_part[blockIdx.x] = ((sw[0] + sw[1]) + sw[2]) + sw[3];
-    return;
-  }
-  if ((threadIdx.x & 63) == 0) atomicAdd(e_out, e);
+  // the four waves of the workgroup in order, one partial per workgroup; k_energy_final adds the partials in order
+  __shared__ double sw[4];
+  if ((threadIdx.x & 63) == 0) sw[threadIdx.x >> 6] = e;
+  __syncthreads();
+  if (threadIdx.x == 0) e_part[blockIdx.x] = ((sw[0] + sw[1]) + sw[2]) + sw[3];
 }
 // sum of n partial energies in a fixed order (one workgroup: strided per-thread sums, then a fixed tree)
 __global__ void __launch_bounds__(256) k_energy_final(int n, const double* __restrict__ part, double* __restrict__ e_out) {
@@ -565,17 +557,12 @@ static int energy_async(tsl_ctx* c, const double* pos, const double* prev, const
   hipStream_t s = c->stream;
   if (c->n_cface) hipLaunchKernelGGL(k_cloth_normals, dim3(nblk(c->n_cface, 256)), dim3(256), 0, s, c->n_cface, pos, c->cf_f2v.p, c->norm_dir.p);
   const int nmax = std::max(std::max(c->NV, c->n_cface), std::max(c->n_hinge, c->n_tet));
-  if (c->deterministic) {   // partials per workgroup, added in a fixed order (the line search decides on E < E0)
-    const int nb1 = nblk(nmax, 256), nb2 = c->nc > 0 ? nblk(c->nc, 64) : 0;
-    if (c->e_part.n < (size_t)nb1 + (size_t)nblk(c->max_n_constraints, 64)) { if (c->e_part.alloc((size_t)nb1 + (size_t)nblk(c->max_n_constraints, 64))) return -1; }
-    hipLaunchKernelGGL(k_energy, dim3(nb1), dim3(256), 0, s, vert_args(c), cloth_args(c), tet_args(c), pos, prev, vel, ref, (double*)nullptr, c->e_part.p);
-    if (nb2 > 0) hipLaunchKernelGGL(k_contact_energy, dim3(nb2), dim3(64), 0, s, c->nc, contact_args(c), pos, (double*)nullptr, c->e_part.p + nb1);
-    hipLaunchKernelGGL(k_energy_final, dim3(1), dim3(256), 0, s, nb1 + nb2, (const double*)c->e_part.p, &SC(c)->energy);
-    return 0;
-  }
-  HIP_OK(hipMemsetAsync(&SC(c)->energy, 0, sizeof(double), s));
-  hipLaunchKernelGGL(k_energy, dim3(nblk(nmax, 256)), dim3(256), 0, s, vert_args(c), cloth_args(c), tet_args(c), pos, prev, vel, ref, &SC(c)->energy, (double*)nullptr);
-  if (c->nc > 0) hipLaunchKernelGGL(k_contact_energy, dim3(nblk(c->nc, 64)), dim3(64), 0, s, c->nc, contact_args(c), pos, &SC(c)->energy, (double*)nullptr);
+  // partials per workgroup, added in a fixed order (the line search decides on E < E0)
+  const int nb1 = nblk(nmax, 256), nb2 = c->nc > 0 ? nblk(c->nc, 64) : 0;
+  if (c->e_part.n < (size_t)nb1 + (size_t)nblk(c->max_n_constraints, 64)) { if (c->e_part.alloc((size_t)nb1 + (size_t)nblk(c->max_n_constraints, 64))) return -1; }
+  hipLaunchKernelGGL(k_energy, dim3(nb1), dim3(256), 0, s, vert_args(c), cloth_args(c), tet_args(c), pos, prev, vel, ref, c->e_part.p);
+  if (nb2 > 0) hipLaunchKernelGGL(k_contact_energy, dim3(nb2), dim3(64), 0, s, c->nc, contact_args(c), pos, c->e_part.p + nb1);
+  hipLaunchKernelGGL(k_energy_final, dim3(1), dim3(256), 0, s, nb1 + nb2, (const double*)c->e_part.p, &SC(c)->energy);
   return 0;
 }
 static int energy_sync(tsl_ctx* c, const double* pos, const double* prev, const double* vel, const double* ref, double* E) {
@@ -624,74 +611,36 @@ static int assemble_enqueue_early(tsl_ctx* c, const double* pos, const double* p
 static int assemble_enqueue(tsl_ctx* c, const double* pos, const double* prev, const double* vel, const double* ref, int spd, double* grad, int tet_warm_flag) {
   hipStream_t s = c->stream;
   const int NV = c->NV;
-  const bool det = c->deterministic != 0;
-  const bool fork = c->nc > 0 || c->n_tet > 0;
-  if (det && fork) return assemble_enqueue_early(c, pos, prev, vel, ref, spd, grad, tet_warm_flag);
+  if (c->nc > 0 || c->n_tet > 0) return assemble_enqueue_early(c, pos, prev, vel, ref, spd, grad, tet_warm_flag);
+  // a bare cloth: one stream
   HIP_OK(hipMemsetAsync(c->vals_full.p, 0, c->vals_full.n * sizeof(double), s));
   if (c->n_cface) hipLaunchKernelGGL(k_cloth_normals, dim3(nblk(c->n_cface, 256)), dim3(256), 0, s, c->n_cface, pos, c->cf_f2v.p, c->norm_dir.p);
   ClothArgs CA = cloth_args(c);
   const VertArgs VA = vert_args(c);
-  TetArgs TA = tet_args(c);
-  if (det) {   // element gradients into staging slots, element blocks into records: summed by k_vertex_gather / k_cloth_gather in a fixed order
-    CA.gstage = c->vg_stage.p; TA.gstage = c->vg_stage.p + 3 * (size_t)c->vg_tet0;
-  }
-  if (grad) HIP_OK(hipMemsetAsync(grad, 0, 3 * (size_t)NV * sizeof(double), s));
-  // contact: gradient into grad (atomics), per-constraint 12x12 into c_Hfull, masked copy + diagonal into c_H / cdiag.  The contact
-  // launches (0.15 + 0.11 ms at 200 constraints) and the tet kernels (0.23 ms) go to a second stream next to the cloth kernels
-  // (face 0.15 ms + hinge 0.28 ms): they share nothing but the zeroed gradient / matrix, which both sides only add to.
-  if (grad) hipLaunchKernelGGL(k_vert_grad, dim3(nblk(NV, 256)), dim3(256), 0, s, VA, pos, prev, vel, grad);   // before the fork: it may store, the others add
-  hipLaunchKernelGGL(k_vert_hess, dim3(nblk(NV, 256)), dim3(256), 0, s, VA, c->diag_blk.p, c->vals_full.p);      // (the mass diagonal: the first contribution to its blocks)
-  hipStream_t st = fork ? c->side : s;   // stream of the contact kernels
-  const bool fork_t = fork && c->n_tet > 0 && c->nc > 0;   // the element kernels of the FEM bodies on a stream of their own (0.4 ms: one lane per element, latency-bound)
-  hipStream_t stt = fork_t ? c->side2 : st;
-  if (fork) {
-    HIP_OK(hipEventRecord(c->ev_fork, s));
-    HIP_OK(hipStreamWaitEvent(c->side, c->ev_fork, 0));
-    if (fork_t) HIP_OK(hipStreamWaitEvent(c->side2, c->ev_fork, 0));
-  }
-  if (c->n_tet) {
-    if (grad) hipLaunchKernelGGL(k_tet_grad, dim3(nblk(c->n_tet, 256)), dim3(256), 0, stt, TA, pos, grad);
-    {
-      // eigen-clamp of the element blocks warm-started from the previous assembly's eigenvectors ("tet_warm", on by default);
-      // every 16th clamped assembly starts from the identity again (orthogonality of the accumulated rotations)
-      double* vws = (c->tet_warm && spd != 0) ? c->tet_V.p : (double*)nullptr;   // (allocated and counted by assemble())
-      const int warm = vws ? tet_warm_flag : 0;
-      if (det) hipLaunchKernelGGL(k_tet_hess_coop, dim3(nblk(c->n_tet, 16)), dim3(256), 0, stt, TA, pos, spd, vws, warm, c->cg_trec.p);
-      else hipLaunchKernelGGL(k_tet_hess, dim3(nblk(c->n_tet, 64)), dim3(64), 0, stt, TA, c->tet_blk.p, pos, spd, c->vals_full.p, vws, warm, (double*)nullptr);
-      const int nt_blk = c->n_cgblk - c->n_cgblk_cloth;
-      if (det && nt_blk > 0)
-        hipLaunchKernelGGL(k_cloth_gather, dim3(nblk(nt_blk, CG_BPW)), dim3(256), 0, stt, nt_blk, c->cg_base.p + c->n_cgblk_cloth, c->cg_ptr.p + c->n_cgblk_cloth, (const unsigned*)c->cg_ent.p,
-                           c->n_hinge, c->n_cface, (const double*)c->cg_hrec.p, (const double*)c->cg_frec.p, (const double*)c->cg_trec.p, c->vals_full.p);
-    }
-  }
-  TSL_TRY(contact_assemble(c, pos, spd, grad, st));
-  hipStream_t sg = det ? stt : (fork ? st : s);
+  CA.gstage = c->vg_stage.p;   // element gradients into staging slots, element blocks into records: summed by k_vertex_gather / k_cloth_gather in a fixed order
   if (grad) {
-    if (c->n_cface) hipLaunchKernelGGL(k_cloth_grad_face, dim3(nblk(c->n_cface, 256)), dim3(256), 0, sg, CA, pos, grad);
-    if (c->n_hinge) hipLaunchKernelGGL(k_cloth_grad_hinge, dim3(nblk(c->n_hinge, 256)), dim3(256), 0, sg, CA, pos, ref, grad);
+    HIP_OK(hipMemsetAsync(grad, 0, 3 * (size_t)NV * sizeof(double), s));
+    hipLaunchKernelGGL(k_vert_grad, dim3(nblk(NV, 256)), dim3(256), 0, s, VA, pos, prev, vel, grad);
   }
-  if (fork) HIP_OK(hipEventRecord(c->ev_join, c->side));
-  if (fork_t) HIP_OK(hipEventRecord(c->ev_join2, c->side2));
-  const bool gather = det && c->n_cgblk > 0;
+  hipLaunchKernelGGL(k_vert_hess, dim3(nblk(NV, 256)), dim3(256), 0, s, VA, c->diag_blk.p, c->vals_full.p);      // (the mass diagonal: the first contribution to its blocks)
+  if (grad) {
+    if (c->n_cface) hipLaunchKernelGGL(k_cloth_grad_face, dim3(nblk(c->n_cface, 256)), dim3(256), 0, s, CA, pos);
+    if (c->n_hinge) hipLaunchKernelGGL(k_cloth_grad_hinge, dim3(nblk(c->n_hinge, 256)), dim3(256), 0, s, CA, pos, ref);
+  }
   if (c->n_cface) {
     const int nq = (int)c->h_cloth.size() * 9;
     hipLaunchKernelGGL(k_cloth_quirk, dim3(nblk(nq, 64)), dim3(64), 0, s, CA, (int)c->h_cloth.size(), pos, ref, c->quirk.p);
-    double* frec = gather ? c->cg_frec.p : (double*)nullptr;
-    if (spd == 2) hipLaunchKernelGGL((k_cloth_hess_face<true>), dim3(nblk(c->n_cface, 128)), dim3(128), 0, s, CA, c->cf_blk.p, pos, ref, c->quirk.p, spd, c->vals_full.p, frec);
-    else hipLaunchKernelGGL((k_cloth_hess_face<false>), dim3(nblk(c->n_cface, 128)), dim3(128), 0, s, CA, c->cf_blk.p, pos, ref, c->quirk.p, spd, c->vals_full.p, frec);
+    if (spd == 2) hipLaunchKernelGGL((k_cloth_hess_face<true>), dim3(nblk(c->n_cface, 128)), dim3(128), 0, s, CA, pos, ref, c->quirk.p, spd, c->cg_frec.p);
+    else hipLaunchKernelGGL((k_cloth_hess_face<false>), dim3(nblk(c->n_cface, 128)), dim3(128), 0, s, CA, pos, ref, c->quirk.p, spd, c->cg_frec.p);
   }
-  if (c->n_hinge) hipLaunchKernelGGL(k_cloth_hess_hinge, dim3(nblk(c->n_hinge, 256)), dim3(256), 0, s, CA, c->hg_blk.p, pos, c->vals_full.p, gather ? c->cg_hrec.p : (double*)nullptr);
-  if (gather && c->n_cgblk_cloth > 0)
+  if (c->n_hinge) hipLaunchKernelGGL(k_cloth_hess_hinge, dim3(nblk(c->n_hinge, 256)), dim3(256), 0, s, CA, pos, c->cg_hrec.p);
+  if (c->n_cgblk_cloth > 0)
     hipLaunchKernelGGL(k_cloth_gather, dim3(nblk(c->n_cgblk_cloth, CG_BPW)), dim3(256), 0, s, c->n_cgblk_cloth, c->cg_base.p, c->cg_ptr.p, (const unsigned*)c->cg_ent.p, c->n_hinge, c->n_cface,
                        (const double*)c->cg_hrec.p, (const double*)c->cg_frec.p, (const double*)c->cg_trec.p, c->vals_full.p);
-  if (fork) HIP_OK(hipStreamWaitEvent(s, c->ev_join, 0));
-  if (fork_t) HIP_OK(hipStreamWaitEvent(s, c->ev_join2, 0));
-  if (det && grad) {
+  if (grad) {
     hipLaunchKernelGGL(k_vertex_gather, dim3(nblk(NV, 256)), dim3(256), 0, s, NV, (const int*)c->vg_ptr.p, (const int*)c->vg_idx.p, (const double*)c->vg_stage.p, 0, c->vg_ns, grad);
-    if (c->nc > 0) hipLaunchKernelGGL(k_contact_row_gather, dim3(nblk((long)NV * 64, 256)), dim3(256), 0, s, NV, (const int*)c->rowpos.p, (const int*)c->cr_ptr.p, (const int*)c->cr_ent.p,
-                                      (const double*)c->c_G.p, grad);
+    hipLaunchKernelGGL(k_mask_vec, dim3(gsz(3 * (size_t)NV)), dim3(256), 0, s, 3 * (size_t)NV, c->frozen.p, grad);
   }
-  if (grad) hipLaunchKernelGGL(k_mask_vec, dim3(gsz(3 * (size_t)NV)), dim3(256), 0, s, 3 * (size_t)NV, c->frozen.p, grad);
   hipLaunchKernelGGL(k_mask_matrix, dim3(c->n_slices), dim3(256), 0, s, c->n_slices, c->slice_off.p, c->slice_len.p, c->colidx.p, c->fzmask.p, c->mdt2.p,
                      c->vals_full.p, c->vals.p, NV);
   if (!c->pc_frozen) {
@@ -733,11 +682,11 @@ static int assemble_enqueue_early(tsl_ctx* c, const double* pos, const double* p
   const bool hh_side = fork_t && gather;
   // element stream: the hinge blocks first (records: they read positions only), so that the cloth gather on the engine stream can start when the face blocks end
   if (hh_side && c->n_hinge) {
-    hipLaunchKernelGGL(k_cloth_hess_hinge, dim3(nblk(c->n_hinge, 256)), dim3(256), 0, stt, CA, c->hg_blk.p, pos, c->vals_full.p, c->cg_hrec.p);
+    hipLaunchKernelGGL(k_cloth_hess_hinge, dim3(nblk(c->n_hinge, 256)), dim3(256), 0, stt, CA, pos, c->cg_hrec.p);
     HIP_OK(hipEventRecord(c->ev_hh, stt));
   }
   if (c->n_tet) {
-    if (grad) { hipLaunchKernelGGL(k_tet_grad, dim3(nblk(c->n_tet, 256)), dim3(256), 0, stt, TA, pos, grad); HIP_OK(hipEventRecord(c->ev_g2, stt)); }   // tet gradients staged
+    if (grad) { hipLaunchKernelGGL(k_tet_grad, dim3(nblk(c->n_tet, 256)), dim3(256), 0, stt, TA, pos); HIP_OK(hipEventRecord(c->ev_g2, stt)); }   // tet gradients staged
     // eigen-clamp of the element blocks warm-started from the previous assembly's eigenvectors ("tet_warm", on by default);
     // every 16th clamped assembly starts from the identity again (orthogonality of the accumulated rotations)
     double* vws = (c->tet_warm && spd != 0) ? c->tet_V.p : (double*)nullptr;   // (allocated and counted by assemble())
@@ -754,16 +703,15 @@ static int assemble_enqueue_early(tsl_ctx* c, const double* pos, const double* p
   if (c->n_cface) {
     const int nq = (int)c->h_cloth.size() * 9;
     hipLaunchKernelGGL(k_cloth_quirk, dim3(nblk(nq, 64)), dim3(64), 0, s, CA, (int)c->h_cloth.size(), pos, ref, c->quirk.p);
-    double* frec = gather ? c->cg_frec.p : (double*)nullptr;
-    if (spd == 2) hipLaunchKernelGGL((k_cloth_hess_face<true>), dim3(nblk(c->n_cface, 128)), dim3(128), 0, s, CA, c->cf_blk.p, pos, ref, c->quirk.p, spd, c->vals_full.p, frec);
-    else hipLaunchKernelGGL((k_cloth_hess_face<false>), dim3(nblk(c->n_cface, 128)), dim3(128), 0, s, CA, c->cf_blk.p, pos, ref, c->quirk.p, spd, c->vals_full.p, frec);
+    if (spd == 2) hipLaunchKernelGGL((k_cloth_hess_face<true>), dim3(nblk(c->n_cface, 128)), dim3(128), 0, s, CA, pos, ref, c->quirk.p, spd, c->cg_frec.p);
+    else hipLaunchKernelGGL((k_cloth_hess_face<false>), dim3(nblk(c->n_cface, 128)), dim3(128), 0, s, CA, pos, ref, c->quirk.p, spd, c->cg_frec.p);
   }
   // element stream, second part (behind the normals and the mass diagonal).  Round 6: the element blocks of the bodies take 55 us since they are formed by 16 lanes
   // per element (k_tet_hess_coop; 170 before), so the hinge blocks (records, 45-60 us) run HERE, next to the face blocks on the engine stream, and the face
   // gradients behind the body blocks: the engine stream's chain is face blocks -> cloth gather -> mask, the contact stream's contact blocks -> hinge gradients ->
   // gradient tail.  (Round 5 had moved them the other way, when this stream was busy with the bodies for 170 us.)
   HIP_OK(hipStreamWaitEvent(stt, c->ev_fork, 0));
-  if (c->n_hinge && !hh_side) hipLaunchKernelGGL(k_cloth_hess_hinge, dim3(nblk(c->n_hinge, 256)), dim3(256), 0, s, CA, c->hg_blk.p, pos, c->vals_full.p, gather ? c->cg_hrec.p : (double*)nullptr);
+  if (c->n_hinge && !hh_side) hipLaunchKernelGGL(k_cloth_hess_hinge, dim3(nblk(c->n_hinge, 256)), dim3(256), 0, s, CA, pos, c->cg_hrec.p);
   const int nt_blk = c->n_cgblk - c->n_cgblk_cloth;
   if (c->n_tet && nt_blk > 0)   // the element records of the bodies -> their matrix blocks (the blocks of the bodies and of the cloth are disjoint)
     hipLaunchKernelGGL(k_cloth_gather, dim3(nblk(nt_blk, CG_BPW)), dim3(256), 0, stt, nt_blk, c->cg_base.p + c->n_cgblk_cloth, c->cg_ptr.p + c->n_cgblk_cloth, (const unsigned*)c->cg_ent.p,
@@ -772,9 +720,9 @@ static int assemble_enqueue_early(tsl_ctx* c, const double* pos, const double* p
   // contact stream, second part: hinge gradients (staging slots); the face gradients behind the body blocks on the element stream
   if (grad) {
     if (fork_t) HIP_OK(hipStreamWaitEvent(st, c->ev_fork, 0));
-    if (c->n_hinge) hipLaunchKernelGGL(k_cloth_grad_hinge, dim3(nblk(c->n_hinge, 256)), dim3(256), 0, st, CA, pos, ref, grad);
+    if (c->n_hinge) hipLaunchKernelGGL(k_cloth_grad_hinge, dim3(nblk(c->n_hinge, 256)), dim3(256), 0, st, CA, pos, ref);
     if (c->n_cface) {
-      hipLaunchKernelGGL(k_cloth_grad_face, dim3(nblk(c->n_cface, 256)), dim3(256), 0, hh_side ? stt : st, CA, pos, grad);
+      hipLaunchKernelGGL(k_cloth_grad_face, dim3(nblk(c->n_cface, 256)), dim3(256), 0, hh_side ? stt : st, CA, pos);
       if (hh_side) HIP_OK(hipEventRecord(c->ev_gf, stt));
     }
   }
@@ -814,14 +762,11 @@ static int assemble_enqueue_early(tsl_ctx* c, const double* pos, const double* p
 // than the launches: 269.2 against 263.4 ms per step on the driver's command.
 static int assemble(tsl_ctx* c, const double* pos, const double* prev, const double* vel, const double* ref, int spd, double* grad) {
   hipStream_t s = c->stream;
-  const bool det = c->deterministic != 0;
-  // ---- allocations the launches rely on
-  if (det) {
-    if (c->vg_stage.n < 3 * (size_t)std::max(c->vg_ns, 1)) { if (c->vg_stage.alloc(3 * (size_t)std::max(c->vg_ns, 1))) return tsl_fail("out of device memory (gradient staging)"); }
-    if (c->n_tet > 0 && c->cg_trec.n < 144 * (size_t)c->n_tet) { if (c->cg_trec.alloc(144 * (size_t)c->n_tet)) return tsl_fail("out of device memory (element records)"); }
-    if (grad && c->nc > 0 && c->c_G.n < 12 * (size_t)c->max_n_constraints) { if (c->c_G.alloc(12 * (size_t)c->max_n_constraints)) return -1; }
-  }
-  if (det && c->n_cgblk > 0 && c->n_cface > 0 && c->cg_frec.n == 0) {
+  // ---- allocations the launches rely on (staging slots of the gradient, element records of the matrix)
+  if (c->vg_stage.n < 3 * (size_t)std::max(c->vg_ns, 1)) { if (c->vg_stage.alloc(3 * (size_t)std::max(c->vg_ns, 1))) return tsl_fail("out of device memory (gradient staging)"); }
+  if (c->n_tet > 0 && c->cg_trec.n < 144 * (size_t)c->n_tet) { if (c->cg_trec.alloc(144 * (size_t)c->n_tet)) return tsl_fail("out of device memory (element records)"); }
+  if (grad && c->nc > 0 && c->c_G.n < 12 * (size_t)c->max_n_constraints) { if (c->c_G.alloc(12 * (size_t)c->max_n_constraints)) return -1; }
+  if (c->n_cgblk > 0 && c->n_cface > 0 && c->cg_frec.n == 0) {
     if (c->cg_hrec.alloc((size_t)std::max(c->n_hinge, 1) * 16) | c->cg_frec.alloc((size_t)c->n_cface * 81)) return tsl_fail("out of device memory (cloth element records)");
   }
   int warm = 0;
@@ -902,7 +847,7 @@ static bool direct_takes_solve(tsl_ctx* c) {
   return direct_enabled(c) && !c->ds_suspended && !(d.enable < 0 && !d.hard && c->n_tet == 0 && c->nc == 0);
 }
 static int block_jacobi_refresh(tsl_ctx* c) {
-  if (c->nc > 0 && c->deterministic && !c->cdiag_valid) contact_diag_refresh(c, c->stream);   // (skipped by an assembly that expected the factorisation to take the solve)
+  if (c->nc > 0 && !c->cdiag_valid) contact_diag_refresh(c, c->stream);   // (skipped by an assembly that expected the factorisation to take the solve)
   hipLaunchKernelGGL(k_block_jacobi, dim3(nblk(c->NV, 256)), dim3(256), 0, c->stream, c->NV, c->diag_perm.p, c->vals.p, c->nc > 0 ? c->c_diag.p : (const double*)nullptr, c->Dinv.p);
   if (body_active(c) && c->bd_valid) body_zero_dinv(c);  // those rows are served by the (lagged) dense inverse
   c->dinv_valid = true;
@@ -2101,11 +2046,11 @@ extern "C" int tsl_elastic_force(tsl_ctx* c, const double* pos, double* force) {
   HIP_OK(hipMemsetAsync(force, 0, n3 * sizeof(double), s));
   if (c->n_tet) {
     TetArgs TA = tet_args(c);
-    const bool det = c->deterministic != 0;   // element gradients staged and summed per vertex in a fixed order (as in the assembly)
-    if (det && c->vg_stage.n < 3 * (size_t)std::max(c->vg_ns, 1)) { if (c->vg_stage.alloc(3 * (size_t)std::max(c->vg_ns, 1))) return tsl_fail("out of device memory (gradient staging)"); }
-    if (det) TA.gstage = c->vg_stage.p + 3 * (size_t)c->vg_tet0;
-    hipLaunchKernelGGL(k_tet_grad, dim3(nblk(c->n_tet, 256)), dim3(256), 0, s, TA, pos, force);
-    if (det) hipLaunchKernelGGL(k_vertex_gather, dim3(nblk(c->NV, 256)), dim3(256), 0, s, c->NV, (const int*)c->vg_ptr.p, (const int*)c->vg_idx.p, (const double*)c->vg_stage.p, c->vg_tet0, c->vg_ns, force);
+    // element gradients staged and summed per vertex in a fixed order (as in the assembly)
+    if (c->vg_stage.n < 3 * (size_t)std::max(c->vg_ns, 1)) { if (c->vg_stage.alloc(3 * (size_t)std::max(c->vg_ns, 1))) return tsl_fail("out of device memory (gradient staging)"); }
+    TA.gstage = c->vg_stage.p + 3 * (size_t)c->vg_tet0;
+    hipLaunchKernelGGL(k_tet_grad, dim3(nblk(c->n_tet, 256)), dim3(256), 0, s, TA, pos);
+    hipLaunchKernelGGL(k_vertex_gather, dim3(nblk(c->NV, 256)), dim3(256), 0, s, c->NV, (const int*)c->vg_ptr.p, (const int*)c->vg_idx.p, (const double*)c->vg_stage.p, c->vg_tet0, c->vg_ns, force);
     for (const ElasticDev& e : c->h_el)
       hipLaunchKernelGGL(k_elastic_force_finish, dim3(nblk(e.n_verts, 256)), dim3(256), 0, s, vert_args(c), e.v_offset, e.v_offset + e.n_verts, force);
   }
@@ -2125,7 +2070,7 @@ extern "C" int tsl_friction_grad(tsl_ctx* c, const double* pos, double* out_host
   HIP_OK(hipMemsetAsync(acc, 0, sizeof(double), s));
   if (c->nc > 0)
     hipLaunchKernelGGL(k_contact_friction_grad, dim3(nblk(c->nc, 64)), dim3(64), 0, s, c->nc, contact_args(c), c->c_kind.p, c->frozen.p, pos, c->pdir.p, c->mu_cloth_cloth, acc,
-                       (c->deterministic && nblk(c->nc, 64) <= 64 * 512) ? c->dot_part.p : (double*)nullptr, c->deterministic ? c->dot_ticket.p : (int*)nullptr);
+                       nblk(c->nc, 64) <= 64 * 512 ? c->dot_part.p : (double*)nullptr, c->dot_ticket.p);
   HIP_OK(hipMemcpyAsync(out_host, acc, sizeof(double), hipMemcpyDeviceToHost, s));
   HIP_OK(hipStreamSynchronize(s));
   return 0;
@@ -2144,18 +2089,17 @@ extern "C" int tsl_param_grad(tsl_ctx* c, const double* pos, const double* ref, 
   double* tmp = c->v_t4.p;
   double* acc = &SC(c)->aux[0];
   HIP_OK(hipMemsetAsync(acc, 0, 2 * sizeof(double), s));
-  // deterministic (default): hinge / tet contributions staged per element and summed per vertex in a fixed order, the dot products joined
-  // from per-block partials -- two runs of a system-identification sweep give the same bits
-  const bool det = c->deterministic != 0;
-  if (det && c->vg_stage.n < 3 * (size_t)std::max(c->vg_ns, 1)) { if (c->vg_stage.alloc(3 * (size_t)std::max(c->vg_ns, 1))) return tsl_fail("out of device memory (gradient staging)"); }
+  // hinge / tet contributions staged per element and summed per vertex in a fixed order, the dot products joined from per-block partials -- two runs of a
+  // system-identification sweep give the same bits
+  if (c->vg_stage.n < 3 * (size_t)std::max(c->vg_ns, 1)) { if (c->vg_stage.alloc(3 * (size_t)std::max(c->vg_ns, 1))) return tsl_fail("out of device memory (gradient staging)"); }
   // d_kb = -(bending gradient) / Kb per cloth
   if (c->n_hinge) {
     HIP_OK(hipMemsetAsync(tmp, 0, n3 * sizeof(double), s));
     hipLaunchKernelGGL(k_cloth_normals, dim3(nblk(c->n_cface, 256)), dim3(256), 0, s, c->n_cface, pos, c->cf_f2v.p, c->norm_dir.p);
     ClothArgs CA = cloth_args(c);
-    if (det) CA.gstage = c->vg_stage.p;
-    hipLaunchKernelGGL(k_cloth_grad_hinge, dim3(nblk(c->n_hinge, 256)), dim3(256), 0, s, CA, pos, ref, tmp);
-    if (det) hipLaunchKernelGGL(k_vertex_gather, dim3(nblk(NV, 256)), dim3(256), 0, s, NV, (const int*)c->vg_ptr.p, (const int*)c->vg_idx.p, (const double*)c->vg_stage.p, c->vg_hinge0, c->vg_tet0, tmp);
+    CA.gstage = c->vg_stage.p;
+    hipLaunchKernelGGL(k_cloth_grad_hinge, dim3(nblk(c->n_hinge, 256)), dim3(256), 0, s, CA, pos, ref);
+    hipLaunchKernelGGL(k_vertex_gather, dim3(nblk(NV, 256)), dim3(256), 0, s, NV, (const int*)c->vg_ptr.p, (const int*)c->vg_idx.p, (const double*)c->vg_stage.p, c->vg_hinge0, c->vg_tet0, tmp);
     for (const ClothDev& cd : c->h_cloth)
       hipLaunchKernelGGL(k_dot_free, dim3(DOT_BLOCKS), dim3(256), 0, s, 3 * (size_t)cd.v_offset, 3 * (size_t)(cd.v_offset + cd.NV), c->pdir.p, tmp, c->frozen.p, -1.0 / cd.Kb, acc, DOT_SCRATCH(c));
   }
@@ -2163,13 +2107,10 @@ extern "C" int tsl_param_grad(tsl_ctx* c, const double* pos, const double* ref, 
   if (c->n_tet) {
     if (c->dmu_accum.n == 0) { TSL_TRY(c->dmu_accum.alloc(n3)); HIP_OK(hipMemsetAsync(c->dmu_accum.p, 0, n3 * sizeof(double), s)); }
     HIP_OK(hipMemsetAsync(tmp, 0, n3 * sizeof(double), s));
-    double *stA = nullptr, *stB = nullptr;
-    if (det) {
-      if (c->vg_stage2.n < 12 * (size_t)c->n_tet) { if (c->vg_stage2.alloc(12 * (size_t)c->n_tet)) return tsl_fail("out of device memory (gradient staging)"); }
-      stA = c->vg_stage.p + 3 * (size_t)c->vg_tet0; stB = c->vg_stage2.p;
-    }
-    hipLaunchKernelGGL(k_tet_deri_mu, dim3(nblk(c->n_tet, 64)), dim3(64), 0, s, tet_args(c), pos, tmp, c->dmu_accum.p, stA, stB);
-    if (det) {   // (the second gather reads the same slot numbers from a staging array that holds the tet slots only)
+    if (c->vg_stage2.n < 12 * (size_t)c->n_tet) { if (c->vg_stage2.alloc(12 * (size_t)c->n_tet)) return tsl_fail("out of device memory (gradient staging)"); }
+    double *stA = c->vg_stage.p + 3 * (size_t)c->vg_tet0, *stB = c->vg_stage2.p;
+    hipLaunchKernelGGL(k_tet_deri_mu, dim3(nblk(c->n_tet, 64)), dim3(64), 0, s, tet_args(c), pos, stA, stB);
+    {   // (the second gather reads the same slot numbers from a staging array that holds the tet slots only)
       hipLaunchKernelGGL(k_vertex_gather, dim3(nblk(NV, 256)), dim3(256), 0, s, NV, (const int*)c->vg_ptr.p, (const int*)c->vg_idx.p, (const double*)c->vg_stage.p, c->vg_tet0, c->vg_ns, tmp);
       hipLaunchKernelGGL(k_vertex_gather, dim3(nblk(NV, 256)), dim3(256), 0, s, NV, (const int*)c->vg_ptr.p, (const int*)c->vg_idx.p, (const double*)c->vg_stage2.p - 3 * (size_t)c->vg_tet0, c->vg_tet0, c->vg_ns,
                          c->dmu_accum.p);
@@ -2354,9 +2295,8 @@ static int group_solve(tsl_group* G, const std::vector<int>& act, std::vector<ts
     const DirectSolver& d0 = G->m[0]->ds;
     for (int i = 1; i < n; i++) {
       const DirectSolver& di = G->m[i]->ds;
-      if (di.piv_tol != d0.piv_tol || di.flow != d0.flow || di.g32_below != d0.g32_below || di.gemv_wide_below != d0.gemv_wide_below || di.small_rounds != d0.small_rounds ||
-          di.xcd_map != d0.xcd_map || di.prezero != d0.prezero)
-        return tsl_fail("scene group: members 0 and %d differ in a parameter of the factorisation (direct_piv_tol / _flow / _g32_below / _gemv_wide_below / _small_rounds / _xcd / _prezero)", i);
+      if (di.piv_tol != d0.piv_tol || di.flow != d0.flow || di.g32_below != d0.g32_below || di.gemv_wide_below != d0.gemv_wide_below || di.small_rounds != d0.small_rounds)
+        return tsl_fail("scene group: members 0 and %d differ in a parameter of the factorisation (direct_piv_tol / _flow / _g32_below / _gemv_wide_below / _small_rounds)", i);
     }
     if (gd.piv_tol != d0.piv_tol) gd.piv_tol = d0.piv_tol;
     gd.flow = G->flow_lost ? 0 : d0.flow; gd.g32_below = d0.g32_below; gd.gemv_wide_below = d0.gemv_wide_below; gd.small_rounds = d0.small_rounds * n; gd.xcd_map = d0.xcd_map;
@@ -2791,8 +2731,7 @@ __global__ void k_clamp(size_t n, double* __restrict__ v, double lim) {
 
 // Cloth.ref_angle_backprop_a2ax (model_fold_offset.py:1179-1206), one lane per hinge.
 // ag_s / ag_prev: angleref_grad[s], angleref_grad[s-1]; pg_s: pos_grad[s]; ref = ref_angle_{s-1}; pos = x_s
-__global__ void __launch_bounds__(256) k_adj_a2ax(ClothArgs A, const double* __restrict__ pos, const double* __restrict__ ref, const double* __restrict__ ag_s, double* __restrict__ ag_prev,
-                           double* __restrict__ pg_s) {
+__global__ void __launch_bounds__(256) k_adj_a2ax(ClothArgs A, const double* __restrict__ pos, const double* __restrict__ ref, const double* __restrict__ ag_s, double* __restrict__ ag_prev) {
   const int h = blockIdx.x * blockDim.x + threadIdx.x;
   if (h >= A.n_hinge) return;
   const int f1 = A.hg_info[8 * h], l = A.hg_info[8 * h + 1], f2 = A.hg_info[8 * h + 2], p4 = A.hg_info[8 * h + 3], p21 = A.hg_info[8 * h + 4];
@@ -2807,15 +2746,8 @@ __global__ void __launch_bounds__(256) k_adj_a2ax(ClothArgs A, const double* __r
   const double a = ag_s[3 * f1 + l];
   ag_prev[3 * f1 + l] += a;
   const double sgn = (fabs(theta - ref[3 * f1 + l]) > c.k_angle) ? a : a * 0.1;
-  if (A.gstage) {   // deterministic: staged, summed per vertex by k_vertex_gather
 #pragma unroll
-    for (int j = 0; j < 4; j++) st3(A.gstage, A.gs_hinge + 4 * h + j, sgn * g[j]);
-    return;
-  }
-  atomic_add3(pg_s, pick3(v1, l), sgn * g[0]);
-  atomic_add3(pg_s, pick3(v1, (l + 1) % 3), sgn * g[1]);
-  atomic_add3(pg_s, pick3(v1, (l + 2) % 3), sgn * g[2]);
-  atomic_add3(pg_s, pick3(v2, p4), sgn * g[3]);
+  for (int j = 0; j < 4; j++) st3(A.gstage, A.gs_hinge + 4 * h + j, sgn * g[j]);   // staged, summed per vertex by k_vertex_gather
 }
 
 // Cloth.ref_angle_backprop_x2a (model_fold_offset.py:1154-1168): angleref_grad[s-1] += -z . (d_ref * grad theta)
@@ -2835,32 +2767,6 @@ __global__ void __launch_bounds__(256) k_adj_x2a(ClothArgs A, const double* __re
   ag_prev[3 * f1 + l] += -s * d_ref;
 }
 
-// tmp_z_frozen[j] -= H_ij z_i for every stored entry with i free, j frozen (BaseScene.add_H second pass, BaseScene.py:403-405).
-// vals = UNMASKED matrix; zp = z in permuted order; out in permuted order.
-__global__ void k_zfrozen_matrix(int NV, int n_slices, const int* __restrict__ slice_off, const int* __restrict__ slice_len, const int* __restrict__ colidx,
-                                 const unsigned char* __restrict__ fz, const double* __restrict__ vals, const double* __restrict__ zp, double* __restrict__ out) {
-  const int slice = blockIdx.x, lane = threadIdx.x & 63;
-  if (slice >= n_slices) return;
-  const int p = slice * 64 + lane;
-  if (p >= NV) return;
-  const unsigned rm = fz[p];
-  if (rm == 7u) return;
-  const d3 zi = ld3(zp, p);
-  const double zr[3] = {zi.x, zi.y, zi.z};
-  const int off = slice_off[slice], len = slice_len[slice];
-  for (int k = threadIdx.x >> 6; k < len; k += (blockDim.x >> 6)) {
-    const int c = colidx[off + 64 * k + lane];
-    const unsigned cm = fz[c];
-    if (!cm) continue;
-    const size_t base = ((size_t)off + 64 * (size_t)k) * 9 + lane;
-    for (int cc = 0; cc < 3; cc++) {
-      if (!((cm >> cc) & 1u)) continue;
-      double s = 0;
-      for (int r = 0; r < 3; r++) if (!((rm >> r) & 1u)) s += vals[base + 64 * (3 * r + cc)] * zr[r];
-      if (s != 0.0) atomicAdd(&out[3 * (size_t)c + cc], -s);
-    }
-  }
-}
 
 // The same sums without atomics: one thread per (permuted) row c with a frozen dof walks ITS blocks (c, p); the block that carries the
 // contribution is the transposed one, (p, c), found through a static table (trans[slot of (c, p)] = address of block (p, c); the
@@ -2960,13 +2866,12 @@ static int adjoint_pre(tsl_ctx* c, const AdjArgs& a, double** rhs) {
   if (c->contact_enable) TSL_TRY(tsl_contact_detect(c, x_prev, x_prev, &nc));
   else { c->nc = 0; c->ds.cons_checked = false; }
   ClothArgs CA = cloth_args(c);
-  const bool det = c->deterministic != 0;
-  if (det && c->vg_stage.n < 3 * (size_t)std::max(c->vg_ns, 1)) { if (c->vg_stage.alloc(3 * (size_t)std::max(c->vg_ns, 1))) return tsl_fail("out of device memory (gradient staging)"); }
+  if (c->vg_stage.n < 3 * (size_t)std::max(c->vg_ns, 1)) { if (c->vg_stage.alloc(3 * (size_t)std::max(c->vg_ns, 1))) return tsl_fail("out of device memory (gradient staging)"); }
   // pos = x_s, ref_angle = ref_{s-1}: init_folding + ref_angle_backprop_a2ax
   if (c->n_hinge) {
-    if (det) CA.gstage = c->vg_stage.p;
-    hipLaunchKernelGGL(k_adj_a2ax, dim3(nblk(c->n_hinge, 256)), dim3(256), 0, s, CA, x_s, ref_prev, ag_s, ag_prev, pg_s);
-    if (det) hipLaunchKernelGGL(k_vertex_gather, dim3(nblk(NV, 256)), dim3(256), 0, s, NV, (const int*)c->vg_ptr.p, (const int*)c->vg_idx.p, (const double*)c->vg_stage.p, c->vg_hinge0, c->vg_tet0, pg_s);
+    CA.gstage = c->vg_stage.p;
+    hipLaunchKernelGGL(k_adj_a2ax, dim3(nblk(c->n_hinge, 256)), dim3(256), 0, s, CA, x_s, ref_prev, ag_s, ag_prev);
+    hipLaunchKernelGGL(k_vertex_gather, dim3(nblk(NV, 256)), dim3(256), 0, s, NV, (const int*)c->vg_ptr.p, (const int*)c->vg_idx.p, (const double*)c->vg_stage.p, c->vg_hinge0, c->vg_tet0, pg_s);
     CA.gstage = nullptr;
   }
   // preconditioner from the SPD-projected Hessian of the same state (block Jacobi + multigrid hierarchy): the operator
@@ -3014,29 +2919,20 @@ static int adjoint_post(tsl_ctx* c, const AdjArgs& a) {
   double* tmp_z_frozen = a.tmp_z_frozen;
   const double adj_damping = a.adj_damping;
   ClothArgs CA = cloth_args(c);
-  const bool det = c->deterministic != 0;
   // tmp_z_frozen (second compute_Hessian pass with counting_z_frozen)
-  if (det) hipLaunchKernelGGL(k_zfrozen_gather, dim3(nblk(NV, 256)), dim3(256), 0, s, NV, c->slice_off.p, c->slice_len.p, c->colidx.p, (const int*)c->trans.p, c->fzmask.p, c->vals_full.p,
-                              c->v_x.p, c->v_t4.p);
-  else {
-    HIP_OK(hipMemsetAsync(c->v_t4.p, 0, n3 * sizeof(double), s));
-    hipLaunchKernelGGL(k_zfrozen_matrix, dim3(c->n_slices), dim3(256), 0, s, NV, c->n_slices, c->slice_off.p, c->slice_len.p, c->colidx.p, c->fzmask.p, c->vals_full.p, c->v_x.p,
-                       c->v_t4.p);
-  }
+  hipLaunchKernelGGL(k_zfrozen_gather, dim3(nblk(NV, 256)), dim3(256), 0, s, NV, c->slice_off.p, c->slice_len.p, c->colidx.p, (const int*)c->trans.p, c->fzmask.p, c->vals_full.p,
+                     c->v_x.p, c->v_t4.p);
   hipLaunchKernelGGL(k_scatter_perm, dim3(nblk(NV, 256)), dim3(256), 0, s, NV, c->perm.p, c->v_t4.p, tmp_z_frozen);
   if (c->nc > 0) {
-    if (det) hipLaunchKernelGGL(k_contact_zfrozen_gather, dim3(nblk((long)NV * 64, 256)), dim3(256), 0, s, NV, (const int*)c->rowpos.p, (const int*)c->cr_ptr.p, (const int*)c->cr_ent.p, c->c_idx.p,
-                                c->frozen.p, c->c_Hfull.p, c->pdir.p, tmp_z_frozen);
-    else hipLaunchKernelGGL(k_contact_zfrozen, dim3(nblk(c->nc, 64)), dim3(64), 0, s, c->nc, c->c_idx.p, c->frozen.p, c->c_Hfull.p, c->pdir.p, tmp_z_frozen);
+    hipLaunchKernelGGL(k_contact_zfrozen_gather, dim3(nblk((long)NV * 64, 256)), dim3(256), 0, s, NV, (const int*)c->rowpos.p, (const int*)c->cr_ptr.p, (const int*)c->cr_ent.p, c->c_idx.p,
+                       c->frozen.p, c->c_Hfull.p, c->pdir.p, tmp_z_frozen);
   }
   // contact_energy_backprop(step-1) ; ref_angle_backprop_x2a
   if (c->nc > 0) {
-    if (det) {
-      if (c->c_G.n < 12 * (size_t)c->max_n_constraints) { if (c->c_G.alloc(12 * (size_t)c->max_n_constraints)) return -1; }
-      hipLaunchKernelGGL(k_contact_backprop, dim3(nblk(c->nc, 64)), dim3(64), 0, s, c->nc, contact_args(c), x_s, c->pdir.p, pg_prev, c->c_G.p);
-      hipLaunchKernelGGL(k_contact_row_gather, dim3(nblk((long)NV * 64, 256)), dim3(256), 0, s, NV, (const int*)c->rowpos.p, (const int*)c->cr_ptr.p, (const int*)c->cr_ent.p,
-                         (const double*)c->c_G.p, pg_prev);
-    } else hipLaunchKernelGGL(k_contact_backprop, dim3(nblk(c->nc, 64)), dim3(64), 0, s, c->nc, contact_args(c), x_s, c->pdir.p, pg_prev, (double*)nullptr);
+    if (c->c_G.n < 12 * (size_t)c->max_n_constraints) { if (c->c_G.alloc(12 * (size_t)c->max_n_constraints)) return -1; }
+    hipLaunchKernelGGL(k_contact_backprop, dim3(nblk(c->nc, 64)), dim3(64), 0, s, c->nc, contact_args(c), x_s, c->pdir.p, c->c_G.p);
+    hipLaunchKernelGGL(k_contact_row_gather, dim3(nblk((long)NV * 64, 256)), dim3(256), 0, s, NV, (const int*)c->rowpos.p, (const int*)c->cr_ptr.p, (const int*)c->cr_ent.p,
+                       (const double*)c->c_G.p, pg_prev);
   }
   if (c->n_hinge) hipLaunchKernelGGL(k_adj_x2a, dim3(nblk(c->n_hinge, 256)), dim3(256), 0, s, CA, x_s, c->pdir.p, ag_prev);
   // get_prev_grad / get_prev_prev_grad
