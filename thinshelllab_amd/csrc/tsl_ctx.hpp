@@ -347,6 +347,8 @@ struct tsl_ctx {
   DevBuf<int> grid_key, grid_val, grid_key2, grid_val2, grid_range;  // per target body: cell id / face id (sorted), active range (6 ints)
   DevBuf<int> vnf_ptr, vnf_lst;   // vertex -> incident surface triangles (vertex normals summed in a fixed order)
   DevBuf<int> cq_flag, cq_scan;   // activity flag / constraint slot of every query vertex of every contact pair (fixed constraint order)
+  DevBuf<int> grid_scan;   // scan scratch of the grids (one region per target body)
+  std::vector<size_t> gb_f0, gb_t0, gb_s0;   // first entry of body b's region in the key / bucket / scan-scratch buffers
   DevBuf<int> grid_cnt, grid_ptr, grid_cur, scan_tmp;   // hash buckets of the broad phase (histogram, offsets, cursors) and the scratch of the scan
   int grid_buckets_max = 0;
   int max_body_faces = 0;
