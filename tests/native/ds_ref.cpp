@@ -55,7 +55,7 @@ extern "C" int dsref_solve(int NV, const int* row_ptr, const int* col, const dou
     for (int e = 0; e < n_cons; e++)
       for (int a = 0; a < 4; a++)
         for (int b = 0; b < 4; b++) {
-          if (P.con_lvl[(size_t)e * 16 + 4 * a + b] != l) continue;
+          if ((P.con_lvl[(size_t)e * 16 + 4 * a + b] >> 1) != l) continue;
           for (int r = 0; r < 3; r++)
             for (int c = 0; c < 3; c++) A[P.con_dst[(size_t)e * 16 + 4 * a + b] + (long long)r * P.con_ld[(size_t)e * 16 + 4 * a + b] + c] += conH[(size_t)e * 144 + (3 * a + r) * 12 + 3 * b + c];
         }
@@ -145,7 +145,11 @@ extern "C" int dsref_plan_stats(int NV, const int* row_ptr, const int* col, int 
   for (const DsFrontDesc& f : P.fr) solve_bytes += 8.0 * ((double)f.p * f.p + 2.0 * f.p * f.b);
   for (const DsBatch& b : P.batches) {
     steps += b.max_pp / DS_T;
-    if (verbose) printf("level %2d: %5d fronts  max pp %4d  max ld %4d  max bp %4d\n", b.level, b.count, b.max_pp, b.max_ld, b.max_bp);
+    if (verbose) {
+      printf("level %2d: %5d fronts  max pp %4d  max ld %4d  max bp %4d", b.level, b.count, b.max_pp, b.max_ld, b.max_bp);
+      if (b.count <= 8) for (int q = 0; q < b.count; q++) { const DsFrontDesc& f = P.fr[P.level_sn[b.first + q]]; printf("  [p %d b %d lead %d]", f.p, f.b, f.lead); }
+      printf("\n");
+    }
   }
   double n_ent = 0;   // Schur-complement entries stored per factorisation
   for (const DsFrontDesc& f : P.fr) n_ent += (double)f.b * f.b;

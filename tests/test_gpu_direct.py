@@ -80,6 +80,33 @@ def test_direct_dataflow_chains_agree_with_block_step_launches():
     assert st["flag"] == 0 and np.array_equal(x0.cpu().numpy(), sols[0])
 
 
+@pytest.mark.parametrize("N,M,leaf", [(160, 96, 16), (96, 96, 64)])
+def test_direct_lookahead_keeps_the_bits(N, M, leaf):
+    """"direct_lookahead" (round 6): on the tree levels of one batch each the leading lead x lead block of every Schur complement -- all that the parent's pivot
+    block receives -- is formed first (with the columns of G it reads), the parent's F11 is gathered and inverted on the engine stream while the other Schur tiles
+    and the gather of F12 / F21 run on a low-priority side stream.  Every tile and every panel entry is the same sum in the same order whichever launch writes it:
+    solutions EQUAL BIT FOR BIT with the look-ahead on and off, over repeated factorisations (events and panels are reused), and right against scipy's LU."""
+    import scipy.sparse.linalg as spl
+    s = _drape(N, M, 5e-5, seed=9)
+    ctx = s._ensure_ctx()
+    ctx.set_param("direct", 1); ctx.set_param("direct_leaf", leaf)
+    s.compute_residual_and_Hessian(spd=True)
+    b = s.F.to_torch().clone()
+    xs = spl.splu(ctx.operator_csr().tocsc()).solve(b.cpu().numpy())
+    sols = {}
+    for la in (0, 1, 0, 1):
+        ctx.set_param("direct_lookahead", la)
+        for rep in range(3):
+            s.compute_residual_and_Hessian(spd=True)      # fresh factors
+            x, st = ctx.solve(b.clone())
+            assert st["flag"] == 0 and st["method"] == 4 and st["iters"] <= 3, (la, st)
+            assert rel_err(x.cpu().numpy(), xs) < 1e-9
+            if la in sols:
+                assert np.array_equal(x.cpu().numpy(), sols[la]), (la, rep)
+            sols[la] = x.cpu().numpy()
+    assert np.array_equal(sols[0], sols[1]), np.abs(sols[0] - sols[1]).max()
+
+
 @pytest.mark.parametrize("N,M,leaf", [(96, 96, 64), (70, 33, 16)])
 def test_direct_dataflow_odd_tile_counts(N, M, leaf):
     """fronts whose tile count is odd (the last super-tile of k_ds_gj_flow is partial) and batches of many small fronts: dataflow launches

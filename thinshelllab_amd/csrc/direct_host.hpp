@@ -69,12 +69,23 @@ static inline bool ds_use_small(const DirectSolver& d, const DsBatch& b) {
 // batch with few 64 x 64 tiles (upper levels) in 32 x 32 tiles, four times the workgroups (the same for the Schur complements was measured
 // slower on the leaf levels and no faster above: gone)
 // "direct_xcd" (DirectSolver::xcd_map): batches of at least this many fronts launch their GEMM tiles with the XCD-aware map (k_ds_gemm_x: a front per XCD); 0: never
-static void ds_launch_gemm(hipStream_t s, const DsDev& D, const DsBatch& b, int mode, int ds_xcd_map, int ds_g32_below = 0) {
+// part (mode 1, the look-ahead of direct_factor): 1 the tiles of the leading lead x lead blocks only (max_lead: the largest of the batch), 2 all others, 0 every tile
+static void ds_launch_gemm(hipStream_t s, const DsDev& D, const DsBatch& b, int mode, int ds_xcd_map, int ds_g32_below = 0, int part = 0, int max_lead = 0) {
   const int rows = mode == 0 ? b.max_pp : b.max_bp, cols = b.max_bp;
   const dim3 grid((cols + 63) / 64, (rows + 63) / 64, b.count);
   const long tiles = (long)grid.x * grid.y * grid.z;
-  if (mode == 0 && ds_g32_below > 0 && tiles < ds_g32_below) {
-    hipLaunchKernelGGL(k_ds_gemm_g32, dim3((cols + 31) / 32, (rows + 31) / 32, b.count), dim3(256), 0, s, D, b.first);
+  const int ta = (max_lead + 63) / 64;   // (part 1: tile columns [0, ta); the kernels drop the tiles of the other part)
+  if (part == 1 && ta == 0) return;
+  if (mode == 1 && part != 0) {
+    hipLaunchKernelGGL((k_ds_gemm<1, 4>), part == 1 ? dim3(ta, ta, b.count) : grid, dim3(256), 0, s, D, b.first, part);
+    return;
+  }
+  if (mode == 0 && ds_g32_below > 0 && tiles < ds_g32_below) {   // (the kernel is chosen by the size of the whole G: both parts in the same one)
+    hipLaunchKernelGGL(k_ds_gemm_g32, dim3(part == 1 ? 2 * ta : (cols + 31) / 32, (rows + 31) / 32, b.count), dim3(256), 0, s, D, b.first, part);
+    return;
+  }
+  if (mode == 0 && part != 0) {
+    hipLaunchKernelGGL((k_ds_gemm<0, 4>), part == 1 ? dim3(ta, grid.y, b.count) : grid, dim3(256), 0, s, D, b.first, part);
     return;
   }
   if (ds_xcd_map > 0 && b.count >= ds_xcd_map) {
@@ -84,27 +95,37 @@ static void ds_launch_gemm(hipStream_t s, const DsDev& D, const DsBatch& b, int 
     else hipLaunchKernelGGL((k_ds_gemm_x<1, 4>), dim3((unsigned)ng), dim3(256), 0, s, D, b.first, gx, gy, nf);
     return;
   }
-  if (mode == 0) hipLaunchKernelGGL((k_ds_gemm<0, 4>), grid, dim3(256), 0, s, D, b.first);
-  else hipLaunchKernelGGL((k_ds_gemm<1, 4>), grid, dim3(256), 0, s, D, b.first);
+  if (mode == 0) hipLaunchKernelGGL((k_ds_gemm<0, 4>), grid, dim3(256), 0, s, D, b.first, 0);
+  else hipLaunchKernelGGL((k_ds_gemm<1, 4>), grid, dim3(256), 0, s, D, b.first, 0);
 }
 // the panels of the fronts level_sn[lv0 .. lv0 + nf) (one level, or one batch of it) are written from their children's Schur complements
-static void ds_launch_extend(hipStream_t s, const DsDev& D, int lv0, int nf, int max_ld) {
-  const int nsp = (max_ld + DS_XSPAN - 1) / DS_XSPAN;
-  hipLaunchKernelGGL(k_ds_extend_panels, dim3(((max_ld / 3 + 2 + 3) / 4) * nsp, nf), dim3(256), 0, s, D, lv0, nsp);   // items: local vertices (<= ld / 3) + 2 for the padding rows, four per workgroup
+// (part 1 / 2: the pivot blocks only / everything else; max_span: the widest column range of the launch -- ld, pp, or max(ld - pp, pp))
+static void ds_launch_extend(hipStream_t s, const DsDev& D, int lv0, int nf, int max_ld, int part = 0, int max_span = 0) {
+  const int xspan = part == 1 ? 64 * DS_XU : DS_XSPAN;   // (the pivot blocks alone are few rows x few columns, on the critical path of the look-ahead: one pass per work item)
+  const int nsp = ((part == 0 ? max_ld : max_span) + xspan - 1) / xspan;
+  if (nsp <= 0) return;
+  hipLaunchKernelGGL(k_ds_extend_panels, dim3(((max_ld / 3 + 2 + 3) / 4) * nsp, nf), dim3(256), 0, s, D, lv0, nsp, part, xspan);   // items: local vertices (<= ld / 3) + 2 for the padding rows, four per workgroup
 }
 // start of level l: its panels are written (level 0: cleared before, see direct_prezero), then its matrix entries are added
-static void ds_launch_level_start(tsl_ctx* c, hipStream_t s, const DsDev& D, int l) {
+// part 1 / 2 (look-ahead; l > 0, a level of one batch b): the pivot blocks F11 -- gather, matrix entries inside F11, identity on the padding, contact groups inside F11 --
+// / the panels F12 and F21 with their entries; the block and group lists of a level hold the F11 part first (blk_lmid, cgr_lmid)
+static void ds_launch_level_start(tsl_ctx* c, hipStream_t s, const DsDev& D, int l, int part = 0, const DsBatch* b = nullptr) {
   DirectSolver& d = c->ds;
   const DirectPlan& P = d.plan;
   const int lv0 = P.level_ptr[l], nf = P.level_ptr[l + 1] - lv0;
-  if (l > 0) ds_launch_extend(s, D, lv0, nf, P.level_maxld[l]);
-  const int nb = P.blk_lptr[l + 1] - P.blk_lptr[l];
-  const long nt = (long)nb * 9 + (long)nf * DS_T;
-  hipLaunchKernelGGL(k_ds_assemble_level, dim3(ds_nblk(nt, 256)), dim3(256), 0, s, P.blk_lptr[l], nb, (const int*)d.blk_q.p, (const double*)c->vals.p, (const long long*)d.blk_dst.p,
-                     (const int*)d.blk_ld.p, lv0, nf, d.frl.p, d.arena.p, l == 0 ? 1 : 0);
-  const int ng = c->nc > 0 ? P.cgr_lptr[l + 1] - P.cgr_lptr[l] : 0;
-  if (ng > 0) hipLaunchKernelGGL(k_ds_assemble_contacts_level, dim3(ds_nblk((long)ng * 64, 256)), dim3(256), 0, s, P.cgr_lptr[l], ng, (const int*)d.cgr_ptr.p, (const int*)d.cgr_ent.p,
-                                 (const long long*)d.cgr_dst.p, (const int*)d.cgr_ld.p, (const double*)c->c_H.p, d.arena.p);
+  if (l > 0) ds_launch_extend(s, D, lv0, nf, P.level_maxld[l], part, part == 0 ? 0 : part == 1 ? b->max_pp : std::max(b->max_bp, b->max_pp));
+  const int i0 = part == 2 ? P.blk_lmid[l] : P.blk_lptr[l], i1 = part == 1 ? P.blk_lmid[l] : P.blk_lptr[l + 1];
+  const int nb = i1 - i0, npad = part == 2 ? 0 : nf;
+  const long nt = (long)nb * 9 + (long)npad * DS_T;
+  if (nt > 0)
+    hipLaunchKernelGGL(k_ds_assemble_level, dim3(ds_nblk(nt, 256)), dim3(256), 0, s, i0, nb, (const int*)d.blk_q.p, (const double*)c->vals.p, (const long long*)d.blk_dst.p,
+                       (const int*)d.blk_ld.p, lv0, npad, d.frl.p, d.arena.p, l == 0 ? 1 : 0);
+  if (c->nc > 0) {
+    const int g0 = part == 2 ? P.cgr_lmid[l] : P.cgr_lptr[l], g1 = part == 1 ? P.cgr_lmid[l] : P.cgr_lptr[l + 1];
+    const int ng = g1 - g0;
+    if (ng > 0) hipLaunchKernelGGL(k_ds_assemble_contacts_level, dim3(ds_nblk((long)ng * 64, 256)), dim3(256), 0, s, g0, ng, (const int*)d.cgr_ptr.p, (const int*)d.cgr_ent.p,
+                                   (const long long*)d.cgr_dst.p, (const int*)d.cgr_ld.p, (const double*)c->c_H.p, d.arena.p);
+  }
 }
 
 
@@ -506,9 +527,9 @@ static int direct_factor(tsl_ctx* c, int stop_sn = -1, const char* dump_path = n
   else for (const auto& r : P.leaf_ranges) HIP_OK(hipMemsetAsync(d.arena.p + r.first, 0, (size_t)r.second * sizeof(double), s));
   HIP_OK(hipMemsetAsync(d.bad.p, 0, 8 * sizeof(int), s));
   // (a persistent dataflow launch runs next to ordinary launches of sibling batches -- those end by themselves --, never next to a second one)
-  auto run_batch = [&](const DsBatch& b, hipStream_t bs, bool& flow_free) {
+  auto invert_batch = [&](const DsBatch& b, hipStream_t bs, bool& flow_free) {
     const int lv0 = b.first, nf = b.count;
-    const int tp = b.max_pp / DS_T, tb = b.max_bp / DS_T;
+    const int tp = b.max_pp / DS_T;
     bool flowed = false;
     {
       const std::vector<DsBatch> pieces = ds_flow_pieces(d, P, b, flow_free, bs);
@@ -528,11 +549,38 @@ static int direct_factor(tsl_ctx* c, int stop_sn = -1, const char* dump_path = n
       for (int k = 0; k < tp; k++) { const int na = P.act_n[b.act_off + k]; hipLaunchKernelGGL(k_ds_gj_step, dim3(na + na * tp * tp), dim3(256), 0, bs, D, lv0, k, tp, na); }   // fronts are sorted by pp: the active ones are a prefix
       hipLaunchKernelGGL(k_ds_gj_finish, dim3(tp, nf), dim3(256), 0, bs, D, lv0);
     }
-    if (tb > 0) {
+  };
+  auto run_batch = [&](const DsBatch& b, hipStream_t bs, bool& flow_free) {
+    invert_batch(b, bs, flow_free);
+    if (b.max_bp > 0) {
       ds_launch_gemm(bs, D, b, 0, d.xcd_map, d.g32_below);
       ds_launch_gemm(bs, D, b, 1, d.xcd_map);
     }
   };
+  auto side_streams = [&]() -> int {
+    if (d.fstream[0] == nullptr)
+      for (int k = 0; k < DS_NSIDE; k++) { HIP_OK(hipStreamCreateWithFlags(&d.fstream[k], hipStreamNonBlocking)); HIP_OK(hipEventCreateWithFlags(&d.ev_fjoin[k], hipEventDisableTiming)); }
+    if (d.ev_ffork == nullptr) HIP_OK(hipEventCreateWithFlags(&d.ev_ffork, hipEventDisableTiming));
+    for (int k = 0; k < 4; k++) if (d.ev_la[k] == nullptr) HIP_OK(hipEventCreateWithFlags(&d.ev_la[k], hipEventDisableTiming));
+    if (d.lastream == nullptr) {   // the side stream of the look-ahead at the LOWEST priority: what it carries is filler next to the chain on the engine stream
+      int lo = 0, hi = 0;
+      HIP_OK(hipDeviceGetStreamPriorityRange(&lo, &hi));
+      HIP_OK(hipStreamCreateWithPriority(&d.lastream, hipStreamNonBlocking, d.la_prio ? lo : 0));
+    }
+    return 0;
+  };
+  // LOOK-AHEAD over the levels of one batch each (the chain of single launches towards the root; "direct_lookahead", round 6).  There the engine stream ran
+  // inversion -> G -> Schur complement -> gather of the next level -> inversion ... one after the other: a latency-bound chain of block steps (a few workgroups busy at a
+  // time) taking turns with a matrix-core-bound launch.  But the parent's pivot block F11 receives only the LEADING block of a child's S (rows and columns that are own dofs
+  // of the parent: the first DsFrontDesc.lead of the boundary, sorted by elimination position -- a quarter of S two levels below cfg4's root, 16-45 % below that).  So:
+  //   engine stream:  ... G_l, [S_l leading tiles], gather + entries of F11_{l+1}, inversion_{l+1}, (wait) G_{l+1}, ...
+  //   side stream:        (after G_l) [S_l other tiles], gather + entries of F12 / F21 of level l + 1, ...
+  // Every tile / panel entry is the same arithmetic whichever launch forms it: the factors keep their bits.  The persistent inversion launch next to the Schur tiles
+  // is safe: the GEMM workgroups wait for nothing and end by themselves, the inversion's become resident as they drain.
+  const bool la_on = d.lookahead && stop_sn < 0 && !P.blk_lmid.empty() && P.la_from < P.n_levels;
+  if (la_on) TSL_TRY(side_streams());
+  hipStream_t ls = d.lastream;
+  enum { LA_W = 0, LA_GA = 1, LA_A = 2, LA_REST = 3 };   // engine stream: W stored, leading columns of G stored, leading Schur tiles stored; side stream: F12 / F21 of the next level written
   // The fronts of a level are independent: where a level was split into batches (by pivot-block size) the batches run on parallel
   // streams -- the latency-bound one (a few fronts in the LDS kernel, or the block steps of a handful of larger fronts) next to the
   // throughput-bound one (a thousand leaves).
@@ -541,7 +589,41 @@ static int direct_factor(tsl_ctx* c, int stop_sn = -1, const char* dump_path = n
     while (be < P.batches.size() && P.batches[be].level == P.batches[bi].level) be++;
     bool stop_here = false;
     if (stop_sn >= 0) for (int q = P.batches[bi].first; q < P.batches[be - 1].first + P.batches[be - 1].count; q++) stop_here |= P.level_sn[q] == stop_sn;
-    ds_launch_level_start(c, s, D, P.batches[bi].level);   // (the children's Schur complements of every lower level are stored)
+    const int lvl = P.batches[bi].level;
+    const bool la_level = la_on && lvl >= P.la_from;   // (one batch)
+    const bool la_in = la_level && lvl > P.la_from;    // the Schur launches of the level below were split: F11 first, the other panels on the side stream
+    if (la_in) {
+      ds_launch_level_start(c, s, D, lvl, 1, &P.batches[bi]);
+      HIP_OK(hipStreamWaitEvent(ls, d.ev_la[LA_A], 0));   // (tiles of the leading blocks hold entries of F12 / F21 too where lead is no multiple of the tile)
+      ds_launch_level_start(c, ls, D, lvl, 2, &P.batches[bi]);
+      HIP_OK(hipEventRecord(d.ev_la[LA_REST], ls));
+    } else
+    ds_launch_level_start(c, s, D, lvl);   // (the children's Schur complements of every lower level are stored)
+    if (la_level) {
+      const DsBatch& b = P.batches[bi];
+      bool flow_free = true;
+      invert_batch(b, s, flow_free);
+      if (la_in) HIP_OK(hipStreamWaitEvent(s, d.ev_la[LA_REST], 0));
+      if (b.max_bp > 0 && be < P.batches.size()) {
+        // engine stream: the columns of G under the leading Schur tiles, those tiles; side stream: the other columns of G, the other tiles
+        int max_lead = 0;
+        for (int q = 0; q < b.count; q++) max_lead = std::max(max_lead, P.fr[P.level_sn[b.first + q]].lead);
+        HIP_OK(hipEventRecord(d.ev_la[LA_W], s));
+        ds_launch_gemm(s, D, b, 0, 0, d.g32_below, 1, max_lead);
+        HIP_OK(hipEventRecord(d.ev_la[LA_GA], s));
+        ds_launch_gemm(s, D, b, 1, 0, 0, 1, max_lead);
+        HIP_OK(hipEventRecord(d.ev_la[LA_A], s));
+        HIP_OK(hipStreamWaitEvent(ls, d.ev_la[LA_W], 0));
+        ds_launch_gemm(ls, D, b, 0, 0, d.g32_below, 2, max_lead);
+        HIP_OK(hipStreamWaitEvent(ls, d.ev_la[LA_GA], 0));
+        ds_launch_gemm(ls, D, b, 1, 0, 0, 2, max_lead);
+      } else if (b.max_bp > 0) {
+        ds_launch_gemm(s, D, b, 0, d.xcd_map, d.g32_below);
+        ds_launch_gemm(s, D, b, 1, d.xcd_map);
+      }
+      bi = be;
+      continue;
+    }
     if (stop_here) {   // diagnostic: the top rows of the assembled front stop_sn (children added, not yet factorised) -> file
       const DsFrontDesc& f = P.fr[stop_sn];
       std::vector<double> h((size_t)f.pp * f.ld);
@@ -559,9 +641,7 @@ static int direct_factor(tsl_ctx* c, int stop_sn = -1, const char* dump_path = n
     }
     const int nside = (int)std::min<size_t>(be - bi - 1, DS_NSIDE);
     if (nside > 0) {
-      if (d.fstream[0] == nullptr)
-        for (int k = 0; k < DS_NSIDE; k++) { HIP_OK(hipStreamCreateWithFlags(&d.fstream[k], hipStreamNonBlocking)); HIP_OK(hipEventCreateWithFlags(&d.ev_fjoin[k], hipEventDisableTiming)); }
-      if (d.ev_ffork == nullptr) HIP_OK(hipEventCreateWithFlags(&d.ev_ffork, hipEventDisableTiming));
+      TSL_TRY(side_streams());
       HIP_OK(hipEventRecord(d.ev_ffork, s));
       for (int k = 0; k < nside; k++) HIP_OK(hipStreamWaitEvent(d.fstream[k], d.ev_ffork, 0));
     }

@@ -38,6 +38,8 @@ struct DsFrontDesc {
   int yoff;                  // y_f (the boundary update of the upward solve sweep, b entries) in the Y buffer
   int cpm[4], cy[4];         // pmap_off / yoff of the first four children, inline: the sweeps' gather then needs no look-up of the child records
   int ch_off, nchild;        // child fronts: ch_rec[ch_off .. ch_off + nchild), ascending supernode id (the summation order of the gather)
+  int lead;                  // boundary dofs that are OWN dofs of the parent: the first `lead` of the boundary (it is sorted by elimination position), i.e. the
+                             // leading lead x lead block of S is all of S the parent's pivot block F11 receives (the look-ahead split of the Schur launches)
 };
 // what the gather kernels need of a child, in the parent's child order
 struct DsChildRec {
@@ -83,8 +85,14 @@ struct DirectPlan {
   std::vector<long long> blk_dst;  // per block of the static pattern (CSR order of `adj`): top-left element in the panel arena
   std::vector<int> blk_ld;
   std::vector<int> blk_q, blk_lptr;   // the same blocks level by level: blk_q[blk_lptr[l] .. blk_lptr[l + 1]) land in fronts of level l
+  // look-ahead (round 6): within a level the blocks that land in a pivot block F11 come first, [blk_lptr[l], blk_lmid[l]); the same for the contact groups
+  // (cgr_lmid).  Levels >= la_from have ONE batch each: there the leading block of every Schur complement (all the parent's F11 receives) is formed first,
+  // the parent's pivot block is gathered and inverted while the rest of the Schur launch and the gather of the parent's F12 / F21 run on a second stream.
+  // Empty tables (merged plans of a scene group) / la_from >= n_levels: no look-ahead.
+  std::vector<int> blk_lmid, cgr_lmid;
+  int la_from = 1 << 30;
   std::vector<long long> con_dst;  // per constraint x 16 (vertex pair a, b)
-  std::vector<int> con_ld, con_lvl;   // row stride and tree level of the destination
+  std::vector<int> con_ld, con_lvl;   // row stride and tree level of the destination (con_lvl: 2 level + 1 outside F11 -- the groups of a level that land in F11 come first)
   // the same sub-blocks grouped by DESTINATION, level by level (groups cgr_lptr[l] .. cgr_lptr[l + 1] land on level l): group g adds the
   // sub-blocks cgr_ent[cgr_ptr[g] .. cgr_ptr[g + 1]) (16 c + sub, ascending) to the 3 x 3 block at cgr_dst[g] -- one writer per entry, a
   // fixed order (several constraints share vertex pairs)
@@ -197,6 +205,13 @@ struct DirectPlan {
       for (int s : fl) for (int r = 0; r < fr[s].b; r += 16) { wl_front.push_back(s); wl_row.push_back(r); }
     }
     wl_own_ptr[L] = (int)wl_front.size();
+    {   // lowest level from which every level is ONE batch (the chain of single launches towards the root); at least two such levels or none
+      std::vector<int> nb(L, 0);
+      for (const DsBatch& b : batches) nb[b.level]++;
+      int l0 = L;
+      while (l0 > 0 && nb[l0 - 1] == 1) l0--;
+      la_from = (L - l0 >= 2) ? std::max(l0, 1) : (1 << 30);
+    }
     for (DsBatch& b : batches) {
       b.act_off = (int)act_n.size();
       for (int k = 0; k * DS_T < b.max_pp; k++) {
@@ -283,6 +298,7 @@ struct DirectPlan {
             pm[l] = 3 * i; pm[l + 1] = 3 * i + 1; pm[l + 2] = 3 * i + 2;
             if (l >= f.pp) cr.nb += 3;
           }
+          fr[cr.sn].lead = ch.b - cr.nb;
         }
         for (int i = 0; i < f.nv_own + f.nv_bnd; i++) lc[fv[i]] = -1;
       }
@@ -322,14 +338,15 @@ struct DirectPlan {
       if ((int)locs.size() < nt) locs.resize(nt);
       // the blocks are also listed LEVEL BY LEVEL (blk_q): the panels of a level are written by the gather of the children's Schur
       // complements when the level starts (a store, nothing is cleared), its matrix entries are added right after
-      if ((int)lists.size() < nt * L) lists.resize((size_t)nt * L);
+      if ((int)lists.size() < 2 * nt * L) lists.resize((size_t)2 * nt * L);   // per thread and level: blocks inside F11, then the others
       for (auto& v : lists) v.clear();
       std::atomic<int> bad{0};
       std::atomic<long long> written{0};
       ds_parallel_for(S, nt, 16, [&](int t, int s) {
         std::vector<int>& loc = locs[t];
         if ((int)loc.size() != NV) loc.assign(NV, -1);
-        std::vector<int>& mine = lists[(size_t)t * L + alap[s]];
+        std::vector<int>& mine11 = lists[2 * ((size_t)t * L + alap[s])];
+        std::vector<int>& mine = lists[2 * ((size_t)t * L + alap[s]) + 1];
         const DsFrontDesc& f = fr[s];
         const int no = f.nv_own;
         long long nw = 0;
@@ -345,7 +362,7 @@ struct DirectPlan {
             const int lc = loc[c];
             if (lc < 0) { bad = 1; continue; }
             const int q = row_ptr[r] + k;
-            blk_dst[q] = f.off + (long long)(3 * i) * f.ld + lc; blk_ld[q] = f.ld; nw++; mine.push_back(q);
+            blk_dst[q] = f.off + (long long)(3 * i) * f.ld + lc; blk_ld[q] = f.ld; nw++; (lc < f.pp ? mine11 : mine).push_back(q);
             if (sym.sn_of[c] > s) {   // the mirrored block (c, r) lies in F21 (c is a boundary vertex of this front)
               const int qt = tpos[q];
               if (qt >= 0) { blk_dst[qt] = f.off21 + (long long)(lc - f.pp) * f.pp + 3 * i; blk_ld[qt] = f.pp; nw++; mine.push_back(qt); }
@@ -356,10 +373,13 @@ struct DirectPlan {
         written += nw;
       });
       if (bad || written != row_ptr[NV]) return -2;
-      blk_q.resize(row_ptr[NV]); blk_lptr.assign(L + 1, 0);
+      blk_q.resize(row_ptr[NV]); blk_lptr.assign(L + 1, 0); blk_lmid.assign(L, 0);
       size_t o = 0;
       for (int l = 0; l < L; l++) {
-        for (int t = 0; t < nt; t++) { const std::vector<int>& v = lists[(size_t)t * L + l]; std::copy(v.begin(), v.end(), blk_q.begin() + o); o += v.size(); }
+        for (int part = 0; part < 2; part++) {
+          for (int t = 0; t < nt; t++) { const std::vector<int>& v = lists[2 * ((size_t)t * L + l) + part]; std::copy(v.begin(), v.end(), blk_q.begin() + o); o += v.size(); }
+          if (part == 0) blk_lmid[l] = (int)o;
+        }
         blk_lptr[l + 1] = (int)o;
       }
     }
@@ -390,7 +410,7 @@ struct DirectPlan {
           if (dst < 0) return -3;
           con_dst[(size_t)e * 16 + a * 4 + b] = dst;
           con_ld[(size_t)e * 16 + a * 4 + b] = ldq;
-          con_lvl[(size_t)e * 16 + a * 4 + b] = sym.level[s];
+          con_lvl[(size_t)e * 16 + a * 4 + b] = 2 * sym.level[s] + ((lr < fr[s].pp && lc < fr[s].pp) ? 0 : 1);
         }
     {
       const size_t n = (size_t)n_cons * 16;
@@ -401,16 +421,17 @@ struct DirectPlan {
         if (con_dst[x] != con_dst[y]) return con_dst[x] < con_dst[y];
         return x < y;
       });
-      cgr_lptr.assign(n_levels + 1, 0); cgr_ptr.clear(); cgr_ent.assign(ord.begin(), ord.end()); cgr_ld.clear(); cgr_dst.clear();
+      cgr_lptr.assign(n_levels + 1, 0); cgr_lmid.assign(n_levels, 0); cgr_ptr.clear(); cgr_ent.assign(ord.begin(), ord.end()); cgr_ld.clear(); cgr_dst.clear();
       for (size_t i = 0; i < n; i++) {
         const int x = ord[i];
         if (i == 0 || con_dst[x] != con_dst[ord[i - 1]] || con_lvl[x] != con_lvl[ord[i - 1]]) {
           cgr_ptr.push_back((int)i); cgr_dst.push_back(con_dst[x]); cgr_ld.push_back(con_ld[x]);
-          cgr_lptr[con_lvl[x] + 1]++;
+          cgr_lptr[(con_lvl[x] >> 1) + 1]++;
+          if ((con_lvl[x] & 1) == 0) cgr_lmid[con_lvl[x] >> 1]++;
         }
       }
       cgr_ptr.push_back((int)n);
-      for (int l = 0; l < n_levels; l++) cgr_lptr[l + 1] += cgr_lptr[l];
+      for (int l = 0; l < n_levels; l++) { cgr_lmid[l] += cgr_lptr[l]; cgr_lptr[l + 1] += cgr_lptr[l]; }
     }
     return 0;
   }

@@ -1053,8 +1053,10 @@ __global__ void __launch_bounds__(256) k_ds_inv_small(DsDev D, int lv0, int ls) 
 // stagger their K loops and epilogues -- no change (976-1004 us for the Schur launches of a factorisation under four priority patterns).
 #define DS_SK 32
 #define DS_GMC 8   // children of a front whose tables the Schur epilogue keeps in LDS per pass
+// part (the look-ahead of the upper levels): 0 every tile; 1 the tiles of the leading block (Schur mode: rows and columns below DsFrontDesc.lead -- all of S that
+// the parent's pivot block receives; G: the tile columns below lead, which those tiles read); 2 the others.  A tile is the same arithmetic whichever launch forms it.
 template <int mode, int WPC>
-TSL_DEV void ds_gemm_tile(const DsDev& D, int lv0, int bx, int by, int bz) {
+TSL_DEV void ds_gemm_tile(const DsDev& D, int lv0, int bx, int by, int bz, int part = 0) {
   constexpr int SA = DS_SK + 1, SB = 64 + 1;
   __shared__ double As[64 * SA];
   __shared__ double Bs[DS_SK * SB];
@@ -1062,6 +1064,8 @@ TSL_DEV void ds_gemm_tile(const DsDev& D, int lv0, int bx, int by, int bz) {
   const int Mr = mode == 0 ? f.pp : f.bp, Nc = f.bp, K = f.pp;
   const int I0 = by * 64, J0 = bx * 64;
   if (I0 >= Mr || J0 >= Nc) return;
+  if (mode == 1 && part != 0 && ((I0 < f.lead && J0 < f.lead) != (part == 1))) return;
+  if (mode == 0 && part != 0 && ((J0 < f.lead) != (part == 1))) return;   // G: the columns the leading Schur tiles read (J0 is a multiple of 64) / the others
   const double* F = D.A + f.off;
   double* G = D.G + f.goff;
   const int ld = f.ld, pp = f.pp;
@@ -1220,27 +1224,30 @@ TSL_DEV void ds_gemm_tile(const DsDev& D, int lv0, int bx, int by, int bz) {
 #define DS_XU 4
 #define DS_XSPAN 1024  // columns per work item (DS_XSPAN / (64 DS_XU) passes: the vertex look-up is paid once per span)
 #define DS_XMAXC 64    // children whose look-up fits one ballot (fronts with more take the general loop)
-__global__ void __launch_bounds__(256) k_ds_extend_panels(DsDev D, int lv0, int nsp) {   // nsp: column spans of the widest front
+// part (the look-ahead of the upper levels, direct_factor): 0 every panel; 1 the pivot block F11 only (top rows, columns 0 .. pp); 2 the rest (F12 = top rows,
+// columns pp .. ld, and F21) -- every entry is the same sum in the same order whichever launch writes it.
+__global__ void __launch_bounds__(256) k_ds_extend_panels(DsDev D, int lv0, int nsp, int part, int xspan) {   // nsp: column spans (of xspan columns, a multiple of 64 DS_XU) of the widest front
   const DsFrontDesc f = D.frl[lv0 + blockIdx.y];
   const int ib = blockIdx.x / nsp, sp = blockIdx.x - ib * nsp;
   const int lane = threadIdx.x & 63, w = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-  const int g = 4 * ib + w, ng = f.nv_own + f.nv_bnd, c0 = sp * DS_XSPAN;
+  const int g = 4 * ib + w, ng = f.nv_own + f.nv_bnd;
   if (g >= ng + 2) return;
+  const bool top = g >= ng ? g == ng : g < f.nv_own;
+  if (!top && part == 1) return;
+  const int ncol = top ? f.ld : f.pp;                                               // row stride of the panel
+  const int cA = (top && part == 2) ? f.pp : 0, cB = (top && part == 1) ? f.pp : ncol;   // columns of this launch
+  const int c0 = cA + sp * xspan;
+  if (c0 >= cB) return;
+  const int c1 = min(cB, c0 + xspan);
   if (g >= ng) {   // padding rows: p .. pp of the top rows (the identity comes with k_ds_assemble_level) / b .. bp of F21
-    const bool top = g == ng;
-    const int nrow = top ? f.pp - f.p : f.bp - f.b, ncol = top ? f.ld : f.pp;
+    const int nrow = top ? f.pp - f.p : f.bp - f.b;
     double* base = top ? D.A + f.off + (size_t)f.p * f.ld : D.A + f.off21 + (size_t)f.b * f.pp;
-    const int c1 = min(ncol, c0 + DS_XSPAN);
     for (int i = 0; i < nrow; i++)
       for (int j = c0 + lane; j < c1; j += 64) base[(size_t)i * ncol + j] = 0.0;
     return;
   }
-  const bool top = g < f.nv_own;
   const int r = top ? 3 * g : f.pp + 3 * (g - f.nv_own);            // first of the three local dofs of the vertex
-  const int ncol = top ? f.ld : f.pp;
-  if (c0 >= ncol) return;
   double* row = top ? D.A + f.off + (size_t)r * f.ld : D.A + f.off21 + (size_t)(r - f.pp) * f.pp;
-  const int c1 = min(ncol, c0 + DS_XSPAN);
   const DsChildRec* ch = D.ch + f.ch_off;
   if (f.nchild <= DS_XMAXC) {   // (every front of the plans seen so far)
     int my_ci = -1, my_off = 0, my_bp = 0;
@@ -1326,7 +1333,7 @@ __global__ void __launch_bounds__(256) k_ds_extend_panels(DsDev D, int lv0, int 
 // tiles of k_ds_gemm are 320 - 670 workgroups -- one to three per CU --, and with so few the global loads of the next slab (prefetched ONE
 // slab = 0.5 us ahead, against ~2 us of latency) are what a slab waits for: the K loop runs at 26-42 instead of 63 TFLOP/s
 // (scripts/exp_gemm_dbg.py).  Four times the workgroups, a quarter of the registers: the latency hides behind occupancy again.
-__global__ void __launch_bounds__(256) k_ds_gemm_g32(DsDev D, int lv0) {
+__global__ void __launch_bounds__(256) k_ds_gemm_g32(DsDev D, int lv0, int part) {   // part 1 / 2: the columns below / from DsFrontDesc.lead rounded up to 64 (what the leading Schur tiles read)
   constexpr int SA = DS_SK + 1, SB = 32 + 1;
   __shared__ double As[32 * SA];
   __shared__ double Bs[DS_SK * SB];
@@ -1334,6 +1341,7 @@ __global__ void __launch_bounds__(256) k_ds_gemm_g32(DsDev D, int lv0) {
   const int Mr = f.pp, Nc = f.bp, K = f.pp;
   const int I0 = blockIdx.y * 32, J0 = blockIdx.x * 32;
   if (I0 >= Mr || J0 >= Nc) return;
+  if (part != 0 && ((J0 < ((f.lead + 63) & ~63)) != (part == 1))) return;
   const double* F = D.A + f.off;
   double* G = D.G + f.goff;
   const int ld = f.ld;
@@ -1367,8 +1375,8 @@ __global__ void __launch_bounds__(256) k_ds_gemm_g32(DsDev D, int lv0) {
 }
 
 template <int mode, int WPC>
-__global__ void __launch_bounds__(256, WPC) k_ds_gemm(DsDev D, int lv0) {
-  ds_gemm_tile<mode, WPC>(D, lv0, blockIdx.x, blockIdx.y, blockIdx.z);
+__global__ void __launch_bounds__(256, WPC) k_ds_gemm(DsDev D, int lv0, int part) {
+  ds_gemm_tile<mode, WPC>(D, lv0, blockIdx.x, blockIdx.y, blockIdx.z, part);
 }
 
 // The same tiles launched as a one-dimensional grid with an XCD-aware map ("direct_xcd", batches of at least that many fronts; default 64):

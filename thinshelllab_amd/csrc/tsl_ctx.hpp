@@ -125,6 +125,10 @@ struct DirectSolver {
   int prezero = 1;          // "direct_prezero"
   hipStream_t fstream[2] = {nullptr, nullptr};   // batches of one level run next to each other (direct_factor)
   hipEvent_t ev_ffork = nullptr, ev_fjoin[2] = {nullptr, nullptr};
+  hipEvent_t ev_la[4] = {nullptr, nullptr, nullptr, nullptr};
+  hipStream_t lastream = nullptr;
+  int la_prio = 1;   // look-ahead of the upper levels: G stored / leading Schur tiles stored (engine stream), other panels of the next level written (side stream)
+  int lookahead = 1;        // "direct_lookahead": the levels of one batch each form the leading block of their Schur complements first and invert the parents' pivot blocks next to the rest (direct_factor)
   // "direct_flow": block steps of a batch alone on its level as one persistent dataflow launch (k_ds_gj_flow)
   int device = 0;          // HIP device of the context (tsl_ctx_create)
   int flow = 3, flow_cap = 0, flow_epoch = 0;   // flow_cap: workgroups of k_ds_gj_flow the device holds at once

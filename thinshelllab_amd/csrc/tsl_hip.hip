@@ -402,6 +402,8 @@ extern "C" void tsl_ctx_destroy(tsl_ctx* c) {
   if (c->ev_out) (void)hipEventDestroy(c->ev_out);
   for (int k = 0; k < DS_NSIDE; k++) if (c->ds.fstream[k]) { (void)hipStreamSynchronize(c->ds.fstream[k]); (void)hipEventDestroy(c->ds.ev_fjoin[k]); (void)hipStreamDestroy(c->ds.fstream[k]); }
   if (c->ds.ev_ffork) (void)hipEventDestroy(c->ds.ev_ffork);
+  for (int k = 0; k < 4; k++) if (c->ds.ev_la[k]) (void)hipEventDestroy(c->ds.ev_la[k]);
+  if (c->ds.lastream) { (void)hipStreamSynchronize(c->ds.lastream); (void)hipStreamDestroy(c->ds.lastream); }
   if (c->ds.h_anorm) (void)hipHostFree(c->ds.h_anorm);
   if (c->ds.pin) (void)hipHostFree(c->ds.pin);
   if (c->h_ir) (void)hipHostFree(c->h_ir);
@@ -455,6 +457,7 @@ extern "C" int tsl_set_param(tsl_ctx* c, const char* key, double v) {
   else if (k == "direct_flow_token") { if (v == 0) ds_flow_token_release(c->ds); }   // 0: hand the device's dataflow token back (asked for again at the next eligible factorisation)
   else if (k == "direct_gemv_wide_below") c->ds.gemv_wide_below = std::max(0, (int)v);
   else if (k == "direct_g32_below") c->ds.g32_below = std::max(0, (int)v);
+  else if (k == "direct_lookahead") { c->ds.lookahead = v != 0.0; c->ds.la_prio = v != 2.0; }   // (2: the side stream at normal priority -- A/B)
   else if (k == "direct_piv_tol") { c->ds.piv_tol = v; c->ds.numeric_valid = false; }
   else if (k == "direct_leaf") { c->ds.leaf = std::max(4, (int)v); c->ds.static_ready = false; c->ds.plan_valid = false; c->ds.numeric_valid = false; }
   else if (k == "gmres_m") c->gmres_m = (int)v;
