@@ -280,7 +280,7 @@ static int direct_static(tsl_ctx* c) {
     for (int k = 0; k < (int)c->h_rows[v].size(); k++) c2s[d.row_ptr[v] + k] = (int)(((long)c->h_slice_off[s] + 64L * k) * 9 + lane);
   }
   d.h_c2s = c2s;   // (SELL address of every CSR block: the plan uploads bake it into their level-ordered lists)
-  if (d.bad.alloc(8 + 4 * DS_BADLOG)) return -1;
+  if (d.bad.alloc(8 + 4 * DS_BADLOG + 8)) return -1;   // (+ 8: the note of a dataflow launch that gave up, ds_flow_poll)
   HIP_OK(hipFuncSetAttribute((const void*)k_ds_inv_small, hipFuncAttributeMaxDynamicSharedMemorySize, (int)ds_small_lds(DS_SMALL)));
   { hipDeviceProp_t prop;   // compute units of THIS device: rounds of the LDS kernel, remainder rule of the batches (was a constant 256)
     if (hipGetDeviceProperties(&prop, d.device) == hipSuccess && prop.multiProcessorCount > 0) d.plan.n_cu = prop.multiProcessorCount; else (void)hipGetLastError(); }
@@ -512,11 +512,15 @@ static void ds_sweep_up_level(hipStream_t s, const DsDev& D, DirectSolver& d, in
   ds_launch_gemv(s, D, d, b0, o1 - b0, 1, (const double*)z, nullptr, P.wl_bnd_wide.empty() ? -1 : P.wl_bnd_wide[l]);
 }
 // numeric factorisation of the operator of the last assemble (c->vals + masked contact blocks c->c_H)
-static int direct_factor(tsl_ctx* c, int stop_sn = -1, const char* dump_path = nullptr) {
+// eager_r / eager_z (round 6, with the look-ahead; "direct_lookahead" bit 1): the right-hand side and the result vector of the application that FOLLOWS this factorisation
+// (the first pass of the solve the factors are made for).  The upward sweep of every level below the last two runs on the look-ahead's side stream next to the chains of the
+// two largest pivot blocks -- ~0.4 ms in which a few workgroups at a time work and the chip is otherwise idle; direct_apply(eager_r, eager_z) then starts at the level they stopped at.
+static int direct_factor(tsl_ctx* c, int stop_sn = -1, const char* dump_path = nullptr, const double* eager_r = nullptr, double* eager_z = nullptr) {
   DirectSolver& d = c->ds;
   hipStream_t s = c->stream;
   TSL_TRY(direct_plan(c));
   if (d.numeric_valid) return 0;
+  d.eager_n = 0;
   const DirectPlan& P = d.plan;
   const DsDev D = ds_dev(c);
   if (d.prezero_pending) {   // cleared on the side stream since the last solve (direct_prezero)
@@ -527,6 +531,7 @@ static int direct_factor(tsl_ctx* c, int stop_sn = -1, const char* dump_path = n
   else for (const auto& r : P.leaf_ranges) HIP_OK(hipMemsetAsync(d.arena.p + r.first, 0, (size_t)r.second * sizeof(double), s));
   HIP_OK(hipMemsetAsync(d.bad.p, 0, 8 * sizeof(int), s));
   // (a persistent dataflow launch runs next to ordinary launches of sibling batches -- those end by themselves --, never next to a second one)
+  int flow_wgs_sent = 0;   // workgroups of the dataflow launches of this factorisation so far (bad[DS_FLOW_ARRIVE] counts those that started)
   auto invert_batch = [&](const DsBatch& b, hipStream_t bs, bool& flow_free) {
     const int lv0 = b.first, nf = b.count;
     const int tp = b.max_pp / DS_T;
@@ -538,7 +543,7 @@ static int direct_factor(tsl_ctx* c, int stop_sn = -1, const char* dump_path = n
       for (size_t i = 0; ready && i < pieces.size(); i++) ready = ds_flow_prepare(d, P, pieces[i], true, fas[i], bs);   // (every piece's buffers before any piece goes out:
                                                                                                                            // a batch is inverted on ONE path)
       if (ready) {
-        for (size_t i = 0; i < pieces.size(); i++) { ds_flow_launch(bs, D, pieces[i].first, fas[i], d); d.n_flow++; }
+        for (size_t i = 0; i < pieces.size(); i++) { ds_flow_launch(bs, D, pieces[i].first, fas[i], d); d.n_flow++; flow_wgs_sent += fas[i].tile0[fas[i].nf]; }
         flowed = true; flow_free = false;
       }
     }
@@ -561,11 +566,11 @@ static int direct_factor(tsl_ctx* c, int stop_sn = -1, const char* dump_path = n
     if (d.fstream[0] == nullptr)
       for (int k = 0; k < DS_NSIDE; k++) { HIP_OK(hipStreamCreateWithFlags(&d.fstream[k], hipStreamNonBlocking)); HIP_OK(hipEventCreateWithFlags(&d.ev_fjoin[k], hipEventDisableTiming)); }
     if (d.ev_ffork == nullptr) HIP_OK(hipEventCreateWithFlags(&d.ev_ffork, hipEventDisableTiming));
-    for (int k = 0; k < 4; k++) if (d.ev_la[k] == nullptr) HIP_OK(hipEventCreateWithFlags(&d.ev_la[k], hipEventDisableTiming));
+    for (int k = 0; k < 5; k++) if (d.ev_la[k] == nullptr) HIP_OK(hipEventCreateWithFlags(&d.ev_la[k], hipEventDisableTiming));
     if (d.lastream == nullptr) {   // the side stream of the look-ahead at the LOWEST priority: what it carries is filler next to the chain on the engine stream
       int lo = 0, hi = 0;
       HIP_OK(hipDeviceGetStreamPriorityRange(&lo, &hi));
-      HIP_OK(hipStreamCreateWithPriority(&d.lastream, hipStreamNonBlocking, d.la_prio ? lo : 0));
+      HIP_OK(hipStreamCreateWithPriority(&d.lastream, hipStreamNonBlocking, lo));   // (measured: at normal priority 223 ms per step against 201 -- it then shares a hardware queue with the engine stream)
     }
     return 0;
   };
@@ -577,10 +582,10 @@ static int direct_factor(tsl_ctx* c, int stop_sn = -1, const char* dump_path = n
   //   side stream:        (after G_l) [S_l other tiles], gather + entries of F12 / F21 of level l + 1, ...
   // Every tile / panel entry is the same arithmetic whichever launch forms it: the factors keep their bits.  The persistent inversion launch next to the Schur tiles
   // is safe: the GEMM workgroups wait for nothing and end by themselves, the inversion's become resident as they drain.
-  const bool la_on = d.lookahead && stop_sn < 0 && !P.blk_lmid.empty() && P.la_from < P.n_levels;
+  const bool la_on = (d.lookahead & 1) && stop_sn < 0 && !P.blk_lmid.empty() && P.la_from < P.n_levels;
   if (la_on) TSL_TRY(side_streams());
   hipStream_t ls = d.lastream;
-  enum { LA_W = 0, LA_GA = 1, LA_A = 2, LA_REST = 3 };   // engine stream: W stored, leading columns of G stored, leading Schur tiles stored; side stream: F12 / F21 of the next level written
+  enum { LA_W = 0, LA_GA = 1, LA_A = 2, LA_REST = 3, LA_DRAIN = 4 };   // engine stream: W stored, leading columns of G stored, leading Schur tiles stored; side stream: F12 / F21 of the next level written
   // The fronts of a level are independent: where a level was split into batches (by pivot-block size) the batches run on parallel
   // streams -- the latency-bound one (a few fronts in the LDS kernel, or the block steps of a handful of larger fronts) next to the
   // throughput-bound one (a thousand leaves).
@@ -602,7 +607,27 @@ static int direct_factor(tsl_ctx* c, int stop_sn = -1, const char* dump_path = n
     if (la_level) {
       const DsBatch& b = P.batches[bi];
       bool flow_free = true;
+      // A dataflow launch of more workgroups than CUs needs SECOND slots on CUs that already hold one of its (waiting) workgroups.  Measured (round 6): next to queued
+      // side-stream work -- thousands of small workgroups of the eager sweeps -- the last few workgroups of cfg4's root launch (289) were then not started for seconds,
+      // once in ~100 time steps (DS_FLOW_SPINS ran out: 0.5 s and the context's dataflow path lost); launches of at most one workgroup per CU never were.  Such a
+      // launch therefore starts with the side stream drained.
+      if (la_in && ds_flow_wgs(P, b) > P.n_cu) {
+        HIP_OK(hipEventRecord(d.ev_la[LA_DRAIN], ls));
+        HIP_OK(hipStreamWaitEvent(s, d.ev_la[LA_DRAIN], 0));
+      }
       invert_batch(b, s, flow_free);
+      if (la_in && eager_r != nullptr && (d.lookahead & 2) && lvl >= P.n_levels - 3 && lvl <= P.n_levels - 2) {
+        // (the side stream has this level's F12 / F21 behind it and, through LA_A, every inversion below; the root's LA_REST, which the engine stream waits for, follows the sweeps)
+        // in two parts: the lowest levels -- most of the bytes -- next to the chain of the third level from the top, where the side stream has ~0.1 ms of slack before its
+        // Schur tiles are needed; the others next to the chain below the root
+        const int n1 = std::min(d.lookahead >> 2, P.n_levels - 3);   // (default 2: 194.1 / 192.0 / 191.8 / 192.8 ms per step with 0 / 1 / 2 / 3 levels in the first part)
+        const bool first = lvl == P.n_levels - 3;
+        if (!first || (n1 > 0 && P.la_from < lvl)) {
+          hipLaunchKernelGGL(k_ds_flow_gate, dim3(1), dim3(64), 0, ls, (const int*)(d.bad.p + DS_FLOW_ARRIVE), flow_wgs_sent);   // (the chain of this level is resident before the flood)
+          for (int l = first ? 0 : d.eager_n; l < (first ? n1 : lvl); l++) ds_sweep_up_level(ls, D, d, l, eager_r, eager_z);
+        }
+        if (!first || (n1 > 0 && P.la_from < lvl)) { d.eager_n = first ? n1 : lvl; d.eager_r = eager_r; d.eager_z = eager_z; }
+      }
       if (la_in) HIP_OK(hipStreamWaitEvent(s, d.ev_la[LA_REST], 0));
       if (b.max_bp > 0 && be < P.batches.size()) {
         // engine stream: the columns of G under the leading Schur tiles, those tiles; side stream: the other columns of G, the other tiles
@@ -678,6 +703,7 @@ static int direct_factor(tsl_ctx* c, int stop_sn = -1, const char* dump_path = n
     }
   }
   HIP_OK(hipGetLastError());
+  d.flow_wgs_last = flow_wgs_sent;
   d.numeric_valid = true;
   d.have_factor = true;
   d.n_factor++;
@@ -710,7 +736,9 @@ static int direct_apply(tsl_ctx* c, const double* r, double* z) {
   hipStream_t s = c->stream;
   const DirectPlan& P = d.plan;
   const DsDev D = ds_dev(c);
-  for (int l = 0; l < P.n_levels; l++) ds_sweep_up_level(s, D, d, l, r, z);
+  const int l0 = (d.eager_n > 0 && r == d.eager_r && z == d.eager_z) ? d.eager_n : 0;   // (levels swept next to the factorisation, direct_factor)
+  d.eager_n = 0;
+  for (int l = l0; l < P.n_levels; l++) ds_sweep_up_level(s, D, d, l, r, z);
   for (int l = P.n_levels - 2; l >= 0; l--) {   // the top level has no boundary
     const int o0 = P.wl_own_ptr[l], b0 = P.wl_bnd_ptr[l];
     ds_launch_gemv(s, D, d, o0, b0 - o0, 2, (const double*)z, z, P.wl_own_wide.empty() ? -1 : P.wl_own_wide[l]);

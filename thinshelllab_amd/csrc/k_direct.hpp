@@ -641,7 +641,8 @@ __global__ void __launch_bounds__(256) k_ds_gj_finish(DsDev D, int lv0) {
 // a flag that does not come within DS_FLOW_SPINS polls raises bad[DS_FLOW_ABORT] and lets every workgroup run out (the host reports it).
 #define DS_FLOW_MAXF 128
 #define DS_FLOW_ABORT 5
-#define DS_FLOW_SPINS (1 << 22)
+#define DS_FLOW_ARRIVE 7   // bad[DS_FLOW_ARRIVE]: workgroups of the dataflow launches of this factorisation that have STARTED (k_ds_flow_gate waits for a launch to be resident)
+#define DS_FLOW_SPINS (1 << 19)   // (4096 polls back to back, then one per ~2 us: about a second)
 #define DS_FLOW_B 2
 struct DsFlowArgs {
   int nf, epoch;
@@ -655,8 +656,15 @@ TSL_DEV void ds_flow_poll(const int* flag, int epoch, int* abort_w, int* s_dead)
   for (;;) {
     const int v = __hip_atomic_load(flag, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     if (v == epoch) break;
-    if (++spins >= DS_FLOW_SPINS) { __hip_atomic_store(abort_w, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); *s_dead = 1; return; }
+    if (++spins >= DS_FLOW_SPINS) {
+      if (atomicCAS(abort_w, 0, 1) == 0) {   // the first to give up leaves a note for the host's report: workgroups of this factorisation's dataflow launches that had started, this launch's grid, who waited for which flag
+        int* note = abort_w - DS_FLOW_ABORT + 8 + 4 * DS_BADLOG;
+        note[0] = __hip_atomic_load(abort_w - DS_FLOW_ABORT + DS_FLOW_ARRIVE, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); note[1] = (int)gridDim.x; note[2] = (int)blockIdx.x; note[3] = v; note[4] = epoch;
+      }
+      *s_dead = 1; return;
+    }
     if ((spins & 1023) == 0 && __hip_atomic_load(abort_w, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0) { *s_dead = 1; return; }
+    if (spins > 4096) __builtin_amdgcn_s_sleep(64);   // (a flag of the chain comes within microseconds: a wait this long is a launch that is not resident yet -- stop hammering the flag's memory channel)
   }
 }
 TSL_DEV void ds_flow_fetch(double (*T)[DS_T + 1], const double* __restrict__ slot, int tx, int ty) {
@@ -677,6 +685,16 @@ TSL_DEV ds_d4 ds_prod32(const double (*Am)[DS_T + 1], const double (*Bm)[DS_T + 
 #pragma unroll
   for (int kk = 0; kk < DS_T / 4; kk++) acc = __builtin_amdgcn_mfma_f64_16x16x4f64(Am[16 * wi + lr][4 * kk + lk], Bm[4 * kk + lk][16 * wj + lr], acc, 0, 0, 0);
   return acc;
+}
+// One wave that ends when `target` workgroups of this factorisation's dataflow launches have started (or after DS_FLOW_SPINS polls): launched on the look-ahead's
+// side stream in front of the eager sweeps (thousands of small workgroups), so that the chain of the level is resident before they arrive.  (Insurance: the stalls
+// that were measured -- see direct_factor -- were all launches of more workgroups than CUs, which now start with the side stream drained.)
+__global__ void k_ds_flow_gate(const int* arrive, int target) {
+  if (threadIdx.x != 0) return;
+  for (int spins = 0; spins < DS_FLOW_SPINS; spins++) {
+    if (__hip_atomic_load(arrive, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) >= target) return;
+    __builtin_amdgcn_s_sleep(32);
+  }
 }
 template <int B>
 __global__ void __launch_bounds__(256, 2) k_ds_gj_flow(DsDev D, int lv0, DsFlowArgs a, double* __restrict__ X, int* __restrict__ Fl) {
@@ -702,7 +720,7 @@ __global__ void __launch_bounds__(256, 2) k_ds_gj_flow(DsDev D, int lv0, DsFlowA
 #define DS_FLOW_PFLAG(k) (Fp + 32 * (k))
 #define DS_FLOW_RFLAG(i, j) (Fp + 32 * nt + (i) * nt + (j))
 #define DS_FLOW_CFLAG(i, j) (Fp + 32 * nt + nt * nt + (i) * nt + (j))
-  if (threadIdx.x == 0) s_dead = 0;
+  if (threadIdx.x == 0) { s_dead = 0; atomicAdd(D.bad + DS_FLOW_ARRIVE, 1); }
   const bool tl = D.tlog != nullptr && z == 0 && threadIdx.x == 0;
   if (tl && t == 0) D.tlog[192] = wall_clock64();
   if (D.tlog != nullptr && threadIdx.x == 0) atomicMin(&D.tlog[194], wall_clock64());   // first workgroup of the launch to start

@@ -125,12 +125,14 @@ struct DirectSolver {
   int prezero = 1;          // "direct_prezero"
   hipStream_t fstream[2] = {nullptr, nullptr};   // batches of one level run next to each other (direct_factor)
   hipEvent_t ev_ffork = nullptr, ev_fjoin[2] = {nullptr, nullptr};
-  hipEvent_t ev_la[4] = {nullptr, nullptr, nullptr, nullptr};
+  hipEvent_t ev_la[5] = {nullptr, nullptr, nullptr, nullptr, nullptr};
   hipStream_t lastream = nullptr;
-  int la_prio = 1;   // look-ahead of the upper levels: G stored / leading Schur tiles stored (engine stream), other panels of the next level written (side stream)
-  int lookahead = 1;        // "direct_lookahead": the levels of one batch each form the leading block of their Schur complements first and invert the parents' pivot blocks next to the rest (direct_factor)
+  // look-ahead of the upper levels: G stored / leading Schur tiles stored (engine stream), other panels of the next level written (side stream)
+  int eager_n = 0; const double* eager_r = nullptr; double* eager_z = nullptr;   // upward sweeps done next to the factorisation: levels [0, eager_n) of the application (eager_r -> eager_z)
+  int lookahead = 11;       // "direct_lookahead" (bit 1: the upward sweep of the first application next to the chains of the levels below the root; value >> 2: leaf levels swept one level earlier): the levels of one batch each form the leading block of their Schur complements first and invert the parents' pivot blocks next to the rest (direct_factor)
   // "direct_flow": block steps of a batch alone on its level as one persistent dataflow launch (k_ds_gj_flow)
   int device = 0;          // HIP device of the context (tsl_ctx_create)
+  int flow_wgs_last = 0;   // workgroups of the dataflow launches of the last factorisation (the abort report compares it with the number that started)
   int flow = 3, flow_cap = 0, flow_epoch = 0;   // flow_cap: workgroups of k_ds_gj_flow the device holds at once
   int flow_token = 0, flow_token_fd = -1;       // the device's dataflow token (direct_host.hpp): 0 not asked yet, 1 held, -1 refused
   long flow_token_asked = 0;                    // n_factor at the last request

@@ -402,7 +402,7 @@ extern "C" void tsl_ctx_destroy(tsl_ctx* c) {
   if (c->ev_out) (void)hipEventDestroy(c->ev_out);
   for (int k = 0; k < DS_NSIDE; k++) if (c->ds.fstream[k]) { (void)hipStreamSynchronize(c->ds.fstream[k]); (void)hipEventDestroy(c->ds.ev_fjoin[k]); (void)hipStreamDestroy(c->ds.fstream[k]); }
   if (c->ds.ev_ffork) (void)hipEventDestroy(c->ds.ev_ffork);
-  for (int k = 0; k < 4; k++) if (c->ds.ev_la[k]) (void)hipEventDestroy(c->ds.ev_la[k]);
+  for (int k = 0; k < 5; k++) if (c->ds.ev_la[k]) (void)hipEventDestroy(c->ds.ev_la[k]);
   if (c->ds.lastream) { (void)hipStreamSynchronize(c->ds.lastream); (void)hipStreamDestroy(c->ds.lastream); }
   if (c->ds.h_anorm) (void)hipHostFree(c->ds.h_anorm);
   if (c->ds.pin) (void)hipHostFree(c->ds.pin);
@@ -457,7 +457,7 @@ extern "C" int tsl_set_param(tsl_ctx* c, const char* key, double v) {
   else if (k == "direct_flow_token") { if (v == 0) ds_flow_token_release(c->ds); }   // 0: hand the device's dataflow token back (asked for again at the next eligible factorisation)
   else if (k == "direct_gemv_wide_below") c->ds.gemv_wide_below = std::max(0, (int)v);
   else if (k == "direct_g32_below") c->ds.g32_below = std::max(0, (int)v);
-  else if (k == "direct_lookahead") { c->ds.lookahead = v != 0.0; c->ds.la_prio = v != 2.0; }   // (2: the side stream at normal priority -- A/B)
+  else if (k == "direct_lookahead") c->ds.lookahead = (int)v;
   else if (k == "direct_piv_tol") { c->ds.piv_tol = v; c->ds.numeric_valid = false; }
   else if (k == "direct_leaf") { c->ds.leaf = std::max(4, (int)v); c->ds.static_ready = false; c->ds.plan_valid = false; c->ds.numeric_valid = false; }
   else if (k == "gmres_m") c->gmres_m = (int)v;
@@ -1324,7 +1324,7 @@ static int solve_perm(tsl_ctx* c, tsl_solve_stats* st) {
     auto direct_try = [&]() -> int {
       if (!d.numeric_valid) {
         TSL_TRY(direct_plan(c));
-        TSL_TRY(direct_factor(c));
+        TSL_TRY(direct_factor(c, -1, nullptr, c->v_b.p, c->v_x.p));   // (the first pass of direct_refine applies the factors to v_b -> v_x)
       }
       // plain refinement first; systems it does not settle go through the flexible GMRES from scratch
       int rc_g = direct_refine(c, &sd);
@@ -1334,7 +1334,10 @@ static int solve_perm(tsl_ctx* c, tsl_solve_stats* st) {
         int ab = 0;
         HIP_OK(hipMemcpy(&ab, d.bad.p + DS_FLOW_ABORT, sizeof(int), hipMemcpyDeviceToHost));
         if (ab || d.dbg == 21) {   // ("ds_dbg" 21: tests force this branch)
-          fprintf(stderr, "[tsl] k_ds_gj_flow: a workgroup waited in vain for a flag (launch not resident as a whole?): \"direct_flow\" disabled for this context, refactorising\n");
+          int note[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+          (void)hipMemcpy(note, d.bad.p + 8 + 4 * DS_BADLOG, sizeof(note), hipMemcpyDeviceToHost);
+          fprintf(stderr, "[tsl] k_ds_gj_flow: a workgroup waited in vain for a flag (launch not resident as a whole?): \"direct_flow\" disabled for this context, refactorising "
+                  "(workgroup %d of %d gave up; %d of the %d workgroups of the factorisation's dataflow launches had started; flag value %d, epoch %d)\n", note[2], note[1], note[0], d.flow_wgs_last, note[3], note[4]);
           d.flow = 0; d.n_flow_abort++;
           d.numeric_valid = false; d.have_factor = false;   // the factors in place are garbage: direct_factor must not return early
           if (d.prezero_pending) { HIP_OK(hipStreamWaitEvent(c->stream, d.ev_zero, 0)); d.prezero_pending = false; }
