@@ -412,6 +412,8 @@ def roofline(ctx, scene, elapsed, K, stats, args):
     except (OSError, KeyError, ValueError):
         insitu = None
     order = sorted(insitu, key=insitu.get, reverse=True) if insitu and max(insitu.values()) > 0 else sorted(share, key=share.get, reverse=True)
+    # a class that did not run in THIS run (no launches in the replays: e.g. the dataflow kernel after the context lost its dataflow path to an aborted launch) cannot lead the line
+    order = [k for k in order if cls[k]["launches"] > 0 and cls[k]["us_per_launch"] > 0] or [max(share, key=share.get)]
     dom = order[0]
 
     def class_roof(k):
@@ -655,6 +657,8 @@ def main():
                    "solver_fallbacks": {"forward": stats["fwd_fallback"], "adjoint": stats["adj_fallback"]},
                    "solves_accepted_at_attainable_accuracy": {"forward": stats["fwd_attained"], "adjoint": stats["adj_attained"]},
                    "first_passes_accepted_on_backward_error": _berr_counters(ctx),
+                   "dataflow_launches": {"launched": int(ctx.direct_counters()["flow_launches"]), "lost": int(ctx.direct_counters()["flow_aborts"]),
+                                         "note": "k_ds_gj_flow launches since context creation; lost = launches that ran into their poll limit (the solve then refactorises on the launch-per-block-step path and the context keeps that path: slower, same bits)"},
                    "max_rel_residual_fwd": stats["max_res_fwd"], "max_rel_residual_adjoint": stats["max_res_adj"], "max_backward_error_adjoint": stats["max_be_adj"],
                    "adjoint_solve_methods": {str(k): v for k, v in stats["methods"].items()}},
     })
