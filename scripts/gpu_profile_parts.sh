@@ -15,7 +15,7 @@ trace)
   rocprofv3 --kernel-trace --stats --output-format csv -d gpurun_out/prof -o ${TAG}_bench -- python bench.py --workload $WL --steps 20 --warmup 5 --no-cpu-baseline > gpurun_out/prof/${TAG}_bench_stdout.log 2>&1
   tail -1 gpurun_out/prof/${TAG}_bench_stdout.log | cut -c1-300
   F=$(find gpurun_out/prof -name "${TAG}_bench_kernel_trace.csv" | head -1)
-  python scripts/trace_timeline.py $F -200 full > gpurun_out/prof/${TAG}_iteration_timeline.txt 2>&1
+  python scripts/trace_timeline.py $F -400 full > gpurun_out/prof/${TAG}_iteration_timeline.txt 2>&1
   python scripts/trace_gaps.py $F > gpurun_out/prof/${TAG}_gap_table.txt 2>&1
   rm -f $F
   head -14 gpurun_out/prof/${TAG}_iteration_timeline.txt ;;

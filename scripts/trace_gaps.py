@@ -3,10 +3,11 @@ the kernels' busy intervals (all streams), the idle remainder, and the idle time
 usage: trace_gaps.py <kernel_trace.csv> [first] [n]"""
 import csv, sys, collections
 rows = list(csv.DictReader(open(sys.argv[1])))
-first = int(sys.argv[2]) if len(sys.argv) > 2 else -60
+first = int(sys.argv[2]) if len(sys.argv) > 2 else 0   # 0: a window in the MIDDLE of the run (the tail of the trace holds bench.py's class replays and parity legs, not time steps)
 n = int(sys.argv[3]) if len(sys.argv) > 3 else 50
 rows.sort(key=lambda r: int(r["Start_Timestamp"]))
-marks = [i for i, r in enumerate(rows) if r["Kernel_Name"].startswith("k_ds_assemble_level") and not rows[i - 1]["Kernel_Name"].startswith("k_ds_")]
+marks = [i for i, r in enumerate(rows) if r["Kernel_Name"].startswith("k_ds_assemble_level") and "k_ds_" not in rows[i - 1]["Kernel_Name"]]
+if first == 0: first = max(0, len(marks) // 2 - n // 2)
 a, b = marks[first], marks[first + n]
 t0, t1 = int(rows[a]["Start_Timestamp"]), int(rows[b]["Start_Timestamp"])
 end = t0; endname = "start"; busy = 0

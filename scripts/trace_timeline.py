@@ -5,7 +5,7 @@ import csv, sys, collections
 rows = list(csv.DictReader(open(sys.argv[1])))
 which = int(sys.argv[2]) if len(sys.argv) > 2 else -20
 rows.sort(key=lambda r: int(r["Start_Timestamp"]))
-marks = [i for i, r in enumerate(rows) if r["Kernel_Name"].startswith("k_ds_assemble_level") and not rows[i - 1]["Kernel_Name"].startswith("k_ds_")]   # first launch of a factorisation
+marks = [i for i, r in enumerate(rows) if r["Kernel_Name"].startswith("k_ds_assemble_level") and "k_ds_" not in rows[i - 1]["Kernel_Name"]]   # first launch of a factorisation
 a, b = marks[which], marks[which + 1]
 t0 = int(rows[a]["Start_Timestamp"])
 busy = collections.defaultdict(float); cnt = collections.Counter()
