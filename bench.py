@@ -456,10 +456,15 @@ def roofline(ctx, scene, elapsed, K, stats, args):
                 if calls:
                     us = tot_ns / calls * 1e-3
                     r["avg_launch_us_rocprof"] = us
+                    # per FACTORISATION where the trace says how many it holds (the look-ahead issues the Schur / G launches of the upper levels in two parts and the sweeps
+                    # of a first application on two streams: in-situ launch averages no longer compare with this run's whole-batch replays, totals per factorisation do)
+                    nf_tr = ks.get("factorisations")
+                    us_cmp = (tot_ns * 1e-3 / nf_tr / max(v["launches"], 1)) if nf_tr else us   # in-situ time of the class per factorisation, per replay launch
+                    r["in_situ_us_per_factorisation"] = (tot_ns * 1e-3 / nf_tr) if nf_tr else None
                     if flop_class:
-                        r["frac_in_situ"] = v["flops_per_launch"] / (us * 1e-6) / 1e12 / F64_MFMA_PEAK_TF
+                        r["frac_in_situ"] = v["flops_per_launch"] / (us_cmp * 1e-6) / 1e12 / F64_MFMA_PEAK_TF
                     else:
-                        r["frac_in_situ"] = v["bytes_per_launch"] / (us * 1e-6) / 1e9 / HBM_PEAK_GBS
+                        r["frac_in_situ"] = v["bytes_per_launch"] / (us_cmp * 1e-6) / 1e9 / HBM_PEAK_GBS
                     r["rocprof_source"] = (f"kernel trace of profile set {ks.get('tag', '?')} (commit {ks.get('commit', '?')}; {ks.get('command', '')}): {calls} launches of {' + '.join(pat)}; "
                                            "a constant read from profiles/, not a measurement of this run")
         except (OSError, KeyError, ValueError):

@@ -17,6 +17,7 @@ trace)
   F=$(find gpurun_out/prof -name "${TAG}_bench_kernel_trace.csv" | head -1)
   python scripts/trace_timeline.py $F -400 full > gpurun_out/prof/${TAG}_iteration_timeline.txt 2>&1
   python scripts/trace_gaps.py $F > gpurun_out/prof/${TAG}_gap_table.txt 2>&1
+  python scripts/trace_counts.py $F gpurun_out/prof/${TAG}_trace_counts.json
   rm -f $F
   head -14 gpurun_out/prof/${TAG}_iteration_timeline.txt ;;
 lines)

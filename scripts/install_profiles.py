@@ -24,7 +24,11 @@ shutil.copy(src + f"{TAG}_bench_kernel_stats.csv", dst + f"{TAG}_{WL}_kernel_sta
 # the in-situ launch durations bench.py quotes next to its own replays (roofline.avg_launch_us_rocprof): name -> calls, total ns, with the set and commit
 with open(dst + f"latest_{WL}_kernel_stats.json", "w") as fh:
     rows_ = list(csv.DictReader(open(dst + f"{TAG}_{WL}_kernel_stats.csv")))
-    json.dump({"tag": TAG, "commit": COMMIT, "command": "rocprofv3 --kernel-trace --stats -- python bench.py --steps 20 --warmup 5 --no-cpu-baseline",
+    try:
+        n_fact = json.load(open(src + f"{TAG}_trace_counts.json"))["factorisations"]
+    except (OSError, KeyError, ValueError):
+        n_fact = None
+    json.dump({"tag": TAG, "commit": COMMIT, "factorisations": n_fact, "command": "rocprofv3 --kernel-trace --stats -- python bench.py --steps 20 --warmup 5 --no-cpu-baseline",
                "kernels": {r["Name"]: {"calls": int(r["Calls"]), "total_ns": float(r["TotalDurationNs"])} for r in rows_}}, fh, indent=0)
 open(dst + f"{TAG}_{WL}_bench_profiled.json", "w").write(last_json_line(src + f"{TAG}_bench_stdout.log"))
 for s, d in ((f"{TAG}_full_default.json", f"{TAG}_{WL}_bench_default.json"), (f"{TAG}_full_driver.json", f"{TAG}_{WL}_bench_driver_cmd.json")):
