@@ -390,6 +390,8 @@ def roofline(ctx, scene, elapsed, K, stats, args):
     for k in names:
         try:
             cls[k] = ctx.bench_direct(k, 10)
+            if k == 5:   # the replays invert their own output again and again: tiles that trip the inversion's guards there take the guarded form as well (none do in the run itself)
+                cls[k]["tiles_guarded_in_replays"] = int(ctx.direct_counters().get("tiles_guarded", 0))
         except Exception as e:
             print(f"roofline: tsl_bench_direct({k}) failed: {e!r}", file=sys.stderr)
             return None, None
@@ -494,7 +496,7 @@ def roofline(ctx, scene, elapsed, K, stats, args):
                                + ", ".join(f"{names[k].split(' ')[0]} {insitu[k] * 1e-6:.0f} ms" for k in sorted(insitu, key=insitu.get, reverse=True)[:3])) if insitu and max(insitu.values()) > 0
                               else "this run's replays (classes_us_per_newton_iteration)",
                "classes_us_per_newton_iteration": {names[k].split(" ")[0]: share[k] for k in share},
-               "classes": {names[k].split(" ")[0]: {"avg_launch_us": cls[k]["us_per_launch"], "launches_per_factorization": cls[k]["launches"],
+               "classes": {names[k].split(" ")[0]: {"avg_launch_us": cls[k]["us_per_launch"], "launches_per_factorization": cls[k]["launches"], **({"tiles_guarded_in_replays": cls[k]["tiles_guarded_in_replays"]} if "tiles_guarded_in_replays" in cls[k] else {}),
                                                     "flops_per_launch": cls[k]["flops_per_launch"], "bytes_per_launch": cls[k]["bytes_per_launch"],
                                                     "TFLOPs": cls[k]["flops_per_launch"] / max(cls[k]["us_per_launch"], 1e-9) / 1e6,
                                                     "GBs": cls[k]["bytes_per_launch"] / max(cls[k]["us_per_launch"], 1e-9) / 1e3} for k in cls},

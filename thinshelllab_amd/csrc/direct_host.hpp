@@ -772,6 +772,14 @@ static int direct_bench(tsl_ctx* c, int cls, int reps, double* out) {
     HIP_OK(hipMemsetAsync(d.garena.p, 0x3F, (size_t)P.garena * sizeof(double), s));
   }
   const DsDev D = ds_dev(c);
+  if (cls == 0 || cls == 3 || cls == 5) {
+    // the inversions are replayed in place, each on the output of the one before: on I + 4.8e-4 (ones) -- diagonally dominant up to 2000 pivots, as is its inverse -- no tile trips
+    // the inversion's guards.  (Round 6: the replays used to run on the REAL factors, and the inverse of an inverse of cfg4's contact-stiff pivot blocks sent nearly every
+    // tile through the guarded form as well: 137 us per dataflow launch in the replays against 100 on these data and 97-113 in situ.)
+    HIP_OK(hipMemsetAsync(d.arena.p, 0x3F, (size_t)P.arena * sizeof(double), s));
+    hipLaunchKernelGGL(k_ds_bench_diag, dim3((unsigned)P.fr.size()), dim3(256), 0, s, D);
+    d.have_factor = false;
+  }
   double flops = 0, bytes = 0;
   long launches = 0;
   // entries of the children's Schur complements that land in the boundary part (-> S) / in the panels of front f

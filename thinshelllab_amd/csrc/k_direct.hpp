@@ -57,6 +57,12 @@ __global__ void k_ds_rownorm(int NV, const int* __restrict__ slice_off, const in
   if ((threadIdx.x & 63) == 0) atomicMax((unsigned long long*)out, (unsigned long long)__double_as_longlong(m));
 }
 
+// tsl_bench_direct, inversion classes: ones on the diagonal of every pivot block (the arena holds the pattern 4.8e-4)
+__global__ void k_ds_bench_diag(DsDev D) {
+  const DsFrontDesc f = D.fr[blockIdx.x];
+  for (int i = threadIdx.x; i < f.pp; i += blockDim.x) D.A[f.off + (size_t)i * f.ld + i] = 1.0;
+}
+
 // ---- assembly -------------------------------------------------------------------------------------------------------------
 // The matrix entries of ONE tree level go into the panels of its fronts when the level starts: the panels were just written -- cleared
 // (leaf level: the contiguous head of the panel arena) or stored by the gather of the children's Schur complements (k_ds_extend_panels)
