@@ -117,9 +117,10 @@ int tsl_set_stream(tsl_ctx* ctx, void* hip_stream);
  *   LDS kernel would take; 0: one launch per 32 pivots -- the same bits either way), "direct_flow_token" (0: hand the device's dataflow token back),
  *   "direct_small_rounds" (2: rounds of the chip a batch may take in the LDS kernel k_ds_inv_small), "direct_g32_below" (1100: G = W F12 of a batch
  *   with fewer 64 x 64 tiles than this uses 32 x 32 tiles), "direct_gemv_wide_below" (300: a sweep launch of fewer 16-row chunks than this runs four
- *   workgroups per chunk), "direct_lookahead" (11; bit 0: on the tree levels of one batch each the leading block of every Schur complement is formed first and
+ *   workgroups per chunk), "direct_lookahead" (103; bit 0: on the tree levels of one batch each the leading block of every Schur complement is formed first and
  *   the parents' pivot blocks are gathered and inverted next to the rest of the Schur launch on a low-priority second stream; bit 1: the upward sweep of the solve's
- *   first application runs on that stream next to the chains below the root, value >> 2 leaf levels of it one level earlier; 0: one after the other -- the same bits).
+ *   first application runs on that stream next to the chains of the last three levels -- levels [0, c0) next to the third from the top, [c0, c1) next to the one below the
+ *   root, [c1, root) next to the root's, c0 = (value >> 2) & 7, c1 = (value >> 5) & 15 (0: none next to the root's); 0: one after the other -- the same bits).
  *   (Fixed since round 6: batches of >= 64 fronts launch their GEMM tiles with the XCD-aware map, the leaf panels of the next
  *   factorisation are cleared on a side stream after each solve of a time step, 64 plans of earlier constraint sets are kept.)
  *   "mg" (-1 auto / 0 / 1), "mg_coarse_exact", "mg_dense_nodes" (largest multigrid level solved exactly; -1 = chosen per time step), "body_inv"

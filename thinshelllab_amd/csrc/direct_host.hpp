@@ -531,6 +531,7 @@ static int direct_factor(tsl_ctx* c, int stop_sn = -1, const char* dump_path = n
   else for (const auto& r : P.leaf_ranges) HIP_OK(hipMemsetAsync(d.arena.p + r.first, 0, (size_t)r.second * sizeof(double), s));
   HIP_OK(hipMemsetAsync(d.bad.p, 0, 8 * sizeof(int), s));
   // (a persistent dataflow launch runs next to ordinary launches of sibling batches -- those end by themselves --, never next to a second one)
+  bool swept_at_root = false;
   int flow_wgs_sent = 0;   // workgroups of the dataflow launches of this factorisation so far (bad[DS_FLOW_ARRIVE] counts those that started)
   auto invert_batch = [&](const DsBatch& b, hipStream_t bs, bool& flow_free) {
     const int lv0 = b.first, nf = b.count;
@@ -618,17 +619,23 @@ static int direct_factor(tsl_ctx* c, int stop_sn = -1, const char* dump_path = n
         HIP_OK(hipStreamWaitEvent(s, d.ev_la[LA_DRAIN], 0));
       }
       invert_batch(b, s, flow_free);
-      if (la_in && eager_r != nullptr && (d.lookahead & 2) && lvl >= P.n_levels - 3 && lvl <= P.n_levels - 2) {
+      if (la_in && eager_r != nullptr && (d.lookahead & 2) && lvl >= P.n_levels - 3) {
         // (the side stream has this level's F12 / F21 behind it and, through LA_A, every inversion below; the root's LA_REST, which the engine stream waits for, follows the sweeps)
-        // in two parts: the lowest levels -- most of the bytes -- next to the chain of the third level from the top, where the side stream has ~0.1 ms of slack before its
-        // Schur tiles are needed; the others next to the chain below the root
-        const int n1 = std::min(d.lookahead >> 2, P.n_levels - 3);   // (default 2: 194.1 / 192.0 / 191.8 / 192.8 ms per step with 0 / 1 / 2 / 3 levels in the first part)
-        const bool first = lvl == P.n_levels - 3;
-        if (!first || (n1 > 0 && P.la_from < lvl)) {
+        // in up to three parts: levels [0, c0) next to the chain of the third level from the top, [c0, c1) next to the chain below the root, [c1, root) next to the root's
+        // chain.  Every part sits behind a gate (k_ds_flow_gate): the level's own chain is resident before the part's workgroups arrive; the root's launch (more workgroups
+        // than CUs) also starts with the side stream drained (above), so that nothing of an earlier part is in flight when it is dispatched.
+        // (cfg4, same-box pairs of 20 + 5 steps: c0 / c1 = 2 / none 193.0, 0 / 3 191.6, 1 / 3 191.5, 1 / 2 193.1, 1 / 5 193.1, 2 / 4 191.8 ms per step; 420 time steps of stress with 1 / 3: no stall)
+        const int top = P.n_levels - 1;
+        const int c0 = std::min((d.lookahead >> 2) & 7, top - 2);
+        const int c1r = (d.lookahead >> 5) & 15, c1 = c1r == 0 ? top - 1 : std::min(std::max(c1r, c0), top - 1);
+        const int stage = lvl - (top - 2);   // 0, 1, 2
+        const int lo = stage == 0 ? 0 : stage == 1 ? c0 : c1, hi = stage == 0 ? c0 : stage == 1 ? c1 : (c1r == 0 ? c1 : top);
+        if (hi > lo && lo == d.eager_n && (stage > 0 || P.la_from < lvl)) {
           hipLaunchKernelGGL(k_ds_flow_gate, dim3(1), dim3(64), 0, ls, (const int*)(d.bad.p + DS_FLOW_ARRIVE), flow_wgs_sent);   // (the chain of this level is resident before the flood)
-          for (int l = first ? 0 : d.eager_n; l < (first ? n1 : lvl); l++) ds_sweep_up_level(ls, D, d, l, eager_r, eager_z);
+          for (int l = lo; l < hi; l++) ds_sweep_up_level(ls, D, d, l, eager_r, eager_z);
+          d.eager_n = hi; d.eager_r = eager_r; d.eager_z = eager_z;
+          if (stage == 2) { HIP_OK(hipEventRecord(d.ev_la[LA_DRAIN], ls)); swept_at_root = true; }   // (joined below: the application goes on from level eager_n on the engine stream)
         }
-        if (!first || (n1 > 0 && P.la_from < lvl)) { d.eager_n = first ? n1 : lvl; d.eager_r = eager_r; d.eager_z = eager_z; }
       }
       if (la_in) HIP_OK(hipStreamWaitEvent(s, d.ev_la[LA_REST], 0));
       if (b.max_bp > 0 && be < P.batches.size()) {
@@ -704,6 +711,7 @@ static int direct_factor(tsl_ctx* c, int stop_sn = -1, const char* dump_path = n
       HIP_OK(hipMemset(d.tlog.p + 194, 0xff, sizeof(unsigned long long)));
     }
   }
+  if (swept_at_root) HIP_OK(hipStreamWaitEvent(s, d.ev_la[LA_DRAIN], 0));
   HIP_OK(hipGetLastError());
   d.flow_wgs_last = flow_wgs_sent;
   d.numeric_valid = true;

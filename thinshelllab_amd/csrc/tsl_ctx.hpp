@@ -129,7 +129,8 @@ struct DirectSolver {
   hipStream_t lastream = nullptr;
   // look-ahead of the upper levels: G stored / leading Schur tiles stored (engine stream), other panels of the next level written (side stream)
   int eager_n = 0; const double* eager_r = nullptr; double* eager_z = nullptr;   // upward sweeps done next to the factorisation: levels [0, eager_n) of the application (eager_r -> eager_z)
-  int lookahead = 11;       // "direct_lookahead" (bit 1: the upward sweep of the first application next to the chains of the levels below the root; value >> 2: leaf levels swept one level earlier): the levels of one batch each form the leading block of their Schur complements first and invert the parents' pivot blocks next to the rest (direct_factor)
+  int lookahead = 103;      // "direct_lookahead" (bit 1: the upward sweep of the first application next to the chains of the last three levels; (value >> 2) & 7 = c0, (value >> 5) & 15 = c1:
+                            // levels [0, c0) next to the third chain from the top, [c0, c1) next to the one below the root, [c1, root) next to the root's (c1 = 0: none there); default c0 = 1, c1 = 3): the levels of one batch each form the leading block of their Schur complements first and invert the parents' pivot blocks next to the rest (direct_factor)
   // "direct_flow": block steps of a batch alone on its level as one persistent dataflow launch (k_ds_gj_flow)
   int device = 0;          // HIP device of the context (tsl_ctx_create)
   int flow_wgs_last = 0;   // workgroups of the dataflow launches of the last factorisation (the abort report compares it with the number that started)
