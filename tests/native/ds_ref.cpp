@@ -157,3 +157,65 @@ extern "C" int dsref_plan_stats(int NV, const int* row_ptr, const int* col, int 
   out[0] = P.sym.n_sn; out[1] = P.n_levels; out[2] = (double)P.batches.size(); out[3] = steps; out[4] = P.flops; out[5] = (double)P.arena * 8; out[6] = solve_bytes;
   return 0;
 }
+
+// The tables of the look-ahead (DirectPlan: DsFrontDesc.lead, blk_lmid, cgr_lmid, la_from), checked against their definitions with plain loops.
+// out: {fronts with a parent, violations of the lead rule, blocks listed, blocks on the wrong side of blk_lmid, contact groups, groups on the wrong side of cgr_lmid,
+//       la_from, levels, levels >= la_from that have more than one batch}
+extern "C" int dsref_check_lookahead(int NV, const int* row_ptr, const int* col, int n_grids, const int* grids, int n_blocks, const int* blocks, int n_cons, const int* cons, int leaf,
+                                     double* out) {
+  std::vector<std::vector<int>> adj(NV);
+  for (int r = 0; r < NV; r++) adj[r].assign(col + row_ptr[r], col + row_ptr[r + 1]);
+  std::vector<int> rp(row_ptr, row_ptr + NV + 1);
+  std::vector<DsGrid> G; std::vector<DsBlock> B;
+  for (int i = 0; i < n_grids; i++) G.push_back({grids[3 * i], grids[3 * i + 1], grids[3 * i + 2]});
+  for (int i = 0; i < n_blocks; i++) B.push_back({blocks[2 * i], blocks[2 * i + 1]});
+  DirectPlan P;
+  P.sym.build_partition(NV, adj, G, B, leaf);
+  const int rc = P.build(adj, rp, cons, n_cons);
+  if (rc) return rc;
+  long with_parent = 0, lead_viol = 0, nblk = 0, blk_viol = 0, ngrp = 0, grp_viol = 0, multi = 0;
+  // lead: the child's boundary dofs that are own dofs of the parent are exactly its FIRST `lead` boundary dofs (the table over the parent's dofs is monotone)
+  for (int s = 0; s < P.sym.n_sn; s++) {
+    const DsFrontDesc& f = P.fr[s];
+    if (f.parent < 0) continue;
+    with_parent++;
+    const DsFrontDesc& pf = P.fr[f.parent];
+    std::vector<int> where(f.b, -1);   // boundary dof of the child -> local dof of the parent
+    for (int d = 0; d < pf.ld; d++) { const int cb = P.pmap[f.pmap_off + d]; if (cb >= 0) { if (cb >= f.b || where[cb] >= 0) lead_viol++; else where[cb] = d; } }
+    int n_own = 0;
+    for (int i = 0; i < f.b; i++) {
+      if (where[i] < 0) { lead_viol++; continue; }
+      const bool own = where[i] < pf.pp;
+      if (own) n_own++;
+      if (own != (i < f.lead)) lead_viol++;
+    }
+    if (n_own != f.lead) lead_viol++;
+  }
+  // block lists: [blk_lptr[l], blk_lmid[l]) lie inside the pivot block F11 of a front of level l, [blk_lmid[l], blk_lptr[l + 1]) in F12 or F21 of one
+  auto region_of = [&](long long dst, int ld, int l) -> int {   // 0 F11, 1 F12 / F21, -1 nowhere on level l
+    for (int q = P.level_ptr[l]; q < P.level_ptr[l + 1]; q++) {
+      const DsFrontDesc& f = P.fr[P.level_sn[q]];
+      if (dst >= f.off && dst < f.off + (long long)f.pp * f.ld) { if (ld != f.ld) return -1; return (dst - f.off) % f.ld < f.pp ? 0 : 1; }
+      if (dst >= f.off21 && dst < f.off21 + (long long)f.bp * f.pp) return ld == f.pp ? 1 : -1;
+    }
+    return -1;
+  };
+  for (int l = 0; l < P.n_levels; l++) {
+    if (P.blk_lmid[l] < P.blk_lptr[l] || P.blk_lmid[l] > P.blk_lptr[l + 1]) blk_viol++;
+    for (int k = P.blk_lptr[l]; k < P.blk_lptr[l + 1]; k++) {
+      const int q = P.blk_q[k];
+      nblk++;
+      if (region_of(P.blk_dst[q], P.blk_ld[q], l) != (k < P.blk_lmid[l] ? 0 : 1)) blk_viol++;
+    }
+    if (n_cons > 0) {
+      if (P.cgr_lmid[l] < P.cgr_lptr[l] || P.cgr_lmid[l] > P.cgr_lptr[l + 1]) grp_viol++;
+      for (int g = P.cgr_lptr[l]; g < P.cgr_lptr[l + 1]; g++) { ngrp++; if (region_of(P.cgr_dst[g], P.cgr_ld[g], l) != (g < P.cgr_lmid[l] ? 0 : 1)) grp_viol++; }
+    }
+  }
+  std::vector<int> nb(P.n_levels, 0);
+  for (const DsBatch& b : P.batches) nb[b.level]++;
+  for (int l = 0; l < P.n_levels; l++) if (l >= P.la_from && nb[l] != 1) multi++;
+  out[0] = (double)with_parent; out[1] = (double)lead_viol; out[2] = (double)nblk; out[3] = (double)blk_viol; out[4] = (double)ngrp; out[5] = (double)grp_viol;
+  out[6] = P.la_from < P.n_levels ? (double)P.la_from : -1.0; out[7] = (double)P.n_levels; out[8] = (double)multi;
+  return 0;
+}

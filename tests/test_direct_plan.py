@@ -123,3 +123,24 @@ def test_multifrontal_plan_matches_sparse_lu(dsref, N, M, n_body, n_cons, leaf, 
     # parent reads it -- the reference run starts from a NaN Schur arena, a value read before it was stored would poison x), and the
     # parents did gather something
     assert stats[5] == 0 and stats[6] > 0, stats
+
+
+@pytest.mark.parametrize("N,M,n_body,n_cons,leaf", [(24, 17, 9, 14, 12), (33, 40, 20, 30, 16), (64, 48, 12, 40, 16), (20, 20, 0, 10, 32)])
+def test_lookahead_tables_follow_their_definitions(dsref, N, M, n_body, n_cons, leaf):
+    """The host tables of the look-ahead (direct_plan.hpp, round 6): DsFrontDesc.lead -- the boundary dofs of a front that are OWN dofs of its parent are exactly its first
+    `lead` boundary dofs (so the leading lead x lead block of S is all the parent's pivot block receives) --, the level-ordered block list and the contact groups with
+    the entries inside F11 first (blk_lmid, cgr_lmid), and la_from: every level from there on is one batch."""
+    rng = np.random.default_rng(7 * N + M)
+    NV, ncloth, row_ptr, col, vals, cons, conH, A = build_system(N, M, n_body, n_cons, rng, False)
+    grids = np.array([0, N, M], np.int32)
+    blocks = np.array([ncloth, n_body], np.int32)
+    out = np.zeros(9)
+    dsref.dsref_check_lookahead.restype = C.c_int
+    rc = dsref.dsref_check_lookahead(NV, row_ptr.ctypes.data_as(C.c_void_p), col.ctypes.data_as(C.c_void_p), 1, grids.ctypes.data_as(C.c_void_p),
+                                     1 if n_body else 0, blocks.ctypes.data_as(C.c_void_p), n_cons, cons.ctypes.data_as(C.c_void_p), leaf, out.ctypes.data_as(C.c_void_p))
+    assert rc == 0
+    with_parent, lead_viol, nblk, blk_viol, ngrp, grp_viol, la_from, levels, multi = out
+    assert with_parent > 0 and lead_viol == 0, out
+    assert nblk == len(col) and blk_viol == 0, out          # every block of the pattern is listed once, on the right side of its level's mid pointer
+    assert (ngrp > 0) == (n_cons > 0) and grp_viol == 0, out
+    assert multi == 0 and (la_from < 0 or 1 <= la_from <= levels - 2), out
