@@ -107,6 +107,11 @@ def test_direct_lookahead_keeps_the_bits(N, M, leaf):
             sols[la] = x.cpu().numpy()
     for la in (1, 3, 11, 67, 103):
         assert np.array_equal(sols[0], sols[la]), (la, np.abs(sols[0] - sols[la]).max())
+    # ... and with the chains on the launch-per-block-step path (a context without the device's dataflow token): the look-ahead and the eager sweep run all the same
+    ctx.set_param("direct_flow", 0); ctx.set_param("direct_lookahead", 103)
+    s.compute_residual_and_Hessian(spd=True)
+    x, st = ctx.solve(b.clone())
+    assert st["flag"] == 0 and np.array_equal(x.cpu().numpy(), sols[0])
 
 
 @pytest.mark.parametrize("N,M,leaf", [(96, 96, 64), (70, 33, 16)])
