@@ -583,7 +583,9 @@ static int direct_factor(tsl_ctx* c, int stop_sn = -1, const char* dump_path = n
   //   side stream:        (after G_l) [S_l other tiles], gather + entries of F12 / F21 of level l + 1, ...
   // Every tile / panel entry is the same arithmetic whichever launch forms it: the factors keep their bits.  The persistent inversion launch next to the Schur tiles
   // is safe: the GEMM workgroups wait for nothing and end by themselves, the inversion's become resident as they drain.
-  const bool la_on = (d.lookahead & 1) && stop_sn < 0 && !P.blk_lmid.empty() && P.la_from < P.n_levels;
+  // (only in the context that holds the device's dataflow token: the drain rule and the gate below protect THIS context's persistent launches from its own side stream; the
+  // low-priority workgroups of a context without the token would arrive next to the token holder's launches unguarded)
+  const bool la_on = (d.lookahead & 1) && stop_sn < 0 && !P.blk_lmid.empty() && P.la_from < P.n_levels && ds_flow_token_held(d);
   if (la_on) TSL_TRY(side_streams());
   hipStream_t ls = d.lastream;
   enum { LA_W = 0, LA_GA = 1, LA_A = 2, LA_REST = 3, LA_DRAIN = 4 };   // engine stream: W stored, leading columns of G stored, leading Schur tiles stored; side stream: F12 / F21 of the next level written
