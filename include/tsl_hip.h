@@ -129,8 +129,8 @@ int tsl_set_stream(tsl_ctx* ctx, void* hip_stream);
  *   (Element gradients / blocks and contact rows go to staging slots and records and are summed by gather kernels in a fixed order, constraint lists are
  *   compacted by scan, energies and dot products joined from per-workgroup partials: no f64 atomics on the step and adjoint path, two runs give the same
  *   bits.  There is no switch: the scattered-atomics assembly of rounds 1-3 and its "deterministic" key are gone.)
- *  Diagnostics: "verbose" (1 phase times per step, 2 plans, 3 batches, 4 Newton iterations, 5 refinement passes), "ds_dbg" (21: force the dataflow-abort
- *   branch, tests; 30: device-clock trace of a dataflow chain), "ds_bench_batch" (tsl_bench_direct on one batch).
+ *  Diagnostics: "verbose" (1 phase times per step, 2 plans, 3 batches, 4 Newton iterations, 5 refinement passes), "ds_dbg" (21 / 22: force the dataflow-abort
+ *   branch, tests -- 22 with the rule that a first loss takes only the look-ahead away; 30: device-clock trace of a dataflow chain), "ds_bench_batch" (tsl_bench_direct on one batch).
  * The experiment switches of rounds 1-4 (factor lagging, alternative GEMM / Schur tilings, one-lane contact and 16-lane element assembly, PCG warm
  * start, ...) are gone with the code they selected; the measurements that retired them are in profiles/README.md and DESIGN.md section 9. */
 int tsl_set_param(tsl_ctx* ctx, const char* key, double value);

@@ -163,6 +163,34 @@ def test_direct_dataflow_abort_refactorises_on_block_step_path():
     assert ctx.direct_counters()["flow_launches"] == c1["flow_launches"] and st["flag"] == 0
 
 
+def test_first_lost_dataflow_launch_costs_the_lookahead_only():
+    """Graceful degradation (round 6): the first dataflow launch a context loses while it runs the look-ahead takes the LOOK-AHEAD away -- side-stream work arriving
+    while a persistent launch is still being dispatched is the one cause known inside a process -- and keeps the dataflow path; the next loss takes the dataflow path.
+    "ds_dbg" 22 forces the abort branch after a converged solve; the answers stay right throughout."""
+    import scipy.sparse.linalg as spl
+    s = _drape(160, 96, 5e-5, seed=8)
+    ctx = s._ensure_ctx()
+    ctx.set_param("direct", 1); ctx.set_param("direct_leaf", 16)
+    s.compute_residual_and_Hessian(spd=True)
+    b = s.F.to_torch().clone()
+    xs = spl.splu(ctx.operator_csr().tocsc()).solve(b.cpu().numpy())
+    x, st = ctx.solve(b.clone())
+    n0 = ctx.direct_counters()["flow_launches"]
+    assert n0 > 0
+    for k in (1, 2):
+        s.compute_residual_and_Hessian(spd=True)
+        ctx.set_param("ds_dbg", 22)
+        x, st = ctx.solve(b.clone())
+        ctx.set_param("ds_dbg", 0)
+        assert ctx.direct_counters()["flow_aborts"] == k and st["flag"] == 0 and rel_err(x.cpu().numpy(), xs) < 1e-9, (k, st)
+        n1 = ctx.direct_counters()["flow_launches"]
+        s.compute_residual_and_Hessian(spd=True)
+        x, st = ctx.solve(b.clone())
+        n2 = ctx.direct_counters()["flow_launches"]
+        assert st["flag"] == 0 and rel_err(x.cpu().numpy(), xs) < 1e-9
+        assert (n2 > n1) == (k == 1), (k, n1, n2)      # after the first loss the chains still run as dataflow launches, after the second they do not
+
+
 def test_direct_wide_sweep_kernel_agrees():
     """"direct_gemv_wide_below": the sweep launches of the upper levels with four narrow workgroups per chunk (k_ds_gemv_wide) against the
     16-row kernel everywhere and against the narrow kernel everywhere"""

@@ -1330,18 +1330,26 @@ static int solve_perm(tsl_ctx* c, tsl_solve_stats* st) {
       int rc_g = direct_refine(c, &sd);
       if (rc_g == 0 && sd.flag != 1) { const int it0 = sd.iters; sd = *st; c->last_xmax_valid = false; rc_g = gmres(c, &sd, true); sd.iters += it0; }
       if (rc_g) return -1;
-      if ((sd.flag != 1 || d.dbg == 21) && d.flow && d.n_flow > 0) {   // a dataflow launch that lost a flag leaves garbage factors: say so, go back to the launch-per-block-step path
+      if ((sd.flag != 1 || d.dbg == 21 || d.dbg == 22) && d.flow && d.n_flow > 0) {   // a dataflow launch that lost a flag leaves garbage factors: say so, go back to the launch-per-block-step path
         int ab = 0;
         HIP_OK(hipMemcpy(&ab, d.bad.p + DS_FLOW_ABORT, sizeof(int), hipMemcpyDeviceToHost));
-        if (ab || d.dbg == 21) {   // ("ds_dbg" 21: tests force this branch)
+        if (ab || d.dbg == 21 || d.dbg == 22) {   // ("ds_dbg" 21 / 22: tests force this branch; 21 as a context without the look-ahead would take it)
           int note[8] = {0, 0, 0, 0, 0, 0, 0, 0};
           (void)hipMemcpy(note, d.bad.p + 8 + 4 * DS_BADLOG, sizeof(note), hipMemcpyDeviceToHost);
-          fprintf(stderr, "[tsl] k_ds_gj_flow: a workgroup waited in vain for a flag (launch not resident as a whole?): \"direct_flow\" disabled for this context, refactorising "
-                  "(workgroup %d of %d gave up; %d of the %d workgroups of the factorisation's dataflow launches had started; flag value %d, epoch %d)\n", note[2], note[1], note[0], d.flow_wgs_last, note[3], note[4]);
+          // The first loss of a context that runs the look-ahead takes the LOOK-AHEAD away (the one known cause inside a process is side-stream work arriving while a launch is
+          // still being dispatched) and keeps the dataflow path; a loss without it -- or a second one -- takes the dataflow path.  Either way this system is
+          // refactorised on the launch-per-block-step path.
+          const bool blame_la = (d.lookahead & 1) != 0 && d.n_flow_abort == 0 && d.dbg != 21;
+          fprintf(stderr, "[tsl] k_ds_gj_flow: a workgroup waited in vain for a flag (launch not resident as a whole?): %s disabled for this context, refactorising "
+                  "(workgroup %d of %d gave up; %d of the %d workgroups of the factorisation's dataflow launches had started; flag value %d, epoch %d)\n",
+                  blame_la ? "\"direct_lookahead\"" : "\"direct_flow\"", note[2], note[1], note[0], d.flow_wgs_last, note[3], note[4]);
+          const int flow_keep = d.flow;
           d.flow = 0; d.n_flow_abort++;
+          if (blame_la) d.lookahead = 0;
           d.numeric_valid = false; d.have_factor = false;   // the factors in place are garbage: direct_factor must not return early
           if (d.prezero_pending) { HIP_OK(hipStreamWaitEvent(c->stream, d.ev_zero, 0)); d.prezero_pending = false; }
           TSL_TRY(direct_factor(c));
+          if (blame_la) d.flow = flow_keep;
           sd = *st; c->last_xmax_valid = false;
           TSL_TRY(direct_refine(c, &sd));
           if (sd.flag != 1) { const int it0 = sd.iters; sd = *st; c->last_xmax_valid = false; TSL_TRY(gmres(c, &sd, true)); sd.iters += it0; }
